@@ -1,0 +1,811 @@
+/*
+ * oracle/jpeg_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the baseline-JPEG arithmetic that lilliput's hot path
+ * reaches through OpenCV imgcodecs -> libjpeg-turbo 3.1.0:
+ *   decode: /root/reference/opencv.cpp:126-171 (opencv_decoder_read_header / read_data)
+ *   encode: /root/reference/opencv.cpp:173-194 (opencv_encoder_create / write)
+ * The arithmetic itself lives in the third-party dependency libjpeg-turbo 3.1.0
+ * (pinned in /root/reference/deps/build-deps-linux.sh:171-182; source NOT in the
+ * reference tree), so this file restates the published algorithm (ITU T.81 +
+ * the libjpeg "islow" DCT, "fancy" triangle upsampling, 16-bit fixed point colour
+ * conversion) and is pinned against
+ *   (a) the reference's own prebuilt libjpeg.a via oracle/_ref (tests/test_oracle_ref.py),
+ *   (b) the ThumbHash known answers of /root/reference/thumbhash_test.go:63-81
+ *       (tests/test_oracle_golden.py).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Scope: 8-bit baseline / extended-sequential Huffman (SOF0/SOF1), 1 or 3 components,
+ * sampling factors 1 or 2 per axis, restart intervals, single interleaved scan.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define LO_OK 0
+#define LO_ERR_FORMAT -1
+#define LO_ERR_UNSUPPORTED -2
+#define LO_ERR_BUF -3
+
+static const uint8_t lo_zigzag[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+typedef struct {
+    int width, height, ncomp;
+    int cid[4], hs[4], vs[4], tq[4], td[4], ta[4];
+    int dri;
+    int orientation;  /* EXIF 1..8, 1 when absent/invalid */
+    int sof;          /* 0,1 supported */
+    int hmax, vmax;
+    int mcus_x, mcus_y;
+    int colorspace;   /* 1 gray, 2 YCbCr, 3 RGB */
+    size_t ecs_off;   /* offset of first entropy-coded byte */
+    uint16_t qt[4][64]; /* natural order */
+    int qt_present[4];
+    uint8_t bits[2][4][17];
+    uint8_t vals[2][4][256];
+    int ht_present[2][4];
+    int saw_jfif, saw_adobe, adobe_transform;
+} lo_jpeg_info;
+
+static int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+/* EXIF orientation: APP1 "Exif\0\0" + TIFF header, IFD0 tag 0x0112 (SHORT). */
+static int parse_exif_orientation(const uint8_t* p, size_t n)
+{
+    if (n < 14 || memcmp(p, "Exif\0\0", 6) != 0) return 0;
+    const uint8_t* t = p + 6;
+    size_t tn = n - 6;
+    int le;
+    if (t[0] == 'I' && t[1] == 'I') le = 1;
+    else if (t[0] == 'M' && t[1] == 'M') le = 0;
+    else return 0;
+#define R16(q) (le ? ((q)[0] | ((q)[1] << 8)) : (((q)[0] << 8) | (q)[1]))
+#define R32(q) (le ? ((uint32_t)(q)[0] | ((uint32_t)(q)[1] << 8) | ((uint32_t)(q)[2] << 16) | ((uint32_t)(q)[3] << 24)) \
+                   : (((uint32_t)(q)[0] << 24) | ((uint32_t)(q)[1] << 16) | ((uint32_t)(q)[2] << 8) | (uint32_t)(q)[3]))
+    if (R16(t + 2) != 42) return 0;
+    uint32_t ifd = R32(t + 4);
+    if ((size_t)ifd + 2 > tn) return 0;
+    int cnt = R16(t + ifd);
+    for (int i = 0; i < cnt; i++) {
+        size_t e = (size_t)ifd + 2 + 12 * (size_t)i;
+        if (e + 12 > tn) return 0;
+        if (R16(t + e) == 0x0112) {
+            int v = R16(t + e + 8);
+            return v;
+        }
+    }
+#undef R16
+#undef R32
+    return 0;
+}
+
+int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
+{
+    memset(in, 0, sizeof(*in));
+    in->orientation = 1;
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return LO_ERR_FORMAT;
+    size_t i = 2;
+    int have_sof = 0;
+    while (i + 4 <= n) {
+        if (d[i] != 0xFF) return LO_ERR_FORMAT;
+        int m = d[i + 1];
+        if (m == 0xFF) { i++; continue; }
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
+        if (m == 0xD9) return LO_ERR_FORMAT;
+        int L = rd16(d + i + 2);
+        if (L < 2 || i + 2 + (size_t)L > n) return LO_ERR_FORMAT;
+        const uint8_t* p = d + i + 4;
+        int pl = L - 2;
+        if (m == 0xDB) {
+            int k = 0;
+            while (k < pl) {
+                int pq = p[k] >> 4, tq = p[k] & 15;
+                k++;
+                if (tq > 3) return LO_ERR_FORMAT;
+                for (int z = 0; z < 64; z++) {
+                    int v;
+                    if (pq) { v = rd16(p + k); k += 2; } else v = p[k++];
+                    in->qt[tq][lo_zigzag[z]] = (uint16_t)v;
+                }
+                in->qt_present[tq] = 1;
+            }
+        } else if (m == 0xC4) {
+            int k = 0;
+            while (k < pl) {
+                int tc = p[k] >> 4, th = p[k] & 15;
+                k++;
+                if (tc > 1 || th > 3) return LO_ERR_FORMAT;
+                int tot = 0;
+                in->bits[tc][th][0] = 0;
+                for (int b = 1; b <= 16; b++) { in->bits[tc][th][b] = p[k++]; tot += in->bits[tc][th][b]; }
+                if (tot > 256 || k + tot > pl) return LO_ERR_FORMAT;
+                memcpy(in->vals[tc][th], p + k, tot);
+                k += tot;
+                in->ht_present[tc][th] = 1;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            in->sof = m - 0xC0;
+            if (p[0] != 8) return LO_ERR_UNSUPPORTED;
+            in->height = rd16(p + 1);
+            in->width = rd16(p + 3);
+            in->ncomp = p[5];
+            if (in->ncomp != 1 && in->ncomp != 3) return LO_ERR_UNSUPPORTED;
+            for (int c = 0; c < in->ncomp; c++) {
+                in->cid[c] = p[6 + 3 * c];
+                in->hs[c] = p[7 + 3 * c] >> 4;
+                in->vs[c] = p[7 + 3 * c] & 15;
+                in->tq[c] = p[8 + 3 * c];
+            }
+            have_sof = 1;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return LO_ERR_UNSUPPORTED; /* progressive / lossless / arithmetic */
+        } else if (m == 0xDD) {
+            in->dri = rd16(p);
+        } else if (m == 0xE0) {
+            if (pl >= 5 && memcmp(p, "JFIF\0", 5) == 0) in->saw_jfif = 1;
+        } else if (m == 0xE1) {
+            int o = parse_exif_orientation(p, (size_t)pl);
+            if (o >= 1 && o <= 8 && in->orientation == 1) in->orientation = o;
+        } else if (m == 0xEE) {
+            if (pl >= 12 && memcmp(p, "Adobe", 5) == 0) { in->saw_adobe = 1; in->adobe_transform = p[11]; }
+        } else if (m == 0xDA) {
+            if (!have_sof) return LO_ERR_FORMAT;
+            int ns = p[0];
+            if (ns != in->ncomp) return LO_ERR_UNSUPPORTED; /* non-interleaved multi-scan */
+            for (int s = 0; s < ns; s++) {
+                int cs = p[1 + 2 * s], t = p[2 + 2 * s], c;
+                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs) break;
+                if (c == in->ncomp) return LO_ERR_FORMAT;
+                if (c != s) return LO_ERR_UNSUPPORTED;
+                in->td[c] = t >> 4;
+                in->ta[c] = t & 15;
+            }
+            in->ecs_off = i + 2 + (size_t)L;
+            break;
+        }
+        i += 2 + (size_t)L;
+    }
+    if (!have_sof || !in->ecs_off) return LO_ERR_FORMAT;
+    if (in->width <= 0 || in->height <= 0) return LO_ERR_FORMAT;
+    in->hmax = in->vmax = 1;
+    for (int c = 0; c < in->ncomp; c++) {
+        if (in->hs[c] < 1 || in->hs[c] > 2 || in->vs[c] < 1 || in->vs[c] > 2) return LO_ERR_UNSUPPORTED;
+        if (in->hs[c] > in->hmax) in->hmax = in->hs[c];
+        if (in->vs[c] > in->vmax) in->vmax = in->vs[c];
+        if (!in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
+        if (!in->ht_present[0][in->td[c]] || !in->ht_present[1][in->ta[c]]) return LO_ERR_FORMAT;
+    }
+    if (in->ncomp == 1) { in->hs[0] = in->vs[0] = 1; in->hmax = in->vmax = 1; }
+    if (in->ncomp == 3 && (in->hs[1] != 1 || in->vs[1] != 1 || in->hs[2] != 1 || in->vs[2] != 1)) return LO_ERR_UNSUPPORTED;
+    in->mcus_x = (in->width + 8 * in->hmax - 1) / (8 * in->hmax);
+    in->mcus_y = (in->height + 8 * in->vmax - 1) / (8 * in->vmax);
+    /* libjpeg colour-space guess (jdapimin.c default_decompress_parms) */
+    if (in->ncomp == 1) in->colorspace = 1;
+    else if (in->saw_jfif) in->colorspace = 2;
+    else if (in->saw_adobe) in->colorspace = (in->adobe_transform == 0) ? 3 : 2;
+    else if (in->cid[0] == 'R' && in->cid[1] == 'G' && in->cid[2] == 'B') in->colorspace = 3;
+    else in->colorspace = 2;
+    return LO_OK;
+}
+
+/* ---- Huffman (T.81 Annex C/F canonical decode) ---- */
+typedef struct {
+    int mincode[17], maxcode[18], valptr[17];
+    const uint8_t* vals;
+} lo_htab;
+
+static void build_htab(lo_htab* t, const uint8_t* bits, const uint8_t* vals)
+{
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        t->valptr[l] = k;
+        t->mincode[l] = code;
+        code += bits[l];
+        k += bits[l];
+        t->maxcode[l] = bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t->maxcode[17] = 0x7fffffff;
+    t->vals = vals;
+}
+
+typedef struct {
+    const uint8_t* d;
+    size_t n, pos;
+    uint64_t acc;
+    int nbits;
+    int marker; /* pending marker (0 = none) */
+} lo_bits;
+
+static void fill(lo_bits* b)
+{
+    while (b->nbits <= 56) {
+        int c = 0;
+        if (!b->marker && b->pos < b->n) {
+            c = b->d[b->pos];
+            if (c == 0xFF) {
+                size_t q = b->pos + 1;
+                while (q < b->n && b->d[q] == 0xFF) q++;
+                int c2 = q < b->n ? b->d[q] : 0xD9;
+                if (c2 == 0) { b->pos = q + 1; }
+                else { b->marker = c2; b->pos = q + 1; c = 0; }
+            } else b->pos++;
+        } else c = 0; /* libjpeg feeds zero bits after a marker / EOF */
+        b->acc |= (uint64_t)c << (56 - b->nbits);
+        b->nbits += 8;
+    }
+}
+static inline int peek(lo_bits* b, int k) { return (int)(b->acc >> (64 - k)); }
+static inline void skip(lo_bits* b, int k) { b->acc <<= k; b->nbits -= k; }
+static inline int getbits(lo_bits* b, int k)
+{
+    if (!k) return 0;
+    int v = peek(b, k);
+    skip(b, k);
+    return v;
+}
+static int decode_sym(lo_bits* b, const lo_htab* t)
+{
+    fill(b);
+    int code = 0;
+    for (int l = 1; l <= 16; l++) {
+        code = peek(b, l);
+        if (t->maxcode[l] >= 0 && code <= t->maxcode[l] && code >= t->mincode[l]) {
+            skip(b, l);
+            return t->vals[t->valptr[l] + code - t->mincode[l]];
+        }
+    }
+    skip(b, 16);
+    return 0; /* corrupt */
+}
+static inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+typedef struct {
+    lo_jpeg_info in;
+    int bw[4], bh[4];      /* blocks per row/col (MCU padded) */
+    int16_t* coef[4];      /* [bh][bw][64] natural order, DC absolute */
+    uint8_t* plane[4];     /* [bh*8][bw*8] */
+} lo_dec;
+
+static void dec_free(lo_dec* D)
+{
+    for (int c = 0; c < 4; c++) { free(D->coef[c]); free(D->plane[c]); }
+}
+
+static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
+{
+    lo_jpeg_info* in = &D->in;
+    int rc = lo_jpeg_read_header(d, n, in);
+    if (rc) return rc;
+    lo_htab dc[4], ac[4];
+    for (int t = 0; t < 4; t++) {
+        if (in->ht_present[0][t]) build_htab(&dc[t], in->bits[0][t], in->vals[0][t]);
+        if (in->ht_present[1][t]) build_htab(&ac[t], in->bits[1][t], in->vals[1][t]);
+    }
+    for (int c = 0; c < in->ncomp; c++) {
+        D->bw[c] = in->mcus_x * in->hs[c];
+        D->bh[c] = in->mcus_y * in->vs[c];
+        D->coef[c] = (int16_t*)calloc((size_t)D->bw[c] * D->bh[c] * 64, sizeof(int16_t));
+        if (!D->coef[c]) return LO_ERR_BUF;
+    }
+    lo_bits b = {d, n, in->ecs_off, 0, 0, 0};
+    int pred[4] = {0, 0, 0, 0};
+    int nmcu = in->mcus_x * in->mcus_y;
+    int rst_left = in->dri;
+    for (int m = 0; m < nmcu; m++) {
+        if (in->dri && rst_left == 0) {
+            /* process restart: discard partial byte, expect RSTn */
+            b.acc = 0; b.nbits = 0;
+            if (!b.marker) { /* scan forward to next marker */
+                while (b.pos + 1 < b.n && !(b.d[b.pos] == 0xFF && b.d[b.pos + 1] >= 0xD0 && b.d[b.pos + 1] <= 0xD7)) b.pos++;
+                if (b.pos + 1 < b.n) b.pos += 2;
+            }
+            b.marker = 0;
+            pred[0] = pred[1] = pred[2] = pred[3] = 0;
+            rst_left = in->dri;
+        }
+        int mx = m % in->mcus_x, my = m / in->mcus_x;
+        for (int c = 0; c < in->ncomp; c++)
+            for (int v = 0; v < in->vs[c]; v++)
+                for (int h = 0; h < in->hs[c]; h++) {
+                    int bx = mx * in->hs[c] + h, by = my * in->vs[c] + v;
+                    int16_t* blk = D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64;
+                    int s = decode_sym(&b, &dc[in->td[c]]);
+                    fill(&b);
+                    int diff = s ? extend(getbits(&b, s), s) : 0;
+                    pred[c] += diff;
+                    blk[0] = (int16_t)pred[c];
+                    for (int k = 1; k < 64;) {
+                        int rs = decode_sym(&b, &ac[in->ta[c]]);
+                        int r = rs >> 4;
+                        s = rs & 15;
+                        if (s) {
+                            k += r;
+                            fill(&b);
+                            int val = extend(getbits(&b, s), s);
+                            if (k < 64) blk[lo_zigzag[k]] = (int16_t)val;
+                            k++;
+                        } else {
+                            if (r != 15) break;
+                            k += 16;
+                        }
+                    }
+                }
+        if (in->dri) rst_left--;
+    }
+    return LO_OK;
+}
+
+/* jidctint.c jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2 */
+#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+static inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+static void idct1d(const int32_t* d, int32_t* o)
+{
+    int32_t z1 = (d[2] + d[6]) * 4433;
+    int32_t tmp2 = z1 - d[6] * 15137, tmp3 = z1 + d[2] * 6270;
+    int32_t tmp0 = (int32_t)((uint32_t)(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)(d[0] - d[4]) << 13);
+    int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
+    tmp0 = d[7]; tmp1 = d[5]; tmp2 = d[3]; tmp3 = d[1];
+    z1 = tmp0 + tmp3;
+    int32_t z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+    z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    o[0] = t10 + tmp3; o[7] = t10 - tmp3; o[1] = t11 + tmp2; o[6] = t11 - tmp2;
+    o[2] = t12 + tmp1; o[5] = t12 - tmp1; o[3] = t13 + tmp0; o[4] = t13 - tmp0;
+}
+
+void lo_idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride)
+{
+    int32_t ws[64], in[8], o[8];
+    for (int c = 0; c < 8; c++) {
+        for (int r = 0; r < 8; r++) in[r] = (int32_t)coef[r * 8 + c] * q[r * 8 + c];
+        idct1d(in, o);
+        for (int r = 0; r < 8; r++) ws[r * 8 + c] = DESCALE(o[r], 11);
+    }
+    for (int r = 0; r < 8; r++) {
+        idct1d(ws + r * 8, o);
+        for (int c = 0; c < 8; c++) out[r * stride + c] = clamp8(DESCALE(o[c], 18) + 128);
+    }
+}
+
+static int decode_planes(const uint8_t* d, size_t n, lo_dec* D)
+{
+    int rc = decode_coefs(d, n, D);
+    if (rc) return rc;
+    lo_jpeg_info* in = &D->in;
+    for (int c = 0; c < in->ncomp; c++) {
+        int pw = D->bw[c] * 8, ph = D->bh[c] * 8;
+        D->plane[c] = (uint8_t*)malloc((size_t)pw * ph);
+        if (!D->plane[c]) return LO_ERR_BUF;
+        for (int by = 0; by < D->bh[c]; by++)
+            for (int bx = 0; bx < D->bw[c]; bx++)
+                lo_idct_islow(D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64, in->qt[in->tq[c]],
+                              D->plane[c] + (size_t)by * 8 * pw + bx * 8, pw);
+    }
+    return LO_OK;
+}
+
+/* jdsample.c fancy upsampling on the VALID (downsampled) extent; edges replicate.
+ * Produces a full-resolution (W x H) plane for component c. */
+static void upsample_plane(const lo_dec* D, int c, uint8_t* out)
+{
+    const lo_jpeg_info* in = &D->in;
+    int W = in->width, H = in->height;
+    int pw = D->bw[c] * 8;
+    const uint8_t* P = D->plane[c];
+    int hr = in->hmax / in->hs[c], vr = in->vmax / in->vs[c];
+    int dw = (W * in->hs[c] + in->hmax - 1) / in->hmax;
+    int dh = (H * in->vs[c] + in->vmax - 1) / in->vmax;
+    if (hr == 1 && vr == 1) {
+        for (int y = 0; y < H; y++) memcpy(out + (size_t)y * W, P + (size_t)y * pw, W);
+    } else if (hr == 2 && vr == 2) { /* h2v2_fancy_upsample */
+        int* cs = (int*)malloc(sizeof(int) * dw);
+        for (int y = 0; y < H; y++) {
+            int cy = y >> 1;
+            int ny = (y & 1) ? cy + 1 : cy - 1;
+            if (ny < 0) ny = 0;
+            if (ny > dh - 1) ny = dh - 1;
+            const uint8_t* r0 = P + (size_t)cy * pw;
+            const uint8_t* r1 = P + (size_t)ny * pw;
+            for (int x = 0; x < dw; x++) cs[x] = 3 * r0[x] + r1[x];
+            uint8_t* o = out + (size_t)y * W;
+            for (int x = 0; x < W; x++) {
+                int cx = x >> 1, v;
+                if (dw == 1) v = (x & 1) ? (cs[0] * 4 + 7) >> 4 : (cs[0] * 4 + 8) >> 4;
+                else if (!(x & 1)) v = cx == 0 ? (cs[0] * 4 + 8) >> 4 : (3 * cs[cx] + cs[cx - 1] + 8) >> 4;
+                else v = cx == dw - 1 ? (cs[cx] * 4 + 7) >> 4 : (3 * cs[cx] + cs[cx + 1] + 7) >> 4;
+                o[x] = (uint8_t)v;
+            }
+        }
+        free(cs);
+    } else if (hr == 2 && vr == 1) { /* h2v1_fancy_upsample */
+        for (int y = 0; y < H; y++) {
+            const uint8_t* r = P + (size_t)y * pw;
+            uint8_t* o = out + (size_t)y * W;
+            for (int x = 0; x < W; x++) {
+                int cx = x >> 1, v;
+                if (!(x & 1)) v = cx == 0 ? r[0] : (3 * r[cx] + r[cx - 1] + 1) >> 2;
+                else v = cx == dw - 1 ? r[cx] : (3 * r[cx] + r[cx + 1] + 2) >> 2;
+                o[x] = (uint8_t)v;
+            }
+        }
+    } else { /* hr == 1 && vr == 2: h1v2_fancy_upsample (libjpeg-turbo >= 2.0) */
+        for (int y = 0; y < H; y++) {
+            int cy = y >> 1;
+            int ny = (y & 1) ? cy + 1 : cy - 1;
+            if (ny < 0) ny = 0;
+            if (ny > dh - 1) ny = dh - 1;
+            int bias = (y & 1) ? 2 : 1;
+            const uint8_t* r0 = P + (size_t)cy * pw;
+            const uint8_t* r1 = P + (size_t)ny * pw;
+            uint8_t* o = out + (size_t)y * W;
+            for (int x = 0; x < W; x++) o[x] = (uint8_t)((3 * r0[x] + r1[x] + bias) >> 2);
+        }
+    }
+}
+
+/* jdcolor.c ycc_rgb_convert with JCS_EXT_BGR output */
+#define FIX16(x) ((int32_t)((x)*65536.0 + 0.5))
+void lo_ycc_to_bgr(int y, int cb, int cr, uint8_t* bgr)
+{
+    cb -= 128; cr -= 128;
+    int r = y + (int)((FIX16(1.40200) * cr + 32768) >> 16);
+    int b = y + (int)((FIX16(1.77200) * cb + 32768) >> 16);
+    int g = y + (int)((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16);
+    bgr[0] = clamp8(b); bgr[1] = clamp8(g); bgr[2] = clamp8(r);
+}
+
+/* Public: decode to pixels the way opencv_decoder_read_data does: 3 comps -> BGR interleaved,
+ * 1 comp -> 8-bit gray. */
+int lo_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* w, int* h, int* ch)
+{
+    lo_dec D;
+    memset(&D, 0, sizeof(D));
+    int rc = decode_planes(d, n, &D);
+    if (rc) { dec_free(&D); return rc; }
+    int W = D.in.width, H = D.in.height, C = D.in.ncomp == 1 ? 1 : 3;
+    *w = W; *h = H; *ch = C;
+    if ((size_t)W * H * C > cap) { dec_free(&D); return LO_ERR_BUF; }
+    if (C == 1) {
+        upsample_plane(&D, 0, out);
+    } else {
+        uint8_t* up[3];
+        for (int c = 0; c < 3; c++) { up[c] = (uint8_t*)malloc((size_t)W * H); upsample_plane(&D, c, up[c]); }
+        for (size_t i = 0; i < (size_t)W * H; i++) {
+            if (D.in.colorspace == 3) { out[3 * i] = up[2][i]; out[3 * i + 1] = up[1][i]; out[3 * i + 2] = up[0][i]; }
+            else lo_ycc_to_bgr(up[0][i], up[1][i], up[2][i], out + 3 * i);
+        }
+        for (int c = 0; c < 3; c++) free(up[c]);
+    }
+    dec_free(&D);
+    return LO_OK;
+}
+
+/* Intermediate stages, for stage-by-stage parity of the HIP kernels. */
+int lo_jpeg_decode_coefs(const uint8_t* d, size_t n, int comp, int16_t* out, size_t cap_elems, int* bw, int* bh)
+{
+    lo_dec D;
+    memset(&D, 0, sizeof(D));
+    int rc = decode_coefs(d, n, &D);
+    if (rc) { dec_free(&D); return rc; }
+    if (comp >= D.in.ncomp) { dec_free(&D); return LO_ERR_FORMAT; }
+    *bw = D.bw[comp]; *bh = D.bh[comp];
+    size_t ne = (size_t)D.bw[comp] * D.bh[comp] * 64;
+    if (ne > cap_elems) { dec_free(&D); return LO_ERR_BUF; }
+    memcpy(out, D.coef[comp], ne * sizeof(int16_t));
+    dec_free(&D);
+    return LO_OK;
+}
+
+int lo_jpeg_decode_plane(const uint8_t* d, size_t n, int comp, uint8_t* out, size_t cap, int* pw, int* ph)
+{
+    lo_dec D;
+    memset(&D, 0, sizeof(D));
+    int rc = decode_planes(d, n, &D);
+    if (rc) { dec_free(&D); return rc; }
+    if (comp >= D.in.ncomp) { dec_free(&D); return LO_ERR_FORMAT; }
+    *pw = D.bw[comp] * 8; *ph = D.bh[comp] * 8;
+    size_t ne = (size_t)(*pw) * (*ph);
+    if (ne > cap) { dec_free(&D); return LO_ERR_BUF; }
+    memcpy(out, D.plane[comp], ne);
+    dec_free(&D);
+    return LO_OK;
+}
+
+/* ------------------------------------------------------------------ encoder */
+/* jcparam.c std tables + jpeg_set_quality(q, TRUE) */
+static const uint8_t std_luma_q[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                                       14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                                       18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                                       49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const uint8_t std_chroma_q[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                         24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                         99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                         99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+static const uint8_t std_bits[4][17] = {
+    {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},  /* DC luma */
+    {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, /* AC luma */
+    {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},  /* DC chroma */
+    {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};/* AC chroma */
+static const uint8_t std_dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t std_ac_luma_vals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t std_ac_chroma_vals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+void lo_quant_table(int quality, int chroma, uint16_t* q_nat)
+{
+    if (quality <= 0) quality = 1;
+    if (quality > 100) quality = 100;
+    int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    const uint8_t* std = chroma ? std_chroma_q : std_luma_q;
+    for (int i = 0; i < 64; i++) {
+        long t = ((long)std[i] * scale + 50L) / 100L;
+        if (t <= 0) t = 1;
+        if (t > 255) t = 255; /* force_baseline */
+        q_nat[i] = (uint16_t)t;
+    }
+}
+
+/* jfdctint.c jpeg_fdct_islow on sample-128 */
+static void fdct_islow(int32_t* d)
+{
+    for (int r = 0; r < 8; r++) {
+        int32_t* p = d + r * 8;
+        int32_t t0 = p[0] + p[7], t7 = p[0] - p[7], t1 = p[1] + p[6], t6 = p[1] - p[6];
+        int32_t t2 = p[2] + p[5], t5 = p[2] - p[5], t3 = p[3] + p[4], t4 = p[3] - p[4];
+        int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        p[0] = (t10 + t11) * 4; p[4] = (t10 - t11) * 4;
+        int32_t z1 = (t12 + t13) * 4433;
+        p[2] = DESCALE(z1 + t13 * 6270, 11); p[6] = DESCALE(z1 - t12 * 15137, 11);
+        z1 = t4 + t7;
+        int32_t z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7, z5 = (z3 + z4) * 9633;
+        t4 *= 2446; t5 *= 16819; t6 *= 25172; t7 *= 12299;
+        z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+        p[7] = DESCALE(t4 + z1 + z3, 11); p[5] = DESCALE(t5 + z2 + z4, 11);
+        p[3] = DESCALE(t6 + z2 + z3, 11); p[1] = DESCALE(t7 + z1 + z4, 11);
+    }
+    for (int c = 0; c < 8; c++) {
+        int32_t* p = d + c;
+        int32_t t0 = p[0] + p[56], t7 = p[0] - p[56], t1 = p[8] + p[48], t6 = p[8] - p[48];
+        int32_t t2 = p[16] + p[40], t5 = p[16] - p[40], t3 = p[24] + p[32], t4 = p[24] - p[32];
+        int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        p[0] = DESCALE(t10 + t11, 2); p[32] = DESCALE(t10 - t11, 2);
+        int32_t z1 = (t12 + t13) * 4433;
+        p[16] = DESCALE(z1 + t13 * 6270, 15); p[48] = DESCALE(z1 - t12 * 15137, 15);
+        z1 = t4 + t7;
+        int32_t z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7, z5 = (z3 + z4) * 9633;
+        t4 *= 2446; t5 *= 16819; t6 *= 25172; t7 *= 12299;
+        z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+        p[56] = DESCALE(t4 + z1 + z3, 15); p[40] = DESCALE(t5 + z2 + z4, 15);
+        p[24] = DESCALE(t6 + z2 + z3, 15); p[8] = DESCALE(t7 + z1 + z4, 15);
+    }
+}
+
+void lo_fdct_quant(const uint8_t* px, int stride, const uint16_t* q_nat, int16_t* out_nat)
+{
+    int32_t d[64];
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) d[r * 8 + c] = (int32_t)px[r * stride + c] - 128;
+    fdct_islow(d);
+    for (int i = 0; i < 64; i++) {
+        int32_t dv = 8 * q_nat[i], x = d[i], v;
+        if (x < 0) { x = -x; x += dv >> 1; v = -(x / dv); }
+        else { x += dv >> 1; v = x / dv; }
+        out_nat[i] = (int16_t)v;
+    }
+}
+
+typedef struct { uint16_t code[256]; uint8_t len[256]; } lo_etab;
+static void build_etab(lo_etab* t, const uint8_t* bits, const uint8_t* vals)
+{
+    memset(t, 0, sizeof(*t));
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l]; i++) { t->code[vals[k]] = (uint16_t)code; t->len[vals[k]] = (uint8_t)l; code++; k++; }
+        code <<= 1;
+    }
+}
+typedef struct { uint8_t* o; size_t cap, n; uint64_t acc; int nb; int ovf; } lo_w;
+static void wbyte(lo_w* w, int c) { if (w->n < w->cap) w->o[w->n++] = (uint8_t)c; else w->ovf = 1; }
+static void wbits(lo_w* w, unsigned v, int n)
+{
+    if (!n) return;
+    w->acc = (w->acc << n) | (v & ((1u << n) - 1));
+    w->nb += n;
+    while (w->nb >= 8) {
+        int c = (int)((w->acc >> (w->nb - 8)) & 0xFF);
+        wbyte(w, c);
+        if (c == 0xFF) wbyte(w, 0);
+        w->nb -= 8;
+    }
+}
+static int bitlen(int v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
+
+static void encode_block(lo_w* w, const int16_t* nat, int* pred, const lo_etab* dc, const lo_etab* ac)
+{
+    int diff = nat[0] - *pred;
+    *pred = nat[0];
+    int a = diff < 0 ? -diff : diff, s = bitlen(a);
+    wbits(w, dc->code[s], dc->len[s]);
+    if (s) wbits(w, (unsigned)(diff < 0 ? diff - 1 : diff), s);
+    int run = 0;
+    for (int k = 1; k < 64; k++) {
+        int v = nat[lo_zigzag[k]];
+        if (!v) { run++; continue; }
+        while (run > 15) { wbits(w, ac->code[0xF0], ac->len[0xF0]); run -= 16; }
+        a = v < 0 ? -v : v;
+        s = bitlen(a);
+        int sym = (run << 4) | s;
+        wbits(w, ac->code[sym], ac->len[sym]);
+        wbits(w, (unsigned)(v < 0 ? v - 1 : v), s);
+        run = 0;
+    }
+    if (run) wbits(w, ac->code[0], ac->len[0]);
+}
+
+static void w16(lo_w* w, int v) { wbyte(w, v >> 8); wbyte(w, v & 255); }
+static void write_dht(lo_w* w, int tc_th, const uint8_t* bits, const uint8_t* vals)
+{
+    int tot = 0;
+    for (int l = 1; l <= 16; l++) tot += bits[l];
+    wbyte(w, 0xFF); wbyte(w, 0xC4); w16(w, 2 + 1 + 16 + tot);
+    wbyte(w, tc_th);
+    for (int l = 1; l <= 16; l++) wbyte(w, bits[l]);
+    for (int i = 0; i < tot; i++) wbyte(w, vals[i]);
+}
+
+/* jccolor.c rgb_ycc_convert */
+void lo_bgr_to_ycc(const uint8_t* bgr, int* y, int* cb, int* cr)
+{
+    int b = bgr[0], g = bgr[1], r = bgr[2];
+    *y = (FIX16(0.29900) * r + FIX16(0.58700) * g + FIX16(0.11400) * b + 32768) >> 16;
+    *cb = (-FIX16(0.16874) * r - FIX16(0.33126) * g + FIX16(0.50000) * b + (128 << 16) + 32767) >> 16;
+    *cr = (FIX16(0.50000) * r - FIX16(0.41869) * g - FIX16(0.08131) * b + (128 << 16) + 32767) >> 16;
+}
+
+/* Encode like cv::JpegEncoder::write with {IMWRITE_JPEG_QUALITY: q}: 3/4-channel BGR(A) -> YCbCr 4:2:0,
+ * 1-channel -> grayscale; std Huffman tables, JFIF 1.01, no restart. Returns length or <0. */
+long lo_jpeg_encode(const uint8_t* px, int W, int H, int ch, size_t stride, int quality, uint8_t* out, size_t cap,
+                    int16_t* coef_dump /* optional: MCU-order blocks, natural order */)
+{
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return LO_ERR_FORMAT;
+    if (ch != 1 && ch != 3 && ch != 4) return LO_ERR_UNSUPPORTED;
+    int nc = ch == 1 ? 1 : 3;
+    uint16_t q[2][64];
+    lo_quant_table(quality, 0, q[0]);
+    lo_quant_table(quality, 1, q[1]);
+    int mcu = nc == 1 ? 8 : 16;
+    int mx = (W + mcu - 1) / mcu, my = (H + mcu - 1) / mcu;
+    int PW = mx * mcu, PH = my * mcu;
+    /* jcprepct.c/jcsample.c edge rules: full-res columns replicate pixel W-1 (expand_right_edge),
+     * full-res rows replicate row H-1 only inside a row group (expand_bottom_edge on color_buf);
+     * DOWNSAMPLED rows past the last real one replicate the last downsampled row. */
+    uint8_t* Y = (uint8_t*)malloc((size_t)PW * PH);
+    uint8_t *cb2 = NULL, *cr2 = NULL;
+    int CW = PW / 2, CH = PH / 2;
+    if (nc == 3) { cb2 = (uint8_t*)malloc((size_t)CW * CH); cr2 = (uint8_t*)malloc((size_t)CW * CH); }
+    for (int y = 0; y < PH; y++) {
+        int sy = y < H ? y : H - 1;
+        for (int x = 0; x < PW; x++) {
+            int sx = x < W ? x : W - 1;
+            const uint8_t* p = px + (size_t)sy * stride + (size_t)sx * ch;
+            if (nc == 1) Y[(size_t)y * PW + x] = p[0];
+            else { int yy, cb, cr; lo_bgr_to_ycc(p, &yy, &cb, &cr); Y[(size_t)y * PW + x] = (uint8_t)yy; }
+        }
+    }
+    if (nc == 3) { /* jcsample.c h2v2_downsample: bias 1,2,1,2 */
+        int dh = (H + 1) / 2;
+        for (int y = 0; y < CH; y++) {
+            if (y >= dh) {
+                memcpy(cb2 + (size_t)y * CW, cb2 + (size_t)(dh - 1) * CW, CW);
+                memcpy(cr2 + (size_t)y * CW, cr2 + (size_t)(dh - 1) * CW, CW);
+                continue;
+            }
+            for (int x = 0; x < CW; x++) {
+                int bias = (x & 1) ? 2 : 1, sb = 0, sr = 0;
+                for (int j = 0; j < 2; j++)
+                    for (int i = 0; i < 2; i++) {
+                        int sy = 2 * y + j, sx = 2 * x + i, yy, cb, cr;
+                        if (sy > H - 1) sy = H - 1;
+                        if (sx > W - 1) sx = W - 1;
+                        lo_bgr_to_ycc(px + (size_t)sy * stride + (size_t)sx * ch, &yy, &cb, &cr);
+                        sb += cb; sr += cr;
+                    }
+                cb2[(size_t)y * CW + x] = (uint8_t)((sb + bias) >> 2);
+                cr2[(size_t)y * CW + x] = (uint8_t)((sr + bias) >> 2);
+            }
+        }
+    }
+    lo_w w = {out, cap, 0, 0, 0, 0};
+    wbyte(&w, 0xFF); wbyte(&w, 0xD8);
+    wbyte(&w, 0xFF); wbyte(&w, 0xE0); w16(&w, 16);
+    wbyte(&w, 'J'); wbyte(&w, 'F'); wbyte(&w, 'I'); wbyte(&w, 'F'); wbyte(&w, 0);
+    wbyte(&w, 1); wbyte(&w, 1); wbyte(&w, 0); w16(&w, 1); w16(&w, 1); wbyte(&w, 0); wbyte(&w, 0);
+    for (int t = 0; t < (nc == 1 ? 1 : 2); t++) {
+        wbyte(&w, 0xFF); wbyte(&w, 0xDB); w16(&w, 67); wbyte(&w, t);
+        for (int z = 0; z < 64; z++) wbyte(&w, q[t][lo_zigzag[z]]);
+    }
+    wbyte(&w, 0xFF); wbyte(&w, 0xC0); w16(&w, 8 + 3 * nc); wbyte(&w, 8); w16(&w, H); w16(&w, W); wbyte(&w, nc);
+    if (nc == 1) { wbyte(&w, 1); wbyte(&w, 0x11); wbyte(&w, 0); }
+    else { wbyte(&w, 1); wbyte(&w, 0x22); wbyte(&w, 0); wbyte(&w, 2); wbyte(&w, 0x11); wbyte(&w, 1); wbyte(&w, 3); wbyte(&w, 0x11); wbyte(&w, 1); }
+    write_dht(&w, 0x00, std_bits[0], std_dc_vals);
+    write_dht(&w, 0x10, std_bits[1], std_ac_luma_vals);
+    if (nc == 3) {
+        write_dht(&w, 0x01, std_bits[2], std_dc_vals);
+        write_dht(&w, 0x11, std_bits[3], std_ac_chroma_vals);
+    }
+    wbyte(&w, 0xFF); wbyte(&w, 0xDA); w16(&w, 6 + 2 * nc); wbyte(&w, nc);
+    wbyte(&w, 1); wbyte(&w, 0x00);
+    if (nc == 3) { wbyte(&w, 2); wbyte(&w, 0x11); wbyte(&w, 3); wbyte(&w, 0x11); }
+    wbyte(&w, 0); wbyte(&w, 63); wbyte(&w, 0);
+    lo_etab dcl, acl, dcc, acc_;
+    build_etab(&dcl, std_bits[0], std_dc_vals); build_etab(&acl, std_bits[1], std_ac_luma_vals);
+    build_etab(&dcc, std_bits[2], std_dc_vals); build_etab(&acc_, std_bits[3], std_ac_chroma_vals);
+    int pred[3] = {0, 0, 0};
+    int16_t blk[64];
+    size_t bi = 0;
+    int wib = (W + 7) / 8, hib = (H + 7) / 8; /* real luma blocks; the rest of the MCU grid is dummy */
+    for (int m = 0; m < mx * my; m++) {
+        int x0 = (m % mx) * mcu, y0 = (m / mx) * mcu;
+        if (nc == 1) {
+            lo_fdct_quant(Y + (size_t)y0 * PW + x0, PW, q[0], blk);
+            if (coef_dump) memcpy(coef_dump + 64 * bi, blk, 128);
+            bi++;
+            encode_block(&w, blk, &pred[0], &dcl, &acl);
+        } else {
+            /* jccoefct.c compress_data: dummy blocks = zero AC, DC copied from the previous block
+             * in the MCU buffer (bottom row: from the last block of the row above). */
+            int16_t mb[4][64];
+            for (int v = 0; v < 2; v++)
+                for (int h = 0; h < 2; h++) {
+                    int bx = x0 / 8 + h, by = y0 / 8 + v, k = 2 * v + h;
+                    if (by < hib && bx < wib) lo_fdct_quant(Y + (size_t)(y0 + 8 * v) * PW + x0 + 8 * h, PW, q[0], mb[k]);
+                    else {
+                        memset(mb[k], 0, 128);
+                        mb[k][0] = (by < hib) ? mb[k - 1][0] : mb[2 * v - 1][0];
+                    }
+                }
+            for (int k = 0; k < 4; k++) {
+                if (coef_dump) memcpy(coef_dump + 64 * bi, mb[k], 128);
+                bi++;
+                encode_block(&w, mb[k], &pred[0], &dcl, &acl);
+            }
+            lo_fdct_quant(cb2 + (size_t)(y0 / 2) * CW + x0 / 2, CW, q[1], blk);
+            if (coef_dump) memcpy(coef_dump + 64 * bi, blk, 128);
+            bi++;
+            encode_block(&w, blk, &pred[1], &dcc, &acc_);
+            lo_fdct_quant(cr2 + (size_t)(y0 / 2) * CW + x0 / 2, CW, q[1], blk);
+            if (coef_dump) memcpy(coef_dump + 64 * bi, blk, 128);
+            bi++;
+            encode_block(&w, blk, &pred[2], &dcc, &acc_);
+        }
+    }
+    if (w.nb) wbits(&w, 0x7F, 8 - w.nb); /* pad with 1-bits */
+    wbyte(&w, 0xFF); wbyte(&w, 0xD9);
+    free(Y); free(cb2); free(cr2);
+    if (w.ovf) return LO_ERR_BUF;
+    return (long)w.n;
+}

@@ -1,0 +1,303 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front-end for the CPU checker:
+  * ``liboracle.so``  -- our restatement (oracle/jpeg_oracle.c, oracle/imgproc_oracle.c)
+  * ``_ref/libref.so`` -- the reference's own prebuilt libjpeg-turbo 3.1.0 behind oracle/ref_driver.c
+plus the pure-integer/float64 control logic of the reference's Go layer (ops.go / opencv.go),
+restated in Python with file:line citations.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u8p = C.POINTER(C.c_uint8)
+_i16p = C.POINTER(C.c_int16)
+
+
+def build():
+    """Compile liboracle.so (and _ref/libref.so when /root/reference is present)."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(os.path.join(_HERE, "liboracle.so")):
+            build()
+        _lib = _load("liboracle.so")
+        _lib.lo_jpeg_encode.restype = C.c_long
+    return _lib
+
+
+def ref():
+    """The reference's libjpeg-turbo driver, or None when it has not been built."""
+    global _ref
+    if _ref is None:
+        _ref = _load(os.path.join("_ref", "libref.so"))
+        if _ref is not None:
+            _ref.ref_jpeg_encode.restype = C.c_long
+    return _ref
+
+
+def _buf(data):
+    arr = np.frombuffer(bytes(data), dtype=np.uint8)
+    return arr, arr.ctypes.data_as(_u8p)
+
+
+def _decode_pixels(fn, data):
+    arr, p = _buf(data)
+    # header first for size
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    probe = np.empty(1, dtype=np.uint8)
+    rc = fn(p, C.c_size_t(len(arr)), probe.ctypes.data_as(_u8p), C.c_size_t(0), C.byref(w), C.byref(h), C.byref(ch))
+    if rc not in (0, -3):
+        raise ValueError("decode failed rc=%d" % rc)
+    out = np.empty(w.value * h.value * ch.value, dtype=np.uint8)
+    rc = fn(p, C.c_size_t(len(arr)), out.ctypes.data_as(_u8p), C.c_size_t(out.size), C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError("decode failed rc=%d" % rc)
+    return out.reshape(h.value, w.value, ch.value)
+
+
+def jpeg_decode(data):
+    """Restatement: JPEG bytes -> HxWxC uint8 (BGR or gray), as opencv_decoder_read_data produces."""
+    return _decode_pixels(lib().lo_jpeg_decode_pixels, data)
+
+
+def ref_jpeg_decode(data):
+    return _decode_pixels(ref().ref_jpeg_decode_pixels, data)
+
+
+def _coefs(fn, data, comp):
+    arr, p = _buf(data)
+    bw, bh = C.c_int(), C.c_int()
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, dtype=np.int16)
+        rc = fn(p, C.c_size_t(len(arr)), C.c_int(comp), out.ctypes.data_as(_i16p), C.c_size_t(cap), C.byref(bw), C.byref(bh))
+        if rc == -3:
+            cap = bw.value * bh.value * 64
+            continue
+        if rc != 0:
+            raise ValueError("coef decode failed rc=%d" % rc)
+        return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64).copy()
+
+
+def jpeg_decode_coefs(data, comp):
+    return _coefs(lib().lo_jpeg_decode_coefs, data, comp)
+
+
+def ref_jpeg_decode_coefs(data, comp):
+    return _coefs(ref().ref_jpeg_decode_coefs, data, comp)
+
+
+def jpeg_decode_plane(data, comp):
+    """Restatement: IDCT output plane of one component, MCU-padded (before upsampling)."""
+    arr, p = _buf(data)
+    pw, ph = C.c_int(), C.c_int()
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        rc = lib().lo_jpeg_decode_plane(p, C.c_size_t(len(arr)), C.c_int(comp), out.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(pw), C.byref(ph))
+        if rc == -3:
+            cap = pw.value * ph.value
+            continue
+        if rc != 0:
+            raise ValueError("plane decode failed rc=%d" % rc)
+        return out[: pw.value * ph.value].reshape(ph.value, pw.value).copy()
+
+
+def ref_jpeg_decode_raw_plane(data, comp):
+    arr, p = _buf(data)
+    dw, dh = C.c_int(), C.c_int()
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        rc = ref().ref_jpeg_decode_raw_plane(p, C.c_size_t(len(arr)), C.c_int(comp), out.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(dw), C.byref(dh))
+        if rc == -3:
+            cap = dw.value * dh.value
+            continue
+        if rc != 0:
+            raise ValueError("raw plane decode failed rc=%d" % rc)
+        return out[: dw.value * dh.value].reshape(dh.value, dw.value).copy()
+
+
+def _encode(fn, px, quality, extra=()):
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    if px.ndim == 2:
+        px = px[:, :, None]
+    h, w, ch = px.shape
+    cap = w * h * ch * 2 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    n = fn(px.ctypes.data_as(_u8p), C.c_int(w), C.c_int(h), C.c_int(ch), C.c_size_t(w * ch), C.c_int(quality),
+           out.ctypes.data_as(_u8p), C.c_size_t(cap), *extra)
+    if n < 0:
+        raise ValueError("encode failed rc=%d" % n)
+    return out[:n].tobytes()
+
+
+def jpeg_encode(px, quality=85):
+    """Restatement of cv::JpegEncoder::write({IMWRITE_JPEG_QUALITY: quality}) -> bytes."""
+    return _encode(lib().lo_jpeg_encode, px, quality, (C.c_void_p(0),))
+
+
+def ref_jpeg_encode(px, quality=85):
+    return _encode(ref().ref_jpeg_encode, px, quality)
+
+
+def resize_area(src, dw, dh):
+    """cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_AREA) restatement. Returns (dst, branch)."""
+    src = np.asarray(src, dtype=np.uint8)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, cn = src.shape
+    assert src.strides[2] == 1 and src.strides[1] == cn
+    dst = np.empty((dh, dw, cn), dtype=np.uint8)
+    br = lib().lo_resize_area(C.c_void_p(src.ctypes.data), C.c_int(sw), C.c_int(sh), C.c_size_t(src.strides[0]), C.c_int(cn),
+                              dst.ctypes.data_as(_u8p), C.c_int(dw), C.c_int(dh), C.c_size_t(dw * cn))
+    return dst, br
+
+
+def orientation_transform(src, orientation):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    h, w, cn = src.shape
+    dst = np.empty(h * w * cn, dtype=np.uint8)
+    dw, dh = C.c_int(), C.c_int()
+    lib().lo_orientation(src.ctypes.data_as(_u8p), C.c_int(w), C.c_int(h), C.c_size_t(w * cn), C.c_int(cn), C.c_int(orientation),
+                         dst.ctypes.data_as(_u8p), C.byref(dw), C.byref(dh))
+    return dst.reshape(dh.value, dw.value, cn)
+
+
+def blend_alpha(src, dst):
+    """opencv_copy_to_region_with_alpha on equal-sized src / dst ROI. Returns the new dst."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.ascontiguousarray(dst, dtype=np.uint8).copy()
+    h, w, scn = src.shape
+    dcn = dst.shape[2]
+    rc = lib().lo_blend_alpha(src.ctypes.data_as(_u8p), C.c_size_t(w * scn), C.c_int(scn), dst.ctypes.data_as(_u8p), C.c_size_t(w * dcn),
+                              C.c_int(dcn), C.c_int(w), C.c_int(h))
+    if rc:
+        raise ValueError("blend rc=%d" % rc)
+    return dst
+
+
+def thumbhash(px):
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    if px.ndim == 2:
+        px = px[:, :, None]
+    h, w, cn = px.shape
+    out = np.empty(64, dtype=np.uint8)
+    n = lib().lo_thumbhash(px.ctypes.data_as(_u8p), C.c_int(w), C.c_int(h), C.c_size_t(w * cn), C.c_int(cn), out.ctypes.data_as(_u8p), C.c_size_t(64))
+    if n < 0:
+        raise ValueError("thumbhash failed")
+    return out[:n].tobytes()
+
+
+# --------------------------------------------------------------------------------------------
+# Go-side control logic (pure integer / float64), restated.
+
+NO_RESIZE, FIT, RESIZE = 0, 1, 2  # ops.go:18-22
+
+
+def calculate_expected_size(ow, oh, rw, rh):
+    """ops.go:243-255."""
+    if rw == rh and rw > min(ow, oh):
+        m = min(ow, oh)
+        return m, m
+    if rw > ow and rh > oh and rw != rh:
+        return ow, oh
+    return rw, rh
+
+
+def fit_crop_rect(fw, fh, width, height):
+    """opencv.go:331-363 -> (left, top, widthPostCrop, heightPostCrop)."""
+    aspect_in = float(fw) / float(fh)
+    aspect_out = float(width) / float(height)
+    if aspect_in > aspect_out:
+        wpc = int(aspect_out * float(fh) + 0.5)
+        hpc = fh
+    else:
+        hpc = int(float(fw) / aspect_out + 0.5)
+        wpc = fw
+    wpc = max(wpc, 1)
+    hpc = max(hpc, 1)
+    left = max(int(float(fw - wpc) * 0.5), 0)
+    top = max(int(float(fh - hpc) * 0.5), 0)
+    return left, top, wpc, hpc
+
+
+def swaps_axes(orientation):
+    """opencv.go:174-180."""
+    return orientation in (5, 6, 7, 8)
+
+
+def transform_static(frame, orientation, width, height, resize_method, normalize_orientation):
+    """ImageOps.Transform for a single-frame source up to (not including) the encoder
+    (ops.go:352-479): unconditional orientation, then NoResize / Fit / Resize."""
+    frame = orientation_transform(frame, orientation) if orientation != 1 else np.asarray(frame)
+    if frame.ndim == 2:
+        frame = frame[:, :, None]
+    if resize_method == NO_RESIZE:
+        return frame
+    fh, fw = frame.shape[:2]
+    # inputCanvasSize (ops.go:474-479) uses the HEADER dims, swapped only when the flag is set.
+    hw, hh = (fw, fh)
+    if swaps_axes(orientation) and not normalize_orientation:
+        hw, hh = fh, fw  # header dims un-swapped: canvas = header width/height
+    if resize_method == FIT:
+        nw, nh = calculate_expected_size(hw, hh, width, height)
+        left, top, wpc, hpc = fit_crop_rect(fw, fh, nw, nh)
+        out, _ = resize_area(frame[top:top + hpc, left:left + wpc], nw, nh)
+        return out
+    nw, nh = max(width, 1), max(height, 1)
+    out, _ = resize_area(frame, nw, nh)
+    return out
+
+
+def transform_jpeg_thumbnail(data, width, height, quality=85, use_ref=False):
+    """CPU path for BASELINE configs[0]/[1]: JPEG -> Fit(width,height) -> JPEG q."""
+    from_ref = use_ref and ref() is not None
+    arr, p = _buf(data)
+    info = jpeg_info(data)
+    px = ref_jpeg_decode(data) if from_ref else jpeg_decode(data)
+    out = transform_static(px, info["orientation"], width, height, FIT, False)
+    return (ref_jpeg_encode if from_ref else jpeg_encode)(out, quality)
+
+
+class _Info(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int),
+                ("cid", C.c_int * 4), ("hs", C.c_int * 4), ("vs", C.c_int * 4), ("tq", C.c_int * 4),
+                ("td", C.c_int * 4), ("ta", C.c_int * 4), ("dri", C.c_int), ("orientation", C.c_int),
+                ("sof", C.c_int), ("hmax", C.c_int), ("vmax", C.c_int), ("mcus_x", C.c_int), ("mcus_y", C.c_int),
+                ("colorspace", C.c_int), ("ecs_off", C.c_size_t), ("qt", (C.c_uint16 * 64) * 4), ("qt_present", C.c_int * 4),
+                ("bits", ((C.c_uint8 * 17) * 4) * 2), ("vals", ((C.c_uint8 * 256) * 4) * 2), ("ht_present", (C.c_int * 4) * 2),
+                ("saw_jfif", C.c_int), ("saw_adobe", C.c_int), ("adobe_transform", C.c_int)]
+
+
+def jpeg_info(data):
+    arr, p = _buf(data)
+    info = _Info()
+    rc = lib().lo_jpeg_read_header(p, C.c_size_t(len(arr)), C.byref(info))
+    if rc:
+        raise ValueError("header rc=%d" % rc)
+    return {"width": info.width, "height": info.height, "ncomp": info.ncomp, "dri": info.dri,
+            "orientation": info.orientation, "hs": list(info.hs), "vs": list(info.vs), "ecs_off": info.ecs_off,
+            "mcus_x": info.mcus_x, "mcus_y": info.mcus_y}

@@ -1,0 +1,177 @@
+/*
+ * oracle/ref_driver.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Thin driver around the REFERENCE's own prebuilt libjpeg-turbo 3.1.0
+ * (/root/reference/deps/linux/amd64/lib/libjpeg.a, headers in deps/linux/amd64/include),
+ * calling it exactly the way the reference's patched OpenCV imgcodecs does for
+ *   opencv_decoder_read_data  (/root/reference/opencv.cpp:166-171): library defaults
+ *       (JDCT_ISLOW, do_fancy_upsampling), out_color_space JCS_EXT_BGR / JCS_GRAYSCALE,
+ *       one jpeg_read_scanlines() per row;
+ *   opencv_encoder_write      (/root/reference/opencv.cpp:185-194): jpeg_set_defaults,
+ *       jpeg_set_quality(q, TRUE), in_color_space JCS_EXT_BGR / JCS_GRAYSCALE.
+ * Built by oracle/Makefile into oracle/_ref/libref.so (git-ignored; travels to the GPU box).
+ * No reference SOURCE is copied: this links the prebuilt archive where it lies.
+ */
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <setjmp.h>
+#include <jpeglib.h>
+
+struct err_mgr { struct jpeg_error_mgr pub; jmp_buf jb; };
+static void on_error(j_common_ptr c) { longjmp(((struct err_mgr*)c->err)->jb, 1); }
+static void on_msg(j_common_ptr c) { (void)c; }
+
+int ref_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* w, int* h, int* ch)
+{
+    struct jpeg_decompress_struct ci;
+    struct err_mgr em;
+    ci.err = jpeg_std_error(&em.pub);
+    em.pub.error_exit = on_error;
+    em.pub.output_message = on_msg;
+    if (setjmp(em.jb)) { jpeg_destroy_decompress(&ci); return -1; }
+    jpeg_create_decompress(&ci);
+    jpeg_mem_src(&ci, d, n);
+    jpeg_read_header(&ci, TRUE);
+    if (ci.num_components == 1) { ci.out_color_space = JCS_GRAYSCALE; ci.out_color_components = 1; }
+    else if (ci.num_components == 3) { ci.out_color_space = JCS_EXT_BGR; ci.out_color_components = 3; }
+    else { jpeg_destroy_decompress(&ci); return -2; }
+    jpeg_start_decompress(&ci);
+    *w = (int)ci.output_width; *h = (int)ci.output_height; *ch = ci.out_color_components;
+    size_t stride = (size_t)*w * *ch;
+    if (stride * *h > cap) { jpeg_destroy_decompress(&ci); return -3; }
+    while (ci.output_scanline < ci.output_height) {
+        JSAMPROW row = out + stride * ci.output_scanline;
+        jpeg_read_scanlines(&ci, &row, 1);
+    }
+    jpeg_finish_decompress(&ci);
+    jpeg_destroy_decompress(&ci);
+    return 0;
+}
+
+/* Quantised coefficients of one component, block raster order over the MCU-padded grid,
+ * natural (row-major) order inside a block, DC absolute. */
+int ref_jpeg_decode_coefs(const uint8_t* d, size_t n, int comp, int16_t* out, size_t cap_elems, int* bw, int* bh)
+{
+    struct jpeg_decompress_struct ci;
+    struct err_mgr em;
+    ci.err = jpeg_std_error(&em.pub);
+    em.pub.error_exit = on_error;
+    em.pub.output_message = on_msg;
+    if (setjmp(em.jb)) { jpeg_destroy_decompress(&ci); return -1; }
+    jpeg_create_decompress(&ci);
+    jpeg_mem_src(&ci, d, n);
+    jpeg_read_header(&ci, TRUE);
+    jvirt_barray_ptr* arr = jpeg_read_coefficients(&ci);
+    if (comp >= ci.num_components) { jpeg_destroy_decompress(&ci); return -2; }
+    jpeg_component_info* cp = &ci.comp_info[comp];
+    int mcus_x = (int)((ci.image_width + 8 * ci.max_h_samp_factor - 1) / (8 * ci.max_h_samp_factor));
+    int mcus_y = (int)((ci.image_height + 8 * ci.max_v_samp_factor - 1) / (8 * ci.max_v_samp_factor));
+    int hs = ci.num_components == 1 ? 1 : cp->h_samp_factor, vs = ci.num_components == 1 ? 1 : cp->v_samp_factor;
+    *bw = mcus_x * hs; *bh = mcus_y * vs;
+    if ((size_t)*bw * *bh * 64 > cap_elems) { jpeg_destroy_decompress(&ci); return -3; }
+    memset(out, 0, (size_t)*bw * *bh * 128);
+    /* the virtual array is allocated padded to whole MCUs (jdcoefct.c) for interleaved scans */
+    for (int by = 0; by < *bh; by++) {
+        if (by >= (int)cp->height_in_blocks && ci.num_components == 1) continue;
+        JBLOCKARRAY rows = (*ci.mem->access_virt_barray)((j_common_ptr)&ci, arr[comp], (JDIMENSION)by, 1, FALSE);
+        for (int bx = 0; bx < *bw; bx++) {
+            if (bx >= (int)cp->width_in_blocks && ci.num_components == 1) continue;
+            memcpy(out + ((size_t)by * *bw + bx) * 64, rows[0][bx], 128);
+        }
+    }
+    jpeg_finish_decompress(&ci);
+    jpeg_destroy_decompress(&ci);
+    return 0;
+}
+
+/* Downsampled component planes straight out of the IDCT (raw_data_out), valid extent only:
+ * out is [dh][dw] tightly packed. */
+int ref_jpeg_decode_raw_plane(const uint8_t* d, size_t n, int comp, uint8_t* out, size_t cap, int* dw, int* dh)
+{
+    struct jpeg_decompress_struct ci;
+    struct err_mgr em;
+    ci.err = jpeg_std_error(&em.pub);
+    em.pub.error_exit = on_error;
+    em.pub.output_message = on_msg;
+    uint8_t* bufs[3] = {0, 0, 0};
+    if (setjmp(em.jb)) { jpeg_destroy_decompress(&ci); for (int c = 0; c < 3; c++) free(bufs[c]); return -1; }
+    jpeg_create_decompress(&ci);
+    jpeg_mem_src(&ci, d, n);
+    jpeg_read_header(&ci, TRUE);
+    ci.raw_data_out = TRUE;
+    ci.out_color_space = ci.jpeg_color_space;
+    jpeg_start_decompress(&ci);
+    if (comp >= ci.num_components) { jpeg_destroy_decompress(&ci); return -2; }
+    int nc = ci.num_components;
+    int rows_per_imcu = ci.max_v_samp_factor * 8;
+    JSAMPROW rowptr[3][16];
+    JSAMPARRAY planes[3];
+    size_t pw[3], ph[3];
+    for (int c = 0; c < nc; c++) {
+        pw[c] = (size_t)ci.comp_info[c].width_in_blocks * 8;
+        ph[c] = (size_t)((ci.image_height + rows_per_imcu - 1) / rows_per_imcu) * ci.comp_info[c].v_samp_factor * 8;
+        if (nc == 1) ph[c] = (size_t)((ci.image_height + 7) / 8) * 8;
+        bufs[c] = (uint8_t*)malloc(pw[c] * ph[c]);
+        planes[c] = rowptr[c];
+    }
+    while (ci.output_scanline < ci.output_height) {
+        size_t imcu = ci.output_scanline / (nc == 1 ? 8 : rows_per_imcu);
+        for (int c = 0; c < nc; c++) {
+            int vr = (nc == 1 ? 1 : ci.comp_info[c].v_samp_factor) * 8;
+            for (int r = 0; r < vr; r++) rowptr[c][r] = bufs[c] + (imcu * vr + r) * pw[c];
+        }
+        jpeg_read_raw_data(&ci, planes, nc == 1 ? 8 : rows_per_imcu);
+    }
+    *dw = (int)ci.comp_info[comp].downsampled_width;
+    *dh = (int)ci.comp_info[comp].downsampled_height;
+    int rc = 0;
+    if ((size_t)*dw * *dh > cap) rc = -3;
+    else for (int y = 0; y < *dh; y++) memcpy(out + (size_t)y * *dw, bufs[comp] + (size_t)y * pw[comp], *dw);
+    jpeg_finish_decompress(&ci);
+    jpeg_destroy_decompress(&ci);
+    for (int c = 0; c < 3; c++) free(bufs[c]);
+    return rc;
+}
+
+long ref_jpeg_encode(const uint8_t* px, int W, int H, int ch, size_t stride, int quality, uint8_t* out, size_t cap)
+{
+    struct jpeg_compress_struct ci;
+    struct err_mgr em;
+    unsigned char* mem = NULL;
+    unsigned long memlen = 0;
+    uint8_t* rowbuf = NULL;
+    ci.err = jpeg_std_error(&em.pub);
+    em.pub.error_exit = on_error;
+    em.pub.output_message = on_msg;
+    if (setjmp(em.jb)) { jpeg_destroy_compress(&ci); free(mem); free(rowbuf); return -1; }
+    jpeg_create_compress(&ci);
+    jpeg_mem_dest(&ci, &mem, &memlen);
+    ci.image_width = (JDIMENSION)W;
+    ci.image_height = (JDIMENSION)H;
+    ci.input_components = ch > 1 ? 3 : 1;
+    ci.in_color_space = ch > 1 ? JCS_EXT_BGR : JCS_GRAYSCALE;
+    jpeg_set_defaults(&ci);
+    if (quality < 0) quality = 0;
+    if (quality > 100) quality = 100;
+    jpeg_set_quality(&ci, quality, TRUE);
+    jpeg_start_compress(&ci, TRUE);
+    if (ch == 4) rowbuf = (uint8_t*)malloc((size_t)W * 3);
+    while (ci.next_scanline < ci.image_height) {
+        const uint8_t* src = px + stride * ci.next_scanline;
+        JSAMPROW row = (JSAMPROW)src;
+        if (ch == 4) {
+            for (int x = 0; x < W; x++) { rowbuf[3 * x] = src[4 * x]; rowbuf[3 * x + 1] = src[4 * x + 1]; rowbuf[3 * x + 2] = src[4 * x + 2]; }
+            row = rowbuf;
+        }
+        jpeg_write_scanlines(&ci, &row, 1);
+    }
+    jpeg_finish_compress(&ci);
+    jpeg_destroy_compress(&ci);
+    free(rowbuf);
+    long rc = (long)memlen;
+    if (memlen > cap) rc = -3; else memcpy(out, mem, memlen);
+    free(mem);
+    return rc;
+}
