@@ -1,0 +1,26 @@
+// lp_jpeg_parse.h -- host-side JPEG marker parsing (S0) and table construction.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "lp_types.h"
+
+enum {
+    LP_PARSE_OK = 0,
+    LP_PARSE_NOT_JPEG = 1,      // no SOI / broken marker structure      -> ErrInvalidImage
+    LP_PARSE_UNSUPPORTED = 2,   // progressive, arithmetic, 12-bit, CMYK, exotic sampling
+    LP_PARSE_TRUNCATED = 3
+};
+
+struct LpJpegHeader {
+    LpJpeg j;                   // geometry + table slots filled; arena offsets left 0
+    LpHuffSet huff;
+    size_t ecs_off;             // first entropy-coded byte in the file
+    size_t ecs_len;             // bytes up to (not including) the terminating marker / end of file
+    int saw_eoi;
+};
+
+// Parses up to SOS, locates the end of the scan, builds the decode tables.
+int lp_jpeg_parse(const uint8_t* data, size_t len, LpJpegHeader* out);
+
+// Build one table slot of an LpHuffSet from DHT counts/values.
+void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals);

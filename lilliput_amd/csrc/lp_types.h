@@ -1,0 +1,87 @@
+// lp_types.h -- descriptors shared by the host orchestration and the HIP kernels.
+//
+// One LpJpeg per source image describes a baseline JPEG (the input side of lilliput's
+// ImageOps.Transform, /root/reference/ops.go:352-444 -> opencv.cpp:126-171) after the host has
+// parsed its markers (S0 in SURVEY.md 2a). Everything below the markers -- unstuffing, Huffman
+// decode, IDCT, upsampling, colour conversion -- runs on the device.
+#pragma once
+#include <stdint.h>
+
+#define LP_MAX_COMP 3
+#define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
+#define LP_LUT_BITS 10          // first-level Huffman lookup width
+#define LP_LUT_SIZE (1 << LP_LUT_BITS)
+#define LP_MAX_CKPT 32          // checkpoints per subsequence
+
+// Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
+// lut[t][i]: (len << 8) | symbol for codes of length <= LP_LUT_BITS, 0 = longer code -> canonical search.
+// Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
+struct LpHuffSet {
+    uint16_t lut[4][LP_LUT_SIZE];
+    int32_t maxcode[4][18];     // maxcode[l] = largest code of length l, -1 if none; [17] = sentinel
+    int32_t valoff[4][17];      // valptr[l] - mincode[l]
+    uint8_t vals[4][256];
+};
+
+struct LpJpeg {
+    // ---- stream
+    uint64_t raw_off;           // byte offset of the entropy-coded segment inside the raw arena
+    uint32_t raw_len;           // bytes of ECS (markers inside: FF00, RSTn; ends before EOI)
+    uint32_t pad0;
+    uint64_t clean_off;         // word (uint32) offset of this image's unstuffed stream in the clean arena
+    uint32_t clean_cap_words;
+    uint32_t huff_idx;          // index into the LpHuffSet array
+    // ---- geometry
+    uint32_t width, height;
+    uint32_t mcus_x, mcus_y;
+    uint32_t total_blocks;
+    uint32_t dri;               // MCUs per restart interval, 0 = none
+    uint8_t ncomp, hmax, vmax, bpm;
+    uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB
+    uint8_t orientation;        // EXIF 1..8
+    uint8_t pad1[2];
+    uint8_t hs[LP_MAX_COMP], vs[LP_MAX_COMP];
+    uint8_t dc_tbl[LP_MAX_COMP], ac_tbl[LP_MAX_COMP];   // slots into LpHuffSet (0..1 / 2..3)
+    uint8_t blk_comp[8], blk_h[8], blk_v[8];            // per block-in-MCU
+    uint32_t bw[LP_MAX_COMP], bh[LP_MAX_COMP];          // blocks per row / column (MCU padded)
+    uint64_t coef_off[LP_MAX_COMP];                     // int16 element offset into the coefficient arena
+    uint64_t plane_off[LP_MAX_COMP];                    // byte offset into the plane arena
+    uint32_t plane_stride[LP_MAX_COMP];                 // = bw*8
+    uint16_t qt[LP_MAX_COMP][64];                       // dequantisation table per component, natural order
+    // ---- subsequence bookkeeping
+    uint32_t sub_off;           // index of this image's first subsequence in the per-subsequence arrays
+    uint32_t sub_cap;           // capacity (from raw_len, an upper bound of the clean length)
+    uint32_t rst_off;           // index of this image's first entry in the restart-position array
+    uint32_t rst_cap;
+    uint32_t chunk_off;         // index of first unstuff chunk in the chunk-count array
+    uint32_t nchunks;
+};
+
+// Per-image results produced on the device.
+struct LpJpegState {
+    uint32_t clean_bytes;       // unstuffed length
+    uint32_t n_rst;             // restart markers found
+    uint32_t nsub;              // ceil(clean_bytes*8 / S)
+    uint32_t error;             // bit 0: unexpected marker in ECS, bit 1: block count mismatch
+    uint32_t end_marker_pos;    // raw position of the first non-RST marker (or raw_len)
+    uint32_t blocks_decoded;
+    uint32_t pad[2];
+};
+
+// Decoder state at a symbol boundary.
+struct LpSubState {
+    uint32_t p;                 // bit position in the clean stream
+    uint32_t bz;                // (b << 8) | z : block-in-MCU, zigzag index of next coefficient
+};
+
+// Summary of the blocks STARTING inside one subsequence (or inside its prefix up to a checkpoint).
+struct LpSubSum {
+    uint32_t nblk;              // block starts
+    uint32_t nreset;            // restart boundaries crossed
+    int32_t dc[LP_MAX_COMP];    // sum of DC differences per component since the last reset
+};
+
+struct LpCkpt {
+    LpSubState st;
+    LpSubSum sum;
+};
