@@ -1,0 +1,223 @@
+/*
+ * lilliput_hip.h -- C ABI of liblilliput_hip.so, the MI355X-native replacement for the hot path of
+ * discord/lilliput's ImageOps.Transform (decode -> orientation/crop -> resize -> encode).
+ *
+ * Part A re-declares, with identical names, argument meaning and error behaviour, the subset of the
+ * reference's cgo boundary /root/reference/opencv.hpp:57-145 that this path crosses; a Go build links
+ * liblilliput_hip.so instead of opencv.cpp + the OpenCV/libjpeg static archives.
+ * Part B is additive: a batched entry point (the synchronous one-image ABI cannot reach the throughput
+ * target) -- same ownership rules, arrays of caller-owned buffers, per-item status.
+ * Part C mirrors the Go-side API surface (Decoder / ImageOps / ImageOptions, ops.go + opencv.go +
+ * lilliput.go) in C, because no Go toolchain exists in the build image; it drives Part A exactly the
+ * way the Go code does.
+ *
+ * No torch / OpenCV types cross this boundary: plain pointers, sizes and ints only.
+ */
+#ifndef LILLIPUT_HIP_H
+#define LILLIPUT_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part A -- drop-in for /root/reference/opencv.hpp
+ * ---------------------------------------------------------------------------------------------- */
+
+/* OpenCV type codes that cross the ABI as plain ints (opencv2/core/hal/interface.h; used by
+ * /root/reference/opencv.go:232,241,443) */
+#ifndef CV_8U
+#define CV_8U 0
+#define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_8UC4 24
+#endif
+
+/* opencv.hpp:17-26 */
+typedef enum CVImageOrientation {
+    CV_IMAGE_ORIENTATION_TL = 1,
+    CV_IMAGE_ORIENTATION_TR = 2,
+    CV_IMAGE_ORIENTATION_BR = 3,
+    CV_IMAGE_ORIENTATION_BL = 4,
+    CV_IMAGE_ORIENTATION_LT = 5,
+    CV_IMAGE_ORIENTATION_RT = 6,
+    CV_IMAGE_ORIENTATION_RB = 7,
+    CV_IMAGE_ORIENTATION_LB = 8
+} CVImageOrientation;
+
+/* opencv.hpp:33-36 */
+#define CV_IMWRITE_JPEG_QUALITY 1
+#define CV_IMWRITE_PNG_COMPRESSION 16
+#define CV_IMWRITE_WEBP_QUALITY 64
+#define CV_IMWRITE_JPEG_PROGRESSIVE 2
+
+/* opencv.hpp:53-55 (values of cv::INTER_AREA / INTER_LINEAR / INTER_CUBIC) */
+extern const int CV_INTER_AREA;
+extern const int CV_INTER_LINEAR;
+extern const int CV_INTER_CUBIC;
+
+/* opencv.hpp:57-59 */
+typedef void* opencv_mat;
+typedef void* opencv_decoder;
+typedef void* opencv_encoder;
+
+/* opencv.hpp:61-63 */
+int opencv_type_depth(int type);
+int opencv_type_channels(int type);
+int opencv_type_convert_depth(int type, int depth);
+
+/* opencv.hpp:65-74 -- JPEG sources are decoded on the device; any other container yields NULL from
+ * opencv_decoder_create (the Go caller maps that to ErrInvalidImage, opencv.go:453-456). */
+opencv_decoder opencv_decoder_create(const opencv_mat buf);
+const char* opencv_decoder_get_description(const opencv_decoder d);
+void opencv_decoder_release(opencv_decoder d);
+bool opencv_decoder_read_header(opencv_decoder d);
+int opencv_decoder_get_width(const opencv_decoder d);
+int opencv_decoder_get_height(const opencv_decoder d);
+int opencv_decoder_get_pixel_type(const opencv_decoder d);
+int opencv_decoder_get_orientation(const opencv_decoder d);
+bool opencv_decoder_read_data(opencv_decoder d, opencv_mat dst);
+
+/* opencv.hpp:75-93 */
+int opencv_copy_to_region_with_alpha(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height);
+int opencv_copy_to_region(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height);
+void opencv_mat_set_color(opencv_mat, int red, int green, int blue, int alpha);
+void opencv_mat_reset(opencv_mat mat);
+int opencv_mat_clear_to_transparent(opencv_mat mat, int xOffset, int yOffset, int width, int height);
+
+/* opencv.hpp:95-114 */
+opencv_mat opencv_mat_create(int width, int height, int type);
+opencv_mat opencv_mat_create_from_data(int width, int height, int type, void* data, size_t data_len);
+opencv_mat opencv_mat_create_empty_from_data(int length, void* data);
+bool opencv_mat_set_row_stride(opencv_mat mat, size_t stride);
+void opencv_mat_release(opencv_mat mat);
+void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int height, int interpolation);
+opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int height);
+void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat mat);
+int opencv_mat_get_width(const opencv_mat mat);
+int opencv_mat_get_height(const opencv_mat mat);
+void* opencv_mat_get_data(const opencv_mat mat);
+
+/* opencv.hpp:116-118 -- ".jpeg" / ".jpg" only; other extensions yield NULL. */
+opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst);
+void opencv_encoder_release(opencv_encoder e);
+bool opencv_encoder_write(opencv_encoder e, const opencv_mat src, const int* opt, size_t opt_len);
+
+/* opencv.hpp:135-145 */
+#define OPENCV_SUCCESS 0
+#define OPENCV_ERROR_INVALID_CHANNEL_COUNT 1
+#define OPENCV_ERROR_OUT_OF_BOUNDS 2
+#define OPENCV_ERROR_NULL_MATRIX 3
+#define OPENCV_ERROR_RESIZE_FAILED 4
+#define OPENCV_ERROR_COPY_FAILED 5
+#define OPENCV_ERROR_CONVERSION_FAILED 6
+#define OPENCV_ERROR_ALPHA_BLENDING_FAILED 7
+#define OPENCV_ERROR_FINAL_CONVERSION_FAILED 8
+#define OPENCV_ERROR_INVALID_DIMENSIONS 9
+#define OPENCV_ERROR_UNKNOWN 10
+
+/* ------------------------------------------------------------------------------------------------
+ * Part B -- batched extension (additive)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* lilliput error values (lilliput.go:24-31) as ints, 0 = nil */
+#define LILLIPUT_OK 0
+#define LILLIPUT_ERR_INVALID_IMAGE 1
+#define LILLIPUT_ERR_DECODING_FAILED 2
+#define LILLIPUT_ERR_BUF_TOO_SMALL 3
+#define LILLIPUT_ERR_UNSUPPORTED 4      /* stream feature the device path does not cover; nothing is written */
+#define LILLIPUT_ERR_DEVICE 5           /* no GPU / HIP failure */
+#define LILLIPUT_ERR_FRAMEBUF_NO_PIXELS 6
+#define LILLIPUT_ERR_ENCODE_TIMEOUT 7
+#define LILLIPUT_ERR_EOF 8
+
+/* ops.go:18-22 */
+#define LILLIPUT_OPS_NO_RESIZE 0
+#define LILLIPUT_OPS_FIT 1
+#define LILLIPUT_OPS_RESIZE 2
+
+typedef struct lilliput_batch_item {
+    const void* src;    /* encoded source image (caller-owned, like Go's []byte input) */
+    size_t src_len;
+    void* dst;          /* caller-owned output buffer, like the dst []byte of ImageOps.Transform */
+    size_t dst_cap;
+    size_t dst_len;     /* out: bytes written */
+    int status;         /* out: LILLIPUT_* */
+    int out_width;      /* out */
+    int out_height;     /* out */
+} lilliput_batch_item;
+
+typedef struct lilliput_batch_options {
+    int width, height;          /* ImageOptions.Width / Height (ops.go:31-35) */
+    int resize_method;          /* ImageOptions.ResizeMethod */
+    int normalize_orientation;  /* ImageOptions.NormalizeOrientation */
+    int jpeg_quality;           /* EncodeOptions[JpegQuality]; 0 -> OpenCV's default 95 */
+    int chunk;                  /* images in flight on the device at once; 0 = automatic */
+} lilliput_batch_options;
+
+typedef void* lilliput_hip_batch;
+
+lilliput_hip_batch lilliput_hip_batch_create(int device);
+void lilliput_hip_batch_destroy(lilliput_hip_batch b);
+/* JPEG -> (orientation, Fit/Resize) -> JPEG for n independent images; returns the number of failed items. */
+int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt);
+/* Staged form used by bench.py: upload parses the headers and moves the compressed bytes into HBM,
+ * run executes every device stage (inputs resident), download copies the encoded results back. */
+int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);
+int lilliput_hip_batch_run(lilliput_hip_batch b, const lilliput_batch_options* opt);
+int lilliput_hip_batch_download(lilliput_hip_batch b, lilliput_batch_item* items, size_t n);
+/* Per-stage device milliseconds of the last run: unstuff, huffman, idct, colour, resize, encode, then verify rounds. */
+void lilliput_hip_batch_timings(lilliput_hip_batch b, float out_ms[6], int* verify_rounds);
+/* Decoder tuning: subsequence bits / checkpoint spacing (0 = automatic). */
+void lilliput_hip_batch_set_subsequence(lilliput_hip_batch b, unsigned S, unsigned C);
+
+/* Stage-level access for parity tests (device results copied to host). */
+int lilliput_hip_decode_jpeg(lilliput_hip_batch b, const void* src, size_t len, void* dst, size_t cap, int* w, int* h, int* channels, int* orientation);
+int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch b, const void* src, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh);
+int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch b, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph);
+const char* lilliput_hip_last_error(void);
+int lilliput_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part C -- host mirror of the Go API (ops.go / opencv.go / lilliput.go)
+ * ---------------------------------------------------------------------------------------------- */
+typedef void* lilliput_decoder;
+typedef void* lilliput_image_ops;
+
+typedef struct lilliput_image_options {     /* ops.go:26-65 */
+    const char* file_type;                  /* ".jpeg" */
+    int width, height;
+    int resize_method;
+    int normalize_orientation;
+    const int* encode_options;              /* flattened map[int]int: key, value, key, value ... */
+    size_t encode_options_len;              /* number of ints */
+    int max_encode_frames;
+    int64_t max_encode_duration_ns;
+    int64_t encode_timeout_ns;
+    int disable_animated_output;
+    int force_sdr;
+} lilliput_image_options;
+
+int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out);           /* lilliput.go:129-164 */
+void lilliput_decoder_close(lilliput_decoder d);
+int lilliput_decoder_header(lilliput_decoder d, int* width, int* height, int* pixel_type, int* orientation, int* num_frames, int* content_length);
+const char* lilliput_decoder_description(lilliput_decoder d);
+lilliput_image_ops lilliput_new_image_ops(int max_size);                                /* ops.go:83-91 */
+void lilliput_image_ops_close(lilliput_image_ops o);
+void lilliput_image_ops_clear(lilliput_image_ops o);
+/* ops.go:352-444: returns LILLIPUT_*; *dst_len = length of the encoded image inside dst. */
+int lilliput_image_ops_transform(lilliput_image_ops o, lilliput_decoder d, const lilliput_image_options* opt, void* dst, size_t dst_cap, size_t* dst_len);
+/* Pure control logic exposed for parity tests. */
+void lilliput_calculate_expected_size(int orig_w, int orig_h, int req_w, int req_h, int* out_w, int* out_h);  /* ops.go:243-255 */
+void lilliput_fit_crop_rect(int fw, int fh, int width, int height, int* left, int* top, int* w, int* h);      /* opencv.go:331-363 */
+int lilliput_detect_content_length(const void* buf, size_t len);                                              /* opencv.go:604-614 */
+int lilliput_detect_apng(const void* buf, size_t len);                                                        /* opencv.go:617-637 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

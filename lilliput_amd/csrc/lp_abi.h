@@ -1,0 +1,48 @@
+// lp_abi.h -- internal types behind the opaque handles of include/lilliput_hip.h.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/lilliput_hip.h"
+#include "lp_engine.h"
+
+struct LpDevBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~LpDevBlock();
+};
+std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes);
+
+// What an `opencv_mat` handle points at (the reference's is a cv::Mat*, opencv.cpp:22-49).
+struct LpMat {
+    uint8_t* data = nullptr;        // first pixel of this (view of a) matrix -- host memory, usually Go-owned
+    uint8_t* datastart = nullptr;
+    uint8_t* datalimit = nullptr;
+    int rows = 0, cols = 0, type = 0;
+    size_t step = 0;
+    std::vector<uint8_t> own;       // host storage when the Mat owns it (opencv_mat_create / reallocation)
+    // device mirror: authoritative between ABI calls while dev_valid
+    std::shared_ptr<LpDevBlock> dev;
+    size_t dev_off = 0, dev_step = 0;
+    bool dev_valid = false;
+    bool dev_shared = false;        // a crop view sharing its parent's block
+};
+
+struct LpDecoder {
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+    bool parsed = false;
+    int parse_rc = 0;
+    LpJpegHeader hdr;
+};
+
+struct LpEncoder {
+    LpMat* dst = nullptr;
+};
+
+LpEngine* lp_thread_engine();
+void lp_set_error(const std::string& s);
+bool lp_mat_to_device(LpMat* m, LpEngine* eng);
+bool lp_mat_to_host(LpMat* m, LpEngine* eng);
+LpFrame lp_mat_frame(const LpMat* m);

@@ -1,0 +1,476 @@
+// lp_abi_opencv.cpp -- Part A of include/lilliput_hip.h: the reference's opencv.hpp C ABI
+// (/root/reference/opencv.hpp:57-145, implemented there by opencv.cpp on top of cv::Mat) re-implemented
+// over an own Mat header with a device mirror. Go keeps owning every big host buffer
+// (/root/reference/opencv.go:207-267, 443, 848-849); results are always written back into those buffers
+// before a call returns, so Go code that reads Framebuffer.buf directly keeps working.
+#include "lp_abi.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+extern "C" {
+const int CV_INTER_AREA = 3;   // cv::INTER_AREA
+const int CV_INTER_LINEAR = 1; // cv::INTER_LINEAR
+const int CV_INTER_CUBIC = 2;  // cv::INTER_CUBIC
+}
+
+static thread_local std::string g_last_error;
+void lp_set_error(const std::string& s) { g_last_error = s; }
+extern "C" const char* lilliput_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int lilliput_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+LpEngine* lp_thread_engine()
+{
+    static thread_local std::unique_ptr<LpEngine> eng;
+    if (!eng) {
+        int dev = 0;
+        if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e);
+        eng.reset(new LpEngine(dev));
+        if (!eng->ok()) {
+            lp_set_error(eng->last_error());
+            fprintf(stderr, "lilliput_hip: no usable MI355X device (%s); the HIP path has no CPU fallback\n", eng->last_error().c_str());
+        }
+    }
+    return eng->ok() ? eng.get() : nullptr;
+}
+
+// ---- device block pool (size-bucketed free lists; hipMalloc is too slow to call per Mat)
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void*>> free_list;
+    ~Pool() { for (auto& b : free_list) (void)hipFree(b.second); }
+} g_pool;
+size_t bucket(size_t n) { size_t b = 4096; while (b < n) b <<= 1; return b; }
+}
+
+LpDevBlock::~LpDevBlock()
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (g_pool.free_list.size() < 64) g_pool.free_list.emplace_back(cap, p);
+    else (void)hipFree(p);
+}
+
+std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes)
+{
+    size_t want = bucket(bytes + 64);
+    auto blk = std::make_shared<LpDevBlock>();
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        for (size_t i = 0; i < g_pool.free_list.size(); i++)
+            if (g_pool.free_list[i].first == want) {
+                blk->p = g_pool.free_list[i].second;
+                blk->cap = want;
+                g_pool.free_list.erase(g_pool.free_list.begin() + (long)i);
+                return blk;
+            }
+    }
+    if (hipMalloc(&blk->p, want) != hipSuccess) { lp_set_error("hipMalloc failed"); return nullptr; }
+    blk->cap = want;
+    return blk;
+}
+
+// CV_ELEM_SIZE for the 8-bit / 16-bit depths that reach this ABI
+static inline int cv_channels(int type) { return (type >> 3) + 1; }
+static inline int cv_depth_bytes(int type)
+{
+    switch (type & 7) { case 0: case 1: return 1; case 2: case 3: return 2; case 4: case 5: return 4; case 6: return 8; default: return 2; }
+}
+static inline size_t cv_elem_size(int type) { return (size_t)cv_channels(type) * cv_depth_bytes(type); }
+
+bool lp_mat_to_device(LpMat* m, LpEngine* eng)
+{
+    if (m->dev && m->dev_valid) return true;
+    const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
+    const size_t need = rowb * (size_t)m->rows;
+    if (!need) return false;
+    if (!m->dev || m->dev->cap < need || m->dev_shared) {
+        m->dev = lp_dev_alloc(need);
+        m->dev_off = 0;
+        m->dev_shared = false;
+        if (!m->dev) return false;
+    }
+    m->dev_step = rowb;
+    if (hipMemcpy2DAsync((uint8_t*)m->dev->p + m->dev_off, rowb, m->data, m->step, rowb, (size_t)m->rows, hipMemcpyHostToDevice, eng->stream()) != hipSuccess)
+        return false;
+    if (eng->sync()) return false;
+    m->dev_valid = true;
+    return true;
+}
+
+bool lp_mat_to_host(LpMat* m, LpEngine* eng)
+{
+    const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
+    if (!m->dev || !rowb || !m->rows) return false;
+    if (hipMemcpy2DAsync(m->data, m->step, (uint8_t*)m->dev->p + m->dev_off, m->dev_step, rowb, (size_t)m->rows, hipMemcpyDeviceToHost, eng->stream()) !=
+        hipSuccess)
+        return false;
+    return eng->sync() == LP_OK;
+}
+
+LpFrame lp_mat_frame(const LpMat* m)
+{
+    LpFrame f;
+    f.off = (uint64_t)(uintptr_t)((uint8_t*)m->dev->p + m->dev_off);
+    f.w = (uint32_t)m->cols; f.h = (uint32_t)m->rows; f.stride = (uint32_t)m->dev_step; f.cn = (uint32_t)cv_channels(m->type);
+    return f;
+}
+
+// Give `m` a fresh, exclusively owned device block for rows x cols of its type.
+static bool mat_new_dev(LpMat* m)
+{
+    const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
+    m->dev = lp_dev_alloc(rowb * (size_t)m->rows);
+    m->dev_off = 0;
+    m->dev_step = rowb;
+    m->dev_shared = false;
+    m->dev_valid = false;
+    return (bool)m->dev;
+}
+
+// cv::Mat::create semantics for an output Mat: keep the external buffer when the new shape fits.
+static bool mat_reshape(LpMat* m, int rows, int cols, int type)
+{
+    const size_t need = (size_t)rows * cols * cv_elem_size(type);
+    if (m->rows == rows && m->cols == cols && m->type == type && m->data) return true;
+    if (m->data && m->datastart && (size_t)(m->datalimit - m->datastart) >= need && m->data == m->datastart) {
+        m->rows = rows; m->cols = cols; m->type = type; m->step = (size_t)cols * cv_elem_size(type);
+        return true;
+    }
+    m->own.assign(need, 0); // reallocation: the Mat no longer aliases the caller's buffer (cv::Mat::create)
+    m->data = m->datastart = m->own.data();
+    m->datalimit = m->data + need;
+    m->rows = rows; m->cols = cols; m->type = type; m->step = (size_t)cols * cv_elem_size(type);
+    return true;
+}
+
+extern "C" {
+
+int opencv_type_depth(int type) { return cv_depth_bytes(type) * 8; }          // opencv.cpp:83-86
+int opencv_type_channels(int type) { return cv_channels(type); }              // opencv.cpp:88-91
+int opencv_type_convert_depth(int t, int depth) { return (depth & 7) + ((cv_channels(t) - 1) << 3); } // opencv.cpp:93-96
+
+opencv_mat opencv_mat_create(int width, int height, int type) // opencv.cpp:22-25
+{
+    auto m = new LpMat();
+    m->rows = height; m->cols = width; m->type = type;
+    m->step = (size_t)width * cv_elem_size(type);
+    m->own.assign(m->step * (size_t)height, 0);
+    m->data = m->datastart = m->own.data();
+    m->datalimit = m->data + m->own.size();
+    return m;
+}
+
+opencv_mat opencv_mat_create_from_data(int width, int height, int type, void* data, size_t data_len) // opencv.cpp:27-36
+{
+    size_t total = (size_t)width * height * cv_elem_size(type);
+    if (total > data_len) return NULL;
+    auto m = new LpMat();
+    m->rows = height; m->cols = width; m->type = type;
+    m->step = (size_t)width * cv_elem_size(type);
+    m->data = m->datastart = (uint8_t*)data;
+    m->datalimit = (uint8_t*)data + data_len;
+    return m;
+}
+
+opencv_mat opencv_mat_create_empty_from_data(int length, void* data) // opencv.cpp:38-49
+{
+    auto m = new LpMat();
+    m->rows = 0; m->cols = 1; m->type = CV_8U; m->step = 1;
+    m->data = m->datastart = (uint8_t*)data;
+    m->datalimit = m->data + length;
+    return m;
+}
+
+bool opencv_mat_set_row_stride(opencv_mat mat, size_t stride) // opencv.cpp:51-75
+{
+    auto m = static_cast<LpMat*>(mat);
+    if (m->step == stride) return true;
+    size_t ws = (size_t)m->cols * cv_elem_size(m->type);
+    if (stride < ws) return false;
+    if (m->step != ws) return false;
+    if (m->datastart + stride * (size_t)m->rows > m->datalimit) return false;
+    m->step = stride;
+    m->dev_valid = false;
+    return true;
+}
+
+void opencv_mat_release(opencv_mat mat) { delete static_cast<LpMat*>(mat); } // opencv.cpp:77-81
+
+int opencv_mat_get_width(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->cols; }   // opencv.cpp:223-227
+int opencv_mat_get_height(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->rows; }  // opencv.cpp:229-233
+void* opencv_mat_get_data(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->data; }  // opencv.cpp:235-239
+
+opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int height) // opencv.cpp:210-215
+{
+    auto s = static_cast<const LpMat*>(src);
+    if (x < 0 || y < 0 || width < 0 || height < 0 || x + width > s->cols || y + height > s->rows) {
+        // cv::Mat(Rect) asserts here and the reference would abort; refuse instead
+        fprintf(stderr, "lilliput_hip: opencv_mat_crop rectangle outside the matrix\n");
+        return NULL;
+    }
+    auto m = new LpMat();
+    m->rows = height; m->cols = width; m->type = s->type; m->step = s->step;
+    m->data = s->data + (size_t)y * s->step + (size_t)x * cv_elem_size(s->type);
+    m->datastart = s->datastart;
+    m->datalimit = s->datalimit;
+    if (s->dev && s->dev_valid) { // a view of the parent's device mirror, like cv::Mat(Rect) is a view of its data
+        m->dev = s->dev;
+        m->dev_off = s->dev_off + (size_t)y * s->dev_step + (size_t)x * cv_elem_size(s->type);
+        m->dev_step = s->dev_step;
+        m->dev_valid = true;
+        m->dev_shared = true;
+    }
+    return m;
+}
+
+void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int height, int interpolation) // opencv.cpp:196-208
+{
+    auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
+    auto d = static_cast<LpMat*>(dst);
+    LpEngine* eng = lp_thread_engine();
+    if (!eng || !s || !d || width <= 0 || height <= 0 || s->rows <= 0 || s->cols <= 0) { fprintf(stderr, "lilliput_hip: opencv_mat_resize failed (no device / empty matrix)\n"); return; }
+    if (interpolation != CV_INTER_AREA) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports CV_INTER_AREA only\n"); return; }
+    if (cv_depth_bytes(s->type) != 1) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports 8-bit matrices only\n"); return; }
+    if (!lp_mat_to_device(s, eng)) return;
+    mat_reshape(d, height, width, s->type);
+    if (!mat_new_dev(d)) return;
+    LpResizeReq rq;
+    rq.src = lp_mat_frame(s);
+    rq.crop_x = rq.crop_y = 0; rq.crop_w = (uint32_t)s->cols; rq.crop_h = (uint32_t)s->rows;
+    rq.dst_w = (uint32_t)width; rq.dst_h = (uint32_t)height;
+    LpFrame df = lp_mat_frame(d);
+    int st = 0;
+    if (eng->resize(&rq, 1, &df, &st) || st) { fprintf(stderr, "lilliput_hip: resize failed: %s\n", eng->last_error().c_str()); return; }
+    d->dev_valid = true;
+    lp_mat_to_host(d, eng);
+}
+
+void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat mat) // opencv.cpp:217-221
+{
+    auto m = static_cast<LpMat*>(mat);
+    int o = (int)orientation;
+    if (!m || o <= 1 || o > 8 || m->rows <= 0 || m->cols <= 0) return; // cv::ExifTransform: TL and unknown values are no-ops
+    LpEngine* eng = lp_thread_engine();
+    if (!eng || !lp_mat_to_device(m, eng)) { fprintf(stderr, "lilliput_hip: orientation transform failed (no device)\n"); return; }
+    const bool swap = o >= 5;
+    LpOrientOp op;
+    op.src = lp_mat_frame(m);
+    op.orientation = (uint32_t)o;
+    op.pad = 0;
+    auto src_blk = m->dev; // keep the source alive until the kernel has run
+    int nr = swap ? m->cols : m->rows, nc = swap ? m->rows : m->cols;
+    LpMat tmp;
+    tmp.rows = nr; tmp.cols = nc; tmp.type = m->type;
+    if (!mat_new_dev(&tmp)) return;
+    op.dst = lp_mat_frame(&tmp);
+    if (eng->orient(&op, 1)) return;
+    // the pixels stay in the caller's buffer (tightly packed), unlike cv::transpose which reallocates
+    const size_t need = (size_t)nr * nc * cv_elem_size(m->type);
+    if ((size_t)(m->datalimit - m->data) < need) { fprintf(stderr, "lilliput_hip: orientation transform: buffer too small\n"); return; }
+    m->rows = nr; m->cols = nc; m->step = (size_t)nc * cv_elem_size(m->type);
+    m->dev = tmp.dev; m->dev_off = 0; m->dev_step = tmp.dev_step; m->dev_shared = false; m->dev_valid = true;
+    lp_mat_to_host(m, eng);
+}
+
+void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
+{
+    auto m = static_cast<LpMat*>(mat);
+    if (!m) return;
+    const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
+    for (int y = 0; y < m->rows; y++) memset(m->data + (size_t)y * m->step, 0, rowb);
+    m->dev_valid = false;
+}
+
+void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alpha) // opencv.cpp:488-496
+{
+    auto m = static_cast<LpMat*>(mat);
+    if (!m) return;
+    const int cn = cv_channels(m->type);
+    const uint8_t v[4] = {(uint8_t)blue, (uint8_t)green, (uint8_t)red, (uint8_t)(alpha >= 0 ? alpha : 0)};
+    for (int y = 0; y < m->rows; y++)
+        for (int x = 0; x < m->cols; x++)
+            for (int c = 0; c < cn && c < 4; c++) m->data[(size_t)y * m->step + (size_t)x * cn + c] = v[c];
+    m->dev_valid = false;
+}
+
+static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int width, int height, int kind)
+{
+    if (!d || (kind != 2 && (!s || s->rows <= 0 || s->cols <= 0)) || d->rows <= 0 || d->cols <= 0) return OPENCV_ERROR_NULL_MATRIX;
+    if (xOffset < 0 || yOffset < 0 || xOffset + width > d->cols || yOffset + height > d->rows) return OPENCV_ERROR_OUT_OF_BOUNDS;
+    if (width <= 0 || height <= 0) return OPENCV_ERROR_INVALID_DIMENSIONS;
+    const int dcn = cv_channels(d->type);
+    if (kind == 2) { if (dcn != 3 && dcn != 4) return OPENCV_ERROR_INVALID_CHANNEL_COUNT; }
+    else {
+        const int scn = cv_channels(s->type);
+        if (kind == 0 && ((scn != 1 && scn != 3 && scn != 4) || (dcn != 3 && dcn != 4))) return OPENCV_ERROR_INVALID_CHANNEL_COUNT;
+        if (kind == 1 && scn != dcn && !((scn == 3 && dcn == 4) || (scn == 4 && dcn == 3) || (scn == 1 && dcn == 3) || (scn == 1 && dcn == 4)))
+            return OPENCV_ERROR_INVALID_CHANNEL_COUNT;
+        if (s->cols != width || s->rows != height) {
+            // the reference would cv::resize(INTER_LINEAR) here; ops.go:552-573 never asks for it
+            return kind == 0 ? OPENCV_ERROR_ALPHA_BLENDING_FAILED : OPENCV_ERROR_COPY_FAILED;
+        }
+    }
+    LpEngine* eng = lp_thread_engine();
+    if (!eng) return OPENCV_ERROR_UNKNOWN;
+    if (!lp_mat_to_device(d, eng)) return OPENCV_ERROR_UNKNOWN;
+    if (kind != 2 && !lp_mat_to_device(s, eng)) return OPENCV_ERROR_UNKNOWN;
+    LpCompositeOp op;
+    memset(&op, 0, sizeof(op));
+    op.dst = lp_mat_frame(d);
+    if (kind != 2) op.src = lp_mat_frame(s);
+    op.kind = (uint32_t)kind;
+    op.x0 = (uint32_t)xOffset; op.y0 = (uint32_t)yOffset; op.w = (uint32_t)width; op.h = (uint32_t)height;
+    if (eng->composite(op)) return kind == 0 ? OPENCV_ERROR_ALPHA_BLENDING_FAILED : OPENCV_ERROR_UNKNOWN;
+    // write the ROI rows back into the caller's buffer
+    const size_t es = cv_elem_size(d->type);
+    if (hipMemcpy2DAsync(d->data + (size_t)yOffset * d->step + (size_t)xOffset * es, d->step,
+                         (uint8_t*)d->dev->p + d->dev_off + (size_t)yOffset * d->dev_step + (size_t)xOffset * es, d->dev_step, (size_t)width * es,
+                         (size_t)height, hipMemcpyDeviceToHost, eng->stream()) != hipSuccess)
+        return OPENCV_ERROR_UNKNOWN;
+    if (eng->sync()) return OPENCV_ERROR_UNKNOWN;
+    return OPENCV_SUCCESS;
+}
+
+int opencv_mat_clear_to_transparent(opencv_mat mat, int xOffset, int yOffset, int width, int height) // opencv.cpp:508-543
+{
+    auto m = static_cast<LpMat*>(mat);
+    if (!m) return OPENCV_ERROR_NULL_MATRIX;
+    if (xOffset < 0 || yOffset < 0 || xOffset + width > m->cols || yOffset + height > m->rows) return OPENCV_ERROR_OUT_OF_BOUNDS;
+    if (width <= 0 || height <= 0) return OPENCV_ERROR_INVALID_DIMENSIONS;
+    return composite_common(nullptr, m, xOffset, yOffset, width, height, 2);
+}
+
+int opencv_copy_to_region_with_alpha(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height) // opencv.cpp:556-667
+{
+    return composite_common(static_cast<LpMat*>(src), static_cast<LpMat*>(dst), xOffset, yOffset, width, height, 0);
+}
+
+int opencv_copy_to_region(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height) // opencv.cpp:680-752
+{
+    return composite_common(static_cast<LpMat*>(src), static_cast<LpMat*>(dst), xOffset, yOffset, width, height, 1);
+}
+
+// ---- decoder (opencv.cpp:99-171)
+opencv_decoder opencv_decoder_create(const opencv_mat buf)
+{
+    auto m = static_cast<const LpMat*>(buf);
+    if (!m || !m->data) return NULL;
+    const size_t len = (size_t)m->cols * (size_t)m->rows * cv_elem_size(m->type);
+    // cv::findDecoder signature check: only the JPEG signature is served by this build
+    if (len < 3 || m->data[0] != 0xFF || m->data[1] != 0xD8 || m->data[2] != 0xFF) return NULL;
+    auto d = new LpDecoder();
+    d->data = m->data;
+    d->len = len;
+    return d;
+}
+
+const char* opencv_decoder_get_description(const opencv_decoder d) { return d ? "JPEG" : nullptr; }
+void opencv_decoder_release(opencv_decoder d) { delete static_cast<LpDecoder*>(d); }
+
+bool opencv_decoder_read_header(opencv_decoder dd)
+{
+    auto d = static_cast<LpDecoder*>(dd);
+    if (!d) return false;
+    if (d->parsed) return d->parse_rc == LP_PARSE_OK;
+    d->parse_rc = lp_jpeg_parse(d->data, d->len, &d->hdr);
+    d->parsed = true;
+    if (d->parse_rc == LP_PARSE_UNSUPPORTED) {
+        lp_set_error("JPEG feature outside the device path (progressive / arithmetic / CMYK / 12-bit / exotic sampling)");
+        fprintf(stderr, "lilliput_hip: %s\n", g_last_error.c_str());
+    }
+    return d->parse_rc == LP_PARSE_OK;
+}
+
+int opencv_decoder_get_width(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.width; }
+int opencv_decoder_get_height(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.height; }
+int opencv_decoder_get_pixel_type(const opencv_decoder d) { return static_cast<const LpDecoder*>(d)->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3; }
+int opencv_decoder_get_orientation(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.orientation; }
+
+bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
+{
+    auto d = static_cast<LpDecoder*>(dd);
+    auto m = static_cast<LpMat*>(dst);
+    if (!d || !m) return false;
+    if (!d->parsed && !opencv_decoder_read_header(dd)) return false;
+    if (d->parse_rc != LP_PARSE_OK) return false;
+    const LpJpeg& j = d->hdr.j;
+    const int cn = j.ncomp == 1 ? 1 : 3;
+    if (m->rows != (int)j.height || m->cols != (int)j.width || cv_channels(m->type) != cn || cv_depth_bytes(m->type) != 1) return false;
+    LpEngine* eng = lp_thread_engine();
+    if (!eng) return false;
+    if (!mat_new_dev(m)) return false;
+    LpFrame f = lp_mat_frame(m);
+    LpJpegSrc src{d->data, d->len};
+    int st = 0;
+    int rc = eng->decode_jpegs(&src, 1, &d->hdr, &f, &st);
+    if (rc || st) { lp_set_error(eng->last_error()); return false; }
+    m->dev_valid = true;
+    return lp_mat_to_host(m, eng);
+}
+
+// ---- encoder (opencv.cpp:173-194)
+opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst)
+{
+    if (!ext || !dst) return NULL;
+    std::string e(ext);
+    for (auto& c : e) c = (char)tolower(c);
+    if (e != ".jpeg" && e != ".jpg" && e != ".jpe") return NULL;
+    auto enc = new LpEncoder();
+    enc->dst = static_cast<LpMat*>(dst);
+    return enc;
+}
+
+void opencv_encoder_release(opencv_encoder e) { delete static_cast<LpEncoder*>(e); }
+
+bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* opt, size_t opt_len)
+{
+    auto e = static_cast<LpEncoder*>(ee);
+    auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
+    if (!e || !s || s->rows <= 0 || s->cols <= 0) return false;
+    int quality = 95; // cv::JpegEncoder default
+    for (size_t i = 0; i + 1 < opt_len; i += 2) {
+        if (opt[i] == CV_IMWRITE_JPEG_QUALITY) quality = opt[i + 1] < 0 ? 0 : opt[i + 1] > 100 ? 100 : opt[i + 1];
+        else if (opt[i] == CV_IMWRITE_JPEG_PROGRESSIVE && opt[i + 1]) {
+            lp_set_error("progressive JPEG output is outside the device path");
+            fprintf(stderr, "lilliput_hip: %s\n", g_last_error.c_str());
+            return false;
+        }
+    }
+    LpEngine* eng = lp_thread_engine();
+    if (!eng || !lp_mat_to_device(s, eng)) return false;
+    LpMat* d = e->dst;
+    const size_t cap = (size_t)(d->datalimit - d->datastart);
+    LpEncodeReq rq;
+    rq.src = lp_mat_frame(s);
+    rq.quality = quality;
+    rq.out_cap = (size_t)s->rows * s->cols * 4 + 4096; // device-side bound; the caller's capacity is checked below
+    int st = 0;
+    uint32_t len = 0;
+    if (eng->encode_jpegs(&rq, 1, &st, &len) || st || !len) return false;
+    if (len <= cap && d->datastart) {
+        if (eng->encoded_copy(0, d->datastart, cap)) return false;
+        d->data = d->datastart;
+    } else {
+        // cv::imencode into a too-small Mat reallocates: the data pointer changes and Go reports ErrBufTooSmall (opencv.go:890-895)
+        d->own.assign(len, 0);
+        if (eng->encoded_copy(0, d->own.data(), len)) return false;
+        d->data = d->datastart = d->own.data();
+        d->datalimit = d->data + len;
+    }
+    d->rows = (int)len; d->cols = 1; d->type = CV_8U; d->step = 1;
+    d->dev_valid = false;
+    return true;
+}
+
+} // extern "C"

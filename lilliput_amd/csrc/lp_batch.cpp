@@ -1,0 +1,321 @@
+// lp_batch.cpp -- Part B of include/lilliput_hip.h: the batched JPEG -> (orientation, Fit/Resize) -> JPEG
+// entry point. Semantics per item are those of ImageOps.Transform for a static JPEG source
+// (/root/reference/ops.go:352-479, opencv.go:326-374, 816-900); the images of a batch are independent,
+// so a multi-GPU caller simply gives each device's batch object its own shard of the items.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lp_abi.h"
+#include "lp_ops_logic.h"
+
+struct LpBatch {
+    LpEngine eng;
+    std::vector<LpJpegHeader> hdrs;
+    std::vector<int> parse_status;      // LILLIPUT_* per uploaded item
+    std::vector<int> valid;             // indices (into the item array) of successfully parsed items, upload order
+    // results of the last run, indexed like the item array
+    std::vector<int> status, out_w, out_h;
+    std::vector<uint32_t> out_len;
+    std::vector<std::vector<uint8_t>> out_bytes;   // host copies fetched during run (download hands them to the caller)
+    size_t n_items = 0;
+    explicit LpBatch(int dev) : eng(dev) {}
+};
+
+static int map_parse(int rc)
+{
+    switch (rc) {
+    case LP_PARSE_OK: return LILLIPUT_OK;
+    case LP_PARSE_UNSUPPORTED: return LILLIPUT_ERR_UNSUPPORTED;
+    default: return LILLIPUT_ERR_INVALID_IMAGE;
+    }
+}
+
+static int map_status(int st)
+{
+    switch (st) {
+    case LP_OK: return LILLIPUT_OK;
+    case LP_ERR_INVALID_IMAGE: return LILLIPUT_ERR_INVALID_IMAGE;
+    case LP_ERR_DECODE_FAILED: return LILLIPUT_ERR_DECODING_FAILED;
+    case LP_ERR_BUF_TOO_SMALL: return LILLIPUT_ERR_BUF_TOO_SMALL;
+    case LP_ERR_UNSUPPORTED: return LILLIPUT_ERR_UNSUPPORTED;
+    default: return LILLIPUT_ERR_DEVICE;
+    }
+}
+
+extern "C" {
+
+lilliput_hip_batch lilliput_hip_batch_create(int device)
+{
+    auto b = new LpBatch(device);
+    if (!b->eng.ok()) {
+        lp_set_error(b->eng.last_error());
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void lilliput_hip_batch_destroy(lilliput_hip_batch b) { delete static_cast<LpBatch*>(b); }
+
+void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C) { static_cast<LpBatch*>(bb)->eng.set_subsequence(S, C); }
+
+void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[6], int* verify_rounds)
+{
+    const LpTimings& t = static_cast<LpBatch*>(bb)->eng.timings();
+    out_ms[0] = t.unstuff_ms; out_ms[1] = t.huff_ms; out_ms[2] = t.idct_ms; out_ms[3] = t.color_ms; out_ms[4] = t.resize_ms; out_ms[5] = t.encode_ms;
+    if (verify_rounds) *verify_rounds = (int)t.verify_rounds;
+}
+
+int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b) return LILLIPUT_ERR_DEVICE;
+    b->n_items = n;
+    b->hdrs.clear();
+    b->parse_status.assign(n, LILLIPUT_OK);
+    b->valid.clear();
+    std::vector<LpJpegSrc> srcs;
+    std::vector<LpJpegHeader> hv;
+    for (size_t i = 0; i < n; i++) {
+        LpJpegHeader h;
+        int rc = (items[i].src && items[i].src_len) ? lp_jpeg_parse((const uint8_t*)items[i].src, items[i].src_len, &h) : LP_PARSE_NOT_JPEG;
+        b->parse_status[i] = map_parse(rc);
+        if (rc == LP_PARSE_OK) {
+            b->valid.push_back((int)i);
+            hv.push_back(h);
+            srcs.push_back(LpJpegSrc{(const uint8_t*)items[i].src, items[i].src_len});
+        }
+    }
+    b->hdrs.swap(hv);
+    if (b->valid.empty()) return LILLIPUT_OK;
+    int rc = b->eng.upload_jpegs(srcs.data(), (int)srcs.size(), b->hdrs.data());
+    if (rc) { lp_set_error(b->eng.last_error()); return map_status(rc); }
+    return LILLIPUT_OK;
+}
+
+int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || !opt) return LILLIPUT_ERR_DEVICE;
+    LpEngine& eng = b->eng;
+    const size_t n = b->n_items, nv = b->valid.size();
+    b->status = b->parse_status;
+    b->out_w.assign(n, 0);
+    b->out_h.assign(n, 0);
+    b->out_len.assign(n, 0);
+    b->out_bytes.assign(n, std::vector<uint8_t>());
+    if (!nv) return LILLIPUT_OK;
+    const int quality = opt->jpeg_quality > 0 ? opt->jpeg_quality : 95;
+    // chunk size: bound the working set (coefficients + planes + BGR frame ~ 7.5 B/pixel + oriented copy)
+    size_t max_px = 1;
+    for (auto& h : b->hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
+    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(24ull << 30) / (max_px * 12)));
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t rounds = 0;
+    eng.enable_timing(true);
+    for (size_t first = 0; first < nv; first += chunk) {
+        const int cnt = (int)std::min(chunk, nv - first);
+        // frame heap: decoded frame (+ oriented copy) + resized frame per image
+        size_t need = 0;
+        for (int k = 0; k < cnt; k++) {
+            const LpJpeg& j = b->hdrs[first + k].j;
+            size_t fb = (size_t)j.width * j.height * (j.ncomp == 1 ? 1 : 3);
+            need += fb + 512;
+            if (j.orientation != 1) need += fb + 512;
+            need += (size_t)std::max(1, opt->width) * std::max(1, opt->height) * 3 + 512;
+            if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) need += 0;
+        }
+        if (!eng.heap_reserve(need + 4096)) { lp_set_error("frame heap allocation failed"); return LILLIPUT_ERR_DEVICE; }
+        eng.heap_reset();
+        std::vector<LpFrame> frames((size_t)cnt);
+        std::vector<int> st((size_t)cnt, 0);
+        memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
+        int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data());
+        if (rc == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+        { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; rounds = std::max(rounds, t.verify_rounds); }
+        // orientation (ops.go:392: unconditional)
+        std::vector<LpOrientOp> oops;
+        std::vector<int> oidx;
+        for (int k = 0; k < cnt; k++) {
+            const LpJpeg& j = b->hdrs[first + k].j;
+            if (st[(size_t)k] || j.orientation == 1) continue;
+            LpOrientOp op;
+            memset(&op, 0, sizeof(op));
+            op.src = frames[(size_t)k];
+            op.orientation = j.orientation;
+            const bool swap = j.orientation >= 5;
+            op.dst = op.src;
+            op.dst.w = swap ? op.src.h : op.src.w;
+            op.dst.h = swap ? op.src.w : op.src.h;
+            op.dst.stride = op.dst.w * op.src.cn;
+            uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);
+            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            op.dst.off = (uint64_t)(uintptr_t)p;
+            oops.push_back(op);
+            oidx.push_back(k);
+        }
+        if (!oops.empty()) {
+            if (eng.orient(oops.data(), (int)oops.size())) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            for (size_t q = 0; q < oops.size(); q++) frames[(size_t)oidx[q]] = oops[q].dst;
+        }
+        // fit / resize (ops.go:449-479 + opencv.go:294-374)
+        std::vector<LpResizeReq> rqs;
+        std::vector<LpFrame> rdst;
+        std::vector<int> ridx;
+        std::vector<LpFrame> final_frames = frames;
+        for (int k = 0; k < cnt; k++) {
+            if (st[(size_t)k]) continue;
+            const LpJpeg& j = b->hdrs[first + k].j;
+            const LpFrame& f = frames[(size_t)k];
+            LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
+                                                      opt->normalize_orientation != 0, (int)f.w, (int)f.h);
+            if (!plan.resize) continue;
+            LpResizeReq rq;
+            rq.src = f;
+            rq.crop_x = (uint32_t)plan.crop_x; rq.crop_y = (uint32_t)plan.crop_y; rq.crop_w = (uint32_t)plan.crop_w; rq.crop_h = (uint32_t)plan.crop_h;
+            rq.dst_w = (uint32_t)plan.out_w; rq.dst_h = (uint32_t)plan.out_h;
+            LpFrame d;
+            memset(&d, 0, sizeof(d));
+            uint8_t* p = eng.heap_alloc((size_t)plan.out_w * plan.out_h * f.cn);
+            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            d.off = (uint64_t)(uintptr_t)p;
+            rqs.push_back(rq);
+            rdst.push_back(d);
+            ridx.push_back(k);
+        }
+        if (!rqs.empty()) {
+            std::vector<int> rst(rqs.size(), 0);
+            if (eng.resize(rqs.data(), (int)rqs.size(), rdst.data(), rst.data()) == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            acc[4] += eng.timings().resize_ms;
+            for (size_t q = 0; q < rqs.size(); q++) {
+                if (rst[q]) st[(size_t)ridx[q]] = rst[q];
+                else final_frames[(size_t)ridx[q]] = rdst[q];
+            }
+        }
+        // encode (opencv.go:872-900)
+        std::vector<LpEncodeReq> erq;
+        std::vector<int> eidx;
+        for (int k = 0; k < cnt; k++) {
+            if (st[(size_t)k]) continue;
+            LpEncodeReq e;
+            e.src = final_frames[(size_t)k];
+            e.quality = quality;
+            e.out_cap = (size_t)e.src.w * e.src.h * 4 + 4096;
+            erq.push_back(e);
+            eidx.push_back(k);
+        }
+        if (!erq.empty()) {
+            std::vector<int> est(erq.size(), 0);
+            std::vector<uint32_t> elen(erq.size(), 0);
+            if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            acc[5] += eng.timings().encode_ms;
+            if (eng.encoded_fetch_all()) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            for (size_t q = 0; q < erq.size(); q++) {
+                const int k = eidx[q];
+                const size_t item = (size_t)b->valid[first + (size_t)k];
+                if (est[q]) { st[(size_t)k] = est[q]; continue; }
+                b->out_len[item] = elen[q];
+                b->out_w[item] = (int)erq[q].src.w;
+                b->out_h[item] = (int)erq[q].src.h;
+                b->out_bytes[item].assign(eng.encoded_host((int)q), eng.encoded_host((int)q) + elen[q]);
+            }
+        }
+        for (int k = 0; k < cnt; k++) {
+            const size_t item = (size_t)b->valid[first + (size_t)k];
+            if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
+        }
+    }
+    b->eng.enable_timing(false);
+    b->eng.set_timings(LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds}); // read by lilliput_hip_batch_timings
+    return LILLIPUT_OK;
+}
+
+int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || n != b->n_items) return -1;
+    int failed = 0;
+    for (size_t i = 0; i < n; i++) {
+        items[i].status = b->status[i];
+        items[i].dst_len = 0;
+        items[i].out_width = b->out_w[i];
+        items[i].out_height = b->out_h[i];
+        if (b->status[i] == LILLIPUT_OK) {
+            if (b->out_len[i] > items[i].dst_cap || !items[i].dst) items[i].status = LILLIPUT_ERR_BUF_TOO_SMALL;
+            else {
+                memcpy(items[i].dst, b->out_bytes[i].data(), b->out_len[i]);
+                items[i].dst_len = b->out_len[i];
+            }
+        }
+        if (items[i].status) failed++;
+    }
+    return failed;
+}
+
+int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+{
+    int rc = lilliput_hip_batch_upload(b, items, n);
+    if (rc) { for (size_t i = 0; i < n; i++) { items[i].status = rc; items[i].dst_len = 0; } return (int)n; }
+    rc = lilliput_hip_batch_run(b, opt);
+    if (rc) { for (size_t i = 0; i < n; i++) { items[i].status = rc; items[i].dst_len = 0; } return (int)n; }
+    return lilliput_hip_batch_download(b, items, n);
+}
+
+// ---- stage-level access for parity tests
+static int decode_one(LpBatch* b, const void* src, size_t len, LpJpegHeader* h, LpFrame* f)
+{
+    int rc = lp_jpeg_parse((const uint8_t*)src, len, h);
+    if (rc) return map_parse(rc);
+    const LpJpeg& j = h->j;
+    size_t fb = (size_t)j.width * j.height * (j.ncomp == 1 ? 1 : 3);
+    if (!b->eng.heap_reserve(fb + 4096)) return LILLIPUT_ERR_DEVICE;
+    b->eng.heap_reset();
+    LpJpegSrc s{(const uint8_t*)src, len};
+    memset(f, 0, sizeof(*f));
+    int st = 0;
+    rc = b->eng.decode_jpegs(&s, 1, h, f, &st);
+    if (rc || st) { lp_set_error(b->eng.last_error()); return map_status(rc ? rc : st); }
+    return LILLIPUT_OK;
+}
+
+int lilliput_hip_decode_jpeg(lilliput_hip_batch bb, const void* src, size_t len, void* dst, size_t cap, int* w, int* h, int* channels, int* orientation)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    LpJpegHeader hd;
+    LpFrame f;
+    int rc = decode_one(b, src, len, &hd, &f);
+    if (rc) return rc;
+    *w = (int)f.w; *h = (int)f.h; *channels = (int)f.cn; *orientation = hd.j.orientation;
+    size_t nb = (size_t)f.stride * f.h;
+    if (nb > cap) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    if (hipMemcpyAsync(dst, (const void*)(uintptr_t)f.off, nb, hipMemcpyDeviceToHost, b->eng.stream()) != hipSuccess) return LILLIPUT_ERR_DEVICE;
+    return b->eng.sync() ? LILLIPUT_ERR_DEVICE : LILLIPUT_OK;
+}
+
+int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch bb, const void* src, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    LpJpegHeader hd;
+    LpFrame f;
+    int rc = decode_one(b, src, len, &hd, &f);
+    if (rc) return rc;
+    if (comp < 0 || comp >= hd.j.ncomp) return LILLIPUT_ERR_INVALID_IMAGE;
+    *bw = (int)hd.j.bw[comp]; *bh = (int)hd.j.bh[comp];
+    return map_status(b->eng.copy_coefs(0, comp, dst, cap_elems));
+}
+
+int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch bb, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    LpJpegHeader hd;
+    LpFrame f;
+    int rc = decode_one(b, src, len, &hd, &f);
+    if (rc) return rc;
+    if (comp < 0 || comp >= hd.j.ncomp) return LILLIPUT_ERR_INVALID_IMAGE;
+    *pw = (int)hd.j.bw[comp] * 8; *ph = (int)hd.j.bh[comp] * 8;
+    return map_status(b->eng.copy_plane(0, comp, dst, cap));
+}
+
+} // extern "C"

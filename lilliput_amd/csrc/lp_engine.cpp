@@ -1,0 +1,624 @@
+// lp_engine.cpp -- see lp_engine.h.
+#include "lp_engine.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+#include "lp_launch.h"
+
+void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
+
+// ------------------------------------------------------------------------------------------------
+LpDevBuf::~LpDevBuf() { if (p) (void)hipFree(p); }
+bool LpDevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap && p) return true;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+}
+LpPinned::~LpPinned() { if (p) (void)hipHostFree(p); }
+bool LpPinned::ensure(size_t bytes)
+{
+    if (bytes <= cap && p) return true;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+LpEngine::LpEngine(int device) : device_(device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { err_ = "no HIP device visible"; return; }
+    if (device_ < 0 || device_ >= n) { err_ = "HIP device index out of range"; return; }
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return;
+    if (!check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
+    for (auto& e : ev_)
+        if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+    ok_ = true;
+}
+
+LpEngine::~LpEngine()
+{
+    if (stream_) { (void)hipStreamSynchronize(stream_); }
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool LpEngine::check(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return true;
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    fprintf(stderr, "lilliput_hip: %s\n", err_.c_str());
+    return false;
+}
+
+int LpEngine::sync() { return check(hipStreamSynchronize(stream_), "hipStreamSynchronize") ? LP_OK : LP_ERR_DEVICE; }
+
+bool LpEngine::heap_reserve(size_t bytes)
+{
+    if (bytes <= heap_.cap) return true;
+    (void)hipStreamSynchronize(stream_);
+    heap_used_ = 0;
+    return heap_.ensure(bytes);
+}
+
+uint8_t* LpEngine::heap_alloc(size_t bytes)
+{
+    size_t off = align_up(heap_used_, 256);
+    if (off + bytes > heap_.cap) return nullptr;
+    heap_used_ = off + bytes;
+    return heap_.as<uint8_t>() + off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+static uint32_t pick_S(size_t max_ecs_bytes)
+{
+    size_t bits = max_ecs_bytes * 8;
+    if (bits >= (1u << 22)) return 16384;
+    if (bits >= (1u << 19)) return 4096;
+    if (bits >= (1u << 16)) return 1024;
+    return 256;
+}
+
+int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    h_src_.assign((size_t)n, LpJpeg());
+    h_huffs_.clear();
+    size_t raw_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        LpJpeg j = hdrs[i].j;
+        // Huffman set dedupe (most batches share one set)
+        uint32_t hi = 0;
+        for (; hi < h_huffs_.size(); hi++)
+            if (memcmp(&h_huffs_[hi], &hdrs[i].huff, sizeof(LpHuffSet)) == 0) break;
+        if (hi == h_huffs_.size()) h_huffs_.push_back(hdrs[i].huff);
+        j.huff_idx = hi;
+        j.raw_off = raw_bytes;
+        j.raw_len = (uint32_t)hdrs[i].ecs_len;
+        raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
+        j.nchunks = (j.raw_len + 4095) / 4096;
+        h_src_[(size_t)i] = j;
+    }
+    if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) || !h_stage_.ensure(raw_bytes + 64)) {
+        err_ = "device allocation failed";
+        return LP_ERR_DEVICE;
+    }
+    uint8_t* stage = h_stage_.as<uint8_t>();
+    for (int i = 0; i < n; i++) {
+        const LpJpeg& j = h_src_[(size_t)i];
+        memcpy(stage + j.raw_off, srcs[i].data + hdrs[i].ecs_off, j.raw_len);
+        memset(stage + j.raw_off + j.raw_len, 0, 32);
+    }
+    if (raw_bytes && !check(hipMemcpyAsync(d_raw_.p, stage, raw_bytes, hipMemcpyHostToDevice, stream_), "H2D raw")) return LP_ERR_DEVICE;
+    if (!h_huffs_.empty() &&
+        !check(hipMemcpyAsync(d_huffs_.p, h_huffs_.data(), sizeof(LpHuffSet) * h_huffs_.size(), hipMemcpyHostToDevice, stream_), "H2D huffs"))
+        return LP_ERR_DEVICE;
+    // the staging buffer is reused by the next upload: wait for the copies
+    if (!check(hipStreamSynchronize(stream_), "upload sync")) return LP_ERR_DEVICE;
+    return LP_OK;
+}
+
+// Lay out the working arenas for images [first, first+n) of the uploaded set and run every decode stage.
+int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    if (n <= 0 || (size_t)(first + n) > h_src_.size()) return LP_ERR_INVALID_IMAGE;
+    h_imgs_.assign(h_src_.begin() + first, h_src_.begin() + first + n);
+    size_t max_ecs = 0;
+    for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
+    S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
+    C_ = C_cfg_ ? C_cfg_ : std::max<uint32_t>(32, S_ / LP_MAX_CKPT);
+    K_ = S_ / C_;
+    if (K_ > LP_MAX_CKPT || K_ == 0 || S_ % 32 || S_ < 64) { err_ = "bad subsequence configuration"; return LP_ERR_DEVICE; }
+    size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
+    tot_sub_ = tot_chunks_ = tot_rst_ = 0;
+    max_chunks_ = max_sub_ = max_tiles_ = max_w_ = max_h_ = 0;
+    for (auto& j : h_imgs_) {
+        j.chunk_off = tot_chunks_;
+        tot_chunks_ += j.nchunks;
+        j.clean_off = clean_words;
+        j.clean_cap_words = j.raw_len / 4 + 32;
+        clean_words += j.clean_cap_words;
+        j.sub_off = tot_sub_;
+        j.sub_cap = (uint32_t)(((uint64_t)j.raw_len * 8 + S_ - 1) / S_) + 1;
+        tot_sub_ += j.sub_cap;
+        j.rst_off = tot_rst_;
+        j.rst_cap = j.dri ? (j.mcus_x * j.mcus_y + j.dri - 1) / j.dri + 2 : 2;
+        tot_rst_ += j.rst_cap;
+        for (int c = 0; c < j.ncomp; c++) {
+            j.coef_off[c] = coef_elems;
+            coef_elems += (size_t)j.bw[c] * j.bh[c] * 64;
+            j.plane_off[c] = plane_bytes;
+            plane_bytes = align_up(plane_bytes + (size_t)j.bw[c] * 8 * j.bh[c] * 8, 16);
+            max_tiles_ = std::max(max_tiles_, (j.bw[c] + 7) / 8 * j.bh[c]);
+        }
+        max_chunks_ = std::max(max_chunks_, j.nchunks);
+        max_sub_ = std::max(max_sub_, j.sub_cap);
+        max_w_ = std::max(max_w_, j.width);
+        max_h_ = std::max(max_h_, j.height);
+    }
+    bool a = d_imgs_.ensure(sizeof(LpJpeg) * (size_t)n) && d_states_.ensure(sizeof(LpJpegState) * (size_t)n) && d_clean_.ensure(clean_words * 4 + 64) &&
+             d_rst_.ensure((size_t)tot_rst_ * 4 + 64) && d_chunk_.ensure((size_t)tot_chunks_ * 8 + 64) &&
+             d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkpt) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
+             d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems * 2 + 64) &&
+             d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
+             h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
+    if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    if (!check(hipMemcpyAsync(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D imgs")) return LP_ERR_DEVICE;
+    const LpJpeg* di = d_imgs_.as<LpJpeg>();
+    LpJpegState* ds = d_states_.as<LpJpegState>();
+    if (!check(hipMemsetAsync(ds, 0, sizeof(LpJpegState) * (size_t)n, stream_), "memset states")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[0], stream_);
+    lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
+                      d_rst_.as<uint32_t>(), S_);
+    if (timing_) (void)hipEventRecord(ev_[1], stream_);
+    lp_launch_huff_count(stream_, false, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
+                         d_ckpt_.as<LpCkpt>(), d_exit_.as<LpSubState>(), d_entry_.as<LpSubState>(), d_tot_.as<LpSubSum>(), d_changed_.as<uint32_t>(),
+                         S_, C_, K_);
+    uint32_t rounds = 0;
+    uint32_t* h_changed = h_small_.as<uint32_t>();
+    for (;;) {
+        if (!check(hipMemsetAsync(d_changed_.p, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
+        lp_launch_huff_count(stream_, true, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
+                             d_ckpt_.as<LpCkpt>(), d_exit_.as<LpSubState>(), d_entry_.as<LpSubState>(), d_tot_.as<LpSubSum>(),
+                             d_changed_.as<uint32_t>(), S_, C_, K_);
+        if (!check(hipMemcpyAsync(h_changed, d_changed_.p, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
+        if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
+        rounds++;
+        if (*h_changed == 0 || rounds >= 4096) break;
+    }
+    tm_.verify_rounds = rounds;
+    lp_launch_sub_scan(stream_, di, ds, (uint32_t)n, d_tot_.as<LpSubSum>(), d_prefix_.as<LpSubSum>());
+    lp_launch_huff_write(stream_, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
+                         d_exit_.as<LpSubState>(), d_prefix_.as<LpSubSum>(), d_coef_.as<int16_t>());
+    if (timing_) (void)hipEventRecord(ev_[2], stream_);
+    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int16_t>(), d_planes_.as<uint8_t>());
+    if (timing_) (void)hipEventRecord(ev_[3], stream_);
+    // frames
+    for (int i = 0; i < n; i++) {
+        const LpJpeg& j = h_imgs_[(size_t)i];
+        LpFrame& f = frames[i];
+        f.w = j.width; f.h = j.height; f.cn = j.ncomp == 1 ? 1 : 3; f.stride = f.w * f.cn;
+        if (!f.off) {
+            uint8_t* p = heap_alloc((size_t)f.stride * f.h);
+            if (!p) { err_ = "frame heap exhausted"; return LP_ERR_DEVICE; }
+            f.off = (uint64_t)(uintptr_t)p;
+        }
+    }
+    if (!check(hipMemcpyAsync(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D frames")) return LP_ERR_DEVICE;
+    lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
+    if (timing_) (void)hipEventRecord(ev_[4], stream_);
+    h_states_.resize((size_t)n);
+    if (!check(hipMemcpyAsync(h_small_.p, ds, sizeof(LpJpegState) * (size_t)n, hipMemcpyDeviceToHost, stream_), "D2H states")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "decode sync")) return LP_ERR_DEVICE;
+    if (!check(hipGetLastError(), "decode kernels")) return LP_ERR_DEVICE;
+    memcpy(h_states_.data(), h_small_.p, sizeof(LpJpegState) * (size_t)n);
+    int rc = LP_OK;
+    for (int i = 0; i < n; i++) {
+        status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
+        if (status[i]) rc = status[i];
+    }
+    if (timing_) {
+        (void)hipEventElapsedTime(&tm_.unstuff_ms, ev_[0], ev_[1]);
+        (void)hipEventElapsedTime(&tm_.huff_ms, ev_[1], ev_[2]);
+        (void)hipEventElapsedTime(&tm_.idct_ms, ev_[2], ev_[3]);
+        (void)hipEventElapsedTime(&tm_.color_ms, ev_[3], ev_[4]);
+    }
+    return rc;
+}
+
+int LpEngine::decode_uploaded(int first, int n, LpFrame* frames, int* status) { return run_decode(first, n, frames, status); }
+
+int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
+{
+    const LpJpeg& j = h_imgs_[(size_t)i];
+    size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
+    if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
+    if (!check(hipMemcpyAsync(dst, d_coef_.as<int16_t>() + j.coef_off[comp], ne * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
+    return sync();
+}
+
+int LpEngine::copy_plane(int i, int comp, uint8_t* dst, size_t cap)
+{
+    const LpJpeg& j = h_imgs_[(size_t)i];
+    size_t nb = (size_t)j.bw[comp] * 8 * j.bh[comp] * 8;
+    if (nb > cap) return LP_ERR_BUF_TOO_SMALL;
+    if (!check(hipMemcpyAsync(dst, d_planes_.as<uint8_t>() + j.plane_off[comp], nb, hipMemcpyDeviceToHost, stream_), "D2H plane")) return LP_ERR_DEVICE;
+    return sync();
+}
+
+int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs, LpFrame* frames, int* status)
+{
+    int rc = upload_jpegs(srcs, n, hdrs);
+    if (rc) return rc;
+    return run_decode(0, n, frames, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation / resize / composite
+int LpEngine::orient(const LpOrientOp* ops, int n)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    if (!d_ops_.ensure(std::max(sizeof(LpOrientOp), sizeof(LpResizeOp)) * (size_t)n)) return LP_ERR_DEVICE;
+    uint32_t mw = 0, mh = 0;
+    for (int i = 0; i < n; i++) { mw = std::max(mw, std::max(ops[i].src.w, ops[i].src.h)); mh = mw; }
+    if (!check(hipMemcpyAsync(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D orient ops")) return LP_ERR_DEVICE;
+    // the op array is pageable host memory: make sure the copy has been consumed before the caller frees it
+    lp_launch_orient(stream_, d_ops_.as<LpOrientOp>(), (uint32_t)n, mw, mh, nullptr, nullptr);
+    if (!check(hipStreamSynchronize(stream_), "orient sync")) return LP_ERR_DEVICE;
+    return check(hipGetLastError(), "orient kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
+int lp_resize_mode(int sw, int sh, int dw, int dh, int* iscale_x, int* iscale_y)
+{
+    // cv::resize (modules/imgproc/src/resize.cpp): dsize == ssize -> copyTo; INTER_AREA with both scales >= 1 ->
+    // integer scales: resizeAreaFast_, else resizeArea_; otherwise bilinear with area-style coefficients.
+    *iscale_x = *iscale_y = 1;
+    if (sw == dw && sh == dh) return 0;
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    if (scale_x >= 1 && scale_y >= 1) {
+        int ix = (int)lrint(scale_x), iy = (int)lrint(scale_y);
+        *iscale_x = ix; *iscale_y = iy;
+        bool fast = fabs(scale_x - ix) < DBL_EPSILON && fabs(scale_y - iy) < DBL_EPSILON;
+        return fast ? 1 : 2;
+    }
+    return 3;
+}
+
+int lp_area_tab(int ssize, int dsize, std::vector<LpTap>& taps, std::vector<uint32_t>& ranges)
+{
+    // resize.cpp computeResizeAreaTab; ranges[dx]..ranges[dx+1] index the taps of destination dx
+    double scale = 1. / ((double)dsize / ssize);
+    const uint32_t base = (uint32_t)taps.size();
+    for (int dx = 0; dx < dsize; dx++) {
+        ranges.push_back((uint32_t)taps.size() - base);
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) taps.push_back(LpTap{(uint32_t)(sx1 - 1), (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; sx++) taps.push_back(LpTap{(uint32_t)sx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) taps.push_back(LpTap{(uint32_t)sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)});
+    }
+    ranges.push_back((uint32_t)taps.size() - base);
+    return (int)(taps.size() - base);
+}
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+
+int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    std::vector<LpResizeOp> ops((size_t)n);
+    std::vector<LpTap> taps;
+    std::vector<uint32_t> ranges;
+    std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> cache; // (ssize,dsize) -> (tap_off, range_off)
+    uint32_t modes = 0, mdw = 0, mdh = 0;
+    for (int i = 0; i < n; i++) {
+        const LpResizeReq& r = reqs[i];
+        LpResizeOp& op = ops[(size_t)i];
+        memset(&op, 0, sizeof(op));
+        status[i] = LP_OK;
+        if (r.crop_w == 0 || r.crop_h == 0 || r.crop_x + r.crop_w > r.src.w || r.crop_y + r.crop_h > r.src.h || r.dst_w == 0 || r.dst_h == 0) {
+            status[i] = LP_ERR_INVALID_IMAGE;
+            op.mode = 99;
+            continue;
+        }
+        op.src = r.src;
+        op.src.off += (uint64_t)r.crop_y * r.src.stride + (uint64_t)r.crop_x * r.src.cn;
+        op.src.w = r.crop_w; op.src.h = r.crop_h;
+        op.dst = dsts[i];
+        op.dst.w = r.dst_w; op.dst.h = r.dst_h; op.dst.cn = r.src.cn;
+        if (!op.dst.stride) op.dst.stride = r.dst_w * r.src.cn;
+        dsts[i] = op.dst;
+        int ix, iy;
+        op.mode = (uint32_t)lp_resize_mode((int)r.crop_w, (int)r.crop_h, (int)r.dst_w, (int)r.dst_h, &ix, &iy);
+        op.iscale_x = (uint32_t)ix; op.iscale_y = (uint32_t)iy;
+        op.inv_area = 1.f / (float)(ix * iy);
+        if (op.mode == 2) {
+            auto kx = std::make_pair((int)r.crop_w, (int)r.dst_w), ky = std::make_pair((int)r.crop_h, (int)r.dst_h);
+            for (int ax = 0; ax < 2; ax++) {
+                auto key = ax ? ky : kx;
+                auto it = cache.find(key);
+                if (it == cache.end()) {
+                    uint32_t to = (uint32_t)taps.size(), ro = (uint32_t)ranges.size();
+                    lp_area_tab(key.first, key.second, taps, ranges);
+                    it = cache.emplace(key, std::make_pair(to, ro)).first;
+                }
+                if (ax) { op.ytab_off = it->second.first; op.yrange_off = it->second.second; }
+                else { op.xtab_off = it->second.first; op.xrange_off = it->second.second; }
+            }
+        } else if (op.mode == 3) {
+            // resizeGeneric_ tables for INTER_AREA with an up-scaling axis (area_mode coefficients, 11-bit fixed point)
+            double inv_x = (double)r.dst_w / r.crop_w, inv_y = (double)r.dst_h / r.crop_h, sc_x = 1. / inv_x, sc_y = 1. / inv_y;
+            op.xrange_off = (uint32_t)ranges.size();
+            uint32_t xmax = r.dst_w;
+            for (uint32_t dx = 0; dx < r.dst_w; dx++) {
+                int sx = (int)floor(dx * sc_x);
+                float fx = (float)((dx + 1) - (sx + 1) * inv_x);
+                fx = fx <= 0 ? 0.f : fx - floorf(fx);
+                if (sx + 1 >= (int)r.crop_w) {
+                    xmax = std::min(xmax, dx);
+                    if (sx >= (int)r.crop_w - 1) { fx = 0; sx = (int)r.crop_w - 1; }
+                }
+                ranges.push_back((uint32_t)sx);
+                ranges.push_back((uint32_t)(int32_t)(short)cv_round_f((1.f - fx) * 2048));
+                ranges.push_back((uint32_t)(int32_t)(short)cv_round_f(fx * 2048));
+            }
+            op.xmax = xmax;
+            op.yrange_off = (uint32_t)ranges.size();
+            for (uint32_t dy = 0; dy < r.dst_h; dy++) {
+                int sy = (int)floor(dy * sc_y);
+                float fy = (float)((dy + 1) - (sy + 1) * inv_y);
+                fy = fy <= 0 ? 0.f : fy - floorf(fy);
+                ranges.push_back((uint32_t)sy);
+                ranges.push_back((uint32_t)(int32_t)(short)cv_round_f((1.f - fy) * 2048));
+                ranges.push_back((uint32_t)(int32_t)(short)cv_round_f(fy * 2048));
+            }
+        }
+        modes |= 1u << op.mode;
+        mdw = std::max(mdw, r.dst_w);
+        mdh = std::max(mdh, r.dst_h);
+    }
+    if (!d_ops_.ensure(sizeof(LpResizeOp) * (size_t)n) || !d_taps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_ranges_.ensure(4 * ranges.size() + 64))
+        return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D resize ops")) return LP_ERR_DEVICE;
+    if (!taps.empty() && !check(hipMemcpyAsync(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size(), hipMemcpyHostToDevice, stream_), "H2D taps"))
+        return LP_ERR_DEVICE;
+    if (!ranges.empty() && !check(hipMemcpyAsync(d_ranges_.p, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, stream_), "H2D ranges"))
+        return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
+    if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    if (!check(hipStreamSynchronize(stream_), "resize sync")) return LP_ERR_DEVICE;
+    if (!check(hipGetLastError(), "resize kernels")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);
+    return LP_OK;
+}
+
+int LpEngine::composite(const LpCompositeOp& op)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    lp_launch_composite(stream_, op, nullptr, nullptr);
+    if (!check(hipStreamSynchronize(stream_), "composite sync")) return LP_ERR_DEVICE;
+    return check(hipGetLastError(), "composite kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode
+static const uint8_t kStdLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+                                      69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55, 64,
+                                      81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const uint8_t kStdChromaQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                        99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                        99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+static const uint8_t kZig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+// T.81 Annex K.3 typical Huffman tables (jstdhuff.c)
+static const uint8_t kBits[4][17] = {{0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},
+                                     {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d},
+                                     {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},
+                                     {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};
+static const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kAcLuma[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+static const uint8_t kAcChroma[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+static void quant_table(int quality, const uint8_t* std_tbl, uint16_t* q)
+{
+    // jcparam.c jpeg_set_quality(q, TRUE): jpeg_quality_scaling + jpeg_add_quant_table(force_baseline)
+    if (quality <= 0) quality = 1;
+    if (quality > 100) quality = 100;
+    int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int i = 0; i < 64; i++) {
+        long t = ((long)std_tbl[i] * scale + 50L) / 100L;
+        if (t <= 0) t = 1;
+        if (t > 255) t = 255;
+        q[i] = (uint16_t)t;
+    }
+}
+
+size_t lp_build_jpeg_header(int W, int H, int ncomp, int quality, uint8_t* o, uint16_t qt[2][64])
+{
+    quant_table(quality, kStdLumaQ, qt[0]);
+    quant_table(quality, kStdChromaQ, qt[1]);
+    size_t n = 0;
+    auto b = [&](int v) { o[n++] = (uint8_t)v; };
+    auto w = [&](int v) { o[n++] = (uint8_t)(v >> 8); o[n++] = (uint8_t)v; };
+    b(0xFF); b(0xD8);
+    b(0xFF); b(0xE0); w(16); b('J'); b('F'); b('I'); b('F'); b(0); b(1); b(1); b(0); w(1); w(1); b(0); b(0);
+    for (int t = 0; t < (ncomp == 1 ? 1 : 2); t++) {
+        b(0xFF); b(0xDB); w(67); b(t);
+        for (int z = 0; z < 64; z++) b(qt[t][kZig[z]]);
+    }
+    b(0xFF); b(0xC0); w(8 + 3 * ncomp); b(8); w(H); w(W); b(ncomp);
+    if (ncomp == 1) { b(1); b(0x11); b(0); }
+    else { b(1); b(0x22); b(0); b(2); b(0x11); b(1); b(3); b(0x11); b(1); }
+    auto dht = [&](int id, const uint8_t* bits, const uint8_t* vals) {
+        int tot = 0;
+        for (int l = 1; l <= 16; l++) tot += bits[l];
+        b(0xFF); b(0xC4); w(19 + tot); b(id);
+        for (int l = 1; l <= 16; l++) b(bits[l]);
+        for (int i = 0; i < tot; i++) b(vals[i]);
+    };
+    dht(0x00, kBits[0], kDcVals);
+    dht(0x10, kBits[1], kAcLuma);
+    if (ncomp == 3) { dht(0x01, kBits[2], kDcVals); dht(0x11, kBits[3], kAcChroma); }
+    b(0xFF); b(0xDA); w(6 + 2 * ncomp); b(ncomp); b(1); b(0x00);
+    if (ncomp == 3) { b(2); b(0x11); b(3); b(0x11); }
+    b(0); b(63); b(0);
+    return n;
+}
+
+void lp_encode_init_tables()
+{
+    uint16_t code[4][256];
+    uint8_t len[4][256];
+    memset(code, 0, sizeof(code));
+    memset(len, 0, sizeof(len));
+    const uint8_t* vals[4] = {kDcVals, kAcLuma, kDcVals, kAcChroma};
+    for (int t = 0; t < 4; t++) {
+        int c = 0, k = 0;
+        for (int l = 1; l <= 16; l++) {
+            for (int i = 0; i < kBits[t][l]; i++, k++, c++) { code[t][vals[t][k]] = (uint16_t)c; len[t][vals[t][k]] = (uint8_t)l; }
+            c <<= 1;
+        }
+    }
+    lp_encode_upload_tables(code, len);
+}
+
+int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t* out_len)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    if (!enc_tables_ready_) { lp_encode_init_tables(); enc_tables_ready_ = true; }
+    h_jobs_.assign((size_t)n, LpEncJob());
+    std::vector<uint8_t> hdrs;
+    size_t coef_elems = 0, bits_words = 0, out_bytes = 0;
+    uint32_t tot_blocks = 0, max_blocks = 0;
+    for (int i = 0; i < n; i++) {
+        LpEncJob& j = h_jobs_[(size_t)i];
+        memset(&j, 0, sizeof(j));
+        const LpEncodeReq& r = reqs[i];
+        status[i] = LP_OK;
+        out_len[i] = 0;
+        if (r.src.w == 0 || r.src.h == 0 || r.src.w > 65535 || r.src.h > 65535 || (r.src.cn != 1 && r.src.cn != 3 && r.src.cn != 4)) {
+            status[i] = LP_ERR_INVALID_IMAGE;
+            continue; // total_blocks == 0: every kernel skips the job
+        }
+        j.src = r.src;
+        j.ncomp = r.src.cn == 1 ? 1 : 3;
+        const uint32_t mcu = j.ncomp == 1 ? 8 : 16;
+        j.mcus_x = (r.src.w + mcu - 1) / mcu;
+        j.mcus_y = (r.src.h + mcu - 1) / mcu;
+        j.bpm = j.ncomp == 1 ? 1 : 6;
+        j.total_blocks = j.mcus_x * j.mcus_y * j.bpm;
+        j.wib = (r.src.w + 7) / 8;
+        j.hib = (r.src.h + 7) / 8;
+        j.blk_off = tot_blocks;
+        tot_blocks += j.total_blocks;
+        max_blocks = std::max(max_blocks, j.total_blocks);
+        j.coef_off = coef_elems;
+        coef_elems += (size_t)j.total_blocks * 64;
+        uint8_t hb[1024];
+        j.hdr_off = (uint32_t)hdrs.size();
+        j.hdr_len = (uint32_t)lp_build_jpeg_header((int)r.src.w, (int)r.src.h, (int)j.ncomp, r.quality, hb, j.qt);
+        hdrs.insert(hdrs.end(), hb, hb + j.hdr_len);
+        size_t cap = std::min<size_t>(r.out_cap, (size_t)j.total_blocks * 448 + 4096);
+        j.out_cap = (uint32_t)std::min<size_t>(cap, 0xfffffff0u);
+        j.out_off = out_bytes;
+        out_bytes = align_up(out_bytes + j.out_cap, 16);
+        j.bits_off = bits_words;
+        j.bits_cap_words = (uint32_t)std::min<size_t>((size_t)j.total_blocks * 54 + 16, (size_t)j.out_cap / 4 + 16);
+        bits_words += j.bits_cap_words;
+    }
+    h_estates_.assign((size_t)n, LpEncState());
+    if (!d_jobs_.ensure(sizeof(LpEncJob) * (size_t)n) || !d_estates_.ensure(sizeof(LpEncState) * (size_t)n) || !d_ecoef_.ensure(coef_elems * 2 + 64) ||
+        !d_blkbits_.ensure((size_t)tot_blocks * 4 + 64) || !d_bits_.ensure(bits_words * 4 + 64) || !d_hdrs_.ensure(hdrs.size() + 64) ||
+        !d_out_.ensure(out_bytes + 64) || !h_small_.ensure(std::max<size_t>(4096, sizeof(LpEncState) * (size_t)n)))
+        return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(d_jobs_.p, h_jobs_.data(), sizeof(LpEncJob) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D enc jobs")) return LP_ERR_DEVICE;
+    if (!hdrs.empty() && !check(hipMemcpyAsync(d_hdrs_.p, hdrs.data(), hdrs.size(), hipMemcpyHostToDevice, stream_), "H2D hdrs")) return LP_ERR_DEVICE;
+    if (!check(hipMemsetAsync(d_bits_.p, 0, bits_words * 4 + 64, stream_), "memset bits")) return LP_ERR_DEVICE;
+    if (!check(hipMemsetAsync(d_estates_.p, 0, sizeof(LpEncState) * (size_t)n, stream_), "memset enc states")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
+                     d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
+    if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    if (!check(hipMemcpyAsync(h_small_.p, d_estates_.p, sizeof(LpEncState) * (size_t)n, hipMemcpyDeviceToHost, stream_), "D2H enc states")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "encode sync")) return LP_ERR_DEVICE;
+    if (!check(hipGetLastError(), "encode kernels")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventElapsedTime(&tm_.encode_ms, ev_[5], ev_[6]);
+    memcpy(h_estates_.data(), h_small_.p, sizeof(LpEncState) * (size_t)n);
+    int rc = LP_OK;
+    for (int i = 0; i < n; i++) {
+        if (status[i]) { rc = status[i]; continue; }
+        const LpEncState& st = h_estates_[(size_t)i];
+        if (st.error || st.out_len == 0) { status[i] = LP_ERR_BUF_TOO_SMALL; rc = status[i]; continue; }
+        out_len[i] = st.out_len;
+    }
+    return rc;
+}
+
+const uint8_t* LpEngine::encoded_device_ptr(int i) const { return d_out_.as<uint8_t>() + h_jobs_[(size_t)i].out_off; }
+
+int LpEngine::encoded_copy(int i, uint8_t* dst, size_t cap)
+{
+    const uint32_t len = h_estates_[(size_t)i].out_len;
+    if (len == 0 || len > cap) return LP_ERR_BUF_TOO_SMALL;
+    if (!check(hipMemcpyAsync(dst, encoded_device_ptr(i), len, hipMemcpyDeviceToHost, stream_), "D2H jpeg")) return LP_ERR_DEVICE;
+    return sync();
+}
+
+int LpEngine::encoded_fetch_all()
+{
+    size_t total = 0;
+    h_out_off_.assign(h_jobs_.size(), 0);
+    for (size_t i = 0; i < h_jobs_.size(); i++) { h_out_off_[i] = total; total += align_up(h_estates_[i].out_len, 16); }
+    if (!h_out_.ensure(total + 64)) return LP_ERR_DEVICE;
+    for (size_t i = 0; i < h_jobs_.size(); i++) {
+        const uint32_t len = h_estates_[i].out_len;
+        if (!len) continue;
+        if (!check(hipMemcpyAsync(h_out_.as<uint8_t>() + h_out_off_[i], encoded_device_ptr((int)i), len, hipMemcpyDeviceToHost, stream_), "D2H jpeg"))
+            return LP_ERR_DEVICE;
+    }
+    return sync();
+}

@@ -1,0 +1,462 @@
+// lp_kernels_decode.hip -- gfx950 kernels for the JPEG decode half of ImageOps.Transform:
+//   unstuff (FF00 / RSTn removal + restart boundary list)  -> k_unstuff_{count,scan,scatter}
+//   Huffman entropy decode (S1)                             -> k_huff_count<VERIFY>, k_sub_scan, k_huff_write
+//   dequantise + 8x8 islow IDCT (S2)                        -> k_idct
+// Replaces the libjpeg-turbo work behind opencv_decoder_read_data (/root/reference/opencv.cpp:166-171).
+// All kernels are batched: blockIdx.y (or .z) selects the image, per-image descriptors live in HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lp_huff_core.h"
+#include "lp_launch.h"
+#include "lp_types.h"
+
+#define UNSTUFF_T 256
+#define UNSTUFF_CHUNK 4096 // bytes per workgroup, 16 per thread
+
+// ------------------------------------------------------------------------------------------------
+// block-wide helpers (256 threads = 4 waves of 64)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of a packed pair (lo 20 bits / hi 12 bits are enough for 16 B per thread, but we keep two words)
+__device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t& ea, uint32_t& eb, uint32_t& ta, uint32_t& tb,
+                                                 uint32_t* s_tmp /* >= 8 words */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    if (lane == 63) { s_tmp[wv] = ia; s_tmp[4 + wv] = ib; }
+    __syncthreads();
+    uint32_t oa = 0, ob = 0;
+    ta = 0; tb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t xa = s_tmp[w], xb = s_tmp[4 + w];
+        if (w < wv) { oa += xa; ob += xb; }
+        ta += xa; tb += xb;
+    }
+    ea = oa + ia - a;
+    eb = ob + ib - b;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Unstuffing. Byte classes inside the entropy-coded segment (T.81 B.1.1.5, F.1.2.3; libjpeg jdhuff.c
+// jpeg_fill_bit_buffer): data byte; FF followed by 00 = data FF (00 dropped); FF FF.. = fill; FF Dn = RSTn.
+struct UnstuffBytes {
+    uint32_t w[4];      // 16 raw bytes
+    uint32_t prev, next; // neighbours
+};
+
+__device__ __forceinline__ void unstuff_classify(const UnstuffBytes& u, uint32_t pos0, uint32_t raw_len, uint32_t& keep_mask,
+                                                 uint32_t& rst_mask, uint32_t& err)
+{
+    keep_mask = 0; rst_mask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
+        uint32_t pv = j == 0 ? u.prev : (u.w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFF;
+        uint32_t nx = j == 15 ? u.next : (u.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFF;
+        bool in = pos0 + j < raw_len;
+        if (pos0 + j + 1 >= raw_len) nx = 0xD9; // nothing follows the last byte
+        bool keep, rst = false;
+        if (c == 0xFF) keep = (nx == 0x00);
+        else if (pv == 0xFF) {
+            keep = false;
+            rst = (c >= 0xD0 && c <= 0xD7);
+            if (in && c != 0 && !rst) err |= 1u; // a real marker inside the scan
+        } else keep = true;
+        if (in && keep) keep_mask |= 1u << j;
+        if (in && rst) rst_mask |= 1u << j;
+    }
+}
+
+__device__ __forceinline__ void unstuff_load(const uint8_t* raw, uint32_t raw_len, uint32_t pos0, UnstuffBytes& u, uint32_t* s_edge)
+{
+    // raw is 16-byte aligned and the arena is padded, so the vector load is always in bounds.
+    uint4 v = *reinterpret_cast<const uint4*>(raw + pos0);
+    u.w[0] = v.x; u.w[1] = v.y; u.w[2] = v.z; u.w[3] = v.w;
+    const int t = threadIdx.x;
+    s_edge[1 + t] = v.x & 0xFF;             // first byte of thread t
+    s_edge[1 + UNSTUFF_T + 1 + t] = v.w >> 24; // last byte of thread t
+    if (t == 0) {
+        uint32_t base = pos0;
+        s_edge[0] = base ? raw[base - 1] : 0;                                        // prev of the chunk
+        uint32_t e = base + UNSTUFF_CHUNK;
+        s_edge[1 + UNSTUFF_T] = e < raw_len ? raw[e] : 0xD9;                          // next of the chunk
+    }
+    __syncthreads();
+    u.prev = t == 0 ? s_edge[0] : s_edge[1 + UNSTUFF_T + 1 + t - 1];
+    u.next = t == UNSTUFF_T - 1 ? s_edge[1 + UNSTUFF_T] : s_edge[1 + t + 1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
+                                                             uint2* __restrict__ chunk_cnt, LpJpegState* __restrict__ states)
+{
+    __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
+    __shared__ uint32_t s_tmp[8];
+    const LpJpeg& img = imgs[blockIdx.y];
+    if (blockIdx.x >= img.nchunks) return;
+    const uint8_t* raw = raw_arena + img.raw_off;
+    uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
+    UnstuffBytes u;
+    unstuff_load(raw, img.raw_len, pos0 - threadIdx.x * 16 + threadIdx.x * 16, u, s_edge);
+    uint32_t km, rm, err = 0;
+    unstuff_classify(u, pos0, img.raw_len, km, rm, err);
+    uint32_t ea, eb, ta, tb;
+    block_excl_scan2(__popc(km), __popc(rm), ea, eb, ta, tb, s_tmp);
+    if (threadIdx.x == 0) chunk_cnt[img.chunk_off + blockIdx.x] = make_uint2(ta, tb);
+    if (err) atomicOr(&states[blockIdx.y].error, err);
+}
+
+// One workgroup per image: exclusive scan of the chunk counts (in place), totals -> state.
+__global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__ imgs, uint2* __restrict__ chunk_cnt,
+                                                      LpJpegState* __restrict__ states, uint32_t* __restrict__ clean_arena, uint32_t S)
+{
+    __shared__ uint32_t s_a[256], s_b[256];
+    const LpJpeg& img = imgs[blockIdx.x];
+    uint2* cc = chunk_cnt + img.chunk_off;
+    const uint32_t n = img.nchunks, t = threadIdx.x;
+    const uint32_t per = (n + 255) / 256;
+    uint32_t b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t i = b0; i < b1; i++) { uint2 v = cc[i]; sa += v.x; sb += v.y; }
+    s_a[t] = sa; s_b[t] = sb;
+    __syncthreads();
+    uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t xa = s_a[i], xb = s_b[i];
+        if (i < t) { oa += xa; ob += xb; }
+        ta += xa; tb += xb;
+    }
+    for (uint32_t i = b0; i < b1; i++) { uint2 v = cc[i]; cc[i] = make_uint2(oa, ob); oa += v.x; ob += v.y; }
+    if (t == 0) {
+        LpJpegState& st = states[blockIdx.x];
+        st.clean_bytes = ta;
+        st.n_rst = tb < img.rst_cap ? tb : img.rst_cap;
+        if (tb > img.rst_cap) st.error |= 4u;
+        uint64_t bits = (uint64_t)ta * 8;
+        st.nsub = (uint32_t)((bits + S - 1) / S);
+    }
+    // zero the tail words so that reads past the end of the stream are deterministic
+    if (t < 12) {
+        uint32_t w = (ta >> 2) + t;
+        if (w < img.clean_cap_words) clean_arena[img.clean_off + w] = 0;
+    }
+}
+
+__global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
+                                                               const uint2* __restrict__ chunk_cnt, uint32_t* __restrict__ clean_arena,
+                                                               uint32_t* __restrict__ rst_bits)
+{
+    __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
+    __shared__ uint32_t s_tmp[8];
+    const LpJpeg& img = imgs[blockIdx.y];
+    if (blockIdx.x >= img.nchunks) return;
+    const uint8_t* raw = raw_arena + img.raw_off;
+    uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
+    UnstuffBytes u;
+    unstuff_load(raw, img.raw_len, pos0, u, s_edge);
+    uint32_t km, rm, err = 0;
+    unstuff_classify(u, pos0, img.raw_len, km, rm, err);
+    uint32_t ea, eb, ta, tb;
+    block_excl_scan2(__popc(km), __popc(rm), ea, eb, ta, tb, s_tmp);
+    uint2 base = chunk_cnt[img.chunk_off + blockIdx.x];
+    uint32_t cpos = base.x + ea, rpos = base.y + eb;
+    uint8_t* out = reinterpret_cast<uint8_t*>(clean_arena + img.clean_off);
+    const uint32_t cap = img.clean_cap_words * 4;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (rm & (1u << j)) {
+            if (rpos < img.rst_cap) rst_bits[img.rst_off + rpos] = cpos * 8;
+            rpos++;
+        }
+        if (km & (1u << j)) {
+            uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            if (cpos < cap) out[cpos ^ 3] = (uint8_t)c; // big-endian words: bit 31 of word 0 is the first bit of the stream
+            cpos++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Huffman decode
+struct DevMem {
+    const uint32_t* words;
+    const LpHuffSet* hs; // LDS
+    const uint32_t* rst;
+    __device__ __forceinline__ uint32_t word(uint32_t w) const { return words[w]; }
+    __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
+    __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
+    __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
+    __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
+    __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
+};
+
+__device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
+{
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(LpHuffSet) / 4; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
+template <bool VERIFY>
+__global__ __launch_bounds__(256) void k_huff_count(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                    const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                    const uint32_t* __restrict__ rst_bits, LpCkpt* __restrict__ ckpts,
+                                                    LpSubState* exits, LpSubState* __restrict__ entry_used, LpSubSum* __restrict__ totals,
+                                                    uint32_t* __restrict__ changed, uint32_t S, uint32_t C, uint32_t K)
+{
+    __shared__ LpHuffSet s_hs;
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub;
+    if (blockIdx.x * 256 >= nsub) return;
+    stage_huff(&s_hs, huffs + img.huff_idx);
+    const uint32_t sub = blockIdx.x * 256 + threadIdx.x;
+    if (sub >= nsub || sub >= img.sub_cap) return;
+    if (VERIFY && sub == 0) return;
+    const uint32_t g = img.sub_off + sub;
+    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off};
+    LpSubState entry;
+    if (VERIFY) {
+        uint64_t raw = *reinterpret_cast<const volatile uint64_t*>(&exits[g - 1]);
+        entry.p = (uint32_t)raw;
+        entry.bz = (uint32_t)(raw >> 32);
+        if (lp_state_eq(entry, entry_used[g])) return;
+    } else {
+        entry.p = sub * S;
+        entry.bz = 0;
+    }
+    LpSubState ex = exits[g];
+    LpSubSum tot = totals[g];
+    if (!VERIFY) { ex.p = 0xffffffffu; ex.bz = 0; }
+    bool ch = lp_count_pass(m, img, st.n_rst, st.clean_bytes * 8, sub, S, C, K, VERIFY, entry, ckpts + (size_t)g * K, &ex, &tot);
+    *reinterpret_cast<volatile uint64_t*>(&exits[g]) = (uint64_t)ex.p | ((uint64_t)ex.bz << 32);
+    totals[g] = tot;
+    entry_used[g] = entry;
+    if (VERIFY && ch) atomicAdd(changed, 1u);
+}
+
+template __global__ void k_huff_count<false>(const LpJpeg*, const LpJpegState*, const LpHuffSet*, const uint32_t*, const uint32_t*, LpCkpt*,
+                                             LpSubState*, LpSubState*, LpSubSum*, uint32_t*, uint32_t, uint32_t, uint32_t);
+template __global__ void k_huff_count<true>(const LpJpeg*, const LpJpegState*, const LpHuffSet*, const uint32_t*, const uint32_t*, LpCkpt*,
+                                            LpSubState*, LpSubState*, LpSubSum*, uint32_t*, uint32_t, uint32_t, uint32_t);
+
+// One workgroup per image: exclusive scan (lp_sum_combine is associative, not commutative) of the
+// per-subsequence sums -> prefixes[]; also validates the block count.
+__global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states,
+                                                  const LpSubSum* __restrict__ totals, LpSubSum* __restrict__ prefixes)
+{
+    __shared__ LpSubSum s_part[256];
+    const LpJpeg& img = imgs[blockIdx.x];
+    LpJpegState& st = states[blockIdx.x];
+    uint32_t n = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    const uint32_t t = threadIdx.x, per = (n + 255) / 256;
+    uint32_t b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    if (b0 > n) b0 = n;
+    LpSubSum acc;
+    lp_sum_zero(acc);
+    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, totals[img.sub_off + i]);
+    s_part[t] = acc;
+    __syncthreads();
+    LpSubSum pre;
+    lp_sum_zero(pre);
+    for (uint32_t i = 0; i < t; i++) pre = lp_sum_combine(pre, s_part[i]);
+    for (uint32_t i = b0; i < b1; i++) {
+        prefixes[img.sub_off + i] = pre;
+        pre = lp_sum_combine(pre, totals[img.sub_off + i]);
+    }
+    if (t == 255) {
+        st.blocks_decoded = pre.nblk;
+        if (pre.nblk < img.total_blocks) st.error |= 2u;
+    }
+}
+
+struct DevSink {
+    int16_t* slot;          // this lane's 64-coefficient LDS slot (kept zero between blocks)
+    uint32_t l7;
+    int16_t* coef_arena;
+    const LpJpeg* img;
+    __device__ __forceinline__ void begin_block() {}
+    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slot[(((nat >> 3) ^ l7) << 3) | (nat & 7)] = (int16_t)v; }
+    __device__ __forceinline__ void end_block(uint32_t c, uint32_t bx, uint32_t by)
+    {
+        const bool ok = bx < img->bw[c] && by < img->bh[c];
+        uint4* dst = reinterpret_cast<uint4*>(coef_arena + img->coef_off[c] + ((size_t)by * img->bw[c] + bx) * 64);
+        uint4* s = reinterpret_cast<uint4*>(slot);
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t ch = 0; ch < 8; ch++) {
+            uint4 v = s[ch ^ l7];
+            if (ok) dst[ch] = v;
+            s[ch ^ l7] = zero;
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void k_huff_write(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                    const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                    const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
+                                                    const LpSubSum* __restrict__ prefixes, int16_t* __restrict__ coef_arena)
+{
+    __shared__ LpHuffSet s_hs;
+    __shared__ __attribute__((aligned(16))) int16_t s_slots[256 * 64];
+    __shared__ uint8_t s_zz[80];
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub;
+    if (blockIdx.x * 256 >= nsub) return;
+    {
+        const uint8_t zz[80] = LP_ZIGZAG_INIT;
+        if (threadIdx.x < 80) s_zz[threadIdx.x] = zz[threadIdx.x];
+        uint4* z4 = reinterpret_cast<uint4*>(s_slots);
+        for (uint32_t i = threadIdx.x; i < 256 * 64 * 2 / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    stage_huff(&s_hs, huffs + img.huff_idx);
+    const uint32_t sub = blockIdx.x * 256 + threadIdx.x;
+    if (sub >= nsub || sub >= img.sub_cap) return;
+    const uint32_t g = img.sub_off + sub;
+    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off};
+    LpSubState entry;
+    if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
+    DevSink sink{s_slots + threadIdx.x * 64, threadIdx.x & 7u, coef_arena, &img};
+    lp_write_pass(m, img, st.n_rst, st.clean_bytes * 8, entry, exits[g].p, prefixes[g], s_zz, sink);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dequantise + jpeg_idct_islow (jidctint.c). One wave = 8 horizontally adjacent
+// blocks of one component; lane = (block j, row/column r). Coefficient rows arrive as one coalesced
+// 1 KiB wave load, are transposed through LDS for the column pass, and leave as 8-byte pixel rows
+// (64 contiguous bytes per row across the 8 blocks).
+__device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
+{
+    int32_t z1 = (d[2] + d[6]) * 4433;
+    int32_t tmp2 = z1 - d[6] * 15137, tmp3 = z1 + d[2] * 6270;
+    int32_t tmp0 = (int32_t)((uint32_t)(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)(d[0] - d[4]) << 13);
+    int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
+    tmp0 = d[7]; tmp1 = d[5]; tmp2 = d[3]; tmp3 = d[1];
+    z1 = tmp0 + tmp3;
+    int32_t z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+    z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    o[0] = t10 + tmp3; o[7] = t10 - tmp3; o[1] = t11 + tmp2; o[6] = t11 - tmp2;
+    o[2] = t12 + tmp1; o[5] = t12 - tmp1; o[3] = t13 + tmp0; o[4] = t13 - tmp0;
+}
+
+#define IDCT_CSTRIDE 72 // int16 per block in LDS (64 + 8 pad): conflict-free column reads
+#define IDCT_WSTRIDE 72 // int32 per block in LDS (64 + 8 pad): conflict-free column writes
+
+__global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                              const int16_t* __restrict__ coef_arena, uint8_t* __restrict__ plane_arena)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_c[4][8 * IDCT_CSTRIDE];
+    __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
+    __shared__ uint16_t s_q[64];
+    const LpJpeg& img = imgs[blockIdx.z];
+    const uint32_t c = blockIdx.y;
+    if (c >= img.ncomp) return;
+    const uint32_t bw = img.bw[c], bh = img.bh[c];
+    const uint32_t tiles_x = (bw + 7) / 8, ntiles = tiles_x * bh;
+    if (blockIdx.x * 4 >= ntiles) return;
+    if (threadIdx.x < 64) s_q[threadIdx.x] = img.qt[c][threadIdx.x];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tile = blockIdx.x * 4 + wv;
+    const bool active = tile < ntiles;
+    const uint32_t by = active ? tile / tiles_x : 0, bx0 = active ? (tile % tiles_x) * 8 : 0;
+    const uint32_t j = lane >> 3, r = lane & 7;
+    const bool blk_ok = active && bx0 + j < bw;
+    const int16_t* src = coef_arena + img.coef_off[c] + ((size_t)by * bw + bx0 + j) * 64 + r * 8;
+    uint4 v = blk_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(&s_c[wv][j * IDCT_CSTRIDE + r * 8]) = v;
+    __syncthreads();
+    {   // pass 1: column r of block j
+        int32_t d[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (int32_t)s_c[wv][j * IDCT_CSTRIDE + k * 8 + r] * (int32_t)s_q[k * 8 + r];
+        idct_1d(d, o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_w[wv][j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
+    }
+    __syncthreads();
+    {   // pass 2: row r of block j
+        int32_t d[8], o[8];
+        const int4* wp = reinterpret_cast<const int4*>(&s_w[wv][j * IDCT_WSTRIDE + r * 8]);
+        int4 a = wp[0], b = wp[1];
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        idct_1d(d, o);
+        uint32_t px[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int32_t s = ((o[k] + (1 << 17)) >> 18) + 128;
+            px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+        }
+        if (blk_ok) {
+            uint2 out;
+            out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+            uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + (bx0 + j) * 8;
+            *reinterpret_cast<uint2*>(dst) = out;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (plain C++ signatures; see lp_launch.h)
+void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
+                       LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst, uint32_t S)
+{
+    if (!nimg || !max_chunks) return;
+    dim3 g(max_chunks, nimg);
+    hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
+    hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean, S);
+    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst);
+}
+
+void lp_launch_huff_count(hipStream_t s, bool verify, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs,
+                          uint32_t nimg, uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, LpCkpt* d_ckpt,
+                          LpSubState* d_exit, LpSubState* d_entry, LpSubSum* d_tot, uint32_t* d_changed, uint32_t S, uint32_t C, uint32_t K)
+{
+    if (!nimg || !max_sub) return;
+    dim3 g((max_sub + 255) / 256, nimg);
+    if (verify)
+        hipLaunchKernelGGL(k_huff_count<true>, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_ckpt, d_exit, d_entry, d_tot,
+                           d_changed, S, C, K);
+    else
+        hipLaunchKernelGGL(k_huff_count<false>, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_ckpt, d_exit, d_entry, d_tot,
+                           d_changed, S, C, K);
+}
+
+void lp_launch_sub_scan(hipStream_t s, const LpJpeg* d_imgs, LpJpegState* d_states, uint32_t nimg, const LpSubSum* d_tot, LpSubSum* d_prefix)
+{
+    if (!nimg) return;
+    hipLaunchKernelGGL(k_sub_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_states, d_tot, d_prefix);
+}
+
+void lp_launch_huff_write(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs, uint32_t nimg,
+                          uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, const LpSubState* d_exit, const LpSubSum* d_prefix,
+                          int16_t* d_coef)
+{
+    if (!nimg || !max_sub) return;
+    dim3 g((max_sub + 255) / 256, nimg);
+    hipLaunchKernelGGL(k_huff_write, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_exit, d_prefix, d_coef);
+}
+
+void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int16_t* d_coef,
+                    uint8_t* d_planes)
+{
+    if (!nimg || !max_tiles) return;
+    dim3 g((max_tiles + 3) / 4, LP_MAX_COMP, nimg);
+    hipLaunchKernelGGL(k_idct, g, dim3(256), 0, s, d_imgs, d_states, d_coef, d_planes);
+}

@@ -1,0 +1,300 @@
+// lp_kernels_pixel.hip -- gfx950 pixel kernels of the ImageOps.Transform path:
+//   k_ycc_to_frame : fancy chroma upsampling (S3) + YCbCr->BGR (S4), the tail of opencv_decoder_read_data
+//                    (/root/reference/opencv.cpp:166-171; libjpeg-turbo jdsample.c / jdcolor.c)
+//   k_orient       : cv::ExifTransform index permutation (S5), opencv_mat_orientation_transform (opencv.cpp:217-221)
+//   k_resize_*     : cv::resize(..., INTER_AREA) (S7), opencv_mat_resize (opencv.cpp:196-208); the crop (S6,
+//                    opencv.cpp:210-215) is folded into the source offset exactly like cv::Mat(Rect) is a view
+//   k_blend / k_clear : opencv_copy_to_region(_with_alpha), opencv_mat_clear_to_transparent (opencv.cpp:508-752)
+// Byte/integer work, HBM-bound: no MFMA. Float taps use explicit non-fused mul/add to follow OpenCV's
+// accumulation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lp_launch.h"
+#include "lp_types.h"
+
+#define FIX16(x) ((int32_t)((x)*65536.0 + 0.5))
+
+__device__ __forceinline__ uint32_t clamp8(int32_t v) { return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// One chroma sample of the upsampled plane at full-resolution (x, y); hr/vr in {1,2}.
+__device__ __forceinline__ int32_t upsampled(const uint8_t* __restrict__ P, uint32_t stride, int32_t dw, int32_t dh, int32_t hr, int32_t vr,
+                                             int32_t x, int32_t y)
+{
+    if (hr == 1 && vr == 1) return P[(size_t)y * stride + x];
+    if (hr == 2 && vr == 2) { // h2v2_fancy_upsample
+        int32_t cy = y >> 1, ny = (y & 1) ? cy + 1 : cy - 1;
+        ny = ny < 0 ? 0 : ny > dh - 1 ? dh - 1 : ny;
+        int32_t cx = x >> 1, nx = (x & 1) ? cx + 1 : cx - 1;
+        const uint8_t* r0 = P + (size_t)cy * stride;
+        const uint8_t* r1 = P + (size_t)ny * stride;
+        int32_t cs = 3 * r0[cx] + r1[cx];
+        int32_t bias = (x & 1) ? 7 : 8;
+        if (nx < 0 || nx > dw - 1) return (4 * cs + bias) >> 4;
+        int32_t cn = 3 * r0[nx] + r1[nx];
+        return (3 * cs + cn + bias) >> 4;
+    }
+    if (hr == 2) { // h2v1_fancy_upsample
+        const uint8_t* r = P + (size_t)y * stride;
+        int32_t cx = x >> 1, nx = (x & 1) ? cx + 1 : cx - 1;
+        if (nx < 0 || nx > dw - 1) return r[cx];
+        return (3 * r[cx] + r[nx] + ((x & 1) ? 2 : 1)) >> 2;
+    }
+    // h1v2_fancy_upsample
+    int32_t cy = y >> 1, ny = (y & 1) ? cy + 1 : cy - 1;
+    ny = ny < 0 ? 0 : ny > dh - 1 ? dh - 1 : ny;
+    return (3 * P[(size_t)cy * stride + x] + P[(size_t)ny * stride + x] + ((y & 1) ? 2 : 1)) >> 2;
+}
+
+__device__ __forceinline__ void ycc_to_bgr(int32_t y, int32_t cb, int32_t cr, uint32_t& b, uint32_t& g, uint32_t& r)
+{
+    cb -= 128; cr -= 128;
+    r = clamp8(y + ((FIX16(1.40200) * cr + 32768) >> 16));
+    b = clamp8(y + ((FIX16(1.77200) * cb + 32768) >> 16));
+    g = clamp8(y + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16));
+}
+
+// planes -> interleaved frame. Thread = 4 horizontally adjacent pixels; block = 64x4 threads.
+__global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ plane_arena,
+                                                      const LpFrame* __restrict__ dsts, uint8_t* __restrict__ frame_arena)
+{
+    const LpJpeg& img = imgs[blockIdx.z];
+    const LpFrame& f = dsts[blockIdx.z];
+    const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
+    const int32_t x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const uint8_t* PY = plane_arena + img.plane_off[0];
+    uint8_t* out = frame_arena + f.off + (size_t)y * f.stride;
+    if (img.ncomp == 1) {
+        for (int i = 0; i < 4 && x0 + i < W; i++) out[x0 + i] = PY[(size_t)y * img.plane_stride[0] + x0 + i];
+        return;
+    }
+    const uint8_t* PB = plane_arena + img.plane_off[1];
+    const uint8_t* PR = plane_arena + img.plane_off[2];
+    const int32_t hr = img.hmax / img.hs[1], vr = img.vmax / img.vs[1];
+    const int32_t dw = (W * img.hs[1] + img.hmax - 1) / img.hmax, dh = (H * img.vs[1] + img.vmax - 1) / img.vmax;
+    uint32_t px[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int32_t x = x0 + i < W ? x0 + i : W - 1;
+        int32_t yy = PY[(size_t)y * img.plane_stride[0] + x];
+        int32_t cb = upsampled(PB, img.plane_stride[1], dw, dh, hr, vr, x, y);
+        int32_t cr = upsampled(PR, img.plane_stride[2], dw, dh, hr, vr, x, y);
+        if (img.colorspace == 3) { px[3 * i] = (uint32_t)cr; px[3 * i + 1] = (uint32_t)cb; px[3 * i + 2] = (uint32_t)yy; } // RGB planes -> BGR
+        else ycc_to_bgr(yy, cb, cr, px[3 * i], px[3 * i + 1], px[3 * i + 2]);
+    }
+    if (x0 + 4 <= W && ((f.off + (size_t)y * f.stride + (size_t)x0 * 3) & 3) == 0) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)x0 * 3);
+        o[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        o[1] = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+        o[2] = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < W; i++) {
+            out[(size_t)(x0 + i) * 3 + 0] = (uint8_t)px[3 * i];
+            out[(size_t)(x0 + i) * 3 + 1] = (uint8_t)px[3 * i + 1];
+            out[(size_t)(x0 + i) * 3 + 2] = (uint8_t)px[3 * i + 2];
+        }
+    }
+}
+
+// dst(y, x) = src(f(y, x)); dst dims are (h, w) for orientations 5..8.
+__global__ __launch_bounds__(256) void k_orient(const LpOrientOp* __restrict__ ops, const uint8_t* __restrict__ src_arena,
+                                                uint8_t* __restrict__ dst_arena)
+{
+    const LpOrientOp& op = ops[blockIdx.z];
+    const uint32_t o = op.orientation;
+    const bool swap = o >= 5 && o <= 8;
+    const uint32_t W = swap ? op.src.h : op.src.w, H = swap ? op.src.w : op.src.h;
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    uint32_t tx = x, ty = y;
+    if (o == 2 || o == 6 || o == 3 || o == 7) tx = W - 1 - x;
+    if (o == 3 || o == 7 || o == 4 || o == 8) ty = H - 1 - y;
+    const uint32_t sx = swap ? ty : tx, sy = swap ? tx : ty;
+    const uint8_t* s = src_arena + op.src.off + (size_t)sy * op.src.stride + (size_t)sx * op.src.cn;
+    uint8_t* d = dst_arena + op.dst.off + (size_t)y * op.dst.stride + (size_t)x * op.src.cn;
+    for (uint32_t c = 0; c < op.src.cn; c++) d[c] = s[c];
+}
+
+__device__ __forceinline__ uint32_t sat_round_u8(float v)
+{
+    int32_t i = __float2int_rn(v); // cvRound: round half to even
+    return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
+}
+
+// INTER_AREA, integer scale (resizeAreaFast_): one wave per destination pixel, lanes stride the
+// iscale_y x (iscale_x*cn) byte box, per-channel sums reduced across the wave.
+__global__ __launch_bounds__(256) void k_resize_area_fast(const LpResizeOp* __restrict__ ops, const uint8_t* __restrict__ src_arena,
+                                                          uint8_t* __restrict__ dst_arena)
+{
+    const LpResizeOp& op = ops[blockIdx.y];
+    if (op.mode != 1) return;
+    const uint32_t npx = op.dst.w * op.dst.h;
+    const uint32_t pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= npx) return;
+    const uint32_t dx = pix % op.dst.w, dy = pix / op.dst.w, cn = op.src.cn;
+    const uint32_t rowb = op.iscale_x * cn, box = rowb * op.iscale_y;
+    const uint8_t* S = src_arena + op.src.off + (size_t)(dy * op.iscale_y) * op.src.stride + (size_t)dx * rowb;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t i = lane; i < box; i += 64) {
+        uint32_t ry = i / rowb, rx = i - ry * rowb;
+        uint32_t v = S[(size_t)ry * op.src.stride + rx];
+        uint32_t ch = rx % cn;
+        acc[0] += ch == 0 ? v : 0; acc[1] += ch == 1 ? v : 0; acc[2] += ch == 2 ? v : 0; acc[3] += ch == 3 ? v : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc[c] += __shfl_xor(acc[c], d, 64);
+    if (lane < cn) {
+        uint32_t sum = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+        uint32_t r;
+        if (op.iscale_x == 2 && op.iscale_y == 2) r = (sum + 2) >> 2;          // ResizeAreaFastVec_SIMD_8u
+        else r = sat_round_u8(__fmul_rn((float)sum, op.inv_area));              // saturate_cast<uchar>(sum * (1.f/area))
+        dst_arena[op.dst.off + (size_t)dy * op.dst.stride + (size_t)dx * cn + lane] = (uint8_t)r;
+    }
+}
+
+// INTER_AREA, fractional scale (ResizeArea_Invoker): thread per destination pixel, taps in OpenCV's order.
+__global__ __launch_bounds__(256) void k_resize_area(const LpResizeOp* __restrict__ ops, const LpTap* __restrict__ taps,
+                                                     const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ src_arena,
+                                                     uint8_t* __restrict__ dst_arena)
+{
+    const LpResizeOp& op = ops[blockIdx.z];
+    if (op.mode != 2) return;
+    const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= op.dst.w || dy >= op.dst.h) return;
+    const uint32_t cn = op.src.cn;
+    const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
+    const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
+    const LpTap* xt = taps + op.xtab_off;
+    const LpTap* yt = taps + op.ytab_off;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t j = y0; j < y1; j++) {
+        const float beta = yt[j].alpha;
+        const uint8_t* S = src_arena + op.src.off + (size_t)yt[j].si * op.src.stride;
+        float buf[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t k = x0; k < x1; k++) {
+            const float a = xt[k].alpha;
+            const uint8_t* p = S + (size_t)xt[k].si * cn;
+            for (uint32_t c = 0; c < cn; c++) buf[c] = __fadd_rn(buf[c], __fmul_rn((float)p[c], a));
+        }
+        for (uint32_t c = 0; c < cn; c++) sum[c] = __fadd_rn(sum[c], __fmul_rn(beta, buf[c]));
+    }
+    uint8_t* D = dst_arena + op.dst.off + (size_t)dy * op.dst.stride + (size_t)dx * cn;
+    for (uint32_t c = 0; c < cn; c++) D[c] = (uint8_t)sat_round_u8(sum[c]);
+}
+
+// INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point
+// (resizeGeneric_<HResizeLinear, VResizeLinear<uchar,int,short,...>>).
+__global__ __launch_bounds__(256) void k_resize_linear(const LpResizeOp* __restrict__ ops, const int32_t* __restrict__ itab,
+                                                       const uint8_t* __restrict__ src_arena, uint8_t* __restrict__ dst_arena)
+{
+    const LpResizeOp& op = ops[blockIdx.z];
+    if (op.mode != 3) return;
+    const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= op.dst.w || dy >= op.dst.h) return;
+    const uint32_t cn = op.src.cn;
+    const int32_t* xo = itab + op.xrange_off;   // per dx: sx, a0, a1
+    const int32_t* yo = itab + op.yrange_off;   // per dy: sy, b0, b1
+    const int32_t sx = xo[3 * dx], a0 = xo[3 * dx + 1], a1 = xo[3 * dx + 2];
+    const int32_t sy = yo[3 * dy], b0 = yo[3 * dy + 1], b1 = yo[3 * dy + 2];
+    const bool edge = dx >= op.xmax;
+    uint8_t* D = dst_arena + op.dst.off + (size_t)dy * op.dst.stride + (size_t)dx * cn;
+    int32_t y0 = sy < 0 ? 0 : sy > (int32_t)op.src.h - 1 ? (int32_t)op.src.h - 1 : sy;
+    int32_t y1 = sy + 1 < 0 ? 0 : sy + 1 > (int32_t)op.src.h - 1 ? (int32_t)op.src.h - 1 : sy + 1;
+    const uint8_t* S0 = src_arena + op.src.off + (size_t)y0 * op.src.stride + (size_t)sx * cn;
+    const uint8_t* S1 = src_arena + op.src.off + (size_t)y1 * op.src.stride + (size_t)sx * cn;
+    for (uint32_t c = 0; c < cn; c++) {
+        int32_t r0 = edge ? S0[c] * 2048 : S0[c] * a0 + S0[c + cn] * a1;
+        int32_t r1 = edge ? S1[c] * 2048 : S1[c] * a0 + S1[c + cn] * a1;
+        D[c] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy_rect(const LpResizeOp* __restrict__ ops, const uint8_t* __restrict__ src_arena,
+                                                   uint8_t* __restrict__ dst_arena)
+{
+    const LpResizeOp& op = ops[blockIdx.z];
+    if (op.mode != 0) return;
+    const uint32_t rowb = op.dst.w * op.src.cn;
+    const uint32_t xb = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (xb >= rowb || y >= op.dst.h) return;
+    const uint8_t* s = src_arena + op.src.off + (size_t)y * op.src.stride + xb;
+    uint8_t* d = dst_arena + op.dst.off + (size_t)y * op.dst.stride + xb;
+    for (uint32_t i = 0; i < 4 && xb + i < rowb; i++) d[i] = s[i];
+}
+
+// opencv_copy_to_region_with_alpha / opencv_copy_to_region / opencv_mat_clear_to_transparent on a ROI.
+__global__ __launch_bounds__(256) void k_composite(LpCompositeOp op, const uint8_t* __restrict__ src_arena, uint8_t* __restrict__ dst_arena)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= op.w || y >= op.h) return;
+    uint8_t* d = dst_arena + op.dst.off + (size_t)(op.y0 + y) * op.dst.stride + (size_t)(op.x0 + x) * op.dst.cn;
+    const uint32_t dcn = op.dst.cn;
+    if (op.kind == 2) { // clear
+        for (uint32_t c = 0; c < dcn; c++) d[c] = 0;
+        return;
+    }
+    const uint32_t scn = op.src.cn;
+    const uint8_t* s = src_arena + op.src.off + (size_t)y * op.src.stride + (size_t)x * scn;
+    uint32_t s4[4] = {s[0], scn == 1 ? s[0] : s[1], scn == 1 ? s[0] : s[2], scn == 4 ? s[3] : 255u};
+    if (op.kind == 1) { // copy with channel fix-up
+        for (uint32_t c = 0; c < dcn; c++) d[c] = (uint8_t)s4[c];
+        return;
+    }
+    const float k = (float)(1.0 / 255.0);
+    uint32_t d4[4] = {d[0], d[1], d[2], dcn == 4 ? d[3] : 255u};
+    float sa = __fmul_rn((float)s4[3], k), da = __fmul_rn((float)d4[3], k);
+    float om = __fsub_rn(1.0f, sa);
+    float oa = __fadd_rn(sa, __fmul_rn(da, om));
+    for (uint32_t c = 0; c < 3; c++) {
+        float sc = __fmul_rn((float)s4[c], k), dc = __fmul_rn((float)d4[c], k);
+        float t1 = __fmul_rn(sc, sa), t3 = __fmul_rn(__fmul_rn(dc, da), om);
+        float bl = __fdiv_rn(__fadd_rn(t1, t3), oa);
+        float v = __fmul_rn(bl, 255.0f);
+        d[c] = (v != v) ? 0 : (uint8_t)sat_round_u8(v);
+    }
+    if (dcn == 4) d[3] = (uint8_t)sat_round_u8(__fmul_rn(oa, 255.0f));
+}
+
+// ------------------------------------------------------------------------------------------------
+void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_planes,
+                            const LpFrame* d_dsts, uint8_t* d_frames)
+{
+    if (!nimg || !max_w || !max_h) return;
+    dim3 g((max_w + 255) / 256, (max_h + 3) / 4, nimg);
+    hipLaunchKernelGGL(k_ycc_to_frame, g, dim3(64, 4), 0, s, d_imgs, d_planes, d_dsts, d_frames);
+}
+
+void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_src, uint8_t* d_dst)
+{
+    if (!nimg || !max_w || !max_h) return;
+    dim3 g((max_w + 63) / 64, (max_h + 3) / 4, nimg);
+    hipLaunchKernelGGL(k_orient, g, dim3(64, 4), 0, s, d_ops, d_src, d_dst);
+}
+
+void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uint32_t modes_present, uint32_t max_dw, uint32_t max_dh,
+                      const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_src, uint8_t* d_dst)
+{
+    if (!nimg || !max_dw || !max_dh) return;
+    dim3 g2((max_dw + 63) / 64, (max_dh + 3) / 4, nimg);
+    if (modes_present & 1u) {
+        dim3 gc((max_dw * 4 + 255) / 256, (max_dh + 3) / 4, nimg);
+        hipLaunchKernelGGL(k_copy_rect, gc, dim3(64, 4), 0, s, d_ops, d_src, d_dst);
+    }
+    if (modes_present & 2u) {
+        dim3 gf((max_dw * max_dh + 3) / 4, nimg);
+        hipLaunchKernelGGL(k_resize_area_fast, gf, dim3(256), 0, s, d_ops, d_src, d_dst);
+    }
+    if (modes_present & 4u) hipLaunchKernelGGL(k_resize_area, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (modes_present & 8u)
+        hipLaunchKernelGGL(k_resize_linear, g2, dim3(64, 4), 0, s, d_ops, reinterpret_cast<const int32_t*>(d_ranges), d_src, d_dst);
+}
+
+void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* d_src, uint8_t* d_dst)
+{
+    if (!op.w || !op.h) return;
+    dim3 g((op.w + 63) / 64, (op.h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_composite, g, dim3(64, 4), 0, s, op, d_src, d_dst);
+}

@@ -1,0 +1,371 @@
+// lp_ops.cpp -- Part C of include/lilliput_hip.h: a C++ mirror of the Go layer that drives the cgo
+// boundary -- Decoder / Framebuffer / ImageOps / Encoder (/root/reference/lilliput.go:42-202,
+// opencv.go:118-146, 207-463, 639-661, 816-905, ops.go:68-591). The reference is compiled Go; with no Go
+// toolchain in this image the host side is written in C++ and calls the SAME opencv_* C ABI functions in
+// the same order the Go code does, so the drop-in boundary is exercised exactly as a Go caller would.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <string>
+
+#include "lp_abi.h"
+#include "lp_ops_logic.h"
+
+// ---------------------------------------------------------------- opencv.go:468-637 byte scanners
+static const uint8_t kPngMagic[8] = {0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a};
+static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+namespace {
+struct PngIter { // opencv.go:468-512 pngChunkIter
+    const uint8_t* png;
+    size_t len;
+    long off;
+    bool has_space() const { return off + 12 <= (long)len; }
+    long next_off() const { return off + (long)be32(png + off) + 12; }
+    bool next()
+    {
+        if (off < 8) { off = 8; return has_space(); }
+        if (!has_space()) return false;
+        off = next_off();
+        return off >= 0 && has_space();
+    }
+    const uint8_t* type() const { return png + off + 4; }
+};
+}
+
+static int content_length_png(const uint8_t* b, size_t n) // opencv.go:514-535
+{
+    if (n < 8 || memcmp(b, kPngMagic, 8) != 0) return (int)n;
+    PngIter it{b, n, 0};
+    while (it.next())
+        if (memcmp(it.type(), "IEND", 4) == 0) {
+            long e = it.next_off();
+            if (e > (long)n) e = (long)n;
+            return (int)e;
+        }
+    return (int)n;
+}
+
+static int content_length_jpeg(const uint8_t* j, size_t n) // opencv.go:537-602
+{
+    if (n < 3 || j[0] != 0xFF || j[1] != 0xD8 || j[2] != 0xFF) return (int)n;
+    size_t idx = 0;
+    for (;;) {
+        if (idx + 1 >= n) break;
+        if (j[idx] != 0xFF) break;
+        size_t next = idx + 2;
+        uint8_t t = j[idx + 1];
+        if (t == 0xD9) return (int)next;
+        if (t == 0xFF) { idx++; continue; }
+        if ((t >= 0xD0 && t <= 0xD8)) { idx = next; continue; }
+        if (idx + 3 >= n) break;
+        next += ((size_t)j[idx + 2] << 8) | j[idx + 3];
+        if (t == 0xDA) {
+            for (; next < n; next++) {
+                if (j[next] != 0xFF) continue;
+                if (next + 1 >= n) { next = n; break; }
+                uint8_t peek = j[next + 1];
+                if (peek == 0xFF) continue;
+                if (peek != 0 && (peek < 0xD0 || peek > 0xD7)) break;
+            }
+        }
+        idx = next;
+    }
+    return (int)n;
+}
+
+int lp_detect_content_length(const uint8_t* b, size_t n) // opencv.go:604-614
+{
+    int a = content_length_jpeg(b, n), p = content_length_png(b, n);
+    return a < p ? a : p;
+}
+
+bool lp_detect_apng(const uint8_t* b, size_t n) // opencv.go:617-637
+{
+    if (n < 8 || memcmp(b, kPngMagic, 8) != 0) return false;
+    PngIter it{b, n, 0};
+    while (it.next()) {
+        const uint8_t* t = it.type();
+        if (memcmp(t, "acTL", 4) == 0 || memcmp(t, "fcTL", 4) == 0 || memcmp(t, "fdAT", 4) == 0) return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- Framebuffer (opencv.go:118-129, 207-374)
+namespace {
+struct Framebuffer {
+    uint8_t* buf = nullptr;
+    size_t buf_len = 0;
+    opencv_mat mat = nullptr;
+    int width = 0, height = 0, pixel_type = 0;
+    int64_t duration = 0;
+    int x_offset = 0, y_offset = 0, dispose = 0, blend = 0;
+
+    void init(int w, int h) // NewFramebuffer
+    {
+        buf_len = (size_t)w * h * 4;
+        buf = (uint8_t*)calloc(buf_len ? buf_len : 1, 1);
+    }
+    void close() { if (mat) { opencv_mat_release(mat); mat = nullptr; } }
+    void destroy() { close(); free(buf); buf = nullptr; }
+    void clear() { if (buf) memset(buf, 0, buf_len); if (mat) opencv_mat_reset(mat); }
+    int resize_mat(int w, int h, int ptype) // opencv.go:250-267
+    {
+        if (mat) { opencv_mat_release(mat); mat = nullptr; }
+        if (opencv_type_depth(ptype) > 8) ptype = opencv_type_convert_depth(ptype, CV_8U);
+        opencv_mat m = opencv_mat_create_from_data(w, h, ptype, buf, buf_len);
+        if (!m) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        mat = m; width = w; height = h; pixel_type = ptype;
+        return LILLIPUT_OK;
+    }
+    void orientation_transform(int orientation) // opencv.go:271-279
+    {
+        if (!mat) return;
+        opencv_mat_orientation_transform((CVImageOrientation)orientation, mat);
+        width = opencv_mat_get_width(mat);
+        height = opencv_mat_get_height(mat);
+    }
+    int resize_to(int w, int h, Framebuffer* dst) // opencv.go:294-309
+    {
+        if (w < 1) w = 1;
+        if (h < 1) h = 1;
+        int e = dst->resize_mat(w, h, pixel_type);
+        if (e) return e;
+        opencv_mat_resize(mat, dst->mat, w, h, CV_INTER_AREA);
+        return LILLIPUT_OK;
+    }
+    int fit(int w, int h, Framebuffer* dst) // opencv.go:326-374
+    {
+        if (!mat) return LILLIPUT_ERR_FRAMEBUF_NO_PIXELS;
+        int left, top, wpc, hpc;
+        lp_fit_crop_rect(width, height, w, h, &left, &top, &wpc, &hpc);
+        opencv_mat nm = opencv_mat_crop(mat, left, top, wpc, hpc);
+        if (!nm) return LILLIPUT_ERR_INVALID_IMAGE;
+        int e = dst->resize_mat(w, h, pixel_type);
+        if (!e) opencv_mat_resize(nm, dst->mat, w, h, CV_INTER_AREA);
+        opencv_mat_release(nm);
+        return e;
+    }
+};
+
+struct Decoder { // openCVDecoder, opencv.go:132-138
+    const uint8_t* buf = nullptr;
+    size_t len = 0;
+    opencv_mat mat = nullptr;
+    opencv_decoder dec = nullptr;
+    bool has_read_header = false, has_decoded = false;
+};
+
+struct Header { int width, height, pixel_type, orientation, num_frames, content_length; };
+
+int decoder_header(Decoder* d, Header* h) // opencv.go:639-661
+{
+    if (!d->has_read_header && !opencv_decoder_read_header(d->dec)) return LILLIPUT_ERR_INVALID_IMAGE;
+    d->has_read_header = true;
+    h->num_frames = lp_detect_apng(d->buf, d->len) ? 2 : 1;
+    h->width = opencv_decoder_get_width(d->dec);
+    h->height = opencv_decoder_get_height(d->dec);
+    h->pixel_type = opencv_decoder_get_pixel_type(d->dec);
+    h->orientation = opencv_decoder_get_orientation(d->dec);
+    h->content_length = lp_detect_content_length(d->buf, d->len);
+    return LILLIPUT_OK;
+}
+
+int decoder_decode_to(Decoder* d, Framebuffer* f) // opencv.go:816-839
+{
+    if (d->has_decoded) return LILLIPUT_ERR_EOF;
+    Header h;
+    int e = decoder_header(d, &h);
+    if (e) return e;
+    e = f->resize_mat(h.width, h.height, h.pixel_type);
+    if (e) return e;
+    if (!opencv_decoder_read_data(d->dec, f->mat)) return LILLIPUT_ERR_DECODING_FAILED;
+    d->has_decoded = true;
+    f->blend = 1;   // NoBlend
+    f->dispose = 1; // DisposeToBackgroundColor
+    f->x_offset = f->y_offset = 0;
+    f->duration = 0;
+    return LILLIPUT_OK;
+}
+
+struct Encoder { // openCVEncoder, opencv.go:141-146, 847-905
+    opencv_encoder enc = nullptr;
+    opencv_mat dst = nullptr;
+    uint8_t* dst_buf = nullptr;
+};
+
+struct ImageOps { // ops.go:68-106
+    Framebuffer frames[2];
+    int frame_index = 0;
+    Framebuffer* active() { return &frames[frame_index]; }
+    Framebuffer* secondary() { return &frames[1 - frame_index]; }
+    void swap() { frame_index = 1 - frame_index; }
+    void copy_props_and_swap() // ops.go:586-591
+    {
+        secondary()->duration = active()->duration;
+        secondary()->dispose = active()->dispose;
+        secondary()->blend = active()->blend;
+        swap();
+    }
+};
+
+int64_t now_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+
+std::string lower(const char* s) { std::string r(s ? s : ""); for (auto& c : r) c = (char)tolower(c); return r; }
+} // namespace
+
+extern "C" {
+
+void lilliput_calculate_expected_size(int ow, int oh, int rw, int rh, int* w, int* h) { lp_calculate_expected_size(ow, oh, rw, rh, w, h); }
+void lilliput_fit_crop_rect(int fw, int fh, int width, int height, int* left, int* top, int* w, int* h) { lp_fit_crop_rect(fw, fh, width, height, left, top, w, h); }
+int lilliput_detect_content_length(const void* buf, size_t len) { return lp_detect_content_length((const uint8_t*)buf, len); }
+int lilliput_detect_apng(const void* buf, size_t len) { return lp_detect_apng((const uint8_t*)buf, len) ? 1 : 0; }
+
+int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // lilliput.go:129-164 + opencv.go:442-463
+{
+    *out = nullptr;
+    if (!buf || len == 0) return LILLIPUT_ERR_INVALID_IMAGE;
+    const uint8_t* b = (const uint8_t*)buf;
+    // GIF / WebP / AVIF sources have their own decoders in the reference (lilliput.go:136-154); they are outside this build.
+    if ((len >= 6 && (memcmp(b, "GIF87a", 6) == 0 || memcmp(b, "GIF89a", 6) == 0)) ||
+        (len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) ||
+        (len >= 12 && memcmp(b + 4, "ftyp", 4) == 0 && (memcmp(b + 8, "avif", 4) == 0 || memcmp(b + 8, "avis", 4) == 0)))
+        return LILLIPUT_ERR_UNSUPPORTED;
+    opencv_mat mat = opencv_mat_create_from_data((int)len, 1, CV_8U, (void*)buf, len);
+    if (!mat) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    opencv_decoder dec = opencv_decoder_create(mat);
+    if (!dec) { opencv_mat_release(mat); return LILLIPUT_ERR_INVALID_IMAGE; }
+    auto d = new Decoder();
+    d->buf = b; d->len = len; d->mat = mat; d->dec = dec;
+    *out = d;
+    return LILLIPUT_OK;
+}
+
+void lilliput_decoder_close(lilliput_decoder dd)
+{
+    auto d = static_cast<Decoder*>(dd);
+    if (!d) return;
+    opencv_decoder_release(d->dec);
+    opencv_mat_release(d->mat);
+    delete d;
+}
+
+int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* pixel_type, int* orientation, int* num_frames, int* content_length)
+{
+    Header h;
+    int e = decoder_header(static_cast<Decoder*>(dd), &h);
+    if (e) return e;
+    if (width) *width = h.width;
+    if (height) *height = h.height;
+    if (pixel_type) *pixel_type = h.pixel_type;
+    if (orientation) *orientation = h.orientation;
+    if (num_frames) *num_frames = h.num_frames;
+    if (content_length) *content_length = h.content_length;
+    return LILLIPUT_OK;
+}
+
+const char* lilliput_decoder_description(lilliput_decoder dd) { return opencv_decoder_get_description(static_cast<Decoder*>(dd)->dec); }
+
+lilliput_image_ops lilliput_new_image_ops(int max_size) // ops.go:83-91
+{
+    auto o = new ImageOps();
+    o->frames[0].init(max_size, max_size);
+    o->frames[1].init(max_size, max_size);
+    if (!o->frames[0].buf || !o->frames[1].buf) { o->frames[0].destroy(); o->frames[1].destroy(); delete o; return nullptr; }
+    return o;
+}
+
+void lilliput_image_ops_clear(lilliput_image_ops oo) { auto o = static_cast<ImageOps*>(oo); o->frames[0].clear(); o->frames[1].clear(); }
+void lilliput_image_ops_close(lilliput_image_ops oo)
+{
+    auto o = static_cast<ImageOps*>(oo);
+    if (!o) return;
+    o->frames[0].destroy();
+    o->frames[1].destroy();
+    delete o;
+}
+
+int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, const lilliput_image_options* opt, void* dst, size_t dst_cap, size_t* dst_len)
+{
+    auto o = static_cast<ImageOps*>(oo);
+    auto d = static_cast<Decoder*>(dd);
+    *dst_len = 0;
+    if (!o || !d || !opt || !dst || dst_cap == 0) return LILLIPUT_ERR_INVALID_IMAGE;
+    // initializeTransform (ops.go:483-546)
+    Header hdr;
+    int e = decoder_header(d, &hdr);
+    if (e) return e;
+    // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
+    std::string ext = lower(opt->file_type);
+    if (ext == ".gif" || ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
+    Encoder enc;
+    enc.dst_buf = (uint8_t*)dst;
+    enc.dst = opencv_mat_create_empty_from_data((int)dst_cap, dst);
+    if (!enc.dst) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
+    if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
+    struct Guard { Encoder& e; ~Guard() { opencv_encoder_release(e.enc); opencv_mat_release(e.dst); } } guard{enc};
+
+    auto encode = [&](Framebuffer* f, size_t* n) -> int { // opencv.go:872-900
+        if (!f) return LILLIPUT_ERR_EOF;
+        if (!opencv_encoder_write(enc.enc, f->mat, opt->encode_options, opt->encode_options_len)) return LILLIPUT_ERR_INVALID_IMAGE;
+        if (opencv_mat_get_data(enc.dst) != (void*)enc.dst_buf) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        *n = (size_t)opencv_mat_get_height(enc.dst);
+        return LILLIPUT_OK;
+    };
+
+    int frame_count = 0;
+    int64_t duration = 0;
+    const int64_t timeout_at = now_ns() + opt->encode_timeout_ns;
+    const bool animated = hdr.num_frames > 1;
+    for (;;) { // ops.go:371-443
+        e = decoder_decode_to(d, o->active());
+        bool empty_frame = false;
+        if (e) {
+            if (e != LILLIPUT_ERR_EOF) return e;
+            empty_frame = true;
+        }
+        duration += o->active()->duration;
+        if (opt->max_encode_duration_ns != 0 && duration > opt->max_encode_duration_ns) return LILLIPUT_ERR_EOF; // skipToEnd: openCVDecoder cannot skip
+        o->active()->orientation_transform(hdr.orientation); // unconditional (ops.go:392)
+        bool swapped = false;
+        if (!empty_frame) { // transformCurrentFrame (ops.go:449-472)
+            if (!(opt->resize_method == LILLIPUT_OPS_NO_RESIZE && !animated)) {
+                int in_w = hdr.width, in_h = hdr.height;
+                if (opt->normalize_orientation && lp_swaps_axes(hdr.orientation)) { in_w = hdr.height; in_h = hdr.width; }
+                int out_w = opt->width, out_h = opt->height;
+                if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { out_w = in_w; out_h = in_h; }
+                if (animated) return LILLIPUT_ERR_UNSUPPORTED; // APNG sources take the composite path (outside this build)
+                if (opt->resize_method == LILLIPUT_OPS_FIT || opt->resize_method == LILLIPUT_OPS_NO_RESIZE) {
+                    int nw, nh;
+                    lp_calculate_expected_size(in_w, in_h, out_w, out_h, &nw, &nh);
+                    e = o->active()->fit(nw, nh, o->secondary());
+                } else if (opt->resize_method == LILLIPUT_OPS_RESIZE) {
+                    e = o->active()->resize_to(out_w, out_h, o->secondary());
+                } else return LILLIPUT_ERR_INVALID_IMAGE;
+                if (e) return e;
+                o->copy_props_and_swap();
+                swapped = true;
+            }
+        }
+        size_t n = 0;
+        e = encode(empty_frame ? nullptr : o->active(), &n);
+        if (e == LILLIPUT_ERR_EOF) return LILLIPUT_ERR_EOF; // Encode(nil) on the OpenCV encoder: io.EOF (opencv.go:873-875)
+        if (e) return e;
+        if (n) { *dst_len = n; return LILLIPUT_OK; }
+        frame_count++;
+        if (opt->disable_animated_output) return LILLIPUT_ERR_EOF;
+        if (opt->max_encode_frames != 0 && frame_count == opt->max_encode_frames) return LILLIPUT_ERR_EOF;
+        if (now_ns() > timeout_at) return LILLIPUT_ERR_ENCODE_TIMEOUT;
+        if (swapped) o->swap();
+    }
+}
+
+} // extern "C"

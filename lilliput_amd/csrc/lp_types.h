@@ -85,3 +85,60 @@ struct LpCkpt {
     LpSubState st;
     LpSubSum sum;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Pixel frames and per-image operation descriptors (orientation, crop+resize, compositing, encode).
+struct LpFrame {
+    uint64_t off;               // byte offset into a frame arena
+    uint32_t w, h, stride, cn;  // cn = 1 (gray), 3 (BGR), 4 (BGRA)
+};
+
+struct LpOrientOp {
+    LpFrame src, dst;
+    uint32_t orientation;       // EXIF 1..8 (opencv.hpp:17-26)
+    uint32_t pad;
+};
+
+struct LpTap { uint32_t si; float alpha; };
+
+struct LpResizeOp {
+    LpFrame src;                // source VIEW: off already includes the crop origin, w/h are the cropped size
+    LpFrame dst;
+    uint32_t mode;              // 0 copy, 1 area-fast (integer scale), 2 area (fractional), 3 linear with area coefficients
+    uint32_t iscale_x, iscale_y;
+    float inv_area;             // 1.f / (iscale_x*iscale_y)
+    uint32_t xtab_off, ytab_off;     // into the tap arena (mode 2)
+    uint32_t xrange_off, yrange_off; // into the range arena: mode 2 -> [dw+1]/[dh+1] tap ranges; mode 3 -> int32 triples
+    uint32_t xmax;              // mode 3: first dx that only has one source column
+    uint32_t pad;
+};
+
+struct LpCompositeOp {
+    LpFrame src, dst;
+    uint32_t kind;              // 0 alpha blend, 1 copy (channel fix-up), 2 clear
+    uint32_t x0, y0, w, h;      // ROI in dst
+    uint32_t pad;
+};
+
+// JPEG encode job (S8-S10): pixels -> baseline 4:2:0 (or grayscale) JFIF stream with Annex-K tables.
+struct LpEncJob {
+    LpFrame src;
+    uint32_t ncomp;             // 1 or 3
+    uint32_t mcus_x, mcus_y, bpm, total_blocks;
+    uint32_t wib, hib;          // real luma blocks per row / column; the rest of the MCU grid is dummy
+    uint32_t blk_off;           // index of this image's first block in the per-block arrays
+    uint64_t coef_off;          // int16 element offset into the encoder coefficient arena (zigzag order, MCU order)
+    uint64_t bits_off;          // uint32 word offset into the bit-buffer arena (unstuffed entropy-coded segment)
+    uint32_t bits_cap_words;
+    uint32_t hdr_off, hdr_len;  // pre-built SOI..SOS header bytes
+    uint32_t out_cap;
+    uint64_t out_off;           // byte offset into the output arena
+    uint16_t qt[2][64];         // luma / chroma quantisation tables, natural order
+};
+
+struct LpEncState {
+    uint32_t total_bits;
+    uint32_t out_len;           // 0 on failure
+    uint32_t error;             // 1 = output buffer too small
+    uint32_t pad;
+};

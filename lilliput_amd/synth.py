@@ -1,0 +1,55 @@
+"""Synthetic workload of BASELINE.md section 3: photo-like 8-bit RGB images (low-frequency sinusoid gradients
++ bicubic-upsampled 128x128 Gaussian noise (sigma 40) + per-pixel Gaussian noise (sigma 6)), seeded per image
+with numpy.random.default_rng(i), encoded once on the host as baseline 4:2:0 q90 JPEG with the Annex-K
+Huffman tables and no restart markers. Used by bench.py and the tests; not part of the product path."""
+import io
+
+import numpy as np
+
+
+def synth_rgb(seed, size=4096):
+    from PIL import Image
+
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    img = np.empty((size, size, 3), np.float32)
+    for c in range(3):
+        f = rng.uniform(0.5, 3.0, 4)
+        ph = rng.uniform(0, 2 * np.pi, 4)
+        base = 128 + 50 * np.sin(2 * np.pi * f[0] * xx + ph[0]) * np.cos(2 * np.pi * f[1] * yy + ph[1]) \
+            + 30 * np.sin(2 * np.pi * (f[2] * xx + f[3] * yy) + ph[2])
+        lo = rng.normal(0, 40, (128, 128)).astype(np.float32)
+        up = np.asarray(Image.fromarray(lo, mode="F").resize((size, size), Image.BICUBIC))
+        img[:, :, c] = base + up + rng.normal(0, 6, (size, size)).astype(np.float32)
+    return np.clip(img + 0.5, 0, 255).astype(np.uint8)
+
+
+def synth_jpeg(seed, size=4096, quality=90, restart_rows=0, width=None, height=None):
+    """Returns the JPEG bytes of synthetic image `seed` (optionally cropped to width x height)."""
+    from PIL import Image
+
+    rgb = synth_rgb(seed, size)
+    if width or height:
+        rgb = np.ascontiguousarray(rgb[: (height or size), : (width or size)])
+    b = io.BytesIO()
+    kw = {}
+    if restart_rows:
+        kw["restart_marker_rows"] = restart_rows
+    Image.fromarray(rgb).save(b, "JPEG", quality=quality, subsampling=2, optimize=False, **kw)
+    return b.getvalue()
+
+
+def _job(args):
+    return synth_jpeg(*args)
+
+
+def synth_jpeg_set(n, size=4096, quality=90, workers=None):
+    """n distinct synthetic JPEGs (seeds 0..n-1), generated in parallel on the host cores."""
+    import multiprocessing as mp
+    import os
+
+    workers = workers or min(n, max(1, (os.cpu_count() or 2) - 1))
+    if workers <= 1 or n <= 1:
+        return [synth_jpeg(i, size, quality) for i in range(n)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_job, [(i, size, quality) for i in range(n)])

@@ -1,0 +1,334 @@
+"""GPU parity tests: the HIP path (through the C ABI of liblilliput_hip.so) against the CPU oracle on the same
+inputs. Bit-exact for integer/byte/index work (Huffman, IDCT, upsampling, colour, orientation, integer-scale
+area resize, the whole JPEG encoder); resampled pixels at fractional scales within +-1 LSB (north_star)."""
+import ctypes as C
+import hashlib
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CV_8UC1, CV_8UC3, CV_8UC4 = 0, 16, 24
+
+
+# ------------------------------------------------------------------------------------------ decode stages
+def test_decode_stages_bit_exact_on_reference_fixtures(batch, oracle, golden, fixture_bytes):
+    for name, data in fixture_bytes.items():
+        info = oracle.jpeg_info(data)
+        for c in range(info["ncomp"]):
+            assert np.array_equal(batch.decode_jpeg_coefs(data, c), oracle.jpeg_decode_coefs(data, c)), (name, "coefs", c)
+            assert np.array_equal(batch.decode_jpeg_plane(data, c), oracle.jpeg_decode_plane(data, c)), (name, "plane", c)
+        px, orientation = batch.decode_jpeg(data)
+        assert orientation == golden[name]["orientation"]
+        assert hashlib.sha256(px.tobytes()).hexdigest() == golden[name]["pixels_sha256"], name
+        assert np.array_equal(px, oracle.jpeg_decode(data)), name
+
+
+@pytest.mark.parametrize("S,Cc", [(64, 32), (256, 32), (1024, 32), (4096, 128), (16384, 512)])
+def test_decode_is_independent_of_subsequence_size(batch, oracle, fixture_bytes, S, Cc):
+    batch.set_subsequence(S, Cc)
+    try:
+        for name in ("sunrise.jpg", "firefox-gray.jpg", "ferry_sunset.jpg", "large-sunrise.jpg"):
+            data = fixture_bytes[name]
+            px, _ = batch.decode_jpeg(data)
+            assert np.array_equal(px, oracle.jpeg_decode(data)), (name, S)
+    finally:
+        batch.set_subsequence(0, 0)
+
+
+def test_decode_samplings_custom_tables_restarts_odd_sizes(batch, oracle):
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rgb = synth.synth_rgb(7, 512)
+    for (w, h) in ((512, 512), (501, 263), (17, 9), (1, 1), (8, 8), (16, 16), (33, 65)):
+        im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
+        for kw in ({"subsampling": 0}, {"subsampling": 1}, {"subsampling": 2}, {"subsampling": 2, "optimize": True},
+                   {"subsampling": 2, "restart_marker_blocks": 2}, {"subsampling": 2, "restart_marker_rows": 1}):
+            b = io.BytesIO()
+            im.save(b, "JPEG", quality=91, **kw)
+            data = b.getvalue()
+            px, _ = batch.decode_jpeg(data)
+            assert np.array_equal(px, oracle.jpeg_decode(data)), (w, h, kw)
+        g = io.BytesIO()
+        im.convert("L").save(g, "JPEG", quality=80)
+        px, _ = batch.decode_jpeg(g.getvalue())
+        assert px.shape[2] == 1 and np.array_equal(px, oracle.jpeg_decode(g.getvalue())), (w, h, "gray")
+
+
+def test_decode_synthetic_1024(batch, oracle):
+    from lilliput_amd import synth
+
+    for seed, rr in ((0, 0), (1, 4)):
+        data = synth.synth_jpeg(seed, 1024, restart_rows=rr)
+        px, _ = batch.decode_jpeg(data)
+        assert np.array_equal(px, oracle.jpeg_decode(data)), seed
+
+
+def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
+    import lilliput_amd
+    from PIL import Image
+
+    data = fixture_bytes["large-sunrise.jpg"]
+    b = io.BytesIO()
+    Image.open(io.BytesIO(data)).save(b, "JPEG", progressive=True)
+    with pytest.raises(lilliput_amd.LilliputError) as e:
+        batch.decode_jpeg(b.getvalue())
+    assert e.value.code == 4
+    with pytest.raises(lilliput_amd.LilliputError) as e:
+        batch.decode_jpeg(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    assert e.value.code == 1
+    with pytest.raises(lilliput_amd.LilliputError) as e:
+        batch.decode_jpeg(data[: len(data) // 2])  # truncated entropy-coded segment: too few blocks
+    assert e.value.code == 2
+
+
+# ------------------------------------------------------------------------------------------ Part A: opencv_* ABI
+class Mat:
+    """A Go-style Framebuffer: host buffer owned by the caller, Mat header over it."""
+
+    def __init__(self, L, arr=None, w=0, h=0, typ=CV_8UC3, cap=None):
+        self.L = L
+        cn = (typ >> 3) + 1
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=np.uint8)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            h, w, cn = arr.shape
+            typ = {1: CV_8UC1, 3: CV_8UC3, 4: CV_8UC4}[cn]
+        self.buf = np.zeros(cap or max(1, w * h * cn), dtype=np.uint8)
+        if arr is not None:
+            self.buf[: arr.size] = arr.ravel()
+        self.typ, self.cn = typ, cn
+        self.h = L.opencv_mat_create_from_data(w, h, typ, self.buf.ctypes.data_as(C.c_void_p), C.c_size_t(self.buf.size))
+        assert self.h
+
+    def array(self):
+        w, h = self.L.opencv_mat_get_width(self.h), self.L.opencv_mat_get_height(self.h)
+        return self.buf[: w * h * self.cn].reshape(h, w, self.cn).copy()
+
+    def release(self):
+        self.L.opencv_mat_release(self.h)
+
+
+def _abi_resize(L, src, dw, dh, crop=None):
+    s = Mat(L, src)
+    view = s.h
+    if crop:
+        view = L.opencv_mat_crop(s.h, *crop)
+    d = Mat(L, w=dw, h=dh, typ=s.typ)
+    L.opencv_mat_resize(view, d.h, dw, dh, C.c_int.in_dll(L, "CV_INTER_AREA").value)
+    out = d.array()
+    if crop:
+        L.opencv_mat_release(view)
+    s.release()
+    d.release()
+    return out
+
+
+def test_area_resize_integer_scales_bit_exact(hip_lib, oracle):
+    rng = np.random.default_rng(3)
+    for (sh, sw, cn, dw, dh) in ((256, 256, 3, 16, 16), (128, 96, 3, 48, 64), (96, 64, 1, 32, 32), (60, 90, 4, 30, 20), (512, 512, 3, 32, 32),
+                                 (64, 64, 3, 64, 64), (48, 48, 3, 16, 24)):
+        src = rng.integers(0, 256, (sh, sw, cn), dtype=np.uint8)
+        exp, br = oracle.resize_area(src, dw, dh)
+        assert br in (0, 1)
+        assert np.array_equal(_abi_resize(hip_lib, src, dw, dh), exp), (sh, sw, cn, dw, dh)
+
+
+def test_area_resize_fractional_within_one_lsb(hip_lib, oracle, fixture_bytes):
+    px = oracle.jpeg_decode(fixture_bytes["large-sunrise.jpg"])
+    cases = [(px[321:1621], 256, 256), (px[:700, :500], 123, 77), (px[:300, :300, :1], 101, 53), (px[:257, :255], 256, 254)]
+    rng = np.random.default_rng(4)
+    cases.append((rng.integers(0, 256, (333, 217, 4), dtype=np.uint8), 100, 150))
+    for src, dw, dh in cases:
+        exp, br = oracle.resize_area(np.ascontiguousarray(src), dw, dh)
+        assert br == 2
+        got = _abi_resize(hip_lib, np.ascontiguousarray(src), dw, dh)
+        diff = np.abs(got.astype(int) - exp.astype(int))
+        assert diff.max() <= 1, (src.shape, dw, dh, diff.max())  # tolerance from north_star: +-1 LSB
+        assert (diff == 0).mean() > 0.999  # same tap order and unfused float ops: expected bit-exact in practice
+
+
+def test_area_upscale_uses_linear_area_branch(hip_lib, oracle):
+    rng = np.random.default_rng(5)
+    for (sh, sw, cn, dw, dh) in ((150, 300, 3, 512, 256), (40, 40, 3, 100, 100), (64, 200, 1, 64, 300), (31, 17, 4, 90, 20)):
+        src = rng.integers(0, 256, (sh, sw, cn), dtype=np.uint8)
+        exp, br = oracle.resize_area(src, dw, dh)
+        assert br == 3
+        assert np.array_equal(_abi_resize(hip_lib, src, dw, dh), exp), (sh, sw, cn, dw, dh)
+
+
+def test_crop_is_a_view_and_resize_reads_through_it(hip_lib, oracle):
+    rng = np.random.default_rng(6)
+    src = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    exp, _ = oracle.resize_area(np.ascontiguousarray(src[20:180, 40:280]), 60, 40)
+    assert np.array_equal(_abi_resize(hip_lib, src, 60, 40, crop=(40, 20, 240, 160)), exp)
+
+
+def test_orientation_transform_all_eight_bit_exact(hip_lib, oracle):
+    rng = np.random.default_rng(7)
+    for cn in (1, 3, 4):
+        src = rng.integers(0, 256, (37, 53, cn), dtype=np.uint8)
+        for o in range(1, 9):
+            m = Mat(hip_lib, src)
+            hip_lib.opencv_mat_orientation_transform(o, m.h)
+            got = m.array()
+            m.release()
+            assert np.array_equal(got, oracle.orientation_transform(src, o)), (cn, o)
+
+
+def _abi_encode(L, px, quality):
+    s = Mat(L, px)
+    dst = np.zeros(px.size * 2 + 4096, dtype=np.uint8)
+    dmat = L.opencv_mat_create_empty_from_data(dst.size, dst.ctypes.data_as(C.c_void_p))
+    enc = L.opencv_encoder_create(b".jpeg", dmat)
+    opts = (C.c_int * 2)(1, quality)
+    ok = L.opencv_encoder_write(enc, s.h, opts, 2)
+    assert ok
+    assert L.opencv_mat_get_data(dmat) == dst.ctypes.data
+    n = L.opencv_mat_get_height(dmat)
+    out = dst[:n].tobytes()
+    L.opencv_encoder_release(enc)
+    L.opencv_mat_release(dmat)
+    s.release()
+    return out
+
+
+def test_jpeg_encoder_bitstream_identical(hip_lib, oracle, fixture_bytes):
+    px = oracle.jpeg_decode(fixture_bytes["large-sunrise.jpg"])
+    rng = np.random.default_rng(8)
+    cases = [px[:256, :256], px[100:343, 50:300], px[:17, :33], px[:1, :1], px[:8, :8], px[:15, :16], px[:16, :15], px[:243, :250],
+             px[300:812, :700], rng.integers(0, 256, (64, 48, 3), dtype=np.uint8), px[:200, :123, 1], np.full((40, 40, 3), 255, np.uint8)]
+    for c in cases:
+        for q in (85, 50, 95, 10, 100):
+            assert _abi_encode(hip_lib, np.ascontiguousarray(c), q) == oracle.jpeg_encode(c, q), (c.shape, q)
+    c4 = np.concatenate([px[:100, :90], np.full((100, 90, 1), 7, np.uint8)], axis=2)
+    assert _abi_encode(hip_lib, c4, 85) == oracle.jpeg_encode(c4, 85)
+
+
+def test_encoder_reports_buffer_too_small_by_moving_the_data_pointer(hip_lib, oracle, fixture_bytes):
+    px = np.ascontiguousarray(oracle.jpeg_decode(fixture_bytes["large-sunrise.jpg"])[:256, :256])
+    s = Mat(hip_lib, px)
+    dst = np.zeros(1000, dtype=np.uint8)
+    dmat = hip_lib.opencv_mat_create_empty_from_data(dst.size, dst.ctypes.data_as(C.c_void_p))
+    enc = hip_lib.opencv_encoder_create(b".jpeg", dmat)
+    opts = (C.c_int * 2)(1, 85)
+    assert hip_lib.opencv_encoder_write(enc, s.h, opts, 2)
+    assert hip_lib.opencv_mat_get_data(dmat) != dst.ctypes.data  # opencv.go:890-895 -> ErrBufTooSmall
+    hip_lib.opencv_encoder_release(enc)
+    hip_lib.opencv_mat_release(dmat)
+    s.release()
+
+
+def test_compositing_blend_copy_clear(hip_lib, oracle):
+    rng = np.random.default_rng(9)
+    for scn, dcn in ((4, 4), (3, 4), (4, 3), (1, 4)):
+        src = rng.integers(0, 256, (18, 28, scn), dtype=np.uint8)
+        if scn == 4:
+            src[:6, :, 3] = 0
+            src[6:12, :, 3] = 255
+        canvas = rng.integers(0, 256, (40, 60, dcn), dtype=np.uint8)
+        if dcn == 4:
+            canvas[:20, :, 3] = 0
+        s, d = Mat(hip_lib, src), Mat(hip_lib, canvas)
+        assert hip_lib.opencv_copy_to_region_with_alpha(s.h, d.h, 5, 7, 28, 18) == 0
+        exp = canvas.copy()
+        exp[7:25, 5:33] = oracle.blend_alpha(src, np.ascontiguousarray(canvas[7:25, 5:33]))
+        assert np.array_equal(d.array(), exp), (scn, dcn)
+        assert hip_lib.opencv_mat_clear_to_transparent(d.h, 1, 2, 10, 11) == 0
+        exp[2:13, 1:11] = 0
+        assert np.array_equal(d.array(), exp)
+        assert hip_lib.opencv_mat_clear_to_transparent(d.h, 55, 2, 10, 11) == 2  # OPENCV_ERROR_OUT_OF_BOUNDS
+        assert hip_lib.opencv_copy_to_region(s.h, d.h, 0, 0, 28, 18) == 0
+        s4 = np.concatenate([src[:, :, :1]] * 3, axis=2) if scn == 1 else src[:, :, :3]
+        exp[:18, :28, :3] = s4
+        if dcn == 4:
+            exp[:18, :28, 3] = src[:, :, 3] if scn == 4 else 255
+        assert np.array_equal(d.array(), exp), (scn, dcn, "copy")
+        s.release()
+        d.release()
+
+
+# ------------------------------------------------------------------------------------------ Part C: Go API mirror
+def test_transform_matches_reference_cpu_path(hip_lib, oracle, golden, fixture_bytes):
+    """BASELINE configs[0] and friends: NewDecoder -> ImageOps.Transform(.jpeg, 256x256, Fit, q85)."""
+    import lilliput_amd as la
+
+    ops = la.ImageOps(2048)
+    for name, data in fixture_bytes.items():
+        d = la.Decoder(data)
+        h = d.Header()
+        assert (h["width"], h["height"], h["orientation"]) == (golden[name]["width"], golden[name]["height"], golden[name]["orientation"])
+        assert d.Description() == "JPEG" and h["content_length"] == len(data)
+        out = ops.Transform(d, la.ImageOptions(".jpeg", 256, 256, la.ImageOpsFit, False, {la.JpegQuality: 85}))
+        d.Close()
+        exp = oracle.transform_jpeg_thumbnail(data, 256, 256, 85)
+        if out != exp:  # fractional-scale resample: +-1 LSB allowed, then the bitstreams may differ legitimately
+            a, b = oracle.jpeg_decode(out), oracle.jpeg_decode(exp)
+            assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).max() <= 8, name
+        else:
+            assert hashlib.sha256(out).hexdigest() == golden[name]["thumb256_q85_sha256"], name
+    ops.Close()
+
+
+def test_transform_option_matrix(hip_lib, oracle, fixture_bytes):
+    import lilliput_amd as la
+
+    ops = la.ImageOps(2048)
+    data = fixture_bytes["sunrise.jpg"]  # EXIF orientation 6
+    info = oracle.jpeg_info(data)
+    px = oracle.jpeg_decode(data)
+    for method, w, h, norm in ((la.ImageOpsFit, 50, 50, True), (la.ImageOpsFit, 50, 50, False), (la.ImageOpsFit, 40, 60, True),
+                               (la.ImageOpsResize, 30, 90, False), (la.ImageOpsNoResize, 0, 0, True), (la.ImageOpsFit, 500, 500, True),
+                               (la.ImageOpsFit, 300, 200, True), (la.ImageOpsResize, 200, 20, True)):
+        d = la.Decoder(data)
+        out = ops.Transform(d, la.ImageOptions(".jpeg", w, h, method, norm, {la.JpegQuality: 77}))
+        d.Close()
+        frame = oracle.transform_static(px, info["orientation"], w, h, method, norm)
+        assert out == oracle.jpeg_encode(frame, 77), (method, w, h, norm)
+    with pytest.raises(la.LilliputError) as e:
+        d = la.Decoder(data)
+        ops.Transform(d, la.ImageOptions(".jpeg", 50, 50, la.ImageOpsFit, False, {la.JpegQuality: 85}), dst_cap=300)
+    assert e.value.code == 3  # ErrBufTooSmall
+    small = la.ImageOps(16)
+    with pytest.raises(la.LilliputError) as e:
+        small.Transform(la.Decoder(data), la.ImageOptions(".jpeg", 8, 8))
+    assert e.value.code == 3  # frame does not fit NewImageOps(16) (opencv.go:258-261)
+    ops.Close()
+
+
+# ------------------------------------------------------------------------------------------ Part B: batch
+def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
+    names = list(fixture_bytes)
+    sources = [fixture_bytes[n] for n in names] + [b"not a jpeg", fixture_bytes["large-sunrise.jpg"][:5000]]
+    res = batch.transform(sources, 64, 64, quality=85)
+    for n, r in zip(names, res):
+        assert r.status == 0, n
+        exp = oracle.transform_jpeg_thumbnail(fixture_bytes[n], 64, 64, 85)
+        if r.data != exp:
+            a, b = oracle.jpeg_decode(r.data), oracle.jpeg_decode(exp)
+            assert np.abs(a.astype(int) - b.astype(int)).max() <= 8, n
+    assert res[-2].status == 1 and res[-1].status == 2
+    res2 = batch.transform(sources[:4], 64, 64, quality=85, chunk=1)  # chunking does not change results
+    assert [r.data for r in res2] == [r.data for r in res[:4]]
+
+
+def test_config2_geometry_full_size_properties(batch, oracle):
+    """BASELINE configs[1] at full size: 4096x4096 4:2:0 q90 -> 256x256 q85 (scale 16: integer path, bit-exact)."""
+    from lilliput_amd import synth
+
+    data = synth.synth_jpeg(0, 4096)
+    px, _ = batch.decode_jpeg(data)
+    assert px.shape == (4096, 4096, 3)
+    # size-independent properties: the box mean of the decoded frame is what the thumbnail encodes
+    r = batch.transform([data, data], 256, 256, quality=85)
+    assert r[0].status == 0 and r[0].data == r[1].data
+    s = px.astype(np.int64).reshape(256, 16, 256, 16, 3).sum(axis=(1, 3))
+    box = np.rint(s.astype(np.float32) * np.float32(1 / 256)).astype(np.uint8)
+    assert r[0].data == oracle.jpeg_encode(box, 85)
+    # and the decoded frame itself equals the oracle's (one full-size decode on the CPU, ~seconds)
+    assert np.array_equal(px, oracle.jpeg_decode(data))

@@ -1,0 +1,121 @@
+"""CPU tests of the product's host side: the C ABI library loads and exports every declared symbol, the JPEG
+marker parser / table builder and the Go-mirroring control logic agree with the oracle, and the per-lane
+Huffman logic (run serially through tests/emu) reproduces the oracle's coefficients."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "lilliput_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b((?:opencv|lilliput)_[a-z0-9_]+)\s*\(", hdr))
+    names |= {"CV_INTER_AREA", "CV_INTER_LINEAR", "CV_INTER_CUBIC"}
+    assert len(names) > 50
+    missing = [n for n in sorted(names) if not hasattr(hip_lib, n)]
+    assert not missing, missing
+    assert C.c_int.in_dll(hip_lib, "CV_INTER_AREA").value == 3
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
+    import lilliput_amd
+
+    if hip_lib.lilliput_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(lilliput_amd.LilliputError):
+        lilliput_amd.Batch(0)
+    with pytest.raises(lilliput_amd.LilliputError):
+        d = lilliput_amd.Decoder(open(os.path.join(ROOT, "tests/golden/inputs/coast.jpg"), "rb").read())
+        ops = lilliput_amd.ImageOps(512)
+        ops.Transform(d, lilliput_amd.ImageOptions(".jpeg", 32, 32))
+
+
+def test_control_logic_matches_oracle(hip_lib, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        ow, oh, rw, rh = [int(x) for x in rng.integers(1, 9000, 4)]
+        if rng.random() < 0.3:
+            rh = rw
+        w, h = C.c_int(), C.c_int()
+        hip_lib.lilliput_calculate_expected_size(ow, oh, rw, rh, C.byref(w), C.byref(h))
+        assert (w.value, h.value) == oracle.calculate_expected_size(ow, oh, rw, rh)
+        l, t, cw, ch = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        hip_lib.lilliput_fit_crop_rect(ow, oh, rw, rh, C.byref(l), C.byref(t), C.byref(cw), C.byref(ch))
+        assert (l.value, t.value, cw.value, ch.value) == oracle.fit_crop_rect(ow, oh, rw, rh)
+
+
+def test_content_length_scanners(hip_lib, fixture_bytes):
+    """opencv_test.go:9-220 style cases for detectContentLength / detectAPNG."""
+    def cl(b):
+        a = np.frombuffer(bytes(b), np.uint8)
+        return hip_lib.lilliput_detect_content_length(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size))
+
+    j = fixture_bytes["coast.jpg"]
+    assert cl(j) == len(j)
+    assert cl(j + b"\x00" * 37) == len(j)          # trailing garbage is cut at EOI
+    assert cl(b"\x01\x02\x03") == 3                # neither JPEG nor PNG: everything
+    png = bytes([0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a]) + b"\x00\x00\x00\x00IHDRxxxx" + b"\x00\x00\x00\x00IENDyyyy"
+    assert cl(png + b"junk") == len(png)
+    a = np.frombuffer(png, np.uint8)
+    assert hip_lib.lilliput_detect_apng(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)) == 0
+    apng = png[:8] + b"\x00\x00\x00\x00acTLzzzz" + png[8:]
+    a = np.frombuffer(apng, np.uint8)
+    assert hip_lib.lilliput_detect_apng(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)) == 1
+
+
+@pytest.fixture(scope="module")
+def emu():
+    d = os.path.join(ROOT, "tests", "emu")
+    so = os.path.join(d, "libemu.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "emu_huff.cpp"),
+                    os.path.join(ROOT, "lilliput_amd", "csrc", "lp_jpeg_parse.cpp")], check=True)
+    return C.CDLL(so)
+
+
+def _emu_coefs(emu, data, S, Cc, comp):
+    a = np.frombuffer(data, np.uint8)
+    cap = 1 << 24
+    out = np.empty(cap, np.int16)
+    bw, bh, r, ns, hits = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = emu.emu_decode_coefs(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_uint32(S), C.c_uint32(Cc), C.c_int(comp),
+                              out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(bw), C.byref(bh), C.byref(r), C.byref(ns), C.byref(hits))
+    assert rc == 0, rc
+    return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64), r.value, ns.value
+
+
+@pytest.mark.parametrize("S,Cc", [(64, 32), (256, 64), (1024, 32), (4096, 128), (16384, 512)])
+def test_lane_logic_reproduces_oracle_coefficients(emu, oracle, fixture_bytes, S, Cc):
+    """speculate -> verify (worst-case Jacobi sweeps) -> scan -> write, restart intervals included."""
+    for name in ("sunrise.jpg", "firefox-gray.jpg", "ferry_sunset.jpg", "large-sunrise.jpg"):
+        if name == "large-sunrise.jpg" and S < 256:
+            continue
+        data = fixture_bytes[name]
+        for comp in range(oracle.jpeg_info(data)["ncomp"]):
+            got, rounds, nsub = _emu_coefs(emu, data, S, Cc, comp)
+            assert np.array_equal(got, oracle.jpeg_decode_coefs(data, comp)), (name, comp)
+
+
+def test_lane_logic_other_samplings_and_tables(emu, oracle):
+    import io
+
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rgb = synth.synth_rgb(5, 256)
+    for (w, h) in ((256, 256), (251, 133), (17, 9)):
+        im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
+        for kw in ({"subsampling": 0}, {"subsampling": 1}, {"subsampling": 2}, {"subsampling": 2, "optimize": True},
+                   {"subsampling": 2, "restart_marker_blocks": 3}):
+            b = io.BytesIO()
+            im.save(b, "JPEG", quality=88, **kw)
+            data = b.getvalue()
+            for comp in range(3):
+                got, _, _ = _emu_coefs(emu, data, 256, 64, comp)
+                assert np.array_equal(got, oracle.jpeg_decode_coefs(data, comp)), (w, h, kw, comp)

@@ -1,0 +1,98 @@
+"""Pins the oracle (CPU restatement) against the committed golden vectors: pixels produced by the reference's
+own libjpeg-turbo 3.1.0, and the ThumbHash known answers of /root/reference/thumbhash_test.go:63-81.
+Runs on CPU."""
+import base64
+import hashlib
+
+import numpy as np
+import pytest
+
+
+def test_decode_matches_reference_libjpeg_pixels(oracle, golden, fixture_bytes):
+    for name, g in golden.items():
+        px = oracle.jpeg_decode(fixture_bytes[name])
+        assert px.shape == (g["height"], g["width"], g["channels"]), name
+        assert hashlib.sha256(px.tobytes()).hexdigest() == g["pixels_sha256"], name
+        assert oracle.jpeg_info(fixture_bytes[name])["orientation"] == g["orientation"], name
+
+
+def test_thumbhash_known_answers(oracle, golden, fixture_bytes):
+    """thumbhash_test.go: Transform(NoResize, NormalizeOrientation) -> .thumbhash; pins decode + orientation."""
+    checked = 0
+    for name, g in golden.items():
+        if not g["thumbhash_b64"]:
+            continue
+        data = fixture_bytes[name]
+        info = oracle.jpeg_info(data)
+        frame = oracle.transform_static(oracle.jpeg_decode(data), info["orientation"], info["width"], info["height"], oracle.NO_RESIZE, True)
+        assert base64.b64encode(oracle.thumbhash(frame)).decode() == g["thumbhash_b64"], name
+        checked += 1
+    assert checked == 9
+
+
+def test_thumbnail_bytes_match_reference_path(oracle, golden, fixture_bytes):
+    """configs[0]: Fit 256x256 q85 through the restatement == through the reference's libjpeg (golden hash)."""
+    for name, g in golden.items():
+        out = oracle.transform_jpeg_thumbnail(fixture_bytes[name], 256, 256, 85)
+        assert len(out) == g["thumb256_q85_len"], name
+        assert hashlib.sha256(out).hexdigest() == g["thumb256_q85_sha256"], name
+
+
+def test_restatement_vs_reference_library_when_present(oracle, fixture_bytes):
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    for name, data in fixture_bytes.items():
+        assert np.array_equal(oracle.jpeg_decode(data), oracle.ref_jpeg_decode(data)), name
+        info = oracle.jpeg_info(data)
+        for c in range(info["ncomp"]):
+            assert np.array_equal(oracle.jpeg_decode_coefs(data, c), oracle.ref_jpeg_decode_coefs(data, c)), (name, c)
+    px = oracle.jpeg_decode(fixture_bytes["large-sunrise.jpg"])
+    for crop in (px[:256, :256], px[100:343, 50:300], px[:17, :33], px[:1, :1], px[:243, :250], px[:200, :123, 1]):
+        for q in (85, 50, 95, 10, 100):
+            assert oracle.jpeg_encode(crop, q) == oracle.ref_jpeg_encode(crop, q)
+
+
+def test_area_resize_branches_and_exact_cases(oracle):
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    d, br = oracle.resize_area(src, 96, 64)
+    assert br == 0 and np.array_equal(d, src)
+    d, br = oracle.resize_area(src, 48, 32)  # 2x2 fast path: (a+b+c+d+2)>>2
+    assert br == 1
+    s = src.astype(np.int32)
+    exp = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(d, exp.astype(np.uint8))
+    d, br = oracle.resize_area(src, 24, 16)  # 4x4: round-half-even of sum/16
+    assert br == 1
+    sums = s.reshape(16, 4, 24, 4, 3).sum(axis=(1, 3))
+    assert np.array_equal(d, np.rint(sums.astype(np.float32) * np.float32(1 / 16)).astype(np.uint8))
+    d, br = oracle.resize_area(src, 50, 30)
+    assert br == 2
+    const = np.full((37, 53, 3), 77, np.uint8)
+    d, br = oracle.resize_area(const, 20, 10)
+    assert br == 2 and np.all(np.abs(d.astype(int) - 77) <= 0)
+    d, br = oracle.resize_area(src, 200, 32)
+    assert br == 3
+
+
+def test_orientation_is_a_permutation(oracle):
+    rng = np.random.default_rng(2)
+    src = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    exp = {1: src, 2: src[:, ::-1], 3: src[::-1, ::-1], 4: src[::-1], 5: src.transpose(1, 0, 2), 6: src.transpose(1, 0, 2)[:, ::-1],
+           7: src.transpose(1, 0, 2)[::-1, ::-1], 8: src.transpose(1, 0, 2)[::-1]}
+    for o, e in exp.items():
+        assert np.array_equal(oracle.orientation_transform(src, o), e), o
+
+
+def test_go_control_logic(oracle):
+    # ops.go:243-255
+    assert oracle.calculate_expected_size(1300, 1942, 256, 256) == (256, 256)
+    assert oracle.calculate_expected_size(800, 297, 512, 512) == (297, 297)
+    assert oracle.calculate_expected_size(100, 75, 400, 300) == (100, 75)
+    assert oracle.calculate_expected_size(100, 75, 50, 300) == (50, 300)
+    # SURVEY.md App. A geometries (opencv.go:331-363)
+    assert oracle.fit_crop_rect(4096, 4096, 256, 256) == (0, 0, 4096, 4096)
+    assert oracle.fit_crop_rect(1300, 1942, 256, 256) == (0, 321, 1300, 1300)
+    assert oracle.fit_crop_rect(800, 297, 297, 297) == (251, 0, 297, 297)
+    assert oracle.fit_crop_rect(480, 270, 128, 128) == (105, 0, 270, 270)
+    assert oracle.fit_crop_rect(8192, 6144, 256, 256) == (1024, 0, 6144, 6144)
