@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: images/s for 4096x4096 -> 256x256 JPEG q85 thumbnails
+(ImageOps.Transform hot path: decode -> orientation/crop -> resize -> encode) on N x MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch (default 1024 synthetic 4096x4096 4:2:0 q90 JPEGs per GPU,
+compressed bytes already resident in HBM when the timed region starts; the thumbnails are copied back to the
+host inside the timed region). Images are independent, so ranks shard them with no data-path collective (weak
+scaling: per-GPU work is fixed); RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (measured live with HIP events
+on the engine's stream) and the reference CPU path timed on this box's host cores.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_sources(batch, distinct, size, rank, world):
+    """`distinct` different synthetic JPEGs (seeds 0..distinct-1) tiled to `batch` items. Rank 0 of the node
+    generates them once into a cache directory; the other ranks read them."""
+    from lilliput_amd import synth
+
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_bench_%d_q90" % size)
+    os.makedirs(cache, exist_ok=True)
+    paths = [os.path.join(cache, "synth_%04d.jpg" % i) for i in range(distinct)]
+    if rank == 0:
+        missing = [i for i, p in enumerate(paths) if not os.path.exists(p)]
+        if missing:
+            t = time.time()
+            import multiprocessing as mp
+
+            workers = max(1, min(len(missing), (os.cpu_count() or 2) - 1, 32))
+            with mp.get_context("fork").Pool(workers) as pool:
+                for i, data in zip(missing, pool.map(synth._job, [(i, size, 90) for i in missing])):
+                    with open(paths[i] + ".tmp", "wb") as f:
+                        f.write(data)
+                    os.replace(paths[i] + ".tmp", paths[i])
+            log("[bench] generated %d synthetic %dx%d JPEGs with %d workers in %.1fs" % (len(missing), size, size, workers, time.time() - t))
+    return paths
+
+
+def cpu_baseline(sample_jpegs, budget_s=12.0):
+    """The reference CPU path (real libjpeg-turbo 3.1.0 decode/encode from the reference's own libjpeg.a when
+    oracle/_ref is built, else our C port) on every host core, on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+
+    O.lib()
+    use_ref = O.ref() is not None
+    kind = "reference" if use_ref else "port"
+    t0 = time.time()
+    O.transform_jpeg_thumbnail(sample_jpegs[0], 256, 256, 85, use_ref=use_ref)
+    t1 = time.time() - t0
+    cores = os.cpu_count() or 1
+    per_thread = max(1, int(budget_s / max(t1, 1e-3)))
+    per_thread = min(per_thread, 8)
+    jobs = [sample_jpegs[i % len(sample_jpegs)] for i in range(cores * per_thread)]
+
+    def work(d):  # ctypes releases the GIL: threads run truly in parallel inside the C code
+        return len(O.transform_jpeg_thumbnail(d, 256, 256, 85, use_ref=use_ref))
+
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, jobs))
+    dt = time.time() - t0
+    return {"value": round(len(jobs) / dt, 2), "unit": "images/s", "cores": cores, "kind": kind,
+            "one_core_images_per_s": round(1.0 / t1, 2),
+            "sample": "%d transforms of the same 4096x4096 q90 -> 256x256 q85 workload on %d host threads (%.1fs)" % (len(jobs), cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic source images tiled to the batch")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    import lilliput_amd as la
+
+    paths = make_sources(args.batch, args.distinct, args.size, local_rank, world)
+    barrier()
+    distinct = [open(p, "rb").read() for p in paths]
+    import numpy as np
+
+    arrays = [np.frombuffer(d, dtype=np.uint8) for d in distinct]
+    sources = [arrays[i % len(arrays)] for i in range(args.batch)]
+    c_in = sum(len(distinct[i % len(distinct)]) for i in range(args.batch)) / args.batch
+
+    b = la.Batch(local_rank)
+    t = time.time()
+    b.upload(sources, dst_cap=256 << 10)   # parse headers + H2D of the compressed bytes: NOT in the timed region
+    upload_s = time.time() - t
+
+    def step():
+        b.run(256, 256, la.ImageOpsFit, False, 85, args.chunk)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    stage = {}
+    for _ in range(args.steps):
+        step()
+        for k, v in b.timings().items():
+            stage[k] = stage.get(k, 0.0) + v
+    barrier()
+    elapsed = time.time() - t0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    res = b.download()
+    ok = sum(1 for r in res if r.status == 0)
+    digest = hashlib.sha256(res[0].data).hexdigest()[:16] if res and res[0].status == 0 else None
+    c_out = sum(len(r.data) for r in res) / max(1, len(res))
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / elapsed
+        px = args.size * args.size
+        # Algorithmic bytes per image and kernel, W=H=4096: coefficients 2 B x 1.5 x W x H, planes 1.5 x W x H.
+        coef_b, plane_b, frame_b = 3 * px, 1.5 * px, 3 * px
+        kernels = {
+            "k_huff_count<false> (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
+            "k_huff_count<true> (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
+            "k_huff_write (entropy decode -> coefficients)": (stage.get("huff_write_ms", 0.0), c_in + coef_b),
+            "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
+            "k_idct": (stage.get("idct_ms", 0.0), coef_b + plane_b),
+            "k_ycc_to_frame": (stage.get("color_ms", 0.0), plane_b + frame_b),
+            "k_resize_area_fast": (stage.get("resize_ms", 0.0), frame_b + 3 * 256 * 256),
+            "k_enc_* (JPEG encode)": (stage.get("encode_ms", 0.0), 3 * 256 * 256 + c_out),
+        }
+        per_rank_images = args.batch * args.steps
+        dom = max(kernels.items(), key=lambda kv: kv[1][0])
+        dom_ms, dom_bytes = dom[1]
+        achieved = (dom_bytes * per_rank_images) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        breakdown = {k: {"ms_per_image": round(v[0] / per_rank_images, 5), "algorithmic_GBps": round(v[1] * per_rank_images / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                     for k, v in kernels.items()}
+        out = {
+            "metric": "images/sec (4096x4096->256x256 JPEG q85)",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU -> 256x256 JPEG q85, ImageOpsFit (BASELINE configs[1])" % (args.batch, args.size, args.size),
+                       "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out),
+                       "parallelism": "independent images sharded per rank, no data-path collective", "ok_images": ok, "first_output_sha256_16": digest,
+                       "end_to_end_algorithmic_bytes_per_image": int(c_in + 2 * plane_b + 3 * 256 * 256 + c_out),
+                       "end_to_end_hbm_roofline_frac": round((c_in + 2 * plane_b + 3 * 256 * 256 + c_out) * value / world / (HBM_PEAK_GBS * 1e9), 5),
+                       "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps), "upload_s_not_timed": round(upload_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "note": "achieved = algorithmic bytes per launch / launch duration (HIP events on the engine stream); "
+                                 "the entropy decoder is latency/ALU bound, not HBM bound (SURVEY.md 8d)",
+                         "per_kernel": breakdown},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(distinct[: min(4, len(distinct))])
+            except Exception as e:  # the checker is optional for the measurement itself
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    b.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,8 +170,9 @@ int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* item
 int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);
 int lilliput_hip_batch_run(lilliput_hip_batch b, const lilliput_batch_options* opt);
 int lilliput_hip_batch_download(lilliput_hip_batch b, lilliput_batch_item* items, size_t n);
-/* Per-stage device milliseconds of the last run: unstuff, huffman, idct, colour, resize, encode, then verify rounds. */
-void lilliput_hip_batch_timings(lilliput_hip_batch b, float out_ms[6], int* verify_rounds);
+/* Per-stage device milliseconds of the last run (HIP events on the engine's stream): unstuff, huffman (total), idct,
+ * colour, resize, encode, then the huffman breakdown: speculate, verify, scan, write; plus the verify rounds. */
+void lilliput_hip_batch_timings(lilliput_hip_batch b, float out_ms[10], int* verify_rounds);
 /* Decoder tuning: subsequence bits / checkpoint spacing (0 = automatic). */
 void lilliput_hip_batch_set_subsequence(lilliput_hip_batch b, unsigned S, unsigned C);
 

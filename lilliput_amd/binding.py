@@ -290,10 +290,10 @@ class Batch:
         return self._results()
 
     def timings(self):
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 10)()
         r = C.c_int()
         lib().lilliput_hip_batch_timings(self._h, ms, C.byref(r))
-        keys = ("unstuff_ms", "huffman_ms", "idct_ms", "color_ms", "resize_ms", "encode_ms")
+        keys = ("unstuff_ms", "huffman_ms", "idct_ms", "color_ms", "resize_ms", "encode_ms", "huff_spec_ms", "huff_verify_ms", "huff_scan_ms", "huff_write_ms")
         d = dict(zip(keys, [float(x) for x in ms]))
         d["verify_rounds"] = r.value
         return d

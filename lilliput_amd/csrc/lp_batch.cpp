@@ -61,9 +61,10 @@ void lilliput_hip_batch_destroy(lilliput_hip_batch b) { delete static_cast<LpBat
 
 void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C) { static_cast<LpBatch*>(bb)->eng.set_subsequence(S, C); }
 
-void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[6], int* verify_rounds)
+void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* verify_rounds)
 {
     const LpTimings& t = static_cast<LpBatch*>(bb)->eng.timings();
+    out_ms[6] = t.huff_spec_ms; out_ms[7] = t.huff_verify_ms; out_ms[8] = t.huff_scan_ms; out_ms[9] = t.huff_write_ms;
     out_ms[0] = t.unstuff_ms; out_ms[1] = t.huff_ms; out_ms[2] = t.idct_ms; out_ms[3] = t.color_ms; out_ms[4] = t.resize_ms; out_ms[5] = t.encode_ms;
     if (verify_rounds) *verify_rounds = (int)t.verify_rounds;
 }
@@ -112,7 +113,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
     size_t max_px = 1;
     for (auto& h : b->hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
     size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(24ull << 30) / (max_px * 12)));
-    float acc[6] = {0, 0, 0, 0, 0, 0};
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
     eng.enable_timing(true);
     for (size_t first = 0; first < nv; first += chunk) {
@@ -134,7 +135,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
         int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data());
         if (rc == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
-        { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; rounds = std::max(rounds, t.verify_rounds); }
+        { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); }
         // orientation (ops.go:392: unconditional)
         std::vector<LpOrientOp> oops;
         std::vector<int> oidx;
@@ -228,7 +229,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         }
     }
     b->eng.enable_timing(false);
-    b->eng.set_timings(LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds}); // read by lilliput_hip_batch_timings
+    b->eng.set_timings(LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}); // read by lilliput_hip_batch_timings
     return LILLIPUT_OK;
 }
 

@@ -114,17 +114,33 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         j.nchunks = (j.raw_len + 4095) / 4096;
         h_src_[(size_t)i] = j;
     }
-    if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) || !h_stage_.ensure(raw_bytes + 64)) {
+    const size_t kStage = 256u << 20; // pinned staging window
+    if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) ||
+        !h_stage_.ensure(std::min(raw_bytes, kStage) + (16u << 20) + 64)) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
     }
     uint8_t* stage = h_stage_.as<uint8_t>();
+    size_t win_begin = 0; // arena offset of the first byte staged in the current window
+    auto flush = [&](size_t win_end) -> bool {
+        if (win_end == win_begin) return true;
+        if (!check(hipMemcpyAsync(d_raw_.as<uint8_t>() + win_begin, stage, win_end - win_begin, hipMemcpyHostToDevice, stream_), "H2D raw")) return false;
+        if (!check(hipStreamSynchronize(stream_), "upload sync")) return false;
+        win_begin = win_end;
+        return true;
+    };
     for (int i = 0; i < n; i++) {
         const LpJpeg& j = h_src_[(size_t)i];
-        memcpy(stage + j.raw_off, srcs[i].data + hdrs[i].ecs_off, j.raw_len);
-        memset(stage + j.raw_off + j.raw_len, 0, 32);
+        const size_t end = j.raw_off + j.raw_len + 32;
+        if (end - win_begin > h_stage_.cap - 64) {
+            if (!flush(j.raw_off)) return LP_ERR_DEVICE;
+            if (end - win_begin > h_stage_.cap - 64 && !h_stage_.ensure(end - win_begin + 64)) return LP_ERR_DEVICE;
+            stage = h_stage_.as<uint8_t>();
+        }
+        memcpy(stage + (j.raw_off - win_begin), srcs[i].data + hdrs[i].ecs_off, j.raw_len);
+        memset(stage + (j.raw_off - win_begin) + j.raw_len, 0, 32);
     }
-    if (raw_bytes && !check(hipMemcpyAsync(d_raw_.p, stage, raw_bytes, hipMemcpyHostToDevice, stream_), "H2D raw")) return LP_ERR_DEVICE;
+    if (!flush(raw_bytes)) return LP_ERR_DEVICE;
     if (!h_huffs_.empty() &&
         !check(hipMemcpyAsync(d_huffs_.p, h_huffs_.data(), sizeof(LpHuffSet) * h_huffs_.size(), hipMemcpyHostToDevice, stream_), "H2D huffs"))
         return LP_ERR_DEVICE;
@@ -192,6 +208,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
     lp_launch_huff_count(stream_, false, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
                          d_ckpt_.as<LpCkpt>(), d_exit_.as<LpSubState>(), d_entry_.as<LpSubState>(), d_tot_.as<LpSubSum>(), d_changed_.as<uint32_t>(),
                          S_, C_, K_);
+    if (timing_) (void)hipEventRecord(ev_[8], stream_);
     uint32_t rounds = 0;
     uint32_t* h_changed = h_small_.as<uint32_t>();
     for (;;) {
@@ -205,7 +222,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
         if (*h_changed == 0 || rounds >= 4096) break;
     }
     tm_.verify_rounds = rounds;
+    if (timing_) (void)hipEventRecord(ev_[9], stream_);
     lp_launch_sub_scan(stream_, di, ds, (uint32_t)n, d_tot_.as<LpSubSum>(), d_prefix_.as<LpSubSum>());
+    if (timing_) (void)hipEventRecord(ev_[10], stream_);
     lp_launch_huff_write(stream_, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
                          d_exit_.as<LpSubState>(), d_prefix_.as<LpSubSum>(), d_coef_.as<int16_t>());
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
@@ -240,6 +259,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
         (void)hipEventElapsedTime(&tm_.huff_ms, ev_[1], ev_[2]);
         (void)hipEventElapsedTime(&tm_.idct_ms, ev_[2], ev_[3]);
         (void)hipEventElapsedTime(&tm_.color_ms, ev_[3], ev_[4]);
+        (void)hipEventElapsedTime(&tm_.huff_spec_ms, ev_[1], ev_[8]);
+        (void)hipEventElapsedTime(&tm_.huff_verify_ms, ev_[8], ev_[9]);
+        (void)hipEventElapsedTime(&tm_.huff_scan_ms, ev_[9], ev_[10]);
+        (void)hipEventElapsedTime(&tm_.huff_write_ms, ev_[10], ev_[2]);
     }
     return rc;
 }

@@ -65,6 +65,7 @@ struct LpEncodeReq {
 struct LpTimings {
     float unstuff_ms, huff_ms, idct_ms, color_ms, resize_ms, encode_ms;
     uint32_t verify_rounds;
+    float huff_spec_ms, huff_verify_ms, huff_scan_ms, huff_write_ms; // breakdown of huff_ms
 };
 
 class LpEngine {
@@ -122,7 +123,7 @@ private:
     bool timing_ = false;
     std::string err_;
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev_[8] = {};
+    hipEvent_t ev_[16] = {};
     uint32_t S_cfg_ = 0, C_cfg_ = 0;
     LpTimings tm_ = {};
 
