@@ -118,30 +118,91 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
     eng.enable_timing(true);
     for (size_t first = 0; first < nv; first += chunk) {
         const int cnt = (int)std::min(chunk, nv - first);
-        // frame heap: decoded frame (+ oriented copy) + resized frame per image
+        // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
         size_t need = 0;
         for (int k = 0; k < cnt; k++) {
             const LpJpeg& j = b->hdrs[first + k].j;
-            size_t fb = (size_t)j.width * j.height * (j.ncomp == 1 ? 1 : 3);
-            need += fb + 512;
-            if (j.orientation != 1) need += fb + 512;
-            need += (size_t)std::max(1, opt->width) * std::max(1, opt->height) * 3 + 512;
-            if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) need += 0;
+            const bool swap = j.orientation >= 5;
+            const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
+            LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
+                                                      opt->normalize_orientation != 0, OW, OH);
+            int ix, iy;
+            const bool fused = plan.resize && lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) == 1;
+            const size_t cn = j.ncomp == 1 ? 1 : 3, fb = (size_t)j.width * j.height * cn;
+            if (!fused) need += fb + 512 + (j.orientation != 1 ? fb + 512 : 0);
+            if (plan.resize) need += (size_t)plan.out_w * plan.out_h * cn + 512;
         }
         if (!eng.heap_reserve(need + 4096)) { lp_set_error("frame heap allocation failed"); return LILLIPUT_ERR_DEVICE; }
         eng.heap_reset();
+        // Plan every image first (ops.go:449-479 + opencv.go:294-374). Integer-scale area resizes take the fused
+        // path (planes -> thumbnail, orientation and crop folded into the addressing); everything else goes through
+        // a materialised BGR frame exactly like the one-image ABI does.
         std::vector<LpFrame> frames((size_t)cnt);
         std::vector<int> st((size_t)cnt, 0);
+        std::vector<uint8_t> want((size_t)cnt, 1);
+        std::vector<LpOpsPlan> plans((size_t)cnt);
+        std::vector<LpFusedOp> fops;
+        std::vector<int> fidx;
         memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
-        int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data());
+        for (int k = 0; k < cnt; k++) {
+            const LpJpeg& j = b->hdrs[first + k].j;
+            const bool swap = j.orientation >= 5;
+            const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
+            LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
+                                                      opt->normalize_orientation != 0, OW, OH);
+            plans[(size_t)k] = plan;
+            int ix = 1, iy = 1;
+            if (!plan.resize || lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) != 1) continue;
+            // oriented-frame rectangle of destination (dx, dy) -> rectangle of the un-oriented decoded image (cv::ExifTransform inverse)
+            auto map = [&](int dx, int dy, int* fx, int* fy) {
+                const int ox0 = plan.crop_x + dx * ix, oy0 = plan.crop_y + dy * iy;
+                switch (j.orientation) {
+                case 2: *fx = OW - ox0 - ix; *fy = oy0; break;
+                case 3: *fx = OW - ox0 - ix; *fy = OH - oy0 - iy; break;
+                case 4: *fx = ox0; *fy = OH - oy0 - iy; break;
+                case 5: *fx = oy0; *fy = ox0; break;
+                case 6: *fx = oy0; *fy = OW - ox0 - ix; break;
+                case 7: *fx = OH - oy0 - iy; *fy = OW - ox0 - ix; break;
+                case 8: *fx = OH - oy0 - iy; *fy = ox0; break;
+                default: *fx = ox0; *fy = oy0; break;
+                }
+            };
+            LpFusedOp op;
+            memset(&op, 0, sizeof(op));
+            op.img = (uint32_t)k;
+            op.rw = (uint32_t)(swap ? iy : ix);
+            op.rh = (uint32_t)(swap ? ix : iy);
+            int ax, ay, bx, by;
+            map(0, 0, &op.x0, &op.y0);
+            map(1, 0, &ax, &ay);
+            map(0, 1, &bx, &by);
+            op.dxx = ax - op.x0; op.dxy = ay - op.y0; op.dyx = bx - op.x0; op.dyy = by - op.y0;
+            op.inv_area = 1.f / (float)(ix * iy);
+            op.round_2x2 = (ix == 2 && iy == 2) ? 1 : 0;
+            op.dst.w = (uint32_t)plan.out_w; op.dst.h = (uint32_t)plan.out_h; op.dst.cn = j.ncomp == 1 ? 1 : 3;
+            op.dst.stride = op.dst.w * op.dst.cn;
+            uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);
+            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            op.dst.off = (uint64_t)(uintptr_t)p;
+            fops.push_back(op);
+            fidx.push_back(k);
+            want[(size_t)k] = 0;
+        }
+        int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data(), want.data());
         if (rc == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
         { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); }
-        // orientation (ops.go:392: unconditional)
+        std::vector<LpFrame> final_frames = frames;
+        if (!fops.empty()) {
+            if (eng.fused_resample(fops.data(), (int)fops.size())) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            acc[4] += eng.timings().resize_ms;
+            for (size_t q = 0; q < fops.size(); q++) final_frames[(size_t)fidx[q]] = fops[q].dst;
+        }
+        // orientation (ops.go:392: unconditional) for the images that kept a frame
         std::vector<LpOrientOp> oops;
         std::vector<int> oidx;
         for (int k = 0; k < cnt; k++) {
             const LpJpeg& j = b->hdrs[first + k].j;
-            if (st[(size_t)k] || j.orientation == 1) continue;
+            if (st[(size_t)k] || j.orientation == 1 || !want[(size_t)k]) continue;
             LpOrientOp op;
             memset(&op, 0, sizeof(op));
             op.src = frames[(size_t)k];
@@ -159,19 +220,16 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         }
         if (!oops.empty()) {
             if (eng.orient(oops.data(), (int)oops.size())) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
-            for (size_t q = 0; q < oops.size(); q++) frames[(size_t)oidx[q]] = oops[q].dst;
+            for (size_t q = 0; q < oops.size(); q++) { frames[(size_t)oidx[q]] = oops[q].dst; final_frames[(size_t)oidx[q]] = oops[q].dst; }
         }
-        // fit / resize (ops.go:449-479 + opencv.go:294-374)
+        // fit / resize through frames
         std::vector<LpResizeReq> rqs;
         std::vector<LpFrame> rdst;
         std::vector<int> ridx;
-        std::vector<LpFrame> final_frames = frames;
         for (int k = 0; k < cnt; k++) {
-            if (st[(size_t)k]) continue;
-            const LpJpeg& j = b->hdrs[first + k].j;
+            if (st[(size_t)k] || !want[(size_t)k]) continue;
             const LpFrame& f = frames[(size_t)k];
-            LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
-                                                      opt->normalize_orientation != 0, (int)f.w, (int)f.h);
+            const LpOpsPlan& plan = plans[(size_t)k];
             if (!plan.resize) continue;
             LpResizeReq rq;
             rq.src = f;

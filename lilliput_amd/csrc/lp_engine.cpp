@@ -150,7 +150,7 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
 }
 
 // Lay out the working arenas for images [first, first+n) of the uploaded set and run every decode stage.
-int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
+int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
@@ -169,7 +169,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
         j.chunk_off = tot_chunks_;
         tot_chunks_ += j.nchunks;
         j.clean_off = clean_words;
-        j.clean_cap_words = j.raw_len / 4 + 32;
+        {   // whole groups of 64 interleaved subsequences (lp_clean_addr), plus slack for reads past the end
+            const uint32_t grp = 64u * (S_ / 32u);
+            j.clean_cap_words = (j.raw_len / 4 + 64 + grp - 1) / grp * grp;
+        }
         clean_words += j.clean_cap_words;
         j.sub_off = tot_sub_;
         j.sub_cap = (uint32_t)(((uint64_t)j.raw_len * 8 + S_ - 1) / S_) + 1;
@@ -226,7 +229,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
     lp_launch_sub_scan(stream_, di, ds, (uint32_t)n, d_tot_.as<LpSubSum>(), d_prefix_.as<LpSubSum>());
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
     lp_launch_huff_write(stream_, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
-                         d_exit_.as<LpSubState>(), d_prefix_.as<LpSubSum>(), d_coef_.as<int16_t>());
+                         d_exit_.as<LpSubState>(), d_prefix_.as<LpSubSum>(), d_coef_.as<int16_t>(), S_);
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int16_t>(), d_planes_.as<uint8_t>());
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
@@ -235,6 +238,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
         const LpJpeg& j = h_imgs_[(size_t)i];
         LpFrame& f = frames[i];
         f.w = j.width; f.h = j.height; f.cn = j.ncomp == 1 ? 1 : 3; f.stride = f.w * f.cn;
+        if (want_frame && !want_frame[i]) { f.off = 0; continue; }
         if (!f.off) {
             uint8_t* p = heap_alloc((size_t)f.stride * f.h);
             if (!p) { err_ = "frame heap exhausted"; return LP_ERR_DEVICE; }
@@ -267,7 +271,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status)
     return rc;
 }
 
-int LpEngine::decode_uploaded(int first, int n, LpFrame* frames, int* status) { return run_decode(first, n, frames, status); }
+int LpEngine::decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame)
+{
+    return run_decode(first, n, frames, status, want_frame);
+}
 
 int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
 {
@@ -291,7 +298,7 @@ int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
 {
     int rc = upload_jpegs(srcs, n, hdrs);
     if (rc) return rc;
-    return run_decode(0, n, frames, status);
+    return run_decode(0, n, frames, status, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +443,23 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
     if (!check(hipStreamSynchronize(stream_), "resize sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "resize kernels")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);
+    return LP_OK;
+}
+
+int LpEngine::fused_resample(const LpFusedOp* ops, int n)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (n <= 0) return LP_OK;
+    if (!d_fops_.ensure(sizeof(LpFusedOp) * (size_t)n)) return LP_ERR_DEVICE;
+    uint32_t max_px = 0;
+    for (int i = 0; i < n; i++) max_px = std::max(max_px, ops[i].dst.w * ops[i].dst.h);
+    if (!check(hipMemcpyAsync(d_fops_.p, ops, sizeof(LpFusedOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D fused ops")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    lp_launch_resample_fused(stream_, d_imgs_.as<LpJpeg>(), d_fops_.as<LpFusedOp>(), (uint32_t)n, max_px, d_planes_.as<uint8_t>());
+    if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    if (!check(hipStreamSynchronize(stream_), "fused resample sync")) return LP_ERR_DEVICE;
+    if (!check(hipGetLastError(), "fused resample kernel")) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);
     return LP_OK;
 }

@@ -91,7 +91,10 @@ public:
     int decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs, LpFrame* frames, int* status);
     // Device-resident variant used by the bench: ECS bytes were uploaded earlier with upload_jpegs().
     int upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs);
-    int decode_uploaded(int first, int n, LpFrame* frames, int* status);
+    // want_frame (optional, per image): 0 = keep only the planes (the image will go through fused_resample)
+    int decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame = nullptr);
+    // planes of the current decode range -> thumbnails, see LpFusedOp
+    int fused_resample(const LpFusedOp* ops, int n);
     size_t uploaded_count() const { return h_src_.size(); }
     const LpJpeg& uploaded(size_t i) const { return h_src_[i]; }
     // stage-level read-back for parity tests (valid after a decode of the current range)
@@ -116,7 +119,7 @@ public:
 
 private:
     bool check(hipError_t e, const char* what);
-    int run_decode(int first, int n, LpFrame* frames, int* status);
+    int run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame);
 
     int device_ = 0;
     bool ok_ = false;
@@ -145,7 +148,7 @@ private:
     size_t heap_used_ = 0;
 
     // resize / orient
-    LpDevBuf d_ops_, d_taps_, d_ranges_;
+    LpDevBuf d_ops_, d_taps_, d_ranges_, d_fops_;
     // encode
     std::vector<LpEncJob> h_jobs_;
     LpDevBuf d_jobs_, d_estates_, d_ecoef_, d_blkbits_, d_bits_, d_hdrs_, d_out_;

@@ -34,8 +34,18 @@
      38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, \
      63, 63}
 
+// Layout of the unstuffed stream in HBM: the stream is cut into subsequences of WPS = S/32 words; groups of 64
+// consecutive subsequences are stored word-interleaved, so that when the 64 lanes of a wave each fetch "their next
+// word" the accesses fall into a few contiguous 256-byte rows (coalesced HBM row loads) instead of 64 cache lines.
+LP_HD uint32_t lp_clean_addr(uint32_t widx, uint32_t wps)
+{
+    uint32_t s = widx / wps, w = widx - s * wps;
+    return ((s >> 6) * wps + w) * 64u + (s & 63u);
+}
+
 // Memory policy M must provide:
-//   uint32_t word(uint32_t widx)            big-endian-corrected 32-bit word of the clean stream
+//   uint32_t word(uint32_t widx)            big-endian-corrected 32-bit word of the clean stream (applies lp_clean_addr)
+//   bool any(bool)                          wave vote (host emulation: identity)
 //   uint32_t lut(uint32_t tbl, uint32_t i)  first-level Huffman lookup
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables for long codes
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
@@ -46,6 +56,7 @@ struct LpLane {
     uint64_t buf;       // next bits, left aligned
     int avail;          // valid bits in buf
     uint32_t widx;      // next word to load
+    uint32_t pending;   // == word(widx), fetched one iteration ahead by every lane of the wave at once
     uint32_t p;         // bit position of the next unread bit
     uint32_t b, z;      // block-in-MCU, zigzag index
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
@@ -54,7 +65,7 @@ struct LpLane {
     uint32_t total_bits;
 
     LP_HD LpLane(const M& m_, const LpJpeg& img_, uint32_t n_rst_, uint32_t total_bits_)
-        : m(m_), img(img_), buf(0), avail(0), widx(0), p(0), b(0), z(0), next_rst(0), rst_k(0), n_rst(n_rst_),
+        : m(m_), img(img_), buf(0), avail(0), widx(0), pending(0), p(0), b(0), z(0), next_rst(0), rst_k(0), n_rst(n_rst_),
           total_bits(total_bits_) {}
 
     LP_HD void seek(uint32_t pos)
@@ -66,7 +77,11 @@ struct LpLane {
         buf = ((w0 << 32) | w1) << off;
         avail = 64 - (int)off;
         widx += 2;
+        pending = m.word(widx);
     }
+    // Wave-uniform fetch of the next word: issued by ALL lanes every iteration, consumed (maybe) one iteration later,
+    // so the load latency overlaps a whole decode step and never sits behind a divergent branch.
+    LP_HD void prefetch() { pending = m.word(widx); }
     LP_HD void start(uint32_t pos, uint32_t bz)
     {
         seek(pos);
@@ -84,7 +99,7 @@ struct LpLane {
     LP_HD void refill()
     {
         if (avail <= 32) {
-            buf |= (uint64_t)m.word(widx) << (32 - avail);
+            buf |= (uint64_t)pending << (32 - avail);
             avail += 32;
             widx++;
         }
@@ -101,7 +116,6 @@ struct LpLane {
     // the lane jumped to the boundary (DC predictors must be reset by the caller).
     LP_HD bool restart_check()
     {
-        refill();
         int32_t rem = (int32_t)(next_rst - p);
         if (rem >= 8) return false;
         bool jump = rem <= 0;
@@ -126,7 +140,6 @@ struct LpLane {
     LP_HD Sym step()
     {
         Sym r;
-        refill();
         r.is_dc = (z == 0);
         r.comp = img.blk_comp[b];
         uint32_t tbl = r.is_dc ? img.dc_tbl[r.comp] : img.ac_tbl[r.comp];
@@ -215,7 +228,12 @@ LP_HD bool lp_count_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint32_t
     LpSubSum sum;
     lp_sum_zero(sum);
     uint32_t k = 0;
-    for (;;) {
+    bool done = false, spliced = false;
+    // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off.
+    while (m.any(!done)) {
+        L.refill();
+        L.prefetch();
+        if (done) continue;
         if (L.z == 0 && L.restart_check()) {
             sum.nreset++;
             for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
@@ -242,17 +260,21 @@ LP_HD bool lp_count_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint32_t
                     ckpt[j].sum = cj;
                 }
                 *total = nt;
-                return false; // exit state unchanged
+                done = true;
+                spliced = true;
+                break;
             }
             ckpt[k].st = st;
             ckpt[k].sum = sum;
             k++;
         }
-        if (L.p >= sub_end) break;
+        if (done) continue;
+        if (L.p >= sub_end) { done = true; continue; }
         if (L.z == 0) sum.nblk++;
         typename LpLane<M>::Sym s = L.step();
         if (s.is_dc) sum.dc[s.comp] += s.val;
     }
+    if (spliced) return false; // exit state unchanged
     LpSubState ne;
     ne.p = L.p;
     ne.bz = L.state_bz();
@@ -263,8 +285,14 @@ LP_HD bool lp_count_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint32_t
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
-//   void begin_block(); void put(uint32_t natural_idx, int32_t v); void end_block(uint32_t comp, uint32_t bx, uint32_t by);
+//   void put(uint32_t natural_idx, int32_t v);          store one coefficient of the block being decoded
+//   void end_block(uint32_t comp, uint32_t bx, uint32_t by);   the block is complete (queued for flushing)
+//   bool stalled();                                      no free slot: the lane must wait for the next flush
+//   void flush();                                        wave-uniform: write out every queued block
 // Returns the number of blocks written.
+#ifndef LP_FLUSH_EVERY
+#define LP_FLUSH_EVERY 4
+#endif
 template <class M, class Sink>
 LP_HD uint32_t lp_write_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint32_t total_bits, LpSubState entry,
                              uint32_t end_p, const LpSubSum& prefix, const uint8_t* zigzag, Sink& sink)
@@ -274,19 +302,22 @@ LP_HD uint32_t lp_write_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint
     uint32_t blk = prefix.nblk;
     int32_t pred[LP_MAX_COMP];
     for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = prefix.dc[c];
-    bool writing = false;
-    uint32_t written = 0;
+    bool writing = false, done = false;
+    uint32_t written = 0, iter = 0;
     // MCU coordinates of the current block, maintained incrementally
     uint32_t mcu = blk / img.bpm;
     uint32_t mx = mcu % img.mcus_x, my = mcu / img.mcus_x;
-    for (;;) {
+    while (m.any(!done)) {
+        L.refill();
+        L.prefetch();
+        if ((++iter % LP_FLUSH_EVERY) == 0) sink.flush();
+        if (done || sink.stalled()) continue;
         if (L.z == 0) {
             if (L.restart_check())
                 for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = 0;
-            if (L.p >= end_p || blk >= img.total_blocks) break;
+            if (L.p >= end_p || blk >= img.total_blocks) { done = true; continue; }
             writing = true;
-            sink.begin_block();
-        } else if (L.p >= total_bits) break; // truncated stream
+        } else if (L.p >= total_bits) { done = true; continue; } // truncated stream
         uint32_t bcur = L.b;
         typename LpLane<M>::Sym s = L.step();
         if (writing) {
@@ -308,5 +339,6 @@ LP_HD uint32_t lp_write_pass(const M& m, const LpJpeg& img, uint32_t n_rst, uint
             }
         }
     }
+    sink.flush();
     return written;
 }

@@ -148,15 +148,16 @@ __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__
         st.nsub = (uint32_t)((bits + S - 1) / S);
     }
     // zero the tail words so that reads past the end of the stream are deterministic
-    if (t < 12) {
+    if (t < 16) {
         uint32_t w = (ta >> 2) + t;
-        if (w < img.clean_cap_words) clean_arena[img.clean_off + w] = 0;
+        uint32_t a = lp_clean_addr(w, S / 32);
+        if (a < img.clean_cap_words) clean_arena[img.clean_off + a] = 0;
     }
 }
 
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
                                                                const uint2* __restrict__ chunk_cnt, uint32_t* __restrict__ clean_arena,
-                                                               uint32_t* __restrict__ rst_bits)
+                                                               uint32_t* __restrict__ rst_bits, uint32_t S)
 {
     __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
     __shared__ uint32_t s_tmp[8];
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
         }
         if (km & (1u << j)) {
             uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
-            if (cpos < cap) out[cpos ^ 3] = (uint8_t)c; // big-endian words: bit 31 of word 0 is the first bit of the stream
+            // big-endian words (bit 31 of word 0 is the first bit of the stream), lane-interleaved word layout
+            if (cpos < cap) out[(size_t)lp_clean_addr(cpos >> 2, S / 32) * 4 + (3 - (cpos & 3))] = (uint8_t)c;
             cpos++;
         }
     }
@@ -194,7 +196,9 @@ struct DevMem {
     const uint32_t* words;
     const LpHuffSet* hs; // LDS
     const uint32_t* rst;
-    __device__ __forceinline__ uint32_t word(uint32_t w) const { return words[w]; }
+    uint32_t wps;        // words per subsequence (S / 32)
+    __device__ __forceinline__ uint32_t word(uint32_t w) const { return words[lp_clean_addr(w, wps)]; }
+    __device__ __forceinline__ bool any(bool p) const { return __any(p); }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void k_huff_count(const LpJpeg* __restrict__ i
     if (sub >= nsub || sub >= img.sub_cap) return;
     if (VERIFY && sub == 0) return;
     const uint32_t g = img.sub_off + sub;
-    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off};
+    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off, S / 32};
     LpSubState entry;
     if (VERIFY) {
         uint64_t raw = *reinterpret_cast<const volatile uint64_t*>(&exits[g - 1]);
@@ -283,24 +287,43 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
 }
 
+// Coefficient sink of the WRITE pass: NSLOT 64-coefficient LDS slots per lane (16-byte chunks XOR-swizzled by lane to
+// spread banks). A finished block is only queued; flush() runs at wave-uniform points so that the 8x(ds_read_b128 +
+// global_store_dwordx4 + ds_write_b128) per block execute with most lanes active instead of once per lane divergently.
+#define LP_NSLOT 1
 struct DevSink {
-    int16_t* slot;          // this lane's 64-coefficient LDS slot (kept zero between blocks)
+    int16_t* slots;         // this lane's LP_NSLOT x 64 coefficients (kept zero between blocks)
     uint32_t l7;
+    uint32_t cur;
+    int16_t* dst[LP_NSLOT]; // queued destination per slot (nullptr = free); (int16_t*)1 = drop (out of range)
     int16_t* coef_arena;
     const LpJpeg* img;
-    __device__ __forceinline__ void begin_block() {}
-    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slot[(((nat >> 3) ^ l7) << 3) | (nat & 7)] = (int16_t)v; }
+    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slots[cur * 64 + ((((nat >> 3) ^ l7) << 3) | (nat & 7))] = (int16_t)v; }
     __device__ __forceinline__ void end_block(uint32_t c, uint32_t bx, uint32_t by)
     {
         const bool ok = bx < img->bw[c] && by < img->bh[c];
-        uint4* dst = reinterpret_cast<uint4*>(coef_arena + img->coef_off[c] + ((size_t)by * img->bw[c] + bx) * 64);
-        uint4* s = reinterpret_cast<uint4*>(slot);
-        const uint4 zero = make_uint4(0, 0, 0, 0);
+        dst[cur] = ok ? coef_arena + img->coef_off[c] + ((size_t)by * img->bw[c] + bx) * 64 : reinterpret_cast<int16_t*>(1);
+        cur = (cur + 1 == LP_NSLOT) ? 0 : cur + 1;
+    }
+    __device__ __forceinline__ bool stalled() const { return dst[cur] != nullptr; }
+    __device__ __forceinline__ void flush()
+    {
 #pragma unroll
-        for (uint32_t ch = 0; ch < 8; ch++) {
-            uint4 v = s[ch ^ l7];
-            if (ok) dst[ch] = v;
-            s[ch ^ l7] = zero;
+        for (uint32_t sl = 0; sl < LP_NSLOT; sl++) {
+            int16_t* d = dst[sl];
+            if (d) {
+                uint4* s = reinterpret_cast<uint4*>(slots + sl * 64);
+                uint4* o = reinterpret_cast<uint4*>(d);
+                const uint4 zero = make_uint4(0, 0, 0, 0);
+                const bool wr = d != reinterpret_cast<int16_t*>(1);
+#pragma unroll
+                for (uint32_t ch = 0; ch < 8; ch++) {
+                    uint4 v = s[ch ^ l7];
+                    if (wr) o[ch] = v;
+                    s[ch ^ l7] = zero;
+                }
+                dst[sl] = nullptr;
+            }
         }
     }
 };
@@ -308,10 +331,10 @@ struct DevSink {
 __global__ __launch_bounds__(256) void k_huff_write(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                                     const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                     const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
-                                                    const LpSubSum* __restrict__ prefixes, int16_t* __restrict__ coef_arena)
+                                                    const LpSubSum* __restrict__ prefixes, int16_t* __restrict__ coef_arena, uint32_t S)
 {
     __shared__ LpHuffSet s_hs;
-    __shared__ __attribute__((aligned(16))) int16_t s_slots[256 * 64];
+    __shared__ __attribute__((aligned(16))) int16_t s_slots[256 * LP_NSLOT * 64];
     __shared__ uint8_t s_zz[80];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
@@ -321,16 +344,22 @@ __global__ __launch_bounds__(256) void k_huff_write(const LpJpeg* __restrict__ i
         const uint8_t zz[80] = LP_ZIGZAG_INIT;
         if (threadIdx.x < 80) s_zz[threadIdx.x] = zz[threadIdx.x];
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
-        for (uint32_t i = threadIdx.x; i < 256 * 64 * 2 / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < 256 * LP_NSLOT * 64 * 2 / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
     }
     stage_huff(&s_hs, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * 256 + threadIdx.x;
     if (sub >= nsub || sub >= img.sub_cap) return;
     const uint32_t g = img.sub_off + sub;
-    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off};
+    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off, S / 32};
     LpSubState entry;
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
-    DevSink sink{s_slots + threadIdx.x * 64, threadIdx.x & 7u, coef_arena, &img};
+    DevSink sink;
+    sink.slots = s_slots + threadIdx.x * LP_NSLOT * 64;
+    sink.l7 = threadIdx.x & 7u;
+    sink.cur = 0;
+    for (int i = 0; i < LP_NSLOT; i++) sink.dst[i] = nullptr;
+    sink.coef_arena = coef_arena;
+    sink.img = &img;
     lp_write_pass(m, img, st.n_rst, st.clean_bytes * 8, entry, exits[g].p, prefixes[g], s_zz, sink);
 }
 
@@ -421,7 +450,7 @@ void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint3
     dim3 g(max_chunks, nimg);
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean, S);
-    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst);
+    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst, S);
 }
 
 void lp_launch_huff_count(hipStream_t s, bool verify, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs,
@@ -446,11 +475,11 @@ void lp_launch_sub_scan(hipStream_t s, const LpJpeg* d_imgs, LpJpegState* d_stat
 
 void lp_launch_huff_write(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs, uint32_t nimg,
                           uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, const LpSubState* d_exit, const LpSubSum* d_prefix,
-                          int16_t* d_coef)
+                          int16_t* d_coef, uint32_t S)
 {
     if (!nimg || !max_sub) return;
     dim3 g((max_sub + 255) / 256, nimg);
-    hipLaunchKernelGGL(k_huff_write, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_exit, d_prefix, d_coef);
+    hipLaunchKernelGGL(k_huff_write, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_exit, d_prefix, d_coef, S);
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int16_t* d_coef,

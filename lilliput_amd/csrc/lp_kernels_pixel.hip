@@ -17,6 +17,12 @@
 
 __device__ __forceinline__ uint32_t clamp8(int32_t v) { return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
+__device__ __forceinline__ uint32_t sat_round_u8(float v)
+{
+    int32_t i = __float2int_rn(v); // cvRound: round half to even
+    return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
+}
+
 // One chroma sample of the upsampled plane at full-resolution (x, y); hr/vr in {1,2}.
 __device__ __forceinline__ int32_t upsampled(const uint8_t* __restrict__ P, uint32_t stride, int32_t dw, int32_t dh, int32_t hr, int32_t vr,
                                              int32_t x, int32_t y)
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
     const LpFrame& f = dsts[blockIdx.z];
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
-    if (x0 >= W || y >= H) return;
+    if (x0 >= W || y >= H || f.off == 0) return; // off == 0: this image takes the fused path
     const uint8_t* PY = plane_arena + img.plane_off[0];
     uint8_t* out = frame_arena + f.off + (size_t)y * f.stride;
     if (img.ncomp == 1) {
@@ -97,6 +103,96 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
     }
 }
 
+// K_resample: planes -> thumbnail in one pass (no full-resolution BGR frame). One wave per destination pixel.
+// Fast path (4:2:0, even rectangle): a lane takes a 2x2 luma quad = one chroma site; general path: a lane takes
+// single pixels through upsampled(). The three channel sums are reduced across the wave.
+__global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+                                                        const uint8_t* __restrict__ plane_arena)
+{
+    const LpFusedOp& op = ops[blockIdx.y];
+    const LpJpeg& img = imgs[op.img];
+    const uint32_t npx = op.dst.w * op.dst.h;
+    const uint32_t pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= npx) return;
+    const int32_t dx = (int32_t)(pix % op.dst.w), dy = (int32_t)(pix / op.dst.w);
+    const int32_t fx0 = op.x0 + dx * op.dxx + dy * op.dyx, fy0 = op.y0 + dx * op.dxy + dy * op.dyy;
+    const uint8_t* PY = plane_arena + img.plane_off[0];
+    const uint32_t sy_ = img.plane_stride[0];
+    int32_t sb = 0, sg = 0, sr = 0;
+    if (img.ncomp == 1) {
+        const uint32_t n = op.rw * op.rh;
+        for (uint32_t i = lane; i < n; i += 64) {
+            uint32_t ry = i / op.rw, rx = i - ry * op.rw;
+            sb += PY[(size_t)(fy0 + (int32_t)ry) * sy_ + fx0 + (int32_t)rx];
+        }
+    } else {
+        const uint8_t* PB = plane_arena + img.plane_off[1];
+        const uint8_t* PR = plane_arena + img.plane_off[2];
+        const uint32_t sc_ = img.plane_stride[1];
+        const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
+        const int32_t hr = img.hmax / img.hs[1], vr = img.vmax / img.vs[1];
+        const int32_t dw = (W * img.hs[1] + img.hmax - 1) / img.hmax, dh = (H * img.vs[1] + img.vmax - 1) / img.vmax;
+        const bool quad = hr == 2 && vr == 2 && !((fx0 | fy0 | (int32_t)op.rw | (int32_t)op.rh) & 1) && img.colorspace == 2;
+        if (quad) {
+            const uint32_t qw = op.rw >> 1, nq = qw * (op.rh >> 1);
+            for (uint32_t i = lane; i < nq; i += 64) {
+                const uint32_t qy = i / qw, qx = i - qy * qw;
+                const int32_t cx = (fx0 >> 1) + (int32_t)qx, cy = (fy0 >> 1) + (int32_t)qy;
+                const int32_t cl = cx > 0 ? cx - 1 : 0, cr_ = cx < dw - 1 ? cx + 1 : dw - 1;
+                const int32_t cu = cy > 0 ? cy - 1 : 0, cd = cy < dh - 1 ? cy + 1 : dh - 1;
+                const uint8_t* bu = PB + (size_t)cu * sc_; const uint8_t* bm = PB + (size_t)cy * sc_; const uint8_t* bd = PB + (size_t)cd * sc_;
+                const uint8_t* ru = PR + (size_t)cu * sc_; const uint8_t* rm = PR + (size_t)cy * sc_; const uint8_t* rd = PR + (size_t)cd * sc_;
+                // vertical 3:1 blends for the three columns, upper (row 2cy) and lower (row 2cy+1) output rows
+                const int32_t bml = 3 * bm[cl], bmc = 3 * bm[cx], bmr = 3 * bm[cr_];
+                const int32_t rml = 3 * rm[cl], rmc = 3 * rm[cx], rmr = 3 * rm[cr_];
+                const int32_t bul = bml + bu[cl], buc = bmc + bu[cx], bur = bmr + bu[cr_];
+                const int32_t bdl = bml + bd[cl], bdc = bmc + bd[cx], bdr = bmr + bd[cr_];
+                const int32_t rul = rml + ru[cl], ruc = rmc + ru[cx], rur = rmr + ru[cr_];
+                const int32_t rdl = rml + rd[cl], rdc = rmc + rd[cx], rdr = rmr + rd[cr_];
+                const int32_t cb[4] = {(3 * buc + bul + 8) >> 4, (3 * buc + bur + 7) >> 4, (3 * bdc + bdl + 8) >> 4, (3 * bdc + bdr + 7) >> 4};
+                const int32_t crv[4] = {(3 * ruc + rul + 8) >> 4, (3 * ruc + rur + 7) >> 4, (3 * rdc + rdl + 8) >> 4, (3 * rdc + rdr + 7) >> 4};
+                const uint8_t* y0p = PY + (size_t)(2 * cy) * sy_ + 2 * cx;
+                const uint32_t ya = *reinterpret_cast<const uint16_t*>(y0p), yb = *reinterpret_cast<const uint16_t*>(y0p + sy_);
+                const int32_t yy[4] = {(int32_t)(ya & 255), (int32_t)(ya >> 8), (int32_t)(yb & 255), (int32_t)(yb >> 8)};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t b, g, r;
+                    ycc_to_bgr(yy[k], cb[k], crv[k], b, g, r);
+                    sb += (int32_t)b; sg += (int32_t)g; sr += (int32_t)r;
+                }
+            }
+        } else {
+            const uint32_t n = op.rw * op.rh;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t ry = i / op.rw, rx = i - ry * op.rw;
+                const int32_t x = fx0 + (int32_t)rx, y = fy0 + (int32_t)ry;
+                const int32_t yy = PY[(size_t)y * sy_ + x];
+                const int32_t cb = upsampled(PB, sc_, dw, dh, hr, vr, x, y);
+                const int32_t cr = upsampled(PR, img.plane_stride[2], dw, dh, hr, vr, x, y);
+                uint32_t b, g, r;
+                if (img.colorspace == 3) { b = (uint32_t)cr; g = (uint32_t)cb; r = (uint32_t)yy; }
+                else ycc_to_bgr(yy, cb, cr, b, g, r);
+                sb += (int32_t)b; sg += (int32_t)g; sr += (int32_t)r;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sb += __shfl_xor(sb, d, 64);
+        sg += __shfl_xor(sg, d, 64);
+        sr += __shfl_xor(sr, d, 64);
+    }
+    const uint32_t cn = op.dst.cn;
+    if (lane < cn) {
+        const int32_t sum = lane == 0 ? sb : lane == 1 ? sg : sr;
+        uint32_t r;
+        if (op.round_2x2) r = (uint32_t)(sum + 2) >> 2;
+        else r = sat_round_u8(__fmul_rn((float)sum, op.inv_area));
+        uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * cn;
+        D[lane] = (uint8_t)r;
+    }
+}
+
 // dst(y, x) = src(f(y, x)); dst dims are (h, w) for orientations 5..8.
 __global__ __launch_bounds__(256) void k_orient(const LpOrientOp* __restrict__ ops, const uint8_t* __restrict__ src_arena,
                                                 uint8_t* __restrict__ dst_arena)
@@ -116,11 +212,6 @@ __global__ __launch_bounds__(256) void k_orient(const LpOrientOp* __restrict__ o
     for (uint32_t c = 0; c < op.src.cn; c++) d[c] = s[c];
 }
 
-__device__ __forceinline__ uint32_t sat_round_u8(float v)
-{
-    int32_t i = __float2int_rn(v); // cvRound: round half to even
-    return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
-}
 
 // INTER_AREA, integer scale (resizeAreaFast_): one wave per destination pixel, lanes stride the
 // iscale_y x (iscale_x*cn) byte box, per-channel sums reduced across the wave.
@@ -265,6 +356,13 @@ void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, 
     if (!nimg || !max_w || !max_h) return;
     dim3 g((max_w + 255) / 256, (max_h + 3) / 4, nimg);
     hipLaunchKernelGGL(k_ycc_to_frame, g, dim3(64, 4), 0, s, d_imgs, d_planes, d_dsts, d_frames);
+}
+
+void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFusedOp* d_ops, uint32_t nops, uint32_t max_px, const uint8_t* d_planes)
+{
+    if (!nops || !max_px) return;
+    dim3 g((max_px + 3) / 4, nops);
+    hipLaunchKernelGGL(k_resample_fused, g, dim3(256), 0, s, d_imgs, d_ops, d_planes);
 }
 
 void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_src, uint8_t* d_dst)

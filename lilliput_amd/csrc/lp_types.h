@@ -113,6 +113,19 @@ struct LpResizeOp {
     uint32_t pad;
 };
 
+// Fused S3+S4+S5+S6+S7 for integer scales (resizeAreaFast_): destination pixel (dx, dy) is the mean of the
+// BGR values of the source rectangle [x0 + dx*dxx + dy*dyx, +rw) x [y0 + dx*dxy + dy*dyy, +rh) of the UN-oriented
+// decoded image; orientation and crop are folded into x0/y0 and the strides (a box sum does not care about order).
+struct LpFusedOp {
+    uint32_t img;               // index into the LpJpeg array of the current decode range
+    uint32_t rw, rh;            // source rectangle size
+    int32_t x0, y0, dxx, dxy, dyx, dyy;
+    float inv_area;
+    uint32_t round_2x2;         // 1: (sum+2)>>2 (ResizeAreaFastVec_SIMD_8u), 0: cvRound(sum * inv_area)
+    uint32_t pad;
+    LpFrame dst;
+};
+
 struct LpCompositeOp {
     LpFrame src, dst;
     uint32_t kind;              // 0 alpha blend, 1 copy (channel fix-up), 2 clear

@@ -11,10 +11,12 @@
 #include "../../lilliput_amd/csrc/lp_jpeg_parse.h"
 
 struct HostMem {
-    const uint32_t* words;
+    const uint32_t* words; // lane-interleaved layout (lp_clean_addr)
     const LpHuffSet* hs;
     const uint32_t* rst;
-    uint32_t word(uint32_t w) const { return words[w]; }
+    uint32_t wps;
+    uint32_t word(uint32_t w) const { return words[lp_clean_addr(w, wps)]; }
+    bool any(bool p) const { return p; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
@@ -22,13 +24,16 @@ struct HostMem {
     uint32_t rst_bit(uint32_t k) const { return rst[k]; }
 };
 
-struct HostSink {
+struct HostSink { // one slot, flushed at the wave-uniform flush points like the device sink
     int16_t blk[64];
     int16_t* coef[3];
     const LpJpeg* img;
-    void begin_block() { memset(blk, 0, sizeof(blk)); }
+    int16_t* pending = nullptr;
+    HostSink() { memset(blk, 0, sizeof(blk)); }
     void put(uint32_t nat, int32_t v) { blk[nat & 63] = (int16_t)v; }
-    void end_block(uint32_t c, uint32_t bx, uint32_t by) { memcpy(coef[c] + ((size_t)by * img->bw[c] + bx) * 64, blk, 128); }
+    void end_block(uint32_t c, uint32_t bx, uint32_t by) { pending = coef[c] + ((size_t)by * img->bw[c] + bx) * 64; }
+    bool stalled() const { return pending != nullptr; }
+    void flush() { if (pending) { memcpy(pending, blk, 128); memset(blk, 0, sizeof(blk)); pending = nullptr; } }
 };
 
 extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uint32_t C, int comp, int16_t* out, size_t cap_elems,
@@ -55,10 +60,12 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         clean.push_back(c);
     }
     uint32_t total_bits = (uint32_t)clean.size() * 8;
-    std::vector<uint32_t> words((clean.size() + 3) / 4 + 16, 0);
-    for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
+    const uint32_t wps = S / 32;
+    const size_t nwords = ((clean.size() + 3) / 4 + 32 + (size_t)64 * wps - 1) / ((size_t)64 * wps) * ((size_t)64 * wps);
+    std::vector<uint32_t> words(nwords, 0);
+    for (size_t q = 0; q < clean.size(); q++) words[lp_clean_addr((uint32_t)(q >> 2), wps)] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
     rst.push_back(0);
-    HostMem m{words.data(), &h.huff, rst.data()};
+    HostMem m{words.data(), &h.huff, rst.data(), wps};
     uint32_t n_rst = (uint32_t)rst.size() - 1;
     uint32_t K = S / C;
     uint32_t nsub = (total_bits + S - 1) / S;

@@ -332,3 +332,41 @@ def test_config2_geometry_full_size_properties(batch, oracle):
     assert r[0].data == oracle.jpeg_encode(box, 85)
     # and the decoded frame itself equals the oracle's (one full-size decode on the CPU, ~seconds)
     assert np.array_equal(px, oracle.jpeg_decode(data))
+
+
+def _with_exif_orientation(jpeg, o):
+    """Insert an APP1/EXIF segment carrying orientation `o` right after SOI."""
+    tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([o, 0, 0, 0]) + b"\x00\x00\x00\x00"
+    payload = b"Exif\x00\x00" + tiff
+    return jpeg[:2] + b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload + jpeg[2:]
+
+
+def test_fused_resample_all_orientations_integer_scales(batch, oracle):
+    """The fused planes->thumbnail kernel (orientation + crop folded into addressing) against decode -> ExifTransform ->
+    crop -> resizeAreaFast_ done step by step on the CPU. Bit-exact: integer sums, exact float scale."""
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rgb = synth.synth_rgb(11, 256)
+    cases = []
+    for (w, h, tw, th, ss) in ((96, 64, 32, 32, 2), (192, 128, 32, 32, 2), (96, 96, 32, 32, 2), (98, 64, 32, 32, 2), (128, 128, 8, 8, 2),
+                               (96, 64, 32, 32, 0), (120, 90, 30, 30, 1), (64, 48, 16, 16, "gray"), (160, 100, 50, 50, 2), (90, 60, 30, 20, 2)):
+        im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
+        b = io.BytesIO()
+        if ss == "gray":
+            im.convert("L").save(b, "JPEG", quality=90)
+        else:
+            im.save(b, "JPEG", quality=90, subsampling=ss)
+        cases.append((b.getvalue(), tw, th))
+    for data, tw, th in cases:
+        for o in range(1, 9):
+            d = _with_exif_orientation(data, o)
+            assert oracle.jpeg_info(d)["orientation"] == o
+            for norm in (False, True):
+                r = batch.transform([d], tw, th, normalize=norm, quality=85)[0]
+                assert r.status == 0
+                info = oracle.jpeg_info(d)
+                frame = oracle.transform_static(oracle.jpeg_decode(d), o, tw, th, oracle.FIT, norm)
+                assert (r.width, r.height) == (frame.shape[1], frame.shape[0]), (o, norm, tw, th)
+                assert r.data == oracle.jpeg_encode(frame, 85), (info["width"], info["height"], o, norm, tw, th)
