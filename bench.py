@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic source images tiled to the batch")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device (0 = automatic)")
+    ap.add_argument("--sub-bits", type=int, default=0, help="Huffman subsequence size in bits (0 = automatic)")
+    ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,6 +127,8 @@ def main():
     c_in = sum(len(distinct[i % len(distinct)]) for i in range(args.batch)) / args.batch
 
     b = la.Batch(local_rank)
+    if args.sub_bits:
+        b.set_subsequence(args.sub_bits, args.ckpt_bits)
     t = time.time()
     b.upload(sources, dst_cap=256 << 10)   # parse headers + H2D of the compressed bytes: NOT in the timed region
     upload_s = time.time() - t

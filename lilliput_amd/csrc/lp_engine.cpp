@@ -87,7 +87,7 @@ uint8_t* LpEngine::heap_alloc(size_t bytes)
 static uint32_t pick_S(size_t max_ecs_bytes)
 {
     size_t bits = max_ecs_bytes * 8;
-    if (bits >= (1u << 22)) return 16384;
+    if (bits >= (1u << 22)) return 8192;
     if (bits >= (1u << 19)) return 4096;
     if (bits >= (1u << 16)) return 1024;
     return 256;
@@ -159,20 +159,26 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     size_t max_ecs = 0;
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
     S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
-    C_ = C_cfg_ ? C_cfg_ : std::max<uint32_t>(32, S_ / LP_MAX_CKPT);
-    K_ = S_ / C_;
-    if (K_ > LP_MAX_CKPT || K_ == 0 || S_ % 32 || S_ < 64) { err_ = "bad subsequence configuration"; return LP_ERR_DEVICE; }
+    if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
+    {   // checkpoint schedule of the speculative pass (iterations of the decode loop, see LpCkSched)
+        const uint32_t cbits = C_cfg_ ? C_cfg_ : 256;
+        sched_.K = std::min<uint32_t>(LP_MAX_CKPT, std::max<uint32_t>(1, S_ / cbits));
+        sched_.td = std::max<uint32_t>(2, cbits / 8);
+        sched_.nd = std::max<uint32_t>(1, sched_.K / 2);
+        const uint32_t span = S_ / 4; // a lane runs about S/6.5 iterations on photographic content
+        sched_.ts = sched_.K > sched_.nd && span > sched_.nd * sched_.td ? std::max(sched_.td, (span - sched_.nd * sched_.td) / (sched_.K - sched_.nd)) : sched_.td;
+    }
+    K_ = sched_.K;
     size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;
     max_chunks_ = max_sub_ = max_tiles_ = max_w_ = max_h_ = 0;
-    for (auto& j : h_imgs_) {
+    bool any_frame = false;
+    for (size_t i = 0; i < h_imgs_.size(); i++) {
+        LpJpeg& j = h_imgs_[i];
         j.chunk_off = tot_chunks_;
         tot_chunks_ += j.nchunks;
-        j.clean_off = clean_words;
-        {   // whole groups of 64 interleaved subsequences (lp_clean_addr), plus slack for reads past the end
-            const uint32_t grp = 64u * (S_ / 32u);
-            j.clean_cap_words = (j.raw_len / 4 + 64 + grp - 1) / grp * grp;
-        }
+        j.clean_off = clean_words;                                  // multiple of 4 words: the bit reader loads 16 bytes at a time
+        j.clean_cap_words = (j.raw_len / 4 + 64 + 3) / 4 * 4;       // + slack for the zeroed tail and reads past the end
         clean_words += j.clean_cap_words;
         j.sub_off = tot_sub_;
         j.sub_cap = (uint32_t)(((uint64_t)j.raw_len * 8 + S_ - 1) / S_) + 1;
@@ -180,23 +186,27 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         j.rst_off = tot_rst_;
         j.rst_cap = j.dri ? (j.mcus_x * j.mcus_y + j.dri - 1) / j.dri + 2 : 2;
         tot_rst_ += j.rst_cap;
+        j.coef_off = coef_elems;
+        coef_elems += (size_t)j.total_blocks * 64;
         for (int c = 0; c < j.ncomp; c++) {
-            j.coef_off[c] = coef_elems;
-            coef_elems += (size_t)j.bw[c] * j.bh[c] * 64;
             j.plane_off[c] = plane_bytes;
             plane_bytes = align_up(plane_bytes + (size_t)j.bw[c] * 8 * j.bh[c] * 8, 16);
             max_tiles_ = std::max(max_tiles_, (j.bw[c] + 7) / 8 * j.bh[c]);
         }
         max_chunks_ = std::max(max_chunks_, j.nchunks);
         max_sub_ = std::max(max_sub_, j.sub_cap);
-        max_w_ = std::max(max_w_, j.width);
-        max_h_ = std::max(max_h_, j.height);
+        if (!want_frame || want_frame[i]) {
+            any_frame = true;
+            max_w_ = std::max(max_w_, j.width);
+            max_h_ = std::max(max_h_, j.height);
+        }
     }
-    bool a = d_imgs_.ensure(sizeof(LpJpeg) * (size_t)n) && d_states_.ensure(sizeof(LpJpegState) * (size_t)n) && d_clean_.ensure(clean_words * 4 + 64) &&
+    bool a = d_imgs_.ensure(sizeof(LpJpeg) * (size_t)n) && d_states_.ensure(sizeof(LpJpegState) * (size_t)n) && d_clean_.ensure(clean_words * 4 + 4096) &&
              d_rst_.ensure((size_t)tot_rst_ * 4 + 64) && d_chunk_.ensure((size_t)tot_chunks_ * 8 + 64) &&
-             d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkpt) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
-             d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems * 2 + 64) &&
+             d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
+             d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
+             d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems * 2 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
@@ -208,17 +218,23 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>(), S_);
     if (timing_) (void)hipEventRecord(ev_[1], stream_);
-    lp_launch_huff_count(stream_, false, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
-                         d_ckpt_.as<LpCkpt>(), d_exit_.as<LpSubState>(), d_entry_.as<LpSubState>(), d_tot_.as<LpSubSum>(), d_changed_.as<uint32_t>(),
-                         S_, C_, K_);
+    LpHuffArgs ha;
+    ha.imgs = di; ha.states = ds; ha.huffs = d_huffs_.as<LpHuffSet>();
+    ha.nimg = (uint32_t)n; ha.max_sub = max_sub_; ha.tot_sub = tot_sub_;
+    ha.clean = d_clean_.as<uint32_t>(); ha.rst = d_rst_.as<uint32_t>();
+    ha.ckpts = d_ckpt_.as<LpCkptPk>();
+    ha.spec_exit = d_spec_exit_.as<LpSubState>(); ha.spec_total = d_spec_tot_.as<LpSumPk>();
+    ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSumPk>();
+    ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSumPk>();
+    ha.changed = d_changed_.as<uint32_t>(); ha.coef = d_coef_.as<int16_t>();
+    ha.S = S_; ha.sched = sched_;
+    lp_launch_huff_spec(stream_, ha);
     if (timing_) (void)hipEventRecord(ev_[8], stream_);
     uint32_t rounds = 0;
     uint32_t* h_changed = h_small_.as<uint32_t>();
     for (;;) {
         if (!check(hipMemsetAsync(d_changed_.p, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
-        lp_launch_huff_count(stream_, true, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
-                             d_ckpt_.as<LpCkpt>(), d_exit_.as<LpSubState>(), d_entry_.as<LpSubState>(), d_tot_.as<LpSubSum>(),
-                             d_changed_.as<uint32_t>(), S_, C_, K_);
+        lp_launch_huff_verify(stream_, ha);
         if (!check(hipMemcpyAsync(h_changed, d_changed_.p, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
         if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
         rounds++;
@@ -226,10 +242,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     tm_.verify_rounds = rounds;
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
-    lp_launch_sub_scan(stream_, di, ds, (uint32_t)n, d_tot_.as<LpSubSum>(), d_prefix_.as<LpSubSum>());
+    lp_launch_sub_scan(stream_, ha);
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
-    lp_launch_huff_write(stream_, di, ds, d_huffs_.as<LpHuffSet>(), (uint32_t)n, max_sub_, d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(),
-                         d_exit_.as<LpSubState>(), d_prefix_.as<LpSubSum>(), d_coef_.as<int16_t>(), S_);
+    lp_launch_huff_write(stream_, ha);
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int16_t>(), d_planes_.as<uint8_t>());
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
@@ -245,8 +260,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             f.off = (uint64_t)(uintptr_t)p;
         }
     }
-    if (!check(hipMemcpyAsync(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D frames")) return LP_ERR_DEVICE;
-    lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
+    if (any_frame) {
+        if (!check(hipMemcpyAsync(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D frames")) return LP_ERR_DEVICE;
+        lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
+    }
     if (timing_) (void)hipEventRecord(ev_[4], stream_);
     h_states_.resize((size_t)n);
     if (!check(hipMemcpyAsync(h_small_.p, ds, sizeof(LpJpegState) * (size_t)n, hipMemcpyDeviceToHost, stream_), "D2H states")) return LP_ERR_DEVICE;
@@ -278,11 +295,21 @@ int LpEngine::decode_uploaded(int first, int n, LpFrame* frames, int* status, co
 
 int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
 {
+    // test access: the arena holds the blocks in decode order; return component `comp` as [by][bx][64]
     const LpJpeg& j = h_imgs_[(size_t)i];
-    size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
+    const size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
     if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
-    if (!check(hipMemcpyAsync(dst, d_coef_.as<int16_t>() + j.coef_off[comp], ne * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
-    return sync();
+    std::vector<int16_t> all((size_t)j.total_blocks * 64);
+    if (!check(hipMemcpyAsync(all.data(), d_coef_.as<int16_t>() + j.coef_off, all.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
+    int rc = sync();
+    if (rc) return rc;
+    const uint32_t hs = j.hs[comp], vs = j.vs[comp];
+    for (uint32_t by = 0; by < j.bh[comp]; by++)
+        for (uint32_t bx = 0; bx < j.bw[comp]; bx++) {
+            const size_t blk = ((size_t)(by / vs) * j.mcus_x + bx / hs) * j.bpm + j.blk_first[comp] + (by % vs) * hs + (bx % hs);
+            memcpy(dst + ((size_t)by * j.bw[comp] + bx) * 64, all.data() + blk * 64, 128);
+        }
+    return LP_OK;
 }
 
 int LpEngine::copy_plane(int i, int comp, uint8_t* dst, size_t cap)

@@ -77,7 +77,7 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
 
-    // Subsequence size in bits (multiple of 32, >= 64) and checkpoint spacing; 0 = automatic.
+    // Subsequence size in bits (multiple of 32, 64..32768) and checkpoint spacing in bits (sets the schedule); 0 = automatic.
     void set_subsequence(uint32_t S, uint32_t C) { S_cfg_ = S; C_cfg_ = C; }
 
     // Heap for intermediate frames: bump-allocated, reset per batch.
@@ -135,10 +135,11 @@ private:
     std::vector<LpJpeg> h_imgs_;  // the range being decoded (working arenas laid out)
     std::vector<LpHuffSet> h_huffs_;
     std::vector<LpJpegState> h_states_;
-    uint32_t S_ = 0, C_ = 0, K_ = 0;
+    uint32_t S_ = 0, K_ = 0;
+    LpCkSched sched_ = {};
     uint32_t max_chunks_ = 0, max_sub_ = 0, max_tiles_ = 0, max_w_ = 0, max_h_ = 0;
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
-    LpDevBuf d_imgs_, d_huffs_, d_states_, d_raw_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_entry_, d_tot_, d_prefix_, d_changed_;
+    LpDevBuf d_imgs_, d_huffs_, d_states_, d_raw_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
     LpDevBuf d_coef_, d_planes_, d_frames_desc_;
     LpPinned h_stage_, h_small_, h_out_;
     std::vector<size_t> h_out_off_;

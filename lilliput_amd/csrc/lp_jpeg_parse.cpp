@@ -44,6 +44,9 @@ static int exif_orientation(const uint8_t* p, size_t n)
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals)
 {
     memset(hs->lut[slot], 0, sizeof(hs->lut[slot]));
+    memset(hs->lut2[slot], 0, sizeof(hs->lut2[slot]));
+    // first pass: canonical code assignment (T.81 Annex C), first-level table, base of the long codes
+    uint32_t base2 = 0x10000u;
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
         int valptr = k, mincode = code;
@@ -51,10 +54,24 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
             if (l <= LP_LUT_BITS) {
                 int first = code << (LP_LUT_BITS - l), n = 1 << (LP_LUT_BITS - l);
                 for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = (uint16_t)((l << 8) | vals[k]);
+            } else {
+                uint32_t left = (uint32_t)code << (16 - l);
+                if (left < base2) base2 = left;
             }
         }
         hs->maxcode[slot][l] = bits[l] ? code - 1 : -1;
         hs->valoff[slot][l] = valptr - mincode;
+        code <<= 1;
+    }
+    hs->base2[slot] = base2;
+    // second pass: second-level table over [base2, base2 + LP_LUT2_SIZE)
+    code = 0; k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l]; i++, k++, code++) {
+            if (l <= LP_LUT_BITS) continue;
+            uint32_t first = ((uint32_t)code << (16 - l)) - base2, n = 1u << (16 - l);
+            for (uint32_t j = 0; j < n && first + j < LP_LUT2_SIZE; j++) hs->lut2[slot][first + j] = (uint16_t)((l << 8) | vals[k]);
+        }
         code <<= 1;
     }
     hs->maxcode[slot][0] = -1;
@@ -62,6 +79,24 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
     hs->valoff[slot][0] = 0;
     memset(hs->vals[slot], 0, 256);
     memcpy(hs->vals[slot], vals, (size_t)(k > 256 ? 256 : k));
+}
+
+// jdhuff.c jpeg_make_d_derived_tbl (run by libjpeg for the tables a scan uses): the code space must not overflow
+// (the all-ones code of any length is reserved) and DC symbols are categories 0..15 -- else JERR_BAD_HUFF_TABLE.
+static bool huff_table_valid(const uint8_t bits[17], const uint8_t* vals, bool is_dc)
+{
+    long code = 0;
+    int tot = 0;
+    for (int l = 1; l <= 16; l++) {
+        code += bits[l];
+        tot += bits[l];
+        if (code >= (1L << l)) return false;
+        code <<= 1;
+    }
+    if (is_dc)
+        for (int q = 0; q < tot; q++)
+            if (vals[q] > 15) return false;
+    return true;
 }
 
 int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
@@ -171,6 +206,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
         if (!qt_ok[tq[c]] || !h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;
         if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
+        if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
+            return LP_PARSE_NOT_JPEG;
     }
     if (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1)) return LP_PARSE_UNSUPPORTED;
     j.mcus_x = (j.width + 8 * j.hmax - 1) / (8 * j.hmax);
@@ -185,6 +222,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 j.blk_v[bpm] = (uint8_t)v;
                 bpm++;
             }
+        j.blk_first[c] = (uint8_t)(bpm - j.hs[c] * j.vs[c]);
         j.bw[c] = j.mcus_x * j.hs[c];
         j.bh[c] = j.mcus_y * j.vs[c];
         j.plane_stride[c] = j.bw[c] * 8;
@@ -193,6 +231,11 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         memcpy(j.qt[c], qt[tq[c]], sizeof(j.qt[c]));
     }
     j.bpm = (uint8_t)bpm;
+    j.blkpack = 0;
+    for (unsigned b = 0; b < bpm; b++) {
+        const unsigned c = j.blk_comp[b];
+        j.blkpack |= (uint64_t)(c | ((unsigned)td[c] << 2) | ((unsigned)ta[c] << 3)) << (4 * b);
+    }
     j.total_blocks = j.mcus_x * j.mcus_y * bpm;
     // libjpeg's colour space guess (jdapimin.c default_decompress_parms)
     if (j.ncomp == 1) j.colorspace = 1;

@@ -1,6 +1,6 @@
 // lp_kernels_decode.hip -- gfx950 kernels for the JPEG decode half of ImageOps.Transform:
 //   unstuff (FF00 / RSTn removal + restart boundary list)  -> k_unstuff_{count,scan,scatter}
-//   Huffman entropy decode (S1)                             -> k_huff_count<VERIFY>, k_sub_scan, k_huff_write
+//   Huffman entropy decode (S1)                             -> k_huff_spec, k_huff_verify, k_sub_scan, k_huff_write
 //   dequantise + 8x8 islow IDCT (S2)                        -> k_idct
 // Replaces the libjpeg-turbo work behind opencv_decoder_read_data (/root/reference/opencv.cpp:166-171).
 // All kernels are batched: blockIdx.y (or .z) selects the image, per-image descriptors live in HBM.
@@ -150,17 +150,20 @@ __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__
     // zero the tail words so that reads past the end of the stream are deterministic
     if (t < 16) {
         uint32_t w = (ta >> 2) + t;
-        uint32_t a = lp_clean_addr(w, S / 32);
-        if (a < img.clean_cap_words) clean_arena[img.clean_off + a] = 0;
+        if (w < img.clean_cap_words) clean_arena[img.clean_off + w] = 0;
     }
 }
 
+// Scatter pass. A workgroup's 4 KiB of raw bytes become <= 4 KiB of CONTIGUOUS clean bytes, so they are compacted in LDS
+// (already in memory byte order: the clean stream is stored as big-endian 32-bit words, bit 31 of word 0 = first bit) and
+// leave as coalesced dword stores; only the <= 3 bytes of a word shared with the neighbouring chunk use byte stores.
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
                                                                const uint2* __restrict__ chunk_cnt, uint32_t* __restrict__ clean_arena,
-                                                               uint32_t* __restrict__ rst_bits, uint32_t S)
+                                                               uint32_t* __restrict__ rst_bits)
 {
     __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
     __shared__ uint32_t s_tmp[8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16];
     const LpJpeg& img = imgs[blockIdx.y];
     if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
@@ -171,10 +174,9 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
     unstuff_classify(u, pos0, img.raw_len, km, rm, err);
     uint32_t ea, eb, ta, tb;
     block_excl_scan2(__popc(km), __popc(rm), ea, eb, ta, tb, s_tmp);
-    uint2 base = chunk_cnt[img.chunk_off + blockIdx.x];
+    const uint2 base = chunk_cnt[img.chunk_off + blockIdx.x];
+    const uint32_t a0 = base.x & ~3u;           // clean position of the first (maybe shared) word
     uint32_t cpos = base.x + ea, rpos = base.y + eb;
-    uint8_t* out = reinterpret_cast<uint8_t*>(clean_arena + img.clean_off);
-    const uint32_t cap = img.clean_cap_words * 4;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (rm & (1u << j)) {
@@ -182,24 +184,70 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
             rpos++;
         }
         if (km & (1u << j)) {
-            uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
-            // big-endian words (bit 31 of word 0 is the first bit of the stream), lane-interleaved word layout
-            if (cpos < cap) out[(size_t)lp_clean_addr(cpos >> 2, S / 32) * 4 + (3 - (cpos & 3))] = (uint8_t)c;
+            const uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            const uint32_t l = cpos - a0;       // clean position relative to a0; memory order swaps the bytes of a word
+            s_out[(l & ~3u) | (3u - (l & 3u))] = (uint8_t)c;
             cpos++;
+        }
+    }
+    __syncthreads();
+    const uint32_t lo = base.x - a0, hi = lo + ta;  // owned clean positions relative to a0: [lo, hi)
+    const uint32_t cap = img.clean_cap_words;
+    uint32_t* out = clean_arena + img.clean_off + (a0 >> 2);
+    const uint32_t nwords = (hi + 3) >> 2;
+    for (uint32_t w = threadIdx.x; w < nwords; w += UNSTUFF_T) {
+        if ((a0 >> 2) + w >= cap) break;
+        const uint32_t q0 = w * 4;
+        if (q0 >= lo && q0 + 4 <= hi) {
+            out[w] = *reinterpret_cast<const uint32_t*>(&s_out[q0]);
+        } else { // word shared with a neighbouring chunk: touch only the owned bytes
+            uint8_t* ob = reinterpret_cast<uint8_t*>(out + w);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t q = q0 + k;
+                if (q >= lo && q < hi) ob[3u - k] = s_out[q0 + (3u - k)];
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Huffman decode
+// Huffman decode. Workgroup = 256 lanes = 256 consecutive subsequences of one image (blockIdx.y).
+// LDS: the image's LpHuffSet (two-level code tables), one bit-reader ring per lane (word-interleaved: word j of lane l at
+// [j][l], so every wave access hits 64 consecutive dwords -- conflict-free whatever the lanes' positions are).
+#define HUFF_T 256
 struct DevMem {
-    const uint32_t* words;
-    const LpHuffSet* hs; // LDS
+    const uint32_t* words;  // this image's clean stream (16-byte aligned)
+    uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % LP_RING_WORDS) * 64]
+    uint32_t fill;          // next stream word to load (multiple of 4)
+    const LpHuffSet* hs;    // LDS
     const uint32_t* rst;
-    uint32_t wps;        // words per subsequence (S / 32)
-    __device__ __forceinline__ uint32_t word(uint32_t w) const { return words[lp_clean_addr(w, wps)]; }
+    __device__ __forceinline__ uint32_t fetch(uint32_t w) const { return ring[(w & (LP_RING_WORDS - 1u)) << 6]; }
+    __device__ __forceinline__ void load_quad()
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(words + fill);
+        ring[((fill + 0u) & (LP_RING_WORDS - 1u)) << 6] = v.x;
+        ring[((fill + 1u) & (LP_RING_WORDS - 1u)) << 6] = v.y;
+        ring[((fill + 2u) & (LP_RING_WORDS - 1u)) << 6] = v.z;
+        ring[((fill + 3u) & (LP_RING_WORDS - 1u)) << 6] = v.w;
+        fill += 4;
+    }
+    __device__ __forceinline__ void reseek(uint32_t w)
+    {
+        fill = w & ~3u;
+#pragma unroll
+        for (int i = 0; i < LP_RING_WORDS / 4; i++) load_quad();
+    }
+    __device__ __forceinline__ void topup(uint32_t w)
+    {
+#pragma unroll
+        for (int i = 0; i < LP_TOPUP_QUADS; i++)
+            if (fill + 4u <= w + LP_RING_WORDS) load_quad();
+    }
     __device__ __forceinline__ bool any(bool p) const { return __any(p); }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
+    __device__ __forceinline__ uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[t][i]; }
+    __device__ __forceinline__ uint32_t base2(uint32_t t) const { return hs->base2[t]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
@@ -208,59 +256,149 @@ struct DevMem {
 
 __device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
 {
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    for (uint32_t i = threadIdx.x; i < sizeof(LpHuffSet) / 4; i += blockDim.x) d[i] = s[i];
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(LpHuffSet) / 16; i += blockDim.x) d[i] = s[i];
     __syncthreads();
 }
 
-template <bool VERIFY>
-__global__ __launch_bounds__(256) void k_huff_count(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
-                                                    const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
-                                                    const uint32_t* __restrict__ rst_bits, LpCkpt* __restrict__ ckpts,
-                                                    LpSubState* exits, LpSubState* __restrict__ entry_used, LpSubSum* __restrict__ totals,
-                                                    uint32_t* __restrict__ changed, uint32_t S, uint32_t C, uint32_t K)
+__device__ __forceinline__ LpImgCtx make_ctx(const LpJpeg& img, const LpJpegState& st)
 {
-    __shared__ LpHuffSet s_hs;
-    const LpJpeg& img = imgs[blockIdx.y];
-    const LpJpegState& st = states[blockIdx.y];
-    const uint32_t nsub = st.nsub;
-    if (blockIdx.x * 256 >= nsub) return;
-    stage_huff(&s_hs, huffs + img.huff_idx);
-    const uint32_t sub = blockIdx.x * 256 + threadIdx.x;
-    if (sub >= nsub || sub >= img.sub_cap) return;
-    if (VERIFY && sub == 0) return;
-    const uint32_t g = img.sub_off + sub;
-    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off, S / 32};
-    LpSubState entry;
-    if (VERIFY) {
-        uint64_t raw = *reinterpret_cast<const volatile uint64_t*>(&exits[g - 1]);
-        entry.p = (uint32_t)raw;
-        entry.bz = (uint32_t)(raw >> 32);
-        if (lp_state_eq(entry, entry_used[g])) return;
-    } else {
-        entry.p = sub * S;
-        entry.bz = 0;
-    }
-    LpSubState ex = exits[g];
-    LpSubSum tot = totals[g];
-    if (!VERIFY) { ex.p = 0xffffffffu; ex.bz = 0; }
-    bool ch = lp_count_pass(m, img, st.n_rst, st.clean_bytes * 8, sub, S, C, K, VERIFY, entry, ckpts + (size_t)g * K, &ex, &tot);
-    *reinterpret_cast<volatile uint64_t*>(&exits[g]) = (uint64_t)ex.p | ((uint64_t)ex.bz << 32);
-    totals[g] = tot;
-    entry_used[g] = entry;
-    if (VERIFY && ch) atomicAdd(changed, 1u);
+    LpImgCtx ic;
+    ic.blkpack = img.blkpack;
+    ic.bpm = img.bpm;
+    ic.n_rst = st.n_rst;
+    ic.total_bits = st.clean_bytes * 8;
+    ic.total_blocks = img.total_blocks;
+    return ic;
 }
 
-template __global__ void k_huff_count<false>(const LpJpeg*, const LpJpegState*, const LpHuffSet*, const uint32_t*, const uint32_t*, LpCkpt*,
-                                             LpSubState*, LpSubState*, LpSubSum*, uint32_t*, uint32_t, uint32_t, uint32_t);
-template __global__ void k_huff_count<true>(const LpJpeg*, const LpJpegState*, const LpHuffSet*, const uint32_t*, const uint32_t*, LpCkpt*,
-                                            LpSubState*, LpSubState*, LpSubSum*, uint32_t*, uint32_t, uint32_t, uint32_t);
+__device__ __forceinline__ LpSubState load_state(const LpSubState* p)
+{
+    const uint64_t raw = *reinterpret_cast<const volatile uint64_t*>(p); // one 8-byte access: never torn
+    LpSubState s;
+    s.p = (uint32_t)raw;
+    s.bz = (uint32_t)(raw >> 32);
+    return s;
+}
+__device__ __forceinline__ void store_state(LpSubState* p, const LpSubState& s)
+{
+    *reinterpret_cast<volatile uint64_t*>(p) = (uint64_t)s.p | ((uint64_t)s.bz << 32);
+}
+
+// Checkpoint records in HBM: [k][subsequence] so that the 64 lanes of a wave store / load 1 KiB rows.
+struct DevCkSink {
+    LpCkptPk* base;     // + g
+    size_t stride;      // tot_sub
+    bool valid;
+    __device__ __forceinline__ void record(uint32_t k, const LpCkptPk& c)
+    {
+        if (valid) *reinterpret_cast<uint4*>(base + (size_t)k * stride) = make_uint4(c.p, c.bz_nreset, c.nblk_dc2, c.dc01);
+    }
+};
+
+__global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                      const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                      const uint32_t* __restrict__ rst_bits, LpCkptPk* __restrict__ ckpts,
+                                                      LpSubState* __restrict__ spec_exit, LpSumPk* __restrict__ spec_total,
+                                                      LpSubState* __restrict__ cur_exit, LpSumPk* __restrict__ cur_total,
+                                                      LpSubState* __restrict__ entry_used, uint32_t S, LpCkSched cs, uint32_t tot_sub)
+{
+    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    if (blockIdx.x * HUFF_T >= nsub) return;
+    stage_huff(&s_hs, huffs + img.huff_idx);
+    const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
+    const bool valid = sub < nsub;
+    const uint32_t g = img.sub_off + (valid ? sub : 0);
+    const LpImgCtx ic = make_ctx(img, st);
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    LpSubState entry;
+    entry.p = valid ? sub * S : 0;
+    entry.bz = 0;
+    uint32_t sub_end = valid ? entry.p + S : 0; // invalid lanes finish immediately but keep the wave-uniform calls company
+    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
+    DevCkSink ck{ckpts + g, tot_sub, valid};
+    LpSubState ex;
+    LpSubSum tot;
+    lp_spec_pass(m, ic, sub_end, entry, cs, ck, &ex, &tot);
+    if (!valid) return;
+    const LpSumPk tp = lp_sum_pack(tot);
+    spec_exit[g] = ex;
+    cur_exit[g] = ex;
+    *reinterpret_cast<uint4*>(spec_total + g) = make_uint4(tp.nblk, tp.nreset, tp.dc01, tp.dc2);
+    *reinterpret_cast<uint4*>(cur_total + g) = make_uint4(tp.nblk, tp.nreset, tp.dc01, tp.dc2);
+    LpSubState none;
+    none.p = 0xffffffffu; none.bz = 0xffffffffu;
+    entry_used[g] = none;
+}
+
+// Checkpoint source of the verify pass: the K positions of the lane's subsequence are staged in LDS (word-interleaved
+// like the ring); a whole record is fetched from HBM only when a position matches.
+struct DevCkSrc {
+    const uint32_t* pos_lds; // + lane
+    const LpCkptPk* base;    // + g
+    size_t stride;
+    __device__ __forceinline__ uint32_t pos(uint32_t k) const { return pos_lds[k << 6]; }
+    __device__ __forceinline__ LpCkptPk load(uint32_t k) const
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)k * stride);
+        LpCkptPk c;
+        c.p = v.x; c.bz_nreset = v.y; c.nblk_dc2 = v.z; c.dc01 = v.w;
+        return c;
+    }
+};
+
+__global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                        const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                        const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
+                                                        const LpSubState* __restrict__ spec_exit, const LpSumPk* __restrict__ spec_total,
+                                                        LpSubState* cur_exit, LpSumPk* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
+                                                        uint32_t* __restrict__ changed, uint32_t S, uint32_t K, uint32_t tot_sub)
+{
+    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    __shared__ uint32_t s_ckpos[HUFF_T * LP_MAX_CKPT];
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    if (blockIdx.x * HUFF_T >= nsub) return;
+    stage_huff(&s_hs, huffs + img.huff_idx);
+    const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
+    if (sub >= nsub || sub == 0) return; // subsequence 0 starts at the true beginning: its SPEC result is exact
+    const uint32_t g = img.sub_off + sub;
+    const LpSubState entry = load_state(cur_exit + g - 1);
+    if (lp_state_eq(entry, entry_used[g])) return; // already verified against this entry state
+    const LpImgCtx ic = make_ctx(img, st);
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    uint32_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
+    for (uint32_t k = 0; k < K; k++) cp[k << 6] = ckpts[(size_t)k * tot_sub + g].p;
+    DevCkSrc ck{cp, ckpts + g, tot_sub};
+    uint32_t sub_end = sub * S + S;
+    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
+    const uint4 tv = *reinterpret_cast<const uint4*>(spec_total + g);
+    LpSumPk tpk;
+    tpk.nblk = tv.x; tpk.nreset = tv.y; tpk.dc01 = tv.z; tpk.dc2 = tv.w;
+    const LpSubState old_exit = load_state(cur_exit + g);
+    LpSubState ex = old_exit;
+    LpSubSum tot;
+    lp_verify_pass(m, ic, sub_end, entry, K, ck, spec_exit[g], lp_sum_unpack(tpk), &ex, &tot);
+    const LpSumPk np = lp_sum_pack(tot);
+    *reinterpret_cast<uint4*>(cur_total + g) = make_uint4(np.nblk, np.nreset, np.dc01, np.dc2);
+    entry_used[g] = entry;
+    if (!lp_state_eq(ex, old_exit)) {
+        store_state(cur_exit + g, ex);
+        atomicAdd(changed, 1u);
+    }
+}
 
 // One workgroup per image: exclusive scan (lp_sum_combine is associative, not commutative) of the
 // per-subsequence sums -> prefixes[]; also validates the block count.
 __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states,
-                                                  const LpSubSum* __restrict__ totals, LpSubSum* __restrict__ prefixes)
+                                                  const LpSumPk* __restrict__ totals, LpSumPk* __restrict__ prefixes)
 {
     __shared__ LpSubSum s_part[256];
     const LpJpeg& img = imgs[blockIdx.x];
@@ -271,15 +409,15 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     if (b0 > n) b0 = n;
     LpSubSum acc;
     lp_sum_zero(acc);
-    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, totals[img.sub_off + i]);
+    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, lp_sum_unpack(totals[img.sub_off + i]));
     s_part[t] = acc;
     __syncthreads();
     LpSubSum pre;
     lp_sum_zero(pre);
     for (uint32_t i = 0; i < t; i++) pre = lp_sum_combine(pre, s_part[i]);
     for (uint32_t i = b0; i < b1; i++) {
-        prefixes[img.sub_off + i] = pre;
-        pre = lp_sum_combine(pre, totals[img.sub_off + i]);
+        prefixes[img.sub_off + i] = lp_sum_pack(pre);
+        pre = lp_sum_combine(pre, lp_sum_unpack(totals[img.sub_off + i]));
     }
     if (t == 255) {
         st.blocks_decoded = pre.nblk;
@@ -287,80 +425,67 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
 }
 
-// Coefficient sink of the WRITE pass: NSLOT 64-coefficient LDS slots per lane (16-byte chunks XOR-swizzled by lane to
+// Coefficient sink of the WRITE pass: one 64-coefficient LDS slot per lane (16-byte chunks XOR-swizzled by lane to
 // spread banks). A finished block is only queued; flush() runs at wave-uniform points so that the 8x(ds_read_b128 +
-// global_store_dwordx4 + ds_write_b128) per block execute with most lanes active instead of once per lane divergently.
-#define LP_NSLOT 1
+// global_store_dwordx4 + ds_write_b128) per block execute with many lanes active instead of once per lane divergently.
+// Blocks are stored in decode order: block n of the image at coef[n * 64], natural coefficient order.
 struct DevSink {
-    int16_t* slots;         // this lane's LP_NSLOT x 64 coefficients (kept zero between blocks)
+    int16_t* slot;          // this lane's 64 coefficients (kept zero between blocks)
     uint32_t l7;
-    uint32_t cur;
-    int16_t* dst[LP_NSLOT]; // queued destination per slot (nullptr = free); (int16_t*)1 = drop (out of range)
-    int16_t* coef_arena;
-    const LpJpeg* img;
-    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slots[cur * 64 + ((((nat >> 3) ^ l7) << 3) | (nat & 7))] = (int16_t)v; }
-    __device__ __forceinline__ void end_block(uint32_t c, uint32_t bx, uint32_t by)
-    {
-        const bool ok = bx < img->bw[c] && by < img->bh[c];
-        dst[cur] = ok ? coef_arena + img->coef_off[c] + ((size_t)by * img->bw[c] + bx) * 64 : reinterpret_cast<int16_t*>(1);
-        cur = (cur + 1 == LP_NSLOT) ? 0 : cur + 1;
-    }
-    __device__ __forceinline__ bool stalled() const { return dst[cur] != nullptr; }
+    int16_t* dst;           // queued destination (nullptr = slot free)
+    int16_t* coef;          // this image's coefficient blocks
+    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slot[(((nat >> 3) ^ l7) << 3) | (nat & 7)] = (int16_t)v; }
+    __device__ __forceinline__ void end_block(uint32_t blk) { dst = coef + (size_t)blk * 64; }
+    __device__ __forceinline__ bool stalled() const { return dst != nullptr; }
     __device__ __forceinline__ void flush()
     {
+        if (dst) {
+            uint4* s = reinterpret_cast<uint4*>(slot);
+            uint4* o = reinterpret_cast<uint4*>(dst);
+            const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (uint32_t sl = 0; sl < LP_NSLOT; sl++) {
-            int16_t* d = dst[sl];
-            if (d) {
-                uint4* s = reinterpret_cast<uint4*>(slots + sl * 64);
-                uint4* o = reinterpret_cast<uint4*>(d);
-                const uint4 zero = make_uint4(0, 0, 0, 0);
-                const bool wr = d != reinterpret_cast<int16_t*>(1);
-#pragma unroll
-                for (uint32_t ch = 0; ch < 8; ch++) {
-                    uint4 v = s[ch ^ l7];
-                    if (wr) o[ch] = v;
-                    s[ch ^ l7] = zero;
-                }
-                dst[sl] = nullptr;
+            for (uint32_t ch = 0; ch < 8; ch++) {
+                o[ch] = s[ch ^ l7];
+                s[ch ^ l7] = zero;
             }
+            dst = nullptr;
         }
     }
 };
 
-__global__ __launch_bounds__(256) void k_huff_write(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
-                                                    const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
-                                                    const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
-                                                    const LpSubSum* __restrict__ prefixes, int16_t* __restrict__ coef_arena, uint32_t S)
+__global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                       const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                       const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
+                                                       const LpSumPk* __restrict__ prefixes, int16_t* __restrict__ coef_arena)
 {
-    __shared__ LpHuffSet s_hs;
-    __shared__ __attribute__((aligned(16))) int16_t s_slots[256 * LP_NSLOT * 64];
+    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    __shared__ __attribute__((aligned(16))) int16_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
-    const uint32_t nsub = st.nsub;
-    if (blockIdx.x * 256 >= nsub) return;
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    if (blockIdx.x * HUFF_T >= nsub) return;
     {
         const uint8_t zz[80] = LP_ZIGZAG_INIT;
         if (threadIdx.x < 80) s_zz[threadIdx.x] = zz[threadIdx.x];
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
-        for (uint32_t i = threadIdx.x; i < 256 * LP_NSLOT * 64 * 2 / 16; i += 256) z4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < HUFF_T * 64 * 2 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
     stage_huff(&s_hs, huffs + img.huff_idx);
-    const uint32_t sub = blockIdx.x * 256 + threadIdx.x;
-    if (sub >= nsub || sub >= img.sub_cap) return;
+    const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
+    if (sub >= nsub) return;
     const uint32_t g = img.sub_off + sub;
-    DevMem m{clean_arena + img.clean_off, &s_hs, rst_bits + img.rst_off, S / 32};
+    const LpImgCtx ic = make_ctx(img, st);
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
     DevSink sink;
-    sink.slots = s_slots + threadIdx.x * LP_NSLOT * 64;
+    sink.slot = s_slots + threadIdx.x * 64;
     sink.l7 = threadIdx.x & 7u;
-    sink.cur = 0;
-    for (int i = 0; i < LP_NSLOT; i++) sink.dst[i] = nullptr;
-    sink.coef_arena = coef_arena;
-    sink.img = &img;
-    lp_write_pass(m, img, st.n_rst, st.clean_bytes * 8, entry, exits[g].p, prefixes[g], s_zz, sink);
+    sink.dst = nullptr;
+    sink.coef = coef_arena + img.coef_off;
+    lp_write_pass(m, ic, entry, exits[g].p, lp_sum_unpack(prefixes[g]), s_zz, sink);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,7 +531,10 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     const uint32_t by = active ? tile / tiles_x : 0, bx0 = active ? (tile % tiles_x) * 8 : 0;
     const uint32_t j = lane >> 3, r = lane & 7;
     const bool blk_ok = active && bx0 + j < bw;
-    const int16_t* src = coef_arena + img.coef_off[c] + ((size_t)by * bw + bx0 + j) * 64 + r * 8;
+    // blocks are stored in decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order
+    const uint32_t hs = img.hs[c], vs = img.vs[c], bx = bx0 + j;
+    const uint32_t blk = ((by / vs) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[c] + (by % vs) * hs + (bx % hs);
+    const int16_t* src = coef_arena + img.coef_off + (size_t)blk * 64 + r * 8;
     uint4 v = blk_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>(&s_c[wv][j * IDCT_CSTRIDE + r * 8]) = v;
     __syncthreads();
@@ -450,36 +578,38 @@ void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint3
     dim3 g(max_chunks, nimg);
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean, S);
-    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst, S);
+    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst);
 }
 
-void lp_launch_huff_count(hipStream_t s, bool verify, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs,
-                          uint32_t nimg, uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, LpCkpt* d_ckpt,
-                          LpSubState* d_exit, LpSubState* d_entry, LpSubSum* d_tot, uint32_t* d_changed, uint32_t S, uint32_t C, uint32_t K)
+void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a)
 {
-    if (!nimg || !max_sub) return;
-    dim3 g((max_sub + 255) / 256, nimg);
-    if (verify)
-        hipLaunchKernelGGL(k_huff_count<true>, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_ckpt, d_exit, d_entry, d_tot,
-                           d_changed, S, C, K);
-    else
-        hipLaunchKernelGGL(k_huff_count<false>, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_ckpt, d_exit, d_entry, d_tot,
-                           d_changed, S, C, K);
+    if (!a.nimg || !a.max_sub) return;
+    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
+    hipLaunchKernelGGL(k_huff_spec, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, a.ckpts, a.spec_exit, a.spec_total, a.cur_exit,
+                       a.cur_total, a.entry_used, a.S, a.sched, a.tot_sub);
 }
 
-void lp_launch_sub_scan(hipStream_t s, const LpJpeg* d_imgs, LpJpegState* d_states, uint32_t nimg, const LpSubSum* d_tot, LpSubSum* d_prefix)
+void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
 {
-    if (!nimg) return;
-    hipLaunchKernelGGL(k_sub_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_states, d_tot, d_prefix);
+    if (!a.nimg || !a.max_sub) return;
+    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
+    hipLaunchKernelGGL(k_huff_verify, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
+                       (const LpSubState*)a.spec_exit, (const LpSumPk*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed, a.S,
+                       a.sched.K, a.tot_sub);
 }
 
-void lp_launch_huff_write(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs, uint32_t nimg,
-                          uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, const LpSubState* d_exit, const LpSubSum* d_prefix,
-                          int16_t* d_coef, uint32_t S)
+void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)
 {
-    if (!nimg || !max_sub) return;
-    dim3 g((max_sub + 255) / 256, nimg);
-    hipLaunchKernelGGL(k_huff_write, g, dim3(256), 0, s, d_imgs, d_states, d_huffs, d_clean, d_rst, d_exit, d_prefix, d_coef, S);
+    if (!a.nimg) return;
+    hipLaunchKernelGGL(k_sub_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSumPk*)a.cur_total, a.prefix);
+}
+
+void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
+{
+    if (!a.nimg || !a.max_sub) return;
+    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
+    hipLaunchKernelGGL(k_huff_write, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
+                       (const LpSumPk*)a.prefix, a.coef);
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int16_t* d_coef,

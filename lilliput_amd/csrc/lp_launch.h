@@ -7,13 +7,30 @@
 // decode
 void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
                        LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst, uint32_t S);
-void lp_launch_huff_count(hipStream_t s, bool verify, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs,
-                          uint32_t nimg, uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, LpCkpt* d_ckpt,
-                          LpSubState* d_exit, LpSubState* d_entry, LpSubSum* d_tot, uint32_t* d_changed, uint32_t S, uint32_t C, uint32_t K);
-void lp_launch_sub_scan(hipStream_t s, const LpJpeg* d_imgs, LpJpegState* d_states, uint32_t nimg, const LpSubSum* d_tot, LpSubSum* d_prefix);
-void lp_launch_huff_write(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, const LpHuffSet* d_huffs, uint32_t nimg,
-                          uint32_t max_sub, const uint32_t* d_clean, const uint32_t* d_rst, const LpSubState* d_exit, const LpSubSum* d_prefix,
-                          int16_t* d_coef, uint32_t S);
+// Everything the Huffman kernels share (device pointers; arrays indexed by LpJpeg::sub_off + subsequence).
+struct LpHuffArgs {
+    const LpJpeg* imgs;
+    LpJpegState* states;
+    const LpHuffSet* huffs;
+    uint32_t nimg, max_sub, tot_sub;
+    const uint32_t* clean;
+    const uint32_t* rst;
+    LpCkptPk* ckpts;            // [K][tot_sub]
+    LpSubState* spec_exit;      // results of the speculative pass (immutable afterwards)
+    LpSumPk* spec_total;
+    LpSubState* cur_exit;       // current (verified) exit state / sums of every subsequence
+    LpSumPk* cur_total;
+    LpSubState* entry_used;     // entry state a subsequence was last verified against
+    LpSumPk* prefix;            // exclusive scan of cur_total
+    uint32_t* changed;
+    int16_t* coef;
+    uint32_t S;
+    LpCkSched sched;
+};
+void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int16_t* d_coef,
                     uint8_t* d_planes);
 // pixels

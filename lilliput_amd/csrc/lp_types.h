@@ -11,13 +11,17 @@
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
 #define LP_LUT_BITS 10          // first-level Huffman lookup width
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
-#define LP_MAX_CKPT 32          // checkpoints per subsequence
+#define LP_LUT2_SIZE 1024       // second-level lookup: one entry per 16-bit prefix above the first code longer than LP_LUT_BITS
+#define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
-// lut[t][i]: (len << 8) | symbol for codes of length <= LP_LUT_BITS, 0 = longer code -> canonical search.
+// lut[t][i]  : (len << 8) | symbol for codes of length <= LP_LUT_BITS, indexed by the next LP_LUT_BITS bits; 0 = longer code.
+// lut2[t][i] : same encoding for the long codes, indexed by (next 16 bits) - base2[t]; 0 = not covered -> canonical search.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
+    uint16_t lut2[4][LP_LUT2_SIZE];
+    uint32_t base2[4];          // smallest left-aligned 16-bit value of a code longer than LP_LUT_BITS (0x10000 if none)
     int32_t maxcode[4][18];     // maxcode[l] = largest code of length l, -1 if none; [17] = sentinel
     int32_t valoff[4][17];      // valptr[l] - mincode[l]
     uint8_t vals[4][256];
@@ -43,8 +47,12 @@ struct LpJpeg {
     uint8_t hs[LP_MAX_COMP], vs[LP_MAX_COMP];
     uint8_t dc_tbl[LP_MAX_COMP], ac_tbl[LP_MAX_COMP];   // slots into LpHuffSet (0..1 / 2..3)
     uint8_t blk_comp[8], blk_h[8], blk_v[8];            // per block-in-MCU
+    uint8_t blk_first[LP_MAX_COMP], pad2;               // index inside the MCU of a component's first block
+    uint32_t pad3;
+    uint64_t blkpack;           // 4 bits per block-in-MCU b (bits 4b..4b+3): component (2) | DC table id (1) << 2 | AC table id (1) << 3
     uint32_t bw[LP_MAX_COMP], bh[LP_MAX_COMP];          // blocks per row / column (MCU padded)
-    uint64_t coef_off[LP_MAX_COMP];                     // int16 element offset into the coefficient arena
+    uint64_t coef_off;          // int16 element offset of this image's blocks in the coefficient arena; blocks are stored
+                                // in DECODE order (MCU by MCU, blocks of an MCU in scan order), 64 natural-order coefficients each
     uint64_t plane_off[LP_MAX_COMP];                    // byte offset into the plane arena
     uint32_t plane_stride[LP_MAX_COMP];                 // = bw*8
     uint16_t qt[LP_MAX_COMP][64];                       // dequantisation table per component, natural order
@@ -75,16 +83,33 @@ struct LpSubState {
 };
 
 // Summary of the blocks STARTING inside one subsequence (or inside its prefix up to a checkpoint).
+// DC sums are kept modulo 2^16: the decoder stores DC as int16 (libjpeg JCOEF), so only the low 16 bits matter.
 struct LpSubSum {
     uint32_t nblk;              // block starts
     uint32_t nreset;            // restart boundaries crossed
     int32_t dc[LP_MAX_COMP];    // sum of DC differences per component since the last reset
 };
 
-struct LpCkpt {
-    LpSubState st;
-    LpSubSum sum;
+// LpSubSum as stored in HBM (16 B, one coalesced dwordx4 per lane).
+struct LpSumPk {
+    uint32_t nblk, nreset;
+    uint32_t dc01;              // (dc0 & 0xffff) | dc1 << 16
+    uint32_t dc2;               // low 16 bits significant
 };
+
+// Checkpoint of the speculative pass (16 B): decoder state + sums at a fixed ITERATION of the lane's decode loop.
+// nblk and nreset fit 16 bits because a subsequence is at most 65 504 bits and a block takes at least 2.
+struct LpCkptPk {
+    uint32_t p;                 // 0xffffffff = not recorded
+    uint32_t bz_nreset;         // bz | nreset << 16
+    uint32_t nblk_dc2;          // nblk | (dc2 & 0xffff) << 16
+    uint32_t dc01;
+};
+
+// Checkpoint schedule: checkpoint k is taken before iteration it(k) of the lane's loop,
+//   it(k) = (k + 1) * td                    for k <  nd   (dense: the verify pass usually re-synchronises early)
+//         = nd * td + (k + 1 - nd) * ts     for k >= nd
+struct LpCkSched { uint32_t K, nd, td, ts; };
 
 // ---------------------------------------------------------------------------------------------
 // Pixel frames and per-image operation descriptors (orientation, crop+resize, compositing, encode).

@@ -11,13 +11,20 @@
 #include "../../lilliput_amd/csrc/lp_jpeg_parse.h"
 
 struct HostMem {
-    const uint32_t* words; // lane-interleaved layout (lp_clean_addr)
+    const uint32_t* words; // linear big-endian words of the clean stream
     const LpHuffSet* hs;
     const uint32_t* rst;
-    uint32_t wps;
-    uint32_t word(uint32_t w) const { return words[lp_clean_addr(w, wps)]; }
+    // Ring emulation: the device keeps LP_RING_WORDS words per lane in LDS and tops them up every LP_TOPUP_EVERY steps;
+    // the emulation tracks the same window and ABORTS when the lane logic fetches outside of it.
+    uint32_t fill = 0, lowest = 0;
+    bool* window_violation;
+    uint32_t fetch(uint32_t w) { if (w >= fill || w + LP_RING_WORDS < fill) *window_violation = true; return words[w]; }
+    void reseek(uint32_t w) { fill = (w & ~3u) + LP_RING_WORDS; }
+    void topup(uint32_t w) { for (int i = 0; i < LP_TOPUP_QUADS; i++) if (fill + 4u <= w + LP_RING_WORDS) fill += 4; }
     bool any(bool p) const { return p; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
+    uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[t][i]; }
+    uint32_t base2(uint32_t t) const { return hs->base2[t]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
@@ -26,14 +33,20 @@ struct HostMem {
 
 struct HostSink { // one slot, flushed at the wave-uniform flush points like the device sink
     int16_t blk[64];
-    int16_t* coef[3];
-    const LpJpeg* img;
+    int16_t* coef;      // decode-order blocks
     int16_t* pending = nullptr;
     HostSink() { memset(blk, 0, sizeof(blk)); }
     void put(uint32_t nat, int32_t v) { blk[nat & 63] = (int16_t)v; }
-    void end_block(uint32_t c, uint32_t bx, uint32_t by) { pending = coef[c] + ((size_t)by * img->bw[c] + bx) * 64; }
+    void end_block(uint32_t b) { pending = coef + (size_t)b * 64; }
     bool stalled() const { return pending != nullptr; }
     void flush() { if (pending) { memcpy(pending, blk, 128); memset(blk, 0, sizeof(blk)); pending = nullptr; } }
+};
+
+struct HostCk {
+    LpCkptPk* rec;
+    void record(uint32_t k, const LpCkptPk& c) { rec[k] = c; }
+    uint32_t pos(uint32_t k) const { return rec[k].p; }
+    LpCkptPk load(uint32_t k) const { return rec[k]; }
 };
 
 extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uint32_t C, int comp, int16_t* out, size_t cap_elems,
@@ -60,24 +73,38 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         clean.push_back(c);
     }
     uint32_t total_bits = (uint32_t)clean.size() * 8;
-    const uint32_t wps = S / 32;
-    const size_t nwords = ((clean.size() + 3) / 4 + 32 + (size_t)64 * wps - 1) / ((size_t)64 * wps) * ((size_t)64 * wps);
-    std::vector<uint32_t> words(nwords, 0);
-    for (size_t q = 0; q < clean.size(); q++) words[lp_clean_addr((uint32_t)(q >> 2), wps)] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
+    std::vector<uint32_t> words((clean.size() + 3) / 4 + 64, 0);
+    for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
+    uint32_t n_rst = (uint32_t)rst.size();
     rst.push_back(0);
-    HostMem m{words.data(), &h.huff, rst.data(), wps};
-    uint32_t n_rst = (uint32_t)rst.size() - 1;
-    uint32_t K = S / C;
+    bool violation = false;
+    LpImgCtx ic;
+    ic.blkpack = img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
+    // the engine's schedule (lp_engine.cpp run_decode)
+    LpCkSched cs;
+    const uint32_t cbits = C ? C : 256;
+    cs.K = S / cbits < 1 ? 1 : (S / cbits > LP_MAX_CKPT ? LP_MAX_CKPT : S / cbits);
+    cs.td = cbits / 8 < 2 ? 2 : cbits / 8;
+    cs.nd = cs.K / 2 < 1 ? 1 : cs.K / 2;
+    const uint32_t span = S / 4;
+    cs.ts = cs.K > cs.nd && span > cs.nd * cs.td ? ((span - cs.nd * cs.td) / (cs.K - cs.nd) > cs.td ? (span - cs.nd * cs.td) / (cs.K - cs.nd) : cs.td) : cs.td;
+    const uint32_t K = cs.K;
     uint32_t nsub = (total_bits + S - 1) / S;
     *nsub_out = (int)nsub;
-    std::vector<LpCkpt> ck((size_t)nsub * K);
-    std::vector<LpSubState> ex(nsub), entry_used(nsub);
-    std::vector<LpSubSum> tot(nsub);
+    std::vector<LpCkptPk> ck((size_t)nsub * K);
+    std::vector<LpSubState> spec_ex(nsub), ex(nsub), entry_used(nsub);
+    std::vector<LpSubSum> spec_tot(nsub), tot(nsub);
     for (uint32_t i = 0; i < nsub; i++) {
         LpSubState e{i * S, 0};
-        ex[i].p = 0xffffffffu; ex[i].bz = 0;
-        lp_count_pass(m, img, n_rst, total_bits, i, S, C, K, false, e, &ck[(size_t)i * K], &ex[i], &tot[i]);
-        entry_used[i] = e;
+        HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
+        HostCk hc{&ck[(size_t)i * K]};
+        uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
+        lp_spec_pass(m, ic, sub_end, e, cs, hc, &spec_ex[i], &spec_tot[i]);
+        // the device stores sums packed (16-bit DC fields): round-trip them the same way
+        spec_tot[i] = lp_sum_unpack(lp_sum_pack(spec_tot[i]));
+        ex[i] = spec_ex[i];
+        tot[i] = spec_tot[i];
+        entry_used[i] = LpSubState{0xffffffffu, 0xffffffffu};
     }
     int r = 0, hits = 0;
     for (;;) {
@@ -85,8 +112,16 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         std::vector<LpSubState> snap(ex); // Jacobi sweep: every lane sees the previous round's exits (worst case on a GPU)
         for (uint32_t i = 1; i < nsub; i++) {
             LpSubState e = snap[i - 1];
-            if (lp_state_eq(e, entry_used[i])) { if (r == 0) hits++; continue; }
-            changed += lp_count_pass(m, img, n_rst, total_bits, i, S, C, K, true, e, &ck[(size_t)i * K], &ex[i], &tot[i]) ? 1 : 0;
+            if (lp_state_eq(e, entry_used[i])) continue;
+            HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
+            HostCk hc{&ck[(size_t)i * K]};
+            uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
+            LpSubState ne = ex[i];
+            LpSubSum nt;
+            lp_verify_pass(m, ic, sub_end, e, K, hc, spec_ex[i], spec_tot[i], &ne, &nt);
+            tot[i] = lp_sum_unpack(lp_sum_pack(nt));
+            if (r == 0 && lp_state_eq(ne, spec_ex[i])) hits++;
+            if (!lp_state_eq(ne, ex[i])) { ex[i] = ne; changed++; }
             entry_used[i] = e;
         }
         r++;
@@ -98,22 +133,28 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     std::vector<LpSubSum> prefix(nsub);
     LpSubSum acc;
     lp_sum_zero(acc);
-    for (uint32_t i = 0; i < nsub; i++) { prefix[i] = acc; acc = lp_sum_combine(acc, tot[i]); }
+    for (uint32_t i = 0; i < nsub; i++) { prefix[i] = lp_sum_unpack(lp_sum_pack(acc)); acc = lp_sum_combine(acc, tot[i]); }
     if (acc.nblk < img.total_blocks) return -13;
     static const uint8_t zz[80] = LP_ZIGZAG_INIT;
+    std::vector<int16_t> all((size_t)img.total_blocks * 64, 0x7fff);
     HostSink sink;
-    sink.img = &img;
-    std::vector<int16_t> cbuf[3];
-    for (int c = 0; c < img.ncomp; c++) { cbuf[c].assign((size_t)img.bw[c] * img.bh[c] * 64, 0x7fff); sink.coef[c] = cbuf[c].data(); }
+    sink.coef = all.data();
     uint32_t written = 0;
     for (uint32_t i = 0; i < nsub; i++) {
         LpSubState e = i ? ex[i - 1] : LpSubState{0, 0};
-        written += lp_write_pass(m, img, n_rst, total_bits, e, ex[i].p, prefix[i], zz, sink);
+        HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
+        written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink);
     }
     if (written != img.total_blocks) return -14;
+    if (violation) return -15; // the lane logic read outside the ring window the device would hold
     *bw = (int)img.bw[comp]; *bh = (int)img.bh[comp];
-    size_t ne = cbuf[comp].size();
+    size_t ne = (size_t)img.bw[comp] * img.bh[comp] * 64;
     if (ne > cap_elems) return -3;
-    memcpy(out, cbuf[comp].data(), ne * 2);
+    const uint32_t hs = img.hs[comp], vs = img.vs[comp];
+    for (uint32_t by = 0; by < img.bh[comp]; by++)
+        for (uint32_t bx = 0; bx < img.bw[comp]; bx++) {
+            size_t blk = ((size_t)(by / vs) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[comp] + (by % vs) * hs + (bx % hs);
+            memcpy(out + ((size_t)by * img.bw[comp] + bx) * 64, all.data() + blk * 64, 128);
+        }
     return 0;
 }
