@@ -2,7 +2,11 @@
 // entry point. Semantics per item are those of ImageOps.Transform for a static JPEG source
 // (/root/reference/ops.go:352-479, opencv.go:326-374, 816-900); the images of a batch are independent,
 // so a multi-GPU caller simply gives each device's batch object its own shard of the items.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include <algorithm>
 #include <vector>
@@ -114,6 +118,12 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
     for (auto& h : b->hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
     size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(24ull << 30) / (max_px * 12)));
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
+    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
+    double tw[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
     uint32_t rounds = 0;
     eng.enable_timing(true);
     for (size_t first = 0; first < nv; first += chunk) {
@@ -188,7 +198,9 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             fidx.push_back(k);
             want[(size_t)k] = 0;
         }
+        lap(0);
         int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data(), want.data());
+        lap(1);
         if (rc == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
         { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); }
         std::vector<LpFrame> final_frames = frames;
@@ -197,6 +209,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             acc[4] += eng.timings().resize_ms;
             for (size_t q = 0; q < fops.size(); q++) final_frames[(size_t)fidx[q]] = fops[q].dst;
         }
+        lap(2);
         // orientation (ops.go:392: unconditional) for the images that kept a frame
         std::vector<LpOrientOp> oops;
         std::vector<int> oidx;
@@ -270,7 +283,9 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             std::vector<uint32_t> elen(erq.size(), 0);
             if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
             acc[5] += eng.timings().encode_ms;
+            lap(3);
             if (eng.encoded_fetch_all()) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            lap(4);
             for (size_t q = 0; q < erq.size(); q++) {
                 const int k = eidx[q];
                 const size_t item = (size_t)b->valid[first + (size_t)k];
@@ -286,6 +301,10 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
         }
     }
+    lap(5);
+    if (trace)
+        fprintf(stderr, "[lilliput_hip] run: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f\n",
+                tw[0], tw[1], tw[2], tw[3], tw[4], tw[5], acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
     b->eng.enable_timing(false);
     b->eng.set_timings(LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}); // read by lilliput_hip_batch_timings
     return LILLIPUT_OK;

@@ -474,17 +474,36 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     return LP_OK;
 }
 
-int LpEngine::fused_resample(const LpFusedOp* ops, int n)
+int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (n <= 0) return LP_OK;
     if (!d_fops_.ensure(sizeof(LpFusedOp) * (size_t)n)) return LP_ERR_DEVICE;
-    uint32_t max_px = 0;
-    for (int i = 0; i < n; i++) max_px = std::max(max_px, ops[i].dst.w * ops[i].dst.h);
-    if (!check(hipMemcpyAsync(d_fops_.p, ops, sizeof(LpFusedOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D fused ops")) return LP_ERR_DEVICE;
+    std::vector<LpFusedOp> ops(ops_in, ops_in + n);
+    uint32_t max_px = 0, fast_mask = 0, fast_grid = 0;
+    bool general = false;
+    for (auto& op : ops) {
+        // the 4:2:0 thread-per-pixel kernel needs aligned, even boxes (see k_resample_420)
+        const LpJpeg& j = h_imgs_[op.img];
+        const bool swapped = op.dxy != 0;
+        const uint32_t U = swapped ? op.dst.h : op.dst.w, V = swapped ? op.dst.w : op.dst.h;
+        const int32_t stepx = swapped ? op.dyx : op.dxx;  // source-x step between neighbouring boxes: +-rw
+        bool fast = j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && (op.rw == 8 || op.rw == 16 || op.rw == 32) && !(op.rh & 1) &&
+                    !(op.y0 & 1) && (op.x0 % (int32_t)op.rw) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3;
+        op.fast = fast ? op.rw / 2 : 0;
+        if (fast) {
+            fast_mask |= op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
+            fast_grid = std::max(fast_grid, V * ((U + 255u) / 256u));
+        } else {
+            general = true;
+            max_px = std::max(max_px, op.dst.w * op.dst.h);
+        }
+    }
+    if (!check(hipMemcpyAsync(d_fops_.p, ops.data(), sizeof(LpFusedOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D fused ops")) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
-    lp_launch_resample_fused(stream_, d_imgs_.as<LpJpeg>(), d_fops_.as<LpFusedOp>(), (uint32_t)n, max_px, d_planes_.as<uint8_t>());
+    lp_launch_resample_fused(stream_, d_imgs_.as<LpJpeg>(), d_fops_.as<LpFusedOp>(), (uint32_t)n, max_px, general, fast_mask, fast_grid, d_planes_.as<uint8_t>());
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    // `ops` is pageable host memory read by the async copy: the sync below also covers it
     if (!check(hipStreamSynchronize(stream_), "fused resample sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "fused resample kernel")) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);

@@ -45,15 +45,15 @@
      63, 63}
 
 // Ring geometry of the bit reader. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so
-// LP_TOPUP_EVERY steps consume at most 8 words; after a top-up at most 3 ring words are free (16-byte granularity);
-// the reader also looks one word ahead: 8 + 3 + 1 <= LP_RING_WORDS.
+// LP_TOPUP_EVERY steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte
+// granularity) and a step reads the word pair (w, w+1): 8 + 3 + 2 <= LP_RING_WORDS.
 #define LP_RING_WORDS 16
 #define LP_TOPUP_EVERY 8
 #define LP_TOPUP_QUADS 2
 
 // Per-image values every lane of a workgroup shares (scalar registers on the device).
 struct LpImgCtx {
-    uint64_t blkpack;       // LpJpeg::blkpack
+    uint32_t blkpack;       // low 32 bits of LpJpeg::blkpack (at most LP_MAX_BPM = 6 nibbles)
     uint32_t bpm;
     uint32_t n_rst;         // restart boundaries found by the unstuff kernels
     uint32_t total_bits;    // length of the clean stream
@@ -61,45 +61,48 @@ struct LpImgCtx {
 };
 
 // Memory policy M must provide (per lane object, non-const):
-//   uint32_t fetch(uint32_t widx)           big-endian-corrected word widx of the clean stream (must be inside the ring window)
-//   void reseek(uint32_t widx)              the lane jumps: make [widx, widx + LP_RING_WORDS - 3) fetchable
-//   void topup(uint32_t widx)               wave-uniform call every LP_TOPUP_EVERY steps: words below widx are dead, refill
+//   void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)   words w and w+1 of the clean stream (big-endian corrected: bit 31 first)
+//   void reseek(uint32_t w)                 the lane jumps: make [w, w + LP_RING_WORDS - 3) fetchable
+//   void topup(uint32_t w)                  wave-uniform call every LP_TOPUP_EVERY steps: words below w are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
 //   uint32_t lut(uint32_t tbl, uint32_t i), lut2(tbl, i), base2(tbl)
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
+//
+// The lane keeps NO bit buffer: every step peeks 32 bits at its bit position straight from the ring (one paired LDS read
+// + one 64-bit shift). On MI355X the kernels are VALU-issue bound, and this costs fewer instructions than maintaining a
+// refillable 64-bit buffer; the extra LDS latency on the dependency chain is hidden by the other waves of the SIMD.
 template <class M>
 struct LpLane {
     M& m;
     const LpImgCtx& ic;
-    uint64_t buf;       // next bits, left aligned
-    int32_t avail;      // valid bits in buf
-    uint32_t widx;      // next word to pull into buf
-    uint32_t pending;   // == word(widx), fetched one step ahead
     uint32_t p;         // bit position of the next unread bit
-    uint32_t b, z;      // block-in-MCU, zigzag index
+    uint32_t z;         // zigzag index of the next coefficient (0 = a block starts here)
+    uint32_t b;         // block-in-MCU
+    uint32_t rot;       // ic.blkpack rotated right by 4*b: the low nibble describes the current block
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), buf(0), avail(0), widx(0), pending(0), p(0), b(0), z(0), next_rst(0), rst_k(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b(0), rot(0), next_rst(0), rst_k(0) {}
 
-    LP_HD void seek(uint32_t pos)
+    LP_HD uint32_t peek()
     {
-        p = pos;
-        widx = pos >> 5;
-        const uint32_t off = pos & 31;
-        m.reseek(widx);
-        const uint64_t w0 = m.fetch(widx), w1 = m.fetch(widx + 1);
-        buf = ((w0 << 32) | w1) << off;
-        avail = 64 - (int32_t)off;
-        widx += 2;
-        pending = m.fetch(widx);
+        uint32_t w0, w1;
+        m.fetch2(p >> 5, w0, w1);
+        return (uint32_t)(((((uint64_t)w0) << 32) | w1) << (p & 31u) >> 32);
+    }
+    LP_HD void set_block(uint32_t nb)
+    {
+        b = nb;
+        const uint32_t span = 4u * ic.bpm; // rotate inside the low 4*bpm bits
+        rot = nb ? ((ic.blkpack >> (4u * nb)) | (ic.blkpack << (span - 4u * nb))) & (span >= 32u ? 0xffffffffu : (1u << span) - 1u) : ic.blkpack;
     }
     LP_HD void start(uint32_t pos, uint32_t bz)
     {
-        seek(pos);
-        b = bz >> 8;
-        z = bz & 255;
+        p = pos;
+        m.reseek(pos >> 5);
+        set_block(bz >> 8);
+        z = bz & 255u;
         rst_k = 0;
         next_rst = ic.total_bits;
         if (ic.n_rst) { // first restart boundary at or after pos (binary search)
@@ -112,26 +115,16 @@ struct LpLane {
             next_rst = lo < ic.n_rst ? m.rst_bit(lo) : ic.total_bits;
         }
     }
-    // Once per step, by every lane: move the look-ahead word into the bit buffer when there is room, look ahead again.
-    LP_HD void refill()
-    {
-        if (avail <= 32) {
-            buf |= (uint64_t)pending << (32 - avail);
-            avail += 32;
-            widx++;
-        }
-        pending = m.fetch(widx);
-    }
     LP_HD uint32_t state_bz() const { return (b << 8) | z; }
 
-    // At a block start: detect the end of a restart interval (or of the stream). Returns true when
-    // the lane jumped to the boundary (DC predictors must be reset by the caller).
-    LP_HD bool restart_check()
+    // At a block start: detect the end of a restart interval (or of the stream). `pk` = peek(). Returns true when
+    // the lane jumped to the boundary (DC predictors must be reset by the caller, and peek() must be redone).
+    LP_HD bool restart_check(uint32_t pk)
     {
         const int32_t rem = (int32_t)(next_rst - p);
         if (rem >= 8) return false;
         bool jump = rem <= 0;
-        if (!jump) jump = (uint32_t)(buf >> (64 - rem)) == ((1u << rem) - 1u);
+        if (!jump) jump = (pk >> (32 - rem)) == ((1u << rem) - 1u);
         if (!jump) return false;
         const uint32_t target = next_rst;
         if (rst_k < ic.n_rst) {
@@ -140,8 +133,9 @@ struct LpLane {
         } else {
             next_rst = 0x7fffffffu; // past the end of the stream: nothing left
         }
-        seek(target);
-        b = 0;
+        p = target;
+        m.reseek(target >> 5);
+        set_block(0);
         z = 0;
         return true;
     }
@@ -166,51 +160,40 @@ struct LpLane {
         return e;
     }
 
-    // Decode one Huffman symbol (+ its extra bits). On return:
+    // Decode one Huffman symbol (+ its extra bits) from pk = peek(). On return:
     //   is_dc, k = zigzag index of the coefficient (valid when has_val), val, block_done, comp.
+    // Written branch-free apart from the long-code lookup: every lane of the wave runs the same instructions.
     struct Sym { bool is_dc; bool has_val; bool block_done; uint32_t k; int32_t val; uint32_t comp; };
-    LP_HD Sym step()
+    LP_HD Sym step(uint32_t pk)
     {
         Sym r;
-        const uint32_t nib = (uint32_t)(ic.blkpack >> (b * 4u)) & 15u;
         r.is_dc = (z == 0);
-        r.comp = nib & 3u;
-        const uint32_t tbl = r.is_dc ? ((nib >> 2) & 1u) : 2u + (nib >> 3);
-        const uint32_t top = (uint32_t)(buf >> 48);
-        uint32_t e = m.lut(tbl, top >> (16 - LP_LUT_BITS));
-        if ((e >> 8) == 0) e = long_code(tbl, top);
-        const uint32_t len = e >> 8, sym = e & 255u;
-        buf <<= len;
-        const uint32_t s = sym & 15u;
-        const uint32_t run = r.is_dc ? 0u : sym >> 4;
-        const uint32_t x = (uint32_t)((buf >> 1) >> (63u - s)); // next s bits (0 when s == 0)
-        buf <<= s;
-        const uint32_t used = len + s;
-        avail -= (int32_t)used;
-        p += used;
-        // HUFF_EXTEND: values whose first bit is 0 are negative
-        r.val = x < ((1u << s) >> 1) ? (int32_t)x - (int32_t)((1u << s) - 1u) : (int32_t)x;
-        uint32_t zn;
-        if (r.is_dc) {
-            r.has_val = true;
-            r.k = 0;
-            zn = 1;
-        } else if (s == 0) {
-            r.has_val = false;
-            r.k = 0;
-            zn = (run == 15) ? z + 16 : 64;
-        } else {
-            r.k = z + run;
-            r.has_val = r.k < 64;
-            zn = r.k + 1;
-        }
+        r.comp = rot & 3u;
+        const uint32_t tbl = r.is_dc ? ((rot >> 2) & 1u) : 2u + ((rot >> 3) & 1u);
+        uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
+        if ((e >> 8) == 0) e = long_code(tbl, pk >> 16);
+        const uint32_t len = e >> 8;
+        const uint32_t s = e & 15u;
+        const uint32_t run = (e >> 4) & 15u;      // DC symbols are categories 0..15 (validated by the parser): run == 0
+        const uint32_t t = pk << len;             // the extra bits, left aligned
+        const uint32_t x = (t >> 1) >> (31u - s); // their value (0 when s == 0)
+        // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1)
+        const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);
+        r.val = (int32_t)(x - (neg & ((1u << s) - 1u)));
+        p += len + s;
+        // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL); a coefficient whose index overruns 63 on
+        // a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table carries the same guard entries)
+        const bool eob = !r.is_dc && s == 0 && run != 15;
+        r.k = z + run;                            // DC: z == run == 0; at most 63 + 15
+        r.has_val = r.is_dc || s != 0;
+        const uint32_t zn = eob ? 64u : r.k + 1u; // ZRL (run 15, size 0) skips 16 coefficients: k + 1 == z + 16
         r.block_done = zn >= 64;
-        if (r.block_done) {
-            z = 0;
-            b = (b + 1 == ic.bpm) ? 0 : b + 1;
-        } else {
-            z = zn;
-        }
+        z = r.block_done ? 0u : zn;
+        // next block of the MCU (rotation of the nibble string); branch-free
+        const uint32_t nb = b + 1 == ic.bpm ? 0u : b + 1;
+        const uint32_t nrot = (rot >> 4) | ((rot & 15u) << (4u * (ic.bpm - 1u)));
+        b = r.block_done ? nb : b;
+        rot = r.block_done ? nrot : rot;
         return r;
     }
 };
@@ -309,12 +292,17 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     uint32_t k = 0, iter = 0, next_ck = cs.K ? lp_ck_iter(cs, 0) : 0xffffffffu;
     bool done = false;
     // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off.
-    while (m.any(!done)) {
-        L.refill();
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.widx);
-        if (!done && L.z == 0 && L.restart_check()) { // also catches the padded end of the stream
-            sum.nreset++;
-            for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
+    // Single back edge, no `continue`: the register allocator then updates the lane state in place (the first version of
+    // this loop carried ~30 v_mov copies per iteration across its exits).
+    do {
+        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
+        uint32_t pk = L.peek();
+        if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) { // rare even per wave: a restart boundary or the stream end is near
+            if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
+                sum.nreset++;
+                for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
+            }
+            pk = L.peek();
         }
         if (iter == next_ck) { // wave-uniform: iter, k and next_ck are the same in every lane
             LpSubState st;
@@ -325,12 +313,13 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
             next_ck = k < cs.K ? lp_ck_iter(cs, k) : 0xffffffffu;
         }
         iter++;
-        if (done) continue;
-        if (L.p >= sub_end) { done = true; continue; }
-        if (L.z == 0) sum.nblk++;
-        const typename LpLane<M>::Sym s = L.step();
-        if (s.is_dc) lp_add3(sum.dc, s.comp, s.val);
-    }
+        done = done || L.p >= sub_end;
+        if (!done) {
+            sum.nblk += L.z == 0 ? 1u : 0u;
+            const typename LpLane<M>::Sym s = L.step(pk);
+            lp_add3(sum.dc, s.comp, s.is_dc ? s.val : 0);
+        }
+    } while (m.any(!done));
     LpCkptPk none;
     none.p = 0xffffffffu; none.bz_nreset = 0; none.nblk_dc2 = 0; none.dc01 = 0;
     for (; k < cs.K; k++) ck.record(k, none);
@@ -356,38 +345,44 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
     uint32_t kk = 0, iter = 0;
     uint32_t cp = K ? ck.pos(0) : 0xffffffffu;
     bool done = false, spliced = false;
-    while (m.any(!done)) {
-        L.refill();
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.widx);
+    do { // same shape as the SPEC loop: one back edge, state updated in place
+        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
+        uint32_t pk = L.peek();
         iter++;
-        if (done) continue;
-        if (L.z == 0 && L.restart_check()) {
-            sum.nreset++;
-            for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
-        }
-        while (cp < L.p) { // checkpoints are strictly ordered until the lane that recorded them finished
-            kk++;
-            cp = kk < K ? ck.pos(kk) : 0xffffffffu;
-        }
-        if (cp == L.p && kk < K) {
-            LpSubState cst;
-            LpSubSum csum;
-            lp_ckpt_unpack(ck.load(kk), cst, csum);
-            if (cst.bz == L.state_bz()) { // synchronised with the recorded trajectory at checkpoint kk
-                *total = lp_sum_combine(sum, lp_sum_tail(spec_total, csum));
-                *exit_st = spec_exit;
-                done = true;
-                spliced = true;
-                continue;
+        if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
+            if (!done && L.z == 0 && L.restart_check(pk)) {
+                sum.nreset++;
+                for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
             }
-            kk++; // same position, different state: this checkpoint can never match
-            cp = kk < K ? ck.pos(kk) : 0xffffffffu;
+            pk = L.peek();
         }
-        if (L.p >= sub_end) { done = true; continue; }
-        if (L.z == 0) sum.nblk++;
-        const typename LpLane<M>::Sym s = L.step();
-        if (s.is_dc) lp_add3(sum.dc, s.comp, s.val);
-    }
+        if (!done) {
+            while (cp < L.p) { // checkpoints are strictly ordered until the lane that recorded them finished
+                kk++;
+                cp = kk < K ? ck.pos(kk) : 0xffffffffu;
+            }
+            if (cp == L.p && kk < K) {
+                LpSubState cst;
+                LpSubSum csum;
+                lp_ckpt_unpack(ck.load(kk), cst, csum);
+                if (cst.bz == L.state_bz()) { // synchronised with the recorded trajectory at checkpoint kk
+                    *total = lp_sum_combine(sum, lp_sum_tail(spec_total, csum));
+                    *exit_st = spec_exit;
+                    done = true;
+                    spliced = true;
+                } else {
+                    kk++; // same position, different state: this checkpoint can never match
+                    cp = kk < K ? ck.pos(kk) : 0xffffffffu;
+                }
+            }
+        }
+        done = done || L.p >= sub_end;
+        if (!done) {
+            sum.nblk += L.z == 0 ? 1u : 0u;
+            const typename LpLane<M>::Sym s = L.step(pk);
+            lp_add3(sum.dc, s.comp, s.is_dc ? s.val : 0);
+        }
+    } while (m.any(!done));
     if (!spliced) {
         exit_st->p = L.p;
         exit_st->bz = L.state_bz();
@@ -415,33 +410,34 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = prefix.dc[c];
     bool writing = false, done = false;
     uint32_t written = 0, iter = 0;
-    while (m.any(!done)) {
-        L.refill();
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.widx);
+    do {
+        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
         if ((iter % LP_FLUSH_EVERY) == LP_FLUSH_EVERY - 1) sink.flush();
+        uint32_t pk = L.peek();
         iter++;
-        if (done || sink.stalled()) continue;
-        if (L.z == 0) {
-            if (L.restart_check())
+        const bool act = !done && !sink.stalled();
+        if (m.any(act && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
+            if (act && L.z == 0 && L.restart_check(pk))
                 for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = 0;
-            if (L.p >= end_p || blk >= ic.total_blocks) { done = true; continue; }
-            writing = true;
-        } else if (L.p >= ic.total_bits) { done = true; continue; } // truncated stream
-        const typename LpLane<M>::Sym s = L.step();
-        if (writing) {
-            if (s.is_dc) {
-                lp_add3(pred, s.comp, s.val);
-                sink.put(0, lp_get3(pred, s.comp));
-            } else if (s.has_val) {
-                sink.put(zigzag[s.k], s.val);
-            }
-            if (s.block_done) {
-                sink.end_block(blk);
-                written++;
-                blk++;
+            pk = L.peek();
+        }
+        // a lane stops at the first block start at or after the end of its subsequence (or when the stream is truncated)
+        const bool stop = L.z == 0 ? (L.p >= end_p || blk >= ic.total_blocks) : L.p >= ic.total_bits;
+        done = done || (act && stop);
+        if (act && !stop) {
+            writing = writing || L.z == 0; // a lane that enters mid-block skips to the first block start
+            const typename LpLane<M>::Sym s = L.step(pk);
+            if (writing) {
+                lp_add3(pred, s.comp, s.is_dc ? s.val : 0);
+                if (s.has_val) sink.put(s.is_dc ? 0u : (uint32_t)zigzag[s.k], s.is_dc ? lp_get3(pred, s.comp) : s.val);
+                if (s.block_done) {
+                    sink.end_block(blk);
+                    written++;
+                    blk++;
+                }
             }
         }
-    }
+    } while (m.any(!done));
     sink.flush();
     return written;
 }

@@ -216,20 +216,28 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
 // LDS: the image's LpHuffSet (two-level code tables), one bit-reader ring per lane (word-interleaved: word j of lane l at
 // [j][l], so every wave access hits 64 consecutive dwords -- conflict-free whatever the lanes' positions are).
 #define HUFF_T 256
+#define RING_ROWS (LP_RING_WORDS + 1) // row LP_RING_WORDS mirrors row 0 so that the pair (w, w+1) is always two adjacent rows
 struct DevMem {
     const uint32_t* words;  // this image's clean stream (16-byte aligned)
     uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % LP_RING_WORDS) * 64]
     uint32_t fill;          // next stream word to load (multiple of 4)
     const LpHuffSet* hs;    // LDS
     const uint32_t* rst;
-    __device__ __forceinline__ uint32_t fetch(uint32_t w) const { return ring[(w & (LP_RING_WORDS - 1u)) << 6]; }
+    __device__ __forceinline__ void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1) const
+    {
+        const uint32_t* r = ring + ((w & (LP_RING_WORDS - 1u)) << 6);
+        w0 = r[0];
+        w1 = r[64]; // one ds_read2_b32
+    }
     __device__ __forceinline__ void load_quad()
     {
         const uint4 v = *reinterpret_cast<const uint4*>(words + fill);
-        ring[((fill + 0u) & (LP_RING_WORDS - 1u)) << 6] = v.x;
-        ring[((fill + 1u) & (LP_RING_WORDS - 1u)) << 6] = v.y;
-        ring[((fill + 2u) & (LP_RING_WORDS - 1u)) << 6] = v.z;
-        ring[((fill + 3u) & (LP_RING_WORDS - 1u)) << 6] = v.w;
+        uint32_t* r = ring + ((fill & (LP_RING_WORDS - 1u)) << 6); // fill is a multiple of 4: the quad never wraps
+        r[0] = v.x;
+        r[64] = v.y;
+        r[128] = v.z;
+        r[192] = v.w;
+        if ((fill & (LP_RING_WORDS - 1u)) == 0) ring[LP_RING_WORDS << 6] = v.x;
         fill += 4;
     }
     __device__ __forceinline__ void reseek(uint32_t w)
@@ -245,7 +253,7 @@ struct DevMem {
             if (fill + 4u <= w + LP_RING_WORDS) load_quad();
     }
     __device__ __forceinline__ bool any(bool p) const { return __any(p); }
-    __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
+    __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[t][i]; }
     __device__ __forceinline__ uint32_t base2(uint32_t t) const { return hs->base2[t]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
@@ -265,7 +273,7 @@ __device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
 __device__ __forceinline__ LpImgCtx make_ctx(const LpJpeg& img, const LpJpegState& st)
 {
     LpImgCtx ic;
-    ic.blkpack = img.blkpack;
+    ic.blkpack = (uint32_t)img.blkpack;
     ic.bpm = img.bpm;
     ic.n_rst = st.n_rst;
     ic.total_bits = st.clean_bytes * 8;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
                                                       LpSubState* __restrict__ entry_used, uint32_t S, LpCkSched cs, uint32_t tot_sub)
 {
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
     const bool valid = sub < nsub;
     const uint32_t g = img.sub_off + (valid ? sub : 0);
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
     entry.p = valid ? sub * S : 0;
     entry.bz = 0;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         uint32_t* __restrict__ changed, uint32_t S, uint32_t K, uint32_t tot_sub)
 {
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
     __shared__ uint32_t s_ckpos[HUFF_T * LP_MAX_CKPT];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     const LpSubState entry = load_state(cur_exit + g - 1);
     if (lp_state_eq(entry, entry_used[g])) return; // already verified against this entry state
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     uint32_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) cp[k << 6] = ckpts[(size_t)k * tot_sub + g].p;
     DevCkSrc ck{cp, ckpts + g, tot_sub};
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
                                                        const LpSumPk* __restrict__ prefixes, int16_t* __restrict__ coef_arena)
 {
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * LP_RING_WORDS];
+    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
     __shared__ __attribute__((aligned(16))) int16_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
     const LpJpeg& img = imgs[blockIdx.y];
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     if (sub >= nsub) return;
     const uint32_t g = img.sub_off + sub;
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * LP_RING_WORDS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
     DevSink sink;

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
                                                         const uint8_t* __restrict__ plane_arena)
 {
     const LpFusedOp& op = ops[blockIdx.y];
+    if (op.fast) return; // taken by k_resample_420
     const LpJpeg& img = imgs[op.img];
     const uint32_t npx = op.dst.w * op.dst.h;
     const uint32_t pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -190,6 +191,124 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
         else r = sat_round_u8(__fmul_rn((float)sum, op.inv_area));
         uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * cn;
         D[lane] = (uint8_t)r;
+    }
+}
+
+// K_resample, 4:2:0 fast path (the BASELINE configs[1] shape: 4096x4096 -> 256x256 is a 16x16 box per thumbnail pixel).
+// One THREAD per destination pixel; consecutive threads own boxes that are adjacent along the source x axis, so each
+// luma row of a wave is one contiguous run of 16-byte loads and each chroma row a run of 8-byte loads. A thread walks its
+// box two luma rows (= one chroma row) at a time with a sliding window of three chroma rows for the vertical half of
+// h2v2_fancy_upsample (jdsample.c), then the horizontal half, YCbCr->BGR (jdcolor.c) and the integer box sums.
+// RWC = chroma columns per box (box width / 2). Requirements (checked by the host, LpFusedOp::fast): YCbCr 4:2:0,
+// box width in {8,16,32}, even box height, every box starts at a multiple of its width in x and at an even y.
+template <int RWC>
+__global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+                                                      const uint8_t* __restrict__ plane_arena)
+{
+    const LpFusedOp& op = ops[blockIdx.y];
+    if (op.fast != (uint32_t)RWC) return;
+    const LpJpeg& img = imgs[op.img];
+    const bool swapped = op.dxy != 0;                     // orientations 5..8: destination x runs along source y
+    const uint32_t U = swapped ? op.dst.h : op.dst.w;     // boxes along source x
+    const uint32_t V = swapped ? op.dst.w : op.dst.h;
+    const uint32_t ublocks = (U + 255u) / 256u;
+    const uint32_t v = blockIdx.x / ublocks, u = (blockIdx.x - v * ublocks) * 256u + threadIdx.x;
+    if (v >= V || u >= U) return;
+    const int32_t dx = (int32_t)(swapped ? v : u), dy = (int32_t)(swapped ? u : v);
+    const int32_t fx0 = op.x0 + dx * op.dxx + dy * op.dyx, fy0 = op.y0 + dx * op.dxy + dy * op.dyy;
+    const uint32_t sy_ = img.plane_stride[0], sc_ = img.plane_stride[1];
+    const uint8_t* PY = plane_arena + img.plane_off[0] + (size_t)fy0 * sy_ + fx0;
+    const uint8_t* PB = plane_arena + img.plane_off[1];
+    const uint8_t* PR = plane_arena + img.plane_off[2];
+    const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
+    const int32_t dw = (W + 1) >> 1, dh = (H + 1) >> 1;
+    const int32_t cx0 = fx0 >> 1, cy0 = fy0 >> 1, nrows = (int32_t)(op.rh >> 1);
+    const bool has_l = cx0 > 0, has_r = cx0 + RWC <= dw - 1;
+    // chroma row r of both planes -> RWC + 2 samples (index 0 = left neighbour, RWC + 1 = right neighbour; replicated at the edges)
+    int32_t cbw[3][RWC + 2], crw[3][RWC + 2];
+    auto load_row = [&](int32_t r, int32_t* cb, int32_t* cr) {
+        r = r < 0 ? 0 : r > dh - 1 ? dh - 1 : r;
+        const uint8_t* b = PB + (size_t)r * sc_ + cx0;
+        const uint8_t* c = PR + (size_t)r * sc_ + cx0;
+        uint32_t wb[RWC / 4], wc[RWC / 4];
+        if (RWC == 4) { wb[0] = *reinterpret_cast<const uint32_t*>(b); wc[0] = *reinterpret_cast<const uint32_t*>(c); }
+        else if (RWC == 8) {
+            const uint2 vb = *reinterpret_cast<const uint2*>(b), vc = *reinterpret_cast<const uint2*>(c);
+            wb[0] = vb.x; wb[1 % (RWC / 4)] = vb.y; wc[0] = vc.x; wc[1 % (RWC / 4)] = vc.y;
+        } else {
+            const uint4 vb = *reinterpret_cast<const uint4*>(b), vc = *reinterpret_cast<const uint4*>(c);
+            wb[0] = vb.x; wb[1 % (RWC / 4)] = vb.y; wb[2 % (RWC / 4)] = vb.z; wb[3 % (RWC / 4)] = vb.w;
+            wc[0] = vc.x; wc[1 % (RWC / 4)] = vc.y; wc[2 % (RWC / 4)] = vc.z; wc[3 % (RWC / 4)] = vc.w;
+        }
+#pragma unroll
+        for (int i = 0; i < RWC; i++) {
+            cb[i + 1] = (int32_t)((wb[i >> 2] >> (8 * (i & 3))) & 255u);
+            cr[i + 1] = (int32_t)((wc[i >> 2] >> (8 * (i & 3))) & 255u);
+        }
+        cb[0] = has_l ? (int32_t)b[-1] : cb[1];
+        cr[0] = has_l ? (int32_t)c[-1] : cr[1];
+        cb[RWC + 1] = has_r ? (int32_t)b[RWC] : cb[RWC];
+        cr[RWC + 1] = has_r ? (int32_t)c[RWC] : cr[RWC];
+    };
+    load_row(cy0 - 1, cbw[0], crw[0]);
+    load_row(cy0, cbw[1], crw[1]);
+    int32_t sb = 0, sg = 0, sr = 0;
+    const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
+    const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
+    for (int32_t q = 0; q < nrows; q++) {
+        load_row(cy0 + q + 1, cbw[2], crw[2]);
+        // luma rows 2q and 2q+1 of the box
+        uint32_t ly[2][RWC / 2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint8_t* yp = PY + (size_t)(2 * q + rr) * sy_;
+            if (RWC == 4) { const uint2 t = *reinterpret_cast<const uint2*>(yp); ly[rr][0] = t.x; ly[rr][1 % (RWC / 2)] = t.y; }
+            else {
+#pragma unroll
+                for (int k4 = 0; k4 < RWC / 8; k4++) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(yp + 16 * k4);
+                    ly[rr][(4 * k4 + 0) % (RWC / 2)] = t.x; ly[rr][(4 * k4 + 1) % (RWC / 2)] = t.y;
+                    ly[rr][(4 * k4 + 2) % (RWC / 2)] = t.z; ly[rr][(4 * k4 + 3) % (RWC / 2)] = t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            // vertical pass: 3 * this row + the nearer neighbour row (above for the upper output row, below for the lower one)
+            int32_t vb[RWC + 2], vr[RWC + 2];
+#pragma unroll
+            for (int i = 0; i < RWC + 2; i++) {
+                vb[i] = 3 * cbw[1][i] + cbw[rr ? 2 : 0][i];
+                vr[i] = 3 * crw[1][i] + crw[rr ? 2 : 0][i];
+            }
+#pragma unroll
+            for (int i = 0; i < RWC; i++) {
+#pragma unroll
+                for (int hx = 0; hx < 2; hx++) {
+                    // horizontal pass: even output column leans on the left neighbour (+8), odd on the right one (+7)
+                    const int32_t cb = (3 * vb[i + 1] + vb[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
+                    const int32_t cr = (3 * vr[i + 1] + vr[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
+                    const int32_t px = 2 * i + hx;
+                    const int32_t yy = (int32_t)((ly[rr][px >> 2] >> (8 * (px & 3))) & 255u);
+                    // jdcolor.c ycc_rgb_convert with the -128 offsets folded into the rounding constants
+                    const int32_t r = yy + ((FIX16(1.40200) * cr + KR) >> 16);
+                    const int32_t b = yy + ((FIX16(1.77200) * cb + KB) >> 16);
+                    const int32_t g = yy + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + KG) >> 16);
+                    sb += (int32_t)clamp8(b); sg += (int32_t)clamp8(g); sr += (int32_t)clamp8(r);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RWC + 2; i++) { cbw[0][i] = cbw[1][i]; cbw[1][i] = cbw[2][i]; crw[0][i] = crw[1][i]; crw[1][i] = crw[2][i]; }
+    }
+    uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
+    const int32_t sums[3] = {sb, sg, sr};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint32_t r;
+        if (op.round_2x2) r = (uint32_t)(sums[c] + 2) >> 2;
+        else r = sat_round_u8(__fmul_rn((float)sums[c], op.inv_area));
+        D[c] = (uint8_t)r;
     }
 }
 
@@ -358,11 +477,16 @@ void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, 
     hipLaunchKernelGGL(k_ycc_to_frame, g, dim3(64, 4), 0, s, d_imgs, d_planes, d_dsts, d_frames);
 }
 
-void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFusedOp* d_ops, uint32_t nops, uint32_t max_px, const uint8_t* d_planes)
+void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFusedOp* d_ops, uint32_t nops, uint32_t max_px, bool general,
+                              uint32_t fast_mask, uint32_t fast_grid, const uint8_t* d_planes)
 {
-    if (!nops || !max_px) return;
+    if (!nops) return;
     dim3 g((max_px + 3) / 4, nops);
-    hipLaunchKernelGGL(k_resample_fused, g, dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (general && max_px) hipLaunchKernelGGL(k_resample_fused, g, dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    // fast_grid = max over the fast ops of V * ceil(U / 256)
+    if (fast_mask & 1u) hipLaunchKernelGGL(k_resample_420<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 2u) hipLaunchKernelGGL(k_resample_420<8>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 4u) hipLaunchKernelGGL(k_resample_420<16>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
 }
 
 void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_src, uint8_t* d_dst)

@@ -147,7 +147,7 @@ struct LpFusedOp {
     int32_t x0, y0, dxx, dxy, dyx, dyy;
     float inv_area;
     uint32_t round_2x2;         // 1: (sum+2)>>2 (ResizeAreaFastVec_SIMD_8u), 0: cvRound(sum * inv_area)
-    uint32_t pad;
+    uint32_t fast;              // 0: general kernel; 4 / 8 / 16: k_resample_420<fast> (chroma columns per box), set by the engine
     LpFrame dst;
 };
 

@@ -18,7 +18,12 @@ struct HostMem {
     // the emulation tracks the same window and ABORTS when the lane logic fetches outside of it.
     uint32_t fill = 0, lowest = 0;
     bool* window_violation;
-    uint32_t fetch(uint32_t w) { if (w >= fill || w + LP_RING_WORDS < fill) *window_violation = true; return words[w]; }
+    void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)
+    {
+        if (w + 1 >= fill || w + LP_RING_WORDS < fill) *window_violation = true;
+        w0 = words[w];
+        w1 = words[w + 1];
+    }
     void reseek(uint32_t w) { fill = (w & ~3u) + LP_RING_WORDS; }
     void topup(uint32_t w) { for (int i = 0; i < LP_TOPUP_QUADS; i++) if (fill + 4u <= w + LP_RING_WORDS) fill += 4; }
     bool any(bool p) const { return p; }
@@ -79,7 +84,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     rst.push_back(0);
     bool violation = false;
     LpImgCtx ic;
-    ic.blkpack = img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
+    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
     // the engine's schedule (lp_engine.cpp run_decode)
     LpCkSched cs;
     const uint32_t cbits = C ? C : 256;
