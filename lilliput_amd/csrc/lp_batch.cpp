@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
+#include <string>
+#include <thread>
 
 #include <algorithm>
 #include <vector>
@@ -14,17 +17,43 @@
 #include "lp_abi.h"
 #include "lp_ops_logic.h"
 
+// One engine (= one HIP stream + its arenas) per worker; a batch is split into contiguous parts, one per worker, and the
+// workers run concurrently on host threads so that one part's HBM-bound stages (IDCT, resample, unstuff) overlap another
+// part's VALU-bound Huffman stages on the same GPU.
+struct LpBatchPart {
+    std::unique_ptr<LpEngine> eng;
+    std::vector<LpJpegHeader> hdrs;     // parsed headers of this part's items (upload order)
+    std::vector<int> items;             // their indices in the item array
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t rounds = 0;
+    double tw[6] = {0, 0, 0, 0, 0, 0};
+    std::string err;
+    int rc = 0;
+};
+
 struct LpBatch {
-    LpEngine eng;
-    std::vector<LpJpegHeader> hdrs;
+    int device = 0;
+    std::vector<LpBatchPart> parts;
     std::vector<int> parse_status;      // LILLIPUT_* per uploaded item
-    std::vector<int> valid;             // indices (into the item array) of successfully parsed items, upload order
     // results of the last run, indexed like the item array
     std::vector<int> status, out_w, out_h;
     std::vector<uint32_t> out_len;
     std::vector<std::vector<uint8_t>> out_bytes;   // host copies fetched during run (download hands them to the caller)
     size_t n_items = 0;
-    explicit LpBatch(int dev) : eng(dev) {}
+    uint32_t S = 0, C = 0;
+    LpTimings tm = {};
+    LpEngine& eng0() { return *parts[0].eng; }
+    bool ensure_parts(size_t n)
+    {
+        while (parts.size() < n) {
+            LpBatchPart p;
+            p.eng.reset(new LpEngine(device));
+            if (!p.eng->ok()) { lp_set_error(p.eng->last_error()); return false; }
+            p.eng->set_subsequence(S, C);
+            parts.push_back(std::move(p));
+        }
+        return true;
+    }
 };
 
 static int map_parse(int rc)
@@ -52,86 +81,102 @@ extern "C" {
 
 lilliput_hip_batch lilliput_hip_batch_create(int device)
 {
-    auto b = new LpBatch(device);
-    if (!b->eng.ok()) {
-        lp_set_error(b->eng.last_error());
-        delete b;
-        return nullptr;
-    }
+    auto b = new LpBatch();
+    b->device = device;
+    if (!b->ensure_parts(1)) { delete b; return nullptr; }
     return b;
 }
 
 void lilliput_hip_batch_destroy(lilliput_hip_batch b) { delete static_cast<LpBatch*>(b); }
 
-void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C) { static_cast<LpBatch*>(bb)->eng.set_subsequence(S, C); }
+void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    b->S = S; b->C = C;
+    for (auto& p : b->parts) p.eng->set_subsequence(S, C);
+}
 
 void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* verify_rounds)
 {
-    const LpTimings& t = static_cast<LpBatch*>(bb)->eng.timings();
+    const LpTimings& t = static_cast<LpBatch*>(bb)->tm;
     out_ms[6] = t.huff_spec_ms; out_ms[7] = t.huff_verify_ms; out_ms[8] = t.huff_scan_ms; out_ms[9] = t.huff_write_ms;
     out_ms[0] = t.unstuff_ms; out_ms[1] = t.huff_ms; out_ms[2] = t.idct_ms; out_ms[3] = t.color_ms; out_ms[4] = t.resize_ms; out_ms[5] = t.encode_ms;
     if (verify_rounds) *verify_rounds = (int)t.verify_rounds;
 }
 
-int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n)
+static int batch_streams(int requested)
+{
+    int n = requested;
+    if (n <= 0) { const char* e = getenv("LILLIPUT_HIP_STREAMS"); n = e ? atoi(e) : 2; }
+    return std::max(1, std::min(8, n));
+}
+
+int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n, int streams)
 {
     auto b = static_cast<LpBatch*>(bb);
     if (!b) return LILLIPUT_ERR_DEVICE;
     b->n_items = n;
-    b->hdrs.clear();
     b->parse_status.assign(n, LILLIPUT_OK);
-    b->valid.clear();
-    std::vector<LpJpegSrc> srcs;
+    std::vector<int> valid;
     std::vector<LpJpegHeader> hv;
     for (size_t i = 0; i < n; i++) {
         LpJpegHeader h;
         int rc = (items[i].src && items[i].src_len) ? lp_jpeg_parse((const uint8_t*)items[i].src, items[i].src_len, &h) : LP_PARSE_NOT_JPEG;
         b->parse_status[i] = map_parse(rc);
-        if (rc == LP_PARSE_OK) {
-            b->valid.push_back((int)i);
-            hv.push_back(h);
-            srcs.push_back(LpJpegSrc{(const uint8_t*)items[i].src, items[i].src_len});
-        }
+        if (rc == LP_PARSE_OK) { valid.push_back((int)i); hv.push_back(h); }
     }
-    b->hdrs.swap(hv);
-    if (b->valid.empty()) return LILLIPUT_OK;
-    int rc = b->eng.upload_jpegs(srcs.data(), (int)srcs.size(), b->hdrs.data());
-    if (rc) { lp_set_error(b->eng.last_error()); return map_status(rc); }
+    // contiguous parts, one per worker; small batches stay on one stream
+    size_t np = (size_t)batch_streams(streams);
+    if (valid.size() < 2 * np) np = 1;
+    if (!b->ensure_parts(np)) return LILLIPUT_ERR_DEVICE;
+    for (auto& p : b->parts) { p.hdrs.clear(); p.items.clear(); }
+    for (size_t q = 0; q < valid.size(); q++) {
+        LpBatchPart& p = b->parts[q * np / valid.size()];
+        p.items.push_back(valid[q]);
+        p.hdrs.push_back(hv[q]);
+    }
+    for (size_t k = 0; k < np; k++) {
+        LpBatchPart& p = b->parts[k];
+        if (p.items.empty()) continue;
+        std::vector<LpJpegSrc> srcs;
+        for (int it : p.items) srcs.push_back(LpJpegSrc{(const uint8_t*)items[it].src, items[it].src_len});
+        int rc = p.eng->upload_jpegs(srcs.data(), (int)srcs.size(), p.hdrs.data());
+        if (rc) { lp_set_error(p.eng->last_error()); return map_status(rc); }
+    }
     return LILLIPUT_OK;
 }
 
-int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
+int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n) { return lilliput_hip_batch_upload2(bb, items, n, 0); }
+
+// Every stage of ImageOps.Transform for one part of the batch (runs on the part's own host thread).
+static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options* opt, bool trace)
 {
-    auto b = static_cast<LpBatch*>(bb);
-    if (!b || !opt) return LILLIPUT_ERR_DEVICE;
-    LpEngine& eng = b->eng;
-    const size_t n = b->n_items, nv = b->valid.size();
-    b->status = b->parse_status;
-    b->out_w.assign(n, 0);
-    b->out_h.assign(n, 0);
-    b->out_len.assign(n, 0);
-    b->out_bytes.assign(n, std::vector<uint8_t>());
+    LpEngine& eng = *part.eng;
+    const size_t nv = part.items.size();
+    float* acc = part.acc;
+    for (int i = 0; i < 10; i++) acc[i] = 0;
+    for (int i = 0; i < 6; i++) part.tw[i] = 0;
+    part.rounds = 0;
     if (!nv) return LILLIPUT_OK;
+    auto fail = [&](const std::string& m) { part.err = m; return LILLIPUT_ERR_DEVICE; };
     const int quality = opt->jpeg_quality > 0 ? opt->jpeg_quality : 95;
     // chunk size: bound the working set (coefficients + planes + BGR frame ~ 7.5 B/pixel + oriented copy)
     size_t max_px = 1;
-    for (auto& h : b->hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
-    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(24ull << 30) / (max_px * 12)));
-    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
-    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
-    double tw[6] = {0, 0, 0, 0, 0, 0};
+    for (auto& h : part.hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
+    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(48ull << 30) / (max_px * 12)));
+    uint32_t& rounds = part.rounds;
+    double* tw = part.tw;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
-    uint32_t rounds = 0;
+    (void)trace;
     eng.enable_timing(true);
     for (size_t first = 0; first < nv; first += chunk) {
         const int cnt = (int)std::min(chunk, nv - first);
         // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
         size_t need = 0;
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = b->hdrs[first + k].j;
+            const LpJpeg& j = part.hdrs[first + k].j;
             const bool swap = j.orientation >= 5;
             const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
@@ -142,7 +187,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             if (!fused) need += fb + 512 + (j.orientation != 1 ? fb + 512 : 0);
             if (plan.resize) need += (size_t)plan.out_w * plan.out_h * cn + 512;
         }
-        if (!eng.heap_reserve(need + 4096)) { lp_set_error("frame heap allocation failed"); return LILLIPUT_ERR_DEVICE; }
+        if (!eng.heap_reserve(need + 4096)) return fail("frame heap allocation failed");
         eng.heap_reset();
         // Plan every image first (ops.go:449-479 + opencv.go:294-374). Integer-scale area resizes take the fused
         // path (planes -> thumbnail, orientation and crop folded into the addressing); everything else goes through
@@ -155,7 +200,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         std::vector<int> fidx;
         memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = b->hdrs[first + k].j;
+            const LpJpeg& j = part.hdrs[first + k].j;
             const bool swap = j.orientation >= 5;
             const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
@@ -192,7 +237,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             op.dst.w = (uint32_t)plan.out_w; op.dst.h = (uint32_t)plan.out_h; op.dst.cn = j.ncomp == 1 ? 1 : 3;
             op.dst.stride = op.dst.w * op.dst.cn;
             uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);
-            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            if (!p) return fail("frame heap exhausted");
             op.dst.off = (uint64_t)(uintptr_t)p;
             fops.push_back(op);
             fidx.push_back(k);
@@ -201,11 +246,11 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         lap(0);
         int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data(), want.data());
         lap(1);
-        if (rc == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+        if (rc == LP_ERR_DEVICE) return fail(eng.last_error());
         { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); }
         std::vector<LpFrame> final_frames = frames;
         if (!fops.empty()) {
-            if (eng.fused_resample(fops.data(), (int)fops.size())) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            if (eng.fused_resample(fops.data(), (int)fops.size())) return fail(eng.last_error());
             acc[4] += eng.timings().resize_ms;
             for (size_t q = 0; q < fops.size(); q++) final_frames[(size_t)fidx[q]] = fops[q].dst;
         }
@@ -214,7 +259,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         std::vector<LpOrientOp> oops;
         std::vector<int> oidx;
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = b->hdrs[first + k].j;
+            const LpJpeg& j = part.hdrs[first + k].j;
             if (st[(size_t)k] || j.orientation == 1 || !want[(size_t)k]) continue;
             LpOrientOp op;
             memset(&op, 0, sizeof(op));
@@ -226,13 +271,13 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             op.dst.h = swap ? op.src.w : op.src.h;
             op.dst.stride = op.dst.w * op.src.cn;
             uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);
-            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            if (!p) return fail("frame heap exhausted");
             op.dst.off = (uint64_t)(uintptr_t)p;
             oops.push_back(op);
             oidx.push_back(k);
         }
         if (!oops.empty()) {
-            if (eng.orient(oops.data(), (int)oops.size())) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            if (eng.orient(oops.data(), (int)oops.size())) return fail(eng.last_error());
             for (size_t q = 0; q < oops.size(); q++) { frames[(size_t)oidx[q]] = oops[q].dst; final_frames[(size_t)oidx[q]] = oops[q].dst; }
         }
         // fit / resize through frames
@@ -251,7 +296,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             LpFrame d;
             memset(&d, 0, sizeof(d));
             uint8_t* p = eng.heap_alloc((size_t)plan.out_w * plan.out_h * f.cn);
-            if (!p) { lp_set_error("frame heap exhausted"); return LILLIPUT_ERR_DEVICE; }
+            if (!p) return fail("frame heap exhausted");
             d.off = (uint64_t)(uintptr_t)p;
             rqs.push_back(rq);
             rdst.push_back(d);
@@ -259,7 +304,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         }
         if (!rqs.empty()) {
             std::vector<int> rst(rqs.size(), 0);
-            if (eng.resize(rqs.data(), (int)rqs.size(), rdst.data(), rst.data()) == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            if (eng.resize(rqs.data(), (int)rqs.size(), rdst.data(), rst.data()) == LP_ERR_DEVICE) return fail(eng.last_error());
             acc[4] += eng.timings().resize_ms;
             for (size_t q = 0; q < rqs.size(); q++) {
                 if (rst[q]) st[(size_t)ridx[q]] = rst[q];
@@ -281,14 +326,14 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
         if (!erq.empty()) {
             std::vector<int> est(erq.size(), 0);
             std::vector<uint32_t> elen(erq.size(), 0);
-            if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) return fail(eng.last_error());
             acc[5] += eng.timings().encode_ms;
             lap(3);
-            if (eng.encoded_fetch_all()) { lp_set_error(eng.last_error()); return LILLIPUT_ERR_DEVICE; }
+            if (eng.encoded_fetch_all()) return fail(eng.last_error());
             lap(4);
             for (size_t q = 0; q < erq.size(); q++) {
                 const int k = eidx[q];
-                const size_t item = (size_t)b->valid[first + (size_t)k];
+                const size_t item = (size_t)part.items[first + (size_t)k];
                 if (est[q]) { st[(size_t)k] = est[q]; continue; }
                 b->out_len[item] = elen[q];
                 b->out_w[item] = (int)erq[q].src.w;
@@ -297,17 +342,52 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             }
         }
         for (int k = 0; k < cnt; k++) {
-            const size_t item = (size_t)b->valid[first + (size_t)k];
+            const size_t item = (size_t)part.items[first + (size_t)k];
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
         }
     }
     lap(5);
-    if (trace)
-        fprintf(stderr, "[lilliput_hip] run: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f\n",
-                tw[0], tw[1], tw[2], tw[3], tw[4], tw[5], acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
-    b->eng.enable_timing(false);
-    b->eng.set_timings(LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}); // read by lilliput_hip_batch_timings
+    eng.enable_timing(false);
     return LILLIPUT_OK;
+}
+
+int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || !opt) return LILLIPUT_ERR_DEVICE;
+    const size_t n = b->n_items;
+    b->status = b->parse_status;
+    b->out_w.assign(n, 0);
+    b->out_h.assign(n, 0);
+    b->out_len.assign(n, 0);
+    b->out_bytes.assign(n, std::vector<uint8_t>());
+    // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
+    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
+    size_t active = 0;
+    for (auto& p : b->parts) active += p.items.empty() ? 0 : 1;
+    if (active <= 1) {
+        for (auto& p : b->parts) p.rc = p.items.empty() ? LILLIPUT_OK : run_part(b, p, opt, trace);
+    } else {
+        std::vector<std::thread> th;
+        for (auto& p : b->parts)
+            if (!p.items.empty()) th.emplace_back([b, &p, opt, trace] { p.rc = run_part(b, p, opt, trace); });
+            else p.rc = LILLIPUT_OK;
+        for (auto& t : th) t.join();
+    }
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t rounds = 0;
+    int rc = LILLIPUT_OK;
+    for (auto& p : b->parts) {
+        if (p.rc) { rc = p.rc; lp_set_error(p.err); }
+        if (p.items.empty()) continue;
+        for (int i = 0; i < 10; i++) acc[i] += p.acc[i];
+        rounds = std::max(rounds, p.rounds);
+        if (trace)
+            fprintf(stderr, "[lilliput_hip] part of %zu: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f\n",
+                    p.items.size(), p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5]);
+    }
+    b->tm = LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}; // read by lilliput_hip_batch_timings
+    return rc;
 }
 
 int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n)
@@ -348,13 +428,13 @@ static int decode_one(LpBatch* b, const void* src, size_t len, LpJpegHeader* h, 
     if (rc) return map_parse(rc);
     const LpJpeg& j = h->j;
     size_t fb = (size_t)j.width * j.height * (j.ncomp == 1 ? 1 : 3);
-    if (!b->eng.heap_reserve(fb + 4096)) return LILLIPUT_ERR_DEVICE;
-    b->eng.heap_reset();
+    if (!b->eng0().heap_reserve(fb + 4096)) return LILLIPUT_ERR_DEVICE;
+    b->eng0().heap_reset();
     LpJpegSrc s{(const uint8_t*)src, len};
     memset(f, 0, sizeof(*f));
     int st = 0;
-    rc = b->eng.decode_jpegs(&s, 1, h, f, &st);
-    if (rc || st) { lp_set_error(b->eng.last_error()); return map_status(rc ? rc : st); }
+    rc = b->eng0().decode_jpegs(&s, 1, h, f, &st);
+    if (rc || st) { lp_set_error(b->eng0().last_error()); return map_status(rc ? rc : st); }
     return LILLIPUT_OK;
 }
 
@@ -368,8 +448,8 @@ int lilliput_hip_decode_jpeg(lilliput_hip_batch bb, const void* src, size_t len,
     *w = (int)f.w; *h = (int)f.h; *channels = (int)f.cn; *orientation = hd.j.orientation;
     size_t nb = (size_t)f.stride * f.h;
     if (nb > cap) return LILLIPUT_ERR_BUF_TOO_SMALL;
-    if (hipMemcpyAsync(dst, (const void*)(uintptr_t)f.off, nb, hipMemcpyDeviceToHost, b->eng.stream()) != hipSuccess) return LILLIPUT_ERR_DEVICE;
-    return b->eng.sync() ? LILLIPUT_ERR_DEVICE : LILLIPUT_OK;
+    if (hipMemcpyAsync(dst, (const void*)(uintptr_t)f.off, nb, hipMemcpyDeviceToHost, b->eng0().stream()) != hipSuccess) return LILLIPUT_ERR_DEVICE;
+    return b->eng0().sync() ? LILLIPUT_ERR_DEVICE : LILLIPUT_OK;
 }
 
 int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch bb, const void* src, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh)
@@ -381,7 +461,7 @@ int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch bb, const void* src, size_
     if (rc) return rc;
     if (comp < 0 || comp >= hd.j.ncomp) return LILLIPUT_ERR_INVALID_IMAGE;
     *bw = (int)hd.j.bw[comp]; *bh = (int)hd.j.bh[comp];
-    return map_status(b->eng.copy_coefs(0, comp, dst, cap_elems));
+    return map_status(b->eng0().copy_coefs(0, comp, dst, cap_elems));
 }
 
 int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch bb, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph)
@@ -393,7 +473,7 @@ int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch bb, const void* src, size_
     if (rc) return rc;
     if (comp < 0 || comp >= hd.j.ncomp) return LILLIPUT_ERR_INVALID_IMAGE;
     *pw = (int)hd.j.bw[comp] * 8; *ph = (int)hd.j.bh[comp] * 8;
-    return map_status(b->eng.copy_plane(0, comp, dst, cap));
+    return map_status(b->eng0().copy_plane(0, comp, dst, cap));
 }
 
 } // extern "C"

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 
 #include "lp_launch.h"
 
@@ -87,7 +88,7 @@ uint8_t* LpEngine::heap_alloc(size_t bytes)
 static uint32_t pick_S(size_t max_ecs_bytes)
 {
     size_t bits = max_ecs_bytes * 8;
-    if (bits >= (1u << 22)) return 8192;
+    if (bits >= (1u << 22)) return 16384;
     if (bits >= (1u << 19)) return 4096;
     if (bits >= (1u << 16)) return 1024;
     return 256;
@@ -622,7 +623,12 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    if (!enc_tables_ready_) { lp_encode_init_tables(); enc_tables_ready_ = true; }
+    if (!enc_tables_ready_) {
+        static std::mutex mu; // engines on several host threads share the device-side table symbol
+        std::lock_guard<std::mutex> lk(mu);
+        lp_encode_init_tables();
+        enc_tables_ready_ = true;
+    }
     h_jobs_.assign((size_t)n, LpEncJob());
     std::vector<uint8_t> hdrs;
     size_t coef_elems = 0, bits_words = 0, out_bytes = 0;
@@ -703,15 +709,17 @@ int LpEngine::encoded_copy(int i, uint8_t* dst, size_t cap)
 
 int LpEngine::encoded_fetch_all()
 {
+    // pack on the device, then ONE D2H copy (a copy per image costs ~10 us each of host time)
+    const size_t n = h_jobs_.size();
     size_t total = 0;
-    h_out_off_.assign(h_jobs_.size(), 0);
-    for (size_t i = 0; i < h_jobs_.size(); i++) { h_out_off_[i] = total; total += align_up(h_estates_[i].out_len, 16); }
-    if (!h_out_.ensure(total + 64)) return LP_ERR_DEVICE;
-    for (size_t i = 0; i < h_jobs_.size(); i++) {
-        const uint32_t len = h_estates_[i].out_len;
-        if (!len) continue;
-        if (!check(hipMemcpyAsync(h_out_.as<uint8_t>() + h_out_off_[i], encoded_device_ptr((int)i), len, hipMemcpyDeviceToHost, stream_), "D2H jpeg"))
-            return LP_ERR_DEVICE;
-    }
-    return sync();
+    h_out_off_.assign(n, 0);
+    std::vector<uint32_t> pk(n);
+    for (size_t i = 0; i < n; i++) { h_out_off_[i] = total; pk[i] = (uint32_t)total; total += align_up(h_estates_[i].out_len, 16) + 16; }
+    if (!n || !total) return LP_OK;
+    if (total > 0xffffffffull || !h_out_.ensure(total + 64) || !d_packed_.ensure(total + 64) || !d_pkoff_.ensure(n * 4 + 64)) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(d_pkoff_.p, pk.data(), n * 4, hipMemcpyHostToDevice, stream_), "H2D pack offsets")) return LP_ERR_DEVICE;
+    lp_launch_enc_pack(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, d_pkoff_.as<uint32_t>(), d_out_.as<uint8_t>(),
+                       d_packed_.as<uint8_t>());
+    if (!check(hipMemcpyAsync(h_out_.p, d_packed_.p, total, hipMemcpyDeviceToHost, stream_), "D2H jpegs")) return LP_ERR_DEVICE;
+    return sync(); // also covers the pageable `pk`
 }

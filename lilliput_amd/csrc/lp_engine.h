@@ -152,7 +152,7 @@ private:
     LpDevBuf d_ops_, d_taps_, d_ranges_, d_fops_;
     // encode
     std::vector<LpEncJob> h_jobs_;
-    LpDevBuf d_jobs_, d_estates_, d_ecoef_, d_blkbits_, d_bits_, d_hdrs_, d_out_;
+    LpDevBuf d_jobs_, d_estates_, d_ecoef_, d_blkbits_, d_bits_, d_hdrs_, d_out_, d_packed_, d_pkoff_;
     std::vector<LpEncState> h_estates_;
     bool enc_tables_ready_ = false;
 };

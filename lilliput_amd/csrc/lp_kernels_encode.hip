@@ -354,6 +354,25 @@ __global__ __launch_bounds__(256) void k_enc_finish(const LpEncJob* __restrict__
     if (t == 0) { out[end] = 0xFF; out[end + 1] = 0xD9; st.out_len = end + 2; }
 }
 
+// Gather the encoded streams (spaced out_cap apart in the output arena) into one contiguous buffer so that a batch leaves
+// the device in a single D2H copy. One workgroup per image; both sides are 16-byte aligned.
+__global__ __launch_bounds__(256) void k_enc_pack(const LpEncJob* __restrict__ jobs, const LpEncState* __restrict__ states,
+                                                  const uint32_t* __restrict__ pk_off, const uint8_t* __restrict__ out_arena, uint8_t* __restrict__ packed)
+{
+    const LpEncJob& job = jobs[blockIdx.x];
+    const uint32_t n = states[blockIdx.x].out_len;
+    const uint4* src = reinterpret_cast<const uint4*>(out_arena + job.out_off);
+    uint4* dst = reinterpret_cast<uint4*>(packed + pk_off[blockIdx.x]);
+    for (uint32_t i = threadIdx.x; i < (n + 15) / 16; i += 256) dst[i] = src[i];
+}
+
+void lp_launch_enc_pack(hipStream_t s, const LpEncJob* d_jobs, const LpEncState* d_states, uint32_t nimg, const uint32_t* d_pk_off, const uint8_t* d_out,
+                        uint8_t* d_packed)
+{
+    if (!nimg) return;
+    hipLaunchKernelGGL(k_enc_pack, dim3(nimg), dim3(256), 0, s, d_jobs, d_states, d_pk_off, d_out, d_packed);
+}
+
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out)
 {

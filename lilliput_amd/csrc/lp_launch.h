@@ -45,3 +45,5 @@ void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* 
 // encode
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out);
+void lp_launch_enc_pack(hipStream_t s, const LpEncJob* d_jobs, const LpEncState* d_states, uint32_t nimg, const uint32_t* d_pk_off, const uint8_t* d_out,
+                        uint8_t* d_packed);
