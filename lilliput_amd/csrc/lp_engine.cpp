@@ -207,7 +207,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems * 2 + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
@@ -227,7 +227,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.spec_exit = d_spec_exit_.as<LpSubState>(); ha.spec_total = d_spec_tot_.as<LpSumPk>();
     ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSumPk>();
     ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSumPk>();
-    ha.changed = d_changed_.as<uint32_t>(); ha.coef = d_coef_.as<int16_t>();
+    ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>();
     ha.S = S_; ha.sched = sched_;
     lp_launch_huff_spec(stream_, ha);
     if (timing_) (void)hipEventRecord(ev_[8], stream_);
@@ -247,7 +247,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
     lp_launch_huff_write(stream_, ha);
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
-    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int16_t>(), d_planes_.as<uint8_t>());
+    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_planes_.as<uint8_t>());
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
     // frames
     for (int i = 0; i < n; i++) {
@@ -300,10 +300,25 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     const LpJpeg& j = h_imgs_[(size_t)i];
     const size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
     if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
-    std::vector<int16_t> all((size_t)j.total_blocks * 64);
-    if (!check(hipMemcpyAsync(all.data(), d_coef_.as<int16_t>() + j.coef_off, all.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
+    const size_t nb = j.total_blocks;
+    std::vector<int8_t> c8(nb * 64);
+    std::vector<uint32_t> wid(nb);
+    if (!check(hipMemcpyAsync(c8.data(), d_coef_.as<int8_t>() + j.coef_off, c8.size(), hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(wid.data(), d_wide_id_.as<uint32_t>() + j.coef_off / 64, nb * 4, hipMemcpyDeviceToHost, stream_), "D2H wide ids")) return LP_ERR_DEVICE;
     int rc = sync();
     if (rc) return rc;
+    const uint32_t n_wide = h_states_[(size_t)i].n_wide;
+    std::vector<int16_t> wide((size_t)n_wide * 64);
+    if (n_wide) {
+        if (!check(hipMemcpyAsync(wide.data(), d_wide_.as<int16_t>() + j.coef_off, wide.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H wide")) return LP_ERR_DEVICE;
+        if ((rc = sync())) return rc;
+    }
+    std::vector<int16_t> all(nb * 64);
+    for (size_t q = 0; q < nb; q++)
+        for (int e = 0; e < 64; e++) {
+            const int8_t v = c8[q * 64 + e];
+            all[q * 64 + e] = v == -128 && wid[q] < n_wide ? wide[(size_t)wid[q] * 64 + e] : v; // -128 = escape to the wide slot
+        }
     const uint32_t hs = j.hs[comp], vs = j.vs[comp];
     for (uint32_t by = 0; by < j.bh[comp]; by++)
         for (uint32_t bx = 0; bx < j.bw[comp]; bx++) {

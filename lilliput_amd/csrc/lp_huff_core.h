@@ -45,11 +45,10 @@
      63, 63}
 
 // Ring geometry of the bit reader. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so
-// LP_TOPUP_EVERY steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte
-// granularity) and a step reads the word pair (w, w+1): 8 + 3 + 2 <= LP_RING_WORDS.
-#define LP_RING_WORDS 16
-#define LP_TOPUP_EVERY 8
-#define LP_TOPUP_QUADS 2
+// kEvery = 8 steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte
+// granularity) and a step reads the word pair (w, w+1): 8 + 3 + 2 <= kRing = 16.
+// The policy fixes the geometry: M::kRing words per lane, a top-up of at most M::kQuads 16-byte loads every M::kEvery steps.
+// Valid pairs: (16, 8, 2) and (8, 4, 1) -- 31 bits x 4 steps = 4 words: 4 + 3 + 1 <= 8.
 
 // Per-image values every lane of a workgroup shares (scalar registers on the device).
 struct LpImgCtx {
@@ -62,10 +61,10 @@ struct LpImgCtx {
 
 // Memory policy M must provide (per lane object, non-const):
 //   void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)   words w and w+1 of the clean stream (big-endian corrected: bit 31 first)
-//   void reseek(uint32_t w)                 the lane jumps: make [w, w + LP_RING_WORDS - 3) fetchable
-//   void topup(uint32_t w)                  wave-uniform call every LP_TOPUP_EVERY steps: words below w are dead, refill
+//   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
+//   void topup(uint32_t w)                  wave-uniform call every kEvery steps: words below w are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
-//   uint32_t lut(uint32_t tbl, uint32_t i), lut2(tbl, i), base2(tbl)
+//   uint32_t lut(uint32_t tbl, uint32_t i), lut2(tbl, i), lut2_n(tbl), base2(tbl)
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
 //
@@ -144,7 +143,7 @@ struct LpLane {
     LP_HD uint32_t long_code(uint32_t tbl, uint32_t top)
     {
         const uint32_t idx = top - m.base2(tbl);
-        uint32_t e = idx < LP_LUT2_SIZE ? m.lut2(tbl, idx) : 0u;
+        uint32_t e = idx < m.lut2_n(tbl) ? m.lut2(tbl, idx) : 0u;
         if ((e >> 8) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix or a table with a very wide tail
             uint32_t len = 16, sym = 0;
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
@@ -295,7 +294,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     // Single back edge, no `continue`: the register allocator then updates the lane state in place (the first version of
     // this loop carried ~30 v_mov copies per iteration across its exits).
     do {
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
         uint32_t pk = L.peek();
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) { // rare even per wave: a restart boundary or the stream end is near
             if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
@@ -346,7 +345,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
     uint32_t cp = K ? ck.pos(0) : 0xffffffffu;
     bool done = false, spliced = false;
     do { // same shape as the SPEC loop: one back edge, state updated in place
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
         uint32_t pk = L.peek();
         iter++;
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
@@ -411,7 +410,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     bool writing = false, done = false;
     uint32_t written = 0, iter = 0;
     do {
-        if ((iter & (LP_TOPUP_EVERY - 1)) == LP_TOPUP_EVERY - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
         if ((iter % LP_FLUSH_EVERY) == LP_FLUSH_EVERY - 1) sink.flush();
         uint32_t pk = L.peek();
         iter++;

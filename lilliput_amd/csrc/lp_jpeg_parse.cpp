@@ -44,8 +44,7 @@ static int exif_orientation(const uint8_t* p, size_t n)
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals)
 {
     memset(hs->lut[slot], 0, sizeof(hs->lut[slot]));
-    memset(hs->lut2[slot], 0, sizeof(hs->lut2[slot]));
-    // first pass: canonical code assignment (T.81 Annex C), first-level table, base of the long codes
+    // canonical code assignment (T.81 Annex C), first-level table, base of the long codes
     uint32_t base2 = 0x10000u;
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
@@ -64,13 +63,20 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
         code <<= 1;
     }
     hs->base2[slot] = base2;
-    // second pass: second-level table over [base2, base2 + LP_LUT2_SIZE)
+    // second-level table: a slice of the shared pool covering [base2, base2 + n); slots are built in order 0..3 and take
+    // what is left of the pool (Annex-K tables need 2 + 320 + 32 + 320 entries)
+    uint32_t used = 0;
+    for (int t = 0; t < slot; t++) used = hs->lut2_off[t] + hs->lut2_n[t] > used ? hs->lut2_off[t] + hs->lut2_n[t] : used;
+    uint32_t need = 0x10000u - base2, n2 = need < LP_LUT2_POOL - used ? need : LP_LUT2_POOL - used;
+    hs->lut2_off[slot] = used;
+    hs->lut2_n[slot] = n2;
+    memset(hs->lut2 + used, 0, n2 * sizeof(uint16_t));
     code = 0; k = 0;
     for (int l = 1; l <= 16; l++) {
         for (int i = 0; i < bits[l]; i++, k++, code++) {
             if (l <= LP_LUT_BITS) continue;
             uint32_t first = ((uint32_t)code << (16 - l)) - base2, n = 1u << (16 - l);
-            for (uint32_t j = 0; j < n && first + j < LP_LUT2_SIZE; j++) hs->lut2[slot][first + j] = (uint16_t)((l << 8) | vals[k]);
+            for (uint32_t j = 0; j < n && first + j < n2; j++) hs->lut2[used + first + j] = (uint16_t)((l << 8) | vals[k]);
         }
         code <<= 1;
     }
@@ -243,9 +249,10 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     else if (saw_adobe) j.colorspace = adobe_tf == 0 ? 3 : 2;
     else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') j.colorspace = 3;
     else j.colorspace = 2;
-    for (int t = 0; t < 2; t++) {
-        if (h_ok[0][t]) lp_build_huff_slot(&out->huff, t, hbits[0][t], hvals[0][t]);
-        if (h_ok[1][t]) lp_build_huff_slot(&out->huff, 2 + t, hbits[1][t], hvals[1][t]);
+    {   // slots are built in order 0..3 (the second-level pool is handed out in that order); an absent table id is an empty table
+        static const uint8_t no_bits[17] = {0}, no_vals[1] = {0};
+        for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, t, h_ok[0][t] ? hbits[0][t] : no_bits, h_ok[0][t] ? hvals[0][t] : no_vals);
+        for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, 2 + t, h_ok[1][t] ? hbits[1][t] : no_bits, h_ok[1][t] ? hvals[1][t] : no_vals);
     }
     // End of the scan: the common case is a file that ends in EOI; otherwise walk the ECS once.
     out->ecs_off = ecs;

@@ -6,6 +6,7 @@
 // All kernels are batched: blockIdx.y (or .z) selects the image, per-image descriptors live in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lp_huff_core.h"
 #include "lp_launch.h"
@@ -216,51 +217,56 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
 // LDS: the image's LpHuffSet (two-level code tables), one bit-reader ring per lane (word-interleaved: word j of lane l at
 // [j][l], so every wave access hits 64 consecutive dwords -- conflict-free whatever the lanes' positions are).
 #define HUFF_T 256
-#define RING_ROWS (LP_RING_WORDS + 1) // row LP_RING_WORDS mirrors row 0 so that the pair (w, w+1) is always two adjacent rows
+// R = ring words per lane; row R mirrors row 0 so that the pair (w, w+1) is always two adjacent rows.
+template <int R, int T, int Q>
 struct DevMem {
+    static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R + 1;
     const uint32_t* words;  // this image's clean stream (16-byte aligned)
-    uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % LP_RING_WORDS) * 64]
+    uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % R) * 64]
     uint32_t fill;          // next stream word to load (multiple of 4)
     const LpHuffSet* hs;    // LDS
     const uint32_t* rst;
     __device__ __forceinline__ void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1) const
     {
-        const uint32_t* r = ring + ((w & (LP_RING_WORDS - 1u)) << 6);
+        const uint32_t* r = ring + ((w & (R - 1u)) << 6);
         w0 = r[0];
-        w1 = r[64]; // one ds_read2_b32
+        w1 = r[64]; // one ds_read2st64_b32
     }
     __device__ __forceinline__ void load_quad()
     {
         const uint4 v = *reinterpret_cast<const uint4*>(words + fill);
-        uint32_t* r = ring + ((fill & (LP_RING_WORDS - 1u)) << 6); // fill is a multiple of 4: the quad never wraps
+        uint32_t* r = ring + ((fill & (R - 1u)) << 6); // fill is a multiple of 4: the quad never wraps
         r[0] = v.x;
         r[64] = v.y;
         r[128] = v.z;
         r[192] = v.w;
-        if ((fill & (LP_RING_WORDS - 1u)) == 0) ring[LP_RING_WORDS << 6] = v.x;
+        if ((fill & (R - 1u)) == 0) ring[R << 6] = v.x;
         fill += 4;
     }
     __device__ __forceinline__ void reseek(uint32_t w)
     {
         fill = w & ~3u;
 #pragma unroll
-        for (int i = 0; i < LP_RING_WORDS / 4; i++) load_quad();
+        for (int i = 0; i < R / 4; i++) load_quad();
     }
     __device__ __forceinline__ void topup(uint32_t w)
     {
 #pragma unroll
-        for (int i = 0; i < LP_TOPUP_QUADS; i++)
-            if (fill + 4u <= w + LP_RING_WORDS) load_quad();
+        for (int i = 0; i < Q; i++)
+            if (fill + 4u <= w + R) load_quad();
     }
     __device__ __forceinline__ bool any(bool p) const { return __any(p); }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
-    __device__ __forceinline__ uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[t][i]; }
+    __device__ __forceinline__ uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[hs->lut2_off[t] + i]; }
+    __device__ __forceinline__ uint32_t lut2_n(uint32_t t) const { return hs->lut2_n[t]; }
     __device__ __forceinline__ uint32_t base2(uint32_t t) const { return hs->base2[t]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
     __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
 };
+typedef DevMem<16, 8, 2> CountMem;  // SPEC / VERIFY: LDS is not the limiter, fewer top-ups
+typedef DevMem<8, 4, 1> WriteMem;   // WRITE: 9 KiB of ring per workgroup so that three workgroups fit a CU next to the coefficient slots
 
 __device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
 {
@@ -312,8 +318,9 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
                                                       LpSubState* __restrict__ cur_exit, LpSumPk* __restrict__ cur_total,
                                                       LpSubState* __restrict__ entry_used, uint32_t S, LpCkSched cs, uint32_t tot_sub)
 {
+    typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
+    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
     const bool valid = sub < nsub;
     const uint32_t g = img.sub_off + (valid ? sub : 0);
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
     entry.p = valid ? sub * S : 0;
     entry.bz = 0;
@@ -367,8 +374,9 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         LpSubState* cur_exit, LpSumPk* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
                                                         uint32_t* __restrict__ changed, uint32_t S, uint32_t K, uint32_t tot_sub)
 {
+    typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
+    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ uint32_t s_ckpos[HUFF_T * LP_MAX_CKPT];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     const LpSubState entry = load_state(cur_exit + g - 1);
     if (lp_state_eq(entry, entry_used[g])) return; // already verified against this entry state
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     uint32_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) cp[k << 6] = ckpts[(size_t)k * tot_sub + g].p;
     DevCkSrc ck{cp, ckpts + g, tot_sub};
@@ -433,17 +441,38 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
 }
 
-// Coefficient sink of the WRITE pass: one 64-coefficient LDS slot per lane (16-byte chunks XOR-swizzled by lane to
-// spread banks). A finished block is only queued; flush() runs at wave-uniform points so that the 8x(ds_read_b128 +
-// global_store_dwordx4 + ds_write_b128) per block execute with many lanes active instead of once per lane divergently.
-// Blocks are stored in decode order: block n of the image at coef[n * 64], natural coefficient order.
+// Coefficient sink of the WRITE pass. Quantised coefficients almost always fit a signed byte, so a block is assembled
+// and stored as 64 x int8 (natural order); a value outside [-127, 127] is stored as the escape -128 and its true 16-bit
+// value goes straight to HBM into a "wide" copy of the block (one slot per block that needs it, handed out by an atomic
+// counter; the slot index is recorded in wide_id[block]). Only escaped positions of a wide slot are ever read, so it needs
+// no initialisation. Halving the slot (64 B per lane instead of 128 B) is what lets three or four workgroups share a CU's
+// LDS -- the WRITE kernel is occupancy-bound -- and it halves the coefficient traffic of WRITE and IDCT.
+// Slot layout in LDS: [16-byte chunk c][lane][16 B] per wave (chunk c = natural coefficients 16c..16c+15), so the
+// ds_read_b128 / ds_write_b128 of a flush touch 1 KiB of consecutive bytes: conflict-free.
+// A finished block is only queued; flush() runs at wave-uniform points so that its loads/stores execute with many lanes
+// active instead of once per lane divergently. Blocks are stored in decode order: block n at coef8[n * 64].
 struct DevSink {
-    int16_t* slot;          // this lane's 64 coefficients (kept zero between blocks)
-    uint32_t l7;
-    int16_t* dst;           // queued destination (nullptr = slot free)
-    int16_t* coef;          // this image's coefficient blocks
-    __device__ __forceinline__ void put(uint32_t nat, int32_t v) { slot[(((nat >> 3) ^ l7) << 3) | (nat & 7)] = (int16_t)v; }
-    __device__ __forceinline__ void end_block(uint32_t blk) { dst = coef + (size_t)blk * 64; }
+    int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * 1024
+    int8_t* dst;            // queued destination (nullptr = slot free)
+    int8_t* coef8;          // this image's coefficient blocks
+    int16_t* wide;          // this image's wide slots (64 int16 each)
+    uint32_t* wide_id;      // this image's block -> wide slot
+    uint32_t* n_wide;       // this image's wide-slot counter
+    uint32_t wslot;         // wide slot of the current block, 0xffffffff = none
+    __device__ __forceinline__ void put(uint32_t nat, int32_t v)
+    {
+        if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
+            if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
+            wide[(size_t)wslot * 64 + nat] = (int16_t)v;
+            v = -128;
+        }
+        slot[((nat >> 4) << 10) | (nat & 15u)] = (int8_t)v;
+    }
+    __device__ __forceinline__ void end_block(uint32_t blk)
+    {
+        dst = coef8 + (size_t)blk * 64;
+        if (wslot != 0xffffffffu) { wide_id[blk] = wslot; wslot = 0xffffffffu; }
+    }
     __device__ __forceinline__ bool stalled() const { return dst != nullptr; }
     __device__ __forceinline__ void flush()
     {
@@ -451,48 +480,51 @@ struct DevSink {
             uint4* s = reinterpret_cast<uint4*>(slot);
             uint4* o = reinterpret_cast<uint4*>(dst);
             const uint4 zero = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (uint32_t ch = 0; ch < 8; ch++) {
-                o[ch] = s[ch ^ l7];
-                s[ch ^ l7] = zero;
-            }
+            const uint4 r0 = s[0], r1 = s[64], r2 = s[128], r3 = s[192];
+            o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+            s[0] = zero; s[64] = zero; s[128] = zero; s[192] = zero;
             dst = nullptr;
         }
     }
 };
 
-__global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+template <class MEM>
+__global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states,
                                                        const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                        const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
-                                                       const LpSumPk* __restrict__ prefixes, int16_t* __restrict__ coef_arena)
+                                                       const LpSumPk* __restrict__ prefixes, int8_t* __restrict__ coef8_arena,
+                                                       int16_t* __restrict__ wide_arena, uint32_t* __restrict__ wide_id_arena)
 {
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
-    __shared__ uint32_t s_ring[HUFF_T * RING_ROWS];
-    __shared__ __attribute__((aligned(16))) int16_t s_slots[HUFF_T * 64];
+    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
+    __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
     const LpJpeg& img = imgs[blockIdx.y];
-    const LpJpegState& st = states[blockIdx.y];
+    LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
     if (blockIdx.x * HUFF_T >= nsub) return;
     {
         const uint8_t zz[80] = LP_ZIGZAG_INIT;
         if (threadIdx.x < 80) s_zz[threadIdx.x] = zz[threadIdx.x];
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
-        for (uint32_t i = threadIdx.x; i < HUFF_T * 64 * 2 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
     stage_huff(&s_hs, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
     if (sub >= nsub) return;
     const uint32_t g = img.sub_off + sub;
     const LpImgCtx ic = make_ctx(img, st);
-    DevMem m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * RING_ROWS) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
     DevSink sink;
-    sink.slot = s_slots + threadIdx.x * 64;
-    sink.l7 = threadIdx.x & 7u;
+    sink.slot = s_slots + (threadIdx.x >> 6) * 4096 + (threadIdx.x & 63) * 16;
     sink.dst = nullptr;
-    sink.coef = coef_arena + img.coef_off;
+    sink.coef8 = coef8_arena + img.coef_off;
+    sink.wide = wide_arena + img.coef_off;
+    sink.wide_id = wide_id_arena + img.coef_off / 64;
+    sink.n_wide = &st.n_wide;
+    sink.wslot = 0xffffffffu;
     lp_write_pass(m, ic, entry, exits[g].p, lp_sum_unpack(prefixes[g]), s_zz, sink);
 }
 
@@ -521,7 +553,8 @@ __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
 #define IDCT_WSTRIDE 72 // int32 per block in LDS (64 + 8 pad): conflict-free column writes
 
 __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
-                                              const int16_t* __restrict__ coef_arena, uint8_t* __restrict__ plane_arena)
+                                              const int8_t* __restrict__ coef8_arena, const int16_t* __restrict__ wide_arena,
+                                              const uint32_t* __restrict__ wide_id_arena, uint8_t* __restrict__ plane_arena)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_c[4][8 * IDCT_CSTRIDE];
     __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
@@ -542,8 +575,27 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     // blocks are stored in decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order
     const uint32_t hs = img.hs[c], vs = img.vs[c], bx = bx0 + j;
     const uint32_t blk = ((by / vs) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[c] + (by % vs) * hs + (bx % hs);
-    const int16_t* src = coef_arena + img.coef_off + (size_t)blk * 64 + r * 8;
-    uint4 v = blk_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+    // 64 x int8 per block (see DevSink); -128 escapes to the block's wide slot
+    int32_t cv[8];
+    {
+        const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+        bool any_esc = false;
+#pragma unroll
+        for (int i = 0; i < 8; i++) any_esc = any_esc || cv[i] == -128;
+        if (any_esc) {
+            const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (cv[i] == -128) cv[i] = w[i];
+        }
+    }
+    uint4 v;
+    v.x = ((uint32_t)cv[0] & 0xffffu) | ((uint32_t)cv[1] << 16);
+    v.y = ((uint32_t)cv[2] & 0xffffu) | ((uint32_t)cv[3] << 16);
+    v.z = ((uint32_t)cv[4] & 0xffffu) | ((uint32_t)cv[5] << 16);
+    v.w = ((uint32_t)cv[6] & 0xffffu) | ((uint32_t)cv[7] << 16);
     *reinterpret_cast<uint4*>(&s_c[wv][j * IDCT_CSTRIDE + r * 8]) = v;
     __syncthreads();
     {   // pass 1: column r of block j
@@ -616,14 +668,14 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
 {
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
-    hipLaunchKernelGGL(k_huff_write, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
-                       (const LpSumPk*)a.prefix, a.coef);
+    hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
+                       (const LpSumPk*)a.prefix, a.coef8, a.wide, a.wide_id);
 }
 
-void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int16_t* d_coef,
-                    uint8_t* d_planes)
+void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int8_t* d_coef8,
+                    const int16_t* d_wide, const uint32_t* d_wide_id, uint8_t* d_planes)
 {
     if (!nimg || !max_tiles) return;
     dim3 g((max_tiles + 3) / 4, LP_MAX_COMP, nimg);
-    hipLaunchKernelGGL(k_idct, g, dim3(256), 0, s, d_imgs, d_states, d_coef, d_planes);
+    hipLaunchKernelGGL(k_idct, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_planes);
 }

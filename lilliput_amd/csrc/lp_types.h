@@ -11,17 +11,19 @@
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
 #define LP_LUT_BITS 10          // first-level Huffman lookup width
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
-#define LP_LUT2_SIZE 1024       // second-level lookup: one entry per 16-bit prefix above the first code longer than LP_LUT_BITS
+#define LP_LUT2_POOL 1024       // second-level lookup entries shared by the four tables (one per 16-bit prefix of a long code)
 #define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
 // lut[t][i]  : (len << 8) | symbol for codes of length <= LP_LUT_BITS, indexed by the next LP_LUT_BITS bits; 0 = longer code.
-// lut2[t][i] : same encoding for the long codes, indexed by (next 16 bits) - base2[t]; 0 = not covered -> canonical search.
+// lut2[lut2_off[t] + i], i < lut2_n[t] : same encoding for the long codes, indexed by (next 16 bits) - base2[t];
+//              0 or i >= lut2_n[t] = not covered -> canonical search.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
-    uint16_t lut2[4][LP_LUT2_SIZE];
+    uint16_t lut2[LP_LUT2_POOL];
     uint32_t base2[4];          // smallest left-aligned 16-bit value of a code longer than LP_LUT_BITS (0x10000 if none)
+    uint32_t lut2_off[4], lut2_n[4];
     int32_t maxcode[4][18];     // maxcode[l] = largest code of length l, -1 if none; [17] = sentinel
     int32_t valoff[4][17];      // valptr[l] - mincode[l]
     uint8_t vals[4][256];
@@ -51,8 +53,9 @@ struct LpJpeg {
     uint32_t pad3;
     uint64_t blkpack;           // 4 bits per block-in-MCU b (bits 4b..4b+3): component (2) | DC table id (1) << 2 | AC table id (1) << 3
     uint32_t bw[LP_MAX_COMP], bh[LP_MAX_COMP];          // blocks per row / column (MCU padded)
-    uint64_t coef_off;          // int16 element offset of this image's blocks in the coefficient arena; blocks are stored
-                                // in DECODE order (MCU by MCU, blocks of an MCU in scan order), 64 natural-order coefficients each
+    uint64_t coef_off;          // element offset of this image's blocks in the coefficient arenas (int8 blocks, int16 wide slots; /64 =
+                                // block offset); blocks are stored in DECODE order (MCU by MCU, blocks of an MCU in scan order),
+                                // 64 natural-order coefficients each
     uint64_t plane_off[LP_MAX_COMP];                    // byte offset into the plane arena
     uint32_t plane_stride[LP_MAX_COMP];                 // = bw*8
     uint16_t qt[LP_MAX_COMP][64];                       // dequantisation table per component, natural order
@@ -73,7 +76,8 @@ struct LpJpegState {
     uint32_t error;             // bit 0: unexpected marker in ECS, bit 1: block count mismatch
     uint32_t end_marker_pos;    // raw position of the first non-RST marker (or raw_len)
     uint32_t blocks_decoded;
-    uint32_t pad[2];
+    uint32_t n_wide;            // blocks that needed a 16-bit (wide) slot
+    uint32_t pad;
 };
 
 // Decoder state at a symbol boundary.

@@ -10,31 +10,36 @@
 #include "../../lilliput_amd/csrc/lp_huff_core.h"
 #include "../../lilliput_amd/csrc/lp_jpeg_parse.h"
 
-struct HostMem {
+template <int R, int T, int Q>
+struct HostMemT {
+    static constexpr int kRing = R, kEvery = T, kQuads = Q;
     const uint32_t* words; // linear big-endian words of the clean stream
     const LpHuffSet* hs;
     const uint32_t* rst;
-    // Ring emulation: the device keeps LP_RING_WORDS words per lane in LDS and tops them up every LP_TOPUP_EVERY steps;
-    // the emulation tracks the same window and ABORTS when the lane logic fetches outside of it.
+    // Ring emulation: the device keeps R words per lane in LDS and tops them up every T steps; the emulation tracks the
+    // same window and reports when the lane logic fetches outside of it.
     uint32_t fill = 0, lowest = 0;
     bool* window_violation;
     void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)
     {
-        if (w + 1 >= fill || w + LP_RING_WORDS < fill) *window_violation = true;
+        if (w + 1 >= fill || w + R < fill) *window_violation = true;
         w0 = words[w];
         w1 = words[w + 1];
     }
-    void reseek(uint32_t w) { fill = (w & ~3u) + LP_RING_WORDS; }
-    void topup(uint32_t w) { for (int i = 0; i < LP_TOPUP_QUADS; i++) if (fill + 4u <= w + LP_RING_WORDS) fill += 4; }
+    void reseek(uint32_t w) { fill = (w & ~3u) + R; }
+    void topup(uint32_t w) { for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
-    uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[t][i]; }
+    uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[hs->lut2_off[t] + i]; }
+    uint32_t lut2_n(uint32_t t) const { return hs->lut2_n[t]; }
     uint32_t base2(uint32_t t) const { return hs->base2[t]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
     uint32_t rst_bit(uint32_t k) const { return rst[k]; }
 };
+typedef HostMemT<16, 8, 2> HostMem;      // geometry of the SPEC / VERIFY kernels
+typedef HostMemT<8, 4, 1> HostMemWrite;  // geometry of the WRITE kernel
 
 struct HostSink { // one slot, flushed at the wave-uniform flush points like the device sink
     int16_t blk[64];
@@ -147,7 +152,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     uint32_t written = 0;
     for (uint32_t i = 0; i < nsub; i++) {
         LpSubState e = i ? ex[i - 1] : LpSubState{0, 0};
-        HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
+        HostMemWrite m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
         written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink);
     }
     if (written != img.total_blocks) return -14;

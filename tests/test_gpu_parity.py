@@ -59,6 +59,31 @@ def test_decode_samplings_custom_tables_restarts_odd_sizes(batch, oracle):
         assert px.shape[2] == 1 and np.array_equal(px, oracle.jpeg_decode(g.getvalue())), (w, h, "gray")
 
 
+def test_decode_wide_coefficients(batch, oracle):
+    """Quantised coefficients outside int8 take the escape / wide-slot path of the WRITE and IDCT kernels."""
+    from PIL import Image
+
+    rng = np.random.default_rng(21)
+    hard = (rng.integers(0, 2, (96, 128, 3)) * 255).astype(np.uint8)       # full-swing noise
+    edges = np.zeros((80, 120, 3), np.uint8)
+    edges[:, ::7] = 255
+    edges[::5, :] = 255
+    for im, q, ss in ((hard, 100, 0), (hard, 97, 2), (edges, 100, 2), (edges, 90, 1), (hard[:, :, 0], 100, None)):
+        b = io.BytesIO()
+        kw = {} if ss is None else {"subsampling": ss}
+        Image.fromarray(im).save(b, "JPEG", quality=q, **kw)
+        data = b.getvalue()
+        ncomp = oracle.jpeg_info(data)["ncomp"]
+        big = 0
+        for c in range(ncomp):
+            exp = oracle.jpeg_decode_coefs(data, c)
+            big += int((np.abs(exp.astype(int)) > 127).sum())
+            assert np.array_equal(batch.decode_jpeg_coefs(data, c), exp), (q, ss, c)
+        assert big > 0
+        px, _ = batch.decode_jpeg(data)
+        assert np.array_equal(px, oracle.jpeg_decode(data)), (q, ss)
+
+
 def test_decode_synthetic_1024(batch, oracle):
     from lilliput_amd import synth
 
