@@ -4,6 +4,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -172,7 +173,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     K_ = sched_.K;
     size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;
-    max_chunks_ = max_sub_ = max_tiles_ = max_w_ = max_h_ = 0;
+    max_chunks_ = max_sub_ = max_bw_ = max_rows_ = max_w_ = max_h_ = 0;
     bool any_frame = false;
     for (size_t i = 0; i < h_imgs_.size(); i++) {
         LpJpeg& j = h_imgs_[i];
@@ -189,11 +190,14 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         tot_rst_ += j.rst_cap;
         j.coef_off = coef_elems;
         coef_elems += (size_t)j.total_blocks * 64;
+        uint32_t rows = 0;
         for (int c = 0; c < j.ncomp; c++) {
             j.plane_off[c] = plane_bytes;
             plane_bytes = align_up(plane_bytes + (size_t)j.bw[c] * 8 * j.bh[c] * 8, 16);
-            max_tiles_ = std::max(max_tiles_, (j.bw[c] + 7) / 8 * j.bh[c]);
+            max_bw_ = std::max(max_bw_, j.bw[c]);
+            rows += j.bh[c];
         }
+        max_rows_ = std::max(max_rows_, rows);
         max_chunks_ = std::max(max_chunks_, j.nchunks);
         max_sub_ = std::max(max_sub_, j.sub_cap);
         if (!want_frame || want_frame[i]) {
@@ -207,7 +211,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
@@ -215,9 +219,19 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     const LpJpeg* di = d_imgs_.as<LpJpeg>();
     LpJpegState* ds = d_states_.as<LpJpegState>();
     if (!check(hipMemsetAsync(ds, 0, sizeof(LpJpegState) * (size_t)n, stream_), "memset states")) return LP_ERR_DEVICE;
+    // LILLIPUT_HIP_DEBUG_SYNC=1: synchronise after every stage and name it on stderr (a faulting kernel aborts the process at
+    // the next synchronisation, so the last line printed is the stage before the culprit)
+    static const bool dbg = getenv("LILLIPUT_HIP_DEBUG_SYNC") != nullptr;
+    auto stage = [&](const char* name) {
+        if (!dbg) return;
+        fprintf(stderr, "[lilliput_hip] stage %s ...\n", name);
+        (void)hipStreamSynchronize(stream_);
+        fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
+    };
     if (timing_) (void)hipEventRecord(ev_[0], stream_);
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>(), S_);
+    stage("unstuff");
     if (timing_) (void)hipEventRecord(ev_[1], stream_);
     LpHuffArgs ha;
     ha.imgs = di; ha.states = ds; ha.huffs = d_huffs_.as<LpHuffSet>();
@@ -227,9 +241,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.spec_exit = d_spec_exit_.as<LpSubState>(); ha.spec_total = d_spec_tot_.as<LpSumPk>();
     ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSumPk>();
     ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSumPk>();
-    ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>();
+    ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>(); ha.dc16 = d_dc_.as<int16_t>();
     ha.S = S_; ha.sched = sched_;
     lp_launch_huff_spec(stream_, ha);
+    stage("huff_spec");
     if (timing_) (void)hipEventRecord(ev_[8], stream_);
     uint32_t rounds = 0;
     uint32_t* h_changed = h_small_.as<uint32_t>();
@@ -243,11 +258,15 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     tm_.verify_rounds = rounds;
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
+    stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
+    stage("sub_scan");
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
     lp_launch_huff_write(stream_, ha);
+    stage("huff_write");
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
-    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_tiles_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_planes_.as<uint8_t>());
+    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>());
+    stage("idct");
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
     // frames
     for (int i = 0; i < n; i++) {
@@ -303,6 +322,8 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     const size_t nb = j.total_blocks;
     std::vector<int8_t> c8(nb * 64);
     std::vector<uint32_t> wid(nb);
+    std::vector<int16_t> dcs(nb);
+    if (!check(hipMemcpyAsync(dcs.data(), d_dc_.as<int16_t>() + j.coef_off / 64, nb * 2, hipMemcpyDeviceToHost, stream_), "D2H dc")) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(c8.data(), d_coef_.as<int8_t>() + j.coef_off, c8.size(), hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(wid.data(), d_wide_id_.as<uint32_t>() + j.coef_off / 64, nb * 4, hipMemcpyDeviceToHost, stream_), "D2H wide ids")) return LP_ERR_DEVICE;
     int rc = sync();
@@ -317,8 +338,10 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     for (size_t q = 0; q < nb; q++)
         for (int e = 0; e < 64; e++) {
             const int8_t v = c8[q * 64 + e];
-            all[q * 64 + e] = v == -128 && wid[q] < n_wide ? wide[(size_t)wid[q] * 64 + e] : v; // -128 = escape to the wide slot
+            const int nat = ((e & 7) << 3) | (e >> 3); // blocks are stored transposed
+            all[q * 64 + nat] = v == -128 && wid[q] < n_wide ? wide[(size_t)wid[q] * 64 + e] : v; // -128 = escape to the wide slot
         }
+    for (size_t q = 0; q < nb; q++) all[q * 64] = dcs[q];
     const uint32_t hs = j.hs[comp], vs = j.vs[comp];
     for (uint32_t by = 0; by < j.bh[comp]; by++)
         for (uint32_t bx = 0; bx < j.bw[comp]; bx++) {
@@ -672,6 +695,7 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         max_blocks = std::max(max_blocks, j.total_blocks);
         j.coef_off = coef_elems;
         coef_elems += (size_t)j.total_blocks * 64;
+        uint32_t rows = 0;
         uint8_t hb[1024];
         j.hdr_off = (uint32_t)hdrs.size();
         j.hdr_len = (uint32_t)lp_build_jpeg_header((int)r.src.w, (int)r.src.h, (int)j.ncomp, r.quality, hb, j.qt);

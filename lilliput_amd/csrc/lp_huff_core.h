@@ -390,7 +390,8 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
-//   void put(uint32_t natural_idx, int32_t v);     store one coefficient of the block being decoded
+//   void put_dc(int32_t v);                        the block's (absolute) DC coefficient
+//   void put(uint32_t natural_idx, int32_t v);     store one AC coefficient of the block being decoded
 //   void end_block(uint32_t blk);                  the block (decode-order index blk) is complete (queued for flushing)
 //   bool stalled();                                no free slot: the lane must wait for the next flush
 //   void flush();                                  wave-uniform: write out every queued block
@@ -428,7 +429,8 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
             const typename LpLane<M>::Sym s = L.step(pk);
             if (writing) {
                 lp_add3(pred, s.comp, s.is_dc ? s.val : 0);
-                if (s.has_val) sink.put(s.is_dc ? 0u : (uint32_t)zigzag[s.k], s.is_dc ? lp_get3(pred, s.comp) : s.val);
+                if (s.is_dc) sink.put_dc(lp_get3(pred, s.comp));
+                else if (s.has_val) sink.put((uint32_t)zigzag[s.k], s.val);
                 if (s.block_done) {
                     sink.end_block(blk);
                     written++;

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
 }
 
-// Coefficient sink of the WRITE pass. Quantised coefficients almost always fit a signed byte, so a block is assembled
+// Coefficient sink of the WRITE pass. Quantised AC coefficients almost always fit a signed byte, so a block is assembled
 // and stored as 64 x int8 (natural order); a value outside [-127, 127] is stored as the escape -128 and its true 16-bit
 // value goes straight to HBM into a "wide" copy of the block (one slot per block that needs it, handed out by an atomic
 // counter; the slot index is recorded in wide_id[block]). Only escaped positions of a wide slot are ever read, so it needs
@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
 // Slot layout in LDS: [16-byte chunk c][lane][16 B] per wave (chunk c = natural coefficients 16c..16c+15), so the
 // ds_read_b128 / ds_write_b128 of a flush touch 1 KiB of consecutive bytes: conflict-free.
 // A finished block is only queued; flush() runs at wave-uniform points so that its loads/stores execute with many lanes
-// active instead of once per lane divergently. Blocks are stored in decode order: block n at coef8[n * 64].
+// active instead of once per lane divergently. Blocks are stored in decode order: block n at coef8[n * 64], and TRANSPOSED
+// (element v * 8 + u holds the coefficient of row u, column v: the write kernel feeds put() a transposed zigzag table).
 struct DevSink {
     int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * 1024
     int8_t* dst;            // queued destination (nullptr = slot free)
@@ -459,6 +460,9 @@ struct DevSink {
     uint32_t* wide_id;      // this image's block -> wide slot
     uint32_t* n_wide;       // this image's wide-slot counter
     uint32_t wslot;         // wide slot of the current block, 0xffffffff = none
+    int16_t* dc16;          // this image's DC coefficients (the DC rarely fits a byte: it has its own 16-bit array)
+    int32_t dcv;            // DC of the current block
+    __device__ __forceinline__ void put_dc(int32_t v) { dcv = v; }
     __device__ __forceinline__ void put(uint32_t nat, int32_t v)
     {
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
@@ -483,6 +487,7 @@ struct DevSink {
             const uint4 r0 = s[0], r1 = s[64], r2 = s[128], r3 = s[192];
             o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
             s[0] = zero; s[64] = zero; s[128] = zero; s[192] = zero;
+            dc16[(dst - coef8) >> 6] = (int16_t)dcv;
             dst = nullptr;
         }
     }
@@ -493,7 +498,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
                                                        const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                        const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
                                                        const LpSumPk* __restrict__ prefixes, int8_t* __restrict__ coef8_arena,
-                                                       int16_t* __restrict__ wide_arena, uint32_t* __restrict__ wide_id_arena)
+                                                       int16_t* __restrict__ wide_arena, uint32_t* __restrict__ wide_id_arena,
+                                                       int16_t* __restrict__ dc_arena)
 {
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
@@ -505,7 +511,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     if (blockIdx.x * HUFF_T >= nsub) return;
     {
         const uint8_t zz[80] = LP_ZIGZAG_INIT;
-        if (threadIdx.x < 80) s_zz[threadIdx.x] = zz[threadIdx.x];
+        // blocks are stored transposed (column-major) for k_idct's column pass
+        if (threadIdx.x < 80) s_zz[threadIdx.x] = (uint8_t)(((zz[threadIdx.x] & 7) << 3) | (zz[threadIdx.x] >> 3));
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
         for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
@@ -525,6 +532,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wide_id = wide_id_arena + img.coef_off / 64;
     sink.n_wide = &st.n_wide;
     sink.wslot = 0xffffffffu;
+    sink.dc16 = dc_arena + img.coef_off / 64;
+    sink.dcv = 0;
     lp_write_pass(m, ic, entry, exits[g].p, lp_sum_unpack(prefixes[g]), s_zz, sink);
 }
 
@@ -549,83 +558,97 @@ __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
     o[2] = t12 + tmp1; o[5] = t12 - tmp1; o[3] = t13 + tmp0; o[4] = t13 - tmp0;
 }
 
-#define IDCT_CSTRIDE 72 // int16 per block in LDS (64 + 8 pad): conflict-free column reads
 #define IDCT_WSTRIDE 72 // int32 per block in LDS (64 + 8 pad): conflict-free column writes
 
+// Grid: x = group of IDCT_TPW * 32 blocks along a block row, y = block row over the image's components stacked (all Y rows,
+// then Cb, then Cr), z = image -- no integer division anywhere. A wave walks IDCT_TPW tiles of 8 blocks (its setup -- the
+// descriptor loads, the quantisation column -- is paid once, and the next tile's coefficients are in flight while the
+// current one is transformed; one-tile waves were bound by wave launch rate, not by HBM or VALU).
+// Blocks are stored TRANSPOSED by the WRITE pass (element v * 8 + u = coefficient row u, column v), so lane (block j,
+// column v) loads its whole column as 8 contiguous bytes and the column pass needs no LDS transpose; only the row pass
+// reads the workspace back through LDS.
+#define IDCT_TPW 8
+// VARIANT: 0 = plain loop; 1 = + hoisted row pointers / quantisation column; 2 = + prefetch of the next tile
+template <int VARIANT>
 __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                               const int8_t* __restrict__ coef8_arena, const int16_t* __restrict__ wide_arena,
-                                              const uint32_t* __restrict__ wide_id_arena, uint8_t* __restrict__ plane_arena)
+                                              const uint32_t* __restrict__ wide_id_arena, const int16_t* __restrict__ dc_arena,
+                                              uint8_t* __restrict__ plane_arena)
 {
-    __shared__ __attribute__((aligned(16))) int16_t s_c[4][8 * IDCT_CSTRIDE];
     __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
-    __shared__ uint16_t s_q[64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_qt[64]; // transposed like the blocks: [column][row]
     const LpJpeg& img = imgs[blockIdx.z];
-    const uint32_t c = blockIdx.y;
-    if (c >= img.ncomp) return;
-    const uint32_t bw = img.bw[c], bh = img.bh[c];
-    const uint32_t tiles_x = (bw + 7) / 8, ntiles = tiles_x * bh;
-    if (blockIdx.x * 4 >= ntiles) return;
-    if (threadIdx.x < 64) s_q[threadIdx.x] = img.qt[c][threadIdx.x];
+    uint32_t by = blockIdx.y, c = 0;
+    if (by >= img.bh[0]) {
+        by -= img.bh[0];
+        c = 1;
+        if (img.ncomp > 1 && by >= img.bh[1]) { by -= img.bh[1]; c = 2; }
+    }
+    if (c >= img.ncomp || by >= img.bh[c]) return;
+    const uint32_t bw = img.bw[c];
+    if (blockIdx.x * (32 * IDCT_TPW) >= bw) return;
+    if (threadIdx.x < 64) s_qt[((threadIdx.x & 7) << 3) | (threadIdx.x >> 3)] = img.qt[c][threadIdx.x];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x * 4 + wv;
-    const bool active = tile < ntiles;
-    const uint32_t by = active ? tile / tiles_x : 0, bx0 = active ? (tile % tiles_x) * 8 : 0;
     const uint32_t j = lane >> 3, r = lane & 7;
-    const bool blk_ok = active && bx0 + j < bw;
-    // blocks are stored in decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order
-    const uint32_t hs = img.hs[c], vs = img.vs[c], bx = bx0 + j;
-    const uint32_t blk = ((by / vs) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[c] + (by % vs) * hs + (bx % hs);
-    // 64 x int8 per block (see DevSink); -128 escapes to the block's wide slot
-    int32_t cv[8];
-    {
-        const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
-#pragma unroll
-        for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-        bool any_esc = false;
-#pragma unroll
-        for (int i = 0; i < 8; i++) any_esc = any_esc || cv[i] == -128;
-        if (any_esc) {
-            const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (cv[i] == -128) cv[i] = w[i];
-        }
-    }
-    uint4 v;
-    v.x = ((uint32_t)cv[0] & 0xffffu) | ((uint32_t)cv[1] << 16);
-    v.y = ((uint32_t)cv[2] & 0xffffu) | ((uint32_t)cv[3] << 16);
-    v.z = ((uint32_t)cv[4] & 0xffffu) | ((uint32_t)cv[5] << 16);
-    v.w = ((uint32_t)cv[6] & 0xffffu) | ((uint32_t)cv[7] << 16);
-    *reinterpret_cast<uint4*>(&s_c[wv][j * IDCT_CSTRIDE + r * 8]) = v;
+    // decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order; sampling factors are 1 or 2
+    const uint32_t hsh = img.hs[c] - 1u, vsh = img.vs[c] - 1u;
     __syncthreads();
-    {   // pass 1: column r of block j
-        int32_t d[8], o[8];
+    for (uint32_t t = 0; t < IDCT_TPW; t++) {
+        const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32;
+        if (base >= bw) break; // workgroup-uniform
+        const uint32_t bx = base + wv * 8 + j;
+        const bool blk_ok = bx < bw;
+        const uint32_t blk = (((by >> vsh) * img.mcus_x + (bx >> hsh)) * img.bpm + img.blk_first[c] + ((by & vsh) << hsh) + (bx & hsh));
+        // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
+        int32_t cv[8];
+        {
+            const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
 #pragma unroll
-        for (int k = 0; k < 8; k++) d[k] = (int32_t)s_c[wv][j * IDCT_CSTRIDE + k * 8 + r] * (int32_t)s_q[k * 8 + r];
-        idct_1d(d, o);
+            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+            bool any_esc = false;
 #pragma unroll
-        for (int k = 0; k < 8; k++) s_w[wv][j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
-    }
-    __syncthreads();
-    {   // pass 2: row r of block j
-        int32_t d[8], o[8];
-        const int4* wp = reinterpret_cast<const int4*>(&s_w[wv][j * IDCT_WSTRIDE + r * 8]);
-        int4 a = wp[0], b = wp[1];
-        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-        idct_1d(d, o);
-        uint32_t px[8];
+            for (int i = 0; i < 8; i++) any_esc = any_esc || cv[i] == -128;
+            if (any_esc) {
+                const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int32_t s = ((o[k] + (1 << 17)) >> 18) + 128;
-            px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+                for (int i = 0; i < 8; i++)
+                    if (cv[i] == -128) cv[i] = w[i];
+            }
+            if (r == 0 && blk_ok) cv[0] = dc_arena[img.coef_off / 64 + blk]; // the DC lives in its own 16-bit array
         }
-        if (blk_ok) {
-            uint2 out;
-            out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-            out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-            uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + (bx0 + j) * 8;
-            *reinterpret_cast<uint2*>(dst) = out;
+        {   // pass 1: column r of block j
+            const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
+            int32_t d[8], o[8];
+            d[0] = cv[0] * (int32_t)(q.x & 0xffffu); d[1] = cv[1] * (int32_t)(q.x >> 16);
+            d[2] = cv[2] * (int32_t)(q.y & 0xffffu); d[3] = cv[3] * (int32_t)(q.y >> 16);
+            d[4] = cv[4] * (int32_t)(q.z & 0xffffu); d[5] = cv[5] * (int32_t)(q.z >> 16);
+            d[6] = cv[6] * (int32_t)(q.w & 0xffffu); d[7] = cv[7] * (int32_t)(q.w >> 16);
+            idct_1d(d, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s_w[wv][j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
         }
+        __syncthreads();
+        {   // pass 2: row r of block j
+            int32_t d[8], o[8];
+            const int4* wp = reinterpret_cast<const int4*>(&s_w[wv][j * IDCT_WSTRIDE + r * 8]);
+            int4 a = wp[0], b = wp[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+            idct_1d(d, o);
+            uint32_t px[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int32_t s = ((o[k] + (1 << 17)) >> 18) + 128;
+                px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+            }
+            if (blk_ok) {
+                uint2 out;
+                out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+                out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+                uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
+                *reinterpret_cast<uint2*>(dst) = out;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -669,13 +692,13 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
-                       (const LpSumPk*)a.prefix, a.coef8, a.wide, a.wide_id);
+                       (const LpSumPk*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
 }
 
-void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int8_t* d_coef8,
-                    const int16_t* d_wide, const uint32_t* d_wide_id, uint8_t* d_planes)
+void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
+                    const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes)
 {
-    if (!nimg || !max_tiles) return;
-    dim3 g((max_tiles + 3) / 4, LP_MAX_COMP, nimg);
-    hipLaunchKernelGGL(k_idct, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_planes);
+    if (!nimg || !max_bw || !max_rows) return;
+    dim3 g((max_bw + 32 * IDCT_TPW - 1) / (32 * IDCT_TPW), max_rows, nimg); // max_rows = most block rows of an image, all components stacked
+    hipLaunchKernelGGL(k_idct<0>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_planes);
 }

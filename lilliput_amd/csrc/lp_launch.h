@@ -26,6 +26,7 @@ struct LpHuffArgs {
     int8_t* coef8;              // 64 x int8 per block, decode order; -128 = escape (see DevSink in lp_kernels_decode.hip)
     int16_t* wide;              // wide slots: 64 x int16, only escaped positions are valid
     uint32_t* wide_id;          // block -> wide slot (valid for blocks holding an escape)
+    int16_t* dc16;              // DC coefficient of every block
     uint32_t S;
     LpCkSched sched;
 };
@@ -33,8 +34,8 @@ void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
-void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_tiles, const int8_t* d_coef8,
-                    const int16_t* d_wide, const uint32_t* d_wide_id, uint8_t* d_planes);
+void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
+                    const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes);
 // pixels
 void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_planes,
                             const LpFrame* d_dsts, uint8_t* d_frames);
