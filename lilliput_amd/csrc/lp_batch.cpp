@@ -107,7 +107,7 @@ void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* ve
 static int batch_streams(int requested)
 {
     int n = requested;
-    if (n <= 0) { const char* e = getenv("LILLIPUT_HIP_STREAMS"); n = e ? atoi(e) : 2; }
+    if (n <= 0) { const char* e = getenv("LILLIPUT_HIP_STREAMS"); n = e ? atoi(e) : 4; }
     return std::max(1, std::min(8, n));
 }
 
@@ -163,7 +163,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     // chunk size: bound the working set (coefficients + planes + BGR frame ~ 7.5 B/pixel + oriented copy)
     size_t max_px = 1;
     for (auto& h : part.hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
-    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(256, (size_t)(48ull << 30) / (max_px * 12)));
+    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(128, (size_t)(24ull << 30) / (max_px * 12)));
     uint32_t& rounds = part.rounds;
     double* tw = part.tw;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
