@@ -542,17 +542,25 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
 // blocks of one component; lane = (block j, row/column r). Coefficient rows arrive as one coalesced
 // 1 KiB wave load, are transposed through LDS for the column pass, and leave as 8-byte pixel rows
 // (64 contiguous bytes per row across the 8 blocks).
+// MUL24: multiply with v_mul_i32_i24 (full rate; the 32-bit v_mul_lo_u32 is a quarter-rate instruction and was the single
+// largest cost of this kernel). Exact as long as every multiplied value fits 24 signed bits -- see the guard in k_idct.
+template <bool MUL24>
+__device__ __forceinline__ int32_t idct_mul(int32_t a, int32_t c)
+{
+    return MUL24 ? __mul24(a, c) : a * c;
+}
+template <bool MUL24>
 __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
 {
-    int32_t z1 = (d[2] + d[6]) * 4433;
-    int32_t tmp2 = z1 - d[6] * 15137, tmp3 = z1 + d[2] * 6270;
+    int32_t z1 = idct_mul<MUL24>(d[2] + d[6], 4433);
+    int32_t tmp2 = z1 - idct_mul<MUL24>(d[6], 15137), tmp3 = z1 + idct_mul<MUL24>(d[2], 6270);
     int32_t tmp0 = (int32_t)((uint32_t)(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)(d[0] - d[4]) << 13);
     int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
     tmp0 = d[7]; tmp1 = d[5]; tmp2 = d[3]; tmp3 = d[1];
     z1 = tmp0 + tmp3;
-    int32_t z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3, z5 = (z3 + z4) * 9633;
-    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
-    z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+    int32_t z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3, z5 = idct_mul<MUL24>(z3 + z4, 9633);
+    tmp0 = idct_mul<MUL24>(tmp0, 2446); tmp1 = idct_mul<MUL24>(tmp1, 16819); tmp2 = idct_mul<MUL24>(tmp2, 25172); tmp3 = idct_mul<MUL24>(tmp3, 12299);
+    z1 = idct_mul<MUL24>(z1, -7373); z2 = idct_mul<MUL24>(z2, -20995); z3 = idct_mul<MUL24>(z3, -16069) + z5; z4 = idct_mul<MUL24>(z4, -3196) + z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
     o[0] = t10 + tmp3; o[7] = t10 - tmp3; o[1] = t11 + tmp2; o[6] = t11 - tmp2;
     o[2] = t12 + tmp1; o[5] = t12 - tmp1; o[3] = t13 + tmp0; o[4] = t13 - tmp0;
@@ -567,6 +575,44 @@ __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
 // Blocks are stored TRANSPOSED by the WRITE pass (element v * 8 + u = coefficient row u, column v), so lane (block j,
 // column v) loads its whole column as 8 contiguous bytes and the column pass needs no LDS transpose; only the row pass
 // reads the workspace back through LDS.
+// The two passes of one 8-block tile for lane (block j, column/row r): column pass from registers into the wave's LDS
+// workspace, row pass back out of it, clamp, 8-byte pixel-row store. (The workgroup barrier between them sits in the
+// caller, outside of any wave-divergent branch.)
+template <bool MUL24>
+__device__ __forceinline__ void idct_cols(const int32_t cv[8], const uint16_t* s_qt, int32_t* s_w, uint32_t j, uint32_t r)
+{
+    const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
+    int32_t d[8], o[8];
+    d[0] = cv[0] * (int32_t)(q.x & 0xffffu); d[1] = idct_mul<MUL24>(cv[1], (int32_t)(q.x >> 16));
+    d[2] = idct_mul<MUL24>(cv[2], (int32_t)(q.y & 0xffffu)); d[3] = idct_mul<MUL24>(cv[3], (int32_t)(q.y >> 16));
+    d[4] = idct_mul<MUL24>(cv[4], (int32_t)(q.z & 0xffffu)); d[5] = idct_mul<MUL24>(cv[5], (int32_t)(q.z >> 16));
+    d[6] = idct_mul<MUL24>(cv[6], (int32_t)(q.w & 0xffffu)); d[7] = idct_mul<MUL24>(cv[7], (int32_t)(q.w >> 16));
+    idct_1d<MUL24>(d, o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_w[j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
+}
+template <bool MUL24>
+__device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32_t r, bool blk_ok, uint8_t* dst)
+{
+    int32_t d[8], o[8];
+    const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
+    int4 a = wp[0], b = wp[1];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    idct_1d<MUL24>(d, o);
+    uint32_t px[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int32_t s = (o[k] + ((1 << 17) + (128 << 18))) >> 18; // DESCALE, then + 128 (folded into the rounding constant)
+        px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+    }
+    if (blk_ok) {
+        uint2 out;
+        out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+        *reinterpret_cast<uint2*>(dst) = out;
+    }
+}
+
 #define IDCT_TPW 8
 // VARIANT: 0 = plain loop; 1 = + hoisted row pointers / quantisation column; 2 = + prefetch of the next tile
 template <int VARIANT>
@@ -593,6 +639,11 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     // decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order; sampling factors are 1 or 2
     const uint32_t hsh = img.hs[c] - 1u, vsh = img.vs[c] - 1u;
     __syncthreads();
+    bool q_small;
+    {
+        const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
+        q_small = ((q.x | q.y | q.z | q.w) & 0xff00ff00u) == 0; // this lane's column of the table; the wave vote below covers all eight
+    }
     for (uint32_t t = 0; t < IDCT_TPW; t++) {
         const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32;
         if (base >= bw) break; // workgroup-uniform
@@ -601,11 +652,11 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         const uint32_t blk = (((by >> vsh) * img.mcus_x + (bx >> hsh)) * img.bpm + img.blk_first[c] + ((by & vsh) << hsh) + (bx & hsh));
         // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
         int32_t cv[8];
+        bool any_esc = false;
         {
             const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
 #pragma unroll
             for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-            bool any_esc = false;
 #pragma unroll
             for (int i = 0; i < 8; i++) any_esc = any_esc || cv[i] == -128;
             if (any_esc) {
@@ -616,38 +667,16 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
             }
             if (r == 0 && blk_ok) cv[0] = dc_arena[img.coef_off / 64 + blk]; // the DC lives in its own 16-bit array
         }
-        {   // pass 1: column r of block j
-            const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
-            int32_t d[8], o[8];
-            d[0] = cv[0] * (int32_t)(q.x & 0xffffu); d[1] = cv[1] * (int32_t)(q.x >> 16);
-            d[2] = cv[2] * (int32_t)(q.y & 0xffffu); d[3] = cv[3] * (int32_t)(q.y >> 16);
-            d[4] = cv[4] * (int32_t)(q.z & 0xffffu); d[5] = cv[5] * (int32_t)(q.z >> 16);
-            d[6] = cv[6] * (int32_t)(q.w & 0xffffu); d[7] = cv[7] * (int32_t)(q.w >> 16);
-            idct_1d(d, o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) s_w[wv][j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
-        }
+        // 24-bit multiplies are exact when every multiplied term fits 24 signed bits. The DC (and the workspace column it feeds) is
+        // only shifted, never multiplied; an AC coefficient without an escape is at most 127, so with 8-bit quantisation tables the
+        // multiplied terms stay below 2^15 in the column pass and 2^23 in the row pass. Anything else takes the 32-bit path.
+        const bool fast = !any_esc && q_small;
+        const bool wave_fast = __all(fast);
+        uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
+        if (wave_fast) idct_cols<true>(cv, s_qt, s_w[wv], j, r); else idct_cols<false>(cv, s_qt, s_w[wv], j, r);
         __syncthreads();
-        {   // pass 2: row r of block j
-            int32_t d[8], o[8];
-            const int4* wp = reinterpret_cast<const int4*>(&s_w[wv][j * IDCT_WSTRIDE + r * 8]);
-            int4 a = wp[0], b = wp[1];
-            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-            idct_1d(d, o);
-            uint32_t px[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                int32_t s = ((o[k] + (1 << 17)) >> 18) + 128;
-                px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
-            }
-            if (blk_ok) {
-                uint2 out;
-                out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-                out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-                uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
-                *reinterpret_cast<uint2*>(dst) = out;
-            }
-        }
+        if (wave_fast) idct_rows<true>(s_w[wv], j, r, blk_ok, dst); else idct_rows<false>(s_w[wv], j, r, blk_ok, dst);
+        __syncthreads();
         __syncthreads();
     }
 }
