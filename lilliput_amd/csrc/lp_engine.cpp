@@ -39,6 +39,27 @@ bool LpPinned::ensure(size_t bytes)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// one mutex per (device, stage group); see LpEngine::set_pipelined
+static std::mutex& group_mutex(int device, int group)
+{
+    static std::mutex mu[16][3];
+    return mu[device & 15][group];
+}
+namespace {
+struct GroupHold { // releases on every exit path of run_decode
+    int dev, g = -1;
+    explicit GroupHold(int d) : dev(d) {}
+    void take(int ng) { release(); group_mutex(dev, ng).lock(); g = ng; }
+    void release() { if (g >= 0) { group_mutex(dev, g).unlock(); g = -1; } }
+    void detach() { g = -1; }
+    ~GroupHold() { release(); }
+};
+}
+void LpEngine::pixel_stage_done()
+{
+    if (holds_pixel_) { holds_pixel_ = false; group_mutex(device_, GROUP_PIXEL).unlock(); }
+}
+
 LpEngine::LpEngine(int device) : device_(device)
 {
     int n = 0;
@@ -210,8 +231,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_rst_.ensure((size_t)tot_rst_ * 4 + 64) && d_chunk_.ensure((size_t)tot_chunks_ * 8 + 64) &&
              d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
-             d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSumPk) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) &&
+             d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
@@ -228,6 +249,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         (void)hipStreamSynchronize(stream_);
         fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
     };
+    GroupHold hold(device_);
+    if (pipelined_) hold.take(GROUP_COUNT);
     if (timing_) (void)hipEventRecord(ev_[0], stream_);
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>(), S_);
@@ -238,9 +261,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.nimg = (uint32_t)n; ha.max_sub = max_sub_; ha.tot_sub = tot_sub_;
     ha.clean = d_clean_.as<uint32_t>(); ha.rst = d_rst_.as<uint32_t>();
     ha.ckpts = d_ckpt_.as<LpCkptPk>();
-    ha.spec_exit = d_spec_exit_.as<LpSubState>(); ha.spec_total = d_spec_tot_.as<LpSumPk>();
-    ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSumPk>();
-    ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSumPk>();
+    ha.spec_exit = d_spec_exit_.as<LpSubState>(); ha.spec_total = d_spec_tot_.as<LpSubSum>();
+    ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSubSum>();
+    ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSubSum>();
     ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>(); ha.dc16 = d_dc_.as<int16_t>();
     ha.S = S_; ha.sched = sched_;
     lp_launch_huff_spec(stream_, ha);
@@ -257,6 +280,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (*h_changed == 0 || rounds >= 4096) break;
     }
     tm_.verify_rounds = rounds;
+    if (pipelined_) hold.take(GROUP_WRITE); // the verify loop ended on a stream synchronisation: the counting group is finished on the device
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
     stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
@@ -264,7 +288,14 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
     lp_launch_huff_write(stream_, ha);
     stage("huff_write");
-    if (timing_) (void)hipEventRecord(ev_[2], stream_);
+    lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>());
+    stage("dc_scan");
+    if (pipelined_) {
+        if (timing_) (void)hipEventRecord(ev_[2], stream_);
+        (void)hipStreamSynchronize(stream_);
+        hold.take(GROUP_PIXEL);
+    }
+    if (timing_ && !pipelined_) (void)hipEventRecord(ev_[2], stream_);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>());
     stage("idct");
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
@@ -295,6 +326,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
         if (status[i]) rc = status[i];
     }
+    if (pipelined_) { hold.detach(); holds_pixel_ = true; } // the caller finishes the pixel group and calls pixel_stage_done()
     if (timing_) {
         (void)hipEventElapsedTime(&tm_.unstuff_ms, ev_[0], ev_[1]);
         (void)hipEventElapsedTime(&tm_.huff_ms, ev_[1], ev_[2]);

@@ -160,25 +160,29 @@ struct LpLane {
     }
 
     // Decode one Huffman symbol (+ its extra bits) from pk = peek(). On return:
-    //   is_dc, k = zigzag index of the coefficient (valid when has_val), val, block_done, comp.
+    //   is_dc, k = zigzag index of the coefficient (valid when has_val), val, block_done.
     // Written branch-free apart from the long-code lookup: every lane of the wave runs the same instructions.
-    struct Sym { bool is_dc; bool has_val; bool block_done; uint32_t k; int32_t val; uint32_t comp; };
+    // NEED_VAL = false (the counting passes) skips the value reconstruction.
+    struct Sym { bool is_dc; bool has_val; bool block_done; uint32_t k; int32_t val; };
+    template <bool NEED_VAL>
     LP_HD Sym step(uint32_t pk)
     {
         Sym r;
         r.is_dc = (z == 0);
-        r.comp = rot & 3u;
         const uint32_t tbl = r.is_dc ? ((rot >> 2) & 1u) : 2u + ((rot >> 3) & 1u);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
         if ((e >> 8) == 0) e = long_code(tbl, pk >> 16);
         const uint32_t len = e >> 8;
         const uint32_t s = e & 15u;
         const uint32_t run = (e >> 4) & 15u;      // DC symbols are categories 0..15 (validated by the parser): run == 0
-        const uint32_t t = pk << len;             // the extra bits, left aligned
-        const uint32_t x = (t >> 1) >> (31u - s); // their value (0 when s == 0)
-        // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1)
-        const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);
-        r.val = (int32_t)(x - (neg & ((1u << s) - 1u)));
+        r.val = 0;
+        if (NEED_VAL) {
+            const uint32_t t = pk << len;             // the extra bits, left aligned
+            const uint32_t x = (t >> 1) >> (31u - s); // their value (0 when s == 0)
+            // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1)
+            const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);
+            r.val = (int32_t)(x - (neg & ((1u << s) - 1u)));
+        }
         p += len + s;
         // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL); a coefficient whose index overruns 63 on
         // a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table carries the same guard entries)
@@ -197,22 +201,12 @@ struct LpLane {
     }
 };
 
-// a[c] += v without indexing a register array by a per-lane value (that would push the array to scratch memory)
-LP_HD void lp_add3(int32_t a[LP_MAX_COMP], uint32_t c, int32_t v)
-{
-    a[0] += c == 0 ? v : 0;
-    a[1] += c == 1 ? v : 0;
-    a[2] += c == 2 ? v : 0;
-}
-LP_HD int32_t lp_get3(const int32_t a[LP_MAX_COMP], uint32_t c) { return c == 0 ? a[0] : c == 1 ? a[1] : a[2]; }
-
 LP_HD bool lp_state_eq(const LpSubState& a, const LpSubState& b) { return a.p == b.p && a.bz == b.bz; }
 
 LP_HD void lp_sum_zero(LpSubSum& s)
 {
     s.nblk = 0;
     s.nreset = 0;
-    for (int c = 0; c < LP_MAX_COMP; c++) s.dc[c] = 0;
 }
 
 // a then b (b later in the stream)
@@ -221,7 +215,6 @@ LP_HD LpSubSum lp_sum_combine(const LpSubSum& a, const LpSubSum& b)
     LpSubSum r;
     r.nblk = a.nblk + b.nblk;
     r.nreset = a.nreset + b.nreset;
-    for (int c = 0; c < LP_MAX_COMP; c++) r.dc[c] = b.nreset ? b.dc[c] : a.dc[c] + b.dc[c];
     return r;
 }
 
@@ -231,49 +224,24 @@ LP_HD LpSubSum lp_sum_tail(const LpSubSum& whole, const LpSubSum& pre)
     LpSubSum t;
     t.nblk = whole.nblk - pre.nblk;
     t.nreset = whole.nreset - pre.nreset;
-    for (int c = 0; c < LP_MAX_COMP; c++) t.dc[c] = t.nreset ? whole.dc[c] : whole.dc[c] - pre.dc[c];
     return t;
 }
 
-LP_HD int32_t lp_sx16(uint32_t v) { return (int32_t)(int16_t)(uint16_t)v; }
-
-LP_HD LpSumPk lp_sum_pack(const LpSubSum& s)
-{
-    LpSumPk k;
-    k.nblk = s.nblk;
-    k.nreset = s.nreset;
-    k.dc01 = ((uint32_t)s.dc[0] & 0xffffu) | ((uint32_t)s.dc[1] << 16);
-    k.dc2 = (uint32_t)s.dc[2] & 0xffffu;
-    return k;
-}
-LP_HD LpSubSum lp_sum_unpack(const LpSumPk& k)
-{
-    LpSubSum s;
-    s.nblk = k.nblk;
-    s.nreset = k.nreset;
-    s.dc[0] = lp_sx16(k.dc01);
-    s.dc[1] = lp_sx16(k.dc01 >> 16);
-    s.dc[2] = lp_sx16(k.dc2);
-    return s;
-}
 LP_HD LpCkptPk lp_ckpt_pack(const LpSubState& st, const LpSubSum& s)
 {
     LpCkptPk k;
     k.p = st.p;
-    k.bz_nreset = (st.bz & 0xffffu) | (s.nreset << 16);
-    k.nblk_dc2 = (s.nblk & 0xffffu) | ((uint32_t)s.dc[2] << 16);
-    k.dc01 = ((uint32_t)s.dc[0] & 0xffffu) | ((uint32_t)s.dc[1] << 16);
+    k.bz = st.bz;
+    k.nblk = s.nblk;
+    k.nreset = s.nreset;
     return k;
 }
 LP_HD void lp_ckpt_unpack(const LpCkptPk& k, LpSubState& st, LpSubSum& s)
 {
     st.p = k.p;
-    st.bz = k.bz_nreset & 0xffffu;
-    s.nreset = k.bz_nreset >> 16;
-    s.nblk = k.nblk_dc2 & 0xffffu;
-    s.dc[2] = lp_sx16(k.nblk_dc2 >> 16);
-    s.dc[0] = lp_sx16(k.dc01);
-    s.dc[1] = lp_sx16(k.dc01 >> 16);
+    st.bz = k.bz;
+    s.nblk = k.nblk;
+    s.nreset = k.nreset;
 }
 
 LP_HD uint32_t lp_ck_iter(const LpCkSched& cs, uint32_t k) { return k < cs.nd ? (k + 1) * cs.td : cs.nd * cs.td + (k + 1 - cs.nd) * cs.ts; }
@@ -299,7 +267,6 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) { // rare even per wave: a restart boundary or the stream end is near
             if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
                 sum.nreset++;
-                for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
             }
             pk = L.peek();
         }
@@ -315,12 +282,11 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
         done = done || L.p >= sub_end;
         if (!done) {
             sum.nblk += L.z == 0 ? 1u : 0u;
-            const typename LpLane<M>::Sym s = L.step(pk);
-            lp_add3(sum.dc, s.comp, s.is_dc ? s.val : 0);
+            (void)L.template step<false>(pk);
         }
     } while (m.any(!done));
     LpCkptPk none;
-    none.p = 0xffffffffu; none.bz_nreset = 0; none.nblk_dc2 = 0; none.dc01 = 0;
+    none.p = 0xffffffffu; none.bz = 0; none.nblk = 0; none.nreset = 0;
     for (; k < cs.K; k++) ck.record(k, none);
     exit_st->p = L.p;
     exit_st->bz = L.state_bz();
@@ -351,7 +317,6 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
             if (!done && L.z == 0 && L.restart_check(pk)) {
                 sum.nreset++;
-                for (int c = 0; c < LP_MAX_COMP; c++) sum.dc[c] = 0;
             }
             pk = L.peek();
         }
@@ -378,8 +343,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
         done = done || L.p >= sub_end;
         if (!done) {
             sum.nblk += L.z == 0 ? 1u : 0u;
-            const typename LpLane<M>::Sym s = L.step(pk);
-            lp_add3(sum.dc, s.comp, s.is_dc ? s.val : 0);
+            (void)L.template step<false>(pk);
         }
     } while (m.any(!done));
     if (!spliced) {
@@ -390,7 +354,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
-//   void put_dc(int32_t v);                        the block's (absolute) DC coefficient
+//   void put_dc(int32_t v);                        the block's DC DIFFERENCE (made absolute later, see lp_dc_scan)
 //   void put(uint32_t natural_idx, int32_t v);     store one AC coefficient of the block being decoded
 //   void end_block(uint32_t blk);                  the block (decode-order index blk) is complete (queued for flushing)
 //   bool stalled();                                no free slot: the lane must wait for the next flush
@@ -406,8 +370,6 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
     uint32_t blk = prefix.nblk;
-    int32_t pred[LP_MAX_COMP];
-    for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = prefix.dc[c];
     bool writing = false, done = false;
     uint32_t written = 0, iter = 0;
     do {
@@ -417,8 +379,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         iter++;
         const bool act = !done && !sink.stalled();
         if (m.any(act && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
-            if (act && L.z == 0 && L.restart_check(pk))
-                for (int c = 0; c < LP_MAX_COMP; c++) pred[c] = 0;
+            if (act && L.z == 0) (void)L.restart_check(pk); // DC predictors restart in k_dc_scan, by MCU index
             pk = L.peek();
         }
         // a lane stops at the first block start at or after the end of its subsequence (or when the stream is truncated)
@@ -426,10 +387,9 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         done = done || (act && stop);
         if (act && !stop) {
             writing = writing || L.z == 0; // a lane that enters mid-block skips to the first block start
-            const typename LpLane<M>::Sym s = L.step(pk);
+            const typename LpLane<M>::Sym s = L.template step<true>(pk);
             if (writing) {
-                lp_add3(pred, s.comp, s.is_dc ? s.val : 0);
-                if (s.is_dc) sink.put_dc(lp_get3(pred, s.comp));
+                if (s.is_dc) sink.put_dc(s.val);
                 else if (s.has_val) sink.put((uint32_t)zigzag[s.k], s.val);
                 if (s.block_done) {
                     sink.end_block(blk);
@@ -441,4 +401,21 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     } while (m.any(!done));
     sink.flush();
     return written;
+}
+
+// DC differences -> absolute DC, in place, for MCUs [m0, m1) of one image given the predictors at m0 (jdhuff.c decode_mcu:
+// last_dc_val per component, reset to 0 every restart interval -- process_restart runs every `dri` MCUs whatever the
+// markers say). dc[] holds one value per block in decode order; comp_of[b] = component of block b of an MCU. Values wrap
+// like libjpeg's store into a 16-bit JCOEF. Returns the predictors after m1 in pred[].
+LP_HD void lp_dc_walk(int16_t* dc, uint32_t m0, uint32_t m1, uint32_t bpm, uint32_t dri, const uint8_t* comp_of, int32_t pred[LP_MAX_COMP], bool write)
+{
+    for (uint32_t m = m0; m < m1; m++) {
+        if (dri && m % dri == 0) pred[0] = pred[1] = pred[2] = 0;
+        for (uint32_t b = 0; b < bpm; b++) {
+            const uint32_t c = comp_of[b];
+            const int32_t v = pred[c] + dc[(size_t)m * bpm + b];
+            pred[c] = v;
+            if (write) dc[(size_t)m * bpm + b] = (int16_t)v;
+        }
+    }
 }

@@ -307,15 +307,15 @@ struct DevCkSink {
     bool valid;
     __device__ __forceinline__ void record(uint32_t k, const LpCkptPk& c)
     {
-        if (valid) *reinterpret_cast<uint4*>(base + (size_t)k * stride) = make_uint4(c.p, c.bz_nreset, c.nblk_dc2, c.dc01);
+        if (valid) *reinterpret_cast<uint4*>(base + (size_t)k * stride) = make_uint4(c.p, c.bz, c.nblk, c.nreset);
     }
 };
 
 __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                                       const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                       const uint32_t* __restrict__ rst_bits, LpCkptPk* __restrict__ ckpts,
-                                                      LpSubState* __restrict__ spec_exit, LpSumPk* __restrict__ spec_total,
-                                                      LpSubState* __restrict__ cur_exit, LpSumPk* __restrict__ cur_total,
+                                                      LpSubState* __restrict__ spec_exit, LpSubSum* __restrict__ spec_total,
+                                                      LpSubState* __restrict__ cur_exit, LpSubSum* __restrict__ cur_total,
                                                       LpSubState* __restrict__ entry_used, uint32_t S, LpCkSched cs, uint32_t tot_sub)
 {
     typedef CountMem MEM;
@@ -341,11 +341,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
     LpSubSum tot;
     lp_spec_pass(m, ic, sub_end, entry, cs, ck, &ex, &tot);
     if (!valid) return;
-    const LpSumPk tp = lp_sum_pack(tot);
     spec_exit[g] = ex;
     cur_exit[g] = ex;
-    *reinterpret_cast<uint4*>(spec_total + g) = make_uint4(tp.nblk, tp.nreset, tp.dc01, tp.dc2);
-    *reinterpret_cast<uint4*>(cur_total + g) = make_uint4(tp.nblk, tp.nreset, tp.dc01, tp.dc2);
+    spec_total[g] = tot;
+    cur_total[g] = tot;
     LpSubState none;
     none.p = 0xffffffffu; none.bz = 0xffffffffu;
     entry_used[g] = none;
@@ -362,7 +361,7 @@ struct DevCkSrc {
     {
         const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)k * stride);
         LpCkptPk c;
-        c.p = v.x; c.bz_nreset = v.y; c.nblk_dc2 = v.z; c.dc01 = v.w;
+        c.p = v.x; c.bz = v.y; c.nblk = v.z; c.nreset = v.w;
         return c;
     }
 };
@@ -370,8 +369,8 @@ struct DevCkSrc {
 __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                                         const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                         const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
-                                                        const LpSubState* __restrict__ spec_exit, const LpSumPk* __restrict__ spec_total,
-                                                        LpSubState* cur_exit, LpSumPk* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
+                                                        const LpSubState* __restrict__ spec_exit, const LpSubSum* __restrict__ spec_total,
+                                                        LpSubState* cur_exit, LpSubSum* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
                                                         uint32_t* __restrict__ changed, uint32_t S, uint32_t K, uint32_t tot_sub)
 {
     typedef CountMem MEM;
@@ -395,15 +394,11 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     DevCkSrc ck{cp, ckpts + g, tot_sub};
     uint32_t sub_end = sub * S + S;
     if (sub_end > ic.total_bits) sub_end = ic.total_bits;
-    const uint4 tv = *reinterpret_cast<const uint4*>(spec_total + g);
-    LpSumPk tpk;
-    tpk.nblk = tv.x; tpk.nreset = tv.y; tpk.dc01 = tv.z; tpk.dc2 = tv.w;
     const LpSubState old_exit = load_state(cur_exit + g);
     LpSubState ex = old_exit;
     LpSubSum tot;
-    lp_verify_pass(m, ic, sub_end, entry, K, ck, spec_exit[g], lp_sum_unpack(tpk), &ex, &tot);
-    const LpSumPk np = lp_sum_pack(tot);
-    *reinterpret_cast<uint4*>(cur_total + g) = make_uint4(np.nblk, np.nreset, np.dc01, np.dc2);
+    lp_verify_pass(m, ic, sub_end, entry, K, ck, spec_exit[g], spec_total[g], &ex, &tot);
+    cur_total[g] = tot;
     entry_used[g] = entry;
     if (!lp_state_eq(ex, old_exit)) {
         store_state(cur_exit + g, ex);
@@ -414,7 +409,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
 // One workgroup per image: exclusive scan (lp_sum_combine is associative, not commutative) of the
 // per-subsequence sums -> prefixes[]; also validates the block count.
 __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states,
-                                                  const LpSumPk* __restrict__ totals, LpSumPk* __restrict__ prefixes)
+                                                  const LpSubSum* __restrict__ totals, LpSubSum* __restrict__ prefixes)
 {
     __shared__ LpSubSum s_part[256];
     const LpJpeg& img = imgs[blockIdx.x];
@@ -425,15 +420,15 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     if (b0 > n) b0 = n;
     LpSubSum acc;
     lp_sum_zero(acc);
-    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, lp_sum_unpack(totals[img.sub_off + i]));
+    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, totals[img.sub_off + i]);
     s_part[t] = acc;
     __syncthreads();
     LpSubSum pre;
     lp_sum_zero(pre);
     for (uint32_t i = 0; i < t; i++) pre = lp_sum_combine(pre, s_part[i]);
     for (uint32_t i = b0; i < b1; i++) {
-        prefixes[img.sub_off + i] = lp_sum_pack(pre);
-        pre = lp_sum_combine(pre, lp_sum_unpack(totals[img.sub_off + i]));
+        prefixes[img.sub_off + i] = pre;
+        pre = lp_sum_combine(pre, totals[img.sub_off + i]);
     }
     if (t == 255) {
         st.blocks_decoded = pre.nblk;
@@ -460,8 +455,9 @@ struct DevSink {
     uint32_t* wide_id;      // this image's block -> wide slot
     uint32_t* n_wide;       // this image's wide-slot counter
     uint32_t wslot;         // wide slot of the current block, 0xffffffff = none
-    int16_t* dc16;          // this image's DC coefficients (the DC rarely fits a byte: it has its own 16-bit array)
-    int32_t dcv;            // DC of the current block
+    int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
+                            // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
+    int32_t dcv;            // DC difference of the current block
     __device__ __forceinline__ void put_dc(int32_t v) { dcv = v; }
     __device__ __forceinline__ void put(uint32_t nat, int32_t v)
     {
@@ -497,7 +493,7 @@ template <class MEM>
 __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states,
                                                        const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                        const uint32_t* __restrict__ rst_bits, const LpSubState* __restrict__ exits,
-                                                       const LpSumPk* __restrict__ prefixes, int8_t* __restrict__ coef8_arena,
+                                                       const LpSubSum* __restrict__ prefixes, int8_t* __restrict__ coef8_arena,
                                                        int16_t* __restrict__ wide_arena, uint32_t* __restrict__ wide_id_arena,
                                                        int16_t* __restrict__ dc_arena)
 {
@@ -534,7 +530,112 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wslot = 0xffffffffu;
     sink.dc16 = dc_arena + img.coef_off / 64;
     sink.dcv = 0;
-    lp_write_pass(m, ic, entry, exits[g].p, lp_sum_unpack(prefixes[g]), s_zz, sink);
+    lp_write_pass(m, ic, entry, exits[g].p, prefixes[g], s_zz, sink);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DC differences -> absolute DC (in place): jdhuff.c decode_mcu keeps last_dc_val per component and process_restart zeroes
+// it every `dri` MCUs. One workgroup of 16 waves per image; wave w owns a contiguous range of MCUs and walks it 64 MCUs at
+// a time, lane = MCU (so the loads/stores of a step cover one contiguous run of bytes): a segmented wave scan of the
+// per-MCU component totals gives every lane its predictors. Phase 1 computes each wave's (total, had-a-reset), phase 2
+// rewrites the range starting from the combined totals of the waves before it. tests/emu checks the same arithmetic
+// through lp_dc_walk. ~0.8 MB per 4096x4096 image: latency-bound, hidden behind the other streams' kernels.
+#define DCSCAN_T 1024
+struct DcSeg { int32_t v[LP_MAX_COMP]; bool f; }; // sums since the last reset, reset seen
+
+// inclusive segmented scan over the wave; carry-in applies to the lanes before the first reset of the step
+__device__ __forceinline__ DcSeg dc_wave_scan(DcSeg x, const DcSeg& carry)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t u[LP_MAX_COMP];
+#pragma unroll
+        for (int c = 0; c < LP_MAX_COMP; c++) u[c] = __shfl_up(x.v[c], d, 64);
+        const bool uf = __shfl_up((int)x.f, d, 64) != 0;
+        if (lane >= (uint32_t)d) {
+            if (!x.f)
+#pragma unroll
+                for (int c = 0; c < LP_MAX_COMP; c++) x.v[c] += u[c];
+            x.f = x.f || uf;
+        }
+    }
+    if (!x.f)
+#pragma unroll
+        for (int c = 0; c < LP_MAX_COMP; c++) x.v[c] += carry.v[c];
+    return x;
+}
+
+template <bool WRITE>
+__device__ __forceinline__ DcSeg dc_walk_range(int16_t* dc, uint32_t m0, uint32_t m1, uint32_t bpm, uint32_t dri, uint32_t comps, DcSeg carry)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t mb = m0; mb < m1; mb += 64) {
+        const uint32_t m = mb + lane;
+        const bool ok = m < m1;
+        int32_t df[LP_MAX_BPM];
+        DcSeg mine;
+        mine.v[0] = mine.v[1] = mine.v[2] = 0;
+        mine.f = ok && dri && m % dri == 0;
+#pragma unroll
+        for (uint32_t b = 0; b < LP_MAX_BPM; b++) {
+            df[b] = (ok && b < bpm) ? (int32_t)dc[(size_t)m * bpm + b] : 0;
+            const uint32_t c = (comps >> (2 * b)) & 3u; // uniform
+            mine.v[0] += c == 0 ? df[b] : 0; mine.v[1] += c == 1 ? df[b] : 0; mine.v[2] += c == 2 ? df[b] : 0;
+        }
+        const DcSeg inc = dc_wave_scan(mine, carry);
+        if (WRITE) {
+            // predictors at the start of this lane's MCU: the inclusive value of the previous lane (the carry for lane 0), 0 after a reset
+            int32_t pr[LP_MAX_COMP];
+#pragma unroll
+            for (int c = 0; c < LP_MAX_COMP; c++) {
+                const int32_t up = __shfl_up(inc.v[c], 1, 64);
+                pr[c] = mine.f ? 0 : (lane ? up : carry.v[c]);
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < LP_MAX_BPM; b++) {
+                const uint32_t c = (comps >> (2 * b)) & 3u;
+                const int32_t v = (c == 0 ? pr[0] : c == 1 ? pr[1] : pr[2]) + df[b];
+                pr[0] = c == 0 ? v : pr[0]; pr[1] = c == 1 ? v : pr[1]; pr[2] = c == 2 ? v : pr[2];
+                if (ok && b < bpm) dc[(size_t)m * bpm + b] = (int16_t)v;
+            }
+        }
+        // the last lane's inclusive value is the carry of the next step
+#pragma unroll
+        for (int c = 0; c < LP_MAX_COMP; c++) carry.v[c] = __shfl(inc.v[c], 63, 64);
+        carry.f = carry.f || __shfl((int)inc.f, 63, 64) != 0;
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(DCSCAN_T) void k_dc_scan(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena)
+{
+    __shared__ int32_t s_sum[DCSCAN_T / 64][LP_MAX_COMP];
+    __shared__ int32_t s_rst[DCSCAN_T / 64];
+    const LpJpeg& img = imgs[blockIdx.x];
+    const uint32_t nmcu = img.mcus_x * img.mcus_y, bpm = img.bpm, dri = img.dri;
+    const uint32_t nw = DCSCAN_T / 64, w = threadIdx.x >> 6;
+    const uint32_t per = ((nmcu + nw - 1) / nw + 63) / 64 * 64; // whole steps per wave
+    const uint32_t m0 = w * per < nmcu ? w * per : nmcu, m1 = m0 + per < nmcu ? m0 + per : nmcu;
+    int16_t* dc = dc_arena + img.coef_off / 64;
+    uint32_t comps = 0;
+    for (uint32_t b = 0; b < LP_MAX_BPM; b++) comps |= (uint32_t)(img.blk_comp[b] & 3u) << (2 * b);
+    DcSeg zero;
+    zero.v[0] = zero.v[1] = zero.v[2] = 0;
+    zero.f = false;
+    const DcSeg tot = dc_walk_range<false>(dc, m0, m1, bpm, dri, comps, zero);
+    if ((threadIdx.x & 63) == 0) {
+        for (int c = 0; c < LP_MAX_COMP; c++) s_sum[w][c] = tot.v[c];
+        s_rst[w] = tot.f ? 1 : 0;
+    }
+    __syncthreads();
+    DcSeg pre = zero;
+    for (uint32_t q = 0; q < w; q++) { // combine the ranges before this wave (16 entries)
+        const bool f = s_rst[q] != 0;
+        for (int c = 0; c < LP_MAX_COMP; c++) pre.v[c] = f ? s_sum[q][c] : pre.v[c] + s_sum[q][c];
+    }
+    pre.f = false;
+    (void)dc_walk_range<true>(dc, m0, m1, bpm, dri, comps, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -706,14 +807,20 @@ void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_verify, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
-                       (const LpSubState*)a.spec_exit, (const LpSumPk*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed, a.S,
+                       (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed, a.S,
                        a.sched.K, a.tot_sub);
+}
+
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc)
+{
+    if (!nimg) return;
+    hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DCSCAN_T), 0, s, d_imgs, d_dc);
 }
 
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)
 {
     if (!a.nimg) return;
-    hipLaunchKernelGGL(k_sub_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSumPk*)a.cur_total, a.prefix);
+    hipLaunchKernelGGL(k_sub_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSubSum*)a.cur_total, a.prefix);
 }
 
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
@@ -721,7 +828,7 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
-                       (const LpSumPk*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
+                       (const LpSubSum*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,

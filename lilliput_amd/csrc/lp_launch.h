@@ -17,11 +17,11 @@ struct LpHuffArgs {
     const uint32_t* rst;
     LpCkptPk* ckpts;            // [K][tot_sub]
     LpSubState* spec_exit;      // results of the speculative pass (immutable afterwards)
-    LpSumPk* spec_total;
+    LpSubSum* spec_total;
     LpSubState* cur_exit;       // current (verified) exit state / sums of every subsequence
-    LpSumPk* cur_total;
+    LpSubSum* cur_total;
     LpSubState* entry_used;     // entry state a subsequence was last verified against
-    LpSumPk* prefix;            // exclusive scan of cur_total
+    LpSubSum* prefix;            // exclusive scan of cur_total
     uint32_t* changed;
     int8_t* coef8;              // 64 x int8 per block, decode order; -128 = escape (see DevSink in lp_kernels_decode.hip)
     int16_t* wide;              // wide slots: 64 x int16, only escaped positions are valid
@@ -34,6 +34,7 @@ void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc);
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
                     const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes);
 // pixels

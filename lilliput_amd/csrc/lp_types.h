@@ -86,28 +86,21 @@ struct LpSubState {
     uint32_t bz;                // (b << 8) | z : block-in-MCU, zigzag index of next coefficient
 };
 
-// Summary of the blocks STARTING inside one subsequence (or inside its prefix up to a checkpoint).
-// DC sums are kept modulo 2^16: the decoder stores DC as int16 (libjpeg JCOEF), so only the low 16 bits matter.
+// Summary of the blocks STARTING inside one subsequence (or inside its prefix up to a checkpoint). DC predictors are not
+// tracked by the entropy passes at all: the WRITE pass stores DC *differences* and k_dc_scan turns them into absolute
+// values afterwards (a prefix sum per component that restarts every restart interval), which removes the per-symbol DC
+// bookkeeping from the three VALU-bound decode loops.
 struct LpSubSum {
     uint32_t nblk;              // block starts
     uint32_t nreset;            // restart boundaries crossed
-    int32_t dc[LP_MAX_COMP];    // sum of DC differences per component since the last reset
-};
-
-// LpSubSum as stored in HBM (16 B, one coalesced dwordx4 per lane).
-struct LpSumPk {
-    uint32_t nblk, nreset;
-    uint32_t dc01;              // (dc0 & 0xffff) | dc1 << 16
-    uint32_t dc2;               // low 16 bits significant
 };
 
 // Checkpoint of the speculative pass (16 B): decoder state + sums at a fixed ITERATION of the lane's decode loop.
-// nblk and nreset fit 16 bits because a subsequence is at most 65 504 bits and a block takes at least 2.
 struct LpCkptPk {
     uint32_t p;                 // 0xffffffff = not recorded
-    uint32_t bz_nreset;         // bz | nreset << 16
-    uint32_t nblk_dc2;          // nblk | (dc2 & 0xffff) << 16
-    uint32_t dc01;
+    uint32_t bz;
+    uint32_t nblk;
+    uint32_t nreset;
 };
 
 // Checkpoint schedule: checkpoint k is taken before iteration it(k) of the lane's loop,

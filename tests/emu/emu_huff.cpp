@@ -111,8 +111,6 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         HostCk hc{&ck[(size_t)i * K]};
         uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
         lp_spec_pass(m, ic, sub_end, e, cs, hc, &spec_ex[i], &spec_tot[i]);
-        // the device stores sums packed (16-bit DC fields): round-trip them the same way
-        spec_tot[i] = lp_sum_unpack(lp_sum_pack(spec_tot[i]));
         ex[i] = spec_ex[i];
         tot[i] = spec_tot[i];
         entry_used[i] = LpSubState{0xffffffffu, 0xffffffffu};
@@ -130,7 +128,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
             LpSubState ne = ex[i];
             LpSubSum nt;
             lp_verify_pass(m, ic, sub_end, e, K, hc, spec_ex[i], spec_tot[i], &ne, &nt);
-            tot[i] = lp_sum_unpack(lp_sum_pack(nt));
+            tot[i] = nt;
             if (r == 0 && lp_state_eq(ne, spec_ex[i])) hits++;
             if (!lp_state_eq(ne, ex[i])) { ex[i] = ne; changed++; }
             entry_used[i] = e;
@@ -144,7 +142,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     std::vector<LpSubSum> prefix(nsub);
     LpSubSum acc;
     lp_sum_zero(acc);
-    for (uint32_t i = 0; i < nsub; i++) { prefix[i] = lp_sum_unpack(lp_sum_pack(acc)); acc = lp_sum_combine(acc, tot[i]); }
+    for (uint32_t i = 0; i < nsub; i++) { prefix[i] = acc; acc = lp_sum_combine(acc, tot[i]); }
     if (acc.nblk < img.total_blocks) return -13;
     static const uint8_t zz[80] = LP_ZIGZAG_INIT;
     std::vector<int16_t> all((size_t)img.total_blocks * 64, 0x7fff);
@@ -157,6 +155,13 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink);
     }
     if (written != img.total_blocks) return -14;
+    {   // DC differences -> absolute values (k_dc_scan on the device; same lane logic, one range)
+        std::vector<int16_t> dcs(img.total_blocks);
+        for (uint32_t q = 0; q < img.total_blocks; q++) dcs[q] = all[(size_t)q * 64];
+        int32_t pred[LP_MAX_COMP] = {0, 0, 0};
+        lp_dc_walk(dcs.data(), 0, img.mcus_x * img.mcus_y, img.bpm, img.dri, img.blk_comp, pred, true);
+        for (uint32_t q = 0; q < img.total_blocks; q++) all[(size_t)q * 64] = dcs[q];
+    }
     if (violation) return -15; // the lane logic read outside the ring window the device would hold
     *bw = (int)img.bw[comp]; *bh = (int)img.bh[comp];
     size_t ne = (size_t)img.bw[comp] * img.bh[comp] * 64;
