@@ -97,23 +97,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
+    from lilliput_amd.dist import Ranks
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if dist is not None:
-            import torch
-
-            dist.barrier()
-            torch.cuda.synchronize()
+    ranks = Ranks()   # one process per GPU (torchrun); backend "nccl" = RCCL; single process when WORLD_SIZE is unset
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    barrier = ranks.barrier
 
     import lilliput_amd as la
 
@@ -136,23 +124,17 @@ def main():
     def step():
         b.run(256, 256, la.ImageOpsFit, False, 85, args.chunk)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.time()
     stage = {}
-    for _ in range(args.steps):
+
+    def timed_step():
         step()
         for k, v in b.timings().items():
             stage[k] = stage.get(k, 0.0) + v
-    barrier()
-    elapsed = time.time() - t0
-    if dist is not None:
-        import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation, MAX over ranks
+    for _ in range(args.warmup):
+        step()
+    elapsed = ranks.timed(timed_step, args.steps, 0)
 
     res = b.download()
     ok = sum(1 for r in res if r.status == 0)
@@ -163,16 +145,18 @@ def main():
         images = args.batch * world * args.steps
         value = images / elapsed
         px = args.size * args.size
-        # Algorithmic bytes per image and kernel, W=H=4096: coefficients 2 B x 1.5 x W x H, planes 1.5 x W x H.
-        coef_b, plane_b, frame_b = 3 * px, 1.5 * px, 3 * px
+        # Algorithmic bytes per image and kernel, W=H=4096: coefficient blocks are 64 x int8 + one int16 DC per
+        # block (1.5 x W x H bytes + 2 B per block), planes 1.5 x W x H.
+        blocks = 1.5 * px / 64
+        coef_b, dc_b, plane_b = 64 * blocks, 2 * blocks, 1.5 * px
         kernels = {
-            "k_huff_count<false> (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
-            "k_huff_count<true> (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
-            "k_huff_write (entropy decode -> coefficients)": (stage.get("huff_write_ms", 0.0), c_in + coef_b),
+            "k_huff_spec (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
+            "k_huff_verify (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
+            "k_huff_write + k_dc_scan (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
             "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
-            "k_idct": (stage.get("idct_ms", 0.0), coef_b + plane_b),
-            "k_ycc_to_frame": (stage.get("color_ms", 0.0), plane_b + frame_b),
-            "k_resize_area_fast": (stage.get("resize_ms", 0.0), frame_b + 3 * 256 * 256),
+            "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
+            "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
+            "k_resample_420 (upsample + colour + 16x16 box mean)": (stage.get("resize_ms", 0.0), plane_b + 3 * 256 * 256),
             "k_enc_* (JPEG encode)": (stage.get("encode_ms", 0.0), 3 * 256 * 256 + c_out),
         }
         per_rank_images = args.batch * args.steps
@@ -181,6 +165,17 @@ def main():
         achieved = (dom_bytes * per_rank_images) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         breakdown = {k: {"ms_per_image": round(v[0] / per_rank_images, 5), "algorithmic_GBps": round(v[1] * per_rank_images / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                      for k, v in kernels.items()}
+        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_e_pmc_hbm_traffic.md): FETCH_SIZE (x2,
+        # the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, per launch of one chunk. Counters cannot be collected
+        # inside this process; the figure is per image x images per launch and is null when the file is absent.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "k_huff_write" if dom[0].startswith("k_huff_write") else dom[0].split(" ")[0]
+            launch_images = min(args.chunk or 128, args.batch)
+            traffic = round(pm[key]["hbm_bytes_per_image"] * launch_images)
+        except Exception:
+            traffic = None
         out = {
             "metric": "images/sec (4096x4096->256x256 JPEG q85)",
             "value": round(value, 2),
@@ -201,9 +196,10 @@ def main():
                        "end_to_end_hbm_roofline_frac": round((c_in + 2 * plane_b + 3 * 256 * 256 + c_out) * value / world / (HBM_PEAK_GBS * 1e9), 5),
                        "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps), "upload_s_not_timed": round(upload_s, 2)},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "note": "achieved = algorithmic bytes per launch / launch duration (HIP events on the engine stream); "
-                                 "the entropy decoder is latency/ALU bound, not HBM bound (SURVEY.md 8d)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "note": "achieved = algorithmic bytes per launch / launch duration (HIP events on the engine streams, summed over the "
+                                 "concurrent parts of the batch: kernels of different parts overlap, so a launch's wall duration includes the "
+                                 "time it shares the GPU); the entropy decoder is VALU-issue bound, not HBM bound (DESIGN.md 4.1)",
                          "per_kernel": breakdown},
         }
         if not args.no_cpu_baseline:
@@ -213,8 +209,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     b.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,36 @@
+"""The N>1 path on CPU: two processes over the gloo backend shard a batch, run the timed region of bench.py's contract
+(barrier on both sides, max over ranks) and account for every item exactly once."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_shard_time_and_reduce(tmp_path):
+    n_items = 11
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(tmp_path), str(n_items)]
+    subprocess.run(cmd, check=True, env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in (0, 1)]
+    items = sorted(res[0]["items"] + res[1]["items"])
+    assert items == list(range(n_items))                       # disjoint cover
+    assert abs(len(res[0]["items"]) - len(res[1]["items"])) <= 1
+    assert res[0]["total"] == res[1]["total"] == n_items       # sum over ranks
+    assert all(r["steps_run"] == 4 for r in res)               # 1 warm-up + exactly 3 timed steps
+    assert res[0]["elapsed"] == res[1]["elapsed"]              # max over ranks, seen by both
+    assert res[0]["elapsed"] >= 3 * 0.1 - 0.01                 # the slow rank (0.1 s per step) sets it
+
+
+def test_single_rank_needs_no_process_group():
+    sys.path.insert(0, ROOT)
+    from lilliput_amd.dist import Ranks
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    r = Ranks()
+    assert (r.rank, r.world, list(r.shard(5))) == (0, 1, [0, 1, 2, 3, 4])
+    assert r.timed(lambda: None, steps=2, warmup=1) >= 0.0
+    assert r.reduce(3.5, "sum") == 3.5
