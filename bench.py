@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device (0 = automatic)")
     ap.add_argument("--sub-bits", type=int, default=0, help="Huffman subsequence size in bits (0 = automatic)")
     ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
+    ap.add_argument("--out", type=int, default=256, help="thumbnail side (256 = the BASELINE workload; other values exercise other resize branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,7 +123,7 @@ def main():
     upload_s = time.time() - t
 
     def step():
-        b.run(256, 256, la.ImageOpsFit, False, 85, args.chunk)
+        b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
 
     stage = {}
 

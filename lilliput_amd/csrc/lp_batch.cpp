@@ -369,6 +369,7 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
     b->out_bytes.assign(n, std::vector<uint8_t>());
     // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
     const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
+    const auto t_run0 = std::chrono::steady_clock::now();
     size_t active = 0;
     for (auto& p : b->parts) active += p.items.empty() ? 0 : 1;
     if (active <= 1) {
@@ -392,6 +393,8 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
             fprintf(stderr, "[lilliput_hip] part of %zu: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f\n",
                     p.items.size(), p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5]);
     }
+    if (trace)
+        fprintf(stderr, "[lilliput_hip] run of %zu items: %.2f ms wall\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
     b->tm = LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}; // read by lilliput_hip_batch_timings
     return rc;
 }

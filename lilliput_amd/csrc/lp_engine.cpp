@@ -204,6 +204,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         j.clean_cap_words = (j.raw_len / 4 + 64 + 3) / 4 * 4;       // + slack for the zeroed tail and reads past the end
         clean_words += j.clean_cap_words;
         j.sub_off = tot_sub_;
+        // Per-image subsequence size. (Rounding it so that the count fills whole 256-lane workgroups was measured and
+        // rejected: workgroups that all start and drain together are 3-5 % slower than the ragged tail they replace.)
+        j.sub_bits = S_;
         j.sub_cap = (uint32_t)(((uint64_t)j.raw_len * 8 + S_ - 1) / S_) + 1;
         tot_sub_ += j.sub_cap;
         j.rst_off = tot_rst_;
@@ -253,7 +256,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (pipelined_) hold.take(GROUP_COUNT);
     if (timing_) (void)hipEventRecord(ev_[0], stream_);
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
-                      d_rst_.as<uint32_t>(), S_);
+                      d_rst_.as<uint32_t>());
     stage("unstuff");
     if (timing_) (void)hipEventRecord(ev_[1], stream_);
     LpHuffArgs ha;
@@ -265,7 +268,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.cur_exit = d_exit_.as<LpSubState>(); ha.cur_total = d_tot_.as<LpSubSum>();
     ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSubSum>();
     ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>(); ha.dc16 = d_dc_.as<int16_t>();
-    ha.S = S_; ha.sched = sched_;
+    ha.sched = sched_;
     lp_launch_huff_spec(stream_, ha);
     stage("huff_spec");
     if (timing_) (void)hipEventRecord(ev_[8], stream_);

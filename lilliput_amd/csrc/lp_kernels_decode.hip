@@ -121,7 +121,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __res
 
 // One workgroup per image: exclusive scan of the chunk counts (in place), totals -> state.
 __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__ imgs, uint2* __restrict__ chunk_cnt,
-                                                      LpJpegState* __restrict__ states, uint32_t* __restrict__ clean_arena, uint32_t S)
+                                                      LpJpegState* __restrict__ states, uint32_t* __restrict__ clean_arena)
 {
     __shared__ uint32_t s_a[256], s_b[256];
     const LpJpeg& img = imgs[blockIdx.x];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__
         st.n_rst = tb < img.rst_cap ? tb : img.rst_cap;
         if (tb > img.rst_cap) st.error |= 4u;
         uint64_t bits = (uint64_t)ta * 8;
-        st.nsub = (uint32_t)((bits + S - 1) / S);
+        st.nsub = (uint32_t)((bits + img.sub_bits - 1) / img.sub_bits);
     }
     // zero the tail words so that reads past the end of the stream are deterministic
     if (t < 16) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
                                                       const uint32_t* __restrict__ rst_bits, LpCkptPk* __restrict__ ckpts,
                                                       LpSubState* __restrict__ spec_exit, LpSubSum* __restrict__ spec_total,
                                                       LpSubState* __restrict__ cur_exit, LpSubSum* __restrict__ cur_total,
-                                                      LpSubState* __restrict__ entry_used, uint32_t S, LpCkSched cs, uint32_t tot_sub)
+                                                      LpSubState* __restrict__ entry_used, LpCkSched cs, uint32_t tot_sub)
 {
     typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
     const LpImgCtx ic = make_ctx(img, st);
     MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
     LpSubState entry;
+    const uint32_t S = img.sub_bits;
     entry.p = valid ? sub * S : 0;
     entry.bz = 0;
     uint32_t sub_end = valid ? entry.p + S : 0; // invalid lanes finish immediately but keep the wave-uniform calls company
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
                                                         const LpSubState* __restrict__ spec_exit, const LpSubSum* __restrict__ spec_total,
                                                         LpSubState* cur_exit, LpSubSum* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
-                                                        uint32_t* __restrict__ changed, uint32_t S, uint32_t K, uint32_t tot_sub)
+                                                        uint32_t* __restrict__ changed, uint32_t K, uint32_t tot_sub)
 {
     typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     uint32_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) cp[k << 6] = ckpts[(size_t)k * tot_sub + g].p;
     DevCkSrc ck{cp, ckpts + g, tot_sub};
+    const uint32_t S = img.sub_bits;
     uint32_t sub_end = sub * S + S;
     if (sub_end > ic.total_bits) sub_end = ic.total_bits;
     const LpSubState old_exit = load_state(cur_exit + g);
@@ -785,12 +787,12 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (plain C++ signatures; see lp_launch.h)
 void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
-                       LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst, uint32_t S)
+                       LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst)
 {
     if (!nimg || !max_chunks) return;
     dim3 g(max_chunks, nimg);
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
-    hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean, S);
+    hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean);
     hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst);
 }
 
@@ -799,7 +801,7 @@ void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a)
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_spec, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, a.ckpts, a.spec_exit, a.spec_total, a.cur_exit,
-                       a.cur_total, a.entry_used, a.S, a.sched, a.tot_sub);
+                       a.cur_total, a.entry_used, a.sched, a.tot_sub);
 }
 
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
@@ -807,7 +809,7 @@ void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_verify, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
-                       (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed, a.S,
+                       (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed,
                        a.sched.K, a.tot_sub);
 }
 

@@ -6,7 +6,7 @@
 
 // decode
 void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
-                       LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst, uint32_t S);
+                       LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst);
 // Everything the Huffman kernels share (device pointers; arrays indexed by LpJpeg::sub_off + subsequence).
 struct LpHuffArgs {
     const LpJpeg* imgs;
@@ -27,7 +27,6 @@ struct LpHuffArgs {
     int16_t* wide;              // wide slots: 64 x int16, only escaped positions are valid
     uint32_t* wide_id;          // block -> wide slot (valid for blocks holding an escape)
     int16_t* dc16;              // DC coefficient of every block
-    uint32_t S;
     LpCkSched sched;
 };
 void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);

@@ -60,6 +60,8 @@ struct LpJpeg {
     uint32_t plane_stride[LP_MAX_COMP];                 // = bw*8
     uint16_t qt[LP_MAX_COMP][64];                       // dequantisation table per component, natural order
     // ---- subsequence bookkeeping
+    uint32_t sub_bits;          // subsequence size S of this image in bits (multiple of 32): chosen so that the subsequence
+                                // count lands just below a multiple of 256 -- whole Huffman workgroups, no nearly-empty tail block
     uint32_t sub_off;           // index of this image's first subsequence in the per-subsequence arrays
     uint32_t sub_cap;           // capacity (from raw_len, an upper bound of the clean length)
     uint32_t rst_off;           // index of this image's first entry in the restart-position array
