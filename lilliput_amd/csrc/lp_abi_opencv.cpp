@@ -63,7 +63,7 @@ LpDevBlock::~LpDevBlock()
 
 std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes)
 {
-    size_t want = bucket(bytes + 64);
+    size_t want = bucket(bytes + 256); // kernels may read up to a few vector widths past the last pixel of a row
     auto blk = std::make_shared<LpDevBlock>();
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);

@@ -195,7 +195,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;
     max_chunks_ = max_sub_ = max_bw_ = max_rows_ = max_w_ = max_h_ = 0;
-    bool any_frame = false;
+    bool any_frame = false, any_generic = false, any_420 = false;
     for (size_t i = 0; i < h_imgs_.size(); i++) {
         LpJpeg& j = h_imgs_[i];
         j.chunk_off = tot_chunks_;
@@ -226,6 +226,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         max_sub_ = std::max(max_sub_, j.sub_cap);
         if (!want_frame || want_frame[i]) {
             any_frame = true;
+            const bool f420 = j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2;
+            any_420 = any_420 || f420;
+            any_generic = any_generic || !f420;
             max_w_ = std::max(max_w_, j.width);
             max_h_ = std::max(max_h_, j.height);
         }
@@ -316,7 +319,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     if (any_frame) {
         if (!check(hipMemcpyAsync(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D frames")) return LP_ERR_DEVICE;
-        lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
+        lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, any_generic, any_420, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
     }
     if (timing_) (void)hipEventRecord(ev_[4], stream_);
     h_states_.resize((size_t)n);
@@ -465,7 +468,7 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     std::vector<LpTap> taps;
     std::vector<uint32_t> ranges;
     std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> cache; // (ssize,dsize) -> (tap_off, range_off)
-    uint32_t modes = 0, mdw = 0, mdh = 0;
+    uint32_t modes = 0, mdw = 0, mdh = 0, area3_mask = 0;
     for (int i = 0; i < n; i++) {
         const LpResizeReq& r = reqs[i];
         LpResizeOp& op = ops[(size_t)i];
@@ -500,6 +503,18 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
                 if (ax) { op.ytab_off = it->second.first; op.yrange_off = it->second.second; }
                 else { op.xtab_off = it->second.first; op.xrange_off = it->second.second; }
             }
+            if (r.src.cn == 3) { // k_resize_area3<MAXT>: every column's taps must be consecutive source columns, at most MAXT of them
+                uint32_t mx = 0;
+                bool contiguous = true;
+                for (uint32_t dx = 0; dx < r.dst_w && contiguous; dx++) {
+                    const uint32_t t0 = ranges[op.xrange_off + dx], t1 = ranges[op.xrange_off + dx + 1];
+                    mx = std::max(mx, t1 - t0);
+                    for (uint32_t k = t0 + 1; k < t1; k++) contiguous = contiguous && taps[op.xtab_off + k].si == taps[op.xtab_off + k - 1].si + 1;
+                    contiguous = contiguous && t1 > t0;
+                }
+                op.fast = !contiguous ? 0u : mx <= 6 ? 6u : mx <= 10 ? 10u : mx <= 18 ? 18u : mx <= 34 ? 34u : mx <= 66 ? 66u : 0u;
+                if (op.fast) area3_mask |= op.fast == 6 ? 1u : op.fast == 10 ? 2u : op.fast == 18 ? 4u : op.fast == 34 ? 8u : 16u;
+            }
         } else if (op.mode == 3) {
             // resizeGeneric_ tables for INTER_AREA with an up-scaling axis (area_mode coefficients, 11-bit fixed point)
             double inv_x = (double)r.dst_w / r.crop_w, inv_y = (double)r.dst_h / r.crop_h, sc_x = 1. / inv_x, sc_y = 1. / inv_y;
@@ -528,7 +543,7 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
                 ranges.push_back((uint32_t)(int32_t)(short)cv_round_f(fy * 2048));
             }
         }
-        modes |= 1u << op.mode;
+        if (!(op.mode == 2 && op.fast)) modes |= 1u << op.mode;
         mdw = std::max(mdw, r.dst_w);
         mdh = std::max(mdh, r.dst_h);
     }
@@ -540,7 +555,7 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     if (!ranges.empty() && !check(hipMemcpyAsync(d_ranges_.p, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, stream_), "H2D ranges"))
         return LP_ERR_DEVICE;
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
-    lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
+    lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, area3_mask, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
     if (!check(hipStreamSynchronize(stream_), "resize sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "resize kernels")) return LP_ERR_DEVICE;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= W || y >= H || f.off == 0) return; // off == 0: this image takes the fused path
+    if (img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2) return; // k_ycc_to_frame_420
     const uint8_t* PY = plane_arena + img.plane_off[0];
     uint8_t* out = frame_arena + f.off + (size_t)y * f.stride;
     if (img.ncomp == 1) {
@@ -99,6 +100,85 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
             out[(size_t)(x0 + i) * 3 + 0] = (uint8_t)px[3 * i];
             out[(size_t)(x0 + i) * 3 + 1] = (uint8_t)px[3 * i + 1];
             out[(size_t)(x0 + i) * 3 + 2] = (uint8_t)px[3 * i + 2];
+        }
+    }
+}
+
+// planes -> interleaved BGR frame, YCbCr 4:2:0 fast path (what opencv_decoder_read_data hands back for almost every JPEG).
+// Thread = 8 luma pixels x 2 rows (one chroma row of 4 samples + its two horizontal neighbours); a wave covers 512 x 2
+// pixels, so its luma loads are one contiguous 512-byte run per row and its chroma loads 256 bytes per plane row. The
+// vertical half of h2v2_fancy_upsample is computed once per chroma column and shared by the two output pixels under it.
+__global__ __launch_bounds__(256) void k_ycc_to_frame_420(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ plane_arena,
+                                                          const LpFrame* __restrict__ dsts)
+{
+    const LpJpeg& img = imgs[blockIdx.z];
+    const LpFrame& f = dsts[blockIdx.z];
+    if (f.off == 0 || !(img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2)) return; // generic kernel's job
+    const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
+    const int32_t x0 = (int32_t)(blockIdx.x * 64 + (threadIdx.x & 63)) * 8, cy = (int32_t)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (x0 >= W || 2 * cy >= H) return;
+    const int32_t dw = (W + 1) >> 1, dh = (H + 1) >> 1, cx0 = x0 >> 1;
+    const uint32_t sy_ = img.plane_stride[0], sc_ = img.plane_stride[1];
+    const uint8_t* PY = plane_arena + img.plane_off[0] + (size_t)(2 * cy) * sy_ + x0;
+    const uint8_t* PB = plane_arena + img.plane_off[1] + cx0;
+    const uint8_t* PR = plane_arena + img.plane_off[2] + cx0;
+    const bool has_l = cx0 > 0, has_r = cx0 + 4 <= dw - 1;
+    // three chroma rows (above / this / below, replicated at the image edges), 6 samples each: left neighbour, 4, right neighbour
+    int32_t cb[3][6], cr[3][6];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        int32_t r = cy - 1 + rr;
+        r = r < 0 ? 0 : r > dh - 1 ? dh - 1 : r;
+        const uint8_t* b = PB + (size_t)r * sc_;
+        const uint8_t* c = PR + (size_t)r * sc_;
+        const uint32_t wb = *reinterpret_cast<const uint32_t*>(b), wc = *reinterpret_cast<const uint32_t*>(c); // planes are MCU padded: in bounds
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cb[rr][i + 1] = (int32_t)((wb >> (8 * i)) & 255u); cr[rr][i + 1] = (int32_t)((wc >> (8 * i)) & 255u); }
+        // the last valid chroma column replicates (jdsample.c works on downsampled_width, not on the padded plane)
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+            if (cx0 + i > dw - 1) { cb[rr][i + 1] = cb[rr][i]; cr[rr][i + 1] = cr[rr][i]; }
+        cb[rr][0] = has_l ? (int32_t)b[-1] : cb[rr][1];
+        cr[rr][0] = has_l ? (int32_t)c[-1] : cr[rr][1];
+        cb[rr][5] = has_r ? (int32_t)b[4] : cb[rr][4];
+        cr[rr][5] = has_r ? (int32_t)c[4] : cr[rr][4];
+    }
+    const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
+    const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
+    uint8_t* out = reinterpret_cast<uint8_t*>((uintptr_t)f.off) + (size_t)(2 * cy) * f.stride + (size_t)x0 * 3;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        if (2 * cy + rr >= H) break;
+        const uint2 yv = *reinterpret_cast<const uint2*>(PY + (size_t)rr * sy_);
+        int32_t vb[6], vr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { vb[i] = 3 * cb[1][i] + cb[rr ? 2 : 0][i]; vr[i] = 3 * cr[1][i] + cr[rr ? 2 : 0][i]; }
+        uint32_t px[24];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int hx = 0; hx < 2; hx++) {
+                const int32_t b_ = (3 * vb[i + 1] + vb[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
+                const int32_t r_ = (3 * vr[i + 1] + vr[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
+                const int p = 2 * i + hx;
+                const int32_t yy = (int32_t)(((p < 4 ? yv.x : yv.y) >> (8 * (p & 3))) & 255u);
+                px[3 * p + 2] = clamp8(yy + ((FIX16(1.40200) * r_ + KR) >> 16));
+                px[3 * p + 0] = clamp8(yy + ((FIX16(1.77200) * b_ + KB) >> 16));
+                px[3 * p + 1] = clamp8(yy + ((-FIX16(0.34414) * b_ - FIX16(0.71414) * r_ + KG) >> 16));
+            }
+        }
+        uint8_t* o = out + (size_t)rr * f.stride;
+        if (x0 + 8 <= W && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+            uint32_t w[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) w[q] = px[4 * q] | (px[4 * q + 1] << 8) | (px[4 * q + 2] << 16) | (px[4 * q + 3] << 24);
+            reinterpret_cast<uint2*>(o)[0] = make_uint2(w[0], w[1]);
+            reinterpret_cast<uint2*>(o)[1] = make_uint2(w[2], w[3]);
+            reinterpret_cast<uint2*>(o)[2] = make_uint2(w[4], w[5]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                if (x0 + p < W) { o[3 * p] = (uint8_t)px[3 * p]; o[3 * p + 1] = (uint8_t)px[3 * p + 1]; o[3 * p + 2] = (uint8_t)px[3 * p + 2]; }
         }
     }
 }
@@ -371,7 +451,7 @@ __global__ __launch_bounds__(256) void k_resize_area(const LpResizeOp* __restric
                                                      uint8_t* __restrict__ dst_arena)
 {
     const LpResizeOp& op = ops[blockIdx.z];
-    if (op.mode != 2) return;
+    if (op.mode != 2 || op.fast) return;
     const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= op.dst.w || dy >= op.dst.h) return;
     const uint32_t cn = op.src.cn;
@@ -393,6 +473,61 @@ __global__ __launch_bounds__(256) void k_resize_area(const LpResizeOp* __restric
     }
     uint8_t* D = dst_arena + op.dst.off + (size_t)dy * op.dst.stride + (size_t)dx * cn;
     for (uint32_t c = 0; c < cn; c++) D[c] = (uint8_t)sat_round_u8(sum[c]);
+}
+
+// INTER_AREA, fractional scale, 3-channel fast path. Same arithmetic and tap order as k_resize_area (ResizeArea_Invoker), but a
+// source row of the box arrives as aligned 16-byte loads (fixed up with v_alignbit for the byte phase of the box start)
+// instead of one byte load per channel and tap. MAXT = most taps per axis (floor(scale) + 2); taps beyond a pixel's count
+// carry weight 0 and add exactly 0. Requires the x taps of every destination column to address consecutive source
+// columns (computeResizeAreaTab always does; the host checks).
+template <int MAXT>
+__global__ __launch_bounds__(256) void k_resize_area3(const LpResizeOp* __restrict__ ops, const LpTap* __restrict__ taps,
+                                                      const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ src_arena,
+                                                      uint8_t* __restrict__ dst_arena)
+{
+    constexpr int NB = MAXT * 3;            // bytes of a box row
+    constexpr int NW = (NB + 3 + 3) / 4;    // aligned dwords that cover them at any byte phase
+    constexpr int NQ = (NW + 1 + 3) / 4;    // 16-byte loads (+1 dword for the alignbit of the last one)
+    const LpResizeOp& op = ops[blockIdx.z];
+    if (op.mode != 2 || op.fast != (uint32_t)MAXT) return;
+    const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= op.dst.w || dy >= op.dst.h) return;
+    const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
+    const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
+    const LpTap* xt = taps + op.xtab_off + x0;
+    const LpTap* yt = taps + op.ytab_off;
+    const uint32_t nx = x1 - x0;
+    float al[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) al[k] = (uint32_t)k < nx ? xt[k].alpha : 0.f;
+    const uint8_t* S0 = src_arena + op.src.off + (size_t)xt[0].si * 3;
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (uint32_t j = y0; j < y1; j++) {
+        const float beta = yt[j].alpha;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(S0 + (size_t)yt[j].si * op.src.stride);
+        const uint4* q = reinterpret_cast<const uint4*>(addr & ~(uintptr_t)3); // 4-byte aligned is all a dwordx4 load needs
+        const uint32_t sh = (uint32_t)(addr & 3) * 8;
+        uint32_t w[NQ * 4];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+        uint32_t a[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) a[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+        float buf[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < MAXT; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int b = 3 * k + c;
+                const float v = (float)((a[b >> 2] >> (8 * (b & 3))) & 255u);
+                buf[c] = __fadd_rn(buf[c], __fmul_rn(v, al[k]));
+            }
+#pragma unroll
+        for (int c = 0; c < 3; c++) sum[c] = __fadd_rn(sum[c], __fmul_rn(beta, buf[c]));
+    }
+    uint8_t* D = dst_arena + op.dst.off + (size_t)dy * op.dst.stride + (size_t)dx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) D[c] = (uint8_t)sat_round_u8(sum[c]);
 }
 
 // INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point
@@ -469,12 +604,14 @@ __global__ __launch_bounds__(256) void k_composite(LpCompositeOp op, const uint8
 }
 
 // ------------------------------------------------------------------------------------------------
-void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_planes,
-                            const LpFrame* d_dsts, uint8_t* d_frames)
+void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, bool any_generic, bool any_420,
+                            const uint8_t* d_planes, const LpFrame* d_dsts, uint8_t* d_frames)
 {
     if (!nimg || !max_w || !max_h) return;
     dim3 g((max_w + 255) / 256, (max_h + 3) / 4, nimg);
-    hipLaunchKernelGGL(k_ycc_to_frame, g, dim3(64, 4), 0, s, d_imgs, d_planes, d_dsts, d_frames);
+    if (any_generic) hipLaunchKernelGGL(k_ycc_to_frame, g, dim3(64, 4), 0, s, d_imgs, d_planes, d_dsts, d_frames);
+    dim3 g2((max_w + 511) / 512, ((max_h + 1) / 2 + 3) / 4, nimg); // thread = 8 x 2 pixels
+    if (any_420) hipLaunchKernelGGL(k_ycc_to_frame_420, g2, dim3(256), 0, s, d_imgs, d_planes, d_dsts);
 }
 
 void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFusedOp* d_ops, uint32_t nops, uint32_t max_px, bool general,
@@ -496,7 +633,7 @@ void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uin
     hipLaunchKernelGGL(k_orient, g, dim3(64, 4), 0, s, d_ops, d_src, d_dst);
 }
 
-void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uint32_t modes_present, uint32_t max_dw, uint32_t max_dh,
+void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uint32_t modes_present, uint32_t area3_mask, uint32_t max_dw, uint32_t max_dh,
                       const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_src, uint8_t* d_dst)
 {
     if (!nimg || !max_dw || !max_dh) return;
@@ -510,6 +647,11 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
         hipLaunchKernelGGL(k_resize_area_fast, gf, dim3(256), 0, s, d_ops, d_src, d_dst);
     }
     if (modes_present & 4u) hipLaunchKernelGGL(k_resize_area, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (area3_mask & 1u) hipLaunchKernelGGL(k_resize_area3<6>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (area3_mask & 2u) hipLaunchKernelGGL(k_resize_area3<10>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (area3_mask & 4u) hipLaunchKernelGGL(k_resize_area3<18>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (area3_mask & 8u) hipLaunchKernelGGL(k_resize_area3<34>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
+    if (area3_mask & 16u) hipLaunchKernelGGL(k_resize_area3<66>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
     if (modes_present & 8u)
         hipLaunchKernelGGL(k_resize_linear, g2, dim3(64, 4), 0, s, d_ops, reinterpret_cast<const int32_t*>(d_ranges), d_src, d_dst);
 }

@@ -134,7 +134,7 @@ struct LpResizeOp {
     uint32_t xtab_off, ytab_off;     // into the tap arena (mode 2)
     uint32_t xrange_off, yrange_off; // into the range arena: mode 2 -> [dw+1]/[dh+1] tap ranges; mode 3 -> int32 triples
     uint32_t xmax;              // mode 3: first dx that only has one source column
-    uint32_t pad;
+    uint32_t fast;              // mode 2: 0 = generic kernel, else MAXT of k_resize_area3<MAXT> (3-channel, contiguous taps)
 };
 
 // Fused S3+S4+S5+S6+S7 for integer scales (resizeAreaFast_): destination pixel (dx, dy) is the mean of the
