@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 
+#include "lp_huff_core.h"
 #include "lp_launch.h"
 
 void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
@@ -183,14 +184,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
     S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
-    {   // checkpoint schedule of the speculative pass (iterations of the decode loop, see LpCkSched)
-        const uint32_t cbits = C_cfg_ ? C_cfg_ : 256;
-        sched_.K = std::min<uint32_t>(LP_MAX_CKPT, std::max<uint32_t>(1, S_ / cbits));
-        sched_.td = std::max<uint32_t>(2, cbits / 8);
-        sched_.nd = std::max<uint32_t>(1, sched_.K / 2);
-        const uint32_t span = S_ / 4; // a lane runs about S/6.5 iterations on photographic content
-        sched_.ts = sched_.K > sched_.nd && span > sched_.nd * sched_.td ? std::max(sched_.td, (span - sched_.nd * sched_.td) / (sched_.K - sched_.nd)) : sched_.td;
-    }
+    sched_ = lp_make_sched(S_, C_cfg_ ? C_cfg_ : 256); // checkpoint schedule of the speculative pass (see LpCkSched)
     K_ = sched_.K;
     size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;

@@ -244,7 +244,25 @@ LP_HD void lp_ckpt_unpack(const LpCkptPk& k, LpSubState& st, LpSubSum& s)
     s.nreset = k.nreset;
 }
 
-LP_HD uint32_t lp_ck_iter(const LpCkSched& cs, uint32_t k) { return k < cs.nd ? (k + 1) * cs.td : cs.nd * cs.td + (k + 1 - cs.nd) * cs.ts; }
+LP_HD uint32_t lp_ck_iter(const LpCkSched& cs, uint32_t k) { return cs.it[k]; }
+
+// Schedule for subsequences of S bits; cbits tunes the first spacing (cbits / 32 iterations, 8 for the default 256).
+inline LpCkSched lp_make_sched(uint32_t S, uint32_t cbits)
+{
+    LpCkSched cs;
+    const uint32_t base = cbits / 32 > 2 ? cbits / 32 : 2, span = S / 4 > base ? S / 4 : base; // a lane runs about S/6.5 iterations
+    uint32_t v = 0;
+    cs.K = 0;
+    for (uint32_t k = 0; k < LP_MAX_CKPT; k++) {
+        const uint32_t step = k < 4 || v / 2 < base ? base : v / 2;
+        v += step;
+        cs.it[k] = v;
+        cs.K = k + 1;
+        if (v >= span) break;
+    }
+    for (uint32_t k = cs.K; k < LP_MAX_CKPT; k++) cs.it[k] = 0xffffffffu;
+    return cs;
+}
 
 // SPEC pass for one subsequence: decode [entry.p, sub_end) from the guessed state.
 // Ck must provide   void record(uint32_t k, const LpCkptPk&)   -- called by ALL lanes of the wave at the same iteration.

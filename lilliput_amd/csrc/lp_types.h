@@ -105,10 +105,10 @@ struct LpCkptPk {
     uint32_t nreset;
 };
 
-// Checkpoint schedule: checkpoint k is taken before iteration it(k) of the lane's loop,
-//   it(k) = (k + 1) * td                    for k <  nd   (dense: the verify pass usually re-synchronises early)
-//         = nd * td + (k + 1 - nd) * ts     for k >= nd
-struct LpCkSched { uint32_t K, nd, td, ts; };
+// Checkpoint schedule: checkpoint k is taken before iteration it[k] of the lane's decode loop. The spacing grows
+// geometrically (8, 16, 24, 32, 48, 72, ... for large images): a verifying lane re-synchronises within a few hundred bits
+// in the common case and can stop at the very next checkpoint, while 16 records still cover a whole subsequence.
+struct LpCkSched { uint32_t K; uint32_t it[LP_MAX_CKPT]; };
 
 // ---------------------------------------------------------------------------------------------
 // Pixel frames and per-image operation descriptors (orientation, crop+resize, compositing, encode).

@@ -92,13 +92,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     LpImgCtx ic;
     ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
     // the engine's schedule (lp_engine.cpp run_decode)
-    LpCkSched cs;
-    const uint32_t cbits = C ? C : 256;
-    cs.K = S / cbits < 1 ? 1 : (S / cbits > LP_MAX_CKPT ? LP_MAX_CKPT : S / cbits);
-    cs.td = cbits / 8 < 2 ? 2 : cbits / 8;
-    cs.nd = cs.K / 2 < 1 ? 1 : cs.K / 2;
-    const uint32_t span = S / 4;
-    cs.ts = cs.K > cs.nd && span > cs.nd * cs.td ? ((span - cs.nd * cs.td) / (cs.K - cs.nd) > cs.td ? (span - cs.nd * cs.td) / (cs.K - cs.nd) : cs.td) : cs.td;
+    const LpCkSched cs = lp_make_sched(S, C ? C : 256); // the engine's schedule (lp_engine.cpp run_decode)
     const uint32_t K = cs.K;
     uint32_t nsub = (total_bits + S - 1) / S;
     *nsub_out = (int)nsub;

@@ -111,6 +111,48 @@ def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
     assert e.value.code == 2
 
 
+def test_corrupt_streams_never_hang_and_are_deterministic(batch):
+    """Robustness: random byte damage / truncation inside the entropy-coded segment. Every item must come back with a
+    lilliput status (decode succeeded on garbage, ErrDecodingFailed, ErrInvalidImage or unsupported) -- no hang, no device
+    fault -- and the same damaged input must give the same answer twice (no dependence on stale device memory)."""
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rgb = synth.synth_rgb(31, 512)[:192, :256]
+    rng = np.random.default_rng(32)
+    bases = []
+    for kw in ({"subsampling": 2}, {"subsampling": 0}, {"subsampling": 2, "restart_marker_rows": 1}, {"subsampling": 1, "optimize": True}):
+        b = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(rgb)).save(b, "JPEG", quality=88, **kw)
+        bases.append(b.getvalue())
+    items = []
+    for base in bases:
+        sos = base.rfind(b"\xff\xda")
+        for _ in range(24):
+            d = bytearray(base)
+            kind = rng.integers(0, 3)
+            if kind == 0:      # flip a few bytes
+                for p in rng.integers(sos + 14, len(d) - 2, rng.integers(1, 6)):
+                    d[p] = int(rng.integers(0, 256))
+            elif kind == 1:    # cut the stream short (keep a plausible tail)
+                d = d[: int(rng.integers(sos + 20, len(d) - 2))] + b"\xff\xd9"
+            else:              # overwrite a run with one value (long zero / one runs, fake markers)
+                p = int(rng.integers(sos + 14, len(d) - 40))
+                d[p : p + 32] = bytes([int(rng.choice([0, 0xFF, 0xD0, 0x7F]))]) * 32
+            items.append(bytes(d))
+    r1 = batch.transform(items, 64, 64, quality=80)
+    r2 = batch.transform(items, 64, 64, quality=80)
+    assert len(r1) == len(items)
+    for a, b2 in zip(r1, r2):
+        assert a.status in (0, 1, 2, 4)
+        assert a.status == b2.status and a.data == b2.data
+    assert any(a.status == 0 for a in r1) and any(a.status != 0 for a in r1)
+    # and the engine is still healthy afterwards
+    ok = batch.transform([bases[0]], 64, 64, quality=80)[0]
+    assert ok.status == 0 and len(ok.data) > 300
+
+
 # ------------------------------------------------------------------------------------------ Part A: opencv_* ABI
 class Mat:
     """A Go-style Framebuffer: host buffer owned by the caller, Mat header over it."""
