@@ -682,14 +682,12 @@ __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
 // workspace, row pass back out of it, clamp, 8-byte pixel-row store. (The workgroup barrier between them sits in the
 // caller, outside of any wave-divergent branch.)
 template <bool MUL24>
-__device__ __forceinline__ void idct_cols(const int32_t cv[8], const uint16_t* s_qt, int32_t* s_w, uint32_t j, uint32_t r)
+__device__ __forceinline__ void idct_cols(const int32_t cv[8], const int32_t qv[8], int32_t* s_w, uint32_t j, uint32_t r)
 {
-    const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
     int32_t d[8], o[8];
-    d[0] = cv[0] * (int32_t)(q.x & 0xffffu); d[1] = idct_mul<MUL24>(cv[1], (int32_t)(q.x >> 16));
-    d[2] = idct_mul<MUL24>(cv[2], (int32_t)(q.y & 0xffffu)); d[3] = idct_mul<MUL24>(cv[3], (int32_t)(q.y >> 16));
-    d[4] = idct_mul<MUL24>(cv[4], (int32_t)(q.z & 0xffffu)); d[5] = idct_mul<MUL24>(cv[5], (int32_t)(q.z >> 16));
-    d[6] = idct_mul<MUL24>(cv[6], (int32_t)(q.w & 0xffffu)); d[7] = idct_mul<MUL24>(cv[7], (int32_t)(q.w >> 16));
+    d[0] = cv[0] * qv[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) d[k] = idct_mul<MUL24>(cv[k], qv[k]);
     idct_1d<MUL24>(d, o);
 #pragma unroll
     for (int k = 0; k < 8; k++) s_w[j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
@@ -743,9 +741,12 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     const uint32_t hsh = img.hs[c] - 1u, vsh = img.vs[c] - 1u;
     __syncthreads();
     bool q_small;
+    int32_t qv[8]; // this lane's column of the quantisation table, unpacked once for all tiles
     {
         const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
-        q_small = ((q.x | q.y | q.z | q.w) & 0xff00ff00u) == 0; // this lane's column of the table; the wave vote below covers all eight
+        q_small = ((q.x | q.y | q.z | q.w) & 0xff00ff00u) == 0; // the wave vote below covers all eight columns
+        qv[0] = (int32_t)(q.x & 0xffffu); qv[1] = (int32_t)(q.x >> 16); qv[2] = (int32_t)(q.y & 0xffffu); qv[3] = (int32_t)(q.y >> 16);
+        qv[4] = (int32_t)(q.z & 0xffffu); qv[5] = (int32_t)(q.z >> 16); qv[6] = (int32_t)(q.w & 0xffffu); qv[7] = (int32_t)(q.w >> 16);
     }
     for (uint32_t t = 0; t < IDCT_TPW; t++) {
         const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32;
@@ -760,8 +761,11 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
             const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
 #pragma unroll
             for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-#pragma unroll
-            for (int i = 0; i < 8; i++) any_esc = any_esc || cv[i] == -128;
+            {   // a byte equals 0x80 <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
+                const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
+                const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
+                any_esc = (zx | zy) != 0;
+            }
             if (any_esc) {
                 const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
 #pragma unroll
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         const bool fast = !any_esc && q_small;
         const bool wave_fast = __all(fast);
         uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
-        if (wave_fast) idct_cols<true>(cv, s_qt, s_w[wv], j, r); else idct_cols<false>(cv, s_qt, s_w[wv], j, r);
+        if (wave_fast) idct_cols<true>(cv, qv, s_w[wv], j, r); else idct_cols<false>(cv, qv, s_w[wv], j, r);
         __syncthreads();
         if (wave_fast) idct_rows<true>(s_w[wv], j, r, blk_ok, dst); else idct_rows<false>(s_w[wv], j, r, blk_ok, dst);
         __syncthreads();
