@@ -203,7 +203,7 @@ def main():
                                  "time it shares the GPU); the entropy decoder is VALU-issue bound, not HBM bound (DESIGN.md 4.1)",
                          "per_kernel": breakdown},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N=1 only (it would steal the other ranks' host cores)
             try:
                 out["cpu_baseline"] = cpu_baseline(distinct[: min(4, len(distinct))])
             except Exception as e:  # the checker is optional for the measurement itself
