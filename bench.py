@@ -100,7 +100,9 @@ def main():
 
     from lilliput_amd.dist import Ranks
 
-    ranks = Ranks()   # one process per GPU (torchrun); backend "nccl" = RCCL; single process when WORLD_SIZE is unset
+    # one process per GPU (torchrun); backend "nccl" = RCCL; single process when WORLD_SIZE is unset.
+    # LILLIPUT_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check on a 1-GPU box).
+    ranks = Ranks(backend=os.environ.get("LILLIPUT_BENCH_BACKEND"))
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     barrier = ranks.barrier
 
@@ -115,7 +117,7 @@ def main():
     sources = [arrays[i % len(arrays)] for i in range(args.batch)]
     c_in = sum(len(distinct[i % len(distinct)]) for i in range(args.batch)) / args.batch
 
-    b = la.Batch(local_rank)
+    b = la.Batch(local_rank % max(1, la.lib().lilliput_hip_device_count()))
     if args.sub_bits:
         b.set_subsequence(args.sub_bits, args.ckpt_bits)
     t = time.time()
