@@ -169,7 +169,9 @@ struct LpLane {
     {
         Sym r;
         r.is_dc = (z == 0);
-        const uint32_t tbl = r.is_dc ? ((rot >> 2) & 1u) : 2u + ((rot >> 3) & 1u);
+        // DC table id = bit 2 of the block's nibble, AC table id = bit 3 (+2); written as arithmetic so that it compiles to
+        // selects, not to an exec-mask branch pair
+        const uint32_t tbl = ((rot >> (r.is_dc ? 2u : 3u)) & 1u) + (r.is_dc ? 0u : 2u);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
         if ((e >> 8) == 0) e = long_code(tbl, pk >> 16);
         const uint32_t len = e >> 8;
@@ -372,9 +374,9 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
-//   void put_dc(int32_t v);                        the block's DC DIFFERENCE (made absolute later, see lp_dc_scan)
+//   void put_dc(int32_t v, bool on);               when `on`: the block's DC DIFFERENCE (made absolute later, see lp_dc_walk)
 //   void put(uint32_t natural_idx, int32_t v);     store one AC coefficient of the block being decoded
-//   void end_block(uint32_t blk);                  the block (decode-order index blk) is complete (queued for flushing)
+//   void end_block(uint32_t blk, bool on);         when `on`: the block (decode-order index blk) is complete (queued for flushing)
 //   bool stalled();                                no free slot: the lane must wait for the next flush
 //   void flush();                                  wave-uniform: write out every queued block
 // Returns the number of blocks written.
@@ -406,15 +408,13 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         if (act && !stop) {
             writing = writing || L.z == 0; // a lane that enters mid-block skips to the first block start
             const typename LpLane<M>::Sym s = L.template step<true>(pk);
-            if (writing) {
-                if (s.is_dc) sink.put_dc(s.val);
-                else if (s.has_val) sink.put((uint32_t)zigzag[s.k], s.val);
-                if (s.block_done) {
-                    sink.end_block(blk);
-                    written++;
-                    blk++;
-                }
-            }
+            // few, flat predicated regions: every exec-mask branch costs scalar instructions in a loop that is issue bound
+            sink.put_dc(s.val, writing && s.is_dc);
+            if (writing && !s.is_dc && s.has_val) sink.put((uint32_t)zigzag[s.k], s.val);
+            const bool bd = writing && s.block_done;
+            sink.end_block(blk, bd);
+            written += bd ? 1u : 0u;
+            blk += bd ? 1u : 0u;
         }
     } while (m.any(!done));
     sink.flush();

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
 // (element v * 8 + u holds the coefficient of row u, column v: the write kernel feeds put() a transposed zigzag table).
 struct DevSink {
     int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * 1024
-    int8_t* dst;            // queued destination (nullptr = slot free)
+    uint32_t qblk;          // queued block index (0xffffffff = slot free)
     int8_t* coef8;          // this image's coefficient blocks
     int16_t* wide;          // this image's wide slots (64 int16 each)
     uint32_t* wide_id;      // this image's block -> wide slot
@@ -460,7 +460,7 @@ struct DevSink {
     int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
                             // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
     int32_t dcv;            // DC difference of the current block
-    __device__ __forceinline__ void put_dc(int32_t v) { dcv = v; }
+    __device__ __forceinline__ void put_dc(int32_t v, bool on) { dcv = on ? v : dcv; }
     __device__ __forceinline__ void put(uint32_t nat, int32_t v)
     {
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
@@ -470,23 +470,23 @@ struct DevSink {
         }
         slot[((nat >> 4) << 10) | (nat & 15u)] = (int8_t)v;
     }
-    __device__ __forceinline__ void end_block(uint32_t blk)
+    __device__ __forceinline__ void end_block(uint32_t blk, bool on)
     {
-        dst = coef8 + (size_t)blk * 64;
-        if (wslot != 0xffffffffu) { wide_id[blk] = wslot; wslot = 0xffffffffu; }
+        qblk = on ? blk : qblk;
+        if (on && wslot != 0xffffffffu) { wide_id[blk] = wslot; wslot = 0xffffffffu; } // rare
     }
-    __device__ __forceinline__ bool stalled() const { return dst != nullptr; }
+    __device__ __forceinline__ bool stalled() const { return qblk != 0xffffffffu; }
     __device__ __forceinline__ void flush()
     {
-        if (dst) {
+        if (qblk != 0xffffffffu) {
             uint4* s = reinterpret_cast<uint4*>(slot);
-            uint4* o = reinterpret_cast<uint4*>(dst);
+            uint4* o = reinterpret_cast<uint4*>(coef8 + ((size_t)qblk << 6));
             const uint4 zero = make_uint4(0, 0, 0, 0);
             const uint4 r0 = s[0], r1 = s[64], r2 = s[128], r3 = s[192];
             o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
             s[0] = zero; s[64] = zero; s[128] = zero; s[192] = zero;
-            dc16[(dst - coef8) >> 6] = (int16_t)dcv;
-            dst = nullptr;
+            dc16[qblk] = (int16_t)dcv;
+            qblk = 0xffffffffu;
         }
     }
 };
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
     DevSink sink;
     sink.slot = s_slots + (threadIdx.x >> 6) * 4096 + (threadIdx.x & 63) * 16;
-    sink.dst = nullptr;
+    sink.qblk = 0xffffffffu;
     sink.coef8 = coef8_arena + img.coef_off;
     sink.wide = wide_arena + img.coef_off;
     sink.wide_id = wide_id_arena + img.coef_off / 64;

@@ -46,9 +46,9 @@ struct HostSink { // one slot, flushed at the wave-uniform flush points like the
     int16_t* coef;      // decode-order blocks
     int16_t* pending = nullptr;
     HostSink() { memset(blk, 0, sizeof(blk)); }
-    void put_dc(int32_t v) { blk[0] = (int16_t)v; }
+    void put_dc(int32_t v, bool on) { if (on) blk[0] = (int16_t)v; }
     void put(uint32_t nat, int32_t v) { blk[nat & 63] = (int16_t)v; }
-    void end_block(uint32_t b) { pending = coef + (size_t)b * 64; }
+    void end_block(uint32_t b, bool on) { if (on) pending = coef + (size_t)b * 64; }
     bool stalled() const { return pending != nullptr; }
     void flush() { if (pending) { memcpy(pending, blk, 128); memset(blk, 0, sizeof(blk)); pending = nullptr; } }
 };
