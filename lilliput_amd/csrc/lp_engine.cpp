@@ -739,7 +739,6 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         max_blocks = std::max(max_blocks, j.total_blocks);
         j.coef_off = coef_elems;
         coef_elems += (size_t)j.total_blocks * 64;
-        uint32_t rows = 0;
         uint8_t hb[1024];
         j.hdr_off = (uint32_t)hdrs.size();
         j.hdr_len = (uint32_t)lp_build_jpeg_header((int)r.src.w, (int)r.src.h, (int)j.ncomp, r.quality, hb, j.qt);
