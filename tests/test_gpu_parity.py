@@ -399,6 +399,18 @@ def test_config2_geometry_full_size_properties(batch, oracle):
     assert r[0].data == oracle.jpeg_encode(box, 85)
     # and the decoded frame itself equals the oracle's (one full-size decode on the CPU, ~seconds)
     assert np.array_equal(px, oracle.jpeg_decode(data))
+    # EXIF orientations at full size: the fused kernel folds ExifTransform into its addressing (5..8 walk source columns)
+    for o in (3, 6, 8):
+        ro = batch.transform([_with_exif_orientation(data, o)], 256, 256, normalize=True, quality=85)[0]
+        assert ro.status == 0
+        fo = oracle.orientation_transform(px, o)
+        so = fo.astype(np.int64).reshape(256, 16, 256, 16, 3).sum(axis=(1, 3))
+        assert ro.data == oracle.jpeg_encode(np.rint(so.astype(np.float32) * np.float32(1 / 256)).astype(np.uint8), 85), o
+    # a non-integer scale at full size goes through k_ycc_to_frame_420 + k_resize_area3: within +-1 LSB of the oracle's resize
+    rf = batch.transform([data], 250, 250, quality=85)[0]
+    exp, branch = oracle.resize_area(px, 250, 250)
+    assert rf.status == 0 and branch == 2
+    assert rf.data == oracle.jpeg_encode(exp, 85) or np.abs(oracle.jpeg_decode(rf.data).astype(int) - oracle.jpeg_decode(oracle.jpeg_encode(exp, 85)).astype(int)).max() <= 8
 
 
 def _with_exif_orientation(jpeg, o):
