@@ -571,11 +571,23 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
         const bool swapped = op.dxy != 0;
         const uint32_t U = swapped ? op.dst.h : op.dst.w, V = swapped ? op.dst.w : op.dst.h;
         const int32_t stepx = swapped ? op.dyx : op.dxx;  // source-x step between neighbouring boxes: +-rw
-        bool fast = j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && (op.rw == 8 || op.rw == 16 || op.rw == 32) && !(op.rh & 1) &&
-                    !(op.y0 & 1) && (op.x0 % (int32_t)op.rw) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3;
-        op.fast = fast ? op.rw / 2 : 0;
+        const bool rw_ok = op.rw == 8 || op.rw == 16 || op.rw == 32;
+        const bool aligned = rw_ok && (op.x0 % (int32_t)op.rw) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3;
+        const bool ycc = j.ncomp == 3 && j.colorspace == 2;
+        const uint32_t rwbit = op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
+        bool fast = false;
+        if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>
+            op.fast = op.rw / 2;
+            fast_mask |= rwbit;
+            fast = true;
+        } else if (ycc && aligned && j.vs[0] == 1 && (j.hs[0] == 1 || j.hs[0] == 2)) {         // k_resample_hv1<rw, hs>: 4:4:4 / 4:2:2
+            op.fast = 0x100u * (1u + j.hs[0]) + op.rw;
+            fast_mask |= rwbit << (j.hs[0] == 1 ? 4 : 8);
+            fast = true;
+        } else {
+            op.fast = 0;
+        }
         if (fast) {
-            fast_mask |= op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
             fast_grid = std::max(fast_grid, V * ((U + 255u) / 256u));
         } else {
             general = true;

@@ -392,6 +392,80 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
     }
 }
 
+// K_resample fast path for YCbCr 4:4:4 (HR = 1) and 4:2:2 (HR = 2, h2v1_fancy_upsample): same thread-per-thumbnail-pixel walk as
+// k_resample_420 but the chroma rows are the luma rows (no vertical filter). RW = box width in pixels. LpFusedOp::fast =
+// 0x100 * (1 + HR) + RW. Requirements: every box starts at a multiple of RW in x (aligned vector loads).
+template <int RW, int HR>
+__global__ __launch_bounds__(256) void k_resample_hv1(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+                                                      const uint8_t* __restrict__ plane_arena)
+{
+    constexpr int CW = RW / HR; // chroma samples per box row
+    const LpFusedOp& op = ops[blockIdx.y];
+    if (op.fast != (uint32_t)(0x100 * (1 + HR) + RW)) return;
+    const LpJpeg& img = imgs[op.img];
+    const bool swapped = op.dxy != 0;
+    const uint32_t U = swapped ? op.dst.h : op.dst.w, V = swapped ? op.dst.w : op.dst.h;
+    const uint32_t ublocks = (U + 255u) / 256u;
+    const uint32_t v = blockIdx.x / ublocks, u = (blockIdx.x - v * ublocks) * 256u + threadIdx.x;
+    if (v >= V || u >= U) return;
+    const int32_t dx = (int32_t)(swapped ? v : u), dy = (int32_t)(swapped ? u : v);
+    const int32_t fx0 = op.x0 + dx * op.dxx + dy * op.dyx, fy0 = op.y0 + dx * op.dxy + dy * op.dyy;
+    const uint32_t sy_ = img.plane_stride[0], sc_ = img.plane_stride[1];
+    const int32_t W = (int32_t)img.width, dw = (W + HR - 1) / HR, cx0 = fx0 / HR;
+    const uint8_t* PY = plane_arena + img.plane_off[0] + (size_t)fy0 * sy_ + fx0;
+    const uint8_t* PB = plane_arena + img.plane_off[1] + (size_t)fy0 * sc_ + cx0;
+    const uint8_t* PR = plane_arena + img.plane_off[2] + (size_t)fy0 * sc_ + cx0;
+    const bool has_l = cx0 > 0, has_r = cx0 + CW <= dw - 1;
+    const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
+    const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
+    int32_t sb = 0, sg = 0, sr = 0;
+    auto load_bytes = [](const uint8_t* p, int n, int32_t* out) { // n in {4, 8, 16, 32}, p aligned to n (<= 16)
+        uint32_t w[8];
+        if (n == 4) w[0] = *reinterpret_cast<const uint32_t*>(p);
+        else if (n == 8) { const uint2 t = *reinterpret_cast<const uint2*>(p); w[0] = t.x; w[1] = t.y; }
+        else
+            for (int q = 0; q < n / 16; q++) { const uint4 t = *reinterpret_cast<const uint4*>(p + 16 * q); w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+        for (int i = 0; i < n; i++) out[i] = (int32_t)((w[i >> 2] >> (8 * (i & 3))) & 255u);
+    };
+    for (uint32_t ry = 0; ry < op.rh; ry++) {
+        int32_t yy[RW], cb[CW + 2], cr[CW + 2];
+        load_bytes(PY + (size_t)ry * sy_, RW, yy);
+        load_bytes(PB + (size_t)ry * sc_, CW, cb + 1);
+        load_bytes(PR + (size_t)ry * sc_, CW, cr + 1);
+        if (HR == 2) {
+            cb[0] = has_l ? (int32_t)PB[(size_t)ry * sc_ - 1] : cb[1];
+            cr[0] = has_l ? (int32_t)PR[(size_t)ry * sc_ - 1] : cr[1];
+            cb[CW + 1] = has_r ? (int32_t)PB[(size_t)ry * sc_ + CW] : cb[CW];
+            cr[CW + 1] = has_r ? (int32_t)PR[(size_t)ry * sc_ + CW] : cr[CW];
+        }
+#pragma unroll
+        for (int x = 0; x < RW; x++) {
+            int32_t b_, r_;
+            if (HR == 1) { b_ = cb[x + 1]; r_ = cr[x + 1]; }
+            else {
+                // h2v1_fancy_upsample: even columns lean on the left neighbour (+1), odd ones on the right (+2); at an image edge the
+                // output is the sample itself, which is what the replicated neighbour gives: (3c + c + k) >> 2 == c
+                const int c = x >> 1, nb = (x & 1) ? c + 2 : c;
+                b_ = (3 * cb[c + 1] + cb[nb] + ((x & 1) ? 2 : 1)) >> 2;
+                r_ = (3 * cr[c + 1] + cr[nb] + ((x & 1) ? 2 : 1)) >> 2;
+            }
+            const int32_t r = yy[x] + ((FIX16(1.40200) * r_ + KR) >> 16);
+            const int32_t b = yy[x] + ((FIX16(1.77200) * b_ + KB) >> 16);
+            const int32_t g = yy[x] + ((-FIX16(0.34414) * b_ - FIX16(0.71414) * r_ + KG) >> 16);
+            sb += (int32_t)clamp8(b); sg += (int32_t)clamp8(g); sr += (int32_t)clamp8(r);
+        }
+    }
+    uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
+    const int32_t sums[3] = {sb, sg, sr};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint32_t r;
+        if (op.round_2x2) r = (uint32_t)(sums[c] + 2) >> 2;
+        else r = sat_round_u8(__fmul_rn((float)sums[c], op.inv_area));
+        D[c] = (uint8_t)r;
+    }
+}
+
 // dst(y, x) = src(f(y, x)); dst dims are (h, w) for orientations 5..8.
 __global__ __launch_bounds__(256) void k_orient(const LpOrientOp* __restrict__ ops, const uint8_t* __restrict__ src_arena,
                                                 uint8_t* __restrict__ dst_arena)
@@ -624,6 +698,12 @@ void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFused
     if (fast_mask & 1u) hipLaunchKernelGGL(k_resample_420<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 2u) hipLaunchKernelGGL(k_resample_420<8>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 4u) hipLaunchKernelGGL(k_resample_420<16>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x10u) hipLaunchKernelGGL((k_resample_hv1<8, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x20u) hipLaunchKernelGGL((k_resample_hv1<16, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x40u) hipLaunchKernelGGL((k_resample_hv1<32, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x100u) hipLaunchKernelGGL((k_resample_hv1<8, 2>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x200u) hipLaunchKernelGGL((k_resample_hv1<16, 2>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x400u) hipLaunchKernelGGL((k_resample_hv1<32, 2>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
 }
 
 void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_src, uint8_t* d_dst)

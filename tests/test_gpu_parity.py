@@ -431,7 +431,9 @@ def test_fused_resample_all_orientations_integer_scales(batch, oracle):
     cases = []
     # (256, 256, 16, 16): 16x16 boxes, (.., 32, 32): 8x8, (.., 8, 8): 32x32 -> k_resample_420; 288x256 crops at x0 = 16 (aligned),
     # 272x256 at x0 = 8 (not aligned to the 16-wide box: general kernel); 250x243 has odd chroma edges
+    # subsampling 0 / 1 with 8-, 16-, 32-pixel boxes: k_resample_hv1 (4:4:4 / 4:2:2)
     for (w, h, tw, th, ss) in ((256, 256, 16, 16, 2), (256, 256, 32, 32, 2), (256, 256, 8, 8, 2), (288, 256, 16, 16, 2), (272, 256, 16, 16, 2),
+                               (256, 256, 16, 16, 0), (256, 256, 32, 32, 1), (256, 256, 8, 8, 1), (288, 256, 16, 16, 0), (250, 243, 15, 15, 1), (256, 128, 16, 16, 1),
                                (256, 192, 12, 12, 2), (250, 243, 15, 15, 2), (96, 64, 32, 32, 2), (192, 128, 32, 32, 2), (96, 96, 32, 32, 2), (98, 64, 32, 32, 2), (128, 128, 8, 8, 2),
                                (96, 64, 32, 32, 0), (120, 90, 30, 30, 1), (64, 48, 16, 16, "gray"), (160, 100, 50, 50, 2), (90, 60, 30, 20, 2)):
         im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
