@@ -8,7 +8,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from lilliput_amd.dist import Ranks  # noqa: E402
+from lilliput_amd.dist import Ranks, WorkQueue  # noqa: E402
 
 
 def main():
@@ -25,8 +25,23 @@ def main():
 
     elapsed = r.timed(step, steps=3, warmup=1)
     total = r.reduce(len(mine), "sum")
+    # work-stealing queue: rank 1 is 4x slower per chunk, so rank 0 must end up processing chunks of rank 1's initial range
+    n_chunks = 16
+    q = WorkQueue(r, n_chunks)
+    epochs = [0]
+    real_sync = q.sync
+
+    def counted_sync():
+        epochs[0] += 1
+        real_sync()
+
+    q.sync = counted_sync
+    t0 = time.time()
+    done = q.run(lambda c: time.sleep(0.02 * (4 if r.rank == 1 else 1)), slice_s=0.1)
+    epochs = epochs[0]
+    queue_s = time.time() - t0
     with open(os.path.join(out_dir, "rank%d.json" % r.rank), "w") as f:
-        json.dump({"rank": r.rank, "world": r.world, "items": mine, "digests": digests, "elapsed": elapsed, "steps_run": len(calls), "total": total}, f)
+        json.dump({"rank": r.rank, "world": r.world, "items": mine, "digests": digests, "elapsed": elapsed, "steps_run": len(calls), "total": total, "queue_done": done, "queue_epochs": epochs, "queue_s": queue_s}, f)
     r.close()
 
 

@@ -384,6 +384,18 @@ def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
     assert [r.data for r in res2] == [r.data for r in res[:4]]
 
 
+def test_queue_driven_firehose_single_rank(batch, oracle, fixture_bytes):
+    """The work-queue front end (lilliput_amd.dist.transform_queue) on one rank: every image exactly once, same bytes as one batch."""
+    from lilliput_amd.dist import Ranks, transform_queue
+
+    names = sorted(fixture_bytes)
+    sources = [fixture_bytes[n] for n in names] * 2
+    got = transform_queue(Ranks(), batch, sources, 64, 64, chunk=3, quality=85)
+    ref = batch.transform(sources, 64, 64, quality=85)
+    assert sorted(got) == list(range(len(sources)))
+    assert all(got[i].status == ref[i].status and got[i].data == ref[i].data for i in range(len(sources)))
+
+
 def test_config2_geometry_full_size_properties(batch, oracle):
     """BASELINE configs[1] at full size: 4096x4096 4:2:0 q90 -> 256x256 q85 (scale 16: integer path, bit-exact)."""
     from lilliput_amd import synth

@@ -22,6 +22,13 @@ def test_two_ranks_shard_time_and_reduce(tmp_path):
     assert all(r["steps_run"] == 4 for r in res)               # 1 warm-up + exactly 3 timed steps
     assert res[0]["elapsed"] == res[1]["elapsed"]              # max over ranks, seen by both
     assert res[0]["elapsed"] >= 3 * 0.1 - 0.01                 # the slow rank (0.1 s per step) sets it
+    # work-stealing queue: every chunk exactly once, the fast rank took more than its initial half, both ranks ran the same epochs
+    d0, d1 = res[0]["queue_done"], res[1]["queue_done"]
+    assert sorted(d0 + d1) == list(range(16))
+    assert len(d0) > 8 > len(d1)
+    assert any(c >= 8 for c in d0)                             # chunks stolen from rank 1's initial range [8, 16)
+    assert res[0]["queue_epochs"] == res[1]["queue_epochs"]
+    assert res[0]["queue_s"] < 16 / 2 * 0.08                    # faster than the static split (8 chunks x 0.08 s on the slow rank)
 
 
 def test_single_rank_needs_no_process_group():
@@ -31,6 +38,10 @@ def test_single_rank_needs_no_process_group():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         os.environ.pop(k, None)
     r = Ranks()
+    from lilliput_amd.dist import WorkQueue
+
+    q = WorkQueue(r, 3)
+    assert q.run(lambda c: None) == [0, 1, 2]
     assert (r.rank, r.world, list(r.shard(5))) == (0, 1, [0, 1, 2, 3, 4])
     assert r.timed(lambda: None, steps=2, warmup=1) >= 0.0
     assert r.reduce(3.5, "sum") == 3.5
