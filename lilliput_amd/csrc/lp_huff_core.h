@@ -144,7 +144,7 @@ struct LpLane {
     {
         const uint32_t idx = top - m.base2(tbl);
         uint32_t e = idx < m.lut2_n(tbl) ? m.lut2(tbl, idx) : 0u;
-        if ((e >> 8) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix or a table with a very wide tail
+        if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix or a table with a very wide tail
             uint32_t len = 16, sym = 0;
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
                 const int32_t code = (int32_t)(top >> (16 - l));
@@ -154,7 +154,7 @@ struct LpLane {
                     break;
                 }
             }
-            e = (len << 8) | sym;
+            e = (len << 8) | sym | ((tbl >= 2 && (sym & 15u) == 0 && (sym >> 4) != 15) ? 0x8000u : 0u);
         }
         return e;
     }
@@ -173,8 +173,8 @@ struct LpLane {
         // selects, not to an exec-mask branch pair
         const uint32_t tbl = ((rot >> (r.is_dc ? 2u : 3u)) & 1u) + (r.is_dc ? 0u : 2u);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
-        if ((e >> 8) == 0) e = long_code(tbl, pk >> 16);
-        const uint32_t len = e >> 8;
+        if ((e & 0x1f00u) == 0) e = long_code(tbl, pk >> 16);
+        const uint32_t len = (e >> 8) & 31u;
         const uint32_t s = e & 15u;
         const uint32_t run = (e >> 4) & 15u;      // DC symbols are categories 0..15 (validated by the parser): run == 0
         r.val = 0;
@@ -188,7 +188,7 @@ struct LpLane {
         p += len + s;
         // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL); a coefficient whose index overruns 63 on
         // a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table carries the same guard entries)
-        const bool eob = !r.is_dc && s == 0 && run != 15;
+        const bool eob = (e & 0x8000u) != 0; // precomputed per table entry: an AC symbol of size 0 other than ZRL
         r.k = z + run;                            // DC: z == run == 0; at most 63 + 15
         r.has_val = r.is_dc || s != 0;
         const uint32_t zn = eob ? 64u : r.k + 1u; // ZRL (run 15, size 0) skips 16 coefficients: k + 1 == z + 16

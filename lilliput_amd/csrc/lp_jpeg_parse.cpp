@@ -41,6 +41,13 @@ static int exif_orientation(const uint8_t* p, size_t n)
     return 0;
 }
 
+// LUT entry for a code of length l decoding to symbol v (see LpHuffSet)
+static inline uint16_t lut_entry(int slot, int l, unsigned v)
+{
+    const bool ends_block = slot >= 2 && (v & 15u) == 0 && (v >> 4) != 15; // AC symbol of size 0 that is not ZRL: EOB (jdhuff.c decode_mcu)
+    return (uint16_t)((ends_block ? 0x8000u : 0u) | ((unsigned)l << 8) | v);
+}
+
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals)
 {
     memset(hs->lut[slot], 0, sizeof(hs->lut[slot]));
@@ -52,7 +59,7 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
         for (int i = 0; i < bits[l]; i++, k++, code++) {
             if (l <= LP_LUT_BITS) {
                 int first = code << (LP_LUT_BITS - l), n = 1 << (LP_LUT_BITS - l);
-                for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = (uint16_t)((l << 8) | vals[k]);
+                for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = lut_entry(slot, l, vals[k]);
             } else {
                 uint32_t left = (uint32_t)code << (16 - l);
                 if (left < base2) base2 = left;
@@ -76,7 +83,7 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
         for (int i = 0; i < bits[l]; i++, k++, code++) {
             if (l <= LP_LUT_BITS) continue;
             uint32_t first = ((uint32_t)code << (16 - l)) - base2, n = 1u << (16 - l);
-            for (uint32_t j = 0; j < n && first + j < n2; j++) hs->lut2[used + first + j] = (uint16_t)((l << 8) | vals[k]);
+            for (uint32_t j = 0; j < n && first + j < n2; j++) hs->lut2[used + first + j] = lut_entry(slot, l, vals[k]);
         }
         code <<= 1;
     }

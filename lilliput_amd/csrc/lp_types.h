@@ -15,7 +15,8 @@
 #define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
-// lut[t][i]  : (len << 8) | symbol for codes of length <= LP_LUT_BITS, indexed by the next LP_LUT_BITS bits; 0 = longer code.
+// lut[t][i]  : (ends_block << 15) | (len << 8) | symbol for codes of length <= LP_LUT_BITS, indexed by the next LP_LUT_BITS bits;
+//              len == 0 = longer code. ends_block marks the AC symbols that finish a block (size 0, run != 15).
 // lut2[lut2_off[t] + i], i < lut2_n[t] : same encoding for the long codes, indexed by (next 16 bits) - base2[t];
 //              0 or i >= lut2_n[t] = not covered -> canonical search.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
