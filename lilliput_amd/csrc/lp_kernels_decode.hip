@@ -268,7 +268,7 @@ struct DevMem {
 typedef DevMem<16, 8, 2> CountMem;  // SPEC / VERIFY
 // WRITE: measured both ways -- DevMem<8, 4, 1> fits four workgroups per CU, DevMem<16, 8, 2> three with half the top-ups;
 // three is 5 % faster alone and leaves LDS for the other parts' kernels when parts of a batch overlap.
-typedef DevMem<16, 8, 2> WriteMem;   // WRITE: 9 KiB of ring per workgroup so that three workgroups fit a CU next to the coefficient slots
+typedef DevMem<16, 8, 2> WriteMem;
 
 __device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
 {
