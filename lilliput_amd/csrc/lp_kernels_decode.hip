@@ -356,10 +356,15 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
 // Checkpoint source of the verify pass: the K positions of the lane's subsequence are staged in LDS (word-interleaved
 // like the ring); a whole record is fetched from HBM only when a position matches.
 struct DevCkSrc {
-    const uint32_t* pos_lds; // + lane
+    const uint16_t* pos_lds; // + lane; positions relative to the start of the subsequence, 0xffff = not recorded
     const LpCkptPk* base;    // + g
     size_t stride;
-    __device__ __forceinline__ uint32_t pos(uint32_t k) const { return pos_lds[k << 6]; }
+    uint32_t sub_begin;
+    __device__ __forceinline__ uint32_t pos(uint32_t k) const
+    {
+        const uint32_t v = pos_lds[k << 6];
+        return v == 0xffffu ? 0xffffffffu : sub_begin + v;
+    }
     __device__ __forceinline__ LpCkptPk load(uint32_t k) const
     {
         const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)k * stride);
@@ -379,23 +384,34 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
-    __shared__ uint32_t s_ckpos[HUFF_T * LP_MAX_CKPT];
+    __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
     if (blockIdx.x * HUFF_T >= nsub) return;
-    stage_huff(&s_hs, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
-    if (sub >= nsub || sub == 0) return; // subsequence 0 starts at the true beginning: its SPEC result is exact
-    const uint32_t g = img.sub_off + sub;
-    const LpSubState entry = load_state(cur_exit + g - 1);
-    if (lp_state_eq(entry, entry_used[g])) return; // already verified against this entry state
+    // subsequence 0 starts at the true beginning (its SPEC result is exact); a lane whose entry state has not changed since its
+    // last verification has nothing to do. A workgroup without work leaves before staging the tables (every later round).
+    const uint32_t g = img.sub_off + (sub < nsub ? sub : 0);
+    LpSubState entry;
+    entry.p = 0; entry.bz = 0;
+    bool need = sub < nsub && sub != 0;
+    if (need) {
+        entry = load_state(cur_exit + g - 1);
+        need = !lp_state_eq(entry, entry_used[g]);
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+    stage_huff(&s_hs, huffs + img.huff_idx);
+    if (!need) return;
     const LpImgCtx ic = make_ctx(img, st);
     MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
-    uint32_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
-    for (uint32_t k = 0; k < K; k++) cp[k << 6] = ckpts[(size_t)k * tot_sub + g].p;
-    DevCkSrc ck{cp, ckpts + g, tot_sub};
     const uint32_t S = img.sub_bits;
+    uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t p = ckpts[(size_t)k * tot_sub + g].p; // recorded positions lie within 40 bits past the subsequence: 16 bits hold them
+        cp[k << 6] = (uint16_t)(p == 0xffffffffu ? 0xffffu : p - sub * S);
+    }
+    DevCkSrc ck{cp, ckpts + g, tot_sub, sub * S};
     uint32_t sub_end = sub * S + S;
     if (sub_end > ic.total_bits) sub_end = ic.total_bits;
     const LpSubState old_exit = load_state(cur_exit + g);
