@@ -147,7 +147,7 @@ private:
     uint32_t max_chunks_ = 0, max_sub_ = 0, max_bw_ = 0, max_rows_ = 0, max_w_ = 0, max_h_ = 0;
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
     LpDevBuf d_imgs_, d_huffs_, d_states_, d_raw_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
-    LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_planes_, d_frames_desc_;
+    LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_dcpart_, d_planes_, d_frames_desc_;
     LpPinned h_stage_, h_small_, h_out_;
     std::vector<size_t> h_out_off_;
 

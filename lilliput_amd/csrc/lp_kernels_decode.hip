@@ -555,12 +555,11 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // DC differences -> absolute DC (in place): jdhuff.c decode_mcu keeps last_dc_val per component and process_restart zeroes
-// it every `dri` MCUs. One workgroup of 16 waves per image; wave w owns a contiguous range of MCUs and walks it 64 MCUs at
+// it every `dri` MCUs. An image is cut into 16 contiguous ranges of MCUs, one wave each; a wave walks its range 64 MCUs at
 // a time, lane = MCU (so the loads/stores of a step cover one contiguous run of bytes): a segmented wave scan of the
-// per-MCU component totals gives every lane its predictors. Phase 1 computes each wave's (total, had-a-reset), phase 2
-// rewrites the range starting from the combined totals of the waves before it. tests/emu checks the same arithmetic
+// per-MCU component totals gives every lane its predictors. Phase 1 computes each range's (total, had-a-reset), phase 2
+// rewrites the range starting from the combined totals of the ranges before it. tests/emu checks the same arithmetic
 // through lp_dc_walk. ~0.8 MB per 4096x4096 image: latency-bound, hidden behind the other streams' kernels.
-#define DCSCAN_T 1024
 struct DcSeg { int32_t v[LP_MAX_COMP]; bool f; }; // sums since the last reset, reset seen
 
 // inclusive segmented scan over the wave; carry-in applies to the lanes before the first reset of the step
@@ -628,34 +627,53 @@ __device__ __forceinline__ DcSeg dc_walk_range(int16_t* dc, uint32_t m0, uint32_
     return carry;
 }
 
-__global__ __launch_bounds__(DCSCAN_T) void k_dc_scan(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena)
+// Two small launches instead of one 1024-thread workgroup per image: a 16-wave workgroup has to find a CU with 16 free wave
+// slots, and while the other parts of a batch keep the CUs full of Huffman workgroups it waited for milliseconds. Here every
+// range of an image is an independent 64-thread workgroup: k_dc_sum stores each range's (sums, had-a-reset), k_dc_apply
+// combines the ranges before its own (at most DCSCAN_RANGES - 1 records) and rewrites its range.
+#define DCSCAN_RANGES 16
+struct DcPartial { int32_t v[LP_MAX_COMP]; int32_t f; };
+
+__device__ __forceinline__ void dc_range(const LpJpeg& img, uint32_t w, uint32_t& m0, uint32_t& m1, uint32_t& comps)
 {
-    __shared__ int32_t s_sum[DCSCAN_T / 64][LP_MAX_COMP];
-    __shared__ int32_t s_rst[DCSCAN_T / 64];
-    const LpJpeg& img = imgs[blockIdx.x];
-    const uint32_t nmcu = img.mcus_x * img.mcus_y, bpm = img.bpm, dri = img.dri;
-    const uint32_t nw = DCSCAN_T / 64, w = threadIdx.x >> 6;
-    const uint32_t per = ((nmcu + nw - 1) / nw + 63) / 64 * 64; // whole steps per wave
-    const uint32_t m0 = w * per < nmcu ? w * per : nmcu, m1 = m0 + per < nmcu ? m0 + per : nmcu;
-    int16_t* dc = dc_arena + img.coef_off / 64;
-    uint32_t comps = 0;
+    const uint32_t nmcu = img.mcus_x * img.mcus_y;
+    const uint32_t per = ((nmcu + DCSCAN_RANGES - 1) / DCSCAN_RANGES + 63) / 64 * 64; // whole 64-MCU steps per range
+    m0 = w * per < nmcu ? w * per : nmcu;
+    m1 = m0 + per < nmcu ? m0 + per : nmcu;
+    comps = 0;
     for (uint32_t b = 0; b < LP_MAX_BPM; b++) comps |= (uint32_t)(img.blk_comp[b] & 3u) << (2 * b);
+}
+
+__global__ __launch_bounds__(64) void k_dc_sum(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, DcPartial* __restrict__ partials)
+{
+    const LpJpeg& img = imgs[blockIdx.y];
+    uint32_t m0, m1, comps;
+    dc_range(img, blockIdx.x, m0, m1, comps);
     DcSeg zero;
     zero.v[0] = zero.v[1] = zero.v[2] = 0;
     zero.f = false;
-    const DcSeg tot = dc_walk_range<false>(dc, m0, m1, bpm, dri, comps, zero);
-    if ((threadIdx.x & 63) == 0) {
-        for (int c = 0; c < LP_MAX_COMP; c++) s_sum[w][c] = tot.v[c];
-        s_rst[w] = tot.f ? 1 : 0;
+    const DcSeg tot = dc_walk_range<false>(dc_arena + img.coef_off / 64, m0, m1, img.bpm, img.dri, comps, zero);
+    if (threadIdx.x == 0) {
+        DcPartial p;
+        for (int c = 0; c < LP_MAX_COMP; c++) p.v[c] = tot.v[c];
+        p.f = tot.f ? 1 : 0;
+        partials[blockIdx.y * DCSCAN_RANGES + blockIdx.x] = p;
     }
-    __syncthreads();
-    DcSeg pre = zero;
-    for (uint32_t q = 0; q < w; q++) { // combine the ranges before this wave (16 entries)
-        const bool f = s_rst[q] != 0;
-        for (int c = 0; c < LP_MAX_COMP; c++) pre.v[c] = f ? s_sum[q][c] : pre.v[c] + s_sum[q][c];
-    }
+}
+
+__global__ __launch_bounds__(64) void k_dc_apply(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, const DcPartial* __restrict__ partials)
+{
+    const LpJpeg& img = imgs[blockIdx.y];
+    uint32_t m0, m1, comps;
+    dc_range(img, blockIdx.x, m0, m1, comps);
+    DcSeg pre;
+    pre.v[0] = pre.v[1] = pre.v[2] = 0;
     pre.f = false;
-    (void)dc_walk_range<true>(dc, m0, m1, bpm, dri, comps, pre);
+    for (uint32_t q = 0; q < blockIdx.x; q++) { // the ranges before this one
+        const DcPartial p = partials[blockIdx.y * DCSCAN_RANGES + q];
+        for (int c = 0; c < LP_MAX_COMP; c++) pre.v[c] = p.f ? p.v[c] : pre.v[c] + p.v[c];
+    }
+    (void)dc_walk_range<true>(dc_arena + img.coef_off / 64, m0, m1, img.bpm, img.dri, comps, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -835,10 +853,11 @@ void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
                        a.sched.K, a.tot_sub);
 }
 
-void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc)
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */)
 {
     if (!nimg) return;
-    hipLaunchKernelGGL(k_dc_scan, dim3(nimg), dim3(DCSCAN_T), 0, s, d_imgs, d_dc);
+    hipLaunchKernelGGL(k_dc_sum, dim3(DCSCAN_RANGES, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<DcPartial*>(d_partials));
+    hipLaunchKernelGGL(k_dc_apply, dim3(DCSCAN_RANGES, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<const DcPartial*>(d_partials));
 }
 
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)

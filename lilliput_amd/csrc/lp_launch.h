@@ -33,7 +33,7 @@ void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
-void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc);
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */);
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
                     const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes);
 // pixels
