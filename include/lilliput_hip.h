@@ -183,6 +183,13 @@ int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch b, const void* src, size_t
 const char* lilliput_hip_last_error(void);
 int lilliput_hip_device_count(void);
 
+/* Lazy host write-back for Part A. Off (the default): every opencv_* call that produces pixels copies them into
+ * the caller's buffer before it returns, as cv::Mat over Go memory does (opencv.go:258-267). On: pixels stay on
+ * the device until opencv_mat_get_data or lilliput_hip_mat_sync_host asks for them -- safe for ImageOps.Transform
+ * (ops.go:331-446), which only hands Mats back to this ABI. Also settable with LILLIPUT_HIP_LAZY_HOST=1. */
+void lilliput_hip_set_lazy_host(int on);
+int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current */
+
 /* ------------------------------------------------------------------------------------------------
  * Part C -- host mirror of the Go API (ops.go / opencv.go / lilliput.go)
  * ---------------------------------------------------------------------------------------------- */

@@ -27,6 +27,7 @@ struct LpMat {
     size_t dev_off = 0, dev_step = 0;
     bool dev_valid = false;
     bool dev_shared = false;        // a crop view sharing its parent's block
+    bool host_stale = false;        // lazy write-back: the device holds newer pixels than `data`
 };
 
 struct LpDecoder {
@@ -45,4 +46,6 @@ LpEngine* lp_thread_engine();
 void lp_set_error(const std::string& s);
 bool lp_mat_to_device(LpMat* m, LpEngine* eng);
 bool lp_mat_to_host(LpMat* m, LpEngine* eng);
+bool lp_mat_host_current(LpMat* m);
+int lp_lazy_host_scope(int on); // per-thread override of the lazy write-back default (-1 = none); returns the previous value
 LpFrame lp_mat_frame(const LpMat* m);

@@ -1,8 +1,12 @@
 // lp_abi_opencv.cpp -- Part A of include/lilliput_hip.h: the reference's opencv.hpp C ABI
 // (/root/reference/opencv.hpp:57-145, implemented there by opencv.cpp on top of cv::Mat) re-implemented
 // over an own Mat header with a device mirror. Go keeps owning every big host buffer
-// (/root/reference/opencv.go:207-267, 443, 848-849); results are always written back into those buffers
-// before a call returns, so Go code that reads Framebuffer.buf directly keeps working.
+// (/root/reference/opencv.go:207-267, 443, 848-849); by default results are written back into those buffers
+// before a call returns, so Go code that reads Framebuffer.buf directly keeps working. With lazy host
+// write-back (lilliput_hip_set_lazy_host / LILLIPUT_HIP_LAZY_HOST=1) pixels stay on the device until somebody
+// asks for them (opencv_mat_get_data, lilliput_hip_mat_sync_host): ImageOps.Transform never reads decoded or
+// resized pixels on the host (ops.go:331-446 only passes Mats back into this ABI), so the JPEG->JPEG path
+// loses two device->host copies per image.
 #include "lp_abi.h"
 
 #include <ctype.h>
@@ -108,14 +112,54 @@ bool lp_mat_to_device(LpMat* m, LpEngine* eng)
     return true;
 }
 
-bool lp_mat_to_host(LpMat* m, LpEngine* eng)
+// ---- lazy host write-back
+static int g_lazy_host = -1;                 // process default; -1 = read LILLIPUT_HIP_LAZY_HOST on first use
+static thread_local int t_lazy_host = -1;    // scoped per-thread override (lp_lazy_host_scope)
+static bool lazy_host()
+{
+    if (t_lazy_host >= 0) return t_lazy_host != 0;
+    int g = __atomic_load_n(&g_lazy_host, __ATOMIC_RELAXED);
+    if (g < 0) {
+        const char* e = getenv("LILLIPUT_HIP_LAZY_HOST");
+        g = e && atoi(e) != 0;
+        __atomic_store_n(&g_lazy_host, g, __ATOMIC_RELAXED);
+    }
+    return g != 0;
+}
+int lp_lazy_host_scope(int on) { int prev = t_lazy_host; t_lazy_host = on; return prev; }
+extern "C" void lilliput_hip_set_lazy_host(int on) { __atomic_store_n(&g_lazy_host, on ? 1 : 0, __ATOMIC_RELAXED); }
+
+static bool mat_copy_to_host(LpMat* m, LpEngine* eng)
 {
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     if (!m->dev || !rowb || !m->rows) return false;
     if (hipMemcpy2DAsync(m->data, m->step, (uint8_t*)m->dev->p + m->dev_off, m->dev_step, rowb, (size_t)m->rows, hipMemcpyDeviceToHost, eng->stream()) !=
         hipSuccess)
         return false;
+    m->host_stale = false;
     return eng->sync() == LP_OK;
+}
+
+// The device mirror of `m` has just been (re)written: bring the caller's buffer up to date, now or on demand.
+bool lp_mat_to_host(LpMat* m, LpEngine* eng)
+{
+    if (lazy_host()) { m->host_stale = true; return true; }
+    return mat_copy_to_host(m, eng);
+}
+
+// Make the host pixels current before something reads or partially overwrites them.
+bool lp_mat_host_current(LpMat* m)
+{
+    if (!m->host_stale) return true;
+    if (!m->dev || !m->dev_valid) { m->host_stale = false; return true; }
+    LpEngine* eng = lp_thread_engine();
+    return eng && mat_copy_to_host(m, eng);
+}
+
+extern "C" int lilliput_hip_mat_sync_host(opencv_mat mat)
+{
+    auto m = static_cast<LpMat*>(mat);
+    return m && lp_mat_host_current(m) ? 0 : -1;
 }
 
 LpFrame lp_mat_frame(const LpMat* m)
@@ -135,6 +179,7 @@ static bool mat_new_dev(LpMat* m)
     m->dev_step = rowb;
     m->dev_shared = false;
     m->dev_valid = false;
+    m->host_stale = false; // every pixel is about to be produced afresh
     return (bool)m->dev;
 }
 
@@ -200,6 +245,7 @@ bool opencv_mat_set_row_stride(opencv_mat mat, size_t stride) // opencv.cpp:51-7
     if (stride < ws) return false;
     if (m->step != ws) return false;
     if (m->datastart + stride * (size_t)m->rows > m->datalimit) return false;
+    if (!lp_mat_host_current(m)) return false;
     m->step = stride;
     m->dev_valid = false;
     return true;
@@ -209,7 +255,12 @@ void opencv_mat_release(opencv_mat mat) { delete static_cast<LpMat*>(mat); } // 
 
 int opencv_mat_get_width(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->cols; }   // opencv.cpp:223-227
 int opencv_mat_get_height(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->rows; }  // opencv.cpp:229-233
-void* opencv_mat_get_data(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->data; }  // opencv.cpp:235-239
+void* opencv_mat_get_data(const opencv_mat mat) // opencv.cpp:235-239
+{
+    auto m = static_cast<LpMat*>(const_cast<void*>((const void*)mat));
+    lp_mat_host_current(m); // a caller that asks for the pointer is about to look at the pixels
+    return m->data;
+}
 
 opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int height) // opencv.cpp:210-215
 {
@@ -230,6 +281,7 @@ opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int he
         m->dev_step = s->dev_step;
         m->dev_valid = true;
         m->dev_shared = true;
+        m->host_stale = s->host_stale;
     }
     return m;
 }
@@ -290,6 +342,7 @@ void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     for (int y = 0; y < m->rows; y++) memset(m->data + (size_t)y * m->step, 0, rowb);
     m->dev_valid = false;
+    m->host_stale = false;
 }
 
 void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alpha) // opencv.cpp:488-496
@@ -302,6 +355,7 @@ void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alph
         for (int x = 0; x < m->cols; x++)
             for (int c = 0; c < cn && c < 4; c++) m->data[(size_t)y * m->step + (size_t)x * cn + c] = v[c];
     m->dev_valid = false;
+    m->host_stale = false;
 }
 
 static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int width, int height, int kind)
@@ -332,6 +386,7 @@ static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int wi
     op.kind = (uint32_t)kind;
     op.x0 = (uint32_t)xOffset; op.y0 = (uint32_t)yOffset; op.w = (uint32_t)width; op.h = (uint32_t)height;
     if (eng->composite(op)) return kind == 0 ? OPENCV_ERROR_ALPHA_BLENDING_FAILED : OPENCV_ERROR_UNKNOWN;
+    if (lazy_host() || d->host_stale) { d->host_stale = true; return OPENCV_SUCCESS; }
     // write the ROI rows back into the caller's buffer
     const size_t es = cv_elem_size(d->type);
     if (hipMemcpy2DAsync(d->data + (size_t)yOffset * d->step + (size_t)xOffset * es, d->step,

@@ -183,6 +183,15 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     size_t max_ecs = 0;
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
     S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
+    if (!S_cfg_) {
+        // Small launches (the one-image ABI) are bound by the length of a lane's serial walk, not by throughput: cut the
+        // subsequences shorter until the launch has enough lanes to occupy a good part of the device.
+        static const uint32_t want_lanes = getenv("LILLIPUT_HIP_LAT_LANES") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_LAT_LANES")) : 32768u;
+        static const uint32_t min_S = getenv("LILLIPUT_HIP_MIN_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_MIN_S")) : 1024u;
+        uint64_t bits = 0;
+        for (auto& j : h_imgs_) bits += (uint64_t)j.raw_len * 8;
+        while (S_ > min_S && bits / S_ < want_lanes) S_ >>= 1;
+    }
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
     sched_ = lp_make_sched(S_, C_cfg_ ? C_cfg_ : 256); // checkpoint schedule of the speculative pass (see LpCkSched)
     K_ = sched_.K;

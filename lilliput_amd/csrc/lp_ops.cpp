@@ -64,7 +64,11 @@ static int content_length_jpeg(const uint8_t* j, size_t n) // opencv.go:537-602
         next += ((size_t)j[idx + 2] << 8) | j[idx + 3];
         if (t == 0xDA) {
             for (; next < n; next++) {
-                if (j[next] != 0xFF) continue;
+                if (j[next] != 0xFF) { // same walk as the reference's byte loop, taken a run at a time
+                    const void* f = memchr(j + next, 0xFF, n - next);
+                    if (!f) { next = n; break; }
+                    next = (size_t)((const uint8_t*)f - j);
+                }
                 if (next + 1 >= n) { next = n; break; }
                 uint8_t peek = j[next + 1];
                 if (peek == 0xFF) continue;
@@ -156,6 +160,7 @@ struct Decoder { // openCVDecoder, opencv.go:132-138
     opencv_mat mat = nullptr;
     opencv_decoder dec = nullptr;
     bool has_read_header = false, has_decoded = false;
+    int content_length = -1, num_frames = 0; // the buffer cannot change under a decoder: scanned once, not per Header() call
 };
 
 struct Header { int width, height, pixel_type, orientation, num_frames, content_length; };
@@ -164,12 +169,14 @@ int decoder_header(Decoder* d, Header* h) // opencv.go:639-661
 {
     if (!d->has_read_header && !opencv_decoder_read_header(d->dec)) return LILLIPUT_ERR_INVALID_IMAGE;
     d->has_read_header = true;
-    h->num_frames = lp_detect_apng(d->buf, d->len) ? 2 : 1;
+    if (!d->num_frames) d->num_frames = lp_detect_apng(d->buf, d->len) ? 2 : 1;
+    h->num_frames = d->num_frames;
     h->width = opencv_decoder_get_width(d->dec);
     h->height = opencv_decoder_get_height(d->dec);
     h->pixel_type = opencv_decoder_get_pixel_type(d->dec);
     h->orientation = opencv_decoder_get_orientation(d->dec);
-    h->content_length = lp_detect_content_length(d->buf, d->len);
+    if (d->content_length < 0) d->content_length = lp_detect_content_length(d->buf, d->len);
+    h->content_length = d->content_length;
     return LILLIPUT_OK;
 }
 
@@ -298,6 +305,9 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     auto d = static_cast<Decoder*>(dd);
     *dst_len = 0;
     if (!o || !d || !opt || !dst || dst_cap == 0) return LILLIPUT_ERR_INVALID_IMAGE;
+    // The two framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so the
+    // decoded and resized frames stay on the device for the duration of the call.
+    struct LazyScope { int prev = lp_lazy_host_scope(1); ~LazyScope() { lp_lazy_host_scope(prev); } } lazy_scope;
     // initializeTransform (ops.go:483-546)
     Header hdr;
     int e = decoder_header(d, &hdr);

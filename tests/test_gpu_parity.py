@@ -248,6 +248,43 @@ def test_orientation_transform_all_eight_bit_exact(hip_lib, oracle):
             assert np.array_equal(got, oracle.orientation_transform(src, o)), (cn, o)
 
 
+def test_lazy_host_write_back_defers_and_materialises(hip_lib, oracle, fixture_bytes):
+    """LILLIPUT_HIP_LAZY_HOST semantics: the decode -> orient -> crop -> resize -> encode chain of ops.go:331-446
+    runs without touching the caller's pixel buffers; pixels appear on request and equal the eager results."""
+    L = hip_lib
+    data = fixture_bytes["ferry_sunset.jpg"]
+    ref = oracle.jpeg_decode(data)
+    h, w = ref.shape[:2]
+    L.lilliput_hip_set_lazy_host(1)
+    try:
+        enc_buf = np.frombuffer(data, dtype=np.uint8).copy()
+        em = L.opencv_mat_create_from_data(len(data), 1, 0, enc_buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)))
+        dec = L.opencv_decoder_create(em)
+        assert dec and L.opencv_decoder_read_header(dec)
+        m = Mat(L, w=w, h=h, typ=CV_8UC3)
+        assert L.opencv_decoder_read_data(dec, m.h)
+        assert not m.buf.any()                                   # nothing written back yet
+        L.opencv_mat_orientation_transform(6, m.h)
+        view = L.opencv_mat_crop(m.h, 8, 16, h - 16, w - 32)     # the Mat is now w rows x h cols
+        d = Mat(L, w=96, h=80, typ=CV_8UC3)
+        L.opencv_mat_resize(view, d.h, 96, 80, C.c_int.in_dll(L, "CV_INTER_AREA").value)
+        assert not m.buf.any() and not d.buf.any()
+        assert L.lilliput_hip_mat_sync_host(d.h) == 0
+        rot = oracle.orientation_transform(ref, 6)
+        exp, _ = oracle.resize_area(np.ascontiguousarray(rot[16 : 16 + w - 32, 8 : 8 + h - 16]), 96, 80)
+        assert np.array_equal(d.array(), exp)
+        assert not m.buf.any()                                   # only the Mat that was asked for is copied
+        assert L.opencv_mat_get_data(m.h) == m.buf.ctypes.data   # asking for the pointer materialises the pixels
+        assert np.array_equal(m.array(), rot)
+        L.opencv_mat_release(view)
+        L.opencv_decoder_release(dec)
+        L.opencv_mat_release(em)
+        m.release()
+        d.release()
+    finally:
+        L.lilliput_hip_set_lazy_host(0)
+
+
 def _abi_encode(L, px, quality):
     s = Mat(L, px)
     dst = np.zeros(px.size * 2 + 4096, dtype=np.uint8)
