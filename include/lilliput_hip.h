@@ -107,6 +107,15 @@ opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst);
 void opencv_encoder_release(opencv_encoder e);
 bool opencv_encoder_write(opencv_encoder e, const opencv_mat src, const int* opt, size_t opt_len);
 
+/* opencv.hpp:118-132 -- colour metadata readers (host-side container walks; opencv.go:697-767, ops.go:306-333).
+ * get_*_icc copy the embedded ICC profile into dest and return its length (0 = none / malformed / does not fit);
+ * get_png_cicp returns 1 and the four H.273 code points when a valid cICP chunk precedes the image data;
+ * png_insert_cicp splices a cICP chunk in after IHDR and returns the new length (the old one if nothing was done). */
+int opencv_decoder_get_jpeg_icc(void* src, size_t src_len, void* dest, size_t dest_len);
+int opencv_decoder_get_png_icc(void* src, size_t src_len, void* dest, size_t dest_len);
+int opencv_decoder_get_png_cicp(void* src, size_t src_len, uint8_t* primaries, uint8_t* transfer, uint8_t* matrix, uint8_t* full_range);
+size_t opencv_png_insert_cicp(void* png, size_t png_len, size_t png_cap, uint8_t primaries, uint8_t transfer, uint8_t matrix, uint8_t full_range);
+
 /* opencv.hpp:135-145 */
 #define OPENCV_SUCCESS 0
 #define OPENCV_ERROR_INVALID_CHANNEL_COUNT 1
@@ -214,6 +223,7 @@ int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out);   
 void lilliput_decoder_close(lilliput_decoder d);
 int lilliput_decoder_header(lilliput_decoder d, int* width, int* height, int* pixel_type, int* orientation, int* num_frames, int* content_length);
 const char* lilliput_decoder_description(lilliput_decoder d);
+int lilliput_decoder_icc(lilliput_decoder d, void* dst, size_t cap);                    /* opencv.go:697-712 */
 lilliput_image_ops lilliput_new_image_ops(int max_size);                                /* ops.go:83-91 */
 void lilliput_image_ops_close(lilliput_image_ops o);
 void lilliput_image_ops_clear(lilliput_image_ops o);

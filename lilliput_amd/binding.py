@@ -93,6 +93,7 @@ def lib():
     L.lilliput_decoder_header.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 6
     L.lilliput_decoder_description.restype = C.c_char_p
     L.lilliput_decoder_description.argtypes = [C.c_void_p]
+    L.lilliput_decoder_icc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.lilliput_new_image_ops.restype = C.c_void_p
     L.lilliput_new_image_ops.argtypes = [C.c_int]
     L.lilliput_image_ops_close.argtypes = [C.c_void_p]
@@ -173,6 +174,10 @@ class Decoder:
 
     def Description(self):
         return lib().lilliput_decoder_description(self._h).decode()
+
+    def ICC(self):
+        out = C.create_string_buffer(32768)  # ICCProfileBufferSize
+        return out.raw[: lib().lilliput_decoder_icc(self._h, out, 32768)]
 
     def Close(self):
         if self._h:

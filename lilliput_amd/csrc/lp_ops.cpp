@@ -9,6 +9,7 @@
 #include <time.h>
 
 #include <string>
+#include <vector>
 
 #include "lp_abi.h"
 #include "lp_ops_logic.h"
@@ -280,6 +281,16 @@ int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* p
 
 const char* lilliput_decoder_description(lilliput_decoder dd) { return opencv_decoder_get_description(static_cast<Decoder*>(dd)->dec); }
 
+int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712
+{
+    auto d = static_cast<Decoder*>(dd);
+    if (!d || !dst) return 0;
+    const char* desc = opencv_decoder_get_description(d->dec);
+    if (desc && strcmp(desc, "JPEG") == 0) return opencv_decoder_get_jpeg_icc((void*)d->buf, d->len, dst, cap);
+    if (desc && strcmp(desc, "PNG") == 0) return opencv_decoder_get_png_icc((void*)d->buf, d->len, dst, cap);
+    return 0;
+}
+
 lilliput_image_ops lilliput_new_image_ops(int max_size) // ops.go:83-91
 {
     auto o = new ImageOps();
@@ -322,6 +333,12 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
     if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
     struct Guard { Encoder& e; ~Guard() { opencv_encoder_release(e.enc); opencv_mat_release(e.dst); } } guard{enc};
+    // newOpenCVEncoder asks the decoder for its ICC profile on every Transform (opencv.go:863); the JPEG writer then drops it
+    // (cv::imencode has no ICC channel), so the read is kept for its cost profile only.
+    {
+        static thread_local std::vector<uint8_t> icc_scratch(32768); // ICCProfileBufferSize, lilliput.go
+        (void)lilliput_decoder_icc(dd, icc_scratch.data(), icc_scratch.size());
+    }
 
     auto encode = [&](Framebuffer* f, size_t* n) -> int { // opencv.go:872-900
         if (!f) return LILLIPUT_ERR_EOF;

@@ -55,6 +55,38 @@ def ref():
     return _ref
 
 
+_refmeta = None
+
+
+def ref_meta():
+    """The reference's libjpeg-turbo / libpng metadata readers (ICC, cICP), or None when not built."""
+    global _refmeta
+    if _refmeta is None:
+        _refmeta = _load(os.path.join("_ref", "librefmeta.so"))
+        if _refmeta is not None:
+            for f in (_refmeta.ref_jpeg_icc, _refmeta.ref_png_icc):
+                f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+            _refmeta.ref_png_cicp.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    return _refmeta
+
+
+def ref_jpeg_icc(data, cap=1 << 16):
+    out = C.create_string_buffer(cap)
+    n = ref_meta().ref_jpeg_icc(bytes(data), len(data), out, cap)
+    return out.raw[:n]
+
+
+def ref_png_icc(data, cap=1 << 16):
+    out = C.create_string_buffer(cap)
+    n = ref_meta().ref_png_icc(bytes(data), len(data), out, cap)
+    return out.raw[:n]
+
+
+def ref_png_cicp(data):
+    out = C.create_string_buffer(4)
+    return out.raw[:4] if ref_meta().ref_png_cicp(bytes(data), len(data), out) else None
+
+
 def _buf(data):
     arr = np.frombuffer(bytes(data), dtype=np.uint8)
     return arr, arr.ctypes.data_as(_u8p)
