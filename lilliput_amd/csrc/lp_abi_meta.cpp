@@ -126,7 +126,7 @@ bool jpeg_header_ok(const uint8_t* s, size_t n, std::vector<App2>& app2)
             }
             return true;
         } else { // APPn / COM / DNL: length-prefixed, skipped or saved
-            if (length < 2) return false;                              // JERR_BAD_LENGTH
+            if (length < 2) continue;                                  // skip_variable / save_marker shrug off a bogus length word
             const size_t at = r.i;
             const uint32_t dl = (uint32_t)length - 2;
             if (m == 0xE2 && at + dl <= n) app2.push_back(App2{s + at, dl}); // one that runs off the end can never be followed by SOS

@@ -94,6 +94,34 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
     memcpy(hs->vals[slot], vals, (size_t)(k > 256 ? 256 : k));
 }
 
+// T.81 Annex K.3 typical Huffman tables (jstdhuff.c): what the encoder writes, and what libjpeg-turbo falls back to for a
+// table id 0/1 that no DHT defined (jdhuff.c jinit_huff_decoder -> std_huff_tables, "Motion JPEG frames typically do not
+// include the Huffman tables"). Order: DC luma, AC luma, DC chroma, AC chroma.
+const uint8_t lp_std_huff_bits[4][17] = {{0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},
+                                     {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d},
+                                     {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},
+                                     {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};
+const uint8_t lp_std_huff_dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t lp_std_huff_ac_luma[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+const uint8_t lp_std_huff_ac_chroma[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+
 // jdhuff.c jpeg_make_d_derived_tbl (run by libjpeg for the tables a scan uses): the code space must not overflow
 // (the all-ones code of any length is reserved) and DC symbols are categories 0..15 -- else JERR_BAD_HUFF_TABLE.
 static bool huff_table_valid(const uint8_t bits[17], const uint8_t* vals, bool is_dc)
@@ -124,26 +152,48 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     uint8_t hvals[2][4][256];
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
     int cid[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
-    bool have_sof = false, saw_jfif = false, saw_adobe = false;
+    bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false;
+    unsigned sof_nc = 0;
+    int scan_comp[3] = {-1, -1, -1};
     int adobe_tf = 0;
     size_t i = 2;
     size_t ecs = 0;
-    while (i + 4 <= n) {
-        if (d[i] != 0xFF) return LP_PARSE_NOT_JPEG;
-        unsigned m = d[i + 1];
-        if (m == 0xFF) { i++; continue; }
-        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
-        if (m == 0xD9) return LP_PARSE_NOT_JPEG;
-        size_t L = be16(d + i + 2);
-        if (L < 2 || i + 2 + L > n) return LP_PARSE_TRUNCATED;
-        const uint8_t* p = d + i + 4;
+    // The walk accepts and rejects what jdmarker.c read_markers does (the reference decodes through it): garbage between
+    // segments is skipped, an unknown marker code, a repeated SOI/SOF, or a table segment whose length does not add up is
+    // an error; running off the end is "no image".
+    for (;;) {
+        // next_marker
+        unsigned m;
+        for (;;) {
+            while (i < n && d[i] != 0xFF) i++;
+            while (i < n && d[i] == 0xFF) i++;
+            if (i >= n) return LP_PARSE_TRUNCATED;
+            m = d[i++];
+            if (m != 0) break; // FF 00: stuffed data, keep looking
+        }
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD8 || m == 0xD9) return LP_PARSE_NOT_JPEG; // JERR_SOI_DUPLICATE / EOI before any scan
+        const bool is_sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
+        const bool known = (m >= 0xC0 && m <= 0xCF && m != 0xC8) || m == 0xDA || m == 0xDB || m == 0xDC || m == 0xDD || (m >= 0xE0 && m <= 0xEF) || m == 0xFE;
+        if (!known) return LP_PARSE_NOT_JPEG;                  // JERR_UNKNOWN_MARKER
+        if (m == 0xC5 || m == 0xC6 || m == 0xC7 || m == 0xCD || m == 0xCE || m == 0xCF) return LP_PARSE_NOT_JPEG; // JERR_SOF_UNSUPPORTED
+        if (i + 2 > n) return LP_PARSE_TRUNCATED;
+        size_t L = be16(d + i);
+        if (L < 2) {
+            // skip_variable / get_interesting_appn shrug off a bogus length word; the table and frame readers do not
+            if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE || m == 0xDC) { i += 2; continue; }
+            return LP_PARSE_NOT_JPEG;                          // JERR_BAD_LENGTH
+        }
+        if (i + L > n) return LP_PARSE_TRUNCATED;
+        const uint8_t* p = d + i + 2;
         size_t pl = L - 2;
-        if (m == 0xDB) {
+        const size_t seg_end = i + L;
+        if (m == 0xDB) { // get_dqt
             size_t k = 0;
             while (k < pl) {
                 unsigned pq = p[k] >> 4, t = p[k] & 15;
                 k++;
-                if (t > 3 || k + (pq ? 128 : 64) > pl) return LP_PARSE_NOT_JPEG;
+                if (t > 3 || k + (pq ? 128 : 64) > pl) return LP_PARSE_NOT_JPEG; // JERR_DQT_INDEX / JERR_BAD_LENGTH
                 for (int z = 0; z < 64; z++) {
                     unsigned v;
                     if (pq) { v = be16(p + k); k += 2; } else v = p[k++];
@@ -151,73 +201,111 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 }
                 qt_ok[t] = true;
             }
-        } else if (m == 0xC4) {
+        } else if (m == 0xC4) { // get_dht
             size_t k = 0;
-            while (k < pl) {
+            while (pl - k > 16) {
                 unsigned tc = p[k] >> 4, th = p[k] & 15;
                 k++;
-                if (tc > 1 || th > 3 || k + 16 > pl) return LP_PARSE_NOT_JPEG;
                 unsigned tot = 0;
-                hbits[tc][th][0] = 0;
-                for (int b = 1; b <= 16; b++) { hbits[tc][th][b] = p[k++]; tot += hbits[tc][th][b]; }
-                if (tot > 256 || k + tot > pl) return LP_PARSE_NOT_JPEG;
+                uint8_t bits[17];
+                bits[0] = 0;
+                for (int b = 1; b <= 16; b++) { bits[b] = p[k++]; tot += bits[b]; }
+                if (tot > 256 || tot > pl - k) return LP_PARSE_NOT_JPEG;  // JERR_BAD_HUFF_TABLE
+                if (tc > 1 || th > 3) return LP_PARSE_NOT_JPEG;           // JERR_DHT_INDEX
+                memcpy(hbits[tc][th], bits, 17);
                 memset(hvals[tc][th], 0, 256);
                 memcpy(hvals[tc][th], p + k, tot);
                 k += tot;
                 h_ok[tc][th] = true;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+            if (k != pl) return LP_PARSE_NOT_JPEG;                        // JERR_BAD_LENGTH
+        } else if (is_sof) { // get_sof
+            if (have_sof) return LP_PARSE_NOT_JPEG;                       // JERR_SOF_DUPLICATE
             if (pl < 6) return LP_PARSE_NOT_JPEG;
-            if (p[0] != 8) return LP_PARSE_UNSUPPORTED;
+            const unsigned prec = p[0], nc = p[5];
             j.height = be16(p + 1);
             j.width = be16(p + 3);
-            j.ncomp = p[5];
-            if (j.ncomp != 1 && j.ncomp != 3) return LP_PARSE_UNSUPPORTED;
-            if (pl < 6 + 3u * j.ncomp) return LP_PARSE_NOT_JPEG;
-            for (int c = 0; c < j.ncomp; c++) {
-                cid[c] = p[6 + 3 * c];
-                j.hs[c] = p[7 + 3 * c] >> 4;
-                j.vs[c] = p[7 + 3 * c] & 15;
-                tq[c] = p[8 + 3 * c] & 3;
+            if (j.height == 0 || j.width == 0 || nc == 0) return LP_PARSE_NOT_JPEG; // JERR_EMPTY_IMAGE
+            if (pl != 6 + 3u * nc) return LP_PARSE_NOT_JPEG;             // JERR_BAD_LENGTH
+            if (m != 0xC0 && m != 0xC1) { sof_unsupported = true; }      // progressive, lossless, arithmetic: judged at SOS
+            if (prec != 8 || (nc != 1 && nc != 3)) sof_unsupported = true; // 12-bit, CMYK/YCCK, two-component
+            sof_nc = nc;
+            for (unsigned c = 0; c < nc; c++) {
+                const unsigned hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
+                if (hs < 1 || hs > 4 || vs < 1 || vs > 4) sof_bad_sampling = true; // JERR_BAD_SAMPLING, raised at the first SOS
+                if (c < 3) {
+                    cid[c] = p[6 + 3 * c];
+                    j.hs[c] = (uint8_t)hs;
+                    j.vs[c] = (uint8_t)vs;
+                    tq[c] = p[8 + 3 * c];
+                }
             }
+            j.ncomp = (uint8_t)(nc <= 3 ? nc : 3);
             have_sof = true;
-        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return LP_PARSE_UNSUPPORTED; // progressive, lossless, arithmetic
-        } else if (m == 0xDD) {
-            if (pl >= 2) j.dri = be16(p);
+        } else if (m == 0xDD) { // get_dri
+            if (L != 4) return LP_PARSE_NOT_JPEG;
+            j.dri = be16(p);
+        } else if (m == 0xCC) { // get_dac: checked like libjpeg does, although no arithmetic scan is accepted further down
+            if (pl & 1) return LP_PARSE_NOT_JPEG;
+            for (size_t k = 0; k < pl; k += 2) {
+                if (p[k] >= 32) return LP_PARSE_NOT_JPEG;                                   // JERR_DAC_INDEX
+                if (p[k] < 16 && (p[k + 1] & 15) > (p[k + 1] >> 4)) return LP_PARSE_NOT_JPEG; // JERR_DAC_VALUE
+            }
         } else if (m == 0xE0) {
-            if (pl >= 5 && memcmp(p, "JFIF\0", 5) == 0) saw_jfif = true;
+            if (pl >= 14 && memcmp(p, "JFIF\0", 5) == 0) saw_jfif = true;
         } else if (m == 0xE1) {
             int o = exif_orientation(p, pl);
             if (o >= 1 && o <= 8 && j.orientation == 1) j.orientation = (uint8_t)o;
         } else if (m == 0xEE) {
             if (pl >= 12 && memcmp(p, "Adobe", 5) == 0) { saw_adobe = true; adobe_tf = p[11]; }
-        } else if (m == 0xDA) {
-            if (!have_sof || pl < 1) return LP_PARSE_NOT_JPEG;
+        } else if (m == 0xDA) { // get_sos, then the checks of jdinput.c initial_setup / jdhuff.c on the first scan
+            if (!have_sof || pl < 1) return LP_PARSE_NOT_JPEG;            // JERR_SOS_NO_SOF
             unsigned ns = p[0];
-            if (ns != j.ncomp) return LP_PARSE_UNSUPPORTED; // non-interleaved / multi-scan
-            if (pl < 1 + 2 * ns + 3) return LP_PARSE_NOT_JPEG;
+            if (L != ns * 2 + 6 || ns < 1 || ns > 4) return LP_PARSE_NOT_JPEG; // JERR_BAD_LENGTH
+            if (j.height > 65500 || j.width > 65500 || sof_bad_sampling) return LP_PARSE_NOT_JPEG;
+            if (sof_unsupported) return LP_PARSE_UNSUPPORTED;
+            int cur[4] = {-1, -1, -1, -1};
             for (unsigned s = 0; s < ns; s++) {
                 int cs = p[1 + 2 * s], t = p[2 + 2 * s], c;
-                for (c = 0; c < j.ncomp; c++) if (cid[c] == cs) break;
-                if (c == j.ncomp) return LP_PARSE_NOT_JPEG;
-                if ((unsigned)c != s) return LP_PARSE_UNSUPPORTED;
-                td[c] = (t >> 4) & 3;
-                ta[c] = t & 3;
+                // libjpeg-turbo's matching rule: the first frame component with this id whose slot is still free
+                for (c = 0; c < j.ncomp; c++) if (cid[c] == cs && cur[c] < 0) break;
+                if (c == j.ncomp) return LP_PARSE_NOT_JPEG;               // JERR_BAD_COMPONENT_ID
+                cur[s] = c;
+                for (unsigned q = 0; q < s; q++) if (cur[q] == c) return LP_PARSE_NOT_JPEG;
+                if ((t >> 4) > 3 || (t & 15) > 3) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
+                if (s < 3) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
-            ecs = i + 2 + L;
+            if (ns != j.ncomp) return LP_PARSE_UNSUPPORTED; // non-interleaved / multi-scan
+            for (unsigned s = 0; s < ns; s++) if (scan_comp[s] != (int)s) return LP_PARSE_UNSUPPORTED;
+            ecs = seg_end;
             break;
         }
-        i += 2 + L;
+        i = seg_end;
     }
     if (!have_sof || !ecs || j.width == 0 || j.height == 0) return LP_PARSE_NOT_JPEG;
+    (void)sof_nc;
+    // std_huff_tables(): ids 0 and 1 get the Annex-K luminance / chrominance tables when no DHT defined them
+    for (int t = 0; t < 2; t++) {
+        if (!h_ok[0][t]) {
+            memcpy(hbits[0][t], lp_std_huff_bits[2 * t], 17);
+            memset(hvals[0][t], 0, 256);
+            memcpy(hvals[0][t], lp_std_huff_dc_vals, 12);
+            h_ok[0][t] = true;
+        }
+        if (!h_ok[1][t]) {
+            memcpy(hbits[1][t], lp_std_huff_bits[2 * t + 1], 17);
+            memset(hvals[1][t], 0, 256);
+            memcpy(hvals[1][t], t ? lp_std_huff_ac_chroma : lp_std_huff_ac_luma, 162);
+            h_ok[1][t] = true;
+        }
+    }
     if (j.ncomp == 1) { j.hs[0] = j.vs[0] = 1; }
     j.hmax = j.vmax = 1;
     for (int c = 0; c < j.ncomp; c++) {
         if (j.hs[c] < 1 || j.hs[c] > 2 || j.vs[c] < 1 || j.vs[c] > 2) return LP_PARSE_UNSUPPORTED;
         if (j.hs[c] > j.hmax) j.hmax = j.hs[c];
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
-        if (!qt_ok[tq[c]] || !h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;
+        if (tq[c] > 3 || !qt_ok[tq[c]] || !h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG; // JERR_NO_QUANT_TABLE / JERR_NO_HUFF_TABLE
         if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
         if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
             return LP_PARSE_NOT_JPEG;

@@ -24,3 +24,9 @@ int lp_jpeg_parse(const uint8_t* data, size_t len, LpJpegHeader* out);
 
 // Build one table slot of an LpHuffSet from DHT counts/values.
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals);
+
+// T.81 Annex K.3 tables (DC luma, AC luma, DC chroma, AC chroma): encoder output and the decoder's fallback for undefined ids 0/1.
+extern const uint8_t lp_std_huff_bits[4][17];
+extern const uint8_t lp_std_huff_dc_vals[12];
+extern const uint8_t lp_std_huff_ac_luma[162];
+extern const uint8_t lp_std_huff_ac_chroma[162];

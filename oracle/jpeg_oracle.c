@@ -83,29 +83,71 @@ static int parse_exif_orientation(const uint8_t* p, size_t n)
     return 0;
 }
 
+/* T.81 Annex K.3 typical Huffman tables (jstdhuff.c): DC luma, AC luma, DC chroma, AC chroma */
+static const uint8_t std_bits[4][17] = {
+    {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},  /* DC luma */
+    {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, /* AC luma */
+    {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},  /* DC chroma */
+    {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};/* AC chroma */
+static const uint8_t std_dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t std_ac_luma_vals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t std_ac_chroma_vals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
 int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
 {
     memset(in, 0, sizeof(*in));
     in->orientation = 1;
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return LO_ERR_FORMAT;
     size_t i = 2;
-    int have_sof = 0;
-    while (i + 4 <= n) {
-        if (d[i] != 0xFF) return LO_ERR_FORMAT;
-        int m = d[i + 1];
-        if (m == 0xFF) { i++; continue; }
-        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
-        if (m == 0xD9) return LO_ERR_FORMAT;
-        int L = rd16(d + i + 2);
-        if (L < 2 || i + 2 + (size_t)L > n) return LO_ERR_FORMAT;
-        const uint8_t* p = d + i + 4;
+    int have_sof = 0, unsupported = 0, bad_sampling = 0;
+    /* jdmarker.c read_markers: garbage before a marker is skipped (next_marker); a second SOI/SOF, an unknown marker code or a
+       table/frame/scan segment whose length does not add up is an error; APPn/COM/DNL with a bogus length word are shrugged off */
+    for (;;) {
+        int m;
+        for (;;) {
+            while (i < n && d[i] != 0xFF) i++;
+            while (i < n && d[i] == 0xFF) i++;
+            if (i >= n) return LO_ERR_FORMAT; /* the memory source would feed a fake EOI: "no image" */
+            m = d[i++];
+            if (m != 0) break;
+        }
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD8 || m == 0xD9) return LO_ERR_FORMAT;
+        int skippable = (m >= 0xE0 && m <= 0xEF) || m == 0xFE || m == 0xDC;
+        int sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
+        if (!(skippable || sof || m == 0xC4 || m == 0xCC || m == 0xDA || m == 0xDB || m == 0xDD)) return LO_ERR_FORMAT; /* JERR_UNKNOWN_MARKER */
+        if (m == 0xC5 || m == 0xC6 || m == 0xC7 || m >= 0xCD) if (sof) return LO_ERR_FORMAT;                              /* JERR_SOF_UNSUPPORTED */
+        if (i + 2 > n) return LO_ERR_FORMAT;
+        int L = rd16(d + i);
+        if (L < 2) { if (skippable) { i += 2; continue; } return LO_ERR_FORMAT; }
+        if (i + (size_t)L > n) return LO_ERR_FORMAT;
+        const uint8_t* p = d + i + 2;
         int pl = L - 2;
-        if (m == 0xDB) {
+        size_t seg_end = i + (size_t)L;
+        if (m == 0xDB) { /* get_dqt */
             int k = 0;
             while (k < pl) {
                 int pq = p[k] >> 4, tq = p[k] & 15;
                 k++;
-                if (tq > 3) return LO_ERR_FORMAT;
+                if (tq > 3 || k + (pq ? 128 : 64) > pl) return LO_ERR_FORMAT;
                 for (int z = 0; z < 64; z++) {
                     int v;
                     if (pq) { v = rd16(p + k); k += 2; } else v = p[k++];
@@ -113,71 +155,119 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
                 }
                 in->qt_present[tq] = 1;
             }
-        } else if (m == 0xC4) {
+        } else if (m == 0xC4) { /* get_dht */
             int k = 0;
-            while (k < pl) {
-                int tc = p[k] >> 4, th = p[k] & 15;
+            while (pl - k > 16) {
+                int tc = p[k] >> 4, th = p[k] & 15, tot = 0;
+                uint8_t bits[17];
                 k++;
+                bits[0] = 0;
+                for (int b = 1; b <= 16; b++) { bits[b] = p[k++]; tot += bits[b]; }
+                if (tot > 256 || tot > pl - k) return LO_ERR_FORMAT;
                 if (tc > 1 || th > 3) return LO_ERR_FORMAT;
-                int tot = 0;
-                in->bits[tc][th][0] = 0;
-                for (int b = 1; b <= 16; b++) { in->bits[tc][th][b] = p[k++]; tot += in->bits[tc][th][b]; }
-                if (tot > 256 || k + tot > pl) return LO_ERR_FORMAT;
+                memcpy(in->bits[tc][th], bits, 17);
+                memset(in->vals[tc][th], 0, 256);
                 memcpy(in->vals[tc][th], p + k, tot);
                 k += tot;
                 in->ht_present[tc][th] = 1;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+            if (k != pl) return LO_ERR_FORMAT;
+        } else if (sof) { /* get_sof */
+            if (have_sof || pl < 6) return LO_ERR_FORMAT;
+            int nc = p[5];
             in->sof = m - 0xC0;
-            if (p[0] != 8) return LO_ERR_UNSUPPORTED;
             in->height = rd16(p + 1);
             in->width = rd16(p + 3);
-            in->ncomp = p[5];
-            if (in->ncomp != 1 && in->ncomp != 3) return LO_ERR_UNSUPPORTED;
-            for (int c = 0; c < in->ncomp; c++) {
-                in->cid[c] = p[6 + 3 * c];
-                in->hs[c] = p[7 + 3 * c] >> 4;
-                in->vs[c] = p[7 + 3 * c] & 15;
-                in->tq[c] = p[8 + 3 * c];
+            if (in->height == 0 || in->width == 0 || nc == 0 || pl != 6 + 3 * nc) return LO_ERR_FORMAT;
+            if ((m != 0xC0 && m != 0xC1) || p[0] != 8 || (nc != 1 && nc != 3)) unsupported = 1;
+            in->ncomp = nc <= 3 ? nc : 3;
+            for (int c = 0; c < nc; c++) {
+                int hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
+                if (hs < 1 || hs > 4 || vs < 1 || vs > 4) bad_sampling = 1; /* jdinput.c initial_setup, at the first SOS */
+                if (c < 3) { in->cid[c] = p[6 + 3 * c]; in->hs[c] = hs; in->vs[c] = vs; in->tq[c] = p[8 + 3 * c]; }
             }
             have_sof = 1;
-        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return LO_ERR_UNSUPPORTED; /* progressive / lossless / arithmetic */
         } else if (m == 0xDD) {
+            if (L != 4) return LO_ERR_FORMAT;
             in->dri = rd16(p);
+        } else if (m == 0xCC) { /* get_dac: parsed and checked even though no arithmetic scan can follow here */
+            if (pl & 1) return LO_ERR_FORMAT;
+            for (int k = 0; k < pl; k += 2) {
+                if (p[k] >= 32) return LO_ERR_FORMAT;                                  /* JERR_DAC_INDEX */
+                if (p[k] < 16 && (p[k + 1] & 15) > (p[k + 1] >> 4)) return LO_ERR_FORMAT; /* JERR_DAC_VALUE */
+            }
         } else if (m == 0xE0) {
-            if (pl >= 5 && memcmp(p, "JFIF\0", 5) == 0) in->saw_jfif = 1;
+            if (pl >= 14 && memcmp(p, "JFIF\0", 5) == 0) in->saw_jfif = 1; /* APP0_DATA_LEN */
         } else if (m == 0xE1) {
             int o = parse_exif_orientation(p, (size_t)pl);
             if (o >= 1 && o <= 8 && in->orientation == 1) in->orientation = o;
         } else if (m == 0xEE) {
             if (pl >= 12 && memcmp(p, "Adobe", 5) == 0) { in->saw_adobe = 1; in->adobe_transform = p[11]; }
-        } else if (m == 0xDA) {
-            if (!have_sof) return LO_ERR_FORMAT;
-            int ns = p[0];
-            if (ns != in->ncomp) return LO_ERR_UNSUPPORTED; /* non-interleaved multi-scan */
+        } else if (m == 0xDA) { /* get_sos */
+            if (!have_sof || pl < 1) return LO_ERR_FORMAT;
+            int ns = p[0], cur[4] = {-1, -1, -1, -1}, order_ok = 1;
+            if (L != ns * 2 + 6 || ns < 1 || ns > 4) return LO_ERR_FORMAT;
+            if (in->height > 65500 || in->width > 65500 || bad_sampling) return LO_ERR_FORMAT;
+            if (unsupported) return LO_ERR_UNSUPPORTED;
             for (int s = 0; s < ns; s++) {
                 int cs = p[1 + 2 * s], t = p[2 + 2 * s], c;
-                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs) break;
+                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs && cur[c] < 0) break; /* libjpeg-turbo's slot rule */
                 if (c == in->ncomp) return LO_ERR_FORMAT;
-                if (c != s) return LO_ERR_UNSUPPORTED;
+                cur[s] = c;
+                for (int q = 0; q < s; q++) if (cur[q] == c) return LO_ERR_FORMAT;
+                if ((t >> 4) > 3 || (t & 15) > 3) return LO_ERR_FORMAT;
+                if (c != s) order_ok = 0;
                 in->td[c] = t >> 4;
                 in->ta[c] = t & 15;
             }
-            in->ecs_off = i + 2 + (size_t)L;
+            if (ns != in->ncomp || !order_ok) return LO_ERR_UNSUPPORTED; /* non-interleaved / multi-scan */
+            in->ecs_off = seg_end;
             break;
         }
-        i += 2 + (size_t)L;
+        i = seg_end;
+    }
+    /* jdhuff.c jinit_huff_decoder -> std_huff_tables: undefined ids 0/1 fall back to the Annex-K tables (Motion-JPEG frames) */
+    for (int t = 0; t < 2; t++) {
+        if (!in->ht_present[0][t]) {
+            memcpy(in->bits[0][t], std_bits[2 * t], 17);
+            memset(in->vals[0][t], 0, 256);
+            memcpy(in->vals[0][t], std_dc_vals, 12);
+            in->ht_present[0][t] = 1;
+        }
+        if (!in->ht_present[1][t]) {
+            memcpy(in->bits[1][t], std_bits[2 * t + 1], 17);
+            memset(in->vals[1][t], 0, 256);
+            memcpy(in->vals[1][t], t ? std_ac_chroma_vals : std_ac_luma_vals, 162);
+            in->ht_present[1][t] = 1;
+        }
     }
     if (!have_sof || !in->ecs_off) return LO_ERR_FORMAT;
     if (in->width <= 0 || in->height <= 0) return LO_ERR_FORMAT;
     in->hmax = in->vmax = 1;
+    if (in->ncomp == 1) in->hs[0] = in->vs[0] = 1; /* a single-component scan is non-interleaved: one block per MCU whatever the factors say */
     for (int c = 0; c < in->ncomp; c++) {
         if (in->hs[c] < 1 || in->hs[c] > 2 || in->vs[c] < 1 || in->vs[c] > 2) return LO_ERR_UNSUPPORTED;
         if (in->hs[c] > in->hmax) in->hmax = in->hs[c];
         if (in->vs[c] > in->vmax) in->vmax = in->vs[c];
-        if (!in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
+        if (in->tq[c] > 3 || !in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
         if (!in->ht_present[0][in->td[c]] || !in->ht_present[1][in->ta[c]]) return LO_ERR_FORMAT;
+        /* jdhuff.c jpeg_make_d_derived_tbl, run for the tables the scan uses: the code space must not overflow (the all-ones
+           code of a length is reserved) and DC symbols are categories 0..15 -- else JERR_BAD_HUFF_TABLE */
+        for (int cls = 0; cls < 2; cls++) {
+            const uint8_t* bits = in->bits[cls][cls ? in->ta[c] : in->td[c]];
+            const uint8_t* vals = in->vals[cls][cls ? in->ta[c] : in->td[c]];
+            long code = 0;
+            int tot = 0;
+            for (int l = 1; l <= 16; l++) {
+                code += bits[l];
+                tot += bits[l];
+                if (code >= (1L << l)) return LO_ERR_FORMAT;
+                code <<= 1;
+            }
+            if (!cls)
+                for (int q = 0; q < tot; q++)
+                    if (vals[q] > 15) return LO_ERR_FORMAT;
+        }
     }
     if (in->ncomp == 1) { in->hs[0] = in->vs[0] = 1; in->hmax = in->vmax = 1; }
     if (in->ncomp == 3 && (in->hs[1] != 1 || in->vs[1] != 1 || in->hs[2] != 1 || in->vs[2] != 1)) return LO_ERR_UNSUPPORTED;
@@ -528,32 +618,6 @@ static const uint8_t std_chroma_q[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21,
                                          24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
                                          99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
                                          99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
-static const uint8_t std_bits[4][17] = {
-    {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},  /* DC luma */
-    {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, /* AC luma */
-    {0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},  /* DC chroma */
-    {0, 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77}};/* AC chroma */
-static const uint8_t std_dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-static const uint8_t std_ac_luma_vals[162] = {
-    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
-    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
-    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
-    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
-    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
-    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
-    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
-    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
-    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
-static const uint8_t std_ac_chroma_vals[162] = {
-    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
-    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
-    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
-    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
-    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
-    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
-    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
-    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
-    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
 
 void lo_quant_table(int quality, int chroma, uint16_t* q_nat)
 {

@@ -84,6 +84,19 @@ def test_decode_wide_coefficients(batch, oracle):
         assert np.array_equal(px, oracle.jpeg_decode(data)), (q, ss)
 
 
+def test_table_less_frames_decode_with_annex_k_tables(batch, oracle):
+    """Motion-JPEG style frames carry no DHT; libjpeg falls back to the Annex-K tables (jdhuff.c jinit_huff_decoder)."""
+    from test_host_logic import _strip_segments
+
+    rng = np.random.default_rng(5)
+    for shape, q in (((40, 56, 3), 80), ((333, 517, 3), 92), ((64, 64), 60)):
+        px = rng.integers(0, 256, shape, dtype=np.uint8)
+        bare = _strip_segments(oracle.jpeg_encode(px, q), 0xC4)
+        got, _ = batch.decode_jpeg(bare)
+        exp = oracle.jpeg_decode(bare)
+        assert np.array_equal(got.reshape(exp.shape), exp)
+
+
 def test_decode_synthetic_1024(batch, oracle):
     from lilliput_amd import synth
 

@@ -119,3 +119,82 @@ def test_lane_logic_other_samplings_and_tables(emu, oracle):
             for comp in range(3):
                 got, _, _ = _emu_coefs(emu, data, 256, 64, comp)
                 assert np.array_equal(got, oracle.jpeg_decode_coefs(data, comp)), (w, h, kw, comp)
+
+
+def _strip_segments(jpeg, marker):
+    """Drop every segment with this marker code between SOI and SOS."""
+    out, i = bytearray(jpeg[:2]), 2
+    while jpeg[i + 1] != 0xDA:
+        L = (jpeg[i + 2] << 8) | jpeg[i + 3]
+        if jpeg[i + 1] != marker:
+            out += jpeg[i : i + 2 + L]
+        i += 2 + L
+    return bytes(out + jpeg[i:])
+
+
+def _header_verdict(L, data):
+    """opencv_decoder_create + read_header on the host (no GPU involved): accepted?"""
+    arr = np.frombuffer(data, np.uint8).copy()
+    em = L.opencv_mat_create_from_data(len(data), 1, 0, arr.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)))
+    dec = L.opencv_decoder_create(em)
+    ok = bool(dec) and bool(L.opencv_decoder_read_header(dec))
+    if dec:
+        L.opencv_decoder_release(dec)
+    L.opencv_mat_release(em)
+    return ok
+
+
+def test_header_walk_accepts_and_rejects_like_libjpeg(hip_lib, oracle, fixture_bytes):
+    """Seeded header mutations: the product parser, the oracle and (when built) the reference's libjpeg-turbo agree on
+    accept/reject, and the oracle's pixels equal libjpeg's whenever a mutation leaves the entropy-coded data decodable
+    without libjpeg warnings (table-less Motion-JPEG frames, shuffled or garbage-separated segments, bogus APPn lengths)."""
+    import random
+
+    rnd = random.Random(11)
+    names = ["field.jpg", "coast.jpg", "firefox-gray.jpg", "sunrise.jpg"]
+    ref = oracle.ref() is not None
+    disagree = []
+    for it in range(1200):
+        b = fixture_bytes[rnd.choice(names)]
+        data = bytearray(b)
+        hdr_end = data.find(b"\xff\xda") + 14
+        mode = rnd.randrange(3)
+        if mode == 0:
+            for _ in range(rnd.randrange(1, 3)):
+                data[rnd.randrange(hdr_end)] = rnd.randrange(256)
+        elif mode == 1:
+            data[rnd.randrange(hdr_end)] ^= 1 << rnd.randrange(8)
+        else:
+            q = rnd.randrange(2, hdr_end)
+            data = data[:q] + data[q + rnd.randrange(1, 4) :]
+        data = bytes(data)
+        mine = _header_verdict(hip_lib, data)
+        try:
+            oracle.jpeg_info(data)
+            orc = True
+        except Exception:
+            orc = False
+        sig = data[:3] == b"\xff\xd8\xff"  # OpenCV picks its JPEG decoder by this signature before libjpeg sees the file
+        if mine != (orc and sig):
+            disagree.append(("oracle", it))
+        if ref:
+            try:
+                oracle.ref_jpeg_decode(data)
+                r = True
+            except Exception:
+                r = False
+            if mine and not r:
+                disagree.append(("libjpeg rejects", it))
+    assert not disagree, disagree[:10]
+
+
+def test_table_less_frames_use_annex_k_tables(hip_lib, oracle):
+    """jdhuff.c jinit_huff_decoder: Huffman table ids 0/1 without a DHT fall back to the Annex-K tables."""
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    full = oracle.jpeg_encode(px, 80)                # libjpeg's default tables ARE the Annex-K ones
+    bare = _strip_segments(full, 0xC4)
+    assert len(bare) < len(full) - 400 and _header_verdict(hip_lib, bare)
+    assert np.array_equal(oracle.jpeg_decode(bare), oracle.jpeg_decode(full))
+    if oracle.ref() is not None:
+        assert np.array_equal(oracle.ref_jpeg_decode(bare), oracle.ref_jpeg_decode(full))
