@@ -130,6 +130,53 @@ size_t opencv_png_insert_cicp(void* png, size_t png_len, size_t png_cap, uint8_t
 #define OPENCV_ERROR_UNKNOWN 10
 
 /* ------------------------------------------------------------------------------------------------
+ * Part A2 -- the decoder half of the reference's giflib.hpp C ABI (giflib.hpp:9-52; Go caller: giflib.go:56-242).
+ * Container walk + LZW on the host, frame compositing (background, disposal, restore-to-previous, palette lookup) on the
+ * device, on a canvas that stays in HBM for the life of the decoder. The encoder half (giflib_encoder_*) is not provided.
+ * ---------------------------------------------------------------------------------------------- */
+struct GifAnimationInfo {   /* giflib.hpp:9-17 */
+    int loop_count;
+    int frame_count;
+    int bg_red;
+    int bg_green;
+    int bg_blue;
+    int bg_alpha;
+    int duration_ms;
+};
+
+#define GIF_DISPOSE_NONE 0          /* giflib.hpp:19-21 */
+#define GIF_DISPOSE_BACKGROUND 1
+#define GIF_DISPOSE_PREVIOUS 2
+
+typedef struct giflib_decoder_struct* giflib_decoder;   /* giflib.hpp:23 */
+
+typedef enum {              /* giflib.hpp:26-30 */
+    giflib_decoder_have_next_frame,
+    giflib_decoder_eof,
+    giflib_decoder_error,
+} giflib_decoder_frame_state;
+
+/* giflib.hpp:33-43, 51-52 */
+giflib_decoder giflib_decoder_create(const opencv_mat buf);
+int giflib_decoder_get_width(const giflib_decoder d);
+int giflib_decoder_get_height(const giflib_decoder d);
+int giflib_decoder_get_num_frames(const giflib_decoder d);
+int giflib_decoder_get_frame_width(const giflib_decoder d);
+int giflib_decoder_get_frame_height(const giflib_decoder d);
+int giflib_decoder_get_prev_frame_delay(const giflib_decoder d);
+void giflib_decoder_release(giflib_decoder d);
+giflib_decoder_frame_state giflib_decoder_decode_frame_header(giflib_decoder d);
+bool giflib_decoder_decode_frame(giflib_decoder d, opencv_mat mat);   /* mat: screen-sized CV_8UC4, as gifDecoder.DecodeTo passes */
+giflib_decoder_frame_state giflib_decoder_skip_frame(giflib_decoder d);
+struct GifAnimationInfo giflib_decoder_get_animation_info(const giflib_decoder d);
+int giflib_decoder_get_prev_frame_disposal(const giflib_decoder d);
+
+/* Test access: the host half of decode_frame for the frame whose header was just read (no device work).
+ * meta = {left, top, width, height, interlace, disposal, delay, transparent, color_count, has_local_map}; returns the
+ * number of indices written, -1 on a decode error, -2 when cap is too small. */
+int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, int meta[10], uint8_t palette_rgb[768]);
+
+/* ------------------------------------------------------------------------------------------------
  * Part B -- batched extension (additive)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -623,6 +623,22 @@ int LpEngine::composite(const LpCompositeOp& op)
     return check(hipGetLastError(), "composite kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
+int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t pal_off = (n_indices + 255) & ~(size_t)255;
+    if (!d_ops_.ensure(pal_off + 1024)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    uint8_t* base = d_ops_.as<uint8_t>();
+    if (n_indices && !check(hipMemcpyAsync(base, indices, n_indices, hipMemcpyHostToDevice, stream_), "H2D gif indices")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D gif palette")) return LP_ERR_DEVICE;
+    op.index_off = (uint64_t)(uintptr_t)base;
+    op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
+    lp_launch_gif_frame(stream_, op);
+    if (!check(hipStreamSynchronize(stream_), "gif frame sync")) return LP_ERR_DEVICE; // the host buffers are the caller's
+    return check(hipGetLastError(), "gif frame kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
 // ------------------------------------------------------------------------------------------------
 // encode
 static const uint8_t kStdLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,

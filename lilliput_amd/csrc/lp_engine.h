@@ -112,6 +112,8 @@ public:
     const uint8_t* encoded_host(int i) const { return h_out_.as<uint8_t>() + h_out_off_[(size_t)i]; }
 
     int composite(const LpCompositeOp& op);
+    // Renders one GIF frame: uploads the indices and the palette (256 x BGRA) and runs k_gif_frame; op.index_off / palette_off are filled here.
+    int gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra);
     int sync();
     // Stage groups of a batch pipeline. Engines that share a device take turns per group so that concurrent parts of a batch
     // run DIFFERENT groups at the same time (entropy decode is VALU-bound, the pixel stages lean on HBM): without the locks

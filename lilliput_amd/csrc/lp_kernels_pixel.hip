@@ -677,6 +677,39 @@ __global__ __launch_bounds__(256) void k_composite(LpCompositeOp op, const uint8
     if (dcn == 4) d[3] = (uint8_t)sat_round_u8(__fmul_rn(oa, 255.0f));
 }
 
+// One GIF frame, one pass over the canvas: every pixel is independent once the four steps of
+// giflib_decoder_render_frame (giflib.cpp:393-540) are taken in order per pixel -- (1) first frame: background;
+// (2) previous frame disposed: its rectangle goes to the background colour or back to the snapshot;
+// (3) the state before drawing becomes the new snapshot; (4) the frame's colour index, unless transparent or out of range.
+__global__ __launch_bounds__(256) void k_gif_frame(LpGifFrameOp op)
+{
+    const int x = (int)(blockIdx.x * 64 + threadIdx.x), y = (int)(blockIdx.y * 4 + threadIdx.y);
+    if (x >= (int)op.canvas.w || y >= (int)op.canvas.h) return;
+    uint32_t* cp = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(op.canvas.off) + (size_t)y * op.canvas.stride) + x;
+    uint32_t* sp = reinterpret_cast<uint32_t*>(op.saved_off) + (size_t)y * op.canvas.w + x;
+    const uint32_t bg = (uint32_t)op.bg[0] | ((uint32_t)op.bg[1] << 8) | ((uint32_t)op.bg[2] << 16) | ((uint32_t)op.bg[3] << 24);
+    uint32_t v;
+    if (op.first) v = bg;
+    else {
+        v = *cp;
+        if (op.dispose && x >= op.px && x < op.px + op.pw && y >= op.py && y < op.py + op.ph) v = op.dispose == 1 ? bg : *sp;
+        *sp = v;
+    }
+    if (x >= op.fx && x < op.fx + op.fw && y >= op.fy && y < op.fy + op.fh) {
+        const size_t pi = (size_t)(op.skip_top + (y - op.fy)) * (size_t)op.raster_w + (size_t)(op.skip_left + (x - op.fx));
+        const int idx = reinterpret_cast<const uint8_t*>(op.index_off)[pi];
+        if (idx != op.transparent && idx < op.color_count) v = reinterpret_cast<const uint32_t*>(op.palette_off)[idx];
+    }
+    *cp = v;
+}
+
+void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op)
+{
+    if (!op.canvas.w || !op.canvas.h) return;
+    dim3 g((op.canvas.w + 63) / 64, (op.canvas.h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_gif_frame, g, dim3(64, 4), 0, s, op);
+}
+
 // ------------------------------------------------------------------------------------------------
 void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, bool any_generic, bool any_420,
                             const uint8_t* d_planes, const LpFrame* d_dsts, uint8_t* d_frames)

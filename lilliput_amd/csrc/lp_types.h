@@ -158,6 +158,24 @@ struct LpCompositeOp {
     uint32_t pad;
 };
 
+// One GIF frame onto the persistent BGRA canvas (giflib.cpp:349-568 giflib_decoder_render_frame): background fill on the
+// first frame, disposal of the previous frame's rectangle, snapshot for "restore to previous", then the palette lookup.
+struct LpGifFrameOp {
+    LpFrame canvas;             // BGRA, cn = 4
+    uint64_t saved_off;         // device address of the snapshot canvas (tightly packed, same size)
+    uint64_t index_off;         // device address of the frame's colour indices (raster_w * raster_h bytes)
+    uint64_t palette_off;       // device address of 256 x {B, G, R, 255}
+    uint32_t first;             // 1: paint the whole canvas with `bg` first, no disposal, no snapshot
+    uint32_t dispose;           // of the previous frame: 0 keep, 1 to background, 2 to previous
+    int32_t px, py, pw, ph;     // previous frame's rectangle, already clipped to the canvas (pw/ph >= 0)
+    int32_t fx, fy, fw, fh;     // this frame's visible rectangle on the canvas (fw/fh may be <= 0: nothing drawn)
+    int32_t skip_left, skip_top;
+    int32_t raster_w;           // width of the index raster (the frame's own width, before clipping)
+    int32_t transparent;        // colour index that leaves the canvas untouched, -1 = none
+    int32_t color_count;        // indices >= this leave the canvas untouched as well
+    uint8_t bg[4];              // B, G, R, A
+};
+
 // JPEG encode job (S8-S10): pixels -> baseline 4:2:0 (or grayscale) JFIF stream with Annex-K tables.
 struct LpEncJob {
     LpFrame src;

@@ -87,6 +87,61 @@ def ref_png_cicp(data):
     return out.raw[:4] if ref_meta().ref_png_cicp(bytes(data), len(data), out) else None
 
 
+_refgif = None
+
+
+def ref_gif():
+    """giflib 5.2.2 of the reference + the restated compositing of giflib.cpp (oracle/ref_gif_driver.c), or None."""
+    global _refgif
+    if _refgif is None:
+        _refgif = _load(os.path.join("_ref", "librefgif.so"))
+        if _refgif is not None:
+            _refgif.rg_open.restype = C.c_void_p
+            _refgif.rg_open.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+            _refgif.rg_close.argtypes = [C.c_void_p]
+            _refgif.rg_next.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+            _refgif.rg_skip.argtypes = [C.c_void_p]
+            _refgif.rg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    return _refgif
+
+
+def ref_gif_info(data):
+    """{loop_count, frame_count, bg_red, bg_green, bg_blue, bg_alpha, duration_ms} as giflib_decoder_get_animation_info reports."""
+    out = (C.c_int * 7)()
+    ref_gif().rg_info(bytes(data), len(data), out)
+    return list(out)
+
+
+def ref_gif_frames(data, max_frames=1 << 30, skip=()):
+    """Decode with the reference's giflib + restated compositing. Returns (width, height, frames, final_state) where each frame is
+    (canvas HxWx4 BGRA copy, meta[11], indices) and final_state is 1 (eof), 2 (header error) or 3 (decode failed); frames whose
+    ordinal is in `skip` go through giflib_decoder_skip_frame instead. None when the decoder cannot be created."""
+    data = bytes(data)
+    dims = (C.c_int * 2)()
+    h = ref_gif().rg_open(data, len(data), dims)
+    if not h:
+        return None
+    w, hh = dims[0], dims[1]
+    canvas = np.zeros((hh, w, 4), dtype=np.uint8)
+    frames, st, k = [], 0, 0
+    while len(frames) < max_frames:
+        if k in skip:
+            st = ref_gif().rg_skip(h)
+            k += 1
+            if st:
+                break
+            continue
+        meta = (C.c_int * 11)()
+        idx = np.zeros(65536 * 4, dtype=np.uint8)
+        st = ref_gif().rg_next(h, canvas.ctypes.data, meta, idx.ctypes.data, idx.size)
+        k += 1
+        if st:
+            break
+        frames.append((canvas.copy(), list(meta), idx[: meta[2] * meta[3]].copy()))
+    ref_gif().rg_close(h)
+    return w, hh, frames, st
+
+
 def _buf(data):
     arr = np.frombuffer(bytes(data), dtype=np.uint8)
     return arr, arr.ctypes.data_as(_u8p)

@@ -1,0 +1,222 @@
+"""giflib_decoder_* ABI (lp_abi_gif.cpp): host container/LZW reader against the reference's giflib 5.2.2, and the device
+compositing against the reference's render loop (oracle/ref_gif_driver.c), on the reference's own GIF fixtures, hand-built
+edge cases and seeded mutations. Recorded answers: tests/golden/gif_golden.json (tests/golden/make_gif_golden.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gif_cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CV_8UC4 = 24
+
+
+class _Info(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("loop_count", "frame_count", "bg_red", "bg_green", "bg_blue", "bg_alpha", "duration_ms")]
+
+
+@pytest.fixture(scope="module")
+def G(hip_lib):
+    L = hip_lib
+    L.giflib_decoder_create.restype = C.c_void_p
+    L.giflib_decoder_create.argtypes = [C.c_void_p]
+    for n in ("get_width", "get_height", "get_num_frames", "get_frame_width", "get_frame_height", "get_prev_frame_delay", "get_prev_frame_disposal",
+              "decode_frame_header", "skip_frame", "release"):
+        getattr(L, "giflib_decoder_" + n).argtypes = [C.c_void_p]
+    L.giflib_decoder_release.restype = None
+    L.giflib_decoder_decode_frame.argtypes = [C.c_void_p, C.c_void_p]
+    L.giflib_decoder_decode_frame.restype = C.c_bool
+    L.giflib_decoder_get_animation_info.argtypes = [C.c_void_p]
+    L.giflib_decoder_get_animation_info.restype = _Info
+    L.lilliput_hip_gif_read_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]
+    return L
+
+
+class Dec:
+    """gifDecoder of giflib.go:56-242 over the C ABI."""
+
+    def __init__(self, L, data):
+        self.L = L
+        self.buf = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+        self.mat = L.opencv_mat_create_from_data(len(data), 1, 0, self.buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)))
+        self.h = L.giflib_decoder_create(self.mat) if self.mat else None
+
+    def close(self):
+        if self.h:
+            self.L.giflib_decoder_release(self.h)
+        if self.mat:
+            self.L.opencv_mat_release(self.mat)
+
+    def info(self):
+        i = self.L.giflib_decoder_get_animation_info(self.h)
+        return [i.loop_count, i.frame_count, i.bg_red, i.bg_green, i.bg_blue, i.bg_alpha, i.duration_ms]
+
+
+def host_walk(L, data, skip=()):
+    """Host half only (no GPU): per frame (meta[10], indices); final state 1 eof / 2 header error / 3 decode failed."""
+    d = Dec(L, data)
+    if not d.h:
+        d.close()
+        return None
+    w, h = L.giflib_decoder_get_width(d.h), L.giflib_decoder_get_height(d.h)
+    frames, st, k = [], 0, 0
+    while True:
+        if k in skip:
+            st = L.giflib_decoder_skip_frame(d.h)
+            k += 1
+            if st:
+                st = 1 if st == 1 else 2
+                break
+            continue
+        st = L.giflib_decoder_decode_frame_header(d.h)
+        k += 1
+        if st:
+            st = 1 if st == 1 else 2
+            break
+        fw, fh = L.giflib_decoder_get_frame_width(d.h), L.giflib_decoder_get_frame_height(d.h)
+        idx = np.zeros(max(1, fw * fh), dtype=np.uint8)
+        meta = (C.c_int * 10)()
+        n = L.lilliput_hip_gif_read_frame(d.h, idx.ctypes.data, idx.size, meta, None)
+        if n < 0:
+            st = 3
+            break
+        frames.append((list(meta), idx[:n].copy()))
+    info = d.info()
+    d.close()
+    return w, h, frames, st, info
+
+
+def _host_digest(r):
+    if r is None:
+        return "none"
+    h = hashlib.sha1()
+    for meta, idx in r[2]:
+        h.update(np.array(meta[:10], dtype=np.int32).tobytes())
+        h.update(idx.tobytes())
+    return "%dx%d:%d:%d:%s:%s" % (r[0], r[1], len(r[2]), r[3], ",".join(map(str, r[4])), h.hexdigest()[:16])
+
+
+def _all_inputs():
+    c = dict(gif_cases.fixtures())
+    c.update(gif_cases.hand_cases())
+    c.update(gif_cases.fuzz_cases(41, 500))
+    return c
+
+
+def test_host_reader_matches_recorded_giflib_answers(G):
+    gold = json.load(open(os.path.join(HERE, "golden", "gif_golden.json")))["host"]
+    bad = [k for k, v in _all_inputs().items() if _host_digest(host_walk(G, v)) != gold[k]]
+    assert not bad, bad[:10]
+
+
+def test_host_reader_matches_giflib_live(G, oracle):
+    if oracle.ref_gif() is None:
+        pytest.skip("oracle/_ref/librefgif.so not built (needs /root/reference)")
+    cases = dict(gif_cases.fixtures())
+    cases.update(gif_cases.hand_cases())
+    cases.update(gif_cases.fuzz_cases(77, 700))
+    for name, data in cases.items():
+        for skip in ((), (1,)):
+            mine, ref = host_walk(G, data, skip), oracle.ref_gif_frames(data, skip=skip)
+            assert (mine is None) == (ref is None), name
+            if mine is None:
+                continue
+            assert mine[:2] == ref[:2] and mine[3] == ref[3] and len(mine[2]) == len(ref[2]), (name, skip, mine[3], ref[3])
+            for (mm, mi), (_, rm, ri) in zip(mine[2], ref[2]):
+                assert mm == rm[:10] and np.array_equal(mi, ri), (name, skip)
+            assert mine[4] == oracle.ref_gif_info(data), name
+
+
+def test_animation_info_known_answers_of_the_reference_tests(G):
+    """giflib_test.go:201-240: loop count, frame count, total duration."""
+    fx = gif_cases.fixtures()
+    for name, loops, frames, ms in (("party-discord.gif", 0, 16, 480), ("ferry_sunset.gif", 1, 1, 0), ("no-loop.gif", 1, 44, 4400),
+                                    ("duplicate_number_of_loops.gif", 2, 2, 0), ("dispose_bgnd.gif", 0, 5, 5000)):
+        d = Dec(G, fx[name])
+        i = d.info()
+        d.close()
+        assert (i[0], i[1], i[6]) == (loops, frames, ms), name
+
+
+def device_frames(L, data, lazy=False):
+    """Full decode through the ABI the way gifDecoder.DecodeTo drives it: a fresh Mat header over the same pixel buffer per frame."""
+    d = Dec(L, data)
+    if not d.h:
+        d.close()
+        return None
+    w, h = L.giflib_decoder_get_width(d.h), L.giflib_decoder_get_height(d.h)
+    fb = np.zeros(w * h * 4, dtype=np.uint8)
+    frames, st = [], 0
+    while True:
+        m = L.opencv_mat_create_from_data(w, h, CV_8UC4, fb.ctypes.data_as(C.c_void_p), C.c_size_t(fb.size))
+        st = L.giflib_decoder_decode_frame_header(d.h)
+        if st:
+            L.opencv_mat_release(m)
+            st = 1 if st == 1 else 2
+            break
+        ok = L.giflib_decoder_decode_frame(d.h, m)
+        if ok and lazy:
+            assert L.lilliput_hip_mat_sync_host(m) == 0
+        L.opencv_mat_release(m)
+        if not ok:
+            st = 3
+            break
+        frames.append((fb.reshape(h, w, 4).copy(), L.giflib_decoder_get_prev_frame_delay(d.h), L.giflib_decoder_get_prev_frame_disposal(d.h)))
+    d.close()
+    return w, h, frames, st
+
+
+def _canvas_digest(r):
+    if r is None:
+        return "none"
+    h = hashlib.sha1()
+    for f in r[2]:
+        h.update(f[0].tobytes())
+    return "%dx%d:%d:%d:%s" % (r[0], r[1], len(r[2]), r[3], h.hexdigest()[:16])
+
+
+@pytest.mark.gpu
+def test_frames_composited_on_device_match_recorded_reference(G):
+    gold = json.load(open(os.path.join(HERE, "golden", "gif_golden.json")))["canvas"]
+    cases = dict(gif_cases.fixtures())
+    cases.update(gif_cases.hand_cases())
+    cases.update(gif_cases.fuzz_cases(41, 120))
+    bad = [k for k, v in cases.items() if _canvas_digest(device_frames(G, v)) != gold[k]]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+def test_frames_composited_on_device_match_reference_live(G, oracle):
+    if oracle.ref_gif() is None:
+        pytest.skip("oracle/_ref/librefgif.so not built")
+    cases = dict(gif_cases.fixtures())
+    cases.update(gif_cases.hand_cases())
+    for name, data in cases.items():
+        mine, ref = device_frames(G, data), oracle.ref_gif_frames(data)
+        assert (mine is None) == (ref is None), name
+        if mine is None:
+            continue
+        assert mine[:2] == ref[:2] and mine[3] == ref[3] and len(mine[2]) == len(ref[2]), name
+        disp = {0: 0, 1: 0, 2: 1, 3: 2}
+        for k, ((canvas, delay, dispose), (rc, rm, _)) in enumerate(zip(mine[2], ref[2])):
+            assert np.array_equal(canvas, rc), (name, k)
+            assert delay == rm[6] and dispose == disp.get(rm[5], 0), (name, k)
+
+
+@pytest.mark.gpu
+def test_canvas_stays_on_device_with_lazy_write_back(G):
+    """Lazy host write-back: nothing reaches the pixel buffer until asked, and the frames are the same."""
+    data = gif_cases.fixtures()["restore_previous.gif"]
+    eager = device_frames(G, data)
+    G.lilliput_hip_set_lazy_host(1)
+    try:
+        lazy = device_frames(G, data, lazy=True)
+    finally:
+        G.lilliput_hip_set_lazy_host(0)
+    assert len(eager[2]) == len(lazy[2]) == 12
+    for a, b in zip(eager[2], lazy[2]):
+        assert np.array_equal(a[0], b[0])
