@@ -190,6 +190,8 @@ int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, 
 #define LILLIPUT_ERR_FRAMEBUF_NO_PIXELS 6
 #define LILLIPUT_ERR_ENCODE_TIMEOUT 7
 #define LILLIPUT_ERR_EOF 8
+#define LILLIPUT_ERR_SKIP_NOT_SUPPORTED 9   /* ErrSkipNotSupported, lilliput.go:29 */
+#define LILLIPUT_ERR_OPENCV_BASE 100        /* + OPENCV_ERROR_* : handleOpenCVError, opencv.go:399-426 */
 
 /* ops.go:18-22 */
 #define LILLIPUT_OPS_NO_RESIZE 0
@@ -271,6 +273,7 @@ void lilliput_decoder_close(lilliput_decoder d);
 int lilliput_decoder_header(lilliput_decoder d, int* width, int* height, int* pixel_type, int* orientation, int* num_frames, int* content_length);
 const char* lilliput_decoder_description(lilliput_decoder d);
 int lilliput_decoder_icc(lilliput_decoder d, void* dst, size_t cap);                    /* opencv.go:697-712 */
+int lilliput_decoder_animation_info(lilliput_decoder d, int out[4]);                    /* giflib.go:126-178: loops, frames, duration ms, background ARGB */
 lilliput_image_ops lilliput_new_image_ops(int max_size);                                /* ops.go:83-91 */
 void lilliput_image_ops_close(lilliput_image_ops o);
 void lilliput_image_ops_clear(lilliput_image_ops o);

@@ -20,4 +20,5 @@ from .binding import (  # noqa: F401
     build,
     lib,
     lib_path,
+    parse_raw_frames,
 )

@@ -94,6 +94,7 @@ def lib():
     L.lilliput_decoder_description.restype = C.c_char_p
     L.lilliput_decoder_description.argtypes = [C.c_void_p]
     L.lilliput_decoder_icc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.lilliput_decoder_animation_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.lilliput_new_image_ops.restype = C.c_void_p
     L.lilliput_new_image_ops.argtypes = [C.c_int]
     L.lilliput_image_ops_close.argtypes = [C.c_void_p]
@@ -175,6 +176,14 @@ class Decoder:
     def Description(self):
         return lib().lilliput_decoder_description(self._h).decode()
 
+    def AnimationInfo(self):
+        """GIF sources: (LoopCount, FrameCount, Duration in ms, BackgroundColor ARGB) of giflib.go:126-178."""
+        v = (C.c_int * 4)()
+        rc = lib().lilliput_decoder_animation_info(self._h, v)
+        if rc:
+            raise LilliputError(rc, "AnimationInfo")
+        return v[0], v[1], v[2], v[3] & 0xFFFFFFFF
+
     def ICC(self):
         out = C.create_string_buffer(32768)  # ICCProfileBufferSize
         return out.raw[: lib().lilliput_decoder_icc(self._h, out, 32768)]
@@ -227,6 +236,17 @@ class ImageOps:
             self.Close()
         except Exception:
             pass
+
+
+def parse_raw_frames(blob):
+    """Frames kept by the ".bgra-frames" test sink of ImageOps.Transform: [(HxWxC uint8 array, duration_ms)]."""
+    out, i = [], 0
+    while i + 16 <= len(blob):
+        w, h, cn, ms = np.frombuffer(blob, dtype=np.uint32, count=4, offset=i)
+        n = int(w) * int(h) * int(cn)
+        out.append((np.frombuffer(blob, dtype=np.uint8, count=n, offset=i + 16).reshape(int(h), int(w), int(cn)).copy(), int(ms)))
+        i += 16 + n
+    return out
 
 
 class BatchItemResult:

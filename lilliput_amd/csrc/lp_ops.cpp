@@ -155,19 +155,37 @@ struct Framebuffer {
     }
 };
 
-struct Decoder { // openCVDecoder, opencv.go:132-138
+struct Decoder { // openCVDecoder (opencv.go:132-138) or gifDecoder (giflib.go:14-28)
+    enum Kind { OPENCV, GIF } kind = OPENCV;
     const uint8_t* buf = nullptr;
     size_t len = 0;
     opencv_mat mat = nullptr;
     opencv_decoder dec = nullptr;
+    giflib_decoder gif = nullptr;
     bool has_read_header = false, has_decoded = false;
     int content_length = -1, num_frames = 0; // the buffer cannot change under a decoder: scanned once, not per Header() call
+    bool anim_read = false;                  // gifDecoder.readAnimationInfo: lazily, once
+    GifAnimationInfo anim = {1, 0, 255, 255, 255, 0, 0};
+    int frame_index = 0;
 };
 
 struct Header { int width, height, pixel_type, orientation, num_frames, content_length; };
 
-int decoder_header(Decoder* d, Header* h) // opencv.go:639-661
+const int kGifMaxFrameDimension = 10000; // defaultMaxFrameDimension, giflib.go:39
+
+int decoder_header(Decoder* d, Header* h)
 {
+    if (d->kind == Decoder::GIF) { // giflib.go:77-87
+        if (!d->anim_read) { d->anim = giflib_decoder_get_animation_info(d->gif); d->anim_read = true; }
+        h->width = giflib_decoder_get_width(d->gif);
+        h->height = giflib_decoder_get_height(d->gif);
+        h->pixel_type = CV_8UC4;
+        h->orientation = 1; // OrientationTopLeft
+        h->num_frames = d->anim.frame_count;
+        h->content_length = (int)d->len;
+        return LILLIPUT_OK;
+    }
+    // opencv.go:639-661
     if (!d->has_read_header && !opencv_decoder_read_header(d->dec)) return LILLIPUT_ERR_INVALID_IMAGE;
     d->has_read_header = true;
     if (!d->num_frames) d->num_frames = lp_detect_apng(d->buf, d->len) ? 2 : 1;
@@ -181,10 +199,28 @@ int decoder_header(Decoder* d, Header* h) // opencv.go:639-661
     return LILLIPUT_OK;
 }
 
-int decoder_decode_to(Decoder* d, Framebuffer* f) // opencv.go:816-839
+int decoder_decode_to(Decoder* d, Framebuffer* f)
 {
-    if (d->has_decoded) return LILLIPUT_ERR_EOF;
     Header h;
+    if (d->kind == Decoder::GIF) { // giflib.go:180-219
+        int e = decoder_header(d, &h);
+        if (e) return e;
+        e = f->resize_mat(h.width, h.height, h.pixel_type);
+        if (e) return e;
+        giflib_decoder_frame_state st = giflib_decoder_decode_frame_header(d->gif);
+        if (st == giflib_decoder_eof) return LILLIPUT_ERR_EOF;
+        if (st == giflib_decoder_error) return LILLIPUT_ERR_INVALID_IMAGE;
+        if (giflib_decoder_get_frame_width(d->gif) > kGifMaxFrameDimension || giflib_decoder_get_frame_height(d->gif) > kGifMaxFrameDimension) return LILLIPUT_ERR_INVALID_IMAGE;
+        if (!giflib_decoder_decode_frame(d->gif, f->mat)) return LILLIPUT_ERR_DECODING_FAILED;
+        f->duration = (int64_t)giflib_decoder_get_prev_frame_delay(d->gif) * 10 * 1000000ll;
+        f->blend = 1; // NoBlend
+        f->dispose = giflib_decoder_get_prev_frame_disposal(d->gif);
+        f->x_offset = f->y_offset = 0;
+        d->frame_index++;
+        return LILLIPUT_OK;
+    }
+    // opencv.go:816-839
+    if (d->has_decoded) return LILLIPUT_ERR_EOF;
     int e = decoder_header(d, &h);
     if (e) return e;
     e = f->resize_mat(h.width, h.height, h.pixel_type);
@@ -198,14 +234,38 @@ int decoder_decode_to(Decoder* d, Framebuffer* f) // opencv.go:816-839
     return LILLIPUT_OK;
 }
 
-struct Encoder { // openCVEncoder, opencv.go:141-146, 847-905
+int decoder_skip_frame(Decoder* d) // giflib.go:223-235 / opencv.go:841-843
+{
+    if (d->kind != Decoder::GIF) return LILLIPUT_ERR_SKIP_NOT_SUPPORTED;
+    giflib_decoder_frame_state st = giflib_decoder_skip_frame(d->gif);
+    if (st == giflib_decoder_eof) return LILLIPUT_ERR_EOF;
+    if (st == giflib_decoder_error) return LILLIPUT_ERR_INVALID_IMAGE;
+    return LILLIPUT_OK;
+}
+
+int skip_to_end(Decoder* d) // ops.go:337-346
+{
+    for (;;) {
+        int e = decoder_skip_frame(d);
+        if (e) return e;
+    }
+}
+
+struct Encoder { // openCVEncoder (opencv.go:141-146, 847-905), or the raw frame sink used by the tests
+    enum Kind { OPENCV, RAW_FRAMES } kind = OPENCV;
     opencv_encoder enc = nullptr;
     opencv_mat dst = nullptr;
     uint8_t* dst_buf = nullptr;
+    size_t dst_cap = 0, raw_len = 0;
+    bool flushed = false;
 };
+
+int opencv_status(int code) { return code == OPENCV_SUCCESS ? LILLIPUT_OK : LILLIPUT_ERR_OPENCV_BASE + code; } // handleOpenCVError, opencv.go:399-426
 
 struct ImageOps { // ops.go:68-106
     Framebuffer frames[2];
+    Framebuffer composite; // animatedCompositeBuffer: lives for one Transform
+    bool have_composite = false;
     int frame_index = 0;
     Framebuffer* active() { return &frames[frame_index]; }
     Framebuffer* secondary() { return &frames[1 - frame_index]; }
@@ -216,6 +276,32 @@ struct ImageOps { // ops.go:68-106
         secondary()->dispose = active()->dispose;
         secondary()->blend = active()->blend;
         swap();
+    }
+    void drop_composite() { if (have_composite) { composite.destroy(); have_composite = false; } }
+    int setup_animated(int w, int h, bool has_alpha) // ops.go:132-150
+    {
+        if (have_composite) return LILLIPUT_OK;
+        composite = Framebuffer();
+        composite.init(w, h);
+        if (!composite.buf) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        have_composite = true;
+        int e = composite.resize_mat(w, h, has_alpha ? CV_8UC4 : CV_8UC3); // Create3Channel / Create4Channel
+        if (e) return e;
+        composite.clear();
+        return opencv_status(opencv_mat_clear_to_transparent(composite.mat, 0, 0, w, h));
+    }
+    int apply_blend() // ops.go:566-582
+    {
+        Framebuffer* a = active();
+        if (a->blend == 0) return opencv_status(opencv_copy_to_region_with_alpha(a->mat, composite.mat, a->x_offset, a->y_offset, a->width, a->height));
+        if (a->blend == 1) return opencv_status(opencv_copy_to_region(a->mat, composite.mat, a->x_offset, a->y_offset, a->width, a->height));
+        return LILLIPUT_OK;
+    }
+    int apply_dispose() // ops.go:552-563
+    {
+        Framebuffer* a = active();
+        if (a->dispose == 1) return opencv_status(opencv_mat_clear_to_transparent(composite.mat, a->x_offset, a->y_offset, a->width, a->height));
+        return LILLIPUT_OK;
     }
 };
 
@@ -236,22 +322,27 @@ void lilliput_fit_crop_rect(int fw, int fh, int width, int height, int* left, in
 int lilliput_detect_content_length(const void* buf, size_t len) { return lp_detect_content_length((const uint8_t*)buf, len); }
 int lilliput_detect_apng(const void* buf, size_t len) { return lp_detect_apng((const uint8_t*)buf, len) ? 1 : 0; }
 
-int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // lilliput.go:129-164 + opencv.go:442-463
+int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // lilliput.go:129-164 + opencv.go:442-463 + giflib.go:56-75
 {
     *out = nullptr;
     if (!buf || len == 0) return LILLIPUT_ERR_INVALID_IMAGE;
     const uint8_t* b = (const uint8_t*)buf;
-    // GIF / WebP / AVIF sources have their own decoders in the reference (lilliput.go:136-154); they are outside this build.
-    if ((len >= 6 && (memcmp(b, "GIF87a", 6) == 0 || memcmp(b, "GIF89a", 6) == 0)) ||
-        (len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) ||
+    // WebP / AVIF sources have their own decoders in the reference (lilliput.go:141-149); they are outside this build.
+    if ((len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) ||
         (len >= 12 && memcmp(b + 4, "ftyp", 4) == 0 && (memcmp(b + 8, "avif", 4) == 0 || memcmp(b + 8, "avis", 4) == 0)))
         return LILLIPUT_ERR_UNSUPPORTED;
     opencv_mat mat = opencv_mat_create_from_data((int)len, 1, CV_8U, (void*)buf, len);
     if (!mat) return LILLIPUT_ERR_BUF_TOO_SMALL;
-    opencv_decoder dec = opencv_decoder_create(mat);
-    if (!dec) { opencv_mat_release(mat); return LILLIPUT_ERR_INVALID_IMAGE; }
     auto d = new Decoder();
-    d->buf = b; d->len = len; d->mat = mat; d->dec = dec;
+    d->buf = b; d->len = len; d->mat = mat;
+    if (len >= 6 && (memcmp(b, "GIF87a", 6) == 0 || memcmp(b, "GIF89a", 6) == 0)) { // isGIF, lilliput.go:100-102
+        d->kind = Decoder::GIF;
+        d->gif = giflib_decoder_create(mat);
+        if (!d->gif) { opencv_mat_release(mat); delete d; return LILLIPUT_ERR_INVALID_IMAGE; } // newGifDecoder leaves the Mat to the GC'd Go object; here it is freed
+    } else {
+        d->dec = opencv_decoder_create(mat);
+        if (!d->dec) { opencv_mat_release(mat); delete d; return LILLIPUT_ERR_INVALID_IMAGE; }
+    }
     *out = d;
     return LILLIPUT_OK;
 }
@@ -260,7 +351,8 @@ void lilliput_decoder_close(lilliput_decoder dd)
 {
     auto d = static_cast<Decoder*>(dd);
     if (!d) return;
-    opencv_decoder_release(d->dec);
+    if (d->gif) giflib_decoder_release(d->gif);
+    if (d->dec) opencv_decoder_release(d->dec);
     opencv_mat_release(d->mat);
     delete d;
 }
@@ -279,16 +371,34 @@ int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* p
     return LILLIPUT_OK;
 }
 
-const char* lilliput_decoder_description(lilliput_decoder dd) { return opencv_decoder_get_description(static_cast<Decoder*>(dd)->dec); }
-
-int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712
+const char* lilliput_decoder_description(lilliput_decoder dd)
 {
     auto d = static_cast<Decoder*>(dd);
-    if (!d || !dst) return 0;
+    return d->kind == Decoder::GIF ? "GIF" : opencv_decoder_get_description(d->dec); // giflib.go:107-109
+}
+
+int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712; gifDecoder.ICC is empty (giflib.go:122-124)
+{
+    auto d = static_cast<Decoder*>(dd);
+    if (!d || !dst || d->kind == Decoder::GIF) return 0;
     const char* desc = opencv_decoder_get_description(d->dec);
     if (desc && strcmp(desc, "JPEG") == 0) return opencv_decoder_get_jpeg_icc((void*)d->buf, d->len, dst, cap);
     if (desc && strcmp(desc, "PNG") == 0) return opencv_decoder_get_png_icc((void*)d->buf, d->len, dst, cap);
     return 0;
+}
+
+// gifDecoder.LoopCount / FrameCount / Duration / BackgroundColor (giflib.go:126-178): {loop_count, frame_count, duration_ms, background ARGB}
+int lilliput_decoder_animation_info(lilliput_decoder dd, int out[4])
+{
+    auto d = static_cast<Decoder*>(dd);
+    if (!d || d->kind != Decoder::GIF) return LILLIPUT_ERR_UNSUPPORTED;
+    Header h;
+    (void)decoder_header(d, &h);
+    out[0] = d->anim.loop_count;
+    out[1] = d->anim.frame_count;
+    out[2] = d->anim.duration_ms;
+    out[3] = (int)(((uint32_t)(uint8_t)d->anim.bg_red << 16) | ((uint32_t)(uint8_t)d->anim.bg_green << 8) | (uint32_t)(uint8_t)d->anim.bg_blue | ((uint32_t)(uint8_t)d->anim.bg_alpha << 24));
+    return LILLIPUT_OK;
 }
 
 lilliput_image_ops lilliput_new_image_ops(int max_size) // ops.go:83-91
@@ -300,13 +410,20 @@ lilliput_image_ops lilliput_new_image_ops(int max_size) // ops.go:83-91
     return o;
 }
 
-void lilliput_image_ops_clear(lilliput_image_ops oo) { auto o = static_cast<ImageOps*>(oo); o->frames[0].clear(); o->frames[1].clear(); }
+void lilliput_image_ops_clear(lilliput_image_ops oo) // ops.go:111-117
+{
+    auto o = static_cast<ImageOps*>(oo);
+    o->frames[0].clear();
+    o->frames[1].clear();
+    if (o->have_composite) o->composite.clear();
+}
 void lilliput_image_ops_close(lilliput_image_ops oo)
 {
     auto o = static_cast<ImageOps*>(oo);
     if (!o) return;
     o->frames[0].destroy();
     o->frames[1].destroy();
+    o->drop_composite();
     delete o;
 }
 
@@ -316,9 +433,10 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     auto d = static_cast<Decoder*>(dd);
     *dst_len = 0;
     if (!o || !d || !opt || !dst || dst_cap == 0) return LILLIPUT_ERR_INVALID_IMAGE;
-    // The two framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so the
-    // decoded and resized frames stay on the device for the duration of the call.
+    // The framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so decoded, composited
+    // and resized frames stay on the device for the duration of the call.
     struct LazyScope { int prev = lp_lazy_host_scope(1); ~LazyScope() { lp_lazy_host_scope(prev); } } lazy_scope;
+    struct CompositeScope { ImageOps* o; ~CompositeScope() { o->drop_composite(); } } composite_scope{o}; // ops.go:353-358
     // initializeTransform (ops.go:483-546)
     Header hdr;
     int e = decoder_header(d, &hdr);
@@ -328,30 +446,62 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     if (ext == ".gif" || ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
     Encoder enc;
     enc.dst_buf = (uint8_t*)dst;
-    enc.dst = opencv_mat_create_empty_from_data((int)dst_cap, dst);
-    if (!enc.dst) return LILLIPUT_ERR_BUF_TOO_SMALL;
-    enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
-    if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
-    struct Guard { Encoder& e; ~Guard() { opencv_encoder_release(e.enc); opencv_mat_release(e.dst); } } guard{enc};
+    enc.dst_cap = dst_cap;
+    if (ext == ".bgra-frames") {
+        // Test access, not a reference format: an "animated encoder" that keeps every frame it is handed as
+        // [u32 width][u32 height][u32 channels][u32 duration_ms][pixels] and, like the reference's animated encoders
+        // (webp.go:220-256, giflib.go:259-292), returns content only when flushed with a nil frame.
+        enc.kind = Encoder::RAW_FRAMES;
+    } else {
+        enc.dst = opencv_mat_create_empty_from_data((int)dst_cap, dst);
+        if (!enc.dst) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
+        if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
+    }
+    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); } } guard{enc};
     // newOpenCVEncoder asks the decoder for its ICC profile on every Transform (opencv.go:863); the JPEG writer then drops it
     // (cv::imencode has no ICC channel), so the read is kept for its cost profile only.
-    {
-        static thread_local std::vector<uint8_t> icc_scratch(32768); // ICCProfileBufferSize, lilliput.go
+    if (enc.kind == Encoder::OPENCV) {
+        static thread_local std::vector<uint8_t> icc_scratch(32768); // ICCProfileBufferSize, lilliput.go:13-16
         (void)lilliput_decoder_icc(dd, icc_scratch.data(), icc_scratch.size());
     }
 
-    auto encode = [&](Framebuffer* f, size_t* n) -> int { // opencv.go:872-900
+    // Encoder.Encode: *n > 0 = finished content, 0 with LILLIPUT_OK = "give me another frame"
+    auto encode = [&](Framebuffer* f, size_t* n) -> int {
+        *n = 0;
+        if (enc.kind == Encoder::RAW_FRAMES) {
+            if (enc.flushed) return LILLIPUT_ERR_EOF;
+            if (!f) { enc.flushed = true; *n = enc.raw_len; return enc.raw_len ? LILLIPUT_OK : LILLIPUT_ERR_EOF; }
+            const int cn = opencv_type_channels(f->pixel_type);
+            const size_t px = (size_t)f->width * f->height * cn;
+            if (enc.raw_len + 16 + px > enc.dst_cap) return LILLIPUT_ERR_BUF_TOO_SMALL;
+            if (lilliput_hip_mat_sync_host(f->mat)) return LILLIPUT_ERR_DEVICE;
+            const uint32_t head[4] = {(uint32_t)f->width, (uint32_t)f->height, (uint32_t)cn, (uint32_t)(f->duration / 1000000ll)};
+            memcpy(enc.dst_buf + enc.raw_len, head, 16);
+            memcpy(enc.dst_buf + enc.raw_len + 16, opencv_mat_get_data(f->mat), px);
+            enc.raw_len += 16 + px;
+            return LILLIPUT_OK;
+        }
+        // opencv.go:872-900
         if (!f) return LILLIPUT_ERR_EOF;
         if (!opencv_encoder_write(enc.enc, f->mat, opt->encode_options, opt->encode_options_len)) return LILLIPUT_ERR_INVALID_IMAGE;
         if (opencv_mat_get_data(enc.dst) != (void*)enc.dst_buf) return LILLIPUT_ERR_BUF_TOO_SMALL;
         *n = (size_t)opencv_mat_get_height(enc.dst);
         return LILLIPUT_OK;
     };
+    auto encode_empty = [&]() -> int { // ops.go:286-292 encodeEmpty + the caller returning its result
+        size_t n = 0;
+        int e2 = encode(nullptr, &n);
+        if (e2) return e2;
+        *dst_len = n;
+        return LILLIPUT_OK;
+    };
 
     int frame_count = 0;
     int64_t duration = 0;
     const int64_t timeout_at = now_ns() + opt->encode_timeout_ns;
-    const bool animated = hdr.num_frames > 1;
+    const bool animated = hdr.num_frames > 1;                 // ImageHeader.IsAnimated, opencv.go:189-191
+    const bool has_alpha = opencv_type_channels(hdr.pixel_type) == 4; // ImageHeader.HasAlpha, opencv.go:194-196
     for (;;) { // ops.go:371-443
         e = decoder_decode_to(d, o->active());
         bool empty_frame = false;
@@ -360,7 +510,11 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
             empty_frame = true;
         }
         duration += o->active()->duration;
-        if (opt->max_encode_duration_ns != 0 && duration > opt->max_encode_duration_ns) return LILLIPUT_ERR_EOF; // skipToEnd: openCVDecoder cannot skip
+        if (opt->max_encode_duration_ns != 0 && duration > opt->max_encode_duration_ns) {
+            e = skip_to_end(d);
+            if (e != LILLIPUT_ERR_EOF) return e;
+            return encode_empty();
+        }
         o->active()->orientation_transform(hdr.orientation); // unconditional (ops.go:392)
         bool swapped = false;
         if (!empty_frame) { // transformCurrentFrame (ops.go:449-472)
@@ -369,27 +523,36 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
                 if (opt->normalize_orientation && lp_swaps_axes(hdr.orientation)) { in_w = hdr.height; in_h = hdr.width; }
                 int out_w = opt->width, out_h = opt->height;
                 if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { out_w = in_w; out_h = in_h; }
-                if (animated) return LILLIPUT_ERR_UNSUPPORTED; // APNG sources take the composite path (outside this build)
-                if (opt->resize_method == LILLIPUT_OPS_FIT || opt->resize_method == LILLIPUT_OPS_NO_RESIZE) {
-                    int nw, nh;
-                    lp_calculate_expected_size(in_w, in_h, out_w, out_h, &nw, &nh);
-                    e = o->active()->fit(nw, nh, o->secondary());
-                } else if (opt->resize_method == LILLIPUT_OPS_RESIZE) {
-                    e = o->active()->resize_to(out_w, out_h, o->secondary());
-                } else return LILLIPUT_ERR_INVALID_IMAGE;
-                if (e) return e;
+                if (opt->resize_method != LILLIPUT_OPS_FIT && opt->resize_method != LILLIPUT_OPS_NO_RESIZE && opt->resize_method != LILLIPUT_OPS_RESIZE)
+                    return LILLIPUT_ERR_INVALID_IMAGE;
+                const bool is_fit = opt->resize_method != LILLIPUT_OPS_RESIZE;
+                int nw = out_w, nh = out_h;
+                if (is_fit) lp_calculate_expected_size(in_w, in_h, out_w, out_h, &nw, &nh); // ops.go:171
+                if (animated) { // ops.go:173-197, 208-229: composite -> resize the composite -> dispose
+                    if ((e = o->setup_animated(in_w, in_h, has_alpha))) return e;
+                    if ((e = o->apply_blend())) return e;
+                    e = is_fit ? o->composite.fit(nw, nh, o->secondary()) : o->composite.resize_to(out_w, out_h, o->secondary());
+                    if (e) return e;
+                    if ((e = o->apply_dispose())) return e;
+                } else {
+                    e = is_fit ? o->active()->fit(nw, nh, o->secondary()) : o->active()->resize_to(out_w, out_h, o->secondary());
+                    if (e) return e;
+                }
                 o->copy_props_and_swap();
                 swapped = true;
             }
         }
         size_t n = 0;
         e = encode(empty_frame ? nullptr : o->active(), &n);
-        if (e == LILLIPUT_ERR_EOF) return LILLIPUT_ERR_EOF; // Encode(nil) on the OpenCV encoder: io.EOF (opencv.go:873-875)
-        if (e) return e;
+        if (e) return e; // Encode(nil) on the OpenCV encoder: io.EOF (opencv.go:873-875)
         if (n) { *dst_len = n; return LILLIPUT_OK; }
         frame_count++;
-        if (opt->disable_animated_output) return LILLIPUT_ERR_EOF;
-        if (opt->max_encode_frames != 0 && frame_count == opt->max_encode_frames) return LILLIPUT_ERR_EOF;
+        if (opt->disable_animated_output) return encode_empty();
+        if (opt->max_encode_frames != 0 && frame_count == opt->max_encode_frames) {
+            e = skip_to_end(d);
+            if (e != LILLIPUT_ERR_EOF) return e;
+            return encode_empty();
+        }
         if (now_ns() > timeout_at) return LILLIPUT_ERR_ENCODE_TIMEOUT;
         if (swapped) o->swap();
     }

@@ -220,3 +220,72 @@ def test_canvas_stays_on_device_with_lazy_write_back(G):
     assert len(eager[2]) == len(lazy[2]) == 12
     for a, b in zip(eager[2], lazy[2]):
         assert np.array_equal(a[0], b[0])
+
+
+# ------------------------------------------------------------------------------------------ ImageOps.Transform on GIF sources
+def _transform(data, **kw):
+    import lilliput_amd as la
+
+    d = la.Decoder(data)
+    ops = la.ImageOps(1024)
+    try:
+        kw.setdefault("EncodeTimeout", 30 * 10**9)
+        return ops.Transform(d, la.ImageOptions(**kw), dst_cap=32 << 20)
+    finally:
+        ops.Close()
+        d.Close()
+
+
+@pytest.mark.gpu
+def test_gif_to_jpeg_thumbnail_is_the_first_composited_frame(G, oracle):
+    """GIF -> .jpeg: the OpenCV encoder returns content on the first frame, so the output is frame 0 through the animated
+    composite path (ops.go:173-197), alpha dropped by the JPEG writer."""
+    import lilliput_amd as la
+
+    for name, w, h in (("party-discord.gif", 16, 16), ("restore_previous.gif", 64, 48), ("ferry_sunset.gif", 200, 200)):
+        data = gif_cases.fixtures()[name]
+        out = _transform(data, FileType=".jpeg", Width=w, Height=h, ResizeMethod=la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
+        canvas = oracle.ref_gif_frames(data, max_frames=1)[2][0][0]
+        exp = oracle.transform_static(canvas, 1, w, h, oracle.FIT, False)
+        assert out == oracle.jpeg_encode(exp, 85), name
+
+
+@pytest.mark.gpu
+def test_animated_loop_composites_resizes_and_disposes_every_frame(G, oracle):
+    """The whole animated loop of ImageOps.Transform (ops.go:371-443) through the raw frame sink: every output frame is the
+    reference canvas of that frame, fitted / resized / passed through, with the frame delay carried along."""
+    import lilliput_amd as la
+
+    fx = gif_cases.fixtures()
+    for name in ("party-discord.gif", "restore_previous.gif", "dispose_bgnd.gif", "no_gce_first_frame.gif"):
+        ref = oracle.ref_gif_frames(fx[name])
+        for method, w, h in ((la.ImageOpsFit, 20, 12), (la.ImageOpsResize, 33, 17), (la.ImageOpsNoResize, 0, 0), (la.ImageOpsFit, 4096, 4096)):
+            frames = la.parse_raw_frames(_transform(fx[name], FileType=".bgra-frames", Width=w, Height=h, ResizeMethod=method))
+            assert len(frames) == len(ref[2]), (name, method)
+            for k, ((got, ms), (canvas, meta, _)) in enumerate(zip(frames, ref[2])):
+                exp = oracle.transform_static(canvas, 1, w, h, {la.ImageOpsFit: oracle.FIT, la.ImageOpsResize: oracle.RESIZE, la.ImageOpsNoResize: oracle.NO_RESIZE}[method], False)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (name, method, k)
+                assert ms == meta[6] * 10, (name, k)
+
+
+@pytest.mark.gpu
+def test_animated_loop_limits(G, oracle):
+    import lilliput_amd as la
+
+    data = gif_cases.fixtures()["no-loop.gif"]           # 44 frames, 100 ms each
+    d = la.Decoder(data)
+    assert d.AnimationInfo()[:3] == (1, 44, 4400) and d.Description() == "GIF" and d.ICC() == b""
+    assert d.Header()["num_frames"] == 44 and d.Header()["pixel_type"] == CV_8UC4
+    d.Close()
+    n = lambda **kw: len(la.parse_raw_frames(_transform(data, FileType=".bgra-frames", Width=32, Height=32, **kw)))
+    assert n() == 44
+    assert n(MaxEncodeFrames=5) == 5                      # skipToEnd + flush (ops.go:425-431)
+    assert n(DisableAnimatedOutput=True) == 1             # ops.go:420-423
+    assert n(MaxEncodeDuration=1050 * 10**6) == 10        # frames are dropped once their running duration passes the cap (ops.go:384-390)
+    with pytest.raises(la.LilliputError) as e:
+        _transform(data, FileType=".bgra-frames", Width=32, Height=32, EncodeTimeout=1)
+    assert e.value.code == 7                              # ErrEncodeTimeout after the first frame
+    # a static source through the same sink: one frame, delivered by the flush
+    jpg = open(os.path.join(HERE, "golden", "inputs", "coast.jpg"), "rb").read()
+    fr = la.parse_raw_frames(_transform(jpg, FileType=".bgra-frames", Width=32, Height=24, ResizeMethod=la.ImageOpsFit))
+    assert len(fr) == 1 and np.array_equal(fr[0][0], oracle.transform_static(oracle.jpeg_decode(jpg), 1, 32, 24, oracle.FIT, False))
