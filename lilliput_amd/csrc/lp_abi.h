@@ -43,6 +43,7 @@ struct LpEncoder {
 };
 
 LpEngine* lp_thread_engine();
+int lp_thread_device(int device); // device for this thread's one-image ABI calls (-1 = default); returns the previous setting
 void lp_set_error(const std::string& s);
 bool lp_mat_to_device(LpMat* m, LpEngine* eng);
 bool lp_mat_to_host(LpMat* m, LpEngine* eng);

@@ -32,12 +32,17 @@ extern "C" int lilliput_hip_device_count(void)
     return n;
 }
 
+static thread_local int t_device = -1; // lp_thread_device: which GPU this thread's one-image calls run on (-1: LILLIPUT_HIP_DEVICE, else 0)
+int lp_thread_device(int device) { int prev = t_device; t_device = device; return prev; }
+
 LpEngine* lp_thread_engine()
 {
     static thread_local std::unique_ptr<LpEngine> eng;
-    if (!eng) {
-        int dev = 0;
-        if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e);
+    static thread_local int eng_dev = -1;
+    int dev = t_device;
+    if (dev < 0) { dev = 0; if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e); }
+    if (!eng || eng_dev != dev) {
+        eng_dev = dev;
         eng.reset(new LpEngine(dev));
         if (!eng->ok()) {
             lp_set_error(eng->last_error());

@@ -42,6 +42,11 @@ struct LpBatch {
     size_t n_items = 0;
     uint32_t S = 0, C = 0;
     LpTimings tm = {};
+    // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path): copied at
+    // upload, transformed one by one on the calling thread while the JPEG parts run
+    std::vector<std::pair<int, std::vector<uint8_t>>> other;
+    lilliput_image_ops other_ops = nullptr;
+    ~LpBatch() { if (other_ops) lilliput_image_ops_close(other_ops); }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
     {
@@ -117,10 +122,16 @@ int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item*
     if (!b) return LILLIPUT_ERR_DEVICE;
     b->n_items = n;
     b->parse_status.assign(n, LILLIPUT_OK);
+    b->other.clear();
     std::vector<int> valid;
     std::vector<LpJpegHeader> hv;
     for (size_t i = 0; i < n; i++) {
         LpJpegHeader h;
+        const uint8_t* sp = (const uint8_t*)items[i].src;
+        if (sp && items[i].src_len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) { // lilliput.go:100-102 isGIF
+            b->other.emplace_back((int)i, std::vector<uint8_t>(sp, sp + items[i].src_len));
+            continue;
+        }
         int rc = (items[i].src && items[i].src_len) ? lp_jpeg_parse((const uint8_t*)items[i].src, items[i].src_len, &h) : LP_PARSE_NOT_JPEG;
         b->parse_status[i] = map_parse(rc);
         if (rc == LP_PARSE_OK) { valid.push_back((int)i); hv.push_back(h); }
@@ -357,6 +368,48 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     return LILLIPUT_OK;
 }
 
+// GIF items: Decoder + ImageOps.Transform of the Go-API mirror (the JPEG writer returns after the first composited frame)
+static void run_other(LpBatch* b, const lilliput_batch_options* opt)
+{
+    if (b->other.empty()) return;
+    const int prev_dev = lp_thread_device(b->device);
+    if (!b->other_ops) b->other_ops = lilliput_new_image_ops(8192);
+    const int enc_opts[2] = {CV_IMWRITE_JPEG_QUALITY, opt->jpeg_quality};
+    lilliput_image_options io;
+    memset(&io, 0, sizeof(io));
+    io.file_type = ".jpeg";
+    io.width = opt->width; io.height = opt->height;
+    io.resize_method = opt->resize_method;
+    io.normalize_orientation = opt->normalize_orientation;
+    io.encode_options = enc_opts;
+    io.encode_options_len = opt->jpeg_quality ? 2 : 0;
+    io.encode_timeout_ns = 30ll * 1000000000ll;
+    for (auto& it : b->other) {
+        const size_t i = (size_t)it.first;
+        if (!b->other_ops) { b->status[i] = LILLIPUT_ERR_DEVICE; continue; }
+        lilliput_decoder d = nullptr;
+        int rc = lilliput_new_decoder(it.second.data(), it.second.size(), &d);
+        if (!rc) {
+            int w = 0, h = 0;
+            (void)lilliput_decoder_header(d, &w, &h, nullptr, nullptr, nullptr, nullptr);
+            std::vector<uint8_t>& out = b->out_bytes[i];
+            out.resize((size_t)std::max(opt->width, 1) * std::max(opt->height, 1) * 3 + ((size_t)w * h * 3 + 65536));
+            size_t n = 0;
+            rc = lilliput_image_ops_transform(b->other_ops, d, &io, out.data(), out.size(), &n);
+            if (!rc) {
+                out.resize(n);
+                b->out_len[i] = (uint32_t)n;
+                if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { b->out_w[i] = w; b->out_h[i] = h; }
+                else if (opt->resize_method == LILLIPUT_OPS_FIT) lilliput_calculate_expected_size(w, h, opt->width, opt->height, &b->out_w[i], &b->out_h[i]);
+                else { b->out_w[i] = std::max(opt->width, 1); b->out_h[i] = std::max(opt->height, 1); }
+            }
+            lilliput_decoder_close(d);
+        }
+        b->status[i] = rc;
+    }
+    (void)lp_thread_device(prev_dev);
+}
+
 int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
 {
     auto b = static_cast<LpBatch*>(bb);
@@ -372,13 +425,14 @@ int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* 
     const auto t_run0 = std::chrono::steady_clock::now();
     size_t active = 0;
     for (auto& p : b->parts) active += p.items.empty() ? 0 : 1;
-    if (active <= 1) {
+    if (active <= 1 && b->other.empty()) {
         for (auto& p : b->parts) p.rc = p.items.empty() ? LILLIPUT_OK : run_part(b, p, opt, trace);
     } else {
         std::vector<std::thread> th;
         for (auto& p : b->parts)
             if (!p.items.empty()) th.emplace_back([b, &p, opt, trace] { p.rc = run_part(b, p, opt, trace); });
             else p.rc = LILLIPUT_OK;
+        run_other(b, opt);
         for (auto& t : th) t.join();
     }
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -289,3 +289,23 @@ def test_animated_loop_limits(G, oracle):
     jpg = open(os.path.join(HERE, "golden", "inputs", "coast.jpg"), "rb").read()
     fr = la.parse_raw_frames(_transform(jpg, FileType=".bgra-frames", Width=32, Height=24, ResizeMethod=la.ImageOpsFit))
     assert len(fr) == 1 and np.array_equal(fr[0][0], oracle.transform_static(oracle.jpeg_decode(jpg), 1, 32, 24, oracle.FIT, False))
+
+
+@pytest.mark.gpu
+def test_batch_serves_gif_items_next_to_jpegs(G, oracle, fixture_bytes):
+    """lilliput_hip_batch_transform: GIF items take the one-image path (first frame -> JPEG) while the JPEG parts run."""
+    import lilliput_amd as la
+
+    fx = gif_cases.fixtures()
+    names = ["party-discord.gif", "restore_previous.gif", "ferry_sunset.gif"]
+    sources = [fixture_bytes["coast.jpg"], fx[names[0]], fixture_bytes["field.jpg"], fx[names[1]], fx[names[2]], b"GIF89a" + b"\0" * 4]
+    b = la.Batch(0)
+    res = b.transform(sources, 48, 48, quality=80)
+    b.close()
+    assert [r.status for r in res] == [0, 0, 0, 0, 0, 1]
+    for k, n in ((1, names[0]), (3, names[1]), (4, names[2])):
+        canvas = oracle.ref_gif_frames(fx[n], max_frames=1)[2][0][0]
+        exp = oracle.transform_static(canvas, 1, 48, 48, oracle.FIT, False)
+        assert res[k].data == oracle.jpeg_encode(exp, 80), n
+        assert (res[k].width, res[k].height) == exp.shape[1::-1]
+    assert res[0].data == oracle.transform_jpeg_thumbnail(fixture_bytes["coast.jpg"], 48, 48, 80)
