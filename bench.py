@@ -155,7 +155,7 @@ def main():
         kernels = {
             "k_huff_spec (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
             "k_huff_verify (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
-            "k_huff_write + k_dc_scan (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
+            "k_huff_write + k_dc_sum + k_dc_apply (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
             "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
             "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
             "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
@@ -174,9 +174,9 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "k_huff_write" if dom[0].startswith("k_huff_write") else dom[0].split(" ")[0]
+            keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
             launch_images = min(args.chunk or 128, args.batch)
-            traffic = round(pm[key]["hbm_bytes_per_image"] * launch_images)
+            traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
         except Exception:
             traffic = None
         out = {

@@ -39,6 +39,6 @@ else:
         if not k.startswith("k_"):
             continue
         f, w = fetch[k], write.get(k, 0.0)
-        out[k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "images_per_launch": n, "hbm_bytes_per_image": (2 * f + w) * 1024 / n}
+        out[k.split("<")[0]] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "images_per_launch": n, "hbm_bytes_per_image": (2 * f + w) * 1024 / n}
         print("| `%s` | %.0f | %.2f | %.0f | %.2f |" % (k, f, 2 * f * 1024 / n / 1e6, w, w * 1024 / n / 1e6))
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "r01_pmc_traffic.json"), "w"), indent=1)
