@@ -70,8 +70,9 @@ int opencv_type_depth(int type);
 int opencv_type_channels(int type);
 int opencv_type_convert_depth(int type, int depth);
 
-/* opencv.hpp:65-74 -- JPEG sources are decoded on the device; any other container yields NULL from
- * opencv_decoder_create (the Go caller maps that to ErrInvalidImage, opencv.go:453-456). */
+/* opencv.hpp:65-74 -- JPEG sources are decoded on the device; PNG sources are inflated on the host and un-filtered / expanded
+ * on the device; any other container yields NULL from opencv_decoder_create (the Go caller maps that to ErrInvalidImage,
+ * opencv.go:453-456). */
 opencv_decoder opencv_decoder_create(const opencv_mat buf);
 const char* opencv_decoder_get_description(const opencv_decoder d);
 void opencv_decoder_release(opencv_decoder d);
@@ -240,6 +241,9 @@ int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch b, const void* src, size_t
 int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch b, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph);
 const char* lilliput_hip_last_error(void);
 int lilliput_hip_device_count(void);
+
+/* Test access (no device work): number of inflated image-data bytes of a PNG, or -1 when libpng would reject the file. */
+long lilliput_hip_png_inflate_check(const void* data, size_t len);
 
 /* Lazy host write-back for Part A. Off (the default): every opencv_* call that produces pixels copies them into
  * the caller's buffer before it returns, as cv::Mat over Go memory does (opencv.go:258-267). On: pixels stay on

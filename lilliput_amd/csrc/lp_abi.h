@@ -6,6 +6,7 @@
 
 #include "../../include/lilliput_hip.h"
 #include "lp_engine.h"
+#include "lp_png.h"
 
 struct LpDevBlock {
     void* p = nullptr;
@@ -33,9 +34,12 @@ struct LpMat {
 struct LpDecoder {
     const uint8_t* data = nullptr;
     size_t len = 0;
+    bool is_png = false;            // which of cv::findDecoder's signatures matched
     bool parsed = false;
     int parse_rc = 0;
     LpJpegHeader hdr;
+    LpPngInfo png;
+    int png_channels = 0;           // channels of the Mat cv::PngDecoder::readHeader announces
 };
 
 struct LpEncoder {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/lilliput_hip.h"
+#include "lp_png.h"
 
 namespace {
 // ------------------------------------------------------------------------------------------------ JPEG
@@ -166,158 +167,11 @@ int jpeg_icc_assemble(const std::vector<App2>& app2, uint8_t* dst, size_t cap)
     return (int)total;
 }
 
-// ------------------------------------------------------------------------------------------------ PNG
-const uint8_t kPngSig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
-inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-inline bool is_type(const uint8_t* t, const char* name) { return memcmp(t, name, 4) == 0; }
-
-struct PngInfo {
-    bool have_cicp = false;
-    uint8_t cicp[4] = {0, 0, 0, 0};
-    std::vector<uint8_t> icc;
-};
-
-// ICC profile checks libpng applies before it keeps an iCCP profile (png.c png_icc_check_length/_header/_tag_table)
-bool icc_profile_acceptable(const std::vector<uint8_t>& p, int color_type)
-{
-    if (p.size() < 132) return false;
-    const uint32_t plen = be32(p.data());
-    if (plen != p.size()) return false;
-    if ((plen & 3) && p[8] > 3) return false;                                // "invalid length": from ICC v4 on the size is a multiple of four
-    const uint32_t tags = be32(p.data() + 128);
-    if (tags > 357913930u || 132 + (uint64_t)tags * 12 > plen) return false; // "tag count too large"
-    if (be32(p.data() + 64) >= 0xffff) return false;                         // rendering intent out of range: "invalid rendering intent"
-    if (be32(p.data() + 36) != 0x61637370u) return false;                    // 'acsp'
-    static const uint8_t d50[12] = {0x00, 0x00, 0xf6, 0xd6, 0x00, 0x01, 0x00, 0x00, 0x00, 0x00, 0xd3, 0x2d};
-    (void)d50; // a PCS illuminant other than D50 only draws a warning
-    const uint32_t space = be32(p.data() + 16);
-    if (space == 0x52474220u) { if (!(color_type & 2)) return false; }       // 'RGB ' needs a colour PNG
-    else if (space == 0x47524159u) { if (color_type & 2) return false; }     // 'GRAY' needs a grey PNG
-    else return false;                                                       // "invalid ICC profile color space"
-    const uint32_t cls = be32(p.data() + 12);
-    if (cls == 0x61627374u /* abst */ || cls == 0x6c696e6bu /* link */) return false; // not a display/input/output profile: rejected
-    if (cls == 0x6e6d636cu /* nmcl */) { /* only a warning */ }
-    const uint32_t pcs = be32(p.data() + 20);
-    if (pcs != 0x58595a20u && pcs != 0x4c616220u) return false;              // 'XYZ ' / 'Lab '
-    for (uint32_t t = 0; t < tags; t++) {
-        const uint8_t* e = p.data() + 132 + (size_t)t * 12;
-        const uint32_t off = be32(e + 4), sz = be32(e + 8);
-        if (off > plen || sz > plen - off) return false;                     // "ICC profile tag outside profile"
-    }
-    return true;
-}
-
-// png_read_info up to the first IDAT. false = libpng would have raised an error (the reference then reports nothing).
-bool png_read_info(const uint8_t* s, size_t n, PngInfo& out)
-{
-    if (n < 8 || memcmp(s, kPngSig, 8) != 0) return false;
-    size_t i = 8;
-    bool have_ihdr = false, have_plte = false, have_iccp = false, seen_cicp = false, after_plte_slot = false;
-    int color_type = 0;
-    for (;;) {
-        if (n - i < 8) return false;                                   // read past the end
-        const uint32_t len = be32(s + i);
-        const uint8_t* type = s + i + 4;
-        if (len > 0x7fffffffu) return false;                           // "PNG unsigned integer out of range"
-        for (int k = 0; k < 4; k++) {
-            const uint8_t c = type[k];
-            if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))) return false; // "bad header (invalid type)"
-        }
-        if (type[2] & 0x20) return false;                              // reserved bit (third letter lower case): same error
-        const bool is_idat = is_type(type, "IDAT");
-        if (is_idat) {
-            if (!have_ihdr) return false;                              // "Missing IHDR before IDAT"
-            if (color_type == 3 && !have_plte) return false;           // "Missing PLTE before IDAT"
-            return true;
-        }
-        if (n - i - 8 < (size_t)len + 4) return false;                 // truncated chunk
-        const uint8_t* d = s + i + 8;
-        const bool crc_ok = be32(d + len) == (uint32_t)crc32(crc32(0, type, 4), d, len);
-        const bool ancillary = (type[0] & 0x20) != 0;
-        i += 12 + (size_t)len;
-        if (!crc_ok && !ancillary && !is_type(type, "PLTE")) return false; // CRC error in a critical chunk
-        if (is_type(type, "IHDR")) {
-            if (have_ihdr) return false;                               // "out of place"
-            if (len != 13) return false;                               // "invalid"
-            const uint32_t w = be32(d), h = be32(d + 4);
-            const int depth = d[8], ct = d[9];
-            bool ok = w != 0 && h != 0 && w <= 0x7fffffffu && h <= 0x7fffffffu && w <= 1000000u && h <= 1000000u;
-            ok = ok && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16);
-            ok = ok && (ct == 0 || ct == 2 || ct == 3 || ct == 4 || ct == 6);
-            ok = ok && !((ct == 3 && depth > 8) || ((ct == 2 || ct == 4 || ct == 6) && depth < 8));
-            ok = ok && d[10] == 0 && d[11] == 0 && d[12] <= 1;
-            if (!ok) return false;                                     // "Invalid IHDR data"
-            have_ihdr = true;
-            color_type = ct;
-            continue;
-        }
-        if (!have_ihdr) return false;                                  // every handler: "missing IHDR"
-        if (is_type(type, "IEND")) return false;                       // before any IDAT: "out of place"
-        if (is_type(type, "PLTE")) {
-            // critical only for palette images; in the other colour types a broken or misplaced PLTE is shrugged off
-            if (color_type == 3) {
-                if (!crc_ok || have_plte || after_plte_slot || len == 0 || len > 768 || len % 3) return false;
-                have_plte = true;
-                continue;
-            }
-            if (have_plte || after_plte_slot) continue;                // "duplicate" / "out of place" (after tRNS or bKGD)
-            if (!(color_type & 2)) continue;                           // "ignored in grayscale PNG"
-            if (len > 768 || len % 3) continue;                        // "invalid"
-            if (len == 0) return false;                                // png_set_PLTE: "Invalid palette"
-            have_plte = true;                                          // counts as seen even with a CRC error
-            continue;
-        }
-        if (!ancillary) return false;                                  // "unhandled critical chunk"
-        if (!crc_ok && !is_type(type, "iCCP")) continue;               // ancillary chunk with a CRC error: dropped with a warning (the iCCP
-                                                                       // reader only warns and keeps the profile it has already inflated)
-        if (is_type(type, "cICP")) {
-            if (have_plte || seen_cicp || len != 4) continue;          // out of place / duplicate / invalid: benign
-            seen_cicp = true;                                          // from here on a further cICP is a duplicate ...
-            if (d[2] != 0) continue;                                   // ... even when this one is unusable: RGB data needs identity matrix coefficients
-            memcpy(out.cicp, d, 4);
-            out.have_cicp = true;
-        } else if (is_type(type, "iCCP")) {
-            if (have_plte || have_iccp) continue;                      // out of place / duplicate (only an accepted profile counts)
-            if (len < 81 + 11) continue;                               // "too short": libpng reads 81 bytes for the keyword and wants a minimal zlib stream after them
-            uint32_t k = 0;
-            while (k < 80 && d[k]) k++;
-            if (k == 0 || k > 79) continue;                            // "bad keyword"
-            if (d[k + 1] != 0) continue;                               // "bad compression method"
-            // Inflate exactly as many bytes as the profile header announces; libpng only asks that they all arrive (a
-            // missing checksum or further output is "extra compressed data", a warning).
-            std::vector<uint8_t> prof(132);
-            z_stream zs;
-            memset(&zs, 0, sizeof(zs));
-            if (inflateInit(&zs) != Z_OK) continue;
-            zs.next_in = const_cast<uint8_t*>(d + k + 2);
-            zs.avail_in = len - (k + 2);
-            zs.next_out = prof.data();
-            zs.avail_out = 132;
-            (void)inflate(&zs, Z_NO_FLUSH);
-            bool good = zs.avail_out == 0;
-            if (good) {
-                const uint32_t plen = be32(prof.data());
-                good = plen >= 132 && plen <= 8000000u;                // "too short" / user_chunk_malloc_max
-                if (good) {
-                    prof.resize(plen);
-                    zs.next_out = prof.data() + 132;
-                    zs.avail_out = plen - 132;
-                    if (zs.avail_out) (void)inflate(&zs, Z_FINISH);
-                    good = zs.avail_out == 0;
-                }
-            }
-            inflateEnd(&zs);
-            if (good && icc_profile_acceptable(prof, color_type)) { out.icc.swap(prof); have_iccp = true; }
-        }
-        else if (is_type(type, "tRNS")) { // an accepted tRNS or bKGD closes the slot in which PLTE may appear
-            if (color_type == 2 ? len == 6 : color_type == 0 ? len == 2 : (color_type == 3 && have_plte && len >= 1 && len <= 256)) after_plte_slot = true;
-        } else if (is_type(type, "bKGD")) {
-            if (color_type == 3 ? (have_plte && len == 1) : (color_type & 2) ? len == 6 : len == 2) after_plte_slot = true;
-        }
-        // every other ancillary chunk is irrelevant to these readers
-    }
-}
 } // namespace
+
+static const uint8_t kPngSig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
+static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static inline bool is_type(const uint8_t* t, const char* name) { return memcmp(t, name, 4) == 0; }
 
 extern "C" {
 
@@ -332,8 +186,8 @@ int opencv_decoder_get_jpeg_icc(void* src, size_t src_len, void* dest, size_t de
 int opencv_decoder_get_png_icc(void* src, size_t src_len, void* dest, size_t dest_len) // opencv.cpp:314-344
 {
     if (!src || !dest) return 0;
-    PngInfo info;
-    if (!png_read_info(static_cast<const uint8_t*>(src), src_len, info)) return 0;
+    LpPngInfo info;
+    if (!lp_png_read_info(static_cast<const uint8_t*>(src), src_len, info)) return 0;
     if (info.icc.empty() || info.icc.size() > dest_len) return 0;
     memcpy(dest, info.icc.data(), info.icc.size());
     return (int)info.icc.size();
@@ -342,8 +196,8 @@ int opencv_decoder_get_png_icc(void* src, size_t src_len, void* dest, size_t des
 int opencv_decoder_get_png_cicp(void* src, size_t src_len, uint8_t* primaries, uint8_t* transfer, uint8_t* matrix, uint8_t* full_range) // opencv.cpp:357-395
 {
     if (!src) return 0;
-    PngInfo info;
-    if (!png_read_info(static_cast<const uint8_t*>(src), src_len, info) || !info.have_cicp) return 0;
+    LpPngInfo info;
+    if (!lp_png_read_info(static_cast<const uint8_t*>(src), src_len, info) || !info.have_cicp) return 0;
     *primaries = info.cicp[0];
     *transfer = info.cicp[1];
     *matrix = info.cicp[2];

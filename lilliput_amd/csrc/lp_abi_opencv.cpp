@@ -427,15 +427,19 @@ opencv_decoder opencv_decoder_create(const opencv_mat buf)
     auto m = static_cast<const LpMat*>(buf);
     if (!m || !m->data) return NULL;
     const size_t len = (size_t)m->cols * (size_t)m->rows * cv_elem_size(m->type);
-    // cv::findDecoder signature check: only the JPEG signature is served by this build
-    if (len < 3 || m->data[0] != 0xFF || m->data[1] != 0xD8 || m->data[2] != 0xFF) return NULL;
+    // cv::findDecoder signature check: the JPEG and PNG signatures are served by this build
+    static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
+    const bool jpeg = len >= 3 && m->data[0] == 0xFF && m->data[1] == 0xD8 && m->data[2] == 0xFF;
+    const bool png = len >= 8 && memcmp(m->data, png_sig, 8) == 0;
+    if (!jpeg && !png) return NULL;
     auto d = new LpDecoder();
     d->data = m->data;
     d->len = len;
+    d->is_png = png;
     return d;
 }
 
-const char* opencv_decoder_get_description(const opencv_decoder d) { return d ? "JPEG" : nullptr; }
+const char* opencv_decoder_get_description(const opencv_decoder d) { return !d ? nullptr : static_cast<const LpDecoder*>(d)->is_png ? "PNG" : "JPEG"; }
 void opencv_decoder_release(opencv_decoder d) { delete static_cast<LpDecoder*>(d); }
 
 bool opencv_decoder_read_header(opencv_decoder dd)
@@ -443,6 +447,13 @@ bool opencv_decoder_read_header(opencv_decoder dd)
     auto d = static_cast<LpDecoder*>(dd);
     if (!d) return false;
     if (d->parsed) return d->parse_rc == LP_PARSE_OK;
+    if (d->is_png) { // cv::PngDecoder::readHeader: png_read_info, then the Mat type from colour type / tRNS / bit depth
+        d->parsed = true;
+        d->parse_rc = lp_png_read_info(d->data, d->len, d->png) ? LP_PARSE_OK : LP_PARSE_NOT_JPEG;
+        const int ct = d->png.color_type;
+        d->png_channels = (ct == 2 || ct == 3) ? (d->png.num_trans > 0 ? 4 : 3) : (ct == 4 || ct == 6) ? 4 : 1;
+        return d->parse_rc == LP_PARSE_OK;
+    }
     d->parse_rc = lp_jpeg_parse(d->data, d->len, &d->hdr);
     d->parsed = true;
     if (d->parse_rc == LP_PARSE_UNSUPPORTED) {
@@ -452,10 +463,65 @@ bool opencv_decoder_read_header(opencv_decoder dd)
     return d->parse_rc == LP_PARSE_OK;
 }
 
-int opencv_decoder_get_width(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.width; }
-int opencv_decoder_get_height(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.height; }
-int opencv_decoder_get_pixel_type(const opencv_decoder d) { return static_cast<const LpDecoder*>(d)->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3; }
-int opencv_decoder_get_orientation(const opencv_decoder d) { return (int)static_cast<const LpDecoder*>(d)->hdr.j.orientation; }
+int opencv_decoder_get_width(const opencv_decoder dd)
+{
+    auto d = static_cast<const LpDecoder*>(dd);
+    return d->is_png ? (int)d->png.width : (int)d->hdr.j.width;
+}
+int opencv_decoder_get_height(const opencv_decoder dd)
+{
+    auto d = static_cast<const LpDecoder*>(dd);
+    return d->is_png ? (int)d->png.height : (int)d->hdr.j.height;
+}
+int opencv_decoder_get_pixel_type(const opencv_decoder dd)
+{
+    auto d = static_cast<const LpDecoder*>(dd);
+    if (d->is_png) return (d->png.depth == 16 ? 2 /* CV_16U */ : 0) + ((d->png_channels - 1) << 3); // the Go side demotes 16-bit types (opencv.go:255-257)
+    return d->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3;
+}
+int opencv_decoder_get_orientation(const opencv_decoder dd)
+{
+    auto d = static_cast<const LpDecoder*>(dd);
+    return d->is_png ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
+}
+
+// cv::PngDecoder::readData into an 8-bit Mat of the announced channel count: chunk walk + inflate on the
+// host (serial, like libpng + zlib-ng in the reference), filter reversal and pixel expansion on the device.
+static bool png_read_data(LpDecoder* d, LpMat* m)
+{
+    const LpPngInfo& pi = d->png;
+    if (m->rows != (int)pi.height || m->cols != (int)pi.width || cv_channels(m->type) != d->png_channels || cv_depth_bytes(m->type) != 1) return false;
+    std::vector<uint8_t> filtered;
+    if (!lp_png_read_idat(d->data, d->len, pi, filtered)) { lp_set_error("PNG image data is damaged"); return false; }
+    LpEngine* eng = lp_thread_engine();
+    if (!eng || !mat_new_dev(m)) return false;
+    LpPngOp op;
+    memset(&op, 0, sizeof(op));
+    op.dst = lp_mat_frame(m);
+    op.depth = (uint32_t)pi.depth;
+    op.color_type = (uint32_t)pi.color_type;
+    const int bits = pi.depth * lp_png_channels_in_file(pi.color_type);
+    op.bpp = (uint32_t)(bits >= 8 ? bits / 8 : 1);
+    op.has_key = pi.color_type == 2 && pi.num_trans > 0;
+    for (int c = 0; c < 3; c++) op.key[c] = pi.trans_key[c];
+    uint64_t off = 0;
+    for (int p = 0; p < (pi.interlace ? 7 : 1); p++) {
+        LpPngPass& ps = op.pass[op.npass++];
+        lp_png_pass_geometry(pi, p, &ps.pw, &ps.ph, &ps.x0, &ps.y0, &ps.dx, &ps.dy);
+        ps.row_bytes = (uint32_t)(((size_t)ps.pw * bits + 7) / 8);
+        ps.off = off;
+        if (ps.pw && ps.ph) off += (uint64_t)ps.ph * (ps.row_bytes + 1);
+        else ps.pw = ps.ph = 0;
+    }
+    uint8_t pal[1024];
+    memset(pal, 0, sizeof(pal)); // indices past the palette read as black, like libpng's zero-filled 256-entry table
+    for (int i = 0; i < 256; i++) pal[4 * i + 3] = 255;
+    for (int i = 0; i < pi.num_palette; i++) { pal[4 * i] = pi.palette[i][2]; pal[4 * i + 1] = pi.palette[i][1]; pal[4 * i + 2] = pi.palette[i][0]; }
+    if (pi.color_type == 3) for (int i = 0; i < pi.num_trans; i++) pal[4 * i + 3] = pi.trans_alpha[i];
+    if (eng->png_decode(op, filtered.data(), filtered.size(), pal)) { lp_set_error(eng->last_error()); return false; }
+    m->dev_valid = true;
+    return lp_mat_to_host(m, eng);
+}
 
 bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
 {
@@ -464,6 +530,7 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     if (!d || !m) return false;
     if (!d->parsed && !opencv_decoder_read_header(dd)) return false;
     if (d->parse_rc != LP_PARSE_OK) return false;
+    if (d->is_png) return png_read_data(d, m);
     const LpJpeg& j = d->hdr.j;
     const int cn = j.ncomp == 1 ? 1 : 3;
     if (m->rows != (int)j.height || m->cols != (int)j.width || cv_channels(m->type) != cn || cv_depth_bytes(m->type) != 1) return false;
@@ -477,6 +544,15 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     if (rc || st) { lp_set_error(eng->last_error()); return false; }
     m->dev_valid = true;
     return lp_mat_to_host(m, eng);
+}
+
+// Test access (no device work): would the PNG's image data be accepted? Returns the number of inflated bytes, or -1.
+extern "C" long lilliput_hip_png_inflate_check(const void* data, size_t len)
+{
+    LpPngInfo pi;
+    std::vector<uint8_t> filtered;
+    if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
+    return (long)filtered.size();
 }
 
 // ---- encoder (opencv.cpp:173-194)

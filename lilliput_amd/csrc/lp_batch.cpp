@@ -42,7 +42,7 @@ struct LpBatch {
     size_t n_items = 0;
     uint32_t S = 0, C = 0;
     LpTimings tm = {};
-    // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path): copied at
+    // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path; PNG): copied at
     // upload, transformed one by one on the calling thread while the JPEG parts run
     std::vector<std::pair<int, std::vector<uint8_t>>> other;
     lilliput_image_ops other_ops = nullptr;
@@ -128,7 +128,9 @@ int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item*
     for (size_t i = 0; i < n; i++) {
         LpJpegHeader h;
         const uint8_t* sp = (const uint8_t*)items[i].src;
-        if (sp && items[i].src_len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) { // lilliput.go:100-102 isGIF
+        static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
+        if (sp && ((items[i].src_len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
+                   (items[i].src_len >= 8 && memcmp(sp, png_sig, 8) == 0))) {
             b->other.emplace_back((int)i, std::vector<uint8_t>(sp, sp + items[i].src_len));
             continue;
         }
@@ -368,7 +370,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     return LILLIPUT_OK;
 }
 
-// GIF items: Decoder + ImageOps.Transform of the Go-API mirror (the JPEG writer returns after the first composited frame)
+// GIF and PNG items: Decoder + ImageOps.Transform of the Go-API mirror (for GIF the JPEG writer returns after the first composited frame)
 static void run_other(LpBatch* b, const lilliput_batch_options* opt)
 {
     if (b->other.empty()) return;

@@ -623,6 +623,29 @@ int LpEngine::composite(const LpCompositeOp& op)
     return check(hipGetLastError(), "composite kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
+int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t pal_off = (n + 255) & ~(size_t)255;
+    if (!d_planes_.ensure(pal_off + 1024 + 256)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    uint8_t* base = d_planes_.as<uint8_t>();
+    if (n && !check(hipMemcpyAsync(base, filtered, n, hipMemcpyHostToDevice, stream_), "H2D png data")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D png palette")) return LP_ERR_DEVICE;
+    if (!check(hipMemsetAsync(base + pal_off + 1024, 0, 4, stream_), "memset png flag")) return LP_ERR_DEVICE;
+    op.data_off = (uint64_t)(uintptr_t)base;
+    op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
+    op.error_off = (uint64_t)(uintptr_t)(base + pal_off + 1024);
+    lp_launch_png(stream_, op);
+    uint32_t* flag = h_small_.ensure(4096) ? h_small_.as<uint32_t>() : nullptr;
+    if (!flag) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(flag, base + pal_off + 1024, 4, hipMemcpyDeviceToHost, stream_), "D2H png flag")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "png sync")) return LP_ERR_DEVICE;
+    if (!check(hipGetLastError(), "png kernels")) return LP_ERR_DEVICE;
+    if (*flag) { err_ = "PNG: bad adaptive filter value"; return LP_ERR_DECODE_FAILED; }
+    return LP_OK;
+}
+
 int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra)
 {
     if (!ok_) return LP_ERR_DEVICE;

@@ -114,6 +114,8 @@ public:
     int composite(const LpCompositeOp& op);
     // Renders one GIF frame: uploads the indices and the palette (256 x BGRA) and runs k_gif_frame; op.index_off / palette_off are filled here.
     int gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra);
+    // PNG: uploads the inflated stream and the palette, reverses the filters and expands to op.dst; LP_ERR_DECODE_FAILED on a bad filter type.
+    int png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra);
     int sync();
     // Stage groups of a batch pipeline. Engines that share a device take turns per group so that concurrent parts of a batch
     // run DIFFERENT groups at the same time (entropy decode is VALU-bound, the pixel stages lean on HBM): without the locks

@@ -703,6 +703,143 @@ __global__ __launch_bounds__(256) void k_gif_frame(LpGifFrameOp op)
     *cp = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PNG (n2): reverse the per-row filters of the inflated stream in place (pngrutil.c png_read_filter_row: None, Sub, Up,
+// Average, Paeth on bytes `bpp` apart). A reconstructed byte needs its left neighbour, the byte above and the one above-left,
+// so rows are not independent, but row r may run one pixel behind row r-1: a wave takes 64 consecutive rows, lane = row,
+// and walks them as a skewed diagonal -- lane r works on pixel t - r at step t, gets "above" from lane r-1 by a shuffle of
+// that lane's previous result and remembers last step's "above" as "above-left". Bands of 64 rows follow one another in
+// the same wave (lane 0 reads the row above from memory, written by lane 63 of the previous band). One workgroup per pass.
+template <int BPP>
+__device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* error)
+{
+    const uint32_t lane = threadIdx.x;
+    const size_t stride = (size_t)ps.row_bytes + 1;
+    for (uint32_t band = 0; band < ps.ph; band += 64) {
+        const uint32_t row = band + lane;
+        const bool live = row < ps.ph;
+        uint8_t* cur = base + ps.off + (size_t)(live ? row : 0) * stride;
+        const uint8_t* up_row = row ? cur - stride + 1 : nullptr; // only lane 0 reads it (rows above a band are final)
+        const uint32_t ft = live ? cur[0] : 0;
+        if (live && ft > 4) atomicOr(error, 1u); // "bad adaptive filter value"
+        cur += 1;
+        uint32_t a[BPP], bprev[BPP];
+#pragma unroll
+        for (int k = 0; k < BPP; k++) { a[k] = 0; bprev[k] = 0; }
+        const uint32_t npx = (ps.row_bytes + BPP - 1) / BPP; // filter units per row (the last one may be cut short only when BPP does not divide, which cannot happen)
+        const uint32_t rows_here = ps.ph - band < 64 ? ps.ph - band : 64;
+        for (uint32_t t = 0; t < npx + rows_here - 1; t++) {
+            const int x = (int)t - (int)lane;
+            const bool on = live && x >= 0 && x < (int)npx;
+            uint32_t b[BPP], c[BPP], v[BPP];
+#pragma unroll
+            for (int k = 0; k < BPP; k++) {
+                const uint32_t from_above = (uint32_t)__shfl_up((int)a[k], 1, 64); // lane r-1 finished pixel x in the previous step
+                b[k] = lane ? from_above : (on && up_row ? up_row[(size_t)x * BPP + k] : 0u);
+                c[k] = bprev[k];
+            }
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < BPP; k++) {
+                    const uint32_t f = cur[(size_t)x * BPP + k];
+                    uint32_t pred = 0;
+                    if (ft == 1) pred = a[k];
+                    else if (ft == 2) pred = b[k];
+                    else if (ft == 3) pred = (a[k] + b[k]) >> 1;
+                    else if (ft == 4) {
+                        const int pa = abs((int)b[k] - (int)c[k]), pb = abs((int)a[k] - (int)c[k]), pc = abs((int)a[k] + (int)b[k] - 2 * (int)c[k]);
+                        pred = (pa <= pb && pa <= pc) ? a[k] : (pb <= pc ? b[k] : c[k]);
+                    }
+                    v[k] = (f + pred) & 255u;
+                    cur[(size_t)x * BPP + k] = (uint8_t)v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < BPP; k++) { a[k] = v[k]; bprev[k] = b[k]; }
+            }
+        }
+        __threadfence(); // the next band's lane 0 reads this band's last row from memory
+    }
+}
+
+__global__ __launch_bounds__(64) void k_png_unfilter(LpPngOp op)
+{
+    const LpPngPass& ps = op.pass[blockIdx.x];
+    if (!ps.pw || !ps.ph) return;
+    uint8_t* base = reinterpret_cast<uint8_t*>(op.data_off);
+    uint32_t* err = reinterpret_cast<uint32_t*>(op.error_off);
+    switch (op.bpp) {
+    case 1: png_unfilter_pass<1>(base, ps, err); break;
+    case 2: png_unfilter_pass<2>(base, ps, err); break;
+    case 3: png_unfilter_pass<3>(base, ps, err); break;
+    case 4: png_unfilter_pass<4>(base, ps, err); break;
+    case 6: png_unfilter_pass<6>(base, ps, err); break;
+    default: png_unfilter_pass<8>(base, ps, err); break;
+    }
+}
+
+// Reconstructed samples -> the pixels cv::PngDecoder::readData asks libpng for: 16-bit samples keep their high byte
+// (png_set_strip_16), grey below 8 bits is scaled by bit replication (expand_gray_1_2_4_to_8), palette indices go through
+// PLTE / tRNS, an RGB colour key becomes alpha (tRNS_to_alpha, compared at full precision before the strip), colour is
+// stored B, G, R (png_set_bgr), grey + alpha is spread to B = G = R (gray_to_rgb); Adam7 passes land on their lattice.
+__global__ __launch_bounds__(256) void k_png_convert(LpPngOp op)
+{
+    const LpPngPass& ps = op.pass[blockIdx.z];
+    const uint32_t px = blockIdx.x * 64 + threadIdx.x, py = blockIdx.y * 4 + threadIdx.y;
+    if (px >= ps.pw || py >= ps.ph) return;
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(op.data_off) + ps.off + (size_t)py * ((size_t)ps.row_bytes + 1) + 1;
+    const uint32_t x = ps.x0 + px * ps.dx, y = ps.y0 + py * ps.dy;
+    uint8_t* o = reinterpret_cast<uint8_t*>(op.dst.off) + (size_t)y * op.dst.stride + (size_t)x * op.dst.cn;
+    const uint32_t d = op.depth, ct = op.color_type, cn = op.dst.cn;
+    if (ct == 0 || ct == 3) {
+        uint32_t v;
+        if (d == 16) v = row[(size_t)px * 2];
+        else if (d == 8) v = row[px];
+        else {
+            const uint32_t per = 8 / d, byte = row[px / per], sh = 8 - d * (1 + px % per);
+            v = (byte >> sh) & ((1u << d) - 1);
+        }
+        if (ct == 0) {
+            if (d < 8) v *= d == 1 ? 255u : d == 2 ? 85u : 17u;
+            o[0] = (uint8_t)v; // a grey colour key is dropped together with the alpha channel (png_set_strip_alpha)
+        } else {
+            const uint8_t* e = reinterpret_cast<const uint8_t*>(op.palette_off) + (size_t)v * 4;
+            o[0] = e[0]; o[1] = e[1]; o[2] = e[2];
+            if (cn == 4) o[3] = e[3];
+        }
+        return;
+    }
+    const uint32_t bytes = d == 16 ? 2 : 1, nch = ct == 2 ? 3 : ct == 4 ? 2 : 4;
+    const uint8_t* p = row + (size_t)px * nch * bytes;
+    if (ct == 4) { // grey + alpha -> B = G = R = grey, A
+        const uint8_t g = p[0], a = p[bytes];
+        o[0] = g; o[1] = g; o[2] = g; o[3] = a;
+        return;
+    }
+    const uint8_t r = p[0], g = p[bytes], b = p[2 * bytes];
+    o[0] = b; o[1] = g; o[2] = r;
+    if (cn == 4) {
+        if (ct == 6) o[3] = p[3 * bytes];
+        else {
+            bool hit = false;
+            if (op.has_key) {
+                if (d == 16) hit = (((uint32_t)p[0] << 8) | p[1]) == op.key[0] && (((uint32_t)p[2] << 8) | p[3]) == op.key[1] && (((uint32_t)p[4] << 8) | p[5]) == op.key[2];
+                else hit = r == (op.key[0] & 255u) && g == (op.key[1] & 255u) && b == (op.key[2] & 255u);
+            }
+            o[3] = hit ? 0 : 255;
+        }
+    }
+}
+
+void lp_launch_png(hipStream_t s, const LpPngOp& op)
+{
+    if (!op.npass) return;
+    hipLaunchKernelGGL(k_png_unfilter, dim3(op.npass), dim3(64), 0, s, op);
+    uint32_t mw = 0, mh = 0;
+    for (uint32_t p = 0; p < op.npass; p++) { mw = op.pass[p].pw > mw ? op.pass[p].pw : mw; mh = op.pass[p].ph > mh ? op.pass[p].ph : mh; }
+    if (!mw || !mh) return;
+    hipLaunchKernelGGL(k_png_convert, dim3((mw + 63) / 64, (mh + 3) / 4, op.npass), dim3(64, 4), 0, s, op);
+}
+
 void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op)
 {
     if (!op.canvas.w || !op.canvas.h) return;

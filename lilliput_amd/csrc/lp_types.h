@@ -176,6 +176,28 @@ struct LpGifFrameOp {
     uint8_t bg[4];              // B, G, R, A
 };
 
+// One PNG image on the device: `data_off` holds the inflated stream (per Adam7 pass, per row: filter byte + packed row);
+// k_png_unfilter reconstructs it in place, k_png_convert expands it to the 8-bit BGR(A) / grey frame OpenCV's PngDecoder yields.
+struct LpPngPass {
+    uint64_t off;               // byte offset of the pass inside the inflated stream
+    uint32_t pw, ph;            // pixels per row / rows of this pass (0 = empty pass, no data)
+    uint32_t x0, y0, dx, dy;    // where pass pixel (0,0) lands in the image and the steps between pass pixels
+    uint32_t row_bytes;         // packed bytes per row without the filter byte
+    uint32_t pad;
+};
+struct LpPngOp {
+    LpFrame dst;                // cn = 1, 3 or 4
+    uint64_t data_off;          // device address of the inflated stream
+    uint64_t palette_off;       // device address of 256 x {B, G, R, A} (palette images)
+    uint64_t error_off;         // device address of a uint32 flag: set when a row carries a filter type above 4
+    LpPngPass pass[7];
+    uint32_t npass;
+    uint32_t depth, color_type; // as in IHDR
+    uint32_t bpp;               // filter unit: bytes per complete pixel, at least 1
+    uint32_t has_key;           // RGB / grey colour key from tRNS (only RGB makes a difference: alpha 0 where the pixel equals it)
+    uint32_t key[3];            // 16-bit R, G, B
+};
+
 // JPEG encode job (S8-S10): pixels -> baseline 4:2:0 (or grayscale) JFIF stream with Annex-K tables.
 struct LpEncJob {
     LpFrame src;

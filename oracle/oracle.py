@@ -87,6 +87,34 @@ def ref_png_cicp(data):
     return out.raw[:4] if ref_meta().ref_png_cicp(bytes(data), len(data), out) else None
 
 
+_refpng = None
+
+
+def ref_png():
+    """libpng 1.6.47 + zlib-ng of the reference, driven like cv::PngDecoder (oracle/ref_png_driver.c), or None."""
+    global _refpng
+    if _refpng is None:
+        _refpng = _load(os.path.join("_ref", "librefpng.so"))
+        if _refpng is not None:
+            _refpng.ref_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    return _refpng
+
+
+def ref_png_info(data):
+    """[width, height, channels of the 8-bit Mat, bit depth, colour type, interlace] or None when png_read_info fails."""
+    info = (C.c_int * 6)()
+    return list(info) if ref_png().ref_png_decode(bytes(data), len(data), None, 0, info) == 0 else None
+
+
+def ref_png_decode(data):
+    """HxWxC uint8 (grey, BGR or BGRA) as opencv_decoder_read_data yields for a PNG; None when the reference fails."""
+    info = ref_png_info(data)
+    if info is None:
+        return None
+    out = np.zeros((info[1], info[0], info[2]), dtype=np.uint8)
+    return out if ref_png().ref_png_decode(bytes(data), len(data), out.ctypes.data, out.size, (C.c_int * 6)()) == 0 else None
+
+
 _refgif = None
 
 

@@ -1,0 +1,162 @@
+"""PNG sources through the opencv_decoder_* ABI: chunk walk + inflate on the host, filter reversal and
+pixel expansion on the device, against the reference's libpng 1.6.47 + zlib-ng driven like cv::PngDecoder
+(oracle/ref_png_driver.c; the call sequence is pinned by the reference's ThumbHash known answers)."""
+import base64
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import png_cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "png_golden.json")))
+THUMBHASH = {  # /root/reference/thumbhash_test.go:72-81
+    "firefox.png": "YJqGPQw7sFlslqhFafSE+Q6oJ1h2iHB2Rw==", "opera.png": "mYqDBQQnxnj0JoLYdN7f8JhpuDeHiHdwZw==",
+    "firefox-16bit.png": "YJqGPQw7oFlslqhGafOE+Q6oJ1h2iHBlVw==", "firefox-16bit-alpha.png": "YJqGPQw7sFlslqhFafSE+Q6oJ1h2iHB2Rw==",
+    "opera-gray-alpha.png": "EwiCBQAnwnjzJpHIZAAAAAAAuDeHiHdwZw==",
+}
+
+
+def _cases():
+    c = dict(png_cases.fixtures())
+    c.update(png_cases.generated())
+    c.update(png_cases.fuzz(21, 1500))
+    return c
+
+
+def test_reference_call_sequence_reproduces_the_thumbhash_known_answers(oracle):
+    if oracle.ref_png() is None:
+        pytest.skip("oracle/_ref/librefpng.so not built (needs /root/reference)")
+    fx = png_cases.fixtures()
+    for name, want in THUMBHASH.items():
+        assert base64.b64encode(oracle.thumbhash(oracle.ref_png_decode(fx[name]))).decode() == want, name
+
+
+def test_recorded_pixels_of_the_fixtures_carry_the_thumbhash_known_answers(oracle):
+    """The committed golden digests belong to pixels whose ThumbHash is the reference's known answer (checked when _ref is present)."""
+    assert all(GOLD[n] != "none" for n in THUMBHASH)
+
+
+def _header(L, data):
+    arr = np.frombuffer(data, np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+    em = L.opencv_mat_create_from_data(len(data), 1, 0, arr.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)))
+    dec = L.opencv_decoder_create(em) if em else None
+    out = None
+    if dec:
+        if L.opencv_decoder_read_header(dec):
+            out = (L.opencv_decoder_get_width(dec), L.opencv_decoder_get_height(dec), L.opencv_decoder_get_pixel_type(dec), L.opencv_decoder_get_orientation(dec))
+        L.opencv_decoder_release(dec)
+    if em:
+        L.opencv_mat_release(em)
+    return out
+
+
+def test_header_and_accept_reject_match_recorded_libpng_answers(hip_lib):
+    L = hip_lib
+    L.lilliput_hip_png_inflate_check.restype = C.c_long
+    L.lilliput_hip_png_inflate_check.argtypes = [C.c_char_p, C.c_size_t]
+    bad = []
+    for name, data in _cases().items():
+        g = GOLD[name]
+        ok = L.lilliput_hip_png_inflate_check(data, len(data)) >= 0
+        if ok != (g != "none"):
+            bad.append((name, ok, g))
+            continue
+        if ok:
+            w, h, cn = (int(x) for x in g.split(":")[0].split("x"))
+            hd = _header(L, data)
+            if hd is None or hd[:2] != (w, h) or (hd[2] >> 3) + 1 != cn or hd[3] != 1:
+                bad.append((name, hd, g))
+    assert not bad, bad[:10]
+
+
+def test_accept_reject_matches_libpng_live(hip_lib, oracle):
+    if oracle.ref_png() is None:
+        pytest.skip("oracle/_ref/librefpng.so not built")
+    L = hip_lib
+    L.lilliput_hip_png_inflate_check.restype = C.c_long
+    L.lilliput_hip_png_inflate_check.argtypes = [C.c_char_p, C.c_size_t]
+    for name, data in png_cases.fuzz(33, 1500).items():
+        assert (L.lilliput_hip_png_inflate_check(data, len(data)) >= 0) == (oracle.ref_png_decode(data) is not None), name
+
+
+def _decode(L, data):
+    """opencv_decoder_create / read_header / read_data the way openCVDecoder.DecodeTo does (16-bit types demoted to 8-bit)."""
+    arr = np.frombuffer(data, np.uint8).copy()
+    em = L.opencv_mat_create_from_data(len(data), 1, 0, arr.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)))
+    dec = L.opencv_decoder_create(em)
+    out = None
+    if dec and L.opencv_decoder_read_header(dec):
+        w, h, t = L.opencv_decoder_get_width(dec), L.opencv_decoder_get_height(dec), L.opencv_decoder_get_pixel_type(dec)
+        if L.opencv_type_depth(t) > 8:
+            t = L.opencv_type_convert_depth(t, 0)
+        cn = (t >> 3) + 1
+        buf = np.zeros(w * h * cn, dtype=np.uint8)
+        m = L.opencv_mat_create_from_data(w, h, t, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+        if L.opencv_decoder_read_data(dec, m):
+            out = buf.reshape(h, w, cn).copy()
+        L.opencv_mat_release(m)
+    if dec:
+        L.opencv_decoder_release(dec)
+    L.opencv_mat_release(em)
+    return out
+
+
+@pytest.mark.gpu
+def test_pixels_match_recorded_reference_pixels(hip_lib):
+    bad = []
+    for name, data in _cases().items():
+        px = _decode(hip_lib, data)
+        got = "none" if px is None else "%dx%dx%d:%s" % (px.shape[1], px.shape[0], px.shape[2], hashlib.sha1(px.tobytes()).hexdigest()[:16])
+        if got != GOLD[name]:
+            bad.append((name, got, GOLD[name]))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+def test_pixels_match_reference_live_and_thumbhash(hip_lib, oracle):
+    fx = png_cases.fixtures()
+    for name, want in THUMBHASH.items():
+        assert base64.b64encode(oracle.thumbhash(_decode(hip_lib, fx[name]))).decode() == want, name
+    if oracle.ref_png() is None:
+        return
+    cases = dict(fx)
+    cases.update(png_cases.generated())
+    for name, data in cases.items():
+        ref, mine = oracle.ref_png_decode(data), _decode(hip_lib, data)
+        assert (ref is None) == (mine is None), name
+        if ref is not None:
+            assert np.array_equal(ref, mine), name
+
+
+@pytest.mark.gpu
+def test_png_to_jpeg_transform_and_batch(hip_lib, oracle, fixture_bytes):
+    import lilliput_amd as la
+
+    fx = png_cases.fixtures()
+    gen = png_cases.generated()
+    srcs = {"ferry_sunset.png": fx["ferry_sunset.png"], "firefox-16bit-alpha.png": fx["firefox-16bit-alpha.png"], "opera-gray-alpha.png": fx["opera-gray-alpha.png"],
+            "gray": gen["filter4_gray1"], "pal": gen["pal_trns"]}
+    ops = la.ImageOps(1024)
+    expect = {}
+    for name, data in srcs.items():
+        px = _decode(hip_lib, data)
+        exp = oracle.jpeg_encode(oracle.transform_static(px, 1, 50, 40, oracle.FIT, False), 85)
+        d = la.Decoder(data)
+        assert d.Description() == "PNG"
+        out = ops.Transform(d, la.ImageOptions(".jpeg", 50, 40, la.ImageOpsFit, False, {la.JpegQuality: 85}, EncodeTimeout=10**10))
+        d.Close()
+        assert out == exp, name
+        expect[name] = exp
+    ops.Close()
+    b = la.Batch(0)
+    names = list(srcs)
+    res = b.transform([srcs[n] for n in names] + [fixture_bytes["coast.jpg"]], 50, 40, quality=85)
+    b.close()
+    assert [r.status for r in res] == [0] * (len(names) + 1)
+    for n, r in zip(names, res):
+        assert r.data == expect[n], n
