@@ -710,51 +710,85 @@ __global__ __launch_bounds__(256) void k_gif_frame(LpGifFrameOp op)
 // and walks them as a skewed diagonal -- lane r works on pixel t - r at step t, gets "above" from lane r-1 by a shuffle of
 // that lane's previous result and remembers last step's "above" as "above-left". Bands of 64 rows follow one another in
 // the same wave (lane 0 reads the row above from memory, written by lane 63 of the previous band). One workgroup per pass.
+struct __attribute__((packed, aligned(1))) PngChunk { uint32_t w[4]; }; // 16 bytes at any address (rows start on odd offsets)
+
+__device__ __forceinline__ uint32_t png_byte(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 255u; }
+
+// The filters work on bytes BPP apart, so a row can be cut into 16-byte chunks regardless of the pixel size: a lane keeps its
+// previous output chunk (left neighbours) and the previous chunk of the row above (above-left), and one step of the diagonal
+// is one chunk: lane r works on chunk t - r, the chunk above arrives from lane r-1 with four shuffles. Loads run one chunk
+// ahead of the arithmetic.
 template <int BPP>
 __device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* error)
 {
     const uint32_t lane = threadIdx.x;
     const size_t stride = (size_t)ps.row_bytes + 1;
+    const uint32_t nchunk = (ps.row_bytes + 15) / 16;
     for (uint32_t band = 0; band < ps.ph; band += 64) {
         const uint32_t row = band + lane;
         const bool live = row < ps.ph;
         uint8_t* cur = base + ps.off + (size_t)(live ? row : 0) * stride;
-        const uint8_t* up_row = row ? cur - stride + 1 : nullptr; // only lane 0 reads it (rows above a band are final)
         const uint32_t ft = live ? cur[0] : 0;
-        if (live && ft > 4) atomicOr(error, 1u); // "bad adaptive filter value"
+        if (live && ft > 4) atomicOr(error, 1u); // "bad adaptive filter value" (the host has already refused such a file)
         cur += 1;
-        uint32_t a[BPP], bprev[BPP];
-#pragma unroll
-        for (int k = 0; k < BPP; k++) { a[k] = 0; bprev[k] = 0; }
-        const uint32_t npx = (ps.row_bytes + BPP - 1) / BPP; // filter units per row (the last one may be cut short only when BPP does not divide, which cannot happen)
+        const uint8_t* up_row = (lane == 0 && row) ? cur - stride : nullptr; // rows above a band are final; only lane 0 reads memory for "above"
+        uint32_t out[4] = {0, 0, 0, 0}, upp[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0}, upn[4] = {0, 0, 0, 0};
         const uint32_t rows_here = ps.ph - band < 64 ? ps.ph - band : 64;
-        for (uint32_t t = 0; t < npx + rows_here - 1; t++) {
-            const int x = (int)t - (int)lane;
-            const bool on = live && x >= 0 && x < (int)npx;
-            uint32_t b[BPP], c[BPP], v[BPP];
+        if (live && lane == 0) { // prime the pipeline of the first row of the band
+            const PngChunk c0 = *reinterpret_cast<const PngChunk*>(cur);
 #pragma unroll
-            for (int k = 0; k < BPP; k++) {
-                const uint32_t from_above = (uint32_t)__shfl_up((int)a[k], 1, 64); // lane r-1 finished pixel x in the previous step
-                b[k] = lane ? from_above : (on && up_row ? up_row[(size_t)x * BPP + k] : 0u);
-                c[k] = bprev[k];
+            for (int k = 0; k < 4; k++) nxt[k] = c0.w[k];
+            if (up_row) {
+                const PngChunk u0 = *reinterpret_cast<const PngChunk*>(up_row);
+#pragma unroll
+                for (int k = 0; k < 4; k++) upn[k] = u0.w[k];
+            }
+        }
+        for (uint32_t t = 0; t < nchunk + rows_here - 1; t++) {
+            const int j = (int)t - (int)lane;
+            const bool on = live && j >= 0 && j < (int)nchunk;
+            uint32_t f[4], up[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t from_above = (uint32_t)__shfl_up((int)out[k], 1, 64); // lane r-1 finished chunk j in the previous step
+                up[k] = lane ? from_above : upn[k];
+                f[k] = nxt[k];
+            }
+            // fetch the chunk of the next step (a lane's first chunk is fetched in the step before it starts)
+            const int jn = j + 1;
+            if (live && jn >= 0 && jn < (int)nchunk) {
+                const PngChunk c = *reinterpret_cast<const PngChunk*>(cur + (size_t)jn * 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) nxt[k] = c.w[k];
+                if (up_row) {
+                    const PngChunk u = *reinterpret_cast<const PngChunk*>(up_row + (size_t)jn * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) upn[k] = u.w[k];
+                }
             }
             if (on) {
+                uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int k = 0; k < BPP; k++) {
-                    const uint32_t f = cur[(size_t)x * BPP + k];
-                    uint32_t pred = 0;
-                    if (ft == 1) pred = a[k];
-                    else if (ft == 2) pred = b[k];
-                    else if (ft == 3) pred = (a[k] + b[k]) >> 1;
-                    else if (ft == 4) {
-                        const int pa = abs((int)b[k] - (int)c[k]), pb = abs((int)a[k] - (int)c[k]), pc = abs((int)a[k] + (int)b[k] - 2 * (int)c[k]);
-                        pred = (pa <= pb && pa <= pc) ? a[k] : (pb <= pc ? b[k] : c[k]);
-                    }
-                    v[k] = (f + pred) & 255u;
-                    cur[(size_t)x * BPP + k] = (uint8_t)v[k];
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t a = i >= BPP ? png_byte(o, i - BPP) : png_byte(out, 16 - BPP + i);
+                    const uint32_t b = up_row || lane || row ? png_byte(up, i) : 0u;
+                    const uint32_t c = i >= BPP ? png_byte(up, i - BPP) : png_byte(upp, 16 - BPP + i);
+                    const int pa = abs((int)b - (int)c), pb = abs((int)a - (int)c), pc = abs((int)a + (int)b - 2 * (int)c);
+                    const uint32_t paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    const uint32_t pred = ft == 0 ? 0u : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) >> 1 : paeth;
+                    o[i >> 2] |= ((png_byte(f, i) + pred) & 255u) << ((i & 3) * 8);
+                }
+                const uint32_t left = ps.row_bytes - (uint32_t)j * 16;
+                if (left >= 16) {
+                    PngChunk c;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c.w[k] = o[k];
+                    *reinterpret_cast<PngChunk*>(cur + (size_t)j * 16) = c;
+                } else {
+                    for (uint32_t i = 0; i < left; i++) cur[(size_t)j * 16 + i] = (uint8_t)(o[i >> 2] >> ((i & 3) * 8));
                 }
 #pragma unroll
-                for (int k = 0; k < BPP; k++) { a[k] = v[k]; bprev[k] = b[k]; }
+                for (int k = 0; k < 4; k++) { out[k] = o[k]; upp[k] = up[k]; }
             }
         }
         __threadfence(); // the next band's lane 0 reads this band's last row from memory

@@ -441,6 +441,15 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     Header hdr;
     int e = decoder_header(d, &hdr);
     if (e) return e;
+    // Container-signalled colour (ops.go:500-541): an HDR transfer function in a PNG's cICP chunk makes the reference tone-map
+    // every decoded frame (color_info.cpp). That kernel is not built: refuse rather than return un-mapped pixels.
+    if (d->kind == Decoder::OPENCV) {
+        const char* desc = opencv_decoder_get_description(d->dec);
+        uint8_t prim = 0, transfer = 0, matrix = 0, range = 0;
+        if (desc && strcmp(desc, "PNG") == 0 && d->len && opencv_decoder_get_png_cicp((void*)d->buf, d->len, &prim, &transfer, &matrix, &range) &&
+            (transfer == 16 || transfer == 18)) // cicp_is_hdr_transfer: SMPTE ST 2084 (PQ), ARIB STD-B67 (HLG)
+            return LILLIPUT_ERR_UNSUPPORTED;
+    }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
     std::string ext = lower(opt->file_type);
     if (ext == ".gif" || ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;

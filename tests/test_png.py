@@ -160,3 +160,26 @@ def test_png_to_jpeg_transform_and_batch(hip_lib, oracle, fixture_bytes):
     assert [r.status for r in res] == [0] * (len(names) + 1)
     for n, r in zip(names, res):
         assert r.data == expect[n], n
+
+
+def test_hdr_png_is_refused_not_mis_rendered(hip_lib):
+    """A PNG whose cICP chunk signals PQ or HLG is tone-mapped by the reference right after decode (ops.go:154-165, 500-512);
+    this build has no tone-map kernel, so the transform refuses instead of returning un-mapped pixels. An SDR cICP passes."""
+    import random
+
+    import lilliput_amd as la
+
+    def with_cicp(transfer):
+        return png_cases.make_png(12, 12, 2, 8, random.Random(1), extra=[png_cases.chunk(b"cICP", bytes([9, transfer, 0, 1]))])[0]
+
+    for transfer, refused in ((16, True), (18, True), (13, False)):
+        d = la.Decoder(with_cicp(transfer))
+        ops = la.ImageOps(256)
+        try:
+            ops.Transform(d, la.ImageOptions(".jpeg", 8, 8, la.ImageOpsFit, EncodeTimeout=10**10))
+            code = 0
+        except la.LilliputError as e:
+            code = e.code
+        ops.Close()
+        d.Close()
+        assert (code == 4) == refused, (transfer, code)   # 4 = unsupported; anything else here is "no GPU" on the CPU runner
