@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -45,8 +46,8 @@ struct LpBatch {
     // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path; PNG): copied at
     // upload, transformed one by one on the calling thread while the JPEG parts run
     std::vector<std::pair<int, std::vector<uint8_t>>> other;
-    lilliput_image_ops other_ops = nullptr;
-    ~LpBatch() { if (other_ops) lilliput_image_ops_close(other_ops); }
+    std::vector<lilliput_image_ops> other_ops; // one per worker
+    ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
     {
@@ -374,8 +375,6 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
 static void run_other(LpBatch* b, const lilliput_batch_options* opt)
 {
     if (b->other.empty()) return;
-    const int prev_dev = lp_thread_device(b->device);
-    if (!b->other_ops) b->other_ops = lilliput_new_image_ops(8192);
     const int enc_opts[2] = {CV_IMWRITE_JPEG_QUALITY, opt->jpeg_quality};
     lilliput_image_options io;
     memset(&io, 0, sizeof(io));
@@ -386,30 +385,46 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt)
     io.encode_options = enc_opts;
     io.encode_options_len = opt->jpeg_quality ? 2 : 0;
     io.encode_timeout_ns = 30ll * 1000000000ll;
-    for (auto& it : b->other) {
-        const size_t i = (size_t)it.first;
-        if (!b->other_ops) { b->status[i] = LILLIPUT_ERR_DEVICE; continue; }
-        lilliput_decoder d = nullptr;
-        int rc = lilliput_new_decoder(it.second.data(), it.second.size(), &d);
-        if (!rc) {
-            int w = 0, h = 0;
-            (void)lilliput_decoder_header(d, &w, &h, nullptr, nullptr, nullptr, nullptr);
-            std::vector<uint8_t>& out = b->out_bytes[i];
-            out.resize((size_t)std::max(opt->width, 1) * std::max(opt->height, 1) * 3 + ((size_t)w * h * 3 + 65536));
-            size_t n = 0;
-            rc = lilliput_image_ops_transform(b->other_ops, d, &io, out.data(), out.size(), &n);
+    // The host side of these sources is serial per image (inflate, LZW), so the items are spread over a few workers, each with its
+    // own ImageOps (ops.go: "one ImageOps per goroutine") and its own per-thread engine on the batch's device.
+    const size_t nw = std::min<size_t>(b->other.size(), (size_t)std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 8)));
+    while (b->other_ops.size() < nw) b->other_ops.push_back(lilliput_new_image_ops(8192));
+    std::atomic<size_t> next{0};
+    auto worker = [&](size_t wi) {
+        const int prev_dev = lp_thread_device(b->device);
+        lilliput_image_ops ops = b->other_ops[wi];
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= b->other.size()) break;
+            auto& it = b->other[k];
+            const size_t i = (size_t)it.first;
+            if (!ops) { b->status[i] = LILLIPUT_ERR_DEVICE; continue; }
+            lilliput_decoder d = nullptr;
+            int rc = lilliput_new_decoder(it.second.data(), it.second.size(), &d);
             if (!rc) {
-                out.resize(n);
-                b->out_len[i] = (uint32_t)n;
-                if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { b->out_w[i] = w; b->out_h[i] = h; }
-                else if (opt->resize_method == LILLIPUT_OPS_FIT) lilliput_calculate_expected_size(w, h, opt->width, opt->height, &b->out_w[i], &b->out_h[i]);
-                else { b->out_w[i] = std::max(opt->width, 1); b->out_h[i] = std::max(opt->height, 1); }
+                int w = 0, h = 0;
+                (void)lilliput_decoder_header(d, &w, &h, nullptr, nullptr, nullptr, nullptr);
+                std::vector<uint8_t>& out = b->out_bytes[i];
+                out.resize((size_t)std::max(opt->width, 1) * std::max(opt->height, 1) * 3 + ((size_t)w * h * 3 + 65536));
+                size_t n = 0;
+                rc = lilliput_image_ops_transform(ops, d, &io, out.data(), out.size(), &n);
+                if (!rc) {
+                    out.resize(n);
+                    b->out_len[i] = (uint32_t)n;
+                    if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { b->out_w[i] = w; b->out_h[i] = h; }
+                    else if (opt->resize_method == LILLIPUT_OPS_FIT) lilliput_calculate_expected_size(w, h, opt->width, opt->height, &b->out_w[i], &b->out_h[i]);
+                    else { b->out_w[i] = std::max(opt->width, 1); b->out_h[i] = std::max(opt->height, 1); }
+                }
+                lilliput_decoder_close(d);
             }
-            lilliput_decoder_close(d);
+            b->status[i] = rc;
         }
-        b->status[i] = rc;
-    }
-    (void)lp_thread_device(prev_dev);
+        (void)lp_thread_device(prev_dev);
+    };
+    std::vector<std::thread> th;
+    for (size_t wi = 1; wi < nw; wi++) th.emplace_back(worker, wi);
+    worker(0);
+    for (auto& t : th) t.join();
 }
 
 int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
