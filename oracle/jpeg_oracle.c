@@ -179,7 +179,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
             in->height = rd16(p + 1);
             in->width = rd16(p + 3);
             if (in->height == 0 || in->width == 0 || nc == 0 || pl != 6 + 3 * nc) return LO_ERR_FORMAT;
-            if ((m != 0xC0 && m != 0xC1) || p[0] != 8 || (nc != 1 && nc != 3)) unsupported = 1;
+            if ((m != 0xC0 && m != 0xC1 && m != 0xC2) || p[0] != 8 || (nc != 1 && nc != 3)) unsupported = 1;
             in->ncomp = nc <= 3 ? nc : 3;
             for (int c = 0; c < nc; c++) {
                 int hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
@@ -209,6 +209,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
             if (L != ns * 2 + 6 || ns < 1 || ns > 4) return LO_ERR_FORMAT;
             if (in->height > 65500 || in->width > 65500 || bad_sampling) return LO_ERR_FORMAT;
             if (unsupported) return LO_ERR_UNSUPPORTED;
+            if (in->sof == 2) { in->ecs_off = seg_end; break; } /* progressive: the scans are walked by decode_coefs_progressive */
             for (int s = 0; s < ns; s++) {
                 int cs = p[1 + 2 * s], t = p[2 + 2 * s], c;
                 for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs && cur[c] < 0) break; /* libjpeg-turbo's slot rule */
@@ -250,6 +251,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
         if (in->hs[c] > in->hmax) in->hmax = in->hs[c];
         if (in->vs[c] > in->vmax) in->vmax = in->vs[c];
         if (in->tq[c] > 3 || !in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
+        if (in->sof == 2) continue; /* Huffman tables are checked scan by scan */
         if (!in->ht_present[0][in->td[c]] || !in->ht_present[1][in->ta[c]]) return LO_ERR_FORMAT;
         /* jdhuff.c jpeg_make_d_derived_tbl, run for the tables the scan uses: the code space must not overflow (the all-ones
            code of a length is reserved) and DC symbols are categories 0..15 -- else JERR_BAD_HUFF_TABLE */
@@ -366,11 +368,219 @@ static void dec_free(lo_dec* D)
     for (int c = 0; c < 4; c++) { free(D->coef[c]); free(D->plane[c]); }
 }
 
+/* ---- progressive JPEG (SOF2): jdphuff.c decode_mcu_DC_first / AC_first / DC_refine / AC_refine, scan by scan ---- */
+static int huff_ok(const uint8_t* bits, const uint8_t* vals, int is_dc)
+{
+    long code = 0;
+    int tot = 0;
+    for (int l = 1; l <= 16; l++) {
+        code += bits[l];
+        tot += bits[l];
+        if (code >= (1L << l)) return 0;
+        code <<= 1;
+    }
+    if (is_dc)
+        for (int q = 0; q < tot; q++)
+            if (vals[q] > 15) return 0;
+    return 1;
+}
+
+static void prog_restart(lo_bits* b) /* process_restart: drop the partial byte, swallow the RSTn marker */
+{
+    b->acc = 0;
+    b->nbits = 0;
+    if (!b->marker) {
+        while (b->pos + 1 < b->n && !(b->d[b->pos] == 0xFF && b->d[b->pos + 1] >= 0xD0 && b->d[b->pos + 1] <= 0xD7)) b->pos++;
+        if (b->pos + 1 < b->n) b->pos += 2;
+    }
+    b->marker = 0;
+}
+
+static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
+{
+    lo_jpeg_info* in = &D->in;
+    /* tables as they stand when a scan starts: DHT segments between scans replace entries */
+    uint8_t bits[2][4][17], vals[2][4][256];
+    int present[2][4];
+    memset(present, 0, sizeof(present));
+    for (int t = 0; t < 2; t++) { /* std_huff_tables(): ids 0/1 default to Annex K */
+        memcpy(bits[0][t], std_bits[2 * t], 17); memset(vals[0][t], 0, 256); memcpy(vals[0][t], std_dc_vals, 12);
+        memcpy(bits[1][t], std_bits[2 * t + 1], 17); memset(vals[1][t], 0, 256); memcpy(vals[1][t], t ? std_ac_chroma_vals : std_ac_luma_vals, 162);
+    }
+    int dri = 0;
+    int wib[4], hib[4]; /* blocks a non-interleaved scan walks: the image's own, not the MCU padding */
+    for (int c = 0; c < in->ncomp; c++) {
+        D->bw[c] = in->mcus_x * in->hs[c];
+        D->bh[c] = in->mcus_y * in->vs[c];
+        D->coef[c] = (int16_t*)calloc((size_t)D->bw[c] * D->bh[c] * 64, sizeof(int16_t));
+        if (!D->coef[c]) return LO_ERR_BUF;
+        wib[c] = (in->width * in->hs[c] + in->hmax * 8 - 1) / (in->hmax * 8);
+        hib[c] = (in->height * in->vs[c] + in->vmax * 8 - 1) / (in->vmax * 8);
+    }
+    size_t i = 2;
+    int scans = 0;
+    for (;;) {
+        int m;
+        for (;;) {
+            while (i < n && d[i] != 0xFF) i++;
+            while (i < n && d[i] == 0xFF) i++;
+            if (i >= n) return scans ? LO_OK : LO_ERR_FORMAT; /* ran off the end after at least one scan: libjpeg fakes an EOI */
+            m = d[i++];
+            if (m != 0) break;
+        }
+        if (m == 0xD9) return scans ? LO_OK : LO_ERR_FORMAT;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (i + 2 > n) return scans ? LO_OK : LO_ERR_FORMAT;
+        int L = rd16(d + i);
+        if (L < 2 || i + (size_t)L > n) return LO_ERR_FORMAT;
+        const uint8_t* p = d + i + 2;
+        int pl = L - 2;
+        size_t seg_end = i + (size_t)L;
+        if (m == 0xC4) {
+            int k = 0;
+            while (pl - k > 16) {
+                int tc = p[k] >> 4, th = p[k] & 15, tot = 0;
+                k++;
+                if (tc > 1 || th > 3) return LO_ERR_FORMAT;
+                bits[tc][th][0] = 0;
+                for (int b = 1; b <= 16; b++) { bits[tc][th][b] = p[k++]; tot += bits[tc][th][b]; }
+                if (tot > 256 || tot > pl - k) return LO_ERR_FORMAT;
+                memset(vals[tc][th], 0, 256);
+                memcpy(vals[tc][th], p + k, tot);
+                k += tot;
+                present[tc][th] = 1;
+            }
+            if (k != pl) return LO_ERR_FORMAT;
+        } else if (m == 0xDD) {
+            if (L != 4) return LO_ERR_FORMAT;
+            dri = rd16(p);
+        } else if (m == 0xDA) {
+            int ns = p[0];
+            if (L != ns * 2 + 6 || ns < 1 || ns > 4) return LO_ERR_FORMAT;
+            int sc[4], std_[4], sta[4];
+            for (int s = 0; s < ns; s++) {
+                int cs = p[1 + 2 * s], c;
+                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs) break;
+                if (c == in->ncomp) return LO_ERR_FORMAT;
+                sc[s] = c; std_[s] = p[2 + 2 * s] >> 4; sta[s] = p[2 + 2 * s] & 15;
+                if (std_[s] > 3 || sta[s] > 3) return LO_ERR_FORMAT;
+            }
+            int Ss = p[1 + 2 * ns], Se = p[2 + 2 * ns], Ah = p[3 + 2 * ns] >> 4, Al = p[3 + 2 * ns] & 15;
+            /* jdphuff.c start_pass_phuff_decoder: validate the progression parameters */
+            int bad = 0;
+            if (Ss == 0) { if (Se != 0) bad = 1; }
+            else { if (Se < Ss || Se > 63) bad = 1; if (ns != 1) bad = 1; }
+            if (Ah != 0 && Ah - 1 != Al) bad = 1;
+            if (Al > 13) bad = 1;
+            if (bad) return LO_ERR_FORMAT; /* JERR_BAD_PROGRESSION */
+            lo_htab tab[4];
+            for (int s = 0; s < ns; s++) {
+                int cls = Ss == 0 ? 0 : 1, id = Ss == 0 ? std_[s] : sta[s];
+                if (Ss == 0 && Ah != 0) continue; /* DC refinement reads raw bits */
+                if (id > 1 && !present[cls][id]) return LO_ERR_FORMAT; /* JERR_NO_HUFF_TABLE */
+                if (!huff_ok(bits[cls][id], vals[cls][id], cls == 0)) return LO_ERR_FORMAT;
+                build_htab(&tab[s], bits[cls][id], vals[cls][id]);
+            }
+            lo_bits b = {d, n, seg_end, 0, 0, 0};
+            int pred[4] = {0, 0, 0, 0}, eobrun = 0, rst_left = dri;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            int mcux, mcuy;
+            if (ns == 1) { mcux = wib[sc[0]]; mcuy = hib[sc[0]]; }
+            else { mcux = in->mcus_x; mcuy = in->mcus_y; }
+            for (int mi = 0; mi < mcux * mcuy; mi++) {
+                if (dri && rst_left == 0) { prog_restart(&b); pred[0] = pred[1] = pred[2] = pred[3] = 0; eobrun = 0; rst_left = dri; }
+                int mx = mi % mcux, my = mi / mcux;
+                for (int s = 0; s < ns; s++) {
+                    int c = sc[s];
+                    int nh = ns == 1 ? 1 : in->hs[c], nv = ns == 1 ? 1 : in->vs[c];
+                    for (int v = 0; v < nv; v++)
+                        for (int h = 0; h < nh; h++) {
+                            int bx = ns == 1 ? mx : mx * in->hs[c] + h, by = ns == 1 ? my : my * in->vs[c] + v;
+                            int16_t* blk = D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64;
+                            if (Ss == 0 && Ah == 0) { /* decode_mcu_DC_first */
+                                int t = decode_sym(&b, &tab[s]);
+                                fill(&b);
+                                int diff = t ? extend(getbits(&b, t), t) : 0;
+                                pred[c] += diff;
+                                blk[0] = (int16_t)(pred[c] * (1 << Al));
+                            } else if (Ss == 0) { /* decode_mcu_DC_refine */
+                                fill(&b);
+                                if (getbits(&b, 1)) blk[0] |= (int16_t)p1;
+                            } else if (Ah == 0) { /* decode_mcu_AC_first */
+                                if (eobrun > 0) { eobrun--; continue; }
+                                for (int k = Ss; k <= Se; k++) {
+                                    int rs = decode_sym(&b, &tab[s]), r = rs >> 4, t = rs & 15;
+                                    if (t) {
+                                        k += r;
+                                        fill(&b);
+                                        int val = extend(getbits(&b, t), t);
+                                        if (k < 64) blk[lo_zigzag[k]] = (int16_t)(val * (1 << Al));
+                                    } else if (r == 15) k += 15;
+                                    else {
+                                        eobrun = 1 << r;
+                                        if (r) { fill(&b); eobrun += getbits(&b, r); }
+                                        eobrun--;
+                                        break;
+                                    }
+                                }
+                            } else { /* decode_mcu_AC_refine */
+                                int k = Ss;
+                                if (eobrun == 0) {
+                                    for (; k <= Se; k++) {
+                                        int rs = decode_sym(&b, &tab[s]), r = rs >> 4, t = rs & 15;
+                                        if (t) {
+                                            fill(&b);
+                                            t = getbits(&b, 1) ? p1 : m1; /* the new coefficient's sign; its size is always 1 */
+                                        } else if (r != 15) {
+                                            eobrun = 1 << r;
+                                            if (r) { fill(&b); eobrun += getbits(&b, r); }
+                                            break; /* the rest of the band is handled as the first block of the run */
+                                        }
+                                        do { /* skip r still-zero coefficients, correcting the non-zero ones passed on the way */
+                                            int16_t* co = blk + lo_zigzag[k];
+                                            if (*co != 0) {
+                                                fill(&b);
+                                                if (getbits(&b, 1) && (*co & p1) == 0) *co = (int16_t)(*co >= 0 ? *co + p1 : *co + m1);
+                                            } else if (--r < 0) break;
+                                            k++;
+                                        } while (k <= Se);
+                                        if (t && k < 64) blk[lo_zigzag[k]] = (int16_t)t;
+                                    }
+                                }
+                                if (eobrun > 0) {
+                                    for (; k <= Se; k++) {
+                                        int16_t* co = blk + lo_zigzag[k];
+                                        if (*co != 0) {
+                                            fill(&b);
+                                            if (getbits(&b, 1) && (*co & p1) == 0) *co = (int16_t)(*co >= 0 ? *co + p1 : *co + m1);
+                                        }
+                                    }
+                                    eobrun--;
+                                }
+                            }
+                        }
+                }
+                if (dri) rst_left--;
+            }
+            scans++;
+            /* continue the marker walk after this scan's entropy-coded data */
+            i = seg_end;
+            while (i + 1 < n) {
+                if (d[i] == 0xFF && d[i + 1] != 0 && !(d[i + 1] >= 0xD0 && d[i + 1] <= 0xD7) && d[i + 1] != 0xFF) break;
+                i++;
+            }
+            continue;
+        }
+        i = seg_end;
+    }
+}
+
 static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
 {
     lo_jpeg_info* in = &D->in;
     int rc = lo_jpeg_read_header(d, n, in);
     if (rc) return rc;
+    if (in->sof == 2) return decode_coefs_progressive(d, n, D);
     lo_htab dc[4], ac[4];
     for (int t = 0; t < 4; t++) {
         if (in->ht_present[0][t]) build_htab(&dc[t], in->bits[0][t], in->vals[0][t]);
