@@ -133,7 +133,7 @@ size_t opencv_png_insert_cicp(void* png, size_t png_len, size_t png_cap, uint8_t
 /* ------------------------------------------------------------------------------------------------
  * Part A2 -- the decoder half of the reference's giflib.hpp C ABI (giflib.hpp:9-52; Go caller: giflib.go:56-242).
  * Container walk + LZW on the host, frame compositing (background, disposal, restore-to-previous, palette lookup) on the
- * device, on a canvas that stays in HBM for the life of the decoder. The encoder half (giflib_encoder_*) is not provided.
+ * device, on a canvas that stays in HBM for the life of the decoder.
  * ---------------------------------------------------------------------------------------------- */
 struct GifAnimationInfo {   /* giflib.hpp:9-17 */
     int loop_count;
@@ -150,6 +150,7 @@ struct GifAnimationInfo {   /* giflib.hpp:9-17 */
 #define GIF_DISPOSE_PREVIOUS 2
 
 typedef struct giflib_decoder_struct* giflib_decoder;   /* giflib.hpp:23 */
+typedef struct giflib_encoder_struct* giflib_encoder;   /* giflib.hpp:24 */
 
 typedef enum {              /* giflib.hpp:26-30 */
     giflib_decoder_have_next_frame,
@@ -172,6 +173,16 @@ giflib_decoder_frame_state giflib_decoder_skip_frame(giflib_decoder d);
 struct GifAnimationInfo giflib_decoder_get_animation_info(const giflib_decoder d);
 int giflib_decoder_get_prev_frame_disposal(const giflib_decoder d);
 
+/* giflib.hpp:45-50 -- a GIF is written from a GIF: palettes, delays and extension blocks come from the decoder `d`. The frame
+ * passed to encode_frame is the screen-sized CV_8UC4 Mat the resize produced; its BGRA -> palette-index mapping runs on the
+ * device, container and LZW coding on the host, byte-identical to giflib's writer. */
+giflib_encoder giflib_encoder_create(void* buf, size_t buf_len);
+bool giflib_encoder_init(giflib_encoder e, const giflib_decoder d, int width, int height);
+bool giflib_encoder_encode_frame(giflib_encoder e, const giflib_decoder d, const opencv_mat frame);
+bool giflib_encoder_flush(giflib_encoder e, const giflib_decoder d);
+void giflib_encoder_release(giflib_encoder e);
+int giflib_encoder_get_output_length(giflib_encoder e);
+
 /* Test access: the host half of decode_frame for the frame whose header was just read (no device work).
  * meta = {left, top, width, height, interlace, disposal, delay, transparent, color_count, has_local_map}; returns the
  * number of indices written, -1 on a decode error, -2 when cap is too small. */
@@ -192,6 +203,7 @@ int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, 
 #define LILLIPUT_ERR_ENCODE_TIMEOUT 7
 #define LILLIPUT_ERR_EOF 8
 #define LILLIPUT_ERR_SKIP_NOT_SUPPORTED 9   /* ErrSkipNotSupported, lilliput.go:29 */
+#define LILLIPUT_ERR_GIF_ENCODER_NEEDS_DECODER 10   /* ErrGifEncoderNeedsDecoder, giflib.go:44 */
 #define LILLIPUT_ERR_OPENCV_BASE 100        /* + OPENCV_ERROR_* : handleOpenCVError, opencv.go:399-426 */
 
 /* ops.go:18-22 */

@@ -19,6 +19,8 @@ ERR_NAMES = {
     6: "ErrFrameBufNoPixels",
     7: "ErrEncodeTimeout",
     8: "io.EOF",
+    9: "ErrSkipNotSupported",
+    10: "ErrGifEncoderNeedsDecoder",
 }
 ImageOpsNoResize, ImageOpsFit, ImageOpsResize = 0, 1, 2  # ops.go:18-22
 JpegQuality = 1  # opencv.go:44 (CV_IMWRITE_JPEG_QUALITY)

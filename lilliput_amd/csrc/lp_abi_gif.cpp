@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "lp_abi.h"
+#include "lp_abi_gif.h"
 #include "lp_gif.h"
 
 struct giflib_decoder_struct {
@@ -24,6 +25,9 @@ struct giflib_decoder_struct {
     // device state
     std::shared_ptr<LpDevBlock> canvas, saved;
 };
+
+const LpGifReader& lp_gif_reader(giflib_decoder d) { return d->gif; }
+int lp_gif_bg_alpha(giflib_decoder d) { return d->bg[3]; }
 
 namespace {
 enum { DISPOSAL_UNSPECIFIED = 0, DISPOSE_DO_NOT = 1, DISPOSE_BACKGROUND = 2, DISPOSE_PREVIOUS = 3 };
@@ -56,7 +60,7 @@ void set_frame_gcb(LpGifReader& g, const LpGifGcb& gcb) // giflib.cpp:266-284 (E
             b.bytes[0] = (uint8_t)(((gcb.disposal & 7) << 2) | (gcb.user_input ? 2 : 0) | (gcb.transparent != -1 ? 1 : 0));
             b.bytes[1] = (uint8_t)(gcb.delay & 0xff);
             b.bytes[2] = (uint8_t)((gcb.delay >> 8) & 0xff);
-            b.bytes[3] = (uint8_t)(gcb.transparent == -1 ? 0 : gcb.transparent);
+            b.bytes[3] = (uint8_t)gcb.transparent; // EGifGCBToExtension stores the field as it is: "none" (-1) becomes 0xff
         }
 }
 

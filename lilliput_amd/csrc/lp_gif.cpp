@@ -37,6 +37,9 @@ bool LpGifReader::open(const uint8_t* data, size_t len) // DGifOpen + DGifGetScr
     uint8_t s[3];
     if (read(s, 3) != 3) return false;
     sbackground = s[1];
+    scolor_resolution = (((s[0] & 0x70) + 1) >> 4) + 1;
+    aspect_byte = s[2];
+    global_sort_flag = (s[0] & 0x08) != 0;
     global_map.count = 0;
     if (s[0] & 0x80) {
         const int n = 1 << ((s[0] & 7) + 1);

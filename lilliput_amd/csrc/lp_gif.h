@@ -34,6 +34,8 @@ class LpGifReader {
     // DGifOpen: signature, logical screen descriptor, global colour map
     bool open(const uint8_t* data, size_t len);
     int swidth = 0, sheight = 0, sbackground = 0;
+    int scolor_resolution = 0, aspect_byte = 0; // SColorResolution, AspectByte: carried over by the encoder
+    bool global_sort_flag = false;              // SColorMap->SortFlag
     LpGifColorMap global_map;
     // current image descriptor (DGifGetImageHeader)
     int left = 0, top = 0, width = 0, height = 0;

@@ -874,6 +874,73 @@ void lp_launch_png(hipStream_t s, const LpPngOp& op)
     hipLaunchKernelGGL(k_png_convert, dim3((mw + 63) / 64, (mh + 3) / 4, op.npass), dim3(64, 4), 0, s, op);
 }
 
+// ---- GIF encoder: palette mapping (see LpGifEncOp)
+__device__ __forceinline__ int gif_dist(int r0, int g0, int b0, int r1, int g1, int b1) { return abs(r0 - r1) + abs(g0 - g1) + abs(b0 - b1); } // giflib.cpp:921-929
+
+__global__ __launch_bounds__(256) void k_gifenc_first(LpGifEncOp op)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= op.frame.w || y >= op.frame.h) return;
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(op.frame.off) + (size_t)y * op.frame.stride + (size_t)x * 4;
+    const uint32_t B = p[0], G = p[1], R = p[2], A = p[3];
+    if (A < 128 && op.transparent >= 0) return; // never reaches the cache
+    const uint32_t crushed = ((R >> 3) << 10) | ((G >> 3) << 5) | (B >> 3);
+    if (reinterpret_cast<const uint16_t*>(op.lookup_off)[crushed] != 0xffffu) return;
+    atomicMin(reinterpret_cast<uint32_t*>(op.first_off) + crushed, y * op.frame.w + x);
+}
+
+__global__ __launch_bounds__(256) void k_gifenc_fill(LpGifEncOp op)
+{
+    const uint32_t bucket = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t first = reinterpret_cast<const uint32_t*>(op.first_off)[bucket];
+    if (first == 0xffffffffu) return;
+    const uint32_t x = first % op.frame.w, y = first / op.frame.w;
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(op.frame.off) + (size_t)y * op.frame.stride + (size_t)x * 4;
+    const int B = p[0], G = p[1], R = p[2];
+    const bool extreme = (R > 240 && G > 240 && B > 240) || (R < 15 && G < 15 && B < 15);
+    const int rc = extreme ? R : (R & 0xf8) | 4, gc = extreme ? G : (G & 0xf8) | 4, bc = extreme ? B : (B & 0xf8) | 4;
+    const uint8_t* pal = reinterpret_cast<const uint8_t*>(op.palette_off);
+    int least = 0x7fffffff, best = 0;
+    for (int i = 0; i < op.color_count; i++) {
+        if (i == op.transparent) continue;
+        const int d = gif_dist(rc, gc, bc, pal[4 * i], pal[4 * i + 1], pal[4 * i + 2]);
+        if (d < least) { least = d; best = i; }
+    }
+    reinterpret_cast<uint16_t*>(op.lookup_off)[bucket] = (uint16_t)best;
+    reinterpret_cast<uint32_t*>(op.fresh_off)[bucket] = (uint32_t)least;
+}
+
+__global__ __launch_bounds__(256) void k_gifenc_map(LpGifEncOp op)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= op.frame.w || y >= op.frame.h) return;
+    const uint32_t idx = y * op.frame.w + x;
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(op.frame.off) + (size_t)y * op.frame.stride + (size_t)x * 4;
+    const int B = p[0], G = p[1], R = p[2], A = p[3];
+    uint8_t* out = reinterpret_cast<uint8_t*>(op.out_off) + idx;
+    if (A < 128 && op.transparent >= 0) { *out = (uint8_t)op.transparent; return; }
+    const uint32_t crushed = (((uint32_t)R >> 3) << 10) | (((uint32_t)G >> 3) << 5) | ((uint32_t)B >> 3);
+    int best = reinterpret_cast<const uint16_t*>(op.lookup_off)[crushed];
+    const uint8_t* pal = reinterpret_cast<const uint8_t*>(op.palette_off);
+    // the pixel that filled the bucket keeps the distance of its search; everybody else measures against the cached entry
+    int least = reinterpret_cast<const uint32_t*>(op.first_off)[crushed] == idx ? (int)reinterpret_cast<const uint32_t*>(op.fresh_off)[crushed]
+                                                                                 : gif_dist(R, G, B, pal[4 * best], pal[4 * best + 1], pal[4 * best + 2]);
+    if (op.use_prev && op.transparent >= 0) {
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(op.prev_off) + (size_t)idx * 4;
+        if (gif_dist(R, G, B, q[2], q[1], q[0]) < least) best = op.transparent;
+    }
+    *out = (uint8_t)best;
+}
+
+void lp_launch_gifenc(hipStream_t s, const LpGifEncOp& op)
+{
+    if (!op.frame.w || !op.frame.h) return;
+    dim3 g((op.frame.w + 63) / 64, (op.frame.h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_gifenc_first, g, dim3(64, 4), 0, s, op);
+    hipLaunchKernelGGL(k_gifenc_fill, dim3(128), dim3(256), 0, s, op);
+    hipLaunchKernelGGL(k_gifenc_map, g, dim3(64, 4), 0, s, op);
+}
+
 void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op)
 {
     if (!op.canvas.w || !op.canvas.h) return;

@@ -47,6 +47,7 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
 void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* d_src, uint8_t* d_dst);
 void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op);
 void lp_launch_png(hipStream_t s, const LpPngOp& op);
+void lp_launch_gifenc(hipStream_t s, const LpGifEncOp& op);
 // encode
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out);

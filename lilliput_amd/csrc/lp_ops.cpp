@@ -252,8 +252,10 @@ int skip_to_end(Decoder* d) // ops.go:337-346
 }
 
 struct Encoder { // openCVEncoder (opencv.go:141-146, 847-905), or the raw frame sink used by the tests
-    enum Kind { OPENCV, RAW_FRAMES } kind = OPENCV;
+    enum Kind { OPENCV, RAW_FRAMES, GIF } kind = OPENCV;
     opencv_encoder enc = nullptr;
+    giflib_encoder gif = nullptr; // gifEncoder, giflib.go:30-37, 239-296
+    int gif_frame_index = 0;
     opencv_mat dst = nullptr;
     uint8_t* dst_buf = nullptr;
     size_t dst_cap = 0, raw_len = 0;
@@ -452,11 +454,16 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
     std::string ext = lower(opt->file_type);
-    if (ext == ".gif" || ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
+    if (ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
     Encoder enc;
     enc.dst_buf = (uint8_t*)dst;
     enc.dst_cap = dst_cap;
-    if (ext == ".bgra-frames") {
+    if (ext == ".gif") { // newGifEncoder (giflib.go:239-256): palettes cannot be invented, the source has to be a GIF
+        if (d->kind != Decoder::GIF) return LILLIPUT_ERR_GIF_ENCODER_NEEDS_DECODER;
+        enc.kind = Encoder::GIF;
+        enc.gif = giflib_encoder_create(dst, dst_cap);
+        if (!enc.gif) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    } else if (ext == ".bgra-frames") {
         // Test access, not a reference format: an "animated encoder" that keeps every frame it is handed as
         // [u32 width][u32 height][u32 channels][u32 duration_ms][pixels] and, like the reference's animated encoders
         // (webp.go:220-256, giflib.go:259-292), returns content only when flushed with a nil frame.
@@ -467,7 +474,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
         if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
     }
-    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); } } guard{enc};
+    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); if (e.gif) giflib_encoder_release(e.gif); } } guard{enc};
     // newOpenCVEncoder asks the decoder for its ICC profile on every Transform (opencv.go:863); the JPEG writer then drops it
     // (cv::imencode has no ICC channel), so the read is kept for its cost profile only.
     if (enc.kind == Encoder::OPENCV) {
@@ -489,6 +496,19 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
             memcpy(enc.dst_buf + enc.raw_len, head, 16);
             memcpy(enc.dst_buf + enc.raw_len + 16, opencv_mat_get_data(f->mat), px);
             enc.raw_len += 16 + px;
+            return LILLIPUT_OK;
+        }
+        if (enc.kind == Encoder::GIF) { // gifEncoder.Encode, giflib.go:259-292
+            if (enc.flushed) return LILLIPUT_ERR_EOF;
+            if (!f) {
+                if (!giflib_encoder_flush(enc.gif, d->gif)) return LILLIPUT_ERR_INVALID_IMAGE;
+                enc.flushed = true;
+                *n = (size_t)giflib_encoder_get_output_length(enc.gif);
+                return *n ? LILLIPUT_OK : LILLIPUT_ERR_EOF;
+            }
+            if (enc.gif_frame_index == 0) (void)giflib_encoder_init(enc.gif, d->gif, f->width, f->height);
+            if (!giflib_encoder_encode_frame(enc.gif, d->gif, f->mat)) return LILLIPUT_ERR_INVALID_IMAGE;
+            enc.gif_frame_index++;
             return LILLIPUT_OK;
         }
         // opencv.go:872-900

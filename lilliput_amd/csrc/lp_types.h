@@ -176,6 +176,27 @@ struct LpGifFrameOp {
     uint8_t bg[4];              // B, G, R, A
 };
 
+// GIF encoder (giflib.cpp:921-1105 giflib_encoder_render_frame): BGRA frame -> palette indices. The reference walks the pixels
+// in raster order with a 32 768-entry cache keyed by the colour crushed to 5 bits per channel: the FIRST pixel that lands in an
+// empty bucket decides the bucket's palette entry (nearest by Manhattan distance to the bucket midpoint, or to the pixel itself
+// when it is nearly white / black), every later pixel of the bucket reuses it. Three kernels reproduce that order dependence:
+// k_gifenc_first (per bucket: lowest raster index among this frame's pixels, only where the cache is empty), k_gifenc_fill
+// (per claimed bucket: the entry that first pixel would have chosen), k_gifenc_map (per pixel: entry, or the transparent
+// index when the pixel is see-through or when the previous output frame already shows a closer colour).
+struct LpGifEncOp {
+    LpFrame frame;              // BGRA, the output-sized frame
+    uint64_t prev_off;          // device address of the previous output frame (tightly packed BGRA), read when use_prev
+    uint64_t lookup_off;        // device address of uint16[32768]: palette index, 0xffff = empty (persists while the palette stays the same)
+    uint64_t first_off;         // device address of uint32[32768]: scratch, 0xffffffff = unclaimed
+    uint64_t fresh_off;         // device address of uint32[32768]: distance found when the bucket was filled
+    uint64_t palette_off;       // device address of 256 x {R, G, B, 0}
+    uint64_t out_off;           // device address of the index raster (frame.w * frame.h bytes)
+    int32_t color_count;
+    int32_t transparent;        // -1 = none
+    uint32_t use_prev;          // previous frame stays on screen (disposal "unspecified" / "do not dispose") and a first frame exists
+    uint32_t pad;
+};
+
 // One PNG image on the device: `data_off` holds the inflated stream (per Adam7 pass, per row: filter byte + packed row);
 // k_png_unfilter reconstructs it in place, k_png_convert expands it to the 8-bit BGR(A) / grey frame OpenCV's PngDecoder yields.
 struct LpPngPass {

@@ -130,6 +130,13 @@ def ref_gif():
             _refgif.rg_next.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
             _refgif.rg_skip.argtypes = [C.c_void_p]
             _refgif.rg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+            _refgif.rg_enc_create.restype = C.c_void_p
+            _refgif.rg_enc_create.argtypes = [C.c_void_p, C.c_size_t]
+            _refgif.rg_enc_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            _refgif.rg_enc_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            _refgif.rg_enc_flush.restype = C.c_long
+            _refgif.rg_enc_flush.argtypes = [C.c_void_p, C.c_void_p]
+            _refgif.rg_enc_release.argtypes = [C.c_void_p]
     return _refgif
 
 
@@ -168,6 +175,48 @@ def ref_gif_frames(data, max_frames=1 << 30, skip=()):
         frames.append((canvas.copy(), list(meta), idx[: meta[2] * meta[3]].copy()))
     ref_gif().rg_close(h)
     return w, hh, frames, st
+
+
+def ref_gif_transcode(data, frame_fn, cap=64 << 20, max_frames=1 << 30):
+    """GIF -> GIF the way ImageOps.Transform drives gifDecoder + gifEncoder (giflib.go:180-296) with the reference's libgif:
+    every decoded canvas goes through frame_fn (HxWx4 BGRA -> H'xW'x4 BGRA, e.g. the oracle's Fit) and into the encoder.
+    Returns the output bytes, or None when decoder creation / a frame / the flush fails."""
+    L = ref_gif()
+    data = bytes(data)
+    dims = (C.c_int * 2)()
+    h = L.rg_open(data, len(data), dims)
+    if not h:
+        return None
+    out = np.zeros(cap, dtype=np.uint8)
+    e = L.rg_enc_create(out.ctypes.data, cap)
+    canvas = np.zeros((dims[1], dims[0], 4), dtype=np.uint8)
+    n, ok = 0, True
+    while n < max_frames:
+        meta = (C.c_int * 11)()
+        st = L.rg_next(h, canvas.ctypes.data, meta, None, 0)
+        if st == 1:
+            break
+        if st:
+            ok = False
+            break
+        fr = np.ascontiguousarray(frame_fn(canvas.copy()))
+        if n == 0:
+            L.rg_enc_init(e, h, fr.shape[1], fr.shape[0])
+        if not L.rg_enc_frame(e, h, fr.ctypes.data, fr.shape[1], fr.shape[0]):
+            ok = False
+            break
+        n += 1
+    res = None
+    if ok:
+        if n >= max_frames:  # skipToEnd: the decoder walks to the end so that the trailing extension blocks are the ones flushed
+            while L.rg_skip(h) == 0:
+                pass
+        length = L.rg_enc_flush(e, h)
+        if length >= 0:
+            res = out[:length].tobytes()
+    L.rg_enc_release(e)
+    L.rg_close(h)
+    return res
 
 
 def _buf(data):

@@ -271,3 +271,182 @@ done:
     DGifCloseFile(gif, &err);
     memcpy(out, info, sizeof(info));
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder side: giflib 5.2.2's EGif* writer driven the way the reference's giflib_encoder_* functions drive it
+ * (/root/reference/giflib.cpp:762-1306): screen descriptor and global palette carried over from the decoder, per frame the
+ * decoder's extension blocks and local palette, the BGRA -> palette-index mapping with its 15-bit bucket cache and the
+ * "previous frame already shows this colour" transparency trick, then EGifPutLine. */
+typedef struct {
+    GifFileType* gif;
+    uint8_t* dst;
+    size_t dst_len, off;
+    uint8_t lut_present[1 << 15], lut_index[1 << 15];
+    GifByteType* pixels;
+    size_t pixel_cap;
+    ColorMapObject* frame_map;      /* this frame's local palette (a copy), or NULL */
+    GifColorType prev_colors[256];  /* the palette used for the previous frame */
+    int prev_count;
+    int prev_disposal;
+    uint8_t* prev_bgra;
+    int have_first;
+} rg_enc;
+
+static int rg_write(GifFileType* gif, const GifByteType* buf, int len) /* giflib.cpp:762-771 */
+{
+    rg_enc* e = (rg_enc*)gif->UserData;
+    if (e->off + (size_t)len > e->dst_len) return 0;
+    memcpy(e->dst + e->off, buf, (size_t)len);
+    e->off += (size_t)len;
+    return len;
+}
+
+void* rg_enc_create(uint8_t* buf, size_t len) /* giflib.cpp:773-797 */
+{
+    rg_enc* e = (rg_enc*)calloc(1, sizeof(rg_enc));
+    int err = 0;
+    e->dst = buf;
+    e->dst_len = len;
+    e->gif = EGifOpen(e, rg_write, &err);
+    if (err || !e->gif) { free(e); return NULL; }
+    return e;
+}
+
+int rg_enc_init(void* he, void* hd, int width, int height) /* giflib.cpp:800-851 */
+{
+    rg_enc* e = (rg_enc*)he;
+    rg_dec* d = (rg_dec*)hd;
+    EGifSetGifVersion(e->gif, true);
+    e->prev_bgra = (uint8_t*)malloc((size_t)width * height * 4);
+    int bg = (d->gif->SColorMap && d->gif->SBackGroundColor >= 0 && d->gif->SBackGroundColor < d->gif->SColorMap->ColorCount) ? d->gif->SBackGroundColor : 0;
+    e->gif->AspectByte = d->gif->AspectByte;
+    return EGifPutScreenDesc(e->gif, width, height, d->gif->SColorResolution, bg, d->gif->SColorMap) != GIF_ERROR;
+}
+
+static int mdist(int r0, int g0, int b0, int r1, int g1, int b1) { return abs(r0 - r1) + abs(g0 - g1) + abs(b0 - b1); }
+
+/* frame: width x height BGRA, tightly packed */
+int rg_enc_frame(void* he, void* hd, const uint8_t* frame, int width, int height) /* giflib.cpp:853-1214 */
+{
+    rg_enc* e = (rg_enc*)he;
+    rg_dec* d = (rg_dec*)hd;
+    GifFileType* out = e->gif;
+    /* ---- setup_frame */
+    const int interlace = d->gif->Image.Interlace;
+    if (e->frame_map) { GifFreeMapObject(e->frame_map); e->frame_map = NULL; }
+    if (d->gif->Image.ColorMap) e->frame_map = GifMakeMapObject(d->gif->Image.ColorMap->ColorCount, d->gif->Image.ColorMap->Colors);
+    GifFreeExtensions(&out->ExtensionBlockCount, &out->ExtensionBlocks);
+    for (int i = 0; i < d->gif->ExtensionBlockCount; i++) {
+        ExtensionBlock* b = &d->gif->ExtensionBlocks[i];
+        GifAddExtensionBlock(&out->ExtensionBlockCount, &out->ExtensionBlocks, b->Function, b->ByteCount, b->Bytes);
+    }
+    GraphicsControlBlock gcb;
+    {
+        int ok = 1;
+        gcb.DisposalMode = DISPOSAL_UNSPECIFIED; gcb.UserInputFlag = 0; gcb.DelayTime = 0; gcb.TransparentColor = NO_TRANSPARENT_COLOR;
+        for (int i = 0; i < out->ExtensionBlockCount; i++)
+            if (out->ExtensionBlocks[i].Function == GRAPHICS_EXT_FUNC_CODE) ok = DGifExtensionToGCB(out->ExtensionBlocks[i].ByteCount, out->ExtensionBlocks[i].Bytes, &gcb) == GIF_OK;
+        if (ok && gcb.TransparentColor != NO_TRANSPARENT_COLOR) {
+            ColorMapObject* cm = e->frame_map ? e->frame_map : out->SColorMap;
+            if (cm && !e->frame_map && gcb.TransparentColor == out->SBackGroundColor && d->bg_a == 255) {
+                gcb.TransparentColor = NO_TRANSPARENT_COLOR;
+                set_frame_gcb(out, &gcb);
+            }
+        }
+    }
+    /* ---- render_frame */
+    if (width > out->SWidth || height > out->SHeight) return 0;
+    const size_t image_size = (size_t)width * height;
+    if (image_size > e->pixel_cap) { e->pixel_cap = image_size; e->pixels = (GifByteType*)realloc(e->pixels, image_size); }
+    ColorMapObject* cm = e->frame_map ? e->frame_map : out->SColorMap;
+    if (!cm) return 0;
+    int clear = 1;
+    if (e->have_first && e->prev_count == cm->ColorCount) clear = memcmp(e->prev_colors, cm->Colors, (size_t)cm->ColorCount * sizeof(GifColorType)) != 0;
+    if (clear) memset(e->lut_present, 0, sizeof(e->lut_present));
+    frame_gcb(out, &gcb);
+    const int tr = gcb.TransparentColor, have_tr = tr != NO_TRANSPARENT_COLOR;
+    const int prev_valid = e->have_first && (e->prev_disposal == DISPOSAL_UNSPECIFIED || e->prev_disposal == DISPOSE_DO_NOT);
+    GifByteType* ro = e->pixels;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint8_t* s = frame + ((size_t)y * width + x) * 4;
+            int B = s[0], G = s[1], R = s[2], A = s[3];
+            if (A < 128 && have_tr) { *ro++ = (GifByteType)tr; continue; }
+            unsigned crushed = ((unsigned)(R >> 3) << 10) | ((unsigned)(G >> 3) << 5) | (unsigned)(B >> 3);
+            int least = INT_MAX, best = 0;
+            if (!e->lut_present[crushed]) {
+                int extreme = (R > 240 && G > 240 && B > 240) || (R < 15 && G < 15 && B < 15);
+                int rc = extreme ? R : (R & 0xf8) | 4, gc = extreme ? G : (G & 0xf8) | 4, bc = extreme ? B : (B & 0xf8) | 4;
+                for (int i = 0; i < cm->ColorCount; i++) {
+                    if (i == tr) continue;
+                    int dd = mdist(rc, gc, bc, cm->Colors[i].Red, cm->Colors[i].Green, cm->Colors[i].Blue);
+                    if (dd < least) { least = dd; best = i; }
+                }
+                e->lut_present[crushed] = 1;
+                e->lut_index[crushed] = (uint8_t)best;
+            } else {
+                best = e->lut_index[crushed];
+                least = mdist(R, G, B, cm->Colors[best].Red, cm->Colors[best].Green, cm->Colors[best].Blue);
+            }
+            if (prev_valid && have_tr) {
+                const uint8_t* q = e->prev_bgra + ((size_t)y * out->SWidth + x) * 4;
+                if (mdist(R, G, B, q[2], q[1], q[0]) < least) best = tr;
+            }
+            *ro++ = (GifByteType)best;
+        }
+    memcpy(e->prev_bgra, frame, (size_t)4 * out->SWidth * out->SHeight);
+    e->prev_count = cm->ColorCount;
+    memcpy(e->prev_colors, cm->Colors, (size_t)cm->ColorCount * sizeof(GifColorType));
+    e->prev_disposal = gcb.DisposalMode;
+    /* ---- write_extensions + image */
+    for (int i = 0; i < out->ExtensionBlockCount; i++) {
+        ExtensionBlock* ep = &out->ExtensionBlocks[i];
+        if (ep->Function != CONTINUE_EXT_FUNC_CODE && EGifPutExtensionLeader(out, ep->Function) == GIF_ERROR) return 0;
+        if (EGifPutExtensionBlock(out, ep->ByteCount, ep->Bytes) == GIF_ERROR) return 0;
+        if ((i == out->ExtensionBlockCount - 1 || (ep + 1)->Function != CONTINUE_EXT_FUNC_CODE) && EGifPutExtensionTrailer(out) == GIF_ERROR) return 0;
+    }
+    if (EGifPutImageDesc(out, 0, 0, width, height, interlace, e->frame_map) == GIF_ERROR) return 0;
+    if (interlace) {
+        static const int off[4] = {0, 4, 2, 1}, jump[4] = {8, 8, 4, 2};
+        for (int i = 0; i < 4; i++)
+            for (int j = off[i]; j < height; j += jump[i])
+                if (EGifPutLine(out, e->pixels + (size_t)j * width, width) == GIF_ERROR) return 0;
+    } else
+        for (int i = 0; i < height; i++)
+            if (EGifPutLine(out, e->pixels + (size_t)i * width, width) == GIF_ERROR) return 0;
+    e->have_first = 1;
+    return 1;
+}
+
+long rg_enc_flush(void* he, void* hd) /* giflib.cpp:1216-1250; returns the output length, -1 on error */
+{
+    rg_enc* e = (rg_enc*)he;
+    rg_dec* d = (rg_dec*)hd;
+    GifFileType* out = e->gif;
+    GifFreeExtensions(&out->ExtensionBlockCount, &out->ExtensionBlocks);
+    for (int i = 0; i < d->gif->ExtensionBlockCount; i++) {
+        ExtensionBlock* b = &d->gif->ExtensionBlocks[i];
+        GifAddExtensionBlock(&out->ExtensionBlockCount, &out->ExtensionBlocks, b->Function, b->ByteCount, b->Bytes);
+    }
+    for (int i = 0; i < out->ExtensionBlockCount; i++) {
+        ExtensionBlock* ep = &out->ExtensionBlocks[i];
+        if (ep->Function != CONTINUE_EXT_FUNC_CODE && EGifPutExtensionLeader(out, ep->Function) == GIF_ERROR) return -1;
+        if (EGifPutExtensionBlock(out, ep->ByteCount, ep->Bytes) == GIF_ERROR) return -1;
+        if ((i == out->ExtensionBlockCount - 1 || (ep + 1)->Function != CONTINUE_EXT_FUNC_CODE) && EGifPutExtensionTrailer(out) == GIF_ERROR) return -1;
+    }
+    if (EGifCloseFile(out, NULL) == GIF_ERROR) { e->gif = NULL; return -1; }
+    e->gif = NULL;
+    return (long)e->off;
+}
+
+void rg_enc_release(void* he)
+{
+    rg_enc* e = (rg_enc*)he;
+    int err = 0;
+    if (!e) return;
+    if (e->gif) EGifCloseFile(e->gif, &err);
+    if (e->frame_map) GifFreeMapObject(e->frame_map);
+    free(e->pixels);
+    free(e->prev_bgra);
+    free(e);
+}

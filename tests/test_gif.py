@@ -309,3 +309,41 @@ def test_batch_serves_gif_items_next_to_jpegs(G, oracle, fixture_bytes):
         assert res[k].data == oracle.jpeg_encode(exp, 80), n
         assert (res[k].width, res[k].height) == exp.shape[1::-1]
     assert res[0].data == oracle.transform_jpeg_thumbnail(fixture_bytes["coast.jpg"], 48, 48, 80)
+
+
+# ------------------------------------------------------------------------------------------ GIF -> GIF
+@pytest.mark.gpu
+def test_gif_to_gif_is_byte_identical_to_the_reference_writer(G, oracle):
+    """ImageOps.Transform with FileType ".gif": decoder canvases -> composite -> Fit -> palette mapping on the device -> LZW on
+    the host. The bytes equal what the reference's libgif writes when driven like giflib.cpp:762-1306."""
+    import lilliput_amd as la
+
+    if oracle.ref_gif() is None:
+        pytest.skip("oracle/_ref/librefgif.so not built")
+    fx = gif_cases.fixtures()
+    hand = gif_cases.hand_cases()
+    sources = {n: fx[n] for n in ("party-discord.gif", "restore_previous.gif", "dispose_bgnd.gif", "no_gce_first_frame.gif", "duplicate_number_of_loops.gif", "no-loop.gif")}
+    sources.update({n: hand[n] for n in ("partial_frames", "local_maps", "interlaced", "transparent_first", "comment_and_app", "big_dictionary", "long_runs", "two_gce")})
+    for name, data in sources.items():
+        hdr = oracle.ref_gif_frames(data, max_frames=1)
+        w, h = hdr[0], hdr[1]
+        for method, tw, th in ((la.ImageOpsFit, max(1, w // 2), max(1, h // 2)), (la.ImageOpsNoResize, 0, 0), (la.ImageOpsResize, w + 3, max(1, h - 1))):
+            om = {la.ImageOpsFit: oracle.FIT, la.ImageOpsResize: oracle.RESIZE, la.ImageOpsNoResize: oracle.NO_RESIZE}[method]
+            exp = oracle.ref_gif_transcode(data, lambda c: oracle.transform_static(c, 1, tw, th, om, False))
+            got = _transform(data, FileType=".gif", Width=tw, Height=th, ResizeMethod=method)
+            assert exp is not None and got == exp, (name, method, len(got), len(exp))
+
+
+@pytest.mark.gpu
+def test_gif_output_needs_a_gif_source_and_respects_frame_limits(G, oracle, fixture_bytes):
+    import lilliput_amd as la
+
+    with pytest.raises(la.LilliputError) as e:
+        _transform(fixture_bytes["coast.jpg"], FileType=".gif", Width=16, Height=16)
+    assert e.value.code == 10
+    data = gif_cases.fixtures()["no-loop.gif"]
+    got = _transform(data, FileType=".gif", Width=40, Height=40, MaxEncodeFrames=3)
+    if oracle.ref_gif() is not None:
+        assert got == oracle.ref_gif_transcode(data, lambda c: oracle.transform_static(c, 1, 40, 40, oracle.FIT, False), max_frames=3)
+    back = oracle.ref_gif_frames(got) if oracle.ref_gif() is not None else None
+    assert back is None or (len(back[2]) == 3 and back[:2] == (40, 40))
