@@ -120,9 +120,21 @@ struct LpLane {
     // the lane jumped to the boundary (DC predictors must be reset by the caller, and peek() must be redone).
     LP_HD bool restart_check(uint32_t pk)
     {
-        const int32_t rem = (int32_t)(next_rst - p);
+        int32_t rem = (int32_t)(next_rst - p);
+        // A boundary BEHIND the lane: only a lane decoding from a wrong state can run over one in the middle of a block. It is
+        // left behind (the lane keeps going and synchronises at a later boundary or by itself): jumping back would make the
+        // lane visit the same positions twice, and a checkpoint of the first visit would splice the second visit's counts in
+        // again (found by tests/test_gpu_sweep.py with one-MCU restart intervals).
+        while (rem < 0) {
+            if (rst_k < ic.n_rst) {
+                rst_k++;
+                next_rst = rst_k < ic.n_rst ? m.rst_bit(rst_k) : ic.total_bits;
+            } else
+                next_rst = 0x7fffffffu;
+            rem = (int32_t)(next_rst - p);
+        }
         if (rem >= 8) return false;
-        bool jump = rem <= 0;
+        bool jump = rem == 0;
         if (!jump) jump = (pk >> (32 - rem)) == ((1u << rem) - 1u);
         if (!jump) return false;
         const uint32_t target = next_rst;

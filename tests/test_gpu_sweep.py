@@ -1,0 +1,70 @@
+"""Randomised sweep of the JPEG hot path: encoder settings Pillow exposes (quality 1-100, every chroma subsampling, optimised
+Huffman tables, restart intervals, greyscale, odd sizes, tiny and skinny images) -> device decode and device Transform against
+the oracle, bit for bit. Seeds are fixed; the sources are generated on the spot."""
+import io
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def _image(rng, h, w, gray):
+    y, x = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 90 * np.sin(x / rng.uniform(3, 40) + c) + 40 * np.cos(y / rng.uniform(3, 40) - c) for c in range(3)], -1)
+    img = base + rng.normal(0, rng.uniform(0, 25), (h, w, 3))
+    if rng.random() < 0.2:
+        img[rng.integers(0, h) :, :, :] = rng.choice([0, 255])  # a hard edge: large coefficients
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    return img[:, :, 0] if gray else img
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        h, w = (int(rng.integers(1, 40)), int(rng.integers(1, 40))) if rng.random() < 0.25 else (int(rng.integers(8, 420)), int(rng.integers(8, 420)))
+        if rng.random() < 0.1:
+            h, w = (1, int(rng.integers(1, 300))) if rng.random() < 0.5 else (int(rng.integers(1, 300)), 1)
+        gray = rng.random() < 0.15
+        kw = {"quality": int(rng.choice([1, 5, 25, 50, 75, 85, 90, 95, 100])), "optimize": bool(rng.random() < 0.4)}
+        if not gray:
+            kw["subsampling"] = int(rng.choice([0, 1, 2]))
+        if rng.random() < 0.35:
+            if rng.random() < 0.5:
+                kw["restart_marker_rows"] = int(rng.integers(1, 4))
+            else:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 12))
+        buf = io.BytesIO()
+        PIL.fromarray(_image(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        yield i, (h, w, gray, kw), buf.getvalue()
+
+
+@pytest.mark.gpu
+def test_random_jpegs_decode_bit_exact(batch, oracle):
+    bad = []
+    for i, desc, data in _cases(2024, 260):
+        exp = oracle.jpeg_decode(data)
+        got, _ = batch.decode_jpeg(data)
+        if got.shape != exp.shape or not np.array_equal(got, exp):
+            bad.append((i, desc))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.gpu
+def test_random_jpegs_transform_matches_oracle(batch, oracle):
+    """Batch Transform (fused and non-fused resample paths, all resize methods the batch takes) on the same kind of sources."""
+    rng = np.random.default_rng(7)
+    cases = list(_cases(99, 96))
+    bad = []
+    for tw, th, q in ((64, 64, 85), (37, 91, 70), (200, 120, 95), (16, 16, 50)):
+        res = batch.transform([c[2] for c in cases], tw, th, quality=q)
+        for (i, desc, data), r in zip(cases, res):
+            if r.status != 0:
+                bad.append((i, desc, (tw, th), "status %d" % r.status))
+                continue
+            exp = oracle.transform_jpeg_thumbnail(data, tw, th, q)
+            if r.data != exp:  # bit-identical except where the float area resize may differ by 1 LSB before the encoder
+                a, b = oracle.jpeg_decode(r.data), oracle.jpeg_decode(exp)
+                if a.shape != b.shape or np.abs(a.astype(int) - b.astype(int)).max() > 8:
+                    bad.append((i, desc, (tw, th), a.shape, b.shape, int(np.abs(a.astype(int) - b.astype(int)).max()) if a.shape == b.shape else -1))
+    assert not bad, (len(bad), bad[:12])

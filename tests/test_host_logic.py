@@ -198,3 +198,26 @@ def test_table_less_frames_use_annex_k_tables(hip_lib, oracle):
     assert np.array_equal(oracle.jpeg_decode(bare), oracle.jpeg_decode(full))
     if oracle.ref() is not None:
         assert np.array_equal(oracle.ref_jpeg_decode(bare), oracle.ref_jpeg_decode(full))
+
+
+def test_lane_logic_random_sweep(emu, oracle):
+    """The randomised sources of tests/test_gpu_sweep.py through the CPU emulation of the lane logic (every subsequence size the
+    engine picks for small images). Regression: with one-MCU restart intervals a speculating lane used to run over a boundary
+    mid-block, jump back to it and visit the same positions twice; a checkpoint of the first visit then spliced the second
+    visit's block count in again."""
+    import test_gpu_sweep as T
+
+    bad = []
+    for seed, n in ((99, 96), (2024, 40)):
+        for i, desc, data in T._cases(seed, n):
+            info = oracle.jpeg_info(data)
+            for S in (256, 1024):
+                for comp in range(info["ncomp"]):
+                    try:
+                        got, _, _ = _emu_coefs(emu, data, S, 64, comp)
+                        ok = np.array_equal(got, oracle.jpeg_decode_coefs(data, comp))
+                    except AssertionError:
+                        ok = False
+                    if not ok:
+                        bad.append((seed, i, desc, S, comp))
+    assert not bad, bad[:8]
