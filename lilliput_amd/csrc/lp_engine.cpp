@@ -286,7 +286,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (!check(hipMemcpyAsync(h_changed, d_changed_.p, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
         if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
         rounds++;
-        if (*h_changed == 0 || rounds >= 4096) break;
+        if (*h_changed == 0) break;
+        // every round makes at least one more subsequence final, so max_sub_ rounds always suffice; real streams need 1-3
+        if (rounds > max_sub_ + 1 || rounds >= 100000) { err_ = "entropy decode did not converge"; return LP_ERR_DECODE_FAILED; }
     }
     tm_.verify_rounds = rounds;
     if (pipelined_) hold.take(GROUP_WRITE); // the verify loop ended on a stream synchronisation: the counting group is finished on the device

@@ -19,23 +19,28 @@ def _image(rng, h, w, gray):
     return img[:, :, 0] if gray else img
 
 
-def _cases(seed, n):
+def _cases(seed, n, big=False):
     rng = np.random.default_rng(seed)
     for i in range(n):
         h, w = (int(rng.integers(1, 40)), int(rng.integers(1, 40))) if rng.random() < 0.25 else (int(rng.integers(8, 420)), int(rng.integers(8, 420)))
+        if big:
+            h, w = int(rng.integers(300, 1700)), int(rng.integers(300, 1700))
         if rng.random() < 0.1:
             h, w = (1, int(rng.integers(1, 300))) if rng.random() < 0.5 else (int(rng.integers(1, 300)), 1)
         gray = rng.random() < 0.15
         kw = {"quality": int(rng.choice([1, 5, 25, 50, 75, 85, 90, 95, 100])), "optimize": bool(rng.random() < 0.4)}
         if not gray:
             kw["subsampling"] = int(rng.choice([0, 1, 2]))
-        if rng.random() < 0.35:
+        if rng.random() < (0.6 if big else 0.35):
             if rng.random() < 0.5:
                 kw["restart_marker_rows"] = int(rng.integers(1, 4))
             else:
                 kw["restart_marker_blocks"] = int(rng.integers(1, 12))
         buf = io.BytesIO()
-        PIL.fromarray(_image(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        try:
+            PIL.fromarray(_image(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        except OSError:  # Pillow's encoder buffer is too small for some tiny-image / many-restart combinations
+            continue
         yield i, (h, w, gray, kw), buf.getvalue()
 
 
