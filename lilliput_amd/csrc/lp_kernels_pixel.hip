@@ -28,6 +28,9 @@ __device__ __forceinline__ int32_t upsampled(const uint8_t* __restrict__ P, uint
                                              int32_t x, int32_t y)
 {
     if (hr == 1 && vr == 1) return P[(size_t)y * stride + x];
+    // jdsample.c jinit_upsampler picks the fancy h2v1 / h2v2 routines only when downsampled_width > 2: the chroma of an image
+    // up to 4 pixels wide is plainly replicated (vertically as well in the h2v2 case)
+    if (hr == 2 && dw <= 2) return P[(size_t)(vr == 2 ? y >> 1 : y) * stride + (x >> 1)];
     if (hr == 2 && vr == 2) { // h2v2_fancy_upsample
         int32_t cy = y >> 1, ny = (y & 1) ? cy + 1 : cy - 1;
         ny = ny < 0 ? 0 : ny > dh - 1 ? dh - 1 : ny;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= W || y >= H || f.off == 0) return; // off == 0: this image takes the fused path
-    if (img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2) return; // k_ycc_to_frame_420
+    if (img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4) return; // k_ycc_to_frame_420
     const uint8_t* PY = plane_arena + img.plane_off[0];
     uint8_t* out = frame_arena + f.off + (size_t)y * f.stride;
     if (img.ncomp == 1) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame_420(const LpJpeg* __restri
 {
     const LpJpeg& img = imgs[blockIdx.z];
     const LpFrame& f = dsts[blockIdx.z];
-    if (f.off == 0 || !(img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2)) return; // generic kernel's job
+    if (f.off == 0 || !(img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4)) return; // generic kernel's job (incl. the non-fancy upsampling of very narrow images)
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (int32_t)(blockIdx.x * 64 + (threadIdx.x & 63)) * 8, cy = (int32_t)(blockIdx.y * 4 + (threadIdx.x >> 6));
     if (x0 >= W || 2 * cy >= H) return;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
         const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
         const int32_t hr = img.hmax / img.hs[1], vr = img.vmax / img.vs[1];
         const int32_t dw = (W * img.hs[1] + img.hmax - 1) / img.hmax, dh = (H * img.vs[1] + img.vmax - 1) / img.vmax;
-        const bool quad = hr == 2 && vr == 2 && !((fx0 | fy0 | (int32_t)op.rw | (int32_t)op.rh) & 1) && img.colorspace == 2;
+        const bool quad = hr == 2 && vr == 2 && dw > 2 && !((fx0 | fy0 | (int32_t)op.rw | (int32_t)op.rh) & 1) && img.colorspace == 2;
         if (quad) {
             const uint32_t qw = op.rw >> 1, nq = qw * (op.rh >> 1);
             for (uint32_t i = lane; i < nq; i += 64) {

@@ -704,6 +704,11 @@ static void upsample_plane(const lo_dec* D, int c, uint8_t* out)
     int dh = (H * in->vs[c] + in->vmax - 1) / in->vmax;
     if (hr == 1 && vr == 1) {
         for (int y = 0; y < H; y++) memcpy(out + (size_t)y * W, P + (size_t)y * pw, W);
+    } else if (hr == 2 && dw <= 2) {
+        /* jdsample.c jinit_upsampler: the fancy h2v1 / h2v2 routines are only chosen when downsampled_width > 2; narrower
+           components (images up to 4 pixels wide) get plain pixel replication, vertically too (h2v2_upsample) */
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) out[(size_t)y * W + x] = P[(size_t)(vr == 2 ? y >> 1 : y) * pw + (x >> 1)];
     } else if (hr == 2 && vr == 2) { /* h2v2_fancy_upsample */
         int* cs = (int*)malloc(sizeof(int) * dw);
         for (int y = 0; y < H; y++) {

@@ -73,3 +73,21 @@ def test_random_jpegs_transform_matches_oracle(batch, oracle):
                 if a.shape != b.shape or np.abs(a.astype(int) - b.astype(int)).max() > 8:
                     bad.append((i, desc, (tw, th), a.shape, b.shape, int(np.abs(a.astype(int) - b.astype(int)).max()) if a.shape == b.shape else -1))
     assert not bad, (len(bad), bad[:12])
+
+
+@pytest.mark.gpu
+def test_narrow_images_use_plain_chroma_replication(batch, oracle):
+    """jdsample.c picks the fancy h2v1 / h2v2 upsamplers only when the chroma plane is more than two samples wide: images up to
+    four pixels wide get plain replication (the oracle is checked against the real libjpeg on the same files in
+    tests/test_oracle_golden.py)."""
+    rng = np.random.default_rng(1)
+    for sub in (2, 1, 0):
+        for w in range(1, 10):
+            for h in (1, 2, 3, 5, 9, 40):
+                buf = io.BytesIO()
+                PIL.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(buf, "JPEG", quality=90, subsampling=sub)
+                data = buf.getvalue()
+                got, _ = batch.decode_jpeg(data)
+                assert np.array_equal(got, oracle.jpeg_decode(data)), (sub, w, h)
+                r = batch.transform([data], max(1, w // 2), max(1, h // 2), quality=90)[0]
+                assert r.status == 0 and r.data == oracle.transform_jpeg_thumbnail(data, max(1, w // 2), max(1, h // 2), 90), (sub, w, h)

@@ -96,3 +96,38 @@ def test_go_control_logic(oracle):
     assert oracle.fit_crop_rect(800, 297, 297, 297) == (251, 0, 297, 297)
     assert oracle.fit_crop_rect(480, 270, 128, 128) == (105, 0, 270, 270)
     assert oracle.fit_crop_rect(8192, 6144, 256, 256) == (1024, 0, 6144, 6144)
+
+
+def test_restatement_vs_reference_library_on_generated_files(oracle):
+    """Randomised sources (every Pillow encoder setting, tiny and skinny images, restart intervals, optimised tables) and
+    progressive files: decode bit-exact against the reference's libjpeg-turbo; random pixels: encode byte-identical."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built (needs /root/reference)")
+    import io
+
+    from PIL import Image
+
+    import test_gpu_sweep as T
+
+    for seed in (11, 12, 13):
+        for i, desc, data in T._cases(seed, 120):
+            assert np.array_equal(oracle.jpeg_decode(data), oracle.ref_jpeg_decode(data)), (seed, i, desc)
+    rng = np.random.default_rng(1)
+    for sub in (2, 1, 0):
+        for w in range(1, 10):
+            for h in (1, 2, 3, 9):
+                b = io.BytesIO()
+                Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(b, "JPEG", quality=90, subsampling=sub)
+                assert np.array_equal(oracle.jpeg_decode(b.getvalue()), oracle.ref_jpeg_decode(b.getvalue())), (sub, w, h)
+    for (h, w, sub, q, extra) in ((64, 64, 2, 85, {}), (123, 77, 2, 90, {}), (200, 333, 0, 75, {}), (97, 150, 1, 95, {"optimize": True}), (64, 80, 2, 85, {"restart_marker_rows": 1})):
+        b = io.BytesIO()
+        y, x = np.mgrid[0:h, 0:w]
+        px = np.clip(np.stack([128 + 90 * np.sin(x / 17.0 + c) + 30 * np.cos(y / 9.0) for c in range(3)], -1) + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+        Image.fromarray(px).save(b, "JPEG", quality=q, progressive=True, subsampling=sub, **extra)
+        assert np.array_equal(oracle.jpeg_decode(b.getvalue()), oracle.ref_jpeg_decode(b.getvalue())), ("progressive", h, w, sub)
+    for it in range(200):
+        cn = int(rng.choice([1, 3, 4]))
+        px = rng.integers(0, 256, (int(rng.integers(1, 200)), int(rng.integers(1, 200)), cn), dtype=np.uint8)
+        q = int(rng.choice([1, 10, 50, 85, 100]))
+        src = px[:, :, 0] if cn == 1 else px
+        assert oracle.jpeg_encode(src, q) == oracle.ref_jpeg_encode(src, q), (px.shape, q)
