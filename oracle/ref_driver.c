@@ -175,3 +175,44 @@ long ref_jpeg_encode(const uint8_t* px, int W, int H, int ch, size_t stride, int
     free(mem);
     return rc;
 }
+
+/* Fixture generator (tests/golden/make_exotic_jpegs.py): libjpeg-turbo's compressor with the knobs Pillow does not expose.
+ * px: W x H x 3 RGB (or W x H grey when ncomp == 1). mode: 0 YCbCr + JFIF, 1 RGB data kept as RGB (Adobe marker, transform 0),
+ * 2 YCbCr without JFIF but with an Adobe marker (transform 1), 3 YCbCr with neither marker.
+ * samp = {h0, v0, h1, v1, h2, v2}; force_baseline 0 lets low qualities produce 16-bit quantisation tables (SOF1). */
+long ref_jpeg_encode_ex(const uint8_t* px, int W, int H, int ncomp, int mode, const int samp[6], int quality, int force_baseline, int restart_interval,
+                        int optimize, uint8_t* out, size_t cap)
+{
+    struct jpeg_compress_struct ci;
+    struct err_mgr em;
+    unsigned char* mem = NULL;
+    unsigned long memlen = 0;
+    ci.err = jpeg_std_error(&em.pub);
+    em.pub.error_exit = on_error;
+    em.pub.output_message = on_msg;
+    if (setjmp(em.jb)) { jpeg_destroy_compress(&ci); free(mem); return -1; }
+    jpeg_create_compress(&ci);
+    jpeg_mem_dest(&ci, &mem, &memlen);
+    ci.image_width = (JDIMENSION)W;
+    ci.image_height = (JDIMENSION)H;
+    ci.input_components = ncomp;
+    ci.in_color_space = ncomp == 1 ? JCS_GRAYSCALE : JCS_RGB;
+    jpeg_set_defaults(&ci);
+    if (ncomp == 3 && mode == 1) jpeg_set_colorspace(&ci, JCS_RGB);
+    if (ncomp == 3 && mode >= 2) { ci.write_JFIF_header = FALSE; ci.write_Adobe_marker = mode == 2; }
+    jpeg_set_quality(&ci, quality, force_baseline);
+    for (int c = 0; c < ncomp; c++) { ci.comp_info[c].h_samp_factor = samp[2 * c]; ci.comp_info[c].v_samp_factor = samp[2 * c + 1]; }
+    ci.restart_interval = (unsigned)restart_interval;
+    ci.optimize_coding = optimize;
+    jpeg_start_compress(&ci, TRUE);
+    while (ci.next_scanline < ci.image_height) {
+        JSAMPROW row = (JSAMPROW)(px + (size_t)ci.next_scanline * W * ncomp);
+        jpeg_write_scanlines(&ci, &row, 1);
+    }
+    jpeg_finish_compress(&ci);
+    jpeg_destroy_compress(&ci);
+    long rc = (long)memlen;
+    if (memlen > cap) rc = -3; else memcpy(out, mem, memlen);
+    free(mem);
+    return rc;
+}

@@ -1,0 +1,52 @@
+"""Writes tests/golden/inputs_exotic/*.jpg with the reference's own libjpeg-turbo compressor (oracle/_ref/libref.so): samplings,
+colour spaces and table widths Pillow cannot produce (4:4:0, 2x2 luma with custom chroma factors, RGB-in-JPEG with an Adobe
+marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row), and
+tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file.
+Run in the build container (needs /root/reference)."""
+import ctypes as C, hashlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O
+
+R = O.ref()
+assert R is not None
+R.ref_jpeg_encode_ex.restype = C.c_long
+out_dir = os.path.join(ROOT, "tests", "golden", "inputs_exotic")
+rng = np.random.default_rng(42)
+
+def photo(h, w, c):
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 95 * np.sin(x / 13.0 + k) + 35 * np.cos(y / 7.0 - k) for k in range(3)], -1) + rng.normal(0, 9, (h, w, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(img[:, :, 0] if c == 1 else img)
+
+def enc(name, h, w, ncomp, mode, samp, q, force_baseline=1, dri=0, optimize=0):
+    px = photo(h, w, ncomp)
+    buf = np.zeros(h * w * 3 + 65536, np.uint8)
+    n = R.ref_jpeg_encode_ex(px.ctypes.data_as(C.c_void_p), w, h, ncomp, mode, (C.c_int * 6)(*samp), q, force_baseline, dri, optimize, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+    assert n > 0, name
+    open(os.path.join(out_dir, name + ".jpg"), "wb").write(buf[:n].tobytes())
+
+S444, S422, S420, S440 = (1, 1, 1, 1, 1, 1), (2, 1, 1, 1, 1, 1), (2, 2, 1, 1, 1, 1), (1, 2, 1, 1, 1, 1)
+enc("s440", 61, 83, 3, 0, S440, 88)
+enc("s440_dri5_opt", 100, 37, 3, 0, S440, 75, dri=5, optimize=1)
+enc("s440_narrow", 40, 3, 3, 0, S440, 90)
+enc("rgb_adobe_444", 45, 52, 3, 1, S444, 90)
+enc("rgb_adobe_dri", 33, 70, 3, 1, S444, 60, dri=3)
+enc("ycc_adobe_420", 70, 90, 3, 2, S420, 85)
+enc("ycc_nomarker_422", 50, 66, 3, 3, S422, 85)
+enc("q1_16bit_tables_420", 64, 64, 3, 0, S420, 1, force_baseline=0)
+enc("q2_16bit_tables_gray", 57, 41, 1, 0, (1, 1, 1, 1, 1, 1), 2, force_baseline=0)
+enc("q1_baseline_444", 30, 30, 3, 0, S444, 1)
+enc("q100_420_opt", 48, 80, 3, 0, S420, 100, optimize=1)
+enc("dri7_420", 90, 75, 3, 0, S420, 80, dri=7)
+enc("dri1_444", 24, 40, 3, 0, S444, 92, dri=1)
+enc("gray_dri2", 40, 56, 1, 0, (1, 1, 1, 1, 1, 1), 70, dri=2)
+gold = {}
+for f in sorted(os.listdir(out_dir)):
+    d = open(os.path.join(out_dir, f), "rb").read()
+    px = O.ref_jpeg_decode(d)
+    gold[f] = "%dx%dx%d:%s" % (px.shape[0], px.shape[1], px.shape[2], hashlib.sha1(px.tobytes()).hexdigest()[:16])
+json.dump(gold, open(os.path.join(ROOT, "tests", "golden", "exotic_golden.json"), "w"), indent=0, sort_keys=True)
+print(len(gold), "files,", sum(os.path.getsize(os.path.join(out_dir, f)) for f in gold), "bytes")

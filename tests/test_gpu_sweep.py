@@ -91,3 +91,44 @@ def test_narrow_images_use_plain_chroma_replication(batch, oracle):
                 assert np.array_equal(got, oracle.jpeg_decode(data)), (sub, w, h)
                 r = batch.transform([data], max(1, w // 2), max(1, h // 2), quality=90)[0]
                 assert r.status == 0 and r.data == oracle.transform_jpeg_thumbnail(data, max(1, w // 2), max(1, h // 2), 90), (sub, w, h)
+
+
+def _exotic():
+    import os
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs_exotic")
+    return {n: open(os.path.join(d, n), "rb").read() for n in sorted(os.listdir(d))}
+
+
+def test_oracle_decodes_exotic_fixtures_like_the_reference_library(oracle):
+    """Files written by the reference's own libjpeg-turbo compressor with settings Pillow cannot produce (4:4:0, RGB-in-JPEG with
+    an Adobe marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, odd restart intervals); the recorded digests are of
+    the pixels the reference's libjpeg decodes (tests/golden/make_exotic_jpegs.py)."""
+    import hashlib
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exotic_golden.json")))
+    for name, data in _exotic().items():
+        px = oracle.jpeg_decode(data)
+        assert "%dx%dx%d:%s" % (px.shape[0], px.shape[1], px.shape[2], hashlib.sha1(px.tobytes()).hexdigest()[:16]) == gold[name], name
+
+
+@pytest.mark.gpu
+def test_exotic_fixtures_on_device(batch, oracle):
+    import hashlib
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "exotic_golden.json")))
+    files = _exotic()
+    for name, data in files.items():
+        got, _ = batch.decode_jpeg(data)
+        exp = oracle.jpeg_decode(data)
+        assert got.shape == exp.shape and np.array_equal(got, exp), name
+        assert "%dx%dx%d:%s" % (got.shape[0], got.shape[1], got.shape[2], hashlib.sha1(got.tobytes()).hexdigest()[:16]) == gold[name], name
+    names = list(files)
+    for tw, th in ((20, 20), (13, 31)):
+        res = batch.transform([files[n] for n in names], tw, th, quality=85)
+        for n, r in zip(names, res):
+            assert r.status == 0 and r.data == oracle.transform_jpeg_thumbnail(files[n], tw, th, 85), (n, tw, th)
