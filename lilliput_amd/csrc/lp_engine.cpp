@@ -215,8 +215,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         j.rst_off = tot_rst_;
         j.rst_cap = j.dri ? (j.mcus_x * j.mcus_y + j.dri - 1) / j.dri + 2 : 2;
         tot_rst_ += j.rst_cap;
-        j.coef_off = coef_elems;
-        coef_elems += (size_t)j.total_blocks * 64;
+        j.coef_off = coef_elems; // a multiple of 8 blocks: a group of eight DC values is one aligned 16-byte store (DevSink)
+        coef_elems += (((size_t)j.total_blocks + 7) & ~(size_t)7) * 64;
         uint32_t rows = 0;
         for (int c = 0; c < j.ncomp; c++) {
             j.plane_off[c] = plane_bytes;

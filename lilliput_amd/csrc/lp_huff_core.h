@@ -391,6 +391,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 //   void end_block(uint32_t blk, bool on);         when `on`: the block (decode-order index blk) is complete (queued for flushing)
 //   bool stalled();                                no free slot: the lane must wait for the next flush
 //   void flush();                                  wave-uniform: write out every queued block
+//   void finish();                                 once, after the last flush
 // Returns the number of blocks written.
 #ifndef LP_FLUSH_EVERY
 #define LP_FLUSH_EVERY 2
@@ -430,6 +431,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         }
     } while (m.any(!done));
     sink.flush();
+    sink.finish();
     return written;
 }
 

@@ -478,6 +478,9 @@ struct DevSink {
     int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
                             // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
     int32_t dcv;            // DC difference of the current block
+    int16_t* dcl;           // LDS: this lane's 8 most recent DC differences (a lane's blocks are consecutive, so eight of them are one
+                            // aligned 16-byte store; one 2-byte store per block cost a 32-byte write transaction each -- profiles/r01_e)
+    uint32_t blk0, last;    // first block of this lane, last block flushed (0xffffffff = none yet)
     __device__ __forceinline__ void put_dc(int32_t v, bool on) { dcv = on ? v : dcv; }
     __device__ __forceinline__ void put(uint32_t nat, int32_t v)
     {
@@ -508,8 +511,22 @@ struct DevSink {
             __builtin_nontemporal_store((u32x4){r0.x, r0.y, r0.z, r0.w}, on); __builtin_nontemporal_store((u32x4){r1.x, r1.y, r1.z, r1.w}, on + 1);
             __builtin_nontemporal_store((u32x4){r2.x, r2.y, r2.z, r2.w}, on + 2); __builtin_nontemporal_store((u32x4){r3.x, r3.y, r3.z, r3.w}, on + 3);
             s[0] = zero; s[64] = zero; s[128] = zero; s[192] = zero;
-            dc16[qblk] = (int16_t)dcv;
+            const uint32_t k = qblk & 7u;
+            dcl[k] = (int16_t)dcv;
+            if (k == 7u) {
+                const uint32_t g0 = qblk - 7u;
+                if (g0 >= blk0) *reinterpret_cast<uint4*>(dc16 + g0) = *reinterpret_cast<const uint4*>(dcl); // the whole group is this lane's
+                else for (uint32_t j = blk0 - g0; j < 8u; j++) dc16[g0 + j] = dcl[j];                        // the lane started inside the group
+            }
+            last = qblk;
             qblk = 0xffffffffu;
+        }
+    }
+    __device__ __forceinline__ void finish() // the lane's last, incomplete group of DC values
+    {
+        if (last != 0xffffffffu && (last & 7u) != 7u) {
+            const uint32_t g0 = last & ~7u;
+            for (uint32_t b = g0 > blk0 ? g0 : blk0; b <= last; b++) dc16[b] = dcl[b & 7u];
         }
     }
 };
@@ -526,6 +543,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
+    __shared__ __attribute__((aligned(16))) int16_t s_dcl[HUFF_T * 8];
     const LpJpeg& img = imgs[blockIdx.y];
     LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -555,6 +573,9 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wslot = 0xffffffffu;
     sink.dc16 = dc_arena + img.coef_off / 64;
     sink.dcv = 0;
+    sink.dcl = s_dcl + threadIdx.x * 8;
+    sink.blk0 = prefixes[g].nblk;
+    sink.last = 0xffffffffu;
     lp_write_pass(m, ic, entry, exits[g].p, prefixes[g], s_zz, sink);
 }
 

@@ -51,6 +51,7 @@ struct HostSink { // one slot, flushed at the wave-uniform flush points like the
     void end_block(uint32_t b, bool on) { if (on) pending = coef + (size_t)b * 64; }
     bool stalled() const { return pending != nullptr; }
     void flush() { if (pending) { memcpy(pending, blk, 128); memset(blk, 0, sizeof(blk)); pending = nullptr; } }
+    void finish() {}
 };
 
 struct HostCk {
