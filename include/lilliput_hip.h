@@ -188,6 +188,13 @@ int giflib_encoder_get_output_length(giflib_encoder e);
  * number of indices written, -1 on a decode error, -2 when cap is too small. */
 int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, int meta[10], uint8_t palette_rgb[768]);
 
+/* thumbhash.hpp:12-16 -- ThumbHash of a frame (CV_8U / CV_8UC3 / CV_8UC4): at most 100 x 100 nearest-neighbour samples are gathered
+ * on the device, the hash is computed on the host in the reference's summation order. Returns its length, -1 on error. */
+typedef struct thumbhash_encoder_struct* thumbhash_encoder;
+thumbhash_encoder thumbhash_encoder_create(void* buf, size_t buf_len);
+int thumbhash_encoder_encode(thumbhash_encoder e, const opencv_mat frame);
+void thumbhash_encoder_release(thumbhash_encoder e);
+
 /* ------------------------------------------------------------------------------------------------
  * Part B -- batched extension (additive)
  * ---------------------------------------------------------------------------------------------- */

@@ -625,6 +625,20 @@ int LpEngine::composite(const LpCompositeOp& op)
     return check(hipGetLastError(), "composite kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
+int LpEngine::gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t ib = ((size_t)(w + h) * 4 + 255) & ~(size_t)255, ob = (size_t)w * h * f.cn;
+    if (!d_ops_.ensure(ib + ob + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    uint8_t* base = d_ops_.as<uint8_t>();
+    if (!check(hipMemcpyAsync(base, idx, (size_t)(w + h) * 4, hipMemcpyHostToDevice, stream_), "H2D sample coordinates")) return LP_ERR_DEVICE;
+    lp_launch_gather_samples(stream_, f, reinterpret_cast<const uint32_t*>(base), w, h, base + ib);
+    if (!check(hipMemcpyAsync(out, base + ib, ob, hipMemcpyDeviceToHost, stream_), "D2H samples")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "gather sync")) return LP_ERR_DEVICE;
+    return check(hipGetLastError(), "gather kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
 int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra)
 {
     if (!ok_) return LP_ERR_DEVICE;

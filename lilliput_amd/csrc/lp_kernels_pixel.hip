@@ -877,6 +877,21 @@ void lp_launch_png(hipStream_t s, const LpPngOp& op)
     hipLaunchKernelGGL(k_png_convert, dim3((mw + 63) / 64, (mh + 3) / 4, op.npass), dim3(64, 4), 0, s, op);
 }
 
+// ThumbHash's nearest-neighbour samples (thumbhash.cpp:118-193): out[(i * w + j) * cn ..] = frame(rows[i], cols[j]).
+__global__ __launch_bounds__(256) void k_gather_samples(LpFrame f, const uint32_t* __restrict__ idx, uint32_t w, uint32_t h, uint8_t* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= w || i >= h) return;
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(f.off) + (size_t)idx[w + i] * f.stride + (size_t)idx[j] * f.cn;
+    uint8_t* o = out + ((size_t)i * w + j) * f.cn;
+    for (uint32_t c = 0; c < f.cn; c++) o[c] = p[c];
+}
+
+void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d_idx, uint32_t w, uint32_t h, uint8_t* d_out)
+{
+    hipLaunchKernelGGL(k_gather_samples, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, f, d_idx, w, h, d_out);
+}
+
 // ---- GIF encoder: palette mapping (see LpGifEncOp)
 __device__ __forceinline__ int gif_dist(int r0, int g0, int b0, int r1, int g1, int b1) { return abs(r0 - r1) + abs(g0 - g1) + abs(b0 - b1); } // giflib.cpp:921-929
 

@@ -48,6 +48,7 @@ void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* 
 void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op);
 void lp_launch_png(hipStream_t s, const LpPngOp& op);
 void lp_launch_gifenc(hipStream_t s, const LpGifEncOp& op);
+void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d_idx, uint32_t w, uint32_t h, uint8_t* d_out);
 // encode
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out);

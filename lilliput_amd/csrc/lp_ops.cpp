@@ -252,7 +252,8 @@ int skip_to_end(Decoder* d) // ops.go:337-346
 }
 
 struct Encoder { // openCVEncoder (opencv.go:141-146, 847-905), or the raw frame sink used by the tests
-    enum Kind { OPENCV, RAW_FRAMES, GIF } kind = OPENCV;
+    enum Kind { OPENCV, RAW_FRAMES, GIF, THUMBHASH } kind = OPENCV;
+    thumbhash_encoder th = nullptr; // thumbhashEncoder, thumbhash.go:12-16
     opencv_encoder enc = nullptr;
     giflib_encoder gif = nullptr; // gifEncoder, giflib.go:30-37, 239-296
     int gif_frame_index = 0;
@@ -454,7 +455,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
     std::string ext = lower(opt->file_type);
-    if (ext == ".webp" || ext == ".avif" || ext == ".thumbhash" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
+    if (ext == ".webp" || ext == ".avif" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
     Encoder enc;
     enc.dst_buf = (uint8_t*)dst;
     enc.dst_cap = dst_cap;
@@ -463,6 +464,10 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         enc.kind = Encoder::GIF;
         enc.gif = giflib_encoder_create(dst, dst_cap);
         if (!enc.gif) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    } else if (ext == ".thumbhash") { // newThumbhashEncoder, thumbhash.go:21-32
+        enc.kind = Encoder::THUMBHASH;
+        enc.th = thumbhash_encoder_create(dst, dst_cap);
+        if (!enc.th) return LILLIPUT_ERR_BUF_TOO_SMALL;
     } else if (ext == ".bgra-frames") {
         // Test access, not a reference format: an "animated encoder" that keeps every frame it is handed as
         // [u32 width][u32 height][u32 channels][u32 duration_ms][pixels] and, like the reference's animated encoders
@@ -474,7 +479,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
         if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
     }
-    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); if (e.gif) giflib_encoder_release(e.gif); } } guard{enc};
+    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); if (e.gif) giflib_encoder_release(e.gif); if (e.th) thumbhash_encoder_release(e.th); } } guard{enc};
     // newOpenCVEncoder asks the decoder for its ICC profile on every Transform (opencv.go:863); the JPEG writer then drops it
     // (cv::imencode has no ICC channel), so the read is kept for its cost profile only.
     if (enc.kind == Encoder::OPENCV) {
@@ -496,6 +501,13 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
             memcpy(enc.dst_buf + enc.raw_len, head, 16);
             memcpy(enc.dst_buf + enc.raw_len + 16, opencv_mat_get_data(f->mat), px);
             enc.raw_len += 16 + px;
+            return LILLIPUT_OK;
+        }
+        if (enc.kind == Encoder::THUMBHASH) { // thumbhashEncoder.Encode, thumbhash.go:37-48
+            if (!f) return LILLIPUT_ERR_EOF;
+            const int len = thumbhash_encoder_encode(enc.th, f->mat);
+            if (len <= 0) return LILLIPUT_ERR_INVALID_IMAGE;
+            *n = (size_t)len;
             return LILLIPUT_OK;
         }
         if (enc.kind == Encoder::GIF) { // gifEncoder.Encode, giflib.go:259-292
