@@ -347,3 +347,21 @@ def test_gif_output_needs_a_gif_source_and_respects_frame_limits(G, oracle, fixt
         assert got == oracle.ref_gif_transcode(data, lambda c: oracle.transform_static(c, 1, 40, 40, oracle.FIT, False), max_frames=3)
     back = oracle.ref_gif_frames(got) if oracle.ref_gif() is not None else None
     assert back is None or (len(back[2]) == 3 and back[:2] == (40, 40))
+
+
+@pytest.mark.gpu
+def test_reference_known_answer_no_gce_first_frame(G):
+    """giflib_test.go:20-66 (discord/lilliput#267): a first frame without a Graphic Control Extension declares no transparent
+    colour, so palette index 0 (opaque yellow, the left half of frame 0) must survive GIF -> GIF: pixel (4,4) of the first output
+    frame is (255,255,0,255)."""
+    import lilliput_amd as la
+
+    data = gif_cases.fixtures()["no_gce_first_frame.gif"]
+    d = la.Decoder(data)
+    h = d.Header()
+    d.Close()
+    out = _transform(data, FileType=".gif", Width=h["width"], Height=h["height"], ResizeMethod=la.ImageOpsNoResize)
+    frames = device_frames(G, out)
+    assert frames is not None and len(frames[2]) >= 1
+    b, g, r, a = (int(v) for v in frames[2][0][0][4, 4])
+    assert (r, g, b, a) == (255, 255, 0, 255)
