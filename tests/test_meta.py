@@ -82,3 +82,20 @@ def test_png_insert_cicp_round_trip(readers):
     odd = src[:12] + b"IHDS" + src[16:]
     ob = C.create_string_buffer(odd, len(odd) + 16)
     assert L.opencv_png_insert_cicp(ob, len(odd), len(odd) + 16, 9, 16, 0, 1) == len(odd) and ob.raw[: len(odd)] == odd
+
+
+def test_reference_icc_presence_cases_through_the_decoder_api(fixture_bytes):
+    """opencv_test.go:222-262 TestICC: Decoder.ICC() is non-empty for the ferry_sunset fixtures that embed a profile and empty for
+    the ones that do not (host-side readers: no GPU needed)."""
+    import lilliput_amd as la
+    import png_cases
+
+    png = png_cases.fixtures()
+    no_icc = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs_misc", "ferry_sunset_no_icc.jpg"), "rb").read()
+    for data, want in ((fixture_bytes["ferry_sunset.jpg"], True), (no_icc, False), (png["ferry_sunset.png"], True), (png["firefox.png"], False)):
+        d = la.Decoder(data)
+        icc = d.ICC()
+        d.Close()
+        assert (len(icc) > 0) == want
+        if want:
+            assert icc[36:40] == b"acsp"
