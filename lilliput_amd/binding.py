@@ -188,7 +188,8 @@ class Decoder:
 
     def ICC(self):
         out = C.create_string_buffer(32768)  # ICCProfileBufferSize
-        return out.raw[: lib().lilliput_decoder_icc(self._h, out, 32768)]
+        n = lib().lilliput_decoder_icc(self._h, out, 32768)
+        return out.raw[:n]
 
     def Close(self):
         if self._h:
