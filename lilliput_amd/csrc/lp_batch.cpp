@@ -185,11 +185,6 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
     (void)trace;
     eng.enable_timing(true);
-    // Stage-group locking between the parts (see LpEngine::set_pipelined) is OFF by default: measured on MI355X it does not
-    // beat free-running parts (11.3k vs 11.7k img/s at 4 parts) -- the whole path is VALU-issue bound, so there is little
-    // complementary work to pair up. LILLIPUT_HIP_PIPELINE=1 turns it on for experiments.
-    eng.set_pipelined(b->parts.size() > 1 && getenv("LILLIPUT_HIP_PIPELINE") != nullptr);
-    struct PixelRelease { LpEngine& e; ~PixelRelease() { e.pixel_stage_done(); e.set_pipelined(false); } } pixel_release{eng};
     for (size_t first = 0; first < nv; first += chunk) {
         const int cnt = (int)std::min(chunk, nv - first);
         // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
@@ -360,7 +355,6 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
                 b->out_bytes[item].assign(eng.encoded_host((int)q), eng.encoded_host((int)q) + elen[q]);
             }
         }
-        eng.pixel_stage_done(); // the device work of this chunk is finished (the fetch synchronised the stream)
         for (int k = 0; k < cnt; k++) {
             const size_t item = (size_t)part.items[first + (size_t)k];
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);

@@ -40,27 +40,6 @@ bool LpPinned::ensure(size_t bytes)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// one mutex per (device, stage group); see LpEngine::set_pipelined
-static std::mutex& group_mutex(int device, int group)
-{
-    static std::mutex mu[16][3];
-    return mu[device & 15][group];
-}
-namespace {
-struct GroupHold { // releases on every exit path of run_decode
-    int dev, g = -1;
-    explicit GroupHold(int d) : dev(d) {}
-    void take(int ng) { release(); group_mutex(dev, ng).lock(); g = ng; }
-    void release() { if (g >= 0) { group_mutex(dev, g).unlock(); g = -1; } }
-    void detach() { g = -1; }
-    ~GroupHold() { release(); }
-};
-}
-void LpEngine::pixel_stage_done()
-{
-    if (holds_pixel_) { holds_pixel_ = false; group_mutex(device_, GROUP_PIXEL).unlock(); }
-}
-
 LpEngine::LpEngine(int device) : device_(device)
 {
     int n = 0;
@@ -258,8 +237,6 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         (void)hipStreamSynchronize(stream_);
         fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
     };
-    GroupHold hold(device_);
-    if (pipelined_) hold.take(GROUP_COUNT);
     if (timing_) (void)hipEventRecord(ev_[0], stream_);
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>());
@@ -291,7 +268,6 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (rounds > max_sub_ + 1 || rounds >= 100000) { err_ = "entropy decode did not converge"; return LP_ERR_DECODE_FAILED; }
     }
     tm_.verify_rounds = rounds;
-    if (pipelined_) hold.take(GROUP_WRITE); // the verify loop ended on a stream synchronisation: the counting group is finished on the device
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
     stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
@@ -301,12 +277,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
-    if (pipelined_) {
-        if (timing_) (void)hipEventRecord(ev_[2], stream_);
-        (void)hipStreamSynchronize(stream_);
-        hold.take(GROUP_PIXEL);
-    }
-    if (timing_ && !pipelined_) (void)hipEventRecord(ev_[2], stream_);
+    if (timing_) (void)hipEventRecord(ev_[2], stream_);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>());
     stage("idct");
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
@@ -337,7 +308,6 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
         if (status[i]) rc = status[i];
     }
-    if (pipelined_) { hold.detach(); holds_pixel_ = true; } // the caller finishes the pixel group and calls pixel_stage_done()
     if (timing_) {
         (void)hipEventElapsedTime(&tm_.unstuff_ms, ev_[0], ev_[1]);
         (void)hipEventElapsedTime(&tm_.huff_ms, ev_[1], ev_[2]);

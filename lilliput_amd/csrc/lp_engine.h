@@ -119,12 +119,6 @@ public:
     // ThumbHash: out[(i * w + j) * cn ..] = frame(idx[w + i], idx[j]) for a w x h lattice of sample coordinates (host memory in and out).
     int gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out);
     int sync();
-    // Stage groups of a batch pipeline. Engines that share a device take turns per group so that concurrent parts of a batch
-    // run DIFFERENT groups at the same time (entropy decode is VALU-bound, the pixel stages lean on HBM): without the locks
-    // all parts march in lock step and same-kind kernels only compete with each other.
-    enum { GROUP_COUNT = 0, GROUP_WRITE = 1, GROUP_PIXEL = 2 };
-    void set_pipelined(bool on) { pipelined_ = on; }
-    void pixel_stage_done();    // release GROUP_PIXEL (taken inside decode_uploaded when pipelined)
     const LpTimings& timings() const { return tm_; }
     void enable_timing(bool on) { timing_ = on; }
     void set_timings(const LpTimings& t) { tm_ = t; }
@@ -136,7 +130,6 @@ private:
     int device_ = 0;
     bool ok_ = false;
     bool timing_ = false;
-    bool pipelined_ = false, holds_pixel_ = false;
     std::string err_;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_[16] = {};
