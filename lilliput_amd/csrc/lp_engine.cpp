@@ -102,6 +102,11 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
     h_src_.assign((size_t)n, LpJpeg());
     h_huffs_.clear();
+    h_prog_.assign((size_t)n, std::vector<ProgScanUp>());
+    h_phuffs_.clear();
+    std::map<uint64_t, std::vector<uint32_t>> phuff_by_hash;
+    struct Piece { size_t arena_off; const uint8_t* src; size_t len; };
+    std::vector<Piece> pieces; // entropy-coded segments, 16-byte aligned in the raw arena, each followed by 32 zero bytes
     size_t raw_bytes = 0;
     for (int i = 0; i < n; i++) {
         LpJpeg j = hdrs[i].j;
@@ -112,13 +117,41 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         if (hi == h_huffs_.size()) h_huffs_.push_back(hdrs[i].huff);
         j.huff_idx = hi;
         j.raw_off = raw_bytes;
-        j.raw_len = (uint32_t)hdrs[i].ecs_len;
-        raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
+        j.progressive = hdrs[i].progressive ? 1 : 0;
+        if (hdrs[i].progressive) { // every scan is a stream of its own
+            j.raw_len = 0;
+            for (const LpProgScanHost& sh : hdrs[i].scans) {
+                ProgScanUp up;
+                up.s = sh.s;
+                uint64_t hash = 1469598103934665603ull;
+                const uint8_t* tb = reinterpret_cast<const uint8_t*>(&sh.tables);
+                for (size_t q = 0; q < sizeof(LpProgHuff); q++) hash = (hash ^ tb[q]) * 1099511628211ull;
+                uint32_t found = 0xffffffffu;
+                for (uint32_t cand : phuff_by_hash[hash])
+                    if (memcmp(&h_phuffs_[cand], &sh.tables, sizeof(LpProgHuff)) == 0) { found = cand; break; }
+                if (found == 0xffffffffu) {
+                    found = (uint32_t)h_phuffs_.size();
+                    h_phuffs_.push_back(sh.tables);
+                    phuff_by_hash[hash].push_back(found);
+                }
+                up.s.huff = found;
+                up.raw_off = raw_bytes;
+                up.raw_len = (uint32_t)sh.ecs_len;
+                pieces.push_back(Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len});
+                raw_bytes = align_up(raw_bytes + up.raw_len + 32, 16);
+                h_prog_[(size_t)i].push_back(up);
+            }
+        } else {
+            j.raw_len = (uint32_t)hdrs[i].ecs_len;
+            pieces.push_back(Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len});
+            raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
+        }
         j.nchunks = (j.raw_len + 4095) / 4096;
         h_src_[(size_t)i] = j;
     }
     const size_t kStage = 256u << 20; // pinned staging window
     if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) ||
+        !d_phuffs_.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, h_phuffs_.size())) ||
         !h_stage_.ensure(std::min(raw_bytes, kStage) + (16u << 20) + 64)) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
@@ -132,20 +165,22 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         win_begin = win_end;
         return true;
     };
-    for (int i = 0; i < n; i++) {
-        const LpJpeg& j = h_src_[(size_t)i];
-        const size_t end = j.raw_off + j.raw_len + 32;
+    for (const Piece& pc : pieces) {
+        const size_t end = pc.arena_off + pc.len + 32;
         if (end - win_begin > h_stage_.cap - 64) {
-            if (!flush(j.raw_off)) return LP_ERR_DEVICE;
+            if (!flush(pc.arena_off)) return LP_ERR_DEVICE;
             if (end - win_begin > h_stage_.cap - 64 && !h_stage_.ensure(end - win_begin + 64)) return LP_ERR_DEVICE;
             stage = h_stage_.as<uint8_t>();
         }
-        memcpy(stage + (j.raw_off - win_begin), srcs[i].data + hdrs[i].ecs_off, j.raw_len);
-        memset(stage + (j.raw_off - win_begin) + j.raw_len, 0, 32);
+        memcpy(stage + (pc.arena_off - win_begin), pc.src, pc.len);
+        memset(stage + (pc.arena_off - win_begin) + pc.len, 0, 32);
     }
     if (!flush(raw_bytes)) return LP_ERR_DEVICE;
     if (!h_huffs_.empty() &&
         !check(hipMemcpyAsync(d_huffs_.p, h_huffs_.data(), sizeof(LpHuffSet) * h_huffs_.size(), hipMemcpyHostToDevice, stream_), "H2D huffs"))
+        return LP_ERR_DEVICE;
+    if (!h_phuffs_.empty() &&
+        !check(hipMemcpyAsync(d_phuffs_.p, h_phuffs_.data(), sizeof(LpProgHuff) * h_phuffs_.size(), hipMemcpyHostToDevice, stream_), "H2D scan tables"))
         return LP_ERR_DEVICE;
     // the staging buffer is reused by the next upload: wait for the copies
     if (!check(hipStreamSynchronize(stream_), "upload sync")) return LP_ERR_DEVICE;
@@ -174,12 +209,16 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
     sched_ = lp_make_sched(S_, C_cfg_ ? C_cfg_ : 256); // checkpoint schedule of the speculative pass (see LpCkSched)
     K_ = sched_.K;
-    size_t clean_words = 0, coef_elems = 0, plane_bytes = 0;
+    size_t clean_words = 0, coef_elems = 0, plane_bytes = 0, pcoef_elems = 0;
+    uint32_t max_pchunks = 0;
+    h_pstreams_.clear();
+    std::vector<std::pair<uint32_t, LpProgScan>> leveled; // (dependency level, scan)
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;
     max_chunks_ = max_sub_ = max_bw_ = max_rows_ = max_w_ = max_h_ = 0;
-    bool any_frame = false, any_generic = false, any_420 = false;
+    bool any_frame = false, any_generic = false, any_420 = false, any_baseline = false;
     for (size_t i = 0; i < h_imgs_.size(); i++) {
         LpJpeg& j = h_imgs_[i];
+        any_baseline = any_baseline || !j.progressive;
         j.chunk_off = tot_chunks_;
         tot_chunks_ += j.nchunks;
         j.clean_off = clean_words;                                  // multiple of 4 words: the bit reader loads 16 bytes at a time
@@ -194,8 +233,49 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         j.rst_off = tot_rst_;
         j.rst_cap = j.dri ? (j.mcus_x * j.mcus_y + j.dri - 1) / j.dri + 2 : 2;
         tot_rst_ += j.rst_cap;
-        j.coef_off = coef_elems; // a multiple of 8 blocks: a group of eight DC values is one aligned 16-byte store (DevSink)
-        coef_elems += (((size_t)j.total_blocks + 7) & ~(size_t)7) * 64;
+        if (j.progressive) {
+            // Scans that touch the same coefficients of the same component must run in file order (a refinement needs what came
+            // before it); all others are independent. Level = 1 + the deepest earlier scan this one overlaps.
+            const std::vector<ProgScanUp>& ups = h_prog_[(size_t)first + i];
+            j.coef_off = pcoef_elems;
+            for (int c = 0; c < j.ncomp; c++) pcoef_elems += (size_t)j.bw[c] * j.bh[c] * 64;
+            std::vector<uint32_t> lev(ups.size(), 0);
+            for (size_t a = 0; a < ups.size(); a++) {
+                const LpProgScan& sa = ups[a].s;
+                for (size_t b = 0; b < a; b++) {
+                    const LpProgScan& sb = ups[b].s;
+                    bool share = false;
+                    for (uint32_t x = 0; x < sa.ns; x++)
+                        for (uint32_t y = 0; y < sb.ns; y++) share = share || sa.comp[x] == sb.comp[y];
+                    if (share && sa.Ss <= sb.Se && sb.Ss <= sa.Se) lev[a] = std::max(lev[a], lev[b] + 1);
+                }
+                LpJpeg ps;
+                memset(&ps, 0, sizeof(ps));
+                ps.raw_off = ups[a].raw_off;
+                ps.raw_len = ups[a].raw_len;
+                ps.nchunks = (ps.raw_len + 4095) / 4096;
+                ps.chunk_off = tot_chunks_;
+                tot_chunks_ += ps.nchunks;
+                ps.clean_off = clean_words;
+                ps.clean_cap_words = (ps.raw_len / 4 + 64 + 3) / 4 * 4;
+                clean_words += ps.clean_cap_words;
+                ps.sub_bits = S_;
+                ps.sub_cap = 1;
+                ps.rst_off = tot_rst_;
+                ps.rst_cap = sa.dri ? (sa.mcux * sa.mcuy + sa.dri - 1) / sa.dri + 2 : 2;
+                tot_rst_ += ps.rst_cap;
+                max_pchunks = std::max(max_pchunks, ps.nchunks);
+                LpProgScan sc = sa;
+                sc.img = (uint32_t)i;
+                sc.stream = (uint32_t)h_pstreams_.size();
+                sc.coef_off = j.coef_off;
+                h_pstreams_.push_back(ps);
+                leveled.push_back(std::make_pair(lev[a], sc));
+            }
+        } else {
+            j.coef_off = coef_elems; // a multiple of 8 blocks: a group of eight DC values is one aligned 16-byte store (DevSink)
+            coef_elems += (((size_t)j.total_blocks + 7) & ~(size_t)7) * 64;
+        }
         uint32_t rows = 0;
         for (int c = 0; c < j.ncomp; c++) {
             j.plane_off[c] = plane_bytes;
@@ -214,6 +294,20 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             max_w_ = std::max(max_w_, j.width);
             max_h_ = std::max(max_h_, j.height);
         }
+    }
+    std::stable_sort(leveled.begin(), leveled.end(), [](const std::pair<uint32_t, LpProgScan>& x, const std::pair<uint32_t, LpProgScan>& y) { return x.first < y.first; });
+    h_pscans_.clear();
+    h_plevel_first_.clear();
+    for (size_t q = 0; q < leveled.size(); q++) {
+        while (h_plevel_first_.size() <= leveled[q].first) h_plevel_first_.push_back((uint32_t)q);
+        h_pscans_.push_back(leveled[q].second);
+    }
+    h_plevel_first_.push_back((uint32_t)leveled.size());
+    const size_t nstreams = h_pstreams_.size();
+    if (nstreams && !(d_pstreams_.ensure(sizeof(LpJpeg) * nstreams) && d_pstates_.ensure(sizeof(LpJpegState) * nstreams) &&
+                      d_pscans_.ensure(sizeof(LpProgScan) * nstreams) && d_pcoef_.ensure(pcoef_elems * 2 + 64))) {
+        err_ = "device allocation failed";
+        return LP_ERR_DEVICE;
     }
     bool a = d_imgs_.ensure(sizeof(LpJpeg) * (size_t)n) && d_states_.ensure(sizeof(LpJpegState) * (size_t)n) && d_clean_.ensure(clean_words * 4 + 4096) &&
              d_rst_.ensure((size_t)tot_rst_ * 4 + 64) && d_chunk_.ensure((size_t)tot_chunks_ * 8 + 64) &&
@@ -277,8 +371,27 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
+    if (nstreams) { // progressive images: unstuff every scan, then the scans level by level into the zeroed int16 arena
+        if (!check(hipMemcpyAsync(d_pstreams_.p, h_pstreams_.data(), sizeof(LpJpeg) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scan streams") ||
+            !check(hipMemcpyAsync(d_pscans_.p, h_pscans_.data(), sizeof(LpProgScan) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scans") ||
+            !check(hipMemsetAsync(d_pstates_.p, 0, sizeof(LpJpegState) * nstreams, stream_), "memset scan states") ||
+            !check(hipMemsetAsync(d_pcoef_.p, 0, pcoef_elems * 2, stream_), "memset coefficients"))
+            return LP_ERR_DEVICE;
+        lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(),
+                          d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
+        stage("prog_unstuff");
+        for (size_t l = 0; l + 1 < h_plevel_first_.size(); l++) {
+            const uint32_t f = h_plevel_first_[l], cnt = h_plevel_first_[l + 1] - f;
+            // few lanes: one per wave (a lane alone on its SIMD runs fastest); many: pack them so that the grid stays a few waves per SIMD
+            const uint32_t lpw = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (cnt + 4095u) / 4096u));
+            lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),
+                                 d_phuffs_.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+        }
+        stage("prog_scans");
+    }
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
-    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>());
+    lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(),
+                   (any_baseline ? 1u : 0u) | (nstreams ? 2u : 0u), d_pcoef_.as<int16_t>());
     stage("idct");
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
     // frames
@@ -303,6 +416,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (!check(hipStreamSynchronize(stream_), "decode sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "decode kernels")) return LP_ERR_DEVICE;
     memcpy(h_states_.data(), h_small_.p, sizeof(LpJpegState) * (size_t)n);
+    if (nstreams) { // a scan that failed to unstuff fails its image
+        h_pstates_.resize(nstreams);
+        if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
+        for (const LpProgScan& sc : h_pscans_) h_states_[sc.img].error |= h_pstates_[sc.stream].error;
+    }
     int rc = LP_OK;
     for (int i = 0; i < n; i++) {
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
@@ -332,6 +450,16 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     const LpJpeg& j = h_imgs_[(size_t)i];
     const size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
     if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
+    if (j.progressive) { // already [by][bx], blocks transposed
+        size_t base = 0;
+        for (int c = 0; c < comp; c++) base += (size_t)j.bw[c] * j.bh[c] * 64;
+        std::vector<int16_t> t(ne);
+        if (!check(hipMemcpyAsync(t.data(), d_pcoef_.as<int16_t>() + j.coef_off + base, ne * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
+        const int rc = sync();
+        if (rc) return rc;
+        for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | ((q & 7) << 3) | ((q >> 3) & 7)] = t[q];
+        return LP_OK;
+    }
     const size_t nb = j.total_blocks;
     std::vector<int8_t> c8(nb * 64);
     std::vector<uint32_t> wid(nb);

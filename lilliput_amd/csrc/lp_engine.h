@@ -150,6 +150,16 @@ private:
     LpPinned h_stage_, h_small_, h_out_;
     std::vector<size_t> h_out_off_;
 
+    // progressive images (SOF2): their scans, laid out per upload and per decode range
+    struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; };
+    std::vector<std::vector<ProgScanUp>> h_prog_;   // per uploaded image; empty for a baseline one
+    std::vector<LpProgHuff> h_phuffs_;
+    std::vector<LpProgScan> h_pscans_;              // the current range's scans, sorted by dependency level
+    std::vector<uint32_t> h_plevel_first_;          // level l = h_pscans_[h_plevel_first_[l] .. h_plevel_first_[l + 1])
+    std::vector<LpJpeg> h_pstreams_;                // one pseudo stream per scan (what the unstuff kernels need)
+    std::vector<LpJpegState> h_pstates_;
+    LpDevBuf d_phuffs_, d_pscans_, d_pstreams_, d_pstates_, d_pcoef_;
+
     // frame heap
     LpDevBuf heap_;
     size_t heap_used_ = 0;

@@ -142,7 +142,9 @@ static bool huff_table_valid(const uint8_t bits[17], const uint8_t* vals, bool i
 
 int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
 {
-    memset(out, 0, sizeof(*out));
+    *out = LpJpegHeader();
+    memset(&out->j, 0, sizeof(out->j));
+    memset(&out->huff, 0, sizeof(out->huff));
     LpJpeg& j = out->j;
     j.orientation = 1;
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return LP_PARSE_NOT_JPEG;
@@ -152,7 +154,9 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     uint8_t hvals[2][4][256];
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
     int cid[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
-    bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false;
+    bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false, progressive = false;
+    struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; uint8_t bits[4][17], vals[4][256]; size_t ecs_off, ecs_len; };
+    std::vector<RawScan> raw_scans;
     unsigned sof_nc = 0;
     int scan_comp[3] = {-1, -1, -1};
     int adobe_tf = 0;
@@ -167,11 +171,12 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         for (;;) {
             while (i < n && d[i] != 0xFF) i++;
             while (i < n && d[i] == 0xFF) i++;
-            if (i >= n) return LP_PARSE_TRUNCATED;
+            if (i >= n) { if (!raw_scans.empty()) { m = 0xD9; break; } return LP_PARSE_TRUNCATED; }
             m = d[i++];
             if (m != 0) break; // FF 00: stuffed data, keep looking
         }
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9 && !raw_scans.empty()) { out->saw_eoi = 1; break; } // end of a progressive file
         if (m == 0xD8 || m == 0xD9) return LP_PARSE_NOT_JPEG; // JERR_SOI_DUPLICATE / EOI before any scan
         const bool is_sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
         const bool known = (m >= 0xC0 && m <= 0xCF && m != 0xC8) || m == 0xDA || m == 0xDB || m == 0xDC || m == 0xDD || (m >= 0xE0 && m <= 0xEF) || m == 0xFE;
@@ -227,7 +232,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
             j.width = be16(p + 3);
             if (j.height == 0 || j.width == 0 || nc == 0) return LP_PARSE_NOT_JPEG; // JERR_EMPTY_IMAGE
             if (pl != 6 + 3u * nc) return LP_PARSE_NOT_JPEG;             // JERR_BAD_LENGTH
-            if (m != 0xC0 && m != 0xC1) { sof_unsupported = true; }      // progressive, lossless, arithmetic: judged at SOS
+            progressive = m == 0xC2;
+            if (m != 0xC0 && m != 0xC1 && m != 0xC2) { sof_unsupported = true; } // lossless, arithmetic: judged at SOS
             if (prec != 8 || (nc != 1 && nc != 3)) sof_unsupported = true; // 12-bit, CMYK/YCCK, two-component
             sof_nc = nc;
             for (unsigned c = 0; c < nc; c++) {
@@ -275,6 +281,47 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if ((t >> 4) > 3 || (t & 15) > 3) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
                 if (s < 3) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
+            if (progressive) { // jdphuff.c start_pass_phuff_decoder: one of up to LP_MAX_SCANS scans; the tables as they stand now
+                RawScan rs;
+                memset(&rs, 0, sizeof(rs));
+                rs.ns = ns;
+                for (unsigned s = 0; s < ns; s++) { rs.comp[s] = cur[s]; rs.td[s] = p[2 + 2 * s] >> 4; rs.ta[s] = p[2 + 2 * s] & 15; }
+                rs.Ss = p[1 + 2 * ns]; rs.Se = p[2 + 2 * ns]; rs.Ah = p[3 + 2 * ns] >> 4; rs.Al = p[3 + 2 * ns] & 15;
+                bool bad = false;
+                if (rs.Ss == 0) { if (rs.Se != 0) bad = true; }
+                else { if (rs.Se < rs.Ss || rs.Se > 63) bad = true; if (ns != 1) bad = true; }
+                if (rs.Ah != 0 && rs.Ah - 1 != rs.Al) bad = true;
+                if (rs.Al > 13) bad = true;
+                if (bad) return LP_PARSE_NOT_JPEG;                        // JERR_BAD_PROGRESSION
+                rs.dri = j.dri;
+                const bool dc_scan = rs.Ss == 0;
+                if (!(dc_scan && rs.Ah != 0))                             // a DC refinement scan reads raw bits only
+                    for (unsigned s = 0; s < ns; s++) {
+                        const int cls = dc_scan ? 0 : 1, id = dc_scan ? rs.td[s] : rs.ta[s];
+                        const uint8_t* tb = h_ok[cls][id] ? hbits[cls][id] : id < 2 ? lp_std_huff_bits[2 * id + cls] : nullptr;
+                        const uint8_t* tv = h_ok[cls][id] ? hvals[cls][id] : id < 2 ? (cls == 0 ? lp_std_huff_dc_vals : id ? lp_std_huff_ac_chroma : lp_std_huff_ac_luma) : nullptr;
+                        if (!tb) return LP_PARSE_NOT_JPEG;                // JERR_NO_HUFF_TABLE
+                        memcpy(rs.bits[s], tb, 17);
+                        memcpy(rs.vals[s], tv, h_ok[cls][id] ? 256 : (cls == 0 ? 12 : 162));
+                        if (!huff_table_valid(rs.bits[s], rs.vals[s], cls == 0)) return LP_PARSE_NOT_JPEG;
+                    }
+                rs.ecs_off = seg_end;
+                size_t q = seg_end;
+                for (; q + 1 < n; q++) {
+                    if (d[q] != 0xFF) continue;
+                    const unsigned c = d[q + 1];
+                    if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
+                    break;
+                }
+                if (q + 1 >= n) q = n;                                    // ran off the end: the scan takes what is there
+                rs.ecs_len = q - seg_end;
+                if (raw_scans.size() >= LP_MAX_SCANS) return LP_PARSE_UNSUPPORTED;
+                raw_scans.push_back(rs);
+                if (!ecs) ecs = seg_end;
+                i = q;
+                if (q >= n || (q + 1 < n && d[q + 1] == 0xD9)) { out->saw_eoi = q < n; break; }
+                continue;
+            }
             if (ns != j.ncomp) return LP_PARSE_UNSUPPORTED; // non-interleaved / multi-scan
             for (unsigned s = 0; s < ns; s++) if (scan_comp[s] != (int)s) return LP_PARSE_UNSUPPORTED;
             ecs = seg_end;
@@ -305,7 +352,9 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (j.hs[c] < 1 || j.hs[c] > 2 || j.vs[c] < 1 || j.vs[c] > 2) return LP_PARSE_UNSUPPORTED;
         if (j.hs[c] > j.hmax) j.hmax = j.hs[c];
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
-        if (tq[c] > 3 || !qt_ok[tq[c]] || !h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG; // JERR_NO_QUANT_TABLE / JERR_NO_HUFF_TABLE
+        if (tq[c] > 3 || !qt_ok[tq[c]]) return LP_PARSE_NOT_JPEG;                                  // JERR_NO_QUANT_TABLE
+        if (progressive) continue;                                                                 // Huffman tables were checked scan by scan
+        if (!h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;                         // JERR_NO_HUFF_TABLE
         if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
         if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
             return LP_PARSE_NOT_JPEG;
@@ -344,6 +393,54 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     else if (saw_adobe) j.colorspace = adobe_tf == 0 ? 3 : 2;
     else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') j.colorspace = 3;
     else j.colorspace = 2;
+    if (progressive) {
+        out->progressive = true;
+        for (const RawScan& rs : raw_scans) {
+            LpProgScanHost hs;
+            memset(&hs.s, 0, sizeof(hs.s));
+            memset(&hs.tables, 0, sizeof(hs.tables));
+            hs.s.ns = rs.ns;
+            for (unsigned s = 0; s < rs.ns; s++) hs.s.comp[s] = (uint8_t)rs.comp[s];
+            hs.s.Ss = (uint8_t)rs.Ss; hs.s.Se = (uint8_t)rs.Se; hs.s.Ah = (uint8_t)rs.Ah; hs.s.Al = (uint8_t)rs.Al;
+            hs.s.dri = rs.dri;
+            if (rs.ns == 1) { // non-interleaved: the component's own blocks, not the MCU padding
+                const int c = rs.comp[0];
+                hs.s.mcux = (j.width * j.hs[c] + j.hmax * 8 - 1) / (j.hmax * 8);
+                hs.s.mcuy = (j.height * j.vs[c] + j.vmax * 8 - 1) / (j.vmax * 8);
+            } else { hs.s.mcux = j.mcus_x; hs.s.mcuy = j.mcus_y; }
+            for (unsigned s = 0; s < rs.ns; s++) {
+                const int c = rs.comp[s];
+                uint32_t base = 0;
+                for (int q = 0; q < c; q++) base += j.bw[q] * j.bh[q];
+                hs.s.cblk[s] = base;
+                hs.s.bw[s] = j.bw[c];
+                hs.s.hs[s] = rs.ns == 1 ? 1 : j.hs[c];
+                hs.s.vs[s] = rs.ns == 1 ? 1 : j.vs[c];
+            }
+            for (unsigned s = 0; s < rs.ns && !(rs.Ss == 0 && rs.Ah != 0); s++) { // canonical tables + an 8-bit first-level lookup
+                int code = 0, k = 0;
+                for (int l = 1; l <= 16; l++) {
+                    const int mincode = code, valptr = k;
+                    for (int q = 0; q < rs.bits[s][l]; q++, k++, code++)
+                        if (l <= 8)
+                            for (int f = 0; f < (1 << (8 - l)); f++) hs.tables.lut8[s][(code << (8 - l)) + f] = (uint16_t)((l << 8) | rs.vals[s][k]);
+                    hs.tables.maxcode[s][l] = rs.bits[s][l] ? code - 1 : -1;
+                    hs.tables.valoff[s][l] = valptr - mincode;
+                    code <<= 1;
+                }
+                hs.tables.maxcode[s][0] = -1;
+                hs.tables.maxcode[s][17] = 0x7fffffff;
+                memcpy(hs.tables.vals[s], rs.vals[s], 256);
+            }
+            hs.ecs_off = rs.ecs_off;
+            hs.ecs_len = rs.ecs_len;
+            out->scans.push_back(hs);
+        }
+        if (out->scans.empty()) return LP_PARSE_NOT_JPEG;
+        out->ecs_off = out->scans.front().ecs_off;
+        out->ecs_len = out->scans.back().ecs_off + out->scans.back().ecs_len - out->ecs_off;
+        return LP_PARSE_OK;
+    }
     {   // slots are built in order 0..3 (the second-level pool is handed out in that order); an absent table id is an empty table
         static const uint8_t no_bits[17] = {0}, no_vals[1] = {0};
         for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, t, h_ok[0][t] ? hbits[0][t] : no_bits, h_ok[0][t] ? hvals[0][t] : no_vals);

@@ -2,6 +2,8 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
+
 #include "lp_types.h"
 
 enum {
@@ -11,12 +13,20 @@ enum {
     LP_PARSE_TRUNCATED = 3
 };
 
+struct LpProgScanHost {         // one scan of a progressive file
+    LpProgScan s;               // img / stream / huff indices are filled in by the engine
+    LpProgHuff tables;
+    size_t ecs_off, ecs_len;    // this scan's entropy-coded bytes in the file
+};
+
 struct LpJpegHeader {
     LpJpeg j;                   // geometry + table slots filled; arena offsets left 0
     LpHuffSet huff;
-    size_t ecs_off;             // first entropy-coded byte in the file
-    size_t ecs_len;             // bytes up to (not including) the terminating marker / end of file
-    int saw_eoi;
+    size_t ecs_off = 0;         // first entropy-coded byte in the file
+    size_t ecs_len = 0;         // bytes up to (not including) the terminating marker / end of file (progressive: through the last scan)
+    int saw_eoi = 0;
+    bool progressive = false;   // SOF2: `scans` lists the scans in file order, `huff` is unused
+    std::vector<LpProgScanHost> scans;
 };
 
 // Parses up to SOS, locates the end of the scan, builds the decode tables.

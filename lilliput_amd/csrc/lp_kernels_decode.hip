@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "lp_huff_core.h"
+#include "lp_prog_core.h"
 #include "lp_launch.h"
 #include "lp_types.h"
 
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
     if (t == 255) {
         st.blocks_decoded = pre.nblk;
-        if (pre.nblk < img.total_blocks) st.error |= 2u;
+        if (pre.nblk < img.total_blocks && !img.progressive) st.error |= 2u;
     }
 }
 
@@ -673,6 +674,7 @@ __device__ __forceinline__ void dc_range(const LpJpeg& img, uint32_t w, uint32_t
 __global__ __launch_bounds__(64) void k_dc_sum(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, DcPartial* __restrict__ partials)
 {
     const LpJpeg& img = imgs[blockIdx.y];
+    if (img.progressive) return; // its scans stored absolute DC values
     uint32_t m0, m1, comps;
     dc_range(img, blockIdx.x, m0, m1, comps);
     DcSeg zero;
@@ -690,6 +692,7 @@ __global__ __launch_bounds__(64) void k_dc_sum(const LpJpeg* __restrict__ imgs, 
 __global__ __launch_bounds__(64) void k_dc_apply(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, const DcPartial* __restrict__ partials)
 {
     const LpJpeg& img = imgs[blockIdx.y];
+    if (img.progressive) return;
     uint32_t m0, m1, comps;
     dc_range(img, blockIdx.x, m0, m1, comps);
     DcSeg pre;
@@ -777,8 +780,9 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
 }
 
 #define IDCT_TPW 8
-// VARIANT: 0 = plain loop; 1 = + hoisted row pointers / quantisation column; 2 = + prefetch of the next tile
-template <int VARIANT>
+// PROG = false: the baseline images of the range (int8 blocks in decode order + wide slots + the DC array);
+// PROG = true: the progressive ones (int16 blocks, raster order per component, see LpProgScan). Each skips the other kind.
+template <bool PROG>
 __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                               const int8_t* __restrict__ coef8_arena, const int16_t* __restrict__ wide_arena,
                                               const uint32_t* __restrict__ wide_id_arena, const int16_t* __restrict__ dc_arena,
@@ -787,6 +791,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t s_qt[64]; // transposed like the blocks: [column][row]
     const LpJpeg& img = imgs[blockIdx.z];
+    if ((img.progressive != 0) != PROG) return;
     uint32_t by = blockIdx.y, c = 0;
     if (by >= img.bh[0]) {
         by -= img.bh[0];
@@ -815,26 +820,38 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         if (base >= bw) break; // workgroup-uniform
         const uint32_t bx = base + wv * 8 + j;
         const bool blk_ok = bx < bw;
-        const uint32_t blk = (((by >> vsh) * img.mcus_x + (bx >> hsh)) * img.bpm + img.blk_first[c] + ((by & vsh) << hsh) + (bx & hsh));
-        // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
         int32_t cv[8];
         bool any_esc = false;
-        {
-            const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
+        if (PROG) {
+            // column r of the block: 8 x int16, 16 contiguous bytes
+            const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u);
+            const int16_t* src = wide_arena /* = the progressive arena in this variant */ + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64 + r * 8;
+            const uint4 raw = blk_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-            {   // a byte equals 0x80 <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
-                const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
-                const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
-                any_esc = (zx | zy) != 0;
-            }
-            if (any_esc) {
-                const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
+            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int16_t)((rw[i >> 1] >> (16 * (i & 1))) & 0xffffu);
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (cv[i] == -128) cv[i] = w[i];
+            for (int i = 0; i < 8; i++) any_esc = any_esc || ((i || r) && (cv[i] > 127 || cv[i] < -127)); // same bound as the int8 path, DC aside
+        } else {
+            const uint32_t blk = (((by >> vsh) * img.mcus_x + (bx >> hsh)) * img.bpm + img.blk_first[c] + ((by & vsh) << hsh) + (bx & hsh));
+            // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
+            {
+                const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+                {   // a byte equals 0x80 <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
+                    const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
+                    const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
+                    any_esc = (zx | zy) != 0;
+                }
+                if (any_esc) {
+                    const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (cv[i] == -128) cv[i] = w[i];
+                }
+                if (r == 0 && blk_ok) cv[0] = dc_arena[img.coef_off / 64 + blk]; // the DC lives in its own 16-bit array
             }
-            if (r == 0 && blk_ok) cv[0] = dc_arena[img.coef_off / 64 + blk]; // the DC lives in its own 16-bit array
         }
         // 24-bit multiplies are exact when every multiplied term fits 24 signed bits. The DC (and the workspace column it feeds) is
         // only shifted, never multiplied; an AC coefficient without an escape is at most 127, so with 8-bit quantisation tables the
@@ -848,6 +865,55 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         __syncthreads();
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Progressive scans (lp_prog_core.h): lane = one scan of one image, decoded serially from its first bit to its last. The lanes
+// of a launch share nothing (different streams, tables and blocks), so a workgroup carries only `lpw` of them: with few scans
+// in flight every lane gets a wave -- and its SIMD's issue slots -- to itself.
+__constant__ uint8_t c_tzigzag[64] = LP_TZIGZAG_INIT;
+
+struct DevProgMem {
+    const uint32_t* words;
+    uint32_t cap;
+    const uint32_t* rst;
+    const LpProgHuff* ht;
+    int16_t* coef;  // the image's first block
+    int16_t* cur;
+    __device__ __forceinline__ uint32_t word(uint32_t w) const { return w < cap ? words[w] : 0u; }
+    __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
+    __device__ __forceinline__ uint32_t lut8(uint32_t s, uint32_t i) const { return ht->lut8[s][i]; }
+    __device__ __forceinline__ int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
+    __device__ __forceinline__ int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
+    __device__ __forceinline__ uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
+    __device__ __forceinline__ uint32_t tz(uint32_t k) const { return c_tzigzag[k & 63u]; }
+    __device__ __forceinline__ void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
+    __device__ __forceinline__ int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
+    __device__ __forceinline__ void open(uint32_t blk) { cur = coef + (size_t)blk * 64; }
+    __device__ __forceinline__ int32_t get(uint32_t e) const { return cur[e]; }
+    __device__ __forceinline__ void set(uint32_t e, int32_t v) { cur[e] = (int16_t)v; }
+    __device__ __forceinline__ void close(uint32_t) {}
+};
+
+__global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, uint32_t lpw,
+                                                  const LpJpeg* __restrict__ streams, const LpJpegState* __restrict__ stream_states,
+                                                  const LpProgHuff* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                  const uint32_t* __restrict__ rst_arena, int16_t* __restrict__ pcoef)
+{
+    if (threadIdx.x >= lpw) return;
+    const uint32_t i = blockIdx.x * lpw + threadIdx.x;
+    if (i >= n) return;
+    const LpProgScan sc = scans[first + i];
+    const LpJpeg& stream = streams[sc.stream];
+    const LpJpegState& st = stream_states[sc.stream];
+    DevProgMem m;
+    m.words = clean_arena + stream.clean_off;
+    m.cap = stream.clean_cap_words;
+    m.rst = rst_arena + stream.rst_off;
+    m.ht = huffs + sc.huff;
+    m.coef = pcoef + sc.coef_off;
+    m.cur = m.coef;
+    lp_prog_scan(m, sc, st.clean_bytes * 8u, st.n_rst);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -901,9 +967,20 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
-                    const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes)
+                    const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes, uint32_t which, const int16_t* d_pcoef)
 {
     if (!nimg || !max_bw || !max_rows) return;
     dim3 g((max_bw + 32 * IDCT_TPW - 1) / (32 * IDCT_TPW), max_rows, nimg); // max_rows = most block rows of an image, all components stacked
-    hipLaunchKernelGGL(k_idct<0>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_planes);
+    if (which & 1u) hipLaunchKernelGGL(k_idct<false>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_planes);
+    if (which & 2u) hipLaunchKernelGGL(k_idct<true>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_pcoef, d_wide_id, d_dc, d_planes);
+}
+
+void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, const LpJpeg* d_streams,
+                          const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
+{
+    if (!n) return;
+    if (lpw < 1) lpw = 1;
+    if (lpw > 64) lpw = 64;
+    hipLaunchKernelGGL(k_prog_scan, dim3((n + lpw - 1) / lpw), dim3(64), 0, s, d_scans, first, n, lpw, d_streams, d_stream_states, d_huffs, d_clean, d_rst,
+                       d_pcoef);
 }

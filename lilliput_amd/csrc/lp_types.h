@@ -46,7 +46,9 @@ struct LpJpeg {
     uint8_t ncomp, hmax, vmax, bpm;
     uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB
     uint8_t orientation;        // EXIF 1..8
-    uint8_t pad1[2];
+    uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans run through k_prog_scan and coef_off counts
+                                // int16 elements in the progressive arena (see LpProgScan)
+    uint8_t pad1;
     uint8_t hs[LP_MAX_COMP], vs[LP_MAX_COMP];
     uint8_t dc_tbl[LP_MAX_COMP], ac_tbl[LP_MAX_COMP];   // slots into LpHuffSet (0..1 / 2..3)
     uint8_t blk_comp[8], blk_h[8], blk_v[8];            // per block-in-MCU
@@ -69,6 +71,35 @@ struct LpJpeg {
     uint32_t rst_cap;
     uint32_t chunk_off;         // index of first unstuff chunk in the chunk-count array
     uint32_t nchunks;
+};
+
+// ---- progressive JPEG (SOF2): one entry per scan. A scan's entropy-coded data is decoded by ONE lane from start to end:
+// DC / AC "first" scans would self-synchronise like a baseline stream, but a refinement scan's parse depends on which
+// coefficients of the block at hand are already non-zero, so a lane that does not know its block index cannot decode it at all.
+// Parallelism comes from the images of a batch and from the scans of an image that touch different (component, band) pairs:
+// the engine sorts the scans into dependency levels and launches one kernel per level (lane = one scan of one image).
+// Coefficients accumulate in an int16 arena: per image, per component, blocks in raster order over the MCU-padded grid,
+// 64 values per block stored TRANSPOSED (element v * 8 + u = row u, column v) like the baseline path hands them to the IDCT.
+#define LP_MAX_SCANS 64
+struct LpProgHuff {             // the (at most four) Huffman tables one scan uses, slot = position of the component in the scan
+    uint16_t lut8[4][256];      // (length << 8) | symbol for codes of up to 8 bits, indexed by the next 8 bits; 0 = longer code
+    int32_t maxcode[4][18];     // canonical decode of the longer codes (T.81 F.2.2.3)
+    int32_t valoff[4][17];
+    uint8_t vals[4][256];
+};
+struct LpProgScan {
+    uint32_t img;               // index of the image in the current decode range
+    uint32_t stream;            // index of this scan's pseudo stream (LpJpeg entry used by the unstuff kernels) and of its LpJpegState
+    uint32_t huff;              // index into the LpProgHuff array
+    uint32_t ns;                // components in the scan
+    uint8_t comp[4];            // component index of scan position s
+    uint8_t Ss, Se, Ah, Al;
+    uint32_t dri;               // restart interval in MCUs of THIS scan, 0 = none
+    uint32_t mcux, mcuy;        // MCU grid of the scan: the padded grid for interleaved scans, the component's own blocks otherwise
+    uint32_t cblk[4];           // first block of scan component s, relative to the image's first block in the arena
+    uint32_t bw[4];             // blocks per row of scan component s (MCU padded)
+    uint8_t hs[4], vs[4];       // blocks of scan component s per MCU (1 x 1 in a single-component scan)
+    uint64_t coef_off;          // element offset of the image in the int16 coefficient arena
 };
 
 // Per-image results produced on the device.

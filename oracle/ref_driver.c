@@ -203,7 +203,38 @@ long ref_jpeg_encode_ex(const uint8_t* px, int W, int H, int ncomp, int mode, co
     jpeg_set_quality(&ci, quality, force_baseline);
     for (int c = 0; c < ncomp; c++) { ci.comp_info[c].h_samp_factor = samp[2 * c]; ci.comp_info[c].v_samp_factor = samp[2 * c + 1]; }
     ci.restart_interval = (unsigned)restart_interval;
-    ci.optimize_coding = optimize;
+    ci.optimize_coding = optimize & 1;
+    /* optimize bit 1: jpeg_simple_progression; bit 2: spectral selection only, one DC scan per component;
+     * bit 3: deep successive approximation (Al = 3 down to 0) with the AC band of every component split in two */
+    static jpeg_scan_info script[64];
+    if (optimize & 2) jpeg_simple_progression(&ci);
+    if (optimize & 12) {
+        int n = 0;
+        if (optimize & 4) {
+            for (int c = 0; c < ncomp; c++) { jpeg_scan_info si = {1, {c, 0, 0, 0}, 0, 0, 0, 0}; script[n++] = si; }
+            for (int c = 0; c < ncomp; c++) {
+                jpeg_scan_info a = {1, {c, 0, 0, 0}, 1, 9, 0, 0}, b = {1, {c, 0, 0, 0}, 10, 63, 0, 0};
+                script[n++] = a; script[n++] = b;
+            }
+        } else {
+            jpeg_scan_info dc = {ncomp, {0, 1, 2, 0}, 0, 0, 0, 3};
+            script[n++] = dc;
+            for (int c = 0; c < ncomp; c++) {
+                jpeg_scan_info a = {1, {c, 0, 0, 0}, 1, 20, 0, 3}, b = {1, {c, 0, 0, 0}, 21, 63, 0, 3};
+                script[n++] = a; script[n++] = b;
+            }
+            for (int al = 2; al >= 0; al--) {
+                jpeg_scan_info dr = {ncomp, {0, 1, 2, 0}, 0, 0, al + 1, al};
+                script[n++] = dr;
+                for (int c = 0; c < ncomp; c++) {
+                    jpeg_scan_info a = {1, {c, 0, 0, 0}, 1, 20, al + 1, al}, b = {1, {c, 0, 0, 0}, 21, 63, al + 1, al};
+                    script[n++] = a; script[n++] = b;
+                }
+            }
+        }
+        ci.scan_info = script;
+        ci.num_scans = n;
+    }
     jpeg_start_compress(&ci, TRUE);
     while (ci.next_scanline < ci.image_height) {
         JSAMPROW row = (JSAMPROW)(px + (size_t)ci.next_scanline * W * ncomp);

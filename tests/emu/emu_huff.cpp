@@ -169,3 +169,72 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         }
     return 0;
 }
+
+// ---- progressive (SOF2) scans: lp_prog_core.h lane logic, scan after scan in file order ----
+#include "../../lilliput_amd/csrc/lp_prog_core.h"
+
+struct HostProgMem {
+    const uint32_t* words;
+    size_t nwords;
+    const uint32_t* rst;
+    const LpProgHuff* ht;
+    int16_t* coef; // the image's blocks
+    int16_t* cur = nullptr;
+    uint32_t word(uint32_t w) const { return w < nwords ? words[w] : 0u; }
+    uint32_t rst_bit(uint32_t k) const { return rst[k]; }
+    uint32_t lut8(uint32_t s, uint32_t i) const { return ht->lut8[s][i]; }
+    int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
+    int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
+    uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
+    uint32_t tz(uint32_t k) const { static const uint8_t t[64] = LP_TZIGZAG_INIT; return t[k]; }
+    void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
+    int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
+    void open(uint32_t blk) { cur = coef + (size_t)blk * 64; }
+    int32_t get(uint32_t e) const { return cur[e]; }
+    void set(uint32_t e, int32_t v) { cur[e] = (int16_t)v; }
+    void close(uint32_t) {}
+};
+
+extern "C" int emu_decode_coefs_progressive(const uint8_t* data, size_t len, int comp, int16_t* out, size_t cap_elems, int* bw, int* bh, int* nscans)
+{
+    LpJpegHeader h;
+    int rc = lp_jpeg_parse(data, len, &h);
+    if (rc) return -rc;
+    if (!h.progressive) return -20;
+    const LpJpeg& img = h.j;
+    if (comp >= img.ncomp) return -10;
+    size_t nblk = 0;
+    for (int c = 0; c < img.ncomp; c++) nblk += (size_t)img.bw[c] * img.bh[c];
+    std::vector<int16_t> coef(nblk * 64, 0);
+    for (const LpProgScanHost& sh : h.scans) {
+        const uint8_t* raw = data + sh.ecs_off;
+        const size_t rl = sh.ecs_len;
+        std::vector<uint8_t> clean;
+        std::vector<uint32_t> rst;
+        for (size_t q = 0; q < rl; q++) { // as k_unstuff_* (see emu_decode_coefs)
+            uint8_t c = raw[q], prev = q ? raw[q - 1] : 0, next = q + 1 < rl ? raw[q + 1] : 0xD9;
+            if (c == 0xFF) { if (next == 0) clean.push_back(0xFF); continue; }
+            if (prev == 0xFF) {
+                if (c == 0) continue;
+                if (c >= 0xD0 && c <= 0xD7) { rst.push_back((uint32_t)clean.size() * 8); continue; }
+                return -11;
+            }
+            clean.push_back(c);
+        }
+        std::vector<uint32_t> words((clean.size() + 3) / 4 + 4, 0);
+        for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
+        const uint32_t n_rst = (uint32_t)rst.size();
+        rst.push_back(0);
+        HostProgMem m{words.data(), words.size(), rst.data(), &sh.tables, coef.data()};
+        lp_prog_scan(m, sh.s, (uint32_t)clean.size() * 8, n_rst);
+    }
+    *nscans = (int)h.scans.size();
+    *bw = (int)img.bw[comp]; *bh = (int)img.bh[comp];
+    const size_t ne = (size_t)img.bw[comp] * img.bh[comp] * 64;
+    if (ne > cap_elems) return -3;
+    size_t base = 0;
+    for (int c = 0; c < comp; c++) base += (size_t)img.bw[c] * img.bh[c];
+    for (size_t q = 0; q < (size_t)img.bw[comp] * img.bh[comp]; q++)
+        for (int e = 0; e < 64; e++) out[q * 64 + (((e & 7) << 3) | (e >> 3))] = coef[(base + q) * 64 + e]; // stored transposed
+    return 0;
+}

@@ -1,6 +1,7 @@
 """Writes tests/golden/inputs_exotic/*.jpg with the reference's own libjpeg-turbo compressor (oracle/_ref/libref.so): samplings,
 colour spaces and table widths Pillow cannot produce (4:4:0, 2x2 luma with custom chroma factors, RGB-in-JPEG with an Adobe
-marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row), and
+marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row, progressive
+files with libjpeg's default script, a spectral-selection-only script and a deep successive-approximation script), and
 tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file.
 Run in the build container (needs /root/reference)."""
 import ctypes as C, hashlib, json, os, sys
@@ -43,6 +44,18 @@ enc("q100_420_opt", 48, 80, 3, 0, S420, 100, optimize=1)
 enc("dri7_420", 90, 75, 3, 0, S420, 80, dri=7)
 enc("dri1_444", 24, 40, 3, 0, S444, 92, dri=1)
 enc("gray_dri2", 40, 56, 1, 0, (1, 1, 1, 1, 1, 1), 70, dri=2)
+# progressive (SOF2): optimize bit 1 = jpeg_simple_progression, bit 2 = spectral selection only with one DC scan per component,
+# bit 3 = successive approximation from Al = 3 with split AC bands (oracle/ref_driver.c ref_jpeg_encode_ex)
+enc("prog_simple_420", 75, 101, 3, 0, S420, 85, optimize=2)
+enc("prog_simple_444_opt_dri3", 41, 67, 3, 0, S444, 92, dri=3, optimize=3)
+enc("prog_simple_gray", 66, 50, 1, 0, S444, 70, optimize=2)
+enc("prog_spectral_422", 58, 77, 3, 0, S422, 80, optimize=4)
+enc("prog_spectral_440_dri1", 35, 90, 3, 0, S440, 60, dri=1, optimize=5)
+enc("prog_deep_420", 90, 64, 3, 0, S420, 95, optimize=8)
+enc("prog_deep_gray_dri17", 120, 33, 1, 0, S444, 99, dri=17, optimize=9)
+enc("prog_q1_16bit_tables", 48, 48, 3, 0, S420, 1, force_baseline=0, optimize=2)
+enc("prog_narrow", 40, 3, 3, 0, S420, 90, optimize=2)
+enc("prog_tiny", 1, 1, 3, 0, S420, 90, optimize=2)
 gold = {}
 for f in sorted(os.listdir(out_dir)):
     d = open(os.path.join(out_dir, f), "rb").read()

@@ -111,11 +111,11 @@ def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
     from PIL import Image
 
     data = fixture_bytes["large-sunrise.jpg"]
-    b = io.BytesIO()
-    Image.open(io.BytesIO(data)).save(b, "JPEG", progressive=True)
-    with pytest.raises(lilliput_amd.LilliputError) as e:
-        batch.decode_jpeg(b.getvalue())
-    assert e.value.code == 4
+    sof = data.index(b"\xff\xc0")
+    for marker in (0xC9, 0xC3, 0xCA):  # arithmetic-coded, lossless, arithmetic progressive: outside the device path, said so loudly
+        with pytest.raises(lilliput_amd.LilliputError) as e:
+            batch.decode_jpeg(data[: sof + 1] + bytes([marker]) + data[sof + 2 :])
+        assert e.value.code == 4, marker
     with pytest.raises(lilliput_amd.LilliputError) as e:
         batch.decode_jpeg(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
     assert e.value.code == 1

@@ -1,0 +1,181 @@
+"""Progressive (SOF2) JPEG sources -- SURVEY.md section 8 row n3. The reference decodes them through libjpeg-turbo's jdphuff.c; the
+device path runs every scan as one lane (lilliput_amd/csrc/lp_prog_core.h) into an int16 coefficient arena and then shares the
+IDCT / upsampling / colour / resample / encode stages with baseline files. Checked against the oracle, which is pinned against the
+reference's libjpeg on progressive files in tests/test_oracle_golden.py and tests/test_gpu_sweep.py (recorded digests)."""
+import ctypes as C
+import io
+import os
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _photo(rng, h, w, gray):
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 90 * np.sin(x / rng.uniform(3, 40) + c) + 40 * np.cos(y / rng.uniform(3, 40) - c) for c in range(3)], -1)
+    img = np.clip(img + rng.normal(0, rng.uniform(0, 25), (h, w, 3)), 0, 255).astype(np.uint8)
+    return img[:, :, 0] if gray else img
+
+
+def _cases(seed, n, lo=1, hi=300):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        h, w = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        gray = rng.random() < 0.15
+        kw = {"quality": int(rng.choice([1, 10, 50, 75, 85, 95, 100])), "optimize": bool(rng.random() < 0.5), "progressive": True}
+        if not gray:
+            kw["subsampling"] = int(rng.choice([0, 1, 2]))
+        buf = io.BytesIO()
+        PIL.fromarray(_photo(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        yield i, (h, w, gray, kw), buf.getvalue()
+
+
+def _exotic_progressive():
+    d = os.path.join(ROOT, "tests", "golden", "inputs_exotic")
+    return {n: open(os.path.join(d, n), "rb").read() for n in sorted(os.listdir(d)) if n.startswith("prog_")}
+
+
+# ------------------------------------------------------------------------------------------ CPU: parser + lane logic
+@pytest.fixture(scope="module")
+def emu():
+    import subprocess
+
+    d = os.path.join(ROOT, "tests", "emu")
+    so = os.path.join(d, "libemu.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(d, "emu_huff.cpp"),
+                    os.path.join(ROOT, "lilliput_amd", "csrc", "lp_jpeg_parse.cpp")], check=True)
+    return C.CDLL(so)
+
+
+def _emu_coefs(emu, data, comp):
+    a = np.frombuffer(data, np.uint8)
+    out = np.zeros(1 << 23, np.int16)
+    bw, bh, ns = C.c_int(), C.c_int(), C.c_int()
+    rc = emu.emu_decode_coefs_progressive(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_int(comp), out.ctypes.data_as(C.c_void_p),
+                                          C.c_size_t(out.size), C.byref(bw), C.byref(bh), C.byref(ns))
+    assert rc == 0, rc
+    return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64), ns.value
+
+
+def test_scan_lane_logic_reproduces_oracle_coefficients(emu, oracle):
+    """lp_prog_core.h run serially on the CPU (tests/emu): DC / AC first and refinement scans, EOB runs, correction bits, restart
+    intervals, interleaved and single-component scans -- coefficient for coefficient what the oracle (jdphuff.c restated) yields."""
+    n = 0
+    for name, data in _exotic_progressive().items():
+        for c in range(oracle.jpeg_info(data)["ncomp"]):
+            got, ns = _emu_coefs(emu, data, c)
+            assert ns >= 2 and np.array_equal(got, oracle.jpeg_decode_coefs(data, c)), (name, c)
+            n += 1
+    for i, desc, data in _cases(5, 40, hi=200):
+        for c in range(1 if desc[2] else 3):
+            got, _ = _emu_coefs(emu, data, c)
+            assert np.array_equal(got, oracle.jpeg_decode_coefs(data, c)), (i, desc, c)
+            n += 1
+    assert n > 100
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_progressive_decode_stages_bit_exact(batch, oracle):
+    for name, data in _exotic_progressive().items():
+        for c in range(oracle.jpeg_info(data)["ncomp"]):
+            assert np.array_equal(batch.decode_jpeg_coefs(data, c), oracle.jpeg_decode_coefs(data, c)), (name, "coefs", c)
+            assert np.array_equal(batch.decode_jpeg_plane(data, c), oracle.jpeg_decode_plane(data, c)), (name, "plane", c)
+        px, _ = batch.decode_jpeg(data)
+        assert np.array_equal(px, oracle.jpeg_decode(data)), name
+
+
+@pytest.mark.gpu
+def test_progressive_random_sweep_decode_and_transform(batch, oracle):
+    cases = list(_cases(11, 80))
+    bad = []
+    for i, desc, data in cases:
+        got, _ = batch.decode_jpeg(data)
+        exp = oracle.jpeg_decode(data)
+        if got.shape != exp.shape or not np.array_equal(got, exp):
+            bad.append((i, desc))
+    assert not bad, bad[:8]
+    for tw, th, q in ((64, 64, 85), (37, 91, 70)):
+        res = batch.transform([c[2] for c in cases], tw, th, quality=q)
+        for (i, desc, data), r in zip(cases, res):
+            assert r.status == 0, (i, desc, r.status)
+            exp = oracle.transform_jpeg_thumbnail(data, tw, th, q)
+            if r.data != exp:  # the float area resize may differ by 1 LSB before the encoder (north_star tolerance)
+                a, b = oracle.jpeg_decode(r.data), oracle.jpeg_decode(exp)
+                assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).max() <= 8, (i, desc, tw, th)
+
+
+@pytest.mark.gpu
+def test_progressive_and_baseline_share_a_batch(batch, oracle, fixture_bytes):
+    """One decode range holding both kinds: the Huffman stages skip the progressive images, the scan lanes skip the others."""
+    prog = [c[2] for c in _cases(3, 6, lo=40, hi=400)]
+    base = [fixture_bytes[n] for n in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg")]
+    srcs = [prog[0], base[0], prog[1], prog[2], base[1], base[2], prog[3], prog[4], prog[5]]
+    for tw, th in ((48, 48), (100, 30)):
+        res = batch.transform(srcs, tw, th, quality=85)
+        for k, (data, r) in enumerate(zip(srcs, res)):
+            assert r.status == 0, k
+            exp = oracle.transform_jpeg_thumbnail(data, tw, th, 85)
+            if r.data != exp:
+                a, b = oracle.jpeg_decode(r.data), oracle.jpeg_decode(exp)
+                assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).max() <= 8, (k, tw, th)
+
+
+@pytest.mark.gpu
+def test_progressive_through_the_go_api_mirror(hip_lib, oracle):
+    """NewDecoder / Header / DecodeTo / ImageOps.Transform on a progressive source, as lilliput's callers drive it."""
+    import lilliput_amd as la
+
+    _, desc, data = next(_cases(21, 1, lo=300, hi=500))
+    d = la.Decoder(data)
+    h = d.Header()
+    assert (h["height"], h["width"]) == desc[:2] and d.Description() == "JPEG"
+    ops = la.ImageOps(2048)
+    out = ops.Transform(d, la.ImageOptions(".jpeg", 96, 96, la.ImageOpsFit, False, {la.JpegQuality: 85}))
+    d.Close()
+    ops.Close()
+    exp = oracle.transform_jpeg_thumbnail(data, 96, 96, 85)
+    if out != exp:
+        a, b = oracle.jpeg_decode(out), oracle.jpeg_decode(exp)
+        assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).max() <= 8
+
+
+@pytest.mark.gpu
+def test_progressive_large_image(batch, oracle):
+    """2048 x 1536, 4:2:0, ten scans: whole-image equality with the oracle plus the thumbnail."""
+    rng = np.random.default_rng(4)
+    buf = io.BytesIO()
+    PIL.fromarray(_photo(rng, 1536, 2048, False)).save(buf, "JPEG", quality=88, progressive=True)
+    data = buf.getvalue()
+    got, _ = batch.decode_jpeg(data)
+    assert np.array_equal(got, oracle.jpeg_decode(data))
+    r = batch.transform([data] * 3, 256, 256, quality=85)
+    assert all(x.status == 0 and x.data == r[0].data for x in r)
+    assert r[0].data == oracle.transform_jpeg_thumbnail(data, 256, 256, 85)
+
+
+@pytest.mark.gpu
+def test_progressive_truncated_and_corrupt_never_hang(batch):
+    """Cut and bit-flipped progressive files: an error or an image, the same one every time, never a hang."""
+    _, _, data = next(_cases(8, 1, lo=100, hi=200))
+    rng = np.random.default_rng(0)
+    import lilliput_amd
+
+    for k in range(40):
+        d = bytearray(data)
+        if k % 2:
+            d = d[: int(rng.integers(200, len(d)))]
+        else:
+            for _ in range(3):
+                d[int(rng.integers(len(d) // 3, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        outs = []
+        for _ in range(2):
+            try:
+                px, _o = batch.decode_jpeg(bytes(d))
+                outs.append(px.tobytes())
+            except lilliput_amd.LilliputError as e:
+                outs.append(e.code)
+        assert outs[0] == outs[1], k
