@@ -271,6 +271,15 @@ long lilliput_hip_png_inflate_check(const void* data, size_t len);
 void lilliput_hip_set_lazy_host(int on);
 int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current */
 
+/* Progressive (SOF2) JPEG sources: where the scans' entropy decode runs. 0 (default): host threads feed the device IDCT with
+ * coefficients (a scan is serial by construction; see lilliput_amd/csrc/lp_prog_host.h), 1: one device lane per scan
+ * (k_prog_scan). Same results either way. Also LILLIPUT_HIP_PROG_ENTROPY=device; host thread count: LILLIPUT_HIP_PROG_THREADS. */
+void lilliput_hip_set_progressive_entropy(int on_device);
+/* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
+ * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
+ * -3 = dst too small. nthreads 0 = default. */
+int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads);
+
 /* ------------------------------------------------------------------------------------------------
  * Part C -- host mirror of the Go API (ops.go / opencv.go / lilliput.go)
  * ---------------------------------------------------------------------------------------------- */

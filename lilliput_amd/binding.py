@@ -133,6 +133,8 @@ def lib():
     L.opencv_encoder_write.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_size_t]
     L.opencv_encoder_write.restype = C.c_bool
     L.lilliput_hip_set_lazy_host.argtypes = [C.c_int]
+    L.lilliput_hip_set_progressive_entropy.argtypes = [C.c_int]
+    L.lilliput_hip_set_progressive_entropy.restype = None
     L.lilliput_hip_mat_sync_host.argtypes = [C.c_void_p]
     _LIB = L
     return L

@@ -13,6 +13,7 @@
 
 #include "lp_huff_core.h"
 #include "lp_launch.h"
+#include "lp_prog_host.h"
 
 void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
 
@@ -104,6 +105,12 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
     h_huffs_.clear();
     h_prog_.assign((size_t)n, std::vector<ProgScanUp>());
     h_phuffs_.clear();
+    prog_on_device_ = lp_prog_entropy_on_device();
+    h_pcoef_off_.assign((size_t)n, 0);
+    h_perr_.assign((size_t)n, 0);
+    size_t pcoef_total = 0;
+    std::vector<LpProgHostTask> host_tasks;
+    std::vector<uint32_t> lev;
     std::map<uint64_t, std::vector<uint32_t>> phuff_by_hash;
     struct Piece { size_t arena_off; const uint8_t* src; size_t len; };
     std::vector<Piece> pieces; // entropy-coded segments, 16-byte aligned in the raw arena, each followed by 32 zero bytes
@@ -118,11 +125,20 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         j.huff_idx = hi;
         j.raw_off = raw_bytes;
         j.progressive = hdrs[i].progressive ? 1 : 0;
-        if (hdrs[i].progressive) { // every scan is a stream of its own
+        if (hdrs[i].progressive && !prog_on_device_) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
             j.raw_len = 0;
+            h_pcoef_off_[(size_t)i] = pcoef_total;
+            for (int c = 0; c < j.ncomp; c++) pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
+            lp_prog_levels(hdrs[i].scans, lev);
+            for (size_t q = 0; q < hdrs[i].scans.size(); q++)
+                host_tasks.push_back(LpProgHostTask{srcs[i].data, &hdrs[i].scans[q], nullptr, lev[q], &h_perr_[(size_t)i]});
+        } else if (hdrs[i].progressive) { // every scan is a stream of its own
+            j.raw_len = 0;
+            lp_prog_levels(hdrs[i].scans, lev);
             for (const LpProgScanHost& sh : hdrs[i].scans) {
                 ProgScanUp up;
                 up.s = sh.s;
+                up.level = lev[h_prog_[(size_t)i].size()];
                 uint64_t hash = 1469598103934665603ull;
                 const uint8_t* tb = reinterpret_cast<const uint8_t*>(&sh.tables);
                 for (size_t q = 0; q < sizeof(LpProgHuff); q++) hash = (hash ^ tb[q]) * 1099511628211ull;
@@ -148,6 +164,15 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         }
         j.nchunks = (j.raw_len + 4095) / 4096;
         h_src_[(size_t)i] = j;
+    }
+    if (!host_tasks.empty()) {
+        if (!h_pcoef_.ensure(pcoef_total * 2 + 64)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
+        memset(h_pcoef_.p, 0, pcoef_total * 2);
+        size_t t = 0;
+        for (int i = 0; i < n; i++)
+            if (hdrs[i].progressive)
+                for (size_t q = 0; q < hdrs[i].scans.size(); q++) host_tasks[t++].coef = h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)i];
+        lp_prog_host_run(host_tasks, 0);
     }
     const size_t kStage = 256u << 20; // pinned staging window
     if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) ||
@@ -235,20 +260,12 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         tot_rst_ += j.rst_cap;
         if (j.progressive) {
             // Scans that touch the same coefficients of the same component must run in file order (a refinement needs what came
-            // before it); all others are independent. Level = 1 + the deepest earlier scan this one overlaps.
+            // before it); all others are independent (lp_prog_levels). Host mode: ups is empty, the coefficients are ready.
             const std::vector<ProgScanUp>& ups = h_prog_[(size_t)first + i];
             j.coef_off = pcoef_elems;
             for (int c = 0; c < j.ncomp; c++) pcoef_elems += (size_t)j.bw[c] * j.bh[c] * 64;
-            std::vector<uint32_t> lev(ups.size(), 0);
             for (size_t a = 0; a < ups.size(); a++) {
                 const LpProgScan& sa = ups[a].s;
-                for (size_t b = 0; b < a; b++) {
-                    const LpProgScan& sb = ups[b].s;
-                    bool share = false;
-                    for (uint32_t x = 0; x < sa.ns; x++)
-                        for (uint32_t y = 0; y < sb.ns; y++) share = share || sa.comp[x] == sb.comp[y];
-                    if (share && sa.Ss <= sb.Se && sb.Ss <= sa.Se) lev[a] = std::max(lev[a], lev[b] + 1);
-                }
                 LpJpeg ps;
                 memset(&ps, 0, sizeof(ps));
                 ps.raw_off = ups[a].raw_off;
@@ -270,7 +287,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
                 sc.stream = (uint32_t)h_pstreams_.size();
                 sc.coef_off = j.coef_off;
                 h_pstreams_.push_back(ps);
-                leveled.push_back(std::make_pair(lev[a], sc));
+                leveled.push_back(std::make_pair(ups[a].level, sc));
             }
         } else {
             j.coef_off = coef_elems; // a multiple of 8 blocks: a group of eight DC values is one aligned 16-byte store (DevSink)
@@ -304,6 +321,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     h_plevel_first_.push_back((uint32_t)leveled.size());
     const size_t nstreams = h_pstreams_.size();
+    if (pcoef_elems && !d_pcoef_.ensure(pcoef_elems * 2 + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     if (nstreams && !(d_pstreams_.ensure(sizeof(LpJpeg) * nstreams) && d_pstates_.ensure(sizeof(LpJpegState) * nstreams) &&
                       d_pscans_.ensure(sizeof(LpProgScan) * nstreams) && d_pcoef_.ensure(pcoef_elems * 2 + 64))) {
         err_ = "device allocation failed";
@@ -371,6 +389,16 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
+    if (pcoef_elems && !prog_on_device_) { // hybrid mode: the coefficients were decoded at upload time
+        for (int i = 0; i < n; i++) {
+            const LpJpeg& j = h_imgs_[(size_t)i];
+            if (!j.progressive) continue;
+            size_t ne = 0;
+            for (int c = 0; c < j.ncomp; c++) ne += (size_t)j.bw[c] * j.bh[c] * 64;
+            if (!check(hipMemcpyAsync(d_pcoef_.as<int16_t>() + j.coef_off, h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)first + i], ne * 2, hipMemcpyHostToDevice, stream_), "H2D coefficients"))
+                return LP_ERR_DEVICE;
+        }
+    }
     if (nstreams) { // progressive images: unstuff every scan, then the scans level by level into the zeroed int16 arena
         if (!check(hipMemcpyAsync(d_pstreams_.p, h_pstreams_.data(), sizeof(LpJpeg) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scan streams") ||
             !check(hipMemcpyAsync(d_pscans_.p, h_pscans_.data(), sizeof(LpProgScan) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scans") ||
@@ -391,7 +419,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(),
-                   (any_baseline ? 1u : 0u) | (nstreams ? 2u : 0u), d_pcoef_.as<int16_t>());
+                   (any_baseline ? 1u : 0u) | (pcoef_elems ? 2u : 0u), d_pcoef_.as<int16_t>());
     stage("idct");
     if (timing_) (void)hipEventRecord(ev_[3], stream_);
     // frames
@@ -421,6 +449,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
         for (const LpProgScan& sc : h_pscans_) h_states_[sc.img].error |= h_pstates_[sc.stream].error;
     }
+    for (int i = 0; i < n; i++)
+        if (h_imgs_[(size_t)i].progressive && !prog_on_device_) h_states_[(size_t)i].error |= h_perr_[(size_t)first + i];
     int rc = LP_OK;
     for (int i = 0; i < n; i++) {
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;

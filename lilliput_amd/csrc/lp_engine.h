@@ -151,7 +151,11 @@ private:
     std::vector<size_t> h_out_off_;
 
     // progressive images (SOF2): their scans, laid out per upload and per decode range
-    struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; };
+    struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; uint32_t level; };
+    bool prog_on_device_ = false;                   // where this upload's scans are entropy-decoded (lp_prog_host.h)
+    LpPinned h_pcoef_;                              // host mode: the decoded int16 coefficients of every progressive image of the upload
+    std::vector<size_t> h_pcoef_off_;               // element offset per uploaded image
+    std::vector<uint32_t> h_perr_;                  // per uploaded image
     std::vector<std::vector<ProgScanUp>> h_prog_;   // per uploaded image; empty for a baseline one
     std::vector<LpProgHuff> h_phuffs_;
     std::vector<LpProgScan> h_pscans_;              // the current range's scans, sorted by dependency level

@@ -11,6 +11,7 @@
 #include "lp_types.h"
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define LP_PHD __host__ __device__ __forceinline__
 #else
 #define LP_PHD inline

@@ -77,9 +77,39 @@ def test_scan_lane_logic_reproduces_oracle_coefficients(emu, oracle):
     assert n > 100
 
 
+def _host_coefs(hip_lib, data, comp, nthreads=0):
+    a = np.frombuffer(data, np.uint8)
+    out = np.zeros(1 << 23, np.int16)
+    bw, bh = C.c_int(), C.c_int()
+    rc = hip_lib.lilliput_hip_progressive_coefs_host(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_int(comp), out.ctypes.data_as(C.c_void_p),
+                                                     C.c_size_t(out.size), C.byref(bw), C.byref(bh), C.c_int(nthreads))
+    assert rc == 0, rc
+    return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64)
+
+
+def test_host_entropy_threads_reproduce_oracle_coefficients(hip_lib, oracle):
+    """The hybrid mode's host side (lp_prog_host.cpp: unstuff + the scan lanes on threads, independent scans concurrently) through
+    the library's test hook -- no device involved."""
+    for name, data in _exotic_progressive().items():
+        for c in range(oracle.jpeg_info(data)["ncomp"]):
+            for nt in (1, 4):
+                assert np.array_equal(_host_coefs(hip_lib, data, c, nt), oracle.jpeg_decode_coefs(data, c)), (name, c, nt)
+    for i, desc, data in _cases(6, 25):
+        for c in range(1 if desc[2] else 3):
+            assert np.array_equal(_host_coefs(hip_lib, data, c), oracle.jpeg_decode_coefs(data, c)), (i, desc, c)
+
+
 # ------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(params=["host-entropy", "device-entropy"])
+def mode(request, hip_lib):
+    """Both homes of the scans' entropy decode (lilliput_hip_set_progressive_entropy): host threads (default) and device lanes."""
+    hip_lib.lilliput_hip_set_progressive_entropy(1 if request.param == "device-entropy" else 0)
+    yield request.param
+    hip_lib.lilliput_hip_set_progressive_entropy(0)
+
+
 @pytest.mark.gpu
-def test_progressive_decode_stages_bit_exact(batch, oracle):
+def test_progressive_decode_stages_bit_exact(batch, oracle, mode):
     for name, data in _exotic_progressive().items():
         for c in range(oracle.jpeg_info(data)["ncomp"]):
             assert np.array_equal(batch.decode_jpeg_coefs(data, c), oracle.jpeg_decode_coefs(data, c)), (name, "coefs", c)
@@ -89,7 +119,7 @@ def test_progressive_decode_stages_bit_exact(batch, oracle):
 
 
 @pytest.mark.gpu
-def test_progressive_random_sweep_decode_and_transform(batch, oracle):
+def test_progressive_random_sweep_decode_and_transform(batch, oracle, mode):
     cases = list(_cases(11, 80))
     bad = []
     for i, desc, data in cases:
@@ -109,7 +139,7 @@ def test_progressive_random_sweep_decode_and_transform(batch, oracle):
 
 
 @pytest.mark.gpu
-def test_progressive_and_baseline_share_a_batch(batch, oracle, fixture_bytes):
+def test_progressive_and_baseline_share_a_batch(batch, oracle, fixture_bytes, mode):
     """One decode range holding both kinds: the Huffman stages skip the progressive images, the scan lanes skip the others."""
     prog = [c[2] for c in _cases(3, 6, lo=40, hi=400)]
     base = [fixture_bytes[n] for n in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg")]
@@ -125,7 +155,7 @@ def test_progressive_and_baseline_share_a_batch(batch, oracle, fixture_bytes):
 
 
 @pytest.mark.gpu
-def test_progressive_through_the_go_api_mirror(hip_lib, oracle):
+def test_progressive_through_the_go_api_mirror(hip_lib, oracle, mode):
     """NewDecoder / Header / DecodeTo / ImageOps.Transform on a progressive source, as lilliput's callers drive it."""
     import lilliput_amd as la
 
@@ -145,7 +175,8 @@ def test_progressive_through_the_go_api_mirror(hip_lib, oracle):
 
 @pytest.mark.gpu
 def test_progressive_large_image(batch, oracle):
-    """2048 x 1536, 4:2:0, ten scans: whole-image equality with the oracle plus the thumbnail."""
+    """2048 x 1536, 4:2:0, ten scans: whole-image equality with the oracle plus the thumbnail (default mode; the device-lane mode
+    is covered at smaller sizes above -- it needs seconds for an image this large)."""
     rng = np.random.default_rng(4)
     buf = io.BytesIO()
     PIL.fromarray(_photo(rng, 1536, 2048, False)).save(buf, "JPEG", quality=88, progressive=True)
@@ -158,7 +189,7 @@ def test_progressive_large_image(batch, oracle):
 
 
 @pytest.mark.gpu
-def test_progressive_truncated_and_corrupt_never_hang(batch):
+def test_progressive_truncated_and_corrupt_never_hang(batch, mode):
     """Cut and bit-flipped progressive files: an error or an image, the same one every time, never a hang."""
     _, _, data = next(_cases(8, 1, lo=100, hi=200))
     rng = np.random.default_rng(0)
@@ -179,3 +210,36 @@ def test_progressive_truncated_and_corrupt_never_hang(batch):
             except lilliput_amd.LilliputError as e:
                 outs.append(e.code)
         assert outs[0] == outs[1], k
+
+
+@pytest.mark.gpu
+def test_progressive_modes_agree_on_damaged_files(batch, hip_lib):
+    """Host threads and device lanes give the same pixels (or the same error) for cut and bit-flipped files too."""
+    import lilliput_amd
+
+    rng = np.random.default_rng(5)
+    files = []
+    for _, _, data in _cases(9, 6, lo=60, hi=160):
+        for k in range(6):
+            d = bytearray(data)
+            if k % 2:
+                d = d[: int(rng.integers(300, len(d)))]
+            else:
+                for _ in range(2):
+                    d[int(rng.integers(len(d) // 2, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            files.append(bytes(d))
+    outs = {}
+    for m in (0, 1):
+        hip_lib.lilliput_hip_set_progressive_entropy(m)
+        try:
+            res = []
+            for d in files:
+                try:
+                    res.append(batch.decode_jpeg(d)[0].tobytes())
+                except lilliput_amd.LilliputError as e:
+                    res.append(e.code)
+            outs[m] = res
+        finally:
+            hip_lib.lilliput_hip_set_progressive_entropy(0)
+    assert outs[0] == outs[1]
+    assert sum(isinstance(x, bytes) for x in outs[0]) > 5
