@@ -480,14 +480,15 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     const LpJpeg& j = h_imgs_[(size_t)i];
     const size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
     if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
-    if (j.progressive) { // already [by][bx], blocks transposed
+    if (j.progressive) { // already [by][bx], every block in zigzag order
         size_t base = 0;
         for (int c = 0; c < comp; c++) base += (size_t)j.bw[c] * j.bh[c] * 64;
         std::vector<int16_t> t(ne);
         if (!check(hipMemcpyAsync(t.data(), d_pcoef_.as<int16_t>() + j.coef_off + base, ne * 2, hipMemcpyDeviceToHost, stream_), "D2H coefs")) return LP_ERR_DEVICE;
         const int rc = sync();
         if (rc) return rc;
-        for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | ((q & 7) << 3) | ((q >> 3) & 7)] = t[q];
+        static const uint8_t zz[80] = LP_ZIGZAG_INIT;
+        for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | zz[q & 63]] = t[q];
         return LP_OK;
     }
     const size_t nb = j.total_blocks;

@@ -157,7 +157,7 @@ struct LpLane {
         const uint32_t idx = top - m.base2(tbl);
         uint32_t e = idx < m.lut2_n(tbl) ? m.lut2(tbl, idx) : 0u;
         if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix or a table with a very wide tail
-            uint32_t len = 16, sym = 0;
+            uint32_t len = 17, sym = 0; // no code matches: jpeg_huff_decode reads on to the sentinel length 17, warns and fakes a zero
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
                 const int32_t code = (int32_t)(top >> (16 - l));
                 if (code <= m.maxcode(tbl, l)) {

@@ -150,6 +150,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return LP_PARSE_NOT_JPEG;
     uint16_t qt[4][64];
     bool qt_ok[4] = {false, false, false, false};
+    bool latched[4] = {false, false, false, false}; // progressive: quantisation table fixed at the component's first scan
+    uint16_t latched_qt[4][64];
     uint8_t hbits[2][4][17];
     uint8_t hvals[2][4][256];
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
@@ -278,7 +280,9 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if (c == j.ncomp) return LP_PARSE_NOT_JPEG;               // JERR_BAD_COMPONENT_ID
                 cur[s] = c;
                 for (unsigned q = 0; q < s; q++) if (cur[q] == c) return LP_PARSE_NOT_JPEG;
-                if ((t >> 4) > 3 || (t & 15) > 3) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
+                // jpeg_make_d_derived_tbl rejects an index above 3 -- of the tables a scan actually builds: both in a sequential
+                // scan, only the DC or the AC one in a progressive scan (checked below)
+                if (!progressive && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
                 if (s < 3) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
             if (progressive) { // jdphuff.c start_pass_phuff_decoder: one of up to LP_MAX_SCANS scans; the tables as they stand now
@@ -293,16 +297,25 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if (rs.Ah != 0 && rs.Ah - 1 != rs.Al) bad = true;
                 if (rs.Al > 13) bad = true;
                 if (bad) return LP_PARSE_NOT_JPEG;                        // JERR_BAD_PROGRESSION
+                for (unsigned s = 0; s < ns; s++) { // jdinput.c latch_quant_tables: a component keeps the table current at its first scan
+                    const int c = cur[s];
+                    if (latched[c]) continue;
+                    if (tq[c] > 3 || !qt_ok[tq[c]]) return LP_PARSE_NOT_JPEG; // JERR_NO_QUANT_TABLE
+                    memcpy(latched_qt[c], qt[tq[c]], sizeof(latched_qt[c]));
+                    latched[c] = true;
+                }
                 rs.dri = j.dri;
                 const bool dc_scan = rs.Ss == 0;
                 if (!(dc_scan && rs.Ah != 0))                             // a DC refinement scan reads raw bits only
                     for (unsigned s = 0; s < ns; s++) {
                         const int cls = dc_scan ? 0 : 1, id = dc_scan ? rs.td[s] : rs.ta[s];
-                        const uint8_t* tb = h_ok[cls][id] ? hbits[cls][id] : id < 2 ? lp_std_huff_bits[2 * id + cls] : nullptr;
-                        const uint8_t* tv = h_ok[cls][id] ? hvals[cls][id] : id < 2 ? (cls == 0 ? lp_std_huff_dc_vals : id ? lp_std_huff_ac_chroma : lp_std_huff_ac_luma) : nullptr;
-                        if (!tb) return LP_PARSE_NOT_JPEG;                // JERR_NO_HUFF_TABLE
+                        if (id > 3) return LP_PARSE_NOT_JPEG;             // JERR_NO_HUFF_TABLE
+                        // no Annex-K fallback here: std_huff_tables() runs in jinit_huff_decoder only, a progressive file defines what it uses
+                        if (!h_ok[cls][id]) return LP_PARSE_NOT_JPEG;     // JERR_NO_HUFF_TABLE
+                        const uint8_t* tb = hbits[cls][id];
+                        const uint8_t* tv = hvals[cls][id];
                         memcpy(rs.bits[s], tb, 17);
-                        memcpy(rs.vals[s], tv, h_ok[cls][id] ? 256 : (cls == 0 ? 12 : 162));
+                        memcpy(rs.vals[s], tv, 256);
                         if (!huff_table_valid(rs.bits[s], rs.vals[s], cls == 0)) return LP_PARSE_NOT_JPEG;
                     }
                 rs.ecs_off = seg_end;
@@ -352,8 +365,9 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (j.hs[c] < 1 || j.hs[c] > 2 || j.vs[c] < 1 || j.vs[c] > 2) return LP_PARSE_UNSUPPORTED;
         if (j.hs[c] > j.hmax) j.hmax = j.hs[c];
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
+        if (progressive && !latched[c]) { memset(latched_qt[c], 0, sizeof(latched_qt[c])); continue; } // in no scan at all: stays zero (libjpeg: never dequantised)
+        if (progressive) continue;                                                                 // tables were checked scan by scan
         if (tq[c] > 3 || !qt_ok[tq[c]]) return LP_PARSE_NOT_JPEG;                                  // JERR_NO_QUANT_TABLE
-        if (progressive) continue;                                                                 // Huffman tables were checked scan by scan
         if (!h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;                         // JERR_NO_HUFF_TABLE
         if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
         if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
@@ -378,7 +392,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         j.plane_stride[c] = j.bw[c] * 8;
         j.dc_tbl[c] = (uint8_t)td[c];
         j.ac_tbl[c] = (uint8_t)(2 + ta[c]);
-        memcpy(j.qt[c], qt[tq[c]], sizeof(j.qt[c]));
+        if (progressive) memcpy(j.qt[c], latched_qt[c], sizeof(j.qt[c]));
+        else memcpy(j.qt[c], qt[tq[c]], sizeof(j.qt[c]));
     }
     j.bpm = (uint8_t)bpm;
     j.blkpack = 0;

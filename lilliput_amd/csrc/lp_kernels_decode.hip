@@ -779,6 +779,8 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
     }
 }
 
+__constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
+
 #define IDCT_TPW 8
 // PROG = false: the baseline images of the range (int8 blocks in decode order + wide slots + the DC array);
 // PROG = true: the progressive ones (int16 blocks, raster order per component, see LpProgScan). Each skips the other kind.
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
 {
     __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t s_qt[64]; // transposed like the blocks: [column][row]
+    __shared__ uint8_t s_n2z[64];
     const LpJpeg& img = imgs[blockIdx.z];
     if ((img.progressive != 0) != PROG) return;
     uint32_t by = blockIdx.y, c = 0;
@@ -802,6 +805,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     const uint32_t bw = img.bw[c];
     if (blockIdx.x * (32 * IDCT_TPW) >= bw) return;
     if (threadIdx.x < 64) s_qt[((threadIdx.x & 7) << 3) | (threadIdx.x >> 3)] = img.qt[c][threadIdx.x];
+    if (PROG && threadIdx.x < 64) s_n2z[threadIdx.x] = c_nat2zigzag[threadIdx.x];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t j = lane >> 3, r = lane & 7;
     // decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order; sampling factors are 1 or 2
@@ -823,13 +827,12 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         int32_t cv[8];
         bool any_esc = false;
         if (PROG) {
-            // column r of the block: 8 x int16, 16 contiguous bytes
+            // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
+            // its 128 bytes between them)
             const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u);
-            const int16_t* src = wide_arena /* = the progressive arena in this variant */ + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64 + r * 8;
-            const uint4 raw = blk_ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-            const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+            const int16_t* src = wide_arena /* = the progressive arena in this variant */ + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
 #pragma unroll
-            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int16_t)((rw[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+            for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) any_esc = any_esc || ((i || r) && (cv[i] > 127 || cv[i] < -127)); // same bound as the int8 path, DC aside
         } else {
@@ -845,7 +848,11 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
                     any_esc = (zx | zy) != 0;
                 }
                 if (any_esc) {
-                    const int16_t* w = wide_arena + img.coef_off + (size_t)wide_id_arena[img.coef_off / 64 + blk] * 64 + r * 8;
+                    // a block no lane wrote (the stream ended early: the image is reported as failed) holds stale bytes, and a stale
+                    // escape comes with a stale slot number: keep the read inside the image's own slots
+                    uint32_t wid = wide_id_arena[img.coef_off / 64 + blk];
+                    wid = wid < img.total_blocks ? wid : 0u;
+                    const int16_t* w = wide_arena + img.coef_off + (size_t)wid * 64 + r * 8;
 #pragma unroll
                     for (int i = 0; i < 8; i++)
                         if (cv[i] == -128) cv[i] = w[i];
@@ -871,28 +878,53 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
 // Progressive scans (lp_prog_core.h): lane = one scan of one image, decoded serially from its first bit to its last. The lanes
 // of a launch share nothing (different streams, tables and blocks), so a workgroup carries only `lpw` of them: with few scans
 // in flight every lane gets a wave -- and its SIMD's issue slots -- to itself.
-__constant__ uint8_t c_tzigzag[64] = LP_TZIGZAG_INIT;
-
 struct DevProgMem {
     const uint32_t* words;
     uint32_t cap;
     const uint32_t* rst;
     const LpProgHuff* ht;
     int16_t* coef;  // the image's first block
-    int16_t* cur;
+    int16_t* stage; // this lane's 128 bytes of LDS: the block an AC refinement is working on
+    uint64_t dirty; // elements changed since open(): only those go back -- other scans of the same level own the rest of the block
     __device__ __forceinline__ uint32_t word(uint32_t w) const { return w < cap ? words[w] : 0u; }
     __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
     __device__ __forceinline__ uint32_t lut8(uint32_t s, uint32_t i) const { return ht->lut8[s][i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
     __device__ __forceinline__ uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
-    __device__ __forceinline__ uint32_t tz(uint32_t k) const { return c_tzigzag[k & 63u]; }
     __device__ __forceinline__ void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
     __device__ __forceinline__ int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
-    __device__ __forceinline__ void open(uint32_t blk) { cur = coef + (size_t)blk * 64; }
-    __device__ __forceinline__ int32_t get(uint32_t e) const { return cur[e]; }
-    __device__ __forceinline__ void set(uint32_t e, int32_t v) { cur[e] = (int16_t)v; }
-    __device__ __forceinline__ void close(uint32_t) {}
+    __device__ __forceinline__ uint64_t open(uint32_t blk) // eight independent 16-byte loads, the non-zero mask on the way into LDS
+    {
+        typedef uint4 __attribute__((may_alias)) uint4_a; // the same bytes are read and written as int16 elsewhere
+        const uint4_a* src = reinterpret_cast<const uint4_a*>(coef + (size_t)blk * 64);
+        uint4_a* dst = reinterpret_cast<uint4_a*>(stage);
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = src[i];
+        uint64_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            dst[i] = v[i];
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                nz |= (uint64_t)(((w[q] & 0xffffu) ? 1u : 0u) | ((w[q] >> 16) ? 2u : 0u)) << (8 * i + 2 * q);
+        }
+        dirty = 0;
+        return nz;
+    }
+    __device__ __forceinline__ int32_t get(uint32_t e) const { return stage[e]; }
+    __device__ __forceinline__ void set(uint32_t e, int32_t v) { stage[e] = (int16_t)v; dirty |= 1ull << e; }
+    __device__ __forceinline__ void close(uint32_t blk)
+    {
+        int16_t* dst = coef + (size_t)blk * 64;
+        while (dirty) {
+            const uint32_t e = (uint32_t)(__ffsll((unsigned long long)dirty) - 1);
+            dirty &= dirty - 1ull;
+            dst[e] = stage[e];
+        }
+    }
 };
 
 __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, uint32_t lpw,
@@ -900,6 +932,7 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
                                                   const LpProgHuff* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                   const uint32_t* __restrict__ rst_arena, int16_t* __restrict__ pcoef)
 {
+    __shared__ __attribute__((aligned(16))) int16_t s_stage[64][64];
     if (threadIdx.x >= lpw) return;
     const uint32_t i = blockIdx.x * lpw + threadIdx.x;
     if (i >= n) return;
@@ -912,7 +945,8 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
     m.rst = rst_arena + stream.rst_off;
     m.ht = huffs + sc.huff;
     m.coef = pcoef + sc.coef_off;
-    m.cur = m.coef;
+    m.stage = s_stage[threadIdx.x];
+    m.dirty = 0;
     lp_prog_scan(m, sc, st.clean_bytes * 8u, st.n_rst);
 }
 

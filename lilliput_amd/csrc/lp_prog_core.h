@@ -17,29 +17,41 @@
 #define LP_PHD inline
 #endif
 
-// zigzag index -> storage index inside a block (transposed natural order); entries past 63 are never used
-#define LP_TZIGZAG_INIT                                                                                   \
-    {0,  8,  1,  2,  9,  16, 24, 17, 10, 3,  4,  11, 18, 25, 32, 40, 33, 26, 19, 12, 5,  6,  13, 20, 27, 34, \
-     41, 48, 56, 49, 42, 35, 28, 21, 14, 7,  15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, \
-     52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63}
+// Blocks are stored in ZIGZAG order (element k = the k-th coefficient of the scan order): a refinement scan walks a band of
+// consecutive k, and the block's non-zero history is then one 64-bit mask whose bit k belongs to element k -- the walk over
+// "the next r still-zero coefficients, correcting every non-zero one on the way" becomes a few bit operations instead of a
+// visit to each of up to 63 coefficients. The IDCT undoes the order when it loads a block.
+// natural (row-major) index -> zigzag index, for the consumers of the arena
+#define LP_NAT2ZIGZAG_INIT                                                                                 \
+    {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, \
+     18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, \
+     50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63}
 
 // Memory policy P must provide:
 //   uint32_t word(uint32_t w)                      word w of the clean stream, bit 31 first (any w the reader asks for below the capacity)
 //   uint32_t rst_bit(uint32_t k)                   bit position of the k-th restart boundary
 //   uint32_t lut8(uint32_t s, uint32_t i); int32_t maxcode(s, l), valoff(s, l); uint32_t val(s, i)    LpProgHuff of the scan
-//   uint32_t tz(uint32_t k)                        LP_TZIGZAG_INIT
-//   void st(uint32_t blk, uint32_t e, int32_t v)   store one coefficient (first scans: write only)
-//   int32_t ld(uint32_t blk, uint32_t e)
-//   void open(uint32_t blk) / int32_t get(uint32_t e) / void set(uint32_t e, int32_t v) / void close(uint32_t blk)
-//                                                  stage one block for an AC refinement (every coefficient of the band is read)
+//   void st(uint32_t blk, uint32_t k, int32_t v)   store coefficient k (zigzag index) of a block (first scans: write only)
+//   int32_t ld(uint32_t blk, uint32_t k)
+//   uint64_t open(uint32_t blk)                    stage one block for an AC refinement; returns its non-zero mask (bit k = element k)
+//   int32_t get(uint32_t k) / void set(uint32_t k, int32_t v) / void close(uint32_t blk)
 template <class P>
 struct LpProgBits {
     P& m;
     uint32_t p;         // next unread bit
-    uint32_t total;     // bits in the stream; everything behind reads as zero
+    uint32_t total;     // end of the data the decoder may use: the next restart boundary or the end of the scan. libjpeg stops
+                        // feeding real bytes at ANY marker and stuffs zero bits from there on (jdhuff.c jpeg_fill_bit_buffer)
     uint32_t cw, w0, w1;
+    bool insufficient;  // jdhuff.c insufficient_data: a read went past `total` (JWRN_HIT_MARKER); until the next restart marker
+                        // the remaining MCUs are left as they are
 
-    LP_PHD LpProgBits(P& m_, uint32_t total_) : m(m_), p(0), total(total_), cw(0xfffffff0u), w0(0), w1(0) {}
+    LP_PHD LpProgBits(P& m_, uint32_t total_) : m(m_), p(0), total(total_), cw(0xfffffff0u), w0(0), w1(0), insufficient(false) {}
+    LP_PHD void seek(uint32_t pos, uint32_t new_total) // start of a restart interval: the cached words were cut at the old end
+    {
+        p = pos;
+        total = new_total;
+        cw = 0xfffffff0u;
+    }
     LP_PHD uint32_t load(uint32_t w)
     {
         const uint32_t base = w << 5;
@@ -58,24 +70,28 @@ struct LpProgBits {
         }
         return (uint32_t)((((((uint64_t)w0) << 32) | w1) << (p & 31u)) >> 32);
     }
-    LP_PHD uint32_t get(uint32_t n) // n <= 16
+    LP_PHD uint32_t get(uint32_t n) // n <= 32
     {
         if (!n) return 0u;
         const uint32_t v = peek() >> (32u - n);
         p += n;
+        insufficient = insufficient || p > total;
         return v;
     }
     LP_PHD uint32_t sym(uint32_t s) // jdhuff.c HUFF_DECODE / jpeg_huff_decode
     {
         const uint32_t pk = peek();
         uint32_t e = m.lut8(s, pk >> 24);
-        if (e) { p += e >> 8; return e & 255u; }
-        for (uint32_t l = 9; l <= 16; l++) {
-            const int32_t code = (int32_t)(pk >> (32u - l));
-            if (code <= m.maxcode(s, l)) { p += l; return m.val(s, (uint32_t)(code + m.valoff(s, l)) & 255u); }
-        }
-        p += 16; // JWRN_HUFF_BAD_CODE: libjpeg carries on with a zero symbol
-        return 0u;
+        uint32_t len = 17, v = 0; // no match (JWRN_HUFF_BAD_CODE): jpeg_huff_decode has walked on to the sentinel length 17 and fakes a zero
+        if (e) { len = e >> 8; v = e & 255u; }
+        else
+            for (uint32_t l = 9; l <= 16; l++) {
+                const int32_t code = (int32_t)(pk >> (32u - l));
+                if (code <= m.maxcode(s, l)) { len = l; v = m.val(s, (uint32_t)(code + m.valoff(s, l)) & 255u); break; }
+            }
+        p += len;
+        insufficient = insufficient || p > total;
+        return v;
     }
 };
 
@@ -84,10 +100,47 @@ LP_PHD int32_t lp_prog_extend(uint32_t v, uint32_t s) // HUFF_EXTEND
     return v < (1u << (s - 1u)) ? (int32_t)v - (int32_t)((1u << s) - 1u) : (int32_t)v;
 }
 
+LP_PHD uint32_t lp_popc64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll((unsigned long long)v);
+#else
+    return (uint32_t)__builtin_popcountll(v);
+#endif
+}
+LP_PHD uint32_t lp_ctz64(uint64_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffsll((unsigned long long)v) - 1);
+#else
+    return (uint32_t)__builtin_ctzll(v);
+#endif
+}
+
+// One correction bit for every coefficient of `bits` (ascending = scan order): a set bit moves a coefficient whose p1 bit is
+// still clear away from zero by p1.
+template <class P>
+LP_PHD void lp_prog_correct(P& m, LpProgBits<P>& b, uint64_t bits, int32_t p1, int32_t m1)
+{
+    while (bits) { // the correction bits of up to 32 coefficients come out of the stream in one read
+        uint32_t n = lp_popc64(bits);
+        if (n > 32u) n = 32u;
+        uint32_t v = b.get(n) << (32u - n); // first coefficient's bit on top
+        for (; n; n--, v <<= 1) {
+            const uint32_t e = lp_ctz64(bits);
+            bits &= bits - 1ull;
+            if (v & 0x80000000u) {
+                const int32_t co = m.get(e);
+                if ((co & p1) == 0) m.set(e, co >= 0 ? co + p1 : co + m1);
+            }
+        }
+    }
+}
+
 template <class P>
 LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32_t n_rst)
 {
-    LpProgBits<P> b(m, total_bits);
+    LpProgBits<P> b(m, n_rst ? m.rst_bit(0) : total_bits);
     const uint32_t Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al;
     const int32_t p1 = 1 << Al, m1 = -(1 << Al);
     int32_t pred[4] = {0, 0, 0, 0};
@@ -95,11 +148,21 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
     for (uint32_t my = 0; my < sc.mcuy; my++)
         for (uint32_t mx = 0; mx < sc.mcux; mx++) {
             if (sc.dri && rst_left == 0) { // process_restart: the rest of the interval's bits are dropped, predictors and the EOB run start over
-                b.p = rst_k < n_rst ? m.rst_bit(rst_k) : total_bits;
+                if (rst_k < n_rst) { // the marker is there: decoding resumes behind it ("reset out-of-data flag, unless ... up against end of data")
+                    b.seek(m.rst_bit(rst_k), rst_k + 1u < n_rst ? m.rst_bit(rst_k + 1u) : total_bits);
+                    b.insufficient = false;
+                } else
+                    b.seek(total_bits, total_bits);
                 rst_k++;
                 pred[0] = pred[1] = pred[2] = pred[3] = 0;
                 eobrun = 0;
                 rst_left = sc.dri;
+            }
+            // "If we've run out of data, don't modify the MCU" (every decode_mcu_* but the DC refinement, which cannot change anything
+            // with zero bits anyway)
+            if (b.insufficient && !(Ss == 0 && Ah != 0)) {
+                if (sc.dri) rst_left--;
+                continue;
             }
             if (Ss == 0) { // DC scans may interleave components
                 for (uint32_t s = 0; s < sc.ns; s++)
@@ -123,7 +186,8 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
                             if (t) {
                                 k += r;
                                 const int32_t val = lp_prog_extend(b.get(t), t);
-                                if (k < 64u) m.st(blk, m.tz(k), (int32_t)((uint32_t)val << Al));
+                                // an index past 63 (corrupt stream) lands on jpeg_natural_order[64..79] = the last coefficient
+                                m.st(blk, k < 64u ? k : 63u, (int32_t)((uint32_t)val << Al));
                             } else if (r == 15u)
                                 k += 15u;
                             else {
@@ -132,35 +196,37 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
                             }
                         }
                 } else { // decode_mcu_AC_refine
-                    m.open(blk);
+                    uint64_t nz = m.open(blk);
+                    const uint64_t band = Se >= 63u ? ~0ull : (1ull << (Se + 1u)) - 1ull; // elements 0..Se
                     uint32_t k = Ss;
                     if (eobrun == 0) {
-                        for (; k <= Se; k++) {
+                        while (k <= Se) {
                             const uint32_t rs = b.sym(0);
-                            int32_t r = (int32_t)(rs >> 4), t = (int32_t)(rs & 15u);
+                            uint32_t r = rs >> 4;
+                            int32_t t = (int32_t)(rs & 15u);
                             if (t) t = b.get(1) ? p1 : m1; // a new coefficient: its size is 1 whatever the symbol says (JWRN_HUFF_BAD_CODE otherwise)
-                            else if (r != 15) {
-                                eobrun = (1u << r) + b.get((uint32_t)r);
+                            else if (r != 15u) {
+                                eobrun = (1u << r) + b.get(r);
                                 break; // the rest of this band is handled as the first block of the run
                             }
-                            do { // pass r still-zero coefficients, correcting the non-zero ones on the way
-                                const uint32_t e = m.tz(k);
-                                const int32_t co = m.get(e);
-                                if (co != 0) {
-                                    if (b.get(1) && (co & p1) == 0) m.set(e, co >= 0 ? co + p1 : co + m1);
-                                } else if (--r < 0)
-                                    break;
-                                k++;
-                            } while (k <= Se);
-                            if (t && k < 64u) m.set(m.tz(k), t);
+                            // pass r still-zero coefficients and stop AT the next one (or behind the band), correcting the non-zero
+                            // ones on the way: the (r + 1)-th zero at or after k
+                            const uint64_t from_k = ~0ull << k;
+                            uint64_t zeros = ~nz & from_k & band;
+                            for (; r && zeros; r--) zeros &= zeros - 1ull;
+                            const uint32_t stop = zeros ? lp_ctz64(zeros) : Se + 1u;
+                            lp_prog_correct(m, b, nz & from_k & (stop >= 64u ? ~0ull : (1ull << stop) - 1ull), p1, m1);
+                            k = stop;
+                            if (t) { // index 64 (band ends at 63 and ran out of zeros) lands on the last coefficient, like jpeg_natural_order[64]
+                                const uint32_t e = k < 64u ? k : 63u;
+                                m.set(e, t);
+                                nz |= 1ull << e;
+                            }
+                            k++;
                         }
                     }
                     if (eobrun > 0) {
-                        for (; k <= Se; k++) {
-                            const uint32_t e = m.tz(k);
-                            const int32_t co = m.get(e);
-                            if (co != 0 && b.get(1) && (co & p1) == 0) m.set(e, co >= 0 ? co + p1 : co + m1);
-                        }
+                        if (k <= Se) lp_prog_correct(m, b, nz & (~0ull << k) & band, p1, m1);
                         eobrun--;
                     }
                     m.close(blk);

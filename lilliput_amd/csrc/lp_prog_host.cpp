@@ -9,6 +9,30 @@
 #include <thread>
 
 #include "lp_prog_core.h"
+#include "lp_huff_core.h" // LP_ZIGZAG_INIT
+
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+// bit k set <=> element k of the block is non-zero
+static inline uint64_t lp_host_nonzero_mask(const int16_t* c)
+{
+#if defined(__SSE2__)
+    const __m128i z = _mm_setzero_si128();
+    uint64_t zero = 0;
+    for (int q = 0; q < 4; q++) {
+        const __m128i a = _mm_cmpeq_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(c + 16 * q)), z);
+        const __m128i b = _mm_cmpeq_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(c + 16 * q + 8)), z);
+        zero |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_packs_epi16(a, b)) << (16 * q);
+    }
+    return ~zero;
+#else
+    uint64_t nz = 0;
+    for (int k = 0; k < 64; k++) nz |= (uint64_t)(c[k] != 0) << k;
+    return nz;
+#endif
+}
 
 namespace {
 struct HostProgMem {
@@ -24,10 +48,13 @@ struct HostProgMem {
     int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
     int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
     uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
-    uint32_t tz(uint32_t k) const { static const uint8_t t[64] = LP_TZIGZAG_INIT; return t[k & 63u]; }
     void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
     int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
-    void open(uint32_t blk) { cur = coef + (size_t)blk * 64; }
+    uint64_t open(uint32_t blk)
+    {
+        cur = coef + (size_t)blk * 64;
+        return lp_host_nonzero_mask(cur);
+    }
     int32_t get(uint32_t e) const { return cur[e]; }
     void set(uint32_t e, int32_t v) { cur[e] = (int16_t)v; }
     void close(uint32_t) {}
@@ -163,7 +190,8 @@ extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len,
     std::vector<LpProgHostTask> tasks;
     for (size_t q = 0; q < h.scans.size(); q++) tasks.push_back(LpProgHostTask{static_cast<const uint8_t*>(data), &h.scans[q], coef.data(), lev[q], &err});
     lp_prog_host_run(tasks, nthreads);
-    for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | ((q & 7) << 3) | ((q >> 3) & 7)] = coef[base + q];
+    static const uint8_t zz[80] = LP_ZIGZAG_INIT;
+    for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | zz[q & 63]] = coef[base + q]; // stored in zigzag order
     *bw = (int)h.j.bw[comp];
     *bh = (int)h.j.bh[comp];
     return err ? -2 : 0;

@@ -46,7 +46,7 @@ struct LpJpeg {
     uint8_t ncomp, hmax, vmax, bpm;
     uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB
     uint8_t orientation;        // EXIF 1..8
-    uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans run through k_prog_scan and coef_off counts
+    uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans are decoded on their own and coef_off counts
                                 // int16 elements in the progressive arena (see LpProgScan)
     uint8_t pad1;
     uint8_t hs[LP_MAX_COMP], vs[LP_MAX_COMP];
@@ -79,7 +79,7 @@ struct LpJpeg {
 // Parallelism comes from the images of a batch and from the scans of an image that touch different (component, band) pairs:
 // the engine sorts the scans into dependency levels and launches one kernel per level (lane = one scan of one image).
 // Coefficients accumulate in an int16 arena: per image, per component, blocks in raster order over the MCU-padded grid,
-// 64 values per block stored TRANSPOSED (element v * 8 + u = row u, column v) like the baseline path hands them to the IDCT.
+// 64 values per block in ZIGZAG order (see lp_prog_core.h: a refinement scan then works on a 64-bit non-zero mask).
 #define LP_MAX_SCANS 64
 struct LpProgHuff {             // the (at most four) Huffman tables one scan uses, slot = position of the component in the scan
     uint16_t lut8[4][256];      // (length << 8) | symbol for codes of up to 8 bits, indexed by the next 8 bits; 0 = longer code

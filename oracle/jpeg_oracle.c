@@ -311,6 +311,8 @@ typedef struct {
     uint64_t acc;
     int nbits;
     int marker; /* pending marker (0 = none) */
+    int pad;    /* how many of the nbits buffered bits are stuffed zeros (they sit at the end) */
+    int insufficient; /* jdhuff.c insufficient_data: a read asked for more bits than the segment holds (JWRN_HIT_MARKER) */
 } lo_bits;
 
 static void fill(lo_bits* b)
@@ -324,15 +326,20 @@ static void fill(lo_bits* b)
                 while (q < b->n && b->d[q] == 0xFF) q++;
                 int c2 = q < b->n ? b->d[q] : 0xD9;
                 if (c2 == 0) { b->pos = q + 1; }
-                else { b->marker = c2; b->pos = q + 1; c = 0; }
+                else { b->marker = c2; b->pos = q + 1; c = 0; b->pad += 8; }
             } else b->pos++;
-        } else c = 0; /* libjpeg feeds zero bits after a marker / EOF */
+        } else { c = 0; b->pad += 8; } /* libjpeg feeds zero bits after a marker / EOF */
         b->acc |= (uint64_t)c << (56 - b->nbits);
         b->nbits += 8;
     }
 }
 static inline int peek(lo_bits* b, int k) { return (int)(b->acc >> (64 - k)); }
-static inline void skip(lo_bits* b, int k) { b->acc <<= k; b->nbits -= k; }
+static inline void skip(lo_bits* b, int k)
+{
+    b->acc <<= k;
+    b->nbits -= k;
+    if (b->nbits < b->pad) { b->insufficient = 1; b->pad = b->nbits; } /* the read went into the stuffed zeros */
+}
 static inline int getbits(lo_bits* b, int k)
 {
     if (!k) return 0;
@@ -351,8 +358,8 @@ static int decode_sym(lo_bits* b, const lo_htab* t)
             return t->vals[t->valptr[l] + code - t->mincode[l]];
         }
     }
-    skip(b, 16);
-    return 0; /* corrupt */
+    skip(b, 17); /* jpeg_huff_decode walks on to the sentinel length 17 before it gives up (JWRN_HUFF_BAD_CODE) and fakes a zero */
+    return 0;
 }
 static inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
@@ -361,6 +368,8 @@ typedef struct {
     int bw[4], bh[4];      /* blocks per row/col (MCU padded) */
     int16_t* coef[4];      /* [bh][bw][64] natural order, DC absolute */
     uint8_t* plane[4];     /* [bh*8][bw*8] */
+    uint16_t latched_qt[4][64]; /* progressive: the table each component had at its first scan (jdinput.c latch_quant_tables) */
+    int have_latched_qt;
 } lo_dec;
 
 static void dec_free(lo_dec* D)
@@ -389,11 +398,14 @@ static void prog_restart(lo_bits* b) /* process_restart: drop the partial byte, 
 {
     b->acc = 0;
     b->nbits = 0;
+    b->pad = 0;
+    int found = b->marker >= 0xD0 && b->marker <= 0xD7;
     if (!b->marker) {
         while (b->pos + 1 < b->n && !(b->d[b->pos] == 0xFF && b->d[b->pos + 1] >= 0xD0 && b->d[b->pos + 1] <= 0xD7)) b->pos++;
-        if (b->pos + 1 < b->n) b->pos += 2;
+        if (b->pos + 1 < b->n) { b->pos += 2; found = 1; }
     }
-    b->marker = 0;
+    /* "Reset out-of-data flag, unless read_restart_marker left us smack up against end of data" */
+    if (found) { b->insufficient = 0; b->marker = 0; }
 }
 
 static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
@@ -408,6 +420,11 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
         memcpy(bits[1][t], std_bits[2 * t + 1], 17); memset(vals[1][t], 0, 256); memcpy(vals[1][t], t ? std_ac_chroma_vals : std_ac_luma_vals, 162);
     }
     int dri = 0;
+    uint16_t cur_qt[4][64];
+    int cur_qt_present[4] = {0, 0, 0, 0}, latched[4] = {0, 0, 0, 0}, seen_sof = 0;
+    memset(cur_qt, 0, sizeof(cur_qt));
+    memset(D->latched_qt, 0, sizeof(D->latched_qt));
+    D->have_latched_qt = 1;
     int wib[4], hib[4]; /* blocks a non-interleaved scan walks: the image's own, not the MCU padding */
     for (int c = 0; c < in->ncomp; c++) {
         D->bw[c] = in->mcus_x * in->hs[c];
@@ -430,9 +447,16 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
         }
         if (m == 0xD9) return scans ? LO_OK : LO_ERR_FORMAT;
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD8) return LO_ERR_FORMAT; /* JERR_SOI_DUPLICATE */
+        /* the same jdmarker.c read_markers rules as the header walk: unknown markers, a second SOF, DAC contents */
+        int skippable = (m >= 0xE0 && m <= 0xEF) || m == 0xFE || m == 0xDC;
+        int sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
+        if (sof && seen_sof++) return LO_ERR_FORMAT; /* JERR_SOF_DUPLICATE (the walk starts over at the top of the file: the first one is the frame header) */
+        if (!(skippable || sof || m == 0xC4 || m == 0xCC || m == 0xDA || m == 0xDB || m == 0xDD)) return LO_ERR_FORMAT; /* JERR_UNKNOWN_MARKER */
         if (i + 2 > n) return scans ? LO_OK : LO_ERR_FORMAT;
         int L = rd16(d + i);
-        if (L < 2 || i + (size_t)L > n) return LO_ERR_FORMAT;
+        if (L < 2) { if (skippable) { i += 2; continue; } return LO_ERR_FORMAT; }
+        if (i + (size_t)L > n) return LO_ERR_FORMAT;
         const uint8_t* p = d + i + 2;
         int pl = L - 2;
         size_t seg_end = i + (size_t)L;
@@ -440,30 +464,60 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
             int k = 0;
             while (pl - k > 16) {
                 int tc = p[k] >> 4, th = p[k] & 15, tot = 0;
+                uint8_t nb[17];
                 k++;
-                if (tc > 1 || th > 3) return LO_ERR_FORMAT;
-                bits[tc][th][0] = 0;
-                for (int b = 1; b <= 16; b++) { bits[tc][th][b] = p[k++]; tot += bits[tc][th][b]; }
+                nb[0] = 0;
+                for (int b = 1; b <= 16; b++) { nb[b] = p[k++]; tot += nb[b]; }
                 if (tot > 256 || tot > pl - k) return LO_ERR_FORMAT;
+                if (tc > 1 || th > 3) return LO_ERR_FORMAT;
+                memcpy(bits[tc][th], nb, 17);
                 memset(vals[tc][th], 0, 256);
                 memcpy(vals[tc][th], p + k, tot);
                 k += tot;
                 present[tc][th] = 1;
             }
             if (k != pl) return LO_ERR_FORMAT;
+        } else if (m == 0xDB) { /* get_dqt: checked; a component keeps the table it had at its first scan (latch_quant_tables) */
+            int k = 0;
+            while (k < pl) {
+                int pq = p[k] >> 4, tq = p[k] & 15;
+                k++;
+                if (tq > 3 || k + (pq ? 128 : 64) > pl) return LO_ERR_FORMAT;
+                for (int z = 0; z < 64; z++) {
+                    int v;
+                    if (pq) { v = rd16(p + k); k += 2; } else v = p[k++];
+                    cur_qt[tq][lo_zigzag[z]] = (uint16_t)v;
+                }
+                cur_qt_present[tq] = 1;
+            }
+        } else if (m == 0xCC) {
+            if (pl & 1) return LO_ERR_FORMAT;
+            for (int k = 0; k < pl; k += 2) {
+                if (p[k] >= 32) return LO_ERR_FORMAT;
+                if (p[k] < 16 && (p[k + 1] & 15) > (p[k + 1] >> 4)) return LO_ERR_FORMAT;
+            }
         } else if (m == 0xDD) {
             if (L != 4) return LO_ERR_FORMAT;
             dri = rd16(p);
         } else if (m == 0xDA) {
+            if (pl < 1) return LO_ERR_FORMAT;
             int ns = p[0];
             if (L != ns * 2 + 6 || ns < 1 || ns > 4) return LO_ERR_FORMAT;
-            int sc[4], std_[4], sta[4];
+            int sc[4], std_[4], sta[4], cur[4] = {-1, -1, -1, -1};
             for (int s = 0; s < ns; s++) {
                 int cs = p[1 + 2 * s], c;
-                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs) break;
+                for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs && cur[c] < 0) break; /* libjpeg-turbo's slot rule */
                 if (c == in->ncomp) return LO_ERR_FORMAT;
-                sc[s] = c; std_[s] = p[2 + 2 * s] >> 4; sta[s] = p[2 + 2 * s] & 15;
-                if (std_[s] > 3 || sta[s] > 3) return LO_ERR_FORMAT;
+                cur[s] = c;
+                for (int q = 0; q < s; q++) if (cur[q] == c) return LO_ERR_FORMAT;
+                sc[s] = c; std_[s] = p[2 + 2 * s] >> 4; sta[s] = p[2 + 2 * s] & 15; /* only the table the scan builds is range-checked */
+            }
+            for (int s = 0; s < ns; s++) { /* jdinput.c latch_quant_tables */
+                int c = sc[s];
+                if (latched[c]) continue;
+                if (in->tq[c] > 3 || !cur_qt_present[in->tq[c]]) return LO_ERR_FORMAT; /* JERR_NO_QUANT_TABLE */
+                memcpy(D->latched_qt[c], cur_qt[in->tq[c]], sizeof(D->latched_qt[c]));
+                latched[c] = 1;
             }
             int Ss = p[1 + 2 * ns], Se = p[2 + 2 * ns], Ah = p[3 + 2 * ns] >> 4, Al = p[3 + 2 * ns] & 15;
             /* jdphuff.c start_pass_phuff_decoder: validate the progression parameters */
@@ -477,11 +531,13 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
             for (int s = 0; s < ns; s++) {
                 int cls = Ss == 0 ? 0 : 1, id = Ss == 0 ? std_[s] : sta[s];
                 if (Ss == 0 && Ah != 0) continue; /* DC refinement reads raw bits */
-                if (id > 1 && !present[cls][id]) return LO_ERR_FORMAT; /* JERR_NO_HUFF_TABLE */
+                /* JERR_NO_HUFF_TABLE. No Annex-K fallback here: std_huff_tables() is called by jinit_huff_decoder only, a progressive
+                   file has to define what it uses */
+                if (id > 3 || !present[cls][id]) return LO_ERR_FORMAT;
                 if (!huff_ok(bits[cls][id], vals[cls][id], cls == 0)) return LO_ERR_FORMAT;
                 build_htab(&tab[s], bits[cls][id], vals[cls][id]);
             }
-            lo_bits b = {d, n, seg_end, 0, 0, 0};
+            lo_bits b = {d, n, seg_end, 0, 0, 0, 0, 0};
             int pred[4] = {0, 0, 0, 0}, eobrun = 0, rst_left = dri;
             const int p1 = 1 << Al, m1 = -(1 << Al);
             int mcux, mcuy;
@@ -490,7 +546,9 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
             for (int mi = 0; mi < mcux * mcuy; mi++) {
                 if (dri && rst_left == 0) { prog_restart(&b); pred[0] = pred[1] = pred[2] = pred[3] = 0; eobrun = 0; rst_left = dri; }
                 int mx = mi % mcux, my = mi / mcux;
-                for (int s = 0; s < ns; s++) {
+                /* "If we've run out of data, don't modify the MCU" -- every scan type but the DC refinement checks this */
+                const int skip_mcu = b.insufficient && !(Ss == 0 && Ah != 0);
+                for (int s = 0; s < ns && !skip_mcu; s++) {
                     int c = sc[s];
                     int nh = ns == 1 ? 1 : in->hs[c], nv = ns == 1 ? 1 : in->vs[c];
                     for (int v = 0; v < nv; v++)
@@ -514,7 +572,7 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                                         k += r;
                                         fill(&b);
                                         int val = extend(getbits(&b, t), t);
-                                        if (k < 64) blk[lo_zigzag[k]] = (int16_t)(val * (1 << Al));
+                                        blk[lo_zigzag[k < 64 ? k : 63]] = (int16_t)(val * (1 << Al)); /* jpeg_natural_order[64..79] = 63 */
                                     } else if (r == 15) k += 15;
                                     else {
                                         eobrun = 1 << r;
@@ -544,7 +602,7 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                                             } else if (--r < 0) break;
                                             k++;
                                         } while (k <= Se);
-                                        if (t && k < 64) blk[lo_zigzag[k]] = (int16_t)t;
+                                        if (t) blk[lo_zigzag[k < 64 ? k : 63]] = (int16_t)t;
                                     }
                                 }
                                 if (eobrun > 0) {
@@ -592,7 +650,7 @@ static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
         D->coef[c] = (int16_t*)calloc((size_t)D->bw[c] * D->bh[c] * 64, sizeof(int16_t));
         if (!D->coef[c]) return LO_ERR_BUF;
     }
-    lo_bits b = {d, n, in->ecs_off, 0, 0, 0};
+    lo_bits b = {d, n, in->ecs_off, 0, 0, 0, 0, 0};
     int pred[4] = {0, 0, 0, 0};
     int nmcu = in->mcus_x * in->mcus_y;
     int rst_left = in->dri;
@@ -685,7 +743,7 @@ static int decode_planes(const uint8_t* d, size_t n, lo_dec* D)
         if (!D->plane[c]) return LO_ERR_BUF;
         for (int by = 0; by < D->bh[c]; by++)
             for (int bx = 0; bx < D->bw[c]; bx++)
-                lo_idct_islow(D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64, in->qt[in->tq[c]],
+                lo_idct_islow(D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64, D->have_latched_qt ? D->latched_qt[c] : in->qt[in->tq[c]],
                               D->plane[c] + (size_t)by * 8 * pw + bx * 8, pw);
     }
     return LO_OK;

@@ -186,10 +186,15 @@ struct HostProgMem {
     int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
     int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
     uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
-    uint32_t tz(uint32_t k) const { static const uint8_t t[64] = LP_TZIGZAG_INIT; return t[k]; }
     void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
     int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
-    void open(uint32_t blk) { cur = coef + (size_t)blk * 64; }
+    uint64_t open(uint32_t blk)
+    {
+        cur = coef + (size_t)blk * 64;
+        uint64_t nz = 0;
+        for (int k = 0; k < 64; k++) nz |= (uint64_t)(cur[k] != 0) << k;
+        return nz;
+    }
     int32_t get(uint32_t e) const { return cur[e]; }
     void set(uint32_t e, int32_t v) { cur[e] = (int16_t)v; }
     void close(uint32_t) {}
@@ -234,7 +239,8 @@ extern "C" int emu_decode_coefs_progressive(const uint8_t* data, size_t len, int
     if (ne > cap_elems) return -3;
     size_t base = 0;
     for (int c = 0; c < comp; c++) base += (size_t)img.bw[c] * img.bh[c];
+    static const uint8_t zz[80] = LP_ZIGZAG_INIT;
     for (size_t q = 0; q < (size_t)img.bw[comp] * img.bh[comp]; q++)
-        for (int e = 0; e < 64; e++) out[q * 64 + (((e & 7) << 3) | (e >> 3))] = coef[(base + q) * 64 + e]; // stored transposed
+        for (int e = 0; e < 64; e++) out[q * 64 + zz[e]] = coef[(base + q) * 64 + e]; // stored in zigzag order
     return 0;
 }

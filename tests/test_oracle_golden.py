@@ -131,3 +131,41 @@ def test_restatement_vs_reference_library_on_generated_files(oracle):
         q = int(rng.choice([1, 10, 50, 85, 100]))
         src = px[:, :, 0] if cn == 1 else px
         assert oracle.jpeg_encode(src, q) == oracle.ref_jpeg_encode(src, q), (px.shape, q)
+
+
+def test_restatement_vs_reference_library_on_damaged_progressive_files(oracle):
+    """Bit-flipped progressive files (entropy data, scan headers, the tables between scans): the oracle accepts and rejects exactly
+    what the reference's libjpeg-turbo does and decodes the same coefficients -- the end of a scan's data (insufficient_data), codes
+    that match no table entry (17 bits, a zero symbol), coefficient indices past 63, missing tables (no Annex-K fallback in
+    jdphuff.c), duplicate SOI / SOF, DAC contents. Pixels are compared where the coefficients stay in range: libjpeg's SIMD IDCT
+    wraps 16-bit products of absurd coefficients and smooths blocks of a file that lost a scan; neither is restated."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built (needs /root/reference)")
+    import test_progressive as TP
+
+    rng = np.random.default_rng(3)
+    n_ok = n_err = n_px = 0
+    for i, desc, data in TP._cases(17, 30, lo=16, hi=120):
+        sos = data.index(b"\xff\xda")
+        for k in range(20):
+            d = bytearray(data)
+            d[int(rng.integers(sos - 30, len(d) - 2))] ^= 1 << int(rng.integers(0, 8))
+            d = bytes(d)
+            try:
+                mine = [oracle.jpeg_decode_coefs(d, c) for c in range(1 if desc[2] else 3)]
+            except Exception:
+                mine = None
+            try:
+                ref = [oracle.ref_jpeg_decode_coefs(d, c) for c in range(1 if desc[2] else 3)]
+            except Exception:
+                ref = None
+            assert (mine is None) == (ref is None), (i, k, desc)
+            if mine is None:
+                n_err += 1
+                continue
+            n_ok += 1
+            assert all(np.array_equal(a, b) for a, b in zip(mine, ref)), (i, k, desc)
+            if max(int(np.abs(a).max()) for a in mine) < 1024:
+                a, b = oracle.jpeg_decode(d), oracle.ref_jpeg_decode(d)
+                n_px += int(np.array_equal(a, b))
+    assert n_ok > 300 and n_err > 20 and n_px > 0.97 * n_ok, (n_ok, n_err, n_px)

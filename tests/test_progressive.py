@@ -99,6 +99,39 @@ def test_host_entropy_threads_reproduce_oracle_coefficients(hip_lib, oracle):
             assert np.array_equal(_host_coefs(hip_lib, data, c), oracle.jpeg_decode_coefs(data, c)), (i, desc, c)
 
 
+def test_damaged_files_same_verdict_and_coefficients_as_the_oracle(hip_lib, oracle):
+    """Bit flips in the entropy data, the scan headers and the tables between scans: the product's parser accepts and rejects what
+    the oracle does (which is pinned against libjpeg on the same kind of files in tests/test_oracle_golden.py), and the host-side
+    scan decoder yields the oracle's coefficients -- end-of-data handling, bad codes, out-of-range indices included."""
+    rng = np.random.default_rng(3)
+    n_ok = n_err = 0
+    for i, desc, data in _cases(17, 30, lo=16, hi=120):
+        sos = data.index(b"\xff\xda")
+        for k in range(20):
+            d = bytearray(data)
+            d[int(rng.integers(sos - 30, len(d) - 2))] ^= 1 << int(rng.integers(0, 8))
+            d = bytes(d)
+            a = np.frombuffer(d, np.uint8)
+            out = np.zeros(1 << 20, np.int16)
+            bw, bh = C.c_int(), C.c_int()
+            try:
+                exp = [oracle.jpeg_decode_coefs(d, c) for c in range(1 if desc[2] else 3)]
+            except Exception:
+                exp = None
+            for c in range(1 if desc[2] else 3):
+                rc = hip_lib.lilliput_hip_progressive_coefs_host(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_int(c), out.ctypes.data_as(C.c_void_p),
+                                                                 C.c_size_t(out.size), C.byref(bw), C.byref(bh), C.c_int(1))
+                if rc == -2:  # more restart markers than the scan has room for: the product refuses (documented difference)
+                    continue
+                assert (rc != 0) == (exp is None), (i, k, desc, rc)
+                if exp is not None:
+                    got = out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64)
+                    assert np.array_equal(got, exp[c]), (i, k, desc, c)
+            n_ok += exp is not None
+            n_err += exp is None
+    assert n_ok > 300 and n_err > 20, (n_ok, n_err)
+
+
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(params=["host-entropy", "device-entropy"])
 def mode(request, hip_lib):
@@ -189,27 +222,42 @@ def test_progressive_large_image(batch, oracle):
 
 
 @pytest.mark.gpu
-def test_progressive_truncated_and_corrupt_never_hang(batch, mode):
-    """Cut and bit-flipped progressive files: an error or an image, the same one every time, never a hang."""
-    _, _, data = next(_cases(8, 1, lo=100, hi=200))
-    rng = np.random.default_rng(0)
+def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
+    """Bit-flipped progressive files through the device path: the oracle's verdict (error or image) and, where the coefficients stay
+    in the range a real image can have, the oracle's pixels; always the same answer twice. (Absurd coefficients overflow libjpeg's
+    16-bit SIMD IDCT in ways neither the oracle nor the device restates.)"""
     import lilliput_amd
 
-    for k in range(40):
-        d = bytearray(data)
-        if k % 2:
-            d = d[: int(rng.integers(200, len(d)))]
-        else:
-            for _ in range(3):
-                d[int(rng.integers(len(d) // 3, len(d)))] ^= 1 << int(rng.integers(0, 8))
-        outs = []
-        for _ in range(2):
+    rng = np.random.default_rng(0)
+    n_img = n_err = 0
+    for i, desc, data in _cases(8, 10, lo=40, hi=200):
+        sos = data.index(b"\xff\xda")
+        for k in range(12):
+            d = bytearray(data)
+            for _ in range(1 + k % 3):
+                d[int(rng.integers(sos - 30, len(d) - 2))] ^= 1 << int(rng.integers(0, 8))
+            d = bytes(d)
+            outs = []
+            for _ in range(2):
+                try:
+                    outs.append(batch.decode_jpeg(d)[0])
+                except lilliput_amd.LilliputError as e:
+                    outs.append(e.code)
+            assert type(outs[0]) is type(outs[1]) and np.array_equal(outs[0], outs[1]), (i, k)
             try:
-                px, _o = batch.decode_jpeg(bytes(d))
-                outs.append(px.tobytes())
-            except lilliput_amd.LilliputError as e:
-                outs.append(e.code)
-        assert outs[0] == outs[1], k
+                exp = oracle.jpeg_decode(d)
+            except Exception:
+                exp = None
+            if isinstance(outs[0], int) and outs[0] == 2 and exp is not None:
+                continue  # restart-marker overflow: the product refuses what libjpeg tolerates (documented)
+            assert isinstance(outs[0], int) == (exp is None), (i, k, desc, outs[0] if isinstance(outs[0], int) else "image")
+            if exp is None:
+                n_err += 1
+                continue
+            n_img += 1
+            if max(int(np.abs(oracle.jpeg_decode_coefs(d, c)).max()) for c in range(1 if desc[2] else 3)) < 1024:
+                assert np.array_equal(outs[0], exp), (i, k, desc)
+    assert n_img > 50 and n_err > 3, (n_img, n_err)
 
 
 @pytest.mark.gpu
