@@ -278,6 +278,10 @@ void lilliput_hip_set_progressive_entropy(int on_device);
 /* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
  * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
  * -3 = dst too small. nthreads 0 = default. */
+/* Test access (no device work): the progressive JPEG writer behind opencv_encoder_write(..., CV_IMWRITE_JPEG_PROGRESSIVE, 1) on
+ * quantised coefficients in the encoder's own layout (MCU order -- 4:2:0: Y00 Y01 Y10 Y11 Cb Cr --, 64 zigzag-order values per block,
+ * dummy blocks included). Returns the byte count, 0 on failure, or minus the count needed when cap is too small. */
+long lilliput_hip_progressive_encode_coefs(int width, int height, int ncomp, int quality, const int16_t* coef, uint8_t* out, size_t cap);
 int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads);
 
 /* ------------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     Decoder,
     ImageOps,
     ImageOptions,
+    JpegProgressive,
     JpegQuality,
     LilliputError,
     ImageOpsFit,

@@ -575,13 +575,10 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
     auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     if (!e || !s || s->rows <= 0 || s->cols <= 0) return false;
     int quality = 95; // cv::JpegEncoder default
+    bool progressive = false;
     for (size_t i = 0; i + 1 < opt_len; i += 2) {
         if (opt[i] == CV_IMWRITE_JPEG_QUALITY) quality = opt[i + 1] < 0 ? 0 : opt[i + 1] > 100 ? 100 : opt[i + 1];
-        else if (opt[i] == CV_IMWRITE_JPEG_PROGRESSIVE && opt[i + 1]) {
-            lp_set_error("progressive JPEG output is outside the device path");
-            fprintf(stderr, "lilliput_hip: %s\n", g_last_error.c_str());
-            return false;
-        }
+        else if (opt[i] == CV_IMWRITE_JPEG_PROGRESSIVE) progressive = opt[i + 1] != 0; // cv::JpegEncoder: jpeg_simple_progression
     }
     LpEngine* eng = lp_thread_engine();
     if (!eng || !lp_mat_to_device(s, eng)) return false;
@@ -593,14 +590,23 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
     rq.out_cap = (size_t)s->rows * s->cols * 4 + 4096; // device-side bound; the caller's capacity is checked below
     int st = 0;
     uint32_t len = 0;
-    if (eng->encode_jpegs(&rq, 1, &st, &len) || st || !len) return false;
+    std::vector<uint8_t> prog;
+    if (progressive) {
+        if (eng->encode_jpeg_progressive(rq, prog) || prog.empty()) return false;
+        len = (uint32_t)prog.size();
+    } else if (eng->encode_jpegs(&rq, 1, &st, &len) || st || !len)
+        return false;
     if (len <= cap && d->datastart) {
-        if (eng->encoded_copy(0, d->datastart, cap)) return false;
+        if (progressive) memcpy(d->datastart, prog.data(), len);
+        else if (eng->encoded_copy(0, d->datastart, cap)) return false;
         d->data = d->datastart;
     } else {
         // cv::imencode into a too-small Mat reallocates: the data pointer changes and Go reports ErrBufTooSmall (opencv.go:890-895)
-        d->own.assign(len, 0);
-        if (eng->encoded_copy(0, d->own.data(), len)) return false;
+        if (progressive) d->own = prog;
+        else {
+            d->own.assign(len, 0);
+            if (eng->encoded_copy(0, d->own.data(), len)) return false;
+        }
         d->data = d->datastart = d->own.data();
         d->datalimit = d->data + len;
     }

@@ -13,6 +13,7 @@
 
 #include "lp_huff_core.h"
 #include "lp_launch.h"
+#include "lp_jpeg_progenc.h"
 #include "lp_prog_host.h"
 
 void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
@@ -940,6 +941,11 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
     if (!hdrs.empty() && !check(hipMemcpyAsync(d_hdrs_.p, hdrs.data(), hdrs.size(), hipMemcpyHostToDevice, stream_), "H2D hdrs")) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(d_bits_.p, 0, bits_words * 4 + 64, stream_), "memset bits")) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(d_estates_.p, 0, sizeof(LpEncState) * (size_t)n, stream_), "memset enc states")) return LP_ERR_DEVICE;
+    if (enc_fdct_only_) { // progressive output: the entropy coding happens on the host
+        lp_launch_enc_fdct(stream_, d_jobs_.as<LpEncJob>(), (uint32_t)n, max_blocks, d_ecoef_.as<int16_t>());
+        if (!check(hipStreamSynchronize(stream_), "fdct sync")) return LP_ERR_DEVICE;
+        return check(hipGetLastError(), "fdct kernel") ? LP_OK : LP_ERR_DEVICE;
+    }
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
     lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
                      d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
@@ -957,6 +963,24 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         out_len[i] = st.out_len;
     }
     return rc;
+}
+
+int LpEngine::encode_jpeg_progressive(const LpEncodeReq& req, std::vector<uint8_t>& out)
+{
+    int st = 0;
+    uint32_t len = 0;
+    enc_fdct_only_ = true;
+    const int rc = encode_jpegs(&req, 1, &st, &len);
+    enc_fdct_only_ = false;
+    if (rc) return rc;
+    if (st) return st;
+    const LpEncJob& j = h_jobs_[0];
+    std::vector<int16_t> coef((size_t)j.total_blocks * 64);
+    if (!check(hipMemcpyAsync(coef.data(), d_ecoef_.as<int16_t>() + j.coef_off, coef.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H coefficients")) return LP_ERR_DEVICE;
+    const int src = sync();
+    if (src) return src;
+    if (!lp_jpeg_encode_progressive((int)j.src.w, (int)j.src.h, (int)j.ncomp, req.quality, coef.data(), out)) { err_ = "coefficient out of range"; return LP_ERR_INVALID_IMAGE; }
+    return LP_OK;
 }
 
 const uint8_t* LpEngine::encoded_device_ptr(int i) const { return d_out_.as<uint8_t>() + h_jobs_[(size_t)i].out_off; }

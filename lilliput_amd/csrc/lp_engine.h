@@ -106,6 +106,8 @@ public:
     int resize(const LpResizeReq* reqs, int n, LpFrame* dsts /* off preset */, int* status);
     // Encodes into the engine's output arena; results are fetched with encoded_copy().
     int encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t* out_len);
+    // Progressive (SOF2) output of one frame: FDCT + quantisation on the device, multi-scan entropy coding on the host (lp_jpeg_progenc.h).
+    int encode_jpeg_progressive(const LpEncodeReq& req, std::vector<uint8_t>& out);
     int encoded_copy(int i, uint8_t* dst, size_t cap);   // D2H of job i's bytes (after encode_jpegs)
     const uint8_t* encoded_device_ptr(int i) const;
     int encoded_fetch_all();                              // D2H of every job's bytes into pinned memory (one sync)
@@ -175,6 +177,7 @@ private:
     LpDevBuf d_jobs_, d_estates_, d_ecoef_, d_blkbits_, d_bits_, d_hdrs_, d_out_, d_packed_, d_pkoff_;
     std::vector<LpEncState> h_estates_;
     bool enc_tables_ready_ = false;
+    bool enc_fdct_only_ = false;
 };
 
 // JFIF header (SOI..SOS) + quantisation tables exactly as cv::JpegEncoder/libjpeg-turbo write them.

@@ -373,6 +373,12 @@ void lp_launch_enc_pack(hipStream_t s, const LpEncJob* d_jobs, const LpEncState*
     hipLaunchKernelGGL(k_enc_pack, dim3(nimg), dim3(256), 0, s, d_jobs, d_states, d_pk_off, d_out, d_packed);
 }
 
+void lp_launch_enc_fdct(hipStream_t s, const LpEncJob* d_jobs, uint32_t nimg, uint32_t max_blocks, int16_t* d_coef)
+{
+    if (!nimg || !max_blocks) return;
+    hipLaunchKernelGGL(k_enc_fdct, dim3((max_blocks + 31) / 32, nimg), dim3(256), 0, s, d_jobs, (const uint8_t*)nullptr, d_coef);
+}
+
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out)
 {

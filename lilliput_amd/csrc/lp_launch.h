@@ -56,5 +56,7 @@ void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d
 // encode
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,
                       int16_t* d_coef, uint32_t* d_blk_bits, uint32_t* d_bits, const uint8_t* d_hdrs, uint8_t* d_out);
+// colour conversion + downsampling + FDCT + quantisation only (the coefficients go to the host for progressive output)
+void lp_launch_enc_fdct(hipStream_t s, const LpEncJob* d_jobs, uint32_t nimg, uint32_t max_blocks, int16_t* d_coef);
 void lp_launch_enc_pack(hipStream_t s, const LpEncJob* d_jobs, const LpEncState* d_states, uint32_t nimg, const uint32_t* d_pk_off, const uint8_t* d_out,
                         uint8_t* d_packed);
