@@ -14,6 +14,7 @@ from .binding import (  # noqa: F401
     ImageOptions,
     JpegProgressive,
     JpegQuality,
+    PngCompression,
     LilliputError,
     ImageOpsFit,
     ImageOpsNoResize,

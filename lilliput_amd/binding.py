@@ -25,6 +25,7 @@ ERR_NAMES = {
 ImageOpsNoResize, ImageOpsFit, ImageOpsResize = 0, 1, 2  # ops.go:18-22
 JpegQuality = 1  # opencv.go:44 (CV_IMWRITE_JPEG_QUALITY)
 JpegProgressive = 2
+PngCompression = 16  # opencv.go:45 (CV_IMWRITE_PNG_COMPRESSION)
 
 
 class LilliputError(RuntimeError):

@@ -44,6 +44,7 @@ struct LpDecoder {
 
 struct LpEncoder {
     LpMat* dst = nullptr;
+    bool png = false; // ".png": cv::PngEncoder semantics, else cv::JpegEncoder
 };
 
 LpEngine* lp_thread_engine();

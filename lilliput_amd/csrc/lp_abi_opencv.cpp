@@ -14,6 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <zlib.h>
+
+#include <algorithm>
 #include <mutex>
 
 extern "C" {
@@ -201,6 +204,87 @@ static bool mat_reshape(LpMat* m, int rows, int cols, int type)
     m->data = m->datastart = m->own.data();
     m->datalimit = m->data + need;
     m->rows = rows; m->cols = cols; m->type = type; m->step = (size_t)cols * cv_elem_size(type);
+    return true;
+}
+
+// ---- PNG output: cv::PngEncoder::write (OpenCV 4.11 grfmt_png.cpp; source not in the reference tree) over libpng 1.6.47.
+// Without IMWRITE_PNG_COMPRESSION in the options OpenCV asks for the SUB filter only, Z_BEST_SPEED and Z_RLE; with it, for libpng's
+// adaptive filtering at that level with the default strategy. Filter choice and filtering run on the device (k_png_filter, the
+// inflated stream equals libpng's byte for byte -- tests/test_png_output.py); deflate runs on the host like inflate does for PNG
+// sources. The reference links zlib-ng, this library the system zlib: the compressed bytes differ, the pixels and the rows do not.
+static void png_put_chunk(std::vector<uint8_t>& o, const char* type, const uint8_t* data, size_t n)
+{
+    const uint8_t len[4] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n};
+    o.insert(o.end(), len, len + 4);
+    const size_t at = o.size();
+    o.insert(o.end(), type, type + 4);
+    if (n) o.insert(o.end(), data, data + n);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), o.data() + at, (uInt)(n + 4));
+    const uint8_t c[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+    o.insert(o.end(), c, c + 4);
+}
+
+static bool lp_png_encoder_write(LpEncoder* e, LpMat* s, const int* opt, size_t opt_len)
+{
+    const int cn = opencv_type_channels(s->type);
+    if (opencv_type_depth(s->type) != 8 || (cn != 1 && cn != 3 && cn != 4)) return false;
+    int level = -1, strategy = 3; // IMWRITE_PNG_STRATEGY_RLE
+    for (size_t i = 0; i + 1 < opt_len; i += 2)
+        if (opt[i] == CV_IMWRITE_PNG_COMPRESSION) {
+            strategy = 0; // IMWRITE_PNG_STRATEGY_DEFAULT
+            level = opt[i + 1] < 0 ? 0 : opt[i + 1] > 9 ? 9 : opt[i + 1];
+        }
+    // png_set_filter(SUB) or libpng's default for 8-bit non-palette images (all five), pruned by png_write_start_row
+    uint32_t filters = level < 0 ? 0x02u : 0x1fu;
+    if (s->rows == 1) filters &= ~0x1cu; // no UP / AVG / PAETH on a single row
+    if (s->cols == 1) filters &= ~0x1au; // no SUB / AVG / PAETH on a single column
+    if (!filters) filters = 0x01u;
+    LpEngine* eng = lp_thread_engine();
+    if (!eng || !lp_mat_to_device(s, eng)) return false;
+    const size_t row = (size_t)s->cols * cn + 1, raw_len = row * (size_t)s->rows;
+    std::vector<uint8_t> raw(raw_len);
+    if (eng->png_filter(lp_mat_frame(s), filters, raw.data())) return false;
+    // png_deflate_claim: a window no larger than the data needs
+    int window_bits = 15;
+    if (raw_len <= 16384) {
+        unsigned half = 1u << (window_bits - 1);
+        while (raw_len + 262 <= half) { half >>= 1; --window_bits; }
+    }
+    if (window_bits < 9) window_bits = 9; // zlib's own lower bound for deflate
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (deflateInit2(&z, level < 0 ? 1 : level, Z_DEFLATED, window_bits, 8, strategy) != Z_OK) return false;
+    std::vector<uint8_t> comp(deflateBound(&z, (uLong)raw_len) + 64);
+    z.next_in = raw.data();
+    z.avail_in = (uInt)raw_len;
+    z.next_out = comp.data();
+    z.avail_out = (uInt)comp.size();
+    const int zr = deflate(&z, Z_FINISH);
+    const size_t clen = comp.size() - z.avail_out;
+    deflateEnd(&z);
+    if (zr != Z_STREAM_END) return false;
+    std::vector<uint8_t> out;
+    out.reserve(clen + 128);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    out.insert(out.end(), sig, sig + 8);
+    const uint32_t W = (uint32_t)s->cols, H = (uint32_t)s->rows;
+    const uint8_t ihdr[13] = {(uint8_t)(W >> 24), (uint8_t)(W >> 16), (uint8_t)(W >> 8), (uint8_t)W, (uint8_t)(H >> 24), (uint8_t)(H >> 16), (uint8_t)(H >> 8), (uint8_t)H,
+                              8, (uint8_t)(cn == 1 ? 0 : cn == 3 ? 2 : 6), 0, 0, 0};
+    png_put_chunk(out, "IHDR", ihdr, 13);
+    for (size_t at = 0; at < clen; at += 8192) png_put_chunk(out, "IDAT", comp.data() + at, std::min<size_t>(8192, clen - at)); // libpng's zbuffer size
+    png_put_chunk(out, "IEND", nullptr, 0);
+    LpMat* d = e->dst;
+    const size_t cap = (size_t)(d->datalimit - d->datastart), len = out.size();
+    if (len <= cap && d->datastart) {
+        memcpy(d->datastart, out.data(), len);
+        d->data = d->datastart;
+    } else { // cv::imencode into a too-small Mat reallocates (opencv.go:890-895 -> ErrBufTooSmall)
+        d->own = out;
+        d->data = d->datastart = d->own.data();
+        d->datalimit = d->data + len;
+    }
+    d->rows = (int)len; d->cols = 1; d->type = CV_8U; d->step = 1;
+    d->dev_valid = false;
     return true;
 }
 
@@ -561,9 +645,11 @@ opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst)
     if (!ext || !dst) return NULL;
     std::string e(ext);
     for (auto& c : e) c = (char)tolower(c);
-    if (e != ".jpeg" && e != ".jpg" && e != ".jpe") return NULL;
+    const bool png = e == ".png";
+    if (!png && e != ".jpeg" && e != ".jpg" && e != ".jpe") return NULL;
     auto enc = new LpEncoder();
     enc->dst = static_cast<LpMat*>(dst);
+    enc->png = png;
     return enc;
 }
 
@@ -574,6 +660,7 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
     auto e = static_cast<LpEncoder*>(ee);
     auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     if (!e || !s || s->rows <= 0 || s->cols <= 0) return false;
+    if (e->png) return lp_png_encoder_write(e, s, opt, opt_len);
     int quality = 95; // cv::JpegEncoder default
     bool progressive = false;
     for (size_t i = 0; i + 1 < opt_len; i += 2) {
@@ -616,3 +703,4 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
 }
 
 } // extern "C"
+

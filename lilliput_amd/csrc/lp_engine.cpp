@@ -792,6 +792,23 @@ int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const ui
     return LP_OK;
 }
 
+int LpEngine::png_filter(const LpFrame& src, uint32_t filters, uint8_t* out)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t n = (size_t)src.h * ((size_t)src.w * src.cn + 1);
+    if (!d_packed_.ensure(n + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    LpPngEncOp op;
+    memset(&op, 0, sizeof(op));
+    op.src = src;
+    op.out_off = (uint64_t)(uintptr_t)d_packed_.p;
+    op.filters = filters;
+    lp_launch_png_filter(stream_, op);
+    if (!check(hipMemcpyAsync(out, d_packed_.p, n, hipMemcpyDeviceToHost, stream_), "D2H filtered rows")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "png filter sync")) return LP_ERR_DEVICE;
+    return check(hipGetLastError(), "png filter kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
 int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra)
 {
     if (!ok_) return LP_ERR_DEVICE;

@@ -118,6 +118,8 @@ public:
     int gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra);
     // PNG: uploads the inflated stream and the palette, reverses the filters and expands to op.dst; LP_ERR_DECODE_FAILED on a bad filter type.
     int png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra);
+    // PNG output: libpng's per-row filter choice + filtering on the device; `out` receives h * (1 + w * cn) bytes (host memory).
+    int png_filter(const LpFrame& src, uint32_t filters, uint8_t* out);
     // ThumbHash: out[(i * w + j) * cn ..] = frame(idx[w + i], idx[j]) for a w x h lattice of sample coordinates (host memory in and out).
     int gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out);
     int sync();

@@ -877,6 +877,71 @@ void lp_launch_png(hipStream_t s, const LpPngOp& op)
     hipLaunchKernelGGL(k_png_convert, dim3((mw + 63) / 64, (mh + 3) / 4, op.npass), dim3(64, 4), 0, s, op);
 }
 
+// ---- PNG output: filter selection + filtering (see LpPngEncOp)
+__device__ __forceinline__ uint32_t png_enc_raw(const LpFrame& f, const uint8_t* row, uint32_t i)
+{
+    // byte i of the RGB(A) / grey row libpng sees after png_set_bgr: channel c of BGR(A) pixel x sits at 2 - c for the colours
+    const uint32_t cn = f.cn, x = i / cn, c = i - x * cn;
+    return row[x * cn + (cn >= 3 && c < 3 ? 2u - c : c)];
+}
+__device__ __forceinline__ uint32_t png_enc_filtered(uint32_t type, uint32_t x, uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t pred = 0;
+    if (type == 1) pred = a;
+    else if (type == 2) pred = b;
+    else if (type == 3) pred = (a + b) >> 1;
+    else if (type == 4) {
+        const int32_t p = (int32_t)a + (int32_t)b - (int32_t)c;
+        const int32_t pa = abs(p - (int32_t)a), pb = abs(p - (int32_t)b), pc = abs(p - (int32_t)c);
+        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    }
+    return (x - pred) & 0xffu;
+}
+__global__ __launch_bounds__(256) void k_png_filter(LpPngEncOp op)
+{
+    __shared__ uint32_t s_sum[5][4];
+    const LpFrame& f = op.src;
+    const uint32_t y = blockIdx.x, cn = f.cn, rb = f.w * cn;
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(f.off) + (size_t)y * f.stride;
+    const uint8_t* up = y ? row - f.stride : nullptr; // libpng's prev_row is all zero above the first row
+    uint32_t sum[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < rb; i += 256) {
+        const uint32_t x = png_enc_raw(f, row, i), a = i >= cn ? png_enc_raw(f, row, i - cn) : 0u, b = up ? png_enc_raw(f, up, i) : 0u,
+                       c = (up && i >= cn) ? png_enc_raw(f, up, i - cn) : 0u;
+#pragma unroll
+        for (uint32_t t = 0; t < 5; t++) {
+            const uint32_t v = png_enc_filtered(t, x, a, b, c);
+            sum[t] += v < 128u ? v : 256u - v;
+        }
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < 5; t++) {
+        uint32_t v = sum[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) s_sum[t][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    uint32_t best = 0, best_sum = 0xffffffffu;
+    bool have = false;
+    for (uint32_t t = 0; t < 5; t++) { // the first enabled filter with the strictly smallest sum
+        if (!(op.filters & (1u << t))) continue;
+        const uint32_t v = s_sum[t][0] + s_sum[t][1] + s_sum[t][2] + s_sum[t][3];
+        if (!have || v < best_sum) { best = t; best_sum = v; have = true; }
+    }
+    uint8_t* out = reinterpret_cast<uint8_t*>(op.out_off) + (size_t)y * (rb + 1);
+    if (threadIdx.x == 0) out[0] = (uint8_t)best;
+    for (uint32_t i = threadIdx.x; i < rb; i += 256) {
+        const uint32_t x = png_enc_raw(f, row, i), a = i >= cn ? png_enc_raw(f, row, i - cn) : 0u, b = up ? png_enc_raw(f, up, i) : 0u,
+                       c = (up && i >= cn) ? png_enc_raw(f, up, i - cn) : 0u;
+        out[1 + i] = (uint8_t)png_enc_filtered(best, x, a, b, c);
+    }
+}
+void lp_launch_png_filter(hipStream_t s, const LpPngEncOp& op)
+{
+    if (!op.src.h || !op.src.w) return;
+    hipLaunchKernelGGL(k_png_filter, dim3(op.src.h), dim3(256), 0, s, op);
+}
+
 // ThumbHash's nearest-neighbour samples (thumbhash.cpp:118-193): out[(i * w + j) * cn ..] = frame(rows[i], cols[j]).
 __global__ __launch_bounds__(256) void k_gather_samples(LpFrame f, const uint32_t* __restrict__ idx, uint32_t w, uint32_t h, uint8_t* __restrict__ out)
 {

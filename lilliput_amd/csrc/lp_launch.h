@@ -51,6 +51,7 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
 void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* d_src, uint8_t* d_dst);
 void lp_launch_gif_frame(hipStream_t s, const LpGifFrameOp& op);
 void lp_launch_png(hipStream_t s, const LpPngOp& op);
+void lp_launch_png_filter(hipStream_t s, const LpPngEncOp& op);
 void lp_launch_gifenc(hipStream_t s, const LpGifEncOp& op);
 void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d_idx, uint32_t w, uint32_t h, uint8_t* d_out);
 // encode

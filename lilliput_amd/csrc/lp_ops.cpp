@@ -446,12 +446,19 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     if (e) return e;
     // Container-signalled colour (ops.go:500-541): an HDR transfer function in a PNG's cICP chunk makes the reference tone-map
     // every decoded frame (color_info.cpp). That kernel is not built: refuse rather than return un-mapped pixels.
+    uint8_t out_cicp[4] = {0, 0, 0, 0};
+    bool have_out_cicp = false;
     if (d->kind == Decoder::OPENCV) {
         const char* desc = opencv_decoder_get_description(d->dec);
         uint8_t prim = 0, transfer = 0, matrix = 0, range = 0;
         if (desc && strcmp(desc, "PNG") == 0 && d->len && opencv_decoder_get_png_cicp((void*)d->buf, d->len, &prim, &transfer, &matrix, &range) &&
             (transfer == 16 || transfer == 18)) // cicp_is_hdr_transfer: SMPTE ST 2084 (PQ), ARIB STD-B67 (HLG)
             return LILLIPUT_ERR_UNSUPPORTED;
+        // an SDR cICP is signalling only: it is carried over to a PNG output (ops.go:511-517, applyOutputCICP ops.go:306-333)
+        if (desc && strcmp(desc, "PNG") == 0 && d->len && opencv_decoder_get_png_cicp((void*)d->buf, d->len, &prim, &transfer, &matrix, &range)) {
+            out_cicp[0] = prim; out_cicp[1] = transfer; out_cicp[2] = matrix; out_cicp[3] = range;
+            have_out_cicp = true;
+        }
     }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
     std::string ext = lower(opt->file_type);
@@ -528,6 +535,8 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         if (!opencv_encoder_write(enc.enc, f->mat, opt->encode_options, opt->encode_options_len)) return LILLIPUT_ERR_INVALID_IMAGE;
         if (opencv_mat_get_data(enc.dst) != (void*)enc.dst_buf) return LILLIPUT_ERR_BUF_TOO_SMALL;
         *n = (size_t)opencv_mat_get_height(enc.dst);
+        if (have_out_cicp && *n >= 8 && memcmp(enc.dst_buf, "\x89PNG\r\n\x1a\n", 8) == 0) // applyOutputCICP: PNG outputs only
+            *n = opencv_png_insert_cicp(enc.dst_buf, *n, enc.dst_cap, out_cicp[0], out_cicp[1], out_cicp[2], out_cicp[3]);
         return LILLIPUT_OK;
     };
     auto encode_empty = [&]() -> int { // ops.go:286-292 encodeEmpty + the caller returning its result

@@ -250,6 +250,17 @@ struct LpPngOp {
     uint32_t key[3];            // 16-bit R, G, B
 };
 
+// PNG output (cv::PngEncoder::write over libpng, opencv.cpp:185-194 with FileType ".png"): every row of the frame becomes a filter
+// byte + the filtered row, RGB(A) byte order. libpng picks a row's filter by trying the enabled ones (NONE, SUB, UP, AVG, PAETH in this
+// order) and keeping the first with the smallest sum of |signed byte| (pngwutil.c png_write_find_filter); a row only needs the
+// UNFILTERED row above, so all rows are independent: one workgroup per row.
+struct LpPngEncOp {
+    LpFrame src;                // grey, BGR or BGRA
+    uint64_t out_off;           // device address of the filtered stream: h * (1 + w * cn) bytes
+    uint32_t filters;           // bit f set = filter type f may be used (libpng's do_filter after png_write_start_row's pruning)
+    uint32_t pad;
+};
+
 // JPEG encode job (S8-S10): pixels -> baseline 4:2:0 (or grayscale) JFIF stream with Annex-K tables.
 struct LpEncJob {
     LpFrame src;

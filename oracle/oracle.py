@@ -115,6 +115,41 @@ def ref_png_decode(data):
     return out if ref_png().ref_png_decode(bytes(data), len(data), out.ctypes.data, out.size, (C.c_int * 6)()) == 0 else None
 
 
+def ref_png_encode(px, level=-1):
+    """Bytes cv::PngEncoder writes for an 8-bit grey / BGR / BGRA Mat through the reference's libpng + zlib-ng (level < 0: no
+    IMWRITE_PNG_COMPRESSION given); None when the reference library is not built."""
+    R = ref_png()
+    if R is None:
+        return None
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    h, w = px.shape[:2]
+    cn = 1 if px.ndim == 2 else px.shape[2]
+    out = np.zeros(h * w * cn * 2 + (1 << 16), dtype=np.uint8)
+    R.ref_png_encode_like_opencv.restype = C.c_long
+    n = R.ref_png_encode_like_opencv(px.ctypes.data_as(C.c_void_p), w, h, cn, int(level), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size))
+    return out[:n].tobytes() if n > 0 else None
+
+
+def png_filtered_stream(data):
+    """(IHDR fields, the inflated IDAT stream: filter byte + filtered row, row after row, names of the chunks) of a PNG file."""
+    import struct
+    import zlib
+
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    i, idat, names, ihdr = 8, b"", [], None
+    while i < len(data):
+        n, typ = struct.unpack(">I4s", data[i : i + 8])
+        body = data[i + 8 : i + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[i + 8 + n : i + 12 + n])[0], typ
+        names.append(typ.decode())
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        i += 12 + n
+    return ihdr, zlib.decompress(idat), names
+
+
 _refgif = None
 
 

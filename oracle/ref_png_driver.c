@@ -68,3 +68,48 @@ int ref_png_decode(const uint8_t* data, size_t n, uint8_t* out, size_t cap, int 
     png_destroy_read_struct(&png, &pi, &end_info);
     return 0;
 }
+
+/* ---- PNG OUTPUT: cv::PngEncoder::write (OpenCV 4.11 grfmt_png.cpp) restated call by call over the reference's libpng + zlib-ng.
+ * px: the Mat (h x w x cn, 8-bit, BGR / BGRA / grey). level < 0: no IMWRITE_PNG_COMPRESSION in the options -> filter SUB only,
+ * Z_BEST_SPEED, strategy RLE; else level 0..9 with libpng's default (adaptive) filters and Z_DEFAULT_STRATEGY. */
+struct sink { uint8_t* p; size_t n, cap; int ovf; };
+static void wr(png_structp png, png_bytep data, png_size_t n)
+{
+    struct sink* s = (struct sink*)png_get_io_ptr(png);
+    if (s->n + n > s->cap) { s->ovf = 1; return; }
+    memcpy(s->p + s->n, data, n);
+    s->n += n;
+}
+static void fl(png_structp png) { (void)png; }
+
+long ref_png_encode_like_opencv(const uint8_t* px, int w, int h, int cn, int level, uint8_t* out, size_t cap)
+{
+    struct sink s = {out, 0, cap, 0};
+    png_structp png = png_create_write_struct(PNG_LIBPNG_VER_STRING, NULL, NULL, quiet);
+    png_infop pi = png_create_info_struct(png);
+    png_bytep* volatile rows = NULL;
+    if (setjmp(png_jmpbuf(png))) { free((void*)rows); png_destroy_write_struct(&png, &pi); return -1; }
+    png_set_write_fn(png, &s, wr, fl);
+    int strategy = 3; /* IMWRITE_PNG_STRATEGY_RLE */
+    if (level >= 0) {
+        strategy = 0; /* IMWRITE_PNG_STRATEGY_DEFAULT */
+        if (level > 9) level = 9;
+        png_set_compression_level(png, level);
+    } else {
+        png_set_filter(png, PNG_FILTER_TYPE_BASE, PNG_FILTER_SUB);
+        png_set_compression_level(png, 1);
+    }
+    png_set_compression_strategy(png, strategy);
+    png_set_IHDR(png, pi, (png_uint_32)w, (png_uint_32)h, 8, cn == 1 ? PNG_COLOR_TYPE_GRAY : cn == 3 ? PNG_COLOR_TYPE_RGB : PNG_COLOR_TYPE_RGBA,
+                 PNG_INTERLACE_NONE, PNG_COMPRESSION_TYPE_DEFAULT, PNG_FILTER_TYPE_DEFAULT);
+    png_write_info(png, pi);
+    png_set_bgr(png);
+    png_set_swap(png); /* little-endian host */
+    rows = (png_bytep*)malloc(sizeof(png_bytep) * (size_t)h);
+    for (int y = 0; y < h; y++) rows[y] = (png_bytep)(px + (size_t)y * w * cn);
+    png_write_image(png, (png_bytep*)rows);
+    png_write_end(png, pi);
+    free((void*)rows);
+    png_destroy_write_struct(&png, &pi);
+    return s.ovf ? -3 : (long)s.n;
+}
