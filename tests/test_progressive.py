@@ -29,7 +29,10 @@ def _cases(seed, n, lo=1, hi=300):
         if not gray:
             kw["subsampling"] = int(rng.choice([0, 1, 2]))
         buf = io.BytesIO()
-        PIL.fromarray(_photo(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        try:
+            PIL.fromarray(_photo(rng, h, w, gray)).save(buf, "JPEG", **kw)
+        except OSError:  # Pillow's encoder buffer is too small for some size / quality combinations
+            continue
         yield i, (h, w, gray, kw), buf.getvalue()
 
 
