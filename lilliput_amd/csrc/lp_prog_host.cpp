@@ -157,10 +157,10 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
                 run_task(tasks[k], clean, rst, words);
             }
         };
-        // a level with little data is decoded faster than threads start: one thread per ~64 KiB of entropy-coded data
+        // a level with little data is decoded faster than threads start: one thread per ~8 KiB of entropy-coded data (≈0.4 ms of work)
         size_t level_bytes = 0;
         for (size_t k = lo; k < hi; k++) level_bytes += tasks[k].scan->ecs_len;
-        const int nt = (int)std::min<size_t>(std::min<size_t>((size_t)nthreads, hi - lo), level_bytes / 65536 + 1);
+        const int nt = (int)std::min<size_t>(std::min<size_t>((size_t)nthreads, hi - lo), level_bytes / 8192 + 1);
         if (nt <= 1) worker();
         else {
             std::vector<std::thread> th;
