@@ -157,7 +157,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
     int cid[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
     bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false, progressive = false;
-    struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; uint8_t bits[4][17], vals[4][256]; size_t ecs_off, ecs_len; };
+    struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; bool sequential; uint8_t bits[8][17], vals[8][256]; size_t ecs_off, ecs_len; };
+    bool seq_scans = false; // a sequential file that goes scan by scan (see LpProgScan::sequential); decided at its first SOS
     std::vector<RawScan> raw_scans;
     unsigned sof_nc = 0;
     int scan_comp[3] = {-1, -1, -1};
@@ -285,10 +286,17 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if (!progressive && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
                 if (s < 3) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
-            if (progressive) { // jdphuff.c start_pass_phuff_decoder: one of up to LP_MAX_SCANS scans; the tables as they stand now
+            if (!progressive && raw_scans.empty()) {
+                // A sequential file the baseline kernels do not take as it is -- fewer components in the first scan than in the frame
+                // (more scans follow), components in another order, table numbers 2 / 3 -- is decoded scan by scan like a progressive one.
+                seq_scans = ns != j.ncomp;
+                for (unsigned s = 0; s < ns; s++) seq_scans = seq_scans || cur[s] != (int)s || (p[2 + 2 * s] >> 4) > 1 || (p[2 + 2 * s] & 15) > 1;
+            }
+            if (progressive || seq_scans) { // jdphuff.c start_pass_phuff_decoder / jdhuff.c start_pass_huff_decoder: one of up to LP_MAX_SCANS scans
                 RawScan rs;
                 memset(&rs, 0, sizeof(rs));
                 rs.ns = ns;
+                rs.sequential = !progressive;
                 for (unsigned s = 0; s < ns; s++) { rs.comp[s] = cur[s]; rs.td[s] = p[2 + 2 * s] >> 4; rs.ta[s] = p[2 + 2 * s] & 15; }
                 rs.Ss = p[1 + 2 * ns]; rs.Se = p[2 + 2 * ns]; rs.Ah = p[3 + 2 * ns] >> 4; rs.Al = p[3 + 2 * ns] & 15;
                 bool bad = false;
@@ -296,7 +304,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 else { if (rs.Se < rs.Ss || rs.Se > 63) bad = true; if (ns != 1) bad = true; }
                 if (rs.Ah != 0 && rs.Ah - 1 != rs.Al) bad = true;
                 if (rs.Al > 13) bad = true;
-                if (bad) return LP_PARSE_NOT_JPEG;                        // JERR_BAD_PROGRESSION
+                if (bad && progressive) return LP_PARSE_NOT_JPEG;         // JERR_BAD_PROGRESSION (a sequential scan only warns: JWRN_NOT_SEQUENTIAL)
                 for (unsigned s = 0; s < ns; s++) { // jdinput.c latch_quant_tables: a component keeps the table current at its first scan
                     const int c = cur[s];
                     if (latched[c]) continue;
@@ -306,7 +314,21 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 }
                 rs.dri = j.dri;
                 const bool dc_scan = rs.Ss == 0;
-                if (!(dc_scan && rs.Ah != 0))                             // a DC refinement scan reads raw bits only
+                if (rs.sequential) { // both tables of every component, Annex-K ones for undefined numbers 0 / 1 (jinit_huff_decoder -> std_huff_tables)
+                    for (unsigned s = 0; s < ns; s++)
+                        for (int cls = 0; cls < 2; cls++) {
+                            const int id = cls ? rs.ta[s] : rs.td[s], slot = cls ? 4 + (int)s : (int)s;
+                            if (h_ok[cls][id]) { memcpy(rs.bits[slot], hbits[cls][id], 17); memcpy(rs.vals[slot], hvals[cls][id], 256); }
+                            else if (id < 2) {
+                                memcpy(rs.bits[slot], lp_std_huff_bits[2 * id + cls], 17);
+                                memset(rs.vals[slot], 0, 256);
+                                if (cls) memcpy(rs.vals[slot], id ? lp_std_huff_ac_chroma : lp_std_huff_ac_luma, 162);
+                                else memcpy(rs.vals[slot], lp_std_huff_dc_vals, 12);
+                            } else
+                                return LP_PARSE_NOT_JPEG;                 // JERR_NO_HUFF_TABLE
+                            if (!huff_table_valid(rs.bits[slot], rs.vals[slot], cls == 0)) return LP_PARSE_NOT_JPEG;
+                        }
+                } else if (!(dc_scan && rs.Ah != 0))                      // a DC refinement scan reads raw bits only
                     for (unsigned s = 0; s < ns; s++) {
                         const int cls = dc_scan ? 0 : 1, id = dc_scan ? rs.td[s] : rs.ta[s];
                         if (id > 3) return LP_PARSE_NOT_JPEG;             // JERR_NO_HUFF_TABLE
@@ -333,6 +355,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if (!ecs) ecs = seg_end;
                 i = q;
                 if (q >= n || (q + 1 < n && d[q + 1] == 0xD9)) { out->saw_eoi = q < n; break; }
+                if (rs.sequential && raw_scans.size() == 1 && ns == j.ncomp) break; // a one-scan file: libjpeg reads nothing past the scan
                 continue;
             }
             if (ns != j.ncomp) return LP_PARSE_UNSUPPORTED; // non-interleaved / multi-scan
@@ -365,8 +388,8 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (j.hs[c] < 1 || j.hs[c] > 2 || j.vs[c] < 1 || j.vs[c] > 2) return LP_PARSE_UNSUPPORTED;
         if (j.hs[c] > j.hmax) j.hmax = j.hs[c];
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
-        if (progressive && !latched[c]) { memset(latched_qt[c], 0, sizeof(latched_qt[c])); continue; } // in no scan at all: stays zero (libjpeg: never dequantised)
-        if (progressive) continue;                                                                 // tables were checked scan by scan
+        if ((progressive || seq_scans) && !latched[c]) { memset(latched_qt[c], 0, sizeof(latched_qt[c])); continue; } // in no scan at all: stays zero (libjpeg: never dequantised)
+        if (progressive || seq_scans) continue;                                                    // tables were checked scan by scan
         if (tq[c] > 3 || !qt_ok[tq[c]]) return LP_PARSE_NOT_JPEG;                                  // JERR_NO_QUANT_TABLE
         if (!h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;                         // JERR_NO_HUFF_TABLE
         if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
@@ -392,7 +415,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         j.plane_stride[c] = j.bw[c] * 8;
         j.dc_tbl[c] = (uint8_t)td[c];
         j.ac_tbl[c] = (uint8_t)(2 + ta[c]);
-        if (progressive) memcpy(j.qt[c], latched_qt[c], sizeof(j.qt[c]));
+        if (progressive || seq_scans) memcpy(j.qt[c], latched_qt[c], sizeof(j.qt[c]));
         else memcpy(j.qt[c], qt[tq[c]], sizeof(j.qt[c]));
     }
     j.bpm = (uint8_t)bpm;
@@ -408,7 +431,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     else if (saw_adobe) j.colorspace = adobe_tf == 0 ? 3 : 2;
     else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') j.colorspace = 3;
     else j.colorspace = 2;
-    if (progressive) {
+    if (progressive || seq_scans) {
         out->progressive = true;
         for (const RawScan& rs : raw_scans) {
             LpProgScanHost hs;
@@ -417,6 +440,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
             hs.s.ns = rs.ns;
             for (unsigned s = 0; s < rs.ns; s++) hs.s.comp[s] = (uint8_t)rs.comp[s];
             hs.s.Ss = (uint8_t)rs.Ss; hs.s.Se = (uint8_t)rs.Se; hs.s.Ah = (uint8_t)rs.Ah; hs.s.Al = (uint8_t)rs.Al;
+            hs.s.sequential = rs.sequential ? 1 : 0;
             hs.s.dri = rs.dri;
             if (rs.ns == 1) { // non-interleaved: the component's own blocks, not the MCU padding
                 const int c = rs.comp[0];
@@ -432,7 +456,10 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 hs.s.hs[s] = rs.ns == 1 ? 1 : j.hs[c];
                 hs.s.vs[s] = rs.ns == 1 ? 1 : j.vs[c];
             }
-            for (unsigned s = 0; s < rs.ns && !(rs.Ss == 0 && rs.Ah != 0); s++) { // canonical tables + an 8-bit first-level lookup
+            for (unsigned slot = 0; slot < 8; slot++) { // canonical tables + an 8-bit first-level lookup
+                const unsigned s = slot;
+                if ((slot & 3u) >= rs.ns) continue;
+                if (rs.sequential ? false : (slot >= 4 || (rs.Ss == 0 && rs.Ah != 0))) continue; // progressive: one table per component, none in a DC refinement
                 int code = 0, k = 0;
                 for (int l = 1; l <= 16; l++) {
                     const int mincode = code, valptr = k;

@@ -160,7 +160,29 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
             }
             // "If we've run out of data, don't modify the MCU" (every decode_mcu_* but the DC refinement, which cannot change anything
             // with zero bits anyway)
-            if (b.insufficient && !(Ss == 0 && Ah != 0)) {
+            if (b.insufficient && (sc.sequential || !(Ss == 0 && Ah != 0))) {
+                if (sc.dri) rst_left--;
+                continue;
+            }
+            if (sc.sequential) { // jdhuff.c decode_mcu: every block of the MCU whole, its DC difference then its AC run/size pairs
+                for (uint32_t s = 0; s < sc.ns; s++)
+                    for (uint32_t v = 0; v < sc.vs[s]; v++)
+                        for (uint32_t h = 0; h < sc.hs[s]; h++) {
+                            const uint32_t blk = sc.cblk[s] + (my * sc.vs[s] + v) * sc.bw[s] + mx * sc.hs[s] + h;
+                            const uint32_t t = b.sym(s) & 15u;
+                            if (t) pred[s] += lp_prog_extend(b.get(t), t);
+                            m.st(blk, 0, pred[s]);
+                            for (uint32_t k = 1; k < 64u; k++) {
+                                const uint32_t rs = b.sym(4u + s), r = rs >> 4, sz = rs & 15u;
+                                if (sz) {
+                                    k += r;
+                                    m.st(blk, k < 64u ? k : 63u, lp_prog_extend(b.get(sz), sz)); // jpeg_natural_order[64..79] = 63
+                                } else if (r == 15u)
+                                    k += 15u;
+                                else
+                                    break;
+                            }
+                        }
                 if (sc.dri) rst_left--;
                 continue;
             }

@@ -81,11 +81,13 @@ struct LpJpeg {
 // Coefficients accumulate in an int16 arena: per image, per component, blocks in raster order over the MCU-padded grid,
 // 64 values per block in ZIGZAG order (see lp_prog_core.h: a refinement scan then works on a 64-bit non-zero mask).
 #define LP_MAX_SCANS 64
-struct LpProgHuff {             // the (at most four) Huffman tables one scan uses, slot = position of the component in the scan
-    uint16_t lut8[4][256];      // (length << 8) | symbol for codes of up to 8 bits, indexed by the next 8 bits; 0 = longer code
-    int32_t maxcode[4][18];     // canonical decode of the longer codes (T.81 F.2.2.3)
-    int32_t valoff[4][17];
-    uint8_t vals[4][256];
+struct LpProgHuff {             // the Huffman tables one scan uses. Progressive scans: slot = position of the component in the scan (its
+                                // DC or its AC table, whichever the scan codes). Sequential scans (see LpProgScan::sequential) need both:
+                                // slot s = DC table, slot 4 + s = AC table of scan component s.
+    uint16_t lut8[8][256];      // (length << 8) | symbol for codes of up to 8 bits, indexed by the next 8 bits; 0 = longer code
+    int32_t maxcode[8][18];     // canonical decode of the longer codes (T.81 F.2.2.3)
+    int32_t valoff[8][17];
+    uint8_t vals[8][256];
 };
 struct LpProgScan {
     uint32_t img;               // index of the image in the current decode range
@@ -99,6 +101,10 @@ struct LpProgScan {
     uint32_t cblk[4];           // first block of scan component s, relative to the image's first block in the arena
     uint32_t bw[4];             // blocks per row of scan component s (MCU padded)
     uint8_t hs[4], vs[4];       // blocks of scan component s per MCU (1 x 1 in a single-component scan)
+    uint8_t sequential;         // 1: a scan of a SEQUENTIAL (SOF0 / SOF1) file the baseline kernels do not take -- several scans, components
+                                // in another order than the frame's, table numbers above 1, four components: whole blocks, DC then AC
+                                // (jdhuff.c decode_mcu), through the same per-scan machinery as progressive scans
+    uint8_t pad8[7];
     uint64_t coef_off;          // element offset of the image in the int16 coefficient arena
 };
 

@@ -39,6 +39,7 @@ typedef struct {
     int dri;
     int orientation;  /* EXIF 1..8, 1 when absent/invalid */
     int sof;          /* 0,1 supported */
+    int scan_path;    /* a sequential file decoded scan by scan (several scans, or components in another order than the frame's) */
     int hmax, vmax;
     int mcus_x, mcus_y;
     int colorspace;   /* 1 gray, 2 YCbCr, 3 RGB */
@@ -221,7 +222,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
                 in->td[c] = t >> 4;
                 in->ta[c] = t & 15;
             }
-            if (ns != in->ncomp || !order_ok) return LO_ERR_UNSUPPORTED; /* non-interleaved / multi-scan */
+            if (ns != in->ncomp || !order_ok) in->scan_path = 1; /* non-interleaved / multi-scan: walked by decode_coefs_progressive */
             in->ecs_off = seg_end;
             break;
         }
@@ -251,7 +252,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
         if (in->hs[c] > in->hmax) in->hmax = in->hs[c];
         if (in->vs[c] > in->vmax) in->vmax = in->vs[c];
         if (in->tq[c] > 3 || !in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
-        if (in->sof == 2) continue; /* Huffman tables are checked scan by scan */
+        if (in->sof == 2 || in->scan_path) continue; /* Huffman tables are checked scan by scan */
         if (!in->ht_present[0][in->td[c]] || !in->ht_present[1][in->ta[c]]) return LO_ERR_FORMAT;
         /* jdhuff.c jpeg_make_d_derived_tbl, run for the tables the scan uses: the code space must not overflow (the all-ones
            code of a length is reserved) and DC symbols are categories 0..15 -- else JERR_BAD_HUFF_TABLE */
@@ -526,9 +527,17 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
             else { if (Se < Ss || Se > 63) bad = 1; if (ns != 1) bad = 1; }
             if (Ah != 0 && Ah - 1 != Al) bad = 1;
             if (Al > 13) bad = 1;
-            if (bad) return LO_ERR_FORMAT; /* JERR_BAD_PROGRESSION */
-            lo_htab tab[4];
-            for (int s = 0; s < ns; s++) {
+            const int sequential = in->sof != 2; /* jdhuff.c: whole blocks, both tables; odd Ss/Se/Ah/Al only warn (JWRN_NOT_SEQUENTIAL) */
+            if (bad && !sequential) return LO_ERR_FORMAT; /* JERR_BAD_PROGRESSION */
+            lo_htab tab[4], actab[4];
+            for (int s = 0; s < ns && sequential; s++) {
+                /* ids 0 / 1 fall back to the Annex-K tables preloaded above (jinit_huff_decoder -> std_huff_tables) */
+                if (std_[s] > 3 || sta[s] > 3 || (std_[s] > 1 && !present[0][std_[s]]) || (sta[s] > 1 && !present[1][sta[s]])) return LO_ERR_FORMAT;
+                if (!huff_ok(bits[0][std_[s]], vals[0][std_[s]], 1) || !huff_ok(bits[1][sta[s]], vals[1][sta[s]], 0)) return LO_ERR_FORMAT;
+                build_htab(&tab[s], bits[0][std_[s]], vals[0][std_[s]]);
+                build_htab(&actab[s], bits[1][sta[s]], vals[1][sta[s]]);
+            }
+            for (int s = 0; s < ns && !sequential; s++) {
                 int cls = Ss == 0 ? 0 : 1, id = Ss == 0 ? std_[s] : sta[s];
                 if (Ss == 0 && Ah != 0) continue; /* DC refinement reads raw bits */
                 /* JERR_NO_HUFF_TABLE. No Annex-K fallback here: std_huff_tables() is called by jinit_huff_decoder only, a progressive
@@ -547,7 +556,7 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                 if (dri && rst_left == 0) { prog_restart(&b); pred[0] = pred[1] = pred[2] = pred[3] = 0; eobrun = 0; rst_left = dri; }
                 int mx = mi % mcux, my = mi / mcux;
                 /* "If we've run out of data, don't modify the MCU" -- every scan type but the DC refinement checks this */
-                const int skip_mcu = b.insufficient && !(Ss == 0 && Ah != 0);
+                const int skip_mcu = b.insufficient && (sequential || !(Ss == 0 && Ah != 0));
                 for (int s = 0; s < ns && !skip_mcu; s++) {
                     int c = sc[s];
                     int nh = ns == 1 ? 1 : in->hs[c], nv = ns == 1 ? 1 : in->vs[c];
@@ -555,7 +564,21 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                         for (int h = 0; h < nh; h++) {
                             int bx = ns == 1 ? mx : mx * in->hs[c] + h, by = ns == 1 ? my : my * in->vs[c] + v;
                             int16_t* blk = D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64;
-                            if (Ss == 0 && Ah == 0) { /* decode_mcu_DC_first */
+                            if (sequential) { /* jdhuff.c decode_mcu */
+                                int t = decode_sym(&b, &tab[s]) & 15;
+                                fill(&b);
+                                pred[c] += t ? extend(getbits(&b, t), t) : 0;
+                                blk[0] = (int16_t)pred[c];
+                                for (int k = 1; k < 64; k++) {
+                                    int rs = decode_sym(&b, &actab[s]), r = rs >> 4, sz = rs & 15;
+                                    if (sz) {
+                                        k += r;
+                                        fill(&b);
+                                        blk[lo_zigzag[k < 64 ? k : 63]] = (int16_t)extend(getbits(&b, sz), sz);
+                                    } else if (r == 15) k += 15;
+                                    else break;
+                                }
+                            } else if (Ss == 0 && Ah == 0) { /* decode_mcu_DC_first */
                                 int t = decode_sym(&b, &tab[s]);
                                 fill(&b);
                                 int diff = t ? extend(getbits(&b, t), t) : 0;
@@ -621,6 +644,7 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                 if (dri) rst_left--;
             }
             scans++;
+            if (sequential && scans == 1 && ns == in->ncomp) return LO_OK; /* a one-scan file: nothing is read past the scan */
             /* continue the marker walk after this scan's entropy-coded data */
             i = seg_end;
             while (i + 1 < n) {
@@ -638,7 +662,7 @@ static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
     lo_jpeg_info* in = &D->in;
     int rc = lo_jpeg_read_header(d, n, in);
     if (rc) return rc;
-    if (in->sof == 2) return decode_coefs_progressive(d, n, D);
+    if (in->sof == 2 || in->scan_path) return decode_coefs_progressive(d, n, D);
     lo_htab dc[4], ac[4];
     for (int t = 0; t < 4; t++) {
         if (in->ht_present[0][t]) build_htab(&dc[t], in->bits[0][t], in->vals[0][t]);

@@ -235,6 +235,21 @@ long ref_jpeg_encode_ex(const uint8_t* px, int W, int H, int ncomp, int mode, co
         ci.scan_info = script;
         ci.num_scans = n;
     }
+    /* bit 4: SEQUENTIAL file with one scan per component (non-interleaved); bit 5: a Huffman table pair of its own for every
+     * component (table numbers 0, 1, 2 -> SOF1, needs optimize bit 0); bit 6 (with bit 4): first scan holds components 0 and 1
+     * interleaved, the second the last one */
+    if (optimize & 16) {
+        int n = 0;
+        if ((optimize & 64) && ncomp == 3) {
+            jpeg_scan_info a = {2, {0, 1, 0, 0}, 0, 63, 0, 0}, b = {1, {2, 0, 0, 0}, 0, 63, 0, 0};
+            script[n++] = a; script[n++] = b;
+        } else
+            for (int c = 0; c < ncomp; c++) { jpeg_scan_info si = {1, {c, 0, 0, 0}, 0, 63, 0, 0}; script[n++] = si; }
+        ci.scan_info = script;
+        ci.num_scans = n;
+    }
+    if (optimize & 32)
+        for (int c = 0; c < ncomp; c++) { ci.comp_info[c].dc_tbl_no = c; ci.comp_info[c].ac_tbl_no = c; }
     jpeg_start_compress(&ci, TRUE);
     while (ci.next_scanline < ci.image_height) {
         JSAMPROW row = (JSAMPROW)(px + (size_t)ci.next_scanline * W * ncomp);

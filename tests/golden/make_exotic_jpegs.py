@@ -1,7 +1,8 @@
 """Writes tests/golden/inputs_exotic/*.jpg with the reference's own libjpeg-turbo compressor (oracle/_ref/libref.so): samplings,
 colour spaces and table widths Pillow cannot produce (4:4:0, 2x2 luma with custom chroma factors, RGB-in-JPEG with an Adobe
 marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row, progressive
-files with libjpeg's default script, a spectral-selection-only script and a deep successive-approximation script), and
+files with libjpeg's default script, a spectral-selection-only script and a deep successive-approximation script, sequential
+files in several scans and with three Huffman table pairs), and
 tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file.
 Run in the build container (needs /root/reference)."""
 import ctypes as C, hashlib, json, os, sys
@@ -56,6 +57,13 @@ enc("prog_deep_gray_dri17", 120, 33, 1, 0, S444, 99, dri=17, optimize=9)
 enc("prog_q1_16bit_tables", 48, 48, 3, 0, S420, 1, force_baseline=0, optimize=2)
 enc("prog_narrow", 40, 3, 3, 0, S420, 90, optimize=2)
 enc("prog_tiny", 1, 1, 3, 0, S420, 90, optimize=2)
+# sequential files that go scan by scan: one scan per component (bit 4), Y+Cb then Cr (bits 4+6), a table pair per component
+# (bit 5 with bit 0: table numbers 0..2, SOF1)
+enc("seq_noninterleaved_420", 70, 85, 3, 0, S420, 85, optimize=16)
+enc("seq_noninterleaved_444_dri4_opt", 33, 58, 3, 0, S444, 92, dri=4, optimize=17)
+enc("seq_two_scans_422", 64, 49, 3, 0, S422, 75, optimize=16 + 64)
+enc("seq_three_table_pairs_420", 55, 90, 3, 0, S420, 80, optimize=33)
+enc("seq_three_table_pairs_noninterleaved_440", 47, 47, 3, 0, S440, 60, dri=2, optimize=16 + 33)
 gold = {}
 for f in sorted(os.listdir(out_dir)):
     d = open(os.path.join(out_dir, f), "rb").read()
