@@ -541,7 +541,7 @@ bool opencv_decoder_read_header(opencv_decoder dd)
     d->parse_rc = lp_jpeg_parse(d->data, d->len, &d->hdr);
     d->parsed = true;
     if (d->parse_rc == LP_PARSE_UNSUPPORTED) {
-        lp_set_error("JPEG feature outside the device path (progressive / arithmetic / CMYK / 12-bit / exotic sampling)");
+        lp_set_error("JPEG feature outside the device path (arithmetic coding / lossless / 12-bit / sampling factors above 2)");
         fprintf(stderr, "lilliput_hip: %s\n", g_last_error.c_str());
     }
     return d->parse_rc == LP_PARSE_OK;

@@ -155,13 +155,13 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     uint8_t hbits[2][4][17];
     uint8_t hvals[2][4][256];
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
-    int cid[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int cid[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0}, td[4] = {0, 0, 0, 0}, ta[4] = {0, 0, 0, 0};
     bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false, progressive = false;
     struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; bool sequential; uint8_t bits[8][17], vals[8][256]; size_t ecs_off, ecs_len; };
     bool seq_scans = false; // a sequential file that goes scan by scan (see LpProgScan::sequential); decided at its first SOS
     std::vector<RawScan> raw_scans;
     unsigned sof_nc = 0;
-    int scan_comp[3] = {-1, -1, -1};
+    int scan_comp[4] = {-1, -1, -1, -1};
     int adobe_tf = 0;
     size_t i = 2;
     size_t ecs = 0;
@@ -237,19 +237,19 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
             if (pl != 6 + 3u * nc) return LP_PARSE_NOT_JPEG;             // JERR_BAD_LENGTH
             progressive = m == 0xC2;
             if (m != 0xC0 && m != 0xC1 && m != 0xC2) { sof_unsupported = true; } // lossless, arithmetic: judged at SOS
-            if (prec != 8 || (nc != 1 && nc != 3)) sof_unsupported = true; // 12-bit, CMYK/YCCK, two-component
+            if (prec != 8 || (nc != 1 && nc != 3 && nc != 4)) sof_unsupported = true; // 12-bit, two-component
             sof_nc = nc;
             for (unsigned c = 0; c < nc; c++) {
                 const unsigned hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
                 if (hs < 1 || hs > 4 || vs < 1 || vs > 4) sof_bad_sampling = true; // JERR_BAD_SAMPLING, raised at the first SOS
-                if (c < 3) {
+                if (c < 4) {
                     cid[c] = p[6 + 3 * c];
                     j.hs[c] = (uint8_t)hs;
                     j.vs[c] = (uint8_t)vs;
                     tq[c] = p[8 + 3 * c];
                 }
             }
-            j.ncomp = (uint8_t)(nc <= 3 ? nc : 3);
+            j.ncomp = (uint8_t)(nc <= 4 ? nc : 4);
             have_sof = true;
         } else if (m == 0xDD) { // get_dri
             if (L != 4) return LP_PARSE_NOT_JPEG;
@@ -284,12 +284,12 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 // jpeg_make_d_derived_tbl rejects an index above 3 -- of the tables a scan actually builds: both in a sequential
                 // scan, only the DC or the AC one in a progressive scan (checked below)
                 if (!progressive && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
-                if (s < 3) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
+                if (s < 4) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
             if (!progressive && raw_scans.empty()) {
                 // A sequential file the baseline kernels do not take as it is -- fewer components in the first scan than in the frame
                 // (more scans follow), components in another order, table numbers 2 / 3 -- is decoded scan by scan like a progressive one.
-                seq_scans = ns != j.ncomp;
+                seq_scans = ns != j.ncomp || j.ncomp == 4; // four components (CMYK / YCCK): up to ten blocks per MCU, always scan by scan
                 for (unsigned s = 0; s < ns; s++) seq_scans = seq_scans || cur[s] != (int)s || (p[2 + 2 * s] >> 4) > 1 || (p[2 + 2 * s] & 15) > 1;
             }
             if (progressive || seq_scans) { // jdphuff.c start_pass_phuff_decoder / jdhuff.c start_pass_huff_decoder: one of up to LP_MAX_SCANS scans
@@ -403,10 +403,12 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     for (int c = 0; c < j.ncomp; c++) {
         for (int v = 0; v < j.vs[c]; v++)
             for (int h = 0; h < j.hs[c]; h++) {
-                if (bpm >= LP_MAX_BPM) return LP_PARSE_UNSUPPORTED;
-                j.blk_comp[bpm] = (uint8_t)c;
-                j.blk_h[bpm] = (uint8_t)h;
-                j.blk_v[bpm] = (uint8_t)v;
+                if (bpm >= LP_MAX_BPM && !(progressive || seq_scans)) return LP_PARSE_UNSUPPORTED;
+                if (bpm < 8) { // the per-block tables only serve the baseline kernels (at most LP_MAX_BPM blocks)
+                    j.blk_comp[bpm] = (uint8_t)c;
+                    j.blk_h[bpm] = (uint8_t)h;
+                    j.blk_v[bpm] = (uint8_t)v;
+                }
                 bpm++;
             }
         j.blk_first[c] = (uint8_t)(bpm - j.hs[c] * j.vs[c]);
@@ -420,13 +422,14 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     }
     j.bpm = (uint8_t)bpm;
     j.blkpack = 0;
-    for (unsigned b = 0; b < bpm; b++) {
+    for (unsigned b = 0; b < bpm && b < 8; b++) {
         const unsigned c = j.blk_comp[b];
         j.blkpack |= (uint64_t)(c | ((unsigned)td[c] << 2) | ((unsigned)ta[c] << 3)) << (4 * b);
     }
     j.total_blocks = j.mcus_x * j.mcus_y * bpm;
     // libjpeg's colour space guess (jdapimin.c default_decompress_parms)
     if (j.ncomp == 1) j.colorspace = 1;
+    else if (j.ncomp == 4) j.colorspace = saw_adobe ? (adobe_tf == 0 ? 4 : 5) : 4; // Adobe transform 2 (or an unknown one): YCCK; no marker: CMYK
     else if (saw_jfif) j.colorspace = 2;
     else if (saw_adobe) j.colorspace = adobe_tf == 0 ? 3 : 2;
     else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') j.colorspace = 3;

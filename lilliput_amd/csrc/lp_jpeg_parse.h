@@ -9,7 +9,7 @@
 enum {
     LP_PARSE_OK = 0,
     LP_PARSE_NOT_JPEG = 1,      // no SOI / broken marker structure      -> ErrInvalidImage
-    LP_PARSE_UNSUPPORTED = 2,   // progressive, arithmetic, 12-bit, CMYK, exotic sampling
+    LP_PARSE_UNSUPPORTED = 2,   // arithmetic coding, lossless, 12-bit, sampling factors above 2
     LP_PARSE_TRUNCATED = 3
 };
 

@@ -796,11 +796,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     const LpJpeg& img = imgs[blockIdx.z];
     if ((img.progressive != 0) != PROG) return;
     uint32_t by = blockIdx.y, c = 0;
-    if (by >= img.bh[0]) {
-        by -= img.bh[0];
-        c = 1;
-        if (img.ncomp > 1 && by >= img.bh[1]) { by -= img.bh[1]; c = 2; }
-    }
+    while (c + 1 < img.ncomp && by >= img.bh[c]) { by -= img.bh[c]; c++; } // at most three steps (four components: CMYK / YCCK)
     if (c >= img.ncomp || by >= img.bh[c]) return;
     const uint32_t bw = img.bw[c];
     if (blockIdx.x * (32 * IDCT_TPW) >= bw) return;
@@ -829,7 +825,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         if (PROG) {
             // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
             // its 128 bytes between them)
-            const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u);
+            const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u) + (c > 2 ? img.bw[2] * img.bh[2] : 0u);
             const int16_t* src = wide_arena /* = the progressive arena in this variant */ + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
 #pragma unroll
             for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;

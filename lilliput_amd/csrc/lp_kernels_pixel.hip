@@ -79,6 +79,33 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
         for (int i = 0; i < 4 && x0 + i < W; i++) out[x0 + i] = PY[(size_t)y * img.plane_stride[0] + x0 + i];
         return;
     }
+    if (img.ncomp == 4) {
+        // Four components: libjpeg hands cv::JpegDecoder CMYK rows -- the stored samples as they are, or jdcolor.c ycck_cmyk_convert
+        // for YCCK data (C, M, Y = 255 - R, G, B of the YCbCr triple, range limited; K unchanged) -- every component through its
+        // own (fancy) upsampler; OpenCV then maps x -> k - ((255 - x) * k >> 8) (imgcodecs utils.cpp icvCvt_CMYK2BGR_8u_C4C3R).
+        for (int i = 0; i < 4 && x0 + i < W; i++) {
+            int32_t v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int32_t hr = img.hmax / img.hs[c], vr = img.vmax / img.vs[c];
+                const int32_t dw = (W * img.hs[c] + img.hmax - 1) / img.hmax, dh = (H * img.vs[c] + img.vmax - 1) / img.vmax;
+                v[c] = upsampled(plane_arena + img.plane_off[c], img.plane_stride[c], dw, dh, hr, vr, x0 + i, y);
+            }
+            if (img.colorspace == 5) {
+                uint32_t b, g, r;
+                const int32_t cb = v[1] - 128, cr = v[2] - 128;
+                r = clamp8(255 - (v[0] + ((FIX16(1.40200) * cr + 32768) >> 16)));
+                b = clamp8(255 - (v[0] + ((FIX16(1.77200) * cb + 32768) >> 16)));
+                g = clamp8(255 - (v[0] + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16)));
+                v[0] = (int32_t)r; v[1] = (int32_t)g; v[2] = (int32_t)b;
+            }
+            const int32_t k = v[3];
+            out[(size_t)(x0 + i) * 3 + 2] = (uint8_t)(k - ((255 - v[0]) * k >> 8));
+            out[(size_t)(x0 + i) * 3 + 1] = (uint8_t)(k - ((255 - v[1]) * k >> 8));
+            out[(size_t)(x0 + i) * 3 + 0] = (uint8_t)(k - ((255 - v[2]) * k >> 8));
+        }
+        return;
+    }
     const uint8_t* PB = plane_arena + img.plane_off[1];
     const uint8_t* PR = plane_arena + img.plane_off[2];
     const int32_t hr = img.hmax / img.hs[1], vr = img.vmax / img.vs[1];

@@ -7,7 +7,8 @@
 #pragma once
 #include <stdint.h>
 
-#define LP_MAX_COMP 3
+#define LP_MAX_COMP 3           // components the subsequence-parallel baseline kernels take (grey, YCbCr, RGB)
+#define LP_GEOM_COMP 4          // components an image may have: CMYK / YCCK files go through the per-scan path (LpProgScan)
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
 #define LP_LUT_BITS 10          // first-level Huffman lookup width
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
@@ -44,24 +45,24 @@ struct LpJpeg {
     uint32_t total_blocks;
     uint32_t dri;               // MCUs per restart interval, 0 = none
     uint8_t ncomp, hmax, vmax, bpm;
-    uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB
+    uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB, 4 CMYK, 5 YCCK (four components: decoded to BGR the way cv::JpegDecoder does)
     uint8_t orientation;        // EXIF 1..8
     uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans are decoded on their own and coef_off counts
                                 // int16 elements in the progressive arena (see LpProgScan)
     uint8_t pad1;
-    uint8_t hs[LP_MAX_COMP], vs[LP_MAX_COMP];
-    uint8_t dc_tbl[LP_MAX_COMP], ac_tbl[LP_MAX_COMP];   // slots into LpHuffSet (0..1 / 2..3)
+    uint8_t hs[LP_GEOM_COMP], vs[LP_GEOM_COMP];
+    uint8_t dc_tbl[LP_GEOM_COMP], ac_tbl[LP_GEOM_COMP];   // slots into LpHuffSet (0..1 / 2..3)
     uint8_t blk_comp[8], blk_h[8], blk_v[8];            // per block-in-MCU
-    uint8_t blk_first[LP_MAX_COMP], pad2;               // index inside the MCU of a component's first block
+    uint8_t blk_first[LP_GEOM_COMP], pad2;               // index inside the MCU of a component's first block
     uint32_t pad3;
     uint64_t blkpack;           // 4 bits per block-in-MCU b (bits 4b..4b+3): component (2) | DC table id (1) << 2 | AC table id (1) << 3
-    uint32_t bw[LP_MAX_COMP], bh[LP_MAX_COMP];          // blocks per row / column (MCU padded)
+    uint32_t bw[LP_GEOM_COMP], bh[LP_GEOM_COMP];          // blocks per row / column (MCU padded)
     uint64_t coef_off;          // element offset of this image's blocks in the coefficient arenas (int8 blocks, int16 wide slots; /64 =
                                 // block offset); blocks are stored in DECODE order (MCU by MCU, blocks of an MCU in scan order),
                                 // 64 natural-order coefficients each
-    uint64_t plane_off[LP_MAX_COMP];                    // byte offset into the plane arena
-    uint32_t plane_stride[LP_MAX_COMP];                 // = bw*8
-    uint16_t qt[LP_MAX_COMP][64];                       // dequantisation table per component, natural order
+    uint64_t plane_off[LP_GEOM_COMP];                    // byte offset into the plane arena
+    uint32_t plane_stride[LP_GEOM_COMP];                 // = bw*8
+    uint16_t qt[LP_GEOM_COMP][64];                       // dequantisation table per component, natural order
     // ---- subsequence bookkeeping
     uint32_t sub_bits;          // subsequence size S of this image in bits (multiple of 32): chosen so that the subsequence
                                 // count lands just below a multiple of 256 -- whole Huffman workgroups, no nearly-empty tail block

@@ -42,7 +42,7 @@ typedef struct {
     int scan_path;    /* a sequential file decoded scan by scan (several scans, or components in another order than the frame's) */
     int hmax, vmax;
     int mcus_x, mcus_y;
-    int colorspace;   /* 1 gray, 2 YCbCr, 3 RGB */
+    int colorspace;   /* 1 gray, 2 YCbCr, 3 RGB, 4 CMYK, 5 YCCK */
     size_t ecs_off;   /* offset of first entropy-coded byte */
     uint16_t qt[4][64]; /* natural order */
     int qt_present[4];
@@ -180,12 +180,12 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
             in->height = rd16(p + 1);
             in->width = rd16(p + 3);
             if (in->height == 0 || in->width == 0 || nc == 0 || pl != 6 + 3 * nc) return LO_ERR_FORMAT;
-            if ((m != 0xC0 && m != 0xC1 && m != 0xC2) || p[0] != 8 || (nc != 1 && nc != 3)) unsupported = 1;
-            in->ncomp = nc <= 3 ? nc : 3;
+            if ((m != 0xC0 && m != 0xC1 && m != 0xC2) || p[0] != 8 || (nc != 1 && nc != 3 && nc != 4)) unsupported = 1;
+            in->ncomp = nc <= 4 ? nc : 4;
             for (int c = 0; c < nc; c++) {
                 int hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
                 if (hs < 1 || hs > 4 || vs < 1 || vs > 4) bad_sampling = 1; /* jdinput.c initial_setup, at the first SOS */
-                if (c < 3) { in->cid[c] = p[6 + 3 * c]; in->hs[c] = hs; in->vs[c] = vs; in->tq[c] = p[8 + 3 * c]; }
+                if (c < 4) { in->cid[c] = p[6 + 3 * c]; in->hs[c] = hs; in->vs[c] = vs; in->tq[c] = p[8 + 3 * c]; }
             }
             have_sof = 1;
         } else if (m == 0xDD) {
@@ -222,7 +222,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
                 in->td[c] = t >> 4;
                 in->ta[c] = t & 15;
             }
-            if (ns != in->ncomp || !order_ok) in->scan_path = 1; /* non-interleaved / multi-scan: walked by decode_coefs_progressive */
+            if (ns != in->ncomp || !order_ok || in->ncomp == 4) in->scan_path = 1; /* non-interleaved / multi-scan: walked by decode_coefs_progressive */
             in->ecs_off = seg_end;
             break;
         }
@@ -278,8 +278,9 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
     in->mcus_y = (in->height + 8 * in->vmax - 1) / (8 * in->vmax);
     /* libjpeg colour-space guess (jdapimin.c default_decompress_parms) */
     if (in->ncomp == 1) in->colorspace = 1;
-    else if (in->saw_jfif) in->colorspace = 2;
-    else if (in->saw_adobe) in->colorspace = (in->adobe_transform == 0) ? 3 : 2;
+    else if (in->saw_jfif && in->ncomp == 3) in->colorspace = 2;
+    else if (in->saw_adobe && in->ncomp == 3) in->colorspace = (in->adobe_transform == 0) ? 3 : 2;
+    else if (in->ncomp == 4) in->colorspace = in->saw_adobe ? (in->adobe_transform == 0 ? 4 : 5) : 4; /* transform 2 or unknown: YCCK */
     else if (in->cid[0] == 'R' && in->cid[1] == 'G' && in->cid[2] == 'B') in->colorspace = 3;
     else in->colorspace = 2;
     return LO_OK;
@@ -862,13 +863,32 @@ int lo_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, 
     if (C == 1) {
         upsample_plane(&D, 0, out);
     } else {
-        uint8_t* up[3];
-        for (int c = 0; c < 3; c++) { up[c] = (uint8_t*)malloc((size_t)W * H); upsample_plane(&D, c, up[c]); }
+        const int nc = D.in.ncomp;
+        uint8_t* up[4] = {0, 0, 0, 0};
+        for (int c = 0; c < nc; c++) { up[c] = (uint8_t*)malloc((size_t)W * H); upsample_plane(&D, c, up[c]); }
         for (size_t i = 0; i < (size_t)W * H; i++) {
-            if (D.in.colorspace == 3) { out[3 * i] = up[2][i]; out[3 * i + 1] = up[1][i]; out[3 * i + 2] = up[0][i]; }
+            if (nc == 4) {
+                /* libjpeg hands cv::JpegDecoder CMYK (JCS_CMYK): the stored values as they are, or jdcolor.c ycck_cmyk_convert for
+                   YCCK data (C, M, Y = 255 - R, G, B of the YCbCr triple, range limited; K unchanged). OpenCV then applies
+                   icvCvt_CMYK2BGR_8u_C4C3R (imgcodecs utils.cpp): x -> k - ((255 - x) * k >> 8). */
+                int cmyk[4] = {up[0][i], up[1][i], up[2][i], up[3][i]};
+                if (D.in.colorspace == 5) {
+                    uint8_t bgr[3];
+                    int cb = up[1][i] - 128, cr = up[2][i] - 128, y = up[0][i];
+                    int r = y + (int)((FIX16(1.40200) * cr + 32768) >> 16);
+                    int b = y + (int)((FIX16(1.77200) * cb + 32768) >> 16);
+                    int g = y + (int)((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16);
+                    bgr[0] = clamp8(255 - b); bgr[1] = clamp8(255 - g); bgr[2] = clamp8(255 - r);
+                    cmyk[0] = bgr[2]; cmyk[1] = bgr[1]; cmyk[2] = bgr[0];
+                }
+                const int k = cmyk[3];
+                out[3 * i + 2] = (uint8_t)(k - ((255 - cmyk[0]) * k >> 8));
+                out[3 * i + 1] = (uint8_t)(k - ((255 - cmyk[1]) * k >> 8));
+                out[3 * i] = (uint8_t)(k - ((255 - cmyk[2]) * k >> 8));
+            } else if (D.in.colorspace == 3) { out[3 * i] = up[2][i]; out[3 * i + 1] = up[1][i]; out[3 * i + 2] = up[0][i]; }
             else lo_ycc_to_bgr(up[0][i], up[1][i], up[2][i], out + 3 * i);
         }
-        for (int c = 0; c < 3; c++) free(up[c]);
+        for (int c = 0; c < nc; c++) free(up[c]);
     }
     dec_free(&D);
     return LO_OK;

@@ -52,7 +52,21 @@ def ref():
         _ref = _load(os.path.join("_ref", "libref.so"))
         if _ref is not None:
             _ref.ref_jpeg_encode.restype = C.c_long
+            cv = ref_cv()
+            if cv is not None and hasattr(_ref, "ref_set_cmyk2bgr"):  # four-component JPEGs go through OpenCV's own CMYK -> BGR rows
+                _ref.ref_set_cmyk2bgr(C.cast(cv.ref_cv_cmyk2bgr, C.c_void_p))
     return _ref
+
+
+_refcv = None
+
+
+def ref_cv():
+    """OpenCV 4.11's icvCvt_CMYK2BGR_8u_C4C3R out of the reference's libopencv_imgcodecs.a (oracle/ref_cv_driver.cpp), or None."""
+    global _refcv
+    if _refcv is None:
+        _refcv = _load(os.path.join("_ref", "librefcv.so"))
+    return _refcv
 
 
 _refmeta = None

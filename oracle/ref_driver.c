@@ -23,6 +23,10 @@ struct err_mgr { struct jpeg_error_mgr pub; jmp_buf jb; };
 static void on_error(j_common_ptr c) { longjmp(((struct err_mgr*)c->err)->jb, 1); }
 static void on_msg(j_common_ptr c) { (void)c; }
 
+/* set by the Python side to librefcv.so's ref_cv_cmyk2bgr when that library could be built */
+static void (*ref_cmyk2bgr_hook)(const uint8_t* cmyk, uint8_t* bgr, int n) = 0;
+void ref_set_cmyk2bgr(void (*f)(const uint8_t*, uint8_t*, int)) { ref_cmyk2bgr_hook = f; }
+
 int ref_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* w, int* h, int* ch)
 {
     struct jpeg_decompress_struct ci;
@@ -36,11 +40,23 @@ int ref_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap,
     jpeg_read_header(&ci, TRUE);
     if (ci.num_components == 1) { ci.out_color_space = JCS_GRAYSCALE; ci.out_color_components = 1; }
     else if (ci.num_components == 3) { ci.out_color_space = JCS_EXT_BGR; ci.out_color_components = 3; }
+    else if (ci.num_components == 4) { ci.out_color_space = JCS_CMYK; ci.out_color_components = 4; } /* cv::JpegDecoder::readData */
     else { jpeg_destroy_decompress(&ci); return -2; }
     jpeg_start_decompress(&ci);
-    *w = (int)ci.output_width; *h = (int)ci.output_height; *ch = ci.out_color_components;
+    *w = (int)ci.output_width; *h = (int)ci.output_height; *ch = ci.out_color_components == 4 ? 3 : ci.out_color_components;
     size_t stride = (size_t)*w * *ch;
     if (stride * *h > cap) { jpeg_destroy_decompress(&ci); return -3; }
+    if (ci.out_color_components == 4) { /* row by row through OpenCV's own icvCvt_CMYK2BGR_8u_C4C3R (ref_cv_driver.cpp, from the reference's archive) */
+        if (!ref_cmyk2bgr_hook) { jpeg_destroy_decompress(&ci); return -2; }
+        uint8_t* rowbuf4 = (uint8_t*)malloc((size_t)*w * 4);
+        while (ci.output_scanline < ci.output_height) {
+            JSAMPROW row = rowbuf4;
+            uint8_t* dst = out + stride * ci.output_scanline;
+            jpeg_read_scanlines(&ci, &row, 1);
+            ref_cmyk2bgr_hook(rowbuf4, dst, *w);
+        }
+        free(rowbuf4);
+    }
     while (ci.output_scanline < ci.output_height) {
         JSAMPROW row = out + stride * ci.output_scanline;
         jpeg_read_scanlines(&ci, &row, 1);
@@ -196,12 +212,19 @@ long ref_jpeg_encode_ex(const uint8_t* px, int W, int H, int ncomp, int mode, co
     ci.image_width = (JDIMENSION)W;
     ci.image_height = (JDIMENSION)H;
     ci.input_components = ncomp;
-    ci.in_color_space = ncomp == 1 ? JCS_GRAYSCALE : JCS_RGB;
+    ci.in_color_space = ncomp == 1 ? JCS_GRAYSCALE : ncomp == 4 ? JCS_CMYK : JCS_RGB;
     jpeg_set_defaults(&ci);
+    /* four components: px is CMYK. mode 0: stored as CMYK with an Adobe marker (transform 0); 1: as YCCK (transform 2); 2: CMYK, no
+     * Adobe marker; 3: YCCK data without the marker (a decoder then takes it for CMYK) */
+    if (ncomp == 4 && (mode == 1 || mode == 3)) jpeg_set_colorspace(&ci, JCS_YCCK);
+    if (ncomp == 4 && mode >= 2) ci.write_Adobe_marker = FALSE;
     if (ncomp == 3 && mode == 1) jpeg_set_colorspace(&ci, JCS_RGB);
     if (ncomp == 3 && mode >= 2) { ci.write_JFIF_header = FALSE; ci.write_Adobe_marker = mode == 2; }
     jpeg_set_quality(&ci, quality, force_baseline);
-    for (int c = 0; c < ncomp; c++) { ci.comp_info[c].h_samp_factor = samp[2 * c]; ci.comp_info[c].v_samp_factor = samp[2 * c + 1]; }
+    for (int c = 0; c < ncomp; c++) { /* the fourth component (K) samples like the first */
+        ci.comp_info[c].h_samp_factor = samp[2 * (c == 3 ? 0 : c)];
+        ci.comp_info[c].v_samp_factor = samp[2 * (c == 3 ? 0 : c) + 1];
+    }
     ci.restart_interval = (unsigned)restart_interval;
     ci.optimize_coding = optimize & 1;
     /* optimize bit 1: jpeg_simple_progression; bit 2: spectral selection only, one DC scan per component;

@@ -2,8 +2,9 @@
 colour spaces and table widths Pillow cannot produce (4:4:0, 2x2 luma with custom chroma factors, RGB-in-JPEG with an Adobe
 marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row, progressive
 files with libjpeg's default script, a spectral-selection-only script and a deep successive-approximation script, sequential
-files in several scans and with three Huffman table pairs), and
-tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file.
+files in several scans and with three Huffman table pairs, four-component CMYK / YCCK files), and
+tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file (four-component files: libjpeg's
+CMYK rows through OpenCV's own icvCvt_CMYK2BGR_8u_C4C3R out of the reference's libopencv_imgcodecs.a, oracle/ref_cv_driver.cpp).
 Run in the build container (needs /root/reference)."""
 import ctypes as C, hashlib, json, os, sys
 import numpy as np
@@ -23,9 +24,15 @@ def photo(h, w, c):
     img = np.clip(img, 0, 255).astype(np.uint8)
     return np.ascontiguousarray(img[:, :, 0] if c == 1 else img)
 
+def photo4(h, w):
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 95 * np.sin(x / 13.0 + k) + 35 * np.cos(y / 7.0 - k) for k in range(4)], -1) + rng.normal(0, 9, (h, w, 4))
+    return np.ascontiguousarray(np.clip(img, 0, 255).astype(np.uint8))
+
+
 def enc(name, h, w, ncomp, mode, samp, q, force_baseline=1, dri=0, optimize=0):
-    px = photo(h, w, ncomp)
-    buf = np.zeros(h * w * 3 + 65536, np.uint8)
+    px = photo4(h, w) if ncomp == 4 else photo(h, w, ncomp)
+    buf = np.zeros(h * w * 4 + 65536, np.uint8)
     n = R.ref_jpeg_encode_ex(px.ctypes.data_as(C.c_void_p), w, h, ncomp, mode, (C.c_int * 6)(*samp), q, force_baseline, dri, optimize, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
     assert n > 0, name
     open(os.path.join(out_dir, name + ".jpg"), "wb").write(buf[:n].tobytes())
@@ -64,6 +71,16 @@ enc("seq_noninterleaved_444_dri4_opt", 33, 58, 3, 0, S444, 92, dri=4, optimize=1
 enc("seq_two_scans_422", 64, 49, 3, 0, S422, 75, optimize=16 + 64)
 enc("seq_three_table_pairs_420", 55, 90, 3, 0, S420, 80, optimize=33)
 enc("seq_three_table_pairs_noninterleaved_440", 47, 47, 3, 0, S440, 60, dri=2, optimize=16 + 33)
+# four components (px = CMYK): mode 0 CMYK + Adobe marker, 1 YCCK + Adobe marker, 2 CMYK without a marker, 3 YCCK data without a marker
+# (decoders take it for CMYK); K samples like the first component
+enc("cmyk_adobe_444", 52, 61, 4, 0, S444, 90)
+enc("cmyk_adobe_420k_dri3", 45, 77, 4, 0, S420, 80, dri=3)
+enc("ycck_adobe_420", 66, 70, 4, 1, S420, 85)
+enc("ycck_adobe_422_opt", 37, 95, 4, 1, S422, 92, optimize=1)
+enc("ycck_adobe_440_progressive", 58, 41, 4, 1, S440, 75, optimize=2)
+enc("cmyk_nomarker_444_progressive", 30, 44, 4, 2, S444, 88, optimize=2)
+enc("ycck_nomarker_420_noninterleaved", 50, 50, 4, 3, S420, 70, optimize=16)
+enc("cmyk_adobe_tiny", 1, 3, 4, 0, S420, 90)
 gold = {}
 for f in sorted(os.listdir(out_dir)):
     d = open(os.path.join(out_dir, f), "rb").read()

@@ -127,6 +127,18 @@ def test_exotic_fixtures_on_device(batch, oracle):
         exp = oracle.jpeg_decode(data)
         assert got.shape == exp.shape and np.array_equal(got, exp), name
         assert "%dx%dx%d:%s" % (got.shape[0], got.shape[1], got.shape[2], hashlib.sha1(got.tobytes()).hexdigest()[:16]) == gold[name], name
+    import lilliput_amd as la
+
+    ops = la.ImageOps(512)  # the same files through NewDecoder / Header / ImageOps.Transform, as lilliput's callers drive them
+    for name in ("cmyk_adobe_420k_dri3.jpg", "ycck_adobe_420.jpg", "seq_two_scans_422.jpg", "prog_deep_420.jpg"):
+        d = la.Decoder(files[name])
+        h = d.Header()
+        exp = oracle.jpeg_decode(files[name])
+        assert (h["height"], h["width"]) == exp.shape[:2] and d.Description() == "JPEG", name
+        out = ops.Transform(d, la.ImageOptions(".jpeg", 24, 24, la.ImageOpsFit, False, {la.JpegQuality: 85}))
+        d.Close()
+        assert out == oracle.transform_jpeg_thumbnail(files[name], 24, 24, 85), name
+    ops.Close()
     names = list(files)
     for tw, th in ((20, 20), (13, 31)):
         res = batch.transform([files[n] for n in names], tw, th, quality=85)

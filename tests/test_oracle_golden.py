@@ -169,3 +169,23 @@ def test_restatement_vs_reference_library_on_damaged_progressive_files(oracle):
                 a, b = oracle.jpeg_decode(d), oracle.ref_jpeg_decode(d)
                 n_px += int(np.array_equal(a, b))
     assert n_ok > 300 and n_err > 20 and n_px > 0.97 * n_ok, (n_ok, n_err, n_px)
+
+
+def test_cmyk_to_bgr_rule_is_opencvs(oracle):
+    """Four-component JPEGs: cv::JpegDecoder asks libjpeg for CMYK rows and runs them through icvCvt_CMYK2BGR_8u_C4C3R. The rule the
+    oracle (and the device kernel) states, x -> k - ((255 - x) * k >> 8), against the compiled function out of the reference's own
+    libopencv_imgcodecs.a on 200 k random quadruples and every (x, k) pair."""
+    cv = oracle.ref_cv()
+    if cv is None:
+        pytest.skip("oracle/_ref/librefcv.so not built (needs /root/reference)")
+    import ctypes as C
+
+    rng = np.random.default_rng(0)
+    grid = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 2)
+    cmyk = np.concatenate([rng.integers(0, 256, (200000, 4)), np.stack([grid[:, 0], 255 - grid[:, 0], grid[:, 0] // 2, grid[:, 1]], -1)]).astype(np.uint8)
+    got = np.zeros((len(cmyk), 3), np.uint8)
+    cv.ref_cv_cmyk2bgr(cmyk.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), len(cmyk))
+    c = cmyk.astype(np.int32)
+    k = c[:, 3:4]
+    exp = (k - (((255 - c[:, :3]) * k) >> 8))[:, ::-1].astype(np.uint8)
+    assert np.array_equal(got, exp)
