@@ -196,7 +196,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
                                                       opt->normalize_orientation != 0, OW, OH);
             int ix, iy;
-            const bool fused = plan.resize && j.ncomp != 4 && lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) == 1;
+            const bool fused = plan.resize && j.ncomp != 4 && !j.generic_sampling && lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) == 1;
             const size_t cn = j.ncomp == 1 ? 1 : 3, fb = (size_t)j.width * j.height * cn;
             if (!fused) need += fb + 512 + (j.orientation != 1 ? fb + 512 : 0);
             if (plan.resize) need += (size_t)plan.out_w * plan.out_h * cn + 512;
@@ -221,7 +221,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
                                                       opt->normalize_orientation != 0, OW, OH);
             plans[(size_t)k] = plan;
             int ix = 1, iy = 1;
-            if (j.ncomp == 4) continue; // CMYK / YCCK: converted to a BGR frame first (the fused kernels read grey / YCbCr / RGB planes)
+            if (j.ncomp == 4 || j.generic_sampling) continue; // CMYK / YCCK, unusual sampling factors: converted to a BGR frame first (the fused kernels read grey / YCbCr / RGB planes)
             if (!plan.resize || lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) != 1) continue;
             // oriented-frame rectangle of destination (dx, dy) -> rectangle of the un-oriented decoded image (cv::ExifTransform inverse)
             auto map = [&](int dx, int dy, int* fx, int* fy) {

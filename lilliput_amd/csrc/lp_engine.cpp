@@ -306,7 +306,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         max_sub_ = std::max(max_sub_, j.sub_cap);
         if (!want_frame || want_frame[i]) {
             any_frame = true;
-            const bool f420 = j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4;
+            const bool f420 = j.ncomp == 3 && !j.generic_sampling && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4;
             any_420 = any_420 || f420;
             any_generic = any_generic || !f420;
             max_w_ = std::max(max_w_, j.width);

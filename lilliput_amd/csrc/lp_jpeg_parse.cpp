@@ -290,7 +290,14 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 // A sequential file the baseline kernels do not take as it is -- fewer components in the first scan than in the frame
                 // (more scans follow), components in another order, table numbers 2 / 3 -- is decoded scan by scan like a progressive one.
                 seq_scans = ns != j.ncomp || j.ncomp == 4; // four components (CMYK / YCCK): up to ten blocks per MCU, always scan by scan
+                // sampling factors the baseline kernels do not take (anything but luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma): same walk
+                if (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1 || j.hs[0] > 2 || j.vs[0] > 2)) seq_scans = true;
                 for (unsigned s = 0; s < ns; s++) seq_scans = seq_scans || cur[s] != (int)s || (p[2 + 2 * s] >> 4) > 1 || (p[2 + 2 * s] & 15) > 1;
+            }
+            if (ns > 1) { // jdinput.c per_scan_setup: an interleaved MCU holds at most D_MAX_BLOCKS_IN_MCU = 10 blocks
+                unsigned blocks = 0;
+                for (unsigned s = 0; s < ns; s++) blocks += j.hs[cur[s]] * j.vs[cur[s]];
+                if (blocks > 10) return LP_PARSE_NOT_JPEG;               // JERR_BAD_MCU_SIZE
             }
             if (progressive || seq_scans) { // jdphuff.c start_pass_phuff_decoder / jdhuff.c start_pass_huff_decoder: one of up to LP_MAX_SCANS scans
                 RawScan rs;
@@ -385,7 +392,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     if (j.ncomp == 1) { j.hs[0] = j.vs[0] = 1; }
     j.hmax = j.vmax = 1;
     for (int c = 0; c < j.ncomp; c++) {
-        if (j.hs[c] < 1 || j.hs[c] > 2 || j.vs[c] < 1 || j.vs[c] > 2) return LP_PARSE_UNSUPPORTED;
+        if (j.hs[c] < 1 || j.hs[c] > 4 || j.vs[c] < 1 || j.vs[c] > 4) return LP_PARSE_NOT_JPEG;
         if (j.hs[c] > j.hmax) j.hmax = j.hs[c];
         if (j.vs[c] > j.vmax) j.vmax = j.vs[c];
         if ((progressive || seq_scans) && !latched[c]) { memset(latched_qt[c], 0, sizeof(latched_qt[c])); continue; } // in no scan at all: stays zero (libjpeg: never dequantised)
@@ -396,7 +403,9 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
             return LP_PARSE_NOT_JPEG;
     }
-    if (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1)) return LP_PARSE_UNSUPPORTED;
+    for (int c = 0; c < j.ncomp; c++) // jdsample.c jinit_upsampler refuses fractional ratios when decoding starts (JERR_FRACT_SAMPLE_NOTIMPL)
+        if (j.hmax % j.hs[c] || j.vmax % j.vs[c]) return LP_PARSE_UNSUPPORTED;
+    j.generic_sampling = (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1 || j.hs[0] > 2 || j.vs[0] > 2)) || j.ncomp == 4;
     j.mcus_x = (j.width + 8 * j.hmax - 1) / (8 * j.hmax);
     j.mcus_y = (j.height + 8 * j.vmax - 1) / (8 * j.vmax);
     unsigned bpm = 0;

@@ -28,6 +28,7 @@ __device__ __forceinline__ int32_t upsampled(const uint8_t* __restrict__ P, uint
                                              int32_t x, int32_t y)
 {
     if (hr == 1 && vr == 1) return P[(size_t)y * stride + x];
+    if (hr > 2 || vr > 2) return P[(size_t)(y / vr) * stride + x / hr]; // int_upsample: every ratio but 2:1 / 1:2 / 2:2 is plain replication
     // jdsample.c jinit_upsampler picks the fancy h2v1 / h2v2 routines only when downsampled_width > 2: the chroma of an image
     // up to 4 pixels wide is plainly replicated (vertically as well in the h2v2 case)
     if (hr == 2 && dw <= 2) return P[(size_t)(vr == 2 ? y >> 1 : y) * stride + (x >> 1)];
@@ -72,37 +73,44 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame(const LpJpeg* __restrict__
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= W || y >= H || f.off == 0) return; // off == 0: this image takes the fused path
-    if (img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4) return; // k_ycc_to_frame_420
+    if (img.ncomp == 3 && !img.generic_sampling && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4) return; // k_ycc_to_frame_420
     const uint8_t* PY = plane_arena + img.plane_off[0];
     uint8_t* out = frame_arena + f.off + (size_t)y * f.stride;
     if (img.ncomp == 1) {
         for (int i = 0; i < 4 && x0 + i < W; i++) out[x0 + i] = PY[(size_t)y * img.plane_stride[0] + x0 + i];
         return;
     }
-    if (img.ncomp == 4) {
-        // Four components: libjpeg hands cv::JpegDecoder CMYK rows -- the stored samples as they are, or jdcolor.c ycck_cmyk_convert
-        // for YCCK data (C, M, Y = 255 - R, G, B of the YCbCr triple, range limited; K unchanged) -- every component through its
-        // own (fancy) upsampler; OpenCV then maps x -> k - ((255 - x) * k >> 8) (imgcodecs utils.cpp icvCvt_CMYK2BGR_8u_C4C3R).
+    if (img.ncomp == 4 || img.generic_sampling) {
+        // Every component through its own upsampler (jdsample.c picks one per component). Three components: the usual colour
+        // conversion. Four: libjpeg hands cv::JpegDecoder CMYK rows -- the stored samples as they are, or jdcolor.c
+        // ycck_cmyk_convert for YCCK data (C, M, Y = 255 - R, G, B of the YCbCr triple, range limited; K unchanged) -- and OpenCV
+        // maps x -> k - ((255 - x) * k >> 8) (imgcodecs utils.cpp icvCvt_CMYK2BGR_8u_C4C3R).
         for (int i = 0; i < 4 && x0 + i < W; i++) {
-            int32_t v[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
+            int32_t v[4] = {0, 0, 0, 0};
+            for (int c = 0; c < (int)img.ncomp; c++) {
                 const int32_t hr = img.hmax / img.hs[c], vr = img.vmax / img.vs[c];
                 const int32_t dw = (W * img.hs[c] + img.hmax - 1) / img.hmax, dh = (H * img.vs[c] + img.vmax - 1) / img.vmax;
                 v[c] = upsampled(plane_arena + img.plane_off[c], img.plane_stride[c], dw, dh, hr, vr, x0 + i, y);
             }
-            if (img.colorspace == 5) {
+            uint8_t* o = out + (size_t)(x0 + i) * 3;
+            if (img.ncomp == 3) {
                 uint32_t b, g, r;
+                if (img.colorspace == 3) { r = (uint32_t)v[0]; g = (uint32_t)v[1]; b = (uint32_t)v[2]; }
+                else ycc_to_bgr(v[0], v[1], v[2], b, g, r);
+                o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+                continue;
+            }
+            if (img.colorspace == 5) {
                 const int32_t cb = v[1] - 128, cr = v[2] - 128;
-                r = clamp8(255 - (v[0] + ((FIX16(1.40200) * cr + 32768) >> 16)));
-                b = clamp8(255 - (v[0] + ((FIX16(1.77200) * cb + 32768) >> 16)));
-                g = clamp8(255 - (v[0] + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16)));
+                const uint32_t r = clamp8(255 - (v[0] + ((FIX16(1.40200) * cr + 32768) >> 16)));
+                const uint32_t b = clamp8(255 - (v[0] + ((FIX16(1.77200) * cb + 32768) >> 16)));
+                const uint32_t g = clamp8(255 - (v[0] + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + 32768) >> 16)));
                 v[0] = (int32_t)r; v[1] = (int32_t)g; v[2] = (int32_t)b;
             }
             const int32_t k = v[3];
-            out[(size_t)(x0 + i) * 3 + 2] = (uint8_t)(k - ((255 - v[0]) * k >> 8));
-            out[(size_t)(x0 + i) * 3 + 1] = (uint8_t)(k - ((255 - v[1]) * k >> 8));
-            out[(size_t)(x0 + i) * 3 + 0] = (uint8_t)(k - ((255 - v[2]) * k >> 8));
+            o[2] = (uint8_t)(k - ((255 - v[0]) * k >> 8));
+            o[1] = (uint8_t)(k - ((255 - v[1]) * k >> 8));
+            o[0] = (uint8_t)(k - ((255 - v[2]) * k >> 8));
         }
         return;
     }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void k_ycc_to_frame_420(const LpJpeg* __restri
 {
     const LpJpeg& img = imgs[blockIdx.z];
     const LpFrame& f = dsts[blockIdx.z];
-    if (f.off == 0 || !(img.ncomp == 3 && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4)) return; // generic kernel's job (incl. the non-fancy upsampling of very narrow images)
+    if (f.off == 0 || !(img.ncomp == 3 && !img.generic_sampling && img.colorspace == 2 && img.hs[0] == 2 && img.vs[0] == 2 && img.width > 4)) return; // generic kernel's job (incl. the non-fancy upsampling of very narrow images)
     const int32_t W = (int32_t)img.width, H = (int32_t)img.height;
     const int32_t x0 = (int32_t)(blockIdx.x * 64 + (threadIdx.x & 63)) * 8, cy = (int32_t)(blockIdx.y * 4 + (threadIdx.x >> 6));
     if (x0 >= W || 2 * cy >= H) return;

@@ -49,7 +49,8 @@ struct LpJpeg {
     uint8_t orientation;        // EXIF 1..8
     uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans are decoded on their own and coef_off counts
                                 // int16 elements in the progressive arena (see LpProgScan)
-    uint8_t pad1;
+    uint8_t generic_sampling;   // 1: sampling factors other than luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma (4:1:1, 4:1:0, chroma larger
+                                // than luma, CMYK ...): every component goes through its own upsampler in k_ycc_to_frame, no fused resample
     uint8_t hs[LP_GEOM_COMP], vs[LP_GEOM_COMP];
     uint8_t dc_tbl[LP_GEOM_COMP], ac_tbl[LP_GEOM_COMP];   // slots into LpHuffSet (0..1 / 2..3)
     uint8_t blk_comp[8], blk_h[8], blk_v[8];            // per block-in-MCU

@@ -222,7 +222,14 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
                 in->td[c] = t >> 4;
                 in->ta[c] = t & 15;
             }
-            if (ns != in->ncomp || !order_ok || in->ncomp == 4) in->scan_path = 1; /* non-interleaved / multi-scan: walked by decode_coefs_progressive */
+            if (ns > 1) { /* jdinput.c per_scan_setup: JERR_BAD_MCU_SIZE */
+                int blocks = 0;
+                for (int s = 0; s < ns; s++) blocks += in->hs[cur[s]] * in->vs[cur[s]];
+                if (blocks > 10) return LO_ERR_FORMAT;
+            }
+            if (ns != in->ncomp || !order_ok || in->ncomp == 4) in->scan_path = 1;
+            /* sampling other than luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma: same per-scan walk (any MCU shape) */
+            if (in->ncomp == 3 && (in->hs[1] != 1 || in->vs[1] != 1 || in->hs[2] != 1 || in->vs[2] != 1 || in->hs[0] > 2 || in->vs[0] > 2)) in->scan_path = 1; /* non-interleaved / multi-scan: walked by decode_coefs_progressive */
             in->ecs_off = seg_end;
             break;
         }
@@ -248,7 +255,7 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
     in->hmax = in->vmax = 1;
     if (in->ncomp == 1) in->hs[0] = in->vs[0] = 1; /* a single-component scan is non-interleaved: one block per MCU whatever the factors say */
     for (int c = 0; c < in->ncomp; c++) {
-        if (in->hs[c] < 1 || in->hs[c] > 2 || in->vs[c] < 1 || in->vs[c] > 2) return LO_ERR_UNSUPPORTED;
+        if (in->hs[c] < 1 || in->hs[c] > 4 || in->vs[c] < 1 || in->vs[c] > 4) return LO_ERR_FORMAT;
         if (in->hs[c] > in->hmax) in->hmax = in->hs[c];
         if (in->vs[c] > in->vmax) in->vmax = in->vs[c];
         if (in->tq[c] > 3 || !in->qt_present[in->tq[c]]) return LO_ERR_FORMAT;
@@ -273,7 +280,8 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
         }
     }
     if (in->ncomp == 1) { in->hs[0] = in->vs[0] = 1; in->hmax = in->vmax = 1; }
-    if (in->ncomp == 3 && (in->hs[1] != 1 || in->vs[1] != 1 || in->hs[2] != 1 || in->vs[2] != 1)) return LO_ERR_UNSUPPORTED;
+    for (int c = 0; c < in->ncomp; c++) /* jdsample.c jinit_upsampler: JERR_FRACT_SAMPLE_NOTIMPL (raised when decoding starts) */
+        if (in->hmax % in->hs[c] || in->vmax % in->vs[c]) return LO_ERR_UNSUPPORTED;
     in->mcus_x = (in->width + 8 * in->hmax - 1) / (8 * in->hmax);
     in->mcus_y = (in->height + 8 * in->vmax - 1) / (8 * in->vmax);
     /* libjpeg colour-space guess (jdapimin.c default_decompress_parms) */
@@ -513,6 +521,11 @@ static int decode_coefs_progressive(const uint8_t* d, size_t n, lo_dec* D)
                 cur[s] = c;
                 for (int q = 0; q < s; q++) if (cur[q] == c) return LO_ERR_FORMAT;
                 sc[s] = c; std_[s] = p[2 + 2 * s] >> 4; sta[s] = p[2 + 2 * s] & 15; /* only the table the scan builds is range-checked */
+            }
+            if (ns > 1) { /* JERR_BAD_MCU_SIZE */
+                int blocks = 0;
+                for (int s = 0; s < ns; s++) blocks += in->hs[sc[s]] * in->vs[sc[s]];
+                if (blocks > 10) return LO_ERR_FORMAT;
             }
             for (int s = 0; s < ns; s++) { /* jdinput.c latch_quant_tables */
                 int c = sc[s];
@@ -787,6 +800,9 @@ static void upsample_plane(const lo_dec* D, int c, uint8_t* out)
     int dh = (H * in->vs[c] + in->vmax - 1) / in->vmax;
     if (hr == 1 && vr == 1) {
         for (int y = 0; y < H; y++) memcpy(out + (size_t)y * W, P + (size_t)y * pw, W);
+    } else if (hr > 2 || vr > 2) { /* int_upsample: every ratio but 2:1 / 1:2 / 2:2 is plain replication */
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) out[(size_t)y * W + x] = P[(size_t)(y / vr) * pw + x / hr];
     } else if (hr == 2 && dw <= 2) {
         /* jdsample.c jinit_upsampler: the fancy h2v1 / h2v2 routines are only chosen when downsampled_width > 2; narrower
            components (images up to 4 pixels wide) get plain pixel replication, vertically too (h2v2_upsample) */

@@ -2,7 +2,7 @@
 colour spaces and table widths Pillow cannot produce (4:4:0, 2x2 luma with custom chroma factors, RGB-in-JPEG with an Adobe
 marker, YCbCr without JFIF, 16-bit quantisation tables / SOF1, restart intervals that are not a multiple of a row, progressive
 files with libjpeg's default script, a spectral-selection-only script and a deep successive-approximation script, sequential
-files in several scans and with three Huffman table pairs, four-component CMYK / YCCK files), and
+files in several scans and with three Huffman table pairs, four-component CMYK / YCCK files, sampling factors 3 and 4 and chroma sampled finer than luma), and
 tests/golden/exotic_golden.json = "<h>x<w>x<c>:<sha1 of the pixels the reference's libjpeg decodes>" per file (four-component files: libjpeg's
 CMYK rows through OpenCV's own icvCvt_CMYK2BGR_8u_C4C3R out of the reference's libopencv_imgcodecs.a, oracle/ref_cv_driver.cpp).
 Run in the build container (needs /root/reference)."""
@@ -81,6 +81,13 @@ enc("ycck_adobe_440_progressive", 58, 41, 4, 1, S440, 75, optimize=2)
 enc("cmyk_nomarker_444_progressive", 30, 44, 4, 2, S444, 88, optimize=2)
 enc("ycck_nomarker_420_noninterleaved", 50, 50, 4, 3, S420, 70, optimize=16)
 enc("cmyk_adobe_tiny", 1, 3, 4, 0, S420, 90)
+# sampling factors beyond 2 and chroma sampled finer than luma (jdsample.c int_upsample = replication for every ratio but 2:1 / 1:2 / 2:2)
+enc("samp_411", 40, 90, 3, 0, (4, 1, 1, 1, 1, 1), 85)
+enc("samp_410_dri2", 70, 70, 3, 0, (4, 2, 1, 1, 1, 1), 80, dri=2)
+enc("samp_chroma_mixed_22_21_11", 45, 63, 3, 0, (2, 2, 2, 1, 1, 1), 90)
+enc("samp_luma_coarser_than_chroma_progressive", 50, 35, 3, 0, (1, 1, 2, 2, 2, 2), 75, optimize=2)
+enc("samp_3x1", 33, 100, 3, 0, (3, 1, 1, 1, 1, 1), 88, optimize=1)
+enc("samp_1x4", 100, 20, 3, 0, (1, 4, 1, 1, 1, 1), 70)
 gold = {}
 for f in sorted(os.listdir(out_dir)):
     d = open(os.path.join(out_dir, f), "rb").read()
