@@ -7,7 +7,8 @@ import time
 import numpy as np
 from PIL import Image
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lilliput_amd as la
 from lilliput_amd import synth
 
