@@ -82,7 +82,7 @@ struct LpJpeg {
 // the engine sorts the scans into dependency levels and launches one kernel per level (lane = one scan of one image).
 // Coefficients accumulate in an int16 arena: per image, per component, blocks in raster order over the MCU-padded grid,
 // 64 values per block in ZIGZAG order (see lp_prog_core.h: a refinement scan then works on a 64-bit non-zero mask).
-#define LP_MAX_SCANS 64
+#define LP_MAX_SCANS 1024        // libjpeg has no limit; real files stay below 20 scans, hostile ones are cut off here ("unsupported")
 struct LpProgHuff {             // the Huffman tables one scan uses. Progressive scans: slot = position of the component in the scan (its
                                 // DC or its AC table, whichever the scan codes). Sequential scans (see LpProgScan::sequential) need both:
                                 // slot s = DC table, slot 4 + s = AC table of scan component s.
