@@ -235,6 +235,7 @@ typedef struct lilliput_batch_options {
     int normalize_orientation;  /* ImageOptions.NormalizeOrientation */
     int jpeg_quality;           /* EncodeOptions[JpegQuality]; 0 -> OpenCV's default 95 */
     int chunk;                  /* images in flight on the device at once; 0 = automatic */
+    int jpeg_progressive;       /* EncodeOptions[JpegProgressive]: non-zero -> progressive output (device FDCT, multi-scan entropy coding on host threads) */
 } lilliput_batch_options;
 
 typedef void* lilliput_hip_batch;

@@ -59,7 +59,7 @@ class _Item(C.Structure):
 
 class _BatchOptions(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("resize_method", C.c_int), ("normalize_orientation", C.c_int),
-                ("jpeg_quality", C.c_int), ("chunk", C.c_int)]
+                ("jpeg_quality", C.c_int), ("chunk", C.c_int), ("jpeg_progressive", C.c_int)]
 
 
 class _ImageOptions(C.Structure):
@@ -290,8 +290,8 @@ class Batch:
         return items, keep
 
     @staticmethod
-    def _opts(width, height, method, normalize, quality, chunk):
-        return _BatchOptions(int(width), int(height), int(method), int(bool(normalize)), int(quality), int(chunk))
+    def _opts(width, height, method, normalize, quality, chunk, progressive=False):
+        return _BatchOptions(int(width), int(height), int(method), int(bool(normalize)), int(quality), int(chunk), int(bool(progressive)))
 
     def _results(self):
         out = []
@@ -299,9 +299,9 @@ class Batch:
             out.append(BatchItemResult(it.status, d[: it.dst_len].tobytes() if it.status == 0 else b"", it.out_width, it.out_height))
         return out
 
-    def transform(self, sources, width, height, method=ImageOpsFit, normalize=False, quality=85, dst_cap=1 << 20, chunk=0):
+    def transform(self, sources, width, height, method=ImageOpsFit, normalize=False, quality=85, dst_cap=1 << 20, chunk=0, progressive=False):
         self._items, self._keep = self._make_items(sources, dst_cap)
-        o = self._opts(width, height, method, normalize, quality, chunk)
+        o = self._opts(width, height, method, normalize, quality, chunk, progressive)
         lib().lilliput_hip_batch_transform(self._h, self._items, len(sources), C.byref(o))
         return self._results()
 
@@ -312,8 +312,8 @@ class Batch:
         if rc:
             raise LilliputError(rc, "batch_upload")
 
-    def run(self, width, height, method=ImageOpsFit, normalize=False, quality=85, chunk=0):
-        o = self._opts(width, height, method, normalize, quality, chunk)
+    def run(self, width, height, method=ImageOpsFit, normalize=False, quality=85, chunk=0, progressive=False):
+        o = self._opts(width, height, method, normalize, quality, chunk, progressive)
         rc = lib().lilliput_hip_batch_run(self._h, C.byref(o))
         if rc:
             raise LilliputError(rc, "batch_run")

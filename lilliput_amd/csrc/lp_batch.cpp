@@ -341,19 +341,31 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
         if (!erq.empty()) {
             std::vector<int> est(erq.size(), 0);
             std::vector<uint32_t> elen(erq.size(), 0);
-            if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) return fail(eng.last_error());
-            acc[5] += eng.timings().encode_ms;
-            lap(3);
-            if (eng.encoded_fetch_all()) return fail(eng.last_error());
-            lap(4);
+            std::vector<std::vector<uint8_t>> prog;
+            if (opt->jpeg_progressive) { // EncodeOptions[JpegProgressive]: FDCT on the device, the scans on host threads
+                if (eng.encode_jpegs_progressive(erq.data(), (int)erq.size(), est.data(), prog) == LP_ERR_DEVICE) return fail(eng.last_error());
+                lap(3);
+                lap(4);
+            } else {
+                if (eng.encode_jpegs(erq.data(), (int)erq.size(), est.data(), elen.data()) == LP_ERR_DEVICE) return fail(eng.last_error());
+                acc[5] += eng.timings().encode_ms;
+                lap(3);
+                if (eng.encoded_fetch_all()) return fail(eng.last_error());
+                lap(4);
+            }
             for (size_t q = 0; q < erq.size(); q++) {
                 const int k = eidx[q];
                 const size_t item = (size_t)part.items[first + (size_t)k];
                 if (est[q]) { st[(size_t)k] = est[q]; continue; }
-                b->out_len[item] = elen[q];
                 b->out_w[item] = (int)erq[q].src.w;
                 b->out_h[item] = (int)erq[q].src.h;
-                b->out_bytes[item].assign(eng.encoded_host((int)q), eng.encoded_host((int)q) + elen[q]);
+                if (opt->jpeg_progressive) {
+                    b->out_len[item] = (uint32_t)prog[q].size();
+                    b->out_bytes[item].swap(prog[q]);
+                } else {
+                    b->out_len[item] = elen[q];
+                    b->out_bytes[item].assign(eng.encoded_host((int)q), eng.encoded_host((int)q) + elen[q]);
+                }
             }
         }
         for (int k = 0; k < cnt; k++) {
@@ -370,7 +382,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
 static void run_other(LpBatch* b, const lilliput_batch_options* opt)
 {
     if (b->other.empty()) return;
-    const int enc_opts[2] = {CV_IMWRITE_JPEG_QUALITY, opt->jpeg_quality};
+    const int enc_opts[4] = {CV_IMWRITE_JPEG_PROGRESSIVE, opt->jpeg_progressive ? 1 : 0, CV_IMWRITE_JPEG_QUALITY, opt->jpeg_quality};
     lilliput_image_options io;
     memset(&io, 0, sizeof(io));
     io.file_type = ".jpeg";
@@ -378,7 +390,7 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt)
     io.resize_method = opt->resize_method;
     io.normalize_orientation = opt->normalize_orientation;
     io.encode_options = enc_opts;
-    io.encode_options_len = opt->jpeg_quality ? 2 : 0;
+    io.encode_options_len = opt->jpeg_quality ? 4 : 2;
     io.encode_timeout_ns = 30ll * 1000000000ll;
     // The host side of these sources is serial per image (inflate, LZW), so the items are spread over a few workers, each with its
     // own ImageOps (ops.go: "one ImageOps per goroutine") and its own per-thread engine on the batch's device.

@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 #include "lp_huff_core.h"
 #include "lp_launch.h"
@@ -998,6 +1000,41 @@ int LpEngine::encode_jpeg_progressive(const LpEncodeReq& req, std::vector<uint8_
     if (src) return src;
     if (!lp_jpeg_encode_progressive((int)j.src.w, (int)j.src.h, (int)j.ncomp, req.quality, coef.data(), out)) { err_ = "coefficient out of range"; return LP_ERR_INVALID_IMAGE; }
     return LP_OK;
+}
+
+int LpEngine::encode_jpegs_progressive(const LpEncodeReq* reqs, int n, int* status, std::vector<std::vector<uint8_t>>& outs)
+{
+    outs.assign((size_t)n, std::vector<uint8_t>());
+    if (n <= 0) return LP_OK;
+    std::vector<uint32_t> len((size_t)n, 0);
+    enc_fdct_only_ = true;
+    const int rc = encode_jpegs(reqs, n, status, len.data());
+    enc_fdct_only_ = false;
+    if (rc == LP_ERR_DEVICE) return rc;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total = std::max(total, (size_t)h_jobs_[(size_t)i].coef_off + (size_t)h_jobs_[(size_t)i].total_blocks * 64);
+    std::vector<int16_t> coef(total);
+    if (total && !check(hipMemcpyAsync(coef.data(), d_ecoef_.p, total * 2, hipMemcpyDeviceToHost, stream_), "D2H coefficients")) return LP_ERR_DEVICE;
+    const int src = sync();
+    if (src) return src;
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) break;
+            if (status[i]) continue;
+            const LpEncJob& j = h_jobs_[(size_t)i];
+            if (!lp_jpeg_encode_progressive((int)j.src.w, (int)j.src.h, (int)j.ncomp, reqs[i].quality, coef.data() + j.coef_off, outs[(size_t)i])) status[i] = LP_ERR_INVALID_IMAGE;
+        }
+    };
+    const int nt = std::min(n, 8);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    int out_rc = LP_OK;
+    for (int i = 0; i < n; i++) if (status[i]) out_rc = status[i];
+    return out_rc;
 }
 
 const uint8_t* LpEngine::encoded_device_ptr(int i) const { return d_out_.as<uint8_t>() + h_jobs_[(size_t)i].out_off; }

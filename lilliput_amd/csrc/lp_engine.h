@@ -108,6 +108,8 @@ public:
     int encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t* out_len);
     // Progressive (SOF2) output of one frame: FDCT + quantisation on the device, multi-scan entropy coding on the host (lp_jpeg_progenc.h).
     int encode_jpeg_progressive(const LpEncodeReq& req, std::vector<uint8_t>& out);
+    // The same for n frames; the host entropy coding runs on a few threads. outs[i] stays empty where status[i] != 0.
+    int encode_jpegs_progressive(const LpEncodeReq* reqs, int n, int* status, std::vector<std::vector<uint8_t>>& outs);
     int encoded_copy(int i, uint8_t* dst, size_t cap);   // D2H of job i's bytes (after encode_jpegs)
     const uint8_t* encoded_device_ptr(int i) const;
     int encoded_fetch_all();                              // D2H of every job's bytes into pinned memory (one sync)

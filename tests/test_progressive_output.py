@@ -145,3 +145,22 @@ def test_transform_with_progressive_output(hip_lib, oracle, fixture_bytes):
         d.Close()
         assert oracle.jpeg_decode(again).shape == oracle.jpeg_decode(outs[0]).shape
     ops.Close()
+
+
+@pytest.mark.gpu
+def test_batch_progressive_output(batch, oracle, fixture_bytes):
+    """lilliput_batch_options.jpeg_progressive: the batch's thumbnails as progressive files -- the very coefficients of the baseline
+    thumbnails (compared through the oracle), SOF2, for JPEG, PNG and GIF items alike."""
+    import test_progressive as TP
+
+    srcs = [fixture_bytes[n] for n in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg")] + [c[2] for c in TP._cases(2, 5, lo=50, hi=300)]
+    png = os.path.join(ROOT, "tests", "golden", "inputs_png")
+    srcs += [open(os.path.join(png, f), "rb").read() for f in sorted(os.listdir(png))[:2]]
+    base = batch.transform(srcs, 120, 90, quality=80)
+    prog = batch.transform(srcs, 120, 90, quality=80, progressive=True)
+    for k, (a, b2) in enumerate(zip(base, prog)):
+        assert a.status == 0 and b2.status == 0, k
+        assert b"\xff\xc2" in b2.data[:700] and b"\xff\xc2" not in a.data[:700], k
+        assert np.array_equal(oracle.jpeg_decode(a.data), oracle.jpeg_decode(b2.data)), k
+        for c in range(oracle.jpeg_info(a.data)["ncomp"]):
+            assert np.array_equal(oracle.jpeg_decode_coefs(a.data, c), oracle.jpeg_decode_coefs(b2.data, c)), (k, c)
