@@ -127,15 +127,15 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         if (hi == h_huffs_.size()) h_huffs_.push_back(hdrs[i].huff);
         j.huff_idx = hi;
         j.raw_off = raw_bytes;
-        j.progressive = hdrs[i].progressive ? 1 : 0;
-        if (hdrs[i].progressive && !prog_on_device_) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
+        j.scan_path = hdrs[i].scan_path ? 1 : 0;
+        if (hdrs[i].scan_path && !prog_on_device_) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
             j.raw_len = 0;
             h_pcoef_off_[(size_t)i] = pcoef_total;
             for (int c = 0; c < j.ncomp; c++) pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
             lp_prog_levels(hdrs[i].scans, lev);
             for (size_t q = 0; q < hdrs[i].scans.size(); q++)
                 host_tasks.push_back(LpProgHostTask{srcs[i].data, &hdrs[i].scans[q], nullptr, lev[q], &h_perr_[(size_t)i]});
-        } else if (hdrs[i].progressive) { // every scan is a stream of its own
+        } else if (hdrs[i].scan_path) { // every scan is a stream of its own
             j.raw_len = 0;
             lp_prog_levels(hdrs[i].scans, lev);
             for (const LpProgScanHost& sh : hdrs[i].scans) {
@@ -173,7 +173,7 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         memset(h_pcoef_.p, 0, pcoef_total * 2);
         size_t t = 0;
         for (int i = 0; i < n; i++)
-            if (hdrs[i].progressive)
+            if (hdrs[i].scan_path)
                 for (size_t q = 0; q < hdrs[i].scans.size(); q++) host_tasks[t++].coef = h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)i];
         lp_prog_host_run(host_tasks, 0);
     }
@@ -246,7 +246,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     bool any_frame = false, any_generic = false, any_420 = false, any_baseline = false;
     for (size_t i = 0; i < h_imgs_.size(); i++) {
         LpJpeg& j = h_imgs_[i];
-        any_baseline = any_baseline || !j.progressive;
+        any_baseline = any_baseline || !j.scan_path;
         j.chunk_off = tot_chunks_;
         tot_chunks_ += j.nchunks;
         j.clean_off = clean_words;                                  // multiple of 4 words: the bit reader loads 16 bytes at a time
@@ -261,7 +261,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         j.rst_off = tot_rst_;
         j.rst_cap = j.dri ? (j.mcus_x * j.mcus_y + j.dri - 1) / j.dri + 2 : 2;
         tot_rst_ += j.rst_cap;
-        if (j.progressive) {
+        if (j.scan_path) {
             // Scans that touch the same coefficients of the same component must run in file order (a refinement needs what came
             // before it); all others are independent (lp_prog_levels). Host mode: ups is empty, the coefficients are ready.
             const std::vector<ProgScanUp>& ups = h_prog_[(size_t)first + i];
@@ -395,7 +395,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (pcoef_elems && !prog_on_device_) { // hybrid mode: the coefficients were decoded at upload time
         for (int i = 0; i < n; i++) {
             const LpJpeg& j = h_imgs_[(size_t)i];
-            if (!j.progressive) continue;
+            if (!j.scan_path) continue;
             size_t ne = 0;
             for (int c = 0; c < j.ncomp; c++) ne += (size_t)j.bw[c] * j.bh[c] * 64;
             if (!check(hipMemcpyAsync(d_pcoef_.as<int16_t>() + j.coef_off, h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)first + i], ne * 2, hipMemcpyHostToDevice, stream_), "H2D coefficients"))
@@ -453,7 +453,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         for (const LpProgScan& sc : h_pscans_) h_states_[sc.img].error |= h_pstates_[sc.stream].error;
     }
     for (int i = 0; i < n; i++)
-        if (h_imgs_[(size_t)i].progressive && !prog_on_device_) h_states_[(size_t)i].error |= h_perr_[(size_t)first + i];
+        if (h_imgs_[(size_t)i].scan_path && !prog_on_device_) h_states_[(size_t)i].error |= h_perr_[(size_t)first + i];
     int rc = LP_OK;
     for (int i = 0; i < n; i++) {
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
@@ -483,7 +483,7 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     const LpJpeg& j = h_imgs_[(size_t)i];
     const size_t ne = (size_t)j.bw[comp] * j.bh[comp] * 64;
     if (ne > cap_elems) return LP_ERR_BUF_TOO_SMALL;
-    if (j.progressive) { // already [by][bx], every block in zigzag order
+    if (j.scan_path) { // already [by][bx], every block in zigzag order
         size_t base = 0;
         for (int c = 0; c < comp; c++) base += (size_t)j.bw[c] * j.bh[c] * 64;
         std::vector<int16_t> t(ne);

@@ -365,9 +365,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 if (rs.sequential && raw_scans.size() == 1 && ns == j.ncomp) break; // a one-scan file: libjpeg reads nothing past the scan
                 continue;
             }
-            if (ns != j.ncomp) return LP_PARSE_UNSUPPORTED; // non-interleaved / multi-scan
-            for (unsigned s = 0; s < ns; s++) if (scan_comp[s] != (int)s) return LP_PARSE_UNSUPPORTED;
-            ecs = seg_end;
+            ecs = seg_end; // one interleaved scan, components in frame order, table numbers 0 / 1: the baseline kernels' case
             break;
         }
         i = seg_end;
@@ -399,7 +397,6 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
         if (progressive || seq_scans) continue;                                                    // tables were checked scan by scan
         if (tq[c] > 3 || !qt_ok[tq[c]]) return LP_PARSE_NOT_JPEG;                                  // JERR_NO_QUANT_TABLE
         if (!h_ok[0][td[c]] || !h_ok[1][ta[c]]) return LP_PARSE_NOT_JPEG;                         // JERR_NO_HUFF_TABLE
-        if (td[c] > 1 || ta[c] > 1) return LP_PARSE_UNSUPPORTED;
         if (!huff_table_valid(hbits[0][td[c]], hvals[0][td[c]], true) || !huff_table_valid(hbits[1][ta[c]], hvals[1][ta[c]], false))
             return LP_PARSE_NOT_JPEG;
     }
@@ -444,7 +441,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
     else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') j.colorspace = 3;
     else j.colorspace = 2;
     if (progressive || seq_scans) {
-        out->progressive = true;
+        out->scan_path = true;
         for (const RawScan& rs : raw_scans) {
             LpProgScanHost hs;
             memset(&hs.s, 0, sizeof(hs.s));

@@ -13,7 +13,7 @@ enum {
     LP_PARSE_TRUNCATED = 3
 };
 
-struct LpProgScanHost {         // one scan of a progressive file
+struct LpProgScanHost {         // one scan of a file that is decoded scan by scan
     LpProgScan s;               // img / stream / huff indices are filled in by the engine
     LpProgHuff tables;
     size_t ecs_off, ecs_len;    // this scan's entropy-coded bytes in the file
@@ -25,7 +25,8 @@ struct LpJpegHeader {
     size_t ecs_off = 0;         // first entropy-coded byte in the file
     size_t ecs_len = 0;         // bytes up to (not including) the terminating marker / end of file (progressive: through the last scan)
     int saw_eoi = 0;
-    bool progressive = false;   // SOF2: `scans` lists the scans in file order, `huff` is unused
+    bool scan_path = false;     // decoded scan by scan (progressive, multi-scan sequential, four components, unusual sampling):
+                                // `scans` lists the scans in file order, `huff` is unused
     std::vector<LpProgScanHost> scans;
 };
 

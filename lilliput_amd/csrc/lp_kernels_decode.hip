@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
     }
     if (t == 255) {
         st.blocks_decoded = pre.nblk;
-        if (pre.nblk < img.total_blocks && !img.progressive) st.error |= 2u;
+        if (pre.nblk < img.total_blocks && !img.scan_path) st.error |= 2u;
     }
 }
 
@@ -674,7 +674,7 @@ __device__ __forceinline__ void dc_range(const LpJpeg& img, uint32_t w, uint32_t
 __global__ __launch_bounds__(64) void k_dc_sum(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, DcPartial* __restrict__ partials)
 {
     const LpJpeg& img = imgs[blockIdx.y];
-    if (img.progressive) return; // its scans stored absolute DC values
+    if (img.scan_path) return; // its scans stored absolute DC values
     uint32_t m0, m1, comps;
     dc_range(img, blockIdx.x, m0, m1, comps);
     DcSeg zero;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void k_dc_sum(const LpJpeg* __restrict__ imgs, 
 __global__ __launch_bounds__(64) void k_dc_apply(const LpJpeg* __restrict__ imgs, int16_t* __restrict__ dc_arena, const DcPartial* __restrict__ partials)
 {
     const LpJpeg& img = imgs[blockIdx.y];
-    if (img.progressive) return;
+    if (img.scan_path) return;
     uint32_t m0, m1, comps;
     dc_range(img, blockIdx.x, m0, m1, comps);
     DcSeg pre;
@@ -788,13 +788,13 @@ template <bool PROG>
 __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                               const int8_t* __restrict__ coef8_arena, const int16_t* __restrict__ wide_arena,
                                               const uint32_t* __restrict__ wide_id_arena, const int16_t* __restrict__ dc_arena,
-                                              uint8_t* __restrict__ plane_arena)
+                                              const int16_t* __restrict__ pcoef_arena, uint8_t* __restrict__ plane_arena)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t s_qt[64]; // transposed like the blocks: [column][row]
     __shared__ uint8_t s_n2z[64];
     const LpJpeg& img = imgs[blockIdx.z];
-    if ((img.progressive != 0) != PROG) return;
+    if ((img.scan_path != 0) != PROG) return;
     uint32_t by = blockIdx.y, c = 0;
     while (c + 1 < img.ncomp && by >= img.bh[c]) { by -= img.bh[c]; c++; } // at most three steps (four components: CMYK / YCCK)
     if (c >= img.ncomp || by >= img.bh[c]) return;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
             // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
             // its 128 bytes between them)
             const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u) + (c > 2 ? img.bw[2] * img.bh[2] : 0u);
-            const int16_t* src = wide_arena /* = the progressive arena in this variant */ + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
+            const int16_t* src = pcoef_arena + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
 #pragma unroll
             for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;
 #pragma unroll
@@ -1001,8 +1001,8 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
 {
     if (!nimg || !max_bw || !max_rows) return;
     dim3 g((max_bw + 32 * IDCT_TPW - 1) / (32 * IDCT_TPW), max_rows, nimg); // max_rows = most block rows of an image, all components stacked
-    if (which & 1u) hipLaunchKernelGGL(k_idct<false>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_planes);
-    if (which & 2u) hipLaunchKernelGGL(k_idct<true>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_pcoef, d_wide_id, d_dc, d_planes);
+    if (which & 1u) hipLaunchKernelGGL(k_idct<false>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_pcoef, d_planes);
+    if (which & 2u) hipLaunchKernelGGL(k_idct<true>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_pcoef, d_planes);
 }
 
 void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, const LpJpeg* d_streams,

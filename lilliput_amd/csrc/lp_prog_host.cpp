@@ -178,7 +178,7 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
 extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads)
 {
     LpJpegHeader h;
-    if (lp_jpeg_parse(static_cast<const uint8_t*>(data), len, &h) != LP_PARSE_OK || !h.progressive || comp < 0 || comp >= h.j.ncomp) return -1;
+    if (lp_jpeg_parse(static_cast<const uint8_t*>(data), len, &h) != LP_PARSE_OK || !h.scan_path || comp < 0 || comp >= h.j.ncomp) return -1;
     size_t total = 0, base = 0;
     for (int c = 0; c < h.j.ncomp; c++) {
         if (c == comp) base = total;

@@ -47,7 +47,8 @@ struct LpJpeg {
     uint8_t ncomp, hmax, vmax, bpm;
     uint8_t colorspace;         // 1 gray, 2 YCbCr, 3 RGB, 4 CMYK, 5 YCCK (four components: decoded to BGR the way cv::JpegDecoder does)
     uint8_t orientation;        // EXIF 1..8
-    uint8_t progressive;        // 1: SOF2 -- the Huffman stages skip the image, its scans are decoded on their own and coef_off counts
+    uint8_t scan_path;          // 1: decoded scan by scan (LpProgScan: progressive files, sequential ones in several scans, four components,
+                                // unusual sampling) -- the subsequence-parallel Huffman stages skip the image and coef_off counts
                                 // int16 elements in the progressive arena (see LpProgScan)
     uint8_t generic_sampling;   // 1: sampling factors other than luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma (4:1:1, 4:1:0, chroma larger
                                 // than luma, CMYK ...): every component goes through its own upsampler in k_ycc_to_frame, no fused resample

@@ -205,7 +205,7 @@ extern "C" int emu_decode_coefs_progressive(const uint8_t* data, size_t len, int
     LpJpegHeader h;
     int rc = lp_jpeg_parse(data, len, &h);
     if (rc) return -rc;
-    if (!h.progressive) return -20;
+    if (!h.scan_path) return -20;
     const LpJpeg& img = h.j;
     if (comp >= img.ncomp) return -10;
     size_t nblk = 0;
