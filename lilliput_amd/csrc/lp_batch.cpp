@@ -137,6 +137,11 @@ int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item*
         }
         int rc = (items[i].src && items[i].src_len) ? lp_jpeg_parse((const uint8_t*)items[i].src, items[i].src_len, &h) : LP_PARSE_NOT_JPEG;
         b->parse_status[i] = map_parse(rc);
+        // The reference sizes its frame buffers with NewImageOps(maxSize) and answers ErrBufTooSmall for anything larger
+        // (opencv.go:250-267 resizeMat); the batch has the same bound -- 8192 x 8192 pixels unless LILLIPUT_HIP_BATCH_MAX_PIXELS says
+        // otherwise -- so that one file with an absurd frame header cannot take the other images' arenas down with it.
+        static const uint64_t max_px = getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS") ? strtoull(getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS"), nullptr, 10) : 8192ull * 8192ull;
+        if (rc == LP_PARSE_OK && (uint64_t)h.j.width * h.j.height > max_px) { b->parse_status[i] = LILLIPUT_ERR_BUF_TOO_SMALL; continue; }
         if (rc == LP_PARSE_OK) { valid.push_back((int)i); hv.push_back(h); }
     }
     // contiguous parts, one per worker; small batches stay on one stream

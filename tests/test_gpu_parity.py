@@ -421,8 +421,12 @@ def test_transform_option_matrix(hip_lib, oracle, fixture_bytes):
 # ------------------------------------------------------------------------------------------ Part B: batch
 def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
     names = list(fixture_bytes)
-    sources = [fixture_bytes[n] for n in names] + [b"not a jpeg", fixture_bytes["large-sunrise.jpg"][:100000]]
+    huge = bytearray(fixture_bytes["sunrise.jpg"])  # a frame header claiming 65 000 x 65 000 pixels: refused by itself, the rest untouched
+    sof = huge.index(b"\xff\xc0")
+    huge[sof + 5 : sof + 9] = bytes([0xFD, 0xE8, 0xFD, 0xE8])
+    sources = [fixture_bytes[n] for n in names] + [bytes(huge), b"not a jpeg", fixture_bytes["large-sunrise.jpg"][:100000]]
     res = batch.transform(sources, 64, 64, quality=85)
+    assert res[-3].status == 3  # ErrBufTooSmall, what lilliput answers for a frame beyond NewImageOps(maxSize)
     for n, r in zip(names, res):
         assert r.status == 0, n
         exp = oracle.transform_jpeg_thumbnail(fixture_bytes[n], 64, 64, 85)
