@@ -40,7 +40,8 @@ class LilliputError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblilliput_hip.so")
+    # LILLIPUT_HIP_LIB: another build of the same library (A/B measurements of kernel variants); the default is the in-tree one
+    return os.environ.get("LILLIPUT_HIP_LIB") or os.path.join(_HERE, "liblilliput_hip.so")
 
 
 def build(force=False):

@@ -44,11 +44,12 @@
      38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, \
      63, 63}
 
-// Ring geometry of the bit reader. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so
-// kEvery = 8 steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte
-// granularity) and a step reads the word pair (w, w+1): 8 + 3 + 2 <= kRing = 16.
+// Ring geometry of the bit reader. A lane keeps the three stream words at its position in registers (w0, w1 = the 64 bits a
+// peek shifts, w2 = the word after them, requested from the ring one step before it can be needed), so the ring read is off
+// the symbol-to-symbol dependency chain. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so kEvery = 8
+// steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte granularity) and a step
+// may ask for word (p >> 5) + 2: 8 + 3 + 3 <= kRing = 16.
 // The policy fixes the geometry: M::kRing words per lane, a top-up of at most M::kQuads 16-byte loads every M::kEvery steps.
-// Valid pairs: (16, 8, 2) and (8, 4, 1) -- 31 bits x 4 steps = 4 words: 4 + 3 + 1 <= 8.
 
 // Per-image values every lane of a workgroup shares (scalar registers on the device).
 struct LpImgCtx {
@@ -60,17 +61,18 @@ struct LpImgCtx {
 };
 
 // Memory policy M must provide (per lane object, non-const):
-//   void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)   words w and w+1 of the clean stream (big-endian corrected: bit 31 first)
+//   uint32_t fetch1(uint32_t w)             word w of the clean stream (big-endian corrected: bit 31 first); w within the ring window
 //   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
 //   void topup(uint32_t w)                  wave-uniform call every kEvery steps: words below w are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
-//   uint32_t lut(uint32_t tbl, uint32_t i), lut2(tbl, i), lut2_n(tbl), base2(tbl)
+//   uint32_t lut(uint32_t tbl, uint32_t i), lut2(uint32_t i)   first-level entry of table tbl, entry i of the second-level pool
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
+//   void settle(uint32_t& v)                v came from rst_bit() inside a rare branch: finish the load there (device), no-op on the host
 //
-// The lane keeps NO bit buffer: every step peeks 32 bits at its bit position straight from the ring (one paired LDS read
-// + one 64-bit shift). On MI355X the kernels are VALU-issue bound, and this costs fewer instructions than maintaining a
-// refillable 64-bit buffer; the extra LDS latency on the dependency chain is hidden by the other waves of the SIMD.
+// The lane keeps no refillable bit buffer: a peek is one 64-bit shift of (w0, w1) by p & 31. What bounds these kernels on
+// MI355X is the latency of the serial chain symbol -> length -> position -> next symbol (PMC: the waves sit in s_waitcnt for
+// half of their cycles with the VALU a third busy), so the chain holds exactly one LDS round trip -- the code-table lookup.
 template <class M>
 struct LpLane {
     M& m;
@@ -81,14 +83,28 @@ struct LpLane {
     uint32_t rot;       // ic.blkpack rotated right by 4*b: the low nibble describes the current block
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
+    uint32_t w0, w1, w2; // stream words (p >> 5), + 1, + 2
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b(0), rot(0), next_rst(0), rst_k(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b(0), rot(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
 
-    LP_HD uint32_t peek()
+    LP_HD uint32_t peek() const { return (uint32_t)(((((uint64_t)w0) << 32) | w1) << (p & 31u) >> 32); }
+    LP_HD void load_window() // after a jump (m.reseek has been called)
     {
-        uint32_t w0, w1;
-        m.fetch2(p >> 5, w0, w1);
-        return (uint32_t)(((((uint64_t)w0) << 32) | w1) << (p & 31u) >> 32);
+        const uint32_t w = p >> 5;
+        w0 = m.fetch1(w);
+        w1 = m.fetch1(w + 1u);
+        w2 = m.fetch1(w + 2u);
+    }
+    // the position moves on by n <= 31 bits: slide the register window when it enters the next word, and ask for the word after
+    // the window again (the same word as before when nothing slid; its value is first used one step later)
+    LP_HD void advance(uint32_t n)
+    {
+        const uint32_t pn = p + n;
+        const bool slid = ((p ^ pn) & 32u) != 0;
+        w0 = slid ? w1 : w0;
+        w1 = slid ? w2 : w1;
+        w2 = m.fetch1((pn >> 5) + 2u);
+        p = pn;
     }
     LP_HD void set_block(uint32_t nb)
     {
@@ -100,6 +116,7 @@ struct LpLane {
     {
         p = pos;
         m.reseek(pos >> 5);
+        load_window();
         set_block(bz >> 8);
         z = bz & 255u;
         rst_k = 0;
@@ -112,6 +129,7 @@ struct LpLane {
             }
             rst_k = lo;
             next_rst = lo < ic.n_rst ? m.rst_bit(lo) : ic.total_bits;
+            m.settle(next_rst);
         }
     }
     LP_HD uint32_t state_bz() const { return (b << 8) | z; }
@@ -131,6 +149,7 @@ struct LpLane {
                 next_rst = rst_k < ic.n_rst ? m.rst_bit(rst_k) : ic.total_bits;
             } else
                 next_rst = 0x7fffffffu;
+            m.settle(next_rst);
             rem = (int32_t)(next_rst - p);
         }
         if (rem >= 8) return false;
@@ -144,19 +163,23 @@ struct LpLane {
         } else {
             next_rst = 0x7fffffffu; // past the end of the stream: nothing left
         }
+        m.settle(next_rst);
         p = target;
         m.reseek(target >> 5);
+        load_window();
         set_block(0);
         z = 0;
         return true;
     }
 
-    // Second/third level of the code lookup (codes longer than LP_LUT_BITS).
-    LP_HD uint32_t long_code(uint32_t tbl, uint32_t top)
+    // Second level of the code lookup: e1 is the first-level entry of a prefix that belongs to codes longer than LP_LUT_BITS; its
+    // low byte names a 64-entry slice of the second-level pool, indexed by the six bits that follow the prefix (see LpHuffSet).
+    // One dependent LDS read: a long code is rare per lane but shows up in most steps of a 64-lane wave.
+    LP_HD uint32_t long_code(uint32_t tbl, uint32_t e1, uint32_t top)
     {
-        const uint32_t idx = top - m.base2(tbl);
-        uint32_t e = idx < m.lut2_n(tbl) ? m.lut2(tbl, idx) : 0u;
-        if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix or a table with a very wide tail
+        const uint32_t sub = e1 & 0xffu;
+        uint32_t e = sub != 0xffu ? m.lut2((sub << 6) | (top & 63u)) : 0u;
+        if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
             uint32_t len = 17, sym = 0; // no code matches: jpeg_huff_decode reads on to the sentinel length 17, warns and fakes a zero
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
                 const int32_t code = (int32_t)(top >> (16 - l));
@@ -185,7 +208,7 @@ struct LpLane {
         // selects, not to an exec-mask branch pair
         const uint32_t tbl = ((rot >> (r.is_dc ? 2u : 3u)) & 1u) + (r.is_dc ? 0u : 2u);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
-        if ((e & 0x1f00u) == 0) e = long_code(tbl, pk >> 16);
+        if ((e & 0x1f00u) == 0) e = long_code(tbl, e, pk >> 16);
         const uint32_t len = (e >> 8) & 31u;
         const uint32_t s = e & 15u;
         const uint32_t run = (e >> 4) & 15u;      // DC symbols are categories 0..15 (validated by the parser): run == 0
@@ -197,7 +220,7 @@ struct LpLane {
             const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);
             r.val = (int32_t)(x - (neg & ((1u << s) - 1u)));
         }
-        p += len + s;
+        advance(len + s);
         // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL); a coefficient whose index overruns 63 on
         // a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table carries the same guard entries)
         const bool eob = (e & 0x8000u) != 0; // precomputed per table entry: an AC symbol of size 0 other than ZRL

@@ -50,9 +50,11 @@ static inline uint16_t lut_entry(int slot, int l, unsigned v)
 
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals)
 {
-    memset(hs->lut[slot], 0, sizeof(hs->lut[slot]));
-    // canonical code assignment (T.81 Annex C), first-level table, base of the long codes
-    uint32_t base2 = 0x10000u;
+    // every prefix starts out as "no code here" (canonical search answers libjpeg's length-17 rule for it)
+    for (int i = 0; i < LP_LUT_SIZE; i++) hs->lut[slot][i] = 0x00ffu;
+    if (slot == 0) hs->lut2_used = 0; // slots are built in order 0..3 and share the second-level pool
+    // canonical code assignment (T.81 Annex C). Short codes fill their span of the first level; a long code gets its prefix's
+    // slice of the second level (allocated on first use) and fills its span of the six bits after the prefix.
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
         int valptr = k, mincode = code;
@@ -61,30 +63,23 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
                 int first = code << (LP_LUT_BITS - l), n = 1 << (LP_LUT_BITS - l);
                 for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = lut_entry(slot, l, vals[k]);
             } else {
-                uint32_t left = (uint32_t)code << (16 - l);
-                if (left < base2) base2 = left;
+                const uint32_t left = (uint32_t)code << (16 - l);           // the code, left aligned in 16 bits
+                if (left >= 0x10000u) continue;                              // over-subscribed table (rejected elsewhere); never index out of range
+                const uint32_t prefix = left >> (16 - LP_LUT_BITS);
+                uint16_t& e1 = hs->lut[slot][prefix];
+                if ((e1 & 0x1f00u) != 0) continue;                           // a shorter code owns the prefix: not a prefix code, leave it to libjpeg's order
+                if ((e1 & 0xffu) == 0xffu) {
+                    if (hs->lut2_used >= LP_LUT2_SUBS) continue;             // pool exhausted: canonical search serves this prefix
+                    e1 = (uint16_t)hs->lut2_used;
+                    memset(hs->lut2 + ((size_t)hs->lut2_used << 6), 0, 64 * sizeof(uint16_t));
+                    hs->lut2_used++;
+                }
+                const uint32_t sub = e1 & 0xffu, first = left & 63u, n = 1u << (16 - l);
+                for (uint32_t j = 0; j < n && first + j < 64; j++) hs->lut2[(sub << 6) | (first + j)] = lut_entry(slot, l, vals[k]);
             }
         }
         hs->maxcode[slot][l] = bits[l] ? code - 1 : -1;
         hs->valoff[slot][l] = valptr - mincode;
-        code <<= 1;
-    }
-    hs->base2[slot] = base2;
-    // second-level table: a slice of the shared pool covering [base2, base2 + n); slots are built in order 0..3 and take
-    // what is left of the pool (Annex-K tables need 2 + 320 + 32 + 320 entries)
-    uint32_t used = 0;
-    for (int t = 0; t < slot; t++) used = hs->lut2_off[t] + hs->lut2_n[t] > used ? hs->lut2_off[t] + hs->lut2_n[t] : used;
-    uint32_t need = 0x10000u - base2, n2 = need < LP_LUT2_POOL - used ? need : LP_LUT2_POOL - used;
-    hs->lut2_off[slot] = used;
-    hs->lut2_n[slot] = n2;
-    memset(hs->lut2 + used, 0, n2 * sizeof(uint16_t));
-    code = 0; k = 0;
-    for (int l = 1; l <= 16; l++) {
-        for (int i = 0; i < bits[l]; i++, k++, code++) {
-            if (l <= LP_LUT_BITS) continue;
-            uint32_t first = ((uint32_t)code << (16 - l)) - base2, n = 1u << (16 - l);
-            for (uint32_t j = 0; j < n && first + j < n2; j++) hs->lut2[used + first + j] = lut_entry(slot, l, vals[k]);
-        }
         code <<= 1;
     }
     hs->maxcode[slot][0] = -1;

@@ -218,49 +218,59 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
 // LDS: the image's LpHuffSet (two-level code tables), one bit-reader ring per lane (word-interleaved: word j of lane l at
 // [j][l], so every wave access hits 64 consecutive dwords -- conflict-free whatever the lanes' positions are).
 #define HUFF_T 256
-// R = ring words per lane; row R mirrors row 0 so that the pair (w, w+1) is always two adjacent rows.
+// R = ring words per lane.
 template <int R, int T, int Q>
 struct DevMem {
-    static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R + 1;
+    static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R;
     const uint32_t* words;  // this image's clean stream (16-byte aligned)
     uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % R) * 64]
     uint32_t fill;          // next stream word to load (multiple of 4)
     const LpHuffSet* hs;    // LDS
     const uint32_t* rst;
-    __device__ __forceinline__ void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1) const
+    uint4 pend[Q];          // see reseek / topup
+    __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[(w & (R - 1u)) << 6]; }
+    // The next Q quads of the stream ([fill, fill + 4Q) words) travel in registers: a top-up stores what the previous top-up
+    // loaded and issues the loads for the one after, so no wave ever sits in s_waitcnt vmcnt(0) behind an HBM round trip
+    // (the first version loaded and stored in the same top-up: PMC showed SPEC at 40 % and WRITE at 20 % of the VALU issue rate).
+    __device__ __forceinline__ uint4 load_words(uint32_t w) const { return *reinterpret_cast<const uint4*>(words + w); }
+    __device__ __forceinline__ void store_quad(const uint4& v)
     {
-        const uint32_t* r = ring + ((w & (R - 1u)) << 6);
-        w0 = r[0];
-        w1 = r[64]; // one ds_read2st64_b32
-    }
-    __device__ __forceinline__ void load_quad()
-    {
-        const uint4 v = *reinterpret_cast<const uint4*>(words + fill);
         uint32_t* r = ring + ((fill & (R - 1u)) << 6); // fill is a multiple of 4: the quad never wraps
         r[0] = v.x;
         r[64] = v.y;
         r[128] = v.z;
         r[192] = v.w;
-        if ((fill & (R - 1u)) == 0) ring[R << 6] = v.x;
         fill += 4;
     }
     __device__ __forceinline__ void reseek(uint32_t w)
     {
         fill = w & ~3u;
 #pragma unroll
-        for (int i = 0; i < R / 4; i++) load_quad();
+        for (int i = 0; i < R / 4; i++) store_quad(load_words(fill));
+#pragma unroll
+        for (int i = 0; i < Q; i++) pend[i] = load_words(fill + 4u * i);
     }
     __device__ __forceinline__ void topup(uint32_t w)
     {
-#pragma unroll
-        for (int i = 0; i < Q; i++)
-            if (fill + 4u <= w + R) load_quad();
+        if (fill + 4u <= w + R) {
+            store_quad(pend[0]);
+            if (Q == 2) {
+                if (fill + 4u <= w + R) {
+                    store_quad(pend[Q - 1]);
+                    pend[0] = load_words(fill);
+                } else
+                    pend[0] = pend[Q - 1];
+                pend[Q - 1] = load_words(fill + 4u);
+            } else
+                pend[0] = load_words(fill);
+        }
     }
+    // a value that came from a global load inside a rare branch: make the branch wait for it, so that the hot path carries no
+    // s_waitcnt vmcnt for it (which would also wait for the prefetched quads, every iteration)
+    __device__ __forceinline__ void settle(uint32_t& v) const { asm volatile("" : "+v"(v)); }
     __device__ __forceinline__ bool any(bool p) const { return __any(p); }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
-    __device__ __forceinline__ uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[hs->lut2_off[t] + i]; }
-    __device__ __forceinline__ uint32_t lut2_n(uint32_t t) const { return hs->lut2_n[t]; }
-    __device__ __forceinline__ uint32_t base2(uint32_t t) const { return hs->base2[t]; }
+    __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }

@@ -12,20 +12,23 @@
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
 #define LP_LUT_BITS 10          // first-level Huffman lookup width
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
-#define LP_LUT2_POOL 1024       // second-level lookup entries shared by the four tables (one per 16-bit prefix of a long code)
+#define LP_LUT2_SUBS 16          // second-level lookup: slices of 64 entries shared by the four tables (one per 10-bit prefix of long codes)
+#define LP_LUT2_POOL (LP_LUT2_SUBS * 64)
 #define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
-// lut[t][i]  : (ends_block << 15) | (len << 8) | symbol for codes of length <= LP_LUT_BITS, indexed by the next LP_LUT_BITS bits;
-//              len == 0 = longer code. ends_block marks the AC symbols that finish a block (size 0, run != 15).
-// lut2[lut2_off[t] + i], i < lut2_n[t] : same encoding for the long codes, indexed by (next 16 bits) - base2[t];
-//              0 or i >= lut2_n[t] = not covered -> canonical search.
+// lut[t][i]  : indexed by the next LP_LUT_BITS bits. A code of length <= LP_LUT_BITS: (ends_block << 15) | (len << 8) | symbol;
+//              ends_block marks the AC symbols that finish a block (size 0, run != 15). The prefix of longer codes: len == 0 and the low
+//              byte = the slice of lut2 that decodes them (0xff: none -- not a prefix of any code, or the pool was exhausted -> canonical
+//              search through maxcode / valoff / vals).
+// lut2[(slice << 6) | j] : same encoding (len 11..16) for the codes that start with the slice's prefix, j = the six bits after the
+//              prefix; 0 = no such code -> canonical search. Annex-K tables need 1 + 5 + 5 slices.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
     uint16_t lut2[LP_LUT2_POOL];
-    uint32_t base2[4];          // smallest left-aligned 16-bit value of a code longer than LP_LUT_BITS (0x10000 if none)
-    uint32_t lut2_off[4], lut2_n[4];
+    uint32_t lut2_used;         // slices handed out so far (host-side bookkeeping while the four slots are built)
+    uint32_t pad[3];
     int32_t maxcode[4][18];     // maxcode[l] = largest code of length l, -1 if none; [17] = sentinel
     int32_t valoff[4][17];      // valptr[l] - mincode[l]
     uint8_t vals[4][256];

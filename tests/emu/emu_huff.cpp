@@ -20,26 +20,24 @@ struct HostMemT {
     // same window and reports when the lane logic fetches outside of it.
     uint32_t fill = 0, lowest = 0;
     bool* window_violation;
-    void fetch2(uint32_t w, uint32_t& w0, uint32_t& w1)
+    uint32_t fetch1(uint32_t w)
     {
-        if (w + 1 >= fill || w + R < fill) *window_violation = true;
-        w0 = words[w];
-        w1 = words[w + 1];
+        if (w >= fill || w + R < fill) *window_violation = true;
+        return words[w];
     }
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t w) { for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
-    uint32_t lut2(uint32_t t, uint32_t i) const { return hs->lut2[hs->lut2_off[t] + i]; }
-    uint32_t lut2_n(uint32_t t) const { return hs->lut2_n[t]; }
-    uint32_t base2(uint32_t t) const { return hs->base2[t]; }
+    uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
     uint32_t rst_bit(uint32_t k) const { return rst[k]; }
+    void settle(uint32_t&) const {}
 };
 typedef HostMemT<16, 8, 2> HostMem;      // geometry of the SPEC / VERIFY kernels
-typedef HostMemT<8, 4, 1> HostMemWrite;  // geometry of the WRITE kernel
+typedef HostMemT<16, 8, 2> HostMemWrite; // geometry of the WRITE kernel
 
 struct HostSink { // one slot, flushed at the wave-uniform flush points like the device sink
     int16_t blk[64];
