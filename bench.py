@@ -5,12 +5,14 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch (default 1024 synthetic 4096x4096 4:2:0 q90 JPEGs per GPU,
-compressed bytes already resident in HBM when the timed region starts; the thumbnails are copied back to the
-host inside the timed region). Images are independent, so ranks shard them with no data-path collective (weak
-scaling: per-GPU work is fixed); RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
-Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (measured live with HIP events
-on the engine's stream) and the reference CPU path timed on this box's host cores.
+One "step" = one pass of the hot path over one batch: 1024 distinct synthetic 4096x4096 4:2:0 q90 JPEGs per GPU handed over as
+host buffers, thumbnails returned in host buffers -- header walk, staging, H2D, every device stage and the D2H of the results are
+inside the timed region (what n ImageOps.Transform calls do in the reference). `--resident` times the device pipeline alone
+(compressed bytes already in HBM); the default run reports that figure too (config.resident_images_per_s), measured after the
+timed region. Images are independent, so ranks shard them with no data-path collective (weak scaling: per-GPU work is fixed);
+RCCL is used only for the barrier and the max-over-ranks of the elapsed time. Rank 0 prints ONE JSON line with the metric, the
+roofline of the dominant kernel (exclusive launch durations measured live with HIP events on the engine's stream) and the
+reference CPU path timed on this box's host cores.
 """
 import argparse
 import hashlib
@@ -43,9 +45,9 @@ def make_sources(batch, distinct, size, rank, world):
             t = time.time()
             import multiprocessing as mp
 
-            workers = max(1, min(len(missing), (os.cpu_count() or 2) - 1, 32))
+            workers = max(1, min(len(missing), (os.cpu_count() or 2) - 1, 96))  # ~0.7 GB of numpy temporaries per worker
             with mp.get_context("fork").Pool(workers) as pool:
-                for i, data in zip(missing, pool.map(synth._job, [(i, size, 90) for i in missing])):
+                for i, data in zip(missing, pool.imap(synth._job, [(i, size, 90) for i in missing], chunksize=1)):
                     with open(paths[i] + ".tmp", "wb") as f:
                         f.write(data)
                     os.replace(paths[i] + ".tmp", paths[i])
@@ -83,19 +85,39 @@ def cpu_baseline(sample_jpegs, budget_s=12.0):
             "sample": "%d transforms of the same 4096x4096 q90 -> 256x256 q85 workload on %d host threads (%.1fs)" % (len(jobs), cores, dt)}
 
 
+def kernel_table(stage, images, c_in, c_out, size):
+    """Per-kernel device ms per image and algorithmic GB/s from the summed HIP-event timings of `images` images:
+    coefficient blocks are 64 x int8 + one int16 DC per block (1.5 x W x H bytes + 2 B per block), planes 1.5 x W x H."""
+    px = size * size
+    blocks = 1.5 * px / 64
+    coef_b, dc_b, plane_b = 64 * blocks, 2 * blocks, 1.5 * px
+    return {
+        "k_huff_spec (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
+        "k_huff_verify (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
+        "k_huff_write + k_dc_sum + k_dc_apply (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
+        "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
+        "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
+        "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
+        "k_resample_420 (upsample + colour + 16x16 box mean)": (stage.get("resize_ms", 0.0), plane_b + 3 * 256 * 256),
+        "k_enc_* (JPEG encode)": (stage.get("encode_ms", 0.0), 3 * 256 * 256 + c_out),
+    }, plane_b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic source images tiled to the batch")
+    ap.add_argument("--distinct", type=int, default=1024, help="distinct synthetic source images (seed = index), tiled to the batch when fewer")
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device (0 = automatic)")
+    ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device per engine (0 = automatic)")
     ap.add_argument("--sub-bits", type=int, default=0, help="Huffman subsequence size in bits (0 = automatic)")
     ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
     ap.add_argument("--out", type=int, default=256, help="thumbnail side (256 = the BASELINE workload; other values exercise other resize branches)")
+    ap.add_argument("--resident", action="store_true", help="time the device pipeline with the compressed bytes already in HBM (kernel measurements) instead of host bytes in -> host bytes out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
     args = ap.parse_args()
 
     from lilliput_amd.dist import Ranks
@@ -108,77 +130,117 @@ def main():
 
     import lilliput_amd as la
 
-    paths = make_sources(args.batch, args.distinct, args.size, local_rank, world)
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
     barrier()
     distinct = [open(p, "rb").read() for p in paths]
     import numpy as np
 
     arrays = [np.frombuffer(d, dtype=np.uint8) for d in distinct]
-    sources = [arrays[i % len(arrays)] for i in range(args.batch)]
-    c_in = sum(len(distinct[i % len(distinct)]) for i in range(args.batch)) / args.batch
+    # every rank works on its own rotation of the set (weak scaling: per-GPU work is fixed)
+    sources = [arrays[(i + rank * 7) % len(arrays)] for i in range(args.batch)]
+    c_in = sum(a.size for a in sources) / args.batch
+    ndev = max(1, la.lib().lilliput_hip_device_count())
+    streams = int(os.environ.get("LILLIPUT_HIP_STREAMS", "4"))
 
-    b = la.Batch(local_rank % max(1, la.lib().lilliput_hip_device_count()))
+    b = la.Batch(local_rank % ndev)
     if args.sub_bits:
         b.set_subsequence(args.sub_bits, args.ckpt_bits)
-    t = time.time()
-    b.upload(sources, dst_cap=256 << 10)   # parse headers + H2D of the compressed bytes: NOT in the timed region
-    upload_s = time.time() - t
+    stage, ingest = {}, {"staged_bytes": 0, "stage_ms": 0.0, "stall_ms": 0.0, "wall_ms": 0.0}
+    upload_s = None
+    if args.resident:
+        t = time.time()
+        b.upload(sources, dst_cap=256 << 10)   # header walk + H2D of the compressed bytes: NOT in the timed region in this mode
+        upload_s = time.time() - t
 
-    def step():
-        b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+        def step():
+            b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+    else:
+        b.prepare(sources, dst_cap=256 << 10)  # the caller's item array: source and destination buffers in (pageable) host memory
 
-    stage = {}
+        def step():
+            # host bytes in -> host bytes out: header walk, staging memcpy, H2D, every device stage, D2H of the encoded thumbnails
+            b.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
 
     def timed_step():
         step()
         for k, v in b.timings().items():
             stage[k] = stage.get(k, 0.0) + v
+        if not args.resident:
+            for k, v in b.ingest_stats().items():
+                ingest[k] += v
 
     # W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation, MAX over ranks
     for _ in range(args.warmup):
         step()
     elapsed = ranks.timed(timed_step, args.steps, 0)
 
-    res = b.download()
+    res = b.download() if args.resident else b.results()
     ok = sum(1 for r in res if r.status == 0)
     digest = hashlib.sha256(res[0].data).hexdigest()[:16] if res and res[0].status == 0 else None
     c_out = sum(len(r.data) for r in res) / max(1, len(res))
+    h2d_gbs = ingest["staged_bytes"] / max(1e-9, ingest["wall_ms"] * 1e-3) / 1e9 if not args.resident else None
+    h2d_all = ranks.all_gather_ints([int((h2d_gbs or 0.0) * 1000)])
+
+    # ---- extra legs, outside the timed region (rank 0, after every rank has left it)
+    resident_ips, excl = None, None
+    if rank == 0 and not args.no_extra_legs:
+        if not args.resident:
+            # the device pipeline alone: the same batch with its compressed bytes resident in HBM
+            b.upload(sources, dst_cap=256 << 10)
+            b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            t = time.time()
+            for _ in range(2):
+                b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            resident_ips = 2 * args.batch / (time.time() - t)
+        # exclusive kernel durations: ONE engine, so that no other stream's kernels share the GPU with the launch being timed
+        nx = min(256, args.batch)
+        b1 = la.Batch(local_rank % ndev)
+        if args.sub_bits:
+            b1.set_subsequence(args.sub_bits, args.ckpt_bits)
+        b1.upload(sources[:nx], dst_cap=256 << 10, streams=1)
+        b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+        b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+        excl = b1.timings()
+        excl["images"] = nx
+        excl["launch_images"] = min(args.chunk or 128, nx)
+        b1.close()
 
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / elapsed
-        px = args.size * args.size
-        # Algorithmic bytes per image and kernel, W=H=4096: coefficient blocks are 64 x int8 + one int16 DC per
-        # block (1.5 x W x H bytes + 2 B per block), planes 1.5 x W x H.
-        blocks = 1.5 * px / 64
-        coef_b, dc_b, plane_b = 64 * blocks, 2 * blocks, 1.5 * px
-        kernels = {
-            "k_huff_spec (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
-            "k_huff_verify (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
-            "k_huff_write + k_dc_sum + k_dc_apply (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
-            "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
-            "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
-            "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
-            "k_resample_420 (upsample + colour + 16x16 box mean)": (stage.get("resize_ms", 0.0), plane_b + 3 * 256 * 256),
-            "k_enc_* (JPEG encode)": (stage.get("encode_ms", 0.0), 3 * 256 * 256 + c_out),
-        }
         per_rank_images = args.batch * args.steps
-        dom = max(kernels.items(), key=lambda kv: kv[1][0])
-        dom_ms, dom_bytes = dom[1]
-        achieved = (dom_bytes * per_rank_images) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        kernels, plane_b = kernel_table(stage, per_rank_images, c_in, c_out, args.size)
         breakdown = {k: {"ms_per_image": round(v[0] / per_rank_images, 5), "algorithmic_GBps": round(v[1] * per_rank_images / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                      for k, v in kernels.items()}
-        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_e_pmc_hbm_traffic.md): FETCH_SIZE (x2,
-        # the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, per launch of one chunk. Counters cannot be collected
-        # inside this process; the figure is per image x images per launch and is null when the file is absent.
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
-            launch_images = min(args.chunk or 128, args.batch)
-            traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
-        except Exception:
+        # Dominant kernel, EXCLUSIVE: algorithmic bytes per launch / average launch duration with one engine (HIP events on its
+        # stream). This is a property of the kernel; the same figure follows from the rocprofv3 kernel trace of
+        # `LILLIPUT_HIP_STREAMS=1 python bench.py --resident` committed under profiles/.
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        src_tab, src_n = (kernel_table(excl, excl["images"], c_in, c_out, args.size)[0], excl["images"]) if excl else (kernels, per_rank_images)
+        dom = max(src_tab.items(), key=lambda kv: kv[1][0])
+        dom_ms, dom_bytes = dom[1]
+        if dom_ms > 0:
+            launch_images = excl["launch_images"] if excl else min(args.chunk or 128, args.batch)
+            achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
             traffic = None
+            try:  # HBM bytes of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
+                traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
+            except Exception:
+                traffic = None
+            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(dom_bytes * launch_images), "launch_images": launch_images,
+                    "avg_launch_us": round(dom_ms * 1e3 / (src_n / launch_images), 1),
+                    "traffic_over_algorithmic": round(traffic / (dom_bytes * launch_images), 3) if traffic else None,
+                    "streams": 1 if excl else streams,
+                    "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
+                            "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by the latency "
+                            "of its serial symbol chain and by LDS-limited occupancy, not by HBM (DESIGN.md 4.1; profiles/r02_*_sq_counters.md)" % streams,
+                    "per_kernel_exclusive_us_per_image": {k.split(" ")[0]: round(v[0] * 1e3 / src_n, 2) for k, v in src_tab.items()} if excl else None,
+                    "per_kernel_in_timed_region": breakdown}
+        e2e_bytes = c_in + 2 * plane_b + 3 * 256 * 256 + c_out
         out = {
             "metric": "images/sec (4096x4096->256x256 JPEG q85)",
             "value": round(value, 2),
@@ -193,19 +255,27 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU -> 256x256 JPEG q85, ImageOpsFit (BASELINE configs[1])" % (args.batch, args.size, args.size),
+                       "timed_region": "compressed bytes resident in HBM -> thumbnails in host memory (device pipeline only)" if args.resident else
+                                       "host bytes in -> host bytes out: header walk + staging + H2D + decode/resample/encode + D2H (lilliput_hip_batch_transform)",
                        "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out),
-                       "parallelism": "independent images sharded per rank, no data-path collective", "ok_images": ok, "first_output_sha256_16": digest,
-                       "end_to_end_algorithmic_bytes_per_image": int(c_in + 2 * plane_b + 3 * 256 * 256 + c_out),
-                       "end_to_end_hbm_roofline_frac": round((c_in + 2 * plane_b + 3 * 256 * 256 + c_out) * value / world / (HBM_PEAK_GBS * 1e9), 5),
-                       "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps), "upload_s_not_timed": round(upload_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "note": "achieved = algorithmic bytes per launch / launch duration (HIP events on the engine streams, summed over the "
-                                 "concurrent parts of the batch: kernels of different parts overlap, so a launch's wall duration includes the "
-                                 "time it shares the GPU); the entropy decoder is VALU-issue bound, not HBM bound (DESIGN.md 4.1)",
-                         "per_kernel": breakdown},
+                       "parallelism": "independent images sharded per rank, no data-path collective", "engines_per_gpu": streams,
+                       "ok_images": ok, "first_output_sha256_16": digest,
+                       "end_to_end_algorithmic_bytes_per_image": int(e2e_bytes),
+                       "end_to_end_hbm_roofline_frac": round(e2e_bytes * value / world / (HBM_PEAK_GBS * 1e9), 5),
+                       "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps)},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU reference is timed at N=1 only (it would steal the other ranks' host cores)
+        if args.resident:
+            out["config"]["upload_s_not_timed"] = round(upload_s, 2)
+        else:
+            out["config"]["h2d_GBps_per_rank"] = [round(v[0] / 1000.0, 2) for v in h2d_all]
+            out["config"]["pcie_gen5_x16_measured_ceiling_GBps"] = 55.5   # scripts/microbench.hip on this box: pinned H2D 57 GB/s, staged pipeline 55.5 GB/s
+            out["config"]["ingest"] = {"staged_MB_per_step": round(ingest["staged_bytes"] / args.steps / 1e6, 1),
+                                       "stager_thread_ms_per_step": round(ingest["stage_ms"] / args.steps, 2),
+                                       "compute_threads_waiting_ms_per_step": round(ingest["stall_ms"] / args.steps, 2)}
+            if resident_ips:
+                out["config"]["resident_images_per_s"] = round(resident_ips, 2)
+        if not args.no_cpu_baseline:  # rank 0 only, after the timed region (every rank has passed the closing barrier)
             try:
                 out["cpu_baseline"] = cpu_baseline(distinct[: min(4, len(distinct))])
             except Exception as e:  # the checker is optional for the measurement itself

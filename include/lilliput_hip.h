@@ -242,11 +242,19 @@ typedef void* lilliput_hip_batch;
 
 lilliput_hip_batch lilliput_hip_batch_create(int device);
 void lilliput_hip_batch_destroy(lilliput_hip_batch b);
-/* JPEG -> (orientation, Fit/Resize) -> JPEG for n independent images; returns the number of failed items. */
+/* What n calls of ImageOps.Transform do in the reference (ops.go:352-444; every call starts from the caller's encoded bytes,
+ * opencv.cpp:99-171, and ends with the encoded result in the caller's dst, opencv.go:872-900), as ONE call: JPEG (and PNG / GIF)
+ * sources -> (orientation, Fit/Resize) -> JPEG for n independent images, host bytes in, host bytes out. Ingest is pipelined with
+ * the device work: per engine a stager thread walks the headers of chunk k + 1, copies its entropy-coded bytes into pinned memory
+ * and enqueues the H2D copy on a copy stream while chunk k is decoded. Returns the number of failed items. */
 int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt);
-/* Staged form used by bench.py: upload parses the headers and moves the compressed bytes into HBM,
+/* Of the last transform: out[0] bytes staged to the device, out[1] host ms spent staging (summed over the stager threads),
+ * out[2] ms the compute threads waited for a staged chunk, out[3] wall ms of the call. */
+void lilliput_hip_batch_ingest_stats(lilliput_hip_batch b, double out[4]);
+/* Resident form (kernel-pipeline measurements, tests): upload parses the headers and moves the compressed bytes into HBM,
  * run executes every device stage (inputs resident), download copies the encoded results back. */
 int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);
+int lilliput_hip_batch_upload2(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n, int engines); /* engines: how many engines (streams) share the batch, 0 = default (LILLIPUT_HIP_STREAMS, 4) */
 int lilliput_hip_batch_run(lilliput_hip_batch b, const lilliput_batch_options* opt);
 int lilliput_hip_batch_download(lilliput_hip_batch b, lilliput_batch_item* items, size_t n);
 /* Per-stage device milliseconds of the last run (HIP events on the engine's stream): unstuff, huffman (total), idct,

@@ -85,10 +85,13 @@ def lib():
     L.lilliput_hip_batch_destroy.argtypes = [C.c_void_p]
     L.lilliput_hip_batch_transform.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t, C.POINTER(_BatchOptions)]
     L.lilliput_hip_batch_upload.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t]
+    L.lilliput_hip_batch_upload2.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t, C.c_int]
     L.lilliput_hip_batch_run.argtypes = [C.c_void_p, C.POINTER(_BatchOptions)]
     L.lilliput_hip_batch_download.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t]
     L.lilliput_hip_batch_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.lilliput_hip_batch_set_subsequence.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    L.lilliput_hip_batch_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.lilliput_hip_batch_ingest_stats.restype = None
     L.lilliput_hip_decode_jpeg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.lilliput_hip_decode_jpeg_coefs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lilliput_hip_decode_jpeg_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -306,10 +309,28 @@ class Batch:
         lib().lilliput_hip_batch_transform(self._h, self._items, len(sources), C.byref(o))
         return self._results()
 
-    # staged form (bench): inputs resident in HBM before run()
-    def upload(self, sources, dst_cap=1 << 20):
+    # the same call with the item array built beforehand (what a caller that already holds its buffers pays: nothing per call)
+    def prepare(self, sources, dst_cap=1 << 20):
         self._items, self._keep = self._make_items(sources, dst_cap)
-        rc = lib().lilliput_hip_batch_upload(self._h, self._items, len(sources))
+
+    def transform_prepared(self, width, height, method=ImageOpsFit, normalize=False, quality=85, chunk=0, progressive=False):
+        o = self._opts(width, height, method, normalize, quality, chunk, progressive)
+        return lib().lilliput_hip_batch_transform(self._h, self._items, len(self._items), C.byref(o))
+
+    def results(self):
+        return self._results()
+
+    def ingest_stats(self):
+        """Of the last transform(): bytes staged to the device, host ms spent staging (summed over the parts' stager threads), ms the
+        compute threads waited for a staged chunk, wall ms of the call."""
+        v = (C.c_double * 4)()
+        lib().lilliput_hip_batch_ingest_stats(self._h, v)
+        return {"staged_bytes": int(v[0]), "stage_ms": v[1], "stall_ms": v[2], "wall_ms": v[3]}
+
+    # staged form (bench): inputs resident in HBM before run()
+    def upload(self, sources, dst_cap=1 << 20, streams=0):
+        self._items, self._keep = self._make_items(sources, dst_cap)
+        rc = lib().lilliput_hip_batch_upload2(self._h, self._items, len(sources), int(streams))  # streams: engines the batch is split over (0 = default)
         if rc:
             raise LilliputError(rc, "batch_upload")
 

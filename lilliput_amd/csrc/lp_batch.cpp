@@ -8,7 +8,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 
@@ -18,19 +21,23 @@
 #include "lp_abi.h"
 #include "lp_ops_logic.h"
 
-// One engine (= one HIP stream + its arenas) per worker; a batch is split into contiguous parts, one per worker, and the
-// workers run concurrently on host threads so that one part's HBM-bound stages (IDCT, resample, unstuff) overlap another
-// part's VALU-bound Huffman stages on the same GPU.
+// One engine (= one compute stream + one copy stream + its arenas) per worker; a batch is split into contiguous parts, one per
+// worker, and the workers run concurrently on host threads so that one part's HBM-bound stages (IDCT, resample, unstuff) overlap
+// another part's latency-bound Huffman stages on the same GPU.
 struct LpBatchPart {
     std::unique_ptr<LpEngine> eng;
-    std::vector<LpJpegHeader> hdrs;     // parsed headers of this part's items (upload order)
+    std::vector<LpJpegHeader> hdrs;     // parsed headers of this part's items (upload order) -- resident (staged) API
     std::vector<int> items;             // their indices in the item array
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
     double tw[6] = {0, 0, 0, 0, 0, 0};
+    double stage_ms = 0, stall_ms = 0;  // pipelined transform: host time spent staging (parse + memcpy + enqueue), compute thread waiting for a staged chunk
+    size_t staged_bytes = 0;
     std::string err;
     int rc = 0;
 };
+
+struct LpOtherItem { int item; const uint8_t* data; size_t len; size_t dst_cap; std::vector<uint8_t> copy; };
 
 struct LpBatch {
     int device = 0;
@@ -43,9 +50,11 @@ struct LpBatch {
     size_t n_items = 0;
     uint32_t S = 0, C = 0;
     LpTimings tm = {};
-    // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path; PNG): copied at
-    // upload, transformed one by one on the calling thread while the JPEG parts run
-    std::vector<std::pair<int, std::vector<uint8_t>>> other;
+    double last_stage_ms = 0, last_stall_ms = 0, last_wall_ms = 0;
+    size_t last_staged_bytes = 0;
+    // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path; PNG):
+    // transformed one by one on a few host workers while the JPEG parts run
+    std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
     ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); }
     LpEngine& eng0() { return *parts[0].eng; }
@@ -83,6 +92,31 @@ static int map_status(int st)
     }
 }
 
+// The reference sizes its frame buffers with NewImageOps(maxSize) and answers ErrBufTooSmall for anything larger
+// (opencv.go:250-267 resizeMat); the batch has the same bound -- 8192 x 8192 pixels unless LILLIPUT_HIP_BATCH_MAX_PIXELS says
+// otherwise -- so that one file with an absurd frame header cannot take the other images' arenas down with it.
+static uint64_t batch_max_pixels()
+{
+    static const uint64_t v = getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS") ? strtoull(getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS"), nullptr, 10) : 8192ull * 8192ull;
+    return v;
+}
+
+static bool is_other_format(const uint8_t* sp, size_t len)
+{
+    static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
+    return sp && ((len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
+                  (len >= 8 && memcmp(sp, png_sig, 8) == 0));
+}
+
+// Header walk of one JPEG item + the batch's size bound. Returns LILLIPUT_OK when the item goes to the device.
+static int parse_item(const void* src, size_t len, LpJpegHeader* h)
+{
+    const int rc = (src && len) ? lp_jpeg_parse((const uint8_t*)src, len, h) : LP_PARSE_NOT_JPEG;
+    if (rc != LP_PARSE_OK) return map_parse(rc);
+    if ((uint64_t)h->j.width * h->j.height > batch_max_pixels()) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    return LILLIPUT_OK;
+}
+
 extern "C" {
 
 lilliput_hip_batch lilliput_hip_batch_create(int device)
@@ -110,6 +144,14 @@ void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* ve
     if (verify_rounds) *verify_rounds = (int)t.verify_rounds;
 }
 
+void lilliput_hip_batch_ingest_stats(lilliput_hip_batch bb, double out[4])
+{
+    auto b = static_cast<LpBatch*>(bb);
+    out[0] = (double)b->last_staged_bytes; out[1] = b->last_stage_ms; out[2] = b->last_stall_ms; out[3] = b->last_wall_ms;
+}
+
+} // extern "C"
+
 static int batch_streams(int requested)
 {
     int n = requested;
@@ -117,7 +159,7 @@ static int batch_streams(int requested)
     return std::max(1, std::min(8, n));
 }
 
-int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n, int streams)
+extern "C" int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n, int streams)
 {
     auto b = static_cast<LpBatch*>(bb);
     if (!b) return LILLIPUT_ERR_DEVICE;
@@ -127,23 +169,17 @@ int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item*
     std::vector<int> valid;
     std::vector<LpJpegHeader> hv;
     for (size_t i = 0; i < n; i++) {
-        LpJpegHeader h;
         const uint8_t* sp = (const uint8_t*)items[i].src;
-        static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
-        if (sp && ((items[i].src_len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
-                   (items[i].src_len >= 8 && memcmp(sp, png_sig, 8) == 0))) {
-            b->other.emplace_back((int)i, std::vector<uint8_t>(sp, sp + items[i].src_len));
+        if (is_other_format(sp, items[i].src_len)) {
+            LpOtherItem o{(int)i, nullptr, items[i].src_len, items[i].dst_cap, std::vector<uint8_t>(sp, sp + items[i].src_len)};
+            b->other.push_back(std::move(o));
             continue;
         }
-        int rc = (items[i].src && items[i].src_len) ? lp_jpeg_parse((const uint8_t*)items[i].src, items[i].src_len, &h) : LP_PARSE_NOT_JPEG;
-        b->parse_status[i] = map_parse(rc);
-        // The reference sizes its frame buffers with NewImageOps(maxSize) and answers ErrBufTooSmall for anything larger
-        // (opencv.go:250-267 resizeMat); the batch has the same bound -- 8192 x 8192 pixels unless LILLIPUT_HIP_BATCH_MAX_PIXELS says
-        // otherwise -- so that one file with an absurd frame header cannot take the other images' arenas down with it.
-        static const uint64_t max_px = getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS") ? strtoull(getenv("LILLIPUT_HIP_BATCH_MAX_PIXELS"), nullptr, 10) : 8192ull * 8192ull;
-        if (rc == LP_PARSE_OK && (uint64_t)h.j.width * h.j.height > max_px) { b->parse_status[i] = LILLIPUT_ERR_BUF_TOO_SMALL; continue; }
-        if (rc == LP_PARSE_OK) { valid.push_back((int)i); hv.push_back(h); }
+        LpJpegHeader h;
+        b->parse_status[i] = parse_item(items[i].src, items[i].src_len, &h);
+        if (b->parse_status[i] == LILLIPUT_OK) { valid.push_back((int)i); hv.push_back(h); }
     }
+    for (auto& o : b->other) o.data = o.copy.data();
     // contiguous parts, one per worker; small batches stay on one stream
     size_t np = (size_t)batch_streams(streams);
     if (valid.size() < 2 * np) np = 1;
@@ -165,37 +201,51 @@ int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item*
     return LILLIPUT_OK;
 }
 
-int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n) { return lilliput_hip_batch_upload2(bb, items, n, 0); }
+extern "C" int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n) { return lilliput_hip_batch_upload2(bb, items, n, 0); }
 
-// Every stage of ImageOps.Transform for one part of the batch (runs on the part's own host thread).
-static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options* opt, bool trace)
+// Where the bytes of a finished item go: the resident API keeps them for download(), the pipelined transform writes the caller's buffer.
+struct LpSink {
+    LpBatch* b;
+    lilliput_batch_item* items;     // nullptr: resident API
+    void put(size_t item, const uint8_t* p, uint32_t len, int w, int h) const
+    {
+        b->out_w[item] = w; b->out_h[item] = h; b->out_len[item] = len;
+        if (!items) { b->out_bytes[item].assign(p, p + len); return; }
+        if (len > items[item].dst_cap || !items[item].dst) { b->status[item] = LILLIPUT_ERR_BUF_TOO_SMALL; return; }
+        memcpy(items[item].dst, p, len);
+    }
+};
+
+static size_t auto_chunk(const lilliput_batch_options* opt, const LpJpegHeader* hdrs, size_t n, size_t cap)
 {
-    LpEngine& eng = *part.eng;
-    const size_t nv = part.items.size();
-    float* acc = part.acc;
-    for (int i = 0; i < 10; i++) acc[i] = 0;
-    for (int i = 0; i < 6; i++) part.tw[i] = 0;
-    part.rounds = 0;
-    if (!nv) return LILLIPUT_OK;
-    auto fail = [&](const std::string& m) { part.err = m; return LILLIPUT_ERR_DEVICE; };
-    const int quality = opt->jpeg_quality > 0 ? opt->jpeg_quality : 95;
     // chunk size: bound the working set (coefficients + planes + BGR frame ~ 7.5 B/pixel + oriented copy)
     size_t max_px = 1;
-    for (auto& h : part.hdrs) max_px = std::max(max_px, (size_t)h.j.mcus_x * h.j.hmax * 8 * h.j.mcus_y * h.j.vmax * 8);
-    size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(128, (size_t)(24ull << 30) / (max_px * 12)));
+    for (size_t i = 0; i < n; i++) max_px = std::max(max_px, (size_t)hdrs[i].j.mcus_x * hdrs[i].j.hmax * 8 * hdrs[i].j.mcus_y * hdrs[i].j.vmax * 8);
+    return opt->chunk > 0 ? (size_t)opt->chunk : std::max<size_t>(1, std::min<size_t>(cap, (size_t)(24ull << 30) / (max_px * 12)));
+}
+
+// Every device stage of ImageOps.Transform for images [first, first + cnt) of the engine's selected upload set: hdrs / item_of are
+// indexed from `first` (hdrs[k] belongs to image first + k). Runs on the part's own host thread.
+// deferred: the decode is only enqueued and collected after the encode, so the chunk runs without a host round trip between its
+// stages (the verify rounds, the resample and the encode are queued behind each other on the engine's stream); the rare chunk whose
+// entropy streams need more verify rounds than were enqueued is run again the plain way.
+static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const LpJpegHeader* hdrs, const int* item_of, const lilliput_batch_options* opt,
+                     const LpSink& sink, bool deferred = true)
+{
+    LpEngine& eng = *part.eng;
+    float* acc = part.acc;
+    auto fail = [&](const std::string& m) { part.err = m; return LILLIPUT_ERR_DEVICE; };
+    const int quality = opt->jpeg_quality > 0 ? opt->jpeg_quality : 95;
     uint32_t& rounds = part.rounds;
     double* tw = part.tw;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
-    (void)trace;
-    eng.enable_timing(true);
-    for (size_t first = 0; first < nv; first += chunk) {
-        const int cnt = (int)std::min(chunk, nv - first);
+    {
         // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
         size_t need = 0;
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = part.hdrs[first + k].j;
+            const LpJpeg& j = hdrs[k].j;
             const bool swap = j.orientation >= 5;
             const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
@@ -219,7 +269,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
         std::vector<int> fidx;
         memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = part.hdrs[first + k].j;
+            const LpJpeg& j = hdrs[k].j;
             const bool swap = j.orientation >= 5;
             const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
@@ -264,14 +314,14 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
             want[(size_t)k] = 0;
         }
         lap(0);
-        int rc = eng.decode_uploaded((int)first, cnt, frames.data(), st.data(), want.data());
+        auto add_decode_timings = [&] { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); };
+        int rc = deferred ? eng.decode_begin(first, cnt, frames.data(), want.data()) : eng.decode_uploaded(first, cnt, frames.data(), st.data(), want.data());
         lap(1);
-        if (rc == LP_ERR_DEVICE) return fail(eng.last_error());
-        { const LpTimings& t = eng.timings(); acc[0] += t.unstuff_ms; acc[1] += t.huff_ms; acc[2] += t.idct_ms; acc[3] += t.color_ms; acc[6] += t.huff_spec_ms; acc[7] += t.huff_verify_ms; acc[8] += t.huff_scan_ms; acc[9] += t.huff_write_ms; rounds = std::max(rounds, t.verify_rounds); }
+        if (rc == LP_ERR_DEVICE || (deferred && rc)) return fail(eng.last_error());
+        if (!deferred) add_decode_timings();
         std::vector<LpFrame> final_frames = frames;
         if (!fops.empty()) {
             if (eng.fused_resample(fops.data(), (int)fops.size())) return fail(eng.last_error());
-            acc[4] += eng.timings().resize_ms;
             for (size_t q = 0; q < fops.size(); q++) final_frames[(size_t)fidx[q]] = fops[q].dst;
         }
         lap(2);
@@ -279,7 +329,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
         std::vector<LpOrientOp> oops;
         std::vector<int> oidx;
         for (int k = 0; k < cnt; k++) {
-            const LpJpeg& j = part.hdrs[first + k].j;
+            const LpJpeg& j = hdrs[k].j;
             if (st[(size_t)k] || j.orientation == 1 || !want[(size_t)k]) continue;
             LpOrientOp op;
             memset(&op, 0, sizeof(op));
@@ -358,33 +408,64 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
                 if (eng.encoded_fetch_all()) return fail(eng.last_error());
                 lap(4);
             }
+            if (deferred) { // collect the decode: by now its stream has drained
+                std::vector<int> dst((size_t)cnt, 0);
+                rc = eng.finish_decode(dst.data());
+                if (rc == LP_RETRY) return run_chunk(b, part, first, cnt, hdrs, item_of, opt, sink, false);
+                if (rc == LP_ERR_DEVICE) return fail(eng.last_error());
+                add_decode_timings();
+                for (int k = 0; k < cnt; k++) if (dst[(size_t)k]) st[(size_t)k] = dst[(size_t)k];
+                deferred = false;
+            }
+            if (!fops.empty()) acc[4] += eng.fused_resample_ms();
             for (size_t q = 0; q < erq.size(); q++) {
                 const int k = eidx[q];
-                const size_t item = (size_t)part.items[first + (size_t)k];
+                const size_t item = (size_t)item_of[k];
+                if (st[(size_t)k]) continue;
                 if (est[q]) { st[(size_t)k] = est[q]; continue; }
-                b->out_w[item] = (int)erq[q].src.w;
-                b->out_h[item] = (int)erq[q].src.h;
-                if (opt->jpeg_progressive) {
-                    b->out_len[item] = (uint32_t)prog[q].size();
-                    b->out_bytes[item].swap(prog[q]);
-                } else {
-                    b->out_len[item] = elen[q];
-                    b->out_bytes[item].assign(eng.encoded_host((int)q), eng.encoded_host((int)q) + elen[q]);
-                }
+                if (opt->jpeg_progressive) sink.put(item, prog[q].data(), (uint32_t)prog[q].size(), (int)erq[q].src.w, (int)erq[q].src.h);
+                else sink.put(item, eng.encoded_host((int)q), elen[q], (int)erq[q].src.w, (int)erq[q].src.h);
             }
         }
+        if (deferred) { // nothing was encoded (every image failed earlier): the decode still has to be collected
+            std::vector<int> dst((size_t)cnt, 0);
+            rc = eng.finish_decode(dst.data());
+            if (rc == LP_RETRY) return run_chunk(b, part, first, cnt, hdrs, item_of, opt, sink, false);
+            if (rc == LP_ERR_DEVICE) return fail(eng.last_error());
+            add_decode_timings();
+            for (int k = 0; k < cnt; k++) if (dst[(size_t)k]) st[(size_t)k] = dst[(size_t)k];
+        }
         for (int k = 0; k < cnt; k++) {
-            const size_t item = (size_t)part.items[first + (size_t)k];
+            const size_t item = (size_t)item_of[k];
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
         }
     }
     lap(5);
-    eng.enable_timing(false);
     return LILLIPUT_OK;
 }
 
+// Resident (staged) API: the part's whole upload set sits in slot 0; chunks of it are decoded one after the other.
+static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options* opt)
+{
+    for (int i = 0; i < 10; i++) part.acc[i] = 0;
+    for (int i = 0; i < 6; i++) part.tw[i] = 0;
+    part.rounds = 0;
+    const size_t nv = part.items.size();
+    if (!nv) return LILLIPUT_OK;
+    LpEngine& eng = *part.eng;
+    eng.select_upload(0);
+    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, 128);
+    const LpSink sink{b, nullptr};
+    eng.enable_timing(true);
+    int rc = LILLIPUT_OK;
+    for (size_t first = 0; first < nv && rc == LILLIPUT_OK; first += chunk)
+        rc = run_chunk(b, part, (int)first, (int)std::min(chunk, nv - first), part.hdrs.data() + first, part.items.data() + first, opt, sink);
+    eng.enable_timing(false);
+    return rc;
+}
+
 // GIF and PNG items: Decoder + ImageOps.Transform of the Go-API mirror (for GIF the JPEG writer returns after the first composited frame)
-static void run_other(LpBatch* b, const lilliput_batch_options* opt)
+static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_batch_item* items)
 {
     if (b->other.empty()) return;
     const int enc_opts[4] = {CV_IMWRITE_JPEG_PROGRESSIVE, opt->jpeg_progressive ? 1 : 0, CV_IMWRITE_JPEG_QUALITY, opt->jpeg_quality};
@@ -402,34 +483,52 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt)
     const size_t nw = std::min<size_t>(b->other.size(), (size_t)std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 8)));
     while (b->other_ops.size() < nw) b->other_ops.push_back(lilliput_new_image_ops(8192));
     std::atomic<size_t> next{0};
+    auto one = [&](lilliput_image_ops ops, LpOtherItem& it) -> int {
+        const size_t i = (size_t)it.item;
+        if (!ops) return LILLIPUT_ERR_DEVICE;
+        lilliput_decoder d = nullptr;
+        int rc = lilliput_new_decoder(it.data, it.len, &d);
+        if (rc) return rc;
+        int w = 0, h = 0;
+        rc = lilliput_decoder_header(d, &w, &h, nullptr, nullptr, nullptr, nullptr);
+        // the same frame bound as the JPEG items: the header is untrusted (a 60-byte PNG may claim 10^6 x 10^6 pixels)
+        if (!rc && (w <= 0 || h <= 0)) rc = LILLIPUT_ERR_INVALID_IMAGE;
+        if (!rc && (uint64_t)w * (uint64_t)h > batch_max_pixels()) rc = LILLIPUT_ERR_BUF_TOO_SMALL;
+        if (rc) { lilliput_decoder_close(d); return rc; }
+        int ow = w, oh = h;
+        if (opt->resize_method == LILLIPUT_OPS_FIT) lilliput_calculate_expected_size(w, h, opt->width, opt->height, &ow, &oh);
+        else if (opt->resize_method == LILLIPUT_OPS_RESIZE) { ow = std::max(opt->width, 1); oh = std::max(opt->height, 1); }
+        // output buffer: the caller's (pipelined transform) or one sized from the OUTPUT dimensions (never from the source header alone)
+        uint8_t* out = nullptr;
+        size_t cap = 0;
+        if (items) { out = (uint8_t*)items[i].dst; cap = items[i].dst_cap; }
+        else {
+            cap = std::min<size_t>(it.dst_cap ? it.dst_cap : SIZE_MAX, (size_t)ow * (size_t)oh * 3 + 65536);
+            b->out_bytes[i].resize(cap);
+            out = b->out_bytes[i].data();
+        }
+        size_t n = 0;
+        rc = out ? lilliput_image_ops_transform(ops, d, &io, out, cap, &n) : LILLIPUT_ERR_BUF_TOO_SMALL;
+        if (!rc) {
+            if (!items) b->out_bytes[i].resize(n);
+            b->out_len[i] = (uint32_t)n;
+            b->out_w[i] = ow; b->out_h[i] = oh;
+        }
+        lilliput_decoder_close(d);
+        return rc;
+    };
     auto worker = [&](size_t wi) {
         const int prev_dev = lp_thread_device(b->device);
         lilliput_image_ops ops = b->other_ops[wi];
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= b->other.size()) break;
-            auto& it = b->other[k];
-            const size_t i = (size_t)it.first;
-            if (!ops) { b->status[i] = LILLIPUT_ERR_DEVICE; continue; }
-            lilliput_decoder d = nullptr;
-            int rc = lilliput_new_decoder(it.second.data(), it.second.size(), &d);
-            if (!rc) {
-                int w = 0, h = 0;
-                (void)lilliput_decoder_header(d, &w, &h, nullptr, nullptr, nullptr, nullptr);
-                std::vector<uint8_t>& out = b->out_bytes[i];
-                out.resize((size_t)std::max(opt->width, 1) * std::max(opt->height, 1) * 3 + ((size_t)w * h * 3 + 65536));
-                size_t n = 0;
-                rc = lilliput_image_ops_transform(ops, d, &io, out.data(), out.size(), &n);
-                if (!rc) {
-                    out.resize(n);
-                    b->out_len[i] = (uint32_t)n;
-                    if (opt->resize_method == LILLIPUT_OPS_NO_RESIZE) { b->out_w[i] = w; b->out_h[i] = h; }
-                    else if (opt->resize_method == LILLIPUT_OPS_FIT) lilliput_calculate_expected_size(w, h, opt->width, opt->height, &b->out_w[i], &b->out_h[i]);
-                    else { b->out_w[i] = std::max(opt->width, 1); b->out_h[i] = std::max(opt->height, 1); }
-                }
-                lilliput_decoder_close(d);
-            }
-            b->status[i] = rc;
+            int rc;
+            // nothing may unwind through a std::thread or the C ABI
+            try { rc = one(ops, b->other[k]); }
+            catch (const std::bad_alloc&) { rc = LILLIPUT_ERR_BUF_TOO_SMALL; }
+            catch (...) { rc = LILLIPUT_ERR_DEVICE; }
+            b->status[(size_t)b->other[k].item] = rc;
         }
         (void)lp_thread_device(prev_dev);
     };
@@ -439,50 +538,62 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt)
     for (auto& t : th) t.join();
 }
 
-int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
+static void begin_run(LpBatch* b, size_t n)
 {
-    auto b = static_cast<LpBatch*>(bb);
-    if (!b || !opt) return LILLIPUT_ERR_DEVICE;
-    const size_t n = b->n_items;
     b->status = b->parse_status;
     b->out_w.assign(n, 0);
     b->out_h.assign(n, 0);
     b->out_len.assign(n, 0);
     b->out_bytes.assign(n, std::vector<uint8_t>());
-    // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
-    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
-    const auto t_run0 = std::chrono::steady_clock::now();
-    size_t active = 0;
-    for (auto& p : b->parts) active += p.items.empty() ? 0 : 1;
-    if (active <= 1 && b->other.empty()) {
-        for (auto& p : b->parts) p.rc = p.items.empty() ? LILLIPUT_OK : run_part(b, p, opt, trace);
-    } else {
-        std::vector<std::thread> th;
-        for (auto& p : b->parts)
-            if (!p.items.empty()) th.emplace_back([b, &p, opt, trace] { p.rc = run_part(b, p, opt, trace); });
-            else p.rc = LILLIPUT_OK;
-        run_other(b, opt);
-        for (auto& t : th) t.join();
-    }
+}
+
+static int end_run(LpBatch* b, size_t n, bool trace, std::chrono::steady_clock::time_point t0)
+{
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
     int rc = LILLIPUT_OK;
+    b->last_stage_ms = b->last_stall_ms = 0;
+    b->last_staged_bytes = 0;
     for (auto& p : b->parts) {
         if (p.rc) { rc = p.rc; lp_set_error(p.err); }
-        if (p.items.empty()) continue;
         for (int i = 0; i < 10; i++) acc[i] += p.acc[i];
         rounds = std::max(rounds, p.rounds);
+        b->last_stage_ms += p.stage_ms; b->last_stall_ms += p.stall_ms; b->last_staged_bytes += p.staged_bytes;
         if (trace)
-            fprintf(stderr, "[lilliput_hip] part of %zu: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f\n",
-                    p.items.size(), p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5]);
+            fprintf(stderr, "[lilliput_hip] part: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f | staging %.2f ms for %.1f MB, waited %.2f ms for staged chunks\n",
+                    p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5], p.stage_ms, p.staged_bytes / 1e6, p.stall_ms);
     }
-    if (trace)
-        fprintf(stderr, "[lilliput_hip] run of %zu items: %.2f ms wall\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
+    b->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (trace) fprintf(stderr, "[lilliput_hip] run of %zu items: %.2f ms wall\n", n, b->last_wall_ms);
     b->tm = LpTimings{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], rounds, acc[6], acc[7], acc[8], acc[9]}; // read by lilliput_hip_batch_timings
     return rc;
 }
 
-int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n)
+extern "C" int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || !opt) return LILLIPUT_ERR_DEVICE;
+    const size_t n = b->n_items;
+    begin_run(b, n);
+    // LILLIPUT_HIP_TRACE=1: host wall-clock per phase of a run (plan / decode / resample / encode / fetch / copy-out)
+    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
+    const auto t_run0 = std::chrono::steady_clock::now();
+    size_t active = 0;
+    for (auto& p : b->parts) { active += p.items.empty() ? 0 : 1; p.stage_ms = p.stall_ms = 0; p.staged_bytes = 0; }
+    if (active <= 1 && b->other.empty()) {
+        for (auto& p : b->parts) p.rc = p.items.empty() ? LILLIPUT_OK : run_part(b, p, opt);
+    } else {
+        std::vector<std::thread> th;
+        for (auto& p : b->parts)
+            if (!p.items.empty()) th.emplace_back([b, &p, opt] { p.rc = run_part(b, p, opt); });
+            else p.rc = LILLIPUT_OK;
+        run_other(b, opt, nullptr);
+        for (auto& t : th) t.join();
+    }
+    return end_run(b, n, trace, t_run0);
+}
+
+extern "C" int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n)
 {
     auto b = static_cast<LpBatch*>(bb);
     if (!b || n != b->n_items) return -1;
@@ -504,14 +615,183 @@ int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* item
     return failed;
 }
 
-int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+// ------------------------------------------------------------------------------------------------
+// Host bytes in -> host bytes out, pipelined: what n calls of ImageOps.Transform do in the reference (each starts from the caller's
+// []byte, opencv.cpp:99-171, and ends with the encoded bytes in the caller's dst, opencv.go:872-900), as one call.
+// Every part (engine) has a stager thread and a compute thread. The stager walks the part's chunks: header walk of the chunk's
+// items, layout, memcpy of the entropy-coded segments into the slot's pinned buffer, asynchronous H2D on the engine's copy stream
+// (one PCIe Gen5 x16 link moves ~55 GB/s -- scripts/microbench.hip -- and one host thread stages ~30 GB/s, so one stager per part
+// keeps the link busy); the compute thread decodes chunk k while chunks k + 1 and k + 2 are being staged and copied. The compute
+// stream waits for a chunk's copies through an event, never the host.
+struct LpPipeJob {
+    size_t i0 = 0, i1 = 0;              // item range
+    std::vector<LpJpegHeader> hdrs;     // the items the device takes
+    std::vector<int> items;
+    std::vector<LpJpegSrc> srcs;
+    int rc = 0;
+};
+// The chunks of a batch form one queue; every part's stager claims the next chunk when one of its slots is free, so the parts
+// finish within a chunk of each other whatever the mix of image sizes (and whichever copy stream the link served first).
+struct LpPipeShared {
+    std::vector<LpPipeJob> jobs;
+    std::atomic<size_t> next{0};
+};
+struct LpPipe {
+    std::vector<size_t> mine;           // claimed jobs, in order (job k of this part uses upload slot k % LP_UPLOAD_SLOTS)
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t staged = 0, done = 0;
+    bool no_more = false, abort = false;
+};
+
+static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_item* items)
 {
-    int rc = lilliput_hip_batch_upload(b, items, n);
-    if (rc) { for (size_t i = 0; i < n; i++) { items[i].status = rc; items[i].dst_len = 0; } return (int)n; }
-    rc = lilliput_hip_batch_run(b, opt);
-    if (rc) { for (size_t i = 0; i < n; i++) { items[i].status = rc; items[i].dst_len = 0; } return (int)n; }
-    return lilliput_hip_batch_download(b, items, n);
+    LpEngine& eng = *part.eng;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (size_t k = 0;; k++) {
+        {
+            std::unique_lock<std::mutex> lk(pp.mu);
+            pp.cv.wait(lk, [&] { return pp.abort || k < pp.done + LP_UPLOAD_SLOTS; }); // slot k % SLOTS: its previous chunk has been decoded
+            if (pp.abort) break;
+        }
+        const size_t ji = sh.next.fetch_add(1);
+        if (ji >= sh.jobs.size()) break;
+        const double t0 = now();
+        LpPipeJob& job = sh.jobs[ji];
+        const int slot = (int)(k % LP_UPLOAD_SLOTS);
+        try {
+            for (size_t i = job.i0; i < job.i1; i++) {
+                if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) continue; // run_other's
+                job.hdrs.emplace_back();
+                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back());
+                b->status[i] = st;
+                if (st != LILLIPUT_OK) { job.hdrs.pop_back(); continue; }
+                job.items.push_back((int)i);
+                job.srcs.push_back(LpJpegSrc{(const uint8_t*)items[i].src, items[i].src_len});
+            }
+            if (!job.items.empty()) {
+                int rc = eng.upload_layout(slot, job.srcs.data(), (int)job.srcs.size(), job.hdrs.data());
+                if (!rc) {
+                    eng.upload_copy(slot, 0, eng.upload_pieces(slot));
+                    rc = eng.upload_commit(slot);
+                    part.staged_bytes += eng.upload_bytes(slot);
+                }
+                if (rc) { job.rc = map_status(rc); part.err = eng.last_error(); }
+            }
+        } catch (...) { job.rc = LILLIPUT_ERR_DEVICE; part.err = "staging failed (out of host memory?)"; }
+        part.stage_ms += now() - t0;
+        {
+            std::lock_guard<std::mutex> lk(pp.mu);
+            pp.mine.push_back(ji);
+            pp.staged = k + 1;
+            if (job.rc) pp.abort = true;
+        }
+        pp.cv.notify_all();
+        if (job.rc) break;
+    }
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        pp.no_more = true;
+    }
+    pp.cv.notify_all();
 }
+
+static void pipe_compute(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_options* opt, const LpSink& sink)
+{
+    LpEngine& eng = *part.eng;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    eng.enable_timing(true);
+    for (size_t k = 0;; k++) {
+        const double t0 = now();
+        size_t ji;
+        {
+            std::unique_lock<std::mutex> lk(pp.mu);
+            pp.cv.wait(lk, [&] { return pp.staged > k || pp.no_more; });
+            if (pp.staged <= k) break; // nothing more for this part
+            ji = pp.mine[k];
+        }
+        part.stall_ms += now() - t0;
+        LpPipeJob& job = sh.jobs[ji];
+        int rc = job.rc;
+        if (!rc && !job.items.empty()) {
+            eng.select_upload((int)(k % LP_UPLOAD_SLOTS));
+            try { rc = run_chunk(b, part, 0, (int)job.items.size(), job.hdrs.data(), job.items.data(), opt, sink); }
+            catch (...) { rc = LILLIPUT_ERR_DEVICE; part.err = "chunk failed (out of host memory?)"; }
+        }
+        {
+            std::lock_guard<std::mutex> lk(pp.mu);
+            pp.done = k + 1;
+            if (rc) { part.rc = rc; pp.abort = true; }
+        }
+        pp.cv.notify_all();
+        if (rc) break;
+    }
+    eng.enable_timing(false);
+    eng.select_upload(0);
+}
+
+extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || !opt || (!items && n)) return (int)n;
+    const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    b->n_items = n;
+    b->parse_status.assign(n, LILLIPUT_OK);
+    begin_run(b, n);
+    b->other.clear();
+    size_t njpeg = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) b->other.push_back(LpOtherItem{(int)i, (const uint8_t*)items[i].src, items[i].src_len, items[i].dst_cap, {}});
+        else njpeg++;
+    }
+    size_t np = (size_t)batch_streams(0);
+    if (njpeg < 2 * np) np = 1;
+    int rc = LILLIPUT_OK;
+    if (!b->ensure_parts(np)) rc = LILLIPUT_ERR_DEVICE;
+    if (!rc) {
+        // chunk: LILLIPUT_HIP_PIPE_CHUNK images (default 32) -- small enough that the first chunk's copy is short, large enough to fill the device
+        static const size_t pipe_chunk = getenv("LILLIPUT_HIP_PIPE_CHUNK") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PIPE_CHUNK"))) : 32;
+        const size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : pipe_chunk;
+        std::vector<std::unique_ptr<LpPipe>> pipes;
+        LpPipeShared sh;
+        for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
+            LpPipeJob job;
+            job.i0 = i;
+            size_t bytes = 0, cnt = 0;
+            while (i < n && cnt < chunk && (cnt == 0 || bytes + items[i].src_len <= (1ull << 30))) { bytes += items[i].src_len; cnt++; i++; }
+            job.i1 = i;
+            sh.jobs.push_back(std::move(job));
+        }
+        for (auto& part : b->parts) {
+            for (int i = 0; i < 10; i++) part.acc[i] = 0;
+            for (int i = 0; i < 6; i++) part.tw[i] = 0;
+            part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = 0; part.staged_bytes = 0; part.err.clear();
+        }
+        const LpSink sink{b, items};
+        std::vector<std::thread> th;
+        for (size_t p = 0; p < np && p < sh.jobs.size(); p++) {
+            pipes.emplace_back(new LpPipe());
+            th.emplace_back(pipe_stager, b, std::ref(b->parts[p]), std::ref(*pipes[p]), std::ref(sh), items);
+            th.emplace_back(pipe_compute, b, std::ref(b->parts[p]), std::ref(*pipes[p]), std::ref(sh), opt, std::cref(sink));
+        }
+        run_other(b, opt, items);
+        for (auto& t : th) t.join();
+        rc = end_run(b, n, trace, t0);
+    }
+    int failed = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (rc) { items[i].status = rc; items[i].dst_len = 0; failed++; continue; }
+        items[i].status = b->status[i];
+        items[i].dst_len = b->status[i] == LILLIPUT_OK ? b->out_len[i] : 0;
+        items[i].out_width = b->out_w[i];
+        items[i].out_height = b->out_h[i];
+        if (items[i].status) failed++;
+    }
+    return failed;
+}
+
+extern "C" {
 
 // ---- stage-level access for parity tests
 static int decode_one(LpBatch* b, const void* src, size_t len, LpJpegHeader* h, LpFrame* f)

@@ -37,7 +37,8 @@ bool LpPinned::ensure(size_t bytes)
     if (bytes <= cap && p) return true;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+    if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; return false; }
+    if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) dev = p; // unified addressing: the same pointer
     cap = want;
     return true;
 }
@@ -51,6 +52,7 @@ LpEngine::LpEngine(int device) : device_(device)
     if (device_ < 0 || device_ >= n) { err_ = "HIP device index out of range"; return; }
     if (!check(hipSetDevice(device_), "hipSetDevice")) return;
     if (!check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
+    if (!check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto& e : ev_)
         if (!check(hipEventCreate(&e), "hipEventCreate")) return;
     ok_ = true;
@@ -59,8 +61,11 @@ LpEngine::LpEngine(int device) : device_(device)
 LpEngine::~LpEngine()
 {
     if (stream_) { (void)hipStreamSynchronize(stream_); }
+    if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); }
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& u : up_) if (u.ready) (void)hipEventDestroy(u.ready);
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
 
 bool LpEngine::check(hipError_t e, const char* what)
@@ -69,6 +74,32 @@ bool LpEngine::check(hipError_t e, const char* what)
     err_ = std::string(what) + ": " + hipGetErrorString(e);
     fprintf(stderr, "lilliput_hip: %s\n", err_.c_str());
     return false;
+}
+
+// Small descriptor upload on the compute stream without the copy engine (see lp_launch_copy_small). The bytes are staged in a
+// pinned ring; a wrap waits for the stream, so nothing in flight is overwritten. dst must have room for bytes rounded up to 16.
+bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return true;
+    const size_t kRing = 8u << 20, need = align_up(bytes, 256);
+    if (need > kRing / 2) // large lists take the ordinary path
+        return check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_), "H2D descriptors");
+    if (!h_desc_.p && !h_desc_.ensure(kRing)) { err_ = "pinned allocation failed"; return false; } // mapped: the kernel reads it through its device alias
+    if (desc_used_ + need > kRing) {
+        if (!check(hipStreamSynchronize(stream_), "descriptor ring sync")) return false;
+        desc_used_ = 0;
+    }
+    uint8_t* stage = h_desc_.as<uint8_t>() + desc_used_;
+    memcpy(stage, src, bytes);
+    desc_used_ += need;
+    lp_launch_copy_small(stream_, dst, static_cast<uint8_t*>(h_desc_.dev) + (stage - h_desc_.as<uint8_t>()), bytes);
+    return true;
+}
+
+// Small device -> pinned host download by a kernel (the counterpart of h2d_small); `host` lies inside the pinned buffer `pin`.
+void LpEngine::d2h_small(const LpPinned& pin, void* host, const void* dev, size_t bytes)
+{
+    lp_launch_copy_small(stream_, static_cast<uint8_t*>(pin.dev) + (static_cast<uint8_t*>(host) - pin.as<uint8_t>()), dev, bytes);
 }
 
 int LpEngine::sync() { return check(hipStreamSynchronize(stream_), "hipStreamSynchronize") ? LP_OK : LP_ERR_DEVICE; }
@@ -100,128 +131,195 @@ static uint32_t pick_S(size_t max_ecs_bytes)
     return 256;
 }
 
-int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
+// Descriptors and arena layout of one set of sources (slot `slot`): every entropy-coded segment becomes a piece at a 16-byte
+// aligned arena offset followed by 32 zero bytes. whole = size the slot's pinned buffer for the whole set (staged uploads).
+static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
 {
-    if (!ok_) return LP_ERR_DEVICE;
-    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    h_src_.assign((size_t)n, LpJpeg());
-    h_huffs_.clear();
-    h_prog_.assign((size_t)n, std::vector<ProgScanUp>());
-    h_phuffs_.clear();
-    prog_on_device_ = lp_prog_entropy_on_device();
-    h_pcoef_off_.assign((size_t)n, 0);
-    h_perr_.assign((size_t)n, 0);
-    size_t pcoef_total = 0;
-    std::vector<LpProgHostTask> host_tasks;
+    u.src.assign((size_t)n, LpJpeg());
+    u.huffs.clear();
+    u.prog.assign((size_t)n, std::vector<LpUpload::ProgScanUp>());
+    u.phuffs.clear();
+    u.prog_on_device = lp_prog_entropy_on_device();
+    u.pcoef_off.assign((size_t)n, 0);
+    u.perr.assign((size_t)n, 0);
+    u.pcoef_total = 0;
+    u.host_tasks.clear();
+    u.pieces.clear();
     std::vector<uint32_t> lev;
     std::map<uint64_t, std::vector<uint32_t>> phuff_by_hash;
-    struct Piece { size_t arena_off; const uint8_t* src; size_t len; };
-    std::vector<Piece> pieces; // entropy-coded segments, 16-byte aligned in the raw arena, each followed by 32 zero bytes
     size_t raw_bytes = 0;
     for (int i = 0; i < n; i++) {
         LpJpeg j = hdrs[i].j;
         // Huffman set dedupe (most batches share one set)
         uint32_t hi = 0;
-        for (; hi < h_huffs_.size(); hi++)
-            if (memcmp(&h_huffs_[hi], &hdrs[i].huff, sizeof(LpHuffSet)) == 0) break;
-        if (hi == h_huffs_.size()) h_huffs_.push_back(hdrs[i].huff);
+        for (; hi < u.huffs.size(); hi++)
+            if (memcmp(&u.huffs[hi], &hdrs[i].huff, sizeof(LpHuffSet)) == 0) break;
+        if (hi == u.huffs.size()) u.huffs.push_back(hdrs[i].huff);
         j.huff_idx = hi;
         j.raw_off = raw_bytes;
         j.scan_path = hdrs[i].scan_path ? 1 : 0;
-        if (hdrs[i].scan_path && !prog_on_device_) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
+        if (hdrs[i].scan_path && !u.prog_on_device) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
             j.raw_len = 0;
-            h_pcoef_off_[(size_t)i] = pcoef_total;
-            for (int c = 0; c < j.ncomp; c++) pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
+            u.pcoef_off[(size_t)i] = u.pcoef_total;
+            for (int c = 0; c < j.ncomp; c++) u.pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
             lp_prog_levels(hdrs[i].scans, lev);
             for (size_t q = 0; q < hdrs[i].scans.size(); q++)
-                host_tasks.push_back(LpProgHostTask{srcs[i].data, &hdrs[i].scans[q], nullptr, lev[q], &h_perr_[(size_t)i]});
+                u.host_tasks.push_back(LpProgHostTask{srcs[i].data, &hdrs[i].scans[q], nullptr, lev[q], &u.perr[(size_t)i]});
         } else if (hdrs[i].scan_path) { // every scan is a stream of its own
             j.raw_len = 0;
             lp_prog_levels(hdrs[i].scans, lev);
             for (const LpProgScanHost& sh : hdrs[i].scans) {
-                ProgScanUp up;
+                LpUpload::ProgScanUp up;
                 up.s = sh.s;
-                up.level = lev[h_prog_[(size_t)i].size()];
+                up.level = lev[u.prog[(size_t)i].size()];
                 uint64_t hash = 1469598103934665603ull;
                 const uint8_t* tb = reinterpret_cast<const uint8_t*>(&sh.tables);
                 for (size_t q = 0; q < sizeof(LpProgHuff); q++) hash = (hash ^ tb[q]) * 1099511628211ull;
                 uint32_t found = 0xffffffffu;
                 for (uint32_t cand : phuff_by_hash[hash])
-                    if (memcmp(&h_phuffs_[cand], &sh.tables, sizeof(LpProgHuff)) == 0) { found = cand; break; }
+                    if (memcmp(&u.phuffs[cand], &sh.tables, sizeof(LpProgHuff)) == 0) { found = cand; break; }
                 if (found == 0xffffffffu) {
-                    found = (uint32_t)h_phuffs_.size();
-                    h_phuffs_.push_back(sh.tables);
+                    found = (uint32_t)u.phuffs.size();
+                    u.phuffs.push_back(sh.tables);
                     phuff_by_hash[hash].push_back(found);
                 }
                 up.s.huff = found;
                 up.raw_off = raw_bytes;
                 up.raw_len = (uint32_t)sh.ecs_len;
-                pieces.push_back(Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len});
+                u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len});
                 raw_bytes = align_up(raw_bytes + up.raw_len + 32, 16);
-                h_prog_[(size_t)i].push_back(up);
+                u.prog[(size_t)i].push_back(up);
             }
         } else {
             j.raw_len = (uint32_t)hdrs[i].ecs_len;
-            pieces.push_back(Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len});
+            u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len});
             raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
         }
         j.nchunks = (j.raw_len + 4095) / 4096;
-        h_src_[(size_t)i] = j;
+        u.src[(size_t)i] = j;
     }
-    if (!host_tasks.empty()) {
-        if (!h_pcoef_.ensure(pcoef_total * 2 + 64)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
-        memset(h_pcoef_.p, 0, pcoef_total * 2);
-        size_t t = 0;
-        for (int i = 0; i < n; i++)
-            if (hdrs[i].scan_path)
-                for (size_t q = 0; q < hdrs[i].scans.size(); q++) host_tasks[t++].coef = h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)i];
-        lp_prog_host_run(host_tasks, 0);
-    }
+    u.raw_bytes = raw_bytes;
+    return LP_OK;
+}
+
+// scan-path images of the set in hybrid mode: the scans' entropy decode on host threads, into the set's pinned coefficient buffer
+static bool host_scan_decode(LpUpload& u, int n, const LpJpegHeader* hdrs)
+{
+    if (u.host_tasks.empty()) return true;
+    if (!u.pcoef.ensure(u.pcoef_total * 2 + 64)) return false;
+    memset(u.pcoef.p, 0, u.pcoef_total * 2);
+    size_t t = 0;
+    for (int i = 0; i < n; i++)
+        if (hdrs[i].scan_path)
+            for (size_t q = 0; q < hdrs[i].scans.size(); q++) u.host_tasks[t++].coef = u.pcoef.as<int16_t>() + u.pcoef_off[(size_t)i];
+    lp_prog_host_run(u.host_tasks, 0);
+    return true;
+}
+
+int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    LpUpload& u = up_[0];
+    u_ = &u;
+    u.staged_whole = false;
+    layout_set(u, srcs, n, hdrs);
+    if (!host_scan_decode(u, n, hdrs)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
+    const size_t raw_bytes = u.raw_bytes;
     const size_t kStage = 256u << 20; // pinned staging window
-    if (!d_huffs_.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, h_huffs_.size())) || !d_raw_.ensure(raw_bytes + 64) ||
-        !d_phuffs_.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, h_phuffs_.size())) ||
-        !h_stage_.ensure(std::min(raw_bytes, kStage) + (16u << 20) + 64)) {
+    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(raw_bytes + 64) ||
+        !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
+        !u.stage.ensure(std::min(raw_bytes, kStage) + (16u << 20) + 64)) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
     }
-    uint8_t* stage = h_stage_.as<uint8_t>();
+    uint8_t* stage = u.stage.as<uint8_t>();
     size_t win_begin = 0; // arena offset of the first byte staged in the current window
     auto flush = [&](size_t win_end) -> bool {
         if (win_end == win_begin) return true;
-        if (!check(hipMemcpyAsync(d_raw_.as<uint8_t>() + win_begin, stage, win_end - win_begin, hipMemcpyHostToDevice, stream_), "H2D raw")) return false;
+        if (!check(hipMemcpyAsync(u.d_raw.as<uint8_t>() + win_begin, stage, win_end - win_begin, hipMemcpyHostToDevice, stream_), "H2D raw")) return false;
         if (!check(hipStreamSynchronize(stream_), "upload sync")) return false;
         win_begin = win_end;
         return true;
     };
-    for (const Piece& pc : pieces) {
+    for (const LpUpload::Piece& pc : u.pieces) {
         const size_t end = pc.arena_off + pc.len + 32;
-        if (end - win_begin > h_stage_.cap - 64) {
+        if (end - win_begin > u.stage.cap - 64) {
             if (!flush(pc.arena_off)) return LP_ERR_DEVICE;
-            if (end - win_begin > h_stage_.cap - 64 && !h_stage_.ensure(end - win_begin + 64)) return LP_ERR_DEVICE;
-            stage = h_stage_.as<uint8_t>();
+            if (end - win_begin > u.stage.cap - 64 && !u.stage.ensure(end - win_begin + 64)) return LP_ERR_DEVICE;
+            stage = u.stage.as<uint8_t>();
         }
         memcpy(stage + (pc.arena_off - win_begin), pc.src, pc.len);
         memset(stage + (pc.arena_off - win_begin) + pc.len, 0, 32);
     }
     if (!flush(raw_bytes)) return LP_ERR_DEVICE;
-    if (!h_huffs_.empty() &&
-        !check(hipMemcpyAsync(d_huffs_.p, h_huffs_.data(), sizeof(LpHuffSet) * h_huffs_.size(), hipMemcpyHostToDevice, stream_), "H2D huffs"))
+    if (!u.huffs.empty() &&
+        !check(hipMemcpyAsync(u.d_huffs.p, u.huffs.data(), sizeof(LpHuffSet) * u.huffs.size(), hipMemcpyHostToDevice, stream_), "H2D huffs"))
         return LP_ERR_DEVICE;
-    if (!h_phuffs_.empty() &&
-        !check(hipMemcpyAsync(d_phuffs_.p, h_phuffs_.data(), sizeof(LpProgHuff) * h_phuffs_.size(), hipMemcpyHostToDevice, stream_), "H2D scan tables"))
+    if (!u.phuffs.empty() &&
+        !check(hipMemcpyAsync(u.d_phuffs.p, u.phuffs.data(), sizeof(LpProgHuff) * u.phuffs.size(), hipMemcpyHostToDevice, stream_), "H2D scan tables"))
         return LP_ERR_DEVICE;
     // the staging buffer is reused by the next upload: wait for the copies
     if (!check(hipStreamSynchronize(stream_), "upload sync")) return LP_ERR_DEVICE;
     return LP_OK;
 }
 
-// Lay out the working arenas for images [first, first+n) of the uploaded set and run every decode stage.
-int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame)
+int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (slot < 0 || slot >= LP_UPLOAD_SLOTS) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    LpUpload& u = up_[slot];
+    u.staged_whole = true;
+    layout_set(u, srcs, n, hdrs);
+    if (!u.ready && !check(hipEventCreateWithFlags(&u.ready, hipEventDisableTiming), "hipEventCreate")) return LP_ERR_DEVICE;
+    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(u.raw_bytes + 64) ||
+        !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
+        !u.stage.ensure(align_up(u.raw_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64)) {
+        err_ = "device allocation failed";
+        return LP_ERR_DEVICE;
+    }
+    if (!host_scan_decode(u, n, hdrs)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
+    return LP_OK;
+}
+
+void LpEngine::upload_copy(int slot, size_t p0, size_t p1)
+{
+    LpUpload& u = up_[slot];
+    uint8_t* stage = u.stage.as<uint8_t>();
+    for (size_t q = p0; q < p1 && q < u.pieces.size(); q++) {
+        const LpUpload::Piece& pc = u.pieces[q];
+        memcpy(stage + pc.arena_off, pc.src, pc.len);
+        memset(stage + pc.arena_off + pc.len, 0, 32);
+    }
+}
+
+int LpEngine::upload_commit(int slot)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    if (n <= 0 || (size_t)(first + n) > h_src_.size()) return LP_ERR_INVALID_IMAGE;
-    h_imgs_.assign(h_src_.begin() + first, h_src_.begin() + first + n);
+    LpUpload& u = up_[slot];
+    // the tables travel from the tail of the pinned buffer too: a copy from pageable memory would hold this thread until the copy
+    // engine has worked through everything queued before it
+    uint8_t* tab = u.stage.as<uint8_t>() + align_up(u.raw_bytes + 64, 256);
+    const size_t hb = sizeof(LpHuffSet) * u.huffs.size(), pb = sizeof(LpProgHuff) * u.phuffs.size();
+    if (hb) memcpy(tab, u.huffs.data(), hb);
+    if (pb) memcpy(tab + hb, u.phuffs.data(), pb);
+    if (u.raw_bytes && !check(hipMemcpyAsync(u.d_raw.p, u.stage.p, u.raw_bytes, hipMemcpyHostToDevice, copy_stream_), "H2D raw")) return LP_ERR_DEVICE;
+    if (hb && !check(hipMemcpyAsync(u.d_huffs.p, tab, hb, hipMemcpyHostToDevice, copy_stream_), "H2D huffs")) return LP_ERR_DEVICE;
+    if (pb && !check(hipMemcpyAsync(u.d_phuffs.p, tab + hb, pb, hipMemcpyHostToDevice, copy_stream_), "H2D scan tables")) return LP_ERR_DEVICE;
+    if (!check(hipEventRecord(u.ready, copy_stream_), "hipEventRecord")) return LP_ERR_DEVICE;
+    return LP_OK;
+}
+
+// Lay out the working arenas for images [first, first+n) of the uploaded set and run every decode stage.
+int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame, bool defer)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    if (n <= 0 || (size_t)(first + n) > u_->src.size()) return LP_ERR_INVALID_IMAGE;
+    if (u_->staged_whole && !check(hipStreamWaitEvent(stream_, u_->ready, 0), "hipStreamWaitEvent")) return LP_ERR_DEVICE; // the set's H2D copies (copy stream)
+    h_imgs_.assign(u_->src.begin() + first, u_->src.begin() + first + n);
     size_t max_ecs = 0;
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
     S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
@@ -264,7 +362,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (j.scan_path) {
             // Scans that touch the same coefficients of the same component must run in file order (a refinement needs what came
             // before it); all others are independent (lp_prog_levels). Host mode: ups is empty, the coefficients are ready.
-            const std::vector<ProgScanUp>& ups = h_prog_[(size_t)first + i];
+            const std::vector<LpUpload::ProgScanUp>& ups = u_->prog[(size_t)first + i];
             j.coef_off = pcoef_elems;
             for (int c = 0; c < j.ncomp; c++) pcoef_elems += (size_t)j.bw[c] * j.bh[c] * 64;
             for (size_t a = 0; a < ups.size(); a++) {
@@ -335,11 +433,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
-    if (!check(hipMemcpyAsync(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D imgs")) return LP_ERR_DEVICE;
+    if (!h2d_small(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n)) return LP_ERR_DEVICE;
     const LpJpeg* di = d_imgs_.as<LpJpeg>();
     LpJpegState* ds = d_states_.as<LpJpegState>();
     if (!check(hipMemsetAsync(ds, 0, sizeof(LpJpegState) * (size_t)n, stream_), "memset states")) return LP_ERR_DEVICE;
@@ -353,12 +451,12 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
     };
     if (timing_) (void)hipEventRecord(ev_[0], stream_);
-    lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
+    lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>());
     stage("unstuff");
     if (timing_) (void)hipEventRecord(ev_[1], stream_);
     LpHuffArgs ha;
-    ha.imgs = di; ha.states = ds; ha.huffs = d_huffs_.as<LpHuffSet>();
+    ha.imgs = di; ha.states = ds; ha.huffs = u_->d_huffs.as<LpHuffSet>();
     ha.nimg = (uint32_t)n; ha.max_sub = max_sub_; ha.tot_sub = tot_sub_;
     ha.clean = d_clean_.as<uint32_t>(); ha.rst = d_rst_.as<uint32_t>();
     ha.ckpts = d_ckpt_.as<LpCkptPk>();
@@ -370,19 +468,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     lp_launch_huff_spec(stream_, ha);
     stage("huff_spec");
     if (timing_) (void)hipEventRecord(ev_[8], stream_);
-    uint32_t rounds = 0;
-    uint32_t* h_changed = h_small_.as<uint32_t>();
-    for (;;) {
-        if (!check(hipMemsetAsync(d_changed_.p, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
-        lp_launch_huff_verify(stream_, ha);
-        if (!check(hipMemcpyAsync(h_changed, d_changed_.p, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
-        if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
-        rounds++;
-        if (*h_changed == 0) break;
-        // every round makes at least one more subsequence final, so max_sub_ rounds always suffice; real streams need 1-3
-        if (rounds > max_sub_ + 1 || rounds >= 100000) { err_ = "entropy decode did not converge"; return LP_ERR_DECODE_FAILED; }
-    }
-    tm_.verify_rounds = rounds;
+    // Verify rounds back to back, no host round trip in between: round r counts the exit states it moved into changed[r] and a
+    // round that follows an idle one returns at once. The last counter is looked at when the decode is collected (finish_decode);
+    // streams that need more than LP_VERIFY_ROUNDS rounds (tiny subsequences, hostile data) continue there under host control.
+    if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (LP_VERIFY_ROUNDS + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
+    for (uint32_t r = 0; r < LP_VERIFY_ROUNDS; r++) lp_launch_huff_verify(stream_, ha, r);
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
     stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
@@ -392,13 +482,13 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
-    if (pcoef_elems && !prog_on_device_) { // hybrid mode: the coefficients were decoded at upload time
+    if (pcoef_elems && !u_->prog_on_device) { // hybrid mode: the coefficients were decoded at upload time
         for (int i = 0; i < n; i++) {
             const LpJpeg& j = h_imgs_[(size_t)i];
             if (!j.scan_path) continue;
             size_t ne = 0;
             for (int c = 0; c < j.ncomp; c++) ne += (size_t)j.bw[c] * j.bh[c] * 64;
-            if (!check(hipMemcpyAsync(d_pcoef_.as<int16_t>() + j.coef_off, h_pcoef_.as<int16_t>() + h_pcoef_off_[(size_t)first + i], ne * 2, hipMemcpyHostToDevice, stream_), "H2D coefficients"))
+            if (!check(hipMemcpyAsync(d_pcoef_.as<int16_t>() + j.coef_off, u_->pcoef.as<int16_t>() + u_->pcoef_off[(size_t)first + i], ne * 2, hipMemcpyHostToDevice, stream_), "H2D coefficients"))
                 return LP_ERR_DEVICE;
         }
     }
@@ -408,7 +498,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             !check(hipMemsetAsync(d_pstates_.p, 0, sizeof(LpJpegState) * nstreams, stream_), "memset scan states") ||
             !check(hipMemsetAsync(d_pcoef_.p, 0, pcoef_elems * 2, stream_), "memset coefficients"))
             return LP_ERR_DEVICE;
-        lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, d_raw_.as<uint8_t>(), d_chunk_.as<uint2>(),
+        lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
                           d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
         stage("prog_unstuff");
         for (size_t l = 0; l + 1 < h_plevel_first_.size(); l++) {
@@ -416,7 +506,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             // few lanes: one per wave (a lane alone on its SIMD runs fastest); many: pack them so that the grid stays a few waves per SIMD
             const uint32_t lpw = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (cnt + 4095u) / 4096u));
             lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),
-                                 d_phuffs_.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+                                 u_->d_phuffs.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
         }
         stage("prog_scans");
     }
@@ -438,22 +528,67 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         }
     }
     if (any_frame) {
-        if (!check(hipMemcpyAsync(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D frames")) return LP_ERR_DEVICE;
+        if (!h2d_small(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n)) return LP_ERR_DEVICE;
         lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, any_generic, any_420, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
     }
     if (timing_) (void)hipEventRecord(ev_[4], stream_);
-    h_states_.resize((size_t)n);
-    if (!check(hipMemcpyAsync(h_small_.p, ds, sizeof(LpJpegState) * (size_t)n, hipMemcpyDeviceToHost, stream_), "D2H states")) return LP_ERR_DEVICE;
+    pend_ = Pending{true, first, n, nstreams, pcoef_elems, any_baseline, any_frame, any_generic, any_420, frames, ha};
+    d2h_small(h_dstate_, h_dstate_.as<uint8_t>() + 64, ds, sizeof(LpJpegState) * (size_t)n);
+    d2h_small(h_dstate_, h_dstate_.p, d_changed_.p, 4 * (LP_VERIFY_ROUNDS + 1));
+    return defer ? LP_OK : finish_decode(status);
+}
+
+// Second half of a decode: wait for the stream, finish the verification under host control if the enqueued rounds did not settle
+// it (then everything behind the verify stage is enqueued again), and turn the per-image device states into statuses.
+// Returns LP_RETRY when a deferred decode had to redo its tail: what the caller enqueued behind it read unfinished planes.
+int LpEngine::finish_decode(int* status)
+{
+    if (!pend_.active) return LP_ERR_DEVICE;
+    pend_.active = false;
+    const int n = pend_.n, first = pend_.first;
+    const size_t nstreams = pend_.nstreams;
     if (!check(hipStreamSynchronize(stream_), "decode sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "decode kernels")) return LP_ERR_DEVICE;
-    memcpy(h_states_.data(), h_small_.p, sizeof(LpJpegState) * (size_t)n);
+    const uint32_t* h_changed = h_dstate_.as<uint32_t>();
+    uint32_t rounds = 1;
+    for (uint32_t r = 0; r + 1 < LP_VERIFY_ROUNDS; r++) rounds += h_changed[r] ? 1u : 0u;
+    bool redone = false;
+    if (h_changed[LP_VERIFY_ROUNDS - 1] != 0) {
+        const LpHuffArgs& ha = pend_.ha;
+        for (;;) { // round index LP_VERIFY_ROUNDS: its gate reads the previous counter, which is non-zero here
+            if (!check(hipMemsetAsync(d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
+            lp_launch_huff_verify(stream_, ha, LP_VERIFY_ROUNDS);
+            if (!check(hipMemcpyAsync(h_small_.p, d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
+            if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
+            rounds++;
+            if (*h_small_.as<uint32_t>() == 0) break;
+            // every round makes at least one more subsequence final, so max_sub_ rounds always suffice; real streams need 1-3
+            if (rounds > max_sub_ + 1 || rounds >= 100000) { err_ = "entropy decode did not converge"; return LP_ERR_DECODE_FAILED; }
+        }
+        // the stages behind the verification ran on unsettled exit states: once more
+        lp_launch_reset_tail_state(stream_, d_states_.as<LpJpegState>(), (uint32_t)n);
+        lp_launch_sub_scan(stream_, ha);
+        lp_launch_huff_write(stream_, ha);
+        lp_launch_dc_scan(stream_, d_imgs_.as<LpJpeg>(), (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
+        lp_launch_idct(stream_, d_imgs_.as<LpJpeg>(), d_states_.as<LpJpegState>(), (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(),
+                       d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(), (pend_.any_baseline ? 1u : 0u) | (pend_.pcoef_elems ? 2u : 0u), d_pcoef_.as<int16_t>());
+        if (pend_.any_frame)
+            lp_launch_ycc_to_frame(stream_, d_imgs_.as<LpJpeg>(), (uint32_t)n, max_w_, max_h_, pend_.any_generic, pend_.any_420, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
+        d2h_small(h_dstate_, h_dstate_.as<uint8_t>() + 64, d_states_.p, sizeof(LpJpegState) * (size_t)n);
+        if (!check(hipStreamSynchronize(stream_), "decode sync")) return LP_ERR_DEVICE;
+        if (!check(hipGetLastError(), "decode kernels")) return LP_ERR_DEVICE;
+        redone = true;
+    }
+    tm_.verify_rounds = rounds;
+    h_states_.resize((size_t)n);
+    memcpy(h_states_.data(), h_dstate_.as<uint8_t>() + 64, sizeof(LpJpegState) * (size_t)n);
     if (nstreams) { // a scan that failed to unstuff fails its image
         h_pstates_.resize(nstreams);
         if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
         for (const LpProgScan& sc : h_pscans_) h_states_[sc.img].error |= h_pstates_[sc.stream].error;
     }
     for (int i = 0; i < n; i++)
-        if (h_imgs_[(size_t)i].scan_path && !prog_on_device_) h_states_[(size_t)i].error |= h_perr_[(size_t)first + i];
+        if (h_imgs_[(size_t)i].scan_path && !u_->prog_on_device) h_states_[(size_t)i].error |= u_->perr[(size_t)first + i];
     int rc = LP_OK;
     for (int i = 0; i < n; i++) {
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
@@ -469,12 +604,18 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         (void)hipEventElapsedTime(&tm_.huff_scan_ms, ev_[9], ev_[10]);
         (void)hipEventElapsedTime(&tm_.huff_write_ms, ev_[10], ev_[2]);
     }
-    return rc;
+    return redone ? LP_RETRY : rc;
 }
 
 int LpEngine::decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame)
 {
-    return run_decode(first, n, frames, status, want_frame);
+    const int rc = run_decode(first, n, frames, status, want_frame, false);
+    return rc == LP_RETRY ? LP_OK : rc; // nothing was enqueued behind the decode: the redone tail is simply the result
+}
+
+int LpEngine::decode_begin(int first, int n, LpFrame* frames, const uint8_t* want_frame)
+{
+    return run_decode(first, n, frames, nullptr, want_frame, true);
 }
 
 int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
@@ -539,7 +680,8 @@ int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
 {
     int rc = upload_jpegs(srcs, n, hdrs);
     if (rc) return rc;
-    return run_decode(0, n, frames, status, nullptr);
+    rc = run_decode(0, n, frames, status, nullptr, false);
+    return rc == LP_RETRY ? LP_OK : rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,7 +847,8 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
     if (!ok_) return LP_ERR_DEVICE;
     if (n <= 0) return LP_OK;
     if (!d_fops_.ensure(sizeof(LpFusedOp) * (size_t)n)) return LP_ERR_DEVICE;
-    std::vector<LpFusedOp> ops(ops_in, ops_in + n);
+    std::vector<LpFusedOp>& ops = h_fops_; // stays alive: the copy below is not waited for
+    ops.assign(ops_in, ops_in + n);
     uint32_t max_px = 0, fast_mask = 0, fast_grid = 0;
     bool general = false;
     for (auto& op : ops) {
@@ -737,15 +880,23 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
             max_px = std::max(max_px, op.dst.w * op.dst.h);
         }
     }
-    if (!check(hipMemcpyAsync(d_fops_.p, ops.data(), sizeof(LpFusedOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D fused ops")) return LP_ERR_DEVICE;
-    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    if (!h2d_small(d_fops_.p, ops.data(), sizeof(LpFusedOp) * (size_t)n)) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[11], stream_);
     lp_launch_resample_fused(stream_, d_imgs_.as<LpJpeg>(), d_fops_.as<LpFusedOp>(), (uint32_t)n, max_px, general, fast_mask, fast_grid, d_planes_.as<uint8_t>());
-    if (timing_) (void)hipEventRecord(ev_[6], stream_);
-    // `ops` is pageable host memory read by the async copy: the sync below also covers it
-    if (!check(hipStreamSynchronize(stream_), "fused resample sync")) return LP_ERR_DEVICE;
+    if (timing_) (void)hipEventRecord(ev_[7], stream_);
+    // not waited for: the encode (or whatever reads the thumbnails next) is enqueued behind it; resample_ms() reads the events
     if (!check(hipGetLastError(), "fused resample kernel")) return LP_ERR_DEVICE;
-    if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);
+    tm_.resize_ms = 0;
+    fused_timed_ = timing_;
     return LP_OK;
+}
+
+float LpEngine::fused_resample_ms()
+{
+    float ms = 0;
+    if (fused_timed_ && hipEventSynchronize(ev_[7]) == hipSuccess) (void)hipEventElapsedTime(&ms, ev_[11], ev_[7]);
+    fused_timed_ = false;
+    return ms;
 }
 
 int LpEngine::composite(const LpCompositeOp& op)
@@ -912,6 +1063,7 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         enc_tables_ready_ = true;
     }
     h_jobs_.assign((size_t)n, LpEncJob());
+    h_big_.clear();
     std::vector<uint8_t> hdrs;
     size_t coef_elems = 0, bits_words = 0, out_bytes = 0;
     uint32_t tot_blocks = 0, max_blocks = 0;
@@ -954,10 +1106,10 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
     h_estates_.assign((size_t)n, LpEncState());
     if (!d_jobs_.ensure(sizeof(LpEncJob) * (size_t)n) || !d_estates_.ensure(sizeof(LpEncState) * (size_t)n) || !d_ecoef_.ensure(coef_elems * 2 + 64) ||
         !d_blkbits_.ensure((size_t)tot_blocks * 4 + 64) || !d_bits_.ensure(bits_words * 4 + 64) || !d_hdrs_.ensure(hdrs.size() + 64) ||
-        !d_out_.ensure(out_bytes + 64) || !h_small_.ensure(std::max<size_t>(4096, sizeof(LpEncState) * (size_t)n)))
+        !d_out_.ensure(out_bytes + 64) || !h_small_.ensure(std::max<size_t>(4096, sizeof(LpEncState) * (size_t)n + 64)))
         return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(d_jobs_.p, h_jobs_.data(), sizeof(LpEncJob) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D enc jobs")) return LP_ERR_DEVICE;
-    if (!hdrs.empty() && !check(hipMemcpyAsync(d_hdrs_.p, hdrs.data(), hdrs.size(), hipMemcpyHostToDevice, stream_), "H2D hdrs")) return LP_ERR_DEVICE;
+    if (!h2d_small(d_jobs_.p, h_jobs_.data(), sizeof(LpEncJob) * (size_t)n)) return LP_ERR_DEVICE;
+    if (!hdrs.empty() && !h2d_small(d_hdrs_.p, hdrs.data(), hdrs.size())) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(d_bits_.p, 0, bits_words * 4 + 64, stream_), "memset bits")) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(d_estates_.p, 0, sizeof(LpEncState) * (size_t)n, stream_), "memset enc states")) return LP_ERR_DEVICE;
     if (enc_fdct_only_) { // progressive output: the entropy coding happens on the host
@@ -969,7 +1121,26 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
     lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
                      d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
-    if (!check(hipMemcpyAsync(h_small_.p, d_estates_.p, sizeof(LpEncState) * (size_t)n, hipMemcpyDeviceToHost, stream_), "D2H enc states")) return LP_ERR_DEVICE;
+    {   // results: every stream into its slot of the pinned output buffer (a slot bounds the usual size; a stream that outgrows it
+        // is fetched from the output arena by encoded_fetch_all), and the states -- one wait for both
+        std::vector<uint32_t>& pk = h_pk_;
+        pk.assign((size_t)n + 1, 0);
+        size_t total = 0;
+        h_out_off_.assign((size_t)n, 0);
+        for (int i = 0; i < n; i++) {
+            const LpEncJob& j = h_jobs_[(size_t)i];
+            const size_t slot = align_up(std::min<size_t>(j.out_cap, std::max<size_t>(16384, (size_t)j.src.w * j.src.h * j.ncomp / 2 + 4096)), 16) + 16;
+            h_out_off_[(size_t)i] = total;
+            pk[(size_t)i] = (uint32_t)total;
+            total += j.total_blocks ? slot : 0;
+        }
+        pk[(size_t)n] = (uint32_t)total;
+        if (total > 0xffffff00ull || !h_out_.ensure(total + 64) || !d_pkoff_.ensure(((size_t)n + 1) * 4 + 64)) return LP_ERR_DEVICE;
+        if (!h2d_small(d_pkoff_.p, pk.data(), ((size_t)n + 1) * 4)) return LP_ERR_DEVICE;
+        lp_launch_enc_pack(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, d_pkoff_.as<uint32_t>(), d_out_.as<uint8_t>(),
+                           static_cast<uint8_t*>(h_out_.dev));
+    }
+    d2h_small(h_small_, h_small_.p, d_estates_.p, sizeof(LpEncState) * (size_t)n);
     if (!check(hipStreamSynchronize(stream_), "encode sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "encode kernels")) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventElapsedTime(&tm_.encode_ms, ev_[5], ev_[6]);
@@ -1049,17 +1220,20 @@ int LpEngine::encoded_copy(int i, uint8_t* dst, size_t cap)
 
 int LpEngine::encoded_fetch_all()
 {
-    // pack on the device, then ONE D2H copy (a copy per image costs ~10 us each of host time)
+    // encode_jpegs has already placed every stream that fits its slot in the pinned buffer; the rest come from the output arena
     const size_t n = h_jobs_.size();
-    size_t total = 0;
-    h_out_off_.assign(n, 0);
-    std::vector<uint32_t> pk(n);
-    for (size_t i = 0; i < n; i++) { h_out_off_[i] = total; pk[i] = (uint32_t)total; total += align_up(h_estates_[i].out_len, 16) + 16; }
-    if (!n || !total) return LP_OK;
-    if (total > 0xffffffffull || !h_out_.ensure(total + 64) || !d_packed_.ensure(total + 64) || !d_pkoff_.ensure(n * 4 + 64)) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(d_pkoff_.p, pk.data(), n * 4, hipMemcpyHostToDevice, stream_), "H2D pack offsets")) return LP_ERR_DEVICE;
-    lp_launch_enc_pack(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, d_pkoff_.as<uint32_t>(), d_out_.as<uint8_t>(),
-                       d_packed_.as<uint8_t>());
-    if (!check(hipMemcpyAsync(h_out_.p, d_packed_.p, total, hipMemcpyDeviceToHost, stream_), "D2H jpegs")) return LP_ERR_DEVICE;
-    return sync(); // also covers the pageable `pk`
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t len = h_estates_[i].out_len;
+        if (!len || len <= h_pk_[i + 1] - h_pk_[i]) continue;
+        h_big_.emplace_back(i, std::vector<uint8_t>(len));
+        if (!check(hipMemcpyAsync(h_big_.back().second.data(), encoded_device_ptr((int)i), len, hipMemcpyDeviceToHost, stream_), "D2H jpeg")) return LP_ERR_DEVICE;
+    }
+    return h_big_.empty() ? LP_OK : sync();
+}
+
+const uint8_t* LpEngine::encoded_host(int i) const
+{
+    for (const auto& b : h_big_)
+        if (b.first == (size_t)i) return b.second.data();
+    return h_out_.as<uint8_t>() + h_out_off_[(size_t)i];
 }

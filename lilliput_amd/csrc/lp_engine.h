@@ -17,6 +17,8 @@
 #include <vector>
 
 #include "lp_jpeg_parse.h"
+#include "lp_prog_host.h"
+#include "lp_launch.h"
 #include "lp_types.h"
 
 struct LpDevBuf {
@@ -30,6 +32,7 @@ struct LpDevBuf {
 
 struct LpPinned {
     void* p = nullptr;
+    void* dev = nullptr;        // the buffer as kernels address it (mapped pinned memory)
     size_t cap = 0;
     ~LpPinned();
     bool ensure(size_t bytes);
@@ -42,7 +45,8 @@ enum LpStatus {
     LP_ERR_DECODE_FAILED = 2,   // lilliput.ErrDecodingFailed
     LP_ERR_BUF_TOO_SMALL = 3,   // lilliput.ErrBufTooSmall
     LP_ERR_UNSUPPORTED = 4,     // stream feature outside the device path (progressive, CMYK, ...)
-    LP_ERR_DEVICE = 5           // HIP failure / no device
+    LP_ERR_DEVICE = 5,          // HIP failure / no device
+    LP_RETRY = 100              // internal: see LpEngine::finish_decode
 };
 
 struct LpJpegSrc {
@@ -68,6 +72,33 @@ struct LpTimings {
     float huff_spec_ms, huff_verify_ms, huff_scan_ms, huff_write_ms; // breakdown of huff_ms
 };
 
+// One staged set of sources: their descriptors, and where their entropy-coded bytes sit (pinned staging buffer, device arena).
+// An engine owns LP_UPLOAD_SLOTS of them so that a batch can stage set n + 1 (memcpy into pinned memory on a host thread, H2D on
+// the engine's copy stream) while set n is being decoded on the compute stream -- the ingest half of ImageOps.Transform
+// (/root/reference/opencv.cpp:99-171: opencv_decoder_create / read_header / read_data start from host bytes).
+#define LP_UPLOAD_SLOTS 4
+struct LpUpload {
+    struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; uint32_t level; };
+    struct Piece { size_t arena_off; const uint8_t* src; size_t len; }; // an entropy-coded segment: 16-byte aligned in the arena, followed by 32 zero bytes
+    std::vector<LpJpeg> src;                        // every image of the set (raw layout only)
+    std::vector<LpHuffSet> huffs;
+    std::vector<Piece> pieces;
+    size_t raw_bytes = 0;
+    bool staged_whole = false;                      // the pinned buffer holds the whole set (upload_copy / upload_commit); else windowed
+    // progressive images (SOF2) and the other scan-by-scan cases
+    bool prog_on_device = false;                    // where this set's scans are entropy-decoded (lp_prog_host.h)
+    LpPinned pcoef;                                 // host mode: the decoded int16 coefficients of every scan-path image of the set
+    std::vector<size_t> pcoef_off;                  // element offset per image
+    std::vector<uint32_t> perr;                     // per image
+    std::vector<std::vector<ProgScanUp>> prog;      // per image; empty for a baseline one
+    std::vector<LpProgHuff> phuffs;
+    std::vector<LpProgHostTask> host_tasks;
+    size_t pcoef_total = 0;
+    LpDevBuf d_raw, d_huffs, d_phuffs;
+    LpPinned stage;
+    hipEvent_t ready = nullptr;                     // recorded behind the set's H2D copies
+};
+
 class LpEngine {
 public:
     explicit LpEngine(int device);
@@ -89,14 +120,30 @@ public:
     // dst[i].off must be preset by the caller (device pointers with room for w*h*cn); status[i] per image.
     // If dst == nullptr the frames are bump-allocated from the heap and returned in out_frames.
     int decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs, LpFrame* frames, int* status);
-    // Device-resident variant used by the bench: ECS bytes were uploaded earlier with upload_jpegs().
+    // Device-resident variant: the entropy-coded bytes are uploaded first (slot 0, through a pinned window, synchronous) ...
     int upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs);
+    // ... or staged: layout (descriptors, arena offsets; sizes the slot's pinned buffer and device arena), copy (memcpy of pieces
+    // [p0, p1) into the pinned buffer -- any host thread), commit (scan-path host decode, asynchronous H2D on the copy stream, event).
+    // The sources must stay valid until commit returns. select_upload makes a slot the one decode_uploaded reads; the compute
+    // stream waits for the slot's event, not the host.
+    int upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs);
+    size_t upload_pieces(int slot) const { return up_[slot].pieces.size(); }
+    size_t upload_bytes(int slot) const { return up_[slot].raw_bytes; }
+    void upload_copy(int slot, size_t p0, size_t p1);
+    int upload_commit(int slot);
+    void select_upload(int slot) { u_ = &up_[slot]; }
     // want_frame (optional, per image): 0 = keep only the planes (the image will go through fused_resample)
     int decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame = nullptr);
+    // The same in two halves, so that the caller can enqueue the stages that follow (fused_resample, encode) without a host round
+    // trip in between: decode_begin enqueues, finish_decode waits and reports. LP_RETRY from finish_decode = the verification needed
+    // more rounds than were enqueued and the tail of the decode ran again: whatever was enqueued behind decode_begin must be redone.
+    int decode_begin(int first, int n, LpFrame* frames, const uint8_t* want_frame = nullptr);
+    int finish_decode(int* status);
+    float fused_resample_ms();                   // device time of the last fused_resample (waits for it)
     // planes of the current decode range -> thumbnails, see LpFusedOp
     int fused_resample(const LpFusedOp* ops, int n);
-    size_t uploaded_count() const { return h_src_.size(); }
-    const LpJpeg& uploaded(size_t i) const { return h_src_[i]; }
+    size_t uploaded_count() const { return u_->src.size(); }
+    const LpJpeg& uploaded(size_t i) const { return u_->src[i]; }
     // stage-level read-back for parity tests (valid after a decode of the current range)
     int copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems);
     int copy_plane(int i, int comp, uint8_t* dst, size_t cap);
@@ -113,7 +160,7 @@ public:
     int encoded_copy(int i, uint8_t* dst, size_t cap);   // D2H of job i's bytes (after encode_jpegs)
     const uint8_t* encoded_device_ptr(int i) const;
     int encoded_fetch_all();                              // D2H of every job's bytes into pinned memory (one sync)
-    const uint8_t* encoded_host(int i) const { return h_out_.as<uint8_t>() + h_out_off_[(size_t)i]; }
+    const uint8_t* encoded_host(int i) const;
 
     int composite(const LpCompositeOp& op);
     // Renders one GIF frame: uploads the indices and the palette (256 x BGRA) and runs k_gif_frame; op.index_off / palette_off are filled here.
@@ -131,44 +178,46 @@ public:
 
 private:
     bool check(hipError_t e, const char* what);
-    int run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame);
+    bool h2d_small(void* dst, const void* src, size_t bytes);
+    void d2h_small(const LpPinned& pin, void* host, const void* dev, size_t bytes);
+    int run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame, bool defer);
 
     int device_ = 0;
     bool ok_ = false;
     bool timing_ = false;
     std::string err_;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
     hipEvent_t ev_[16] = {};
     uint32_t S_cfg_ = 0, C_cfg_ = 0;
     LpTimings tm_ = {};
 
     // decode state for the current batch
-    std::vector<LpJpeg> h_src_;   // every uploaded image (raw layout only)
+    LpUpload up_[LP_UPLOAD_SLOTS];
+    LpUpload* u_ = &up_[0];       // the set decode_uploaded reads
     std::vector<LpJpeg> h_imgs_;  // the range being decoded (working arenas laid out)
-    std::vector<LpHuffSet> h_huffs_;
     std::vector<LpJpegState> h_states_;
     uint32_t S_ = 0, K_ = 0;
     LpCkSched sched_ = {};
     uint32_t max_chunks_ = 0, max_sub_ = 0, max_bw_ = 0, max_rows_ = 0, max_w_ = 0, max_h_ = 0;
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
-    LpDevBuf d_imgs_, d_huffs_, d_states_, d_raw_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
+    LpDevBuf d_imgs_, d_states_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
     LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_dcpart_, d_planes_, d_frames_desc_;
-    LpPinned h_stage_, h_small_, h_out_;
+    LpPinned h_small_, h_out_, h_dstate_, h_desc_;
+    size_t desc_used_ = 0;
+    std::vector<uint32_t> h_pk_;                                    // slot offsets of the encoded streams in h_out_ (n + 1 entries)
+    std::vector<std::pair<size_t, std::vector<uint8_t>>> h_big_;    // streams that outgrew their slot
+    std::vector<LpFusedOp> h_fops_;
+    bool fused_timed_ = false;
+    struct Pending { bool active; int first, n; size_t nstreams, pcoef_elems; bool any_baseline, any_frame, any_generic, any_420; LpFrame* frames; LpHuffArgs ha; };
+    Pending pend_ = {};
     std::vector<size_t> h_out_off_;
 
-    // progressive images (SOF2): their scans, laid out per upload and per decode range
-    struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; uint32_t level; };
-    bool prog_on_device_ = false;                   // where this upload's scans are entropy-decoded (lp_prog_host.h)
-    LpPinned h_pcoef_;                              // host mode: the decoded int16 coefficients of every progressive image of the upload
-    std::vector<size_t> h_pcoef_off_;               // element offset per uploaded image
-    std::vector<uint32_t> h_perr_;                  // per uploaded image
-    std::vector<std::vector<ProgScanUp>> h_prog_;   // per uploaded image; empty for a baseline one
-    std::vector<LpProgHuff> h_phuffs_;
+    // progressive images (SOF2): their scans of the current decode range (the per-set part lives in LpUpload)
     std::vector<LpProgScan> h_pscans_;              // the current range's scans, sorted by dependency level
     std::vector<uint32_t> h_plevel_first_;          // level l = h_pscans_[h_plevel_first_[l] .. h_plevel_first_[l + 1])
     std::vector<LpJpeg> h_pstreams_;                // one pseudo stream per scan (what the unstuff kernels need)
     std::vector<LpJpegState> h_pstates_;
-    LpDevBuf d_phuffs_, d_pscans_, d_pstreams_, d_pstates_, d_pcoef_;
+    LpDevBuf d_pscans_, d_pstreams_, d_pstates_, d_pcoef_;
 
     // frame heap
     LpDevBuf heap_;

@@ -390,12 +390,16 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
                                                         const LpSubState* __restrict__ spec_exit, const LpSubSum* __restrict__ spec_total,
                                                         LpSubState* cur_exit, LpSubSum* __restrict__ cur_total, LpSubState* __restrict__ entry_used,
-                                                        uint32_t* __restrict__ changed, uint32_t K, uint32_t tot_sub)
+                                                        uint32_t* changed, uint32_t round, uint32_t K, uint32_t tot_sub)
 {
     typedef CountMem MEM;
     __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
+    // changed[r] counts the exit states round r moved. The rounds of a decode are enqueued back to back without a host round
+    // trip; a round that follows one which moved nothing has nothing to do (the host checks the last counter at the end).
+    if (round && __hip_atomic_load(changed + round - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    changed += round;
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -976,13 +980,42 @@ void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a)
                        a.cur_total, a.entry_used, a.sched, a.tot_sub);
 }
 
-void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a)
+// Before the stages behind the verification run a second time (LpEngine::finish_decode): forget what their first run left in
+// the per-image state -- the block-count verdict of k_sub_scan and the wide-slot counter of k_huff_write.
+__global__ void k_reset_tail_state(LpJpegState* __restrict__ states, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    states[i].error &= ~2u;
+    states[i].blocks_decoded = 0;
+    states[i].n_wide = 0;
+}
+void lp_launch_reset_tail_state(hipStream_t s, LpJpegState* d_states, uint32_t n)
+{
+    if (n) hipLaunchKernelGGL(k_reset_tail_state, dim3((n + 63) / 64), dim3(64), 0, s, d_states, n);
+}
+
+// Small host -> device uploads (descriptors, op lists) as a kernel reading pinned host memory: a copy-engine transfer would queue
+// behind the multi-hundred-megabyte H2D copies of the ingest pipeline and hold the compute stream up for milliseconds.
+__global__ void k_copy_small(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size_t bytes)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (!n16) return;
+    const uint32_t blocks = n16 < 256u * 64u ? (n16 + 255u) / 256u : 64u;
+    hipLaunchKernelGGL(k_copy_small, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src_pinned), n16);
+}
+
+void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round)
 {
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_verify, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
                        (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, a.cur_exit, a.cur_total, a.entry_used, a.changed,
-                       a.sched.K, a.tot_sub);
+                       round, a.sched.K, a.tot_sub);
 }
 
 void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */)

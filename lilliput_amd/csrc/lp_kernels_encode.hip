@@ -354,13 +354,15 @@ __global__ __launch_bounds__(256) void k_enc_finish(const LpEncJob* __restrict__
     if (t == 0) { out[end] = 0xFF; out[end + 1] = 0xD9; st.out_len = end + 2; }
 }
 
-// Gather the encoded streams (spaced out_cap apart in the output arena) into one contiguous buffer so that a batch leaves
-// the device in a single D2H copy. One workgroup per image; both sides are 16-byte aligned.
+// Gather the encoded streams (spaced out_cap apart in the output arena) into the slots pk_off[i] .. pk_off[i + 1] of `packed` -- mapped
+// pinned host memory: the results of a chunk leave the device by the kernel's own stores, not through the copy engine (which is
+// busy with the ingest pipeline's H2D copies). One workgroup per image; both sides are 16-byte aligned.
 __global__ __launch_bounds__(256) void k_enc_pack(const LpEncJob* __restrict__ jobs, const LpEncState* __restrict__ states,
                                                   const uint32_t* __restrict__ pk_off, const uint8_t* __restrict__ out_arena, uint8_t* __restrict__ packed)
 {
     const LpEncJob& job = jobs[blockIdx.x];
     const uint32_t n = states[blockIdx.x].out_len;
+    if (n > pk_off[blockIdx.x + 1] - pk_off[blockIdx.x]) return; // larger than its slot (the host fetches it from the output arena)
     const uint4* src = reinterpret_cast<const uint4*>(out_arena + job.out_off);
     uint4* dst = reinterpret_cast<uint4*>(packed + pk_off[blockIdx.x]);
     for (uint32_t i = threadIdx.x; i < (n + 15) / 16; i += 256) dst[i] = src[i];

@@ -22,7 +22,7 @@ struct LpHuffArgs {
     LpSubSum* cur_total;
     LpSubState* entry_used;     // entry state a subsequence was last verified against
     LpSubSum* prefix;            // exclusive scan of cur_total
-    uint32_t* changed;
+    uint32_t* changed;          // [LP_VERIFY_ROUNDS + 1] counters, see lp_launch_huff_verify
     int8_t* coef8;              // 64 x int8 per block, decode order; -128 = escape (see DevSink in lp_kernels_decode.hip)
     int16_t* wide;              // wide slots: 64 x int16, only escaped positions are valid
     uint32_t* wide_id;          // block -> wide slot (valid for blocks holding an escape)
@@ -30,8 +30,11 @@ struct LpHuffArgs {
     LpCkSched sched;
 };
 void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
-void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round); // counts into a.changed[round]; idle when changed[round - 1] == 0
+#define LP_VERIFY_ROUNDS 4      // rounds enqueued without looking (photographic streams settle in two); more only after a host check
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
+void lp_launch_reset_tail_state(hipStream_t s, LpJpegState* d_states, uint32_t n);
+void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size_t bytes); // bytes rounded up to 16: both buffers padded accordingly
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */);
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
