@@ -78,6 +78,7 @@ def lib():
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError("liblilliput_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises (see lp_engine.cpp: LpRuntimeEnv)
     L = C.CDLL(path)
     L.lilliput_hip_last_error.restype = C.c_char_p
     L.lilliput_hip_batch_create.restype = C.c_void_p

@@ -56,7 +56,8 @@ struct LpBatch {
     // transformed one by one on a few host workers while the JPEG parts run
     std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
-    ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); }
+    hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
+    ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); if (shared_copy) { (void)hipStreamSynchronize(shared_copy); (void)hipStreamDestroy(shared_copy); } }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
     {
@@ -629,12 +630,15 @@ struct LpPipeJob {
     std::vector<int> items;
     std::vector<LpJpegSrc> srcs;
     int rc = 0;
+    double t_claim = 0, t_staged = 0, t_begin = 0, t_done = 0; // ms since the call started (LILLIPUT_HIP_TRACE)
+    int part = -1;
 };
 // The chunks of a batch form one queue; every part's stager claims the next chunk when one of its slots is free, so the parts
 // finish within a chunk of each other whatever the mix of image sizes (and whichever copy stream the link served first).
 struct LpPipeShared {
     std::vector<LpPipeJob> jobs;
     std::atomic<size_t> next{0};
+    double t0 = 0;
 };
 struct LpPipe {
     std::vector<size_t> mine;           // claimed jobs, in order (job k of this part uses upload slot k % LP_UPLOAD_SLOTS)
@@ -658,6 +662,8 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
         if (ji >= sh.jobs.size()) break;
         const double t0 = now();
         LpPipeJob& job = sh.jobs[ji];
+        job.t_claim = t0 - sh.t0;
+        job.part = (int)(&part - b->parts.data());
         const int slot = (int)(k % LP_UPLOAD_SLOTS);
         try {
             for (size_t i = job.i0; i < job.i1; i++) {
@@ -672,14 +678,22 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
             if (!job.items.empty()) {
                 int rc = eng.upload_layout(slot, job.srcs.data(), (int)job.srcs.size(), job.hdrs.data());
                 if (!rc) {
-                    eng.upload_copy(slot, 0, eng.upload_pieces(slot));
-                    rc = eng.upload_commit(slot);
+                    // the staging memcpy has to outrun the link (~55 GB/s for all engines together); one thread moves 20-30 GB/s when the
+                    // DMA engine reads the same memory, so every stager brings a few helpers (LILLIPUT_HIP_STAGE_THREADS, default 3 in all)
+                    static const size_t team = getenv("LILLIPUT_HIP_STAGE_THREADS") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_STAGE_THREADS"))) : 3;
+                    const size_t np = eng.upload_pieces(slot), nt = std::min(team, std::max<size_t>(1, np / 4));
+                    std::vector<std::thread> helpers;
+                    for (size_t t = 1; t < nt; t++) helpers.emplace_back([&eng, slot, np, nt, t] { eng.upload_copy(slot, np * t / nt, np * (t + 1) / nt); });
+                    eng.upload_copy(slot, 0, np / nt);
+                    for (auto& h : helpers) h.join();
+                    rc = eng.upload_commit(slot, b->shared_copy);
                     part.staged_bytes += eng.upload_bytes(slot);
                 }
                 if (rc) { job.rc = map_status(rc); part.err = eng.last_error(); }
             }
         } catch (...) { job.rc = LILLIPUT_ERR_DEVICE; part.err = "staging failed (out of host memory?)"; }
         part.stage_ms += now() - t0;
+        job.t_staged = now() - sh.t0;
         {
             std::lock_guard<std::mutex> lk(pp.mu);
             pp.mine.push_back(ji);
@@ -713,11 +727,13 @@ static void pipe_compute(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared
         part.stall_ms += now() - t0;
         LpPipeJob& job = sh.jobs[ji];
         int rc = job.rc;
+        job.t_begin = now() - sh.t0;
         if (!rc && !job.items.empty()) {
             eng.select_upload((int)(k % LP_UPLOAD_SLOTS));
             try { rc = run_chunk(b, part, 0, (int)job.items.size(), job.hdrs.data(), job.items.data(), opt, sink); }
             catch (...) { rc = LILLIPUT_ERR_DEVICE; part.err = "chunk failed (out of host memory?)"; }
         }
+        job.t_done = now() - sh.t0;
         {
             std::lock_guard<std::mutex> lk(pp.mu);
             pp.done = k + 1;
@@ -749,6 +765,11 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
     if (njpeg < 2 * np) np = 1;
     int rc = LILLIPUT_OK;
     if (!b->ensure_parts(np)) rc = LILLIPUT_ERR_DEVICE;
+    static const bool one_copy_queue = !getenv("LILLIPUT_HIP_COPY_QUEUES") || atoi(getenv("LILLIPUT_HIP_COPY_QUEUES")) <= 1;
+    if (!rc && one_copy_queue && !b->shared_copy) {
+        (void)hipSetDevice(b->device);
+        if (hipStreamCreateWithFlags(&b->shared_copy, hipStreamNonBlocking) != hipSuccess) b->shared_copy = nullptr; // the engines' own streams then
+    }
     if (!rc) {
         // chunk: LILLIPUT_HIP_PIPE_CHUNK images (default 32) -- small enough that the first chunk's copy is short, large enough to fill the device
         static const size_t pipe_chunk = getenv("LILLIPUT_HIP_PIPE_CHUNK") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PIPE_CHUNK"))) : 32;
@@ -769,6 +790,7 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
             part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = 0; part.staged_bytes = 0; part.err.clear();
         }
         const LpSink sink{b, items};
+        sh.t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         std::vector<std::thread> th;
         for (size_t p = 0; p < np && p < sh.jobs.size(); p++) {
             pipes.emplace_back(new LpPipe());
@@ -777,6 +799,10 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
         }
         run_other(b, opt, items);
         for (auto& t : th) t.join();
+        if (trace)
+            for (size_t j = 0; j < sh.jobs.size(); j++)
+                fprintf(stderr, "[lilliput_hip] chunk %2zu part %d: claimed %6.1f staged %6.1f compute %6.1f .. %6.1f ms (%zu images)\n", j, sh.jobs[j].part, sh.jobs[j].t_claim,
+                        sh.jobs[j].t_staged, sh.jobs[j].t_begin, sh.jobs[j].t_done, sh.jobs[j].items.size());
         rc = end_run(b, n, trace, t0);
     }
     int failed = 0;

@@ -130,7 +130,7 @@ public:
     size_t upload_pieces(int slot) const { return up_[slot].pieces.size(); }
     size_t upload_bytes(int slot) const { return up_[slot].raw_bytes; }
     void upload_copy(int slot, size_t p0, size_t p1);
-    int upload_commit(int slot);
+    int upload_commit(int slot, hipStream_t on = nullptr);   // on: a copy stream shared by several engines (sets arrive in enqueue order); default: the engine's own
     void select_upload(int slot) { u_ = &up_[slot]; }
     // want_frame (optional, per image): 0 = keep only the planes (the image will go through fused_resample)
     int decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame = nullptr);

@@ -11,17 +11,27 @@ def synth_rgb(seed, size=4096):
     from PIL import Image
 
     rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    t = np.arange(size, dtype=np.float32) / size
     img = np.empty((size, size, 3), np.float32)
+    tau = np.float32(2 * np.pi)
     for c in range(3):
-        f = rng.uniform(0.5, 3.0, 4)
-        ph = rng.uniform(0, 2 * np.pi, 4)
-        base = 128 + 50 * np.sin(2 * np.pi * f[0] * xx + ph[0]) * np.cos(2 * np.pi * f[1] * yy + ph[1]) \
-            + 30 * np.sin(2 * np.pi * (f[2] * xx + f[3] * yy) + ph[2])
+        f = rng.uniform(0.5, 3.0, 4).astype(np.float32)
+        ph = rng.uniform(0, 2 * np.pi, 4).astype(np.float32)
+        # 128 + 50 sin(2 pi f0 x + ph0) cos(2 pi f1 y + ph1) + 30 sin(2 pi (f2 x + f3 y) + ph2): both terms are sums of outer products
+        # of per-axis vectors (sin(a + b) = sin a cos b + cos a sin b), so the gradients cost O(size) trigonometry, not O(size^2)
+        sx, cy = np.sin(tau * f[0] * t + ph[0]), np.cos(tau * f[1] * t + ph[1])
+        ax, by = tau * f[2] * t + ph[2], tau * f[3] * t
+        plane = img[:, :, c]
+        np.multiply.outer(np.float32(50) * cy, sx, out=plane)
+        plane += np.multiply.outer(np.float32(30) * np.cos(by), np.sin(ax))
+        plane += np.multiply.outer(np.float32(30) * np.sin(by), np.cos(ax))
         lo = rng.normal(0, 40, (128, 128)).astype(np.float32)
-        up = np.asarray(Image.fromarray(lo, mode="F").resize((size, size), Image.BICUBIC))
-        img[:, :, c] = base + up + rng.normal(0, 6, (size, size)).astype(np.float32)
-    return np.clip(img + 0.5, 0, 255).astype(np.uint8)
+        plane += np.asarray(Image.fromarray(lo, mode="F").resize((size, size), Image.BICUBIC))
+        noise = rng.standard_normal((size, size), dtype=np.float32)
+        noise *= np.float32(6)
+        plane += noise
+    img += np.float32(128.5)
+    return np.clip(img, 0, 255, out=img).astype(np.uint8)
 
 
 def synth_jpeg(seed, size=4096, quality=90, restart_rows=0, width=None, height=None):
