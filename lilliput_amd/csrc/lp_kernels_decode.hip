@@ -225,7 +225,8 @@ struct DevMem {
     const uint32_t* words;  // this image's clean stream (16-byte aligned)
     uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % R) * 64]
     uint32_t fill;          // next stream word to load (multiple of 4)
-    const LpHuffSet* hs;    // LDS
+    const LpHuffSet* hs;    // LDS: the lookup part (lut, lut2) only
+    const LpHuffSet* hsg;   // HBM: the whole set; the canonical tables are read on damaged streams only
     const uint32_t* rst;
     uint4 pend[Q];          // see reseek / topup
     __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[(w & (R - 1u)) << 6]; }
@@ -271,21 +272,29 @@ struct DevMem {
     __device__ __forceinline__ bool any(bool p) const { return __any(p); }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
-    __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
-    __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
-    __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
+    __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hsg->maxcode[t][l]; }
+    __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hsg->valoff[t][l]; }
+    __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hsg->vals[t][i & 255]; }
     __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
 };
+#ifndef LP_RING
+#define LP_RING 8   // measured against 16 (top-up of two quads every 8 steps): 8 KB less LDS per workgroup, 3-6 % more images/s
+#endif
+#if LP_RING == 8
+typedef DevMem<8, 2, 1> CountMem;   // SPEC / VERIFY: 8 words per lane, a top-up of one quad every 2 steps (2 + 3 + 3 <= 8)
+typedef DevMem<8, 2, 1> WriteMemSel;
+#else
 typedef DevMem<16, 8, 2> CountMem;  // SPEC / VERIFY
+typedef DevMem<16, 8, 2> WriteMemSel;
+#endif
 // WRITE: measured both ways -- DevMem<8, 4, 1> fits four workgroups per CU, DevMem<16, 8, 2> three with half the top-ups;
 // three is 5 % faster alone and leaves LDS for the other parts' kernels when parts of a batch overlap.
-typedef DevMem<16, 8, 2> WriteMem;
+typedef WriteMemSel WriteMem;
 
-__device__ __forceinline__ void stage_huff(LpHuffSet* dst, const LpHuffSet* src)
+__device__ __forceinline__ void stage_huff(uint4* d, const LpHuffSet* src)
 {
     const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    for (uint32_t i = threadIdx.x; i < sizeof(LpHuffSet) / 16; i += blockDim.x) d[i] = s[i];
+    for (uint32_t i = threadIdx.x; i < LP_HUFF_LDS_BYTES / 16; i += blockDim.x) d[i] = s[i];
     __syncthreads();
 }
 
@@ -332,18 +341,19 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
                                                       LpSubState* __restrict__ entry_used, LpCkSched cs, uint32_t tot_sub)
 {
     typedef CountMem MEM;
-    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
+    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
     if (blockIdx.x * HUFF_T >= nsub) return;
-    stage_huff(&s_hs, huffs + img.huff_idx);
+    stage_huff(s_hs4, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
     const bool valid = sub < nsub;
     const uint32_t g = img.sub_off + (valid ? sub : 0);
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
     LpSubState entry;
     const uint32_t S = img.sub_bits;
     entry.p = valid ? sub * S : 0;
@@ -393,7 +403,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         uint32_t* changed, uint32_t round, uint32_t K, uint32_t tot_sub)
 {
     typedef CountMem MEM;
-    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
+    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
     // changed[r] counts the exit states round r moved. The rounds of a decode are enqueued back to back without a host round
@@ -416,10 +427,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
         need = !lp_state_eq(entry, entry_used[g]);
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;
-    stage_huff(&s_hs, huffs + img.huff_idx);
+    stage_huff(s_hs4, huffs + img.huff_idx);
     if (!need) return;
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
     const uint32_t S = img.sub_bits;
     uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) {
@@ -554,7 +565,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
                                                        int16_t* __restrict__ wide_arena, uint32_t* __restrict__ wide_id_arena,
                                                        int16_t* __restrict__ dc_arena)
 {
-    __shared__ __attribute__((aligned(16))) LpHuffSet s_hs;
+    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
+    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
@@ -570,12 +582,12 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
         for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
-    stage_huff(&s_hs, huffs + img.huff_idx);
+    stage_huff(s_hs4, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
     if (sub >= nsub) return;
     const uint32_t g = img.sub_off + sub;
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, &s_hs, rst_bits + img.rst_off};
+    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
     LpSubState entry;
     if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
     DevSink sink;
@@ -796,6 +808,9 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
 __constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
 
 #define IDCT_TPW 8
+#ifndef IDCT_AHEAD
+#define IDCT_AHEAD 4      // divides IDCT_TPW
+#endif
 // PROG = false: the baseline images of the range (int8 blocks in decode order + wide slots + the DC array);
 // PROG = true: the progressive ones (int16 blocks, raster order per component, see LpProgScan). Each skips the other kind.
 template <bool PROG>
@@ -829,13 +844,46 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         qv[0] = (int32_t)(q.x & 0xffffu); qv[1] = (int32_t)(q.x >> 16); qv[2] = (int32_t)(q.y & 0xffffu); qv[3] = (int32_t)(q.y >> 16);
         qv[4] = (int32_t)(q.z & 0xffffu); qv[5] = (int32_t)(q.z >> 16); qv[6] = (int32_t)(q.w & 0xffffu); qv[7] = (int32_t)(q.w >> 16);
     }
-    for (uint32_t t = 0; t < IDCT_TPW; t++) {
+    // Baseline blocks: the coefficient column (8 bytes) and the DC of the tiles IDCT_AHEAD steps ahead are requested before the
+    // current tile is transformed -- one 8-byte load per lane and tile in flight kept the kernel at a third of the HBM rate
+    // (bytes in flight per CU, not VALU, bound it: 73 % of the wave cycles in s_waitcnt, profiles/r02_a_sq_counters.md).
+    uint2 pre_raw[IDCT_AHEAD];
+    int32_t pre_dc[IDCT_AHEAD];
+    // the descriptor fields the block index needs, read once (a load inside the loop would make every step wait for the prefetches too)
+    const uint32_t d_mcus_x = img.mcus_x, d_bpm = img.bpm, d_first = img.blk_first[c];
+    const int8_t* const coef8 = coef8_arena + img.coef_off;
+    const int16_t* const dc16 = dc_arena + img.coef_off / 64;
+    const uint32_t row_blk = (by >> vsh) * d_mcus_x, row_in = d_first + ((by & vsh) << hsh);
+    auto block_of = [&](uint32_t bx) { return (row_blk + (bx >> hsh)) * d_bpm + row_in + (bx & hsh); };
+    // unconditional loads from a clamped block index (a load under a lane mask would be merged with a constant afterwards, and
+    // that merge waits for the load): a tile past the end of the row re-reads the row's last block and is masked where it is used
+    auto fetch = [&](uint32_t t, uint2& raw, int32_t& dcv) {
+        if (PROG) { raw = make_uint2(0, 0); dcv = 0; return; }
+        const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32, bx = base + wv * 8 + j;
+        const uint32_t blk = block_of(bx < bw ? bx : bw - 1u);
+        raw = *reinterpret_cast<const uint2*>(coef8 + (size_t)blk * 64 + r * 8);
+        dcv = dc16[blk];
+    };
+#pragma unroll
+    for (uint32_t a = 0; a < IDCT_AHEAD; a++) fetch(a, pre_raw[a], pre_dc[a]);
+    // unrolled by IDCT_AHEAD: tile t lives in register slot t % IDCT_AHEAD, which is refilled with tile t + IDCT_AHEAD as soon as it
+    // has been read (moving a pending load's register to another slot would wait for it)
+    for (uint32_t t0 = 0; t0 < IDCT_TPW; t0 += IDCT_AHEAD) {
+      bool out = false;
+#pragma unroll
+      for (uint32_t a = 0; a < IDCT_AHEAD; a++) {
+        const uint32_t t = t0 + a;
         const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32;
-        if (base >= bw) break; // workgroup-uniform
+        if (t >= IDCT_TPW || base >= bw) { out = true; break; } // workgroup-uniform
         const uint32_t bx = base + wv * 8 + j;
         const bool blk_ok = bx < bw;
         int32_t cv[8];
         bool any_esc = false;
+        uint2 raw = pre_raw[a];
+        raw.x = blk_ok ? raw.x : 0u;
+        raw.y = blk_ok ? raw.y : 0u;
+        const int32_t dc_now = pre_dc[a];
+        fetch(t + IDCT_AHEAD, pre_raw[a], pre_dc[a]);
         if (PROG) {
             // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
             // its 128 bytes between them)
@@ -846,10 +894,9 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
 #pragma unroll
             for (int i = 0; i < 8; i++) any_esc = any_esc || ((i || r) && (cv[i] > 127 || cv[i] < -127)); // same bound as the int8 path, DC aside
         } else {
-            const uint32_t blk = (((by >> vsh) * img.mcus_x + (bx >> hsh)) * img.bpm + img.blk_first[c] + ((by & vsh) << hsh) + (bx & hsh));
+            const uint32_t blk = block_of(bx);
             // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
             {
-                const uint2 raw = blk_ok ? *reinterpret_cast<const uint2*>(coef8_arena + img.coef_off + (size_t)blk * 64 + r * 8) : make_uint2(0, 0);
 #pragma unroll
                 for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
                 {   // a byte equals 0x80 <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
@@ -867,7 +914,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
                     for (int i = 0; i < 8; i++)
                         if (cv[i] == -128) cv[i] = w[i];
                 }
-                if (r == 0 && blk_ok) cv[0] = dc_arena[img.coef_off / 64 + blk]; // the DC lives in its own 16-bit array
+                if (r == 0 && blk_ok) cv[0] = dc_now; // the DC lives in its own 16-bit array
             }
         }
         // 24-bit multiplies are exact when every multiplied term fits 24 signed bits. The DC (and the workspace column it feeds) is
@@ -881,6 +928,8 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         if (wave_fast) idct_rows<true>(s_w[wv], j, r, blk_ok, dst); else idct_rows<false>(s_w[wv], j, r, blk_ok, dst);
         __syncthreads();
         __syncthreads();
+      }
+      if (out) break;
     }
 }
 

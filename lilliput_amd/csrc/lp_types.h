@@ -24,6 +24,7 @@
 // lut2[(slice << 6) | j] : same encoding (len 11..16) for the codes that start with the slice's prefix, j = the six bits after the
 //              prefix; 0 = no such code -> canonical search. Annex-K tables need 1 + 5 + 5 slices.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
+#define LP_HUFF_LDS_BYTES ((4 * LP_LUT_SIZE + LP_LUT2_POOL) * 2)   // the lookup part the kernels stage in LDS; the canonical part stays in HBM
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
     uint16_t lut2[LP_LUT2_POOL];

@@ -36,8 +36,8 @@ struct HostMemT {
     uint32_t rst_bit(uint32_t k) const { return rst[k]; }
     void settle(uint32_t&) const {}
 };
-typedef HostMemT<16, 8, 2> HostMem;      // geometry of the SPEC / VERIFY kernels
-typedef HostMemT<16, 8, 2> HostMemWrite; // geometry of the WRITE kernel
+typedef HostMemT<8, 2, 1> HostMem;       // geometry of the SPEC / VERIFY kernels
+typedef HostMemT<8, 2, 1> HostMemWrite;  // geometry of the WRITE kernel
 
 struct HostSink { // one slot, flushed at the wave-uniform flush points like the device sink
     int16_t blk[64];
