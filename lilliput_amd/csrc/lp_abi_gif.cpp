@@ -156,8 +156,13 @@ static bool read_frame_indices(giflib_decoder d)
 {
     LpGifReader& g = d->gif;
     if (g.width <= 0 || g.height <= 0) { fprintf(stderr, "encountered error, gif frame has negative or zero width or height\n"); return false; }
+    // the reference's guards (giflib.cpp giflib_decoder_decode_frame): the pixel count must fit an int (get_line takes one) -- a
+    // 65535 x 65535 frame does not -- and the buffer must be obtainable; nothing may unwind through the C ABI
+    if (g.width > INT_MAX / g.height) { fprintf(stderr, "encountered error, gif frame too large\n"); return false; }
     const size_t image_size = (size_t)g.width * (size_t)g.height;
-    if (image_size > d->pixels.size()) d->pixels.resize(image_size); // never shrinks: pixels past a shorter frame keep older values, as in the reference
+    try {
+        if (image_size > d->pixels.size()) d->pixels.resize(image_size); // never shrinks: pixels past a shorter frame keep older values, as in the reference
+    } catch (const std::bad_alloc&) { fprintf(stderr, "encountered error, could not allocate gif frame\n"); return false; }
     if (g.interlace) {
         static const int offset[4] = {0, 4, 2, 1}, jump[4] = {8, 8, 4, 2};
         for (int i = 0; i < 4; i++)

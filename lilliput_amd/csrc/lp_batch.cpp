@@ -109,12 +109,28 @@ static bool is_other_format(const uint8_t* sp, size_t len)
                   (len >= 8 && memcmp(sp, png_sig, 8) == 0));
 }
 
-// Header walk of one JPEG item + the batch's size bound. Returns LILLIPUT_OK when the item goes to the device.
-static int parse_item(const void* src, size_t len, LpJpegHeader* h)
+// Scan-path sources (progressive, multi-scan ...) are entropy-decoded by host threads into a pinned int16 buffer whose size follows
+// from the frame header alone -- a tiny file claiming 8192 x 8192 4:4:4 asks for 400 MB. One upload set never pins more than
+// LILLIPUT_HIP_PROG_PINNED_MAX bytes (default 4 GiB) of it: the items that would go beyond answer ErrBufTooSmall, the others are untouched.
+static size_t prog_pinned_max()
+{
+    static const size_t v = getenv("LILLIPUT_HIP_PROG_PINNED_MAX") ? (size_t)strtoull(getenv("LILLIPUT_HIP_PROG_PINNED_MAX"), nullptr, 10) : (size_t)4 << 30;
+    return v;
+}
+
+// Header walk of one JPEG item + the batch's size bounds. Returns LILLIPUT_OK when the item goes to the device. *pinned accumulates the
+// host coefficient bytes of the set the item joins.
+static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinned)
 {
     const int rc = (src && len) ? lp_jpeg_parse((const uint8_t*)src, len, h) : LP_PARSE_NOT_JPEG;
     if (rc != LP_PARSE_OK) return map_parse(rc);
     if ((uint64_t)h->j.width * h->j.height > batch_max_pixels()) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    if (h->scan_path) {
+        size_t need = 0;
+        for (int c = 0; c < h->j.ncomp; c++) need += (size_t)h->j.bw[c] * h->j.bh[c] * 128;
+        if (*pinned + need > prog_pinned_max()) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        *pinned += need;
+    }
     return LILLIPUT_OK;
 }
 
@@ -169,6 +185,7 @@ extern "C" int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_
     b->other.clear();
     std::vector<int> valid;
     std::vector<LpJpegHeader> hv;
+    size_t pinned = 0; // the whole upload shares the bound (its parts are cut afterwards)
     for (size_t i = 0; i < n; i++) {
         const uint8_t* sp = (const uint8_t*)items[i].src;
         if (is_other_format(sp, items[i].src_len)) {
@@ -177,7 +194,7 @@ extern "C" int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_
             continue;
         }
         LpJpegHeader h;
-        b->parse_status[i] = parse_item(items[i].src, items[i].src_len, &h);
+        b->parse_status[i] = parse_item(items[i].src, items[i].src_len, &h, &pinned);
         if (b->parse_status[i] == LILLIPUT_OK) { valid.push_back((int)i); hv.push_back(h); }
     }
     for (auto& o : b->other) o.data = o.copy.data();
@@ -666,10 +683,11 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
         job.part = (int)(&part - b->parts.data());
         const int slot = (int)(k % LP_UPLOAD_SLOTS);
         try {
+            size_t pinned = 0;
             for (size_t i = job.i0; i < job.i1; i++) {
                 if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) continue; // run_other's
                 job.hdrs.emplace_back();
-                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back());
+                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), &pinned);
                 b->status[i] = st;
                 if (st != LILLIPUT_OK) { job.hdrs.pop_back(); continue; }
                 job.items.push_back((int)i);

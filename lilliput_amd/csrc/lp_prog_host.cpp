@@ -123,7 +123,10 @@ void lp_prog_levels(const std::vector<LpProgScanHost>& scans, std::vector<uint32
             bool share = false;
             for (uint32_t x = 0; x < sa.ns; x++)
                 for (uint32_t y = 0; y < sb.ns; y++) share = share || sa.comp[x] == sb.comp[y];
-            if (share && sa.Ss <= sb.Se && sb.Ss <= sa.Se) level[a] = std::max(level[a], level[b] + 1);
+            // a sequential scan writes whole blocks whatever band its header declares (libjpeg only warns, JWRN_NOT_SEQUENTIAL):
+            // it depends on, and is depended on by, every other scan of its components, in file order
+            const bool overlap = sa.sequential || sb.sequential || (sa.Ss <= sb.Se && sb.Ss <= sa.Se);
+            if (share && overlap) level[a] = std::max(level[a], level[b] + 1);
         }
     }
 }

@@ -131,6 +131,21 @@ def test_host_reader_matches_giflib_live(G, oracle):
             assert mine[4] == oracle.ref_gif_info(data), name
 
 
+def test_frame_whose_pixel_count_overflows_an_int_is_refused_like_the_reference(G):
+    """giflib.cpp giflib_decoder_decode_frame: `desc.Width > INT_MAX / desc.Height` fails the frame. A 65535 x 65535 frame (4 294 836 225
+    pixels) must not be allocated, must not wrap get_line's int length and must not unwind through the C ABI."""
+    L = G
+    data = gif_cases.gif(65535, 65535, [gif_cases.image(0, 0, 65535, 65535, [0, 1, 2, 3])])
+    d = Dec(L, data)
+    assert d.h
+    assert L.giflib_decoder_decode_frame_header(d.h) == 0
+    assert (L.giflib_decoder_get_frame_width(d.h), L.giflib_decoder_get_frame_height(d.h)) == (65535, 65535)
+    idx = np.zeros(16, dtype=np.uint8)
+    meta = (C.c_int * 10)()
+    assert L.lilliput_hip_gif_read_frame(d.h, idx.ctypes.data, idx.size, meta, None) == -1
+    d.close()
+
+
 def test_animation_info_known_answers_of_the_reference_tests(G):
     """giflib_test.go:201-240: loop count, frame count, total duration."""
     fx = gif_cases.fixtures()

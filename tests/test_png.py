@@ -162,6 +162,29 @@ def test_png_to_jpeg_transform_and_batch(hip_lib, oracle, fixture_bytes):
         assert r.data == expect[n], n
 
 
+@pytest.mark.gpu
+def test_batch_bounds_png_and_gif_items_by_their_claimed_size(hip_lib, fixture_bytes):
+    """A 60-byte PNG may claim 10^6 x 10^6 pixels and a GIF a 65535 x 65535 screen: the batch applies the same frame bound to them as
+    to JPEG items (ErrBufTooSmall, what NewImageOps(maxSize) answers), allocates nothing from the claimed size and serves the rest
+    (these items used to size a host buffer from the untrusted header on a worker thread)."""
+    import struct
+    import zlib
+
+    import gif_cases
+    import lilliput_amd as la
+
+    ihdr = struct.pack(">IIBBBBB", 1000000, 1000000, 8, 2, 0, 0, 0)
+    png = b"\x89PNG\r\n\x1a\n" + png_cases.chunk(b"IHDR", ihdr) + png_cases.chunk(b"IDAT", zlib.compress(b"\x00" * 16)) + png_cases.chunk(b"IEND", b"")
+    gif = gif_cases.gif(65535, 65535, [gif_cases.image(0, 0, 65535, 65535, [0, 1, 2, 3])])
+    ok_png = png_cases.fixtures()["ferry_sunset.png"]
+    b = la.Batch(0)
+    for _ in range(2):  # the second call shows the batch object survived the first
+        res = b.transform([png, fixture_bytes["coast.jpg"], gif, ok_png], 50, 40, quality=85)
+        assert [r.status for r in res] == [3, 0, 3, 0], [r.status for r in res]
+        assert res[0].data == b"" and res[2].data == b""
+    b.close()
+
+
 def test_hdr_png_is_refused_not_mis_rendered(hip_lib):
     """A PNG whose cICP chunk signals PQ or HLG is tone-mapped by the reference right after decode (ops.go:154-165, 500-512);
     this build has no tone-map kernel, so the transform refuses instead of returning un-mapped pixels. An SDR cICP passes."""
