@@ -257,6 +257,18 @@ int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* i
 int lilliput_hip_batch_upload2(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n, int engines); /* engines: how many engines (streams) share the batch, 0 = default (LILLIPUT_HIP_STREAMS, 4) */
 int lilliput_hip_batch_run(lilliput_hip_batch b, const lilliput_batch_options* opt);
 int lilliput_hip_batch_download(lilliput_hip_batch b, lilliput_batch_item* items, size_t n);
+/* One process, several GPUs (what a Go service links: cgo cannot be one process per GPU). The devices of a node share one chunk queue in
+ * host memory -- an atomic counter claimed chunk by chunk by every engine of every device -- so the batch is sharded dynamically and a
+ * device that finishes early takes more chunks; no pixel or bitstream byte crosses between devices. devices == NULL: every visible GPU.
+ * The same device may be listed more than once (two engine sets on one GPU; used by the tests on a one-GPU box).
+ * (Across PROCESSES -- torchrun, one rank per GPU -- lilliput_amd/dist.py keeps the queue state in step with one small RCCL all-gather.) */
+typedef void* lilliput_hip_node;
+lilliput_hip_node lilliput_hip_node_create(const int* devices, int n_devices);
+void lilliput_hip_node_destroy(lilliput_hip_node n);
+int lilliput_hip_node_device_count(lilliput_hip_node n);
+int lilliput_hip_node_transform(lilliput_hip_node n, lilliput_batch_item* items, size_t n_items, const lilliput_batch_options* opt); /* like lilliput_hip_batch_transform */
+void lilliput_hip_node_device_stats(lilliput_hip_node n, int k, double out[2]); /* device k in the last transform: images served, bytes staged */
+
 /* Per-stage device milliseconds of the last run (HIP events on the engine's stream): unstuff, huffman (total), idct,
  * colour, resize, encode, then the huffman breakdown: speculate, verify, scan, write; plus the verify rounds. */
 void lilliput_hip_batch_timings(lilliput_hip_batch b, float out_ms[10], int* verify_rounds);

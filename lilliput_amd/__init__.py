@@ -16,6 +16,7 @@ from .binding import (  # noqa: F401
     JpegQuality,
     PngCompression,
     LilliputError,
+    Node,
     ImageOpsFit,
     ImageOpsNoResize,
     ImageOpsResize,

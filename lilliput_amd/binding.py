@@ -93,6 +93,13 @@ def lib():
     L.lilliput_hip_batch_set_subsequence.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     L.lilliput_hip_batch_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.lilliput_hip_batch_ingest_stats.restype = None
+    L.lilliput_hip_node_create.restype = C.c_void_p
+    L.lilliput_hip_node_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.lilliput_hip_node_destroy.argtypes = [C.c_void_p]
+    L.lilliput_hip_node_device_count.argtypes = [C.c_void_p]
+    L.lilliput_hip_node_transform.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t, C.POINTER(_BatchOptions)]
+    L.lilliput_hip_node_device_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.lilliput_hip_node_device_stats.restype = None
     L.lilliput_hip_decode_jpeg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.lilliput_hip_decode_jpeg_coefs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lilliput_hip_decode_jpeg_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -407,3 +414,46 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class Node(Batch):
+    """lilliput_hip_node_*: one process, several GPUs sharing one chunk queue (devices=None: every visible GPU)."""
+
+    def __init__(self, devices=None):
+        if devices is None:
+            h = lib().lilliput_hip_node_create(None, 0)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            h = lib().lilliput_hip_node_create(arr, len(devices))
+        if not h:
+            raise LilliputError(5, "lilliput_hip_node_create")
+        self._n = h
+        self._h = None
+        self._items = None
+        self._keep = None
+
+    def device_count(self):
+        return lib().lilliput_hip_node_device_count(self._n)
+
+    def transform(self, sources, width, height, method=ImageOpsFit, normalize=False, quality=85, dst_cap=1 << 20, chunk=0, progressive=False):
+        self._items, self._keep = self._make_items(sources, dst_cap)
+        o = self._opts(width, height, method, normalize, quality, chunk, progressive)
+        lib().lilliput_hip_node_transform(self._n, self._items, len(sources), C.byref(o))
+        return self._results()
+
+    def transform_prepared(self, width, height, method=ImageOpsFit, normalize=False, quality=85, chunk=0, progressive=False):
+        o = self._opts(width, height, method, normalize, quality, chunk, progressive)
+        return lib().lilliput_hip_node_transform(self._n, self._items, len(self._items), C.byref(o))
+
+    def device_stats(self):
+        out = []
+        for k in range(self.device_count()):
+            v = (C.c_double * 2)()
+            lib().lilliput_hip_node_device_stats(self._n, k, v)
+            out.append({"images": int(v[0]), "staged_bytes": int(v[1])})
+        return out
+
+    def close(self):
+        if self._n:
+            lib().lilliput_hip_node_destroy(self._n)
+            self._n = None

@@ -57,6 +57,8 @@ struct LpBatch {
     std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
     hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
+    int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
+    size_t last_images = 0;                    // images this device's engines served in the last transform
     ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); if (shared_copy) { (void)hipStreamSynchronize(shared_copy); (void)hipStreamDestroy(shared_copy); } }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
@@ -665,7 +667,7 @@ struct LpPipe {
     bool no_more = false, abort = false;
 };
 
-static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_item* items)
+static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_item* items)
 {
     LpEngine& eng = *part.eng;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -680,7 +682,7 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
         const double t0 = now();
         LpPipeJob& job = sh.jobs[ji];
         job.t_claim = t0 - sh.t0;
-        job.part = (int)(&part - b->parts.data());
+        job.part = (int)(&part - b->parts.data()) + 16 * b->node_index;
         const int slot = (int)(k % LP_UPLOAD_SLOTS);
         try {
             size_t pinned = 0;
@@ -688,7 +690,7 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
                 if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) continue; // run_other's
                 job.hdrs.emplace_back();
                 const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), &pinned);
-                b->status[i] = st;
+                res->status[i] = st;
                 if (st != LILLIPUT_OK) { job.hdrs.pop_back(); continue; }
                 job.items.push_back((int)i);
                 job.srcs.push_back(LpJpegSrc{(const uint8_t*)items[i].src, items[i].src_len});
@@ -728,7 +730,7 @@ static void pipe_stager(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared&
     pp.cv.notify_all();
 }
 
-static void pipe_compute(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_options* opt, const LpSink& sink)
+static void pipe_compute(LpBatch* res, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_options* opt, const LpSink& sink)
 {
     LpEngine& eng = *part.eng;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -748,7 +750,7 @@ static void pipe_compute(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared
         job.t_begin = now() - sh.t0;
         if (!rc && !job.items.empty()) {
             eng.select_upload((int)(k % LP_UPLOAD_SLOTS));
-            try { rc = run_chunk(b, part, 0, (int)job.items.size(), job.hdrs.data(), job.items.data(), opt, sink); }
+            try { rc = run_chunk(res, part, 0, (int)job.items.size(), job.hdrs.data(), job.items.data(), opt, sink); }
             catch (...) { rc = LILLIPUT_ERR_DEVICE; part.err = "chunk failed (out of host memory?)"; }
         }
         job.t_done = now() - sh.t0;
@@ -764,10 +766,10 @@ static void pipe_compute(LpBatch* b, LpBatchPart& part, LpPipe& pp, LpPipeShared
     eng.select_upload(0);
 }
 
-extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+// devs[0] owns the result arrays and serves the PNG / GIF items; every device contributes its engines to one chunk queue.
+static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
 {
-    auto b = static_cast<LpBatch*>(bb);
-    if (!b || !opt || (!items && n)) return (int)n;
+    LpBatch* b = devs[0];
     const bool trace = getenv("LILLIPUT_HIP_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     b->n_items = n;
@@ -780,13 +782,15 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
         else njpeg++;
     }
     size_t np = (size_t)batch_streams(0);
-    if (njpeg < 2 * np) np = 1;
+    if (njpeg < 2 * np * devs.size()) np = 1;
     int rc = LILLIPUT_OK;
-    if (!b->ensure_parts(np)) rc = LILLIPUT_ERR_DEVICE;
     static const bool one_copy_queue = !getenv("LILLIPUT_HIP_COPY_QUEUES") || atoi(getenv("LILLIPUT_HIP_COPY_QUEUES")) <= 1;
-    if (!rc && one_copy_queue && !b->shared_copy) {
-        (void)hipSetDevice(b->device);
-        if (hipStreamCreateWithFlags(&b->shared_copy, hipStreamNonBlocking) != hipSuccess) b->shared_copy = nullptr; // the engines' own streams then
+    for (LpBatch* d : devs) {
+        if (!d->ensure_parts(np)) rc = LILLIPUT_ERR_DEVICE;
+        if (!rc && one_copy_queue && !d->shared_copy) {
+            (void)hipSetDevice(d->device);
+            if (hipStreamCreateWithFlags(&d->shared_copy, hipStreamNonBlocking) != hipSuccess) d->shared_copy = nullptr; // the engines' own streams then
+        }
     }
     if (!rc) {
         // chunk: LILLIPUT_HIP_PIPE_CHUNK images (default 32) -- small enough that the first chunk's copy is short, large enough to fill the device
@@ -802,26 +806,37 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
             job.i1 = i;
             sh.jobs.push_back(std::move(job));
         }
-        for (auto& part : b->parts) {
-            for (int i = 0; i < 10; i++) part.acc[i] = 0;
-            for (int i = 0; i < 6; i++) part.tw[i] = 0;
-            part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = 0; part.staged_bytes = 0; part.err.clear();
-        }
+        for (LpBatch* d : devs)
+            for (auto& part : d->parts) {
+                for (int i = 0; i < 10; i++) part.acc[i] = 0;
+                for (int i = 0; i < 6; i++) part.tw[i] = 0;
+                part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = 0; part.staged_bytes = 0; part.err.clear();
+            }
         const LpSink sink{b, items};
         sh.t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         std::vector<std::thread> th;
-        for (size_t p = 0; p < np && p < sh.jobs.size(); p++) {
-            pipes.emplace_back(new LpPipe());
-            th.emplace_back(pipe_stager, b, std::ref(b->parts[p]), std::ref(*pipes[p]), std::ref(sh), items);
-            th.emplace_back(pipe_compute, b, std::ref(b->parts[p]), std::ref(*pipes[p]), std::ref(sh), opt, std::cref(sink));
-        }
+        // engines are started device by device in turn (engine 0 of every device, then engine 1 ...) so that a short queue spreads over the devices
+        for (size_t p = 0; p < np; p++)
+            for (LpBatch* d : devs) {
+                if (pipes.size() >= sh.jobs.size()) break;
+                pipes.emplace_back(new LpPipe());
+                LpPipe& pp = *pipes.back();
+                th.emplace_back(pipe_stager, d, b, std::ref(d->parts[p]), std::ref(pp), std::ref(sh), items);
+                th.emplace_back(pipe_compute, b, std::ref(d->parts[p]), std::ref(pp), std::ref(sh), opt, std::cref(sink));
+            }
         run_other(b, opt, items);
         for (auto& t : th) t.join();
-        if (trace)
-            for (size_t j = 0; j < sh.jobs.size(); j++)
-                fprintf(stderr, "[lilliput_hip] chunk %2zu part %d: claimed %6.1f staged %6.1f compute %6.1f .. %6.1f ms (%zu images)\n", j, sh.jobs[j].part, sh.jobs[j].t_claim,
-                        sh.jobs[j].t_staged, sh.jobs[j].t_begin, sh.jobs[j].t_done, sh.jobs[j].items.size());
-        rc = end_run(b, n, trace, t0);
+        for (LpBatch* d : devs) d->last_images = 0;
+        for (size_t j = 0; j < sh.jobs.size(); j++) {
+            if (sh.jobs[j].part >= 0) devs[(size_t)(sh.jobs[j].part / 16)]->last_images += sh.jobs[j].items.size();
+            if (trace)
+                fprintf(stderr, "[lilliput_hip] chunk %2zu device %d engine %d: claimed %6.1f staged %6.1f compute %6.1f .. %6.1f ms (%zu images)\n", j, sh.jobs[j].part / 16,
+                        sh.jobs[j].part % 16, sh.jobs[j].t_claim, sh.jobs[j].t_staged, sh.jobs[j].t_begin, sh.jobs[j].t_done, sh.jobs[j].items.size());
+        }
+        for (size_t k = devs.size(); k-- > 0;) { // devs[0] last: its totals are what lilliput_hip_batch_timings reports for a one-device call
+            const int r = end_run(devs[k], n, trace && k == 0, t0);
+            if (r) rc = r;
+        }
     }
     int failed = 0;
     for (size_t i = 0; i < n; i++) {
@@ -833,6 +848,65 @@ extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batc
         if (items[i].status) failed++;
     }
     return failed;
+}
+
+extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    if (!b || !opt || (!items && n)) return (int)n;
+    b->node_index = 0;
+    return transform_on(std::vector<LpBatch*>{b}, items, n, opt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One process, every GPU of the node: what a Go service links (cgo cannot run one process per GPU under torchrun). The devices
+// share ONE chunk queue in host memory -- an atomic counter, claimed chunk by chunk by every engine of every device -- so a device
+// that finishes early (smaller images, a faster link) simply takes more chunks: work stealing without any device-to-device traffic.
+// (lilliput_amd/dist.py does the same across PROCESSES, where the queue state travels through one tiny RCCL all-gather per epoch.)
+struct LpNode {
+    std::vector<std::unique_ptr<LpBatch>> devs;
+};
+
+extern "C" lilliput_hip_node lilliput_hip_node_create(const int* devices, int n_devices)
+{
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { lp_set_error("no HIP device visible"); fprintf(stderr, "lilliput_hip: no HIP device visible\n"); return nullptr; }
+    std::vector<int> ids;
+    if (devices && n_devices > 0) ids.assign(devices, devices + n_devices);
+    else for (int i = 0; i < visible; i++) ids.push_back(i);
+    auto node = new LpNode();
+    for (size_t k = 0; k < ids.size(); k++) {
+        if (ids[k] < 0 || ids[k] >= visible) { lp_set_error("HIP device index out of range"); delete node; return nullptr; }
+        std::unique_ptr<LpBatch> b(new LpBatch());
+        b->device = ids[k];
+        b->node_index = (int)k;
+        if (!b->ensure_parts(1)) { delete node; return nullptr; }
+        node->devs.push_back(std::move(b));
+    }
+    return node;
+}
+
+extern "C" void lilliput_hip_node_destroy(lilliput_hip_node n) { delete static_cast<LpNode*>(n); }
+
+extern "C" int lilliput_hip_node_device_count(lilliput_hip_node n) { return n ? (int)static_cast<LpNode*>(n)->devs.size() : 0; }
+
+extern "C" int lilliput_hip_node_transform(lilliput_hip_node nn, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
+{
+    auto node = static_cast<LpNode*>(nn);
+    if (!node || node->devs.empty() || !opt || (!items && n)) return (int)n;
+    std::vector<LpBatch*> devs;
+    for (auto& d : node->devs) devs.push_back(d.get());
+    return transform_on(devs, items, n, opt);
+}
+
+// images served and bytes staged by device k in the last node transform
+extern "C" void lilliput_hip_node_device_stats(lilliput_hip_node nn, int k, double out[2])
+{
+    auto node = static_cast<LpNode*>(nn);
+    out[0] = out[1] = 0;
+    if (!node || k < 0 || (size_t)k >= node->devs.size()) return;
+    out[0] = (double)node->devs[(size_t)k]->last_images;
+    out[1] = (double)node->devs[(size_t)k]->last_staged_bytes;
 }
 
 extern "C" {

@@ -1,9 +1,12 @@
 """The N>1 path on CPU: two processes over the gloo backend shard a batch, run the timed region of bench.py's contract
 (barrier on both sides, max over ranks) and account for every item exactly once."""
+import hashlib
 import json
 import os
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -45,3 +48,57 @@ def test_single_rank_needs_no_process_group():
     assert (r.rank, r.world, list(r.shard(5))) == (0, 1, [0, 1, 2, 3, 4])
     assert r.timed(lambda: None, steps=2, warmup=1) >= 0.0
     assert r.reduce(3.5, "sum") == 3.5
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_through_the_queue(tmp_path):
+    """The multi-process path with REAL images: two gloo ranks, each with its own Batch on GPU 0, claim chunks through the work
+    queue; together they produce every image exactly once and byte for byte what one Batch produces alone."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "multi_rank_gpu_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = [json.load(open(os.path.join(tmp_path, "gpu_rank%d.json" % r))) for r in (0, 1)]
+    n = res[0]["n"]
+    assert sorted(int(i) for r in res for i in r["items"]) == list(range(n))   # disjoint cover
+    assert all(len(r["items"]) > 0 for r in res)
+    sys.path.insert(0, ROOT)
+    import lilliput_amd as la
+
+    fix = os.path.join(ROOT, "tests", "golden", "inputs")
+    names = sorted(x for x in os.listdir(fix) if x.endswith(".jpg"))
+    sources = [open(os.path.join(fix, x), "rb").read() for x in names] * 3
+    b = la.Batch(0)
+    ref = b.transform(sources, 64, 64, quality=85)
+    b.close()
+    merged = {int(i): v for r in res for i, v in r["items"].items()}
+    for i, rr in enumerate(ref):
+        assert merged[i] == [rr.status, hashlib.sha256(rr.data).hexdigest()], i
+
+
+@pytest.mark.gpu
+def test_node_entry_point_shares_one_queue_between_device_slots():
+    """lilliput_hip_node_*: one process, several devices, ONE chunk queue in host memory. On a one-GPU box the same device is listed
+    twice (two engine sets): every image exactly once, the same bytes as a single batch, and both slots took part."""
+    sys.path.insert(0, ROOT)
+    import lilliput_amd as la
+    from lilliput_amd import synth
+
+    fix = os.path.join(ROOT, "tests", "golden", "inputs")
+    names = sorted(x for x in os.listdir(fix) if x.endswith(".jpg"))
+    sources = [open(os.path.join(fix, x), "rb").read() for x in names] * 4 + [synth.synth_jpeg(s, 1024) for s in range(6)] + [b"junk"]
+    b = la.Batch(0)
+    ref = b.transform(sources, 96, 96, quality=85, chunk=3)
+    b.close()
+    node = la.Node([0, 0])
+    assert node.device_count() == 2
+    for _ in range(2):
+        got = node.transform(sources, 96, 96, quality=85, chunk=3)
+        assert [(g.status, g.data) for g in got] == [(r.status, r.data) for r in ref]
+        stats = node.device_stats()
+        assert sum(s["images"] for s in stats) == sum(1 for r in ref if r.status == 0) and all(s["images"] > 0 for s in stats), stats
+    node.close()
+    every = la.Node()          # every visible GPU
+    assert every.device_count() >= 1
+    assert [(g.status, g.data) for g in every.transform(sources[:7], 96, 96, quality=85)] == [(r.status, r.data) for r in ref[:7]]
+    every.close()
