@@ -193,7 +193,7 @@ def main():
                 b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
             resident_ips = 2 * args.batch / (time.time() - t)
         # exclusive kernel durations: ONE engine, so that no other stream's kernels share the GPU with the launch being timed
-        nx = min(256, args.batch)
+        nx = min(224, args.batch)   # two launches of the resident chunk size
         b1 = la.Batch(local_rank % ndev)
         if args.sub_bits:
             b1.set_subsequence(args.sub_bits, args.ckpt_bits)
@@ -202,7 +202,7 @@ def main():
         b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
         excl = b1.timings()
         excl["images"] = nx
-        excl["launch_images"] = min(args.chunk or 128, nx)
+        excl["launch_images"] = min(args.chunk or 112, nx)
         b1.close()
 
     if rank == 0:
@@ -220,7 +220,7 @@ def main():
         dom = max(src_tab.items(), key=lambda kv: kv[1][0])
         dom_ms, dom_bytes = dom[1]
         if dom_ms > 0:
-            launch_images = excl["launch_images"] if excl else min(args.chunk or 128, args.batch)
+            launch_images = excl["launch_images"] if excl else min(args.chunk or 112, args.batch)
             achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
             traffic = None
             try:  # HBM bytes of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE)

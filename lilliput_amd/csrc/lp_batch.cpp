@@ -474,7 +474,9 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     if (!nv) return LILLIPUT_OK;
     LpEngine& eng = *part.eng;
     eng.select_upload(0);
-    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, 128);
+    // 112, not 128: a 4096 x 4096 image is 9 workgroups of the WRITE kernel, four of which fit a CU (LDS): 113 images fill the 256 CUs
+    // exactly once, 128 would leave an eighth of the grid for a second, nearly empty round (measured: 28 instead of 36 us per image)
+    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, 112);
     const LpSink sink{b, nullptr};
     eng.enable_timing(true);
     int rc = LILLIPUT_OK;

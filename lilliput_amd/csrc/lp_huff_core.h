@@ -417,7 +417,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 //   void finish();                                 once, after the last flush
 // Returns the number of blocks written.
 #ifndef LP_FLUSH_EVERY
-#define LP_FLUSH_EVERY 3   // 2 / 3 / 4 measured: 3 is the best trade of flush instructions against lanes waiting for the flush
+#define LP_FLUSH_EVERY 4   // 2 / 3 / 4 / 6 measured (8-word ring, top-up every 2 steps): 4 is the best trade of flush instructions against lanes waiting for the flush
 #endif
 template <class M, class Sink>
 LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_t end_p, const LpSubSum& prefix, const uint8_t* zigzag,

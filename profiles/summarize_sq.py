@@ -18,15 +18,14 @@ def short(name):
 
 
 def counters(p):
-    acc, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    vals = defaultdict(lambda: defaultdict(list))
     hits = glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)
     if not hits:
         return {}
     for r in csv.DictReader(open(hits[0])):
-        k = short(r["Kernel_Name"])
-        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k][r["Counter_Name"]] += 1
-    return {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}
+        vals[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # median over the launches of the run (the first launch of a process carries one-off work)
+    return {k: {c: sorted(v)[len(v) // 2] for c, v in vals[k].items()} for k in vals}
 
 
 dur = {}
@@ -44,14 +43,16 @@ for k, (us, calls) in sorted(dur.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         continue
     waves = c.get("SQ_WAVES", 0) or 1
     wc = c.get("SQ_WAVE_CYCLES", 0) * 4 or 1  # quad-cycles -> cycles
-    clk = c.get("GRBM_GUI_ACTIVE", 0) / (us * 1e-6) if c.get("GRBM_GUI_ACTIVE") else CLK
+    clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (us * 1e-6) if c.get("GRBM_GUI_ACTIVE") else CLK  # the counter is summed over the 8 XCDs
     valu_util = c.get("SQ_INSTS_VALU", 0) * 2 / (SIMDS * us * 1e-6 * CLK)
     hbm = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
+    fetch_raw, write_raw = c.get("FETCH_SIZE", 0) * 1024, c.get("WRITE_SIZE", 0) * 1024
     o = {"us_per_launch": us, "us_per_image": us / nimg, "waves": waves, "valu_per_wave": c.get("SQ_INSTS_VALU", 0) / waves,
          "salu_per_wave": c.get("SQ_INSTS_SALU", 0) / waves, "lds_per_wave": c.get("SQ_INSTS_LDS", 0) / waves,
          "valu_issue_util": valu_util, "wait_any": c.get("SQ_WAIT_ANY", 0) * 4 / wc, "wait_inst": c.get("SQ_WAIT_INST_ANY", 0) * 4 / wc,
          "lds_conflict_share": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, c.get("SQ_LDS_IDX_ACTIVE", 0) or c.get("SQ_ACTIVE_INST_LDS", 1)),
-         "waves_per_simd": wc / (SIMDS * us * 1e-6 * CLK), "hbm_bytes_per_image": hbm / nimg, "gui_clock_ghz": clk / 1e9}
+         "waves_per_simd": wc / (SIMDS * us * 1e-6 * CLK), "hbm_bytes_per_image": hbm / nimg, "fetch_size_bytes_per_image_uncorrected": fetch_raw / nimg,
+         "write_size_bytes_per_image": write_raw / nimg, "gui_clock_ghz": clk / 1e9}
     out[k] = o
     rows.append("| `%s` | %.1f | %.2f | %d | %.0f | %.0f | %.0f | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.1f | %.2f |" % (
         k, us, us / nimg, waves, o["valu_per_wave"], o["salu_per_wave"], o["lds_per_wave"], 100 * valu_util, 100 * o["wait_any"], 100 * o["wait_inst"],

@@ -4,7 +4,7 @@
 # together with the API trace domains; counters serialise the dispatches, so these are EXCLUSIVE per-kernel figures: one stream).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=$1; shift
 export TMPDIR=/tmp LILLIPUT_HIP_STREAMS=1; cd /tmp
-B="python $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 --batch 256 $*"
+B="python $R/bench.py --resident --no-extra-legs --no-cpu-baseline --distinct 64 --steps 1 --warmup 1 --batch 256 $*"
 o=$R/gpurun_out/$tag; mkdir -p $o
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace -o trace -- $B > $o/trace.json 2> $o/trace.err
 pass() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $o/$n -o $n -- $B > $o/$n.json 2> $o/$n.err || echo "pass $n failed: $(tail -2 $o/$n.err)"; }
