@@ -183,6 +183,53 @@ bool giflib_encoder_flush(giflib_encoder e, const giflib_decoder d);
 void giflib_encoder_release(giflib_encoder e);
 int giflib_encoder_get_output_length(giflib_encoder e);
 
+/* ------------------------------------------------------------------------------------------------
+ * Part A3 -- the reference's webp.hpp C ABI (webp.hpp:13-75; Go caller: webp.go:27-261). RIFF container walk and animation writer are
+ * this library's own; the VP8 / VP8L payloads are (de)coded on the host by libwebp; decoded (sub-)frames join the device path at the
+ * next opencv_* call (blend / dispose on the HBM canvas, Fit, resize).
+ * ---------------------------------------------------------------------------------------------- */
+enum WebpEncoderOptions {   /* webp.hpp:13-23 */
+    WEBP_METHOD = 1000,
+    WEBP_FILTER_STRENGTH = 1001,
+    WEBP_FILTER_TYPE = 1002,
+    WEBP_AUTOFILTER = 1003,
+    WEBP_PARTITIONS = 1004,
+    WEBP_SEGMENTS = 1005,
+    WEBP_PREPROCESSING = 1006,
+    WEBP_THREAD_LEVEL = 1007,
+    WEBP_PALETTE = 1008
+};
+typedef struct webp_decoder_struct* webp_decoder;   /* webp.hpp:28-29 */
+typedef struct webp_encoder_struct* webp_encoder;
+/* webp.hpp:35-51, 72-73 */
+webp_decoder webp_decoder_create(const opencv_mat buf);
+int webp_decoder_get_width(const webp_decoder d);
+int webp_decoder_get_height(const webp_decoder d);
+int webp_decoder_get_pixel_type(const webp_decoder d);
+int webp_decoder_get_num_frames(const webp_decoder d);
+int webp_decoder_get_total_duration(const webp_decoder d);
+int webp_decoder_get_prev_frame_delay(const webp_decoder d);
+int webp_decoder_get_prev_frame_dispose(const webp_decoder d);
+int webp_decoder_get_prev_frame_blend(const webp_decoder d);
+int webp_decoder_get_prev_frame_x_offset(const webp_decoder d);
+int webp_decoder_get_prev_frame_y_offset(const webp_decoder d);
+bool webp_decoder_get_prev_frame_has_alpha(const webp_decoder d);
+uint32_t webp_decoder_get_bg_color(const webp_decoder d);
+uint32_t webp_decoder_get_loop_count(const webp_decoder d);
+size_t webp_decoder_get_icc(const webp_decoder d, void* buf, size_t buf_len);
+void webp_decoder_release(webp_decoder d);
+bool webp_decoder_decode(webp_decoder d, opencv_mat mat);   /* the Mat takes the frame's own dimensions: animation frames are sub-rectangles */
+void webp_decoder_advance_frame(webp_decoder d);
+int webp_decoder_has_more_frames(webp_decoder d);
+/* webp.hpp:56-71 -- one frame: a still image through libwebp's simple API (quality / lossless above 100; the other options are
+ * ignored for stills, as in the reference); from the second frame on an animation: every frame's changed rectangle coded with the
+ * caller's options and placed without blending (the reference's WebPAnimEncoder picks rectangles and key frames its own way: the
+ * files differ, the decoded frames do not beyond the lossy coder's error). flush assembles the container, ICCP chunk included. */
+webp_encoder webp_encoder_create(void* buf, size_t buf_len, const void* icc, size_t icc_len, uint32_t bgcolor, int loop_count);
+size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, size_t opt_len, int delay, int blend, int dispose, int x_offset, int y_offset);
+void webp_encoder_release(webp_encoder e);
+size_t webp_encoder_flush(webp_encoder e);
+
 /* Test access: the host half of decode_frame for the frame whose header was just read (no device work).
  * meta = {left, top, width, height, interlace, disposal, delay, transparent, color_count, has_local_map}; returns the
  * number of indices written, -1 on a decode error, -2 when cap is too small. */

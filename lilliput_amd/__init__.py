@@ -15,6 +15,9 @@ from .binding import (  # noqa: F401
     JpegProgressive,
     JpegQuality,
     PngCompression,
+    WebpQuality,
+    WebpMethod,
+    WebpSegments,
     LilliputError,
     Node,
     ImageOpsFit,

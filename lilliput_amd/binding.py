@@ -26,6 +26,8 @@ ImageOpsNoResize, ImageOpsFit, ImageOpsResize = 0, 1, 2  # ops.go:18-22
 JpegQuality = 1  # opencv.go:44 (CV_IMWRITE_JPEG_QUALITY)
 JpegProgressive = 2
 PngCompression = 16  # opencv.go:45 (CV_IMWRITE_PNG_COMPRESSION)
+WebpQuality = 64  # opencv.go:46 (CV_IMWRITE_WEBP_QUALITY); above 100 = lossless (webp.cpp:466-470)
+WebpMethod, WebpFilterStrength, WebpFilterType, WebpAutofilter, WebpPartitions, WebpSegments, WebpPreprocessing, WebpThreadLevel, WebpPalette = range(1000, 1009)  # webp.hpp:13-23
 
 
 class LilliputError(RuntimeError):

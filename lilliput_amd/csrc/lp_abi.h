@@ -55,3 +55,4 @@ bool lp_mat_to_host(LpMat* m, LpEngine* eng);
 bool lp_mat_host_current(LpMat* m);
 int lp_lazy_host_scope(int on); // per-thread override of the lazy write-back default (-1 = none); returns the previous value
 LpFrame lp_mat_frame(const LpMat* m);
+bool lp_mat_reshape(LpMat* m, int rows, int cols, int type); // cv::Mat::create for an output Mat: the external buffer is kept when the new shape fits

@@ -192,7 +192,7 @@ static bool mat_new_dev(LpMat* m)
 }
 
 // cv::Mat::create semantics for an output Mat: keep the external buffer when the new shape fits.
-static bool mat_reshape(LpMat* m, int rows, int cols, int type)
+bool lp_mat_reshape(LpMat* m, int rows, int cols, int type)
 {
     const size_t need = (size_t)rows * cols * cv_elem_size(type);
     if (m->rows == rows && m->cols == cols && m->type == type && m->data) return true;
@@ -384,7 +384,7 @@ void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int heig
     if (interpolation != CV_INTER_AREA) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports CV_INTER_AREA only\n"); return; }
     if (cv_depth_bytes(s->type) != 1) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports 8-bit matrices only\n"); return; }
     if (!lp_mat_to_device(s, eng)) return;
-    mat_reshape(d, height, width, s->type);
+    lp_mat_reshape(d, height, width, s->type);
     if (!mat_new_dev(d)) return;
     LpResizeReq rq;
     rq.src = lp_mat_frame(s);

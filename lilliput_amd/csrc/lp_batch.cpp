@@ -108,7 +108,8 @@ static bool is_other_format(const uint8_t* sp, size_t len)
 {
     static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
     return sp && ((len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
-                  (len >= 8 && memcmp(sp, png_sig, 8) == 0));
+                  (len >= 8 && memcmp(sp, png_sig, 8) == 0) ||
+                  (len >= 12 && memcmp(sp, "RIFF", 4) == 0 && memcmp(sp + 8, "WEBP", 4) == 0)); // isWebp, lilliput.go:104-115
 }
 
 // Scan-path sources (progressive, multi-scan ...) are entropy-decoded by host threads into a pinned int16 buffer whose size follows
@@ -486,7 +487,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     return rc;
 }
 
-// GIF and PNG items: Decoder + ImageOps.Transform of the Go-API mirror (for GIF the JPEG writer returns after the first composited frame)
+// GIF, PNG and WebP items: Decoder + ImageOps.Transform of the Go-API mirror (for animated sources the JPEG writer returns after the first composited frame)
 static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_batch_item* items)
 {
     if (b->other.empty()) return;

@@ -155,13 +155,14 @@ struct Framebuffer {
     }
 };
 
-struct Decoder { // openCVDecoder (opencv.go:132-138) or gifDecoder (giflib.go:14-28)
-    enum Kind { OPENCV, GIF } kind = OPENCV;
+struct Decoder { // openCVDecoder (opencv.go:132-138), gifDecoder (giflib.go:14-28) or webpDecoder (webp.go:14-18)
+    enum Kind { OPENCV, GIF, WEBP } kind = OPENCV;
     const uint8_t* buf = nullptr;
     size_t len = 0;
     opencv_mat mat = nullptr;
     opencv_decoder dec = nullptr;
     giflib_decoder gif = nullptr;
+    webp_decoder webp = nullptr;
     bool has_read_header = false, has_decoded = false;
     int content_length = -1, num_frames = 0; // the buffer cannot change under a decoder: scanned once, not per Header() call
     bool anim_read = false;                  // gifDecoder.readAnimationInfo: lazily, once
@@ -182,6 +183,15 @@ int decoder_header(Decoder* d, Header* h)
         h->pixel_type = CV_8UC4;
         h->orientation = 1; // OrientationTopLeft
         h->num_frames = d->anim.frame_count;
+        h->content_length = (int)d->len;
+        return LILLIPUT_OK;
+    }
+    if (d->kind == Decoder::WEBP) { // webp.go:50-59
+        h->width = webp_decoder_get_width(d->webp);
+        h->height = webp_decoder_get_height(d->webp);
+        h->pixel_type = webp_decoder_get_pixel_type(d->webp);
+        h->orientation = 1;
+        h->num_frames = webp_decoder_get_num_frames(d->webp);
         h->content_length = (int)d->len;
         return LILLIPUT_OK;
     }
@@ -219,6 +229,20 @@ int decoder_decode_to(Decoder* d, Framebuffer* f)
         d->frame_index++;
         return LILLIPUT_OK;
     }
+    if (d->kind == Decoder::WEBP) { // webp.go:129-167
+        int e = decoder_header(d, &h);
+        if (e) return e;
+        e = f->resize_mat(h.width, h.height, h.pixel_type);
+        if (e) return e;
+        if (!webp_decoder_decode(d->webp, f->mat)) return webp_decoder_has_more_frames(d->webp) == 0 ? LILLIPUT_ERR_EOF : LILLIPUT_ERR_DECODING_FAILED;
+        f->duration = (int64_t)webp_decoder_get_prev_frame_delay(d->webp) * 1000000ll;
+        f->x_offset = webp_decoder_get_prev_frame_x_offset(d->webp);
+        f->y_offset = webp_decoder_get_prev_frame_y_offset(d->webp);
+        f->dispose = webp_decoder_get_prev_frame_dispose(d->webp);
+        f->blend = webp_decoder_get_prev_frame_blend(d->webp);
+        webp_decoder_advance_frame(d->webp);
+        return LILLIPUT_OK;
+    }
     // opencv.go:816-839
     if (d->has_decoded) return LILLIPUT_ERR_EOF;
     int e = decoder_header(d, &h);
@@ -252,7 +276,8 @@ int skip_to_end(Decoder* d) // ops.go:337-346
 }
 
 struct Encoder { // openCVEncoder (opencv.go:141-146, 847-905), or the raw frame sink used by the tests
-    enum Kind { OPENCV, RAW_FRAMES, GIF, THUMBHASH } kind = OPENCV;
+    enum Kind { OPENCV, RAW_FRAMES, GIF, THUMBHASH, WEBP } kind = OPENCV;
+    webp_encoder webp = nullptr; // webpEncoder, webp.go:20-26, 174-261
     thumbhash_encoder th = nullptr; // thumbhashEncoder, thumbhash.go:12-16
     opencv_encoder enc = nullptr;
     giflib_encoder gif = nullptr; // gifEncoder, giflib.go:30-37, 239-296
@@ -330,14 +355,19 @@ int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // 
     *out = nullptr;
     if (!buf || len == 0) return LILLIPUT_ERR_INVALID_IMAGE;
     const uint8_t* b = (const uint8_t*)buf;
-    // WebP / AVIF sources have their own decoders in the reference (lilliput.go:141-149); they are outside this build.
-    if ((len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) ||
-        (len >= 12 && memcmp(b + 4, "ftyp", 4) == 0 && (memcmp(b + 8, "avif", 4) == 0 || memcmp(b + 8, "avis", 4) == 0)))
-        return LILLIPUT_ERR_UNSUPPORTED;
+    // AVIF sources have their own decoder in the reference (lilliput.go:146-149: libavif + dav1d / aom -- an AV1 codec); it is outside this build.
+    if (len >= 12 && memcmp(b + 4, "ftyp", 4) == 0 && (memcmp(b + 8, "avif", 4) == 0 || memcmp(b + 8, "avis", 4) == 0)) return LILLIPUT_ERR_UNSUPPORTED;
     opencv_mat mat = opencv_mat_create_from_data((int)len, 1, CV_8U, (void*)buf, len);
     if (!mat) return LILLIPUT_ERR_BUF_TOO_SMALL;
     auto d = new Decoder();
     d->buf = b; d->len = len; d->mat = mat;
+    if (len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) { // isWebp, lilliput.go:104-115 -> newWebpDecoder, webp.go:27-48
+        d->kind = Decoder::WEBP;
+        d->webp = webp_decoder_create(mat);
+        if (!d->webp) { opencv_mat_release(mat); delete d; return LILLIPUT_ERR_INVALID_IMAGE; }
+        *out = d;
+        return LILLIPUT_OK;
+    }
     if (len >= 6 && (memcmp(b, "GIF87a", 6) == 0 || memcmp(b, "GIF89a", 6) == 0)) { // isGIF, lilliput.go:100-102
         d->kind = Decoder::GIF;
         d->gif = giflib_decoder_create(mat);
@@ -355,6 +385,7 @@ void lilliput_decoder_close(lilliput_decoder dd)
     auto d = static_cast<Decoder*>(dd);
     if (!d) return;
     if (d->gif) giflib_decoder_release(d->gif);
+    if (d->webp) webp_decoder_release(d->webp);
     if (d->dec) opencv_decoder_release(d->dec);
     opencv_mat_release(d->mat);
     delete d;
@@ -377,13 +408,14 @@ int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* p
 const char* lilliput_decoder_description(lilliput_decoder dd)
 {
     auto d = static_cast<Decoder*>(dd);
-    return d->kind == Decoder::GIF ? "GIF" : opencv_decoder_get_description(d->dec); // giflib.go:107-109
+    return d->kind == Decoder::GIF ? "GIF" : d->kind == Decoder::WEBP ? "WEBP" : opencv_decoder_get_description(d->dec); // giflib.go:107-109, webp.go:67-69
 }
 
 int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712; gifDecoder.ICC is empty (giflib.go:122-124)
 {
     auto d = static_cast<Decoder*>(dd);
     if (!d || !dst || d->kind == Decoder::GIF) return 0;
+    if (d->kind == Decoder::WEBP) return (int)webp_decoder_get_icc(d->webp, dst, cap); // webp.go:99-103
     const char* desc = opencv_decoder_get_description(d->dec);
     if (desc && strcmp(desc, "JPEG") == 0) return opencv_decoder_get_jpeg_icc((void*)d->buf, d->len, dst, cap);
     if (desc && strcmp(desc, "PNG") == 0) return opencv_decoder_get_png_icc((void*)d->buf, d->len, dst, cap);
@@ -394,6 +426,13 @@ int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDe
 int lilliput_decoder_animation_info(lilliput_decoder dd, int out[4])
 {
     auto d = static_cast<Decoder*>(dd);
+    if (d && d->kind == Decoder::WEBP) { // webp.go:71-73, 105-111: Duration, BackgroundColor, LoopCount
+        out[0] = (int)webp_decoder_get_loop_count(d->webp);
+        out[1] = webp_decoder_get_num_frames(d->webp);
+        out[2] = webp_decoder_get_total_duration(d->webp);
+        out[3] = (int)webp_decoder_get_bg_color(d->webp);
+        return LILLIPUT_OK;
+    }
     if (!d || d->kind != Decoder::GIF) return LILLIPUT_ERR_UNSUPPORTED;
     Header h;
     (void)decoder_header(d, &h);
@@ -462,7 +501,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
     std::string ext = lower(opt->file_type);
-    if (ext == ".webp" || ext == ".avif" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
+    if (ext == ".avif" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
     Encoder enc;
     enc.dst_buf = (uint8_t*)dst;
     enc.dst_cap = dst_cap;
@@ -471,6 +510,18 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         enc.kind = Encoder::GIF;
         enc.gif = giflib_encoder_create(dst, dst_cap);
         if (!enc.gif) return LILLIPUT_ERR_BUF_TOO_SMALL;
+    } else if (ext == ".webp") { // newWebpEncoder, webp.go:174-212: the source's ICC profile (when its header is sane), background colour and loop count
+        enc.kind = Encoder::WEBP;
+        static thread_local std::vector<uint8_t> icc(32768); // ICCProfileBufferSize
+        int icc_len = lilliput_decoder_icc(dd, icc.data(), icc.size());
+        // ICCHeaderIsSane (opencv.go:784-789 -> color_info.cpp:70-79): a full 128-byte header whose size field equals the blob's length
+        if (icc_len < 128 || ((uint32_t)icc[0] << 24 | (uint32_t)icc[1] << 16 | (uint32_t)icc[2] << 8 | icc[3]) != (uint32_t)icc_len) icc_len = 0;
+        uint32_t bg = 0xFFFFFFFFu; // openCVDecoder.BackgroundColor (opencv.go:665-667) and gifDecoder's (giflib.go:161-178)
+        int loops = 0;
+        if (d->kind == Decoder::WEBP) { bg = webp_decoder_get_bg_color(d->webp); loops = (int)webp_decoder_get_loop_count(d->webp); }
+        else if (d->kind == Decoder::GIF) { int ai[4]; (void)lilliput_decoder_animation_info(dd, ai); bg = (uint32_t)ai[3]; loops = ai[0]; }
+        enc.webp = webp_encoder_create(dst, dst_cap, icc_len ? icc.data() : nullptr, (size_t)icc_len, bg, loops);
+        if (!enc.webp) return LILLIPUT_ERR_BUF_TOO_SMALL;
     } else if (ext == ".thumbhash") { // newThumbhashEncoder, thumbhash.go:21-32
         enc.kind = Encoder::THUMBHASH;
         enc.th = thumbhash_encoder_create(dst, dst_cap);
@@ -486,7 +537,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         enc.enc = opencv_encoder_create(opt->file_type, enc.dst);
         if (!enc.enc) { opencv_mat_release(enc.dst); return LILLIPUT_ERR_INVALID_IMAGE; }
     }
-    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); if (e.gif) giflib_encoder_release(e.gif); if (e.th) thumbhash_encoder_release(e.th); } } guard{enc};
+    struct Guard { Encoder& e; ~Guard() { if (e.enc) opencv_encoder_release(e.enc); if (e.dst) opencv_mat_release(e.dst); if (e.gif) giflib_encoder_release(e.gif); if (e.th) thumbhash_encoder_release(e.th); if (e.webp) webp_encoder_release(e.webp); } } guard{enc};
     // newOpenCVEncoder asks the decoder for its ICC profile on every Transform (opencv.go:863); the JPEG writer then drops it
     // (cv::imencode has no ICC channel), so the read is kept for its cost profile only.
     if (enc.kind == Encoder::OPENCV) {
@@ -515,6 +566,19 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
             const int len = thumbhash_encoder_encode(enc.th, f->mat);
             if (len <= 0) return LILLIPUT_ERR_INVALID_IMAGE;
             *n = (size_t)len;
+            return LILLIPUT_OK;
+        }
+        if (enc.kind == Encoder::WEBP) { // webpEncoder.Encode, webp.go:214-256
+            if (enc.flushed) return LILLIPUT_ERR_EOF;
+            if (!f) {
+                const size_t len = webp_encoder_flush(enc.webp);
+                if (!len) return LILLIPUT_ERR_INVALID_IMAGE;
+                enc.flushed = true;
+                *n = len;
+                return LILLIPUT_OK;
+            }
+            const int delay_ms = (int)(f->duration / 1000000ll);
+            if (!webp_encoder_write(enc.webp, f->mat, opt->encode_options, opt->encode_options_len, delay_ms, f->blend, f->dispose, 0, 0)) return LILLIPUT_ERR_INVALID_IMAGE;
             return LILLIPUT_OK;
         }
         if (enc.kind == Encoder::GIF) { // gifEncoder.Encode, giflib.go:259-292

@@ -268,6 +268,90 @@ def ref_gif_transcode(data, frame_fn, cap=64 << 20, max_frames=1 << 30):
     return res
 
 
+_refwebp = None
+
+
+def ref_webp():
+    """libwebp 1.5.0 + libwebpmux + libwebpdemux of the reference driven like webp.cpp (oracle/ref_webp_driver.c), or None."""
+    global _refwebp
+    if _refwebp is None:
+        _refwebp = _load(os.path.join("_ref", "librefwebp.so"))
+        if _refwebp is not None:
+            L = _refwebp
+            L.ref_webp_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+            L.ref_webp_icc.restype = C.c_size_t
+            L.ref_webp_icc.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.ref_webp_decode_frame.restype = C.c_long
+            L.ref_webp_decode_frame.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+            L.ref_webp_encode_still.restype = C.c_size_t
+            L.ref_webp_encode_still.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.ref_webp_play.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint32)]
+    return _refwebp
+
+
+def ref_webp_info(data):
+    """What webp_decoder_create + the getters report, from the reference's libwebpmux: dict, or None when creation fails."""
+    out = (C.c_uint32 * 8)()
+    if not ref_webp().ref_webp_info(bytes(data), len(data), out):
+        return None
+    keys = ("width", "height", "has_alpha", "num_frames", "total_duration", "bgcolor", "loop_count", "icc_len")
+    return dict(zip(keys, [int(v) for v in out]))
+
+
+def ref_webp_icc(data, cap=1 << 20):
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = ref_webp().ref_webp_icc(bytes(data), len(data), buf.ctypes.data, cap)
+    return buf[:n].tobytes()
+
+
+def ref_webp_frames(data):
+    """Every frame as webp_decoder_decode yields it (the reference's libwebp): [(HxWxC array, meta dict)] or None."""
+    info = ref_webp_info(data)
+    if info is None:
+        return None
+    frames = []
+    cap = info["width"] * info["height"] * 4 + 16
+    for k in range(1, info["num_frames"] + 1):
+        buf = np.zeros(cap, dtype=np.uint8)
+        meta = (C.c_int * 8)()
+        n = ref_webp().ref_webp_decode_frame(bytes(data), len(data), k, buf.ctypes.data, cap, meta)
+        if n < 0:
+            frames.append(None)
+            continue
+        w, h, cn = meta[0], meta[1], meta[2]
+        frames.append((buf[:n].reshape(h, w, cn).copy(), {"duration": meta[3], "x_offset": meta[4], "y_offset": meta[5], "dispose": meta[6], "blend": meta[7]}))
+    return frames
+
+
+def ref_webp_encode_still(px, quality, icc=b""):
+    """The reference's still-image writer (WebPEncode(Lossless)BGR(A) + WebPMuxSetImage + ICCP) on a HxWx3/4 frame."""
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    h, w, cn = px.shape
+    cap = w * h * 8 + len(icc) + 65536
+    out = np.zeros(cap, dtype=np.uint8)
+    n = ref_webp().ref_webp_encode_still(px.ctypes.data, w, h, cn, float(quality), bytes(icc), len(icc), out.ctypes.data, cap)
+    return out[:n].tobytes()
+
+
+def ref_webp_play(data, max_frames=4096):
+    """Any WebP file played back by libwebpdemux's WebPAnimDecoder: (canvases [n, H, W, 4] BGRA, end timestamps, loop_count, bgcolor)
+    or None. This is how a viewer sees the file -- used to read the product's own animated output back."""
+    data = bytes(data)
+    info = ref_webp_info(data)
+    if info is None:
+        return None
+    n_max = min(max_frames, info["num_frames"])
+    cap = info["width"] * info["height"] * 4 * n_max
+    out = np.zeros(max(cap, 4), dtype=np.uint8)
+    w, h = C.c_int(), C.c_int()
+    ts = (C.c_int * n_max)()
+    ai = (C.c_uint32 * 2)()
+    n = ref_webp().ref_webp_play(data, len(data), out.ctypes.data, cap, C.byref(w), C.byref(h), ts, n_max, ai)
+    if n <= 0:
+        return None
+    return out[: n * w.value * h.value * 4].reshape(n, h.value, w.value, 4).copy(), list(ts)[:n], int(ai[0]), int(ai[1])
+
+
 def _buf(data):
     arr = np.frombuffer(bytes(data), dtype=np.uint8)
     return arr, arr.ctypes.data_as(_u8p)
