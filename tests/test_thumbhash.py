@@ -1,7 +1,8 @@
 """The reference's own ThumbHash known answers (/root/reference/thumbhash_test.go:63-81), reproduced END TO END through the product:
-NewDecoder -> ImageOps.Transform(FileType ".thumbhash", NoResize, NormalizeOrientation) -- device decode (JPEG / PNG), device
+NewDecoder -> ImageOps.Transform(FileType ".thumbhash", NoResize, NormalizeOrientation) -- device decode (JPEG / PNG; WebP payload on the host), device
 orientation, samples gathered on the device, hash in the reference's float order."""
 import base64
+import os
 
 import pytest
 
@@ -18,6 +19,10 @@ def test_reference_thumbhash_known_answers_through_the_product(golden, fixture_b
     sources = {n: fixture_bytes[n] for n in want}
     want.update(PNG_HASHES)
     sources.update({n: png_cases.fixtures()[n] for n in PNG_HASHES})
+    # thumbhash_test.go:78: the one WebP fixture (grey + alpha, lossless) -- container walk + libwebp decode + BGRA on the device
+    want["firefox-gray-alpha.webp"] = "4AeKBQA7oFl7lqhmaDBp92yJJ1h2iHB2Rw=="
+    sources["firefox-gray-alpha.webp"] = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs_webp", "firefox-gray-alpha.webp"), "rb").read()
+    assert len(want) == 15  # every known answer of thumbhash_test.go:63-81
     ops = la.ImageOps(4096)
     for name, data in sources.items():
         d = la.Decoder(data)
