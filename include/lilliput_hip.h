@@ -230,6 +230,21 @@ size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, 
 void webp_encoder_release(webp_encoder e);
 size_t webp_encoder_flush(webp_encoder e);
 
+/* ------------------------------------------------------------------------------------------------
+ * Part A4 -- the reference's color_info.hpp C ABI (color_info.hpp:24-106; Go callers: opencv.go:281-290, 730-812, ops.go:154-165,
+ * 489-538). The tone map (PQ / HLG -> linear light -> Reinhard -> BT.709 primaries -> 8 bit) runs on the device; the ICC profiles
+ * cicp_get_icc_profile hands out are derived from the standards' chromaticities at first use (ICC v4.2 matrix/TRC), not embedded blobs.
+ * ---------------------------------------------------------------------------------------------- */
+bool is_hdr_transfer_function(const uint8_t* icc_data, size_t icc_len);            /* color_info.cpp:17-36: ICC 'cicp' tag names PQ or HLG */
+bool cicp_is_hdr_transfer(uint8_t transfer);                                       /* color_info.cpp:38-41 */
+const uint8_t* cicp_get_icc_profile(uint8_t primaries, size_t* profile_size);      /* color_info.cpp:43-68 */
+bool icc_header_is_sane(const uint8_t* icc, size_t icc_len);                       /* color_info.cpp:70-79 */
+void tonemap_rgb_to_sdr(const uint16_t* src, uint8_t* dst, int width, int height, int src_depth, uint8_t transfer, uint8_t primaries); /* :112-204 */
+void tonemap_rgb_8u_inplace(uint8_t* pixels, int width, int height, int channels, uint8_t transfer, uint8_t primaries);                /* :206-236 */
+const uint8_t* lilliput_hip_srgb_icc_profile(size_t* profile_size);                /* lilliput.go:18-22 SRGBICCProfile */
+/* Framebuffer.TonemapToSDR (opencv.go:794-812) on a Mat whose pixels are resident on the device. 0 = done (or not a 3/4-channel 8-bit Mat). */
+int lilliput_hip_mat_tonemap(opencv_mat mat, uint8_t transfer, uint8_t primaries);
+
 /* Test access: the host half of decode_frame for the frame whose header was just read (no device work).
  * meta = {left, top, width, height, interlace, disposal, delay, transparent, color_count, has_local_map}; returns the
  * number of indices written, -1 on a decode error, -2 when cap is too small. */

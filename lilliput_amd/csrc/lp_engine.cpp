@@ -976,6 +976,91 @@ int LpEngine::png_filter(const LpFrame& src, uint32_t filters, uint8_t* out)
     return check(hipGetLastError(), "png filter kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
+int LpEngine::tonemap(const LpFrame& f, int transfer, int primaries, const uint16_t* d_src16, int depth)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    if (f.cn != 3 && f.cn != 4) { err_ = "tone map: 3 or 4 channels"; return LP_ERR_INVALID_IMAGE; }
+    const size_t npix = (size_t)f.w * f.h;
+    if (!npix) return LP_OK;
+    const size_t stats_bytes = (size_t)LP_TONE_MAX_WG * LP_TONE_STATS * sizeof(double);
+    if (!d_packed_.ensure(npix * 3 * sizeof(float) + stats_bytes)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    LpToneOp op;
+    memset(&op, 0, sizeof(op));
+    op.f = f;
+    op.stats = (uint64_t)(uintptr_t)d_packed_.p;
+    op.img = op.stats + stats_bytes;
+    op.transfer = transfer; op.primaries = primaries;
+    op.src16 = (uint64_t)(uintptr_t)d_src16; op.depth = (uint32_t)depth;
+    std::vector<double> part((size_t)LP_TONE_MAX_WG * LP_TONE_STATS);
+    double mn = 0, mx = 0, sum[5];
+    // one pass + the fold of its per-workgroup partials
+    auto run = [&](int pass) -> bool {
+        uint32_t nwg = 0;
+        lp_launch_tonemap(stream_, op, pass, &nwg);
+        if (pass == 3) return check(hipStreamSynchronize(stream_), "tone map sync") && check(hipGetLastError(), "tone map kernels");
+        if (!check(hipMemcpyAsync(part.data(), d_packed_.p, (size_t)nwg * LP_TONE_STATS * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H tone stats")) return false;
+        if (!check(hipStreamSynchronize(stream_), "tone map sync") || !check(hipGetLastError(), "tone map kernels")) return false;
+        mn = part[0]; mx = part[1];
+        for (int k = 0; k < 5; k++) sum[k] = 0;
+        for (uint32_t w = 0; w < nwg; w++) {
+            const double* q = &part[(size_t)w * LP_TONE_STATS];
+            mn = std::min(mn, q[0]); mx = std::max(mx, q[1]);
+            for (int k = 0; k < 5; k++) sum[k] += q[2 + k];
+        }
+        return true;
+    };
+    // cv::Tonemap's linear map: (v - min) / (max - min) as convertTo(alpha, beta); identity when the image is flat
+    auto normalise = [&]() {
+        if (mx - mn > DBL_EPSILON) { op.a = (float)(1.0 / (mx - mn)); op.b = (float)(-mn / (mx - mn)); }
+        else { op.a = 1.0f; op.b = 0.0f; }
+    };
+    if (!run(0)) return LP_ERR_DEVICE;
+    normalise();
+    if (!run(1)) return LP_ERR_DEVICE;
+    {   // cv::TonemapReinhard::process: key of the log-luminance histogram, global adaptation levels
+        const float color_adapt = 0.3f;
+        const double n = (double)npix;
+        const float log_mean = (float)(sum[0] / n);
+        const double key = (float)((mx - log_mean) / (mx - mn));
+        op.map_key = 0.3f + 0.7f * powf((float)key, 1.4f);
+        op.intensity = expf(-0.6f);
+        const float gray_mean = (float)(sum[1] / n);
+        for (int c = 0; c < 3; c++) op.glob[c] = color_adapt * (float)(sum[2 + c] / n) + (1.0f - color_adapt) * gray_mean;
+    }
+    if (!run(2)) return LP_ERR_DEVICE;
+    normalise();
+    return run(3) ? LP_OK : LP_ERR_DEVICE;
+}
+
+int LpEngine::tonemap_host8(uint8_t* pixels, int w, int h, int cn, int transfer, int primaries)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t bytes = (size_t)w * h * cn;
+    if (!d_tone_.ensure(bytes)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    if (!check(hipMemcpyAsync(d_tone_.p, pixels, bytes, hipMemcpyHostToDevice, stream_), "H2D tone map")) return LP_ERR_DEVICE;
+    LpFrame f;
+    f.off = (uint64_t)(uintptr_t)d_tone_.p; f.w = (uint32_t)w; f.h = (uint32_t)h; f.stride = (uint32_t)(w * cn); f.cn = (uint32_t)cn;
+    if (int rc = tonemap(f, transfer, primaries)) return rc;
+    if (!check(hipMemcpyAsync(pixels, d_tone_.p, bytes, hipMemcpyDeviceToHost, stream_), "D2H tone map")) return LP_ERR_DEVICE;
+    return check(hipStreamSynchronize(stream_), "tone map sync") ? LP_OK : LP_ERR_DEVICE;
+}
+
+int LpEngine::tonemap_host(const uint16_t* src, uint8_t* dst, int w, int h, int depth, int transfer, int primaries)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t n = (size_t)w * h * 3, dst_off = (n * 2 + 255) & ~(size_t)255;
+    if (!d_tone_.ensure(dst_off + n)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    if (!check(hipMemcpyAsync(d_tone_.p, src, n * 2, hipMemcpyHostToDevice, stream_), "H2D tone map")) return LP_ERR_DEVICE;
+    LpFrame f;
+    f.off = (uint64_t)(uintptr_t)d_tone_.p + dst_off; f.w = (uint32_t)w; f.h = (uint32_t)h; f.stride = (uint32_t)(w * 3); f.cn = 3;
+    if (int rc = tonemap(f, transfer, primaries, d_tone_.as<uint16_t>(), depth)) return rc;
+    if (!check(hipMemcpyAsync(dst, d_tone_.as<uint8_t>() + dst_off, n, hipMemcpyDeviceToHost, stream_), "D2H tone map")) return LP_ERR_DEVICE;
+    return check(hipStreamSynchronize(stream_), "tone map sync") ? LP_OK : LP_ERR_DEVICE;
+}
+
 int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indices, const uint8_t* palette_bgra)
 {
     if (!ok_) return LP_ERR_DEVICE;

@@ -169,6 +169,11 @@ public:
     int png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra);
     // PNG output: libpng's per-row filter choice + filtering on the device; `out` receives h * (1 + w * cn) bytes (host memory).
     int png_filter(const LpFrame& src, uint32_t filters, uint8_t* out);
+    // HDR -> SDR tone map in place (color_info.cpp:206-236 tonemap_rgb_8u_inplace): 3- or 4-channel 8-bit frame, cICP code points
+    int tonemap(const LpFrame& f, int transfer, int primaries, const uint16_t* d_src16 = nullptr, int depth = 8);
+    // the same for host buffers (the reference's own signatures): tightly packed 8-bit pixels in place; 16-bit samples -> 8-bit
+    int tonemap_host8(uint8_t* pixels, int w, int h, int cn, int transfer, int primaries);
+    int tonemap_host(const uint16_t* src, uint8_t* dst, int w, int h, int depth, int transfer, int primaries);
     // ThumbHash: out[(i * w + j) * cn ..] = frame(idx[w + i], idx[j]) for a w x h lattice of sample coordinates (host memory in and out).
     int gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out);
     int sync();
@@ -225,6 +230,7 @@ private:
 
     // resize / orient
     LpDevBuf d_ops_, d_taps_, d_ranges_, d_fops_;
+    LpDevBuf d_tone_;           // staging for the host-pointer tone-map entry points
     // encode
     std::vector<LpEncJob> h_jobs_;
     LpDevBuf d_jobs_, d_estates_, d_ecoef_, d_blkbits_, d_bits_, d_hdrs_, d_out_, d_packed_, d_pkoff_;

@@ -8,6 +8,7 @@
 // Byte/integer work, HBM-bound: no MFMA. Float taps use explicit non-fused mul/add to follow OpenCV's
 // accumulation order.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "lp_launch.h"
@@ -1130,4 +1131,167 @@ void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* 
     if (!op.w || !op.h) return;
     dim3 g((op.w + 63) / 64, (op.h + 3) / 4, 1);
     hipLaunchKernelGGL(k_composite, g, dim3(64, 4), 0, s, op, d_src, d_dst);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// HDR -> SDR (color_info.cpp:80-236). PQ / HLG inverse transfer functions and the primaries matrices are the reference's own; the
+// tone curve is cv::TonemapReinhard(gamma 1, intensity 0.6, light_adapt 0.2, color_adapt 0.3) as the reference configures it. The
+// operator needs three global reductions (range of the linear image; log-luminance and channel statistics of the normalised image;
+// range of the mapped image), so it runs as four grid-stride passes with per-workgroup partials folded on the host in between.
+// One thread per pixel, 12 bytes of float state per pixel: HBM bound (8 B read + 12 B written in pass 0, 24 B in passes 1-2, 15 B in
+// pass 3).
+__device__ __forceinline__ float tone_pq(float x)
+{
+    const float m1 = 0.1593017578125f, m2 = 78.84375f, c1 = 0.8359375f, c2 = 18.8515625f, c3 = 18.6875f;
+    const float xp = powf(x, 1.0f / m2);
+    const float num = fmaxf(xp - c1, 0.0f), den = c2 - c3 * xp;
+    return powf(num / den, 1.0f / m1);
+}
+__device__ __forceinline__ float tone_hlg(float x)
+{
+    const float a = 0.17883277f, b = 0.28466892f, c = 0.55991073f;
+    return x <= 0.5f ? x * x / 3.0f : (expf((x - c) / a) + b) / 12.0f;
+}
+__device__ __forceinline__ float tone_gray(float c0, float c1, float c2) { return c0 * 0.299f + c1 * 0.587f + c2 * 0.114f; } // COLOR_RGB2GRAY, 32F
+
+__device__ __forceinline__ void tone_reduce(double mn, double mx, const double (&sum)[5], double* __restrict__ out)
+{
+    constexpr int NS = 5;
+    __shared__ double s_part[4][2 + NS];
+    for (int o = 32; o; o >>= 1) {
+        mn = fmin(mn, __shfl_down(mn, o));
+        mx = fmax(mx, __shfl_down(mx, o));
+    }
+    double acc[NS];
+    for (int k = 0; k < NS; k++) {
+        acc[k] = sum[k];
+        for (int o = 32; o; o >>= 1) acc[k] += __shfl_down(acc[k], o);
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_part[wave][0] = mn; s_part[wave][1] = mx;
+        for (int k = 0; k < NS; k++) s_part[wave][2 + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = out + (size_t)blockIdx.x * LP_TONE_STATS;
+        for (int w = 1; w < 4; w++) {
+            s_part[0][0] = fmin(s_part[0][0], s_part[w][0]);
+            s_part[0][1] = fmax(s_part[0][1], s_part[w][1]);
+            for (int k = 0; k < NS; k++) s_part[0][2 + k] += s_part[w][2 + k];
+        }
+        o[0] = s_part[0][0]; o[1] = s_part[0][1];
+        for (int k = 0; k < NS; k++) o[2 + k] = s_part[0][2 + k];
+    }
+}
+
+// pass 0: bytes -> linear light, range
+__global__ __launch_bounds__(256) void k_tone_linearize(LpToneOp op)
+{
+    const LpFrame& f = op.f;
+    const uint32_t npix = f.w * f.h;
+    float* __restrict__ img = reinterpret_cast<float*>(op.img);
+    const uint16_t* __restrict__ src16 = reinterpret_cast<const uint16_t*>(op.src16);
+    const float scale = 1.0f / (float)((1u << (src16 ? op.depth : 8u)) - 1u);
+    double mn = INFINITY, mx = -INFINITY;
+    const double none[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(f.off) + (size_t)(i / f.w) * f.stride + (size_t)(i % f.w) * f.cn;
+        for (int c = 0; c < 3; c++) {
+            float v = (src16 ? (float)src16[(size_t)i * 3 + c] : (float)p[c]) * scale;
+            if (op.transfer == 16) v = tone_pq(v);
+            else if (op.transfer == 18) v = tone_hlg(v);
+            img[(size_t)i * 3 + c] = v;
+            mn = fmin(mn, (double)v); mx = fmax(mx, (double)v);
+        }
+    }
+    tone_reduce(mn, mx, none, reinterpret_cast<double*>(op.stats));
+}
+
+// pass 1: normalise to [0, 1]; log-luminance range and sum, gray sum, channel sums
+__global__ __launch_bounds__(256) void k_tone_stats(LpToneOp op)
+{
+    const uint32_t npix = op.f.w * op.f.h;
+    float* __restrict__ img = reinterpret_cast<float*>(op.img);
+    double mn = INFINITY, mx = -INFINITY, sum[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        float c[3];
+        for (int k = 0; k < 3; k++) {
+            c[k] = fmaf(img[(size_t)i * 3 + k], op.a, op.b);
+            img[(size_t)i * 3 + k] = c[k];
+            sum[2 + k] += c[k];
+        }
+        const float g = tone_gray(c[0], c[1], c[2]);
+        const float lg = logf(fmaxf(g, 1e-4f));
+        sum[0] += lg; sum[1] += g;
+        mn = fmin(mn, (double)lg); mx = fmax(mx, (double)lg);
+    }
+    tone_reduce(mn, mx, sum, reinterpret_cast<double*>(op.stats));
+}
+
+// pass 2: the Reinhard curve per channel; range of the result
+__global__ __launch_bounds__(256) void k_tone_map(LpToneOp op)
+{
+    const uint32_t npix = op.f.w * op.f.h;
+    float* __restrict__ img = reinterpret_cast<float*>(op.img);
+    const float light_adapt = 0.2f, color_adapt = 0.3f;
+    double mn = INFINITY, mx = -INFINITY;
+    const double none[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        float c[3];
+        for (int k = 0; k < 3; k++) c[k] = img[(size_t)i * 3 + k];
+        const float g = tone_gray(c[0], c[1], c[2]);
+        for (int k = 0; k < 3; k++) {
+            float adapt = color_adapt * c[k] + (1.0f - color_adapt) * g;
+            adapt = light_adapt * adapt + (1.0f - light_adapt) * op.glob[k];
+            adapt = powf(op.intensity * adapt, op.map_key);
+            const float v = c[k] * (1.0f / (adapt + c[k]));
+            img[(size_t)i * 3 + k] = v;
+            mn = fmin(mn, (double)v); mx = fmax(mx, (double)v);
+        }
+    }
+    tone_reduce(mn, mx, none, reinterpret_cast<double*>(op.stats));
+}
+
+__constant__ float c_tone_matrix[4][9] = {
+    {1.6605f, -0.5876f, -0.0728f, -0.1246f, 1.1329f, -0.0083f, -0.0182f, -0.1006f, 1.1187f},                    // BT.2020 -> BT.709
+    {1.2249f, -0.2247f, -0.0002f, -0.0420f, 1.0419f, 0.0001f, -0.0197f, 0.0754f, 0.9443f},                      // P3 -> BT.709
+    {1.0440f, -0.0440f, 0.0000f, -0.0000f, 1.0000f, 0.0000f, 0.0000f, 0.0000f, 1.0000f},                        // BT.601 -> BT.709
+    {1.0569715f, -0.2039770f, 0.0556301f, 0.0415551f, 1.8759675f, -0.9692436f, -0.4986108f, -1.5373832f, 3.2409699f}, // XYZ -> BT.709
+};
+
+// pass 3: normalise, primaries, (gamma for linear-light input), back to bytes
+__global__ __launch_bounds__(256) void k_tone_final(LpToneOp op)
+{
+    const LpFrame& f = op.f;
+    const uint32_t npix = f.w * f.h;
+    const float* __restrict__ img = reinterpret_cast<const float*>(op.img);
+    const int mi = op.primaries == 9 ? 0 : (op.primaries == 11 || op.primaries == 12) ? 1 : op.primaries == 6 ? 2 : op.primaries == 10 ? 3 : -1;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        uint8_t* p = reinterpret_cast<uint8_t*>(f.off) + (size_t)(i / f.w) * f.stride + (size_t)(i % f.w) * f.cn;
+        float v[3], o[3];
+        for (int k = 0; k < 3; k++) v[k] = fmaf(img[(size_t)i * 3 + k], op.a, op.b);
+        for (int j = 0; j < 3; j++)
+            o[j] = mi < 0 ? v[j] : c_tone_matrix[mi][j * 3] * v[0] + c_tone_matrix[mi][j * 3 + 1] * v[1] + c_tone_matrix[mi][j * 3 + 2] * v[2];
+        for (int j = 0; j < 3; j++) {
+            float t = o[j];
+            if (op.transfer == 8) t = powf(t, 1.0f / 2.2f);
+            t *= 255.0f;
+            p[j] = t == t ? (uint8_t)fminf(fmaxf(rintf(t), 0.0f), 255.0f) : (uint8_t)0; // saturate_cast<uchar>(cvRound(t))
+        }
+    }
+}
+
+void lp_launch_tonemap(hipStream_t s, const LpToneOp& op, int pass, uint32_t* n_wg)
+{
+    const uint64_t npix = (uint64_t)op.f.w * op.f.h;
+    const uint32_t g = (uint32_t)std::min<uint64_t>(LP_TONE_MAX_WG, (npix + 255) / 256);
+    if (n_wg) *n_wg = g;
+    if (!g) return;
+    switch (pass) {
+    case 0: hipLaunchKernelGGL(k_tone_linearize, dim3(g), dim3(256), 0, s, op); break;
+    case 1: hipLaunchKernelGGL(k_tone_stats, dim3(g), dim3(256), 0, s, op); break;
+    case 2: hipLaunchKernelGGL(k_tone_map, dim3(g), dim3(256), 0, s, op); break;
+    default: hipLaunchKernelGGL(k_tone_final, dim3(g), dim3(256), 0, s, op); break;
+    }
 }

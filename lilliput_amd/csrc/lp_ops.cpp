@@ -483,24 +483,39 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     Header hdr;
     int e = decoder_header(d, &hdr);
     if (e) return e;
-    // Container-signalled colour (ops.go:500-541): an HDR transfer function in a PNG's cICP chunk makes the reference tone-map
-    // every decoded frame (color_info.cpp). That kernel is not built: refuse rather than return un-mapped pixels.
+    // ICC override for HDR -> SDR (ops.go:489-498): ForceSdr + a source profile whose 'cicp' tag names PQ / HLG -> tag the output sRGB
+    const uint8_t* icc_override = nullptr;
+    size_t icc_override_len = 0;
+    static thread_local std::vector<uint8_t> icc(32768); // ICCProfileBufferSize, lilliput.go:13-16
+    if (opt->force_sdr) {
+        const int n = lilliput_decoder_icc(dd, icc.data(), icc.size());
+        if (n > 0 && is_hdr_transfer_function(icc.data(), (size_t)n)) icc_override = lilliput_hip_srgb_icc_profile(&icc_override_len);
+    }
+    // Container-signalled colour (ops.go:500-541): a PNG's cICP chunk. An HDR transfer function (PQ, HLG) makes every decoded frame
+    // go through the tone map right after decode (ops.go:154-165); an SDR cICP is signalling only: it is carried over to a PNG output
+    // (applyOutputCICP ops.go:306-333) and, for the outputs that embed a profile, replaces the source's ICC by one for its primaries.
     uint8_t out_cicp[4] = {0, 0, 0, 0};
-    bool have_out_cicp = false;
+    bool have_out_cicp = false, tonemap = false;
+    uint8_t tm_transfer = 0, tm_primaries = 0;
+    std::string ext = lower(opt->file_type);
     if (d->kind == Decoder::OPENCV) {
         const char* desc = opencv_decoder_get_description(d->dec);
         uint8_t prim = 0, transfer = 0, matrix = 0, range = 0;
-        if (desc && strcmp(desc, "PNG") == 0 && d->len && opencv_decoder_get_png_cicp((void*)d->buf, d->len, &prim, &transfer, &matrix, &range) &&
-            (transfer == 16 || transfer == 18)) // cicp_is_hdr_transfer: SMPTE ST 2084 (PQ), ARIB STD-B67 (HLG)
-            return LILLIPUT_ERR_UNSUPPORTED;
-        // an SDR cICP is signalling only: it is carried over to a PNG output (ops.go:511-517, applyOutputCICP ops.go:306-333)
         if (desc && strcmp(desc, "PNG") == 0 && d->len && opencv_decoder_get_png_cicp((void*)d->buf, d->len, &prim, &transfer, &matrix, &range)) {
-            out_cicp[0] = prim; out_cicp[1] = transfer; out_cicp[2] = matrix; out_cicp[3] = range;
-            have_out_cicp = true;
+            if (cicp_is_hdr_transfer(transfer)) {
+                tonemap = true; tm_transfer = transfer; tm_primaries = prim;
+            } else {
+                out_cicp[0] = prim; out_cicp[1] = transfer; out_cicp[2] = matrix; out_cicp[3] = range;
+                have_out_cicp = true;
+                if (ext == ".webp" || ext == ".avif") { // outputTagsICC, ops.go:297-304
+                    size_t n = 0;
+                    const uint8_t* syn = cicp_get_icc_profile(prim, &n);
+                    if (icc_header_is_sane(syn, n)) { icc_override = syn; icc_override_len = n; }
+                }
+            }
         }
     }
     // NewEncoder (lilliput.go:180-202) -> newOpenCVEncoder (opencv.go:847-870)
-    std::string ext = lower(opt->file_type);
     if (ext == ".avif" || ext == ".mp4" || ext == ".webm") return LILLIPUT_ERR_UNSUPPORTED;
     Encoder enc;
     enc.dst_buf = (uint8_t*)dst;
@@ -512,10 +527,15 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         if (!enc.gif) return LILLIPUT_ERR_BUF_TOO_SMALL;
     } else if (ext == ".webp") { // newWebpEncoder, webp.go:174-212: the source's ICC profile (when its header is sane), background colour and loop count
         enc.kind = Encoder::WEBP;
-        static thread_local std::vector<uint8_t> icc(32768); // ICCProfileBufferSize
-        int icc_len = lilliput_decoder_icc(dd, icc.data(), icc.size());
-        // ICCHeaderIsSane (opencv.go:784-789 -> color_info.cpp:70-79): a full 128-byte header whose size field equals the blob's length
-        if (icc_len < 128 || ((uint32_t)icc[0] << 24 | (uint32_t)icc[1] << 16 | (uint32_t)icc[2] << 8 | icc[3]) != (uint32_t)icc_len) icc_len = 0;
+        int icc_len;
+        if (icc_override_len) { // EncodeConfig.ICCOverride, webp.go:181-185
+            icc_len = (int)std::min(icc_override_len, icc.size());
+            memcpy(icc.data(), icc_override, (size_t)icc_len);
+        } else {
+            icc_len = lilliput_decoder_icc(dd, icc.data(), icc.size());
+        }
+        if (icc_len > 0 && !icc_header_is_sane(icc.data(), (size_t)icc_len)) icc_len = 0; // ICCHeaderIsSane, webp.go:192-194
+        if (icc_len < 0) icc_len = 0;
         uint32_t bg = 0xFFFFFFFFu; // openCVDecoder.BackgroundColor (opencv.go:665-667) and gifDecoder's (giflib.go:161-178)
         int loops = 0;
         if (d->kind == Decoder::WEBP) { bg = webp_decoder_get_bg_color(d->webp); loops = (int)webp_decoder_get_loop_count(d->webp); }
@@ -623,6 +643,8 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
             if (e != LILLIPUT_ERR_EOF) return e;
             empty_frame = true;
         }
+        // ImageOps.decode (ops.go:154-165): HDR pixels become SDR before any resize or composite
+        if (tonemap && !e && lilliput_hip_mat_tonemap(o->active()->mat, tm_transfer, tm_primaries)) return LILLIPUT_ERR_DEVICE;
         duration += o->active()->duration;
         if (opt->max_encode_duration_ns != 0 && duration > opt->max_encode_duration_ns) {
             e = skip_to_end(d);

@@ -274,6 +274,23 @@ struct LpPngEncOp {
     uint32_t pad;
 };
 
+// HDR -> SDR tone map of a decoded 8-bit frame (color_info.cpp:80-236 tonemap_rgb_to_sdr): four passes over a float copy of the
+// three colour channels; the global statistics between the passes (minimum / maximum, log-luminance mean, channel means) come back as
+// per-workgroup partials in `stats` (LP_TONE_STATS doubles each) and are folded on the host, which also derives the next pass's scalars.
+#define LP_TONE_STATS 8         // per workgroup: min, max, sum log, sum gray, sum c0, sum c1, sum c2, -
+#define LP_TONE_MAX_WG 1024
+struct LpToneOp {
+    LpFrame f;                  // 3 or 4 channels; a fourth channel (alpha) is left as it is
+    uint64_t img;               // device address: w * h * 3 floats
+    uint64_t stats;             // device address: LP_TONE_MAX_WG * LP_TONE_STATS doubles
+    int32_t transfer, primaries; // cICP code points
+    float a, b;                 // the pass's normalisation: v * a + b
+    float glob[3];              // Reinhard: per-channel global adaptation level
+    float map_key, intensity;
+    uint32_t depth;             // bits per sample of src16 (tonemap_rgb_to_sdr), unused for an 8-bit frame
+    uint64_t src16;             // device address of w * h * 3 uint16 samples, or 0: pass 0 reads the frame's own bytes
+};
+
 // JPEG encode job (S8-S10): pixels -> baseline 4:2:0 (or grayscale) JFIF stream with Annex-K tables.
 struct LpEncJob {
     LpFrame src;

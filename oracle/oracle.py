@@ -496,6 +496,30 @@ def blend_alpha(src, dst):
     return dst
 
 
+def tonemap_8u(px, transfer, primaries):
+    """tonemap_rgb_8u_inplace (color_info.cpp:206-236) restated (oracle/color_oracle.c; OpenCV's Reinhard operator from upstream: parity
+    unpinned). px: HxWx3/4; returns the tone-mapped copy."""
+    out = np.ascontiguousarray(px, dtype=np.uint8).copy()
+    h, w, cn = out.shape
+    lib().lo_tonemap_8u_inplace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    rc = lib().lo_tonemap_8u_inplace(out.ctypes.data, w, h, cn, int(transfer), int(primaries))
+    if rc:
+        raise ValueError("tonemap rc=%d" % rc)
+    return out
+
+
+def tonemap_16(px, depth, transfer, primaries):
+    """tonemap_rgb_to_sdr (color_info.cpp:112-204) restated: HxWx3 uint16 samples of `depth` bits -> HxWx3 uint8."""
+    src = np.ascontiguousarray(px, dtype=np.uint16)
+    h, w, _ = src.shape
+    out = np.zeros((h, w, 3), np.uint8)
+    lib().lo_tonemap_16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    rc = lib().lo_tonemap_16(src.ctypes.data, out.ctypes.data, w, h, int(depth), int(transfer), int(primaries))
+    if rc:
+        raise ValueError("tonemap rc=%d" % rc)
+    return out
+
+
 def thumbhash(px):
     px = np.ascontiguousarray(px, dtype=np.uint8)
     if px.ndim == 2:
