@@ -280,6 +280,24 @@ void thumbhash_encoder_release(thumbhash_encoder e);
 #define LILLIPUT_OPS_FIT 1
 #define LILLIPUT_OPS_RESIZE 2
 
+/* Hand-over of frames that were decoded outside this library (lilliput.go:136-164 sends AVIF to libavif and MP4 / MOV / WEBM to
+ * libavcodec: AV1 / H.264 / VPx are serial codecs that stay on the host; SURVEY.md section 2 #6 "host decode -> GPU takes over at
+ * BGR(A)"). A source buffer that starts with this header is a decoded frame: the header, then height rows of width * channels bytes
+ * (B, G, R[, A], the layout avcodec_decoder_decode / avif_decoder_decode leave in the framebuffer), stride bytes apart. It is accepted
+ * wherever an encoded source is -- lilliput_new_decoder, every batch / node call -- and goes through the same orientation, Fit / resize
+ * and encode stages on the device; Description() is "PIXELS". */
+#define LILLIPUT_HIP_PIXELS_MAGIC "LPPIXELS"
+typedef struct lilliput_hip_pixels_header {
+    char magic[8];          /* LILLIPUT_HIP_PIXELS_MAGIC */
+    uint32_t width, height;
+    uint32_t channels;      /* 1 (gray), 3 (BGR) or 4 (BGRA) */
+    uint32_t stride;        /* bytes between rows; 0 = width * channels */
+    uint32_t orientation;   /* EXIF orientation 1..8 the decoder reported (avcodec's display matrix, avif's irot / imir) */
+    uint32_t duration_ms;   /* frame duration; 0 for a still */
+} lilliput_hip_pixels_header;
+/* Copy rows of pixels into a Mat of the matching shape (the host side of the hand-over). 0 = ok. */
+int lilliput_hip_mat_set_pixels(opencv_mat mat, const void* pixels, size_t stride);
+
 typedef struct lilliput_batch_item {
     const void* src;    /* encoded source image (caller-owned, like Go's []byte input) */
     size_t src_len;

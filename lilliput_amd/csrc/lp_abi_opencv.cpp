@@ -424,6 +424,20 @@ void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat
     lp_mat_to_host(m, eng);
 }
 
+// The host side of the pixel hand-over (lilliput_hip_pixels_header): rows from a frame decoded elsewhere become the Mat's content;
+// they reach the device with the next opencv_* call, like a WebP frame decoded by libwebp.
+extern "C" int lilliput_hip_mat_set_pixels(opencv_mat mat, const void* pixels, size_t stride)
+{
+    auto m = static_cast<LpMat*>(mat);
+    if (!m || !pixels || !m->data || m->rows <= 0 || m->cols <= 0) return -1;
+    const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
+    if (stride < rowb || (size_t)(m->datalimit - m->data) < m->step * (size_t)(m->rows - 1) + rowb) return -1;
+    for (int y = 0; y < m->rows; y++) memcpy(m->data + (size_t)y * m->step, (const uint8_t*)pixels + (size_t)y * stride, rowb);
+    m->dev_valid = false;
+    m->host_stale = false;
+    return 0;
+}
+
 void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
 {
     auto m = static_cast<LpMat*>(mat);

@@ -10,6 +10,7 @@
 
 #include "lp_huff_core.h"
 #include "lp_prog_core.h"
+#include "lp_unstuff_core.h"
 #include "lp_launch.h"
 #include "lp_types.h"
 
@@ -29,24 +30,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
-// exclusive scan of a packed pair (lo 20 bits / hi 12 bits are enough for 16 B per thread, but we keep two words)
+// exclusive scan of a pair of small counts (a <= 16, b <= 8 per thread: the block totals fit 16 bits each), packed into one word so
+// that the wave scan's cross-lane steps are paid once
 __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t& ea, uint32_t& eb, uint32_t& ta, uint32_t& tb,
-                                                 uint32_t* s_tmp /* >= 8 words */)
+                                                 uint32_t* s_tmp /* >= 4 words */)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
-    if (lane == 63) { s_tmp[wv] = ia; s_tmp[4 + wv] = ib; }
+    const uint32_t v = a | (b << 16);
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) s_tmp[wv] = inc;
     __syncthreads();
-    uint32_t oa = 0, ob = 0;
-    ta = 0; tb = 0;
+    uint32_t o = 0, t = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        uint32_t xa = s_tmp[w], xb = s_tmp[4 + w];
-        if (w < wv) { oa += xa; ob += xb; }
-        ta += xa; tb += xb;
+        const uint32_t x = s_tmp[w];
+        if (w < wv) o += x;
+        t += x;
     }
-    ea = oa + ia - a;
-    eb = ob + ib - b;
+    const uint32_t e = o + inc - v;
+    ea = e & 0xffffu; eb = e >> 16;
+    ta = t & 0xffffu; tb = t >> 16;
     __syncthreads();
 }
 
@@ -58,64 +61,35 @@ struct UnstuffBytes {
     uint32_t prev, next; // neighbours
 };
 
-__device__ __forceinline__ void unstuff_classify(const UnstuffBytes& u, uint32_t pos0, uint32_t raw_len, uint32_t& keep_mask,
-                                                 uint32_t& rst_mask, uint32_t& err)
-{
-    keep_mask = 0; rst_mask = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
-        uint32_t pv = j == 0 ? u.prev : (u.w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFF;
-        uint32_t nx = j == 15 ? u.next : (u.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFF;
-        bool in = pos0 + j < raw_len;
-        if (pos0 + j + 1 >= raw_len) nx = 0xD9; // nothing follows the last byte
-        bool keep, rst = false;
-        if (c == 0xFF) keep = (nx == 0x00);
-        else if (pv == 0xFF) {
-            keep = false;
-            rst = (c >= 0xD0 && c <= 0xD7);
-            if (in && c != 0 && !rst) err |= 1u; // a real marker inside the scan
-        } else keep = true;
-        if (in && keep) keep_mask |= 1u << j;
-        if (in && rst) rst_mask |= 1u << j;
-    }
-}
-
-__device__ __forceinline__ void unstuff_load(const uint8_t* raw, uint32_t raw_len, uint32_t pos0, UnstuffBytes& u, uint32_t* s_edge)
+__device__ __forceinline__ void unstuff_load(const uint8_t* raw, uint32_t raw_len, uint32_t pos0, UnstuffBytes& u)
 {
     // raw is 16-byte aligned and the arena is padded, so the vector load is always in bounds.
-    uint4 v = *reinterpret_cast<const uint4*>(raw + pos0);
+    const uint4 v = *reinterpret_cast<const uint4*>(raw + pos0);
     u.w[0] = v.x; u.w[1] = v.y; u.w[2] = v.z; u.w[3] = v.w;
-    const int t = threadIdx.x;
-    s_edge[1 + t] = v.x & 0xFF;             // first byte of thread t
-    s_edge[1 + UNSTUFF_T + 1 + t] = v.w >> 24; // last byte of thread t
-    if (t == 0) {
-        uint32_t base = pos0;
-        s_edge[0] = base ? raw[base - 1] : 0;                                        // prev of the chunk
-        uint32_t e = base + UNSTUFF_CHUNK;
-        s_edge[1 + UNSTUFF_T] = e < raw_len ? raw[e] : 0xD9;                          // next of the chunk
-    }
-    __syncthreads();
-    u.prev = t == 0 ? s_edge[0] : s_edge[1 + UNSTUFF_T + 1 + t - 1];
-    u.next = t == UNSTUFF_T - 1 ? s_edge[1 + UNSTUFF_T] : s_edge[1 + t + 1];
-    __syncthreads();
+    // the neighbours' edge bytes travel by lane shuffle; only the two lanes at the ends of a wave read theirs from memory (the same
+    // cache lines the wave is loading anyway). The first version exchanged them through LDS: two barriers per workgroup.
+    const uint32_t lane = threadIdx.x & 63u;
+    u.prev = __shfl_up(v.w >> 24, 1, 64);
+    u.next = __shfl_down(v.x & 0xFFu, 1, 64);
+    if (lane == 0u) u.prev = pos0 ? raw[pos0 - 1u] : 0u;
+    if (lane == 63u) u.next = pos0 + 16u < raw_len ? raw[pos0 + 16u] : 0xD9u; // past the segment: never looked at (see lp_unstuff_classify)
 }
 
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
                                                              uint2* __restrict__ chunk_cnt, LpJpegState* __restrict__ states)
 {
-    __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_tmp[4];
     const LpJpeg& img = imgs[blockIdx.y];
     if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
     uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
-    unstuff_load(raw, img.raw_len, pos0 - threadIdx.x * 16 + threadIdx.x * 16, u, s_edge);
-    uint32_t km, rm, err = 0;
-    unstuff_classify(u, pos0, img.raw_len, km, rm, err);
+    unstuff_load(raw, img.raw_len, pos0, u);
+    uint32_t K[4], R[4], err = 0;
+    if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < img.raw_len) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err); // workgroup-uniform
+    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err);
     uint32_t ea, eb, ta, tb;
-    block_excl_scan2(__popc(km), __popc(rm), ea, eb, ta, tb, s_tmp);
+    block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
     if (threadIdx.x == 0) chunk_cnt[img.chunk_off + blockIdx.x] = make_uint2(ta, tb);
     if (err) atomicOr(&states[blockIdx.y].error, err);
 }
@@ -163,34 +137,43 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
                                                                const uint2* __restrict__ chunk_cnt, uint32_t* __restrict__ clean_arena,
                                                                uint32_t* __restrict__ rst_bits)
 {
-    __shared__ uint32_t s_edge[2 * UNSTUFF_T + 4];
-    __shared__ uint32_t s_tmp[8];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16];
+    __shared__ uint32_t s_tmp[4];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16 + UNSTUFF_T]; // + one byte per lane where dropped bytes go
     const LpJpeg& img = imgs[blockIdx.y];
     if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
     uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
-    unstuff_load(raw, img.raw_len, pos0, u, s_edge);
-    uint32_t km, rm, err = 0;
-    unstuff_classify(u, pos0, img.raw_len, km, rm, err);
+    unstuff_load(raw, img.raw_len, pos0, u);
+    uint32_t K[4], R[4], err = 0;
+    if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < img.raw_len) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err); // workgroup-uniform
+    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err);
+    const uint32_t rany = R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3; // disjoint bit positions: one popcount for the four words
     uint32_t ea, eb, ta, tb;
-    block_excl_scan2(__popc(km), __popc(rm), ea, eb, ta, tb, s_tmp);
+    block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
     const uint2 base = chunk_cnt[img.chunk_off + blockIdx.x];
     const uint32_t a0 = base.x & ~3u;           // clean position of the first (maybe shared) word
-    uint32_t cpos = base.x + ea, rpos = base.y + eb;
+    uint32_t cpos = base.x + ea;
+    if (rany) { // restart markers: a handful per image
+        uint32_t rpos = base.y + eb, c = cpos;
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t bit = 0x80u << (8u * (j & 3u));
+            if (R[j >> 2] & bit) {
+                if (rpos < img.rst_cap) rst_bits[img.rst_off + rpos] = c * 8;
+                rpos++;
+            }
+            c += (K[j >> 2] & bit) ? 1u : 0u;
+        }
+    }
+    // Compaction, branch-free: byte j goes to its clean position (stream order; the words are byte-swapped on the way out) or, when
+    // it is dropped, to the lane's dump byte -- no exec-mask pair per byte (the first version spent 2 x 16 of them per lane).
+    uint32_t l = cpos - a0;
+    const uint32_t dump = UNSTUFF_CHUNK + 16 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        if (rm & (1u << j)) {
-            if (rpos < img.rst_cap) rst_bits[img.rst_off + rpos] = cpos * 8;
-            rpos++;
-        }
-        if (km & (1u << j)) {
-            const uint32_t c = (u.w[j >> 2] >> (8 * (j & 3))) & 0xFF;
-            const uint32_t l = cpos - a0;       // clean position relative to a0; memory order swaps the bytes of a word
-            s_out[(l & ~3u) | (3u - (l & 3u))] = (uint8_t)c;
-            cpos++;
-        }
+        const uint32_t kept = (K[j >> 2] >> (8 * (j & 3) + 7)) & 1u;
+        s_out[kept ? l : dump] = (uint8_t)(u.w[j >> 2] >> (8 * (j & 3)));
+        l += kept;
     }
     __syncthreads();
     const uint32_t lo = base.x - a0, hi = lo + ta;  // owned clean positions relative to a0: [lo, hi)
@@ -201,13 +184,13 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
         if ((a0 >> 2) + w >= cap) break;
         const uint32_t q0 = w * 4;
         if (q0 >= lo && q0 + 4 <= hi) {
-            out[w] = *reinterpret_cast<const uint32_t*>(&s_out[q0]);
+            out[w] = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(&s_out[q0])); // the clean stream is big-endian words: bit 31 = first bit
         } else { // word shared with a neighbouring chunk: touch only the owned bytes
             uint8_t* ob = reinterpret_cast<uint8_t*>(out + w);
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t q = q0 + k;
-                if (q >= lo && q < hi) ob[3u - k] = s_out[q0 + (3u - k)];
+                if (q >= lo && q < hi) ob[3u - k] = s_out[q];
             }
         }
     }

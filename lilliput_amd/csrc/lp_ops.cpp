@@ -156,7 +156,7 @@ struct Framebuffer {
 };
 
 struct Decoder { // openCVDecoder (opencv.go:132-138), gifDecoder (giflib.go:14-28) or webpDecoder (webp.go:14-18)
-    enum Kind { OPENCV, GIF, WEBP } kind = OPENCV;
+    enum Kind { OPENCV, GIF, WEBP, PIXELS } kind = OPENCV;
     const uint8_t* buf = nullptr;
     size_t len = 0;
     opencv_mat mat = nullptr;
@@ -192,6 +192,16 @@ int decoder_header(Decoder* d, Header* h)
         h->pixel_type = webp_decoder_get_pixel_type(d->webp);
         h->orientation = 1;
         h->num_frames = webp_decoder_get_num_frames(d->webp);
+        h->content_length = (int)d->len;
+        return LILLIPUT_OK;
+    }
+    if (d->kind == Decoder::PIXELS) { // the hand-over item: a frame some host decoder (AVIF, video) produced, see lilliput_hip_pixels_header
+        const auto* ph = reinterpret_cast<const lilliput_hip_pixels_header*>(d->buf);
+        h->width = (int)ph->width;
+        h->height = (int)ph->height;
+        h->pixel_type = ph->channels == 1 ? CV_8U : ph->channels == 3 ? CV_8UC3 : CV_8UC4;
+        h->orientation = (int)ph->orientation;
+        h->num_frames = 1;
         h->content_length = (int)d->len;
         return LILLIPUT_OK;
     }
@@ -249,6 +259,15 @@ int decoder_decode_to(Decoder* d, Framebuffer* f)
     if (e) return e;
     e = f->resize_mat(h.width, h.height, h.pixel_type);
     if (e) return e;
+    if (d->kind == Decoder::PIXELS) { // what avcodecDecoder.DecodeTo / avifDecoder.DecodeTo leave behind: one BGR(A) frame in the framebuffer
+        const auto* ph = reinterpret_cast<const lilliput_hip_pixels_header*>(d->buf);
+        const size_t rowb = (size_t)ph->width * ph->channels, stride = ph->stride ? ph->stride : rowb;
+        if (lilliput_hip_mat_set_pixels(f->mat, d->buf + sizeof(*ph), stride)) return LILLIPUT_ERR_DECODING_FAILED;
+        d->has_decoded = true;
+        f->blend = 1; f->dispose = 1; f->x_offset = f->y_offset = 0;
+        f->duration = (int64_t)ph->duration_ms * 1000000ll;
+        return LILLIPUT_OK;
+    }
     if (!opencv_decoder_read_data(d->dec, f->mat)) return LILLIPUT_ERR_DECODING_FAILED;
     d->has_decoded = true;
     f->blend = 1;   // NoBlend
@@ -361,6 +380,16 @@ int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // 
     if (!mat) return LILLIPUT_ERR_BUF_TOO_SMALL;
     auto d = new Decoder();
     d->buf = b; d->len = len; d->mat = mat;
+    if (len >= sizeof(lilliput_hip_pixels_header) && memcmp(b, LILLIPUT_HIP_PIXELS_MAGIC, 8) == 0) { // decoded elsewhere, handed over as pixels
+        const auto* ph = reinterpret_cast<const lilliput_hip_pixels_header*>(b);
+        const uint64_t rowb = (uint64_t)ph->width * ph->channels, stride = ph->stride ? ph->stride : rowb;
+        const bool ok = ph->width && ph->height && ph->width <= 65535 && ph->height <= 65535 && (ph->channels == 1 || ph->channels == 3 || ph->channels == 4) &&
+                        stride >= rowb && ph->orientation >= 1 && ph->orientation <= 8 && sizeof(*ph) + stride * (ph->height - 1) + rowb <= len;
+        if (!ok) { opencv_mat_release(mat); delete d; return LILLIPUT_ERR_INVALID_IMAGE; }
+        d->kind = Decoder::PIXELS;
+        *out = d;
+        return LILLIPUT_OK;
+    }
     if (len >= 12 && memcmp(b, "RIFF", 4) == 0 && memcmp(b + 8, "WEBP", 4) == 0) { // isWebp, lilliput.go:104-115 -> newWebpDecoder, webp.go:27-48
         d->kind = Decoder::WEBP;
         d->webp = webp_decoder_create(mat);
@@ -408,13 +437,14 @@ int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* p
 const char* lilliput_decoder_description(lilliput_decoder dd)
 {
     auto d = static_cast<Decoder*>(dd);
+    if (d->kind == Decoder::PIXELS) return "PIXELS";
     return d->kind == Decoder::GIF ? "GIF" : d->kind == Decoder::WEBP ? "WEBP" : opencv_decoder_get_description(d->dec); // giflib.go:107-109, webp.go:67-69
 }
 
 int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712; gifDecoder.ICC is empty (giflib.go:122-124)
 {
     auto d = static_cast<Decoder*>(dd);
-    if (!d || !dst || d->kind == Decoder::GIF) return 0;
+    if (!d || !dst || d->kind == Decoder::GIF || d->kind == Decoder::PIXELS) return 0;
     if (d->kind == Decoder::WEBP) return (int)webp_decoder_get_icc(d->webp, dst, cap); // webp.go:99-103
     const char* desc = opencv_decoder_get_description(d->dec);
     if (desc && strcmp(desc, "JPEG") == 0) return opencv_decoder_get_jpeg_icc((void*)d->buf, d->len, dst, cap);

@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../lilliput_amd/csrc/lp_huff_core.h"
 #include "../../lilliput_amd/csrc/lp_jpeg_parse.h"
+#include "../../lilliput_amd/csrc/lp_unstuff_core.h"
 
 template <int R, int T, int Q>
 struct HostMemT {
@@ -241,4 +242,46 @@ extern "C" int emu_decode_coefs_progressive(const uint8_t* data, size_t len, int
     for (size_t q = 0; q < (size_t)img.bw[comp] * img.bh[comp]; q++)
         for (int e = 0; e < 64; e++) out[q * 64 + zz[e]] = coef[(base + q) * 64 + e]; // stored in zigzag order
     return 0;
+}
+
+// The word-arithmetic byte classifier of the unstuff kernels (lp_unstuff_core.h) against the byte-by-byte definition of the classes
+// (T.81 B.1.1.5 / jdhuff.c jpeg_fill_bit_buffer) on `iters` pseudo-random 16-byte groups drawn from marker-heavy alphabets, with
+// every neighbour byte and segment-end position. Returns the number of disagreements.
+extern "C" long emu_unstuff_classify_check(long iters, uint32_t seed)
+{
+    static const uint8_t alphabet[] = {0xFF, 0x00, 0xD0, 0xD7, 0xD8, 0xCF, 0xD9, 0x01, 0x80, 0xFE, 0x7F, 0xF8};
+    uint32_t x = seed ? seed : 1u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    long bad = 0;
+    for (long it = 0; it < iters; it++) {
+        uint8_t b[16];
+        const int mode = (int)(it & 3);
+        for (int j = 0; j < 16; j++) b[j] = mode == 0 ? (uint8_t)rnd() : alphabet[rnd() % (mode == 1 ? 12u : mode == 2 ? 4u : 2u)];
+        const uint32_t prev = alphabet[rnd() % 12u], next = alphabet[rnd() % 12u];
+        const uint32_t pos0 = (rnd() % 4u) * 16u, raw_len = rnd() % 8u == 0 ? rnd() % 100u : pos0 + 1000u;
+        uint32_t km = 0, rm = 0, err = 0;
+        for (int j = 0; j < 16; j++) {
+            const uint32_t c = b[j], pv = j == 0 ? prev : b[j - 1];
+            uint32_t nx = j == 15 ? next : b[j + 1];
+            const bool in = pos0 + j < raw_len;
+            if (pos0 + j + 1 >= raw_len) nx = 0xD9; // nothing follows the last byte
+            bool keep, rst = false;
+            if (c == 0xFF) keep = nx == 0x00;
+            else if (pv == 0xFF) { keep = false; rst = c >= 0xD0 && c <= 0xD7; if (in && c != 0 && !rst) err |= 1u; }
+            else keep = true;
+            if (in && keep) km |= 1u << j;
+            if (in && rst) rm |= 1u << j;
+        }
+        uint32_t w[4], km2 = 0, rm2 = 0, err2 = 0;
+        memcpy(w, b, 16);
+        lp_unstuff_classify(w, prev, next, pos0, raw_len, km2, rm2, err2);
+        if (km != km2 || rm != rm2 || err != err2) bad++;
+        if (pos0 + 17u <= raw_len) { // the range-free form used for every chunk but a segment's last must agree where it applies
+            uint32_t K1[4], R1[4], K2[4], R2[4], e1 = 0, e2 = 0;
+            lp_unstuff_classify_masks<true>(w, prev, next, pos0, raw_len, K1, R1, e1);
+            lp_unstuff_classify_masks<false>(w, prev, next, pos0, raw_len, K2, R2, e2);
+            if (memcmp(K1, K2, 16) || memcmp(R1, R2, 16) || e1 != e2) bad++;
+        }
+    }
+    return bad;
 }

@@ -78,6 +78,13 @@ def emu():
     return C.CDLL(so)
 
 
+def test_unstuff_classifier_word_arithmetic(emu):
+    """lp_unstuff_core.h (the byte classes of k_unstuff_count / k_unstuff_scatter as 4-bytes-at-a-time arithmetic) against the
+    byte-by-byte definition: 4 M groups from marker-heavy alphabets, every neighbour and segment-end case."""
+    emu.emu_unstuff_classify_check.restype = C.c_long
+    assert emu.emu_unstuff_classify_check(C.c_long(4_000_000), C.c_uint32(7)) == 0
+
+
 def _emu_coefs(emu, data, S, Cc, comp):
     a = np.frombuffer(data, np.uint8)
     cap = 1 << 24
