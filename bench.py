@@ -193,8 +193,9 @@ def main():
                 b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
             resident_ips = 2 * args.batch / (time.time() - t)
         # exclusive kernel durations: ONE engine, so that no other stream's kernels share the GPU with the launch being timed
-        nx = min(224, args.batch)   # two launches of the resident chunk size
         b1 = la.Batch(local_rank % ndev)
+        round_images = args.chunk or b1.resident_round(max(len(x) for x in sources))
+        nx = min(2 * round_images, args.batch)   # two launches of the resident chunk size
         if args.sub_bits:
             b1.set_subsequence(args.sub_bits, args.ckpt_bits)
         b1.upload(sources[:nx], dst_cap=256 << 10, streams=1)
@@ -202,7 +203,7 @@ def main():
         b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
         excl = b1.timings()
         excl["images"] = nx
-        excl["launch_images"] = min(args.chunk or 112, nx)
+        excl["launch_images"] = min(round_images, nx)
         b1.close()
 
     if rank == 0:

@@ -354,6 +354,9 @@ void lilliput_hip_node_device_stats(lilliput_hip_node n, int k, double out[2]); 
 void lilliput_hip_batch_timings(lilliput_hip_batch b, float out_ms[10], int* verify_rounds);
 /* Decoder tuning: subsequence bits / checkpoint spacing (0 = automatic). */
 void lilliput_hip_batch_set_subsequence(lilliput_hip_batch b, unsigned S, unsigned C);
+/* Images (of at most max_src_len encoded bytes) per launch of a resident run when options.chunk is 0: one full round of the entropy
+ * decoder's workgroups on this device. LILLIPUT_HIP_RESIDENT_CHUNK overrides it. */
+int lilliput_hip_batch_resident_round(lilliput_hip_batch b, size_t max_src_len);
 
 /* Stage-level access for parity tests (device results copied to host). */
 int lilliput_hip_decode_jpeg(lilliput_hip_batch b, const void* src, size_t len, void* dst, size_t cap, int* w, int* h, int* channels, int* orientation);

@@ -93,6 +93,7 @@ def lib():
     L.lilliput_hip_batch_download.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t]
     L.lilliput_hip_batch_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.lilliput_hip_batch_set_subsequence.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    L.lilliput_hip_batch_resident_round.argtypes = [C.c_void_p, C.c_size_t]
     L.lilliput_hip_batch_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.lilliput_hip_batch_ingest_stats.restype = None
     L.lilliput_hip_node_create.restype = C.c_void_p
@@ -285,6 +286,10 @@ class Batch:
             raise LilliputError(5, "lilliput_hip_batch_create")
         self._items = None
         self._keep = None
+
+    def resident_round(self, max_src_len):
+        """Images per launch of a resident run (one full round of the entropy decoder's workgroups on the device)."""
+        return int(lib().lilliput_hip_batch_resident_round(self._h, int(max_src_len)))
 
     def set_subsequence(self, S, C_):
         lib().lilliput_hip_batch_set_subsequence(self._h, int(S), int(C_))

@@ -157,6 +157,15 @@ void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsig
     for (auto& p : b->parts) p.eng->set_subsequence(S, C);
 }
 
+int lilliput_hip_batch_resident_round(lilliput_hip_batch bb, size_t max_src_len)
+{
+    auto b = static_cast<LpBatch*>(bb);
+    static const int round_env = getenv("LILLIPUT_HIP_RESIDENT_CHUNK") ? atoi(getenv("LILLIPUT_HIP_RESIDENT_CHUNK")) : 0;
+    if (round_env > 0) return round_env;
+    if (!b || b->parts.empty() || !b->parts[0].eng) return 112;
+    return (int)b->parts[0].eng->resident_round(max_src_len);
+}
+
 void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* verify_rounds)
 {
     const LpTimings& t = static_cast<LpBatch*>(bb)->tm;
@@ -476,9 +485,13 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     if (!nv) return LILLIPUT_OK;
     LpEngine& eng = *part.eng;
     eng.select_upload(0);
-    // 112, not 128: a 4096 x 4096 image is 9 workgroups of the WRITE kernel, four of which fit a CU (LDS): 113 images fill the 256 CUs
-    // exactly once, 128 would leave an eighth of the grid for a second, nearly empty round (measured: 28 instead of 36 us per image)
-    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, 112);
+    // One full round of the WRITE kernel's workgroups per launch: a 4096 x 4096 image is 9 of them and the CUs hold five each (LDS), so
+    // 142 images fill the device exactly once; a few more would leave a second, nearly empty round that costs as much as the first
+    // (measured with four per CU: 112 images 28 us per image, 128 images 36)
+    size_t max_raw = 0;
+    for (const LpJpegHeader& h : part.hdrs) max_raw = std::max(max_raw, (size_t)h.ecs_len);
+    static const size_t round_env = getenv("LILLIPUT_HIP_RESIDENT_CHUNK") ? (size_t)atoi(getenv("LILLIPUT_HIP_RESIDENT_CHUNK")) : 0;
+    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, round_env ? round_env : eng.resident_round(max_raw));
     const LpSink sink{b, nullptr};
     eng.enable_timing(true);
     int rc = LILLIPUT_OK;

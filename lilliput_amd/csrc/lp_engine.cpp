@@ -142,6 +142,17 @@ static uint32_t pick_S(size_t max_ecs_bytes)
     return 256;
 }
 
+size_t LpEngine::resident_round(size_t max_raw_len)
+{
+    if (!ok_ || hipSetDevice(device_) != hipSuccess) return 112;
+    static thread_local uint32_t slots = 0;
+    if (!slots) slots = lp_huff_write_slots();
+    const uint32_t S = S_cfg_ ? S_cfg_ : pick_S(max_raw_len);
+    const uint64_t nsub = ((uint64_t)max_raw_len * 8 + S - 1) / S + 1;
+    const uint64_t wgs = (nsub + 255) / 256;
+    return (size_t)std::max<uint64_t>(16, std::min<uint64_t>(512, slots / std::max<uint64_t>(1, wgs)));
+}
+
 // Descriptors and arena layout of one set of sources (slot `slot`): every entropy-coded segment becomes a piece at a 16-byte
 // aligned arena offset followed by 32 zero bytes. whole = size the slot's pinned buffer for the whole set (staged uploads).
 static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)

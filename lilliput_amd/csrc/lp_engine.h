@@ -170,6 +170,8 @@ public:
     // PNG output: libpng's per-row filter choice + filtering on the device; `out` receives h * (1 + w * cn) bytes (host memory).
     int png_filter(const LpFrame& src, uint32_t filters, uint8_t* out);
     // HDR -> SDR tone map in place (color_info.cpp:206-236 tonemap_rgb_8u_inplace): 3- or 4-channel 8-bit frame, cICP code points
+    // images of at most max_raw_len entropy-coded bytes whose WRITE workgroups fill the device exactly once
+    size_t resident_round(size_t max_raw_len);
     int tonemap(const LpFrame& f, int transfer, int primaries, const uint16_t* d_src16 = nullptr, int depth = 8);
     // the same for host buffers (the reference's own signatures): tightly packed 8-bit pixels in place; 16-bit samples -> 8-bit
     int tonemap_host8(uint8_t* pixels, int w, int h, int cn, int transfer, int primaries);

@@ -173,12 +173,12 @@ struct LpLane {
     }
 
     // Second level of the code lookup: e1 is the first-level entry of a prefix that belongs to codes longer than LP_LUT_BITS; its
-    // low byte names a 64-entry slice of the second-level pool, indexed by the six bits that follow the prefix (see LpHuffSet).
+    // low byte names a slice of the second-level pool, indexed by the LP_LUT2_BITS bits that follow the prefix (see LpHuffSet).
     // One dependent LDS read: a long code is rare per lane but shows up in most steps of a 64-lane wave.
     LP_HD uint32_t long_code(uint32_t tbl, uint32_t e1, uint32_t top)
     {
         const uint32_t sub = e1 & 0xffu;
-        uint32_t e = sub != 0xffu ? m.lut2((sub << 6) | (top & 63u)) : 0u;
+        uint32_t e = sub != 0xffu ? m.lut2((sub << LP_LUT2_BITS) | (top & ((1u << LP_LUT2_BITS) - 1u))) : 0u;
         if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
             uint32_t len = 17, sym = 0; // no code matches: jpeg_huff_decode reads on to the sentinel length 17, warns and fakes a zero
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {

@@ -54,7 +54,7 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
     for (int i = 0; i < LP_LUT_SIZE; i++) hs->lut[slot][i] = 0x00ffu;
     if (slot == 0) hs->lut2_used = 0; // slots are built in order 0..3 and share the second-level pool
     // canonical code assignment (T.81 Annex C). Short codes fill their span of the first level; a long code gets its prefix's
-    // slice of the second level (allocated on first use) and fills its span of the six bits after the prefix.
+    // slice of the second level (allocated on first use) and fills its span of the LP_LUT2_BITS bits after the prefix.
     int code = 0, k = 0;
     for (int l = 1; l <= 16; l++) {
         int valptr = k, mincode = code;
@@ -71,11 +71,11 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
                 if ((e1 & 0xffu) == 0xffu) {
                     if (hs->lut2_used >= LP_LUT2_SUBS) continue;             // pool exhausted: canonical search serves this prefix
                     e1 = (uint16_t)hs->lut2_used;
-                    memset(hs->lut2 + ((size_t)hs->lut2_used << 6), 0, 64 * sizeof(uint16_t));
+                    memset(hs->lut2 + ((size_t)hs->lut2_used << LP_LUT2_BITS), 0, sizeof(uint16_t) << LP_LUT2_BITS);
                     hs->lut2_used++;
                 }
-                const uint32_t sub = e1 & 0xffu, first = left & 63u, n = 1u << (16 - l);
-                for (uint32_t j = 0; j < n && first + j < 64; j++) hs->lut2[(sub << 6) | (first + j)] = lut_entry(slot, l, vals[k]);
+                const uint32_t sub = e1 & 0xffu, first = left & ((1u << LP_LUT2_BITS) - 1u), n = 1u << (16 - l);
+                for (uint32_t j = 0; j < n && first + j < (1u << LP_LUT2_BITS); j++) hs->lut2[(sub << LP_LUT2_BITS) | (first + j)] = lut_entry(slot, l, vals[k]);
             }
         }
         hs->maxcode[slot][l] = bits[l] ? code - 1 : -1;

@@ -478,6 +478,9 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
 // (element v * 8 + u holds the coefficient of row u, column v: the write kernel feeds put() a transposed zigzag table).
 struct DevSink {
     int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * 1024
+    int8_t* wslots;         // LDS: the wave's slots (lane 0's chunk 0)
+    uint32_t* qlist;        // LDS: the wave's list of finished blocks, (block << 6) | lane -- 64 entries
+    uint32_t lane;
     uint32_t qblk;          // queued block index (0xffffffff = slot free)
     int8_t* coef8;          // this image's coefficient blocks
     int16_t* wide;          // this image's wide slots (64 int16 each)
@@ -487,12 +490,22 @@ struct DevSink {
     int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
                             // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
     int32_t dcv;            // DC difference of the current block
-    int16_t* dcl;           // LDS: this lane's 8 most recent DC differences (a lane's blocks are consecutive, so eight of them are one
-                            // aligned 16-byte store; one 2-byte store per block cost a 32-byte write transaction each -- profiles/r01_e)
+    uint32_t dq0, dq1, dq2, dq3; // this lane's 8 most recent DC differences, newest in the top half of dq3 (a lane's blocks are consecutive, so
+                            // eight of them are one aligned 16-byte store; one 2-byte store per block cost a 32-byte write transaction
+                            // each -- profiles/r01_e). A 128-bit shift register in VGPRs: it was 4 KB of LDS per workgroup.
+    __device__ __forceinline__ uint32_t dq_get(uint32_t i) const // 16-bit element i (rare paths only)
+    {
+        const uint32_t lo = (i & 2u) ? dq1 : dq0, hi = (i & 2u) ? dq3 : dq2; // four scalars, not an array: an indexed array lands in scratch
+        const uint32_t w = (i & 4u) ? hi : lo;
+        return (i & 1u) ? w >> 16 : w & 0xffffu;
+    }
     uint32_t blk0, last;    // first block of this lane, last block flushed (0xffffffff = none yet)
     __device__ __forceinline__ void put_dc(int32_t v, bool on) { dcv = on ? v : dcv; }
     __device__ __forceinline__ void put(uint32_t nat, int32_t v)
     {
+#ifdef LP_EXP_NOPUT
+        asm volatile("" :: "v"(nat), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
+#endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
             wide[(size_t)wslot * 64 + nat] = (int16_t)v;
@@ -506,36 +519,55 @@ struct DevSink {
         if (on && wslot != 0xffffffffu) { wide_id[blk] = wslot; wslot = 0xffffffffu; } // rare
     }
     __device__ __forceinline__ bool stalled() const { return qblk != 0xffffffffu; }
+    // Wave-cooperative: the lanes with a finished block put (block, lane) on a per-wave list; then four lanes move one block each --
+    // lane 4e + c reads chunk c of the e-th listed lane's slot, stores it (64 contiguous bytes per four lanes) and clears it. The cost
+    // follows the number of finished blocks (about a quarter of the lanes per flush) instead of four full-wave 16-byte reads, stores and
+    // clears whatever the number (PMC / timing experiment: the flush was 30 % of the kernel).
     __device__ __forceinline__ void flush()
     {
-        if (qblk != 0xffffffffu) {
-            uint4* s = reinterpret_cast<uint4*>(slot);
-            uint4* o = reinterpret_cast<uint4*>(coef8 + ((size_t)qblk << 6));
-            const uint4 zero = make_uint4(0, 0, 0, 0);
-            const uint4 r0 = s[0], r1 = s[64], r2 = s[128], r3 = s[192];
-            // streaming stores: the block is written once and read once by k_idct; a regular store write-allocates the 128-byte
-            // line for each 64-byte block (PMC: 33 MB fetched per image by a kernel that reads 4 MB)
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            u32x4* on = reinterpret_cast<u32x4*>(o);
-            __builtin_nontemporal_store((u32x4){r0.x, r0.y, r0.z, r0.w}, on); __builtin_nontemporal_store((u32x4){r1.x, r1.y, r1.z, r1.w}, on + 1);
-            __builtin_nontemporal_store((u32x4){r2.x, r2.y, r2.z, r2.w}, on + 2); __builtin_nontemporal_store((u32x4){r3.x, r3.y, r3.z, r3.w}, on + 3);
-            s[0] = zero; s[64] = zero; s[128] = zero; s[192] = zero;
+#ifdef LP_EXP_NOFLUSH
+        if (qblk != 0xffffffffu) { last = qblk; qblk = 0xffffffffu; } // timing experiment: what does the block flush cost?
+        return;
+#endif
+        const bool q = qblk != 0xffffffffu;
+        const uint64_t mask = __ballot(q);
+        if (!mask) return; // wave-uniform
+        if (q) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            qlist[pos] = (qblk << 6) | lane;
             const uint32_t k = qblk & 7u;
-            dcl[k] = (int16_t)dcv;
-            if (k == 7u) {
+            dq0 = (dq0 >> 16) | (dq1 << 16); dq1 = (dq1 >> 16) | (dq2 << 16); // four v_alignbit
+            dq2 = (dq2 >> 16) | (dq3 << 16); dq3 = (dq3 >> 16) | ((uint32_t)dcv << 16);
+            if (k == 7u) { // after the eighth block of an aligned group, element j holds block g0 + j
                 const uint32_t g0 = qblk - 7u;
-                if (g0 >= blk0) *reinterpret_cast<uint4*>(dc16 + g0) = *reinterpret_cast<const uint4*>(dcl); // the whole group is this lane's
-                else for (uint32_t j = blk0 - g0; j < 8u; j++) dc16[g0 + j] = dcl[j];                        // the lane started inside the group
+                if (g0 >= blk0) *reinterpret_cast<uint4*>(dc16 + g0) = make_uint4(dq0, dq1, dq2, dq3); // the whole group is this lane's
+                else for (uint32_t j = blk0 - g0; j < 8u; j++) dc16[g0 + j] = (int16_t)dq_get(j);           // the lane started inside the group
             }
             last = qblk;
             qblk = 0xffffffffu;
         }
+        __builtin_amdgcn_wave_barrier(); // the list is read by other lanes of the same wave: LDS operations of a wave execute in order
+        const uint32_t n = (uint32_t)__popcll(mask);
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        for (uint32_t i = 0; i < n; i += 16u) { // wave-uniform
+            const uint32_t e = i + (lane >> 2);
+            if (e < n) {
+                const uint32_t ent = qlist[e], c = lane & 3u;
+                uint4* s = reinterpret_cast<uint4*>(wslots + (c << 10) + ((ent & 63u) << 4));
+                const uint4 r = *s;
+                *s = make_uint4(0, 0, 0, 0);
+                // streaming store: the block is written once and read once by k_idct; a regular store write-allocates the line
+                // (PMC: 33 MB fetched per image by a kernel that reads 4 MB)
+                __builtin_nontemporal_store((u32x4){r.x, r.y, r.z, r.w}, reinterpret_cast<u32x4*>(coef8 + ((size_t)(ent >> 6) << 6) + (c << 4)));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void finish() // the lane's last, incomplete group of DC values
     {
         if (last != 0xffffffffu && (last & 7u) != 7u) {
             const uint32_t g0 = last & ~7u;
-            for (uint32_t b = g0 > blk0 ? g0 : blk0; b <= last; b++) dc16[b] = dcl[b & 7u];
+            for (uint32_t b = g0 > blk0 ? g0 : blk0; b <= last; b++) dc16[b] = (int16_t)dq_get(7u - (last - b)); // the newest sits in element 7
         }
     }
 };
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
     __shared__ uint8_t s_zz[80];
-    __shared__ __attribute__((aligned(16))) int16_t s_dcl[HUFF_T * 8];
+    __shared__ uint32_t s_qlist[HUFF_T];
     const LpJpeg& img = imgs[blockIdx.y];
     LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -567,14 +599,24 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     }
     stage_huff(s_hs4, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
-    if (sub >= nsub) return;
-    const uint32_t g = img.sub_off + sub;
+    if ((sub & ~63u) >= nsub) return; // a whole wave without work
+    // the flush is wave-cooperative, so the lanes past the last subsequence of a partly filled wave stay: they start at the end of
+    // the stream with nothing to decode and only help moving the others' blocks
+    const bool idle = sub >= nsub;
+    const uint32_t g = img.sub_off + (idle ? nsub - 1u : sub);
     const LpImgCtx ic = make_ctx(img, st);
     MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
     LpSubState entry;
-    if (sub == 0) { entry.p = 0; entry.bz = 0; } else entry = exits[g - 1];
+    entry.p = 0; entry.bz = 0;
+    if (sub != 0 && !idle) entry = exits[g - 1];
+    LpSubSum prefix = prefixes[g];
+    uint32_t end_p = exits[g].p;
+    if (idle) { entry.p = end_p = ic.total_bits; prefix.nblk = ic.total_blocks; }
     DevSink sink;
-    sink.slot = s_slots + (threadIdx.x >> 6) * 4096 + (threadIdx.x & 63) * 16;
+    sink.wslots = s_slots + (threadIdx.x >> 6) * 4096;
+    sink.lane = threadIdx.x & 63;
+    sink.slot = sink.wslots + sink.lane * 16;
+    sink.qlist = s_qlist + (threadIdx.x >> 6) * 64;
     sink.qblk = 0xffffffffu;
     sink.coef8 = coef8_arena + img.coef_off;
     sink.wide = wide_arena + img.coef_off;
@@ -583,10 +625,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wslot = 0xffffffffu;
     sink.dc16 = dc_arena + img.coef_off / 64;
     sink.dcv = 0;
-    sink.dcl = s_dcl + threadIdx.x * 8;
-    sink.blk0 = prefixes[g].nblk;
+    sink.dq0 = sink.dq1 = sink.dq2 = sink.dq3 = 0;
+    sink.blk0 = prefix.nblk;
     sink.last = 0xffffffffu;
-    lp_write_pass(m, ic, entry, exits[g].p, prefixes[g], s_zz, sink);
+    lp_write_pass(m, ic, entry, end_p, prefix, s_zz, sink);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1061,6 +1103,16 @@ void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)
 {
     if (!a.nimg) return;
     hipLaunchKernelGGL(k_sub_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSubSum*)a.cur_total, a.prefix);
+}
+
+// How many workgroups of the WRITE kernel the device holds at once (LDS-limited occupancy x CUs): a resident batch sizes its chunks
+// so that a launch is one full round of them (a second, mostly empty round costs as much as the first).
+uint32_t lp_huff_write_slots()
+{
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_huff_write<WriteMem>, HUFF_T, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus;
 }
 
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)

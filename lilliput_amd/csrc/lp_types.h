@@ -10,10 +10,13 @@
 #define LP_MAX_COMP 3           // components the subsequence-parallel baseline kernels take (grey, YCbCr, RGB)
 #define LP_GEOM_COMP 4          // components an image may have: CMYK / YCCK files go through the per-scan path (LpProgScan)
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
-#define LP_LUT_BITS 10          // first-level Huffman lookup width
+#define LP_LUT_BITS 10          // first-level Huffman lookup width. 9 (with 128-entry slices) was measured: it saves 3 KB of LDS per workgroup and
+                                // lets a fifth WRITE workgroup onto each CU, which buys nothing (27.5 us per image either way: the kernel is
+                                // not occupancy-bound at four) while the extra second-level lookups cost SPEC / VERIFY / WRITE 2-4 % each
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
-#define LP_LUT2_SUBS 16          // second-level lookup: slices of 64 entries shared by the four tables (one per 10-bit prefix of long codes)
-#define LP_LUT2_POOL (LP_LUT2_SUBS * 64)
+#define LP_LUT2_BITS (16 - LP_LUT_BITS) // second-level lookup: slices indexed by the bits that follow the first-level prefix (codes up to 16 bits)
+#define LP_LUT2_SUBS 16          // slices shared by the four tables, one per first-level prefix of long codes (Annex-K tables need 1 + 5 + 5)
+#define LP_LUT2_POOL (LP_LUT2_SUBS << LP_LUT2_BITS)
 #define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
@@ -21,8 +24,8 @@
 //              ends_block marks the AC symbols that finish a block (size 0, run != 15). The prefix of longer codes: len == 0 and the low
 //              byte = the slice of lut2 that decodes them (0xff: none -- not a prefix of any code, or the pool was exhausted -> canonical
 //              search through maxcode / valoff / vals).
-// lut2[(slice << 6) | j] : same encoding (len 11..16) for the codes that start with the slice's prefix, j = the six bits after the
-//              prefix; 0 = no such code -> canonical search. Annex-K tables need 1 + 5 + 5 slices.
+// lut2[(slice << LP_LUT2_BITS) | j] : same encoding (len LP_LUT_BITS + 1 .. 16) for the codes that start with the slice's prefix, j = the
+//              LP_LUT2_BITS bits after the prefix; 0 = no such code -> canonical search.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
 #define LP_HUFF_LDS_BYTES ((4 * LP_LUT_SIZE + LP_LUT2_POOL) * 2)   // the lookup part the kernels stage in LDS; the canonical part stays in HBM
 struct LpHuffSet {
