@@ -832,6 +832,19 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
 
 __constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
 
+// Orders this wave's LDS writes before its following LDS reads of other lanes' data (and the other way round) for the compiler; the
+// hardware keeps a wave's DS operations in issue order.
+__device__ __forceinline__ void idct_wave_sync()
+{
+#ifdef LP_IDCT_WG_BARRIER
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 #define IDCT_TPW 8
 #ifndef IDCT_AHEAD
 #define IDCT_AHEAD 4      // divides IDCT_TPW
@@ -948,11 +961,12 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         const bool fast = !any_esc && q_small;
         const bool wave_fast = __all(fast);
         uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
+        // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between the
+        // passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every load wait
         if (wave_fast) idct_cols<true>(cv, qv, s_w[wv], j, r); else idct_cols<false>(cv, qv, s_w[wv], j, r);
-        __syncthreads();
+        idct_wave_sync();
         if (wave_fast) idct_rows<true>(s_w[wv], j, r, blk_ok, dst); else idct_rows<false>(s_w[wv], j, r, blk_ok, dst);
-        __syncthreads();
-        __syncthreads();
+        idct_wave_sync();
       }
       if (out) break;
     }
