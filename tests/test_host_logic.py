@@ -69,6 +69,22 @@ def test_content_length_scanners(hip_lib, fixture_bytes):
     assert hip_lib.lilliput_detect_apng(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)) == 1
 
 
+def test_sidecar_build_exports_only_its_own_entry_points():
+    """INTEGRATION.md section 1, side-by-side mode: `make sidecar` links the same objects with an export list that keeps the re-declared
+    reference symbols (opencv_*, giflib_*, webp_*, thumbhash_*, the color_info functions) local, so the library can sit next to the
+    reference's stock shims in one binary."""
+    d = os.path.join(ROOT, "lilliput_amd", "csrc")
+    subprocess.run(["make", "-C", d, "sidecar"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    so = os.path.join(ROOT, "lilliput_amd", "liblilliput_hip_sidecar.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert {"lilliput_hip_batch_transform", "lilliput_hip_node_transform", "lilliput_new_decoder", "lilliput_image_ops_transform"} <= names
+    clash = [n for n in names if n.startswith(("opencv_", "giflib_", "webp_", "thumbhash_", "tonemap_", "cicp_", "icc_", "is_hdr"))]
+    assert not clash, clash
+    assert all(n.startswith("lilliput_") for n in names), sorted(n for n in names if not n.startswith("lilliput_"))
+    C.CDLL(so)  # loads: every internal reference was bound at link time
+
+
 @pytest.fixture(scope="module")
 def emu():
     d = os.path.join(ROOT, "tests", "emu")
