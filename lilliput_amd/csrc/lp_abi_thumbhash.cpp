@@ -19,33 +19,115 @@ struct thumbhash_encoder_struct {
 };
 
 namespace {
-const size_t kMaxDimension = 100;
-const float kPi = 3.14159265f;
+const size_t kMaxSamples = 100; // per axis
 
-// thumbhash.cpp:27-72 encode_channel
-void encode_channel(const std::vector<float>& ch, size_t nx, size_t ny, size_t w, size_t h, float* dc, std::vector<float>* ac, float* scale)
+// ThumbHash (the public algorithm; the reference's float evaluation order is what fixes the low bits of its known answers) restated
+// around three pieces of its own: planar opponent-colour channels, one cosine table per axis and channel shape, and a nibble writer.
+// What must not change is the ORDER of the float operations: a coefficient is ONE accumulator running over the samples row by row,
+// each term (sample * cos_x) * cos_y, divided by the sample count at the end (thumbhash.cpp:27-72); the alpha-weighted means are
+// running sums in sample order (thumbhash.cpp:118-193).
+
+// cos(pi / n * k * (i + 0.5)) for k < kmax, i < n -- evaluated in float exactly as the reference spells it, once per axis
+// (the reference re-evaluates the row of x factors for every coefficient and the y factor for every row of every coefficient)
+struct CosTable {
+    size_t n = 0, kmax = 0;
+    std::vector<float> v; // [k][i]
+    void build(size_t n_, size_t kmax_)
+    {
+        n = n_; kmax = kmax_;
+        v.resize(n * kmax);
+        const float pi = 3.14159265f;
+        for (size_t k = 0; k < kmax; k++)
+            for (size_t i = 0; i < n; i++) v[k * n + i] = (float)cos(pi / (float)n * (float)k * ((float)i + 0.5f));
+    }
+    const float* row(size_t k) const { return &v[k * n]; }
+};
+
+struct ChannelCode {
+    float dc = 0.0f, scale = 0.0f;
+    std::vector<float> ac; // the triangle cx * ny < nx * (ny - cy), row by row, DC left out; mapped to [0, 1] once the scale is known
+};
+
+// The low-frequency cosine coefficients of one w x h channel: nx x ny triangle.
+ChannelCode code_channel(const float* plane, size_t w, size_t h, size_t nx, size_t ny, const CosTable& tx, const CosTable& ty)
 {
-    *dc = 0.0f;
-    *scale = 0.0f;
-    ac->clear();
-    std::vector<float> fx(w, 0.0f);
-    for (size_t cy = 0; cy < ny; ++cy)
-        for (size_t cx = 0; cx * ny < nx * (ny - cy); ++cx) {
-            float f = 0.0f;
-            for (size_t x = 0; x < w; ++x) fx[x] = (float)cos(kPi / (float)w * (float)cx * ((float)x + 0.5f));
-            for (size_t y = 0; y < h; ++y) {
-                const float fy = (float)cos(kPi / (float)h * (float)cy * ((float)y + 0.5f));
-                for (size_t x = 0; x < w; ++x) f += ch[x + y * w] * fx[x] * fy;
+    ChannelCode out;
+    const float count = (float)(w * h);
+    for (size_t ky = 0; ky < ny; ky++) {
+        const float* cy = ty.row(ky);
+        for (size_t kx = 0; kx * ny < nx * (ny - ky); kx++) {
+            const float* cx = tx.row(kx);
+            float acc = 0.0f;
+            const float* s = plane;
+            for (size_t y = 0; y < h; y++, s += w) {
+                const float fy = cy[y];
+                for (size_t x = 0; x < w; x++) acc += s[x] * cx[x] * fy;
             }
-            f /= (float)(w * h);
-            if (cx > 0 || cy > 0) {
-                ac->push_back(f);
-                *scale = std::max(fabsf(f), *scale);
-            } else
-                *dc = f;
+            acc /= count;
+            if (kx == 0 && ky == 0) { out.dc = acc; continue; }
+            out.ac.push_back(acc);
+            out.scale = std::max(fabsf(acc), out.scale);
         }
-    if (*scale > 0.0f)
-        for (float& v : *ac) v = 0.5f + 0.5f / *scale * v;
+    }
+    if (out.scale > 0.0f)
+        for (float& v : out.ac) v = 0.5f + 0.5f / out.scale * v;
+    return out;
+}
+
+// Four-bit values, low nibble first.
+struct NibbleWriter {
+    std::vector<uint8_t>& bytes;
+    bool high = false;
+    void put(const std::vector<float>& unit_values)
+    {
+        for (float f : unit_values) {
+            const uint8_t u = (uint8_t)roundf(15.0f * f);
+            if (high) bytes.back() |= (uint8_t)(u << 4);
+            else bytes.push_back(u);
+            high = !high;
+        }
+    }
+};
+
+// L (luminance), P (yellow - blue), Q (red - green), A planes of the sampled pixels; returns whether any sample is not opaque.
+// A translucent sample is composited over the alpha-weighted mean colour of the image.
+bool opponent_planes(const uint8_t* px, size_t n, int cn, float* L, float* P, float* Q, float* A)
+{
+    if (cn == 1) {
+        for (size_t k = 0; k < n; k++) { L[k] = (float)px[k] / 255.0f; P[k] = 0.0f; Q[k] = 0.0f; A[k] = 1.0f; }
+        return false;
+    }
+    float mean_b = 0.0f, mean_g = 0.0f, mean_r = 0.0f, alpha_sum = (float)n;
+    const bool rgba = cn == 4;
+    if (rgba) { // running sums in sample order
+        alpha_sum = 0.0f;
+        for (size_t k = 0; k < n; k++) {
+            const uint8_t* s = px + 4 * k;
+            const float al = (float)s[3] / 255.0f;
+            mean_b += (al / 255.0f) * (float)s[0];
+            mean_g += (al / 255.0f) * (float)s[1];
+            mean_r += (al / 255.0f) * (float)s[2];
+            alpha_sum += al;
+        }
+        if (alpha_sum > 0.0f) { mean_r /= alpha_sum; mean_g /= alpha_sum; mean_b /= alpha_sum; }
+    }
+    for (size_t k = 0; k < n; k++) {
+        const uint8_t* s = px + (size_t)cn * k;
+        float b, g, r, al = 1.0f;
+        if (rgba) {
+            al = (float)s[3] / 255.0f;
+            b = mean_b * (1.0f - al) + (al / 255.0f) * (float)s[0];
+            g = mean_g * (1.0f - al) + (al / 255.0f) * (float)s[1];
+            r = mean_r * (1.0f - al) + (al / 255.0f) * (float)s[2];
+        } else {
+            b = (1.0f / 255.0f) * (float)s[0]; g = (1.0f / 255.0f) * (float)s[1]; r = (1.0f / 255.0f) * (float)s[2];
+        }
+        L[k] = (r + g + b) / 3.0f;
+        P[k] = (r + g) / 2.0f - b;
+        Q[k] = r - g;
+        A[k] = al;
+    }
+    return rgba && alpha_sum < (float)n;
 }
 }
 
@@ -65,100 +147,61 @@ int thumbhash_encoder_encode(thumbhash_encoder e, const opencv_mat opaque_frame)
     if (!e || !m || m->rows <= 0 || m->cols <= 0) return -1;
     const int cn = m->type == CV_8UC4 ? 4 : m->type == CV_8UC3 ? 3 : m->type == CV_8U ? 1 : 0;
     if (!cn) return -1; // "Unsupported format"
-    const size_t orig_w = (size_t)m->cols, orig_h = (size_t)m->rows;
-    size_t w = orig_w, h = orig_h;
-    if (orig_w > kMaxDimension || orig_h > kMaxDimension) {
-        const float aspect = (float)orig_w / orig_h;
-        if (orig_w > orig_h) { w = kMaxDimension; h = (size_t)(w / aspect); }
-        else { h = kMaxDimension; w = (size_t)(h * aspect); }
+    // at most 100 x 100 nearest-neighbour samples, the longer side pinned to 100 (thumbhash.cpp:100-116)
+    const size_t src_w = (size_t)m->cols, src_h = (size_t)m->rows;
+    size_t w = src_w, h = src_h;
+    if (src_w > kMaxSamples || src_h > kMaxSamples) {
+        const float aspect = (float)src_w / src_h;
+        if (src_w > src_h) { w = kMaxSamples; h = (size_t)(w / aspect); }
+        else { h = kMaxSamples; w = (size_t)(h * aspect); }
     }
     if (!w || !h) return -1; // an aspect ratio beyond 100:1 leaves no samples (the reference would divide by zero further down)
-    const float row_ratio = (float)orig_h / h, col_ratio = (float)orig_w / w;
-    // the sample coordinates exactly as the reference computes them (float product, truncated)
-    std::vector<uint32_t> idx(w + h);
-    for (size_t j = 0; j < w; j++) idx[j] = (uint32_t)std::min((size_t)((int)j * col_ratio), orig_w - 1);
-    for (size_t i = 0; i < h; i++) idx[w + i] = (uint32_t)std::min((size_t)((int)i * row_ratio), orig_h - 1);
+    // sample coordinates: float product, truncated, clamped -- gathered on the device from wherever the frame lives
+    std::vector<uint32_t> pick(w + h);
+    const float step_x = (float)src_w / w, step_y = (float)src_h / h;
+    for (size_t j = 0; j < w; j++) pick[j] = (uint32_t)std::min((size_t)((int)j * step_x), src_w - 1);
+    for (size_t i = 0; i < h; i++) pick[w + i] = (uint32_t)std::min((size_t)((int)i * step_y), src_h - 1);
     LpEngine* eng = lp_thread_engine();
     if (!eng || !lp_mat_to_device(m, eng)) return -1;
-    std::vector<uint8_t> px(w * h * (size_t)cn);
-    if (eng->gather_samples(lp_mat_frame(m), idx.data(), (uint32_t)w, (uint32_t)h, px.data())) return -1;
+    const size_t n = w * h;
+    std::vector<uint8_t> px(n * (size_t)cn);
+    if (eng->gather_samples(lp_mat_frame(m), pick.data(), (uint32_t)w, (uint32_t)h, px.data())) return -1;
 
-    bool has_alpha = false;
-    std::vector<float> l, p, q, a;
-    l.reserve(w * h); p.reserve(w * h); q.reserve(w * h); a.reserve(w * h);
-    if (cn == 4) {
-        float avg_r = 0.0f, avg_g = 0.0f, avg_b = 0.0f, avg_a = 0.0f;
-        for (size_t k = 0; k < w * h; k++) {
-            const uint8_t* s = &px[4 * k];
-            const float alpha = (float)s[3] / 255.0f;
-            avg_b += (alpha / 255.0f) * (float)s[0];
-            avg_g += (alpha / 255.0f) * (float)s[1];
-            avg_r += (alpha / 255.0f) * (float)s[2];
-            avg_a += alpha;
-        }
-        if (avg_a > 0.0f) { avg_r /= avg_a; avg_g /= avg_a; avg_b /= avg_a; }
-        has_alpha = avg_a < (float)(w * h);
-        for (size_t k = 0; k < w * h; k++) {
-            const uint8_t* s = &px[4 * k];
-            const float alpha = (float)s[3] / 255.0f;
-            const float b = avg_b * (1.0f - alpha) + (alpha / 255.0f) * (float)s[0];
-            const float g = avg_g * (1.0f - alpha) + (alpha / 255.0f) * (float)s[1];
-            const float r = avg_r * (1.0f - alpha) + (alpha / 255.0f) * (float)s[2];
-            l.push_back((r + g + b) / 3.0f);
-            p.push_back((r + g) / 2.0f - b);
-            q.push_back(r - g);
-            a.push_back(alpha);
-        }
-    } else if (cn == 3) {
-        for (size_t k = 0; k < w * h; k++) {
-            const uint8_t* s = &px[3 * k];
-            const float b = (1.0f / 255.0f) * (float)s[0], g = (1.0f / 255.0f) * (float)s[1], r = (1.0f / 255.0f) * (float)s[2];
-            l.push_back((r + g + b) / 3.0f);
-            p.push_back((r + g) / 2.0f - b);
-            q.push_back(r - g);
-            a.push_back(1.0f);
-        }
-    } else {
-        for (size_t k = 0; k < w * h; k++) {
-            l.push_back((float)px[k] / 255.0f);
-            p.push_back(0.0f);
-            q.push_back(0.0f);
-            a.push_back(1.0f);
-        }
-    }
-    const size_t l_limit = has_alpha ? 5 : 7;
-    const size_t lx = std::max((size_t)roundf((float)(l_limit * w) / (float)std::max(w, h)), (size_t)1);
-    const size_t ly = std::max((size_t)roundf((float)(l_limit * h) / (float)std::max(w, h)), (size_t)1);
-    float l_dc, l_scale, p_dc, p_scale, q_dc, q_scale, a_dc = 1.0f, a_scale = 1.0f;
-    std::vector<float> l_ac, p_ac, q_ac, a_ac;
-    encode_channel(l, std::max(lx, (size_t)3), std::max(ly, (size_t)3), w, h, &l_dc, &l_ac, &l_scale);
-    encode_channel(p, 3, 3, w, h, &p_dc, &p_ac, &p_scale);
-    encode_channel(q, 3, 3, w, h, &q_dc, &q_ac, &q_scale);
-    if (has_alpha) encode_channel(a, 5, 5, w, h, &a_dc, &a_ac, &a_scale);
+    std::vector<float> planes(4 * n);
+    float *L = planes.data(), *P = L + n, *Q = P + n, *A = Q + n;
+    const bool translucent = opponent_planes(px.data(), n, cn, L, P, Q, A);
+
+    // luminance keeps up to 7 (5 with alpha) coefficients along the longer side, at least 3 per axis; chroma 3 x 3; alpha 5 x 5
+    const size_t longest = std::max(w, h), budget = translucent ? 5 : 7;
+    const size_t lum_x = std::max((size_t)roundf((float)(budget * w) / (float)longest), (size_t)1);
+    const size_t lum_y = std::max((size_t)roundf((float)(budget * h) / (float)longest), (size_t)1);
+    const size_t nx = std::max(lum_x, (size_t)3), ny = std::max(lum_y, (size_t)3);
+    CosTable tx, ty;
+    tx.build(w, std::max(nx, (size_t)5));
+    ty.build(h, std::max(ny, (size_t)5));
+    const ChannelCode lum = code_channel(L, w, h, nx, ny, tx, ty);
+    const ChannelCode yb = code_channel(P, w, h, 3, 3, tx, ty);
+    const ChannelCode rg = code_channel(Q, w, h, 3, 3, tx, ty);
+    ChannelCode alpha;
+    alpha.dc = 1.0f; alpha.scale = 1.0f;
+    if (translucent) alpha = code_channel(A, w, h, 5, 5, tx, ty);
+
+    // 24-bit header: L dc (6 bits), P dc (6), Q dc (6), L scale (5), alpha flag; 16-bit header: the shorter side's coefficient count
+    // (3 bits), P scale (6), Q scale (6), landscape flag (thumbhash.cpp:230-246)
     const bool landscape = w > h;
-    const uint32_t header24 = (uint32_t)roundf(63.0f * l_dc) | ((uint32_t)roundf(31.5f + 31.5f * p_dc) << 6) | ((uint32_t)roundf(31.5f + 31.5f * q_dc) << 12) |
-                              ((uint32_t)roundf(31.0f * l_scale) << 18) | (has_alpha ? 1u << 23 : 0u);
-    const uint16_t header16 = (uint16_t)((uint16_t)(landscape ? ly : lx) | ((uint16_t)roundf(63.0f * p_scale) << 3) | ((uint16_t)roundf(63.0f * q_scale) << 9) |
-                                         (landscape ? 1 << 15 : 0));
+    const uint32_t head24 = (uint32_t)roundf(63.0f * lum.dc) | ((uint32_t)roundf(31.5f + 31.5f * yb.dc) << 6) | ((uint32_t)roundf(31.5f + 31.5f * rg.dc) << 12) |
+                            ((uint32_t)roundf(31.0f * lum.scale) << 18) | (translucent ? 1u << 23 : 0u);
+    const uint16_t head16 = (uint16_t)((uint16_t)(landscape ? lum_y : lum_x) | ((uint16_t)roundf(63.0f * yb.scale) << 3) | ((uint16_t)roundf(63.0f * rg.scale) << 9) |
+                                       (landscape ? 1 << 15 : 0));
     std::vector<uint8_t> hash;
-    hash.reserve(25);
-    hash.push_back((uint8_t)(header24 & 255));
-    hash.push_back((uint8_t)((header24 >> 8) & 255));
-    hash.push_back((uint8_t)(header24 >> 16));
-    hash.push_back((uint8_t)(header16 & 255));
-    hash.push_back((uint8_t)(header16 >> 8));
-    if (has_alpha) hash.push_back((uint8_t)((uint8_t)roundf(15.0f * a_dc) | ((uint8_t)roundf(15.0f * a_scale) << 4)));
-    bool odd = false;
-    auto pack = [&](const std::vector<float>& ac) {
-        for (float f : ac) {
-            const uint8_t u = (uint8_t)roundf(15.0f * f);
-            if (odd) hash.back() |= (uint8_t)(u << 4);
-            else hash.push_back(u);
-            odd = !odd;
-        }
-    };
-    pack(l_ac); pack(p_ac); pack(q_ac);
-    if (has_alpha) pack(a_ac);
+    hash.reserve(32);
+    for (int k = 0; k < 3; k++) hash.push_back((uint8_t)(head24 >> (8 * k)));
+    hash.push_back((uint8_t)(head16 & 255));
+    hash.push_back((uint8_t)(head16 >> 8));
+    if (translucent) hash.push_back((uint8_t)((uint8_t)roundf(15.0f * alpha.dc) | ((uint8_t)roundf(15.0f * alpha.scale) << 4)));
+    NibbleWriter nib{hash};
+    nib.put(lum.ac); nib.put(yb.ac); nib.put(rg.ac);
+    if (translucent) nib.put(alpha.ac);
     if (hash.size() > e->dst_len) return -1;
     memcpy(e->dst, hash.data(), hash.size());
     return (int)hash.size();
