@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -39,6 +40,81 @@ struct LpBatchPart {
 
 struct LpOtherItem { int item; const uint8_t* data; size_t len; size_t dst_cap; std::vector<uint8_t> copy; };
 
+// Long-lived helper threads of a batch for the items the one-image path serves (PNG, GIF, WebP, handed-over pixels): a worker keeps
+// its per-thread engine (stream + arenas) from one batch to the next instead of building and tearing one down per call.
+struct LpWorkerPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable wake, idle;
+    std::function<void(size_t)> job;
+    size_t gen = 0, want = 0, running = 0;
+    bool stop = false;
+    void body(size_t wi)
+    {
+        size_t seen = 0;
+        for (;;) {
+            std::function<void(size_t)> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                wake.wait(lk, [&] { return stop || (gen != seen && wi < want); });
+                if (stop) return;
+                seen = gen;
+                f = job;
+            }
+            f(wi + 1); // worker 0 is the calling thread
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--running == 0) idle.notify_all();
+            }
+        }
+    }
+    // runs f(1 .. n) on the pool and f(0) on the caller; returns when all are done
+    void run(size_t n, const std::function<void(size_t)>& f)
+    {
+        if (n) {
+            std::lock_guard<std::mutex> lk(m);
+            while (th.size() < n) { const size_t wi = th.size(); th.emplace_back([this, wi] { body(wi); }); }
+            job = f; want = n; running = n; gen++;
+        }
+        if (n) wake.notify_all();
+        f(0);
+        if (n) {
+            std::unique_lock<std::mutex> lk(m);
+            idle.wait(lk, [&] { return running == 0; });
+        }
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(m); if (stop) return; stop = true; }
+        wake.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+    LpWorkerPool() { registry(this, true); }
+    ~LpWorkerPool() { shutdown(); registry(this, false); }
+    // Pools that are still alive when the process exits are stopped from an atexit handler registered after the HIP runtime's own, so
+    // it runs before it: a worker's per-thread engine frees its stream and arenas while the runtime is still there (a thread that is
+    // torn down during or after the runtime's shutdown was seen to abort the process once in a handful of runs).
+    static void registry(LpWorkerPool* p, bool add)
+    {
+        static std::mutex rm;
+        static std::vector<LpWorkerPool*>* live = new std::vector<LpWorkerPool*>(); // never destroyed: used from atexit
+        static bool hooked = false;
+        std::lock_guard<std::mutex> lk(rm);
+        if (add) {
+            live->push_back(p);
+            if (!hooked) {
+                hooked = true;
+                atexit([] { registry(nullptr, false); });
+            }
+        } else if (p) {
+            live->erase(std::remove(live->begin(), live->end(), p), live->end());
+        } else {
+            for (LpWorkerPool* q : *live) q->shutdown();
+        }
+    }
+};
+
 struct LpBatch {
     int device = 0;
     std::vector<LpBatchPart> parts;
@@ -56,6 +132,7 @@ struct LpBatch {
     // transformed one by one on a few host workers while the JPEG parts run
     std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
+    LpWorkerPool pool;
     hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
     int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
     size_t last_images = 0;                    // images this device's engines served in the last transform
@@ -569,10 +646,7 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
         }
         (void)lp_thread_device(prev_dev);
     };
-    std::vector<std::thread> th;
-    for (size_t wi = 1; wi < nw; wi++) th.emplace_back(worker, wi);
-    worker(0);
-    for (auto& t : th) t.join();
+    b->pool.run(nw - 1, worker);
 }
 
 static void begin_run(LpBatch* b, size_t n)
