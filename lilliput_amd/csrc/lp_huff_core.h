@@ -36,6 +36,13 @@
 #else
 #define LP_HD inline
 #endif
+// Inside a branch on a wave-uniform condition: keeps it a scalar branch. Without it the compiler folds the uniform test into the
+// per-lane condition that follows and evaluates both in every iteration (the ring top-up test ran every step instead of every second).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LP_KEEP_UNIFORM_BRANCH() asm volatile("")
+#else
+#define LP_KEEP_UNIFORM_BRANCH() ((void)0)
+#endif
 
 // zigzag index -> natural (row-major) index; 16 guard entries like libjpeg's jpeg_natural_order
 #define LP_ZIGZAG_INIT                                                                                    \
@@ -63,7 +70,7 @@ struct LpImgCtx {
 // Memory policy M must provide (per lane object, non-const):
 //   uint32_t fetch1(uint32_t w)             word w of the clean stream (big-endian corrected: bit 31 first); w within the ring window
 //   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
-//   void topup(uint32_t w)                  wave-uniform call every kEvery steps: words below w are dead, refill
+//   void topup(uint32_t p)                  wave-uniform call every kEvery steps with the lane's bit position: words below p >> 5 are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
 //   uint32_t lut(uint32_t tbl, uint32_t i), lut2(uint32_t i)   first-level entry of table tbl, entry i of the second-level pool
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
@@ -79,13 +86,13 @@ struct LpLane {
     const LpImgCtx& ic;
     uint32_t p;         // bit position of the next unread bit
     uint32_t z;         // zigzag index of the next coefficient (0 = a block starts here)
-    uint32_t b;         // block-in-MCU
-    uint32_t rot;       // ic.blkpack rotated right by 4*b: the low nibble describes the current block
+    uint32_t b4;        // 4 x block-in-MCU: the shift that brings the current block's nibble of ic.blkpack down (one add + compare per block
+                        // end; the first version also kept the rotated nibble string: four more VALU instructions in every step)
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
     uint32_t w0, w1, w2; // stream words (p >> 5), + 1, + 2
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b(0), rot(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b4(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
 
     LP_HD uint32_t peek() const { return (uint32_t)(((((uint64_t)w0) << 32) | w1) << (p & 31u) >> 32); }
     LP_HD void load_window() // after a jump (m.reseek has been called)
@@ -106,12 +113,7 @@ struct LpLane {
         w2 = m.fetch1((pn >> 5) + 2u);
         p = pn;
     }
-    LP_HD void set_block(uint32_t nb)
-    {
-        b = nb;
-        const uint32_t span = 4u * ic.bpm; // rotate inside the low 4*bpm bits
-        rot = nb ? ((ic.blkpack >> (4u * nb)) | (ic.blkpack << (span - 4u * nb))) & (span >= 32u ? 0xffffffffu : (1u << span) - 1u) : ic.blkpack;
-    }
+    LP_HD void set_block(uint32_t nb) { b4 = 4u * nb; }
     LP_HD void start(uint32_t pos, uint32_t bz)
     {
         p = pos;
@@ -132,7 +134,7 @@ struct LpLane {
             m.settle(next_rst);
         }
     }
-    LP_HD uint32_t state_bz() const { return (b << 8) | z; }
+    LP_HD uint32_t state_bz() const { return (b4 << 6) | z; } // (block-in-MCU << 8) | zigzag index
 
     // At a block start: detect the end of a restart interval (or of the stream). `pk` = peek(). Returns true when
     // the lane jumped to the boundary (DC predictors must be reset by the caller, and peek() must be redone).
@@ -206,7 +208,7 @@ struct LpLane {
         r.is_dc = (z == 0);
         // DC table id = bit 2 of the block's nibble, AC table id = bit 3 (+2); written as arithmetic so that it compiles to
         // selects, not to an exec-mask branch pair
-        const uint32_t tbl = ((rot >> (r.is_dc ? 2u : 3u)) & 1u) + (r.is_dc ? 0u : 2u);
+        const uint32_t tbl = ((ic.blkpack >> (b4 + (r.is_dc ? 2u : 3u))) & 1u) + (r.is_dc ? 0u : 2u);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
         if ((e & 0x1f00u) == 0) e = long_code(tbl, e, pk >> 16);
         const uint32_t len = (e >> 8) & 31u;
@@ -229,11 +231,9 @@ struct LpLane {
         const uint32_t zn = eob ? 64u : r.k + 1u; // ZRL (run 15, size 0) skips 16 coefficients: k + 1 == z + 16
         r.block_done = zn >= 64;
         z = r.block_done ? 0u : zn;
-        // next block of the MCU (rotation of the nibble string); branch-free
-        const uint32_t nb = b + 1 == ic.bpm ? 0u : b + 1;
-        const uint32_t nrot = (rot >> 4) | ((rot & 15u) << (4u * (ic.bpm - 1u)));
-        b = r.block_done ? nb : b;
-        rot = r.block_done ? nrot : rot;
+        // next block of the MCU; branch-free
+        const uint32_t nb4 = b4 + 4u == 4u * ic.bpm ? 0u : b4 + 4u;
+        b4 = r.block_done ? nb4 : b4;
         return r;
     }
 };
@@ -317,7 +317,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     // Single back edge, no `continue`: the register allocator then updates the lane state in place (the first version of
     // this loop carried ~30 v_mov copies per iteration across its exits).
     do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
         uint32_t pk = L.peek();
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) { // rare even per wave: a restart boundary or the stream end is near
             if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
@@ -366,7 +366,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
     uint32_t cp = K ? ck.pos(0) : 0xffffffffu;
     bool done = false, spliced = false;
     do { // same shape as the SPEC loop: one back edge, state updated in place
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
         uint32_t pk = L.peek();
         iter++;
         if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
@@ -429,7 +429,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     bool writing = false, done = false;
     uint32_t written = 0, iter = 0;
     do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) m.topup(L.p >> 5);
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
         if ((iter % LP_FLUSH_EVERY) == LP_FLUSH_EVERY - 1) sink.flush();
         uint32_t pk = L.peek();
         iter++;

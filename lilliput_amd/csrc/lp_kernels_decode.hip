@@ -205,54 +205,73 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
 template <int R, int T, int Q>
 struct DevMem {
     static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R;
-    const uint32_t* words;  // this image's clean stream (16-byte aligned)
+    __amdgpu_buffer_rsrc_t words; // this image's clean stream as a raw buffer: a 32-bit byte offset per lane instead of 64-bit address
+                                  // arithmetic in the loop, and reads past the image's region return 0
     uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % R) * 64]
-    uint32_t fill;          // next stream word to load (multiple of 4)
+    uint32_t fbits;         // next stream word to load, as a BIT position (a multiple of 128): the top-up test compares it with the
+                            // lane's bit position directly
     const LpHuffSet* hs;    // LDS: the lookup part (lut, lut2) only
     const LpHuffSet* hsg;   // HBM: the whole set; the canonical tables are read on damaged streams only
     const uint32_t* rst;
     uint4 pend[Q];          // see reseek / topup
+    static __device__ __forceinline__ DevMem make(const uint32_t* stream, uint32_t cap_words, uint32_t* ring_, const LpHuffSet* hs_, const LpHuffSet* hsg_,
+                                                  const uint32_t* rst_)
+    {
+        DevMem m;
+        m.words = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(stream), 0, (int)(cap_words * 4u), 0x00020000);
+        m.ring = ring_; m.fbits = 0; m.hs = hs_; m.hsg = hsg_; m.rst = rst_;
+        return m;
+    }
     __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[(w & (R - 1u)) << 6]; }
-    // The next Q quads of the stream ([fill, fill + 4Q) words) travel in registers: a top-up stores what the previous top-up
-    // loaded and issues the loads for the one after, so no wave ever sits in s_waitcnt vmcnt(0) behind an HBM round trip
-    // (the first version loaded and stored in the same top-up: PMC showed SPEC at 40 % and WRITE at 20 % of the VALU issue rate).
-    __device__ __forceinline__ uint4 load_words(uint32_t w) const { return *reinterpret_cast<const uint4*>(words + w); }
+    // The next Q quads of the stream travel in registers: a top-up stores what the previous top-up loaded and issues the loads for the
+    // one after, so no wave ever sits in s_waitcnt vmcnt(0) behind an HBM round trip (the first version loaded and stored in the same
+    // top-up: PMC showed SPEC at 40 % and WRITE at 20 % of the VALU issue rate).
+    __device__ __forceinline__ uint4 load_quad(uint32_t bits) const
+    {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(words, (int)(bits >> 3), 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
     __device__ __forceinline__ void store_quad(const uint4& v)
     {
-        uint32_t* r = ring + ((fill & (R - 1u)) << 6); // fill is a multiple of 4: the quad never wraps
+        uint32_t* r = ring + (((fbits >> 5) & (R - 1u)) << 6); // the quad never wraps: fbits / 32 is a multiple of 4
         r[0] = v.x;
         r[64] = v.y;
         r[128] = v.z;
         r[192] = v.w;
-        fill += 4;
+        fbits += 128u;
     }
     __device__ __forceinline__ void reseek(uint32_t w)
     {
-        fill = w & ~3u;
+        fbits = (w & ~3u) << 5;
 #pragma unroll
-        for (int i = 0; i < R / 4; i++) store_quad(load_words(fill));
+        for (int i = 0; i < R / 4; i++) store_quad(load_quad(fbits));
 #pragma unroll
-        for (int i = 0; i < Q; i++) pend[i] = load_words(fill + 4u * i);
+        for (int i = 0; i < Q; i++) pend[i] = load_quad(fbits + 128u * i);
     }
-    __device__ __forceinline__ void topup(uint32_t w)
+    // p = the lane's bit position. "fill + 4 <= (p >> 5) + R" in words is "fbits <= p + 32 R - 128" in bits (both sides of the word
+    // form are multiples of 32 bits).
+    __device__ __forceinline__ void topup(uint32_t p)
     {
-        if (fill + 4u <= w + R) {
+        if (fbits <= p + (32u * R - 128u)) {
             store_quad(pend[0]);
             if (Q == 2) {
-                if (fill + 4u <= w + R) {
+                if (fbits <= p + (32u * R - 128u)) {
                     store_quad(pend[Q - 1]);
-                    pend[0] = load_words(fill);
+                    pend[0] = load_quad(fbits);
                 } else
                     pend[0] = pend[Q - 1];
-                pend[Q - 1] = load_words(fill + 4u);
+                pend[Q - 1] = load_quad(fbits + 128u);
             } else
-                pend[0] = load_words(fill);
+                pend[0] = load_quad(fbits);
         }
     }
     // a value that came from a global load inside a rare branch: make the branch wait for it, so that the hot path carries no
     // s_waitcnt vmcnt for it (which would also wait for the prefetched quads, every iteration)
     __device__ __forceinline__ void settle(uint32_t& v) const { asm volatile("" : "+v"(v)); }
-    __device__ __forceinline__ bool any(bool p) const { return __any(p); }
+    // (a ballot compared with zero stays in scalar registers; __any() materialises the vote in a VGPR and compares it again: two VALU
+    // instructions per vote, three votes per decode step)
+    __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hsg->maxcode[t][l]; }
@@ -336,7 +355,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
     const bool valid = sub < nsub;
     const uint32_t g = img.sub_off + (valid ? sub : 0);
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+                      rst_bits + img.rst_off);
     LpSubState entry;
     const uint32_t S = img.sub_bits;
     entry.p = valid ? sub * S : 0;
@@ -413,7 +433,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
     stage_huff(s_hs4, huffs + img.huff_idx);
     if (!need) return;
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+                      rst_bits + img.rst_off);
     const uint32_t S = img.sub_bits;
     uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) {
@@ -605,7 +626,8 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     const bool idle = sub >= nsub;
     const uint32_t g = img.sub_off + (idle ? nsub - 1u : sub);
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m{clean_arena + img.clean_off, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), 0, s_hs, huffs + img.huff_idx, rst_bits + img.rst_off};
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+                      rst_bits + img.rst_off);
     LpSubState entry;
     entry.p = 0; entry.bz = 0;
     if (sub != 0 && !idle) entry = exits[g - 1];

@@ -27,7 +27,7 @@ struct HostMemT {
         return words[w];
     }
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
-    void topup(uint32_t w) { for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
+    void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
