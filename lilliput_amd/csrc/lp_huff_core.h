@@ -282,6 +282,9 @@ LP_HD void lp_ckpt_unpack(const LpCkptPk& k, LpSubState& st, LpSubSum& s)
 }
 
 LP_HD uint32_t lp_ck_iter(const LpCkSched& cs, uint32_t k) { return cs.it[k]; }
+// it[k] from it[k - 1] (0 for k == 0): the rule of lp_make_sched as arithmetic, so that the decode loop needs no table load (a scalar
+// load in the loop makes every iteration wait on lgkmcnt -- and with it on the lane's outstanding LDS reads)
+LP_HD uint32_t lp_ck_next(uint32_t base, uint32_t k, uint32_t prev) { return prev + ((k < 4 || prev / 2 < base) ? base : prev / 2); }
 
 // Schedule for subsequences of S bits; cbits tunes the first spacing (cbits / 32 iterations, 8 for the default 256).
 inline LpCkSched lp_make_sched(uint32_t S, uint32_t cbits)
@@ -290,9 +293,9 @@ inline LpCkSched lp_make_sched(uint32_t S, uint32_t cbits)
     const uint32_t base = cbits / 32 > 2 ? cbits / 32 : 2, span = S / 4 > base ? S / 4 : base; // a lane runs about S/6.5 iterations
     uint32_t v = 0;
     cs.K = 0;
+    cs.base = base;
     for (uint32_t k = 0; k < LP_MAX_CKPT; k++) {
-        const uint32_t step = k < 4 || v / 2 < base ? base : v / 2;
-        v += step;
+        v = lp_ck_next(base, k, v);
         cs.it[k] = v;
         cs.K = k + 1;
         if (v >= span) break;
@@ -311,7 +314,8 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     L.start(entry.p, entry.bz);
     LpSubSum sum;
     lp_sum_zero(sum);
-    uint32_t k = 0, iter = 0, next_ck = cs.K ? lp_ck_iter(cs, 0) : 0xffffffffu;
+    const uint32_t K = cs.K, ck_base = cs.base;
+    uint32_t k = 0, iter = 0, next_ck = K ? lp_ck_next(ck_base, 0, 0) : 0xffffffffu;
     bool done = false;
     // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off.
     // Single back edge, no `continue`: the register allocator then updates the lane state in place (the first version of
@@ -331,7 +335,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
             st.bz = L.state_bz();
             ck.record(k, lp_ckpt_pack(st, sum));
             k++;
-            next_ck = k < cs.K ? lp_ck_iter(cs, k) : 0xffffffffu;
+            next_ck = k < K ? lp_ck_next(ck_base, k, next_ck) : 0xffffffffu;
         }
         iter++;
         done = done || L.p >= sub_end;
@@ -342,7 +346,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     } while (m.any(!done));
     LpCkptPk none;
     none.p = 0xffffffffu; none.bz = 0; none.nblk = 0; none.nreset = 0;
-    for (; k < cs.K; k++) ck.record(k, none);
+    for (; k < K; k++) ck.record(k, none);
     exit_st->p = L.p;
     exit_st->bz = L.state_bz();
     *total = sum;

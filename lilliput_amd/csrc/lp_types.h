@@ -156,7 +156,7 @@ struct LpCkptPk {
 // Checkpoint schedule: checkpoint k is taken before iteration it[k] of the lane's decode loop. The spacing grows
 // geometrically (8, 16, 24, 32, 48, 72, ... for large images): a verifying lane re-synchronises within a few hundred bits
 // in the common case and can stop at the very next checkpoint, while 16 records still cover a whole subsequence.
-struct LpCkSched { uint32_t K; uint32_t it[LP_MAX_CKPT]; };
+struct LpCkSched { uint32_t K; uint32_t base; uint32_t it[LP_MAX_CKPT]; }; // it[] = the iterations; base = the first spacing (the kernels regenerate it[] from it)
 
 // ---------------------------------------------------------------------------------------------
 // Pixel frames and per-image operation descriptors (orientation, crop+resize, compositing, encode).
