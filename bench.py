@@ -221,7 +221,7 @@ def main():
         dom = max(src_tab.items(), key=lambda kv: kv[1][0])
         dom_ms, dom_bytes = dom[1]
         if dom_ms > 0:
-            launch_images = excl["launch_images"] if excl else min(args.chunk or 112, args.batch)
+            launch_images = excl["launch_images"] if excl else min(args.chunk or (32 if not args.resident else 113), args.batch)  # without the exclusive leg: the chunk size of the timed mode
             achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
             traffic = None
             try:  # HBM bytes of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE)

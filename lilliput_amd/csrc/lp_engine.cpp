@@ -1,6 +1,7 @@
 // lp_engine.cpp -- see lp_engine.h.
 #include "lp_engine.h"
 
+#include <emmintrin.h>
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -305,13 +306,31 @@ int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpeg
     return LP_OK;
 }
 
+// Staging copy into the pinned slot with streaming stores: the destination is written once and next read by the DMA engine, so
+// allocating its lines in the cache (a read-for-ownership of every line, which glibc's memcpy does for pieces of this size) is a
+// third of the DRAM traffic of the copy for nothing -- per GPU the stager moves ~50 GB/s, and eight ranks share two sockets.
+static void stream_copy(uint8_t* dst /* 16-byte aligned */, const uint8_t* src, size_t n)
+{
+    static const bool plain = getenv("LILLIPUT_HIP_STAGE_PLAIN_MEMCPY") != nullptr;
+    if (plain || n < 4096 || ((uintptr_t)dst & 15)) { memcpy(dst, src, n); return; }
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+        _mm_stream_si128((__m128i*)(dst + i), a); _mm_stream_si128((__m128i*)(dst + i + 16), b);
+        _mm_stream_si128((__m128i*)(dst + i + 32), c); _mm_stream_si128((__m128i*)(dst + i + 48), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
+
 void LpEngine::upload_copy(int slot, size_t p0, size_t p1)
 {
     LpUpload& u = up_[slot];
     uint8_t* stage = u.stage.as<uint8_t>();
     for (size_t q = p0; q < p1 && q < u.pieces.size(); q++) {
         const LpUpload::Piece& pc = u.pieces[q];
-        memcpy(stage + pc.arena_off, pc.src, pc.len);
+        stream_copy(stage + pc.arena_off, pc.src, pc.len);
         memset(stage + pc.arena_off + pc.len, 0, 32);
     }
 }
