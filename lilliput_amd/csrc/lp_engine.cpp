@@ -37,7 +37,10 @@ LpDevBuf::~LpDevBuf() { if (p) (void)hipFree(p); }
 bool LpDevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    // Growing replaces the block. Stages of a chunk are enqueued back to back without host synchronisation, so a kernel that is
+    // still in flight may hold the old address: wait for the device before the old block goes away (growth happens in the first
+    // chunks of an engine's life; the wait is noise there).
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
     if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
     cap = want;
@@ -47,7 +50,7 @@ LpPinned::~LpPinned() { if (p) (void)hipHostFree(p); }
 bool LpPinned::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; } // kernels read and write these blocks through their device alias
     size_t want = bytes + bytes / 8 + 256;
     if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; return false; }
     if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) dev = p; // unified addressing: the same pointer
@@ -154,6 +157,12 @@ size_t LpEngine::resident_round(size_t max_raw_len)
     return (size_t)std::max<uint64_t>(16, std::min<uint64_t>(512, slots / std::max<uint64_t>(1, wgs)));
 }
 
+// The unstuff kernels read whole 4 KiB chunks (16 bytes per lane, unconditionally): the last chunk of the last segment reaches up to 4095
+// bytes past the data, so the arena carries that much padding. (With only the growth slack of LpDevBuf a small upload -- three small
+// files -- read past its allocation: a GPU memory fault whenever the block happened to end a mapped region, one run in four of the
+// two-slot node test.)
+static const size_t kRawPad = 4096 + 64;
+
 // Descriptors and arena layout of one set of sources (slot `slot`): every entropy-coded segment becomes a piece at a 16-byte
 // aligned arena offset followed by 32 zero bytes. whole = size the slot's pinned buffer for the whole set (staged uploads).
 static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs)
@@ -250,7 +259,7 @@ int LpEngine::upload_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
     if (!host_scan_decode(u, n, hdrs)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
     const size_t raw_bytes = u.raw_bytes;
     const size_t kStage = 256u << 20; // pinned staging window
-    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(raw_bytes + 64) ||
+    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(raw_bytes + kRawPad) ||
         !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
         !u.stage.ensure(std::min(raw_bytes, kStage) + (16u << 20) + 64)) {
         err_ = "device allocation failed";
@@ -296,7 +305,7 @@ int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpeg
     u.staged_whole = true;
     layout_set(u, srcs, n, hdrs);
     if (!u.ready && !check(hipEventCreateWithFlags(&u.ready, hipEventDisableTiming), "hipEventCreate")) return LP_ERR_DEVICE;
-    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(u.raw_bytes + 64) ||
+    if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(u.raw_bytes + kRawPad) ||
         !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
         !u.stage.ensure(align_up(u.raw_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64)) {
         err_ = "device allocation failed";
@@ -688,7 +697,7 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     if (!check(hipMemcpyAsync(wid.data(), d_wide_id_.as<uint32_t>() + j.coef_off / 64, nb * 4, hipMemcpyDeviceToHost, stream_), "D2H wide ids")) return LP_ERR_DEVICE;
     int rc = sync();
     if (rc) return rc;
-    const uint32_t n_wide = h_states_[(size_t)i].n_wide;
+    const uint32_t n_wide = std::min<uint32_t>(h_states_[(size_t)i].n_wide, (uint32_t)nb); // never more slots than blocks
     std::vector<int16_t> wide((size_t)n_wide * 64);
     if (n_wide) {
         if (!check(hipMemcpyAsync(wide.data(), d_wide_.as<int16_t>() + j.coef_off, wide.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H wide")) return LP_ERR_DEVICE;

@@ -508,6 +508,7 @@ struct DevSink {
     uint32_t* wide_id;      // this image's block -> wide slot
     uint32_t* n_wide;       // this image's wide-slot counter
     uint32_t wslot;         // wide slot of the current block, 0xffffffff = none
+    uint32_t wide_cap;      // slots in this image's wide arena (= its block count)
     int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
                             // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
     int32_t dcv;            // DC difference of the current block
@@ -529,7 +530,11 @@ struct DevSink {
 #endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
-            wide[(size_t)wslot * 64 + nat] = (int16_t)v;
+            // A settled decode hands out at most one slot per block. A pass over UNSETTLED exit states (the deferred chunk whose verify
+            // rounds were not enough: it is decoded again afterwards) lets subsequences overlap, so more slots than blocks can be asked
+            // for: those writes are dropped instead of running off the image's wide arena (seen as a GPU memory fault, one run in five,
+            // with noisy 1024 x 1024 sources in 3-image chunks).
+            if (wslot < wide_cap) wide[(size_t)wslot * 64 + nat] = (int16_t)v;
             v = -128;
         }
         slot[((nat >> 4) << 10) | (nat & 15u)] = (int8_t)v;
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wide_id = wide_id_arena + img.coef_off / 64;
     sink.n_wide = &st.n_wide;
     sink.wslot = 0xffffffffu;
+    sink.wide_cap = img.total_blocks;
     sink.dc16 = dc_arena + img.coef_off / 64;
     sink.dcv = 0;
     sink.dq0 = sink.dq1 = sink.dq2 = sink.dq3 = 0;

@@ -343,9 +343,16 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
     const int32_t dw = (W + 1) >> 1, dh = (H + 1) >> 1;
     const int32_t cx0 = fx0 >> 1, cy0 = fy0 >> 1, nrows = (int32_t)(op.rh >> 1);
     const bool has_l = cx0 > 0, has_r = cx0 + RWC <= dw - 1;
+    // Packed arithmetic (v_pk_*_u16): a chroma sample travels as {Cb, Cr} in the two halves of one register, so the vertical and the
+    // horizontal pass of the upsampler run once for both planes (every intermediate fits 16 bits: at most 3 * 1020 + 1020 + 8); a pixel's
+    // three channels are computed as 32-bit sums whose upper halves are the channel values, two pixels' halves are packed with one
+    // v_perm, clamped with one v_sat_pk_u8_i16 and added to the box sum with one v_sad_u8. About 17 instead of 23 instructions per
+    // source pixel (the kernel is instruction-issue bound, profiles/r02_e_final.md); the arithmetic is exactly jdsample.c / jdcolor.c's.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto pk = [](uint32_t v) { return __builtin_bit_cast(u16x2, v); };
     // chroma row r of both planes -> RWC + 2 samples (index 0 = left neighbour, RWC + 1 = right neighbour; replicated at the edges)
-    int32_t cbw[3][RWC + 2], crw[3][RWC + 2];
-    auto load_row = [&](int32_t r, int32_t* cb, int32_t* cr) {
+    uint32_t P[3][RWC + 2];
+    auto load_row = [&](int32_t r, uint32_t* row) {
         r = r < 0 ? 0 : r > dh - 1 ? dh - 1 : r;
         const uint8_t* b = PB + (size_t)r * sc_ + cx0;
         const uint8_t* c = PR + (size_t)r * sc_ + cx0;
@@ -360,22 +367,19 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
             wc[0] = vc.x; wc[1 % (RWC / 4)] = vc.y; wc[2 % (RWC / 4)] = vc.z; wc[3 % (RWC / 4)] = vc.w;
         }
 #pragma unroll
-        for (int i = 0; i < RWC; i++) {
-            cb[i + 1] = (int32_t)((wb[i >> 2] >> (8 * (i & 3))) & 255u);
-            cr[i + 1] = (int32_t)((wc[i >> 2] >> (8 * (i & 3))) & 255u);
-        }
-        cb[0] = has_l ? (int32_t)b[-1] : cb[1];
-        cr[0] = has_l ? (int32_t)c[-1] : cr[1];
-        cb[RWC + 1] = has_r ? (int32_t)b[RWC] : cb[RWC];
-        cr[RWC + 1] = has_r ? (int32_t)c[RWC] : cr[RWC];
+        for (int i = 0; i < RWC; i++) // byte i of the Cb word -> bits 0..7, byte i of the Cr word -> bits 16..23: one v_perm_b32
+            row[i + 1] = __builtin_amdgcn_perm(wc[i >> 2], wb[i >> 2], 0x0c000c00u | ((4u + (i & 3)) << 16) | (uint32_t)(i & 3));
+        row[0] = has_l ? (uint32_t)b[-1] | ((uint32_t)c[-1] << 16) : row[1];
+        row[RWC + 1] = has_r ? (uint32_t)b[RWC] | ((uint32_t)c[RWC] << 16) : row[RWC];
     };
-    load_row(cy0 - 1, cbw[0], crw[0]);
-    load_row(cy0, cbw[1], crw[1]);
-    int32_t sb = 0, sg = 0, sr = 0;
+    load_row(cy0 - 1, P[0]);
+    load_row(cy0, P[1]);
+    uint32_t sb = 0, sg = 0, sr = 0;
     const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
     const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
+    auto sat_pk = [](uint32_t x) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x)); return d; }; // two signed halves -> two bytes clamped to 0..255
     for (int32_t q = 0; q < nrows; q++) {
-        load_row(cy0 + q + 1, cbw[2], crw[2]);
+        load_row(cy0 + q + 1, P[2]);
         // luma rows 2q and 2q+1 of the box
         uint32_t ly[2][RWC / 2];
 #pragma unroll
@@ -394,34 +398,38 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
             // vertical pass: 3 * this row + the nearer neighbour row (above for the upper output row, below for the lower one)
-            int32_t vb[RWC + 2], vr[RWC + 2];
+            u16x2 V[RWC + 2];
 #pragma unroll
-            for (int i = 0; i < RWC + 2; i++) {
-                vb[i] = 3 * cbw[1][i] + cbw[rr ? 2 : 0][i];
-                vr[i] = 3 * crw[1][i] + crw[rr ? 2 : 0][i];
-            }
+            for (int i = 0; i < RWC + 2; i++) V[i] = pk(P[1][i]) * (u16x2){3, 3} + pk(P[rr ? 2 : 0][i]);
 #pragma unroll
             for (int i = 0; i < RWC; i++) {
+                // horizontal pass: even output column leans on the left neighbour (+8), odd on the right one (+7)
+                const u16x2 c3 = V[i + 1] * (u16x2){3, 3};
+                const uint32_t H[2] = {__builtin_bit_cast(uint32_t, (u16x2)((c3 + V[i] + (u16x2){8, 8}) >> (u16x2){4, 4})),
+                                       __builtin_bit_cast(uint32_t, (u16x2)((c3 + V[i + 2] + (u16x2){7, 7}) >> (u16x2){4, 4}))};
+                uint32_t Tr[2], Tg[2], Tb[2];
 #pragma unroll
                 for (int hx = 0; hx < 2; hx++) {
-                    // horizontal pass: even output column leans on the left neighbour (+8), odd on the right one (+7)
-                    const int32_t cb = (3 * vb[i + 1] + vb[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
-                    const int32_t cr = (3 * vr[i + 1] + vr[hx ? i + 2 : i] + (hx ? 7 : 8)) >> 4;
-                    const int32_t px = 2 * i + hx;
-                    const int32_t yy = (int32_t)((ly[rr][px >> 2] >> (8 * (px & 3))) & 255u);
+                    const int32_t cb = (int32_t)(H[hx] & 0xffffu), cr = (int32_t)(H[hx] >> 16);
+                    const int px = 2 * i + hx;
+                    // the luma sample in bits 16..23: channel = (luma << 16 + fixed-point chroma term) >> 16, read off as the upper half
+                    const uint32_t yk = __builtin_amdgcn_perm(0u, ly[rr][px >> 2], 0x0c000c0cu | ((uint32_t)(px & 3) << 16));
                     // jdcolor.c ycc_rgb_convert with the -128 offsets folded into the rounding constants
-                    const int32_t r = yy + ((FIX16(1.40200) * cr + KR) >> 16);
-                    const int32_t b = yy + ((FIX16(1.77200) * cb + KB) >> 16);
-                    const int32_t g = yy + ((-FIX16(0.34414) * cb - FIX16(0.71414) * cr + KG) >> 16);
-                    sb += (int32_t)clamp8(b); sg += (int32_t)clamp8(g); sr += (int32_t)clamp8(r);
+                    Tr[hx] = (uint32_t)(FIX16(1.40200) * cr + (int32_t)(yk + (uint32_t)KR));
+                    Tb[hx] = (uint32_t)(FIX16(1.77200) * cb + (int32_t)(yk + (uint32_t)KB));
+                    Tg[hx] = (uint32_t)(-FIX16(0.34414) * cb - FIX16(0.71414) * cr + (int32_t)(yk + (uint32_t)KG));
                 }
+                // upper halves of the two pixels side by side, clamped to bytes, summed
+                sr = __builtin_amdgcn_sad_u8(sat_pk(__builtin_amdgcn_perm(Tr[1], Tr[0], 0x07060302u)), 0u, sr);
+                sg = __builtin_amdgcn_sad_u8(sat_pk(__builtin_amdgcn_perm(Tg[1], Tg[0], 0x07060302u)), 0u, sg);
+                sb = __builtin_amdgcn_sad_u8(sat_pk(__builtin_amdgcn_perm(Tb[1], Tb[0], 0x07060302u)), 0u, sb);
             }
         }
 #pragma unroll
-        for (int i = 0; i < RWC + 2; i++) { cbw[0][i] = cbw[1][i]; cbw[1][i] = cbw[2][i]; crw[0][i] = crw[1][i]; crw[1][i] = crw[2][i]; }
+        for (int i = 0; i < RWC + 2; i++) { P[0][i] = P[1][i]; P[1][i] = P[2][i]; }
     }
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    const int32_t sums[3] = {sb, sg, sr};
+    const int32_t sums[3] = {(int32_t)sb, (int32_t)sg, (int32_t)sr};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         uint32_t r;
