@@ -72,6 +72,7 @@ struct LpImgCtx {
 //   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
 //   void topup(uint32_t p)                  wave-uniform call every kEvery steps with the lane's bit position: words below p >> 5 are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
+//   bool any_lt8(int32_t v)                 wave vote on v < 8 (see lp_near_boundary)
 //   uint32_t lut(uint32_t tbl, uint32_t i), lut2(uint32_t i)   first-level entry of table tbl, entry i of the second-level pool
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
@@ -238,6 +239,16 @@ struct LpLane {
     }
 };
 
+// "Is a restart boundary (or the stream end) fewer than 8 bits ahead of a lane that stands at a block start and is still working?" as ONE
+// signed value to compare with 8: the bits to the boundary, raised to at least 8 * z (so a lane inside a block never qualifies) or to 8
+// when the lane is not working. The wave vote on `value < 8` is then a single v_cmp feeding the scalar branch; voting on the three
+// conditions as a boolean cost eleven instructions per decode step (the compiler materialises the boolean in a VGPR and compares it again).
+LP_HD int32_t lp_near_boundary(uint32_t next_rst, uint32_t p, uint32_t z, bool off)
+{
+    const int32_t rem = (int32_t)(next_rst - p), floor = off ? 8 : (int32_t)(z << 3);
+    return rem > floor ? rem : floor;
+}
+
 LP_HD bool lp_state_eq(const LpSubState& a, const LpSubState& b) { return a.p == b.p && a.bz == b.bz; }
 
 LP_HD void lp_sum_zero(LpSubSum& s)
@@ -323,7 +334,8 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     do {
         if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
         uint32_t pk = L.peek();
-        if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) { // rare even per wave: a restart boundary or the stream end is near
+        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, done))) { // rare even per wave: a restart boundary or the stream end is near
+            LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
                 sum.nreset++;
             }
@@ -373,7 +385,8 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
         if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
         uint32_t pk = L.peek();
         iter++;
-        if (m.any(!done && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
+        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, done))) {
+            LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.z == 0 && L.restart_check(pk)) {
                 sum.nreset++;
             }
@@ -438,7 +451,8 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         uint32_t pk = L.peek();
         iter++;
         const bool act = !done && !sink.stalled();
-        if (m.any(act && L.z == 0 && (int32_t)(L.next_rst - L.p) < 8)) {
+        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, !act))) {
+            LP_KEEP_UNIFORM_BRANCH();
             if (act && L.z == 0) (void)L.restart_check(pk); // DC predictors restart in k_dc_scan, by MCU index
             pk = L.peek();
         }

@@ -272,6 +272,7 @@ struct DevMem {
     // (a ballot compared with zero stays in scalar registers; __any() materialises the vote in a VGPR and compares it again: two VALU
     // instructions per vote, three votes per decode step)
     __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+    __device__ __forceinline__ bool any_lt8(int32_t v) const { return __builtin_amdgcn_ballot_w64(v < 8) != 0ull; }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hsg->maxcode[t][l]; }

@@ -29,6 +29,7 @@ struct HostMemT {
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
+    bool any_lt8(int32_t v) const { return v < 8; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
