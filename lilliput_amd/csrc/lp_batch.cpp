@@ -133,6 +133,8 @@ struct LpBatch {
     std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
     LpWorkerPool pool;
+    std::mutex retry_mu;
+    std::vector<int> retry;                     // baseline items the device decoder gave up on (too few blocks): decoded again libjpeg's way
     hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
     int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
     size_t last_images = 0;                    // images this device's engines served in the last transform
@@ -546,6 +548,10 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
         for (int k = 0; k < cnt; k++) {
             const size_t item = (size_t)item_of[k];
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
+            if (st[(size_t)k] == LP_ERR_DECODE_FAILED && sink.items && !hdrs[k].scan_path) { // see LpEngine::decode_jpegs
+                std::lock_guard<std::mutex> lk(b->retry_mu);
+                b->retry.push_back((int)item);
+            }
         }
     }
     lap(5);
@@ -867,6 +873,7 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
     b->parse_status.assign(n, LILLIPUT_OK);
     begin_run(b, n);
     b->other.clear();
+    b->retry.clear();
     size_t njpeg = 0;
     for (size_t i = 0; i < n; i++) {
         if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) b->other.push_back(LpOtherItem{(int)i, (const uint8_t*)items[i].src, items[i].src_len, items[i].dst_cap, {}});
@@ -917,6 +924,14 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
             }
         run_other(b, opt, items);
         for (auto& t : th) t.join();
+        if (!b->retry.empty()) { // short baseline streams: once more through the one-image path, whose decoder falls back to libjpeg's serial rule
+            b->other.clear();
+            std::sort(b->retry.begin(), b->retry.end());
+            for (int idx : b->retry) b->other.push_back(LpOtherItem{idx, (const uint8_t*)items[idx].src, items[idx].src_len, items[idx].dst_cap, {}});
+            b->retry.clear();
+            run_other(b, opt, items);
+            b->other.clear();
+        }
         for (LpBatch* d : devs) d->last_images = 0;
         for (size_t j = 0; j < sh.jobs.size(); j++) {
             if (sh.jobs[j].part >= 0) devs[(size_t)(sh.jobs[j].part / 16)]->last_images += sh.jobs[j].items.size();

@@ -734,7 +734,24 @@ int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
     int rc = upload_jpegs(srcs, n, hdrs);
     if (rc) return rc;
     rc = run_decode(0, n, frames, status, nullptr, false);
-    return rc == LP_RETRY ? LP_OK : rc;
+    if (rc == LP_RETRY) rc = LP_OK;
+    if (rc == LP_ERR_DEVICE) return rc; // anything else is the status of an image that failed
+    // A baseline stream that came up short of blocks (truncated upload, damaged data) is not an error to libjpeg: it warns, feeds zero
+    // bits to the MCU at hand and leaves the following MCUs untouched (grey). The serial scan decoder implements exactly that rule
+    // (lp_prog_core.h, pinned against libjpeg on damaged files), so such an image is decoded once more through it.
+    for (int i = 0; i < n; i++) {
+        if (status[i] != LP_ERR_DECODE_FAILED || hdrs[i].scan_path) continue;
+        LpJpegHeader again;
+        if (lp_jpeg_parse_opts(srcs[i].data, srcs[i].len, &again, true) != LP_PARSE_OK || !again.scan_path) continue;
+        int st = 0;
+        if (upload_jpegs(&srcs[i], 1, &again)) continue;
+        const int r2 = run_decode(0, 1, &frames[i], &st, nullptr, false);
+        if (r2 != LP_ERR_DEVICE) status[i] = st;
+    }
+    rc = LP_OK;
+    for (int i = 0; i < n; i++)
+        if (status[i]) rc = status[i];
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

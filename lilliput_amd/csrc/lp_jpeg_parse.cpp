@@ -135,7 +135,9 @@ static bool huff_table_valid(const uint8_t bits[17], const uint8_t* vals, bool i
     return true;
 }
 
-int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
+int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out) { return lp_jpeg_parse_opts(d, n, out, false); }
+
+int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force_scans)
 {
     *out = LpJpegHeader();
     memset(&out->j, 0, sizeof(out->j));
@@ -288,6 +290,7 @@ int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
                 // sampling factors the baseline kernels do not take (anything but luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma): same walk
                 if (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1 || j.hs[0] > 2 || j.vs[0] > 2)) seq_scans = true;
                 for (unsigned s = 0; s < ns; s++) seq_scans = seq_scans || cur[s] != (int)s || (p[2 + 2 * s] >> 4) > 1 || (p[2 + 2 * s] & 15) > 1;
+                seq_scans = seq_scans || force_scans;
             }
             if (ns > 1) { // jdinput.c per_scan_setup: an interleaved MCU holds at most D_MAX_BLOCKS_IN_MCU = 10 blocks
                 unsigned blocks = 0;

@@ -32,6 +32,10 @@ struct LpJpegHeader {
 
 // Parses up to SOS, locates the end of the scan, builds the decode tables.
 int lp_jpeg_parse(const uint8_t* data, size_t len, LpJpegHeader* out);
+// force_scans: take a sequential file scan by scan (LpProgScan::sequential, libjpeg's serial decode_mcu with its end-of-data rule) even
+// when the subsequence-parallel baseline kernels could take it -- how a baseline stream that came up short of blocks on the device
+// (truncated, damaged) is decoded again, to the pixels libjpeg returns for it.
+int lp_jpeg_parse_opts(const uint8_t* data, size_t len, LpJpegHeader* out, bool force_scans);
 
 // Build one table slot of an LpHuffSet from DHT counts/values.
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals);

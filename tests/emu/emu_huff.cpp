@@ -203,7 +203,7 @@ struct HostProgMem {
 extern "C" int emu_decode_coefs_progressive(const uint8_t* data, size_t len, int comp, int16_t* out, size_t cap_elems, int* bw, int* bh, int* nscans)
 {
     LpJpegHeader h;
-    int rc = lp_jpeg_parse(data, len, &h);
+    int rc = lp_jpeg_parse_opts(data, len, &h, *nscans < 0); // *nscans < 0 on entry: force the scan-by-scan walk on a baseline file
     if (rc) return -rc;
     if (!h.scan_path) return -20;
     const LpJpeg& img = h.j;

@@ -119,15 +119,47 @@ def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
     with pytest.raises(lilliput_amd.LilliputError) as e:
         batch.decode_jpeg(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
     assert e.value.code == 1
-    with pytest.raises(lilliput_amd.LilliputError) as e:
-        batch.decode_jpeg(data[: len(data) // 2])  # truncated entropy-coded segment: too few blocks
-    assert e.value.code == 2
+
+
+def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes):
+    """A baseline stream that ends before its last block (truncated upload) or loses blocks to damage is not an error to libjpeg: it
+    warns, feeds zero bits to the MCU at hand and leaves the following MCUs untouched (flat grey). The device decoder notices the
+    missing blocks and the image is decoded once more by the serial scan decoder, which implements libjpeg's rule: coefficients and
+    pixels must equal the reference's own libjpeg-turbo (oracle/_ref; the C restatement does not model the rule for baseline files).
+    Round 1 answered ErrDecodingFailed here. What the reference's patched OpenCV source manager does at the end of a truncated
+    memory buffer cannot be checked (its archives are unlinkable): this pins the codec's behaviour, not OpenCV's."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    import lilliput_amd as la
+
+    n = 0
+    for name in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg", "coast.jpg", "large-sunrise.jpg"):
+        data = fixture_bytes[name]
+        for frac in (0.3, 0.5, 0.8, 0.95):
+            cut = data[: int(len(data) * frac)]
+            px, _ = batch.decode_jpeg(cut)
+            assert np.array_equal(px, oracle.ref_jpeg_decode(cut)), (name, frac)
+            n += 1
+    assert n == 20
+    # through the whole transform, one image at a time and as a batch item next to an intact one
+    cut = fixture_bytes["coast.jpg"][: len(fixture_bytes["coast.jpg"]) * 2 // 3]
+    want = oracle.jpeg_encode(oracle.transform_static(oracle.ref_jpeg_decode(cut), 1, 64, 48, oracle.FIT, False), 85)
+    d = la.Decoder(cut)
+    ops = la.ImageOps(2048)
+    got = ops.Transform(d, la.ImageOptions(".jpeg", 64, 48, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85}, EncodeTimeout=10**10))
+    ops.Close()
+    d.Close()
+    assert got == want
+    b = la.Batch(0)
+    res = b.transform([fixture_bytes["coast.jpg"], cut, fixture_bytes["field.jpg"]], 64, 48, quality=85)
+    b.close()
+    assert [r.status for r in res] == [0, 0, 0] and res[1].data == want
 
 
 def test_corrupt_streams_never_hang_and_are_deterministic(batch):
-    """Robustness: random byte damage / truncation inside the entropy-coded segment. Every item must come back with a
-    lilliput status (decode succeeded on garbage, ErrDecodingFailed, ErrInvalidImage or unsupported) -- no hang, no device
-    fault -- and the same damaged input must give the same answer twice (no dependence on stale device memory)."""
+    """Robustness: random byte damage / truncation inside the entropy-coded segment. Every item must come back decoded (what the
+    device decoder cannot finish goes through the serial scan decoder, test_short_baseline_streams_decode_like_libjpeg) -- no hang,
+    no device fault -- and the same damaged input must give the same answer twice (no dependence on stale device memory)."""
     from PIL import Image
 
     from lilliput_amd import synth
@@ -160,7 +192,8 @@ def test_corrupt_streams_never_hang_and_are_deterministic(batch):
     for a, b2 in zip(r1, r2):
         assert a.status in (0, 1, 2, 4)
         assert a.status == b2.status and a.data == b2.data
-    assert any(a.status == 0 for a in r1) and any(a.status != 0 for a in r1)
+    # libjpeg never fails on damaged entropy data (it warns and carries on); since the short-stream fallback neither does this path
+    assert all(a.status == 0 for a in r1), [a.status for a in r1]
     # and the engine is still healthy afterwards
     ok = batch.transform([bases[0]], 64, 64, quality=80)[0]
     assert ok.status == 0 and len(ok.data) > 300
@@ -450,7 +483,12 @@ def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
         assert r.status == 0, n
         _check_thumbnail(la, ops, oracle, fixture_bytes[n], r.data, 64, 64, 85, n)
     ops.Close()
-    assert res[-2].status == 1 and res[-1].status == 2
+    assert res[-2].status == 1
+    # the truncated file decodes like libjpeg decodes it (the part that arrived, grey below): test_short_baseline_streams_decode_like_libjpeg
+    assert res[-1].status == 0
+    if oracle.ref() is not None:
+        cut = oracle.ref_jpeg_decode(sources[-1])
+        assert res[-1].data == oracle.jpeg_encode(oracle.transform_static(cut, oracle.jpeg_info(sources[-1])["orientation"], 64, 64, oracle.FIT, False), 85)
     res2 = batch.transform(sources[:4], 64, 64, quality=85, chunk=1)  # chunking does not change results
     assert [r.data for r in res2] == [r.data for r in res[:4]]
 
