@@ -63,6 +63,31 @@ def _emu_coefs(emu, data, comp):
     return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64), ns.value
 
 
+def test_forced_scan_walk_of_short_baseline_files_matches_libjpeg(emu, oracle):
+    """A baseline file the device decoder cannot finish (too few blocks) is parsed again with `force_scans` and decoded by the serial
+    scan decoder: lp_prog_core.h's sequential walk with libjpeg's end-of-data rule (zero bits for the MCU at hand, the following MCUs
+    untouched). Coefficients against the reference's own libjpeg-turbo on truncated fixtures (CPU: the lane logic through tests/emu)."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    fix = os.path.join(ROOT, "tests", "golden", "inputs")
+    n = 0
+    for name in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg", "coast.jpg"):
+        data = open(os.path.join(fix, name), "rb").read()
+        for frac in (0.3, 0.5, 0.8, 0.95, 1.0):
+            cut = data[: int(len(data) * frac)]
+            for c in range(oracle.jpeg_info(cut)["ncomp"]):
+                a = np.frombuffer(cut, np.uint8)
+                out = np.zeros(1 << 23, np.int16)
+                bw, bh, ns = C.c_int(), C.c_int(), C.c_int(-1)   # -1: force the scan-by-scan walk
+                rc = emu.emu_decode_coefs_progressive(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_int(c), out.ctypes.data_as(C.c_void_p),
+                                                      C.c_size_t(out.size), C.byref(bw), C.byref(bh), C.byref(ns))
+                assert rc == 0, (name, frac, rc)
+                got = out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64)
+                assert np.array_equal(got, oracle.ref_jpeg_decode_coefs(cut, c)), (name, frac, c)
+                n += 1
+    assert n >= 50
+
+
 def test_scan_lane_logic_reproduces_oracle_coefficients(emu, oracle):
     """lp_prog_core.h run serially on the CPU (tests/emu): DC / AC first and refinement scans, EOB runs, correction bits, restart
     intervals, interleaved and single-component scans -- coefficient for coefficient what the oracle (jdphuff.c restated) yields."""
