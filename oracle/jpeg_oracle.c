@@ -693,17 +693,15 @@ static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
     int nmcu = in->mcus_x * in->mcus_y;
     int rst_left = in->dri;
     for (int m = 0; m < nmcu; m++) {
-        if (in->dri && rst_left == 0) {
-            /* process restart: discard partial byte, expect RSTn */
-            b.acc = 0; b.nbits = 0;
-            if (!b.marker) { /* scan forward to next marker */
-                while (b.pos + 1 < b.n && !(b.d[b.pos] == 0xFF && b.d[b.pos + 1] >= 0xD0 && b.d[b.pos + 1] <= 0xD7)) b.pos++;
-                if (b.pos + 1 < b.n) b.pos += 2;
-            }
-            b.marker = 0;
+        if (in->dri && rst_left == 0) { /* jdhuff.c process_restart */
+            prog_restart(&b);
             pred[0] = pred[1] = pred[2] = pred[3] = 0;
             rst_left = in->dri;
         }
+        /* jdhuff.c decode_mcu: "if (!entropy->insufficient_data)" -- once a read has gone past the data (truncated file, a marker in the
+         * scan) the MCU at hand was finished on zero bits and the following ones are left as they are (zero: flat grey) until a
+         * restart marker is found again */
+        if (b.insufficient) { if (in->dri) rst_left--; continue; }
         int mx = m % in->mcus_x, my = m / in->mcus_x;
         for (int c = 0; c < in->ncomp; c++)
             for (int v = 0; v < in->vs[c]; v++)

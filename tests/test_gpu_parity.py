@@ -125,25 +125,27 @@ def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes
     """A baseline stream that ends before its last block (truncated upload) or loses blocks to damage is not an error to libjpeg: it
     warns, feeds zero bits to the MCU at hand and leaves the following MCUs untouched (flat grey). The device decoder notices the
     missing blocks and the image is decoded once more by the serial scan decoder, which implements libjpeg's rule: coefficients and
-    pixels must equal the reference's own libjpeg-turbo (oracle/_ref; the C restatement does not model the rule for baseline files).
+    pixels must equal the oracle's (jdhuff.c's "if (!entropy->insufficient_data)" restated; itself held to the reference's own
+    libjpeg-turbo on truncated files by tests/test_oracle_golden.py) and, when oracle/_ref is there, the real library's.
     Round 1 answered ErrDecodingFailed here. What the reference's patched OpenCV source manager does at the end of a truncated
     memory buffer cannot be checked (its archives are unlinkable): this pins the codec's behaviour, not OpenCV's."""
-    if oracle.ref() is None:
-        pytest.skip("oracle/_ref/libref.so not built")
     import lilliput_amd as la
 
+    have_ref = oracle.ref() is not None
     n = 0
     for name in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg", "coast.jpg", "large-sunrise.jpg"):
         data = fixture_bytes[name]
         for frac in (0.3, 0.5, 0.8, 0.95):
             cut = data[: int(len(data) * frac)]
             px, _ = batch.decode_jpeg(cut)
-            assert np.array_equal(px, oracle.ref_jpeg_decode(cut)), (name, frac)
+            assert np.array_equal(px, oracle.jpeg_decode(cut)), (name, frac)
+            if have_ref:
+                assert np.array_equal(px, oracle.ref_jpeg_decode(cut)), (name, frac)
             n += 1
     assert n == 20
     # through the whole transform, one image at a time and as a batch item next to an intact one
     cut = fixture_bytes["coast.jpg"][: len(fixture_bytes["coast.jpg"]) * 2 // 3]
-    want = oracle.jpeg_encode(oracle.transform_static(oracle.ref_jpeg_decode(cut), 1, 64, 48, oracle.FIT, False), 85)
+    want = oracle.jpeg_encode(oracle.transform_static(oracle.jpeg_decode(cut), 1, 64, 48, oracle.FIT, False), 85)
     d = la.Decoder(cut)
     ops = la.ImageOps(2048)
     got = ops.Transform(d, la.ImageOptions(".jpeg", 64, 48, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85}, EncodeTimeout=10**10))
@@ -486,9 +488,8 @@ def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
     assert res[-2].status == 1
     # the truncated file decodes like libjpeg decodes it (the part that arrived, grey below): test_short_baseline_streams_decode_like_libjpeg
     assert res[-1].status == 0
-    if oracle.ref() is not None:
-        cut = oracle.ref_jpeg_decode(sources[-1])
-        assert res[-1].data == oracle.jpeg_encode(oracle.transform_static(cut, oracle.jpeg_info(sources[-1])["orientation"], 64, 64, oracle.FIT, False), 85)
+    cut = oracle.jpeg_decode(sources[-1])
+    assert res[-1].data == oracle.jpeg_encode(oracle.transform_static(cut, oracle.jpeg_info(sources[-1])["orientation"], 64, 64, oracle.FIT, False), 85)
     res2 = batch.transform(sources[:4], 64, 64, quality=85, chunk=1)  # chunking does not change results
     assert [r.data for r in res2] == [r.data for r in res[:4]]
 

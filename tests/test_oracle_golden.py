@@ -133,6 +133,28 @@ def test_restatement_vs_reference_library_on_generated_files(oracle):
         assert oracle.jpeg_encode(src, q) == oracle.ref_jpeg_encode(src, q), (px.shape, q)
 
 
+def test_restatement_vs_reference_library_on_truncated_baseline_files(oracle, fixture_bytes):
+    """jdhuff.c decode_mcu's end-of-data rule for baseline files -- the MCU at hand is finished on zero bits, the following ones are
+    left untouched (flat grey) until a restart marker is found again -- restated in jpeg_oracle.c decode_coefs: pixels and coefficients
+    against the reference's own libjpeg-turbo on truncated fixtures (with and without restart intervals, colour and grey)."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    n = 0
+    for name in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg", "coast.jpg", "large-sunrise.jpg"):
+        data = fixture_bytes[name]
+        for frac in (0.1, 0.3, 0.5, 0.8, 0.95, 0.999):
+            cut = data[: int(len(data) * frac)]
+            try:
+                want = oracle.ref_jpeg_decode(cut)
+            except Exception:
+                continue   # cut inside the headers: no image either way
+            assert np.array_equal(oracle.jpeg_decode(cut), want), (name, frac)
+            for c in range(oracle.jpeg_info(cut)["ncomp"]):
+                assert np.array_equal(oracle.jpeg_decode_coefs(cut, c), oracle.ref_jpeg_decode_coefs(cut, c)), (name, frac, c)
+            n += 1
+    assert n >= 25
+
+
 def test_restatement_vs_reference_library_on_damaged_progressive_files(oracle):
     """Bit-flipped progressive files (entropy data, scan headers, the tables between scans): the oracle accepts and rejects exactly
     what the reference's libjpeg-turbo does and decodes the same coefficients -- the end of a scan's data (insufficient_data), codes
