@@ -82,7 +82,15 @@ def cpu_baseline(sample_jpegs, budget_s=12.0):
     dt = time.time() - t0
     return {"value": round(len(jobs) / dt, 2), "unit": "images/s", "cores": cores, "kind": kind,
             "one_core_images_per_s": round(1.0 / t1, 2),
-            "sample": "%d transforms of the same 4096x4096 q90 -> 256x256 q85 workload on %d host threads (%.1fs)" % (len(jobs), cores, dt)}
+            "sample": "%d transforms (%d distinct sources of the timed workload, cycled) of 4096x4096 q90 -> 256x256 q85 on %d host threads (%.1fs)" % (len(jobs), len(sample_jpegs), cores, dt)}
+
+
+def kernel_source_sha16():
+    """Hash of the sources the decode kernels are built from (stamped into profiles/r*_pmc_traffic.json by scripts/pmc_traffic.py)."""
+    h = hashlib.sha256()
+    for n in ("lp_kernels_decode.hip", "lp_huff_core.h", "lp_unstuff_core.h", "lp_types.h"):
+        h.update(open(os.path.join(ROOT, "lilliput_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_table(stage, images, c_in, c_out, size):
@@ -116,6 +124,11 @@ def main():
     ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
     ap.add_argument("--out", type=int, default=256, help="thumbnail side (256 = the BASELINE workload; other values exercise other resize branches)")
     ap.add_argument("--resident", action="store_true", help="time the device pipeline with the compressed bytes already in HBM (kernel measurements) instead of host bytes in -> host bytes out")
+    ap.add_argument("--ingest", choices=["auto", "staged", "pinned"], default="auto",
+                    help="where the source bytes are and how they reach the device: auto = the caller's pageable buffers, their pages registered for the call and read "
+                         "by the DMA engine in place (zero-copy); pinned = the sources sit in a lilliput_hip_host_alloc arena (what a service that reads network "
+                         "bytes into pinned memory has; zero-copy, nothing registered per call); staged = every byte memcpy'd through pinned slots (round 2)")
+    ap.add_argument("--verify", type=int, default=8, help="outputs of the last timed step compared byte for byte with the oracle's after the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
     args = ap.parse_args()
@@ -128,6 +141,8 @@ def main():
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     barrier = ranks.barrier
 
+    if args.ingest == "staged":
+        os.environ["LILLIPUT_HIP_INGEST"] = "staged"    # read once by the library, before its first transform
     import lilliput_amd as la
 
     paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
@@ -135,7 +150,14 @@ def main():
     distinct = [open(p, "rb").read() for p in paths]
     import numpy as np
 
-    arrays = [np.frombuffer(d, dtype=np.uint8) for d in distinct]
+    arena = None
+    if args.ingest == "pinned" and not args.resident:
+        # the sources in a pinned, device-mapped arena on the GPU's NUMA node (lilliput_hip_host_alloc): placed there BEFORE the timed
+        # region, like the bytes a service received into such a buffer
+        arena = la.HostArena(sum(len(d) + 64 for d in distinct) + 4096, local_rank % max(1, la.lib().lilliput_hip_device_count()))
+        arrays = [arena.put(d) for d in distinct]
+    else:
+        arrays = [np.frombuffer(d, dtype=np.uint8) for d in distinct]
     # every rank works on its own rotation of the set (weak scaling: per-GPU work is fixed)
     sources = [arrays[(i + rank * 7) % len(arrays)] for i in range(args.batch)]
     c_in = sum(a.size for a in sources) / args.batch
@@ -145,7 +167,7 @@ def main():
     b = la.Batch(local_rank % ndev)
     if args.sub_bits:
         b.set_subsequence(args.sub_bits, args.ckpt_bits)
-    stage, ingest = {}, {"staged_bytes": 0, "stage_ms": 0.0, "stall_ms": 0.0, "wall_ms": 0.0}
+    stage, ingest = {}, {"staged_bytes": 0, "stage_ms": 0.0, "stall_ms": 0.0, "wall_ms": 0.0, "copied_bytes": 0, "direct_bytes": 0, "register_ms": 0.0, "numa_node": -1}
     upload_s = None
     if args.resident:
         t = time.time()
@@ -167,7 +189,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
         if not args.resident:
             for k, v in b.ingest_stats().items():
-                ingest[k] += v
+                ingest[k] = v if k == "numa_node" else ingest[k] + v
 
     # W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation, MAX over ranks
     for _ in range(args.warmup):
@@ -178,6 +200,28 @@ def main():
     ok = sum(1 for r in res if r.status == 0)
     digest = hashlib.sha256(res[0].data).hexdigest()[:16] if res and res[0].status == 0 else None
     c_out = sum(len(r.data) for r in res) / max(1, len(res))
+    # ---- correctness gate: K outputs of the LAST timed step, picked by sha256(step, i), against the reference CPU path's bytes
+    # (oracle.transform_jpeg_thumbnail: libjpeg-turbo decode -> INTER_AREA -> libjpeg-turbo encode, opencv.go:872-900 is what Encode
+    # must return). Integer-scale boxes are exact, so the comparison is byte for byte; every rank checks its own shard.
+    verified, mismatched = 0, []
+    if args.verify > 0:
+        from oracle import oracle as O
+
+        O.lib()
+        use_ref = O.ref() is not None
+        seen = set()
+        for j in range(args.verify * 4):
+            if len(seen) >= min(args.verify, args.batch):
+                break
+            i = int.from_bytes(hashlib.sha256(b"%d:%d:%d" % (args.steps - 1, rank, j)).digest()[:8], "little") % args.batch
+            if i in seen:
+                continue
+            seen.add(i)
+            exp = O.transform_jpeg_thumbnail(bytes(sources[i]), args.out, args.out, 85, use_ref=use_ref)
+            verified += 1
+            if res[i].status != 0 or res[i].data != exp:
+                mismatched.append(i)
+    gate = ranks.all_gather_ints([verified, len(mismatched), ok])
     h2d_gbs = ingest["staged_bytes"] / max(1e-9, ingest["wall_ms"] * 1e-3) / 1e9 if not args.resident else None
     h2d_all = ranks.all_gather_ints([int((h2d_gbs or 0.0) * 1000)])
 
@@ -223,11 +267,22 @@ def main():
         if dom_ms > 0:
             launch_images = excl["launch_images"] if excl else min(args.chunk or (32 if not args.resident else 113), args.batch)  # without the exclusive leg: the chunk size of the timed mode
             achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            try:  # HBM bytes of the dominant kernel from the committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
-                traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
+            # HBM bytes of the dominant kernel from the newest committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE;
+            # rocprofv3 counters cannot be collected from inside this process). The file is stamped with a hash of the kernel sources it was
+            # measured on; a stamp that no longer matches means the number is stale and it is withheld.
+            traffic, traffic_src = None, None
+            try:
+                import glob
+
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+                pm = json.load(open(cand[-1]))
+                stamp = pm.get("kernel_source_sha16")
+                if stamp is not None and stamp != kernel_source_sha16():
+                    traffic_src = "%s is stale (kernel sources changed since it was measured)" % os.path.basename(cand[-1])
+                else:
+                    keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
+                    traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
+                    traffic_src = os.path.basename(cand[-1])
             except Exception:
                 traffic = None
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -235,6 +290,7 @@ def main():
                     "algorithmic_bytes_per_launch": int(dom_bytes * launch_images), "launch_images": launch_images,
                     "avg_launch_us": round(dom_ms * 1e3 / (src_n / launch_images), 1),
                     "traffic_over_algorithmic": round(traffic / (dom_bytes * launch_images), 3) if traffic else None,
+                    "traffic_source": traffic_src,
                     "streams": 1 if excl else streams,
                     "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
                             "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
@@ -262,6 +318,9 @@ def main():
                        "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out),
                        "parallelism": "independent images sharded per rank, no data-path collective", "engines_per_gpu": streams,
                        "ok_images": ok, "first_output_sha256_16": digest,
+                       "verified_outputs": sum(g[0] for g in gate), "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
+                       "verified_against": "oracle.transform_jpeg_thumbnail (reference libjpeg-turbo decode -> INTER_AREA restatement -> reference libjpeg-turbo encode), byte for byte, "
+                                           "outputs of the last timed step picked by sha256(step:rank:j)",
                        "end_to_end_algorithmic_bytes_per_image": int(e2e_bytes),
                        "end_to_end_hbm_roofline_frac": round(e2e_bytes * value / world / (HBM_PEAK_GBS * 1e9), 5),
                        "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps)},
@@ -272,19 +331,33 @@ def main():
         else:
             out["config"]["h2d_GBps_per_rank"] = [round(v[0] / 1000.0, 2) for v in h2d_all]
             out["config"]["pcie_gen5_x16_measured_ceiling_GBps"] = 55.5   # scripts/microbench.hip on this box: pinned H2D 57 GB/s, staged pipeline 55.5 GB/s
-            out["config"]["ingest"] = {"staged_MB_per_step": round(ingest["staged_bytes"] / args.steps / 1e6, 1),
+            zero_copy = ingest["direct_bytes"] > 0 and ingest["copied_bytes"] * 50 < ingest["staged_bytes"]
+            out["config"]["ingest"] = {"mode": "zero-copy" if zero_copy else "staged",
+                                       "source_memory": {"auto": "caller's pageable buffers; page ranges registered per call (hipHostRegister, each distinct range once)",
+                                                         "pinned": "lilliput_hip_host_alloc arena (pinned, device-mapped, on the GPU's NUMA node), filled before the timed region",
+                                                         "staged": "caller's pageable buffers; every byte memcpy'd into pinned slots"}[args.ingest],
+                                       "MB_to_device_per_step": round(ingest["staged_bytes"] / args.steps / 1e6, 1),
+                                       "MB_read_in_place_per_step": round(ingest["direct_bytes"] / args.steps / 1e6, 1),
+                                       "MB_copied_through_pinned_slots_per_step": round(ingest["copied_bytes"] / args.steps / 1e6, 1),
                                        "stager_thread_ms_per_step": round(ingest["stage_ms"] / args.steps, 2),
-                                       "compute_threads_waiting_ms_per_step": round(ingest["stall_ms"] / args.steps, 2)}
+                                       "of_which_hipHostRegister_ms_per_step": round(ingest["register_ms"] / args.steps, 2),
+                                       "compute_threads_waiting_ms_per_step": round(ingest["stall_ms"] / args.steps, 2),
+                                       "numa_node_of_ingest_threads": ingest["numa_node"]}
             if resident_ips:
                 out["config"]["resident_images_per_s"] = round(resident_ips, 2)
         if not args.no_cpu_baseline:  # rank 0 only, after the timed region (every rank has passed the closing barrier)
             try:
-                out["cpu_baseline"] = cpu_baseline(distinct[: min(4, len(distinct))])
+                out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))])
             except Exception as e:  # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     b.close()
+    if arena is not None:
+        arena.close()
     ranks.close()
+    if args.verify > 0 and (any(g[1] for g in gate) or any(g[2] != args.batch for g in gate)):
+        log("[bench] CORRECTNESS GATE FAILED: rank %d mismatched outputs %r, ok images per rank %r" % (rank, mismatched, [g[2] for g in gate]))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

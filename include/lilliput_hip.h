@@ -328,9 +328,33 @@ void lilliput_hip_batch_destroy(lilliput_hip_batch b);
  * the device work: per engine a stager thread walks the headers of chunk k + 1, copies its entropy-coded bytes into pinned memory
  * and enqueues the H2D copy on a copy stream while chunk k is decoded. Returns the number of failed items. */
 int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt);
-/* Of the last transform: out[0] bytes staged to the device, out[1] host ms spent staging (summed over the stager threads),
- * out[2] ms the compute threads waited for a staged chunk, out[3] wall ms of the call. */
+/* Of the last transform: out[0] entropy-coded bytes that reached the device, out[1] host ms the ingest threads spent (header walk,
+ * registration, staging copies, copy enqueue; summed over the threads), out[2] ms the compute threads waited for a chunk, out[3] wall
+ * ms of the call. ingest_stats2 adds: out[4] bytes that were copied through the engines' pinned slots (a host memcpy each), out[5]
+ * bytes the DMA engine read from the caller's own pages (pinned arena, registered buffers, or pages registered for the call),
+ * out[6] host ms inside hipHostRegister, out[7] NUMA node the ingest threads were bound to (-1: none / unknown). */
 void lilliput_hip_batch_ingest_stats(lilliput_hip_batch b, double out[4]);
+void lilliput_hip_batch_ingest_stats2(lilliput_hip_batch b, double out[8]);
+
+/* Where the caller's encoded bytes live (lilliput_amd/csrc/lp_hostmem.h). The reference decodes from the caller's []byte in place
+ * (opencv.cpp:99-171); so does the batched path whenever the DMA engine can read those pages:
+ *   - lilliput_hip_host_alloc / _free: a pinned, device-mapped arena on the NUMA node next to `device` (-1: the current one). A
+ *     service that reads its network bytes into such an arena (Go: unsafe.Slice over the pointer) has nothing copied or registered
+ *     per call.
+ *   - lilliput_hip_host_register / _unregister: pin a long-lived buffer of the caller's once (a receive-buffer pool).
+ *   - anything else: the page range of every distinct source of a call is registered for the duration of the call (each range once,
+ *     however many items name it) when it is at least LILLIPUT_HIP_REGISTER_MIN bytes (default 64 KiB); smaller sources, sources that
+ *     share pages with a live registration and sources the driver refuses to pin are copied through the engine's pinned slots.
+ * LILLIPUT_HIP_INGEST = auto (default) | staged (everything through the slots: the round-2 pipeline) | pinned (no per-call
+ * registration: arena / registered sources in place, the rest through the slots). Ingest threads and their pinned slots are placed on
+ * the NUMA node the device hangs off (/sys/bus/pci/devices/<bdf>/numa_node); LILLIPUT_HIP_NUMA=0 switches that off. */
+void* lilliput_hip_host_alloc(size_t bytes, int device);
+void lilliput_hip_host_free(void* p);
+int lilliput_hip_host_register(void* p, size_t bytes);      /* LILLIPUT_OK, or LILLIPUT_ERR_DEVICE when the range cannot be pinned */
+int lilliput_hip_host_unregister(void* p);
+int lilliput_hip_host_is_pinned(const void* p, size_t bytes); /* 1: the DMA engine will read [p, p + bytes) in place */
+int lilliput_hip_set_ingest_mode(const char* mode);         /* "auto" | "staged" | "pinned" for the transforms that start after the call (process-wide, like
+                                                             * LILLIPUT_HIP_INGEST); returns the previous mode as 0 / 1 / 2 */
 /* Resident form (kernel-pipeline measurements, tests): upload parses the headers and moves the compressed bytes into HBM,
  * run executes every device stage (inputs resident), download copies the encoded results back. */
 int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);
@@ -364,6 +388,20 @@ int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch b, const void* src, size_t
 int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch b, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph);
 const char* lilliput_hip_last_error(void);
 int lilliput_hip_device_count(void);
+
+/* Process-wide effects of loading this library, and its resource bounds:
+ *   - GPU_MAX_HW_QUEUES: the library's static initialiser sets it to 8 with setenv(.., overwrite = 0) BEFORE the HIP runtime reads it
+ *     (first HIP call of the process), because with the runtime's default of 4 hardware queues one of a batch's four engines ends up
+ *     behind the copy stream's barrier packets (8.9 k -> 10.6 k images/s end to end). It affects every HIP user in the process. A
+ *     value the host application exported itself is left alone; LILLIPUT_HIP_KEEP_RUNTIME_ENV=1 makes the library touch nothing.
+ *   - one-image ABI (Parts A, A2-A4, C): every call checks an engine (one stream + grow-only device arenas) out of a process-wide
+ *     pool and returns it synchronised, so consecutive calls on one handle may come from any OS thread (cgo) and the number of
+ *     engines follows the number of calls in flight, not the number of threads. At most LILLIPUT_HIP_ENGINE_POOL (default 8) idle
+ *     engines are kept; an engine whose arenas grew beyond LILLIPUT_HIP_ENGINE_TRIM_MB (default 1024) is destroyed on return.
+ * lilliput_hip_engine_pool_stats: engines checked out now, idle in the pool, created so far, destroyed by the bounds.
+ * lilliput_hip_mem_info: hipMemGetInfo of `device` (LILLIPUT_OK or LILLIPUT_ERR_DEVICE). */
+void lilliput_hip_engine_pool_stats(size_t out[4]);
+int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* Test access (no device work): number of inflated image-data bytes of a PNG, or -1 when libpng would reject the file. */
 long lilliput_hip_png_inflate_check(const void* data, size_t len);

@@ -10,6 +10,7 @@ from .binding import (  # noqa: F401
     Batch,
     BatchItemResult,
     Decoder,
+    HostArena,
     ImageOps,
     ImageOptions,
     JpegProgressive,

@@ -80,7 +80,8 @@ def lib():
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError("liblilliput_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises (see lp_engine.cpp: LpRuntimeEnv)
+    if not os.environ.get("LILLIPUT_HIP_KEEP_RUNTIME_ENV"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises (see lp_engine.cpp: LpRuntimeEnv)
     L = C.CDLL(path)
     L.lilliput_hip_last_error.restype = C.c_char_p
     L.lilliput_hip_batch_create.restype = C.c_void_p
@@ -96,6 +97,19 @@ def lib():
     L.lilliput_hip_batch_resident_round.argtypes = [C.c_void_p, C.c_size_t]
     L.lilliput_hip_batch_ingest_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.lilliput_hip_batch_ingest_stats.restype = None
+    L.lilliput_hip_batch_ingest_stats2.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.lilliput_hip_batch_ingest_stats2.restype = None
+    L.lilliput_hip_host_alloc.restype = C.c_void_p
+    L.lilliput_hip_host_alloc.argtypes = [C.c_size_t, C.c_int]
+    L.lilliput_hip_host_free.argtypes = [C.c_void_p]
+    L.lilliput_hip_host_free.restype = None
+    L.lilliput_hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.lilliput_hip_host_unregister.argtypes = [C.c_void_p]
+    L.lilliput_hip_host_is_pinned.argtypes = [C.c_void_p, C.c_size_t]
+    L.lilliput_hip_set_ingest_mode.argtypes = [C.c_char_p]
+    L.lilliput_hip_engine_pool_stats.argtypes = [C.POINTER(C.c_size_t)]
+    L.lilliput_hip_engine_pool_stats.restype = None
+    L.lilliput_hip_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.lilliput_hip_node_create.restype = C.c_void_p
     L.lilliput_hip_node_create.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.lilliput_hip_node_destroy.argtypes = [C.c_void_p]
@@ -270,6 +284,41 @@ def parse_raw_frames(blob):
     return out
 
 
+class HostArena:
+    """lilliput_hip_host_alloc: one pinned, device-mapped block the caller places its encoded sources in (what a service that reads
+    network bytes straight into pinned memory has); put() returns numpy views the batch calls read in place."""
+
+    def __init__(self, nbytes, device=0):
+        self._p = lib().lilliput_hip_host_alloc(int(nbytes), int(device))
+        if not self._p:
+            raise MemoryError("lilliput_hip_host_alloc(%d)" % nbytes)
+        self.nbytes = int(nbytes)
+        self._used = 0
+        self._buf = (C.c_uint8 * self.nbytes).from_address(self._p)
+
+    def put(self, data, align=64):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        off = (self._used + align - 1) // align * align
+        if off + a.size > self.nbytes:
+            raise MemoryError("host arena exhausted")
+        view = np.frombuffer(self._buf, dtype=np.uint8, count=a.size, offset=off)
+        view[:] = a
+        self._used = off + a.size
+        return view
+
+    def close(self):
+        if self._p:
+            self._buf = None
+            lib().lilliput_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BatchItemResult:
     __slots__ = ("status", "data", "width", "height")
 
@@ -336,11 +385,13 @@ class Batch:
         return self._results()
 
     def ingest_stats(self):
-        """Of the last transform(): bytes staged to the device, host ms spent staging (summed over the parts' stager threads), ms the
-        compute threads waited for a staged chunk, wall ms of the call."""
-        v = (C.c_double * 4)()
-        lib().lilliput_hip_batch_ingest_stats(self._h, v)
-        return {"staged_bytes": int(v[0]), "stage_ms": v[1], "stall_ms": v[2], "wall_ms": v[3]}
+        """Of the last transform(): entropy-coded bytes that reached the device, host ms of the ingest threads (summed), ms the compute
+        threads waited for a chunk, wall ms of the call; bytes copied through pinned slots, bytes the DMA engine read from the caller's
+        own pages, ms inside hipHostRegister, NUMA node of the ingest threads."""
+        v = (C.c_double * 8)()
+        lib().lilliput_hip_batch_ingest_stats2(self._h, v)
+        return {"staged_bytes": int(v[0]), "stage_ms": v[1], "stall_ms": v[2], "wall_ms": v[3], "copied_bytes": int(v[4]), "direct_bytes": int(v[5]),
+                "register_ms": v[6], "numa_node": int(v[7])}
 
     # staged form (bench): inputs resident in HBM before run()
     def upload(self, sources, dst_cap=1 << 20, streams=0):

@@ -47,7 +47,22 @@ struct LpEncoder {
     bool png = false; // ".png": cv::PngEncoder semantics, else cv::JpegEncoder
 };
 
-LpEngine* lp_thread_engine();
+// One-image ABI calls check an engine (stream + grow-only arenas) out of a small per-device pool for the duration of the call and
+// hand it back synchronised: under cgo a goroutine's consecutive calls arrive on whatever OS thread the Go scheduler picked
+// (SURVEY.md 8b "no thread-affine state"), and a process with hundreds of threads must not hold hundreds of engines. Leases nest: a
+// caller that wraps a whole Transform in one lease (lp_ops.cpp) keeps its calls on ONE stream, unsynchronised in between.
+class LpEngineLease {
+public:
+    LpEngineLease();
+    ~LpEngineLease();
+    LpEngineLease(const LpEngineLease&) = delete;
+    LpEngineLease& operator=(const LpEngineLease&) = delete;
+    LpEngine* get() const { return eng_; }   // nullptr: no usable device (the error text is set)
+private:
+    LpEngine* eng_ = nullptr;
+    int dev_ = 0;
+    bool owner_ = false, tls_ = false;
+};
 int lp_thread_device(int device); // device for this thread's one-image ABI calls (-1 = default); returns the previous setting
 void lp_set_error(const std::string& s);
 bool lp_mat_to_device(LpMat* m, LpEngine* eng);

@@ -195,7 +195,8 @@ const uint8_t* lilliput_hip_srgb_icc_profile(size_t* profile_size) // lilliput.g
 void tonemap_rgb_to_sdr(const uint16_t* src, uint8_t* dst, int width, int height, int src_depth, uint8_t transfer, uint8_t primaries)
 {
     if (!src || !dst || width <= 0 || height <= 0 || src_depth < 1 || src_depth > 16) return;
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng) { fprintf(stderr, "lilliput_hip: tone map failed (no device)\n"); return; }
     if (eng->tonemap_host(src, dst, width, height, src_depth, transfer, primaries)) fprintf(stderr, "lilliput_hip: tone map failed: %s\n", eng->last_error().c_str());
 }
@@ -204,7 +205,8 @@ void tonemap_rgb_to_sdr(const uint16_t* src, uint8_t* dst, int width, int height
 void tonemap_rgb_8u_inplace(uint8_t* pixels, int width, int height, int channels, uint8_t transfer, uint8_t primaries)
 {
     if (!pixels || width <= 0 || height <= 0 || (channels != 3 && channels != 4)) return;
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng) { fprintf(stderr, "lilliput_hip: tone map failed (no device)\n"); return; }
     if (eng->tonemap_host8(pixels, width, height, channels, transfer, primaries)) fprintf(stderr, "lilliput_hip: tone map failed: %s\n", eng->last_error().c_str());
 }
@@ -216,7 +218,8 @@ int lilliput_hip_mat_tonemap(opencv_mat mat, uint8_t transfer, uint8_t primaries
     if (!m || m->rows <= 0 || m->cols <= 0) return 0;
     const int type_cn = ((m->type >> 3) & 511) + 1, depth = m->type & 7;
     if (depth != 0 || (type_cn != 3 && type_cn != 4)) return 0; // TonemapToSDR returns without touching other layouts
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(m, eng)) return -1;
     if (eng->tonemap(lp_mat_frame(m), transfer, primaries)) { lp_set_error(eng->last_error()); return -1; }
     m->dev_valid = true;

@@ -209,7 +209,8 @@ bool giflib_decoder_decode_frame(giflib_decoder d, opencv_mat mat) // giflib.cpp
     }
     const LpGifColorMap& map = g.local_map.count ? g.local_map : g.global_map;
     if (!map.count) { fprintf(stderr, "encountered error, gif frame has no color map\n"); return false; }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng) return false;
     const size_t canvas_bytes = (size_t)bw * bh * 4;
     if (!d->canvas) {

@@ -240,7 +240,8 @@ bool giflib_encoder_encode_frame(giflib_encoder e, const giflib_decoder d, const
     }
     const LpGifColorMap& map = e->frame_map.count ? e->frame_map : e->global_map;
     if (!map.count) { fprintf(stderr, "encountered error, gif frame has no color map\n"); return false; }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(m, eng)) return false;
     const size_t npx = (size_t)fw * fh;
     if (!e->lookup) {

@@ -38,21 +38,102 @@ extern "C" int lilliput_hip_device_count(void)
 static thread_local int t_device = -1; // lp_thread_device: which GPU this thread's one-image calls run on (-1: LILLIPUT_HIP_DEVICE, else 0)
 int lp_thread_device(int device) { int prev = t_device; t_device = device; return prev; }
 
-LpEngine* lp_thread_engine()
+// ---- engine pool (see LpEngineLease in lp_abi.h)
+namespace {
+struct EnginePool {
+    std::mutex mu;
+    std::vector<std::pair<int, LpEngine*>> idle;    // most recently used last
+    size_t live = 0, created = 0, trimmed = 0;
+};
+EnginePool& engine_pool()
 {
-    static thread_local std::unique_ptr<LpEngine> eng;
-    static thread_local int eng_dev = -1;
+    static EnginePool* p = new EnginePool(); // never destroyed: at process exit the HIP runtime may already be gone
+    return *p;
+}
+size_t pool_keep() // idle engines kept per process (LILLIPUT_HIP_ENGINE_POOL)
+{
+    static const size_t v = getenv("LILLIPUT_HIP_ENGINE_POOL") ? (size_t)std::max(0, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL"))) : 8;
+    return v;
+}
+size_t pool_trim_bytes() // an engine whose arenas grew beyond this is not kept (LILLIPUT_HIP_ENGINE_TRIM_MB, default 1 GiB: a 8192 x 8192 decode is ~0.5 GiB)
+{
+    static const size_t v = (getenv("LILLIPUT_HIP_ENGINE_TRIM_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_ENGINE_TRIM_MB"))) : 1024) << 20;
+    return v;
+}
+thread_local LpEngine* t_lease_eng = nullptr;
+thread_local int t_lease_dev = -1;
+}
+
+LpEngineLease::LpEngineLease()
+{
     int dev = t_device;
     if (dev < 0) { dev = 0; if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e); }
-    if (!eng || eng_dev != dev) {
-        eng_dev = dev;
-        eng.reset(new LpEngine(dev));
-        if (!eng->ok()) {
-            lp_set_error(eng->last_error());
-            fprintf(stderr, "lilliput_hip: no usable MI355X device (%s); the HIP path has no CPU fallback\n", eng->last_error().c_str());
-        }
+    dev_ = dev;
+    if (t_lease_eng && t_lease_dev == dev) { eng_ = t_lease_eng; return; } // nested: the outer lease's engine, no hand-over
+    EnginePool& P = engine_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (size_t i = P.idle.size(); i-- > 0;)
+            if (P.idle[i].first == dev) { eng_ = P.idle[i].second; P.idle.erase(P.idle.begin() + (long)i); break; }
+        if (eng_) P.live++;
     }
-    return eng->ok() ? eng.get() : nullptr;
+    if (!eng_) {
+        LpEngine* e = new LpEngine(dev);
+        if (!e->ok()) {
+            lp_set_error(e->last_error());
+            fprintf(stderr, "lilliput_hip: no usable MI355X device (%s); the HIP path has no CPU fallback\n", e->last_error().c_str());
+            delete e;
+            return;
+        }
+        eng_ = e;
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.live++; P.created++;
+    }
+    owner_ = true;
+    if (!t_lease_eng) { t_lease_eng = eng_; t_lease_dev = dev; tls_ = true; }
+}
+
+LpEngineLease::~LpEngineLease()
+{
+    if (!owner_ || !eng_) return;
+    if (tls_) { t_lease_eng = nullptr; t_lease_dev = -1; }
+    // what the call left in flight (lazy write-back) must be visible to whichever engine serves the handle's next call
+    (void)eng_->sync();
+    EnginePool& P = engine_pool();
+    bool keep = eng_->device_bytes() <= pool_trim_bytes();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.live--;
+        if (keep && P.idle.size() >= pool_keep()) { // the least recently used one goes
+            if (!P.idle.empty()) { LpEngine* old = P.idle.front().second; P.idle.erase(P.idle.begin()); P.idle.emplace_back(dev_, eng_); eng_ = old; }
+            keep = false;
+        } else if (keep)
+            P.idle.emplace_back(dev_, eng_);
+        if (!keep) P.trimmed++;
+    }
+    if (!keep) delete eng_;
+}
+
+// engines checked out now, idle in the pool, created so far, destroyed by the pool's bounds
+extern "C" void lilliput_hip_engine_pool_stats(size_t out[4])
+{
+    EnginePool& P = engine_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    out[0] = P.live; out[1] = P.idle.size(); out[2] = P.created; out[3] = P.trimmed;
+}
+
+extern "C" int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes)
+{
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return LILLIPUT_ERR_DEVICE; }
+    size_t f = 0, t = 0;
+    const hipError_t e = hipMemGetInfo(&f, &t);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return LILLIPUT_ERR_DEVICE; }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return LILLIPUT_OK;
 }
 
 // ---- device block pool (size-bucketed free lists; hipMalloc is too slow to call per Mat)
@@ -160,7 +241,8 @@ bool lp_mat_host_current(LpMat* m)
 {
     if (!m->host_stale) return true;
     if (!m->dev || !m->dev_valid) { m->host_stale = false; return true; }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     return eng && mat_copy_to_host(m, eng);
 }
 
@@ -239,7 +321,8 @@ static bool lp_png_encoder_write(LpEncoder* e, LpMat* s, const int* opt, size_t 
     if (s->rows == 1) filters &= ~0x1cu; // no UP / AVG / PAETH on a single row
     if (s->cols == 1) filters &= ~0x1au; // no SUB / AVG / PAETH on a single column
     if (!filters) filters = 0x01u;
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(s, eng)) return false;
     const size_t row = (size_t)s->cols * cn + 1, raw_len = row * (size_t)s->rows;
     std::vector<uint8_t> raw(raw_len);
@@ -379,7 +462,8 @@ void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int heig
 {
     auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     auto d = static_cast<LpMat*>(dst);
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !s || !d || width <= 0 || height <= 0 || s->rows <= 0 || s->cols <= 0) { fprintf(stderr, "lilliput_hip: opencv_mat_resize failed (no device / empty matrix)\n"); return; }
     if (interpolation != CV_INTER_AREA) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports CV_INTER_AREA only\n"); return; }
     if (cv_depth_bytes(s->type) != 1) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports 8-bit matrices only\n"); return; }
@@ -402,7 +486,8 @@ void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat
     auto m = static_cast<LpMat*>(mat);
     int o = (int)orientation;
     if (!m || o <= 1 || o > 8 || m->rows <= 0 || m->cols <= 0) return; // cv::ExifTransform: TL and unknown values are no-ops
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(m, eng)) { fprintf(stderr, "lilliput_hip: orientation transform failed (no device)\n"); return; }
     const bool swap = o >= 5;
     LpOrientOp op;
@@ -478,7 +563,8 @@ static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int wi
             return kind == 0 ? OPENCV_ERROR_ALPHA_BLENDING_FAILED : OPENCV_ERROR_COPY_FAILED;
         }
     }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng) return OPENCV_ERROR_UNKNOWN;
     if (!lp_mat_to_device(d, eng)) return OPENCV_ERROR_UNKNOWN;
     if (kind != 2 && !lp_mat_to_device(s, eng)) return OPENCV_ERROR_UNKNOWN;
@@ -591,7 +677,8 @@ static bool png_read_data(LpDecoder* d, LpMat* m)
     if (m->rows != (int)pi.height || m->cols != (int)pi.width || cv_channels(m->type) != d->png_channels || cv_depth_bytes(m->type) != 1) return false;
     std::vector<uint8_t> filtered;
     if (!lp_png_read_idat(d->data, d->len, pi, filtered)) { lp_set_error("PNG image data is damaged"); return false; }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !mat_new_dev(m)) return false;
     LpPngOp op;
     memset(&op, 0, sizeof(op));
@@ -632,7 +719,8 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     const LpJpeg& j = d->hdr.j;
     const int cn = j.ncomp == 1 ? 1 : 3;
     if (m->rows != (int)j.height || m->cols != (int)j.width || cv_channels(m->type) != cn || cv_depth_bytes(m->type) != 1) return false;
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng) return false;
     if (!mat_new_dev(m)) return false;
     LpFrame f = lp_mat_frame(m);
@@ -681,7 +769,8 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
         if (opt[i] == CV_IMWRITE_JPEG_QUALITY) quality = opt[i + 1] < 0 ? 0 : opt[i + 1] > 100 ? 100 : opt[i + 1];
         else if (opt[i] == CV_IMWRITE_JPEG_PROGRESSIVE) progressive = opt[i + 1] != 0; // cv::JpegEncoder: jpeg_simple_progression
     }
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(s, eng)) return false;
     LpMat* d = e->dst;
     const size_t cap = (size_t)(d->datalimit - d->datastart);

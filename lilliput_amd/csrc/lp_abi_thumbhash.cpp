@@ -161,7 +161,8 @@ int thumbhash_encoder_encode(thumbhash_encoder e, const opencv_mat opaque_frame)
     const float step_x = (float)src_w / w, step_y = (float)src_h / h;
     for (size_t j = 0; j < w; j++) pick[j] = (uint32_t)std::min((size_t)((int)j * step_x), src_w - 1);
     for (size_t i = 0; i < h; i++) pick[w + i] = (uint32_t)std::min((size_t)((int)i * step_y), src_h - 1);
-    LpEngine* eng = lp_thread_engine();
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(m, eng)) return -1;
     const size_t n = w * h;
     std::vector<uint8_t> px(n * (size_t)cn);

@@ -23,7 +23,7 @@ struct webp_decoder_struct {        // webp.cpp:10-29
     uint32_t bgcolor = 0xFFFFFFFFu, loop_count = 0;
     int current_frame_index = 1;
     int prev_frame_delay_time = 0, prev_frame_x_offset = 0, prev_frame_y_offset = 0, prev_frame_dispose = 0, prev_frame_blend = 0;
-    std::vector<uint8_t> decode_buffer, bitstream;
+    std::vector<uint8_t> bitstream;
 };
 
 struct webp_encoder_struct {        // webp.cpp:31-55
@@ -70,8 +70,9 @@ webp_decoder webp_decoder_create(const opencv_mat buf) // webp.cpp:61-134
         d->has_animation = true;
     } else
         d->total_duration = 0; // static images report no duration
-    try { d->decode_buffer.resize((size_t)d->width * (size_t)d->height * 4); }
-    catch (const std::bad_alloc&) { delete d; return nullptr; }
+    // No canvas-sized scratch buffer here: the canvas size comes from an untrusted VP8X header (a 100-byte file may claim 16383 x 16383
+    // -- or, through VP8X, 2^24 x 2^24), and the reference's `new uint8_t[w * h * 4]` (webp.cpp:118) at least does not touch the pages.
+    // webp_decoder_decode writes the frame straight into the caller's Mat, whose size the caller has checked (opencv.go:250-267).
     return d;
 }
 
@@ -119,10 +120,11 @@ bool webp_decoder_decode(webp_decoder d, opencv_mat mat) // webp.cpp:302-362
     d->prev_frame_y_offset = fr.y_offset;
     d->prev_frame_dispose = fr.dispose;
     d->prev_frame_blend = fr.blend;
-    uint8_t* res = cn == 4 ? WebPDecodeBGRAInto(d->bitstream.data(), d->bitstream.size(), d->decode_buffer.data(), d->decode_buffer.size(), row_size)
-                           : WebPDecodeBGRInto(d->bitstream.data(), d->bitstream.size(), d->decode_buffer.data(), d->decode_buffer.size(), row_size);
+    if (m->rows <= 0 || row_size <= 0 || m->step < (size_t)row_size) return false;
+    const size_t span = m->step * (size_t)(m->rows - 1) + (size_t)row_size; // rows m->step apart, straight into the Mat (the reference copies them there row by row)
+    uint8_t* res = cn == 4 ? WebPDecodeBGRAInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step)
+                           : WebPDecodeBGRInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step);
     if (!res) return false;
-    for (int y = 0; y < m->rows; y++) memcpy(m->data + (size_t)y * m->step, d->decode_buffer.data() + (size_t)y * row_size, (size_t)row_size);
     m->dev_valid = false;   // the host copy is the frame now; it reaches the device with the next opencv_* call
     m->host_stale = false;
     return true;
@@ -200,7 +202,10 @@ static bool anim_add(webp_encoder e, const WebPConfig& cfg, const uint8_t* px, i
     if (!e->frames.empty() && cn == e->canvas_cn) {
         int top = 0, bot = h;
         while (top < h && memcmp(px + (size_t)top * row, e->canvas.data() + (size_t)top * row, row) == 0) top++;
-        if (top == h) { e->frames.back().duration += duration; return true; }
+        // an unchanged frame only lengthens the one before it -- as far as the ANMF duration field goes (24 bits); beyond that the time goes
+        // into a frame of its own (one pixel of the unchanged canvas) instead of wrapping
+        if (top == h && (int64_t)e->frames.back().duration + duration <= 0xFFFFFF) { e->frames.back().duration += duration; return true; }
+        if (top == h) { top = 0; bot = 1; }
         while (bot > top && memcmp(px + (size_t)(bot - 1) * row, e->canvas.data() + (size_t)(bot - 1) * row, row) == 0) bot--;
         int left = w, right = 0;
         for (int y = top; y < bot; y++) {
@@ -211,11 +216,12 @@ static bool anim_add(webp_encoder e, const WebPConfig& cfg, const uint8_t* px, i
             left = std::min(left, l);
             right = std::max(right, r);
         }
+        if (right <= left) { left = 0; right = 1; } // the unchanged-frame case above
         x0 = left & ~1; y0 = top & ~1; x1 = right; y1 = bot; // frame offsets are stored halved: even positions only
     }
     LpWebpAnimFrame f;
     if (!encode_rect(cfg, px + (size_t)y0 * row + (size_t)x0 * cn, (int)row, x1 - x0, y1 - y0, cn, &f.im)) return false;
-    f.x_offset = x0; f.y_offset = y0; f.duration = duration;
+    f.x_offset = x0; f.y_offset = y0; f.duration = std::min(std::max(duration, 0), 0xFFFFFF);
     f.dispose = 0;  // WEBP_MUX_DISPOSE_NONE
     f.blend = 1;    // WEBP_MUX_NO_BLEND: the rectangle replaces what the canvas held, alpha included
     e->frames.push_back(std::move(f));

@@ -33,9 +33,13 @@ struct LpBatchPart {
     uint32_t rounds = 0;
     double tw[6] = {0, 0, 0, 0, 0, 0};
     double stage_ms = 0, stall_ms = 0;  // pipelined transform: host time spent staging (parse + memcpy + enqueue), compute thread waiting for a staged chunk
-    size_t staged_bytes = 0;
-    std::string err;
-    int rc = 0;
+    size_t staged_bytes = 0;            // entropy-coded bytes that reached the device in the last transform ...
+    size_t copied_bytes = 0;            // ... of them: through the engine's pinned slots (a host memcpy each)
+    size_t direct_bytes = 0;            // ... of them: read by the DMA engine from the caller's own (pinned or registered) pages
+    double register_ms = 0;             // host ms inside hipHostRegister for this part's chunks
+    std::string err;                    // written by the compute thread only (the stager reports through its job)
+    int rc = 0;                         // resident API: the part's run failed
+    size_t failed_chunks = 0;           // pipelined transform: chunks whose items were failed as a group
 };
 
 struct LpOtherItem { int item; const uint8_t* data; size_t len; size_t dst_cap; std::vector<uint8_t> copy; };
@@ -126,8 +130,9 @@ struct LpBatch {
     size_t n_items = 0;
     uint32_t S = 0, C = 0;
     LpTimings tm = {};
-    double last_stage_ms = 0, last_stall_ms = 0, last_wall_ms = 0;
-    size_t last_staged_bytes = 0;
+    double last_stage_ms = 0, last_stall_ms = 0, last_wall_ms = 0, last_register_ms = 0;
+    size_t last_staged_bytes = 0, last_copied_bytes = 0, last_direct_bytes = 0;
+    int last_numa_node = -1;
     // sources other than JPEG that the one-image path can serve (GIF: first frame through the animated composite path; PNG):
     // transformed one by one on a few host workers while the JPEG parts run
     std::vector<LpOtherItem> other;
@@ -257,6 +262,13 @@ void lilliput_hip_batch_ingest_stats(lilliput_hip_batch bb, double out[4])
 {
     auto b = static_cast<LpBatch*>(bb);
     out[0] = (double)b->last_staged_bytes; out[1] = b->last_stage_ms; out[2] = b->last_stall_ms; out[3] = b->last_wall_ms;
+}
+
+void lilliput_hip_batch_ingest_stats2(lilliput_hip_batch bb, double out[8])
+{
+    auto b = static_cast<LpBatch*>(bb);
+    out[0] = (double)b->last_staged_bytes; out[1] = b->last_stage_ms; out[2] = b->last_stall_ms; out[3] = b->last_wall_ms;
+    out[4] = (double)b->last_copied_bytes; out[5] = (double)b->last_direct_bytes; out[6] = b->last_register_ms; out[7] = (double)b->last_numa_node;
 }
 
 } // extern "C"
@@ -673,16 +685,20 @@ static int end_run(LpBatch* b, size_t n, bool trace, std::chrono::steady_clock::
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
     int rc = LILLIPUT_OK;
-    b->last_stage_ms = b->last_stall_ms = 0;
-    b->last_staged_bytes = 0;
+    b->last_stage_ms = b->last_stall_ms = b->last_register_ms = 0;
+    b->last_staged_bytes = b->last_copied_bytes = b->last_direct_bytes = 0;
+    b->last_numa_node = lp_device_numa_node(b->device);
     for (auto& p : b->parts) {
         if (p.rc) { rc = p.rc; lp_set_error(p.err); }
+        else if (p.failed_chunks) lp_set_error(p.err); // the items of those chunks carry the status; the call itself went through
         for (int i = 0; i < 10; i++) acc[i] += p.acc[i];
         rounds = std::max(rounds, p.rounds);
         b->last_stage_ms += p.stage_ms; b->last_stall_ms += p.stall_ms; b->last_staged_bytes += p.staged_bytes;
+        b->last_copied_bytes += p.copied_bytes; b->last_direct_bytes += p.direct_bytes; b->last_register_ms += p.register_ms;
         if (trace)
-            fprintf(stderr, "[lilliput_hip] part: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f | staging %.2f ms for %.1f MB, waited %.2f ms for staged chunks\n",
-                    p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5], p.stage_ms, p.staged_bytes / 1e6, p.stall_ms);
+            fprintf(stderr, "[lilliput_hip] part: plan %.2f ms, decode %.2f, resample %.2f, orient+resize+encode %.2f, fetch %.2f, copy-out %.2f | kernels: unstuff %.2f huff %.2f idct %.2f colour %.2f resize %.2f encode %.2f | ingest %.2f ms for %.1f MB (%.1f MB copied through pinned slots, %.1f MB read in place, %.2f ms registering), waited %.2f ms for chunks\n",
+                    p.tw[0], p.tw[1], p.tw[2], p.tw[3], p.tw[4], p.tw[5], p.acc[0], p.acc[1], p.acc[2], p.acc[3], p.acc[4], p.acc[5], p.stage_ms, p.staged_bytes / 1e6, p.copied_bytes / 1e6,
+                    p.direct_bytes / 1e6, p.register_ms, p.stall_ms);
     }
     b->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (trace) fprintf(stderr, "[lilliput_hip] run of %zu items: %.2f ms wall\n", n, b->last_wall_ms);
@@ -750,6 +766,7 @@ struct LpPipeJob {
     std::vector<int> items;
     std::vector<LpJpegSrc> srcs;
     int rc = 0;
+    std::string err;                    // why staging failed (the stager's own string: the engine's is the compute thread's)
     double t_claim = 0, t_staged = 0, t_begin = 0, t_done = 0; // ms since the call started (LILLIPUT_HIP_TRACE)
     int part = -1;
 };
@@ -768,9 +785,18 @@ struct LpPipe {
     bool no_more = false, abort = false;
 };
 
+// A chunk that fails -- its staging (allocation, copy enqueue) or its decode -- fails ITS items only: the other chunks of the call go on
+// (one absurd file must not take the batch down). A lost device shows the same way, chunk after chunk.
+static void fail_job(LpBatch* res, const LpPipeJob& job, int rc, const lilliput_batch_item* items)
+{
+    for (size_t i = job.i0; i < job.i1; i++)
+        if (res->status[i] == LILLIPUT_OK && !is_other_format((const uint8_t*)items[i].src, items[i].src_len)) res->status[i] = rc; // the others are run_other's
+}
+
 static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_item* items)
 {
     LpEngine& eng = *part.eng;
+    (void)lp_bind_thread_near(b->device); // the pinned slots this thread fills (first touch) and the copies it enqueues belong next to the GPU
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t k = 0;; k++) {
         {
@@ -799,30 +825,34 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
             if (!job.items.empty()) {
                 int rc = eng.upload_layout(slot, job.srcs.data(), (int)job.srcs.size(), job.hdrs.data());
                 if (!rc) {
-                    // the staging memcpy has to outrun the link (~55 GB/s for all engines together); one thread moves 20-30 GB/s when the
-                    // DMA engine reads the same memory, so every stager brings a few helpers (LILLIPUT_HIP_STAGE_THREADS, default 3 in all)
+                    // What is not read from the caller's pages directly goes through the slot's pinned buffer. That memcpy has to outrun the
+                    // link (~55 GB/s for all engines together); one thread moves 20-30 GB/s when the DMA engine reads the same memory, so
+                    // the stager brings a few helpers (LILLIPUT_HIP_STAGE_THREADS, default 3 in all) when there is enough to copy.
                     static const size_t team = getenv("LILLIPUT_HIP_STAGE_THREADS") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_STAGE_THREADS"))) : 3;
-                    const size_t np = eng.upload_pieces(slot), nt = std::min(team, std::max<size_t>(1, np / 4));
+                    const size_t np = eng.upload_pieces(slot), copied = eng.upload_staged_bytes(slot);
+                    const size_t nt = copied < (8u << 20) ? 1 : std::min(team, std::max<size_t>(1, np / 4));
                     std::vector<std::thread> helpers;
-                    for (size_t t = 1; t < nt; t++) helpers.emplace_back([&eng, slot, np, nt, t] { eng.upload_copy(slot, np * t / nt, np * (t + 1) / nt); });
-                    eng.upload_copy(slot, 0, np / nt);
+                    const int dev = b->device;
+                    for (size_t t = 1; t < nt; t++) helpers.emplace_back([&eng, slot, np, nt, t, dev] { (void)lp_bind_thread_near(dev); eng.upload_copy(slot, np * t / nt, np * (t + 1) / nt); });
+                    if (copied) eng.upload_copy(slot, 0, np / nt);
                     for (auto& h : helpers) h.join();
                     rc = eng.upload_commit(slot, b->shared_copy);
                     part.staged_bytes += eng.upload_bytes(slot);
+                    part.copied_bytes += copied;
+                    part.direct_bytes += eng.upload_direct_bytes(slot);
+                    part.register_ms += eng.upload_register_ms(slot);
                 }
-                if (rc) { job.rc = map_status(rc); part.err = eng.last_error(); }
+                if (rc) { job.rc = map_status(rc); job.err = eng.last_error(); }
             }
-        } catch (...) { job.rc = LILLIPUT_ERR_DEVICE; part.err = "staging failed (out of host memory?)"; }
+        } catch (...) { job.rc = LILLIPUT_ERR_DEVICE; job.err = "staging failed (out of host memory?)"; }
         part.stage_ms += now() - t0;
         job.t_staged = now() - sh.t0;
         {
             std::lock_guard<std::mutex> lk(pp.mu);
             pp.mine.push_back(ji);
             pp.staged = k + 1;
-            if (job.rc) pp.abort = true;
         }
         pp.cv.notify_all();
-        if (job.rc) break;
     }
     {
         std::lock_guard<std::mutex> lk(pp.mu);
@@ -834,6 +864,7 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
 static void pipe_compute(LpBatch* res, LpBatchPart& part, LpPipe& pp, LpPipeShared& sh, const lilliput_batch_options* opt, const LpSink& sink)
 {
     LpEngine& eng = *part.eng;
+    (void)lp_bind_thread_near(eng.device());
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     eng.enable_timing(true);
     for (size_t k = 0;; k++) {
@@ -848,20 +879,25 @@ static void pipe_compute(LpBatch* res, LpBatchPart& part, LpPipe& pp, LpPipeShar
         part.stall_ms += now() - t0;
         LpPipeJob& job = sh.jobs[ji];
         int rc = job.rc;
+        if (rc) part.err = job.err;
         job.t_begin = now() - sh.t0;
         if (!rc && !job.items.empty()) {
             eng.select_upload((int)(k % LP_UPLOAD_SLOTS));
             try { rc = run_chunk(res, part, 0, (int)job.items.size(), job.hdrs.data(), job.items.data(), opt, sink); }
             catch (...) { rc = LILLIPUT_ERR_DEVICE; part.err = "chunk failed (out of host memory?)"; }
+            if (rc) (void)eng.sync(); // whatever of the chunk is still in flight reads the slot the stager is about to reuse
         }
         job.t_done = now() - sh.t0;
+        if (rc) {
+            fail_job(res, job, rc, sink.items);
+            part.failed_chunks++;
+            if (getenv("LILLIPUT_HIP_TRACE")) fprintf(stderr, "[lilliput_hip] chunk %zu failed (%d): %s\n", ji, rc, part.err.c_str());
+        }
         {
             std::lock_guard<std::mutex> lk(pp.mu);
             pp.done = k + 1;
-            if (rc) { part.rc = rc; pp.abort = true; }
         }
         pp.cv.notify_all();
-        if (rc) break;
     }
     eng.enable_timing(false);
     eng.select_upload(0);
@@ -912,7 +948,8 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
             for (auto& part : d->parts) {
                 for (int i = 0; i < 10; i++) part.acc[i] = 0;
                 for (int i = 0; i < 6; i++) part.tw[i] = 0;
-                part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = 0; part.staged_bytes = 0; part.err.clear();
+                part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = part.register_ms = 0; part.staged_bytes = part.copied_bytes = part.direct_bytes = 0;
+                part.failed_chunks = 0; part.err.clear();
             }
         const LpSink sink{b, items};
         sh.t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -928,6 +965,8 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
             }
         run_other(b, opt, items);
         for (auto& t : th) t.join();
+        for (LpBatch* d : devs) // every chunk has been decoded: the caller's pages that were registered for this call are released
+            for (auto& part : d->parts) part.eng->upload_release_pins();
         if (!b->retry.empty()) { // short baseline streams: once more through the one-image path, whose decoder falls back to libjpeg's serial rule
             b->other.clear();
             std::sort(b->retry.begin(), b->retry.end());

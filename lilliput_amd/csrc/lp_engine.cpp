@@ -21,14 +21,24 @@
 
 void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
 
+// The last error text is per THREAD: the ingest stager (upload_layout / upload_commit) and the compute thread (run_decode ...) of a
+// batch part work on the same engine at the same time, and each reports its own failure.
+std::string& LpEngine::err_ref()
+{
+    static thread_local std::string e;
+    return e;
+}
+#define err_ (LpEngine::err_ref())
+
 // The HIP runtime multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues, four by default. A batch runs four engines, each
 // with a compute stream, next to the copy stream(s) of the ingest pipeline; with four queues a compute stream ends up behind a copy
 // stream's barrier packets and one engine of four decodes at a third of the others' rate (measured: 8.9 k -> 10.6 k images/s end to
 // end with eight queues). The variable is read when the runtime initialises, i.e. at the first HIP call of the process; a value the
-// user has set is left alone.
+// user has set is left alone, and LILLIPUT_HIP_KEEP_RUNTIME_ENV=1 keeps the library from touching the environment at all (the effect
+// is process-wide: documented in include/lilliput_hip.h).
 namespace {
 struct LpRuntimeEnv {
-    LpRuntimeEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+    LpRuntimeEnv() { if (!(getenv("LILLIPUT_HIP_KEEP_RUNTIME_ENV") && atoi(getenv("LILLIPUT_HIP_KEEP_RUNTIME_ENV")))) setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 } lp_runtime_env;
 }
 
@@ -115,6 +125,17 @@ bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
 void LpEngine::d2h_small(const LpPinned& pin, void* host, const void* dev, size_t bytes)
 {
     lp_launch_copy_small(stream_, static_cast<uint8_t*>(pin.dev) + (static_cast<uint8_t*>(host) - pin.as<uint8_t>()), dev, bytes);
+}
+
+size_t LpEngine::device_bytes() const
+{
+    size_t n = 0;
+    for (const LpUpload& u : up_) n += u.d_raw.cap + u.d_huffs.cap + u.d_phuffs.cap;
+    for (const LpDevBuf* b : {&d_imgs_, &d_states_, &d_clean_, &d_rst_, &d_chunk_, &d_ckpt_, &d_exit_, &d_spec_exit_, &d_entry_, &d_tot_, &d_spec_tot_, &d_prefix_, &d_changed_,
+                              &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &heap_,
+                              &d_ops_, &d_taps_, &d_ranges_, &d_fops_, &d_tone_, &d_jobs_, &d_estates_, &d_ecoef_, &d_blkbits_, &d_bits_, &d_hdrs_, &d_out_, &d_packed_, &d_pkoff_})
+        n += b->cap;
+    return n;
 }
 
 int LpEngine::sync() { return check(hipStreamSynchronize(stream_), "hipStreamSynchronize") ? LP_OK : LP_ERR_DEVICE; }
@@ -218,19 +239,23 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
                 up.s.huff = found;
                 up.raw_off = raw_bytes;
                 up.raw_len = (uint32_t)sh.ecs_len;
-                u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len});
+                u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len, srcs[i].data, srcs[i].len, raw_bytes, false});
                 raw_bytes = align_up(raw_bytes + up.raw_len + 32, 16);
                 u.prog[(size_t)i].push_back(up);
             }
         } else {
             j.raw_len = (uint32_t)hdrs[i].ecs_len;
-            u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len});
+            u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len, srcs[i].data, srcs[i].len, raw_bytes, false});
             raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
         }
         j.nchunks = (j.raw_len + 4095) / 4096;
         u.src[(size_t)i] = j;
     }
     u.raw_bytes = raw_bytes;
+    u.stage_bytes = raw_bytes;
+    u.direct_bytes = 0;
+    u.copied_bytes = 0;
+    for (const LpUpload::Piece& pc : u.pieces) u.copied_bytes += pc.len;
     return LP_OK;
 }
 
@@ -302,17 +327,42 @@ int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpeg
     if (slot < 0 || slot >= LP_UPLOAD_SLOTS) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
     LpUpload& u = up_[slot];
+    u.pins.release(); // the set this slot held before has been decoded: its copies are long done
     u.staged_whole = true;
     layout_set(u, srcs, n, hdrs);
+    // How every segment travels (lp_hostmem.h): straight from the caller's pages when they are pinned -- already, or for the duration
+    // of this set -- else through the slot's pinned buffer. The item's whole buffer is registered, so the scans of a multi-scan file
+    // share one registration.
+    const LpIngestMode mode = lp_ingest_mode();
+    size_t so = 0, direct = 0, copied = 0;
+    for (LpUpload::Piece& pc : u.pieces) {
+        pc.direct = false;
+        if (mode != LP_INGEST_STAGED && pc.len) {
+            if (lp_host_is_pinned(pc.src, pc.len)) pc.direct = true;
+            else if (mode == LP_INGEST_AUTO && u.pins.add(pc.item, pc.item_len)) pc.direct = true;
+        }
+        if (pc.direct) { direct += pc.len; continue; }
+        pc.stage_off = so;
+        so = align_up(so + pc.len + 32, 16);
+        copied += pc.len;
+    }
+    u.stage_bytes = so;
+    u.direct_bytes = direct;
+    u.copied_bytes = copied;
     if (!u.ready && !check(hipEventCreateWithFlags(&u.ready, hipEventDisableTiming), "hipEventCreate")) return LP_ERR_DEVICE;
     if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(u.raw_bytes + kRawPad) ||
         !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
-        !u.stage.ensure(align_up(u.raw_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64)) {
+        !u.stage.ensure(align_up(u.stage_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64)) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
     }
     if (!host_scan_decode(u, n, hdrs)) { err_ = "pinned allocation failed"; return LP_ERR_DEVICE; }
     return LP_OK;
+}
+
+void LpEngine::upload_release_pins()
+{
+    for (auto& u : up_) u.pins.release();
 }
 
 // Staging copy into the pinned slot with streaming stores: the destination is written once and next read by the DMA engine, so
@@ -339,8 +389,9 @@ void LpEngine::upload_copy(int slot, size_t p0, size_t p1)
     uint8_t* stage = u.stage.as<uint8_t>();
     for (size_t q = p0; q < p1 && q < u.pieces.size(); q++) {
         const LpUpload::Piece& pc = u.pieces[q];
-        stream_copy(stage + pc.arena_off, pc.src, pc.len);
-        memset(stage + pc.arena_off + pc.len, 0, 32);
+        if (pc.direct) continue;
+        stream_copy(stage + pc.stage_off, pc.src, pc.len);
+        memset(stage + pc.stage_off + pc.len, 0, 32);
     }
 }
 
@@ -352,11 +403,30 @@ int LpEngine::upload_commit(int slot, hipStream_t on)
     hipStream_t copy_stream_ = on ? on : this->copy_stream_;
     // the tables travel from the tail of the pinned buffer too: a copy from pageable memory would hold this thread until the copy
     // engine has worked through everything queued before it
-    uint8_t* tab = u.stage.as<uint8_t>() + align_up(u.raw_bytes + 64, 256);
+    uint8_t* tab = u.stage.as<uint8_t>() + align_up(u.stage_bytes + 64, 256);
     const size_t hb = sizeof(LpHuffSet) * u.huffs.size(), pb = sizeof(LpProgHuff) * u.phuffs.size();
     if (hb) memcpy(tab, u.huffs.data(), hb);
     if (pb) memcpy(tab + hb, u.phuffs.data(), pb);
-    if (u.raw_bytes && !check(hipMemcpyAsync(u.d_raw.p, u.stage.p, u.raw_bytes, hipMemcpyHostToDevice, copy_stream_), "H2D raw")) return LP_ERR_DEVICE;
+    // One copy per pinned source segment; the staged ones leave the slot's buffer in runs (a run = neighbours in the arena that are
+    // neighbours in the buffer: a set without a pinned source is still ONE copy). The unstuff kernels mask by the segment's length,
+    // so what follows a directly copied segment in the arena (the previous set's bytes) is never looked at.
+    uint8_t* d_raw = u.d_raw.as<uint8_t>();
+    const uint8_t* stage = u.stage.as<uint8_t>();
+    for (size_t q = 0; q < u.pieces.size();) {
+        const LpUpload::Piece& pc = u.pieces[q];
+        if (pc.direct) {
+            if (pc.len && !check(hipMemcpyAsync(d_raw + pc.arena_off, pc.src, pc.len, hipMemcpyHostToDevice, copy_stream_), "H2D raw (caller's pages)")) return LP_ERR_DEVICE;
+            q++;
+            continue;
+        }
+        size_t r = q + 1, end = pc.stage_off + pc.len + 32;
+        while (r < u.pieces.size() && !u.pieces[r].direct && u.pieces[r].arena_off - pc.arena_off == u.pieces[r].stage_off - pc.stage_off) {
+            end = u.pieces[r].stage_off + u.pieces[r].len + 32;
+            r++;
+        }
+        if (!check(hipMemcpyAsync(d_raw + pc.arena_off, stage + pc.stage_off, end - pc.stage_off, hipMemcpyHostToDevice, copy_stream_), "H2D raw")) return LP_ERR_DEVICE;
+        q = r;
+    }
     if (hb && !check(hipMemcpyAsync(u.d_huffs.p, tab, hb, hipMemcpyHostToDevice, copy_stream_), "H2D huffs")) return LP_ERR_DEVICE;
     if (pb && !check(hipMemcpyAsync(u.d_phuffs.p, tab + hb, pb, hipMemcpyHostToDevice, copy_stream_), "H2D scan tables")) return LP_ERR_DEVICE;
     if (!check(hipEventRecord(u.ready, copy_stream_), "hipEventRecord")) return LP_ERR_DEVICE;

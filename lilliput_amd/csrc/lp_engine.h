@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "lp_hostmem.h"
 #include "lp_jpeg_parse.h"
 #include "lp_prog_host.h"
 #include "lp_launch.h"
@@ -79,11 +80,16 @@ struct LpTimings {
 #define LP_UPLOAD_SLOTS 4
 struct LpUpload {
     struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; uint32_t level; };
-    struct Piece { size_t arena_off; const uint8_t* src; size_t len; }; // an entropy-coded segment: 16-byte aligned in the arena, followed by 32 zero bytes
+    // An entropy-coded segment: 16-byte aligned in the arena. direct: the caller's bytes are pinned (lp_hostmem.h) and the DMA engine reads
+    // them where they lie; else they pass through the slot's pinned buffer at stage_off (followed by 32 zero bytes there).
+    struct Piece { size_t arena_off; const uint8_t* src; size_t len; const uint8_t* item; size_t item_len; size_t stage_off; bool direct; };
     std::vector<LpJpeg> src;                        // every image of the set (raw layout only)
     std::vector<LpHuffSet> huffs;
     std::vector<Piece> pieces;
     size_t raw_bytes = 0;
+    size_t stage_bytes = 0;                         // extent of the staged segments in the slot's pinned buffer (with their padding)
+    size_t copied_bytes = 0, direct_bytes = 0;      // entropy-coded bytes that travel through the pinned slot / straight from the caller's pages
+    LpPinScope pins;                                // the page ranges registered for this set (released when the slot is reused)
     bool staged_whole = false;                      // the pinned buffer holds the whole set (upload_copy / upload_commit); else windowed
     // progressive images (SOF2) and the other scan-by-scan cases
     bool prog_on_device = false;                    // where this set's scans are entropy-decoded (lp_prog_host.h)
@@ -104,7 +110,7 @@ public:
     explicit LpEngine(int device);
     ~LpEngine();
     bool ok() const { return ok_; }
-    const std::string& last_error() const { return err_; }
+    const std::string& last_error() const { return err_ref(); }  // of the calling thread: the stager and the compute thread of a batch part share an engine
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
 
@@ -128,7 +134,11 @@ public:
     // stream waits for the slot's event, not the host.
     int upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpegHeader* hdrs);
     size_t upload_pieces(int slot) const { return up_[slot].pieces.size(); }
-    size_t upload_bytes(int slot) const { return up_[slot].raw_bytes; }
+    size_t upload_bytes(int slot) const { return up_[slot].copied_bytes + up_[slot].direct_bytes; }   // entropy-coded bytes of the set
+    size_t upload_staged_bytes(int slot) const { return up_[slot].copied_bytes; }   // of them: copied through the pinned slot
+    size_t upload_direct_bytes(int slot) const { return up_[slot].direct_bytes; }   // read by the DMA engine from the caller's own pages
+    double upload_register_ms(int slot) const { return up_[slot].pins.register_ms(); }
+    void upload_release_pins();                      // after the last set's copies have completed: drop every temporary registration
     void upload_copy(int slot, size_t p0, size_t p1);
     int upload_commit(int slot, hipStream_t on = nullptr);   // on: a copy stream shared by several engines (sets arrive in enqueue order); default: the engine's own
     void select_upload(int slot) { u_ = &up_[slot]; }
@@ -179,6 +189,7 @@ public:
     // ThumbHash: out[(i * w + j) * cn ..] = frame(idx[w + i], idx[j]) for a w x h lattice of sample coordinates (host memory in and out).
     int gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out);
     int sync();
+    size_t device_bytes() const;                 // HBM held by this engine's grow-only arenas (the pool of the one-image ABI trims by it)
     const LpTimings& timings() const { return tm_; }
     void enable_timing(bool on) { timing_ = on; }
     void set_timings(const LpTimings& t) { tm_ = t; }
@@ -192,7 +203,7 @@ private:
     int device_ = 0;
     bool ok_ = false;
     bool timing_ = false;
-    std::string err_;
+    static std::string& err_ref();
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
     hipEvent_t ev_[16] = {};
     uint32_t S_cfg_ = 0, C_cfg_ = 0;

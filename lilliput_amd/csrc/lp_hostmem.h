@@ -1,0 +1,49 @@
+// lp_hostmem.h -- where the caller's encoded bytes are, as far as the DMA engines are concerned.
+//
+// The reference decodes from the caller's []byte in place (/root/reference/opencv.cpp:99-171: opencv_decoder_create wraps the Go
+// slice, nothing is copied). The batched path keeps that: a source that already sits in pinned memory -- because the service read it
+// into a lilliput_hip_host_alloc arena, or registered its receive buffers once with lilliput_hip_host_register -- is copied to the
+// device straight from where it is; any other source is pinned for the duration of the call (hipHostRegister on its page range,
+// every distinct range once however many items share it) and copied from there too. Only sources that cannot be pinned (tiny ones
+// that share pages with other work, ranges that partly overlap an existing registration, a failed hipHostRegister) take the staged
+// route through the engine's pinned slot.
+//
+// One process-wide table of page ranges answers "is [p, p + n) pinned?" and counts the users of a temporary registration, so the same
+// buffer appearing twice in a batch -- or in two batches running at once -- is registered exactly once (ROCclr aborts the process on
+// a second hipHostRegister of the same pages: "Memobj map does not have ptr").
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+enum LpIngestMode {
+    LP_INGEST_AUTO = 0,     // known-pinned sources direct, large pageable ones registered for the call, the rest staged
+    LP_INGEST_STAGED = 1,   // everything through the pinned slot (the round-2 pipeline; A/B measurements)
+    LP_INGEST_PINNED_ONLY = 2 // known-pinned sources direct, everything else staged (no per-call registration)
+};
+LpIngestMode lp_ingest_mode();      // LILLIPUT_HIP_INGEST = auto | register (= auto) | staged | pinned
+
+// True when every byte of [p, p + n) lies in memory this process has pinned through this library (arena or explicit registration).
+bool lp_host_is_pinned(const void* p, size_t n);
+
+// Temporary registrations of one chunk of a batch. add() tries to make [p, p + n) DMA-able and says whether it is; release() drops
+// what add() took (the last user of a range unregisters it). Not thread-safe by itself -- one scope per upload slot -- but any number
+// of scopes may be active at once.
+class LpPinScope {
+public:
+    ~LpPinScope() { release(); }
+    bool add(const void* p, size_t n);
+    void release();
+    size_t registered_bytes() const { return reg_bytes_; }  // bytes this scope registered itself (not those it found pinned)
+    double register_ms() const { return reg_ms_; }
+private:
+    std::vector<uintptr_t> held_;   // start addresses of the table entries this scope holds a reference on
+    size_t reg_bytes_ = 0;
+    double reg_ms_ = 0;
+};
+
+// NUMA placement of the ingest threads: the CPUs of the node the device hangs off (empty when unknown or switched off with
+// LILLIPUT_HIP_NUMA=0). lp_bind_thread_near(device) pins the calling thread to them; returns the node or -1.
+int lp_device_numa_node(int device);
+int lp_bind_thread_near(int device);

@@ -508,6 +508,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     // The framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so decoded, composited
     // and resized frames stay on the device for the duration of the call.
     struct LazyScope { int prev = lp_lazy_host_scope(1); ~LazyScope() { lp_lazy_host_scope(prev); } } lazy_scope;
+    LpEngineLease lease; // the whole Transform on one engine, one stream: the ABI calls below nest inside it
     struct CompositeScope { ImageOps* o; ~CompositeScope() { o->drop_composite(); } } composite_scope{o}; // ops.go:353-358
     // initializeTransform (ops.go:483-546)
     Header hdr;

@@ -15,7 +15,9 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = None
-        if self.world > 1:
+        # under torchrun (RANK set) the process group is brought up even for ONE rank, so that the RCCL path of the multi-GPU runs
+        # (backend "nccl": barrier, all-reduce of the elapsed time, all-gather of the counters) is the path a 1-GPU run takes too
+        if self.world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_ADDR")):
             import torch
             import torch.distributed as dist
 

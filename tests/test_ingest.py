@@ -1,0 +1,267 @@
+"""GPU tests of the ingest half of the batched transform (lilliput_hip_batch_transform / lilliput_hip_node_transform): however the
+caller's encoded bytes reach the device -- read in place from a pinned arena, from pages registered for the call, or copied through
+the engines' pinned slots -- the thumbnails are the reference CPU path's bytes (opencv.cpp:99-171 starts from the caller's []byte;
+opencv.go:872-900 is what Encode returns). Also: the headline configuration (default engines, default chunks, 4096 x 4096 sources)
+with EVERY output checked, the engine pool of the one-image ABI, and untrusted WebP canvas sizes."""
+import ctypes as C
+import hashlib
+import os
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth_jpegs(seeds, size, quality=90):
+    import multiprocessing as mp
+
+    from lilliput_amd import synth
+
+    workers = max(1, min(len(seeds), (os.cpu_count() or 2) - 1, 64))
+    with mp.get_context("fork").Pool(workers) as pool:
+        return list(pool.imap(synth._job, [(s, size, quality) for s in seeds], chunksize=1))
+
+
+def _expect(oracle, datas, w, h, q=85):
+    from concurrent.futures import ThreadPoolExecutor
+
+    use_ref = oracle.ref() is not None
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 4)) as ex:  # ctypes releases the GIL
+        return list(ex.map(lambda d: oracle.transform_jpeg_thumbnail(bytes(d), w, h, q, use_ref=use_ref), datas))
+
+
+@pytest.fixture(scope="module")
+def small_set(oracle):
+    datas = _synth_jpegs(range(100, 140), 512)
+    return datas, _expect(oracle, datas, 64, 64)
+
+
+def test_every_ingest_route_yields_the_reference_bytes(hip_lib, small_set):
+    import lilliput_amd as la
+
+    datas, exp = small_set
+    b = la.Batch(0)
+    prev = hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    try:
+        # (1) pageable sources, registered for the call (512 x 512 q90 sources are ~100 KB: above the 64 KiB registration floor)
+        r = b.transform(datas, 64, 64, quality=85)
+        st = b.ingest_stats()
+        assert [x.status for x in r] == [0] * len(datas)
+        assert [x.data for x in r] == exp
+        assert st["direct_bytes"] > 0 and st["direct_bytes"] + st["copied_bytes"] == st["staged_bytes"], st
+        # (2) everything through the pinned slots
+        hip_lib.lilliput_hip_set_ingest_mode(b"staged")
+        r = b.transform(datas, 64, 64, quality=85)
+        st = b.ingest_stats()
+        assert [x.data for x in r] == exp
+        assert st["direct_bytes"] == 0 and st["copied_bytes"] == st["staged_bytes"] > 0, st
+        # (3) sources in a pinned arena: read in place, nothing registered, nothing copied by the host
+        hip_lib.lilliput_hip_set_ingest_mode(b"pinned")
+        arena = la.HostArena(sum(len(d) + 64 for d in datas) + 4096, 0)
+        views = [arena.put(d) for d in datas]
+        assert hip_lib.lilliput_hip_host_is_pinned(views[3].ctypes.data, views[3].size) == 1
+        r = b.transform(views, 64, 64, quality=85)
+        st = b.ingest_stats()
+        assert [x.data for x in r] == exp
+        assert st["copied_bytes"] == 0 and st["direct_bytes"] == st["staged_bytes"] and st["register_ms"] == 0.0, st
+        # pageable sources in "pinned" mode are staged, not registered
+        r = b.transform(datas[:8], 64, 64, quality=85)
+        st = b.ingest_stats()
+        assert [x.data for x in r] == exp[:8] and st["direct_bytes"] == 0, st
+        arena.close()
+    finally:
+        hip_lib.lilliput_hip_set_ingest_mode([b"auto", b"staged", b"pinned"][prev])
+        b.close()
+
+
+def test_duplicate_overlapping_and_tiny_sources_in_one_batch(hip_lib, small_set, fixture_bytes):
+    """The same buffer named by several items (round 2's registration attempt aborted the process on that), two items that are views
+    of one allocation, sources far below the registration floor, and items sharing pages with registered ones."""
+    import lilliput_amd as la
+
+    datas, exp = small_set
+    hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    a = np.frombuffer(datas[0], dtype=np.uint8).copy()
+    big = np.concatenate([np.frombuffer(datas[1], dtype=np.uint8), np.frombuffer(datas[2], dtype=np.uint8)])  # two files in ONE allocation
+    v1, v2 = big[: len(datas[1])], big[len(datas[1]):]
+    tiny = np.frombuffer(fixture_bytes["sunrise.jpg"], dtype=np.uint8).copy()  # a few KB
+    items = [a, a, v1, v2, tiny, a, v2, tiny] * 5
+    want = {id(a): exp[0], id(v1): exp[1], id(v2): exp[2]}
+    b = la.Batch(0)
+    try:
+        for chunk in (0, 3):  # chunk 3: the duplicates land in different chunks, staged by different threads at the same time
+            r = b.transform(items, 64, 64, quality=85, chunk=chunk)
+            assert all(x.status == 0 for x in r)
+            tiny_out = {x.data for x, it in zip(r, items) if it is tiny}
+            assert len(tiny_out) == 1
+            for x, it in zip(r, items):
+                if it is not tiny:
+                    assert x.data == want[id(it)]
+        # nothing stays registered after the call: an explicit long-lived registration of the same buffer must succeed ...
+        assert hip_lib.lilliput_hip_host_register(big.ctypes.data, big.size) == 0
+        assert hip_lib.lilliput_hip_host_is_pinned(v2.ctypes.data, v2.size) == 1
+        r = b.transform([v1, v2, a], 64, 64, quality=85)
+        assert [x.data for x in r] == [exp[1], exp[2], exp[0]]
+        assert hip_lib.lilliput_hip_host_unregister(big.ctypes.data) == 0
+        assert hip_lib.lilliput_hip_host_is_pinned(v2.ctypes.data, v2.size) == 0
+        # ... and a read-only mapping (a bytes object's pages may be) or any other refusal falls back to staging, never fails the item
+        r = b.transform([bytes(datas[5])], 64, 64, quality=85)
+        assert r[0].data == exp[5]
+    finally:
+        b.close()
+
+
+def test_two_batches_at_once_share_registrations(hip_lib, small_set):
+    """Two batch objects (two goroutines of a service) transform the SAME source buffers concurrently: the page-range table counts the
+    users of a registration, the second call finds the pages pinned and the last one out unregisters."""
+    import lilliput_amd as la
+
+    datas, exp = small_set
+    hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    arrays = [np.frombuffer(d, dtype=np.uint8).copy() for d in datas]
+    out = [None, None]
+
+    def work(k):
+        b = la.Batch(0)
+        for _ in range(3):
+            out[k] = [x.data for x in b.transform(arrays, 64, 64, quality=85, chunk=5)]
+        b.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out[0] == exp and out[1] == exp
+
+
+def test_headline_configuration_every_output_checked(hip_lib, oracle):
+    """BASELINE configs[1] as bench.py runs it -- lilliput_hip_batch_transform with the default four engines and 32-image chunks, 8 192-bit
+    subsequences, pageable 4096 x 4096 q90 sources read in place -- on 64 distinct seeds, EVERY thumbnail compared with the reference
+    CPU path's bytes; then the same items through the two-slot node entry point."""
+    import lilliput_amd as la
+
+    hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    seeds = list(range(2000, 2064))
+    datas = _synth_jpegs(seeds, 4096)
+    exp = _expect(oracle, datas, 256, 256)
+    arrays = [np.frombuffer(d, dtype=np.uint8) for d in datas]
+    # 192 items = 6 chunks of 32 over 4 engines, every source three times (the duplicates exercise the page-range table at full size)
+    items = arrays * 3
+    b = la.Batch(0)
+    try:
+        b.prepare(items, dst_cap=256 << 10)
+        for _ in range(2):
+            failed = b.transform_prepared(256, 256, la.ImageOpsFit, False, 85, 0)
+            assert failed == 0
+            res = b.results()
+            bad = [i for i, r in enumerate(res) if r.status != 0 or r.data != exp[i % len(exp)]]
+            assert not bad, bad
+        st = b.ingest_stats()
+        assert st["direct_bytes"] == st["staged_bytes"] > 0 and st["copied_bytes"] == 0, st
+    finally:
+        b.close()
+    n = la.Node([0, 0])
+    try:
+        res = n.transform(items, 256, 256, quality=85, dst_cap=256 << 10)
+        bad = [i for i, r in enumerate(res) if r.status != 0 or r.data != exp[i % len(exp)]]
+        assert not bad, bad
+    finally:
+        n.close()
+
+
+def test_one_image_abi_engines_are_pooled_not_per_thread(hip_lib, fixture_bytes):
+    """README.md:82-85 / SURVEY 8(b): handles are used from whatever OS thread cgo picked. 128 threads each run one
+    ImageOps.Transform; afterwards the process holds at most the pool's idle engines (8), not one engine per thread."""
+    import lilliput_amd as la
+
+    data = fixture_bytes["large-sunrise.jpg"]
+    ops0 = la.ImageOps(2048)
+    d0 = la.Decoder(data)
+    want = ops0.Transform(d0, la.ImageOptions(".jpeg", 128, 128, la.ImageOpsFit, False, {la.JpegQuality: 85}))
+    d0.Close()
+    ops0.Close()
+    free0, total = C.c_size_t(), C.c_size_t()
+    assert hip_lib.lilliput_hip_mem_info(0, C.byref(free0), C.byref(total)) == 0
+    stats = (C.c_size_t * 4)()
+    hip_lib.lilliput_hip_engine_pool_stats(stats)
+    created0 = stats[2]
+    outs, errs = [None] * 128, []
+    gate = threading.Barrier(128)
+
+    def work(i):
+        try:
+            ops = la.ImageOps(2048)
+            dec = la.Decoder(data)
+            gate.wait()
+            outs[i] = ops.Transform(dec, la.ImageOptions(".jpeg", 128, 128, la.ImageOpsFit, False, {la.JpegQuality: 85}))
+            dec.Close()
+            ops.Close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(128)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]
+    assert all(o == want for o in outs)
+    hip_lib.lilliput_hip_engine_pool_stats(stats)
+    live, idle, created, trimmed = list(stats)
+    assert live == 0 and idle <= 8, list(stats)
+    assert created - created0 <= 128
+    # a handle used from two different threads one call after the other (what a migrating goroutine does): the second call's engine
+    # sees what the first one's left on the device
+    ops = la.ImageOps(2048)
+    dec = la.Decoder(data)
+    res = []
+    t = threading.Thread(target=lambda: res.append(ops.Transform(dec, la.ImageOptions(".jpeg", 128, 128, la.ImageOpsFit, False, {la.JpegQuality: 85}))))
+    t.start()
+    t.join()
+    dec.Close()
+    dec = la.Decoder(data)
+    res.append(ops.Transform(dec, la.ImageOptions(".jpeg", 128, 128, la.ImageOpsFit, False, {la.JpegQuality: 85})))
+    dec.Close()
+    ops.Close()
+    assert res == [want, want]
+    # device memory: the idle engines' arenas for a 1300 x 1942 decode are tens of MB each; 128 per-thread engines were ~4 GB
+    free1 = C.c_size_t()
+    hip_lib.lilliput_hip_mem_info(0, C.byref(free1), C.byref(total))
+    assert free0.value - free1.value < (2 << 30), (free0.value, free1.value)
+
+
+def _vp8x_anim_claiming(w, h):
+    """A tiny animated WebP whose VP8X header claims a w x h canvas (one 1 x 1 lossless frame)."""
+    vp8l = bytes([0x2F, 0x00, 0x00, 0x00, 0x00, 0x88, 0x88, 0x08])  # 1 x 1, no alpha -- minimal VP8L bitstream
+    def chunk(tag, body):
+        return tag + struct.pack("<I", len(body)) + body + (b"\x00" if len(body) & 1 else b"")
+    vp8x = bytes([0x02, 0, 0, 0]) + struct.pack("<I", w - 1)[:3] + struct.pack("<I", h - 1)[:3]
+    anim = struct.pack("<IH", 0, 0)
+    anmf = struct.pack("<I", 0)[:3] * 2 + struct.pack("<I", 0)[:3] * 2 + struct.pack("<I", 100)[:3] + b"\x00" + chunk(b"VP8L", vp8l)
+    body = b"WEBP" + chunk(b"VP8X", vp8x) + chunk(b"ANIM", anim) + chunk(b"ANMF", anmf)
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_webp_canvas_size_is_untrusted(hip_lib, small_set):
+    """A ~100-byte animated WebP that claims a 16 000 x 16 000 canvas: webp_decoder_create must not allocate (let alone touch) a
+    canvas-sized buffer, and the batch answers ErrBufTooSmall for the item while its neighbours are served."""
+    import resource
+
+    import lilliput_amd as la
+
+    datas, exp = small_set
+    evil = _vp8x_anim_claiming(16000, 16000)
+    b = la.Batch(0)
+    try:
+        rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        r = b.transform([datas[0], evil, datas[1]] + [evil] * 16, 64, 64, quality=85)
+        rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        assert r[0].data == exp[0] and r[2].data == exp[1]
+        assert all(x.status in (1, 3) for x in r[3:]) and r[1].status in (1, 3), [x.status for x in r]  # ErrBufTooSmall (or rejected as invalid), never served, never a crash
+        assert rss1 - rss0 < (512 << 10), (rss0, rss1)  # KiB: 17 x 1 GB canvases would show
+    finally:
+        b.close()
