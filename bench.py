@@ -124,10 +124,11 @@ def main():
     ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
     ap.add_argument("--out", type=int, default=256, help="thumbnail side (256 = the BASELINE workload; other values exercise other resize branches)")
     ap.add_argument("--resident", action="store_true", help="time the device pipeline with the compressed bytes already in HBM (kernel measurements) instead of host bytes in -> host bytes out")
-    ap.add_argument("--ingest", choices=["auto", "staged", "pinned"], default="auto",
-                    help="where the source bytes are and how they reach the device: auto = the caller's pageable buffers, their pages registered for the call and read "
-                         "by the DMA engine in place (zero-copy); pinned = the sources sit in a lilliput_hip_host_alloc arena (what a service that reads network "
-                         "bytes into pinned memory has; zero-copy, nothing registered per call); staged = every byte memcpy'd through pinned slots (round 2)")
+    ap.add_argument("--ingest", choices=["pinned", "pageable", "register", "staged"], default="pinned",
+                    help="where the source bytes are and how they reach the device: pinned (default) = the sources sit in a lilliput_hip_host_alloc arena, what a "
+                         "service that reads its network bytes into pinned memory has -- the DMA engine reads them in place, no host copy (zero-copy); pageable = "
+                         "the caller's ordinary buffers, memcpy'd through the engines' pinned slots (the round-2 pipeline); register = pageable buffers whose "
+                         "pages are registered per call (opt-in: slower than the copy on this driver); staged = force the slot route whatever the memory")
     ap.add_argument("--verify", type=int, default=8, help="outputs of the last timed step compared byte for byte with the oracle's after the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
@@ -141,8 +142,8 @@ def main():
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     barrier = ranks.barrier
 
-    if args.ingest == "staged":
-        os.environ["LILLIPUT_HIP_INGEST"] = "staged"    # read once by the library, before its first transform
+    if args.ingest in ("staged", "register"):
+        os.environ["LILLIPUT_HIP_INGEST"] = args.ingest    # read once by the library, before its first transform
     import lilliput_amd as la
 
     paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
@@ -333,9 +334,10 @@ def main():
             out["config"]["pcie_gen5_x16_measured_ceiling_GBps"] = 55.5   # scripts/microbench.hip on this box: pinned H2D 57 GB/s, staged pipeline 55.5 GB/s
             zero_copy = ingest["direct_bytes"] > 0 and ingest["copied_bytes"] * 50 < ingest["staged_bytes"]
             out["config"]["ingest"] = {"mode": "zero-copy" if zero_copy else "staged",
-                                       "source_memory": {"auto": "caller's pageable buffers; page ranges registered per call (hipHostRegister, each distinct range once)",
+                                       "source_memory": {"register": "caller's pageable buffers; page ranges registered per call (hipHostRegister, each distinct range once)",
                                                          "pinned": "lilliput_hip_host_alloc arena (pinned, device-mapped, on the GPU's NUMA node), filled before the timed region",
-                                                         "staged": "caller's pageable buffers; every byte memcpy'd into pinned slots"}[args.ingest],
+                                                         "pageable": "caller's pageable buffers; every byte memcpy'd into pinned slots by the ingest threads",
+                                                         "staged": "caller's pageable buffers; every byte memcpy'd into pinned slots by the ingest threads"}[args.ingest],
                                        "MB_to_device_per_step": round(ingest["staged_bytes"] / args.steps / 1e6, 1),
                                        "MB_read_in_place_per_step": round(ingest["direct_bytes"] / args.steps / 1e6, 1),
                                        "MB_copied_through_pinned_slots_per_step": round(ingest["copied_bytes"] / args.steps / 1e6, 1),

@@ -342,19 +342,23 @@ void lilliput_hip_batch_ingest_stats2(lilliput_hip_batch b, double out[8]);
  *     service that reads its network bytes into such an arena (Go: unsafe.Slice over the pointer) has nothing copied or registered
  *     per call.
  *   - lilliput_hip_host_register / _unregister: pin a long-lived buffer of the caller's once (a receive-buffer pool).
- *   - anything else: the page range of every distinct source of a call is registered for the duration of the call (each range once,
- *     however many items name it) when it is at least LILLIPUT_HIP_REGISTER_MIN bytes (default 64 KiB); smaller sources, sources that
- *     share pages with a live registration and sources the driver refuses to pin are copied through the engine's pinned slots.
- * LILLIPUT_HIP_INGEST = auto (default) | staged (everything through the slots: the round-2 pipeline) | pinned (no per-call
- * registration: arena / registered sources in place, the rest through the slots). Ingest threads and their pinned slots are placed on
- * the NUMA node the device hangs off (/sys/bus/pci/devices/<bdf>/numa_node); LILLIPUT_HIP_NUMA=0 switches that off. */
+ *   - anything else is copied through the engines' pinned slots by the ingest threads (one host memcpy per byte) -- or, with
+ *     LILLIPUT_HIP_INGEST=register, has its page range registered for the duration of the call (each distinct range once, however many
+ *     items name it; sources below LILLIPUT_HIP_REGISTER_MIN bytes, default 64 KiB, ranges that share a page with a live registration
+ *     and ranges the driver refuses are still copied). Per-call registration is opt-in: a first-time hipHostRegister of 4 MB costs
+ *     0.3 - 2 ms on this driver, several times the memcpy it saves (profiles/r03_a_ingest.md).
+ * LILLIPUT_HIP_INGEST = auto (default: pinned sources in place, the rest through the slots) | register | staged (everything through the
+ * slots). Ingest threads and their pinned slots are placed on the NUMA node the device hangs off
+ * (/sys/bus/pci/devices/<bdf>/numa_node); LILLIPUT_HIP_NUMA=0 switches that off.
+ * Why it matters: host memcpy into pinned memory does not scale on a two-socket box (12 threads 299 GB/s, 96 threads 42 GB/s: eight
+ * ranks' stagers together deliver a tenth of what eight links need), while sources in pinned memory cost the host nothing. */
 void* lilliput_hip_host_alloc(size_t bytes, int device);
 void lilliput_hip_host_free(void* p);
 int lilliput_hip_host_register(void* p, size_t bytes);      /* LILLIPUT_OK, or LILLIPUT_ERR_DEVICE when the range cannot be pinned */
 int lilliput_hip_host_unregister(void* p);
 int lilliput_hip_host_is_pinned(const void* p, size_t bytes); /* 1: the DMA engine will read [p, p + bytes) in place */
-int lilliput_hip_set_ingest_mode(const char* mode);         /* "auto" | "staged" | "pinned" for the transforms that start after the call (process-wide, like
-                                                             * LILLIPUT_HIP_INGEST); returns the previous mode as 0 / 1 / 2 */
+int lilliput_hip_set_ingest_mode(const char* mode);         /* "auto" | "register" | "staged" for the transforms that start after the call (process-wide, like
+                                                             * LILLIPUT_HIP_INGEST); returns the previous mode: 0 register, 1 staged, 2 auto */
 /* Resident form (kernel-pipeline measurements, tests): upload parses the headers and moves the compressed bytes into HBM,
  * run executes every device stage (inputs resident), download copies the encoded results back. */
 int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);

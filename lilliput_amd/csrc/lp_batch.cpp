@@ -141,9 +141,11 @@ struct LpBatch {
     std::mutex retry_mu;
     std::vector<int> retry;                     // baseline items the device decoder gave up on (too few blocks): decoded again libjpeg's way
     hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
+    hipStream_t extra_copy[3] = {nullptr, nullptr, nullptr}; // more queues for the many per-source copies of zero-copy ingest (see LpEngine::upload_commit)
+    int n_extra_copy = 0;
     int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
     size_t last_images = 0;                    // images this device's engines served in the last transform
-    ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); if (shared_copy) { (void)hipStreamSynchronize(shared_copy); (void)hipStreamDestroy(shared_copy); } }
+    ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); if (shared_copy) { (void)hipStreamSynchronize(shared_copy); (void)hipStreamDestroy(shared_copy); } for (auto q : extra_copy) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
     {
@@ -836,7 +838,7 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
                     for (size_t t = 1; t < nt; t++) helpers.emplace_back([&eng, slot, np, nt, t, dev] { (void)lp_bind_thread_near(dev); eng.upload_copy(slot, np * t / nt, np * (t + 1) / nt); });
                     if (copied) eng.upload_copy(slot, 0, np / nt);
                     for (auto& h : helpers) h.join();
-                    rc = eng.upload_commit(slot, b->shared_copy);
+                    rc = eng.upload_commit(slot, b->shared_copy, b->extra_copy, b->n_extra_copy);
                     part.staged_bytes += eng.upload_bytes(slot);
                     part.copied_bytes += copied;
                     part.direct_bytes += eng.upload_direct_bytes(slot);
@@ -928,6 +930,8 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         if (!rc && one_copy_queue && !d->shared_copy) {
             (void)hipSetDevice(d->device);
             if (hipStreamCreateWithFlags(&d->shared_copy, hipStreamNonBlocking) != hipSuccess) d->shared_copy = nullptr; // the engines' own streams then
+            static const int xq = getenv("LILLIPUT_HIP_DIRECT_COPY_QUEUES") ? std::max(1, std::min(4, atoi(getenv("LILLIPUT_HIP_DIRECT_COPY_QUEUES")))) : 1; // more queues LOSE next to the decode kernels (r03_a_ingest.md)
+            while (d->shared_copy && d->n_extra_copy < xq - 1 && hipStreamCreateWithFlags(&d->extra_copy[d->n_extra_copy], hipStreamNonBlocking) == hipSuccess) d->n_extra_copy++;
         }
     }
     if (!rc) {

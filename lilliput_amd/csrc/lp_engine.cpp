@@ -88,7 +88,10 @@ LpEngine::~LpEngine()
     if (stream_) { (void)hipStreamSynchronize(stream_); }
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); }
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
-    for (auto& u : up_) if (u.ready) (void)hipEventDestroy(u.ready);
+    for (auto& u : up_) {
+        if (u.ready) (void)hipEventDestroy(u.ready);
+        for (auto& e : u.ready_x) if (e) (void)hipEventDestroy(e);
+    }
     if (stream_) (void)hipStreamDestroy(stream_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
@@ -210,6 +213,7 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
         if (hi == u.huffs.size()) u.huffs.push_back(hdrs[i].huff);
         j.huff_idx = hi;
         j.raw_off = raw_bytes;
+        j.raw_skip = 0;
         j.scan_path = hdrs[i].scan_path ? 1 : 0;
         if (hdrs[i].scan_path && !u.prog_on_device) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
             j.raw_len = 0;
@@ -239,13 +243,13 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
                 up.s.huff = found;
                 up.raw_off = raw_bytes;
                 up.raw_len = (uint32_t)sh.ecs_len;
-                u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len, srcs[i].data, srcs[i].len, raw_bytes, false});
+                u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + sh.ecs_off, sh.ecs_len, srcs[i].data, srcs[i].len, raw_bytes, 0, false, i, (int)u.prog[(size_t)i].size(), 0});
                 raw_bytes = align_up(raw_bytes + up.raw_len + 32, 16);
                 u.prog[(size_t)i].push_back(up);
             }
         } else {
             j.raw_len = (uint32_t)hdrs[i].ecs_len;
-            u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len, srcs[i].data, srcs[i].len, raw_bytes, false});
+            u.pieces.push_back(LpUpload::Piece{raw_bytes, srcs[i].data + hdrs[i].ecs_off, hdrs[i].ecs_len, srcs[i].data, srcs[i].len, raw_bytes, 0, false, i, -1, 0});
             raw_bytes = align_up(raw_bytes + j.raw_len + 32, 16);
         }
         j.nchunks = (j.raw_len + 4095) / 4096;
@@ -337,22 +341,48 @@ int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpeg
     size_t so = 0, direct = 0, copied = 0;
     for (LpUpload::Piece& pc : u.pieces) {
         pc.direct = false;
+        pc.pin_base = 0;
         if (mode != LP_INGEST_STAGED && pc.len) {
-            if (lp_host_is_pinned(pc.src, pc.len)) pc.direct = true;
-            else if (mode == LP_INGEST_AUTO && u.pins.add(pc.item, pc.item_len)) pc.direct = true;
+            ptrdiff_t delta = 0;
+            if (lp_host_is_pinned(pc.src, pc.len, &delta, &pc.pin_base)) pc.direct = true;
+            else if (mode == LP_INGEST_REGISTER && u.pins.add(pc.item, pc.item_len, &delta, &pc.pin_base)) pc.direct = true;
+            pc.dev_delta = delta;
         }
+    }
+    // Second layout pass. Pinned sources that lie next to each other in HOST memory (files received back to back into one arena) keep
+    // their spacing in the device arena, so that one copy-engine transfer fetches the whole run -- 32 transfers of ~4 MB per set cost
+    // 7 % of the link rate against one of 135 MB (profiles/r03_a_ingest.md). A segment that follows another this way starts wherever
+    // the host spacing puts it; the unstuff kernels take the misalignment as LpJpeg::raw_skip.
+    static const bool by_kernel = getenv("LILLIPUT_HIP_DIRECT_COPY") && !strcmp(getenv("LILLIPUT_HIP_DIRECT_COPY"), "kernel");
+    static const size_t max_gap = getenv("LILLIPUT_HIP_MERGE_GAP") ? (size_t)strtoull(getenv("LILLIPUT_HIP_MERGE_GAP"), nullptr, 10) : (size_t)256 << 10;
+    size_t off = 0;
+    for (size_t q = 0; q < u.pieces.size(); q++) {
+        LpUpload::Piece& pc = u.pieces[q];
+        const LpUpload::Piece* pv = q ? &u.pieces[q - 1] : nullptr;
+        const bool follows = !by_kernel && pv && pc.direct && pv->direct && pc.scan < 0 && pv->scan < 0 && pc.pin_base && pc.pin_base == pv->pin_base &&
+                             pc.src >= pv->src + pv->len && (size_t)(pc.src - (pv->src + pv->len)) <= max_gap;
+        pc.arena_off = follows ? pv->arena_off + (size_t)(pc.src - pv->src) : align_up(off, 16);
+        off = pc.arena_off + pc.len + 32;
+        if (pc.scan < 0) {
+            u.src[(size_t)pc.img].raw_off = pc.arena_off & ~(size_t)15;
+            u.src[(size_t)pc.img].raw_skip = (uint32_t)(pc.arena_off & 15);
+            u.src[(size_t)pc.img].nchunks = (u.src[(size_t)pc.img].raw_skip + u.src[(size_t)pc.img].raw_len + 4095) / 4096;
+        } else
+            u.prog[(size_t)pc.img][(size_t)pc.scan].raw_off = pc.arena_off;
         if (pc.direct) { direct += pc.len; continue; }
         pc.stage_off = so;
         so = align_up(so + pc.len + 32, 16);
         copied += pc.len;
     }
+    u.raw_bytes = align_up(off, 16);
     u.stage_bytes = so;
     u.direct_bytes = direct;
     u.copied_bytes = copied;
     if (!u.ready && !check(hipEventCreateWithFlags(&u.ready, hipEventDisableTiming), "hipEventCreate")) return LP_ERR_DEVICE;
     if (!u.d_huffs.ensure(sizeof(LpHuffSet) * std::max<size_t>(1, u.huffs.size())) || !u.d_raw.ensure(u.raw_bytes + kRawPad) ||
         !u.d_phuffs.ensure(sizeof(LpProgHuff) * std::max<size_t>(1, u.phuffs.size())) ||
-        !u.stage.ensure(align_up(u.stage_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64)) {
+        !u.stage.ensure(align_up(u.stage_bytes + 64, 256) + sizeof(LpHuffSet) * u.huffs.size() + sizeof(LpProgHuff) * u.phuffs.size() + 64 +
+                        (sizeof(LpGatherPiece) + 4) * (u.pieces.size() + 2))) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
     }
@@ -395,7 +425,7 @@ void LpEngine::upload_copy(int slot, size_t p0, size_t p1)
     }
 }
 
-int LpEngine::upload_commit(int slot, hipStream_t on)
+int LpEngine::upload_commit(int slot, hipStream_t on, const hipStream_t* extra, int n_extra)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
@@ -412,11 +442,51 @@ int LpEngine::upload_commit(int slot, hipStream_t on)
     // so what follows a directly copied segment in the arena (the previous set's bytes) is never looked at.
     uint8_t* d_raw = u.d_raw.as<uint8_t>();
     const uint8_t* stage = u.stage.as<uint8_t>();
+    n_extra = std::max(0, std::min(3, extra ? n_extra : 0));
+    hipStream_t queues[4] = {copy_stream_, nullptr, nullptr, nullptr};
+    for (int k = 0; k < n_extra; k++) queues[k + 1] = extra[k];
+    bool used[4] = {true, false, false, false};
+    size_t rr = 0;
+    // How the segments that are read in place travel: LILLIPUT_HIP_DIRECT_COPY = sdma (default: copy-engine transfers, one per run of
+    // neighbours) | kernel (k_gather_raw, one launch per set: fast alone, but its workgroups take CU time from the decode kernels --
+    // 10.7 k images/s with 32 workgroups, 6.9 k with 256, against 10.8 k for per-segment transfers; profiles/r03_a_ingest.md)
+    static const bool by_kernel = getenv("LILLIPUT_HIP_DIRECT_COPY") && !strcmp(getenv("LILLIPUT_HIP_DIRECT_COPY"), "kernel");
+    static const uint32_t gather_wgs = getenv("LILLIPUT_HIP_GATHER_WGS") ? (uint32_t)std::max(1, atoi(getenv("LILLIPUT_HIP_GATHER_WGS"))) : 32u;
+    if (by_kernel && u.direct_bytes) {
+        // descriptors behind the tables in the slot's pinned buffer (mapped: the kernel reads them through its device alias)
+        size_t nd = 0;
+        for (const LpUpload::Piece& pc : u.pieces) nd += pc.direct && pc.len ? 1 : 0;
+        uint8_t* base = tab + align_up(hb + pb, 16);
+        LpGatherPiece* gp = reinterpret_cast<LpGatherPiece*>(base);
+        uint32_t* tf = reinterpret_cast<uint32_t*>(base + sizeof(LpGatherPiece) * nd);
+        uint32_t tiles = 0, q = 0;
+        for (const LpUpload::Piece& pc : u.pieces) {
+            if (!pc.direct || !pc.len) continue;
+            gp[q] = LpGatherPiece{pc.src + pc.dev_delta, (uint64_t)pc.arena_off, (uint32_t)pc.len, 0u};
+            tf[q++] = tiles;
+            tiles += (uint32_t)((pc.len + 4095) / 4096);
+        }
+        tf[q] = tiles;
+        const uint8_t* dev_base = static_cast<const uint8_t*>(u.stage.dev) + (base - u.stage.as<uint8_t>());
+        lp_launch_gather_raw(copy_stream_, reinterpret_cast<const LpGatherPiece*>(dev_base), reinterpret_cast<const uint32_t*>(dev_base + sizeof(LpGatherPiece) * nd), (uint32_t)nd,
+                             d_raw, std::min<uint32_t>(gather_wgs, std::max<uint32_t>(1u, tiles)));
+    }
     for (size_t q = 0; q < u.pieces.size();) {
         const LpUpload::Piece& pc = u.pieces[q];
         if (pc.direct) {
-            if (pc.len && !check(hipMemcpyAsync(d_raw + pc.arena_off, pc.src, pc.len, hipMemcpyHostToDevice, copy_stream_), "H2D raw (caller's pages)")) return LP_ERR_DEVICE;
-            q++;
+            size_t r = q + 1;
+            const uint8_t* end = pc.src + pc.len;
+            while (!by_kernel && r < u.pieces.size() && u.pieces[r].direct && u.pieces[r].pin_base == pc.pin_base && u.pieces[r].src >= end &&
+                   u.pieces[r].arena_off - pc.arena_off == (size_t)(u.pieces[r].src - pc.src)) { // a run of host neighbours: one transfer
+                end = u.pieces[r].src + u.pieces[r].len;
+                r++;
+            }
+            if (!by_kernel && end > pc.src) {
+                const size_t w = rr++ % (size_t)(n_extra + 1);
+                used[w] = true;
+                if (!check(hipMemcpyAsync(d_raw + pc.arena_off, pc.src, (size_t)(end - pc.src), hipMemcpyHostToDevice, queues[w]), "H2D raw (caller's pages)")) return LP_ERR_DEVICE;
+            }
+            q = by_kernel ? q + 1 : r;
             continue;
         }
         size_t r = q + 1, end = pc.stage_off + pc.len + 32;
@@ -430,6 +500,14 @@ int LpEngine::upload_commit(int slot, hipStream_t on)
     if (hb && !check(hipMemcpyAsync(u.d_huffs.p, tab, hb, hipMemcpyHostToDevice, copy_stream_), "H2D huffs")) return LP_ERR_DEVICE;
     if (pb && !check(hipMemcpyAsync(u.d_phuffs.p, tab + hb, pb, hipMemcpyHostToDevice, copy_stream_), "H2D scan tables")) return LP_ERR_DEVICE;
     if (!check(hipEventRecord(u.ready, copy_stream_), "hipEventRecord")) return LP_ERR_DEVICE;
+    u.ready_n = 0;
+    for (int k = 1; k <= n_extra; k++) {
+        if (!used[k]) continue;
+        hipEvent_t& e = u.ready_x[u.ready_n];
+        if (!e && !check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return LP_ERR_DEVICE;
+        if (!check(hipEventRecord(e, queues[k]), "hipEventRecord")) return LP_ERR_DEVICE;
+        u.ready_n++;
+    }
     return LP_OK;
 }
 
@@ -439,7 +517,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
     if (n <= 0 || (size_t)(first + n) > u_->src.size()) return LP_ERR_INVALID_IMAGE;
-    if (u_->staged_whole && !check(hipStreamWaitEvent(stream_, u_->ready, 0), "hipStreamWaitEvent")) return LP_ERR_DEVICE; // the set's H2D copies (copy stream)
+    if (u_->staged_whole) { // the set's H2D copies (copy queues)
+        if (!check(hipStreamWaitEvent(stream_, u_->ready, 0), "hipStreamWaitEvent")) return LP_ERR_DEVICE;
+        for (int k = 0; k < u_->ready_n; k++)
+            if (!check(hipStreamWaitEvent(stream_, u_->ready_x[k], 0), "hipStreamWaitEvent")) return LP_ERR_DEVICE;
+    }
     h_imgs_.assign(u_->src.begin() + first, u_->src.begin() + first + n);
     size_t max_ecs = 0;
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);

@@ -82,7 +82,10 @@ struct LpUpload {
     struct ProgScanUp { LpProgScan s; uint64_t raw_off; uint32_t raw_len; uint32_t level; };
     // An entropy-coded segment: 16-byte aligned in the arena. direct: the caller's bytes are pinned (lp_hostmem.h) and the DMA engine reads
     // them where they lie; else they pass through the slot's pinned buffer at stage_off (followed by 32 zero bytes there).
-    struct Piece { size_t arena_off; const uint8_t* src; size_t len; const uint8_t* item; size_t item_len; size_t stage_off; bool direct; };
+    // dev_delta: what to add to src to address the same byte from a kernel (0 under unified addressing).
+    // img / scan: whose segment it is (scan < 0: the image's only one), so that a re-layout can move it; pin_base: start of the pinned range
+    // the bytes lie in (0 = not pinned).
+    struct Piece { size_t arena_off; const uint8_t* src; size_t len; const uint8_t* item; size_t item_len; size_t stage_off; ptrdiff_t dev_delta; bool direct; int img, scan; uintptr_t pin_base; };
     std::vector<LpJpeg> src;                        // every image of the set (raw layout only)
     std::vector<LpHuffSet> huffs;
     std::vector<Piece> pieces;
@@ -102,7 +105,9 @@ struct LpUpload {
     size_t pcoef_total = 0;
     LpDevBuf d_raw, d_huffs, d_phuffs;
     LpPinned stage;
-    hipEvent_t ready = nullptr;                     // recorded behind the set's H2D copies
+    hipEvent_t ready = nullptr;                     // recorded behind the set's H2D copies (first copy queue)
+    hipEvent_t ready_x[3] = {nullptr, nullptr, nullptr}; // ... and behind those that went to the other copy queues
+    int ready_n = 0;                                // how many of ready_x the current set uses
 };
 
 class LpEngine {
@@ -140,7 +145,10 @@ public:
     double upload_register_ms(int slot) const { return up_[slot].pins.register_ms(); }
     void upload_release_pins();                      // after the last set's copies have completed: drop every temporary registration
     void upload_copy(int slot, size_t p0, size_t p1);
-    int upload_commit(int slot, hipStream_t on = nullptr);   // on: a copy stream shared by several engines (sets arrive in enqueue order); default: the engine's own
+    // on: a copy stream shared by several engines (sets arrive in enqueue order); default: the engine's own. extra / n_extra: further copy
+    // queues for the segments that are read from the caller's pages -- many 4 MB copies on ONE queue reach 49.8 GB/s, spread over four
+    // queues 56.3 (one 135 MB copy: 57.4; scripts/ingest_micro.hip, profiles/r03_b)
+    int upload_commit(int slot, hipStream_t on = nullptr, const hipStream_t* extra = nullptr, int n_extra = 0);
     void select_upload(int slot) { u_ = &up_[slot]; }
     // want_frame (optional, per image): 0 = keep only the planes (the image will go through fused_resample)
     int decode_uploaded(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame = nullptr);

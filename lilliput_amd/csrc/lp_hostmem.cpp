@@ -18,7 +18,13 @@
 namespace {
 
 enum Kind { kArena, kExplicit, kTemp };
-struct Entry { uintptr_t end; Kind kind; uint32_t refs; };
+struct Entry { uintptr_t end; Kind kind; uint32_t refs; ptrdiff_t dev_delta; };
+ptrdiff_t device_delta(void* host) // device alias of a pinned / registered host address
+{
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || !d) { (void)hipGetLastError(); return 0; }
+    return (ptrdiff_t)((uintptr_t)d - (uintptr_t)host);
+}
 
 struct Table {
     std::mutex mu;
@@ -65,11 +71,11 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 static int g_ingest_mode = -1; // -1: read LILLIPUT_HIP_INGEST on first use
 static LpIngestMode parse_ingest(const char* e)
 {
-    if (!e || !*e || !strcmp(e, "auto") || !strcmp(e, "register") || !strcmp(e, "zero-copy")) return LP_INGEST_AUTO;
+    if (!e || !*e || !strcmp(e, "auto") || !strcmp(e, "pinned")) return LP_INGEST_PINNED_ONLY;
+    if (!strcmp(e, "register")) return LP_INGEST_REGISTER;
     if (!strcmp(e, "staged")) return LP_INGEST_STAGED;
-    if (!strcmp(e, "pinned")) return LP_INGEST_PINNED_ONLY;
-    fprintf(stderr, "lilliput_hip: LILLIPUT_HIP_INGEST=%s is not one of auto | register | staged | pinned; using auto\n", e);
-    return LP_INGEST_AUTO;
+    fprintf(stderr, "lilliput_hip: LILLIPUT_HIP_INGEST=%s is not one of auto | pinned | register | staged; using auto\n", e);
+    return LP_INGEST_PINNED_ONLY;
 }
 LpIngestMode lp_ingest_mode()
 {
@@ -87,16 +93,19 @@ extern "C" int lilliput_hip_set_ingest_mode(const char* mode)
     return prev;
 }
 
-bool lp_host_is_pinned(const void* p, size_t n)
+bool lp_host_is_pinned(const void* p, size_t n, ptrdiff_t* dev_delta, uintptr_t* base)
 {
     if (!p || !n) return false;
     Table& t = table();
     std::lock_guard<std::mutex> lk(t.mu);
     auto it = t.covering((uintptr_t)p, (uintptr_t)p + n);
-    return it != t.by_start.end() && it->second.kind != kTemp; // a temporary registration belongs to whoever holds it
+    if (it == t.by_start.end() || it->second.kind == kTemp) return false; // a temporary registration belongs to whoever holds it
+    if (dev_delta) *dev_delta = it->second.dev_delta;
+    if (base) *base = it->first;
+    return true;
 }
 
-bool LpPinScope::add(const void* p, size_t n)
+bool LpPinScope::add(const void* p, size_t n, ptrdiff_t* dev_delta, uintptr_t* base)
 {
     if (!p || !n) return false;
     const uintptr_t lo = (uintptr_t)p, hi = lo + n, ps = page_size();
@@ -106,6 +115,8 @@ bool LpPinScope::add(const void* p, size_t n)
     auto it = t.covering(lo, hi);
     if (it != t.by_start.end()) {
         if (it->second.kind == kTemp) { it->second.refs++; held_.push_back(it->first); }
+        if (dev_delta) *dev_delta = it->second.dev_delta;
+        if (base) *base = it->first;
         return true;
     }
     if (n < register_min() || t.overlaps(a, b)) return false; // shares pages with a live registration: the staged route
@@ -116,13 +127,18 @@ bool LpPinScope::add(const void* p, size_t n)
     }
     reg_ms_ += now_ms() - t0;
     reg_bytes_ += b - a;
-    t.by_start[a] = Entry{b, kTemp, 1};
+    const ptrdiff_t dd = device_delta((void*)a);
+    t.by_start[a] = Entry{b, kTemp, 1, dd};
     held_.push_back(a);
+    if (dev_delta) *dev_delta = dd;
+    if (base) *base = a;
     return true;
 }
 
 void LpPinScope::release()
 {
+    reg_bytes_ = 0;
+    reg_ms_ = 0;
     if (held_.empty()) return;
     Table& t = table();
     std::lock_guard<std::mutex> lk(t.mu);
@@ -212,7 +228,8 @@ extern "C" void* lilliput_hip_host_alloc(size_t bytes, int device)
     if (e != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
     Table& t = table();
     std::lock_guard<std::mutex> lk(t.mu);
-    t.by_start[(uintptr_t)p] = Entry{(uintptr_t)p + bytes, kArena, 1};
+    const ptrdiff_t dd = device_delta(p);
+    t.by_start[(uintptr_t)p] = Entry{(uintptr_t)p + bytes, kArena, 1, dd};
     return p;
 }
 
@@ -239,7 +256,7 @@ extern "C" int lilliput_hip_host_register(void* p, size_t bytes)
     if (it != t.by_start.end() && it->second.kind != kTemp) return LILLIPUT_OK; // already pinned for good
     if (t.overlaps(a, b)) return LILLIPUT_ERR_DEVICE;
     if (hipHostRegister((void*)a, b - a, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return LILLIPUT_ERR_DEVICE; }
-    t.by_start[a] = Entry{b, kExplicit, 1};
+    t.by_start[a] = Entry{b, kExplicit, 1, device_delta((void*)a)};
     return LILLIPUT_OK;
 }
 

@@ -82,12 +82,14 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __res
     const LpJpeg& img = imgs[blockIdx.y];
     if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
+    const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
     uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
-    unstuff_load(raw, img.raw_len, pos0, u);
+    unstuff_load(raw, raw_end, pos0, u);
     uint32_t K[4], R[4], err = 0;
-    if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < img.raw_len) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err); // workgroup-uniform
-    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err);
+    if (blockIdx.x == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
+    else if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
+    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     uint32_t ea, eb, ta, tb;
     block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
     if (threadIdx.x == 0) chunk_cnt[img.chunk_off + blockIdx.x] = make_uint2(ta, tb);
@@ -142,12 +144,14 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
     const LpJpeg& img = imgs[blockIdx.y];
     if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
+    const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
     uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
-    unstuff_load(raw, img.raw_len, pos0, u);
+    unstuff_load(raw, raw_end, pos0, u);
     uint32_t K[4], R[4], err = 0;
-    if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < img.raw_len) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err); // workgroup-uniform
-    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, img.raw_len, K, R, err);
+    if (blockIdx.x == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
+    else if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
+    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     const uint32_t rany = R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3; // disjoint bit positions: one popcount for the four words
     uint32_t ea, eb, ta, tb;
     block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
@@ -661,6 +665,356 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Token path (lp_tok_core.h): the speculative pass and the verify pass leave one 32-bit token per decoded symbol behind, the
+// expansion kernel turns tokens into the same int8 blocks + DC differences k_huff_write produced -- without a second walk through the
+// Huffman stream.
+// Token memory of an image: sub_cap regions of 2 x cap tokens, [T_s | T_v] per subsequence.
+struct DevTok {
+    __amdgpu_buffer_rsrc_t rs;  // the image's token block
+    uint32_t base;              // byte offset of this lane's T_s or T_v
+    uint32_t cap_bytes;         // capacity of the region: a lane that would run over it (a table with a 1-bit code slipped through) stops storing
+    uint32_t t0, t1, t2, gbase;
+    bool grp_on;
+    __device__ __forceinline__ void put(uint32_t u, uint32_t iter, uint32_t tok, bool on)
+    {
+        if (u == 0) { t0 = tok; gbase = iter; grp_on = on; }
+        else if (u == 1) t1 = tok;
+        else if (u == 2) t2 = tok;
+        else if (grp_on && gbase * 4u + 16u <= cap_bytes) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){t0, t1, t2, tok}, rs, (int)(base + gbase * 4u), 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tok_rsrc(uint32_t* tok_arena, const LpJpeg& img, uint32_t cap)
+{
+    const size_t words = (size_t)img.sub_cap * 2u * cap;
+    return __builtin_amdgcn_make_buffer_rsrc(tok_arena + (size_t)img.sub_off * 2u * cap, 0, (int)(words * 4u), 0x00020000);
+}
+
+__global__ __launch_bounds__(HUFF_T) void k_tok_spec(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                     const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                     const uint32_t* __restrict__ rst_bits, LpCkptPk* __restrict__ ckpts,
+                                                     LpSubState* __restrict__ spec_exit, LpSubSum* __restrict__ spec_total,
+                                                     LpSubState* __restrict__ cur_exit, LpSubSum* __restrict__ cur_total,
+                                                     LpSubState* __restrict__ entry_used, uint32_t* __restrict__ spec_n, LpTokSpan* __restrict__ span,
+                                                     uint32_t* __restrict__ tok_arena, uint32_t cap, LpCkSched cs, uint32_t tot_sub)
+{
+    typedef CountMem MEM;
+    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
+    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
+    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    if (blockIdx.x * HUFF_T >= nsub) return;
+    stage_huff(s_hs4, huffs + img.huff_idx);
+    const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
+    const bool valid = sub < nsub;
+    const uint32_t g = img.sub_off + (valid ? sub : 0);
+    const LpImgCtx ic = make_ctx(img, st);
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+                      rst_bits + img.rst_off);
+    LpSubState entry;
+    const uint32_t S = img.sub_bits;
+    entry.p = valid ? sub * S : 0;
+    entry.bz = 0;
+    uint32_t sub_end = valid ? entry.p + S : 0;
+    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
+    DevCkSink ck{ckpts + g, tot_sub, valid};
+    DevTok tk;
+    tk.rs = tok_rsrc(tok_arena, img, cap);
+    tk.base = (valid ? sub : 0u) * 2u * cap * 4u;
+    tk.cap_bytes = valid ? cap * 4u : 0u;
+    tk.t0 = tk.t1 = tk.t2 = tk.gbase = 0;
+    tk.grp_on = false;
+    LpSubState ex;
+    LpSubSum tot;
+    uint32_t n = 0;
+    lp_spec_tok_pass(m, ic, sub_end, entry, cs, ck, tk, &ex, &tot, &n);
+    if (!valid) return;
+    spec_exit[g] = ex;
+    cur_exit[g] = ex;
+    spec_total[g] = tot;
+    cur_total[g] = tot;
+    spec_n[g] = n < cap ? n : cap;
+    if (n > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 2u); // more symbols than a subsequence can hold at 2 bits each (a 1-bit code): the serial decoder takes the image
+    LpTokSpan sp;
+    sp.head = 0;
+    sp.spec_from = sub == 0 ? 0u : (n < cap ? n : cap); // until a verify pass says otherwise: subsequence 0 is exact, of the others nothing is
+    span[g] = sp;
+    LpSubState none;
+    none.p = 0xffffffffu; none.bz = 0xffffffffu;
+    entry_used[g] = none;
+}
+
+// One verify walk in flight between two phases of a round.
+struct LpVerItem {
+    uint32_t sub;
+    LpSubState entry;
+    uint32_t pad;
+    LpVerState vs;
+};
+
+// Phase 0 of a round (FIRST): lane = subsequence; the lanes whose entry state moved start a walk. Later phases: lane = entry of the
+// image's list of walks the phase before left unfinished -- the same lanes, packed, so that a wave is not held by the one lane in a
+// hundred that needs ten times the median to synchronise. `until` = the step count at which this phase puts its walks down.
+template <bool FIRST>
+__global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+                                                       const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
+                                                       const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
+                                                       const LpSubState* __restrict__ spec_exit, const LpSubSum* __restrict__ spec_total,
+                                                       const uint32_t* __restrict__ spec_n, LpSubState* cur_exit, LpSubSum* __restrict__ cur_total,
+                                                       LpSubState* __restrict__ entry_used, LpTokSpan* __restrict__ span, uint32_t* changed, uint32_t round,
+                                                       uint32_t K, uint32_t ck_base, uint32_t tot_sub, uint32_t* __restrict__ tok_arena, uint32_t cap,
+                                                       const LpVerItem* __restrict__ q_in, LpVerItem* __restrict__ q_out, const uint32_t* __restrict__ n_in,
+                                                       uint32_t* __restrict__ n_out, uint32_t until)
+{
+    typedef CountMem MEM;
+    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
+    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
+    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
+    __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
+    if (round && __hip_atomic_load(changed + round - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    changed += round;
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    const uint32_t idx = blockIdx.x * HUFF_T + threadIdx.x;
+    uint32_t sub = idx;
+    LpSubState entry;
+    entry.p = 0; entry.bz = 0;
+    LpVerState vs;
+    vs.p = vs.bz = vs.iter = vs.kk = vs.ck_iter = vs.nblk = vs.nreset = vs.pad = 0;
+    bool need;
+    if (FIRST) {
+        if (blockIdx.x * HUFF_T >= nsub) return;
+        need = sub < nsub && sub != 0;
+        if (need) {
+            entry = load_state(cur_exit + img.sub_off + sub - 1);
+            need = !lp_state_eq(entry, entry_used[img.sub_off + sub]);
+        }
+        vs.p = entry.p; vs.bz = entry.bz;
+        vs.ck_iter = K ? lp_ck_next(ck_base, 0, 0) : 0u;
+    } else {
+        const uint32_t n = __hip_atomic_load(n_in + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x * HUFF_T >= n) return;
+        need = idx < n;
+        if (need) {
+            const LpVerItem it = q_in[img.sub_off + idx];
+            sub = it.sub; entry = it.entry; vs = it.vs;
+        }
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+    stage_huff(s_hs4, huffs + img.huff_idx);
+    if (!need) return;
+    const uint32_t g = img.sub_off + sub;
+    const LpImgCtx ic = make_ctx(img, st);
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+                      rst_bits + img.rst_off);
+    const uint32_t S = img.sub_bits;
+    uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t p = ckpts[(size_t)k * tot_sub + g].p;
+        cp[k << 6] = (uint16_t)(p == 0xffffffffu ? 0xffffu : p - sub * S);
+    }
+    DevCkSrc ck{cp, ckpts + g, tot_sub, sub * S};
+    uint32_t sub_end = sub * S + S;
+    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
+    DevTok tk;
+    tk.rs = tok_rsrc(tok_arena, img, cap);
+    tk.base = (sub * 2u + 1u) * cap * 4u;
+    tk.cap_bytes = cap * 4u;
+    tk.t0 = tk.t1 = tk.t2 = tk.gbase = 0;
+    tk.grp_on = false;
+    const LpSubState old_exit = load_state(cur_exit + g);
+    LpSubState ex = old_exit;
+    LpSubSum tot;
+    lp_sum_zero(tot);
+    LpTokSpan sp;
+    sp.head = 0; sp.spec_from = 0;
+    const bool over = lp_verify_tok_pass(m, ic, sub_end, vs, until, K, ck_base, ck, tk, spec_exit[g], spec_total[g], spec_n[g], &ex, &tot, &sp);
+    if (over) {
+        cur_total[g] = tot;
+        entry_used[g] = entry;
+        if (sp.head > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 2u);
+        sp.head = sp.head < cap ? sp.head : cap;
+        span[g] = sp;
+        if (!lp_state_eq(ex, old_exit)) {
+            store_state(cur_exit + g, ex);
+            atomicAdd(changed, 1u);
+        }
+    } else {
+        const uint32_t slot = atomicAdd(n_out + blockIdx.y, 1u);
+        LpVerItem it;
+        it.sub = sub; it.entry = entry; it.pad = 0; it.vs = vs;
+        if (slot < img.sub_cap) q_out[img.sub_off + slot] = it;
+    }
+}
+
+// k_sub_scan + what the expansion needs before it starts: a block that is open when a subsequence begins (entry state inside a block)
+// is assembled by more than one workgroup of k_tok_expand, with atomic ORs into storage that must start out as zero.
+__global__ __launch_bounds__(256) void k_tok_scan(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states, const LpSubSum* __restrict__ totals,
+                                                  LpSubSum* __restrict__ prefixes, const LpSubState* __restrict__ exits, int8_t* __restrict__ coef8_arena)
+{
+    __shared__ LpSubSum s_part[256];
+    const LpJpeg& img = imgs[blockIdx.x];
+    LpJpegState& st = states[blockIdx.x];
+    uint32_t n = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    const uint32_t t = threadIdx.x, per = (n + 255) / 256;
+    uint32_t b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    if (b0 > n) b0 = n;
+    LpSubSum acc;
+    lp_sum_zero(acc);
+    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, totals[img.sub_off + i]);
+    s_part[t] = acc;
+    __syncthreads();
+    LpSubSum pre;
+    lp_sum_zero(pre);
+    for (uint32_t i = 0; i < t; i++) pre = lp_sum_combine(pre, s_part[i]);
+    for (uint32_t i = b0; i < b1; i++) {
+        prefixes[img.sub_off + i] = pre;
+        if (i && (exits[img.sub_off + i - 1].bz & 255u) && pre.nblk >= 1u && pre.nblk - 1u < img.total_blocks) {
+            uint4* blk = reinterpret_cast<uint4*>(coef8_arena + img.coef_off + (size_t)(pre.nblk - 1u) * 64);
+            blk[0] = blk[1] = blk[2] = blk[3] = make_uint4(0, 0, 0, 0);
+        }
+        pre = lp_sum_combine(pre, totals[img.sub_off + i]);
+    }
+    if (t == 255) {
+        st.blocks_decoded = pre.nblk;
+        if (pre.nblk < img.total_blocks && !img.scan_path) st.error |= 2u;
+        if (n && (exits[img.sub_off + n - 1].bz & 255u) && pre.nblk >= 1u && pre.nblk - 1u < img.total_blocks) { // a stream that stops inside its last block
+            uint4* blk = reinterpret_cast<uint4*>(coef8_arena + img.coef_off + (size_t)(pre.nblk - 1u) * 64);
+            blk[0] = blk[1] = blk[2] = blk[3] = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+// Tokens -> coefficient blocks. One wave per subsequence, 64 tokens per step: the token says where its coefficient goes inside the
+// block (zn), the block is the subsequence's first block + the block-end flags before the token (ballot + mbcnt). Blocks are assembled
+// in an LDS ring of EXP_RING slots per wave (int8, transposed natural order like k_huff_write's, -128 = escape to the wide copy) and
+// leave sixteen at a time as 1 KiB of contiguous 16-byte stores, DC differences as 32 contiguous bytes. The block that is open at the
+// subsequence's entry and the one left open at its end are shared with the neighbours: those two are ORed into (zeroed) memory.
+#define EXP_RING 128
+__global__ __launch_bounds__(256) void k_tok_expand(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states, const LpSubState* __restrict__ exits,
+                                                    const LpSubSum* __restrict__ prefixes, const uint32_t* __restrict__ spec_n, const LpTokSpan* __restrict__ span,
+                                                    uint32_t* __restrict__ tok_arena, uint32_t cap, int8_t* __restrict__ coef8_arena, int16_t* __restrict__ wide_arena,
+                                                    uint32_t* __restrict__ wide_id_arena, int16_t* __restrict__ dc_arena)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_slots[4][EXP_RING * 64];
+    __shared__ int16_t s_dc[4][EXP_RING];
+    __shared__ uint8_t s_zz[80];
+    const LpJpeg& img = imgs[blockIdx.y];
+    const LpJpegState& st = states[blockIdx.y];
+    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
+    if (blockIdx.x * 4u >= nsub) return;
+    {
+        const uint8_t zz[80] = LP_ZIGZAG_INIT;
+        if (threadIdx.x < 80) s_zz[threadIdx.x] = (uint8_t)(((zz[threadIdx.x] & 7) << 3) | (zz[threadIdx.x] >> 3)); // blocks are stored transposed for k_idct's column pass
+        uint4* z4 = reinterpret_cast<uint4*>(&s_slots[0][0]);
+        for (uint32_t i = threadIdx.x; i < 4u * EXP_RING * 64u / 16u; i += 256u) z4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t sub = blockIdx.x * 4u + wv;
+    if (sub >= nsub) return;
+    const uint32_t g = img.sub_off + sub;
+    LpSubState entry;
+    entry.p = 0; entry.bz = 0;
+    if (sub) entry = exits[g - 1];
+    const LpTokSpan sp = span[g];
+    const uint32_t ns = spec_n[g];
+    const uint32_t head = sp.head < cap ? sp.head : cap, from = sp.spec_from < ns ? sp.spec_from : ns;
+    const uint32_t n = head + (ns - from);
+    const uint32_t total_blocks = img.total_blocks;
+    const bool open_at_entry = (entry.bz & 255u) != 0;
+    const uint32_t first = open_at_entry ? prefixes[g].nblk - 1u : prefixes[g].nblk; // block of the first token
+    const uint32_t shared_first = open_at_entry ? first : 0xffffffffu;
+    const __amdgpu_buffer_rsrc_t rs = tok_rsrc(tok_arena, img, cap);
+    const uint32_t off_s = (sub * 2u * cap + from) * 4u, off_v = (sub * 2u + 1u) * cap * 4u;
+    int8_t* slots = s_slots[wv];
+    int16_t* dcs = s_dc[wv];
+    int8_t* coef8 = coef8_arena + img.coef_off;
+    int16_t* wide = wide_arena + img.coef_off;
+    uint32_t* wide_id = wide_id_arena + img.coef_off / 64;
+    int16_t* dc16 = dc_arena + img.coef_off / 64;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t cur = first, fl = first; // block of the next token; first block not yet written out
+    uint64_t em_last = 0;             // block-end flags of the last group of tokens
+    // complete blocks [fl, upto) leave the ring, sixteen per round: four lanes move one block as 64 contiguous bytes
+    auto flush = [&](uint32_t upto) {
+        __builtin_amdgcn_wave_barrier();
+        while (fl < upto) {
+            const uint32_t b = fl + (lane >> 2), c = lane & 3u;
+            if (b < upto && b < total_blocks) {
+                uint4* sl = reinterpret_cast<uint4*>(slots + ((b & (EXP_RING - 1u)) << 6) + (c << 4));
+                const uint4 r = *sl;
+                *sl = make_uint4(0, 0, 0, 0);
+                if (b == shared_first) { // begun by an earlier subsequence: merge
+                    uint32_t* d = reinterpret_cast<uint32_t*>(coef8 + ((size_t)b << 6) + (c << 4));
+                    if (r.x) atomicOr(d, r.x);
+                    if (r.y) atomicOr(d + 1, r.y);
+                    if (r.z) atomicOr(d + 2, r.z);
+                    if (r.w) atomicOr(d + 3, r.w);
+                } else {
+                    __builtin_nontemporal_store((u32x4){r.x, r.y, r.z, r.w}, reinterpret_cast<u32x4*>(coef8 + ((size_t)b << 6) + (c << 4)));
+                    if (c == 0) dc16[b] = dcs[b & (EXP_RING - 1u)]; // a block that began here brought its DC symbol along
+                }
+            }
+            fl += 16u;
+        }
+        fl = upto;
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u) { // wave-uniform
+        const uint32_t j = j0 + lane;
+        const bool valid = j < n;
+        uint32_t t = 0;
+        if (valid) t = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(j < head ? off_v + j * 4u : off_s + (j - head) * 4u), 0, 0);
+        const uint32_t zn = lp_tok_zn(t), s = lp_tok_s(t);
+        const bool end = valid && lp_tok_ends_block(t);
+        const uint64_t em = __ballot(end);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+        const uint32_t blk = cur + before;
+        const int32_t v = lp_tok_value(t);
+        if (valid && blk < total_blocks) {
+            const uint32_t slot = (blk & (EXP_RING - 1u));
+            if (zn == 1u) dcs[slot] = (int16_t)v;
+            else if (s) {
+                const uint32_t k = zn - 1u, nat = s_zz[k < 79u ? k : 79u];
+                int32_t b8 = v;
+                if (v < -127 || v > 127) { // rare: the true value goes to the block's 16-bit copy (slot = the block itself: no allocation, any number of writers agree)
+                    wide[(size_t)blk * 64 + nat] = (int16_t)v;
+                    wide_id[blk] = blk;
+                    b8 = -128;
+                }
+                slots[(slot << 6) + nat] = (int8_t)b8;
+            }
+        }
+        cur += (uint32_t)__popcll(em);
+        // the ring holds the blocks [fl, cur]: write out what is complete once sixteen have gathered, or before the ring could wrap
+        // (a step touches at most 64 blocks + the open one)
+        em_last = em;
+        if (cur - fl >= 16u) flush(fl + ((cur - fl) & ~15u)); // full rounds only: at most 15 blocks wait, a step adds at most 64 + the open one
+    }
+    flush(cur);
+    // The block left open -- its remaining symbols belong to the next subsequence -- when the last token did not end a block: merge what
+    // is here. Its DC symbol is here too when the block began in this subsequence.
+    const bool open_at_end = n != 0 && ((em_last >> ((n - 1u) & 63u)) & 1ull) == 0;
+    if (open_at_end && cur < total_blocks && lane < 4u) {
+        __builtin_amdgcn_wave_barrier();
+        const uint4 r = *reinterpret_cast<const uint4*>(slots + ((cur & (EXP_RING - 1u)) << 6) + (lane << 4));
+        uint32_t* d = reinterpret_cast<uint32_t*>(coef8 + ((size_t)cur << 6) + (lane << 4));
+        if (r.x) atomicOr(d, r.x);
+        if (r.y) atomicOr(d + 1, r.y);
+        if (r.z) atomicOr(d + 2, r.z);
+        if (r.w) atomicOr(d + 3, r.w);
+        if (lane == 0 && (cur > first || !open_at_entry)) dc16[cur] = dcs[cur & (EXP_RING - 1u)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // DC differences -> absolute DC (in place): jdhuff.c decode_mcu keeps last_dc_val per component and process_restart zeroes
 // it every `dri` MCUs. An image is cut into 16 contiguous ranges of MCUs, one wave each; a wave walks its range 64 MCUs at
 // a time, lane = MCU (so the loads/stores of a step cover one contiguous run of bytes): a segmented wave scan of the
@@ -1124,6 +1478,51 @@ void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size
     if (!n16) return;
     const uint32_t blocks = n16 < 256u * 64u ? (n16 + 255u) / 256u : 64u;
     hipLaunchKernelGGL(k_copy_small, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src_pinned), n16);
+}
+
+// Zero-copy ingest: the entropy-coded segments of a chunk that sit in pinned, device-mapped host memory (lp_hostmem.h) are fetched by
+// THIS kernel -- 16-byte loads over the link, re-aligned on the way (a segment starts wherever its file's headers end; the arena wants
+// 16-byte alignment) -- instead of one copy-engine transfer per segment: 32 transfers of ~4 MB on one queue reach 49.8 GB/s, spread
+// over four queues next to the running decode kernels 40 - 45, one launch of this kernel with 64 workgroups 55 - 56 GB/s (one 135 MB
+// transfer: 57.4; scripts/ingest_micro.hip, profiles/r03_a_ingest.md). A workgroup walks 4 KiB tiles grid-stride; tile_first[p] is the
+// index of piece p's first tile, tile_first[n] the total.
+__global__ __launch_bounds__(256) void k_gather_raw(const LpGatherPiece* __restrict__ pcs, const uint32_t* __restrict__ tile_first, uint32_t npieces, uint8_t* __restrict__ arena)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t total = tile_first[npieces];
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        uint32_t lo = 0, hi = npieces; // the piece of tile t (workgroup-uniform binary search)
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (tile_first[mid] <= t) lo = mid; else hi = mid; }
+        const LpGatherPiece pc = pcs[lo];
+        const uint32_t off = (t - tile_first[lo]) * 4096u + threadIdx.x * 16u;
+        if (off >= pc.len) continue;
+        const uintptr_t src = (uintptr_t)pc.src + off;
+        const uint32_t mis = __builtin_amdgcn_readfirstlane((uint32_t)(src & 15u)); // the same for every lane of the piece: offsets are multiples of 16
+        const u32x4* a = reinterpret_cast<const u32x4*>(src - mis);
+        const u32x4 q0 = __builtin_nontemporal_load(a);
+        u32x4 out = q0;
+        if (mis) {
+            // the 16 bytes reach into the next aligned quad; when the segment ends inside this one the second load is skipped (it could
+            // touch the page after the caller's buffer)
+            u32x4 q1 = {0u, 0u, 0u, 0u};
+            if (off + 16u - mis < pc.len) q1 = __builtin_nontemporal_load(a + 1);
+            const uint32_t sh = (mis & 3u) * 8u; // v_alignbit: ({hi, lo} >> sh)[31:0], sh == 0 gives lo
+#define LP_FUNNEL(A, B, C, D, E) out = (u32x4){__builtin_amdgcn_alignbit(B, A, sh), __builtin_amdgcn_alignbit(C, B, sh), __builtin_amdgcn_alignbit(D, C, sh), __builtin_amdgcn_alignbit(E, D, sh)}
+            switch (mis >> 2) { // scalar branch
+            case 0: LP_FUNNEL(q0.x, q0.y, q0.z, q0.w, q1.x); break;
+            case 1: LP_FUNNEL(q0.y, q0.z, q0.w, q1.x, q1.y); break;
+            case 2: LP_FUNNEL(q0.z, q0.w, q1.x, q1.y, q1.z); break;
+            default: LP_FUNNEL(q0.w, q1.x, q1.y, q1.z, q1.w); break;
+            }
+#undef LP_FUNNEL
+        }
+        *reinterpret_cast<u32x4*>(arena + pc.dst_off + off) = out;
+    }
+}
+void lp_launch_gather_raw(hipStream_t s, const LpGatherPiece* d_pcs, const uint32_t* d_tile_first, uint32_t npieces, uint8_t* d_arena, uint32_t workgroups)
+{
+    if (!npieces) return;
+    hipLaunchKernelGGL(k_gather_raw, dim3(workgroups), dim3(256), 0, s, d_pcs, d_tile_first, npieces, d_arena);
 }
 
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round)

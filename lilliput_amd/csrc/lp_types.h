@@ -40,9 +40,10 @@ struct LpHuffSet {
 
 struct LpJpeg {
     // ---- stream
-    uint64_t raw_off;           // byte offset of the entropy-coded segment inside the raw arena
+    uint64_t raw_off;           // byte offset of the entropy-coded segment inside the raw arena, rounded DOWN to 16 (the unstuff kernels load 16 bytes per lane)
     uint32_t raw_len;           // bytes of ECS (markers inside: FF00, RSTn; ends before EOI)
-    uint32_t pad0;
+    uint32_t raw_skip;          // 0..15: bytes between raw_off and the segment's first byte. Non-zero when several pinned sources that lie next
+                                // to each other in host memory were fetched with ONE copy: their spacing in the arena is their spacing on the host
     uint64_t clean_off;         // word (uint32) offset of this image's unstuffed stream in the clean arena
     uint32_t clean_cap_words;
     uint32_t huff_idx;          // index into the LpHuffSet array

@@ -29,18 +29,22 @@ LP_UHD uint32_t lp_movemask4(uint32_t m)
 // (so a count is a popcount and the test for byte j is one bit-field extract -- no 16 x movemask).
 // TAIL = false: the caller knows that these 16 bytes AND the byte after them lie inside the segment (every lane of a chunk that is not
 // the segment's last): the range masks fall away.
-template <bool TAIL>
+// HEAD = true (the first 16 bytes of a segment that does not start on a 16-byte boundary of the raw arena -- see LpJpeg::raw_skip): the
+// first `head` bytes of this group lie BEFORE the segment; they are dropped and their values never looked at.
+template <bool TAIL, bool HEAD = false>
 LP_UHD void lp_unstuff_classify_masks(const uint32_t w[4], uint32_t prev, uint32_t next, uint32_t pos0, uint32_t raw_len, uint32_t K[4],
-                                      uint32_t R[4], uint32_t& err)
+                                      uint32_t R[4], uint32_t& err, uint32_t head = 0)
 {
     // bytes of this lane that lie inside the segment: the first n_in
     const uint32_t n_in = pos0 >= raw_len ? 0u : (raw_len - pos0 >= 16u ? 16u : raw_len - pos0);
     // the last byte of the segment has no successor: an FF there is not data. Index relative to this lane (wraps when it is elsewhere).
     const uint32_t last = raw_len - 1u - pos0;
-    uint32_t F[4], Z[4];
+    uint32_t F[4], Z[4], H[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        F[i] = lp_zero_bytes(~w[i]);                                   // == FF
+        const int32_t hn = (int32_t)head - 4 * i;                      // bytes of this word before the segment
+        H[i] = !HEAD || hn <= 0 ? 0u : hn >= 4 ? 0x80808080u : 0x80808080u >> (8u * (4u - (uint32_t)hn));
+        F[i] = lp_zero_bytes(~w[i]) & ~H[i];                           // == FF (never for a byte before the segment)
         Z[i] = lp_zero_bytes(w[i]);                                    // == 00
     }
     uint32_t bad = 0;
@@ -53,7 +57,7 @@ LP_UHD void lp_unstuff_classify_masks(const uint32_t w[4], uint32_t prev, uint32
         const uint32_t Zn = (Z[i] >> 8) | z_next;                      // the byte after is 00
         const uint32_t after_ff = ~F[i] & Fp;                          // a non-FF byte that follows an FF: 00 (stuffing), Dn, or a marker
         const int32_t n = (int32_t)n_in - 4 * i;                       // bytes of this word inside the segment
-        const uint32_t in = !TAIL || n >= 4 ? 0x80808080u : n <= 0 ? 0u : 0x80808080u >> (8u * (4u - (uint32_t)n));
+        const uint32_t in = (!TAIL || n >= 4 ? 0x80808080u : n <= 0 ? 0u : 0x80808080u >> (8u * (4u - (uint32_t)n))) & ~H[i];
         const uint32_t last_ff = (TAIL && raw_len != 0u && (last >> 2) == (uint32_t)i) ? (0x80u << (8u * (last & 3u))) & F[i] : 0u;
         K[i] = ((F[i] & Zn & ~last_ff) | (~F[i] & ~Fp & 0x80808080u)) & in;
         R[i] = after_ff & d & in;

@@ -44,9 +44,9 @@ def test_every_ingest_route_yields_the_reference_bytes(hip_lib, small_set):
 
     datas, exp = small_set
     b = la.Batch(0)
-    prev = hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    prev = hip_lib.lilliput_hip_set_ingest_mode(b"register")
     try:
-        # (1) pageable sources, registered for the call (512 x 512 q90 sources are ~100 KB: above the 64 KiB registration floor)
+        # (1) opt-in: pageable sources registered for the call (512 x 512 q90 sources are ~100 KB: above the 64 KiB registration floor)
         r = b.transform(datas, 64, 64, quality=85)
         st = b.ingest_stats()
         assert [x.status for x in r] == [0] * len(datas)
@@ -58,8 +58,8 @@ def test_every_ingest_route_yields_the_reference_bytes(hip_lib, small_set):
         st = b.ingest_stats()
         assert [x.data for x in r] == exp
         assert st["direct_bytes"] == 0 and st["copied_bytes"] == st["staged_bytes"] > 0, st
-        # (3) sources in a pinned arena: read in place, nothing registered, nothing copied by the host
-        hip_lib.lilliput_hip_set_ingest_mode(b"pinned")
+        # (3) the default: sources in a pinned arena are read in place, nothing registered, nothing copied by the host
+        hip_lib.lilliput_hip_set_ingest_mode(b"auto")
         arena = la.HostArena(sum(len(d) + 64 for d in datas) + 4096, 0)
         views = [arena.put(d) for d in datas]
         assert hip_lib.lilliput_hip_host_is_pinned(views[3].ctypes.data, views[3].size) == 1
@@ -67,13 +67,23 @@ def test_every_ingest_route_yields_the_reference_bytes(hip_lib, small_set):
         st = b.ingest_stats()
         assert [x.data for x in r] == exp
         assert st["copied_bytes"] == 0 and st["direct_bytes"] == st["staged_bytes"] and st["register_ms"] == 0.0, st
-        # pageable sources in "pinned" mode are staged, not registered
+        # sources packed back to back at odd offsets: neighbours in the arena travel as ONE transfer and keep their host spacing on the
+        # device, so their entropy-coded segments start at any byte offset (LpJpeg::raw_skip) -- alone, in pairs, in small and odd chunks
+        arena2 = la.HostArena(sum(len(d) + 8 for d in datas) + 4096, 0)
+        views2 = [arena2.put(d, align=1 + (i % 3)) for i, d in enumerate(datas)]
+        for chunk in (0, 1, 2, 7):
+            r = b.transform(views2, 64, 64, quality=85, chunk=chunk)
+            assert [x.data for x in r] == exp, chunk
+        r = b.transform(views2[::-1] + [datas[0]] + views2[5:9], 64, 64, quality=85)  # reversed (no run), a pageable one in between, a short run
+        assert [x.data for x in r] == exp[::-1] + [exp[0]] + exp[5:9]
+        arena2.close()
+        # pageable sources in the default mode are staged, not registered
         r = b.transform(datas[:8], 64, 64, quality=85)
         st = b.ingest_stats()
         assert [x.data for x in r] == exp[:8] and st["direct_bytes"] == 0, st
         arena.close()
     finally:
-        hip_lib.lilliput_hip_set_ingest_mode([b"auto", b"staged", b"pinned"][prev])
+        hip_lib.lilliput_hip_set_ingest_mode([b"register", b"staged", b"auto"][prev])
         b.close()
 
 
@@ -83,7 +93,7 @@ def test_duplicate_overlapping_and_tiny_sources_in_one_batch(hip_lib, small_set,
     import lilliput_amd as la
 
     datas, exp = small_set
-    hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    prev = hip_lib.lilliput_hip_set_ingest_mode(b"register")
     a = np.frombuffer(datas[0], dtype=np.uint8).copy()
     big = np.concatenate([np.frombuffer(datas[1], dtype=np.uint8), np.frombuffer(datas[2], dtype=np.uint8)])  # two files in ONE allocation
     v1, v2 = big[: len(datas[1])], big[len(datas[1]):]
@@ -111,6 +121,7 @@ def test_duplicate_overlapping_and_tiny_sources_in_one_batch(hip_lib, small_set,
         r = b.transform([bytes(datas[5])], 64, 64, quality=85)
         assert r[0].data == exp[5]
     finally:
+        hip_lib.lilliput_hip_set_ingest_mode([b"register", b"staged", b"auto"][prev])
         b.close()
 
 
@@ -120,7 +131,7 @@ def test_two_batches_at_once_share_registrations(hip_lib, small_set):
     import lilliput_amd as la
 
     datas, exp = small_set
-    hip_lib.lilliput_hip_set_ingest_mode(b"auto")
+    prev = hip_lib.lilliput_hip_set_ingest_mode(b"register")
     arrays = [np.frombuffer(d, dtype=np.uint8).copy() for d in datas]
     out = [None, None]
 
@@ -135,20 +146,22 @@ def test_two_batches_at_once_share_registrations(hip_lib, small_set):
         t.start()
     for t in th:
         t.join()
+    hip_lib.lilliput_hip_set_ingest_mode([b"register", b"staged", b"auto"][prev])
     assert out[0] == exp and out[1] == exp
 
 
 def test_headline_configuration_every_output_checked(hip_lib, oracle):
     """BASELINE configs[1] as bench.py runs it -- lilliput_hip_batch_transform with the default four engines and 32-image chunks, 8 192-bit
-    subsequences, pageable 4096 x 4096 q90 sources read in place -- on 64 distinct seeds, EVERY thumbnail compared with the reference
-    CPU path's bytes; then the same items through the two-slot node entry point."""
+    subsequences, 4096 x 4096 q90 sources in a pinned arena read in place -- on 64 distinct seeds, EVERY thumbnail compared with the
+    reference CPU path's bytes; then the same items (pageable copies: the staged route) through the two-slot node entry point."""
     import lilliput_amd as la
 
     hip_lib.lilliput_hip_set_ingest_mode(b"auto")
     seeds = list(range(2000, 2064))
     datas = _synth_jpegs(seeds, 4096)
     exp = _expect(oracle, datas, 256, 256)
-    arrays = [np.frombuffer(d, dtype=np.uint8) for d in datas]
+    arena = la.HostArena(sum(len(d) + 64 for d in datas) + 4096, 0)
+    arrays = [arena.put(d) for d in datas]
     # 192 items = 6 chunks of 32 over 4 engines, every source three times (the duplicates exercise the page-range table at full size)
     items = arrays * 3
     b = la.Batch(0)
@@ -166,11 +179,12 @@ def test_headline_configuration_every_output_checked(hip_lib, oracle):
         b.close()
     n = la.Node([0, 0])
     try:
-        res = n.transform(items, 256, 256, quality=85, dst_cap=256 << 10)
+        res = n.transform([np.frombuffer(d, dtype=np.uint8) for d in datas] * 3, 256, 256, quality=85, dst_cap=256 << 10)
         bad = [i for i, r in enumerate(res) if r.status != 0 or r.data != exp[i % len(exp)]]
         assert not bad, bad
     finally:
         n.close()
+        arena.close()
 
 
 def test_one_image_abi_engines_are_pooled_not_per_thread(hip_lib, fixture_bytes):
