@@ -10,6 +10,7 @@
 
 #include "lp_huff_core.h"
 #include "lp_prog_core.h"
+#include "lp_tok_core.h"
 #include "lp_unstuff_core.h"
 #include "lp_launch.h"
 #include "lp_types.h"
@@ -1563,6 +1564,55 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
                        (const LpSubSum*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
+}
+
+size_t lp_tok_item_bytes() { return sizeof(LpVerItem); }
+
+void lp_launch_tok_spec(hipStream_t s, const LpHuffArgs& a)
+{
+    if (!a.nimg || !a.max_sub) return;
+    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
+    hipLaunchKernelGGL(k_tok_spec, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, a.ckpts, a.spec_exit, a.spec_total, a.cur_exit, a.cur_total,
+                       a.entry_used, a.spec_n, static_cast<LpTokSpan*>(a.span), a.tok, a.tok_cap, a.sched, a.tot_sub);
+}
+
+// A round = phases with growing step budgets; a phase picks up the walks the one before put down (lists per image, so that a
+// workgroup still serves one image: its tables in LDS, its context in scalar registers). Synchronisation distances on photographic
+// streams: median ~110 steps, p90 ~360, p99 ~800, a few lanes the whole subsequence.
+void lp_launch_tok_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round)
+{
+    if (!a.nimg || !a.max_sub) return;
+    static const uint32_t until[LP_TOK_PHASES] = {96u, 320u, 1024u, 0xfffffff0u};
+    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
+    uint32_t* cnt = a.vq_cnt + (size_t)round * LP_TOK_PHASES * a.nimg;
+    for (uint32_t ph = 0; ph < LP_TOK_PHASES; ph++) {
+        const LpVerItem* qin = static_cast<const LpVerItem*>(a.vq[(ph + 1u) & 1u]);
+        LpVerItem* qout = static_cast<LpVerItem*>(a.vq[ph & 1u]);
+        const uint32_t* nin = ph ? cnt + (size_t)(ph - 1u) * a.nimg : cnt;
+        uint32_t* nout = cnt + (size_t)ph * a.nimg;
+        if (ph == 0)
+            hipLaunchKernelGGL(k_tok_verify<true>, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
+                               (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, (const uint32_t*)a.spec_n, a.cur_exit, a.cur_total, a.entry_used,
+                               static_cast<LpTokSpan*>(a.span), a.changed, round, a.sched.K, a.sched.base, a.tot_sub, a.tok, a.tok_cap, qin, qout, nin, nout, until[ph]);
+        else
+            hipLaunchKernelGGL(k_tok_verify<false>, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
+                               (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, (const uint32_t*)a.spec_n, a.cur_exit, a.cur_total, a.entry_used,
+                               static_cast<LpTokSpan*>(a.span), a.changed, round, a.sched.K, a.sched.base, a.tot_sub, a.tok, a.tok_cap, qin, qout, nin, nout, until[ph]);
+    }
+}
+
+void lp_launch_tok_scan(hipStream_t s, const LpHuffArgs& a)
+{
+    if (!a.nimg) return;
+    hipLaunchKernelGGL(k_tok_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSubSum*)a.cur_total, a.prefix, (const LpSubState*)a.cur_exit, a.coef8);
+}
+
+void lp_launch_tok_expand(hipStream_t s, const LpHuffArgs& a)
+{
+    if (!a.nimg || !a.max_sub) return;
+    dim3 g((a.max_sub + 3) / 4, a.nimg);
+    hipLaunchKernelGGL(k_tok_expand, g, dim3(256), 0, s, a.imgs, a.states, (const LpSubState*)a.cur_exit, (const LpSubSum*)a.prefix, (const uint32_t*)a.spec_n,
+                       static_cast<const LpTokSpan*>(a.span), a.tok, a.tok_cap, a.coef8, a.wide, a.wide_id, a.dc16);
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,

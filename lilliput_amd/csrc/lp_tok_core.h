@@ -80,9 +80,9 @@ LP_HD uint32_t lp_step_tok(LpLane<M>& L, uint32_t pk)
     return tok;
 }
 
-// SPEC pass that emits tokens. Tk must provide   void put(uint32_t iter, uint32_t tok, bool on)   -- called in every iteration by all
-// lanes of the wave (`on` = the lane decoded a symbol in this iteration); the device sink keeps four tokens in registers and stores them
-// at iterations 4q + 3, which is why the loop below is written four steps at a time.
+// SPEC pass that emits tokens. Tk must provide   void put(uint32_t u, uint32_t iter, uint32_t tok, bool on)   -- called in every step by
+// all lanes of the wave (u = position of the step inside its group of four, a compile-time constant after unrolling; `on` = the lane
+// decoded a symbol in this step); the device sink keeps the tokens of a group in registers and stores them at u == 3 as 16 bytes.
 // Ck as in lp_spec_pass. *ntok = tokens emitted (= decode steps of the lane).
 template <class M, class Ck, class Tk>
 LP_HD void lp_spec_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, const LpCkSched& cs, Ck& ck, Tk& tk, LpSubState* exit_st,
@@ -120,7 +120,7 @@ LP_HD void lp_spec_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubSta
                 tok = lp_step_tok(L, pk);
                 n++;
             }
-            tk.put(iter, tok, !done);
+            tk.put(u, iter, tok, !done);
             iter++;
         }
     } while (m.any(!done));
@@ -187,7 +187,7 @@ LP_HD bool lp_verify_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpVerS
                 sum.nblk += L.z == 0 ? 1u : 0u;
                 tok = lp_step_tok(L, pk);
             }
-            tk.put(iter, tok, on);
+            tk.put(u, iter, tok, on);
             iter += on ? 1u : 0u;
         }
         done = done || iter >= until_iter; // the budget is checked between groups of four: a store group is never split over two instalments

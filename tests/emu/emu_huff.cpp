@@ -176,7 +176,7 @@ struct HostTok {
     std::vector<uint32_t>* buf;
     uint32_t cap;
     bool* overflow;
-    void put(uint32_t iter, uint32_t tok, bool on)
+    void put(uint32_t, uint32_t iter, uint32_t tok, bool on)
     {
         if (!on) return;
         if (iter >= cap) { *overflow = true; return; }
