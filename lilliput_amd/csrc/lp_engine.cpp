@@ -627,6 +627,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             max_h_ = std::max(max_h_, j.height);
         }
     }
+    // token capacity of a subsequence (lp_tok_cap): from the shortest codes of the tables in this range
+    uint32_t tok_cap = 64;
+    for (const LpJpeg& j : h_imgs_)
+        if (!j.scan_path && j.huff_idx < u_->huffs.size()) tok_cap = std::max(tok_cap, lp_tok_cap(S_, j.bpm, lp_min_mcu_bits(u_->huffs[j.huff_idx], j.blkpack, j.bpm)));
     std::stable_sort(leveled.begin(), leveled.end(), [](const std::pair<uint32_t, LpProgScan>& x, const std::pair<uint32_t, LpProgScan>& y) { return x.first < y.first; });
     h_pscans_.clear();
     h_plevel_first_.clear();
@@ -649,7 +653,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
              d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
-             (!lp_entropy_tokens() || (d_tok_.ensure((size_t)tot_sub_ * 2u * lp_tok_cap(S_) * 4u + 256) && d_spec_n_.ensure((size_t)tot_sub_ * 4u + 64) &&
+             (!lp_entropy_tokens() || (d_tok_.ensure((size_t)tot_sub_ * 2u * tok_cap * 4u + 256) && d_spec_n_.ensure((size_t)tot_sub_ * 4u + 64) &&
                                        d_span_.ensure((size_t)tot_sub_ * 8u + 64) && d_vq_[0].ensure((size_t)tot_sub_ * lp_tok_item_bytes() + 64) &&
                                        d_vq_[1].ensure((size_t)tot_sub_ * lp_tok_item_bytes() + 64) &&
                                        d_vq_cnt_.ensure((size_t)(LP_VERIFY_ROUNDS + 1) * LP_TOK_PHASES * (size_t)n * 4u + 64))) &&
@@ -684,7 +688,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>(); ha.dc16 = d_dc_.as<int16_t>();
     ha.sched = sched_;
     const bool tokens = lp_entropy_tokens();
-    ha.tok = d_tok_.as<uint32_t>(); ha.tok_cap = lp_tok_cap(S_); ha.spec_n = d_spec_n_.as<uint32_t>(); ha.span = d_span_.p;
+    ha.tok = d_tok_.as<uint32_t>(); ha.tok_cap = tok_cap; ha.spec_n = d_spec_n_.as<uint32_t>(); ha.span = d_span_.p;
     ha.vq[0] = d_vq_[0].p; ha.vq[1] = d_vq_[1].p; ha.vq_cnt = d_vq_cnt_.as<uint32_t>();
     if (tokens) {
         if (!check(hipMemsetAsync(d_vq_cnt_.p, 0, (size_t)(LP_VERIFY_ROUNDS + 1) * LP_TOK_PHASES * (size_t)n * 4u, stream_), "memset verify lists")) return LP_ERR_DEVICE;
@@ -811,6 +815,12 @@ int LpEngine::finish_decode(int* status)
     tm_.verify_rounds = rounds;
     h_states_.resize((size_t)n);
     memcpy(h_states_.data(), h_dstate_.as<uint8_t>() + 64, sizeof(LpJpegState) * (size_t)n);
+    if (getenv("LILLIPUT_HIP_DEBUG_COUNTERS")) { // variant builds with -DLP_DEBUG_COUNTERS: verify walk statistics
+        uint64_t lane_steps = 0, wave_steps = 0, subs = 0;
+        for (int i = 0; i < n; i++) { lane_steps += h_states_[(size_t)i].pad; wave_steps += h_states_[(size_t)i].end_marker_pos; subs += h_states_[(size_t)i].nsub; }
+        fprintf(stderr, "[lilliput_hip] verify walks: %llu lane-steps (%.1f per subsequence), %llu wave-steps summed over the waves (x 64 = %.1f per subsequence); S = %u, %llu subsequences\n",
+                (unsigned long long)lane_steps, (double)lane_steps / std::max<uint64_t>(1, subs), (unsigned long long)wave_steps, 64.0 * wave_steps / std::max<uint64_t>(1, subs), S_, (unsigned long long)subs);
+    }
     if (nstreams) { // a scan that failed to unstuff fails its image
         h_pstates_.resize(nstreams);
         if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
@@ -873,7 +883,8 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     if (!check(hipMemcpyAsync(wid.data(), d_wide_id_.as<uint32_t>() + j.coef_off / 64, nb * 4, hipMemcpyDeviceToHost, stream_), "D2H wide ids")) return LP_ERR_DEVICE;
     int rc = sync();
     if (rc) return rc;
-    const uint32_t n_wide = std::min<uint32_t>(h_states_[(size_t)i].n_wide, (uint32_t)nb); // never more slots than blocks
+    // wide slots: handed out by a counter (WRITE kernel) or the block's own index (token path: every block owns slot = its index)
+    const uint32_t n_wide = lp_entropy_tokens() ? (uint32_t)nb : std::min<uint32_t>(h_states_[(size_t)i].n_wide, (uint32_t)nb);
     std::vector<int16_t> wide((size_t)n_wide * 64);
     if (n_wide) {
         if (!check(hipMemcpyAsync(wide.data(), d_wide_.as<int16_t>() + j.coef_off, wide.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H wide")) return LP_ERR_DEVICE;

@@ -277,6 +277,7 @@ struct DevMem {
     // (a ballot compared with zero stays in scalar registers; __any() materialises the vote in a VGPR and compares it again: two VALU
     // instructions per vote, three votes per decode step)
     __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+    __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ bool any_lt8(int32_t v) const { return __builtin_amdgcn_ballot_w64(v < 8) != 0ull; }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
@@ -670,21 +671,52 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
 // expansion kernel turns tokens into the same int8 blocks + DC differences k_huff_write produced -- without a second walk through the
 // Huffman stream.
 // Token memory of an image: sub_cap regions of 2 x cap tokens, [T_s | T_v] per subsequence.
+// Token sink. A lane parks its tokens in LDS -- window slot (step & 15), layout [slot][lane]: a conflict-free ds_write_b32 per step -- and
+// at the end of every window of 16 steps the wave writes the windows out together: four lanes move one lane's 64 bytes (lane 4e + q
+// takes tokens 4q .. 4q + 3 of lane 16r + e), so a store instruction covers sixteen 64-byte runs instead of sixty-four 16-byte pieces.
+#define TOK_WIN 16
 struct DevTok {
     __amdgpu_buffer_rsrc_t rs;  // the image's token block
-    uint32_t base;              // byte offset of this lane's T_s or T_v
-    uint32_t cap_bytes;         // capacity of the region: a lane that would run over it (a table with a 1-bit code slipped through) stops storing
-    uint32_t t0, t1, t2, gbase;
-    bool grp_on;
-    __device__ __forceinline__ void put(uint32_t u, uint32_t iter, uint32_t tok, bool on)
+    uint32_t base;              // byte offset of this lane's T_s or T_v inside it
+    uint32_t cap_bytes;         // capacity of the region (0 = a lane without a subsequence): nothing is stored past it
+    uint32_t* win;              // LDS: the wave's windows, TOK_WIN x 64 words; this lane's word of slot 0
+    uint32_t lane;
+    bool win_on;                // the lane was decoding at the start of the current window
+    __device__ __forceinline__ void flush(uint32_t first_step) // wave-uniform call; first_step = step of window slot 0
     {
-        if (u == 0) { t0 = tok; gbase = iter; grp_on = on; }
-        else if (u == 1) t1 = tok;
-        else if (u == 2) t2 = tok;
-        else if (grp_on && gbase * 4u + 16u <= cap_bytes) {
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){t0, t1, t2, tok}, rs, (int)(base + gbase * 4u), 0, 0);
+        const uint64_t on = __ballot(win_on);
+        __builtin_amdgcn_wave_barrier();
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t q = lane & 3u;
+        const uint32_t* wv = win - lane; // the wave's window block
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint32_t src = 16u * r + (lane >> 2);
+            const uint32_t sb = (uint32_t)__shfl((int)base, (int)src, 64), sc = (uint32_t)__shfl((int)cap_bytes, (int)src, 64);
+            const uint32_t off = (first_step + 4u * q) * 4u;
+            if (((on >> src) & 1ull) && off + 16u <= sc) {
+                const uint32_t* w = wv + src + (4u * q) * 64u;
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[64], w[128], w[192]}, rs, (int)(sb + off), 0, 2 /* nt */);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void put(uint32_t u, uint32_t step, uint32_t tok, bool on)
+    {
+        (void)u;
+#ifdef LP_EXP_NOTOK
+        asm volatile("" :: "v"(tok)); (void)step; (void)on; return; // timing experiment: what do the token stores cost?
+#endif
+        const uint32_t slot = step & (TOK_WIN - 1u); // wave-uniform
+        if (slot == 0u) win_on = on;
+        win[slot * 64u] = tok;
+#ifndef LP_EXP_NOTOKFLUSH
+        if (slot == TOK_WIN - 1u) { LP_KEEP_UNIFORM_BRANCH(); flush(step - (TOK_WIN - 1u)); }
+#endif
+    }
+    __device__ __forceinline__ void finish(uint32_t step) // the window the loop ended in
+    {
+        if (step & (TOK_WIN - 1u)) flush(step & ~(TOK_WIN - 1u));
     }
 };
 
@@ -706,6 +738,7 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_spec(const LpJpeg* __restrict__ 
     __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
     const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
+    __shared__ uint32_t s_tokwin[HUFF_T * TOK_WIN];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
@@ -728,8 +761,9 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_spec(const LpJpeg* __restrict__ 
     tk.rs = tok_rsrc(tok_arena, img, cap);
     tk.base = (valid ? sub : 0u) * 2u * cap * 4u;
     tk.cap_bytes = valid ? cap * 4u : 0u;
-    tk.t0 = tk.t1 = tk.t2 = tk.gbase = 0;
-    tk.grp_on = false;
+    tk.lane = threadIdx.x & 63u;
+    tk.win = s_tokwin + (threadIdx.x >> 6) * (TOK_WIN * 64) + tk.lane;
+    tk.win_on = false;
     LpSubState ex;
     LpSubSum tot;
     uint32_t n = 0;
@@ -740,7 +774,7 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_spec(const LpJpeg* __restrict__ 
     spec_total[g] = tot;
     cur_total[g] = tot;
     spec_n[g] = n < cap ? n : cap;
-    if (n > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 2u); // more symbols than a subsequence can hold at 2 bits each (a 1-bit code): the serial decoder takes the image
+    if (n > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 8u); // more symbols than a subsequence holds at 2 bits each (a table with a 1-bit code): the serial decoder takes the image (bit 3 survives k_reset_tail_state)
     LpTokSpan sp;
     sp.head = 0;
     sp.spec_from = sub == 0 ? 0u : (n < cap ? n : cap); // until a verify pass says otherwise: subsequence 0 is exact, of the others nothing is
@@ -777,6 +811,7 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict_
     const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
+    __shared__ uint32_t s_tokwin[HUFF_T * TOK_WIN];
     if (round && __hip_atomic_load(changed + round - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     changed += round;
     const LpJpeg& img = imgs[blockIdx.y];
@@ -809,7 +844,12 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict_
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;
     stage_huff(s_hs4, huffs + img.huff_idx);
-    if (!need) return;
+    const uint64_t walkers = __builtin_amdgcn_ballot_w64(need);
+    if (!walkers) return; // a whole wave without a walk
+    // lanes without a walk stay: the token windows leave the wave cooperatively (DevTok::flush), four lanes per walking lane. They
+    // count steps like the walkers (every walk of a phase is at the same step).
+    const uint32_t step0 = (uint32_t)__shfl((int)vs.iter, (int)__builtin_ctzll(walkers), 64);
+    if (!need) { sub = 0; vs.p = vs.bz = vs.kk = vs.nblk = vs.nreset = 0; vs.iter = step0; }
     const uint32_t g = img.sub_off + sub;
     const LpImgCtx ic = make_ctx(img, st);
     MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
@@ -817,7 +857,7 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict_
     const uint32_t S = img.sub_bits;
     uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
     for (uint32_t k = 0; k < K; k++) {
-        const uint32_t p = ckpts[(size_t)k * tot_sub + g].p;
+        const uint32_t p = need ? ckpts[(size_t)k * tot_sub + g].p : 0xffffffffu;
         cp[k << 6] = (uint16_t)(p == 0xffffffffu ? 0xffffu : p - sub * S);
     }
     DevCkSrc ck{cp, ckpts + g, tot_sub, sub * S};
@@ -826,20 +866,33 @@ __global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict_
     DevTok tk;
     tk.rs = tok_rsrc(tok_arena, img, cap);
     tk.base = (sub * 2u + 1u) * cap * 4u;
-    tk.cap_bytes = cap * 4u;
-    tk.t0 = tk.t1 = tk.t2 = tk.gbase = 0;
-    tk.grp_on = false;
+    tk.cap_bytes = need ? cap * 4u : 0u;
+    tk.lane = threadIdx.x & 63u;
+    tk.win = s_tokwin + (threadIdx.x >> 6) * (TOK_WIN * 64) + tk.lane;
+    tk.win_on = false;
     const LpSubState old_exit = load_state(cur_exit + g);
     LpSubState ex = old_exit;
     LpSubSum tot;
     lp_sum_zero(tot);
     LpTokSpan sp;
     sp.head = 0; sp.spec_from = 0;
-    const bool over = lp_verify_tok_pass(m, ic, sub_end, vs, until, K, ck_base, ck, tk, spec_exit[g], spec_total[g], spec_n[g], &ex, &tot, &sp);
+#ifdef LP_DEBUG_COUNTERS
+    const uint32_t steps0 = vs.iter;
+#endif
+    const bool over = lp_verify_tok_pass(m, ic, sub_end, vs, until, K, ck_base, ck, tk, spec_exit[g], spec_total[g], spec_n[g], &ex, &tot, &sp, need);
+    if (!need) return;
+#ifdef LP_DEBUG_COUNTERS
+    { // steps this instalment walked: summed over the lanes, and the wave's longest (what the wave costs)
+        uint32_t steps = vs.iter - steps0, mx = steps;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
+        atomicAdd(const_cast<uint32_t*>(&states[blockIdx.y].pad), steps);
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(const_cast<uint32_t*>(&states[blockIdx.y].end_marker_pos), mx);
+    }
+#endif
     if (over) {
         cur_total[g] = tot;
         entry_used[g] = entry;
-        if (sp.head > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 2u);
+        if (sp.head > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 8u);
         sp.head = sp.head < cap ? sp.head : cap;
         span[g] = sp;
         if (!lp_state_eq(ex, old_exit)) {
@@ -943,6 +996,7 @@ __global__ __launch_bounds__(256) void k_tok_expand(const LpJpeg* __restrict__ i
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     uint32_t cur = first, fl = first; // block of the next token; first block not yet written out
     uint64_t em_last = 0;             // block-end flags of the last group of tokens
+    uint32_t n_last = 0;              // index of that group's first token
     // complete blocks [fl, upto) leave the ring, sixteen per round: four lanes move one block as 64 contiguous bytes
     auto flush = [&](uint32_t upto) {
         __builtin_amdgcn_wave_barrier();
@@ -968,41 +1022,51 @@ __global__ __launch_bounds__(256) void k_tok_expand(const LpJpeg* __restrict__ i
         fl = upto;
         __builtin_amdgcn_wave_barrier();
     };
-    for (uint32_t j0 = 0; j0 < n; j0 += 64u) { // wave-uniform
-        const uint32_t j = j0 + lane;
-        const bool valid = j < n;
-        uint32_t t = 0;
-        if (valid) t = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(j < head ? off_v + j * 4u : off_s + (j - head) * 4u), 0, 0);
-        const uint32_t zn = lp_tok_zn(t), s = lp_tok_s(t);
-        const bool end = valid && lp_tok_ends_block(t);
-        const uint64_t em = __ballot(end);
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-        const uint32_t blk = cur + before;
-        const int32_t v = lp_tok_value(t);
-        if (valid && blk < total_blocks) {
-            const uint32_t slot = (blk & (EXP_RING - 1u));
-            if (zn == 1u) dcs[slot] = (int16_t)v;
-            else if (s) {
-                const uint32_t k = zn - 1u, nat = s_zz[k < 79u ? k : 79u];
-                int32_t b8 = v;
-                if (v < -127 || v > 127) { // rare: the true value goes to the block's 16-bit copy (slot = the block itself: no allocation, any number of writers agree)
-                    wide[(size_t)blk * 64 + nat] = (int16_t)v;
-                    wide_id[blk] = blk;
-                    b8 = -128;
+    // 256 tokens per round: four coalesced loads in flight while the four before them are expanded (one dependent load per step left
+    // the kernel waiting on memory: 25 us per image instead of ~8)
+    auto load = [&](uint32_t j) -> uint32_t {
+        return j < n ? __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(j < head ? off_v + j * 4u : off_s + (j - head) * 4u), 0, 0) : 0u;
+    };
+    uint32_t nx0 = load(lane), nx1 = load(64u + lane), nx2 = load(128u + lane), nx3 = load(192u + lane);
+    for (uint32_t j0 = 0; j0 < n; j0 += 256u) { // wave-uniform
+        const uint32_t tq[4] = {nx0, nx1, nx2, nx3};
+        if (j0 + 256u < n) { nx0 = load(j0 + 256u + lane); nx1 = load(j0 + 320u + lane); nx2 = load(j0 + 384u + lane); nx3 = load(j0 + 448u + lane); }
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; qq++) {
+            const uint32_t j = j0 + qq * 64u + lane;
+            if (j0 + qq * 64u >= n) break; // wave-uniform
+            const bool valid = j < n;
+            const uint32_t t = tq[qq];
+            const uint32_t zn = lp_tok_zn(t), s = lp_tok_s(t);
+            const bool end = valid && lp_tok_ends_block(t);
+            const uint64_t em = __ballot(end);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+            const uint32_t blk = cur + before;
+            const int32_t v = lp_tok_value(t);
+            if (valid && blk < total_blocks) {
+                const uint32_t slot = (blk & (EXP_RING - 1u));
+                if (zn == 1u) dcs[slot] = (int16_t)v;
+                else if (s) {
+                    const uint32_t k = zn - 1u, nat = s_zz[k < 79u ? k : 79u];
+                    int32_t b8 = v;
+                    if (v < -127 || v > 127) { // rare: the true value goes to the block's 16-bit copy (slot = the block itself: no allocation, any number of writers agree)
+                        wide[(size_t)blk * 64 + nat] = (int16_t)v;
+                        wide_id[blk] = blk;
+                        b8 = -128;
+                    }
+                    slots[(slot << 6) + nat] = (int8_t)b8;
                 }
-                slots[(slot << 6) + nat] = (int8_t)b8;
             }
+            cur += (uint32_t)__popcll(em);
+            em_last = em;
+            n_last = j0 + qq * 64u;
+            if (cur - fl >= 16u) flush(fl + ((cur - fl) & ~15u)); // full rounds only: at most 15 blocks wait, a step adds at most 64 + the open one
         }
-        cur += (uint32_t)__popcll(em);
-        // the ring holds the blocks [fl, cur]: write out what is complete once sixteen have gathered, or before the ring could wrap
-        // (a step touches at most 64 blocks + the open one)
-        em_last = em;
-        if (cur - fl >= 16u) flush(fl + ((cur - fl) & ~15u)); // full rounds only: at most 15 blocks wait, a step adds at most 64 + the open one
     }
     flush(cur);
     // The block left open -- its remaining symbols belong to the next subsequence -- when the last token did not end a block: merge what
     // is here. Its DC symbol is here too when the block began in this subsequence.
-    const bool open_at_end = n != 0 && ((em_last >> ((n - 1u) & 63u)) & 1ull) == 0;
+    const bool open_at_end = n != 0 && ((em_last >> (n - 1u - n_last)) & 1ull) == 0;
     if (open_at_end && cur < total_blocks && lane < 4u) {
         __builtin_amdgcn_wave_barrier();
         const uint4 r = *reinterpret_cast<const uint4*>(slots + ((cur & (EXP_RING - 1u)) << 6) + (lane << 4));

@@ -37,9 +37,31 @@ LP_HD int32_t lp_tok_value(uint32_t t) // jdhuff.c HUFF_EXTEND of the extra bits
     const uint32_t neg = (t & 0x80000000u) ? 0u : 0xffffffffu; // a first extra bit of 0 means negative
     return s ? (int32_t)(x - (neg & ((1u << s) - 1u))) : 0;
 }
-// Most tokens a subsequence of S bits can produce: the shortest symbol of a table the fast path accepts is 2 bits (the parser sends
-// tables with a 1-bit code down the scan path), + the steps of the last group of four.
-LP_HD uint32_t lp_tok_cap(uint32_t S) { return S / 2u + 8u; }
+// Most tokens a subsequence of S bits can produce. Whatever state a lane is in, it walks the MCU's blocks in order, and a block costs
+// at least its tables' shortest DC code + shortest AC code for two tokens (DC symbol, end of block): with min_mcu_bits = that sum over
+// the MCU's blocks, S bits hold at most S * 2 * bpm / min_mcu_bits tokens (+ an MCU for the ends, + a window of the device sink).
+// Annex-K tables: 2 bits per token; optimised chroma tables often carry 1-bit codes (data/large-sunrise.jpg: 20 bits per 12-token MCU).
+LP_HD uint32_t lp_tok_cap(uint32_t S, uint32_t bpm, uint32_t min_mcu_bits)
+{
+    const uint32_t mb = min_mcu_bits ? min_mcu_bits : 1u;
+    return ((uint32_t)(((uint64_t)S * 2u * bpm + mb - 1u) / mb) + 4u * bpm + 32u + 15u) & ~15u; // a multiple of 16: the device sink stores windows of 16 tokens
+}
+// shortest code of table slot t (0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1)
+inline uint32_t lp_huff_min_len(const LpHuffSet& hs, int t)
+{
+    for (uint32_t l = 1; l <= 16; l++)
+        if (hs.maxcode[t][l] >= 0) return l;
+    return 16;
+}
+inline uint32_t lp_min_mcu_bits(const LpHuffSet& hs, uint64_t blkpack, uint32_t bpm)
+{
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < bpm; b++) {
+        const uint32_t nib = (uint32_t)(blkpack >> (4 * b)) & 15u;
+        bits += lp_huff_min_len(hs, (int)((nib >> 2) & 1u)) + lp_huff_min_len(hs, 2 + (int)((nib >> 3) & 1u));
+    }
+    return bits;
+}
 
 // What the verify pass leaves per subsequence for the expansion: T_v[0 .. head) then T_s[spec_from .. spec_n).
 struct LpTokSpan {
@@ -80,9 +102,11 @@ LP_HD uint32_t lp_step_tok(LpLane<M>& L, uint32_t pk)
     return tok;
 }
 
-// SPEC pass that emits tokens. Tk must provide   void put(uint32_t u, uint32_t iter, uint32_t tok, bool on)   -- called in every step by
-// all lanes of the wave (u = position of the step inside its group of four, a compile-time constant after unrolling; `on` = the lane
-// decoded a symbol in this step); the device sink keeps the tokens of a group in registers and stores them at u == 3 as 16 bytes.
+// SPEC pass that emits tokens. Tk must provide   void put(uint32_t u, uint32_t step, uint32_t tok, bool on)   -- called in every step by
+// all lanes of the wave (u = position of the step inside its group of four, a compile-time constant after unrolling; step = the token's
+// index, the same in every lane that is `on`; `on` = the lane decoded a symbol in this step) -- and   void finish(uint32_t step)   once
+// after the loop. The device sink parks a window of 16 tokens per lane in LDS and the wave writes the windows out together, four lanes
+// per 64-byte run (per-lane 16-byte stores 32 KB apart made the speculative pass 2.2x slower: 64 lines per store instruction).
 // Ck as in lp_spec_pass. *ntok = tokens emitted (= decode steps of the lane).
 template <class M, class Ck, class Tk>
 LP_HD void lp_spec_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, const LpCkSched& cs, Ck& ck, Tk& tk, LpSubState* exit_st,
@@ -124,6 +148,7 @@ LP_HD void lp_spec_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubSta
             iter++;
         }
     } while (m.any(!done));
+    tk.finish(iter);
     LpCkptPk none;
     none.p = 0xffffffffu; none.bz = 0; none.nblk = 0; none.nreset = 0;
     for (; k < K; k++) ck.record(k, none);
@@ -136,17 +161,20 @@ LP_HD void lp_spec_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubSta
 // VERIFY pass that emits the head tokens, in instalments: runs from `vs` until the subsequence synchronises with one of its
 // checkpoints, ends, or vs.iter reaches `until_iter` (a multiple of 4). Returns true when the walk is over; then *exit_st / *total /
 // *span are set. Ck as in lp_verify_pass plus   uint32_t pos(k). Tk as above (tokens go to T_v).
+// active = false: a lane without a walk of its own that stays with the wave (the device sink writes the tokens out cooperatively).
 template <class M, class Ck, class Tk>
 LP_HD bool lp_verify_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpVerState& vs, uint32_t until_iter, uint32_t K, uint32_t ck_base, Ck& ck, Tk& tk,
-                              const LpSubState& spec_exit, const LpSubSum& spec_total, uint32_t spec_n, LpSubState* exit_st, LpSubSum* total, LpTokSpan* span)
+                              const LpSubState& spec_exit, const LpSubSum& spec_total, uint32_t spec_n, LpSubState* exit_st, LpSubSum* total, LpTokSpan* span,
+                              bool active = true)
 {
     LpLane<M> L(m, ic);
     L.start(vs.p, vs.bz);
     LpSubSum sum;
     sum.nblk = vs.nblk; sum.nreset = vs.nreset;
     uint32_t kk = vs.kk, ck_iter = vs.ck_iter, iter = vs.iter;
+    uint32_t step = m.uniform(vs.iter); // every walk of a wave is at the same step: 0 in the first instalment, the previous budget afterwards
     uint32_t cp = kk < K ? ck.pos(kk) : 0xffffffffu;
-    bool done = false, over = false, spliced = false;
+    bool done = !active, over = false, spliced = false;
     do {
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -187,11 +215,13 @@ LP_HD bool lp_verify_tok_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpVerS
                 sum.nblk += L.z == 0 ? 1u : 0u;
                 tok = lp_step_tok(L, pk);
             }
-            tk.put(u, iter, tok, on);
+            tk.put(u, step, tok, on);
             iter += on ? 1u : 0u;
+            step++;
         }
-        done = done || iter >= until_iter; // the budget is checked between groups of four: a store group is never split over two instalments
+        done = done || iter >= until_iter; // the budget (a multiple of 16) is checked between groups of four: a token window is never split over two instalments
     } while (m.any(!done));
+    tk.finish(step);
     if (over && !spliced) {
         exit_st->p = L.p;
         exit_st->bz = L.state_bz();

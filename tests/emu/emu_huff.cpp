@@ -30,6 +30,7 @@ struct HostMemT {
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
+    uint32_t uniform(uint32_t v) const { return v; }
     bool any_lt8(int32_t v) const { return v < 8; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
@@ -183,6 +184,7 @@ struct HostTok {
         if (buf->size() <= iter) buf->resize(iter + 1, 0xdeadbeefu);
         (*buf)[iter] = tok;
     }
+    void finish(uint32_t) {}
 };
 struct HostExpandSink {
     int16_t* all; // decode-order blocks, natural order inside
@@ -221,7 +223,7 @@ extern "C" int emu_decode_coefs_tok(const uint8_t* data, size_t len, uint32_t S,
     LpImgCtx ic;
     ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
     const LpCkSched cs = lp_make_sched(S, C ? C : 256);
-    const uint32_t K = cs.K, cap = lp_tok_cap(S);
+    const uint32_t K = cs.K, cap = lp_tok_cap(S, img.bpm, lp_min_mcu_bits(h.huff, img.blkpack, img.bpm));
     uint32_t nsub = (total_bits + S - 1) / S;
     *nsub_out = (int)nsub;
     std::vector<LpCkptPk> ck((size_t)nsub * K);
@@ -263,7 +265,7 @@ extern "C" int emu_decode_coefs_tok(const uint8_t* data, size_t len, uint32_t S,
             for (;;) { // instalments of `budget` steps, the lane state put down and picked up in between (what the phased kernels do)
                 HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
                 stats[2]++;
-                const uint32_t until = budget ? (vs.iter + budget + 3u) / 4u * 4u : 0xfffffff0u;
+                const uint32_t until = budget ? (vs.iter + budget + 15u) / 16u * 16u : 0xfffffff0u;
                 if (lp_verify_tok_pass(m, ic, sub_end, vs, until, K, cs.base, hc, tk, spec_ex[i], spec_tot[i], spec_n[i], &ne, &nt, &sp)) break;
             }
             if (tv[i].size() < sp.head) return -22;
