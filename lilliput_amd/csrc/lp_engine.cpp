@@ -15,7 +15,6 @@
 #include <thread>
 
 #include "lp_huff_core.h"
-#include "lp_tok_core.h"
 #include "lp_launch.h"
 #include "lp_jpeg_progenc.h"
 #include "lp_prog_host.h"
@@ -136,7 +135,7 @@ size_t LpEngine::device_bytes() const
     size_t n = 0;
     for (const LpUpload& u : up_) n += u.d_raw.cap + u.d_huffs.cap + u.d_phuffs.cap;
     for (const LpDevBuf* b : {&d_imgs_, &d_states_, &d_clean_, &d_rst_, &d_chunk_, &d_ckpt_, &d_exit_, &d_spec_exit_, &d_entry_, &d_tot_, &d_spec_tot_, &d_prefix_, &d_changed_,
-                              &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_tok_, &d_spec_n_, &d_span_, &d_vq_[0], &d_vq_[1], &d_vq_cnt_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &heap_,
+                              &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &heap_,
                               &d_ops_, &d_taps_, &d_ranges_, &d_fops_, &d_tone_, &d_jobs_, &d_estates_, &d_ecoef_, &d_blkbits_, &d_bits_, &d_hdrs_, &d_out_, &d_packed_, &d_pkoff_})
         n += b->cap;
     return n;
@@ -162,14 +161,6 @@ uint8_t* LpEngine::heap_alloc(size_t bytes)
 
 // ------------------------------------------------------------------------------------------------
 // decode
-// Which entropy decoder the baseline images take: the token path (default) or round 2's SPEC / VERIFY / WRITE kernels (LILLIPUT_HIP_ENTROPY=write;
-// kept for A/B measurements -- same results).
-static bool lp_entropy_tokens()
-{
-    static const bool on = !(getenv("LILLIPUT_HIP_ENTROPY") && !strcmp(getenv("LILLIPUT_HIP_ENTROPY"), "write"));
-    return on;
-}
-
 static uint32_t pick_S(size_t max_ecs_bytes)
 {
     size_t bits = max_ecs_bytes * 8;
@@ -627,10 +618,6 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             max_h_ = std::max(max_h_, j.height);
         }
     }
-    // token capacity of a subsequence (lp_tok_cap): from the shortest codes of the tables in this range
-    uint32_t tok_cap = 64;
-    for (const LpJpeg& j : h_imgs_)
-        if (!j.scan_path && j.huff_idx < u_->huffs.size()) tok_cap = std::max(tok_cap, lp_tok_cap(S_, j.bpm, lp_min_mcu_bits(u_->huffs[j.huff_idx], j.blkpack, j.bpm)));
     std::stable_sort(leveled.begin(), leveled.end(), [](const std::pair<uint32_t, LpProgScan>& x, const std::pair<uint32_t, LpProgScan>& y) { return x.first < y.first; });
     h_pscans_.clear();
     h_plevel_first_.clear();
@@ -653,10 +640,6 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
              d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
              d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
-             (!lp_entropy_tokens() || (d_tok_.ensure((size_t)tot_sub_ * 2u * tok_cap * 4u + 256) && d_spec_n_.ensure((size_t)tot_sub_ * 4u + 64) &&
-                                       d_span_.ensure((size_t)tot_sub_ * 8u + 64) && d_vq_[0].ensure((size_t)tot_sub_ * lp_tok_item_bytes() + 64) &&
-                                       d_vq_[1].ensure((size_t)tot_sub_ * lp_tok_item_bytes() + 64) &&
-                                       d_vq_cnt_.ensure((size_t)(LP_VERIFY_ROUNDS + 1) * LP_TOK_PHASES * (size_t)n * 4u + 64))) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     if (!h2d_small(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n)) return LP_ERR_DEVICE;
@@ -687,27 +670,20 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.entry_used = d_entry_.as<LpSubState>(); ha.prefix = d_prefix_.as<LpSubSum>();
     ha.changed = d_changed_.as<uint32_t>(); ha.coef8 = d_coef_.as<int8_t>(); ha.wide = d_wide_.as<int16_t>(); ha.wide_id = d_wide_id_.as<uint32_t>(); ha.dc16 = d_dc_.as<int16_t>();
     ha.sched = sched_;
-    const bool tokens = lp_entropy_tokens();
-    ha.tok = d_tok_.as<uint32_t>(); ha.tok_cap = tok_cap; ha.spec_n = d_spec_n_.as<uint32_t>(); ha.span = d_span_.p;
-    ha.vq[0] = d_vq_[0].p; ha.vq[1] = d_vq_[1].p; ha.vq_cnt = d_vq_cnt_.as<uint32_t>();
-    if (tokens) {
-        if (!check(hipMemsetAsync(d_vq_cnt_.p, 0, (size_t)(LP_VERIFY_ROUNDS + 1) * LP_TOK_PHASES * (size_t)n * 4u, stream_), "memset verify lists")) return LP_ERR_DEVICE;
-        lp_launch_tok_spec(stream_, ha);
-    } else
-        lp_launch_huff_spec(stream_, ha);
+    lp_launch_huff_spec(stream_, ha);
     stage("huff_spec");
     if (timing_) (void)hipEventRecord(ev_[8], stream_);
     // Verify rounds back to back, no host round trip in between: round r counts the exit states it moved into changed[r] and a
     // round that follows an idle one returns at once. The last counter is looked at when the decode is collected (finish_decode);
     // streams that need more than LP_VERIFY_ROUNDS rounds (tiny subsequences, hostile data) continue there under host control.
     if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (LP_VERIFY_ROUNDS + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
-    for (uint32_t r = 0; r < LP_VERIFY_ROUNDS; r++) { if (tokens) lp_launch_tok_verify(stream_, ha, r); else lp_launch_huff_verify(stream_, ha, r); }
+    for (uint32_t r = 0; r < LP_VERIFY_ROUNDS; r++) lp_launch_huff_verify(stream_, ha, r);
     if (timing_) (void)hipEventRecord(ev_[9], stream_);
     stage("huff_verify");
-    if (tokens) lp_launch_tok_scan(stream_, ha); else lp_launch_sub_scan(stream_, ha);
+    lp_launch_sub_scan(stream_, ha);
     stage("sub_scan");
     if (timing_) (void)hipEventRecord(ev_[10], stream_);
-    if (tokens) lp_launch_tok_expand(stream_, ha); else lp_launch_huff_write(stream_, ha);
+    lp_launch_huff_write(stream_, ha);
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
@@ -786,11 +762,7 @@ int LpEngine::finish_decode(int* status)
         const LpHuffArgs& ha = pend_.ha;
         for (;;) { // round index LP_VERIFY_ROUNDS: its gate reads the previous counter, which is non-zero here
             if (!check(hipMemsetAsync(d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
-            if (lp_entropy_tokens()) {
-                if (!check(hipMemsetAsync(d_vq_cnt_.as<uint32_t>() + (size_t)LP_VERIFY_ROUNDS * LP_TOK_PHASES * (size_t)n, 0, (size_t)LP_TOK_PHASES * (size_t)n * 4u, stream_), "memset verify lists")) return LP_ERR_DEVICE;
-                lp_launch_tok_verify(stream_, ha, LP_VERIFY_ROUNDS);
-            } else
-                lp_launch_huff_verify(stream_, ha, LP_VERIFY_ROUNDS);
+            lp_launch_huff_verify(stream_, ha, LP_VERIFY_ROUNDS);
             if (!check(hipMemcpyAsync(h_small_.p, d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
             if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
             rounds++;
@@ -800,8 +772,8 @@ int LpEngine::finish_decode(int* status)
         }
         // the stages behind the verification ran on unsettled exit states: once more
         lp_launch_reset_tail_state(stream_, d_states_.as<LpJpegState>(), (uint32_t)n);
-        if (lp_entropy_tokens()) { lp_launch_tok_scan(stream_, ha); lp_launch_tok_expand(stream_, ha); }
-        else { lp_launch_sub_scan(stream_, ha); lp_launch_huff_write(stream_, ha); }
+        lp_launch_sub_scan(stream_, ha);
+        lp_launch_huff_write(stream_, ha);
         lp_launch_dc_scan(stream_, d_imgs_.as<LpJpeg>(), (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
         lp_launch_idct(stream_, d_imgs_.as<LpJpeg>(), d_states_.as<LpJpegState>(), (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(),
                        d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(), (pend_.any_baseline ? 1u : 0u) | (pend_.pcoef_elems ? 2u : 0u), d_pcoef_.as<int16_t>());
@@ -815,12 +787,6 @@ int LpEngine::finish_decode(int* status)
     tm_.verify_rounds = rounds;
     h_states_.resize((size_t)n);
     memcpy(h_states_.data(), h_dstate_.as<uint8_t>() + 64, sizeof(LpJpegState) * (size_t)n);
-    if (getenv("LILLIPUT_HIP_DEBUG_COUNTERS")) { // variant builds with -DLP_DEBUG_COUNTERS: verify walk statistics
-        uint64_t lane_steps = 0, wave_steps = 0, subs = 0;
-        for (int i = 0; i < n; i++) { lane_steps += h_states_[(size_t)i].pad; wave_steps += h_states_[(size_t)i].end_marker_pos; subs += h_states_[(size_t)i].nsub; }
-        fprintf(stderr, "[lilliput_hip] verify walks: %llu lane-steps (%.1f per subsequence), %llu wave-steps summed over the waves (x 64 = %.1f per subsequence); S = %u, %llu subsequences\n",
-                (unsigned long long)lane_steps, (double)lane_steps / std::max<uint64_t>(1, subs), (unsigned long long)wave_steps, 64.0 * wave_steps / std::max<uint64_t>(1, subs), S_, (unsigned long long)subs);
-    }
     if (nstreams) { // a scan that failed to unstuff fails its image
         h_pstates_.resize(nstreams);
         if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
@@ -883,8 +849,7 @@ int LpEngine::copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems)
     if (!check(hipMemcpyAsync(wid.data(), d_wide_id_.as<uint32_t>() + j.coef_off / 64, nb * 4, hipMemcpyDeviceToHost, stream_), "D2H wide ids")) return LP_ERR_DEVICE;
     int rc = sync();
     if (rc) return rc;
-    // wide slots: handed out by a counter (WRITE kernel) or the block's own index (token path: every block owns slot = its index)
-    const uint32_t n_wide = lp_entropy_tokens() ? (uint32_t)nb : std::min<uint32_t>(h_states_[(size_t)i].n_wide, (uint32_t)nb);
+    const uint32_t n_wide = std::min<uint32_t>(h_states_[(size_t)i].n_wide, (uint32_t)nb); // never more slots than blocks
     std::vector<int16_t> wide((size_t)n_wide * 64);
     if (n_wide) {
         if (!check(hipMemcpyAsync(wide.data(), d_wide_.as<int16_t>() + j.coef_off, wide.size() * 2, hipMemcpyDeviceToHost, stream_), "D2H wide")) return LP_ERR_DEVICE;

@@ -228,7 +228,6 @@ private:
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
     LpDevBuf d_imgs_, d_states_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
     LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_dcpart_, d_planes_, d_frames_desc_;
-    LpDevBuf d_tok_, d_spec_n_, d_span_, d_vq_[2], d_vq_cnt_;       // token path (lp_tok_core.h)
     LpPinned h_small_, h_out_, h_dstate_, h_desc_;
     size_t desc_used_ = 0;
     std::vector<uint32_t> h_pk_;                                    // slot offsets of the encoded streams in h_out_ (n + 1 entries)

@@ -10,7 +10,6 @@
 
 #include "lp_huff_core.h"
 #include "lp_prog_core.h"
-#include "lp_tok_core.h"
 #include "lp_unstuff_core.h"
 #include "lp_launch.h"
 #include "lp_types.h"
@@ -277,7 +276,6 @@ struct DevMem {
     // (a ballot compared with zero stays in scalar registers; __any() materialises the vote in a VGPR and compares it again: two VALU
     // instructions per vote, three votes per decode step)
     __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-    __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ bool any_lt8(int32_t v) const { return __builtin_amdgcn_ballot_w64(v < 8) != 0ull; }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
@@ -664,419 +662,6 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.blk0 = prefix.nblk;
     sink.last = 0xffffffffu;
     lp_write_pass(m, ic, entry, end_p, prefix, s_zz, sink);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Token path (lp_tok_core.h): the speculative pass and the verify pass leave one 32-bit token per decoded symbol behind, the
-// expansion kernel turns tokens into the same int8 blocks + DC differences k_huff_write produced -- without a second walk through the
-// Huffman stream.
-// Token memory of an image: sub_cap regions of 2 x cap tokens, [T_s | T_v] per subsequence.
-// Token sink. A lane parks its tokens in LDS -- window slot (step & 15), layout [slot][lane]: a conflict-free ds_write_b32 per step -- and
-// at the end of every window of 16 steps the wave writes the windows out together: four lanes move one lane's 64 bytes (lane 4e + q
-// takes tokens 4q .. 4q + 3 of lane 16r + e), so a store instruction covers sixteen 64-byte runs instead of sixty-four 16-byte pieces.
-#define TOK_WIN 16
-struct DevTok {
-    __amdgpu_buffer_rsrc_t rs;  // the image's token block
-    uint32_t base;              // byte offset of this lane's T_s or T_v inside it
-    uint32_t cap_bytes;         // capacity of the region (0 = a lane without a subsequence): nothing is stored past it
-    uint32_t* win;              // LDS: the wave's windows, TOK_WIN x 64 words; this lane's word of slot 0
-    uint32_t lane;
-    bool win_on;                // the lane was decoding at the start of the current window
-    __device__ __forceinline__ void flush(uint32_t first_step) // wave-uniform call; first_step = step of window slot 0
-    {
-        const uint64_t on = __ballot(win_on);
-        __builtin_amdgcn_wave_barrier();
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const uint32_t q = lane & 3u;
-        const uint32_t* wv = win - lane; // the wave's window block
-#pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
-            const uint32_t src = 16u * r + (lane >> 2);
-            const uint32_t sb = (uint32_t)__shfl((int)base, (int)src, 64), sc = (uint32_t)__shfl((int)cap_bytes, (int)src, 64);
-            const uint32_t off = (first_step + 4u * q) * 4u;
-            if (((on >> src) & 1ull) && off + 16u <= sc) {
-                const uint32_t* w = wv + src + (4u * q) * 64u;
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){w[0], w[64], w[128], w[192]}, rs, (int)(sb + off), 0, 2 /* nt */);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ void put(uint32_t u, uint32_t step, uint32_t tok, bool on)
-    {
-        (void)u;
-#ifdef LP_EXP_NOTOK
-        asm volatile("" :: "v"(tok)); (void)step; (void)on; return; // timing experiment: what do the token stores cost?
-#endif
-        const uint32_t slot = step & (TOK_WIN - 1u); // wave-uniform
-        if (slot == 0u) win_on = on;
-        win[slot * 64u] = tok;
-#ifndef LP_EXP_NOTOKFLUSH
-        if (slot == TOK_WIN - 1u) { LP_KEEP_UNIFORM_BRANCH(); flush(step - (TOK_WIN - 1u)); }
-#endif
-    }
-    __device__ __forceinline__ void finish(uint32_t step) // the window the loop ended in
-    {
-        if (step & (TOK_WIN - 1u)) flush(step & ~(TOK_WIN - 1u));
-    }
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tok_rsrc(uint32_t* tok_arena, const LpJpeg& img, uint32_t cap)
-{
-    const size_t words = (size_t)img.sub_cap * 2u * cap;
-    return __builtin_amdgcn_make_buffer_rsrc(tok_arena + (size_t)img.sub_off * 2u * cap, 0, (int)(words * 4u), 0x00020000);
-}
-
-__global__ __launch_bounds__(HUFF_T) void k_tok_spec(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
-                                                     const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
-                                                     const uint32_t* __restrict__ rst_bits, LpCkptPk* __restrict__ ckpts,
-                                                     LpSubState* __restrict__ spec_exit, LpSubSum* __restrict__ spec_total,
-                                                     LpSubState* __restrict__ cur_exit, LpSubSum* __restrict__ cur_total,
-                                                     LpSubState* __restrict__ entry_used, uint32_t* __restrict__ spec_n, LpTokSpan* __restrict__ span,
-                                                     uint32_t* __restrict__ tok_arena, uint32_t cap, LpCkSched cs, uint32_t tot_sub)
-{
-    typedef CountMem MEM;
-    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
-    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
-    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
-    __shared__ uint32_t s_tokwin[HUFF_T * TOK_WIN];
-    const LpJpeg& img = imgs[blockIdx.y];
-    const LpJpegState& st = states[blockIdx.y];
-    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
-    if (blockIdx.x * HUFF_T >= nsub) return;
-    stage_huff(s_hs4, huffs + img.huff_idx);
-    const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
-    const bool valid = sub < nsub;
-    const uint32_t g = img.sub_off + (valid ? sub : 0);
-    const LpImgCtx ic = make_ctx(img, st);
-    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
-                      rst_bits + img.rst_off);
-    LpSubState entry;
-    const uint32_t S = img.sub_bits;
-    entry.p = valid ? sub * S : 0;
-    entry.bz = 0;
-    uint32_t sub_end = valid ? entry.p + S : 0;
-    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
-    DevCkSink ck{ckpts + g, tot_sub, valid};
-    DevTok tk;
-    tk.rs = tok_rsrc(tok_arena, img, cap);
-    tk.base = (valid ? sub : 0u) * 2u * cap * 4u;
-    tk.cap_bytes = valid ? cap * 4u : 0u;
-    tk.lane = threadIdx.x & 63u;
-    tk.win = s_tokwin + (threadIdx.x >> 6) * (TOK_WIN * 64) + tk.lane;
-    tk.win_on = false;
-    LpSubState ex;
-    LpSubSum tot;
-    uint32_t n = 0;
-    lp_spec_tok_pass(m, ic, sub_end, entry, cs, ck, tk, &ex, &tot, &n);
-    if (!valid) return;
-    spec_exit[g] = ex;
-    cur_exit[g] = ex;
-    spec_total[g] = tot;
-    cur_total[g] = tot;
-    spec_n[g] = n < cap ? n : cap;
-    if (n > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 8u); // more symbols than a subsequence holds at 2 bits each (a table with a 1-bit code): the serial decoder takes the image (bit 3 survives k_reset_tail_state)
-    LpTokSpan sp;
-    sp.head = 0;
-    sp.spec_from = sub == 0 ? 0u : (n < cap ? n : cap); // until a verify pass says otherwise: subsequence 0 is exact, of the others nothing is
-    span[g] = sp;
-    LpSubState none;
-    none.p = 0xffffffffu; none.bz = 0xffffffffu;
-    entry_used[g] = none;
-}
-
-// One verify walk in flight between two phases of a round.
-struct LpVerItem {
-    uint32_t sub;
-    LpSubState entry;
-    uint32_t pad;
-    LpVerState vs;
-};
-
-// Phase 0 of a round (FIRST): lane = subsequence; the lanes whose entry state moved start a walk. Later phases: lane = entry of the
-// image's list of walks the phase before left unfinished -- the same lanes, packed, so that a wave is not held by the one lane in a
-// hundred that needs ten times the median to synchronise. `until` = the step count at which this phase puts its walks down.
-template <bool FIRST>
-__global__ __launch_bounds__(HUFF_T) void k_tok_verify(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
-                                                       const LpHuffSet* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
-                                                       const uint32_t* __restrict__ rst_bits, const LpCkptPk* __restrict__ ckpts,
-                                                       const LpSubState* __restrict__ spec_exit, const LpSubSum* __restrict__ spec_total,
-                                                       const uint32_t* __restrict__ spec_n, LpSubState* cur_exit, LpSubSum* __restrict__ cur_total,
-                                                       LpSubState* __restrict__ entry_used, LpTokSpan* __restrict__ span, uint32_t* changed, uint32_t round,
-                                                       uint32_t K, uint32_t ck_base, uint32_t tot_sub, uint32_t* __restrict__ tok_arena, uint32_t cap,
-                                                       const LpVerItem* __restrict__ q_in, LpVerItem* __restrict__ q_out, const uint32_t* __restrict__ n_in,
-                                                       uint32_t* __restrict__ n_out, uint32_t until)
-{
-    typedef CountMem MEM;
-    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
-    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
-    __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
-    __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
-    __shared__ uint32_t s_tokwin[HUFF_T * TOK_WIN];
-    if (round && __hip_atomic_load(changed + round - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    changed += round;
-    const LpJpeg& img = imgs[blockIdx.y];
-    const LpJpegState& st = states[blockIdx.y];
-    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
-    const uint32_t idx = blockIdx.x * HUFF_T + threadIdx.x;
-    uint32_t sub = idx;
-    LpSubState entry;
-    entry.p = 0; entry.bz = 0;
-    LpVerState vs;
-    vs.p = vs.bz = vs.iter = vs.kk = vs.ck_iter = vs.nblk = vs.nreset = vs.pad = 0;
-    bool need;
-    if (FIRST) {
-        if (blockIdx.x * HUFF_T >= nsub) return;
-        need = sub < nsub && sub != 0;
-        if (need) {
-            entry = load_state(cur_exit + img.sub_off + sub - 1);
-            need = !lp_state_eq(entry, entry_used[img.sub_off + sub]);
-        }
-        vs.p = entry.p; vs.bz = entry.bz;
-        vs.ck_iter = K ? lp_ck_next(ck_base, 0, 0) : 0u;
-    } else {
-        const uint32_t n = __hip_atomic_load(n_in + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x * HUFF_T >= n) return;
-        need = idx < n;
-        if (need) {
-            const LpVerItem it = q_in[img.sub_off + idx];
-            sub = it.sub; entry = it.entry; vs = it.vs;
-        }
-    }
-    if (!__syncthreads_or(need ? 1 : 0)) return;
-    stage_huff(s_hs4, huffs + img.huff_idx);
-    const uint64_t walkers = __builtin_amdgcn_ballot_w64(need);
-    if (!walkers) return; // a whole wave without a walk
-    // lanes without a walk stay: the token windows leave the wave cooperatively (DevTok::flush), four lanes per walking lane. They
-    // count steps like the walkers (every walk of a phase is at the same step).
-    const uint32_t step0 = (uint32_t)__shfl((int)vs.iter, (int)__builtin_ctzll(walkers), 64);
-    if (!need) { sub = 0; vs.p = vs.bz = vs.kk = vs.nblk = vs.nreset = 0; vs.iter = step0; }
-    const uint32_t g = img.sub_off + sub;
-    const LpImgCtx ic = make_ctx(img, st);
-    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
-                      rst_bits + img.rst_off);
-    const uint32_t S = img.sub_bits;
-    uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
-    for (uint32_t k = 0; k < K; k++) {
-        const uint32_t p = need ? ckpts[(size_t)k * tot_sub + g].p : 0xffffffffu;
-        cp[k << 6] = (uint16_t)(p == 0xffffffffu ? 0xffffu : p - sub * S);
-    }
-    DevCkSrc ck{cp, ckpts + g, tot_sub, sub * S};
-    uint32_t sub_end = sub * S + S;
-    if (sub_end > ic.total_bits) sub_end = ic.total_bits;
-    DevTok tk;
-    tk.rs = tok_rsrc(tok_arena, img, cap);
-    tk.base = (sub * 2u + 1u) * cap * 4u;
-    tk.cap_bytes = need ? cap * 4u : 0u;
-    tk.lane = threadIdx.x & 63u;
-    tk.win = s_tokwin + (threadIdx.x >> 6) * (TOK_WIN * 64) + tk.lane;
-    tk.win_on = false;
-    const LpSubState old_exit = load_state(cur_exit + g);
-    LpSubState ex = old_exit;
-    LpSubSum tot;
-    lp_sum_zero(tot);
-    LpTokSpan sp;
-    sp.head = 0; sp.spec_from = 0;
-#ifdef LP_DEBUG_COUNTERS
-    const uint32_t steps0 = vs.iter;
-#endif
-    const bool over = lp_verify_tok_pass(m, ic, sub_end, vs, until, K, ck_base, ck, tk, spec_exit[g], spec_total[g], spec_n[g], &ex, &tot, &sp, need);
-    if (!need) return;
-#ifdef LP_DEBUG_COUNTERS
-    { // steps this instalment walked: summed over the lanes, and the wave's longest (what the wave costs)
-        uint32_t steps = vs.iter - steps0, mx = steps;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
-        atomicAdd(const_cast<uint32_t*>(&states[blockIdx.y].pad), steps);
-        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(const_cast<uint32_t*>(&states[blockIdx.y].end_marker_pos), mx);
-    }
-#endif
-    if (over) {
-        cur_total[g] = tot;
-        entry_used[g] = entry;
-        if (sp.head > cap) atomicOr(const_cast<uint32_t*>(&states[blockIdx.y].error), 8u);
-        sp.head = sp.head < cap ? sp.head : cap;
-        span[g] = sp;
-        if (!lp_state_eq(ex, old_exit)) {
-            store_state(cur_exit + g, ex);
-            atomicAdd(changed, 1u);
-        }
-    } else {
-        const uint32_t slot = atomicAdd(n_out + blockIdx.y, 1u);
-        LpVerItem it;
-        it.sub = sub; it.entry = entry; it.pad = 0; it.vs = vs;
-        if (slot < img.sub_cap) q_out[img.sub_off + slot] = it;
-    }
-}
-
-// k_sub_scan + what the expansion needs before it starts: a block that is open when a subsequence begins (entry state inside a block)
-// is assembled by more than one workgroup of k_tok_expand, with atomic ORs into storage that must start out as zero.
-__global__ __launch_bounds__(256) void k_tok_scan(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states, const LpSubSum* __restrict__ totals,
-                                                  LpSubSum* __restrict__ prefixes, const LpSubState* __restrict__ exits, int8_t* __restrict__ coef8_arena)
-{
-    __shared__ LpSubSum s_part[256];
-    const LpJpeg& img = imgs[blockIdx.x];
-    LpJpegState& st = states[blockIdx.x];
-    uint32_t n = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
-    const uint32_t t = threadIdx.x, per = (n + 255) / 256;
-    uint32_t b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
-    if (b0 > n) b0 = n;
-    LpSubSum acc;
-    lp_sum_zero(acc);
-    for (uint32_t i = b0; i < b1; i++) acc = lp_sum_combine(acc, totals[img.sub_off + i]);
-    s_part[t] = acc;
-    __syncthreads();
-    LpSubSum pre;
-    lp_sum_zero(pre);
-    for (uint32_t i = 0; i < t; i++) pre = lp_sum_combine(pre, s_part[i]);
-    for (uint32_t i = b0; i < b1; i++) {
-        prefixes[img.sub_off + i] = pre;
-        if (i && (exits[img.sub_off + i - 1].bz & 255u) && pre.nblk >= 1u && pre.nblk - 1u < img.total_blocks) {
-            uint4* blk = reinterpret_cast<uint4*>(coef8_arena + img.coef_off + (size_t)(pre.nblk - 1u) * 64);
-            blk[0] = blk[1] = blk[2] = blk[3] = make_uint4(0, 0, 0, 0);
-        }
-        pre = lp_sum_combine(pre, totals[img.sub_off + i]);
-    }
-    if (t == 255) {
-        st.blocks_decoded = pre.nblk;
-        if (pre.nblk < img.total_blocks && !img.scan_path) st.error |= 2u;
-        if (n && (exits[img.sub_off + n - 1].bz & 255u) && pre.nblk >= 1u && pre.nblk - 1u < img.total_blocks) { // a stream that stops inside its last block
-            uint4* blk = reinterpret_cast<uint4*>(coef8_arena + img.coef_off + (size_t)(pre.nblk - 1u) * 64);
-            blk[0] = blk[1] = blk[2] = blk[3] = make_uint4(0, 0, 0, 0);
-        }
-    }
-}
-
-// Tokens -> coefficient blocks. One wave per subsequence, 64 tokens per step: the token says where its coefficient goes inside the
-// block (zn), the block is the subsequence's first block + the block-end flags before the token (ballot + mbcnt). Blocks are assembled
-// in an LDS ring of EXP_RING slots per wave (int8, transposed natural order like k_huff_write's, -128 = escape to the wide copy) and
-// leave sixteen at a time as 1 KiB of contiguous 16-byte stores, DC differences as 32 contiguous bytes. The block that is open at the
-// subsequence's entry and the one left open at its end are shared with the neighbours: those two are ORed into (zeroed) memory.
-#define EXP_RING 128
-__global__ __launch_bounds__(256) void k_tok_expand(const LpJpeg* __restrict__ imgs, LpJpegState* __restrict__ states, const LpSubState* __restrict__ exits,
-                                                    const LpSubSum* __restrict__ prefixes, const uint32_t* __restrict__ spec_n, const LpTokSpan* __restrict__ span,
-                                                    uint32_t* __restrict__ tok_arena, uint32_t cap, int8_t* __restrict__ coef8_arena, int16_t* __restrict__ wide_arena,
-                                                    uint32_t* __restrict__ wide_id_arena, int16_t* __restrict__ dc_arena)
-{
-    __shared__ __attribute__((aligned(16))) int8_t s_slots[4][EXP_RING * 64];
-    __shared__ int16_t s_dc[4][EXP_RING];
-    __shared__ uint8_t s_zz[80];
-    const LpJpeg& img = imgs[blockIdx.y];
-    const LpJpegState& st = states[blockIdx.y];
-    const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
-    if (blockIdx.x * 4u >= nsub) return;
-    {
-        const uint8_t zz[80] = LP_ZIGZAG_INIT;
-        if (threadIdx.x < 80) s_zz[threadIdx.x] = (uint8_t)(((zz[threadIdx.x] & 7) << 3) | (zz[threadIdx.x] >> 3)); // blocks are stored transposed for k_idct's column pass
-        uint4* z4 = reinterpret_cast<uint4*>(&s_slots[0][0]);
-        for (uint32_t i = threadIdx.x; i < 4u * EXP_RING * 64u / 16u; i += 256u) z4[i] = make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t sub = blockIdx.x * 4u + wv;
-    if (sub >= nsub) return;
-    const uint32_t g = img.sub_off + sub;
-    LpSubState entry;
-    entry.p = 0; entry.bz = 0;
-    if (sub) entry = exits[g - 1];
-    const LpTokSpan sp = span[g];
-    const uint32_t ns = spec_n[g];
-    const uint32_t head = sp.head < cap ? sp.head : cap, from = sp.spec_from < ns ? sp.spec_from : ns;
-    const uint32_t n = head + (ns - from);
-    const uint32_t total_blocks = img.total_blocks;
-    const bool open_at_entry = (entry.bz & 255u) != 0;
-    const uint32_t first = open_at_entry ? prefixes[g].nblk - 1u : prefixes[g].nblk; // block of the first token
-    const uint32_t shared_first = open_at_entry ? first : 0xffffffffu;
-    const __amdgpu_buffer_rsrc_t rs = tok_rsrc(tok_arena, img, cap);
-    const uint32_t off_s = (sub * 2u * cap + from) * 4u, off_v = (sub * 2u + 1u) * cap * 4u;
-    int8_t* slots = s_slots[wv];
-    int16_t* dcs = s_dc[wv];
-    int8_t* coef8 = coef8_arena + img.coef_off;
-    int16_t* wide = wide_arena + img.coef_off;
-    uint32_t* wide_id = wide_id_arena + img.coef_off / 64;
-    int16_t* dc16 = dc_arena + img.coef_off / 64;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    uint32_t cur = first, fl = first; // block of the next token; first block not yet written out
-    uint64_t em_last = 0;             // block-end flags of the last group of tokens
-    uint32_t n_last = 0;              // index of that group's first token
-    // complete blocks [fl, upto) leave the ring, sixteen per round: four lanes move one block as 64 contiguous bytes
-    auto flush = [&](uint32_t upto) {
-        __builtin_amdgcn_wave_barrier();
-        while (fl < upto) {
-            const uint32_t b = fl + (lane >> 2), c = lane & 3u;
-            if (b < upto && b < total_blocks) {
-                uint4* sl = reinterpret_cast<uint4*>(slots + ((b & (EXP_RING - 1u)) << 6) + (c << 4));
-                const uint4 r = *sl;
-                *sl = make_uint4(0, 0, 0, 0);
-                if (b == shared_first) { // begun by an earlier subsequence: merge
-                    uint32_t* d = reinterpret_cast<uint32_t*>(coef8 + ((size_t)b << 6) + (c << 4));
-                    if (r.x) atomicOr(d, r.x);
-                    if (r.y) atomicOr(d + 1, r.y);
-                    if (r.z) atomicOr(d + 2, r.z);
-                    if (r.w) atomicOr(d + 3, r.w);
-                } else {
-                    __builtin_nontemporal_store((u32x4){r.x, r.y, r.z, r.w}, reinterpret_cast<u32x4*>(coef8 + ((size_t)b << 6) + (c << 4)));
-                    if (c == 0) dc16[b] = dcs[b & (EXP_RING - 1u)]; // a block that began here brought its DC symbol along
-                }
-            }
-            fl += 16u;
-        }
-        fl = upto;
-        __builtin_amdgcn_wave_barrier();
-    };
-    // 256 tokens per round: four coalesced loads in flight while the four before them are expanded (one dependent load per step left
-    // the kernel waiting on memory: 25 us per image instead of ~8)
-    auto load = [&](uint32_t j) -> uint32_t {
-        return j < n ? __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(j < head ? off_v + j * 4u : off_s + (j - head) * 4u), 0, 0) : 0u;
-    };
-    uint32_t nx0 = load(lane), nx1 = load(64u + lane), nx2 = load(128u + lane), nx3 = load(192u + lane);
-    for (uint32_t j0 = 0; j0 < n; j0 += 256u) { // wave-uniform
-        const uint32_t tq[4] = {nx0, nx1, nx2, nx3};
-        if (j0 + 256u < n) { nx0 = load(j0 + 256u + lane); nx1 = load(j0 + 320u + lane); nx2 = load(j0 + 384u + lane); nx3 = load(j0 + 448u + lane); }
-#pragma unroll
-        for (uint32_t qq = 0; qq < 4; qq++) {
-            const uint32_t j = j0 + qq * 64u + lane;
-            if (j0 + qq * 64u >= n) break; // wave-uniform
-            const bool valid = j < n;
-            const uint32_t t = tq[qq];
-            const uint32_t zn = lp_tok_zn(t), s = lp_tok_s(t);
-            const bool end = valid && lp_tok_ends_block(t);
-            const uint64_t em = __ballot(end);
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-            const uint32_t blk = cur + before;
-            const int32_t v = lp_tok_value(t);
-            if (valid && blk < total_blocks) {
-                const uint32_t slot = (blk & (EXP_RING - 1u));
-                if (zn == 1u) dcs[slot] = (int16_t)v;
-                else if (s) {
-                    const uint32_t k = zn - 1u, nat = s_zz[k < 79u ? k : 79u];
-                    int32_t b8 = v;
-                    if (v < -127 || v > 127) { // rare: the true value goes to the block's 16-bit copy (slot = the block itself: no allocation, any number of writers agree)
-                        wide[(size_t)blk * 64 + nat] = (int16_t)v;
-                        wide_id[blk] = blk;
-                        b8 = -128;
-                    }
-                    slots[(slot << 6) + nat] = (int8_t)b8;
-                }
-            }
-            cur += (uint32_t)__popcll(em);
-            em_last = em;
-            n_last = j0 + qq * 64u;
-            if (cur - fl >= 16u) flush(fl + ((cur - fl) & ~15u)); // full rounds only: at most 15 blocks wait, a step adds at most 64 + the open one
-        }
-    }
-    flush(cur);
-    // The block left open -- its remaining symbols belong to the next subsequence -- when the last token did not end a block: merge what
-    // is here. Its DC symbol is here too when the block began in this subsequence.
-    const bool open_at_end = n != 0 && ((em_last >> (n - 1u - n_last)) & 1ull) == 0;
-    if (open_at_end && cur < total_blocks && lane < 4u) {
-        __builtin_amdgcn_wave_barrier();
-        const uint4 r = *reinterpret_cast<const uint4*>(slots + ((cur & (EXP_RING - 1u)) << 6) + (lane << 4));
-        uint32_t* d = reinterpret_cast<uint32_t*>(coef8 + ((size_t)cur << 6) + (lane << 4));
-        if (r.x) atomicOr(d, r.x);
-        if (r.y) atomicOr(d + 1, r.y);
-        if (r.z) atomicOr(d + 2, r.z);
-        if (r.w) atomicOr(d + 3, r.w);
-        if (lane == 0 && (cur > first || !open_at_entry)) dc16[cur] = dcs[cur & (EXP_RING - 1u)];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1628,55 +1213,6 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
     hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
                        (const LpSubSum*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
-}
-
-size_t lp_tok_item_bytes() { return sizeof(LpVerItem); }
-
-void lp_launch_tok_spec(hipStream_t s, const LpHuffArgs& a)
-{
-    if (!a.nimg || !a.max_sub) return;
-    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
-    hipLaunchKernelGGL(k_tok_spec, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, a.ckpts, a.spec_exit, a.spec_total, a.cur_exit, a.cur_total,
-                       a.entry_used, a.spec_n, static_cast<LpTokSpan*>(a.span), a.tok, a.tok_cap, a.sched, a.tot_sub);
-}
-
-// A round = phases with growing step budgets; a phase picks up the walks the one before put down (lists per image, so that a
-// workgroup still serves one image: its tables in LDS, its context in scalar registers). Synchronisation distances on photographic
-// streams: median ~110 steps, p90 ~360, p99 ~800, a few lanes the whole subsequence.
-void lp_launch_tok_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round)
-{
-    if (!a.nimg || !a.max_sub) return;
-    static const uint32_t until[LP_TOK_PHASES] = {96u, 320u, 1024u, 0xfffffff0u};
-    dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
-    uint32_t* cnt = a.vq_cnt + (size_t)round * LP_TOK_PHASES * a.nimg;
-    for (uint32_t ph = 0; ph < LP_TOK_PHASES; ph++) {
-        const LpVerItem* qin = static_cast<const LpVerItem*>(a.vq[(ph + 1u) & 1u]);
-        LpVerItem* qout = static_cast<LpVerItem*>(a.vq[ph & 1u]);
-        const uint32_t* nin = ph ? cnt + (size_t)(ph - 1u) * a.nimg : cnt;
-        uint32_t* nout = cnt + (size_t)ph * a.nimg;
-        if (ph == 0)
-            hipLaunchKernelGGL(k_tok_verify<true>, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
-                               (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, (const uint32_t*)a.spec_n, a.cur_exit, a.cur_total, a.entry_used,
-                               static_cast<LpTokSpan*>(a.span), a.changed, round, a.sched.K, a.sched.base, a.tot_sub, a.tok, a.tok_cap, qin, qout, nin, nout, until[ph]);
-        else
-            hipLaunchKernelGGL(k_tok_verify<false>, g, dim3(HUFF_T), 0, s, a.imgs, (const LpJpegState*)a.states, a.huffs, a.clean, a.rst, (const LpCkptPk*)a.ckpts,
-                               (const LpSubState*)a.spec_exit, (const LpSubSum*)a.spec_total, (const uint32_t*)a.spec_n, a.cur_exit, a.cur_total, a.entry_used,
-                               static_cast<LpTokSpan*>(a.span), a.changed, round, a.sched.K, a.sched.base, a.tot_sub, a.tok, a.tok_cap, qin, qout, nin, nout, until[ph]);
-    }
-}
-
-void lp_launch_tok_scan(hipStream_t s, const LpHuffArgs& a)
-{
-    if (!a.nimg) return;
-    hipLaunchKernelGGL(k_tok_scan, dim3(a.nimg), dim3(256), 0, s, a.imgs, a.states, (const LpSubSum*)a.cur_total, a.prefix, (const LpSubState*)a.cur_exit, a.coef8);
-}
-
-void lp_launch_tok_expand(hipStream_t s, const LpHuffArgs& a)
-{
-    if (!a.nimg || !a.max_sub) return;
-    dim3 g((a.max_sub + 3) / 4, a.nimg);
-    hipLaunchKernelGGL(k_tok_expand, g, dim3(256), 0, s, a.imgs, a.states, (const LpSubState*)a.cur_exit, (const LpSubSum*)a.prefix, (const uint32_t*)a.spec_n,
-                       static_cast<const LpTokSpan*>(a.span), a.tok, a.tok_cap, a.coef8, a.wide, a.wide_id, a.dc16);
 }
 
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,

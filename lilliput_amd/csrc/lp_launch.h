@@ -28,21 +28,7 @@ struct LpHuffArgs {
     uint32_t* wide_id;          // block -> wide slot (valid for blocks holding an escape)
     int16_t* dc16;              // DC coefficient of every block
     LpCkSched sched;
-    // token path (lp_tok_core.h)
-    uint32_t* tok;              // per subsequence 2 x tok_cap tokens: [T_s | T_v]
-    uint32_t tok_cap;
-    uint32_t* spec_n;           // tokens of the speculative pass
-    void* span;                 // LpTokSpan per subsequence
-    void* vq[2];                // LpVerItem lists (ping-pong between the phases of a verify round), indexed like the subsequences
-    uint32_t* vq_cnt;           // list lengths: [round][phase][image]
 };
-// Token path: speculate + tokens; verify round `round` in LP_TOK_PHASES budgeted phases (+ head tokens); scan; tokens -> blocks.
-#define LP_TOK_PHASES 4
-void lp_launch_tok_spec(hipStream_t s, const LpHuffArgs& a);
-void lp_launch_tok_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round);
-void lp_launch_tok_scan(hipStream_t s, const LpHuffArgs& a);
-void lp_launch_tok_expand(hipStream_t s, const LpHuffArgs& a);
-size_t lp_tok_item_bytes();     // sizeof(LpVerItem)
 void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
 uint32_t lp_huff_write_slots(); // WRITE workgroups resident on the current device at once
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round); // counts into a.changed[round]; idle when changed[round - 1] == 0

@@ -8,7 +8,6 @@
 #include <string.h>
 #include <vector>
 #include "../../lilliput_amd/csrc/lp_huff_core.h"
-#include "../../lilliput_amd/csrc/lp_tok_core.h"
 #include "../../lilliput_amd/csrc/lp_jpeg_parse.h"
 #include "../../lilliput_amd/csrc/lp_unstuff_core.h"
 
@@ -30,7 +29,6 @@ struct HostMemT {
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
-    uint32_t uniform(uint32_t v) const { return v; }
     bool any_lt8(int32_t v) const { return v < 8; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
@@ -167,147 +165,6 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     for (uint32_t by = 0; by < img.bh[comp]; by++)
         for (uint32_t bx = 0; bx < img.bw[comp]; bx++) {
             size_t blk = ((size_t)(by / vs) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[comp] + (by % vs) * hs + (bx % hs);
-            memcpy(out + ((size_t)by * img.bw[comp] + bx) * 64, all.data() + blk * 64, 128);
-        }
-    return 0;
-}
-
-// ---- the token path (lp_tok_core.h): speculate + emit tokens -> verify in instalments + emit head tokens -> scan -> expand
-struct HostTok {
-    std::vector<uint32_t>* buf;
-    uint32_t cap;
-    bool* overflow;
-    void put(uint32_t, uint32_t iter, uint32_t tok, bool on)
-    {
-        if (!on) return;
-        if (iter >= cap) { *overflow = true; return; }
-        if (buf->size() <= iter) buf->resize(iter + 1, 0xdeadbeefu);
-        (*buf)[iter] = tok;
-    }
-    void finish(uint32_t) {}
-};
-struct HostExpandSink {
-    int16_t* all; // decode-order blocks, natural order inside
-    void coef(uint32_t blk, uint32_t k, int32_t v) { static const uint8_t zz[80] = LP_ZIGZAG_INIT; all[(size_t)blk * 64 + zz[k < 79 ? k : 79]] = (int16_t)v; }
-    void dc(uint32_t blk, int32_t d) { all[(size_t)blk * 64] = (int16_t)d; }
-};
-
-extern "C" int emu_decode_coefs_tok(const uint8_t* data, size_t len, uint32_t S, uint32_t C, uint32_t budget, int comp, int16_t* out, size_t cap_elems,
-                                    int* bw, int* bh, int* rounds, int* nsub_out, long* stats /* [0] spec tokens, [1] head tokens, [2] instalments */)
-{
-    LpJpegHeader h;
-    int rc = lp_jpeg_parse(data, len, &h);
-    if (rc) return -rc;
-    const LpJpeg& img = h.j;
-    if (comp >= img.ncomp) return -10;
-    const uint8_t* raw = data + h.ecs_off;
-    size_t rl = h.ecs_len;
-    std::vector<uint8_t> clean;
-    std::vector<uint32_t> rst;
-    for (size_t q = 0; q < rl; q++) {
-        uint8_t c = raw[q], prev = q ? raw[q - 1] : 0, next = q + 1 < rl ? raw[q + 1] : 0xD9;
-        if (c == 0xFF) { if (next == 0) clean.push_back(0xFF); continue; }
-        if (prev == 0xFF) {
-            if (c == 0) continue;
-            if (c >= 0xD0 && c <= 0xD7) { rst.push_back((uint32_t)clean.size() * 8); continue; }
-            return -11;
-        }
-        clean.push_back(c);
-    }
-    uint32_t total_bits = (uint32_t)clean.size() * 8;
-    std::vector<uint32_t> words((clean.size() + 3) / 4 + 64, 0);
-    for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
-    uint32_t n_rst = (uint32_t)rst.size();
-    rst.push_back(0);
-    bool violation = false, overflow = false;
-    LpImgCtx ic;
-    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
-    const LpCkSched cs = lp_make_sched(S, C ? C : 256);
-    const uint32_t K = cs.K, cap = lp_tok_cap(S, img.bpm, lp_min_mcu_bits(h.huff, img.blkpack, img.bpm));
-    uint32_t nsub = (total_bits + S - 1) / S;
-    *nsub_out = (int)nsub;
-    std::vector<LpCkptPk> ck((size_t)nsub * K);
-    std::vector<LpSubState> spec_ex(nsub), ex(nsub), entry_used(nsub);
-    std::vector<LpSubSum> spec_tot(nsub), tot(nsub);
-    std::vector<std::vector<uint32_t>> ts(nsub), tv(nsub);
-    std::vector<uint32_t> spec_n(nsub);
-    std::vector<LpTokSpan> span(nsub, LpTokSpan{0, 0});
-    stats[0] = stats[1] = stats[2] = 0;
-    for (uint32_t i = 0; i < nsub; i++) {
-        LpSubState e{i * S, 0};
-        HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
-        HostCk hc{&ck[(size_t)i * K]};
-        HostTok tk{&ts[i], cap, &overflow};
-        uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
-        lp_spec_tok_pass(m, ic, sub_end, e, cs, hc, tk, &spec_ex[i], &spec_tot[i], &spec_n[i]);
-        if (ts[i].size() != spec_n[i]) return -21;
-        ex[i] = spec_ex[i];
-        tot[i] = spec_tot[i];
-        entry_used[i] = LpSubState{0xffffffffu, 0xffffffffu};
-        stats[0] += spec_n[i];
-    }
-    int r = 0;
-    for (;;) {
-        int changed = 0;
-        std::vector<LpSubState> snap(ex); // Jacobi sweep
-        for (uint32_t i = 1; i < nsub; i++) {
-            LpSubState e = snap[i - 1];
-            if (lp_state_eq(e, entry_used[i])) continue;
-            HostCk hc{&ck[(size_t)i * K]};
-            tv[i].clear();
-            HostTok tk{&tv[i], cap, &overflow};
-            uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
-            LpVerState vs;
-            vs.p = e.p; vs.bz = e.bz; vs.iter = 0; vs.kk = 0; vs.ck_iter = K ? lp_ck_next(cs.base, 0, 0) : 0; vs.nblk = vs.nreset = 0; vs.pad = 0;
-            LpSubState ne = ex[i];
-            LpSubSum nt = tot[i];
-            LpTokSpan sp{0, 0};
-            for (;;) { // instalments of `budget` steps, the lane state put down and picked up in between (what the phased kernels do)
-                HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
-                stats[2]++;
-                const uint32_t until = budget ? (vs.iter + budget + 15u) / 16u * 16u : 0xfffffff0u;
-                if (lp_verify_tok_pass(m, ic, sub_end, vs, until, K, cs.base, hc, tk, spec_ex[i], spec_tot[i], spec_n[i], &ne, &nt, &sp)) break;
-            }
-            if (tv[i].size() < sp.head) return -22;
-            span[i] = sp;
-            tot[i] = nt;
-            if (!lp_state_eq(ne, ex[i])) { ex[i] = ne; changed++; }
-            entry_used[i] = e;
-        }
-        r++;
-        if (!changed) break;
-        if (r > 1000) return -12;
-    }
-    *rounds = r;
-    if (overflow) return -23;
-    std::vector<LpSubSum> prefix(nsub);
-    LpSubSum acc;
-    lp_sum_zero(acc);
-    for (uint32_t i = 0; i < nsub; i++) { prefix[i] = acc; acc = lp_sum_combine(acc, tot[i]); }
-    if (acc.nblk < img.total_blocks) return -13;
-    std::vector<int16_t> all((size_t)img.total_blocks * 64, 0);
-    HostExpandSink sink{all.data()};
-    for (uint32_t i = 0; i < nsub; i++) {
-        const LpSubState e = i ? ex[i - 1] : LpSubState{0, 0};
-        const uint32_t first = (e.bz & 255u) ? prefix[i].nblk - 1u : prefix[i].nblk; // the block that is open at the entry state belongs to an earlier subsequence's count
-        stats[1] += span[i].head;
-        (void)lp_expand_tokens(tv[i].data(), ts[i].data(), span[i], spec_n[i], first, img.total_blocks, sink);
-    }
-    {
-        std::vector<int16_t> dcs(img.total_blocks);
-        for (uint32_t q = 0; q < img.total_blocks; q++) dcs[q] = all[(size_t)q * 64];
-        int32_t pred[LP_MAX_COMP] = {0, 0, 0};
-        lp_dc_walk(dcs.data(), 0, img.mcus_x * img.mcus_y, img.bpm, img.dri, img.blk_comp, pred, true);
-        for (uint32_t q = 0; q < img.total_blocks; q++) all[(size_t)q * 64] = dcs[q];
-    }
-    if (violation) return -15;
-    *bw = (int)img.bw[comp]; *bh = (int)img.bh[comp];
-    size_t ne = (size_t)img.bw[comp] * img.bh[comp] * 64;
-    if (ne > cap_elems) return -3;
-    const uint32_t hs = img.hs[comp], vs_ = img.vs[comp];
-    for (uint32_t by = 0; by < img.bh[comp]; by++)
-        for (uint32_t bx = 0; bx < img.bw[comp]; bx++) {
-            size_t blk = ((size_t)(by / vs_) * img.mcus_x + bx / hs) * img.bpm + img.blk_first[comp] + (by % vs_) * hs + (bx % hs);
             memcpy(out + ((size_t)by * img.bw[comp] + bx) * 64, all.data() + blk * 64, 128);
         }
     return 0;
