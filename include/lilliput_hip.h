@@ -417,10 +417,13 @@ long lilliput_hip_png_inflate_check(const void* data, size_t len);
 void lilliput_hip_set_lazy_host(int on);
 int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current */
 
-/* Progressive (SOF2) JPEG sources: where the scans' entropy decode runs. 0 (default): host threads feed the device IDCT with
- * coefficients (a scan is serial by construction; see lilliput_amd/csrc/lp_prog_host.h), 1: one device lane per scan
- * (k_prog_scan). Same results either way. Also LILLIPUT_HIP_PROG_ENTROPY=device; host thread count: LILLIPUT_HIP_PROG_THREADS. */
+/* Progressive (SOF2) JPEG sources: the scans' entropy decode runs on host threads feeding the device IDCT with coefficients (a scan
+ * is serial by construction; see lilliput_amd/csrc/lp_prog_host.h; thread count: LILLIPUT_HIP_PROG_THREADS). A second home -- one device
+ * lane per scan (k_prog_scan), 25x slower at 4096 x 4096 -- is a BUILD option since round 3 (make DEFS=-DLP_PROG_DEVICE_LANES);
+ * lilliput_hip_progressive_device_lanes_built() says whether this library carries it, and only then do
+ * lilliput_hip_set_progressive_entropy(1) / LILLIPUT_HIP_PROG_ENTROPY=device select it. Same results either way. */
 void lilliput_hip_set_progressive_entropy(int on_device);
+int lilliput_hip_progressive_device_lanes_built(void);
 /* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
  * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
  * -3 = dst too small. nthreads 0 = default. */

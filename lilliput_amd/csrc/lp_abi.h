@@ -54,14 +54,16 @@ struct LpEncoder {
 class LpEngineLease {
 public:
     LpEngineLease();
+    explicit LpEngineLease(LpEngine* own);   // the caller's own engine becomes this thread's engine for the scope (nullptr: like the default constructor)
     ~LpEngineLease();
     LpEngineLease(const LpEngineLease&) = delete;
     LpEngineLease& operator=(const LpEngineLease&) = delete;
     LpEngine* get() const { return eng_; }   // nullptr: no usable device (the error text is set)
 private:
+    void acquire();
     LpEngine* eng_ = nullptr;
     int dev_ = 0;
-    bool owner_ = false, tls_ = false;
+    bool owner_ = false, tls_ = false, adopted_ = false;
 };
 int lp_thread_device(int device); // device for this thread's one-image ABI calls (-1 = default); returns the previous setting
 void lp_set_error(const std::string& s);

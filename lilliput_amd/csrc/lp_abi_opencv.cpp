@@ -64,7 +64,9 @@ thread_local LpEngine* t_lease_eng = nullptr;
 thread_local int t_lease_dev = -1;
 }
 
-LpEngineLease::LpEngineLease()
+LpEngineLease::LpEngineLease() { acquire(); }
+
+void LpEngineLease::acquire()
 {
     int dev = t_device;
     if (dev < 0) { dev = 0; if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e); }
@@ -93,8 +95,18 @@ LpEngineLease::LpEngineLease()
     if (!t_lease_eng) { t_lease_eng = eng_; t_lease_dev = dev; tls_ = true; }
 }
 
+LpEngineLease::LpEngineLease(LpEngine* own)
+{
+    if (!own) { acquire(); return; }
+    eng_ = own;
+    dev_ = own->device();
+    adopted_ = true;
+    if (!t_lease_eng) { t_lease_eng = own; t_lease_dev = dev_; tls_ = true; }
+}
+
 LpEngineLease::~LpEngineLease()
 {
+    if (adopted_) { if (tls_) { t_lease_eng = nullptr; t_lease_dev = -1; } (void)eng_->sync(); return; }
     if (!owner_ || !eng_) return;
     if (tls_) { t_lease_eng = nullptr; t_lease_dev = -1; }
     // what the call left in flight (lazy write-back) must be visible to whichever engine serves the handle's next call

@@ -137,6 +137,9 @@ struct LpBatch {
     // transformed one by one on a few host workers while the JPEG parts run
     std::vector<LpOtherItem> other;
     std::vector<lilliput_image_ops> other_ops; // one per worker
+    std::vector<std::unique_ptr<LpEngine>> other_eng; // ... and its engine: a worker keeps stream and arenas from item to item and call to call
+                                                      // (the pool of the one-image ABI keeps only a few idle engines: 32 workers cycling through
+                                                      // it built and tore down an engine per item)
     LpWorkerPool pool;
     std::mutex retry_mu;
     std::vector<int> retry;                     // baseline items the device decoder gave up on (too few blocks): decoded again libjpeg's way
@@ -620,7 +623,12 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
                                                                            : std::max(1, std::min(32, (int)std::thread::hardware_concurrency() / 8));
     const size_t nw = std::min<size_t>(b->other.size(), (size_t)other_workers);
     while (b->other_ops.size() < nw) b->other_ops.push_back(lilliput_new_image_ops(8192));
+    while (b->other_eng.size() < nw) {
+        b->other_eng.emplace_back(new LpEngine(b->device));
+        if (!b->other_eng.back()->ok()) b->other_eng.back().reset(); // the worker then leases from the pool like any caller
+    }
     std::atomic<size_t> next{0};
+    static const bool trace_items = getenv("LILLIPUT_HIP_TRACE") && atoi(getenv("LILLIPUT_HIP_TRACE")) >= 2;
     auto one = [&](lilliput_image_ops ops, LpOtherItem& it) -> int {
         const size_t i = (size_t)it.item;
         if (!ops) return LILLIPUT_ERR_DEVICE;
@@ -658,14 +666,20 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
     auto worker = [&](size_t wi) {
         const int prev_dev = lp_thread_device(b->device);
         lilliput_image_ops ops = b->other_ops[wi];
+        LpEngineLease own(b->other_eng[wi].get()); // every ABI call of this worker nests inside: its own engine, no pool traffic
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= b->other.size()) break;
             int rc;
             // nothing may unwind through a std::thread or the C ABI
+            const auto t_item = std::chrono::steady_clock::now();
             try { rc = one(ops, b->other[k]); }
             catch (const std::bad_alloc&) { rc = LILLIPUT_ERR_BUF_TOO_SMALL; }
             catch (...) { rc = LILLIPUT_ERR_DEVICE; }
+            if (trace_items)
+                fprintf(stderr, "[lilliput_hip] item %d (%.4s, %zu bytes) on worker %zu: %.2f ms, status %d\n", b->other[k].item,
+                        b->other[k].len >= 12 && !memcmp(b->other[k].data, "RIFF", 4) ? "webp" : b->other[k].len >= 8 && !memcmp(b->other[k].data, "LPPIXELS", 8) ? "pix " : (const char*)b->other[k].data + 1,
+                        b->other[k].len, wi, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_item).count(), rc);
             b->status[(size_t)b->other[k].item] = rc;
         }
         (void)lp_thread_device(prev_dev);
@@ -729,6 +743,7 @@ extern "C" int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batc
         run_other(b, opt, nullptr);
         for (auto& t : th) t.join();
     }
+    lp_retired_collect();
     return end_run(b, n, trace, t_run0);
 }
 
@@ -971,6 +986,7 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         for (auto& t : th) t.join();
         for (LpBatch* d : devs) // every chunk has been decoded: the caller's pages that were registered for this call are released
             for (auto& part : d->parts) part.eng->upload_release_pins();
+        lp_retired_collect(); // arenas that grew during the call: their old blocks go now, while nothing is in flight
         if (!b->retry.empty()) { // short baseline streams: once more through the one-image path, whose decoder falls back to libjpeg's serial rule
             b->other.clear();
             std::sort(b->retry.begin(), b->retry.end());

@@ -43,16 +43,55 @@ struct LpRuntimeEnv {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Growing an arena replaces its block. The old block is NOT freed on the spot: hipFree / hipHostFree synchronise the whole device, and
+// stages of a chunk are enqueued back to back without host synchronisation, so a kernel still in flight may hold the old address -- with
+// four engines and the batch's host workers sharing the GPU a growth in the middle of a call stalled everything for up to a second
+// (one chunk of a mixed-size batch: 940 ms). Retired blocks wait in a list that is emptied at the quiet points: the end of a batch /
+// node call and engine destruction (lp_retired_collect). Growth is geometric (x 1.5), so the waste is bounded.
+namespace {
+struct Retired {
+    std::mutex mu;
+    std::vector<void*> dev, host;
+};
+Retired& retired()
+{
+    static Retired* r = new Retired(); // never destroyed: engines may be torn down from atexit handlers
+    return *r;
+}
+size_t grown(size_t cap, size_t bytes) { return std::max(bytes + bytes / 8 + 256, cap + cap / 2); }
+}
+void lp_retired_collect()
+{
+    std::vector<void*> d, h;
+    {
+        Retired& r = retired();
+        std::lock_guard<std::mutex> lk(r.mu);
+        d.swap(r.dev);
+        h.swap(r.host);
+    }
+    if (d.empty() && h.empty()) return;
+    (void)hipDeviceSynchronize(); // whatever was enqueued against the old blocks has run
+    for (void* p : d) (void)hipFree(p);
+    for (void* p : h) (void)hipHostFree(p);
+}
+
 LpDevBuf::~LpDevBuf() { if (p) (void)hipFree(p); }
 bool LpDevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
-    // Growing replaces the block. Stages of a chunk are enqueued back to back without host synchronisation, so a kernel that is
-    // still in flight may hold the old address: wait for the device before the old block goes away (growth happens in the first
-    // chunks of an engine's life; the wait is noise there).
-    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 8 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+    const size_t want = grown(cap, bytes);
+    void* np = nullptr;
+    if (hipMalloc(&np, want) != hipSuccess) { // out of memory: give the retired blocks back first, then try once more
+        (void)hipGetLastError();
+        lp_retired_collect();
+        if (hipMalloc(&np, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    if (p) {
+        Retired& r = retired();
+        std::lock_guard<std::mutex> lk(r.mu);
+        r.dev.push_back(p);
+    }
+    p = np;
     cap = want;
     return true;
 }
@@ -60,9 +99,15 @@ LpPinned::~LpPinned() { if (p) (void)hipHostFree(p); }
 bool LpPinned::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
-    if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; } // kernels read and write these blocks through their device alias
-    size_t want = bytes + bytes / 8 + 256;
-    if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; return false; }
+    const size_t want = grown(cap, bytes);
+    void* np = nullptr;
+    if (hipHostMalloc(&np, want, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (p) { // kernels read and write these blocks through their device alias
+        Retired& r = retired();
+        std::lock_guard<std::mutex> lk(r.mu);
+        r.host.push_back(p);
+    }
+    p = np;
     if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) dev = p; // unified addressing: the same pointer
     cap = want;
     return true;
@@ -85,6 +130,7 @@ LpEngine::LpEngine(int device) : device_(device)
 
 LpEngine::~LpEngine()
 {
+    lp_retired_collect();
     if (stream_) { (void)hipStreamSynchronize(stream_); }
     if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); }
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -706,6 +752,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
                           d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
         stage("prog_unstuff");
+#ifdef LP_PROG_DEVICE_LANES
         for (size_t l = 0; l + 1 < h_plevel_first_.size(); l++) {
             const uint32_t f = h_plevel_first_[l], cnt = h_plevel_first_[l + 1] - f;
             // few lanes: one per wave (a lane alone on its SIMD runs fastest); many: pack them so that the grid stays a few waves per SIMD
@@ -713,6 +760,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),
                                  u_->d_phuffs.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
         }
+#else
+        err_ = "this build carries no device-lane scan decoder"; // unreachable: lp_prog_entropy_on_device() is false without the build flag
+        return LP_ERR_DEVICE;
+#endif
         stage("prog_scans");
     }
     if (timing_) (void)hipEventRecord(ev_[2], stream_);
@@ -1149,20 +1200,22 @@ int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const ui
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
     const size_t pal_off = (n + 255) & ~(size_t)255;
-    if (!d_planes_.ensure(pal_off + 1024 + 256)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    if (!d_planes_.ensure(pal_off + 1024 + 256 + LP_PNG_SYNC_BYTES)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     uint8_t* base = d_planes_.as<uint8_t>();
     if (n && !check(hipMemcpyAsync(base, filtered, n, hipMemcpyHostToDevice, stream_), "H2D png data")) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D png palette")) return LP_ERR_DEVICE;
-    if (!check(hipMemsetAsync(base + pal_off + 1024, 0, 4, stream_), "memset png flag")) return LP_ERR_DEVICE;
+    if (!check(hipMemsetAsync(base + pal_off + 1024, 0, 256 + LP_PNG_SYNC_BYTES, stream_), "memset png flag")) return LP_ERR_DEVICE; // the error flag and the un-filter kernel's progress words
     op.data_off = (uint64_t)(uintptr_t)base;
     op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
     op.error_off = (uint64_t)(uintptr_t)(base + pal_off + 1024);
+    op.sync_off = (uint64_t)(uintptr_t)(base + pal_off + 1024 + 256);
     lp_launch_png(stream_, op);
     uint32_t* flag = h_small_.ensure(4096) ? h_small_.as<uint32_t>() : nullptr;
     if (!flag) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(flag, base + pal_off + 1024, 4, hipMemcpyDeviceToHost, stream_), "D2H png flag")) return LP_ERR_DEVICE;
     if (!check(hipStreamSynchronize(stream_), "png sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "png kernels")) return LP_ERR_DEVICE;
+    if (*flag & 2u) { err_ = "PNG: the un-filter kernel gave up waiting for a band (device trouble)"; return LP_ERR_DEVICE; }
     if (*flag) { err_ = "PNG: bad adaptive filter value"; return LP_ERR_DECODE_FAILED; }
     return LP_OK;
 }

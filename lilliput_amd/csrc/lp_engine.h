@@ -22,11 +22,14 @@
 #include "lp_launch.h"
 #include "lp_types.h"
 
+// Frees the blocks that growing arenas have retired (see LpDevBuf::ensure in lp_engine.cpp); called at the end of a batch / node call.
+void lp_retired_collect();
+
 struct LpDevBuf {
     void* p = nullptr;
     size_t cap = 0;
     ~LpDevBuf();
-    // grow-only; contents are NOT preserved across growth
+    // grow-only (x 1.5 at least); contents are NOT preserved across growth; the old block is retired, not freed (lp_retired_collect)
     bool ensure(size_t bytes);
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };

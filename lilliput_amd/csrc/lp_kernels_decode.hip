@@ -1005,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     }
 }
 
+#ifdef LP_PROG_DEVICE_LANES // the device-lane home of the progressive scans is a build option (make DEFS=-DLP_PROG_DEVICE_LANES): see lp_prog_host.h
 // ------------------------------------------------------------------------------------------------
 // Progressive scans (lp_prog_core.h): lane = one scan of one image, decoded serially from its first bit to its last. The lanes
 // of a launch share nothing (different streams, tables and blocks), so a workgroup carries only `lpw` of them: with few scans
@@ -1080,6 +1081,8 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
     m.dirty = 0;
     lp_prog_scan(m, sc, st.clean_bytes * 8u, st.n_rst);
 }
+
+#endif // LP_PROG_DEVICE_LANES
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (plain C++ signatures; see lp_launch.h)
@@ -1224,6 +1227,7 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
     if (which & 2u) hipLaunchKernelGGL(k_idct<true>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_pcoef, d_planes);
 }
 
+#ifdef LP_PROG_DEVICE_LANES
 void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, const LpJpeg* d_streams,
                           const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
 {
@@ -1233,3 +1237,4 @@ void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t fir
     hipLaunchKernelGGL(k_prog_scan, dim3((n + lpw - 1) / lpw), dim3(64), 0, s, d_scans, first, n, lpw, d_streams, d_stream_states, d_huffs, d_clean, d_rst,
                        d_pcoef);
 }
+#endif

@@ -765,22 +765,57 @@ __device__ __forceinline__ uint32_t png_byte(const uint32_t (&w)[4], int i) { re
 // previous output chunk (left neighbours) and the previous chunk of the row above (above-left), and one step of the diagonal
 // is one chunk: lane r works on chunk t - r, the chunk above arrives from lane r-1 with four shuffles. Loads run one chunk
 // ahead of the arithmetic.
+// Bands of 64 rows are spread over the 16 waves of LP_PNG_WGS workgroups (band b on wave b mod (16 x LP_PNG_WGS) of the pass) and
+// run as ONE diagonal across the whole pass: band b + 1 starts as soon as band b's last row has produced its first chunks. That row's
+// output is read back from memory by lane 0 of the band below; the writer publishes its progress (count of finished chunks, tagged
+// with the band number) every PNG_PUB chunks behind an agent-scope release fence. The only waits in the kernel go from a band to the
+// band ABOVE it, and workgroups are dispatched in index order, so the band above is always running or done; a spin that does not end
+// (it cannot, short of a lost device) gives up after PNG_SPIN_MAX polls and flags the image as failed instead of hanging the queue.
+// Round 2 ran the bands one after the other in a single wave: rows / 64 x (chunks + 63) steps for a pass, ~0.6 - 1 GB/s; one workgroup
+// of sixteen waves pipelined this way reaches 3.5 GB/s (one CU's issue rate), eight of them share the pass.
+#define PNG_WAVES 16
+#define PNG_PUB 4       // the last row of a band publishes every fourth chunk (one fence per four steps)
+#define PNG_SPIN_MAX (1u << 24)
 template <int BPP>
-__device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* error)
+__device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* error, unsigned long long* prog, uint32_t wgi)
 {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wv = wgi * PNG_WAVES + (threadIdx.x >> 6);
     const size_t stride = (size_t)ps.row_bytes + 1;
     const uint32_t nchunk = (ps.row_bytes + 15) / 16;
-    for (uint32_t band = 0; band < ps.ph; band += 64) {
+    const uint32_t nbands = (ps.ph + 63u) / 64u;
+    for (uint32_t bi = wv; bi < nbands; bi += PNG_WAVES * LP_PNG_WGS) {
+        const uint32_t band = bi * 64u;
         const uint32_t row = band + lane;
         const bool live = row < ps.ph;
         uint8_t* cur = base + ps.off + (size_t)(live ? row : 0) * stride;
         const uint32_t ft = live ? cur[0] : 0;
         if (live && ft > 4) atomicOr(error, 1u); // "bad adaptive filter value" (the host has already refused such a file)
         cur += 1;
-        const uint8_t* up_row = (lane == 0 && row) ? cur - stride : nullptr; // rows above a band are final; only lane 0 reads memory for "above"
+        const uint8_t* up_row = (lane == 0 && row && ft > 1u) ? cur - stride : nullptr; // lane 0's "above" is the last row of the band above (not needed by None / Sub)
+        const uint32_t slot = bi % LP_PNG_SLOTS, pslot = (bi + LP_PNG_SLOTS - 1u) % LP_PNG_SLOTS;
+        const unsigned long long tag = (unsigned long long)(bi + 1u) << 32;
         uint32_t out[4] = {0, 0, 0, 0}, upp[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0}, upn[4] = {0, 0, 0, 0};
         const uint32_t rows_here = ps.ph - band < 64 ? ps.ph - band : 64;
+        const bool hands_off = bi + 1u < nbands;             // a band below reads this band's last row
+        if (lane == 0) __hip_atomic_store(&prog[slot], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this band: nothing final yet
+        // wave-uniform wait until the band above has `want` chunks of its last row final in memory
+        auto wait_above = [&](uint32_t want) -> uint32_t {
+            uint32_t have = 0;
+            for (uint32_t spin = 0;; spin++) {
+                const unsigned long long v = __hip_atomic_load(&prog[pslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have = (uint32_t)v;
+                if ((uint32_t)(v >> 32) == bi && have >= want) break; // the band above carries tag (bi - 1) + 1
+                if (spin > PNG_SPIN_MAX) { if (lane == 0) atomicOr(error, 2u); have = 0xffffffffu; break; } // never seen; see the header comment
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return have;
+        };
+        // A band whose first row is filtered None or Sub does not look at the row above at all: it starts at once, and the diagonal of
+        // dependencies is cut there (adaptive encoders choose those filters for a good share of the rows)
+        const bool chained = bi && (uint32_t)__builtin_amdgcn_readfirstlane((int)ft) > 1u;
+        uint32_t seen = 0; // chunks of the row above known to be final
+        if (chained) seen = wait_above(1u);
         if (live && lane == 0) { // prime the pipeline of the first row of the band
             const PngChunk c0 = *reinterpret_cast<const PngChunk*>(cur);
 #pragma unroll
@@ -794,6 +829,8 @@ __device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* 
         for (uint32_t t = 0; t < nchunk + rows_here - 1; t++) {
             const int j = (int)t - (int)lane;
             const bool on = live && j >= 0 && j < (int)nchunk;
+            // lane 0 fetches chunk t + 1 of the row above in this step
+            if (chained && t + 1u < nchunk && seen < t + 2u) seen = wait_above(t + 2u);
             uint32_t f[4], up[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -818,7 +855,7 @@ __device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* 
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const uint32_t a = i >= BPP ? png_byte(o, i - BPP) : png_byte(out, 16 - BPP + i);
-                    const uint32_t b = up_row || lane || row ? png_byte(up, i) : 0u;
+                    const uint32_t b = row ? png_byte(up, i) : 0u;
                     const uint32_t c = i >= BPP ? png_byte(up, i - BPP) : png_byte(upp, 16 - BPP + i);
                     const int pa = abs((int)b - (int)c), pb = abs((int)a - (int)c), pc = abs((int)a + (int)b - 2 * (int)c);
                     const uint32_t paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
@@ -837,24 +874,34 @@ __device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* 
 #pragma unroll
                 for (int k = 0; k < 4; k++) { out[k] = o[k]; upp[k] = up[k]; }
             }
+            // the band's last row tells the band below how far it is: every PNG_PUB chunks and at the end of the row
+            if (hands_off) {
+                const int jl = (int)t - (int)(rows_here - 1u); // chunk the last row finished in this step (wave-uniform)
+                if (jl >= 0 && jl < (int)nchunk && (((uint32_t)jl % PNG_PUB) == PNG_PUB - 1u || jl == (int)nchunk - 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // its stores first
+                    if (lane == rows_here - 1u) __hip_atomic_store(&prog[slot], tag | (uint32_t)(jl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
-        __threadfence(); // the next band's lane 0 reads this band's last row from memory
     }
 }
 
-__global__ __launch_bounds__(64) void k_png_unfilter(LpPngOp op)
+__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(LpPngOp op)
 {
-    const LpPngPass& ps = op.pass[blockIdx.x];
+    const uint32_t pass = blockIdx.x / LP_PNG_WGS, wgi = blockIdx.x % LP_PNG_WGS;
+    const LpPngPass& ps = op.pass[pass];
     if (!ps.pw || !ps.ph) return;
+    if (wgi * PNG_WAVES * 64u >= ps.ph) return; // no band for this workgroup
     uint8_t* base = reinterpret_cast<uint8_t*>(op.data_off);
     uint32_t* err = reinterpret_cast<uint32_t*>(op.error_off);
+    unsigned long long* prog = reinterpret_cast<unsigned long long*>(op.sync_off) + (size_t)pass * LP_PNG_SLOTS;
     switch (op.bpp) {
-    case 1: png_unfilter_pass<1>(base, ps, err); break;
-    case 2: png_unfilter_pass<2>(base, ps, err); break;
-    case 3: png_unfilter_pass<3>(base, ps, err); break;
-    case 4: png_unfilter_pass<4>(base, ps, err); break;
-    case 6: png_unfilter_pass<6>(base, ps, err); break;
-    default: png_unfilter_pass<8>(base, ps, err); break;
+    case 1: png_unfilter_pass<1>(base, ps, err, prog, wgi); break;
+    case 2: png_unfilter_pass<2>(base, ps, err, prog, wgi); break;
+    case 3: png_unfilter_pass<3>(base, ps, err, prog, wgi); break;
+    case 4: png_unfilter_pass<4>(base, ps, err, prog, wgi); break;
+    case 6: png_unfilter_pass<6>(base, ps, err, prog, wgi); break;
+    default: png_unfilter_pass<8>(base, ps, err, prog, wgi); break;
     }
 }
 
@@ -914,7 +961,7 @@ __global__ __launch_bounds__(256) void k_png_convert(LpPngOp op)
 void lp_launch_png(hipStream_t s, const LpPngOp& op)
 {
     if (!op.npass) return;
-    hipLaunchKernelGGL(k_png_unfilter, dim3(op.npass), dim3(64), 0, s, op);
+    hipLaunchKernelGGL(k_png_unfilter, dim3(op.npass * LP_PNG_WGS), dim3(PNG_WAVES * 64), 0, s, op);
     uint32_t mw = 0, mh = 0;
     for (uint32_t p = 0; p < op.npass; p++) { mw = op.pass[p].pw > mw ? op.pass[p].pw : mw; mh = op.pass[p].ph > mh ? op.pass[p].ph : mh; }
     if (!mw || !mh) return;

@@ -1,8 +1,11 @@
 // lp_png.cpp -- see lp_png.h.
 #include "lp_png.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 namespace {
 const uint8_t kPngSig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
@@ -258,8 +261,86 @@ struct IdatFeed {
 };
 }
 
+// png_read_end: the chunks after the image data, up to IEND (from offset i, the first byte behind the last IDAT's CRC)
+static bool png_tail_ok(const uint8_t* s, size_t n, size_t i, const LpPngInfo& info)
+{
+    for (;;) {
+        if (n - i < 8) return false;           // no IEND: read past the end
+        const uint32_t len = be32(s + i);
+        const uint8_t* type = s + i + 4;
+        if (len > 0x7fffffffu || !chunk_name_ok(type)) return false;
+        if (n - i - 8 < (size_t)len + 4) return false;
+        const uint8_t* d = s + i + 8;
+        const bool crc_ok = be32(d + len) == (uint32_t)crc32(crc32(0, type, 4), d, len);
+        const bool ancillary = (type[0] & 0x20) != 0;
+        i += 12 + (size_t)len;
+        if (is_type(type, "IEND")) return true;                        // a CRC error or a payload here only draws a warning
+        if (is_type(type, "IDAT")) { if (!crc_ok) return false; continue; } // "Too many IDATs found" is benign, a CRC error is not
+        if (is_type(type, "IHDR")) return false;                       // "out of place"
+        if (is_type(type, "PLTE")) { if (!crc_ok && info.color_type == 3) return false; continue; } // after IDAT: "out of place", benign
+        if (!ancillary) return false;                                  // "unhandled critical chunk" (or its CRC error)
+    }
+}
+
+// The common case in one sweep: every IDAT chunk whole, the whole image as the output buffer -- zlib then stays in its fast loop
+// instead of being entered once per row with 8 KiB of input (libpng's pattern, reproduced below for the exact verdict on anything
+// unusual; per-row calls cost ~1.5x: the window copy on every return and the call overhead). Returns 1 when the stream is a perfectly
+// ordinary one -- consecutive IDAT chunks with good CRCs, a deflate stream that ends exactly with the last row and the last IDAT byte,
+// filter bytes 0..4, a well-formed tail -- and `filtered` holds it; 0 = anything else: the caller takes libpng's walk, whose accept /
+// reject rules (warnings against errors, where damage is tolerated) are then authoritative.
+static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
+{
+    const size_t need = filtered.size();
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 0) != Z_OK) return 0;
+    struct ZEnd { z_stream* z; ~ZEnd() { inflateEnd(z); } } zend{&zs};
+    zs.next_out = filtered.data();
+    zs.avail_out = (uInt)std::min<size_t>(need, 0xffffffffu);
+    if (need > 0xffffffffu) return 0;
+    size_t i = info.idat_off;
+    bool ended = false;
+    for (;;) {
+        if (n - i < 12) return 0;
+        const uint32_t len = be32(s + i);
+        const uint8_t* type = s + i + 4;
+        if (len > 0x7fffffffu || n - i - 8 < (size_t)len + 4) return 0;
+        if (!is_type(type, "IDAT")) break;
+        if (ended) return 0; // data behind the end of the stream: libpng's rules decide
+        const uint8_t* d = s + i + 8;
+        if (be32(d + len) != (uint32_t)crc32(crc32(0, type, 4), d, len)) return 0;
+        zs.next_in = const_cast<uint8_t*>(d);
+        zs.avail_in = len;
+        if (len) {
+            const int ret = inflate(&zs, Z_NO_FLUSH);
+            if (ret == Z_STREAM_END) { if (zs.avail_in) return 0; ended = true; }
+            else if (ret != Z_OK || zs.avail_in) return 0; // an error, or output that does not fit the image
+        }
+        i += 12 + (size_t)len;
+    }
+    if (!ended || zs.avail_out != 0) return 0;
+    // png_read_filter_row's check of every row's filter byte
+    const int bits = info.depth * lp_png_channels_in_file(info.color_type);
+    size_t o = 0;
+    for (int p = 0; p < (info.interlace ? 7 : 1); p++) {
+        uint32_t pw, ph, x0, y0, dx, dy;
+        lp_png_pass_geometry(info, p, &pw, &ph, &x0, &y0, &dx, &dy);
+        if (!pw || !ph) continue;
+        const size_t row = 1 + packed_row_bytes(pw, bits);
+        for (uint32_t r = 0; r < ph; r++, o += row)
+            if (filtered[o] > 4) return 0;
+    }
+    return png_tail_ok(s, n, i, info) ? 1 : 0;
+}
+
 bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
 {
+    {
+        const size_t need0 = lp_png_filtered_size(info);
+        filtered.resize(need0); // no zero-fill: inflate writes every byte of an ordinary stream
+        static const bool no_fast = getenv("LILLIPUT_HIP_PNG_ROWWISE") != nullptr; // A/B: libpng's row-by-row pattern for every file
+        if (!no_fast && need0 && png_idat_fast(s, n, info, filtered) == 1) return true;
+    }
     IdatFeed in{s, n, info.idat_off};
     if (!in.open_chunk(true)) return false;
     const size_t need = lp_png_filtered_size(info);
@@ -303,22 +384,5 @@ bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::ve
         } while (produced > 0);
     }
     if (!in.skip_rest()) return false;
-    size_t i = in.i;
-    // png_read_end: the chunks after the image data, up to IEND
-    for (;;) {
-        if (n - i < 8) return false;           // no IEND: read past the end
-        const uint32_t len = be32(s + i);
-        const uint8_t* type = s + i + 4;
-        if (len > 0x7fffffffu || !chunk_name_ok(type)) return false;
-        if (n - i - 8 < (size_t)len + 4) return false;
-        const uint8_t* d = s + i + 8;
-        const bool crc_ok = be32(d + len) == (uint32_t)crc32(crc32(0, type, 4), d, len);
-        const bool ancillary = (type[0] & 0x20) != 0;
-        i += 12 + (size_t)len;
-        if (is_type(type, "IEND")) return true;                        // a CRC error or a payload here only draws a warning
-        if (is_type(type, "IDAT")) { if (!crc_ok) return false; continue; } // "Too many IDATs found" is benign, a CRC error is not
-        if (is_type(type, "IHDR")) return false;                       // "out of place"
-        if (is_type(type, "PLTE")) { if (!crc_ok && info.color_type == 3) return false; continue; } // after IDAT: "out of place", benign
-        if (!ancillary) return false;                                  // "unhandled critical chunk" (or its CRC error)
-    }
+    return png_tail_ok(s, n, in.i, info);
 }

@@ -247,6 +247,9 @@ struct LpGifEncOp {
 
 // One PNG image on the device: `data_off` holds the inflated stream (per Adam7 pass, per row: filter byte + packed row);
 // k_png_unfilter reconstructs it in place, k_png_convert expands it to the 8-bit BGR(A) / grey frame OpenCV's PngDecoder yields.
+#define LP_PNG_WGS 8            // workgroups of 16 waves that share one Adam7 pass (one band of 64 rows per wave at a time)
+#define LP_PNG_SLOTS (2 * LP_PNG_WGS * 16)
+#define LP_PNG_SYNC_BYTES (7 * LP_PNG_SLOTS * 8)
 struct LpPngPass {
     uint64_t off;               // byte offset of the pass inside the inflated stream
     uint32_t pw, ph;            // pixels per row / rows of this pass (0 = empty pass, no data)
@@ -259,6 +262,7 @@ struct LpPngOp {
     uint64_t data_off;          // device address of the inflated stream
     uint64_t palette_off;       // device address of 256 x {B, G, R, A} (palette images)
     uint64_t error_off;         // device address of a uint32 flag: set when a row carries a filter type above 4
+    uint64_t sync_off;          // device address of the un-filter kernel's progress words (LP_PNG_SYNC_BYTES, zeroed before the launch)
     LpPngPass pass[7];
     uint32_t npass;
     uint32_t depth, color_type; // as in IHDR

@@ -63,3 +63,68 @@ def synth_jpeg_set(n, size=4096, quality=90, workers=None):
         return [synth_jpeg(i, size, quality) for i in range(n)]
     with mp.get_context("fork").Pool(workers) as pool:
         return pool.map(_job, [(i, size, quality) for i in range(n)])
+
+
+# ---- BASELINE configs[4] in miniature: the mixed-format firehose (JPEG 70 %, PNG 15 %, WebP 10 %, AVIF 5 %;
+# side lengths log-uniform). AV1 is a host codec outside this library: its items arrive as handed-over decoded frames
+# (include/lilliput_hip.h lilliput_hip_pixels_header), which is how a service with libavif in front would feed them.
+FIREHOSE_MIX = (("jpeg", 0.70), ("png", 0.15), ("webp", 0.10), ("pixels", 0.05))
+
+
+def firehose_source(kind, seed, side):
+    """One source of the mix: `kind` in jpeg / png / webp / pixels, content = synth_rgb(seed, side) (aspect 4:3 for odd seeds)."""
+    import struct
+
+    from PIL import Image
+
+    rgb = synth_rgb(seed, side)
+    if seed & 1:
+        rgb = np.ascontiguousarray(rgb[: max(8, side * 3 // 4)])
+    im = Image.fromarray(rgb)
+    b = io.BytesIO()
+    if kind == "jpeg":
+        im.save(b, "JPEG", quality=(75, 85, 90, 95)[seed % 4], subsampling=(2, 2, 1, 0)[seed % 4], optimize=bool(seed % 3 == 0))
+    elif kind == "png":
+        if seed % 4 == 3:
+            im = im.convert("RGBA")
+        im.save(b, "PNG", compress_level=3)
+    elif kind == "webp":
+        im.save(b, "WEBP", quality=80, method=2) if seed % 4 else im.save(b, "WEBP", lossless=True, method=0)
+    else:
+        h, w = rgb.shape[:2]
+        return b"LPPIXELS" + struct.pack("<6I", w, h, 3, 0, 1 + (seed % 8 if seed % 5 == 0 else 0), 0) + np.ascontiguousarray(rgb[..., ::-1]).tobytes()
+    return b.getvalue()
+
+
+def _fh_job(args):
+    return firehose_source(*args)
+
+
+def firehose_pool(distinct_per_kind, lo=512, hi=4096, seed=1, workers=None):
+    """{kind: [bytes]}: `distinct_per_kind` sources per format, sides log-uniform in [lo, hi] (seeded), generated on the host cores."""
+    import multiprocessing as mp
+    import os
+
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for k, (kind, _) in enumerate(FIREHOSE_MIX):
+        for i in range(distinct_per_kind):
+            side = int(round(float(np.exp(rng.uniform(np.log(lo), np.log(hi)))) / 8) * 8)
+            jobs.append((kind, 1000 * (k + 1) + i, side))
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) - 1, 64))
+    if workers <= 1:
+        out = [firehose_source(*j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            out = pool.map(_fh_job, jobs, chunksize=1)
+    pools = {kind: [] for kind, _ in FIREHOSE_MIX}
+    for j, d in zip(jobs, out):
+        pools[j[0]].append(d)
+    return pools
+
+
+def firehose_items(pools, n, seed=2):
+    """n items drawn from the pools with the mix's probabilities: [(kind, bytes)]."""
+    rng = np.random.default_rng(seed)
+    kinds = rng.choice([k for k, _ in FIREHOSE_MIX], size=n, p=[p for _, p in FIREHOSE_MIX])
+    return [(str(k), pools[str(k)][int(rng.integers(len(pools[str(k)])))]) for k in kinds]

@@ -603,6 +603,35 @@ def transform_jpeg_thumbnail(data, width, height, quality=85, use_ref=False):
     return (ref_jpeg_encode if from_ref else jpeg_encode)(out, quality)
 
 
+def transform_any_frame(data, width, height, resize_method=FIT):
+    """The frame ImageOps.Transform hands its encoder for a still source of any kind the firehose carries (BASELINE configs[4]):
+    JPEG (this file's libjpeg restatement), PNG and WebP (the reference's own libpng / libwebp through oracle/_ref: first frame),
+    or a handed-over decoded frame (include/lilliput_hip.h lilliput_hip_pixels_header) -> orientation -> Fit / Resize
+    (ops.go:352-479). None when the reference library for the format is not built."""
+    import struct
+
+    d = bytes(data)
+    if d[:8] == b"LPPIXELS":
+        w, h, cn, stride, orientation, _ms = struct.unpack("<6I", d[8:32])
+        stride = stride or w * cn
+        rows = np.frombuffer(d, dtype=np.uint8, offset=32, count=stride * (h - 1) + w * cn)
+        px = np.stack([rows[y * stride: y * stride + w * cn] for y in range(h)]).reshape(h, w, cn)
+        return transform_static(px, orientation, width, height, resize_method, False)
+    if d[:8] == b"\x89PNG\r\n\x1a\n":
+        px = ref_png_decode(d) if ref_png() is not None else None
+        return None if px is None else transform_static(px, 1, width, height, resize_method, False)
+    if d[:4] == b"RIFF" and d[8:12] == b"WEBP":
+        fr = ref_webp_frames(d) if ref_webp() is not None else None
+        return None if not fr or fr[0] is None else transform_static(fr[0][0], 1, width, height, resize_method, False)
+    return transform_static(jpeg_decode(d), jpeg_info(d)["orientation"], width, height, resize_method, False)
+
+
+def transform_any_to_jpeg(data, width, height, quality=85, resize_method=FIT):
+    """The reference CPU path's bytes for `data` -> (Fit) -> JPEG quality q; None when the format's reference library is missing."""
+    f = transform_any_frame(data, width, height, resize_method)
+    return None if f is None else jpeg_encode(f if f.shape[2] > 1 else f[:, :, 0], quality)
+
+
 class _Info(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int),
                 ("cid", C.c_int * 4), ("hs", C.c_int * 4), ("vs", C.c_int * 4), ("tq", C.c_int * 4),

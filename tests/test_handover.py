@@ -61,6 +61,21 @@ def test_handed_over_pixels_take_the_jpeg_path(hip_lib, fixture_bytes):
     want, _ = _transform(src, ".jpeg", 96, 64, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
     got, desc = _transform(_handover(px), ".jpeg", 96, 64, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
     assert desc == "PIXELS" and got == want
+    # ... and against the ORACLE's frame for the hand-over route (not only the product's other route): the pre-encode frame within
+    # +-1 LSB of transform_static on the handed-over pixels (a fractional scale: float taps), the output its byte-exact encoding
+    from oracle import oracle as O
+    O.lib()
+    for o in (1, 3, 6, 8):
+        blob = _handover(px, orientation=o)
+        ref = O.transform_any_frame(blob, 96, 64)
+        raw2, _ = _transform(blob, ".bgra-frames", 96, 64, la.ImageOpsFit)
+        (frame, _d), = la.parse_raw_frames(raw2)
+        assert frame.shape == ref.shape and np.abs(frame.astype(int) - ref.astype(int)).max() <= 1, o
+        out2, _ = _transform(blob, ".jpeg", 96, 64, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
+        assert out2 == O.jpeg_encode(frame, 85), o
+    exact = _handover(np.ascontiguousarray(px[:64, :96]))                   # 96 x 64 -> 48 x 32: an integer scale, bit-exact
+    out3, _ = _transform(exact, ".jpeg", 48, 32, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
+    assert out3 == O.transform_any_to_jpeg(exact, 48, 32, 85)
     got, _ = _transform(_handover(px, stride=w * cn + 13, pad=7), ".jpeg", 96, 64, la.ImageOpsFit, EncodeOptions={la.JpegQuality: 85})
     assert got == want                                                      # padded rows, trailing bytes
     # orientation 6 (rotate 90 degrees clockwise to display) == the pre-rotated frame with orientation 1
@@ -89,3 +104,10 @@ def test_handover_items_in_a_batch(hip_lib, fixture_bytes):
     b.close()
     assert [r.status for r in res] == [0, 0, 1, 0]
     assert res[1].data == res[0].data == res[3].data
+    from oracle import oracle as O
+    O.lib()
+    exact = _handover(np.ascontiguousarray(px[:64, :96]))                   # integer scale: the batch's bytes are the oracle's
+    b = la.Batch(0)
+    res = b.transform([exact, src, exact], 48, 32, quality=85)
+    b.close()
+    assert res[0].status == 0 and res[0].data == res[2].data == O.transform_any_to_jpeg(exact, 48, 32, 85)

@@ -164,6 +164,8 @@ def test_damaged_files_same_verdict_and_coefficients_as_the_oracle(hip_lib, orac
 @pytest.fixture(params=["host-entropy", "device-entropy"])
 def mode(request, hip_lib):
     """Both homes of the scans' entropy decode (lilliput_hip_set_progressive_entropy): host threads (default) and device lanes."""
+    if request.param == "device-entropy" and not hip_lib.lilliput_hip_progressive_device_lanes_built():
+        pytest.skip("the device-lane scan decoder is a build option (make DEFS=-DLP_PROG_DEVICE_LANES): not in this library")
     hip_lib.lilliput_hip_set_progressive_entropy(1 if request.param == "device-entropy" else 0)
     yield request.param
     hip_lib.lilliput_hip_set_progressive_entropy(0)
@@ -291,6 +293,8 @@ def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
 @pytest.mark.gpu
 def test_progressive_modes_agree_on_damaged_files(batch, hip_lib):
     """Host threads and device lanes give the same pixels (or the same error) for cut and bit-flipped files too."""
+    if not hip_lib.lilliput_hip_progressive_device_lanes_built():
+        pytest.skip("the device-lane scan decoder is a build option (make DEFS=-DLP_PROG_DEVICE_LANES): not in this library")
     import lilliput_amd
 
     rng = np.random.default_rng(5)
