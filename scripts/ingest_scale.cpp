@@ -94,7 +94,10 @@ int main(int argc, char** argv)
     printf("# host: %u hardware threads, %zu NUMA nodes; %zu distinct sources; %.1f s per point\n", std::thread::hardware_concurrency(), nodes.size(), files.size(), secs);
     const int kStagers = 4, kChunk = 32;
     printf("| mode | engine sets (GPUs) | host threads | GB/s made DMA-ready | per set | needed at the 1-GPU link rate (49 GB/s each) |\n|---|---:|---:|---:|---:|---:|\n");
-    for (int mode = 0; mode < 2; mode++) {
+    // mode 1 (register / unregister the caller's pages per chunk) is kept for reference only: re-registering the SAME buffers in a loop
+    // hits the runtime's cache of pinned ranges and reports a rate no first-time registration reaches (profiles/r03_a_ingest.md section 3);
+    // run it with a third argument
+    for (int mode = 0; mode < (argc > 3 ? 2 : 1); mode++) {
         for (int N : {1, 2, 4, 8}) {
             const int team = mode == 0 ? 3 : 1;
             std::atomic<size_t> bytes{0};
