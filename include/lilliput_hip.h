@@ -360,7 +360,11 @@ int lilliput_hip_host_is_pinned(const void* p, size_t bytes); /* 1: the DMA engi
 int lilliput_hip_set_ingest_mode(const char* mode);         /* "auto" | "register" | "staged" for the transforms that start after the call (process-wide, like
                                                              * LILLIPUT_HIP_INGEST); returns the previous mode: 0 register, 1 staged, 2 auto */
 /* Resident form (kernel-pipeline measurements, tests): upload parses the headers and moves the compressed bytes into HBM,
- * run executes every device stage (inputs resident), download copies the encoded results back. */
+ * run executes every device stage (inputs resident), download copies the encoded results back.
+ * One difference to lilliput_hip_batch_transform and the one-image ABI: a baseline stream that ends short of its blocks (a truncated
+ * file) answers LILLIPUT_ERR_DECODING_FAILED here, because the second pass that decodes it the way libjpeg does (zero bits from the
+ * end of data on, lp_prog_core.h) re-reads the SOURCE bytes, which the resident form no longer has after upload; transform keeps the
+ * caller's buffers for the duration of the call and retries such items itself. */
 int lilliput_hip_batch_upload(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n);
 int lilliput_hip_batch_upload2(lilliput_hip_batch b, const lilliput_batch_item* items, size_t n, int engines); /* engines: how many engines (streams) share the batch, 0 = default (LILLIPUT_HIP_STREAMS, 4) */
 int lilliput_hip_batch_run(lilliput_hip_batch b, const lilliput_batch_options* opt);
