@@ -51,8 +51,8 @@
      38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, \
      63, 63}
 
-// Ring geometry of the bit reader. A lane keeps the three stream words at its position in registers (w0, w1 = the 64 bits a
-// peek shifts, w2 = the word after them, requested from the ring one step before it can be needed), so the ring read is off
+// Ring geometry of the bit reader. A lane keeps the three stream words around its position in registers (w0, w1 = the 64 bits a
+// peek funnel-shifts, w2 = the word after them, requested from the ring one step before it can be needed), so the ring read is off
 // the symbol-to-symbol dependency chain. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so kEvery = 8
 // steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte granularity) and a step
 // may ask for word (p >> 5) + 2: 8 + 3 + 3 <= kRing = 16.
@@ -65,83 +65,162 @@ struct LpImgCtx {
     uint32_t n_rst;         // restart boundaries found by the unstuff kernels
     uint32_t total_bits;    // length of the clean stream
     uint32_t total_blocks;
+    uint32_t tb, nx;        // derived from blkpack / bpm by lp_ctx_tables(): 5-bit field i (at bit 5 i) belongs to block i of the MCU.
+                            // tb: bits 0..1 = the block's DC table slot (0 / 1), bits 2..3 = its AC table slot (2 / 3);
+                            // nx: 5 x the index of the block that follows it (0 after the last block of the MCU)
 };
+LP_HD void lp_ctx_tables(LpImgCtx& ic)
+{
+    ic.tb = ic.nx = 0;
+    for (uint32_t i = 0; i < ic.bpm && i < LP_MAX_BPM; i++) {
+        const uint32_t nib = (ic.blkpack >> (4u * i)) & 15u; // bit 2 = DC table id, bit 3 = AC table id
+        ic.tb |= (((nib >> 2) & 1u) | ((2u + ((nib >> 3) & 1u)) << 2)) << (5u * i);
+        ic.nx |= (5u * (i + 1u == ic.bpm ? 0u : i + 1u)) << (5u * i);
+    }
+}
+
+// funnel shift: the low 32 bits of (hi:lo) >> (sh & 31) -- one v_alignbit_b32
+LP_HD uint32_t lp_funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u));
+#endif
+}
+// min(v, 1) as ONE instruction (the compiler turns the C form into a compare and a select, two instructions and a wait state)
+LP_HD uint32_t lp_min1(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    return v < 1u ? v : 1u;
+#endif
+}
+// ... with a per-lane width (0..15 here; width 0 yields 0)
+LP_HD uint32_t lp_bfe_w(uint32_t v, uint32_t off, uint32_t width)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return width ? (v >> (off & 31u)) & ((1u << width) - 1u) : 0u;
+#endif
+}
+// bit field: (v >> (off & 31)) & ((1 << width) - 1) -- one v_bfe_u32; the hardware ignores the offset's upper bits like the host form does
+LP_HD uint32_t lp_bfe(uint32_t v, uint32_t off, uint32_t width)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return (v >> (off & 31u)) & ((1u << width) - 1u);
+#endif
+}
 
 // Memory policy M must provide (per lane object, non-const):
 //   uint32_t fetch1(uint32_t w)             word w of the clean stream (big-endian corrected: bit 31 first); w within the ring window
+//   uint32_t fetch_np(uint32_t np)          fetch1(3 - (int32_t)np >> 5) = the word after the window of a lane whose negated, biased position is
+//                                           np (LpLane::np), for the hot path: the device ring is laid out so that this is a bit field of np
 //   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
 //   void topup(uint32_t p)                  wave-uniform call every kEvery steps with the lane's bit position: words below p >> 5 are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
-//   bool any_lt8(int32_t v)                 wave vote on v < 8 (see lp_near_boundary)
+//   bool any2(bool a, bool b)               any(a || b), as two votes or-ed in scalar registers (a vote on a compare costs nothing; a vote on
+//                                           a combination of compares is materialised in a VGPR first: two more vector instructions)
 //   uint32_t lut(uint32_t tbl, uint32_t i), lut2(uint32_t i)   first-level entry of table tbl, entry i of the second-level pool
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
 //   void settle(uint32_t& v)                v came from rst_bit() inside a rare branch: finish the load there (device), no-op on the host
 //
-// The lane keeps no refillable bit buffer: a peek is one 64-bit shift of (w0, w1) by p & 31. What bounds these kernels on
-// MI355X is the latency of the serial chain symbol -> length -> position -> next symbol (PMC: the waves sit in s_waitcnt for
-// half of their cycles with the VALU a third busy), so the chain holds exactly one LDS round trip -- the code-table lookup.
+// What bounds these kernels on MI355X is VALU issue (a wave64 instruction occupies its SIMD for four cycles; PMC and the ISA
+// listing agree: SPEC ran 45 vector instructions per symbol in round 2), so the lane state is laid out for the fewest
+// instructions per step, not for readability:
+//   * the position is kept NEGATED (np = -p): a peek is then ONE funnel shift of (w0, w1) by np -- with the convention that w0 is
+//     the word holding bit p - 1 (the window slides when the position LEAVES a word, not when it enters one), the shift amount
+//     32 - (p mod 32) taken mod 32 is right for every p, including p on a word boundary (shift 0 returns w1);
+//   * "is anything special about this step" (end of the subsequence, a restart boundary or the stream end fewer than 8 bits ahead)
+//     is ONE signed compare of np with a per-lane limit; the wave branches to the slow path on the vote;
+//   * block-in-MCU and the count of completed blocks share a register (bc): 5 x block in the low five bits -- the offset of the
+//     block's field in ic.tb / ic.nx, which v_bfe_u32 reads without masking -- and the count above, incremented by the same add
+//     that installs the next block;
+//   * the table entry carries run + 64 x (ends the block), so z + runx + 1 > 63 is the block-done test for coefficient overrun,
+//     ZRL and EOB alike.
 template <class M>
 struct LpLane {
     M& m;
     const LpImgCtx& ic;
-    uint32_t p;         // bit position of the next unread bit
+    uint32_t np;        // LP_NP0 MINUS the bit position of the next unread bit (two's complement; LP_NP0 = 64, see pos())
     uint32_t z;         // zigzag index of the next coefficient (0 = a block starts here)
-    uint32_t b4;        // 4 x block-in-MCU: the shift that brings the current block's nibble of ic.blkpack down (one add + compare per block
-                        // end; the first version also kept the rotated nibble string: four more VALU instructions in every step)
+    uint32_t bc;        // bits 0..4: 5 x block-in-MCU; bits 5..31: blocks completed since start(), starting at -1 when start() was inside
+                        // a block -- so the field is also "blocks STARTED since start()" minus (z != 0), and it is negative exactly while
+                        // the lane has not seen a block start yet
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
-    uint32_t w0, w1, w2; // stream words (p >> 5), + 1, + 2
+    uint32_t w0, w1, w2; // stream words ceil(p / 32) - 1, + 1, + 2
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), p(0), z(0), b4(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), np(0), z(0), bc(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
 
-    LP_HD uint32_t peek() const { return (uint32_t)(((((uint64_t)w0) << 32) | w1) << (p & 31u) >> 32); }
-    LP_HD void load_window() // after a jump (m.reseek has been called)
+    // The bias of two words changes nothing for the funnel shift or the slide test (both look at np mod 32 / bit 5 flips) and makes
+    // "the ring slot of the word after the window" a bit field of np itself (M::fetch_np): the policy stores word w at slot
+    // (3 - w) mod kRing, and ((np >> 5) mod kRing) is that slot for w = ceil(p / 32) + 1.
+    static constexpr uint32_t LP_NP0 = 64u;
+    LP_HD uint32_t pos() const { return LP_NP0 - np; }
+    LP_HD uint32_t peek() const { return lp_funnel(w0, w1, np); }
+    LP_HD void load_window() // after a jump
     {
-        const uint32_t w = p >> 5;
-        w0 = m.fetch1(w);
-        w1 = m.fetch1(w + 1u);
-        w2 = m.fetch1(w + 2u);
+        const uint32_t wi = (pos() + 31u) >> 5; // index of w1
+        m.reseek(wi ? wi - 1u : 0u);
+        w0 = wi ? m.fetch1(wi - 1u) : 0u;       // p == 0: no such word, and the peek does not look at it
+        w1 = m.fetch1(wi);
+        w2 = m.fetch1(wi + 1u);
     }
-    // the position moves on by n <= 31 bits: slide the register window when it enters the next word, and ask for the word after
+    // the position moves on by n <= 31 bits: slide the register window when it leaves a word, and ask for the word after
     // the window again (the same word as before when nothing slid; its value is first used one step later)
     LP_HD void advance(uint32_t n)
     {
-        const uint32_t pn = p + n;
-        const bool slid = ((p ^ pn) & 32u) != 0;
+        const uint32_t nn = np - n;
+        const bool slid = ((np ^ nn) & 32u) != 0; // (p - 1) >> 5 changed: p - 1 == ~np
         w0 = slid ? w1 : w0;
         w1 = slid ? w2 : w1;
-        w2 = m.fetch1((pn >> 5) + 2u);
-        p = pn;
+        w2 = m.fetch_np(nn);                      // word ceil(p' / 32) + 1 = (p' + 63) >> 5 = 3 - (nn >> 5) (arithmetic shift)
+        np = nn;
     }
-    LP_HD void set_block(uint32_t nb) { b4 = 4u * nb; }
-    LP_HD void start(uint32_t pos, uint32_t bz)
+    LP_HD void start(uint32_t pos_, uint32_t bz)
     {
-        p = pos;
-        m.reseek(pos >> 5);
+        np = LP_NP0 - pos_;
         load_window();
-        set_block(bz >> 8);
         z = bz & 255u;
+        bc = ((bz >> 8) & 31u) | (z ? 0xffffffe0u : 0u);
         rst_k = 0;
         next_rst = ic.total_bits;
         if (ic.n_rst) { // first restart boundary at or after pos (binary search)
             uint32_t lo = 0, hi = ic.n_rst;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (m.rst_bit(mid) < pos) lo = mid + 1; else hi = mid;
+                if (m.rst_bit(mid) < pos_) lo = mid + 1; else hi = mid;
             }
             rst_k = lo;
             next_rst = lo < ic.n_rst ? m.rst_bit(lo) : ic.total_bits;
             m.settle(next_rst);
         }
     }
-    LP_HD uint32_t state_bz() const { return (b4 << 6) | z; } // (block-in-MCU << 8) | zigzag index
+    LP_HD uint32_t state_bz() const { return ((bc & 31u) << 8) | z; } // opaque to everything but start(): (5 x block-in-MCU << 8) | zigzag index
+    LP_HD uint32_t started() const { return (bc >> 5) + (z ? 1u : 0u); } // blocks whose first symbol this lane has decoded since start() (mod 2^27)
+    LP_HD bool seen_block_start() const { return (int32_t)bc >= 0; }
+
+    // The limit the hot loops compare np with: the lane needs the slow path when p >= min(end, next_rst - 7), i.e. np <= -that.
+    LP_HD int32_t limit(uint32_t end) const
+    {
+        const uint32_t r = next_rst - 7u; // next_rst >= 8 in any stream with a block in it; a wrapped value only sends the lane through the slow path
+        const uint32_t lim = (int32_t)r < (int32_t)end ? r : end;
+        return (int32_t)(LP_NP0 - lim);
+    }
 
     // At a block start: detect the end of a restart interval (or of the stream). `pk` = peek(). Returns true when
     // the lane jumped to the boundary (DC predictors must be reset by the caller, and peek() must be redone).
     LP_HD bool restart_check(uint32_t pk)
     {
-        int32_t rem = (int32_t)(next_rst - p);
+        int32_t rem = (int32_t)(next_rst - pos());
         // A boundary BEHIND the lane: only a lane decoding from a wrong state can run over one in the middle of a block. It is
         // left behind (the lane keeps going and synchronises at a later boundary or by itself): jumping back would make the
         // lane visit the same positions twice, and a checkpoint of the first visit would splice the second visit's counts in
@@ -153,7 +232,7 @@ struct LpLane {
             } else
                 next_rst = 0x7fffffffu;
             m.settle(next_rst);
-            rem = (int32_t)(next_rst - p);
+            rem = (int32_t)(next_rst - pos());
         }
         if (rem >= 8) return false;
         bool jump = rem == 0;
@@ -167,22 +246,21 @@ struct LpLane {
             next_rst = 0x7fffffffu; // past the end of the stream: nothing left
         }
         m.settle(next_rst);
-        p = target;
-        m.reseek(target >> 5);
+        np = LP_NP0 - target;
         load_window();
-        set_block(0);
+        bc &= ~31u;
         z = 0;
         return true;
     }
 
-    // Second level of the code lookup: e1 is the first-level entry of a prefix that belongs to codes longer than LP_LUT_BITS; its
-    // low byte names a slice of the second-level pool, indexed by the LP_LUT2_BITS bits that follow the prefix (see LpHuffSet).
+    // Second level of the code lookup: e1 is the first-level entry of a prefix that belongs to codes longer than LP_LUT_BITS; it
+    // names a slice of the second-level pool, indexed by the LP_LUT2_BITS bits that follow the prefix (see LpHuffSet).
     // One dependent LDS read: a long code is rare per lane but shows up in most steps of a 64-lane wave.
     LP_HD uint32_t long_code(uint32_t tbl, uint32_t e1, uint32_t top)
     {
-        const uint32_t sub = e1 & 0xffu;
+        const uint32_t sub = LP_E_SLICE(e1);
         uint32_t e = sub != 0xffu ? m.lut2((sub << LP_LUT2_BITS) | (top & ((1u << LP_LUT2_BITS) - 1u))) : 0u;
-        if ((e & 0x1f00u) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
+        if (LP_E_BITS(e) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
             uint32_t len = 17, sym = 0; // no code matches: jpeg_huff_decode reads on to the sentinel length 17, warns and fakes a zero
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
                 const int32_t code = (int32_t)(top >> (16 - l));
@@ -192,7 +270,7 @@ struct LpLane {
                     break;
                 }
             }
-            e = (len << 8) | sym | ((tbl >= 2 && (sym & 15u) == 0 && (sym >> 4) != 15) ? 0x8000u : 0u);
+            e = lp_lut_entry((int)tbl, (int)len, sym);
         }
         return e;
     }
@@ -200,54 +278,42 @@ struct LpLane {
     // Decode one Huffman symbol (+ its extra bits) from pk = peek(). On return:
     //   is_dc, k = zigzag index of the coefficient (valid when has_val), val, block_done.
     // Written branch-free apart from the long-code lookup: every lane of the wave runs the same instructions.
-    // NEED_VAL = false (the counting passes) skips the value reconstruction.
+    // NEED_VAL = false (the counting passes) skips the value reconstruction; what a pass does not read of Sym is never computed.
     struct Sym { bool is_dc; bool has_val; bool block_done; uint32_t k; int32_t val; };
     template <bool NEED_VAL>
     LP_HD Sym step(uint32_t pk)
     {
         Sym r;
-        r.is_dc = (z == 0);
-        // DC table id = bit 2 of the block's nibble, AC table id = bit 3 (+2); written as arithmetic so that it compiles to
-        // selects, not to an exec-mask branch pair
-        const uint32_t tbl = ((ic.blkpack >> (b4 + (r.is_dc ? 2u : 3u))) & 1u) + (r.is_dc ? 0u : 2u);
+        // DC table at a block start, the block's AC table inside: two bits of the block's field in ic.tb
+        const uint32_t tbl = lp_bfe(ic.tb, bc + 2u * lp_min1(z), 2);
         uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
-        if ((e & 0x1f00u) == 0) e = long_code(tbl, e, pk >> 16);
-        const uint32_t len = (e >> 8) & 31u;
-        const uint32_t s = e & 15u;
-        const uint32_t run = (e >> 4) & 15u;      // DC symbols are categories 0..15 (validated by the parser): run == 0
+        if (LP_E_BITS(e) == 0) e = long_code(tbl, e, pk >> 16);
+        const uint32_t n = LP_E_BITS(e);          // code + extra bits
+        const uint32_t s = LP_E_SIZE(e);
+        const uint32_t runx = LP_E_RUNX(e);       // run, + 64 when the symbol ends the block. DC symbols are categories 0..15 (validated by the parser): run == 0
         r.val = 0;
         if (NEED_VAL) {
-            const uint32_t t = pk << len;             // the extra bits, left aligned
-            const uint32_t x = (t >> 1) >> (31u - s); // their value (0 when s == 0)
-            // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1)
-            const uint32_t neg = ~(uint32_t)((int32_t)t >> 31);
-            r.val = (int32_t)(x - (neg & ((1u << s) - 1u)));
+            const uint32_t x = lp_bfe_w(pk, 32u - n, s);  // the s extra bits that follow the code (0 when s == 0)
+            // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1). nm = 1 - 2^s; the first bit is set iff 2x + nm > 0
+            const uint32_t nm = (0xffffffffu << s) + 1u;
+            r.val = (int32_t)(x + ((int32_t)(2u * x + nm) > 0 ? 0u : nm));
         }
-        advance(len + s);
-        // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL); a coefficient whose index overruns 63 on
-        // a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table carries the same guard entries)
-        const bool eob = (e & 0x8000u) != 0; // precomputed per table entry: an AC symbol of size 0 other than ZRL
-        r.k = z + run;                            // DC: z == run == 0; at most 63 + 15
+        advance(n);
+        // jdhuff.c decode_mcu: size 0 ends the block unless the run is 15 (ZRL, which skips 16 coefficients: k + 1 == z + 16); a
+        // coefficient whose index overruns 63 on a corrupt stream still lands on jpeg_natural_order[64..79] = 63 (the zigzag table
+        // carries the same guard entries)
+        r.is_dc = z == 0;
+        r.k = z + runx;                           // DC: z == run == 0; at most 63 + 15 when has_val
         r.has_val = r.is_dc || s != 0;
-        const uint32_t zn = eob ? 64u : r.k + 1u; // ZRL (run 15, size 0) skips 16 coefficients: k + 1 == z + 16
-        r.block_done = zn >= 64;
+        const uint32_t zn = r.k + 1u;
+        r.block_done = zn > 63u;
         z = r.block_done ? 0u : zn;
-        // next block of the MCU; branch-free
-        const uint32_t nb4 = b4 + 4u == 4u * ic.bpm ? 0u : b4 + 4u;
-        b4 = r.block_done ? nb4 : b4;
+        // next block of the MCU, one more block completed; branch-free
+        const uint32_t bn = ((bc | 31u) + 1u) | lp_bfe(ic.nx, bc, 5);
+        bc = r.block_done ? bn : bc;
         return r;
     }
 };
-
-// "Is a restart boundary (or the stream end) fewer than 8 bits ahead of a lane that stands at a block start and is still working?" as ONE
-// signed value to compare with 8: the bits to the boundary, raised to at least 8 * z (so a lane inside a block never qualifies) or to 8
-// when the lane is not working. The wave vote on `value < 8` is then a single v_cmp feeding the scalar branch; voting on the three
-// conditions as a boolean cost eleven instructions per decode step (the compiler materialises the boolean in a VGPR and compares it again).
-LP_HD int32_t lp_near_boundary(uint32_t next_rst, uint32_t p, uint32_t z, bool off)
-{
-    const int32_t rem = (int32_t)(next_rst - p), floor = off ? 8 : (int32_t)(z << 3);
-    return rem > floor ? rem : floor;
-}
 
 LP_HD bool lp_state_eq(const LpSubState& a, const LpSubState& b) { return a.p == b.p && a.bz == b.bz; }
 
@@ -315,6 +381,16 @@ inline LpCkSched lp_make_sched(uint32_t S, uint32_t cbits)
     return cs;
 }
 
+// The lane's sums so far: blocks STARTED (first symbol decoded) and restart boundaries crossed since start().
+template <class M>
+LP_HD LpSubSum lp_lane_sum(const LpLane<M>& L, uint32_t nreset)
+{
+    LpSubSum s;
+    s.nblk = L.started() & 0x07ffffffu;
+    s.nreset = nreset;
+    return s;
+}
+
 // SPEC pass for one subsequence: decode [entry.p, sub_end) from the guessed state.
 // Ck must provide   void record(uint32_t k, const LpCkptPk&)   -- called by ALL lanes of the wave at the same iteration.
 template <class M, class Ck>
@@ -323,45 +399,47 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
 {
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
-    LpSubSum sum;
-    lp_sum_zero(sum);
+    uint32_t nreset = 0;
     const uint32_t K = cs.K, ck_base = cs.base;
     uint32_t k = 0, iter = 0, next_ck = K ? lp_ck_next(ck_base, 0, 0) : 0xffffffffu;
     bool done = false;
-    // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off.
-    // Single back edge, no `continue`: the register allocator then updates the lane state in place (the first version of
-    // this loop carried ~30 v_mov copies per iteration across its exits).
+    int32_t nlim = L.limit(sub_end);
+    // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off (their limit can no
+    // longer be reached). Single back edge, no `continue`: the register allocator then updates the lane state in place (the first
+    // version of this loop carried ~30 v_mov copies per iteration across its exits).
+    bool live = true;
     do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
         uint32_t pk = L.peek();
-        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, done))) { // rare even per wave: a restart boundary or the stream end is near
+        const bool near = m.any((int32_t)L.np <= nlim); // rare even per wave: the subsequence ends here, or a restart boundary / the stream end is near
+        if (near) {
             LP_KEEP_UNIFORM_BRANCH();
-            if (!done && L.z == 0 && L.restart_check(pk)) { // also catches the padded end of the stream
-                sum.nreset++;
-            }
+            if (!done && L.z == 0 && L.restart_check(pk)) nreset++; // also catches the padded end of the stream
             pk = L.peek();
         }
         if (iter == next_ck) { // wave-uniform: iter, k and next_ck are the same in every lane
             LpSubState st;
-            st.p = L.p;
+            st.p = L.pos();
             st.bz = L.state_bz();
-            ck.record(k, lp_ckpt_pack(st, sum));
+            ck.record(k, lp_ckpt_pack(st, lp_lane_sum(L, nreset)));
             k++;
             next_ck = k < K ? lp_ck_next(ck_base, k, next_ck) : 0xffffffffu;
         }
         iter++;
-        done = done || L.p >= sub_end;
-        if (!done) {
-            sum.nblk += L.z == 0 ? 1u : 0u;
-            (void)L.template step<false>(pk);
+        if (near) {
+            LP_KEEP_UNIFORM_BRANCH();
+            done = done || L.pos() >= sub_end;
+            nlim = done ? (int32_t)0x80000000 : L.limit(sub_end);
+            live = m.any(!done);
         }
-    } while (m.any(!done));
+        if (!done) (void)L.template step<false>(pk);
+    } while (live);
     LpCkptPk none;
     none.p = 0xffffffffu; none.bz = 0; none.nblk = 0; none.nreset = 0;
     for (; k < K; k++) ck.record(k, none);
-    exit_st->p = L.p;
+    exit_st->p = L.pos();
     exit_st->bz = L.state_bz();
-    *total = sum;
+    *total = lp_lane_sum(L, nreset);
 }
 
 // VERIFY pass for one subsequence: decode from `entry` (= current exit state of the previous subsequence) until the state
@@ -370,65 +448,79 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
 // Ck must provide   uint32_t pos(uint32_t k)   (cheap: position of checkpoint k, 0xffffffff if not recorded)
 //                   LpCkptPk load(uint32_t k)  (the whole record; called once or twice per lane)
 // Outputs the new exit state and total of the subsequence.
+template <class Ck>
+LP_HD int32_t lp_ck_npos(Ck& ck, uint32_t kk, uint32_t K) // checkpoint kk's position, negated like the lane's; "none" can never be reached
+{
+    const uint32_t cp = kk < K ? ck.pos(kk) : 0xffffffffu;
+    return cp == 0xffffffffu ? (int32_t)0x80000000 : (int32_t)(64u - cp); // LpLane::LP_NP0
+}
 template <class M, class Ck>
 LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, uint32_t K, Ck& ck, const LpSubState& spec_exit,
                           const LpSubSum& spec_total, LpSubState* exit_st, LpSubSum* total)
 {
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
-    LpSubSum sum;
-    lp_sum_zero(sum);
+    uint32_t nreset = 0;
     uint32_t kk = 0, iter = 0;
-    uint32_t cp = K ? ck.pos(0) : 0xffffffffu;
+    int32_t ncp = lp_ck_npos(ck, 0, K);
     bool done = false, spliced = false;
+    int32_t nlim = L.limit(sub_end);
+    bool live = true;
     do { // same shape as the SPEC loop: one back edge, state updated in place
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
         uint32_t pk = L.peek();
         iter++;
-        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, done))) {
+        const bool near = m.any((int32_t)L.np <= nlim);
+        if (near) {
             LP_KEEP_UNIFORM_BRANCH();
-            if (!done && L.z == 0 && L.restart_check(pk)) {
-                sum.nreset++;
-            }
+            if (!done && L.z == 0 && L.restart_check(pk)) nreset++;
             pk = L.peek();
         }
-        if (!done) {
-            while (cp < L.p) { // checkpoints are strictly ordered until the lane that recorded them finished
-                kk++;
-                cp = kk < K ? ck.pos(kk) : 0xffffffffu;
-            }
-            if (cp == L.p && kk < K) {
-                LpSubState cst;
-                LpSubSum csum;
-                lp_ckpt_unpack(ck.load(kk), cst, csum);
-                if (cst.bz == L.state_bz()) { // synchronised with the recorded trajectory at checkpoint kk
-                    *total = lp_sum_combine(sum, lp_sum_tail(spec_total, csum));
-                    *exit_st = spec_exit;
-                    done = true;
-                    spliced = true;
-                } else {
-                    kk++; // same position, different state: this checkpoint can never match
-                    cp = kk < K ? ck.pos(kk) : 0xffffffffu;
+        bool now_done = false;
+        if (m.any(!done && ncp >= (int32_t)L.np)) { // some lane stands at or behind its next checkpoint
+            LP_KEEP_UNIFORM_BRANCH();
+            if (!done) {
+                while (ncp > (int32_t)L.np) { // checkpoints are strictly ordered until the lane that recorded them finished
+                    kk++;
+                    ncp = lp_ck_npos(ck, kk, K);
+                }
+                if (ncp == (int32_t)L.np && kk < K) {
+                    LpSubState cst;
+                    LpSubSum csum;
+                    lp_ckpt_unpack(ck.load(kk), cst, csum);
+                    if (cst.bz == L.state_bz()) { // synchronised with the recorded trajectory at checkpoint kk
+                        *total = lp_sum_combine(lp_lane_sum(L, nreset), lp_sum_tail(spec_total, csum));
+                        *exit_st = spec_exit;
+                        now_done = true;
+                        spliced = true;
+                    } else {
+                        kk++; // same position, different state: this checkpoint can never match
+                        ncp = lp_ck_npos(ck, kk, K);
+                    }
                 }
             }
         }
-        done = done || L.p >= sub_end;
-        if (!done) {
-            sum.nblk += L.z == 0 ? 1u : 0u;
-            (void)L.template step<false>(pk);
+        if (near || m.any(now_done)) {
+            LP_KEEP_UNIFORM_BRANCH();
+            done = done || now_done || L.pos() >= sub_end;
+            nlim = done ? (int32_t)0x80000000 : L.limit(sub_end);
+            live = m.any(!done);
         }
-    } while (m.any(!done));
+        if (!done) (void)L.template step<false>(pk);
+    } while (live);
     if (!spliced) {
-        exit_st->p = L.p;
+        exit_st->p = L.pos();
         exit_st->bz = L.state_bz();
-        *total = sum;
+        *total = lp_lane_sum(L, nreset);
     }
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
 //   void put_dc(int32_t v, bool on);               when `on`: the block's DC DIFFERENCE (made absolute later, see lp_dc_walk)
-//   void put(uint32_t natural_idx, int32_t v);     store one AC coefficient of the block being decoded
-//   void end_block(uint32_t blk, bool on);         when `on`: the block (decode-order index blk) is complete (queued for flushing)
+//   void put(ZZ where, int32_t v);                 store one AC coefficient of the block being decoded; `where` = the caller's zigzag table
+//                                                  entry for it (the natural index, or whatever address form the sink precomputed there)
+//   void end_block(uint32_t bc, bool on);          when `on`: a block is complete (queued for flushing); bc = the lane's LpLane::bc after the
+//                                                  step: the block's decode-order index is (first block of the lane) + (bc >> 5) - 1
 //   bool stalled();                                no free slot: the lane must wait for the next flush
 //   void flush();                                  wave-uniform: write out every queued block
 //   void finish();                                 once, after the last flush
@@ -436,41 +528,61 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 #ifndef LP_FLUSH_EVERY
 #define LP_FLUSH_EVERY 4   // 2 / 3 / 4 / 6 measured (8-word ring, top-up every 2 steps): 4 is the best trade of flush instructions against lanes waiting for the flush
 #endif
-template <class M, class Sink>
-LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_t end_p, const LpSubSum& prefix, const uint8_t* zigzag,
+template <class M, class Sink, class ZZ>
+LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_t end_p, const LpSubSum& prefix, const ZZ* zigzag,
                              Sink& sink)
 {
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
-    uint32_t blk = prefix.nblk;
-    bool writing = false, done = false;
+    // A lane that enters mid-block skips to the first block start: L.bc counts that partial block from -1, so the block that
+    // completes when the count field reads c (after the step) is block prefix.nblk + c - 1 of the image, and the lane is "writing"
+    // exactly while the field is not negative before the step.
+    const uint32_t left = ic.total_blocks > prefix.nblk ? ic.total_blocks - prefix.nblk : 0u; // blocks this lane may still write
+    int32_t left_bc = (int32_t)(left << 5); // ... as a bound on L.bc; lowered to "the block at hand" once the lane is past its end (below)
+    const uint32_t stream_end = end_p < ic.total_bits ? end_p : ic.total_bits;
+    bool done = false;
     uint32_t written = 0, iter = 0;
+    int32_t nlim = L.limit(stream_end);
+    bool live = true;
     do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.p); }
+        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
         if ((iter % LP_FLUSH_EVERY) == LP_FLUSH_EVERY - 1) sink.flush();
         uint32_t pk = L.peek();
         iter++;
         const bool act = !done && !sink.stalled();
-        if (m.any_lt8(lp_near_boundary(L.next_rst, L.p, L.z, !act))) {
+        bool go = act;
+        // slow path: the lane is at / past the end of its subsequence or of the stream, near a restart boundary, or out of blocks
+        // (a stalled lane may cast a vote too: it costs a pass through here and changes nothing)
+        if (m.any2((int32_t)L.np <= nlim, (int32_t)L.bc >= left_bc)) {
             LP_KEEP_UNIFORM_BRANCH();
-            if (act && L.z == 0) (void)L.restart_check(pk); // DC predictors restart in k_dc_scan, by MCU index
-            pk = L.peek();
+            if (act) {
+                if (L.z == 0) (void)L.restart_check(pk); // DC predictors restart in k_dc_scan, by MCU index
+                pk = L.peek();
+                // a lane stops at the first block start at or after the end of its subsequence (or when the stream is truncated)
+                const uint32_t p = L.pos();
+                const bool stop = L.z == 0 ? (p >= end_p || (int32_t)L.bc >= left_bc) : p >= ic.total_bits;
+                done = stop;
+                go = !stop;
+                // past the end of the subsequence inside a block: the lane finishes the block. Instead of coming through here at every
+                // step until then, it is called back by the block count (and by the end of the stream)
+                const bool finishing = !stop && L.z != 0 && p >= end_p;
+                if (finishing) left_bc = (int32_t)((L.bc | 31u) + 1u);
+                nlim = stop ? (int32_t)0x80000000 : L.limit(finishing ? ic.total_bits : stream_end);
+                if (stop) left_bc = 0x7fffffff;
+            }
+            live = m.any(!done);
         }
-        // a lane stops at the first block start at or after the end of its subsequence (or when the stream is truncated)
-        const bool stop = L.z == 0 ? (L.p >= end_p || blk >= ic.total_blocks) : L.p >= ic.total_bits;
-        done = done || (act && stop);
-        if (act && !stop) {
-            writing = writing || L.z == 0; // a lane that enters mid-block skips to the first block start
+        if (go) {
+            const bool writing = L.seen_block_start();
             const typename LpLane<M>::Sym s = L.template step<true>(pk);
             // few, flat predicated regions: every exec-mask branch costs scalar instructions in a loop that is issue bound
             sink.put_dc(s.val, writing && s.is_dc);
-            if (writing && !s.is_dc && s.has_val) sink.put((uint32_t)zigzag[s.k], s.val);
+            if (writing && !s.is_dc && s.has_val) sink.put(zigzag[s.k], s.val);
             const bool bd = writing && s.block_done;
-            sink.end_block(blk, bd);
+            sink.end_block(L.bc, bd);
             written += bd ? 1u : 0u;
-            blk += bd ? 1u : 0u;
         }
-    } while (m.any(!done));
+    } while (live);
     sink.flush();
     sink.finish();
     return written;

@@ -41,17 +41,10 @@ static int exif_orientation(const uint8_t* p, size_t n)
     return 0;
 }
 
-// LUT entry for a code of length l decoding to symbol v (see LpHuffSet)
-static inline uint16_t lut_entry(int slot, int l, unsigned v)
-{
-    const bool ends_block = slot >= 2 && (v & 15u) == 0 && (v >> 4) != 15; // AC symbol of size 0 that is not ZRL: EOB (jdhuff.c decode_mcu)
-    return (uint16_t)((ends_block ? 0x8000u : 0u) | ((unsigned)l << 8) | v);
-}
-
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals)
 {
     // every prefix starts out as "no code here" (canonical search answers libjpeg's length-17 rule for it)
-    for (int i = 0; i < LP_LUT_SIZE; i++) hs->lut[slot][i] = 0x00ffu;
+    for (int i = 0; i < LP_LUT_SIZE; i++) hs->lut[slot][i] = LP_E_NO_SLICE;
     if (slot == 0) hs->lut2_used = 0; // slots are built in order 0..3 and share the second-level pool
     // canonical code assignment (T.81 Annex C). Short codes fill their span of the first level; a long code gets its prefix's
     // slice of the second level (allocated on first use) and fills its span of the LP_LUT2_BITS bits after the prefix.
@@ -61,21 +54,21 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
         for (int i = 0; i < bits[l]; i++, k++, code++) {
             if (l <= LP_LUT_BITS) {
                 int first = code << (LP_LUT_BITS - l), n = 1 << (LP_LUT_BITS - l);
-                for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = lut_entry(slot, l, vals[k]);
+                for (int j = 0; j < n && first + j < LP_LUT_SIZE; j++) hs->lut[slot][first + j] = lp_lut_entry(slot, l, vals[k]);
             } else {
                 const uint32_t left = (uint32_t)code << (16 - l);           // the code, left aligned in 16 bits
                 if (left >= 0x10000u) continue;                              // over-subscribed table (rejected elsewhere); never index out of range
                 const uint32_t prefix = left >> (16 - LP_LUT_BITS);
                 uint16_t& e1 = hs->lut[slot][prefix];
-                if ((e1 & 0x1f00u) != 0) continue;                           // a shorter code owns the prefix: not a prefix code, leave it to libjpeg's order
-                if ((e1 & 0xffu) == 0xffu) {
+                if (LP_E_BITS(e1) != 0) continue;                               // a shorter code owns the prefix: not a prefix code, leave it to libjpeg's order
+                if (LP_E_SLICE(e1) == 0xffu) {
                     if (hs->lut2_used >= LP_LUT2_SUBS) continue;             // pool exhausted: canonical search serves this prefix
-                    e1 = (uint16_t)hs->lut2_used;
+                    e1 = (uint16_t)(hs->lut2_used << 5);
                     memset(hs->lut2 + ((size_t)hs->lut2_used << LP_LUT2_BITS), 0, sizeof(uint16_t) << LP_LUT2_BITS);
                     hs->lut2_used++;
                 }
-                const uint32_t sub = e1 & 0xffu, first = left & ((1u << LP_LUT2_BITS) - 1u), n = 1u << (16 - l);
-                for (uint32_t j = 0; j < n && first + j < (1u << LP_LUT2_BITS); j++) hs->lut2[(sub << LP_LUT2_BITS) | (first + j)] = lut_entry(slot, l, vals[k]);
+                const uint32_t sub = LP_E_SLICE(e1), first = left & ((1u << LP_LUT2_BITS) - 1u), n = 1u << (16 - l);
+                for (uint32_t j = 0; j < n && first + j < (1u << LP_LUT2_BITS); j++) hs->lut2[(sub << LP_LUT2_BITS) | (first + j)] = lp_lut_entry(slot, l, vals[k]);
             }
         }
         hs->maxcode[slot][l] = bits[l] ? code - 1 : -1;

@@ -211,7 +211,8 @@ struct DevMem {
     static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R;
     __amdgpu_buffer_rsrc_t words; // this image's clean stream as a raw buffer: a 32-bit byte offset per lane instead of 64-bit address
                                   // arithmetic in the loop, and reads past the image's region return 0
-    uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[(w % R) * 64]
+    uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[((3 - w) % R) * 64] -- descending, so that
+                            // the slot a decode step asks for is a bit field of the lane's negated position (LpLane::np, fetch_np)
     uint32_t fbits;         // next stream word to load, as a BIT position (a multiple of 128): the top-up test compares it with the
                             // lane's bit position directly
     const LpHuffSet* hs;    // LDS: the lookup part (lut, lut2) only
@@ -226,7 +227,14 @@ struct DevMem {
         m.ring = ring_; m.fbits = 0; m.hs = hs_; m.hsg = hsg_; m.rst = rst_;
         return m;
     }
-    __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[(w & (R - 1u)) << 6]; }
+    __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[((3u - w) & (R - 1u)) << 6]; }
+    __device__ __forceinline__ uint32_t fetch_np(uint32_t np) const
+    {
+        uint32_t slot; // v_bfe + v_lshl_add; written in C the compiler re-associates it into shift, mask and add
+        if (R == 8) asm("v_bfe_u32 %0, %1, 5, 3" : "=v"(slot) : "v"(np));
+        else asm("v_bfe_u32 %0, %1, 5, 4" : "=v"(slot) : "v"(np));
+        return ring[slot << 6];
+    }
     // The next Q quads of the stream travel in registers: a top-up stores what the previous top-up loaded and issues the loads for the
     // one after, so no wave ever sits in s_waitcnt vmcnt(0) behind an HBM round trip (the first version loaded and stored in the same
     // top-up: PMC showed SPEC at 40 % and WRITE at 20 % of the VALU issue rate).
@@ -238,11 +246,11 @@ struct DevMem {
     }
     __device__ __forceinline__ void store_quad(const uint4& v)
     {
-        uint32_t* r = ring + (((fbits >> 5) & (R - 1u)) << 6); // the quad never wraps: fbits / 32 is a multiple of 4
-        r[0] = v.x;
-        r[64] = v.y;
-        r[128] = v.z;
-        r[192] = v.w;
+        uint32_t* r = ring + (((0u - (fbits >> 5)) & (R - 1u)) << 6); // words 4k .. 4k + 3 -> slots s + 3 .. s, s = (-4k) mod R: the quad never wraps
+        r[192] = v.x;
+        r[128] = v.y;
+        r[64] = v.z;
+        r[0] = v.w;
         fbits += 128u;
     }
     __device__ __forceinline__ void reseek(uint32_t w)
@@ -276,7 +284,7 @@ struct DevMem {
     // (a ballot compared with zero stays in scalar registers; __any() materialises the vote in a VGPR and compares it again: two VALU
     // instructions per vote, three votes per decode step)
     __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-    __device__ __forceinline__ bool any_lt8(int32_t v) const { return __builtin_amdgcn_ballot_w64(v < 8) != 0ull; }
+    __device__ __forceinline__ bool any2(bool a, bool b) const { return (__builtin_amdgcn_ballot_w64(a) | __builtin_amdgcn_ballot_w64(b)) != 0ull; }
     __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
     __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hsg->maxcode[t][l]; }
@@ -313,6 +321,7 @@ __device__ __forceinline__ LpImgCtx make_ctx(const LpJpeg& img, const LpJpegStat
     ic.n_rst = st.n_rst;
     ic.total_bits = st.clean_bytes * 8;
     ic.total_blocks = img.total_blocks;
+    lp_ctx_tables(ic);
     return ic;
 }
 
@@ -507,7 +516,7 @@ struct DevSink {
     int8_t* wslots;         // LDS: the wave's slots (lane 0's chunk 0)
     uint32_t* qlist;        // LDS: the wave's list of finished blocks, (block << 6) | lane -- 64 entries
     uint32_t lane;
-    uint32_t qblk;          // queued block index (0xffffffff = slot free)
+    uint32_t qbc;           // queued block, as the lane's counter word after the block's last step (LpLane::bc; 0xffffffff = slot free)
     int8_t* coef8;          // this image's coefficient blocks
     int16_t* wide;          // this image's wide slots (64 int16 each)
     uint32_t* wide_id;      // this image's block -> wide slot
@@ -528,12 +537,14 @@ struct DevSink {
     }
     uint32_t blk0, last;    // first block of this lane, last block flushed (0xffffffff = none yet)
     __device__ __forceinline__ void put_dc(int32_t v, bool on) { dcv = on ? v : dcv; }
-    __device__ __forceinline__ void put(uint32_t nat, int32_t v)
+    // where = the coefficient's byte offset inside the lane's slot: ((nat >> 4) << 10) | (nat & 15), precomputed per zigzag index (s_zz)
+    __device__ __forceinline__ void put(uint16_t where, int32_t v)
     {
 #ifdef LP_EXP_NOPUT
-        asm volatile("" :: "v"(nat), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
+        asm volatile("" :: "v"(where), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
 #endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
+            const uint32_t nat = (((uint32_t)where >> 10) << 4) | (where & 15u);
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
             // A settled decode hands out at most one slot per block. A pass over UNSETTLED exit states (the deferred chunk whose verify
             // rounds were not enough: it is decoded again afterwards) lets subsequences overlap, so more slots than blocks can be asked
@@ -542,14 +553,15 @@ struct DevSink {
             if (wslot < wide_cap) wide[(size_t)wslot * 64 + nat] = (int16_t)v;
             v = -128;
         }
-        slot[((nat >> 4) << 10) | (nat & 15u)] = (int8_t)v;
+        slot[where] = (int8_t)v;
     }
-    __device__ __forceinline__ void end_block(uint32_t blk, bool on)
+    // the queue entry is the lane's block counter word as it is (no arithmetic in the decode step); flush() turns it into the block index
+    __device__ __forceinline__ void end_block(uint32_t bc, bool on)
     {
-        qblk = on ? blk : qblk;
-        if (on && wslot != 0xffffffffu) { wide_id[blk] = wslot; wslot = 0xffffffffu; } // rare
+        qbc = on ? bc : qbc;
+        if (on && wslot != 0xffffffffu) { wide_id[blk0 + (bc >> 5) - 1u] = wslot; wslot = 0xffffffffu; } // rare
     }
-    __device__ __forceinline__ bool stalled() const { return qblk != 0xffffffffu; }
+    __device__ __forceinline__ bool stalled() const { return qbc != 0xffffffffu; }
     // Wave-cooperative: the lanes with a finished block put (block, lane) on a per-wave list; then four lanes move one block each --
     // lane 4e + c reads chunk c of the e-th listed lane's slot, stores it (64 contiguous bytes per four lanes) and clears it. The cost
     // follows the number of finished blocks (about a quarter of the lanes per flush) instead of four full-wave 16-byte reads, stores and
@@ -557,13 +569,14 @@ struct DevSink {
     __device__ __forceinline__ void flush()
     {
 #ifdef LP_EXP_NOFLUSH
-        if (qblk != 0xffffffffu) { last = qblk; qblk = 0xffffffffu; } // timing experiment: what does the block flush cost?
+        if (qbc != 0xffffffffu) { last = blk0 + (qbc >> 5) - 1u; qbc = 0xffffffffu; } // timing experiment: what does the block flush cost?
         return;
 #endif
-        const bool q = qblk != 0xffffffffu;
+        const bool q = qbc != 0xffffffffu;
         const uint64_t mask = __ballot(q);
         if (!mask) return; // wave-uniform
         if (q) {
+            const uint32_t qblk = blk0 + (qbc >> 5) - 1u;
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             qlist[pos] = (qblk << 6) | lane;
             const uint32_t k = qblk & 7u;
@@ -575,7 +588,7 @@ struct DevSink {
                 else for (uint32_t j = blk0 - g0; j < 8u; j++) dc16[g0 + j] = (int16_t)dq_get(j);           // the lane started inside the group
             }
             last = qblk;
-            qblk = 0xffffffffu;
+            qbc = 0xffffffffu;
         }
         __builtin_amdgcn_wave_barrier(); // the list is read by other lanes of the same wave: LDS operations of a wave execute in order
         const uint32_t n = (uint32_t)__popcll(mask);
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
-    __shared__ uint8_t s_zz[80];
+    __shared__ uint16_t s_zz[80];
     __shared__ uint32_t s_qlist[HUFF_T];
     const LpJpeg& img = imgs[blockIdx.y];
     LpJpegState& st = states[blockIdx.y];
@@ -624,7 +637,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     {
         const uint8_t zz[80] = LP_ZIGZAG_INIT;
         // blocks are stored transposed (column-major) for k_idct's column pass
-        if (threadIdx.x < 80) s_zz[threadIdx.x] = (uint8_t)(((zz[threadIdx.x] & 7) << 3) | (zz[threadIdx.x] >> 3));
+        if (threadIdx.x < 80) {
+            const uint32_t nat = ((zz[threadIdx.x] & 7u) << 3) | (zz[threadIdx.x] >> 3);
+            s_zz[threadIdx.x] = (uint16_t)(((nat >> 4) << 10) | (nat & 15u)); // where DevSink::put stores it, relative to the lane's slot
+        }
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
         for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.lane = threadIdx.x & 63;
     sink.slot = sink.wslots + sink.lane * 16;
     sink.qlist = s_qlist + (threadIdx.x >> 6) * 64;
-    sink.qblk = 0xffffffffu;
+    sink.qbc = 0xffffffffu;
     sink.coef8 = coef8_arena + img.coef_off;
     sink.wide = wide_arena + img.coef_off;
     sink.wide_id = wide_id_arena + img.coef_off / 64;

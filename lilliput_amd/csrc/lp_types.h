@@ -20,14 +20,30 @@
 #define LP_MAX_CKPT 16          // checkpoints per subsequence
 
 // Huffman decode tables of one image: 2 DC + 2 AC (baseline allows ids 0..1).
-// lut[t][i]  : indexed by the next LP_LUT_BITS bits. A code of length <= LP_LUT_BITS: (ends_block << 15) | (len << 8) | symbol;
-//              ends_block marks the AC symbols that finish a block (size 0, run != 15). The prefix of longer codes: len == 0 and the low
-//              byte = the slice of lut2 that decodes them (0xff: none -- not a prefix of any code, or the pool was exhausted -> canonical
-//              search through maxcode / valoff / vals).
+// lut[t][i]  : indexed by the next LP_LUT_BITS bits. A code of length <= LP_LUT_BITS: lp_lut_entry(t, len, symbol) =
+//              (len + size) | size << 5 | run << 9 | ends_block << 15 (size / run = the symbol's nibbles; the first field is what the
+//              counting passes advance by -- they never need the code length alone; ends_block marks the AC symbols that finish a
+//              block: size 0, run != 15 -- it sits 64 x above the run so that one shift yields "run, + 64 at the end of a block", see
+//              LpLane::step). The prefix of longer codes: first field 0 and bits 5..12 = the slice of lut2 that decodes them (0xff:
+//              none -- not a prefix of any code, or the pool was exhausted -> canonical search through maxcode / valoff / vals).
 // lut2[(slice << LP_LUT2_BITS) | j] : same encoding (len LP_LUT_BITS + 1 .. 16) for the codes that start with the slice's prefix, j = the
 //              LP_LUT2_BITS bits after the prefix; 0 = no such code -> canonical search.
 // Table slot t: 0 = DC0, 1 = DC1, 2 = AC0, 3 = AC1.
 #define LP_HUFF_LDS_BYTES ((4 * LP_LUT_SIZE + LP_LUT2_POOL) * 2)   // the lookup part the kernels stage in LDS; the canonical part stays in HBM
+#define LP_E_BITS(e) ((e) & 31u)            // code length + extra bits: what the symbol consumes; 0 = no short code here
+#define LP_E_SIZE(e) (((e) >> 5) & 15u)
+#define LP_E_RUNX(e) ((e) >> 9)              // run, + 64 when the symbol ends the block (entries are 16 bits wide)
+#define LP_E_SLICE(e) (((e) >> 5) & 0xffu)   // of a first-level entry with LP_E_BITS == 0
+#define LP_E_NO_SLICE ((uint16_t)(0xffu << 5))
+// entry for a code of length len (1..17: 17 = libjpeg's "no code matches" sentinel) of table slot t decoding to symbol v
+#if defined(__HIP__)
+__host__ __device__
+#endif
+static inline uint16_t lp_lut_entry(int t, int len, unsigned v)
+{
+    const bool ends_block = t >= 2 && (v & 15u) == 0 && (v >> 4) != 15; // AC symbol of size 0 that is not ZRL: EOB (jdhuff.c decode_mcu)
+    return (uint16_t)(((unsigned)len + (v & 15u)) | ((v & 15u) << 5) | (((v >> 4) & 15u) << 9) | (ends_block ? 0x8000u : 0u));
+}
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
     uint16_t lut2[LP_LUT2_POOL];

@@ -26,10 +26,11 @@ struct HostMemT {
         if (w >= fill || w + R < fill) *window_violation = true;
         return words[w];
     }
+    uint32_t fetch_np(uint32_t np) { return fetch1((uint32_t)(3 - ((int32_t)np >> 5))); }
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
-    bool any_lt8(int32_t v) const { return v < 8; }
+    bool any2(bool a, bool b) const { return a || b; }
     uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
@@ -48,7 +49,8 @@ struct HostSink { // one slot, flushed at the wave-uniform flush points like the
     HostSink() { memset(blk, 0, sizeof(blk)); }
     void put_dc(int32_t v, bool on) { if (on) blk[0] = (int16_t)v; }
     void put(uint32_t nat, int32_t v) { blk[nat & 63] = (int16_t)v; }
-    void end_block(uint32_t b, bool on) { if (on) pending = coef + (size_t)b * 64; }
+    uint32_t blk0 = 0;  // the lane's first block
+    void end_block(uint32_t bc, bool on) { if (on) pending = coef + (size_t)(blk0 + (bc >> 5) - 1u) * 64; }
     bool stalled() const { return pending != nullptr; }
     void flush() { if (pending) { memcpy(pending, blk, 128); memset(blk, 0, sizeof(blk)); pending = nullptr; } }
     void finish() {}
@@ -91,7 +93,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     rst.push_back(0);
     bool violation = false;
     LpImgCtx ic;
-    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks;
+    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks; lp_ctx_tables(ic);
     // the engine's schedule (lp_engine.cpp run_decode)
     const LpCkSched cs = lp_make_sched(S, C ? C : 256); // the engine's schedule (lp_engine.cpp run_decode)
     const uint32_t K = cs.K;
@@ -147,6 +149,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     for (uint32_t i = 0; i < nsub; i++) {
         LpSubState e = i ? ex[i - 1] : LpSubState{0, 0};
         HostMemWrite m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
+        sink.blk0 = prefix[i].nblk;
         written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink);
     }
     if (written != img.total_blocks) return -14;
