@@ -51,11 +51,10 @@
      38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, \
      63, 63}
 
-// Ring geometry of the bit reader. A lane keeps the three stream words around its position in registers (w0, w1 = the 64 bits a
-// peek funnel-shifts, w2 = the word after them, requested from the ring one step before it can be needed), so the ring read is off
-// the symbol-to-symbol dependency chain. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so kEvery = 8
+// Ring geometry of the bit reader. A peek reads the two stream words around the lane's position, words ceil(p / 32) - 1 and
+// ceil(p / 32), from a per-lane ring. One decode step consumes at most 16 (code) + 15 (extra bits) = 31 bits, so kEvery = 8
 // steps advance the position by at most 8 words; after a top-up at most 3 ring words are free (16-byte granularity) and a step
-// may ask for word (p >> 5) + 2: 8 + 3 + 3 <= kRing = 16.
+// may ask for word (p >> 5) + 1: 8 + 3 + 2 <= kRing = 16 (and 2 + 3 + 2 <= 8 for the ring of eight with a top-up every second step).
 // The policy fixes the geometry: M::kRing words per lane, a top-up of at most M::kQuads 16-byte loads every M::kEvery steps.
 
 // Per-image values every lane of a workgroup shares (scalar registers on the device).
@@ -119,9 +118,9 @@ LP_HD uint32_t lp_bfe(uint32_t v, uint32_t off, uint32_t width)
 }
 
 // Memory policy M must provide (per lane object, non-const):
-//   uint32_t fetch1(uint32_t w)             word w of the clean stream (big-endian corrected: bit 31 first); w within the ring window
-//   uint32_t fetch_np(uint32_t np)          fetch1(3 - (int32_t)np >> 5) = the word after the window of a lane whose negated, biased position is
-//                                           np (LpLane::np), for the hot path: the device ring is laid out so that this is a bit field of np
+//   uint32_t peek_np(uint32_t np)           the 32 stream bits at the position np encodes (LpLane::np): with w1 = 3 - ((int32_t)np >> 5) -- the
+//                                           word index ceil(p / 32) -- the funnel shift of words (w1 - 1, w1) by np. The device ring is laid out
+//                                           so that both words are one two-address LDS read at a bit field of np
 //   void reseek(uint32_t w)                 the lane jumps: make [w, w + kRing - 3) fetchable
 //   void topup(uint32_t p)                  wave-uniform call every kEvery steps with the lane's bit position: words below p >> 5 are dead, refill
 //   bool any(bool)                          wave vote (host emulation: identity)
@@ -135,9 +134,9 @@ LP_HD uint32_t lp_bfe(uint32_t v, uint32_t off, uint32_t width)
 // What bounds these kernels on MI355X is VALU issue (a wave64 instruction occupies its SIMD for four cycles; PMC and the ISA
 // listing agree: SPEC ran 45 vector instructions per symbol in round 2), so the lane state is laid out for the fewest
 // instructions per step, not for readability:
-//   * the position is kept NEGATED (np = -p): a peek is then ONE funnel shift of (w0, w1) by np -- with the convention that w0 is
-//     the word holding bit p - 1 (the window slides when the position LEAVES a word, not when it enters one), the shift amount
-//     32 - (p mod 32) taken mod 32 is right for every p, including p on a word boundary (shift 0 returns w1);
+//   * the position is kept NEGATED (np = bias - p): a peek is then ONE funnel shift of two stream words by np -- taking the words
+//     ceil(p / 32) - 1 and ceil(p / 32), the shift amount 32 - (p mod 32) taken mod 32 is right for every p, including p on a word
+//     boundary (shift 0 returns the lower word);
 //   * "is anything special about this step" (end of the subsequence, a restart boundary or the stream end fewer than 8 bits ahead)
 //     is ONE signed compare of np with a per-lane limit; the wave branches to the slow path on the vote;
 //   * block-in-MCU and the count of completed blocks share a register (bc): 5 x block in the low five bits -- the offset of the
@@ -156,35 +155,24 @@ struct LpLane {
                         // the lane has not seen a block start yet
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
-    uint32_t w0, w1, w2; // stream words ceil(p / 32) - 1, + 1, + 2
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), np(0), z(0), bc(0), next_rst(0), rst_k(0), w0(0), w1(0), w2(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), np(0), z(0), bc(0), next_rst(0), rst_k(0) {}
 
-    // The bias of two words changes nothing for the funnel shift or the slide test (both look at np mod 32 / bit 5 flips) and makes
-    // "the ring slot of the word after the window" a bit field of np itself (M::fetch_np): the policy stores word w at slot
-    // (3 - w) mod kRing, and ((np >> 5) mod kRing) is that slot for w = ceil(p / 32) + 1.
-    static constexpr uint32_t LP_NP0 = 64u;
+    // The bias of three words changes nothing for the funnel shift (it looks at np mod 32) and makes "the ring slot of word
+    // ceil(p / 32)" a bit field of np itself: the policy stores word w at slot (3 - w) mod kRing, and (np >> 5) mod kRing is that slot.
+    // The lane keeps no stream words in registers: a peek reads the two words around the position from the ring (one LDS
+    // instruction) and funnel-shifts them. Round 2 kept a three-word register window with a look-ahead read, which took the LDS
+    // round trip off the symbol-to-symbol chain and cost four vector instructions per step to slide; with the kernels bound by
+    // instruction issue and four to eight waves per SIMD to hide the latency, the instructions were the worse deal.
+    static constexpr uint32_t LP_NP0 = 96u;
     LP_HD uint32_t pos() const { return LP_NP0 - np; }
-    LP_HD uint32_t peek() const { return lp_funnel(w0, w1, np); }
+    LP_HD uint32_t peek() const { return m.peek_np(np); }
     LP_HD void load_window() // after a jump
     {
-        const uint32_t wi = (pos() + 31u) >> 5; // index of w1
+        const uint32_t wi = (pos() + 31u) >> 5; // ceil(p / 32)
         m.reseek(wi ? wi - 1u : 0u);
-        w0 = wi ? m.fetch1(wi - 1u) : 0u;       // p == 0: no such word, and the peek does not look at it
-        w1 = m.fetch1(wi);
-        w2 = m.fetch1(wi + 1u);
     }
-    // the position moves on by n <= 31 bits: slide the register window when it leaves a word, and ask for the word after
-    // the window again (the same word as before when nothing slid; its value is first used one step later)
-    LP_HD void advance(uint32_t n)
-    {
-        const uint32_t nn = np - n;
-        const bool slid = ((np ^ nn) & 32u) != 0; // (p - 1) >> 5 changed: p - 1 == ~np
-        w0 = slid ? w1 : w0;
-        w1 = slid ? w2 : w1;
-        w2 = m.fetch_np(nn);                      // word ceil(p' / 32) + 1 = (p' + 63) >> 5 = 3 - (nn >> 5) (arithmetic shift)
-        np = nn;
-    }
+    LP_HD void advance(uint32_t n) { np -= n; } // n <= 31 bits
     LP_HD void start(uint32_t pos_, uint32_t bz)
     {
         np = LP_NP0 - pos_;
@@ -452,7 +440,7 @@ template <class Ck>
 LP_HD int32_t lp_ck_npos(Ck& ck, uint32_t kk, uint32_t K) // checkpoint kk's position, negated like the lane's; "none" can never be reached
 {
     const uint32_t cp = kk < K ? ck.pos(kk) : 0xffffffffu;
-    return cp == 0xffffffffu ? (int32_t)0x80000000 : (int32_t)(64u - cp); // LpLane::LP_NP0
+    return cp == 0xffffffffu ? (int32_t)0x80000000 : (int32_t)(96u - cp); // LpLane::LP_NP0
 }
 template <class M, class Ck>
 LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, uint32_t K, Ck& ck, const LpSubState& spec_exit,

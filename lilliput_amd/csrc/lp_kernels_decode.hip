@@ -208,7 +208,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
 // R = ring words per lane.
 template <int R, int T, int Q>
 struct DevMem {
-    static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R;
+    static constexpr int kRing = R, kEvery = T, kQuads = Q, kRows = R + 1; // row R mirrors row 0, so that "slot s and slot s + 1" never wraps
     __amdgpu_buffer_rsrc_t words; // this image's clean stream as a raw buffer: a 32-bit byte offset per lane instead of 64-bit address
                                   // arithmetic in the loop, and reads past the image's region return 0
     uint32_t* ring;         // LDS, already offset by the lane: word w of the stream lives at ring[((3 - w) % R) * 64] -- descending, so that
@@ -228,12 +228,13 @@ struct DevMem {
         return m;
     }
     __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[((3u - w) & (R - 1u)) << 6]; }
-    __device__ __forceinline__ uint32_t fetch_np(uint32_t np) const
+    __device__ __forceinline__ uint32_t peek_np(uint32_t np) const
     {
         uint32_t slot; // v_bfe + v_lshl_add; written in C the compiler re-associates it into shift, mask and add
         if (R == 8) asm("v_bfe_u32 %0, %1, 5, 3" : "=v"(slot) : "v"(np));
         else asm("v_bfe_u32 %0, %1, 5, 4" : "=v"(slot) : "v"(np));
-        return ring[slot << 6];
+        const uint32_t* r = ring + (slot << 6);
+        return __builtin_amdgcn_alignbit(r[64], r[0], np); // words ceil(p / 32) - 1 (one slot up) and ceil(p / 32): one ds_read2st64_b32
     }
     // The next Q quads of the stream travel in registers: a top-up stores what the previous top-up loaded and issues the loads for the
     // one after, so no wave ever sits in s_waitcnt vmcnt(0) behind an HBM round trip (the first version loaded and stored in the same
@@ -251,6 +252,7 @@ struct DevMem {
         r[128] = v.y;
         r[64] = v.z;
         r[0] = v.w;
+        if (r == ring) ring[R * 64] = v.w; // the mirror of slot 0
         fbits += 128u;
     }
     __device__ __forceinline__ void reseek(uint32_t w)

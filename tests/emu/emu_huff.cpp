@@ -26,7 +26,12 @@ struct HostMemT {
         if (w >= fill || w + R < fill) *window_violation = true;
         return words[w];
     }
-    uint32_t fetch_np(uint32_t np) { return fetch1((uint32_t)(3 - ((int32_t)np >> 5))); }
+    uint32_t peek_np(uint32_t np)
+    {
+        const uint32_t w1 = (uint32_t)(3 - ((int32_t)np >> 5));
+        const uint32_t hi = (np & 31u) ? fetch1(w1 - 1u) : 0u; // on a word boundary the shift is 0 and the upper word is not looked at (the device reads whatever the ring holds there)
+        return (uint32_t)(((((uint64_t)hi) << 32) | fetch1(w1)) >> (np & 31u));
+    }
     void reseek(uint32_t w) { fill = (w & ~3u) + R; }
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
