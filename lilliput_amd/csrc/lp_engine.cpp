@@ -581,7 +581,12 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         static const uint32_t min_S = getenv("LILLIPUT_HIP_MIN_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_MIN_S")) : 1024u;
         uint64_t bits = 0;
         for (auto& j : h_imgs_) bits += (uint64_t)j.raw_len * 8;
-        while (S_ > min_S && bits / S_ < want_lanes) S_ >>= 1;
+        // A deferred decode (the chunks of the ingest pipeline) has a fixed number of verify rounds queued behind it and pays for a
+        // subsequence that does not settle within them with a second pass: below 4 096 bits the self-synchronisation distance of
+        // 4096 x 4096 sources (p99 ~800 symbols) spans several subsequences. Measured, 4 / 8 images per call: 5.3 / 6.4 ms with the
+        // floor at 1 024, 2.5 / 4.3 ms at 4 096 (profiles/r03_c_final.md).
+        const uint32_t floor_S = defer ? std::max(min_S, 4096u) : min_S;
+        while (S_ > floor_S && bits / S_ < want_lanes) S_ >>= 1;
     }
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
     sched_ = lp_make_sched(S_, C_cfg_ ? C_cfg_ : 256); // checkpoint schedule of the speculative pass (see LpCkSched)
