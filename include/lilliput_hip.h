@@ -413,6 +413,10 @@ int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 
 /* Test access (no device work): number of inflated image-data bytes of a PNG, or -1 when libpng would reject the file. */
 long lilliput_hip_png_inflate_check(const void* data, size_t len);
+long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap); /* test access: the filtered rows; -1 rejected, -2 cap too small */
+int lilliput_hip_png_set_inflater(int own);   /* test access / A-B: 1 = the library's one-shot inflater first (default), 0 = zlib only; returns the previous setting */
+uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n); /* test access: 0 = Adler-32, 1 = CRC-32 of the PNG path (zlib's conventions) */
+int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t* out, size_t out_len); /* test access: 1 = ordinary zlib stream of exactly out_len bytes, decoded; 0 = ask zlib */
 
 /* Lazy host write-back for Part A. Off (the default): every opencv_* call that produces pixels copies them into
  * the caller's buffer before it returns, as cv::Mat over Go memory does (opencv.go:258-267). On: pixels stay on

@@ -8,6 +8,7 @@
 // resized pixels on the host (ops.go:331-446 only passes Mats back into this ABI), so the JPEG->JPEG path
 // loses two device->host copies per image.
 #include "lp_abi.h"
+#include "lp_inflate.h"
 
 #include <ctype.h>
 #include <stdio.h>
@@ -751,6 +752,37 @@ extern "C" long lilliput_hip_png_inflate_check(const void* data, size_t len)
     std::vector<uint8_t> filtered;
     if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
     return (long)filtered.size();
+}
+
+// Test access: the filtered rows the image data inflates to (what the un-filter kernel is given). Returns their size, -1 when the file
+// is rejected, -2 when `cap` is too small.
+extern "C" long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap)
+{
+    LpPngInfo pi;
+    std::vector<uint8_t> filtered;
+    if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
+    if (filtered.size() > cap) return -2;
+    memcpy(out, filtered.data(), filtered.size());
+    return (long)filtered.size();
+}
+// Test access: which inflater lp_png_read_idat tries first: 1 the library's own (default), 0 zlib only. Returns the previous setting.
+extern "C" int lilliput_hip_png_set_inflater(int own) { return lp_png_set_inflater(own); }
+// Test access: lp_inflate_exact on a caller's buffer (copied behind the padding the bit reader wants)
+extern "C" int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t* out, size_t out_len)
+{
+    std::vector<uint8_t> z(in_len + LP_INFLATE_PAD, 0);
+    memcpy(z.data(), in, in_len);
+    std::vector<uint8_t> o(out_len + 1, 0xa5); // one guard byte: the decoder must not write past out_len
+    const int r = lp_inflate_exact(z.data(), in_len, o.data(), out_len);
+    if (o[out_len] != 0xa5) return -1;
+    if (r == 1 && out_len) memcpy(out, o.data(), out_len);
+    return r;
+}
+
+// Test access: the checksum routines of lp_inflate.cpp (which = 0 Adler-32, 1 CRC-32), same conventions as zlib's
+extern "C" uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n)
+{
+    return which ? lp_crc32(seed, (const uint8_t*)p, n) : lp_adler32(seed, (const uint8_t*)p, n);
 }
 
 // ---- encoder (opencv.cpp:173-194)

@@ -1,5 +1,7 @@
 // lp_png.cpp -- see lp_png.h.
 #include "lp_png.h"
+#include "lp_inflate.h"
+#include <atomic>
 
 #include <stdlib.h>
 #include <string.h>
@@ -288,6 +290,58 @@ static bool png_tail_ok(const uint8_t* s, size_t n, size_t i, const LpPngInfo& i
 // ordinary one -- consecutive IDAT chunks with good CRCs, a deflate stream that ends exactly with the last row and the last IDAT byte,
 // filter bytes 0..4, a well-formed tail -- and `filtered` holds it; 0 = anything else: the caller takes libpng's walk, whose accept /
 // reject rules (warnings against errors, where damage is tolerated) are then authoritative.
+// png_read_filter_row's check of every row's filter byte
+static bool png_filter_bytes_ok(const LpPngInfo& info, const std::vector<uint8_t>& filtered)
+{
+    const int bits = info.depth * lp_png_channels_in_file(info.color_type);
+    size_t o = 0;
+    for (int p = 0; p < (info.interlace ? 7 : 1); p++) {
+        uint32_t pw, ph, x0, y0, dx, dy;
+        lp_png_pass_geometry(info, p, &pw, &ph, &x0, &y0, &dx, &dy);
+        if (!pw || !ph) continue;
+        const size_t row = 1 + packed_row_bytes(pw, bits);
+        for (uint32_t r = 0; r < ph; r++, o += row)
+            if (filtered[o] > 4) return false;
+    }
+    return true;
+}
+
+static std::atomic<int> g_own_inflater{getenv("LILLIPUT_HIP_PNG_ZLIB") ? 0 : 1}; // A/B and tests: zlib for every file
+int lp_png_set_inflater(int own) { return g_own_inflater.exchange(own ? 1 : 0); }
+
+// ... and the same sweep through the library's own inflater (lp_inflate.cpp), which only ever says
+// "ordinary, here it is" or "ask zlib". LILLIPUT_HIP_PNG_ZLIB=1 skips it (A/B, tests).
+static int png_idat_own(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
+{
+    static thread_local std::vector<uint8_t> z; // the IDAT payloads, joined
+    size_t total = 0, i = info.idat_off;
+    for (;;) { // first walk: sizes
+        if (n - i < 12) return 0;
+        const uint32_t len = be32(s + i);
+        if (len > 0x7fffffffu || n - i - 8 < (size_t)len + 4) return 0;
+        if (!is_type(s + i + 4, "IDAT")) break;
+        total += len;
+        i += 12 + (size_t)len;
+    }
+    if (total < 6) return 0;
+    if (z.size() < total + LP_INFLATE_PAD) z.resize(total + LP_INFLATE_PAD);
+    size_t o = 0;
+    for (i = info.idat_off;;) {
+        const uint32_t len = be32(s + i);
+        const uint8_t* type = s + i + 4;
+        if (!is_type(type, "IDAT")) break;
+        const uint8_t* d = s + i + 8;
+        if (be32(d + len) != lp_crc32((uint32_t)crc32(0, type, 4), d, len)) return 0;
+        memcpy(z.data() + o, d, len);
+        o += len;
+        i += 12 + (size_t)len;
+    }
+    memset(z.data() + total, 0, LP_INFLATE_PAD);
+    if (lp_inflate_exact(z.data(), total, filtered.data(), filtered.size()) != 1) return 0;
+    if (!png_filter_bytes_ok(info, filtered)) return 0;
+    return png_tail_ok(s, n, i, info) ? 1 : 0;
+}
+
 static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
 {
     const size_t need = filtered.size();
@@ -308,7 +362,7 @@ static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std:
         if (!is_type(type, "IDAT")) break;
         if (ended) return 0; // data behind the end of the stream: libpng's rules decide
         const uint8_t* d = s + i + 8;
-        if (be32(d + len) != (uint32_t)crc32(crc32(0, type, 4), d, len)) return 0;
+        if (be32(d + len) != lp_crc32((uint32_t)crc32(0, type, 4), d, len)) return 0;
         zs.next_in = const_cast<uint8_t*>(d);
         zs.avail_in = len;
         if (len) {
@@ -319,17 +373,7 @@ static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std:
         i += 12 + (size_t)len;
     }
     if (!ended || zs.avail_out != 0) return 0;
-    // png_read_filter_row's check of every row's filter byte
-    const int bits = info.depth * lp_png_channels_in_file(info.color_type);
-    size_t o = 0;
-    for (int p = 0; p < (info.interlace ? 7 : 1); p++) {
-        uint32_t pw, ph, x0, y0, dx, dy;
-        lp_png_pass_geometry(info, p, &pw, &ph, &x0, &y0, &dx, &dy);
-        if (!pw || !ph) continue;
-        const size_t row = 1 + packed_row_bytes(pw, bits);
-        for (uint32_t r = 0; r < ph; r++, o += row)
-            if (filtered[o] > 4) return 0;
-    }
+    if (!png_filter_bytes_ok(info, filtered)) return 0;
     return png_tail_ok(s, n, i, info) ? 1 : 0;
 }
 
@@ -339,6 +383,7 @@ bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::ve
         const size_t need0 = lp_png_filtered_size(info);
         filtered.resize(need0); // no zero-fill: inflate writes every byte of an ordinary stream
         static const bool no_fast = getenv("LILLIPUT_HIP_PNG_ROWWISE") != nullptr; // A/B: libpng's row-by-row pattern for every file
+        if (!no_fast && g_own_inflater.load(std::memory_order_relaxed) && need0 && png_idat_own(s, n, info, filtered) == 1) return true;
         if (!no_fast && need0 && png_idat_fast(s, n, info, filtered) == 1) return true;
     }
     IdatFeed in{s, n, info.idat_off};

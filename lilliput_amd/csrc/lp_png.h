@@ -38,3 +38,5 @@ bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::ve
 size_t lp_png_filtered_size(const LpPngInfo& info);
 void lp_png_pass_geometry(const LpPngInfo& info, int pass, uint32_t* pw, uint32_t* ph, uint32_t* x0, uint32_t* y0, uint32_t* dx, uint32_t* dy);
 inline int lp_png_channels_in_file(int color_type) { return color_type == 0 || color_type == 3 ? 1 : color_type == 4 ? 2 : color_type == 2 ? 3 : 4; }
+// which inflater lp_png_read_idat tries first on an ordinary stream: 1 = lp_inflate.cpp (default), 0 = zlib only; returns the previous setting
+int lp_png_set_inflater(int own);
