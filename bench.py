@@ -410,8 +410,8 @@ def main():
                     "streams": 1 if excl else streams,
                     "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
                             "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
-                            "(about 4.4 cycles per instruction and SIMD for its scalar / vector / LDS mix at four waves per SIMD; a fifth wave changes nothing), "
-                            "not by HBM (DESIGN.md 4.1; profiles/r02_e_final.md)" % streams,
+                            "(a wave64 vector instruction holds its SIMD for four cycles; ~47 vector instructions per Huffman symbol in this kernel "
+                            "after round 3's rewrite of the decode step, ~60 before), not by HBM (DESIGN.md 4.1; profiles/r03_c_final.md)" % streams,
                     "per_kernel_exclusive_us_per_image": {k.split(" ")[0]: round(v[0] * 1e3 / src_n, 2) for k, v in src_tab.items()} if excl else None,
                     "per_kernel_in_timed_region": breakdown}
         e2e_bytes = c_in + 2 * plane_b + 3 * 256 * 256 + c_out

@@ -10,9 +10,11 @@
 #define LP_MAX_COMP 3           // components the subsequence-parallel baseline kernels take (grey, YCbCr, RGB)
 #define LP_GEOM_COMP 4          // components an image may have: CMYK / YCCK files go through the per-scan path (LpProgScan)
 #define LP_MAX_BPM 6            // blocks per MCU: 4:2:0 = 6, 4:2:2/4:4:0 = 4, 4:4:4 = 3, gray = 1
+#ifndef LP_LUT_BITS
 #define LP_LUT_BITS 10          // first-level Huffman lookup width. 9 (with 128-entry slices) was measured: it saves 3 KB of LDS per workgroup and
                                 // lets a fifth WRITE workgroup onto each CU, which buys nothing (27.5 us per image either way: the kernel is
                                 // not occupancy-bound at four) while the extra second-level lookups cost SPEC / VERIFY / WRITE 2-4 % each
+#endif
 #define LP_LUT_SIZE (1 << LP_LUT_BITS)
 #define LP_LUT2_BITS (16 - LP_LUT_BITS) // second-level lookup: slices indexed by the bits that follow the first-level prefix (codes up to 16 bits)
 #define LP_LUT2_SUBS 16          // slices shared by the four tables, one per first-level prefix of long codes (Annex-K tables need 1 + 5 + 5)
