@@ -349,13 +349,14 @@ LP_HD void lp_ckpt_unpack(const LpCkptPk& k, LpSubState& st, LpSubSum& s)
 LP_HD uint32_t lp_ck_iter(const LpCkSched& cs, uint32_t k) { return cs.it[k]; }
 // it[k] from it[k - 1] (0 for k == 0): the rule of lp_make_sched as arithmetic, so that the decode loop needs no table load (a scalar
 // load in the loop makes every iteration wait on lgkmcnt -- and with it on the lane's outstanding LDS reads)
-LP_HD uint32_t lp_ck_next(uint32_t base, uint32_t k, uint32_t prev) { return prev + ((k < 4 || prev / 2 < base) ? base : prev / 2); }
+// Every checkpoint iteration is even (the counting loops run their steps in pairs): base is even, the geometric spacing rounded up.
+LP_HD uint32_t lp_ck_next(uint32_t base, uint32_t k, uint32_t prev) { return prev + ((k < 4 || prev / 2 < base) ? base : ((prev / 2 + 1u) & ~1u)); }
 
 // Schedule for subsequences of S bits; cbits tunes the first spacing (cbits / 32 iterations, 8 for the default 256).
 inline LpCkSched lp_make_sched(uint32_t S, uint32_t cbits)
 {
     LpCkSched cs;
-    const uint32_t base = cbits / 32 > 2 ? cbits / 32 : 2, span = S / 4 > base ? S / 4 : base; // a lane runs about S/6.5 iterations
+    const uint32_t base = cbits / 32 > 2 ? (cbits / 32 + 1u) & ~1u : 2, span = S / 4 > base ? S / 4 : base; // a lane runs about S/6.5 iterations
     uint32_t v = 0;
     cs.K = 0;
     cs.base = base;
@@ -379,55 +380,96 @@ LP_HD LpSubSum lp_lane_sum(const LpLane<M>& L, uint32_t nreset)
     return s;
 }
 
+// The counting passes (SPEC, VERIFY) keep a finished lane RUNNING: masking it off costs four scalar instructions per step in a loop
+// that is bound by the instructions it issues, vector and scalar alike (profiles/r03_c_final.md), while letting it decode on --
+// garbage, past its subsequence -- costs nothing: its results were set aside when it finished (LpLaneExit), its limit can no longer
+// be reached, its ring reads stay inside LDS and its stream loads inside the image's buffer descriptor.
+struct LpLaneExit {
+    uint32_t p, bz, nblk, nreset;
+};
+template <class M>
+LP_HD LpLaneExit lp_lane_exit(const LpLane<M>& L, uint32_t nreset)
+{
+    LpLaneExit e;
+    e.p = L.pos();
+    e.bz = L.state_bz();
+    e.nblk = L.started() & 0x07ffffffu;
+    e.nreset = nreset;
+    return e;
+}
+
 // SPEC pass for one subsequence: decode [entry.p, sub_end) from the guessed state.
 // Ck must provide   void record(uint32_t k, const LpCkptPk&)   -- called by ALL lanes of the wave at the same iteration.
+// Loop shape: the steps between two checkpoints run in pairs (one ring top-up per M::kEvery = 2 steps, no per-step test of the
+// iteration count; every checkpoint iteration is even, see lp_ck_next); the checkpoint itself is recorded in the middle of the step
+// that follows them -- after that step's restart check, before its decode, exactly where the one-test-per-step loop of round 2 had it.
 template <class M, class Ck>
 LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, const LpCkSched& cs, Ck& ck, LpSubState* exit_st,
                         LpSubSum* total)
 {
+    static_assert(M::kEvery == 2, "the step pairs of the counting loops assume a top-up every second step");
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
     uint32_t nreset = 0;
     const uint32_t K = cs.K, ck_base = cs.base;
-    uint32_t k = 0, iter = 0, next_ck = K ? lp_ck_next(ck_base, 0, 0) : 0xffffffffu;
-    bool done = false;
+    uint32_t k = 0, steps = 0, next_ck = K ? lp_ck_next(ck_base, 0, 0) : 0xffffffffu;
+    bool done = false, live = true, near = false;
     int32_t nlim = L.limit(sub_end);
-    // Wave-uniform loop: every lane executes the same instruction stream; finished lanes are predicated off (their limit can no
-    // longer be reached). Single back edge, no `continue`: the register allocator then updates the lane state in place (the first
-    // version of this loop carried ~30 v_mov copies per iteration across its exits).
-    bool live = true;
-    do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
-        uint32_t pk = L.peek();
-        const bool near = m.any((int32_t)L.np <= nlim); // rare even per wave: the subsequence ends here, or a restart boundary / the stream end is near
+    LpLaneExit ex = lp_lane_exit(L, 0);
+    uint32_t pk = 0;
+    // first half of a step: the bits at the position and, rarely per wave, the restart check
+    auto pre = [&] {
+        pk = L.peek();
+        near = m.any((int32_t)L.np <= nlim); // the subsequence ends here, or a restart boundary / the stream end is near
         if (near) {
             LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.z == 0 && L.restart_check(pk)) nreset++; // also catches the padded end of the stream
             pk = L.peek();
         }
-        if (iter == next_ck) { // wave-uniform: iter, k and next_ck are the same in every lane
-            LpSubState st;
-            st.p = L.pos();
-            st.bz = L.state_bz();
-            ck.record(k, lp_ckpt_pack(st, lp_lane_sum(L, nreset)));
-            k++;
-            next_ck = k < K ? lp_ck_next(ck_base, k, next_ck) : 0xffffffffu;
-        }
-        iter++;
+    };
+    // second half: a lane that has reached the end of its subsequence sets its results aside; then the decode, for every lane
+    auto post = [&] {
         if (near) {
             LP_KEEP_UNIFORM_BRANCH();
-            done = done || L.pos() >= sub_end;
+            if (!done && L.pos() >= sub_end) {
+                ex = lp_lane_exit(L, nreset);
+                done = true;
+            }
             nlim = done ? (int32_t)0x80000000 : L.limit(sub_end);
             live = m.any(!done);
         }
-        if (!done) (void)L.template step<false>(pk);
-    } while (live);
+        (void)L.template step<false>(pk);
+    };
+    while (live) {
+        // the whole pairs before the next checkpoint (all of them, two at a time, once the checkpoints have run out)
+        while (live && steps != next_ck) {
+            m.topup(L.pos());
+            pre(); post();
+            pre(); post();
+            steps += 2;
+        }
+        if (!live) break;
+        m.topup(L.pos());
+        pre();
+        { // wave-uniform: every lane records checkpoint k now -- a finished lane its exit state again
+            const LpLaneExit now = lp_lane_exit(L, nreset);
+            LpCkptPk c;
+            c.p = done ? ex.p : now.p; c.bz = done ? ex.bz : now.bz; c.nblk = done ? ex.nblk : now.nblk; c.nreset = done ? ex.nreset : now.nreset;
+            ck.record(k, c);
+            k++;
+            next_ck = k < K ? lp_ck_next(ck_base, k, next_ck) : 0xffffffffu;
+        }
+        post();
+        pre(); post();
+        steps += 2;
+    }
     LpCkptPk none;
     none.p = 0xffffffffu; none.bz = 0; none.nblk = 0; none.nreset = 0;
     for (; k < K; k++) ck.record(k, none);
-    exit_st->p = L.pos();
-    exit_st->bz = L.state_bz();
-    *total = lp_lane_sum(L, nreset);
+    exit_st->p = ex.p;
+    exit_st->bz = ex.bz;
+    total->nblk = ex.nblk;
+    total->nreset = ex.nreset;
 }
 
 // VERIFY pass for one subsequence: decode from `entry` (= current exit state of the previous subsequence) until the state
@@ -446,18 +488,17 @@ template <class M, class Ck>
 LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState entry, uint32_t K, Ck& ck, const LpSubState& spec_exit,
                           const LpSubSum& spec_total, LpSubState* exit_st, LpSubSum* total)
 {
+    static_assert(M::kEvery == 2, "the step pairs of the counting loops assume a top-up every second step");
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
-    uint32_t nreset = 0;
-    uint32_t kk = 0, iter = 0;
+    uint32_t nreset = 0, kk = 0;
+    const int32_t never = (int32_t)0x80000000;
     int32_t ncp = lp_ck_npos(ck, 0, K);
-    bool done = false, spliced = false;
+    bool done = false, live = true;
     int32_t nlim = L.limit(sub_end);
-    bool live = true;
-    do { // same shape as the SPEC loop: one back edge, state updated in place
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
+    LpLaneExit ex = lp_lane_exit(L, 0);
+    auto one_step = [&] { // same shape as a SPEC step, plus the look at the lane's next checkpoint
         uint32_t pk = L.peek();
-        iter++;
         const bool near = m.any((int32_t)L.np <= nlim);
         if (near) {
             LP_KEEP_UNIFORM_BRANCH();
@@ -465,7 +506,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
             pk = L.peek();
         }
         bool now_done = false;
-        if (m.any(!done && ncp >= (int32_t)L.np)) { // some lane stands at or behind its next checkpoint
+        if (m.any(ncp >= (int32_t)L.np)) { // some lane stands at or behind its next checkpoint (a finished lane's is out of reach)
             LP_KEEP_UNIFORM_BRANCH();
             if (!done) {
                 while (ncp > (int32_t)L.np) { // checkpoints are strictly ordered until the lane that recorded them finished
@@ -477,10 +518,9 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
                     LpSubSum csum;
                     lp_ckpt_unpack(ck.load(kk), cst, csum);
                     if (cst.bz == L.state_bz()) { // synchronised with the recorded trajectory at checkpoint kk
-                        *total = lp_sum_combine(lp_lane_sum(L, nreset), lp_sum_tail(spec_total, csum));
-                        *exit_st = spec_exit;
+                        const LpSubSum t = lp_sum_combine(lp_lane_sum(L, nreset), lp_sum_tail(spec_total, csum));
+                        ex.p = spec_exit.p; ex.bz = spec_exit.bz; ex.nblk = t.nblk; ex.nreset = t.nreset;
                         now_done = true;
-                        spliced = true;
                     } else {
                         kk++; // same position, different state: this checkpoint can never match
                         ncp = lp_ck_npos(ck, kk, K);
@@ -490,17 +530,29 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
         }
         if (near || m.any(now_done)) {
             LP_KEEP_UNIFORM_BRANCH();
-            done = done || now_done || L.pos() >= sub_end;
-            nlim = done ? (int32_t)0x80000000 : L.limit(sub_end);
+            if (!done && !now_done && L.pos() >= sub_end) {
+                ex = lp_lane_exit(L, nreset);
+                now_done = true;
+            }
+            done = done || now_done;
+            if (done) ncp = never;
+            nlim = done ? never : L.limit(sub_end);
             live = m.any(!done);
         }
+        // (masked here, unlike in the SPEC pass: most lanes of a verify wave are finished most of the time -- a walk is a tenth of a
+        // subsequence -- and sixty lanes decoding garbage cost the few that still work their LDS and load bandwidth: measured 7.6
+        // against 7.1 us per image)
         if (!done) (void)L.template step<false>(pk);
-    } while (live);
-    if (!spliced) {
-        exit_st->p = L.pos();
-        exit_st->bz = L.state_bz();
-        *total = lp_lane_sum(L, nreset);
+    };
+    while (live) {
+        if (!done) m.topup(L.pos());
+        one_step();
+        one_step();
     }
+    exit_st->p = ex.p;
+    exit_st->bz = ex.bz;
+    total->nblk = ex.nblk;
+    total->nreset = ex.nreset;
 }
 
 // WRITE pass for one subsequence. Sink S must provide:
