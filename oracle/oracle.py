@@ -352,6 +352,20 @@ def ref_webp_play(data, max_frames=4096):
     return out[: n * w.value * h.value * 4].reshape(n, h.value, w.value, 4).copy(), list(ts)[:n], int(ai[0]), int(ai[1])
 
 
+def ref_webp_encode_anim(frames, delays, quality, loop_count=0, bgcolor=0xFFFFFFFF):
+    """The reference's animation writer (WebPAnimEncoder, kmin 3 / kmax 4, webp.cpp:631-706) over whole canvases [n, H, W, 3 or 4]."""
+    fr = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w, cn = fr.shape
+    cap = n * w * h * 4 + (1 << 16)
+    out = np.zeros(cap, dtype=np.uint8)
+    d = (C.c_int * n)(*[int(x) for x in delays])
+    f = ref_webp().ref_webp_encode_anim
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+    size = f(fr.ctypes.data, n, w, h, cn, d, float(quality), int(loop_count) & 0xFFFFFFFF, int(bgcolor) & 0xFFFFFFFF, out.ctypes.data, cap)
+    return out[:size].tobytes() if size else None
+
+
 def _buf(data):
     arr = np.frombuffer(bytes(data), dtype=np.uint8)
     return arr, arr.ctypes.data_as(_u8p)

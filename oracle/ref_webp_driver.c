@@ -148,4 +148,48 @@ int ref_webp_play(const uint8_t* data, size_t len, uint8_t* out, size_t cap, int
     return n;
 }
 
+/* The reference's animation writer (webp.cpp:631-706, 508-548): every frame a whole canvas through WebPAnimEncoderAdd with kmin 3 / kmax 4,
+ * the closing NULL frame at the total duration, WebPAnimEncoderAssemble. quality > 100 = lossless, as webp.cpp:463-467 maps it.
+ * frames: n canvases of w x h x cn (cn 3 = BGR, 4 = BGRA); delays in ms. Returns the file size (0 on failure). */
+size_t ref_webp_encode_anim(const uint8_t* frames, int n, int w, int h, int cn, const int* delays, float quality, uint32_t loop_count, uint32_t bgcolor,
+                            uint8_t* out, size_t cap)
+{
+    WebPConfig config;
+    if (!WebPConfigInit(&config)) return 0;
+    const float q = quality < 1.f ? 1.f : quality;
+    config.quality = q > 100.f ? 100.f : q;
+    config.lossless = q > 100.f;
+    WebPAnimEncoderOptions ao;
+    if (!WebPAnimEncoderOptionsInit(&ao)) return 0;
+    ao.anim_params.loop_count = (int)loop_count;
+    ao.anim_params.bgcolor = bgcolor;
+    ao.kmin = 3;
+    ao.kmax = 4;
+    WebPAnimEncoder* enc = WebPAnimEncoderNew(w, h, &ao);
+    if (!enc) return 0;
+    int ts = 0, ok = 1;
+    for (int i = 0; i < n && ok; i++) {
+        WebPPicture pic;
+        WebPPictureInit(&pic);
+        pic.width = w; pic.height = h; pic.use_argb = 1;
+        ok = WebPPictureAlloc(&pic);
+        const uint8_t* px = frames + (size_t)i * w * h * cn;
+        if (ok) ok = cn == 3 ? WebPPictureImportBGR(&pic, px, w * cn) : WebPPictureImportBGRA(&pic, px, w * cn);
+        if (ok) ok = WebPAnimEncoderAdd(enc, &pic, ts, &config);
+        WebPPictureFree(&pic);
+        ts += delays[i];
+    }
+    size_t size = 0;
+    if (ok && WebPAnimEncoderAdd(enc, NULL, ts, &config)) {
+        WebPData d;
+        WebPDataInit(&d);
+        if (WebPAnimEncoderAssemble(enc, &d)) {
+            if (d.size <= cap) { memcpy(out, d.bytes, d.size); size = d.size; }
+            WebPDataClear(&d);
+        }
+    }
+    WebPAnimEncoderDelete(enc);
+    return size;
+}
+
 int ref_webp_version(void) { return WebPGetDecoderVersion(); }

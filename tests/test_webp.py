@@ -423,3 +423,32 @@ def test_config4_animated_sources_to_animated_webp(W, oracle):
     assert oracle.ref_webp_info(one)["num_frames"] == 1
     five = _transform(gif, FileType=".webp", Width=16, Height=16, ResizeMethod=la.ImageOpsFit, MaxEncodeFrames=5, EncodeOptions={la.WebpQuality: 101})
     assert oracle.ref_webp_info(five)["total_duration"] == 150 and len(oracle.ref_webp_play(five)[0]) <= 5
+
+
+@pytest.mark.gpu
+def test_animation_writer_file_size_against_the_reference_writer(W, oracle):
+    """The product's animation writer places changed rectangles of whole frames (lp_abi_webp.cpp); the reference hands whole canvases to
+    libwebp's WebPAnimEncoder (kmin 3 / kmax 4, webp.cpp:631-706), which also tries blended sub-frames and key frames. Same frames on
+    playback (test above) -- here: what the difference costs in bytes, on the BASELINE configs[3] sources. The reference writer runs
+    over the very frames the product's encoder was handed (the raw frame sink)."""
+    import lilliput_amd as la
+
+    if oracle.ref_webp() is None:
+        pytest.skip("reference libwebp driver not built")
+    gif = open(os.path.join(ROOT, "tests", "golden", "inputs_gif", "party-discord.gif"), "rb").read()
+    ratios = {}
+    for name, data, q in (("party-discord.gif lossless", gif, 101), ("party-discord.gif q80", gif, 80),
+                          ("big_buck_bunny_720_5s.webp q75", fixtures()["big_buck_bunny_720_5s.webp"], 75),
+                          ("party-discord.webp lossless", fixtures()["party-discord.webp"], 101)):
+        pre = la.parse_raw_frames(_transform(data, FileType=".bgra-frames", Width=128, Height=128, ResizeMethod=la.ImageOpsFit))
+        out = _transform(data, FileType=".webp", Width=128, Height=128, ResizeMethod=la.ImageOpsFit, EncodeOptions={la.WebpQuality: q})
+        d = la.Decoder(data)
+        loops, nfr, dur, bg = d.AnimationInfo()
+        d.Close()
+        frames = np.stack([f if f.shape[2] == 4 else np.concatenate([f, np.full(f.shape[:2] + (1,), 255, np.uint8)], axis=2) for f, _ in pre])
+        ref = oracle.ref_webp_encode_anim(frames, [ms for _, ms in pre], q, loops, bg)
+        assert ref is not None
+        ratios[name] = (len(out), len(ref), round(len(out) / len(ref), 3))
+    print("animated WebP, product bytes / reference bytes:", ratios)
+    # lossless: rectangles against blended sub-frames cost little; lossy: the reference re-encodes only what changed too
+    assert all(r[2] <= 1.15 for r in ratios.values()), ratios
