@@ -5,6 +5,7 @@
 // (k_composite), Fit, resize (ops.go:552-582 through opencv.cpp:508-752).
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
@@ -171,6 +172,54 @@ static bool config_from_options(WebPConfig* c, const int* opt, size_t opt_len) /
     return true;
 }
 
+// libwebp's tables for the gamma-aware chroma down-sampling of its RGB -> YUV 4:2:0 import (picture_csp_enc.c InitGammaTables: gamma
+// 0.80, 12-bit linear values, 32 + 1 interpolation points back), computed with the library's formula by the same libm
+static const LpWebpYuvTab& webp_yuv_tables()
+{
+    static const LpWebpYuvTab tab = [] {
+        LpWebpYuvTab t;
+        memset(&t, 0, sizeof(t));
+        const double kGamma = 0.80, kGammaScale = (double)((1 << 12) - 1), scale = (double)(1 << 7) / kGammaScale, norm = 1. / 255.;
+        for (int v = 0; v <= 255; v++) t.gamma_to_linear[v] = (uint16_t)(pow(norm * v, kGamma) * kGammaScale + .5);
+        for (int v = 0; v <= 32; v++) t.linear_to_gamma[v] = (int)(255. * pow(scale * v, 1. / kGamma) + .5);
+        return t;
+    }();
+    return tab;
+}
+
+// The lossy still path with the colour conversion on the device: Y, U, V planes of a frame the device holds, then WebPEncode on them
+// with the configuration WebPEncodeBGR(A) builds (WebPConfigPreset(default, quality)): the same bitstream, the import step skipped.
+// false: not applicable (translucent pixels -- the alpha-weighted import stays libwebp's -- or no device), the caller takes the host route.
+static bool encode_still_from_device(LpMat* m, float quality, LpWebpEncodedImage* out)
+{
+    static const bool off = getenv("LILLIPUT_HIP_WEBP_YUV") && !strcmp(getenv("LILLIPUT_HIP_WEBP_YUV"), "host");
+    const int cn = cvc(m->type);
+    if (off || !m->dev_valid || (cn != 3 && cn != 4)) return false;
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
+    if (!eng || !lp_mat_to_device(m, eng)) return false;
+    const int w = m->cols, h = m->rows, uvw = (w + 1) / 2, uvh = (h + 1) / 2;
+    std::vector<uint8_t> planes((size_t)w * h + 2 * (size_t)uvw * uvh);
+    uint8_t *y = planes.data(), *u = y + (size_t)w * h, *v = u + (size_t)uvw * uvh;
+    bool translucent = false;
+    if (eng->webp_yuv420(lp_mat_frame(m), webp_yuv_tables(), y, u, v, &translucent) || translucent) return false;
+    WebPConfig cfg;
+    WebPPicture pic;
+    if (!WebPConfigInitInternal(&cfg, 0 /* WEBP_PRESET_DEFAULT */, quality, LP_WEBP_ENCODER_ABI) || !WebPPictureInitInternal(&pic, LP_WEBP_ENCODER_ABI)) return false;
+    pic.use_argb = 0;
+    pic.colorspace = 0; // WEBP_YUV420
+    pic.width = w; pic.height = h;
+    pic.y = y; pic.u = u; pic.v = v;
+    pic.y_stride = w; pic.uv_stride = uvw;
+    WebPMemoryWriter wr;
+    WebPMemoryWriterInit(&wr);
+    pic.writer = WebPMemoryWrite;
+    pic.custom_ptr = &wr;
+    const bool good = WebPEncode(&cfg, &pic) && lp_webp_split_encoded(wr.mem, wr.size, out);
+    WebPMemoryWriterClear(&wr); // the planes are the caller's: nothing for WebPPictureFree to release
+    return good;
+}
+
 // One rectangle of a frame through libwebp's advanced API with the caller's configuration (what WebPAnimEncoderAdd does per frame).
 static bool encode_rect(const WebPConfig& cfg, const uint8_t* px, int stride, int w, int h, int cn, LpWebpEncodedImage* out)
 {
@@ -274,6 +323,11 @@ size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, 
             size = 1; // WebPPictureImport's return value in the reference: non-zero
         } else {
             uint8_t* outp = nullptr;
+            if (!config.lossless && encode_still_from_device(m, config.quality, &e->still)) {
+                e->first_delay = delay;
+                e->frame_count++;
+                return 1; // the reference returns the coded size here; the Go layer only tests it against zero (webp.go: EncodeFrame)
+            }
             if (config.lossless) size = cn == 3 ? WebPEncodeLosslessBGR(px.data(), w, h, stride, &outp) : WebPEncodeLosslessBGRA(px.data(), w, h, stride, &outp);
             else size = cn == 3 ? WebPEncodeBGR(px.data(), w, h, stride, config.quality, &outp) : WebPEncodeBGRA(px.data(), w, h, stride, config.quality, &outp);
             if (size == 0) return 0;
@@ -288,6 +342,20 @@ size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, 
         e->failed = true;
         return 0;
     }
+}
+
+// Test access: the Y, U, V planes the lossy encoder is handed for this frame (k_webp_yuv420). 0 = ok, 1 = the frame has translucent pixels
+// (the product then lets libwebp import it), -1 = error.
+int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8_t* v)
+{
+    auto m = static_cast<LpMat*>(const_cast<void*>((const void*)src));
+    if (!m || m->rows <= 0 || m->cols <= 0 || (cvc(m->type) != 3 && cvc(m->type) != 4)) return -1;
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
+    if (!eng || !lp_mat_to_device(m, eng)) return -1;
+    bool translucent = false;
+    if (eng->webp_yuv420(lp_mat_frame(m), webp_yuv_tables(), y, u, v, &translucent)) return -1;
+    return translucent ? 1 : 0;
 }
 
 size_t webp_encoder_flush(webp_encoder e) { return webp_encoder_write(e, nullptr, nullptr, 0, 0, 0, 0, 0, 0); } // webp.cpp:780-783

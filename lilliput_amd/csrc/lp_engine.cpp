@@ -1200,6 +1200,29 @@ int LpEngine::gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, 
     return check(hipGetLastError(), "gather kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
+int LpEngine::webp_yuv420(const LpFrame& f, const LpWebpYuvTab& tab, uint8_t* y, uint8_t* u, uint8_t* v, bool* translucent)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
+    const size_t yb = (size_t)f.w * f.h, cb = (size_t)((f.w + 1) / 2) * ((f.h + 1) / 2);
+    const size_t tab_b = (sizeof(LpWebpYuvTab) + 255) & ~(size_t)255, y_b = (yb + 255) & ~(size_t)255, c_b = (cb + 255) & ~(size_t)255;
+    if (!d_ops_.ensure(tab_b + 256 + y_b + 2 * c_b + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    uint8_t* base = d_ops_.as<uint8_t>();
+    uint32_t* flag = h_small_.ensure(4096) ? h_small_.as<uint32_t>() : nullptr;
+    if (!flag) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(base, &tab, sizeof(tab), hipMemcpyHostToDevice, stream_), "H2D webp tables")) return LP_ERR_DEVICE;
+    if (!check(hipMemsetAsync(base + tab_b, 0, 256, stream_), "memset webp flag")) return LP_ERR_DEVICE;
+    uint8_t *dy = base + tab_b + 256, *du = dy + y_b, *dv = du + c_b;
+    lp_launch_webp_yuv420(stream_, f, reinterpret_cast<const LpWebpYuvTab*>(base), dy, du, dv, reinterpret_cast<uint32_t*>(base + tab_b));
+    if (!check(hipMemcpyAsync(y, dy, yb, hipMemcpyDeviceToHost, stream_), "D2H Y plane")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(u, du, cb, hipMemcpyDeviceToHost, stream_), "D2H U plane")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(v, dv, cb, hipMemcpyDeviceToHost, stream_), "D2H V plane")) return LP_ERR_DEVICE;
+    if (!check(hipMemcpyAsync(flag, base + tab_b, 4, hipMemcpyDeviceToHost, stream_), "D2H webp flag")) return LP_ERR_DEVICE;
+    if (!check(hipStreamSynchronize(stream_), "webp yuv sync")) return LP_ERR_DEVICE;
+    *translucent = *flag != 0;
+    return check(hipGetLastError(), "webp yuv kernel") ? LP_OK : LP_ERR_DEVICE;
+}
+
 int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const uint8_t* palette_bgra)
 {
     if (!ok_) return LP_ERR_DEVICE;

@@ -199,6 +199,8 @@ public:
     int tonemap_host(const uint16_t* src, uint8_t* dst, int w, int h, int depth, int transfer, int primaries);
     // ThumbHash: out[(i * w + j) * cn ..] = frame(idx[w + i], idx[j]) for a w x h lattice of sample coordinates (host memory in and out).
     int gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, uint32_t h, uint8_t* out);
+    // lossy WebP front end: the frame as Y (w x h), U, V ((w + 1) / 2 x (h + 1) / 2) planes into host memory; *translucent = some alpha below 255
+    int webp_yuv420(const LpFrame& f, const LpWebpYuvTab& tab, uint8_t* y, uint8_t* u, uint8_t* v, bool* translucent);
     int sync();
     size_t device_bytes() const;                 // HBM held by this engine's grow-only arenas (the pool of the one-image ABI trims by it)
     const LpTimings& timings() const { return tm_; }

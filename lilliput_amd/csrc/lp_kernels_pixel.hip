@@ -1048,6 +1048,51 @@ void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d
     hipLaunchKernelGGL(k_gather_samples, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, f, d_idx, w, h, d_out);
 }
 
+// ---- lossy WebP output: the encoder's BGR -> Y'CbCr 4:2:0 front end (libwebp picture_csp_enc.c ImportYUVAFromRGBA for opaque pictures,
+// what WebPEncodeBGR / WebPPictureImportBGR + WebPEncode run first; reference call sites webp.cpp:707-751). Luma per pixel in 16-bit
+// fixed point; chroma from the 2 x 2 mean taken in LINEAR light -- gamma 0.80 through a 256-entry table, back through a 33-entry
+// table with linear interpolation -- with the last column / row standing in for the missing one of an odd size. One thread per 2 x 2
+// block. The two tables are computed by the host with the library's own formula (lp_abi_webp.cpp) and passed in.
+__global__ __launch_bounds__(256) void k_webp_yuv420(LpFrame f, const LpWebpYuvTab* __restrict__ tab, uint8_t* __restrict__ Y, uint8_t* __restrict__ U,
+                                                     uint8_t* __restrict__ V, uint32_t* __restrict__ non_opaque)
+{
+    __shared__ uint16_t s_g2l[256];
+    __shared__ int32_t s_l2g[33];
+    const uint32_t t = threadIdx.y * 64 + threadIdx.x;
+    s_g2l[t] = tab->gamma_to_linear[t];
+    if (t < 33) s_l2g[t] = tab->linear_to_gamma[t];
+    __syncthreads();
+    const uint32_t bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    const uint32_t uvw = (f.w + 1) >> 1, uvh = (f.h + 1) >> 1;
+    if (bx >= uvw || by >= uvh) return;
+    uint32_t lin[3] = {0, 0, 0};
+    bool translucent = false;
+    for (uint32_t dy = 0; dy < 2; dy++)
+        for (uint32_t dx = 0; dx < 2; dx++) {
+            const uint32_t x = 2 * bx + dx, y = 2 * by + dy;
+            const uint32_t xc = x < f.w ? x : f.w - 1, yc = y < f.h ? y : f.h - 1;
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(f.off) + (size_t)yc * f.stride + (size_t)xc * f.cn;
+            const uint32_t b = p[0], g = p[1], r = p[2];
+            if (f.cn == 4 && p[3] != 255) translucent = true;
+            if (x < f.w && y < f.h) Y[(size_t)y * f.w + x] = (uint8_t)((16839u * r + 33059u * g + 6420u * b + (1u << 15) + (16u << 16)) >> 16); // VP8RGBToY
+            lin[0] += s_g2l[r]; lin[1] += s_g2l[g]; lin[2] += s_g2l[b];
+        }
+    int32_t c[3]; // LinearToGamma(sum, 0): the 2 x 2 sum back in gamma space, scaled by 4
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = lin[k], pos = v >> 9, x = v & 511u;
+        c[k] = (s_l2g[pos + 1] * (int32_t)x + s_l2g[pos] * (int32_t)(512u - x) + 64) >> 7;
+    }
+    auto clip = [](int32_t uv) { uv = (uv + (1 << 17) + (128 << 18)) >> 18; return (uint8_t)(uv < 0 ? 0 : uv > 255 ? 255 : uv); }; // VP8ClipUV, YUV_HALF << 2
+    U[(size_t)by * uvw + bx] = clip(-9719 * c[0] - 19081 * c[1] + 28800 * c[2]);
+    V[(size_t)by * uvw + bx] = clip(28800 * c[0] - 24116 * c[1] - 4684 * c[2]);
+    if (translucent) atomicOr(non_opaque, 1u);
+}
+
+void lp_launch_webp_yuv420(hipStream_t s, const LpFrame& f, const LpWebpYuvTab* d_tab, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, uint32_t* d_flag)
+{
+    hipLaunchKernelGGL(k_webp_yuv420, dim3(((f.w + 1) / 2 + 63) / 64, ((f.h + 1) / 2 + 3) / 4), dim3(64, 4), 0, s, f, d_tab, d_y, d_u, d_v, d_flag);
+}
+
 // ---- GIF encoder: palette mapping (see LpGifEncOp)
 __device__ __forceinline__ int gif_dist(int r0, int g0, int b0, int r1, int g1, int b1) { return abs(r0 - r1) + abs(g0 - g1) + abs(b0 - b1); } // giflib.cpp:921-929
 

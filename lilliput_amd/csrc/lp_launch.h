@@ -61,6 +61,7 @@ void lp_launch_png(hipStream_t s, const LpPngOp& op);
 void lp_launch_png_filter(hipStream_t s, const LpPngEncOp& op);
 void lp_launch_gifenc(hipStream_t s, const LpGifEncOp& op);
 void lp_launch_tonemap(hipStream_t s, const LpToneOp& op, int pass, uint32_t* n_wg); // pass 0..3, see LpToneOp
+void lp_launch_webp_yuv420(hipStream_t s, const LpFrame& f, const LpWebpYuvTab* d_tab, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, uint32_t* d_flag);
 void lp_launch_gather_samples(hipStream_t s, const LpFrame& f, const uint32_t* d_idx, uint32_t w, uint32_t h, uint8_t* d_out);
 // encode
 void lp_launch_encode(hipStream_t s, const LpEncJob* d_jobs, LpEncState* d_states, uint32_t nimg, uint32_t max_blocks, const uint8_t* d_frames,

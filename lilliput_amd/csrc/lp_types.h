@@ -184,6 +184,13 @@ struct LpFrame {
     uint32_t w, h, stride, cn;  // cn = 1 (gray), 3 (BGR), 4 (BGRA)
 };
 
+// Tables of libwebp's gamma-aware chroma down-sampling (k_webp_yuv420)
+struct LpWebpYuvTab {
+    uint16_t gamma_to_linear[256];
+    int32_t linear_to_gamma[33];
+    uint32_t pad[3];
+};
+
 struct LpOrientOp {
     LpFrame src, dst;
     uint32_t orientation;       // EXIF 1..8 (opencv.hpp:17-26)

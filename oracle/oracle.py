@@ -352,6 +352,21 @@ def ref_webp_play(data, max_frames=4096):
     return out[: n * w.value * h.value * 4].reshape(n, h.value, w.value, 4).copy(), list(ts)[:n], int(ai[0]), int(ai[1])
 
 
+def ref_webp_yuv420(px):
+    """Y, U, V planes of the reference's lossy still writer for a BGR / BGRA frame (libwebp's import with use_argb = 0), and whether it
+    kept an alpha plane."""
+    a = np.ascontiguousarray(px, dtype=np.uint8)
+    h, w, cn = a.shape
+    uvw, uvh = (w + 1) // 2, (h + 1) // 2
+    y, u, v = np.zeros((h, w), np.uint8), np.zeros((uvh, uvw), np.uint8), np.zeros((uvh, uvw), np.uint8)
+    f = ref_webp().ref_webp_yuv420
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = f(a.ctypes.data, w, h, cn, y.ctypes.data, u.ctypes.data, v.ctypes.data)
+    assert r >= 0
+    return y, u, v, bool(r)
+
+
 def ref_webp_encode_anim(frames, delays, quality, loop_count=0, bgcolor=0xFFFFFFFF):
     """The reference's animation writer (WebPAnimEncoder, kmin 3 / kmax 4, webp.cpp:631-706) over whole canvases [n, H, W, 3 or 4]."""
     fr = np.ascontiguousarray(frames, dtype=np.uint8)

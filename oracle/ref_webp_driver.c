@@ -192,4 +192,24 @@ size_t ref_webp_encode_anim(const uint8_t* frames, int n, int w, int h, int cn, 
     return size;
 }
 
+/* The planes the reference's lossy still writer codes (webp.cpp:707-751: WebPEncodeBGR(A) -> WebPPictureImportBGR(A) with use_argb = 0,
+ * i.e. picture_csp_enc.c ImportYUVAFromRGBA): Y (w x h), U, V ((w+1)/2 x (h+1)/2). Returns 1 when the picture came out with an alpha plane. */
+int ref_webp_yuv420(const uint8_t* px, int w, int h, int cn, uint8_t* y, uint8_t* u, uint8_t* v)
+{
+    WebPPicture pic;
+    if (!WebPPictureInit(&pic)) return -1;
+    pic.use_argb = 0;
+    pic.width = w; pic.height = h;
+    if (!(cn == 3 ? WebPPictureImportBGR(&pic, px, w * cn) : WebPPictureImportBGRA(&pic, px, w * cn))) { WebPPictureFree(&pic); return -1; }
+    const int uvw = (w + 1) / 2, uvh = (h + 1) / 2;
+    for (int r = 0; r < h; r++) memcpy(y + (size_t)r * w, pic.y + (size_t)r * pic.y_stride, (size_t)w);
+    for (int r = 0; r < uvh; r++) {
+        memcpy(u + (size_t)r * uvw, pic.u + (size_t)r * pic.uv_stride, (size_t)uvw);
+        memcpy(v + (size_t)r * uvw, pic.v + (size_t)r * pic.uv_stride, (size_t)uvw);
+    }
+    const int alpha = pic.a != NULL;
+    WebPPictureFree(&pic);
+    return alpha;
+}
+
 int ref_webp_version(void) { return WebPGetDecoderVersion(); }

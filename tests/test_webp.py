@@ -452,3 +452,43 @@ def test_animation_writer_file_size_against_the_reference_writer(W, oracle):
     print("animated WebP, product bytes / reference bytes:", ratios)
     # lossless: rectangles against blended sub-frames cost little; lossy: the reference re-encodes only what changed too
     assert all(r[2] <= 1.15 for r in ratios.values()), ratios
+
+
+@pytest.mark.gpu
+def test_lossy_front_end_planes_equal_libwebps(W, oracle):
+    """The lossy still writer codes Y'CbCr 4:2:0 planes; the reference lets libwebp derive them from the BGR frame (WebPEncodeBGR ->
+    picture_csp_enc.c: 16-bit fixed-point luma, chroma from the 2 x 2 mean in linear light). The product derives them on the device
+    (k_webp_yuv420) for frames the device holds: bit for bit the planes of the reference's libwebp, odd sizes and flat / banded /
+    noisy content included; a frame with translucent pixels is left to libwebp's alpha-weighted import."""
+    if oracle.ref_webp() is None:
+        pytest.skip("reference libwebp driver not built")
+    L = W
+    L.lilliput_hip_webp_yuv420.restype = C.c_int
+    L.lilliput_hip_webp_yuv420.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(8)
+
+    def planes(px):
+        h, w, cn = px.shape
+        buf = np.ascontiguousarray(px)
+        m = L.opencv_mat_create_from_data(w, h, 16 if cn == 3 else 24, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+        uvw, uvh = (w + 1) // 2, (h + 1) // 2
+        y, u, v = np.zeros((h, w), np.uint8), np.zeros((uvh, uvw), np.uint8), np.zeros((uvh, uvw), np.uint8)
+        r = L.lilliput_hip_webp_yuv420(m, y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p))
+        L.opencv_mat_release(m)
+        return r, y, u, v
+
+    for h, w in ((1, 1), (2, 2), (5, 7), (2, 9), (33, 17), (64, 64), (101, 3), (297, 297), (480, 641)):
+        for kind in range(4):
+            px = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            if kind == 1:
+                px = (px // 32 * 32).astype(np.uint8)
+            elif kind == 2:
+                px[:] = rng.integers(0, 256, 3, dtype=np.uint8)
+            elif kind == 3:  # opaque BGRA takes the same route
+                px = np.concatenate([px, np.full((h, w, 1), 255, np.uint8)], axis=2)
+            r, y, u, v = planes(px)
+            ry, ru, rv, ralpha = oracle.ref_webp_yuv420(px)
+            assert r == 0 and not ralpha
+            assert np.array_equal(y, ry) and np.array_equal(u, ru) and np.array_equal(v, rv), (h, w, kind)
+    px = rng.integers(0, 256, (9, 9, 4), dtype=np.uint8)
+    assert planes(px)[0] == 1 and oracle.ref_webp_yuv420(px)[3]
