@@ -7,6 +7,7 @@
 #include "../../include/lilliput_hip.h"
 #include "lp_engine.h"
 #include "lp_png.h"
+#include "lp_bmp.h"
 
 struct LpDevBlock {
     void* p = nullptr;
@@ -35,6 +36,8 @@ struct LpDecoder {
     const uint8_t* data = nullptr;
     size_t len = 0;
     bool is_png = false;            // which of cv::findDecoder's signatures matched
+    bool is_bmp = false;
+    LpBmpInfo bmp;
     bool parsed = false;
     int parse_rc = 0;
     LpJpegHeader hdr;

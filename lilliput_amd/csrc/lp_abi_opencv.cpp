@@ -628,15 +628,22 @@ opencv_decoder opencv_decoder_create(const opencv_mat buf)
     static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
     const bool jpeg = len >= 3 && m->data[0] == 0xFF && m->data[1] == 0xD8 && m->data[2] == 0xFF;
     const bool png = len >= 8 && memcmp(m->data, png_sig, 8) == 0;
-    if (!jpeg && !png) return NULL;
+    const bool bmp = len >= 2 && m->data[0] == 'B' && m->data[1] == 'M'; // cv::BmpDecoder's signature: the two letters, nothing more
+    if (!jpeg && !png && !bmp) return NULL;
     auto d = new LpDecoder();
     d->data = m->data;
     d->len = len;
     d->is_png = png;
+    d->is_bmp = bmp;
     return d;
 }
 
-const char* opencv_decoder_get_description(const opencv_decoder d) { return !d ? nullptr : static_cast<const LpDecoder*>(d)->is_png ? "PNG" : "JPEG"; }
+const char* opencv_decoder_get_description(const opencv_decoder d)
+{
+    if (!d) return nullptr;
+    auto p = static_cast<const LpDecoder*>(d);
+    return p->is_png ? "PNG" : p->is_bmp ? "BMP" : "JPEG";
+}
 void opencv_decoder_release(opencv_decoder d) { delete static_cast<LpDecoder*>(d); }
 
 bool opencv_decoder_read_header(opencv_decoder dd)
@@ -644,6 +651,11 @@ bool opencv_decoder_read_header(opencv_decoder dd)
     auto d = static_cast<LpDecoder*>(dd);
     if (!d) return false;
     if (d->parsed) return d->parse_rc == LP_PARSE_OK;
+    if (d->is_bmp) { // cv::BmpDecoder::readHeader
+        d->parsed = true;
+        d->parse_rc = lp_bmp_read_info(d->data, d->len, d->bmp) ? LP_PARSE_OK : LP_PARSE_NOT_JPEG;
+        return d->parse_rc == LP_PARSE_OK;
+    }
     if (d->is_png) { // cv::PngDecoder::readHeader: png_read_info, then the Mat type from colour type / tRNS / bit depth
         d->parsed = true;
         d->parse_rc = lp_png_read_info(d->data, d->len, d->png) ? LP_PARSE_OK : LP_PARSE_NOT_JPEG;
@@ -663,23 +675,24 @@ bool opencv_decoder_read_header(opencv_decoder dd)
 int opencv_decoder_get_width(const opencv_decoder dd)
 {
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png ? (int)d->png.width : (int)d->hdr.j.width;
+    return d->is_png ? (int)d->png.width : d->is_bmp ? d->bmp.width : (int)d->hdr.j.width;
 }
 int opencv_decoder_get_height(const opencv_decoder dd)
 {
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png ? (int)d->png.height : (int)d->hdr.j.height;
+    return d->is_png ? (int)d->png.height : d->is_bmp ? d->bmp.height : (int)d->hdr.j.height;
 }
 int opencv_decoder_get_pixel_type(const opencv_decoder dd)
 {
     auto d = static_cast<const LpDecoder*>(dd);
     if (d->is_png) return (d->png.depth == 16 ? 2 /* CV_16U */ : 0) + ((d->png_channels - 1) << 3); // the Go side demotes 16-bit types (opencv.go:255-257)
+    if (d->is_bmp) return (d->bmp.channels - 1) << 3; // CV_8UC1 / C3 / C4
     return d->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3;
 }
 int opencv_decoder_get_orientation(const opencv_decoder dd)
 {
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
+    return d->is_png || d->is_bmp ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
 }
 
 // cv::PngDecoder::readData into an 8-bit Mat of the announced channel count: chunk walk + inflate on the
@@ -729,6 +742,16 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     if (!d->parsed && !opencv_decoder_read_header(dd)) return false;
     if (d->parse_rc != LP_PARSE_OK) return false;
     if (d->is_png) return png_read_data(d, m);
+    if (d->is_bmp) { // cv::BmpDecoder::readData: rows unpacked on the host, straight into the Mat (lp_bmp.h)
+        const LpBmpInfo& bi = d->bmp;
+        if (m->rows != bi.height || m->cols != bi.width || cv_channels(m->type) != bi.channels || cv_depth_bytes(m->type) != 1 || !m->data) return false;
+        if (m->step < (size_t)bi.width * bi.channels) return false;
+        const bool ok = lp_bmp_read_data(d->data, d->len, bi, m->data, m->step);
+        m->dev_valid = false; // the host copy is the frame now; it reaches the device with the next opencv_* call
+        m->host_stale = false;
+        if (!ok) lp_set_error("BMP image data is damaged");
+        return ok;
+    }
     const LpJpeg& j = d->hdr.j;
     const int cn = j.ncomp == 1 ? 1 : 3;
     if (m->rows != (int)j.height || m->cols != (int)j.width || cv_channels(m->type) != cn || cv_depth_bytes(m->type) != 1) return false;
@@ -783,6 +806,16 @@ extern "C" int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t
 extern "C" uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n)
 {
     return which ? lp_crc32(seed, (const uint8_t*)p, n) : lp_adler32(seed, (const uint8_t*)p, n);
+}
+
+// Test access (no device work): cv::BmpDecoder's answer for a file -- 0 decoded (w, h, channels, pixels), 1 header refused, 2 data refused, -1 cap
+extern "C" int lilliput_hip_bmp_decode(const void* data, size_t len, int* w, int* h, int* channels, uint8_t* out, size_t cap)
+{
+    LpBmpInfo bi;
+    if (!lp_bmp_read_info((const uint8_t*)data, len, bi)) return 1;
+    *w = bi.width; *h = bi.height; *channels = bi.channels;
+    if ((size_t)bi.width * bi.height * bi.channels > cap) return -1;
+    return lp_bmp_read_data((const uint8_t*)data, len, bi, out, (size_t)bi.width * bi.channels) ? 0 : 2;
 }
 
 // ---- encoder (opencv.cpp:173-194)

@@ -198,6 +198,7 @@ static bool is_other_format(const uint8_t* sp, size_t len)
     static const uint8_t png_sig[8] = {0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A};
     return sp && ((len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
                   (len >= 8 && memcmp(sp, png_sig, 8) == 0) ||
+                  (len >= 2 && sp[0] == 'B' && sp[1] == 'M') || // what cv::findDecoder takes for a BMP: the OpenCV decoder's path (lp_bmp.h)
                   (len >= 12 && memcmp(sp, "RIFF", 4) == 0 && memcmp(sp + 8, "WEBP", 4) == 0) || // isWebp, lilliput.go:104-115
                   (len >= sizeof(lilliput_hip_pixels_header) && memcmp(sp, LILLIPUT_HIP_PIXELS_MAGIC, 8) == 0)); // frames a host decoder handed over
 }

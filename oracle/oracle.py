@@ -72,6 +72,28 @@ def ref_cv():
 _refmeta = None
 
 
+def ref_bmp():
+    """oracle/_ref/librefbmp.so: the reference's own cv::BmpDecoder (None when not built)."""
+    return _load("_ref/librefbmp.so")
+
+
+def ref_bmp_decode(data):
+    """cv::BmpDecoder on a file, the way opencv_decoder_read_header / _read_data drive it: (pixels [h, w, channels], None) when it
+    decodes, (None, 1) when readHeader refuses the file, (None, 2) when readData fails."""
+    L = ref_bmp()
+    data = bytes(data)
+    w, h, t = C.c_int(), C.c_int(), C.c_int()
+    cap = 1 << 26
+    out = np.zeros(cap, dtype=np.uint8)
+    L.ref_bmp_decode.restype = C.c_int
+    L.ref_bmp_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    r = L.ref_bmp_decode(data, len(data), C.byref(w), C.byref(h), C.byref(t), out.ctypes.data, cap)
+    if r == 0:
+        cn = (t.value >> 3) + 1
+        return out[: w.value * h.value * cn].reshape(h.value, w.value, cn).copy(), None
+    return None, r
+
+
 def ref_meta():
     """The reference's libjpeg-turbo / libpng metadata readers (ICC, cICP), or None when not built."""
     global _refmeta
@@ -648,6 +670,9 @@ def transform_any_frame(data, width, height, resize_method=FIT):
         return transform_static(px, orientation, width, height, resize_method, False)
     if d[:8] == b"\x89PNG\r\n\x1a\n":
         px = ref_png_decode(d) if ref_png() is not None else None
+        return None if px is None else transform_static(px, 1, width, height, resize_method, False)
+    if d[:2] == b"BM":
+        px = ref_bmp_decode(d)[0] if ref_bmp() is not None else None
         return None if px is None else transform_static(px, 1, width, height, resize_method, False)
     if d[:4] == b"RIFF" and d[8:12] == b"WEBP":
         fr = ref_webp_frames(d) if ref_webp() is not None else None
