@@ -580,15 +580,13 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     const uint32_t left = ic.total_blocks > prefix.nblk ? ic.total_blocks - prefix.nblk : 0u; // blocks this lane may still write
     int32_t left_bc = (int32_t)(left << 5); // ... as a bound on L.bc; lowered to "the block at hand" once the lane is past its end (below)
     const uint32_t stream_end = end_p < ic.total_bits ? end_p : ic.total_bits;
+    static_assert(M::kEvery == 2 && LP_FLUSH_EVERY == 4, "the step groups of the WRITE loop are written out for a top-up every second and a flush every fourth step");
     bool done = false;
-    uint32_t written = 0, iter = 0;
+    uint32_t written = 0;
     int32_t nlim = L.limit(stream_end);
     bool live = true;
-    do {
-        if ((iter & (M::kEvery - 1)) == M::kEvery - 1) { LP_KEEP_UNIFORM_BRANCH(); m.topup(L.pos()); }
-        if ((iter % LP_FLUSH_EVERY) == LP_FLUSH_EVERY - 1) sink.flush();
+    auto one_step = [&] {
         uint32_t pk = L.peek();
-        iter++;
         const bool act = !done && !sink.stalled();
         bool go = act;
         // slow path: the lane is at / past the end of its subsequence or of the stream, near a restart boundary, or out of blocks
@@ -622,7 +620,18 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
             sink.end_block(L.bc, bd);
             written += bd ? 1u : 0u;
         }
-    } while (live);
+    };
+    // groups of four steps: a ring top-up before the second and the fourth, a flush before the fourth (the order the one-step loop
+    // with its tests of the iteration count had); whether anyone is still working is looked at once per group
+    while (live) {
+        one_step();
+        m.topup(L.pos());
+        one_step();
+        one_step();
+        m.topup(L.pos());
+        sink.flush();
+        one_step();
+    }
     sink.flush();
     sink.finish();
     return written;

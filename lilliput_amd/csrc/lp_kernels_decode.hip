@@ -896,7 +896,11 @@ __device__ __forceinline__ void idct_wave_sync()
 #endif
 }
 
-#define IDCT_TPW 8
+#ifndef IDCT_TPW
+#define IDCT_TPW 16     // tiles of 32 blocks a workgroup walks along a block row (16 = a whole 4096-pixel luma row). The kernel is bound by
+                        // how long its waves live against the rate they are dispatched at: 4 / 8 / 16 tiles -> 22.8 / 18.2 / 13.6 us per
+                        // 4096 x 4096 image (scripts/r03_run18.sh); taking several block rows per workgroup on top of that gains nothing
+#endif
 #ifndef IDCT_AHEAD
 #define IDCT_AHEAD 4      // divides IDCT_TPW
 #endif
