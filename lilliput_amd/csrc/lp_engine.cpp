@@ -578,7 +578,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // 128 k lanes = two waves per SIMD: the 32-image chunks of the ingest pipeline decode with 8 192-bit subsequences (measured
         // 11.05 k against 10.8 k images/s end to end), the 112-image chunks of a resident batch keep 16 384
         static const uint32_t want_lanes = getenv("LILLIPUT_HIP_LAT_LANES") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_LAT_LANES")) : 131072u;
-        static const uint32_t min_S = getenv("LILLIPUT_HIP_MIN_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_MIN_S")) : 1024u;
+        // (floor: 512 / 1 024 / 2 048 / 4 096 / 8 192 bits -> 2.28 / 1.95 / 1.52 / 1.79 / 2.33 ms for one 4096 x 4096 Transform through the
+        // one-image ABI, 1.45 / 1.50 / 1.23 / 1.62 / 1.63 ms for a 1300 x 1942 one: below 2 048 the verify rounds outgrow what the
+        // shorter walks save)
+        static const uint32_t min_S = getenv("LILLIPUT_HIP_MIN_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_MIN_S")) : 2048u;
         uint64_t bits = 0;
         for (auto& j : h_imgs_) bits += (uint64_t)j.raw_len * 8;
         // A deferred decode (the chunks of the ingest pipeline) has a fixed number of verify rounds queued behind it and pays for a
