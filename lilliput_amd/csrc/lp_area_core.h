@@ -1,0 +1,187 @@
+// Fractional INTER_AREA straight from 4:2:0 planes: one destination pixel of cv::resize's resizeArea_ (resize.cpp ResizeArea_Invoker:
+// a row buffer of alpha-weighted sums per source row, then beta-weighted into the destination row; all in float, in tap order), with
+// the source pixel produced on the fly from the decoded planes -- jdsample.c h2v2_fancy_upsample, then jdcolor.c ycc_rgb_convert in
+// BGR order -- instead of read from a materialised BGR frame. The arithmetic and its order are k_ycc_to_frame_420's followed by
+// k_resize_area3's, so the bytes are the same as the frame route's.
+//
+// Host + device: the device kernel (lp_kernels_pixel.hip k_area_420) and the CPU-side test hook (lilliput_hip_area420_host, which lets
+// the tests compare this restated order of operations with the oracle without a GPU) both instantiate lp_area420_pixel.
+#pragma once
+#include <cstdint>
+#include "lp_types.h"
+
+#if defined(__HIPCC__)
+#define LPA_HD __host__ __device__ __forceinline__
+#else
+#define LPA_HD inline
+#endif
+
+// One image's share of the work: orientation 1-4 only (a tap index of the oriented frame maps to source column x0 + xstep * si
+// and source row y0 + ystep * si; the transposing orientations walk source columns per destination row and keep the frame route).
+struct LpArea420Op {
+    uint32_t img;                       // index into the LpJpeg array of the current decode range
+    int32_t x0, y0, xstep, ystep;
+    uint32_t xtab_off, ytab_off;        // into the tap arena
+    uint32_t xrange_off, yrange_off;    // into the range arena: [dw + 1] / [dh + 1] tap ranges
+    uint32_t maxt;                      // 6 / 10 / 18 / 34 / 66: which instantiation takes it
+    uint32_t pad;
+    LpFrame dst;
+};
+
+struct LpAreaPlanes {
+    const uint8_t* py; const uint8_t* pb; const uint8_t* pr;
+    uint32_t sy, sc;                    // plane strides (luma, chroma)
+    int32_t dw, dh;                     // chroma size that jdsample.c works on: ceil(W / 2), ceil(H / 2)
+};
+
+LPA_HD uint32_t lpa_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) // bytes of {hi:lo} from bit sh (0 / 8 / 16 / 24)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+#endif
+}
+template <int B> LPA_HD uint32_t lpa_pair(uint32_t wr, uint32_t wb) // {Cb = byte B of wb, Cr = byte B of wr} in the two halves
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(wr, wb, 0x0c000c00u | ((4u + B) << 16) | (uint32_t)B);
+#else
+    return ((wb >> (8 * B)) & 255u) | (((wr >> (8 * B)) & 255u) << 16);
+#endif
+}
+LPA_HD int32_t lpa_clamp(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
+LPA_HD float lpa_mul(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmul_rn(a, b);
+#else
+    return a * b; // built with -ffp-contract=off
+#endif
+}
+LPA_HD float lpa_add(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fadd_rn(a, b);
+#else
+    return a + b;
+#endif
+}
+LPA_HD uint32_t lpa_round_u8(float v) // saturate_cast<uchar>(float): cvRound (half to even), then clamp
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t i = __float2int_rn(v);
+#else
+    const int32_t i = (int32_t)__builtin_lrintf(v);
+#endif
+    return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
+}
+
+#define LPA_FIX16(x) ((int32_t)((x)*65536.0 + 0.5))
+
+// MAXT = taps per axis the instantiation covers (a destination column with fewer carries weight 0 in the rest, which adds exactly
+// 0); FLIPX: tap k reads the column MAXT-1-k of [xa, xa + MAXT) (orientations 2 and 3) -- the sums still run in tap order.
+//   xa     leftmost source column the taps can reach; columns outside [0, W) only ever meet weight 0
+//   al[k]  x weights in tap order
+//   yt, y0..y1, ybase, ystep  the destination row's taps: source row = ybase + ystep * yt[j].si
+// The window the kernel walks starts at the even column xa & ~1 and is MAXT + 1 wide, so that which chroma column and which
+// neighbour a window column uses is known at compile time; the weights are shifted by xa's parity instead (one more weight-0 term
+// at one end of the sum).
+template <int MAXT, bool FLIPX>
+LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al)[MAXT], const LpTap* __restrict__ yt, uint32_t y0, uint32_t y1,
+                             int32_t ybase, int32_t ystep, uint8_t* __restrict__ out)
+{
+    static_assert(MAXT % 2 == 0, "even tap counts only");
+    constexpr int NX = MAXT + 1;                    // window columns
+    constexpr int NWY = (NX + 3) / 4;               // luma dwords of the window (after the byte-phase fix-up)
+    constexpr int NC = MAXT / 2 + 2;                // chroma columns: the window's own MAXT / 2 + 1 and a neighbour either side
+    constexpr int NWC = (NC + 3) / 4;
+    const int32_t odd = xa & 1, xe = xa - odd;
+    // weight of window column c: tap k sits at column k + odd (FLIPX: MAXT - 1 - k + odd)
+    float w[NX];
+#pragma unroll
+    for (int c = 0; c < NX; c++) {
+        const float w0 = c < MAXT ? al[FLIPX ? MAXT - 1 - c : c] : 0.f;   // xa even
+        const float w1 = c >= 1 ? al[FLIPX ? MAXT - c : c - 1] : 0.f;     // xa odd
+        w[c] = odd ? w1 : w0;
+    }
+    // dword offsets inside a plane row, clamped into the row: a clamped dword only feeds columns outside the image
+    int32_t oy[NWY + 1], oc[NWC + 1];
+    const int32_t xo = xe & ~3, c_lo = (xe >> 1) - 1, co = c_lo & ~3;
+    const uint32_t shy = (uint32_t)(xe & 3) * 8, shc = (uint32_t)(c_lo & 3) * 8;
+#pragma unroll
+    for (int i = 0; i <= NWY; i++) oy[i] = lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
+#pragma unroll
+    for (int i = 0; i <= NWC; i++) oc[i] = lpa_clamp(co + 4 * i, 0, (int32_t)P.sc - 4);
+    // jdsample.c replicates the first and the last chroma column (of downsampled_width, not of the padded plane): window index
+    // il stands for column -1, ir for column dw. Columns further out are only reached by weight-0 taps.
+    const int32_t il = -1 - c_lo, ir = P.dw - c_lo;
+    const bool edge = il >= 0 || ir < NC;
+    const int32_t KR = 32768 - 128 * LPA_FIX16(1.40200), KB = 32768 - 128 * LPA_FIX16(1.77200);
+    const int32_t KG = 32768 + 128 * LPA_FIX16(0.34414) + 128 * LPA_FIX16(0.71414);
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (uint32_t j = y0; j < y1; j++) {
+        const float beta = yt[j].alpha;
+        const int32_t sy = ybase + ystep * (int32_t)yt[j].si;
+        const int32_t cy = sy >> 1;
+        const int32_t ny = lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1);
+        const uint8_t* ry = P.py + (size_t)sy * P.sy;
+        const uint8_t* b0 = P.pb + (size_t)cy * P.sc; const uint8_t* b1 = P.pb + (size_t)ny * P.sc;
+        const uint8_t* r0 = P.pr + (size_t)cy * P.sc; const uint8_t* r1 = P.pr + (size_t)ny * P.sc;
+        uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
+#pragma unroll
+        for (int i = 0; i <= NWY; i++) wy[i] = *reinterpret_cast<const uint32_t*>(ry + oy[i]);
+#pragma unroll
+        for (int i = 0; i <= NWC; i++) {
+            wb0[i] = *reinterpret_cast<const uint32_t*>(b0 + oc[i]); wb1[i] = *reinterpret_cast<const uint32_t*>(b1 + oc[i]);
+            wr0[i] = *reinterpret_cast<const uint32_t*>(r0 + oc[i]); wr1[i] = *reinterpret_cast<const uint32_t*>(r1 + oc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], shy);
+#pragma unroll
+        for (int i = 0; i < NWC; i++) {
+            wb0[i] = lpa_alignbit(wb0[i + 1], wb0[i], shc); wb1[i] = lpa_alignbit(wb1[i + 1], wb1[i], shc);
+            wr0[i] = lpa_alignbit(wr0[i + 1], wr0[i], shc); wr1[i] = lpa_alignbit(wr1[i + 1], wr1[i], shc);
+        }
+        // vertical half of the upsampler, {Cb, Cr} packed in the halves of one register: 3 * nearer row + further row (<= 1020)
+        uint32_t V[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            uint32_t a, b;
+            switch (i & 3) {
+            case 0: a = lpa_pair<0>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<0>(wr1[i >> 2], wb1[i >> 2]); break;
+            case 1: a = lpa_pair<1>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<1>(wr1[i >> 2], wb1[i >> 2]); break;
+            case 2: a = lpa_pair<2>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<2>(wr1[i >> 2], wb1[i >> 2]); break;
+            default: a = lpa_pair<3>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<3>(wr1[i >> 2], wb1[i >> 2]); break;
+            }
+            V[i] = 3u * a + b;
+        }
+        if (edge) {
+#pragma unroll
+            for (int i = 0; i + 1 < NC; i++) V[i] = i == il ? V[i + 1] : V[i];
+#pragma unroll
+            for (int i = 1; i < NC; i++) V[i] = i == ir ? V[i - 1] : V[i];
+        }
+        float buf[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NX; t++) {
+            const int c = FLIPX ? NX - 1 - t : t;   // window column, in tap order
+            // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right (bias 7), even ones with
+            // the one to the left (bias 8) -- h2v2_fancy_upsample's horizontal half on the vertical sums: (3 * near + far + bias) >> 4
+            const int ic = c / 2 + 1;
+            const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + ((c & 1) ? 0x00070007u : 0x00080008u);
+            const int32_t cb = (int32_t)((h >> 4) & 0xfffu), cr = (int32_t)(h >> 20);
+            const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
+            const int32_t r = lpa_clamp(yy + ((LPA_FIX16(1.40200) * cr + KR) >> 16), 0, 255);
+            const int32_t b = lpa_clamp(yy + ((LPA_FIX16(1.77200) * cb + KB) >> 16), 0, 255);
+            const int32_t g = lpa_clamp(yy + ((-LPA_FIX16(0.34414) * cb - LPA_FIX16(0.71414) * cr + KG) >> 16), 0, 255);
+            buf[0] = lpa_add(buf[0], lpa_mul((float)b, w[c]));
+            buf[1] = lpa_add(buf[1], lpa_mul((float)g, w[c]));
+            buf[2] = lpa_add(buf[2], lpa_mul((float)r, w[c]));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) sum[c] = lpa_add(sum[c], lpa_mul(beta, buf[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[c] = (uint8_t)lpa_round_u8(sum[c]);
+}

@@ -17,6 +17,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "lp_abi.h"
@@ -370,6 +371,22 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
     double t_prev = now();
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
     {
+        // How an image gets from planes to its output size: 1 = integer-scale area resize, fused (k_resample_*); 2 = fractional area
+        // resize of a YCbCr 4:2:0 image in a row-wise orientation, fused (k_area_420; LILLIPUT_HIP_AREA_FUSED=0 sends these through
+        // the frame as before round 3); 0 = through a materialised BGR frame, exactly like the one-image ABI.
+        static const bool area_on = !(getenv("LILLIPUT_HIP_AREA_FUSED") && atoi(getenv("LILLIPUT_HIP_AREA_FUSED")) == 0);
+        std::map<std::pair<int, int>, uint32_t> bucket_cache;
+        auto route_of = [&](const LpJpeg& j, const LpOpsPlan& plan) -> int {
+            if (!plan.resize || j.ncomp == 4 || j.generic_sampling) return 0; // CMYK / YCCK, unusual sampling factors: the fused kernels read grey / YCbCr / RGB planes
+            int ix, iy;
+            const int mode = lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
+            if (mode == 1) return 1;
+            if (mode != 2 || !area_on || j.orientation > 4 || !(j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4)) return 0;
+            const auto key = std::make_pair(plan.crop_w, plan.out_w);
+            auto it = bucket_cache.find(key);
+            if (it == bucket_cache.end()) it = bucket_cache.emplace(key, lp_area420_bucket(plan.crop_w, plan.out_w)).first;
+            return it->second ? 2 : 0;
+        };
         // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
         size_t need = 0;
         for (int k = 0; k < cnt; k++) {
@@ -378,8 +395,7 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
             const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
             LpOpsPlan plan = lp_plan_static_transform((int)j.width, (int)j.height, (int)j.orientation, opt->width, opt->height, opt->resize_method,
                                                       opt->normalize_orientation != 0, OW, OH);
-            int ix, iy;
-            const bool fused = plan.resize && j.ncomp != 4 && !j.generic_sampling && lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) == 1;
+            const bool fused = route_of(j, plan) != 0;
             const size_t cn = j.ncomp == 1 ? 1 : 3, fb = (size_t)j.width * j.height * cn;
             if (!fused) need += fb + 512 + (j.orientation != 1 ? fb + 512 : 0);
             if (plan.resize) need += (size_t)plan.out_w * plan.out_h * cn + 512;
@@ -395,6 +411,8 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
         std::vector<LpOpsPlan> plans((size_t)cnt);
         std::vector<LpFusedOp> fops;
         std::vector<int> fidx;
+        std::vector<LpAreaReq> areqs;
+        std::vector<int> aidx;
         memset(frames.data(), 0, sizeof(LpFrame) * (size_t)cnt);
         for (int k = 0; k < cnt; k++) {
             const LpJpeg& j = hdrs[k].j;
@@ -404,8 +422,28 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
                                                       opt->normalize_orientation != 0, OW, OH);
             plans[(size_t)k] = plan;
             int ix = 1, iy = 1;
-            if (j.ncomp == 4 || j.generic_sampling) continue; // CMYK / YCCK, unusual sampling factors: converted to a BGR frame first (the fused kernels read grey / YCbCr / RGB planes)
-            if (!plan.resize || lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy) != 1) continue;
+            const int route = route_of(j, plan);
+            if (route == 0) continue;
+            if (route == 2) {
+                // oriented-frame column ox is source column ox (orientations 1, 4) or W - 1 - ox (2, 3); rows likewise (3, 4 flip)
+                const bool fx = j.orientation == 2 || j.orientation == 3, fy = j.orientation == 3 || j.orientation == 4;
+                LpAreaReq rq;
+                memset(&rq, 0, sizeof(rq));
+                rq.img = (uint32_t)k;
+                rq.x0 = fx ? (int)j.width - 1 - plan.crop_x : plan.crop_x; rq.xstep = fx ? -1 : 1;
+                rq.y0 = fy ? (int)j.height - 1 - plan.crop_y : plan.crop_y; rq.ystep = fy ? -1 : 1;
+                rq.crop_w = (uint32_t)plan.crop_w; rq.crop_h = (uint32_t)plan.crop_h;
+                rq.dst.w = (uint32_t)plan.out_w; rq.dst.h = (uint32_t)plan.out_h; rq.dst.cn = 3;
+                rq.dst.stride = rq.dst.w * 3;
+                uint8_t* p = eng.heap_alloc((size_t)rq.dst.stride * rq.dst.h);
+                if (!p) return fail("frame heap exhausted");
+                rq.dst.off = (uint64_t)(uintptr_t)p;
+                areqs.push_back(rq);
+                aidx.push_back(k);
+                want[(size_t)k] = 0;
+                continue;
+            }
+            lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
             // oriented-frame rectangle of destination (dx, dy) -> rectangle of the un-oriented decoded image (cv::ExifTransform inverse)
             auto map = [&](int dx, int dy, int* fx, int* fy) {
                 const int ox0 = plan.crop_x + dx * ix, oy0 = plan.crop_y + dy * iy;
@@ -451,6 +489,10 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
         if (!fops.empty()) {
             if (eng.fused_resample(fops.data(), (int)fops.size())) return fail(eng.last_error());
             for (size_t q = 0; q < fops.size(); q++) final_frames[(size_t)fidx[q]] = fops[q].dst;
+        }
+        if (!areqs.empty()) {
+            if (eng.area_resample(areqs.data(), (int)areqs.size(), !fops.empty())) return fail(eng.last_error());
+            for (size_t q = 0; q < areqs.size(); q++) final_frames[(size_t)aidx[q]] = areqs[q].dst;
         }
         lap(2);
         // orientation (ops.go:392: unconditional) for the images that kept a frame
@@ -545,7 +587,7 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
                 for (int k = 0; k < cnt; k++) if (dst[(size_t)k]) st[(size_t)k] = dst[(size_t)k];
                 deferred = false;
             }
-            if (!fops.empty()) acc[4] += eng.fused_resample_ms();
+            if (!fops.empty() || !areqs.empty()) acc[4] += eng.fused_resample_ms();
             for (size_t q = 0; q < erq.size(); q++) {
                 const int k = eidx[q];
                 const size_t item = (size_t)item_of[k];

@@ -182,7 +182,7 @@ size_t LpEngine::device_bytes() const
     for (const LpUpload& u : up_) n += u.d_raw.cap + u.d_huffs.cap + u.d_phuffs.cap;
     for (const LpDevBuf* b : {&d_imgs_, &d_states_, &d_clean_, &d_rst_, &d_chunk_, &d_ckpt_, &d_exit_, &d_spec_exit_, &d_entry_, &d_tot_, &d_spec_tot_, &d_prefix_, &d_changed_,
                               &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &heap_,
-                              &d_ops_, &d_taps_, &d_ranges_, &d_fops_, &d_tone_, &d_jobs_, &d_estates_, &d_ecoef_, &d_blkbits_, &d_bits_, &d_hdrs_, &d_out_, &d_packed_, &d_pkoff_})
+                              &d_ops_, &d_taps_, &d_ranges_, &d_fops_, &d_aops_, &d_ataps_, &d_aranges_, &d_tone_, &d_jobs_, &d_estates_, &d_ecoef_, &d_blkbits_, &d_bits_, &d_hdrs_, &d_out_, &d_packed_, &d_pkoff_})
         n += b->cap;
     return n;
 }
@@ -1170,6 +1170,130 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
     tm_.resize_ms = 0;
     fused_timed_ = timing_;
     return LP_OK;
+}
+
+static uint32_t area_bucket_of(const std::vector<LpTap>& taps, const std::vector<uint32_t>& ranges, uint32_t tab_off, uint32_t range_off, uint32_t dsize)
+{
+    uint32_t mx = 0;
+    for (uint32_t d = 0; d < dsize; d++) {
+        const uint32_t t0 = ranges[range_off + d], t1 = ranges[range_off + d + 1];
+        if (t1 <= t0) return 0;
+        mx = std::max(mx, t1 - t0);
+        for (uint32_t k = t0 + 1; k < t1; k++)
+            if (taps[tab_off + k].si != taps[tab_off + k - 1].si + 1) return 0;
+    }
+    return mx <= 6 ? 6u : mx <= 10 ? 10u : mx <= 18 ? 18u : mx <= 34 ? 34u : mx <= 66 ? 66u : 0u;
+}
+
+uint32_t lp_area420_bucket(int ssize, int dsize)
+{
+    if (ssize <= 0 || dsize <= 0 || dsize >= ssize) return 0;
+    std::vector<LpTap> taps;
+    std::vector<uint32_t> ranges;
+    lp_area_tab(ssize, dsize, taps, ranges);
+    return area_bucket_of(taps, ranges, 0, 0, (uint32_t)dsize);
+}
+
+int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
+{
+    if (!ok_) return LP_ERR_DEVICE;
+    if (n <= 0) return LP_OK;
+    std::vector<LpArea420Op>& ops = h_aops_; // these three stay alive: the copies below are not waited for
+    std::vector<LpTap>& taps = h_ataps_;
+    std::vector<uint32_t>& ranges = h_aranges_;
+    ops.assign((size_t)n, LpArea420Op{});
+    taps.clear();
+    ranges.clear();
+    std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> cache; // (ssize, dsize) -> (tap_off, range_off)
+    uint32_t mask = 0, mdw = 0, mdh = 0;
+    for (int i = 0; i < n; i++) {
+        const LpAreaReq& r = reqs[i];
+        const LpJpeg& j = h_imgs_[r.img];
+        LpArea420Op& op = ops[(size_t)i];
+        if (!(j.ncomp == 3 && !j.generic_sampling && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4) || (r.xstep != 1 && r.xstep != -1) ||
+            (r.ystep != 1 && r.ystep != -1) || !r.dst.off || !r.dst.w || !r.dst.h) {
+            err_ = "area_resample: not a YCbCr 4:2:0 image / not a row-wise orientation";
+            return LP_ERR_DEVICE;
+        }
+        op.img = r.img; op.x0 = r.x0; op.y0 = r.y0; op.xstep = r.xstep; op.ystep = r.ystep;
+        op.dst = r.dst; op.dst.cn = 3;
+        if (!op.dst.stride) op.dst.stride = r.dst.w * 3;
+        const auto kx = std::make_pair((int)r.crop_w, (int)r.dst.w), ky = std::make_pair((int)r.crop_h, (int)r.dst.h);
+        for (int ax = 0; ax < 2; ax++) {
+            const auto key = ax ? ky : kx;
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                const uint32_t to = (uint32_t)taps.size(), ro = (uint32_t)ranges.size();
+                lp_area_tab(key.first, key.second, taps, ranges);
+                it = cache.emplace(key, std::make_pair(to, ro)).first;
+            }
+            if (ax) { op.ytab_off = it->second.first; op.yrange_off = it->second.second; }
+            else { op.xtab_off = it->second.first; op.xrange_off = it->second.second; }
+        }
+        op.maxt = area_bucket_of(taps, ranges, op.xtab_off, op.xrange_off, r.dst.w);
+        if (!op.maxt) { err_ = "area_resample: no kernel for this many taps"; return LP_ERR_DEVICE; }
+        const uint32_t bit = op.maxt == 6 ? 0u : op.maxt == 10 ? 1u : op.maxt == 18 ? 2u : op.maxt == 34 ? 3u : 4u;
+        mask |= 1u << (bit + (r.xstep < 0 ? 5u : 0u));
+        mdw = std::max(mdw, r.dst.w);
+        mdh = std::max(mdh, r.dst.h);
+    }
+    if (!d_aops_.ensure(sizeof(LpArea420Op) * (size_t)n) || !d_ataps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_aranges_.ensure(4 * ranges.size() + 64))
+        return LP_ERR_DEVICE;
+    if (!h2d_small(d_aops_.p, ops.data(), sizeof(LpArea420Op) * (size_t)n) || !h2d_small(d_ataps_.p, taps.data(), sizeof(LpTap) * taps.size()) ||
+        !h2d_small(d_aranges_.p, ranges.data(), 4 * ranges.size()))
+        return LP_ERR_DEVICE;
+    if (timing_ && !(after_fused && fused_timed_)) (void)hipEventRecord(ev_[11], stream_); // behind a fused_resample: its start event stands
+    lp_launch_area_420(stream_, d_imgs_.as<LpJpeg>(), d_aops_.as<LpArea420Op>(), (uint32_t)n, mask, mdw, mdh, d_ataps_.as<LpTap>(), d_aranges_.as<uint32_t>(),
+                       d_planes_.as<uint8_t>());
+    if (timing_) (void)hipEventRecord(ev_[7], stream_);
+    if (!check(hipGetLastError(), "area resample kernel")) return LP_ERR_DEVICE;
+    tm_.resize_ms = 0;
+    fused_timed_ = timing_;
+    return LP_OK;
+}
+
+// Test access: lp_area420_pixel on the host (what k_area_420 runs per thread), so that the order of operations can be compared with
+// the oracle without a GPU. Not a product path: nothing in the library calls it.
+template <int MAXT, bool FLIPX>
+static void area420_host_run(const LpAreaPlanes& P, const LpArea420Op& op, const std::vector<LpTap>& taps, const std::vector<uint32_t>& ranges, uint8_t* out)
+{
+    for (uint32_t dy = 0; dy < op.dst.h; dy++)
+        for (uint32_t dx = 0; dx < op.dst.w; dx++) {
+            const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
+            const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
+            const LpTap* xt = taps.data() + op.xtab_off + x0;
+            float al[MAXT];
+            for (int k = 0; k < MAXT; k++) al[k] = (uint32_t)k < x1 - x0 ? xt[k].alpha : 0.f;
+            const int32_t si0 = (int32_t)xt[0].si;
+            const int32_t xa = FLIPX ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
+            lp_area420_pixel<MAXT, FLIPX>(P, xa, al, taps.data() + op.ytab_off, y0, y1, op.y0, op.ystep, out + ((size_t)dy * op.dst.w + dx) * 3);
+        }
+}
+
+extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h,
+                                         int orientation, int crop_x, int crop_y, int crop_w, int crop_h, int dst_w, int dst_h, uint8_t* out)
+{
+    if (orientation < 1 || orientation > 4 || w <= 4 || (stride_y & 3) || (stride_c & 3)) return 1;
+    int ix, iy;
+    if (lp_resize_mode(crop_w, crop_h, dst_w, dst_h, &ix, &iy) != 2) return 1;
+    std::vector<LpTap> taps;
+    std::vector<uint32_t> ranges;
+    LpArea420Op op{};
+    op.xtab_off = 0; op.xrange_off = 0;
+    lp_area_tab(crop_w, dst_w, taps, ranges);
+    op.ytab_off = (uint32_t)taps.size(); op.yrange_off = (uint32_t)ranges.size();
+    lp_area_tab(crop_h, dst_h, taps, ranges);
+    op.maxt = area_bucket_of(taps, ranges, 0, 0, (uint32_t)dst_w);
+    if (!op.maxt) return 1;
+    const bool fx = orientation == 2 || orientation == 3, fy = orientation == 3 || orientation == 4;
+    op.x0 = fx ? w - 1 - crop_x : crop_x; op.xstep = fx ? -1 : 1;
+    op.y0 = fy ? h - 1 - crop_y : crop_y; op.ystep = fy ? -1 : 1;
+    op.dst.w = (uint32_t)dst_w; op.dst.h = (uint32_t)dst_h;
+    LpAreaPlanes P{py, pb, pr, stride_y, stride_c, (w + 1) >> 1, (h + 1) >> 1};
+#define LP_AREA_HOST(T) case T: if (fx) area420_host_run<T, true>(P, op, taps, ranges, out); else area420_host_run<T, false>(P, op, taps, ranges, out); break
+    switch (op.maxt) { LP_AREA_HOST(6); LP_AREA_HOST(10); LP_AREA_HOST(18); LP_AREA_HOST(34); LP_AREA_HOST(66); default: return 1; }
+#undef LP_AREA_HOST
+    return 0;
 }
 
 float LpEngine::fused_resample_ms()

@@ -21,6 +21,7 @@
 #include "lp_prog_host.h"
 #include "lp_launch.h"
 #include "lp_types.h"
+#include "lp_area_core.h"
 
 // Frees the blocks that growing arenas have retired (see LpDevBuf::ensure in lp_engine.cpp); called at the end of a batch / node call.
 void lp_retired_collect();
@@ -62,6 +63,15 @@ struct LpResizeReq {
     LpFrame src;                // full source frame
     uint32_t crop_x, crop_y, crop_w, crop_h;
     uint32_t dst_w, dst_h;
+};
+
+// One image of area_resample: the oriented crop (crop_w x crop_h, its tap index si at source column x0 + xstep * si and source row
+// y0 + ystep * si of the decoded planes) -> dst (BGR; off = where to write, w / h = the size asked for).
+struct LpAreaReq {
+    uint32_t img;
+    int32_t x0, y0, xstep, ystep;
+    uint32_t crop_w, crop_h;
+    LpFrame dst;
 };
 
 struct LpEncodeReq {
@@ -163,6 +173,9 @@ public:
     float fused_resample_ms();                   // device time of the last fused_resample (waits for it)
     // planes of the current decode range -> thumbnails, see LpFusedOp
     int fused_resample(const LpFusedOp* ops, int n);
+    // planes of the current decode range -> fractional INTER_AREA thumbnails (lp_area_core.h); enqueued like fused_resample and, when
+    // both are used, AFTER it (fused_resample_ms then covers both). Every request must have passed lp_area420_bucket.
+    int area_resample(const LpAreaReq* reqs, int n, bool after_fused = false);
     size_t uploaded_count() const { return u_->src.size(); }
     const LpJpeg& uploaded(size_t i) const { return u_->src[i]; }
     // stage-level read-back for parity tests (valid after a decode of the current range)
@@ -256,6 +269,10 @@ private:
 
     // resize / orient
     LpDevBuf d_ops_, d_taps_, d_ranges_, d_fops_;
+    LpDevBuf d_aops_, d_ataps_, d_aranges_;     // area_resample: ops, tap and range arenas (their own: the kernel is not waited for)
+    std::vector<LpArea420Op> h_aops_;
+    std::vector<LpTap> h_ataps_;
+    std::vector<uint32_t> h_aranges_;
     LpDevBuf d_tone_;           // staging for the host-pointer tone-map entry points
     // encode
     std::vector<LpEncJob> h_jobs_;
@@ -272,3 +289,6 @@ void lp_encode_init_tables();
 // cv::resize(INTER_AREA) dispatch arithmetic (mode, integer scales) -- shared with tests.
 int lp_resize_mode(int sw, int sh, int dw, int dh, int* iscale_x, int* iscale_y);
 int lp_area_tab(int ssize, int dsize, std::vector<LpTap>& taps, std::vector<uint32_t>& ranges);
+// k_area_420's instantiation for an x axis ssize -> dsize (6 / 10 / 18 / 34 / 66 taps), 0 = none (more taps, or a table whose
+// columns are not runs of consecutive source columns)
+uint32_t lp_area420_bucket(int ssize, int dsize);

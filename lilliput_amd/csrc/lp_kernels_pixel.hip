@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <stdint.h>
 
+#include "lp_area_core.h"
 #include "lp_launch.h"
 #include "lp_types.h"
 
@@ -651,6 +652,37 @@ __global__ __launch_bounds__(256) void k_resize_area3(const LpResizeOp* __restri
     for (int c = 0; c < 3; c++) D[c] = (uint8_t)sat_round_u8(sum[c]);
 }
 
+// Fractional INTER_AREA straight from YCbCr 4:2:0 planes (no BGR frame in between): lp_area_core.h has the per-pixel walk -- the
+// upsampler and the colour conversion of k_ycc_to_frame_420 feeding the float sums of k_resize_area3 in the same order, so the
+// bytes equal the frame route's. One thread per destination pixel; a wave is 64 neighbouring columns of one destination row,
+// so its loads of a source row fall into one contiguous run of the luma row and of the two chroma rows. Per destination
+// pixel the frame route read and wrote 3 bytes per source pixel twice over; this reads 1.5.
+template <int MAXT, bool FLIPX>
+__global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ imgs, const LpArea420Op* __restrict__ ops, const LpTap* __restrict__ taps,
+                                                  const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ plane_arena)
+{
+    const LpArea420Op& op = ops[blockIdx.z];
+    if (op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPX) return;
+    const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= op.dst.w || dy >= op.dst.h) return;
+    const LpJpeg& img = imgs[op.img];
+    const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
+    const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
+    const LpTap* xt = taps + op.xtab_off + x0;
+    const uint32_t nx = x1 - x0;
+    float al[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) al[k] = (uint32_t)k < nx ? xt[k].alpha : 0.f;
+    const int32_t si0 = (int32_t)xt[0].si;
+    const int32_t xa = FLIPX ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
+    LpAreaPlanes P;
+    P.py = plane_arena + img.plane_off[0]; P.pb = plane_arena + img.plane_off[1]; P.pr = plane_arena + img.plane_off[2];
+    P.sy = img.plane_stride[0]; P.sc = img.plane_stride[1];
+    P.dw = (int32_t)(img.width + 1) >> 1; P.dh = (int32_t)(img.height + 1) >> 1;
+    uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
+    lp_area420_pixel<MAXT, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D);
+}
+
 // INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point
 // (resizeGeneric_<HResizeLinear, VResizeLinear<uchar,int,short,...>>).
 __global__ __launch_bounds__(256) void k_resize_linear(const LpResizeOp* __restrict__ ops, const int32_t* __restrict__ itab,
@@ -1224,6 +1256,18 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
     if (area3_mask & 16u) hipLaunchKernelGGL(k_resize_area3<66>, g2, dim3(64, 4), 0, s, d_ops, d_taps, d_ranges, d_src, d_dst);
     if (modes_present & 8u)
         hipLaunchKernelGGL(k_resize_linear, g2, dim3(64, 4), 0, s, d_ops, reinterpret_cast<const int32_t*>(d_ranges), d_src, d_dst);
+}
+
+// mask: bit b = MAXT bucket b of {6, 10, 18, 34, 66} present, +5 for the mirrored (xstep < 0) instantiation
+void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, uint32_t mask, uint32_t max_dw, uint32_t max_dh,
+                        const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes)
+{
+    if (!nops || !max_dw || !max_dh) return;
+    dim3 g((max_dw + 63) / 64, (max_dh + 3) / 4, nops);
+#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420<T, F>), g, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
+    LP_AREA_LAUNCH(0, 6, false); LP_AREA_LAUNCH(1, 10, false); LP_AREA_LAUNCH(2, 18, false); LP_AREA_LAUNCH(3, 34, false); LP_AREA_LAUNCH(4, 66, false);
+    LP_AREA_LAUNCH(5, 6, true); LP_AREA_LAUNCH(6, 10, true); LP_AREA_LAUNCH(7, 18, true); LP_AREA_LAUNCH(8, 34, true); LP_AREA_LAUNCH(9, 66, true);
+#undef LP_AREA_LAUNCH
 }
 
 void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* d_src, uint8_t* d_dst)
