@@ -50,6 +50,46 @@ template <int B> LPA_HD uint32_t lpa_pair(uint32_t wr, uint32_t wb) // {Cb = byt
     return ((wb >> (8 * B)) & 255u) | (((wr >> (8 * B)) & 255u) << 16);
 #endif
 }
+LPA_HD int32_t lpa_uniform(int32_t v) // a value every lane of the wave holds alike (the wave is one destination row): keep it in a scalar register
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+// One decoded plane as the walk reads it: an aligned dword at (row offset, lane offset). On the device a buffer resource built from
+// wave-uniform values: the row offset rides in the scalar offset, the lane's dword offset in the 32-bit vector offset, so a load costs
+// no address arithmetic (a flat load wanted a 64-bit add per load: 22 of them per source row).
+struct LpaPlane {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ uint32_t word(uint32_t row_off, uint32_t lane_off) const
+    {
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, (int)row_off, 0);
+    }
+#else
+    const uint8_t* p;
+    uint32_t word(uint32_t row_off, uint32_t lane_off) const
+    {
+        uint32_t v;
+        __builtin_memcpy(&v, p + row_off + lane_off, 4);
+        return v;
+    }
+#endif
+};
+LPA_HD LpaPlane lpa_plane(const uint8_t* p)
+{
+    LpaPlane q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(a >> 32));
+    q.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
+#else
+    q.p = p;
+#endif
+    return q;
+}
 LPA_HD int32_t lpa_clamp(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
 LPA_HD float lpa_mul(float a, float b)
 {
@@ -77,6 +117,19 @@ LPA_HD uint32_t lpa_round_u8(float v) // saturate_cast<uchar>(float): cvRound (h
     return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
 }
 
+LPA_HD int32_t lpa_mad24(int32_t a, int32_t b, int32_t c) // a * b + c, both factors within 24 bits
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // spelled out: left to itself the compiler splits the green channel's two of these into two multiplies and a three-way add
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(b), "s"(a), "v"(c));
+    return d;
+#else
+    return a * b + c;
+#endif
+}
+typedef float lpa_f2 __attribute__((ext_vector_type(2)));
+
 #define LPA_FIX16(x) ((int32_t)((x)*65536.0 + 0.5))
 
 // MAXT = taps per axis the instantiation covers (a destination column with fewer carries weight 0 in the rest, which adds exactly
@@ -91,6 +144,7 @@ template <int MAXT, bool FLIPX>
 LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al)[MAXT], const LpTap* __restrict__ yt, uint32_t y0, uint32_t y1,
                              int32_t ybase, int32_t ystep, uint8_t* __restrict__ out)
 {
+#pragma clang fp contract(off) // every product is rounded before it is added, as in resize.cpp's scalar loops
     static_assert(MAXT % 2 == 0, "even tap counts only");
     constexpr int NX = MAXT + 1;                    // window columns
     constexpr int NWY = (NX + 3) / 4;               // luma dwords of the window (after the byte-phase fix-up)
@@ -106,35 +160,37 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
         w[c] = odd ? w1 : w0;
     }
     // dword offsets inside a plane row, clamped into the row: a clamped dword only feeds columns outside the image
-    int32_t oy[NWY + 1], oc[NWC + 1];
+    uint32_t oy[NWY + 1], oc[NWC + 1]; // unsigned: scalar row address + zero-extended lane offset is one addressing mode
     const int32_t xo = xe & ~3, c_lo = (xe >> 1) - 1, co = c_lo & ~3;
     const uint32_t shy = (uint32_t)(xe & 3) * 8, shc = (uint32_t)(c_lo & 3) * 8;
 #pragma unroll
-    for (int i = 0; i <= NWY; i++) oy[i] = lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
+    for (int i = 0; i <= NWY; i++) oy[i] = (uint32_t)lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
 #pragma unroll
-    for (int i = 0; i <= NWC; i++) oc[i] = lpa_clamp(co + 4 * i, 0, (int32_t)P.sc - 4);
+    for (int i = 0; i <= NWC; i++) oc[i] = (uint32_t)lpa_clamp(co + 4 * i, 0, (int32_t)P.sc - 4);
     // jdsample.c replicates the first and the last chroma column (of downsampled_width, not of the padded plane): window index
     // il stands for column -1, ir for column dw. Columns further out are only reached by weight-0 taps.
     const int32_t il = -1 - c_lo, ir = P.dw - c_lo;
     const bool edge = il >= 0 || ir < NC;
     const int32_t KR = 32768 - 128 * LPA_FIX16(1.40200), KB = 32768 - 128 * LPA_FIX16(1.77200);
     const int32_t KG = 32768 + 128 * LPA_FIX16(0.34414) + 128 * LPA_FIX16(0.71414);
-    float sum[3] = {0.f, 0.f, 0.f};
-    for (uint32_t j = y0; j < y1; j++) {
+    const LpaPlane PY = lpa_plane(P.py), PB = lpa_plane(P.pb), PR = lpa_plane(P.pr);
+    lpa_f2 sbg = {0.f, 0.f};
+    float sum_r = 0.f;
+    // the rows are the same for the whole wave: scalar loop, scalar row addresses, per-lane offsets only
+    const uint32_t j0 = (uint32_t)lpa_uniform((int32_t)y0), j1 = (uint32_t)lpa_uniform((int32_t)y1);
+    for (uint32_t j = j0; j < j1; j++) {
         const float beta = yt[j].alpha;
         const int32_t sy = ybase + ystep * (int32_t)yt[j].si;
         const int32_t cy = sy >> 1;
         const int32_t ny = lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1);
-        const uint8_t* ry = P.py + (size_t)sy * P.sy;
-        const uint8_t* b0 = P.pb + (size_t)cy * P.sc; const uint8_t* b1 = P.pb + (size_t)ny * P.sc;
-        const uint8_t* r0 = P.pr + (size_t)cy * P.sc; const uint8_t* r1 = P.pr + (size_t)ny * P.sc;
+        const uint32_t ry = (uint32_t)sy * P.sy, rc0 = (uint32_t)cy * P.sc, rc1 = (uint32_t)ny * P.sc;
         uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
 #pragma unroll
-        for (int i = 0; i <= NWY; i++) wy[i] = *reinterpret_cast<const uint32_t*>(ry + oy[i]);
+        for (int i = 0; i <= NWY; i++) wy[i] = PY.word(ry, oy[i]);
 #pragma unroll
         for (int i = 0; i <= NWC; i++) {
-            wb0[i] = *reinterpret_cast<const uint32_t*>(b0 + oc[i]); wb1[i] = *reinterpret_cast<const uint32_t*>(b1 + oc[i]);
-            wr0[i] = *reinterpret_cast<const uint32_t*>(r0 + oc[i]); wr1[i] = *reinterpret_cast<const uint32_t*>(r1 + oc[i]);
+            wb0[i] = PB.word(rc0, oc[i]); wb1[i] = PB.word(rc1, oc[i]);
+            wr0[i] = PR.word(rc0, oc[i]); wr1[i] = PR.word(rc1, oc[i]);
         }
 #pragma unroll
         for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], shy);
@@ -162,7 +218,9 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
 #pragma unroll
             for (int i = 1; i < NC; i++) V[i] = i == ir ? V[i - 1] : V[i];
         }
-        float buf[3] = {0.f, 0.f, 0.f};
+        // blue and green travel as a pair (one v_pk_mul_f32 + one v_pk_add_f32 for the two: each half is the same IEEE multiply and add)
+        lpa_f2 bg = {0.f, 0.f};
+        float rs = 0.f;
 #pragma unroll
         for (int t = 0; t < NX; t++) {
             const int c = FLIPX ? NX - 1 - t : t;   // window column, in tap order
@@ -172,16 +230,16 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
             const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + ((c & 1) ? 0x00070007u : 0x00080008u);
             const int32_t cb = (int32_t)((h >> 4) & 0xfffu), cr = (int32_t)(h >> 20);
             const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
-            const int32_t r = lpa_clamp(yy + ((LPA_FIX16(1.40200) * cr + KR) >> 16), 0, 255);
-            const int32_t b = lpa_clamp(yy + ((LPA_FIX16(1.77200) * cb + KB) >> 16), 0, 255);
-            const int32_t g = lpa_clamp(yy + ((-LPA_FIX16(0.34414) * cb - LPA_FIX16(0.71414) * cr + KG) >> 16), 0, 255);
-            buf[0] = lpa_add(buf[0], lpa_mul((float)b, w[c]));
-            buf[1] = lpa_add(buf[1], lpa_mul((float)g, w[c]));
-            buf[2] = lpa_add(buf[2], lpa_mul((float)r, w[c]));
+            const int32_t r = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.40200), cr, KR) >> 16), 0, 255);
+            const int32_t b = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.77200), cb, KB) >> 16), 0, 255);
+            const int32_t g = lpa_clamp(yy + (lpa_mad24(-LPA_FIX16(0.34414), cb, lpa_mad24(-LPA_FIX16(0.71414), cr, KG)) >> 16), 0, 255);
+            const lpa_f2 pbg = {(float)b, (float)g}, ww = {w[c], w[c]};
+            bg = bg + pbg * ww;
+            rs = lpa_add(rs, lpa_mul((float)r, w[c]));
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) sum[c] = lpa_add(sum[c], lpa_mul(beta, buf[c]));
+        const lpa_f2 bb = {beta, beta};
+        sbg = sbg + bb * bg;
+        sum_r = lpa_add(sum_r, lpa_mul(beta, rs));
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) out[c] = (uint8_t)lpa_round_u8(sum[c]);
+    out[0] = (uint8_t)lpa_round_u8(sbg.x); out[1] = (uint8_t)lpa_round_u8(sbg.y); out[2] = (uint8_t)lpa_round_u8(sum_r);
 }
