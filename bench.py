@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct synthetic source images (seed = index), tiled to the batch when fewer")
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--orientation", type=int, default=1, choices=range(1, 9), help="EXIF orientation written into the sources (1 = the BASELINE workload; others measure the orientation folded into the resample kernels)")
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device per engine (0 = automatic)")
     ap.add_argument("--sub-bits", type=int, default=0, help="Huffman subsequence size in bits (0 = automatic)")
     ap.add_argument("--ckpt-bits", type=int, default=0, help="checkpoint spacing parameter (0 = automatic)")
@@ -264,6 +265,10 @@ def main():
     paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
     barrier()
     distinct = [open(p, "rb").read() for p in paths]
+    if args.orientation != 1:  # an APP1 / EXIF segment with that orientation right after SOI (ops.go:392 applies it unconditionally)
+        tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([args.orientation, 0, 0, 0]) + b"\x00\x00\x00\x00"
+        app1 = b"\xff\xe1" + (len(tiff) + 8).to_bytes(2, "big") + b"Exif\x00\x00" + tiff
+        distinct = [d[:2] + app1 + d[2:] for d in distinct]
     import numpy as np
 
     arena = None
@@ -428,7 +433,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU -> 256x256 JPEG q85, ImageOpsFit (BASELINE configs[1])" % (args.batch, args.size, args.size),
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU -> 256x256 JPEG q85, ImageOpsFit (BASELINE configs[1])%s" % (args.batch, args.size, args.size, "" if args.orientation == 1 else ", EXIF orientation %d" % args.orientation),
                        "timed_region": "compressed bytes resident in HBM -> thumbnails in host memory (device pipeline only)" if args.resident else
                                        "host bytes in -> host bytes out: header walk + staging + H2D + decode/resample/encode + D2H (lilliput_hip_batch_transform)",
                        "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out),

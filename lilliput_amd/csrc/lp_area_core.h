@@ -16,15 +16,15 @@
 #define LPA_HD inline
 #endif
 
-// One image's share of the work: orientation 1-4 only (a tap index of the oriented frame maps to source column x0 + xstep * si
-// and source row y0 + ystep * si; the transposing orientations walk source columns per destination row and keep the frame route).
+// One image's share of the work. Orientations 1-4: tap index si of the oriented frame's x axis is source column x0 + xstep * si, of its
+// y axis source row y0 + ystep * si. Orientations 5-8 (`transposed`): the oriented x axis runs down the source rows.
 struct LpArea420Op {
     uint32_t img;                       // index into the LpJpeg array of the current decode range
     int32_t x0, y0, xstep, ystep;
     uint32_t xtab_off, ytab_off;        // into the tap arena
     uint32_t xrange_off, yrange_off;    // into the range arena: [dw + 1] / [dh + 1] tap ranges
     uint32_t maxt;                      // 6 / 10 / 18 / 34 / 66: which instantiation takes it
-    uint32_t pad;
+    uint32_t transposed;                // orientations 5-8 (k_area_420t): x0 / xstep place the Y taps along source x, y0 / ystep the X taps along source y; maxt counts y taps
     LpFrame dst;
 };
 
@@ -132,47 +132,127 @@ typedef float lpa_f2 __attribute__((ext_vector_type(2)));
 
 #define LPA_FIX16(x) ((int32_t)((x)*65536.0 + 0.5))
 
-// MAXT = taps per axis the instantiation covers (a destination column with fewer carries weight 0 in the rest, which adds exactly
-// 0); FLIPX: tap k reads the column MAXT-1-k of [xa, xa + MAXT) (orientations 2 and 3) -- the sums still run in tap order.
-//   xa     leftmost source column the taps can reach; columns outside [0, W) only ever meet weight 0
+// ---- the window a lane walks along source x ------------------------------------------------------------------------------------
+// MAXT = taps per axis the instantiation covers (a destination pixel with fewer carries weight 0 in the rest, which adds exactly 0).
+// The taps can reach the source columns [xa, xa + MAXT); the window starts at the even column xe = xa & ~1 and is MAXT + 1 wide, so
+// that which chroma column and which neighbour a window column uses is known at compile time; the weights are shifted by xa's
+// parity instead (one more weight-0 term at one end of the sum). Columns outside [0, W) only ever meet weight 0.
+template <int MAXT>
+struct LpaWindow {
+    static_assert(MAXT % 2 == 0, "even tap counts only");
+    static constexpr int NX = MAXT + 1;             // window columns
+    static constexpr int NWY = (NX + 3) / 4;        // luma dwords of the window (after the byte-phase fix-up)
+    static constexpr int NC = MAXT / 2 + 2;         // chroma columns: the window's own MAXT / 2 + 1 and a neighbour either side
+    static constexpr int NWC = (NC + 3) / 4;
+    uint32_t oy[NWY + 1], oc[NWC + 1];              // dword offsets inside a plane row (unsigned: scalar row + zero-extended lane offset is one addressing mode)
+    uint32_t shy, shc;                              // byte phase of the window in its first dword, luma / chroma
+    int32_t il, ir;                                 // window index that stands for chroma column -1 / column dw
+    bool edge;
+
+    LPA_HD void init(const LpAreaPlanes& P, int32_t xe)
+    {
+        const int32_t xo = xe & ~3, c_lo = (xe >> 1) - 1, co = c_lo & ~3;
+        shy = (uint32_t)(xe & 3) * 8; shc = (uint32_t)(c_lo & 3) * 8;
+        // clamped into the row: a clamped dword only feeds columns outside the image
+#pragma unroll
+        for (int i = 0; i <= NWY; i++) oy[i] = (uint32_t)lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
+#pragma unroll
+        for (int i = 0; i <= NWC; i++) oc[i] = (uint32_t)lpa_clamp(co + 4 * i, 0, (int32_t)P.sc - 4);
+        // jdsample.c replicates the first and the last chroma column (of downsampled_width, not of the padded plane). Columns further
+        // out are only reached by weight-0 taps.
+        il = -1 - c_lo; ir = P.dw - c_lo;
+        edge = il >= 0 || ir < NC;
+    }
+    // weight of window column c from the weights in tap order: tap k sits at column k + odd (FLIP: MAXT - 1 - k + odd)
+    template <bool FLIP>
+    LPA_HD static void weights(int32_t odd, const float (&tap)[MAXT], float (&w)[NX])
+    {
+#pragma unroll
+        for (int c = 0; c < NX; c++) {
+            const float w0 = c < MAXT ? tap[FLIP ? MAXT - 1 - c : c] : 0.f;   // xa even
+            const float w1 = c >= 1 ? tap[FLIP ? MAXT - c : c - 1] : 0.f;     // xa odd
+            w[c] = odd ? w1 : w0;
+        }
+    }
+};
+
+// One source row sy (the same for the whole wave) of a lane's window: f(c, b, g, r) for its NX columns, ascending or (REV) descending.
+// The upsampler's and the colour conversion's integer arithmetic as in k_ycc_to_frame_420.
+template <int MAXT, bool REV, class F>
+LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& PB, const LpaPlane& PR, const LpaWindow<MAXT>& W, int32_t sy, F&& f)
+{
+    constexpr int NX = LpaWindow<MAXT>::NX, NWY = LpaWindow<MAXT>::NWY, NC = LpaWindow<MAXT>::NC, NWC = LpaWindow<MAXT>::NWC;
+    const int32_t KR = 32768 - 128 * LPA_FIX16(1.40200), KB = 32768 - 128 * LPA_FIX16(1.77200);
+    const int32_t KG = 32768 + 128 * LPA_FIX16(0.34414) + 128 * LPA_FIX16(0.71414);
+    const int32_t cy = sy >> 1;
+    const int32_t ny = lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1);
+    const uint32_t ry = (uint32_t)sy * P.sy, rc0 = (uint32_t)cy * P.sc, rc1 = (uint32_t)ny * P.sc;
+    uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
+#pragma unroll
+    for (int i = 0; i <= NWY; i++) wy[i] = PY.word(ry, W.oy[i]);
+#pragma unroll
+    for (int i = 0; i <= NWC; i++) {
+        wb0[i] = PB.word(rc0, W.oc[i]); wb1[i] = PB.word(rc1, W.oc[i]);
+        wr0[i] = PR.word(rc0, W.oc[i]); wr1[i] = PR.word(rc1, W.oc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], W.shy);
+#pragma unroll
+    for (int i = 0; i < NWC; i++) {
+        wb0[i] = lpa_alignbit(wb0[i + 1], wb0[i], W.shc); wb1[i] = lpa_alignbit(wb1[i + 1], wb1[i], W.shc);
+        wr0[i] = lpa_alignbit(wr0[i + 1], wr0[i], W.shc); wr1[i] = lpa_alignbit(wr1[i + 1], wr1[i], W.shc);
+    }
+    // vertical half of the upsampler, {Cb, Cr} packed in the halves of one register: 3 * nearer row + further row (<= 1020)
+    uint32_t V[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        uint32_t a, b;
+        switch (i & 3) {
+        case 0: a = lpa_pair<0>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<0>(wr1[i >> 2], wb1[i >> 2]); break;
+        case 1: a = lpa_pair<1>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<1>(wr1[i >> 2], wb1[i >> 2]); break;
+        case 2: a = lpa_pair<2>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<2>(wr1[i >> 2], wb1[i >> 2]); break;
+        default: a = lpa_pair<3>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<3>(wr1[i >> 2], wb1[i >> 2]); break;
+        }
+        V[i] = 3u * a + b;
+    }
+    if (W.edge) {
+#pragma unroll
+        for (int i = 0; i + 1 < NC; i++) V[i] = i == W.il ? V[i + 1] : V[i];
+#pragma unroll
+        for (int i = 1; i < NC; i++) V[i] = i == W.ir ? V[i - 1] : V[i];
+    }
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        const int c = REV ? NX - 1 - t : t;
+        // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right (bias 7), even ones with the
+        // one to the left (bias 8) -- h2v2_fancy_upsample's horizontal half on the vertical sums: (3 * near + far + bias) >> 4
+        const int ic = c / 2 + 1;
+        const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + ((c & 1) ? 0x00070007u : 0x00080008u);
+        const int32_t cb = (int32_t)((h >> 4) & 0xfffu), cr = (int32_t)(h >> 20);
+        const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
+        const int32_t r = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.40200), cr, KR) >> 16), 0, 255);
+        const int32_t b = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.77200), cb, KB) >> 16), 0, 255);
+        const int32_t g = lpa_clamp(yy + (lpa_mad24(-LPA_FIX16(0.34414), cb, lpa_mad24(-LPA_FIX16(0.71414), cr, KG)) >> 16), 0, 255);
+        f(c, b, g, r);
+    }
+}
+
+// ---- orientations 1-4: destination x runs along source x -------------------------------------------------------------------------
+// FLIPX: tap k reads column MAXT-1-k of [xa, xa + MAXT) (orientations 2 and 3) -- the sums still run in tap order.
 //   al[k]  x weights in tap order
-//   yt, y0..y1, ybase, ystep  the destination row's taps: source row = ybase + ystep * yt[j].si
-// The window the kernel walks starts at the even column xa & ~1 and is MAXT + 1 wide, so that which chroma column and which
-// neighbour a window column uses is known at compile time; the weights are shifted by xa's parity instead (one more weight-0 term
-// at one end of the sum).
+//   yt, y0..y1, ybase, ystep  the destination row's taps (wave-uniform): source row = ybase + ystep * yt[j].si
+// resize.cpp ResizeArea_Invoker: per source row buf = sum over the x taps of value * alpha; sum += beta * buf.
 template <int MAXT, bool FLIPX>
 LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al)[MAXT], const LpTap* __restrict__ yt, uint32_t y0, uint32_t y1,
                              int32_t ybase, int32_t ystep, uint8_t* __restrict__ out)
 {
 #pragma clang fp contract(off) // every product is rounded before it is added, as in resize.cpp's scalar loops
-    static_assert(MAXT % 2 == 0, "even tap counts only");
-    constexpr int NX = MAXT + 1;                    // window columns
-    constexpr int NWY = (NX + 3) / 4;               // luma dwords of the window (after the byte-phase fix-up)
-    constexpr int NC = MAXT / 2 + 2;                // chroma columns: the window's own MAXT / 2 + 1 and a neighbour either side
-    constexpr int NWC = (NC + 3) / 4;
-    const int32_t odd = xa & 1, xe = xa - odd;
-    // weight of window column c: tap k sits at column k + odd (FLIPX: MAXT - 1 - k + odd)
+    constexpr int NX = LpaWindow<MAXT>::NX;
+    const int32_t odd = xa & 1;
     float w[NX];
-#pragma unroll
-    for (int c = 0; c < NX; c++) {
-        const float w0 = c < MAXT ? al[FLIPX ? MAXT - 1 - c : c] : 0.f;   // xa even
-        const float w1 = c >= 1 ? al[FLIPX ? MAXT - c : c - 1] : 0.f;     // xa odd
-        w[c] = odd ? w1 : w0;
-    }
-    // dword offsets inside a plane row, clamped into the row: a clamped dword only feeds columns outside the image
-    uint32_t oy[NWY + 1], oc[NWC + 1]; // unsigned: scalar row address + zero-extended lane offset is one addressing mode
-    const int32_t xo = xe & ~3, c_lo = (xe >> 1) - 1, co = c_lo & ~3;
-    const uint32_t shy = (uint32_t)(xe & 3) * 8, shc = (uint32_t)(c_lo & 3) * 8;
-#pragma unroll
-    for (int i = 0; i <= NWY; i++) oy[i] = (uint32_t)lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
-#pragma unroll
-    for (int i = 0; i <= NWC; i++) oc[i] = (uint32_t)lpa_clamp(co + 4 * i, 0, (int32_t)P.sc - 4);
-    // jdsample.c replicates the first and the last chroma column (of downsampled_width, not of the padded plane): window index
-    // il stands for column -1, ir for column dw. Columns further out are only reached by weight-0 taps.
-    const int32_t il = -1 - c_lo, ir = P.dw - c_lo;
-    const bool edge = il >= 0 || ir < NC;
-    const int32_t KR = 32768 - 128 * LPA_FIX16(1.40200), KB = 32768 - 128 * LPA_FIX16(1.77200);
-    const int32_t KG = 32768 + 128 * LPA_FIX16(0.34414) + 128 * LPA_FIX16(0.71414);
+    LpaWindow<MAXT>::template weights<FLIPX>(odd, al, w);
+    LpaWindow<MAXT> W;
+    W.init(P, xa - odd);
     const LpaPlane PY = lpa_plane(P.py), PB = lpa_plane(P.pb), PR = lpa_plane(P.pr);
     lpa_f2 sbg = {0.f, 0.f};
     float sum_r = 0.f;
@@ -181,65 +261,64 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
     for (uint32_t j = j0; j < j1; j++) {
         const float beta = yt[j].alpha;
         const int32_t sy = ybase + ystep * (int32_t)yt[j].si;
-        const int32_t cy = sy >> 1;
-        const int32_t ny = lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1);
-        const uint32_t ry = (uint32_t)sy * P.sy, rc0 = (uint32_t)cy * P.sc, rc1 = (uint32_t)ny * P.sc;
-        uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
-#pragma unroll
-        for (int i = 0; i <= NWY; i++) wy[i] = PY.word(ry, oy[i]);
-#pragma unroll
-        for (int i = 0; i <= NWC; i++) {
-            wb0[i] = PB.word(rc0, oc[i]); wb1[i] = PB.word(rc1, oc[i]);
-            wr0[i] = PR.word(rc0, oc[i]); wr1[i] = PR.word(rc1, oc[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], shy);
-#pragma unroll
-        for (int i = 0; i < NWC; i++) {
-            wb0[i] = lpa_alignbit(wb0[i + 1], wb0[i], shc); wb1[i] = lpa_alignbit(wb1[i + 1], wb1[i], shc);
-            wr0[i] = lpa_alignbit(wr0[i + 1], wr0[i], shc); wr1[i] = lpa_alignbit(wr1[i + 1], wr1[i], shc);
-        }
-        // vertical half of the upsampler, {Cb, Cr} packed in the halves of one register: 3 * nearer row + further row (<= 1020)
-        uint32_t V[NC];
-#pragma unroll
-        for (int i = 0; i < NC; i++) {
-            uint32_t a, b;
-            switch (i & 3) {
-            case 0: a = lpa_pair<0>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<0>(wr1[i >> 2], wb1[i >> 2]); break;
-            case 1: a = lpa_pair<1>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<1>(wr1[i >> 2], wb1[i >> 2]); break;
-            case 2: a = lpa_pair<2>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<2>(wr1[i >> 2], wb1[i >> 2]); break;
-            default: a = lpa_pair<3>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<3>(wr1[i >> 2], wb1[i >> 2]); break;
-            }
-            V[i] = 3u * a + b;
-        }
-        if (edge) {
-#pragma unroll
-            for (int i = 0; i + 1 < NC; i++) V[i] = i == il ? V[i + 1] : V[i];
-#pragma unroll
-            for (int i = 1; i < NC; i++) V[i] = i == ir ? V[i - 1] : V[i];
-        }
         // blue and green travel as a pair (one v_pk_mul_f32 + one v_pk_add_f32 for the two: each half is the same IEEE multiply and add)
         lpa_f2 bg = {0.f, 0.f};
         float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < NX; t++) {
-            const int c = FLIPX ? NX - 1 - t : t;   // window column, in tap order
-            // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right (bias 7), even ones with
-            // the one to the left (bias 8) -- h2v2_fancy_upsample's horizontal half on the vertical sums: (3 * near + far + bias) >> 4
-            const int ic = c / 2 + 1;
-            const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + ((c & 1) ? 0x00070007u : 0x00080008u);
-            const int32_t cb = (int32_t)((h >> 4) & 0xfffu), cr = (int32_t)(h >> 20);
-            const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
-            const int32_t r = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.40200), cr, KR) >> 16), 0, 255);
-            const int32_t b = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.77200), cb, KB) >> 16), 0, 255);
-            const int32_t g = lpa_clamp(yy + (lpa_mad24(-LPA_FIX16(0.34414), cb, lpa_mad24(-LPA_FIX16(0.71414), cr, KG)) >> 16), 0, 255);
+        lpa_row<MAXT, FLIPX>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
             const lpa_f2 pbg = {(float)b, (float)g}, ww = {w[c], w[c]};
             bg = bg + pbg * ww;
             rs = lpa_add(rs, lpa_mul((float)r, w[c]));
-        }
+        });
         const lpa_f2 bb = {beta, beta};
         sbg = sbg + bb * bg;
         sum_r = lpa_add(sum_r, lpa_mul(beta, rs));
+    }
+    out[0] = (uint8_t)lpa_round_u8(sbg.x); out[1] = (uint8_t)lpa_round_u8(sbg.y); out[2] = (uint8_t)lpa_round_u8(sum_r);
+}
+
+// ---- orientations 5-8: destination x runs along source y --------------------------------------------------------------------------
+// A row of the oriented frame is a COLUMN of the decoded image: for destination (dx, dy) the row buffer of oriented row j is the
+// alpha-weighted sum down source column c_j over the source rows the x taps name, and the rows are beta-weighted in j order. The
+// planes are still read row by row (the lanes of a wave are neighbouring dy = neighbouring source columns, so the loads coalesce as in
+// the row-wise kernel): every window column keeps its own row buffer while the source rows go by in tap order, and the beta pass runs
+// over the window's columns at the end -- the same products added in the same order as resize.cpp's.
+//   xa, be[k]  leftmost source column the y taps can reach, y weights in tap order; FLIPC: tap k reads column MAXT-1-k (orientations 7, 8)
+//   xt, x0..x1, rbase, rstep  the destination column's taps (wave-uniform): source row = rbase + rstep * xt[k].si
+template <int MAXT, bool FLIPC>
+LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&be)[MAXT], const LpTap* __restrict__ xt, uint32_t x0, uint32_t x1,
+                              int32_t rbase, int32_t rstep, uint8_t* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    constexpr int NX = LpaWindow<MAXT>::NX;
+    const int32_t odd = xa & 1;
+    float w[NX];
+    LpaWindow<MAXT>::template weights<FLIPC>(odd, be, w);
+    LpaWindow<MAXT> W;
+    W.init(P, xa - odd);
+    const LpaPlane PY = lpa_plane(P.py), PB = lpa_plane(P.pb), PR = lpa_plane(P.pr);
+    lpa_f2 bg[NX];
+    float rs[NX];
+#pragma unroll
+    for (int c = 0; c < NX; c++) { bg[c] = lpa_f2{0.f, 0.f}; rs[c] = 0.f; }
+    const uint32_t k0 = (uint32_t)lpa_uniform((int32_t)x0), k1 = (uint32_t)lpa_uniform((int32_t)x1);
+    for (uint32_t k = k0; k < k1; k++) {
+        const float alpha = xt[k].alpha;
+        const int32_t sy = rbase + rstep * (int32_t)xt[k].si;
+        const lpa_f2 aa = {alpha, alpha};
+        lpa_row<MAXT, false>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
+            const lpa_f2 pbg = {(float)b, (float)g};
+            bg[c] = bg[c] + pbg * aa;
+            rs[c] = lpa_add(rs[c], lpa_mul((float)r, alpha));
+        });
+    }
+    lpa_f2 sbg = {0.f, 0.f};
+    float sum_r = 0.f;
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        const int c = FLIPC ? NX - 1 - t : t;   // oriented rows in order
+        const lpa_f2 ww = {w[c], w[c]};
+        sbg = sbg + ww * bg[c];
+        sum_r = lpa_add(sum_r, lpa_mul(w[c], rs[c]));
     }
     out[0] = (uint8_t)lpa_round_u8(sbg.x); out[1] = (uint8_t)lpa_round_u8(sbg.y); out[2] = (uint8_t)lpa_round_u8(sum_r);
 }

@@ -372,8 +372,8 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
     {
         // How an image gets from planes to its output size: 1 = integer-scale area resize, fused (k_resample_*); 2 = fractional area
-        // resize of a YCbCr 4:2:0 image in a row-wise orientation, fused (k_area_420; LILLIPUT_HIP_AREA_FUSED=0 sends these through
-        // the frame as before round 3); 0 = through a materialised BGR frame, exactly like the one-image ABI.
+        // resize of a YCbCr 4:2:0 image, fused (k_area_420 / k_area_420t; LILLIPUT_HIP_AREA_FUSED=0 sends these through the frame as
+        // before round 3); 0 = through a materialised BGR frame, exactly like the one-image ABI.
         static const bool area_on = !(getenv("LILLIPUT_HIP_AREA_FUSED") && atoi(getenv("LILLIPUT_HIP_AREA_FUSED")) == 0);
         std::map<std::pair<int, int>, uint32_t> bucket_cache;
         auto route_of = [&](const LpJpeg& j, const LpOpsPlan& plan) -> int {
@@ -381,10 +381,13 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
             int ix, iy;
             const int mode = lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
             if (mode == 1) return 1;
-            if (mode != 2 || !area_on || j.orientation > 4 || !(j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4)) return 0;
-            const auto key = std::make_pair(plan.crop_w, plan.out_w);
+            if (mode != 2 || !area_on || !(j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4)) return 0;
+            // the axis of the oriented crop that runs along source x picks the instantiation: x for orientations 1-4, y for 5-8
+            const bool swapped = j.orientation >= 5;
+            const auto key = swapped ? std::make_pair(-plan.crop_h, plan.out_h) : std::make_pair(plan.crop_w, plan.out_w);
             auto it = bucket_cache.find(key);
-            if (it == bucket_cache.end()) it = bucket_cache.emplace(key, lp_area420_bucket(plan.crop_w, plan.out_w)).first;
+            if (it == bucket_cache.end())
+                it = bucket_cache.emplace(key, swapped ? lp_area420_bucket(plan.crop_h, plan.out_h, true) : lp_area420_bucket(plan.crop_w, plan.out_w)).first;
             return it->second ? 2 : 0;
         };
         // frame heap: thumbnails for the fused images; decoded frame (+ oriented copy) + resized frame for the others
@@ -425,13 +428,10 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
             const int route = route_of(j, plan);
             if (route == 0) continue;
             if (route == 2) {
-                // oriented-frame column ox is source column ox (orientations 1, 4) or W - 1 - ox (2, 3); rows likewise (3, 4 flip)
-                const bool fx = j.orientation == 2 || j.orientation == 3, fy = j.orientation == 3 || j.orientation == 4;
                 LpAreaReq rq;
                 memset(&rq, 0, sizeof(rq));
                 rq.img = (uint32_t)k;
-                rq.x0 = fx ? (int)j.width - 1 - plan.crop_x : plan.crop_x; rq.xstep = fx ? -1 : 1;
-                rq.y0 = fy ? (int)j.height - 1 - plan.crop_y : plan.crop_y; rq.ystep = fy ? -1 : 1;
+                lp_area420_place((int)j.orientation, (int)j.width, (int)j.height, plan.crop_x, plan.crop_y, &rq);
                 rq.crop_w = (uint32_t)plan.crop_w; rq.crop_h = (uint32_t)plan.crop_h;
                 rq.dst.w = (uint32_t)plan.out_w; rq.dst.h = (uint32_t)plan.out_h; rq.dst.cn = 3;
                 rq.dst.stride = rq.dst.w * 3;

@@ -1185,13 +1185,14 @@ static uint32_t area_bucket_of(const std::vector<LpTap>& taps, const std::vector
     return mx <= 6 ? 6u : mx <= 10 ? 10u : mx <= 18 ? 18u : mx <= 34 ? 34u : mx <= 66 ? 66u : 0u;
 }
 
-uint32_t lp_area420_bucket(int ssize, int dsize)
+uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed)
 {
     if (ssize <= 0 || dsize <= 0 || dsize >= ssize) return 0;
     std::vector<LpTap> taps;
     std::vector<uint32_t> ranges;
     lp_area_tab(ssize, dsize, taps, ranges);
-    return area_bucket_of(taps, ranges, 0, 0, (uint32_t)dsize);
+    const uint32_t b = area_bucket_of(taps, ranges, 0, 0, (uint32_t)dsize);
+    return transposed && b > 34 ? 0 : b;
 }
 
 int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
@@ -1216,6 +1217,7 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
             return LP_ERR_DEVICE;
         }
         op.img = r.img; op.x0 = r.x0; op.y0 = r.y0; op.xstep = r.xstep; op.ystep = r.ystep;
+        op.transposed = r.transposed ? 1u : 0u;
         op.dst = r.dst; op.dst.cn = 3;
         if (!op.dst.stride) op.dst.stride = r.dst.w * 3;
         const auto kx = std::make_pair((int)r.crop_w, (int)r.dst.w), ky = std::make_pair((int)r.crop_h, (int)r.dst.h);
@@ -1230,10 +1232,11 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
             if (ax) { op.ytab_off = it->second.first; op.yrange_off = it->second.second; }
             else { op.xtab_off = it->second.first; op.xrange_off = it->second.second; }
         }
-        op.maxt = area_bucket_of(taps, ranges, op.xtab_off, op.xrange_off, r.dst.w);
-        if (!op.maxt) { err_ = "area_resample: no kernel for this many taps"; return LP_ERR_DEVICE; }
+        // the axis that runs along source x sets the instantiation
+        op.maxt = op.transposed ? area_bucket_of(taps, ranges, op.ytab_off, op.yrange_off, r.dst.h) : area_bucket_of(taps, ranges, op.xtab_off, op.xrange_off, r.dst.w);
+        if (!op.maxt || (op.transposed && op.maxt > 34)) { err_ = "area_resample: no kernel for this many taps"; return LP_ERR_DEVICE; }
         const uint32_t bit = op.maxt == 6 ? 0u : op.maxt == 10 ? 1u : op.maxt == 18 ? 2u : op.maxt == 34 ? 3u : 4u;
-        mask |= 1u << (bit + (r.xstep < 0 ? 5u : 0u));
+        mask |= op.transposed ? 1u << (10u + bit + (r.xstep < 0 ? 4u : 0u)) : 1u << (bit + (r.xstep < 0 ? 5u : 0u));
         mdw = std::max(mdw, r.dst.w);
         mdh = std::max(mdh, r.dst.h);
     }
@@ -1252,28 +1255,60 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
     return LP_OK;
 }
 
-// Test access: lp_area420_pixel on the host (what k_area_420 runs per thread), so that the order of operations can be compared with
-// the oracle without a GPU. Not a product path: nothing in the library calls it.
-template <int MAXT, bool FLIPX>
+// Test access: lp_area420_pixel / lp_area420t_pixel on the host (what k_area_420 / k_area_420t run per thread), so that the order of
+// operations can be compared with the oracle without a GPU. Not a product path: nothing in the library calls it.
+template <int MAXT, bool FLIP>
 static void area420_host_run(const LpAreaPlanes& P, const LpArea420Op& op, const std::vector<LpTap>& taps, const std::vector<uint32_t>& ranges, uint8_t* out)
 {
     for (uint32_t dy = 0; dy < op.dst.h; dy++)
         for (uint32_t dx = 0; dx < op.dst.w; dx++) {
             const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
             const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
-            const LpTap* xt = taps.data() + op.xtab_off + x0;
-            float al[MAXT];
-            for (int k = 0; k < MAXT; k++) al[k] = (uint32_t)k < x1 - x0 ? xt[k].alpha : 0.f;
-            const int32_t si0 = (int32_t)xt[0].si;
-            const int32_t xa = FLIPX ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
-            lp_area420_pixel<MAXT, FLIPX>(P, xa, al, taps.data() + op.ytab_off, y0, y1, op.y0, op.ystep, out + ((size_t)dy * op.dst.w + dx) * 3);
+            uint8_t* o = out + ((size_t)dy * op.dst.w + dx) * 3;
+            float wt[MAXT];
+            if (op.transposed) {
+                const LpTap* yt = taps.data() + op.ytab_off + y0;
+                for (int k = 0; k < MAXT; k++) wt[k] = (uint32_t)k < y1 - y0 ? yt[k].alpha : 0.f;
+                const int32_t si0 = (int32_t)yt[0].si;
+                const int32_t xa = FLIP ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
+                lp_area420t_pixel<MAXT, FLIP>(P, xa, wt, taps.data() + op.xtab_off, x0, x1, op.y0, op.ystep, o);
+            } else {
+                const LpTap* xt = taps.data() + op.xtab_off + x0;
+                for (int k = 0; k < MAXT; k++) wt[k] = (uint32_t)k < x1 - x0 ? xt[k].alpha : 0.f;
+                const int32_t si0 = (int32_t)xt[0].si;
+                const int32_t xa = FLIP ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
+                lp_area420_pixel<MAXT, FLIP>(P, xa, wt, taps.data() + op.ytab_off, y0, y1, op.y0, op.ystep, o);
+            }
         }
+}
+
+// crop_* in oriented coordinates, w / h the decoded (un-oriented) size
+static void area420_place(int orientation, int w, int h, int crop_x, int crop_y, int32_t* x0, int32_t* xstep, int32_t* y0, int32_t* ystep, uint32_t* transposed)
+{
+    // cv::ExifTransform inverse: which source column / row an oriented index names
+    if (orientation <= 4) {
+        const bool fx = orientation == 2 || orientation == 3, fy = orientation == 3 || orientation == 4;
+        *transposed = 0;
+        *x0 = fx ? w - 1 - crop_x : crop_x; *xstep = fx ? -1 : 1;
+        *y0 = fy ? h - 1 - crop_y : crop_y; *ystep = fy ? -1 : 1;
+    } else {
+        // oriented row oy is source column oy (5, 6) or w - 1 - oy (7, 8); oriented column ox is source row ox (5, 8) or h - 1 - ox (6, 7)
+        const bool fc = orientation == 7 || orientation == 8, fr = orientation == 6 || orientation == 7;
+        *transposed = 1;
+        *x0 = fc ? w - 1 - crop_y : crop_y; *xstep = fc ? -1 : 1;
+        *y0 = fr ? h - 1 - crop_x : crop_x; *ystep = fr ? -1 : 1;
+    }
+}
+
+void lp_area420_place(int orientation, int w, int h, int crop_x, int crop_y, LpAreaReq* rq)
+{
+    area420_place(orientation, w, h, crop_x, crop_y, &rq->x0, &rq->xstep, &rq->y0, &rq->ystep, &rq->transposed);
 }
 
 extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h,
                                          int orientation, int crop_x, int crop_y, int crop_w, int crop_h, int dst_w, int dst_h, uint8_t* out)
 {
-    if (orientation < 1 || orientation > 4 || w <= 4 || (stride_y & 3) || (stride_c & 3)) return 1;
+    if (orientation < 1 || orientation > 8 || w <= 4 || (stride_y & 3) || (stride_c & 3)) return 1;
     int ix, iy;
     if (lp_resize_mode(crop_w, crop_h, dst_w, dst_h, &ix, &iy) != 2) return 1;
     std::vector<LpTap> taps;
@@ -1283,14 +1318,13 @@ extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, c
     lp_area_tab(crop_w, dst_w, taps, ranges);
     op.ytab_off = (uint32_t)taps.size(); op.yrange_off = (uint32_t)ranges.size();
     lp_area_tab(crop_h, dst_h, taps, ranges);
-    op.maxt = area_bucket_of(taps, ranges, 0, 0, (uint32_t)dst_w);
-    if (!op.maxt) return 1;
-    const bool fx = orientation == 2 || orientation == 3, fy = orientation == 3 || orientation == 4;
-    op.x0 = fx ? w - 1 - crop_x : crop_x; op.xstep = fx ? -1 : 1;
-    op.y0 = fy ? h - 1 - crop_y : crop_y; op.ystep = fy ? -1 : 1;
+    area420_place(orientation, w, h, crop_x, crop_y, &op.x0, &op.xstep, &op.y0, &op.ystep, &op.transposed);
+    op.maxt = op.transposed ? area_bucket_of(taps, ranges, op.ytab_off, op.yrange_off, (uint32_t)dst_h) : area_bucket_of(taps, ranges, 0, 0, (uint32_t)dst_w);
+    if (!op.maxt || (op.transposed && op.maxt > 34)) return 1;
     op.dst.w = (uint32_t)dst_w; op.dst.h = (uint32_t)dst_h;
+    const bool flip = op.xstep < 0;
     LpAreaPlanes P{py, pb, pr, stride_y, stride_c, (w + 1) >> 1, (h + 1) >> 1};
-#define LP_AREA_HOST(T) case T: if (fx) area420_host_run<T, true>(P, op, taps, ranges, out); else area420_host_run<T, false>(P, op, taps, ranges, out); break
+#define LP_AREA_HOST(T) case T: if (flip) area420_host_run<T, true>(P, op, taps, ranges, out); else area420_host_run<T, false>(P, op, taps, ranges, out); break
     switch (op.maxt) { LP_AREA_HOST(6); LP_AREA_HOST(10); LP_AREA_HOST(18); LP_AREA_HOST(34); LP_AREA_HOST(66); default: return 1; }
 #undef LP_AREA_HOST
     return 0;

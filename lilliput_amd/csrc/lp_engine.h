@@ -65,12 +65,15 @@ struct LpResizeReq {
     uint32_t dst_w, dst_h;
 };
 
-// One image of area_resample: the oriented crop (crop_w x crop_h, its tap index si at source column x0 + xstep * si and source row
-// y0 + ystep * si of the decoded planes) -> dst (BGR; off = where to write, w / h = the size asked for).
+// One image of area_resample: the oriented crop (crop_w x crop_h) -> dst (BGR; off = where to write, w / h = the size asked for).
+// Orientations 1-4: index si along the crop's x axis is source column x0 + xstep * si, along its y axis source row y0 + ystep * si.
+// Orientations 5-8 (transposed): index si along the crop's Y axis is source column x0 + xstep * si, along its X axis source row
+// y0 + ystep * si.
 struct LpAreaReq {
     uint32_t img;
     int32_t x0, y0, xstep, ystep;
     uint32_t crop_w, crop_h;
+    uint32_t transposed;
     LpFrame dst;
 };
 
@@ -291,4 +294,9 @@ int lp_resize_mode(int sw, int sh, int dw, int dh, int* iscale_x, int* iscale_y)
 int lp_area_tab(int ssize, int dsize, std::vector<LpTap>& taps, std::vector<uint32_t>& ranges);
 // k_area_420's instantiation for an x axis ssize -> dsize (6 / 10 / 18 / 34 / 66 taps), 0 = none (more taps, or a table whose
 // columns are not runs of consecutive source columns)
-uint32_t lp_area420_bucket(int ssize, int dsize);
+// (the axis meant is the one that runs along source x: the crop's x axis, or its y axis for the transposing orientations, whose
+// kernel stops at 34 taps)
+uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed = false);
+// fills x0 / xstep / y0 / ystep / transposed of a request from the EXIF orientation (cv::ExifTransform's inverse), the decoded size and
+// the crop origin in oriented coordinates
+void lp_area420_place(int orientation, int w, int h, int crop_x, int crop_y, LpAreaReq* rq);

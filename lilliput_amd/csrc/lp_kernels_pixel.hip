@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ img
                                                   const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ plane_arena)
 {
     const LpArea420Op& op = ops[blockIdx.z];
-    if (op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPX) return;
+    if (op.transposed || op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPX) return;
     const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= op.dst.w || dy >= op.dst.h) return;
     const LpJpeg& img = imgs[op.img];
@@ -681,6 +681,35 @@ __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ img
     P.dw = (int32_t)(img.width + 1) >> 1; P.dh = (int32_t)(img.height + 1) >> 1;
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
     lp_area420_pixel<MAXT, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D);
+}
+
+// The same for the orientations that swap the axes (5-8): the lanes of a wave are 64 neighbouring destination ROWS of one destination
+// column -- neighbouring source columns, one shared run of source rows -- so the plane loads coalesce exactly as above; the three
+// output bytes of a lane land a destination row apart (64 small writes per wave against ~20 k instructions of work).
+template <int MAXT, bool FLIPC>
+__global__ __launch_bounds__(256) void k_area_420t(const LpJpeg* __restrict__ imgs, const LpArea420Op* __restrict__ ops, const LpTap* __restrict__ taps,
+                                                   const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ plane_arena)
+{
+    const LpArea420Op& op = ops[blockIdx.z];
+    if (!op.transposed || op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPC) return;
+    const uint32_t dy = blockIdx.x * 64 + threadIdx.x, dx = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= op.dst.w || dy >= op.dst.h) return;
+    const LpJpeg& img = imgs[op.img];
+    const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
+    const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
+    const LpTap* yt = taps + op.ytab_off + y0;
+    const uint32_t ny = y1 - y0;
+    float be[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) be[k] = (uint32_t)k < ny ? yt[k].alpha : 0.f;
+    const int32_t si0 = (int32_t)yt[0].si;
+    const int32_t xa = FLIPC ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
+    LpAreaPlanes P;
+    P.py = plane_arena + img.plane_off[0]; P.pb = plane_arena + img.plane_off[1]; P.pr = plane_arena + img.plane_off[2];
+    P.sy = img.plane_stride[0]; P.sc = img.plane_stride[1];
+    P.dw = (int32_t)(img.width + 1) >> 1; P.dh = (int32_t)(img.height + 1) >> 1;
+    uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
+    lp_area420t_pixel<MAXT, FLIPC>(P, xa, be, taps + op.xtab_off, x0, x1, op.y0, op.ystep, D);
 }
 
 // INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point
@@ -1258,7 +1287,8 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
         hipLaunchKernelGGL(k_resize_linear, g2, dim3(64, 4), 0, s, d_ops, reinterpret_cast<const int32_t*>(d_ranges), d_src, d_dst);
 }
 
-// mask: bit b = MAXT bucket b of {6, 10, 18, 34, 66} present, +5 for the mirrored (xstep < 0) instantiation
+// mask: bit b = MAXT bucket b of {6, 10, 18, 34, 66} present, +5 for the mirrored (xstep < 0) instantiation; bits 10-17 the same
+// for the axis-swapping orientations (k_area_420t; buckets up to 34: a window column there costs three accumulators)
 void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, uint32_t mask, uint32_t max_dw, uint32_t max_dh,
                         const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes)
 {
@@ -1267,6 +1297,11 @@ void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* 
 #define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420<T, F>), g, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
     LP_AREA_LAUNCH(0, 6, false); LP_AREA_LAUNCH(1, 10, false); LP_AREA_LAUNCH(2, 18, false); LP_AREA_LAUNCH(3, 34, false); LP_AREA_LAUNCH(4, 66, false);
     LP_AREA_LAUNCH(5, 6, true); LP_AREA_LAUNCH(6, 10, true); LP_AREA_LAUNCH(7, 18, true); LP_AREA_LAUNCH(8, 34, true); LP_AREA_LAUNCH(9, 66, true);
+#undef LP_AREA_LAUNCH
+    dim3 gt((max_dh + 63) / 64, (max_dw + 3) / 4, nops);
+#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420t<T, F>), gt, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
+    LP_AREA_LAUNCH(10, 6, false); LP_AREA_LAUNCH(11, 10, false); LP_AREA_LAUNCH(12, 18, false); LP_AREA_LAUNCH(13, 34, false);
+    LP_AREA_LAUNCH(14, 6, true); LP_AREA_LAUNCH(15, 10, true); LP_AREA_LAUNCH(16, 18, true); LP_AREA_LAUNCH(17, 34, true);
 #undef LP_AREA_LAUNCH
 }
 

@@ -29,12 +29,14 @@ CASES = ((250, 243, 100, 100), (256, 256, 100, 77), (301, 200, 64, 64), (512, 51
          (333, 222, 100, 100), (512, 512, 300, 300), (6, 200, 5, 50), (511, 509, 17, 16), (5, 5, 4, 4), (512, 9, 500, 2), (509, 512, 8, 500))
 
 
-def _crop_plan(oracle, w, h, tw, th, method):
+def _crop_plan(oracle, w, h, o, tw, th, method):
+    """Output size and crop rectangle (oriented coordinates) as oracle.transform_static / ops.go:449-479 derive them, normalize off."""
+    fw, fh = (h, w) if o >= 5 else (w, h)
     if method == oracle.FIT:
-        nw, nh = oracle.calculate_expected_size(w, h, tw, th)
-        left, top, wpc, hpc = oracle.fit_crop_rect(w, h, nw, nh)
+        nw, nh = oracle.calculate_expected_size(w, h, tw, th)  # header dimensions
+        left, top, wpc, hpc = oracle.fit_crop_rect(fw, fh, nw, nh)
         return nw, nh, left, top, wpc, hpc
-    return max(tw, 1), max(th, 1), 0, 0, w, h
+    return max(tw, 1), max(th, 1), 0, 0, fw, fh
 
 
 def test_area_walk_on_the_host_matches_the_oracle(hip_lib, oracle):
@@ -55,24 +57,25 @@ def test_area_walk_on_the_host_matches_the_oracle(hip_lib, oracle):
         data = _jpeg(rgb, w, h)
         planes = [np.ascontiguousarray(oracle.jpeg_decode_plane(data, c)) for c in range(3)]
         px = oracle.jpeg_decode(data)
-        for o in (1, 2, 3, 4):
+        for o in range(1, 9):
             for method in (oracle.FIT, oracle.RESIZE):
                 exp = oracle.transform_static(px, o, tw, th, method, False)
-                nw, nh, left, top, wpc, hpc = _crop_plan(oracle, w, h, tw, th, method)
+                nw, nh, left, top, wpc, hpc = _crop_plan(oracle, w, h, o, tw, th, method)
                 out = np.zeros((nh, nw, 3), np.uint8)
                 rc = fn(planes[0].ctypes.data_as(u8p), planes[1].ctypes.data_as(u8p), planes[2].ctypes.data_as(u8p), planes[0].shape[1], planes[1].shape[1],
                         w, h, o, left, top, wpc, hpc, nw, nh, out.ctypes.data_as(u8p))
-                if rc == 1:  # integer scale, an up-scaling axis, or more than 66 taps: not this kernel's
+                if rc == 1:  # integer scale, an up-scaling axis, or more than 66 (34 when the axes swap) taps: not these kernels'
                     continue
                 assert rc == 0
                 ran += 1
                 assert exp.shape == out.shape and np.array_equal(exp, out), (w, h, tw, th, o, method)
-    assert ran > 100
+    assert ran > 200
 
 
 @pytest.mark.gpu
 def test_fractional_scales_all_orientations_bit_exact(batch, oracle):
-    """Orientations 1-4 take k_area_420, 5-8 (and the other sampling layouts) the frame route: both must give the oracle's bytes."""
+    """Orientations 1-4 take k_area_420, 5-8 k_area_420t, the other sampling layouts (and tap counts past the kernels') the frame route:
+    all must give the oracle's bytes."""
     from lilliput_amd import synth
 
     rgb = synth.synth_rgb(11, 512)
@@ -91,7 +94,7 @@ def test_fractional_scales_all_orientations_bit_exact(batch, oracle):
 
 @pytest.mark.gpu
 def test_fractional_scales_in_one_mixed_batch(batch, oracle):
-    """One call with images of every route (integer scale, fractional row-wise, fractional transposed, grey) and several tap counts:
+    """One call with images of every route (integer scale, fractional row-wise, fractional axis-swapping, 4:2:2) and several tap counts:
     the kernels share launches through their op lists."""
     from lilliput_amd import synth
 
