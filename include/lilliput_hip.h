@@ -421,10 +421,10 @@ int lilliput_hip_png_set_inflater(int own);   /* test access / A-B: 1 = the libr
 uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n); /* test access: 0 = Adler-32, 1 = CRC-32 of the PNG path (zlib's conventions) */
 int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t* out, size_t out_len); /* test access: 1 = ordinary zlib stream of exactly out_len bytes, decoded; 0 = ask zlib */
 /* Test access, no device work: the per-pixel walk of the fused fractional INTER_AREA kernel (lp_area_core.h), run on the host over
- * decoded 4:2:0 planes the caller supplies (strides multiples of 4, chroma planes ceil(w/2) x ceil(h/2) or MCU padded). orientation
- * 1-4; crop in oriented coordinates; out = dst_w * dst_h * 3 bytes BGR. 0 = done, 1 = this geometry keeps the frame route. */
-int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h, int orientation,
-                              int crop_x, int crop_y, int crop_w, int crop_h, int dst_w, int dst_h, uint8_t* out);
+ * decoded YCbCr planes the caller supplies (strides multiples of 4; sampling 2 = 4:2:0, 1 = 4:2:2, 0 = 4:4:4). orientation 1-8; crop in
+ * oriented coordinates; out = dst_w * dst_h * 3 bytes BGR. 0 = done, 1 = this geometry keeps the frame route. */
+int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h, int sampling,
+                              int orientation, int crop_x, int crop_y, int crop_w, int crop_h, int dst_w, int dst_h, uint8_t* out);
 
 /* Lazy host write-back for Part A. Off (the default): every opencv_* call that produces pixels copies them into
  * the caller's buffer before it returns, as cv::Mat over Go memory does (opencv.go:258-267). On: pixels stay on

@@ -31,7 +31,7 @@ struct LpArea420Op {
 struct LpAreaPlanes {
     const uint8_t* py; const uint8_t* pb; const uint8_t* pr;
     uint32_t sy, sc;                    // plane strides (luma, chroma)
-    int32_t dw, dh;                     // chroma size that jdsample.c works on: ceil(W / 2), ceil(H / 2)
+    int32_t dw, dh;                     // chroma size that jdsample.c works on: 4:2:0 ceil(W / 2), ceil(H / 2); 4:2:2 ceil(W / 2), H; 4:4:4 W, H
 };
 
 LPA_HD uint32_t lpa_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) // bytes of {hi:lo} from bit sh (0 / 8 / 16 / 24)
@@ -137,12 +137,13 @@ typedef float lpa_f2 __attribute__((ext_vector_type(2)));
 // The taps can reach the source columns [xa, xa + MAXT); the window starts at the even column xe = xa & ~1 and is MAXT + 1 wide, so
 // that which chroma column and which neighbour a window column uses is known at compile time; the weights are shifted by xa's
 // parity instead (one more weight-0 term at one end of the sum). Columns outside [0, W) only ever meet weight 0.
-template <int MAXT>
+// SS = how the chroma planes are sampled: 2 = 4:2:0 (h2v2 fancy upsampling), 1 = 4:2:2 (h2v1 fancy upsampling), 0 = 4:4:4 (none).
+template <int MAXT, int SS>
 struct LpaWindow {
     static_assert(MAXT % 2 == 0, "even tap counts only");
     static constexpr int NX = MAXT + 1;             // window columns
     static constexpr int NWY = (NX + 3) / 4;        // luma dwords of the window (after the byte-phase fix-up)
-    static constexpr int NC = MAXT / 2 + 2;         // chroma columns: the window's own MAXT / 2 + 1 and a neighbour either side
+    static constexpr int NC = SS ? MAXT / 2 + 2 : NX; // chroma columns: subsampled, the window's own MAXT / 2 + 1 and a neighbour either side
     static constexpr int NWC = (NC + 3) / 4;
     uint32_t oy[NWY + 1], oc[NWC + 1];              // dword offsets inside a plane row (unsigned: scalar row + zero-extended lane offset is one addressing mode)
     uint32_t shy, shc;                              // byte phase of the window in its first dword, luma / chroma
@@ -151,7 +152,7 @@ struct LpaWindow {
 
     LPA_HD void init(const LpAreaPlanes& P, int32_t xe)
     {
-        const int32_t xo = xe & ~3, c_lo = (xe >> 1) - 1, co = c_lo & ~3;
+        const int32_t xo = xe & ~3, c_lo = SS ? (xe >> 1) - 1 : xe, co = c_lo & ~3;
         shy = (uint32_t)(xe & 3) * 8; shc = (uint32_t)(c_lo & 3) * 8;
         // clamped into the row: a clamped dword only feeds columns outside the image
 #pragma unroll
@@ -161,7 +162,7 @@ struct LpaWindow {
         // jdsample.c replicates the first and the last chroma column (of downsampled_width, not of the padded plane). Columns further
         // out are only reached by weight-0 taps.
         il = -1 - c_lo; ir = P.dw - c_lo;
-        edge = il >= 0 || ir < NC;
+        edge = SS && (il >= 0 || ir < NC);
     }
     // weight of window column c from the weights in tap order: tap k sits at column k + odd (FLIP: MAXT - 1 - k + odd)
     template <bool FLIP>
@@ -177,45 +178,47 @@ struct LpaWindow {
 };
 
 // One source row sy (the same for the whole wave) of a lane's window: f(c, b, g, r) for its NX columns, ascending or (REV) descending.
-// The upsampler's and the colour conversion's integer arithmetic as in k_ycc_to_frame_420.
-template <int MAXT, bool REV, class F>
-LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& PB, const LpaPlane& PR, const LpaWindow<MAXT>& W, int32_t sy, F&& f)
+// The upsamplers' (jdsample.c h2v2_fancy_upsample / h2v1_fancy_upsample) and the colour conversion's integer arithmetic as in
+// k_ycc_to_frame_420 / k_ycc_to_frame.
+template <int MAXT, int SS, bool REV, class F>
+LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& PB, const LpaPlane& PR, const LpaWindow<MAXT, SS>& W, int32_t sy, F&& f)
 {
-    constexpr int NX = LpaWindow<MAXT>::NX, NWY = LpaWindow<MAXT>::NWY, NC = LpaWindow<MAXT>::NC, NWC = LpaWindow<MAXT>::NWC;
+    typedef LpaWindow<MAXT, SS> Win;
+    constexpr int NX = Win::NX, NWY = Win::NWY, NC = Win::NC, NWC = Win::NWC;
     const int32_t KR = 32768 - 128 * LPA_FIX16(1.40200), KB = 32768 - 128 * LPA_FIX16(1.77200);
     const int32_t KG = 32768 + 128 * LPA_FIX16(0.34414) + 128 * LPA_FIX16(0.71414);
-    const int32_t cy = sy >> 1;
-    const int32_t ny = lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1);
+    const int32_t cy = SS == 2 ? sy >> 1 : sy;
+    const int32_t ny = SS == 2 ? lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1) : cy;
     const uint32_t ry = (uint32_t)sy * P.sy, rc0 = (uint32_t)cy * P.sc, rc1 = (uint32_t)ny * P.sc;
     uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
 #pragma unroll
     for (int i = 0; i <= NWY; i++) wy[i] = PY.word(ry, W.oy[i]);
 #pragma unroll
     for (int i = 0; i <= NWC; i++) {
-        wb0[i] = PB.word(rc0, W.oc[i]); wb1[i] = PB.word(rc1, W.oc[i]);
-        wr0[i] = PR.word(rc0, W.oc[i]); wr1[i] = PR.word(rc1, W.oc[i]);
+        wb0[i] = PB.word(rc0, W.oc[i]); wr0[i] = PR.word(rc0, W.oc[i]);
+        if (SS == 2) { wb1[i] = PB.word(rc1, W.oc[i]); wr1[i] = PR.word(rc1, W.oc[i]); }
     }
 #pragma unroll
     for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], W.shy);
 #pragma unroll
     for (int i = 0; i < NWC; i++) {
-        wb0[i] = lpa_alignbit(wb0[i + 1], wb0[i], W.shc); wb1[i] = lpa_alignbit(wb1[i + 1], wb1[i], W.shc);
-        wr0[i] = lpa_alignbit(wr0[i + 1], wr0[i], W.shc); wr1[i] = lpa_alignbit(wr1[i + 1], wr1[i], W.shc);
+        wb0[i] = lpa_alignbit(wb0[i + 1], wb0[i], W.shc); wr0[i] = lpa_alignbit(wr0[i + 1], wr0[i], W.shc);
+        if (SS == 2) { wb1[i] = lpa_alignbit(wb1[i + 1], wb1[i], W.shc); wr1[i] = lpa_alignbit(wr1[i + 1], wr1[i], W.shc); }
     }
-    // vertical half of the upsampler, {Cb, Cr} packed in the halves of one register: 3 * nearer row + further row (<= 1020)
+    // {Cb, Cr} packed in the halves of one register. 4:2:0: the vertical half of the upsampler, 3 * nearer row + further row (<= 1020)
     uint32_t V[NC];
 #pragma unroll
     for (int i = 0; i < NC; i++) {
-        uint32_t a, b;
+        uint32_t a, b = 0;
         switch (i & 3) {
-        case 0: a = lpa_pair<0>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<0>(wr1[i >> 2], wb1[i >> 2]); break;
-        case 1: a = lpa_pair<1>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<1>(wr1[i >> 2], wb1[i >> 2]); break;
-        case 2: a = lpa_pair<2>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<2>(wr1[i >> 2], wb1[i >> 2]); break;
-        default: a = lpa_pair<3>(wr0[i >> 2], wb0[i >> 2]); b = lpa_pair<3>(wr1[i >> 2], wb1[i >> 2]); break;
+        case 0: a = lpa_pair<0>(wr0[i >> 2], wb0[i >> 2]); if (SS == 2) b = lpa_pair<0>(wr1[i >> 2], wb1[i >> 2]); break;
+        case 1: a = lpa_pair<1>(wr0[i >> 2], wb0[i >> 2]); if (SS == 2) b = lpa_pair<1>(wr1[i >> 2], wb1[i >> 2]); break;
+        case 2: a = lpa_pair<2>(wr0[i >> 2], wb0[i >> 2]); if (SS == 2) b = lpa_pair<2>(wr1[i >> 2], wb1[i >> 2]); break;
+        default: a = lpa_pair<3>(wr0[i >> 2], wb0[i >> 2]); if (SS == 2) b = lpa_pair<3>(wr1[i >> 2], wb1[i >> 2]); break;
         }
-        V[i] = 3u * a + b;
+        V[i] = SS == 2 ? 3u * a + b : a;
     }
-    if (W.edge) {
+    if (SS && W.edge) {
 #pragma unroll
         for (int i = 0; i + 1 < NC; i++) V[i] = i == W.il ? V[i + 1] : V[i];
 #pragma unroll
@@ -224,11 +227,18 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
 #pragma unroll
     for (int t = 0; t < NX; t++) {
         const int c = REV ? NX - 1 - t : t;
-        // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right (bias 7), even ones with the
-        // one to the left (bias 8) -- h2v2_fancy_upsample's horizontal half on the vertical sums: (3 * near + far + bias) >> 4
-        const int ic = c / 2 + 1;
-        const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + ((c & 1) ? 0x00070007u : 0x00080008u);
-        const int32_t cb = (int32_t)((h >> 4) & 0xfffu), cr = (int32_t)(h >> 20);
+        int32_t cb, cr;
+        if (SS) {
+            // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right, even ones with the one to the
+            // left -- the horizontal half of h2v2_fancy_upsample on the vertical sums, (3 * near + far + 7 or 8) >> 4, or
+            // h2v1_fancy_upsample on the samples, (3 * near + far + 2 or 1) >> 2 (a replicated neighbour gives the edge rule: near itself)
+            const int ic = c / 2 + 1;
+            const uint32_t bias = SS == 2 ? ((c & 1) ? 0x00070007u : 0x00080008u) : ((c & 1) ? 0x00020002u : 0x00010001u);
+            const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + bias;
+            cb = (int32_t)((h >> (SS == 2 ? 4 : 2)) & 0xfffu); cr = (int32_t)(h >> (SS == 2 ? 20 : 18));
+        } else {
+            cb = (int32_t)(V[c] & 0xffffu); cr = (int32_t)(V[c] >> 16);
+        }
         const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
         const int32_t r = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.40200), cr, KR) >> 16), 0, 255);
         const int32_t b = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.77200), cb, KB) >> 16), 0, 255);
@@ -242,16 +252,16 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
 //   al[k]  x weights in tap order
 //   yt, y0..y1, ybase, ystep  the destination row's taps (wave-uniform): source row = ybase + ystep * yt[j].si
 // resize.cpp ResizeArea_Invoker: per source row buf = sum over the x taps of value * alpha; sum += beta * buf.
-template <int MAXT, bool FLIPX>
+template <int MAXT, int SS, bool FLIPX>
 LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al)[MAXT], const LpTap* __restrict__ yt, uint32_t y0, uint32_t y1,
                              int32_t ybase, int32_t ystep, uint8_t* __restrict__ out)
 {
 #pragma clang fp contract(off) // every product is rounded before it is added, as in resize.cpp's scalar loops
-    constexpr int NX = LpaWindow<MAXT>::NX;
+    constexpr int NX = LpaWindow<MAXT, SS>::NX;
     const int32_t odd = xa & 1;
     float w[NX];
-    LpaWindow<MAXT>::template weights<FLIPX>(odd, al, w);
-    LpaWindow<MAXT> W;
+    LpaWindow<MAXT, SS>::template weights<FLIPX>(odd, al, w);
+    LpaWindow<MAXT, SS> W;
     W.init(P, xa - odd);
     const LpaPlane PY = lpa_plane(P.py), PB = lpa_plane(P.pb), PR = lpa_plane(P.pr);
     lpa_f2 sbg = {0.f, 0.f};
@@ -264,7 +274,7 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
         // blue and green travel as a pair (one v_pk_mul_f32 + one v_pk_add_f32 for the two: each half is the same IEEE multiply and add)
         lpa_f2 bg = {0.f, 0.f};
         float rs = 0.f;
-        lpa_row<MAXT, FLIPX>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
+        lpa_row<MAXT, SS, FLIPX>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
             const lpa_f2 pbg = {(float)b, (float)g}, ww = {w[c], w[c]};
             bg = bg + pbg * ww;
             rs = lpa_add(rs, lpa_mul((float)r, w[c]));
@@ -284,16 +294,16 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
 // over the window's columns at the end -- the same products added in the same order as resize.cpp's.
 //   xa, be[k]  leftmost source column the y taps can reach, y weights in tap order; FLIPC: tap k reads column MAXT-1-k (orientations 7, 8)
 //   xt, x0..x1, rbase, rstep  the destination column's taps (wave-uniform): source row = rbase + rstep * xt[k].si
-template <int MAXT, bool FLIPC>
+template <int MAXT, int SS, bool FLIPC>
 LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&be)[MAXT], const LpTap* __restrict__ xt, uint32_t x0, uint32_t x1,
                               int32_t rbase, int32_t rstep, uint8_t* __restrict__ out)
 {
 #pragma clang fp contract(off)
-    constexpr int NX = LpaWindow<MAXT>::NX;
+    constexpr int NX = LpaWindow<MAXT, SS>::NX;
     const int32_t odd = xa & 1;
     float w[NX];
-    LpaWindow<MAXT>::template weights<FLIPC>(odd, be, w);
-    LpaWindow<MAXT> W;
+    LpaWindow<MAXT, SS>::template weights<FLIPC>(odd, be, w);
+    LpaWindow<MAXT, SS> W;
     W.init(P, xa - odd);
     const LpaPlane PY = lpa_plane(P.py), PB = lpa_plane(P.pb), PR = lpa_plane(P.pr);
     lpa_f2 bg[NX];
@@ -305,7 +315,7 @@ LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&b
         const float alpha = xt[k].alpha;
         const int32_t sy = rbase + rstep * (int32_t)xt[k].si;
         const lpa_f2 aa = {alpha, alpha};
-        lpa_row<MAXT, false>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
+        lpa_row<MAXT, SS, false>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
             const lpa_f2 pbg = {(float)b, (float)g};
             bg[c] = bg[c] + pbg * aa;
             rs[c] = lpa_add(rs[c], lpa_mul((float)r, alpha));

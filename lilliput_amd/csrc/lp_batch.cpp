@@ -372,7 +372,7 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
     auto lap = [&](int k) { const double t = now(); tw[k] += t - t_prev; t_prev = t; };
     {
         // How an image gets from planes to its output size: 1 = integer-scale area resize, fused (k_resample_*); 2 = fractional area
-        // resize of a YCbCr 4:2:0 image, fused (k_area_420 / k_area_420t; LILLIPUT_HIP_AREA_FUSED=0 sends these through the frame as
+        // resize of a YCbCr 4:2:0 / 4:2:2 / 4:4:4 image, fused (k_area_420 / k_area_420t; LILLIPUT_HIP_AREA_FUSED=0 sends these through the frame as
         // before round 3); 0 = through a materialised BGR frame, exactly like the one-image ABI.
         static const bool area_on = !(getenv("LILLIPUT_HIP_AREA_FUSED") && atoi(getenv("LILLIPUT_HIP_AREA_FUSED")) == 0);
         std::map<std::pair<int, int>, uint32_t> bucket_cache;
@@ -381,7 +381,7 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
             int ix, iy;
             const int mode = lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
             if (mode == 1) return 1;
-            if (mode != 2 || !area_on || !(j.ncomp == 3 && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4)) return 0;
+            if (mode != 2 || !area_on || lp_area_sampling(j) < 0) return 0;
             // the axis of the oriented crop that runs along source x picks the instantiation: x for orientations 1-4, y for 5-8
             const bool swapped = j.orientation >= 5;
             const auto key = swapped ? std::make_pair(-plan.crop_h, plan.out_h) : std::make_pair(plan.crop_w, plan.out_w);

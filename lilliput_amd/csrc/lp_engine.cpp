@@ -1185,6 +1185,14 @@ static uint32_t area_bucket_of(const std::vector<LpTap>& taps, const std::vector
     return mx <= 6 ? 6u : mx <= 10 ? 10u : mx <= 18 ? 18u : mx <= 34 ? 34u : mx <= 66 ? 66u : 0u;
 }
 
+int lp_area_sampling(const LpJpeg& j)
+{
+    if (j.ncomp != 3 || j.generic_sampling || j.colorspace != 2) return -1;
+    if (j.hs[0] == 1 && j.vs[0] == 1) return 0;
+    if (j.hs[0] == 2 && j.width > 4) return j.vs[0] == 2 ? 2 : j.vs[0] == 1 ? 1 : -1; // jdsample.c: no fancy upsampling up to 4 pixels of width
+    return -1;
+}
+
 uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed)
 {
     if (ssize <= 0 || dsize <= 0 || dsize >= ssize) return 0;
@@ -1206,14 +1214,15 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
     taps.clear();
     ranges.clear();
     std::map<std::pair<int, int>, std::pair<uint32_t, uint32_t>> cache; // (ssize, dsize) -> (tap_off, range_off)
-    uint32_t mask = 0, mdw = 0, mdh = 0;
+    uint32_t mask[3] = {0, 0, 0}, mdw = 0, mdh = 0;
     for (int i = 0; i < n; i++) {
         const LpAreaReq& r = reqs[i];
         const LpJpeg& j = h_imgs_[r.img];
         LpArea420Op& op = ops[(size_t)i];
-        if (!(j.ncomp == 3 && !j.generic_sampling && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4) || (r.xstep != 1 && r.xstep != -1) ||
+        const int ss = lp_area_sampling(j);
+        if (ss < 0 || (r.xstep != 1 && r.xstep != -1) ||
             (r.ystep != 1 && r.ystep != -1) || !r.dst.off || !r.dst.w || !r.dst.h) {
-            err_ = "area_resample: not a YCbCr 4:2:0 image / not a row-wise orientation";
+            err_ = "area_resample: not a YCbCr 4:2:0 / 4:2:2 / 4:4:4 image";
             return LP_ERR_DEVICE;
         }
         op.img = r.img; op.x0 = r.x0; op.y0 = r.y0; op.xstep = r.xstep; op.ystep = r.ystep;
@@ -1236,7 +1245,7 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
         op.maxt = op.transposed ? area_bucket_of(taps, ranges, op.ytab_off, op.yrange_off, r.dst.h) : area_bucket_of(taps, ranges, op.xtab_off, op.xrange_off, r.dst.w);
         if (!op.maxt || (op.transposed && op.maxt > 34)) { err_ = "area_resample: no kernel for this many taps"; return LP_ERR_DEVICE; }
         const uint32_t bit = op.maxt == 6 ? 0u : op.maxt == 10 ? 1u : op.maxt == 18 ? 2u : op.maxt == 34 ? 3u : 4u;
-        mask |= op.transposed ? 1u << (10u + bit + (r.xstep < 0 ? 4u : 0u)) : 1u << (bit + (r.xstep < 0 ? 5u : 0u));
+        mask[ss] |= op.transposed ? 1u << (10u + bit + (r.xstep < 0 ? 4u : 0u)) : 1u << (bit + (r.xstep < 0 ? 5u : 0u));
         mdw = std::max(mdw, r.dst.w);
         mdh = std::max(mdh, r.dst.h);
     }
@@ -1257,7 +1266,7 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
 
 // Test access: lp_area420_pixel / lp_area420t_pixel on the host (what k_area_420 / k_area_420t run per thread), so that the order of
 // operations can be compared with the oracle without a GPU. Not a product path: nothing in the library calls it.
-template <int MAXT, bool FLIP>
+template <int MAXT, int SS, bool FLIP>
 static void area420_host_run(const LpAreaPlanes& P, const LpArea420Op& op, const std::vector<LpTap>& taps, const std::vector<uint32_t>& ranges, uint8_t* out)
 {
     for (uint32_t dy = 0; dy < op.dst.h; dy++)
@@ -1271,13 +1280,13 @@ static void area420_host_run(const LpAreaPlanes& P, const LpArea420Op& op, const
                 for (int k = 0; k < MAXT; k++) wt[k] = (uint32_t)k < y1 - y0 ? yt[k].alpha : 0.f;
                 const int32_t si0 = (int32_t)yt[0].si;
                 const int32_t xa = FLIP ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
-                lp_area420t_pixel<MAXT, FLIP>(P, xa, wt, taps.data() + op.xtab_off, x0, x1, op.y0, op.ystep, o);
+                lp_area420t_pixel<MAXT, SS, FLIP>(P, xa, wt, taps.data() + op.xtab_off, x0, x1, op.y0, op.ystep, o);
             } else {
                 const LpTap* xt = taps.data() + op.xtab_off + x0;
                 for (int k = 0; k < MAXT; k++) wt[k] = (uint32_t)k < x1 - x0 ? xt[k].alpha : 0.f;
                 const int32_t si0 = (int32_t)xt[0].si;
                 const int32_t xa = FLIP ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
-                lp_area420_pixel<MAXT, FLIP>(P, xa, wt, taps.data() + op.ytab_off, y0, y1, op.y0, op.ystep, o);
+                lp_area420_pixel<MAXT, SS, FLIP>(P, xa, wt, taps.data() + op.ytab_off, y0, y1, op.y0, op.ystep, o);
             }
         }
 }
@@ -1305,10 +1314,10 @@ void lp_area420_place(int orientation, int w, int h, int crop_x, int crop_y, LpA
     area420_place(orientation, w, h, crop_x, crop_y, &rq->x0, &rq->xstep, &rq->y0, &rq->ystep, &rq->transposed);
 }
 
-extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h,
+extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_t* pr, uint32_t stride_y, uint32_t stride_c, int w, int h, int sampling,
                                          int orientation, int crop_x, int crop_y, int crop_w, int crop_h, int dst_w, int dst_h, uint8_t* out)
 {
-    if (orientation < 1 || orientation > 8 || w <= 4 || (stride_y & 3) || (stride_c & 3)) return 1;
+    if (orientation < 1 || orientation > 8 || sampling < 0 || sampling > 2 || (sampling && w <= 4) || (stride_y & 3) || (stride_c & 3)) return 1;
     int ix, iy;
     if (lp_resize_mode(crop_w, crop_h, dst_w, dst_h, &ix, &iy) != 2) return 1;
     std::vector<LpTap> taps;
@@ -1323,10 +1332,12 @@ extern "C" int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, c
     if (!op.maxt || (op.transposed && op.maxt > 34)) return 1;
     op.dst.w = (uint32_t)dst_w; op.dst.h = (uint32_t)dst_h;
     const bool flip = op.xstep < 0;
-    LpAreaPlanes P{py, pb, pr, stride_y, stride_c, (w + 1) >> 1, (h + 1) >> 1};
-#define LP_AREA_HOST(T) case T: if (flip) area420_host_run<T, true>(P, op, taps, ranges, out); else area420_host_run<T, false>(P, op, taps, ranges, out); break
+    LpAreaPlanes P{py, pb, pr, stride_y, stride_c, sampling ? (w + 1) >> 1 : w, sampling == 2 ? (h + 1) >> 1 : h};
+#define LP_AREA_HOST2(T, S) if (flip) area420_host_run<T, S, true>(P, op, taps, ranges, out); else area420_host_run<T, S, false>(P, op, taps, ranges, out)
+#define LP_AREA_HOST(T) case T: if (sampling == 2) { LP_AREA_HOST2(T, 2); } else if (sampling == 1) { LP_AREA_HOST2(T, 1); } else { LP_AREA_HOST2(T, 0); } break
     switch (op.maxt) { LP_AREA_HOST(6); LP_AREA_HOST(10); LP_AREA_HOST(18); LP_AREA_HOST(34); LP_AREA_HOST(66); default: return 1; }
 #undef LP_AREA_HOST
+#undef LP_AREA_HOST2
     return 0;
 }
 

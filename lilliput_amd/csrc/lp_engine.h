@@ -297,6 +297,8 @@ int lp_area_tab(int ssize, int dsize, std::vector<LpTap>& taps, std::vector<uint
 // (the axis meant is the one that runs along source x: the crop's x axis, or its y axis for the transposing orientations, whose
 // kernel stops at 34 taps)
 uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed = false);
+// which chroma layout of k_area_420 an image has: 2 = YCbCr 4:2:0, 1 = 4:2:2, 0 = 4:4:4, -1 = none of them (frame route)
+int lp_area_sampling(const LpJpeg& j);
 // fills x0 / xstep / y0 / ystep / transposed of a request from the EXIF orientation (cv::ExifTransform's inverse), the decoded size and
 // the crop origin in oriented coordinates
 void lp_area420_place(int orientation, int w, int h, int crop_x, int crop_y, LpAreaReq* rq);

@@ -652,12 +652,22 @@ __global__ __launch_bounds__(256) void k_resize_area3(const LpResizeOp* __restri
     for (int c = 0; c < 3; c++) D[c] = (uint8_t)sat_round_u8(sum[c]);
 }
 
-// Fractional INTER_AREA straight from YCbCr 4:2:0 planes (no BGR frame in between): lp_area_core.h has the per-pixel walk -- the
-// upsampler and the colour conversion of k_ycc_to_frame_420 feeding the float sums of k_resize_area3 in the same order, so the
-// bytes equal the frame route's. One thread per destination pixel; a wave is 64 neighbouring columns of one destination row,
-// so its loads of a source row fall into one contiguous run of the luma row and of the two chroma rows. Per destination
-// pixel the frame route read and wrote 3 bytes per source pixel twice over; this reads 1.5.
-template <int MAXT, bool FLIPX>
+// Fractional INTER_AREA straight from YCbCr planes (no BGR frame in between): lp_area_core.h has the per-pixel walk -- the upsampler
+// and the colour conversion of k_ycc_to_frame(_420) feeding the float sums of k_resize_area3 in the same order, so the bytes equal
+// the frame route's. One thread per destination pixel; a wave is 64 neighbouring columns of one destination row, so its loads of a
+// source row fall into one contiguous run of the luma row and of the chroma rows. Per destination pixel the frame route read and
+// wrote 3 bytes per source pixel twice over; this reads 1.5 (4:2:0). SS: 2 = 4:2:0, 1 = 4:2:2, 0 = 4:4:4.
+__device__ __forceinline__ bool area_planes(const LpJpeg& img, const uint8_t* __restrict__ plane_arena, int ss, LpAreaPlanes& P)
+{
+    if ((img.hs[0] == 2 ? (img.vs[0] == 2 ? 2 : 1) : 0) != ss) return false;
+    P.py = plane_arena + img.plane_off[0]; P.pb = plane_arena + img.plane_off[1]; P.pr = plane_arena + img.plane_off[2];
+    P.sy = img.plane_stride[0]; P.sc = img.plane_stride[1];
+    P.dw = ss ? (int32_t)(img.width + 1) >> 1 : (int32_t)img.width;
+    P.dh = ss == 2 ? (int32_t)(img.height + 1) >> 1 : (int32_t)img.height;
+    return true;
+}
+
+template <int MAXT, int SS, bool FLIPX>
 __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ imgs, const LpArea420Op* __restrict__ ops, const LpTap* __restrict__ taps,
                                                   const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ plane_arena)
 {
@@ -665,7 +675,8 @@ __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ img
     if (op.transposed || op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPX) return;
     const uint32_t dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= op.dst.w || dy >= op.dst.h) return;
-    const LpJpeg& img = imgs[op.img];
+    LpAreaPlanes P;
+    if (!area_planes(imgs[op.img], plane_arena, SS, P)) return;
     const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
     const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
     const LpTap* xt = taps + op.xtab_off + x0;
@@ -675,18 +686,14 @@ __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ img
     for (int k = 0; k < MAXT; k++) al[k] = (uint32_t)k < nx ? xt[k].alpha : 0.f;
     const int32_t si0 = (int32_t)xt[0].si;
     const int32_t xa = FLIPX ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
-    LpAreaPlanes P;
-    P.py = plane_arena + img.plane_off[0]; P.pb = plane_arena + img.plane_off[1]; P.pr = plane_arena + img.plane_off[2];
-    P.sy = img.plane_stride[0]; P.sc = img.plane_stride[1];
-    P.dw = (int32_t)(img.width + 1) >> 1; P.dh = (int32_t)(img.height + 1) >> 1;
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    lp_area420_pixel<MAXT, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D);
+    lp_area420_pixel<MAXT, SS, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D);
 }
 
 // The same for the orientations that swap the axes (5-8): the lanes of a wave are 64 neighbouring destination ROWS of one destination
 // column -- neighbouring source columns, one shared run of source rows -- so the plane loads coalesce exactly as above; the three
 // output bytes of a lane land a destination row apart (64 small writes per wave against ~20 k instructions of work).
-template <int MAXT, bool FLIPC>
+template <int MAXT, int SS, bool FLIPC>
 __global__ __launch_bounds__(256) void k_area_420t(const LpJpeg* __restrict__ imgs, const LpArea420Op* __restrict__ ops, const LpTap* __restrict__ taps,
                                                    const uint32_t* __restrict__ ranges, const uint8_t* __restrict__ plane_arena)
 {
@@ -694,7 +701,8 @@ __global__ __launch_bounds__(256) void k_area_420t(const LpJpeg* __restrict__ im
     if (!op.transposed || op.maxt != (uint32_t)MAXT || (op.xstep < 0) != FLIPC) return;
     const uint32_t dy = blockIdx.x * 64 + threadIdx.x, dx = blockIdx.y * 4 + threadIdx.y;
     if (dx >= op.dst.w || dy >= op.dst.h) return;
-    const LpJpeg& img = imgs[op.img];
+    LpAreaPlanes P;
+    if (!area_planes(imgs[op.img], plane_arena, SS, P)) return;
     const uint32_t x0 = ranges[op.xrange_off + dx], x1 = ranges[op.xrange_off + dx + 1];
     const uint32_t y0 = ranges[op.yrange_off + dy], y1 = ranges[op.yrange_off + dy + 1];
     const LpTap* yt = taps + op.ytab_off + y0;
@@ -704,12 +712,8 @@ __global__ __launch_bounds__(256) void k_area_420t(const LpJpeg* __restrict__ im
     for (int k = 0; k < MAXT; k++) be[k] = (uint32_t)k < ny ? yt[k].alpha : 0.f;
     const int32_t si0 = (int32_t)yt[0].si;
     const int32_t xa = FLIPC ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
-    LpAreaPlanes P;
-    P.py = plane_arena + img.plane_off[0]; P.pb = plane_arena + img.plane_off[1]; P.pr = plane_arena + img.plane_off[2];
-    P.sy = img.plane_stride[0]; P.sc = img.plane_stride[1];
-    P.dw = (int32_t)(img.width + 1) >> 1; P.dh = (int32_t)(img.height + 1) >> 1;
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    lp_area420t_pixel<MAXT, FLIPC>(P, xa, be, taps + op.xtab_off, x0, x1, op.y0, op.ystep, D);
+    lp_area420t_pixel<MAXT, SS, FLIPC>(P, xa, be, taps + op.xtab_off, x0, x1, op.y0, op.ystep, D);
 }
 
 // INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point
@@ -1287,22 +1291,32 @@ void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uin
         hipLaunchKernelGGL(k_resize_linear, g2, dim3(64, 4), 0, s, d_ops, reinterpret_cast<const int32_t*>(d_ranges), d_src, d_dst);
 }
 
-// mask: bit b = MAXT bucket b of {6, 10, 18, 34, 66} present, +5 for the mirrored (xstep < 0) instantiation; bits 10-17 the same
-// for the axis-swapping orientations (k_area_420t; buckets up to 34: a window column there costs three accumulators)
-void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, uint32_t mask, uint32_t max_dw, uint32_t max_dh,
-                        const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes)
+// mask[ss] (ss = 0 4:4:4, 1 4:2:2, 2 4:2:0): bit b = MAXT bucket b of {6, 10, 18, 34, 66} present, +5 for the mirrored (xstep < 0)
+// instantiation; bits 10-17 the same for the axis-swapping orientations (k_area_420t; buckets up to 34: a window column there costs
+// three accumulators)
+template <int SS>
+static void launch_area_ss(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, uint32_t mask, uint32_t max_dw, uint32_t max_dh,
+                           const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes)
 {
-    if (!nops || !max_dw || !max_dh) return;
     dim3 g((max_dw + 63) / 64, (max_dh + 3) / 4, nops);
-#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420<T, F>), g, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
+#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420<T, SS, F>), g, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
     LP_AREA_LAUNCH(0, 6, false); LP_AREA_LAUNCH(1, 10, false); LP_AREA_LAUNCH(2, 18, false); LP_AREA_LAUNCH(3, 34, false); LP_AREA_LAUNCH(4, 66, false);
     LP_AREA_LAUNCH(5, 6, true); LP_AREA_LAUNCH(6, 10, true); LP_AREA_LAUNCH(7, 18, true); LP_AREA_LAUNCH(8, 34, true); LP_AREA_LAUNCH(9, 66, true);
 #undef LP_AREA_LAUNCH
     dim3 gt((max_dh + 63) / 64, (max_dw + 3) / 4, nops);
-#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420t<T, F>), gt, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
+#define LP_AREA_LAUNCH(bit, T, F) if (mask & (1u << (bit))) hipLaunchKernelGGL((k_area_420t<T, SS, F>), gt, dim3(64, 4), 0, s, d_imgs, d_ops, d_taps, d_ranges, d_planes)
     LP_AREA_LAUNCH(10, 6, false); LP_AREA_LAUNCH(11, 10, false); LP_AREA_LAUNCH(12, 18, false); LP_AREA_LAUNCH(13, 34, false);
     LP_AREA_LAUNCH(14, 6, true); LP_AREA_LAUNCH(15, 10, true); LP_AREA_LAUNCH(16, 18, true); LP_AREA_LAUNCH(17, 34, true);
 #undef LP_AREA_LAUNCH
+}
+
+void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, const uint32_t mask[3], uint32_t max_dw, uint32_t max_dh,
+                        const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes)
+{
+    if (!nops || !max_dw || !max_dh) return;
+    if (mask[0]) launch_area_ss<0>(s, d_imgs, d_ops, nops, mask[0], max_dw, max_dh, d_taps, d_ranges, d_planes);
+    if (mask[1]) launch_area_ss<1>(s, d_imgs, d_ops, nops, mask[1], max_dw, max_dh, d_taps, d_ranges, d_planes);
+    if (mask[2]) launch_area_ss<2>(s, d_imgs, d_ops, nops, mask[2], max_dw, max_dh, d_taps, d_ranges, d_planes);
 }
 
 void lp_launch_composite(hipStream_t s, const LpCompositeOp& op, const uint8_t* d_src, uint8_t* d_dst)

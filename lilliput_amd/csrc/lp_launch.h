@@ -53,7 +53,7 @@ void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, 
 void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFusedOp* d_ops, uint32_t nops, uint32_t max_px, bool general,
                               uint32_t fast_mask, uint32_t fast_grid, const uint8_t* d_planes);
 struct LpArea420Op;
-void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, uint32_t mask, uint32_t max_dw, uint32_t max_dh,
+void lp_launch_area_420(hipStream_t s, const LpJpeg* d_imgs, const LpArea420Op* d_ops, uint32_t nops, const uint32_t mask[3], uint32_t max_dw, uint32_t max_dh,
                         const LpTap* d_taps, const uint32_t* d_ranges, const uint8_t* d_planes);
 void lp_launch_orient(hipStream_t s, const LpOrientOp* d_ops, uint32_t nimg, uint32_t max_w, uint32_t max_h, const uint8_t* d_src, uint8_t* d_dst);
 void lp_launch_resize(hipStream_t s, const LpResizeOp* d_ops, uint32_t nimg, uint32_t modes_present, uint32_t area3_mask, uint32_t max_dw, uint32_t max_dh,

@@ -44,7 +44,7 @@ def test_area_walk_on_the_host_matches_the_oracle(hip_lib, oracle):
 
     u8p = C.POINTER(C.c_uint8)
     fn = hip_lib.lilliput_hip_area420_host
-    fn.argtypes = [u8p, u8p, u8p, C.c_uint32, C.c_uint32] + [C.c_int] * 9 + [u8p]
+    fn.argtypes = [u8p, u8p, u8p, C.c_uint32, C.c_uint32] + [C.c_int] * 10 + [u8p]
     fn.restype = C.c_int
     rgb = synth.synth_rgb(11, 512)
     rng = np.random.default_rng(5)
@@ -53,34 +53,35 @@ def test_area_walk_on_the_host_matches_the_oracle(hip_lib, oracle):
         w, h = int(rng.integers(5, 512)), int(rng.integers(2, 512))
         cases.append((w, h, int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))))
     ran = 0
-    for (w, h, tw, th) in cases:
-        data = _jpeg(rgb, w, h)
-        planes = [np.ascontiguousarray(oracle.jpeg_decode_plane(data, c)) for c in range(3)]
-        px = oracle.jpeg_decode(data)
-        for o in range(1, 9):
-            for method in (oracle.FIT, oracle.RESIZE):
-                exp = oracle.transform_static(px, o, tw, th, method, False)
-                nw, nh, left, top, wpc, hpc = _crop_plan(oracle, w, h, o, tw, th, method)
-                out = np.zeros((nh, nw, 3), np.uint8)
-                rc = fn(planes[0].ctypes.data_as(u8p), planes[1].ctypes.data_as(u8p), planes[2].ctypes.data_as(u8p), planes[0].shape[1], planes[1].shape[1],
-                        w, h, o, left, top, wpc, hpc, nw, nh, out.ctypes.data_as(u8p))
-                if rc == 1:  # integer scale, an up-scaling axis, or more than 66 (34 when the axes swap) taps: not these kernels'
-                    continue
-                assert rc == 0
-                ran += 1
-                assert exp.shape == out.shape and np.array_equal(exp, out), (w, h, tw, th, o, method)
-    assert ran > 200
+    for n, (w, h, tw, th) in enumerate(cases):
+        for ss in ((2, 1, 0) if n % 3 == 0 else (2,) if n % 3 == 1 else (1, 0)):  # PIL's subsampling: 2 = 4:2:0, 1 = 4:2:2, 0 = 4:4:4
+            data = _jpeg(rgb, w, h, ss)
+            planes = [np.ascontiguousarray(oracle.jpeg_decode_plane(data, c)) for c in range(3)]
+            px = oracle.jpeg_decode(data)
+            for o in range(1, 9):
+                for method in (oracle.FIT, oracle.RESIZE):
+                    exp = oracle.transform_static(px, o, tw, th, method, False)
+                    nw, nh, left, top, wpc, hpc = _crop_plan(oracle, w, h, o, tw, th, method)
+                    out = np.zeros((nh, nw, 3), np.uint8)
+                    rc = fn(planes[0].ctypes.data_as(u8p), planes[1].ctypes.data_as(u8p), planes[2].ctypes.data_as(u8p), planes[0].shape[1],
+                            planes[1].shape[1], w, h, ss, o, left, top, wpc, hpc, nw, nh, out.ctypes.data_as(u8p))
+                    if rc == 1:  # integer scale, an up-scaling axis, or more than 66 (34 when the axes swap) taps: not these kernels'
+                        continue
+                    assert rc == 0
+                    ran += 1
+                    assert exp.shape == out.shape and np.array_equal(exp, out), (w, h, tw, th, ss, o, method)
+    assert ran > 400
 
 
 @pytest.mark.gpu
 def test_fractional_scales_all_orientations_bit_exact(batch, oracle):
-    """Orientations 1-4 take k_area_420, 5-8 k_area_420t, the other sampling layouts (and tap counts past the kernels') the frame route:
-    all must give the oracle's bytes."""
+    """Orientations 1-4 take k_area_420, 5-8 k_area_420t (4:2:0, 4:2:2 and 4:4:4 each have their instantiations); tap counts past the
+    kernels' take the frame route: all must give the oracle's bytes."""
     from lilliput_amd import synth
 
     rgb = synth.synth_rgb(11, 512)
     for (w, h, tw, th) in CASES:
-        for ss in ((2,) if (w, h) != (250, 243) else (2, 1, 0)):
+        for ss in ((2,) if (w * 7 + h) % 3 else (2, 1, 0)):
             data = _jpeg(rgb, w, h, ss)
             for o in range(1, 9):
                 d = _with_exif_orientation(data, o)
@@ -94,14 +95,14 @@ def test_fractional_scales_all_orientations_bit_exact(batch, oracle):
 
 @pytest.mark.gpu
 def test_fractional_scales_in_one_mixed_batch(batch, oracle):
-    """One call with images of every route (integer scale, fractional row-wise, fractional axis-swapping, 4:2:2) and several tap counts:
+    """One call with images of every route (integer scale, fractional row-wise, fractional axis-swapping; 4:2:0, 4:2:2, 4:4:4) and several tap counts:
     the kernels share launches through their op lists."""
     from lilliput_amd import synth
 
     rgb = synth.synth_rgb(23, 512)
     srcs = []
     for i, (w, h) in enumerate(((500, 500), (512, 512), (400, 300), (333, 222), (512, 256), (250, 243), (97, 131), (300, 500))):
-        d = _jpeg(rgb, w, h, 2 if i != 4 else 1)
+        d = _jpeg(rgb, w, h, (2, 2, 1, 0)[i % 4])
         srcs.append(_with_exif_orientation(d, 1 + (i * 3) % 8))
     res = batch.transform(srcs, 64, 64, quality=85)
     for d, r in zip(srcs, res):
