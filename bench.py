@@ -106,7 +106,8 @@ def kernel_table(stage, images, c_in, c_out, size):
         "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
         "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
         "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
-        "k_resample_420 (upsample + colour + 16x16 box mean)": (stage.get("resize_ms", 0.0), plane_b + 3 * 256 * 256),
+        ("k_resample_420 (upsample + colour + 16x16 box mean)" if size % 256 == 0 else "k_area_420 (upsample + colour + fractional INTER_AREA taps; k_resample_* for the integer scales)"):
+            (stage.get("resize_ms", 0.0), plane_b + 3 * 256 * 256),
         "k_enc_* (JPEG encode)": (stage.get("encode_ms", 0.0), 3 * 256 * 256 + c_out),
     }, plane_b
 
