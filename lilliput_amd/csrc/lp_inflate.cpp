@@ -115,7 +115,11 @@ uint32_t lp_crc32(uint32_t crc, const uint8_t* p, size_t n)
 
 namespace {
 
-enum : uint32_t { K_LIT = 0, K_BASE = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4, K_LIT2 = 5 };
+// kinds: bit 2 (bit 15 of the entry, E_NOT_LITERAL) is clear for the two literal kinds and set for everything else, so the test the loop
+// makes after every lookup is one bit -- and not "one literal or two?", which is a coin toss on photographic data and cost a branch
+// miss on a third of the lookups when it was a branch; the count of literals is bit 13
+enum : uint32_t { K_LIT = 0, K_LIT2 = 1, K_BASE = 4, K_EOB = 5, K_SUB = 6, K_BAD = 7 };
+constexpr uint32_t E_NOT_LITERAL = 1u << 15;
 // entry: bits 0..7 code length (K_SUB: bits of the second-level index), 8..12 extra bits, 13..15 kind, 16..31 value
 inline uint32_t mk(uint32_t len, uint32_t extra, uint32_t kind, uint32_t value) { return len | (extra << 8) | (kind << 13) | (value << 16); }
 inline uint32_t e_len(uint32_t e) { return e & 255u; }
@@ -319,33 +323,42 @@ int lp_inflate_exact(const uint8_t* in0, size_t in_len, uint8_t* out0, size_t ou
             if (in > in_stop) return 0;
             REFILL();
             uint32_t e = LL[bitbuf & ((1u << LL_BITS) - 1u)];
-            if (e_kind(e) == K_SUB) e = LL[e_value(e) + ((bitbuf >> LL_BITS) & ((1u << e_len(e)) - 1u))];
-            // up to three lookups on one refill (3 x 15 bits), each one or two literals
-            if (e_kind(e) == K_LIT || e_kind(e) == K_LIT2) {
+            // up to three lookups on one refill (each at most LL_BITS bits: longer codes leave through the second-level branch below),
+            // each one or two literals
+            if (!(e & E_NOT_LITERAL)) {
                 if (out_end - out < 6) { // close to the end of the image: one lookup at a time, with the room checked
-                    const size_t nlit = e_kind(e) == K_LIT2 ? 2 : 1;
+                    const size_t nlit = 1 + ((e >> 13) & 1u);
                     if ((size_t)(out_end - out) < nlit) return 0;
                     DROP(e_len(e));
                     *out++ = (uint8_t)e_value(e);
                     if (nlit == 2) *out++ = (uint8_t)(e_value(e) >> 8);
                     continue;
                 }
-#define PUT_LITERALS() do { const uint16_t v = (uint16_t)e_value(e); memcpy(out, &v, 2); out += e_kind(e) == K_LIT2 ? 2 : 1; DROP(e_len(e)); } while (0)
-#define NEXT_ENTRY() do { e = LL[bitbuf & ((1u << LL_BITS) - 1u)]; if (e_kind(e) == K_SUB) e = LL[e_value(e) + ((bitbuf >> LL_BITS) & ((1u << e_len(e)) - 1u))]; } while (0)
+#define PUT_LITERALS() do { const uint16_t v = (uint16_t)e_value(e); memcpy(out, &v, 2); out += 1 + ((e >> 13) & 1u); DROP(e_len(e)); } while (0)
+#define NEXT_ENTRY() do { e = LL[bitbuf & ((1u << LL_BITS) - 1u)]; } while (0)
                 PUT_LITERALS();
                 NEXT_ENTRY();
-                if (e_kind(e) == K_LIT || e_kind(e) == K_LIT2) {
+                if (!(e & E_NOT_LITERAL)) {
                     PUT_LITERALS();
                     NEXT_ENTRY();
-                    if (e_kind(e) == K_LIT || e_kind(e) == K_LIT2) {
+                    if (!(e & E_NOT_LITERAL)) {
                         PUT_LITERALS();
                         continue;
                     }
                 }
 #undef PUT_LITERALS
 #undef NEXT_ENTRY
-                // a length or the end of the block behind the literals: at most 30 bits are gone, 26 remain; top the buffer up
+                // a length, a long code or the end of the block behind the literals: at most 33 bits are gone; top the buffer up
                 REFILL();
+            }
+            if (e_kind(e) == K_SUB) {
+                e = LL[e_value(e) + ((bitbuf >> LL_BITS) & ((1u << e_len(e)) - 1u))];
+                if (!(e & E_NOT_LITERAL)) { // a literal with a code longer than LL_BITS
+                    if (out == out_end) return 0;
+                    DROP(e_len(e));
+                    *out++ = (uint8_t)e_value(e);
+                    continue;
+                }
             }
             const uint32_t kind = e_kind(e);
             if (kind == K_EOB) { DROP(e_len(e)); break; }
