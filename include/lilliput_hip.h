@@ -410,6 +410,12 @@ int lilliput_hip_device_count(void);
  * lilliput_hip_mem_info: hipMemGetInfo of `device` (LILLIPUT_OK or LILLIPUT_ERR_DEVICE). */
 void lilliput_hip_engine_pool_stats(size_t out[4]);
 int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
+/* Guard-page debugging mode (LILLIPUT_HIP_GUARD=<alignment>, read once; lilliput_amd/csrc/lp_guard.h): every device and pinned buffer of
+ * the library ends flush against an unmapped page, so one byte read or written past a buffer by a kernel or a DMA transfer is a GPU
+ * memory fault on the spot (the reference never touches a byte outside the caller's buffer, opencv.cpp:99-124), and a canary band in
+ * front of each buffer is checked when it is freed. out[0] = alignment in force (0: mode off), out[1] = guarded allocations so far,
+ * out[2] = canary violations found, out[3] = peak of mapped device bytes. */
+void lilliput_hip_guard_stats(size_t out[4]);
 
 /* Test access (no device work): number of inflated image-data bytes of a PNG, or -1 when libpng would reject the file. */
 int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8_t* v); /* test access: the planes the lossy WebP encoder is handed

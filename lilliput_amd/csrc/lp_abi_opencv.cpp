@@ -154,7 +154,7 @@ namespace {
 struct Pool {
     std::mutex mu;
     std::vector<std::pair<size_t, void*>> free_list;
-    ~Pool() { for (auto& b : free_list) (void)hipFree(b.second); }
+    ~Pool() { for (auto& b : free_list) lp_dev_free(b.second); }
 } g_pool;
 size_t bucket(size_t n) { size_t b = 4096; while (b < n) b <<= 1; return b; }
 }
@@ -163,13 +163,14 @@ LpDevBlock::~LpDevBlock()
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    if (g_pool.free_list.size() < 64) g_pool.free_list.emplace_back(cap, p);
-    else (void)hipFree(p);
+    if (g_pool.free_list.size() < 64 && !lp_guard_on()) g_pool.free_list.emplace_back(cap, p);
+    else lp_dev_free(p);
 }
 
 std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes)
 {
-    size_t want = bucket(bytes + 256); // kernels may read up to a few vector widths past the last pixel of a row
+    // kernels may read up to a few vector widths past the last pixel of a row (guard mode, lp_guard.h: that slack and not a byte more)
+    size_t want = lp_guard_on() ? bytes + 256 : bucket(bytes + 256);
     auto blk = std::make_shared<LpDevBlock>();
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -181,7 +182,7 @@ std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes)
                 return blk;
             }
     }
-    if (hipMalloc(&blk->p, want) != hipSuccess) { lp_set_error("hipMalloc failed"); return nullptr; }
+    if (lp_dev_malloc(&blk->p, want, "mat")) { lp_set_error("hipMalloc failed"); return nullptr; }
     blk->cap = want;
     return blk;
 }

@@ -58,7 +58,8 @@ Retired& retired()
     static Retired* r = new Retired(); // never destroyed: engines may be torn down from atexit handlers
     return *r;
 }
-size_t grown(size_t cap, size_t bytes) { return std::max(bytes + bytes / 8 + 256, cap + cap / 2); }
+// guard mode (lp_guard.h): exactly what was asked for, so that the byte after it is the unmapped page
+size_t grown(size_t cap, size_t bytes) { return lp_guard_on() ? bytes : std::max(bytes + bytes / 8 + 256, cap + cap / 2); }
 }
 void lp_retired_collect()
 {
@@ -71,20 +72,19 @@ void lp_retired_collect()
     }
     if (d.empty() && h.empty()) return;
     (void)hipDeviceSynchronize(); // whatever was enqueued against the old blocks has run
-    for (void* p : d) (void)hipFree(p);
-    for (void* p : h) (void)hipHostFree(p);
+    for (void* p : d) lp_dev_free(p);
+    for (void* p : h) lp_pinned_free(p);
 }
 
-LpDevBuf::~LpDevBuf() { if (p) (void)hipFree(p); }
+LpDevBuf::~LpDevBuf() { if (p) lp_dev_free(p); }
 bool LpDevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
     const size_t want = grown(cap, bytes);
     void* np = nullptr;
-    if (hipMalloc(&np, want) != hipSuccess) { // out of memory: give the retired blocks back first, then try once more
-        (void)hipGetLastError();
+    if (lp_dev_malloc(&np, want, tag)) { // out of memory: give the retired blocks back first, then try once more
         lp_retired_collect();
-        if (hipMalloc(&np, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (lp_dev_malloc(&np, want, tag)) return false;
     }
     if (p) {
         Retired& r = retired();
@@ -95,13 +95,13 @@ bool LpDevBuf::ensure(size_t bytes)
     cap = want;
     return true;
 }
-LpPinned::~LpPinned() { if (p) (void)hipHostFree(p); }
+LpPinned::~LpPinned() { if (p) lp_pinned_free(p); }
 bool LpPinned::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return true;
     const size_t want = grown(cap, bytes);
     void* np = nullptr;
-    if (hipHostMalloc(&np, want, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (lp_pinned_malloc(&np, want, false, tag)) return false;
     if (p) { // kernels read and write these blocks through their device alias
         Retired& r = retired();
         std::lock_guard<std::mutex> lk(r.mu);
@@ -117,6 +117,16 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 LpEngine::LpEngine(int device) : device_(device)
 {
+    // names for the guard mode's allocation log (lp_guard.h)
+#define LP_TAG(b) b.tag = #b
+    LP_TAG(d_imgs_); LP_TAG(d_states_); LP_TAG(d_clean_); LP_TAG(d_rst_); LP_TAG(d_chunk_); LP_TAG(d_ckpt_); LP_TAG(d_exit_); LP_TAG(d_spec_exit_); LP_TAG(d_entry_);
+    LP_TAG(d_tot_); LP_TAG(d_spec_tot_); LP_TAG(d_prefix_); LP_TAG(d_changed_); LP_TAG(d_coef_); LP_TAG(d_wide_); LP_TAG(d_wide_id_); LP_TAG(d_dc_); LP_TAG(d_dcpart_);
+    LP_TAG(d_planes_); LP_TAG(d_frames_desc_); LP_TAG(h_small_); LP_TAG(h_out_); LP_TAG(h_dstate_); LP_TAG(h_desc_); LP_TAG(d_pscans_); LP_TAG(d_pstreams_);
+    LP_TAG(d_pstates_); LP_TAG(d_pcoef_); LP_TAG(heap_); LP_TAG(d_ops_); LP_TAG(d_taps_); LP_TAG(d_ranges_); LP_TAG(d_fops_); LP_TAG(d_aops_); LP_TAG(d_ataps_);
+    LP_TAG(d_aranges_); LP_TAG(d_tone_); LP_TAG(d_jobs_); LP_TAG(d_estates_); LP_TAG(d_ecoef_); LP_TAG(d_blkbits_); LP_TAG(d_bits_); LP_TAG(d_hdrs_); LP_TAG(d_out_);
+    LP_TAG(d_packed_); LP_TAG(d_pkoff_);
+#undef LP_TAG
+    for (auto& u : up_) { u.d_raw.tag = "up.d_raw"; u.d_huffs.tag = "up.d_huffs"; u.d_phuffs.tag = "up.d_phuffs"; u.stage.tag = "up.stage"; u.pcoef.tag = "up.pcoef"; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { err_ = "no HIP device visible"; return; }
     if (device_ < 0 || device_ >= n) { err_ = "HIP device index out of range"; return; }

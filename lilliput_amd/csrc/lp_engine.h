@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "lp_guard.h"
 #include "lp_hostmem.h"
 #include "lp_jpeg_parse.h"
 #include "lp_prog_host.h"
@@ -29,6 +30,7 @@ void lp_retired_collect();
 struct LpDevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    const char* tag = "arena";  // names the buffer in the guard mode's log (lp_guard.h)
     ~LpDevBuf();
     // grow-only (x 1.5 at least); contents are NOT preserved across growth; the old block is retired, not freed (lp_retired_collect)
     bool ensure(size_t bytes);
@@ -39,6 +41,7 @@ struct LpPinned {
     void* p = nullptr;
     void* dev = nullptr;        // the buffer as kernels address it (mapped pinned memory)
     size_t cap = 0;
+    const char* tag = "pinned";
     ~LpPinned();
     bool ensure(size_t bytes);
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }

@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/lilliput_hip.h"
+#include "lp_guard.h"
 
 namespace {
 
@@ -223,9 +224,9 @@ extern "C" void* lilliput_hip_host_alloc(size_t bytes, int device)
     if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     void* p = nullptr;
     // ROCr places the pages on the NUMA node closest to the current device; mapped + portable: every device of the node may copy from it
-    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
+    const int e = lp_pinned_malloc(&p, bytes, true, "host_alloc");
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
-    if (e != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    if (e || !p) return nullptr;
     Table& t = table();
     std::lock_guard<std::mutex> lk(t.mu);
     const ptrdiff_t dd = device_delta(p);
@@ -243,7 +244,7 @@ extern "C" void lilliput_hip_host_free(void* p)
         if (it == t.by_start.end() || it->second.kind != kArena) return; // not ours
         t.by_start.erase(it);
     }
-    (void)hipHostFree(p);
+    lp_pinned_free(p);
 }
 
 extern "C" int lilliput_hip_host_register(void* p, size_t bytes)
