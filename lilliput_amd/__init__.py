@@ -28,4 +28,5 @@ from .binding import (  # noqa: F401
     lib,
     lib_path,
     parse_raw_frames,
+    service_sim,
 )

@@ -69,6 +69,7 @@ private:
     bool owner_ = false, tls_ = false, adopted_ = false;
 };
 int lp_thread_device(int device); // device for this thread's one-image ABI calls (-1 = default); returns the previous setting
+int lp_current_device();          // the device this thread's one-image calls run on
 void lp_set_error(const std::string& s);
 bool lp_mat_to_device(LpMat* m, LpEngine* eng);
 bool lp_mat_to_host(LpMat* m, LpEngine* eng);

@@ -38,6 +38,12 @@ extern "C" int lilliput_hip_device_count(void)
 
 static thread_local int t_device = -1; // lp_thread_device: which GPU this thread's one-image calls run on (-1: LILLIPUT_HIP_DEVICE, else 0)
 int lp_thread_device(int device) { int prev = t_device; t_device = device; return prev; }
+int lp_current_device() // the device a one-image call of this thread runs on
+{
+    if (t_device >= 0) return t_device;
+    static const int env = getenv("LILLIPUT_HIP_DEVICE") ? atoi(getenv("LILLIPUT_HIP_DEVICE")) : 0;
+    return env;
+}
 
 // ---- engine pool (see LpEngineLease in lp_abi.h)
 namespace {
@@ -69,8 +75,7 @@ LpEngineLease::LpEngineLease() { acquire(); }
 
 void LpEngineLease::acquire()
 {
-    int dev = t_device;
-    if (dev < 0) { dev = 0; if (const char* e = getenv("LILLIPUT_HIP_DEVICE")) dev = atoi(e); }
+    int dev = lp_current_device();
     dev_ = dev;
     if (t_lease_eng && t_lease_dev == dev) { eng_ = t_lease_eng; return; } // nested: the outer lease's engine, no hand-over
     EnginePool& P = engine_pool();

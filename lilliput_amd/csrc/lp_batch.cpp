@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "lp_abi.h"
+#include "lp_coalesce.h"
 #include "lp_ops_logic.h"
 
 // One engine (= one compute stream + one copy stream + its arenas) per worker; a batch is split into contiguous parts, one per
@@ -707,6 +708,7 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
         return rc;
     };
     auto worker = [&](size_t wi) {
+        LpCoalesceSuppress no_coalesce; // these Transform calls belong to this batch: they must not queue behind it (lp_coalesce.h)
         const int prev_dev = lp_thread_device(b->device);
         lilliput_image_ops ops = b->other_ops[wi];
         LpEngineLease own(b->other_eng[wi].get()); // every ABI call of this worker nests inside: its own engine, no pool traffic

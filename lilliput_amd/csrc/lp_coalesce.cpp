@@ -1,0 +1,188 @@
+// lp_coalesce.cpp -- see lp_coalesce.h.
+#include "lp_coalesce.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+std::atomic<int> g_in_flight{0};
+thread_local int t_suppress = 0;
+
+int env_int(const char* name, int dflt, int lo, int hi)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo ? lo : v > hi ? hi : v;
+}
+int threshold() { static const int v = env_int("LILLIPUT_HIP_COALESCE", 3, 0, 1 << 20); return v; }
+int n_workers() { static const int v = env_int("LILLIPUT_HIP_COALESCE_WORKERS", 4, 1, 16); return v; }
+size_t max_take() { static const int v = env_int("LILLIPUT_HIP_COALESCE_MAX", 32, 1, 1024); return (size_t)v; }
+
+struct Req {
+    const void* src; size_t len; void* dst; size_t cap;
+    lilliput_batch_options opt;
+    int status = -1;
+    size_t out_len = 0;
+    bool done = false;
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+bool same_options(const lilliput_batch_options& a, const lilliput_batch_options& b)
+{
+    return a.width == b.width && a.height == b.height && a.resize_method == b.resize_method && a.normalize_orientation == b.normalize_orientation &&
+           a.jpeg_quality == b.jpeg_quality && a.jpeg_progressive == b.jpeg_progressive;
+}
+
+// The dispatchers of one device.
+struct Dispatch {
+    int device;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Req*> q;
+    std::vector<std::thread> th;
+    bool stop = false;
+
+    explicit Dispatch(int dev) : device(dev) {}
+
+    void body()
+    {
+        LpCoalesceSuppress inner; // whatever this batch calls back into the one-image path stays on this thread
+        lilliput_hip_batch batch = nullptr;
+        std::vector<Req*> take;
+        std::vector<lilliput_batch_item> items;
+        for (;;) {
+            take.clear();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (stop) break;
+                // the oldest request and every waiting one with the same options, in arrival order
+                const lilliput_batch_options key = q.front()->opt;
+                for (auto it = q.begin(); it != q.end() && take.size() < max_take();) {
+                    if (same_options((*it)->opt, key)) { take.push_back(*it); it = q.erase(it); }
+                    else ++it;
+                }
+            }
+            if (!batch) batch = lilliput_hip_batch_create(device);
+            items.assign(take.size(), lilliput_batch_item());
+            for (size_t i = 0; i < take.size(); i++) {
+                memset(&items[i], 0, sizeof(items[i]));
+                items[i].src = take[i]->src; items[i].src_len = take[i]->len;
+                items[i].dst = take[i]->dst; items[i].dst_cap = take[i]->cap;
+                items[i].status = LILLIPUT_ERR_DEVICE;
+            }
+            if (batch) (void)lilliput_hip_batch_transform(batch, items.data(), items.size(), &take[0]->opt);
+            for (size_t i = 0; i < take.size(); i++) {
+                Req* r = take[i];
+                std::lock_guard<std::mutex> lk(r->mu);
+                r->status = batch ? items[i].status : LILLIPUT_ERR_DEVICE;
+                r->out_len = items[i].dst_len;
+                r->done = true;
+                r->cv.notify_one(); // under the lock: the requester destroys *r as soon as it has seen `done`, which it cannot before the lock is released
+            }
+        }
+        if (batch) lilliput_hip_batch_destroy(batch);
+    }
+
+    void start()
+    {
+        for (int i = 0; i < n_workers(); i++) th.emplace_back([this] { body(); });
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(mu); if (stop) return; stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+        // requests that were still queued: back to their callers, who take the direct route
+        for (Req* r : q) { std::lock_guard<std::mutex> lk(r->mu); r->status = LILLIPUT_ERR_DEVICE; r->done = true; r->cv.notify_one(); }
+        q.clear();
+    }
+};
+
+struct Registry {
+    std::mutex mu;
+    std::map<int, std::unique_ptr<Dispatch>> by_device;
+    bool closed = false;
+};
+Registry& registry()
+{
+    static Registry* r = new Registry(); // never destroyed: used from an atexit handler
+    return *r;
+}
+
+Dispatch* dispatch_for(int device)
+{
+    Registry& R = registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    if (R.closed) return nullptr;
+    auto it = R.by_device.find(device);
+    if (it != R.by_device.end()) return it->second.get();
+    // The dispatchers hold engines (streams, arenas) that must go before the HIP runtime does: an atexit handler registered after the
+    // runtime's own (the runtime is up: the caller has parsed a header through the one-image ABI... make sure) runs before it.
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return nullptr; }
+    static bool hooked = false;
+    if (!hooked) {
+        hooked = true;
+        atexit([] {
+            Registry& R2 = registry();
+            std::map<int, std::unique_ptr<Dispatch>> all;
+            { std::lock_guard<std::mutex> lk2(R2.mu); R2.closed = true; all.swap(R2.by_device); }
+            for (auto& kv : all) kv.second->shutdown();
+        });
+    }
+    auto d = std::unique_ptr<Dispatch>(new Dispatch(device));
+    d->start();
+    Dispatch* p = d.get();
+    R.by_device[device] = std::move(d);
+    return p;
+}
+
+} // namespace
+
+LpTransformInFlight::LpTransformInFlight() { now = g_in_flight.fetch_add(1, std::memory_order_relaxed) + 1; }
+LpTransformInFlight::~LpTransformInFlight() { g_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+
+LpCoalesceSuppress::LpCoalesceSuppress() { prev = t_suppress; t_suppress = 1; }
+LpCoalesceSuppress::~LpCoalesceSuppress() { t_suppress = prev; }
+
+bool lp_coalesce_wanted(int in_flight)
+{
+    const int t = threshold();
+    return t > 0 && !t_suppress && in_flight >= t;
+}
+
+bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len)
+{
+    Dispatch* D = dispatch_for(device);
+    if (!D) return false;
+    Req r;
+    r.src = src; r.len = len; r.dst = dst; r.cap = cap; r.opt = opt;
+    {
+        std::lock_guard<std::mutex> lk(D->mu);
+        if (D->stop) return false;
+        D->q.push_back(&r);
+    }
+    D->cv.notify_one();
+    {
+        std::unique_lock<std::mutex> lk(r.mu);
+        r.cv.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != LILLIPUT_OK) return false;
+    *out_len = r.out_len;
+    return true;
+}

@@ -1,0 +1,34 @@
+// lp_coalesce.h -- concurrent one-image Transform calls share device launches.
+//
+// The reference's deployment shape is many goroutines, each with its own ImageOps, each calling ops.Transform on one image
+// (/root/reference/README.md:82-85, ops.go:83-91, 352-444). Served one by one, every such call pays its own launches, its own
+// synchronisations and a decode that cannot fill the device (one 4096 x 4096 image is 9 workgroups' worth of entropy data per kernel),
+// and N callers get N engines' worth of arenas. When several Transform calls are in flight at once, the calls that the batched path
+// serves with identical results -- a static baseline / progressive JPEG source, JPEG output -- are handed to a small set of dispatcher
+// threads instead: each dispatcher owns a batch object (lp_batch.cpp), takes whatever requests with equal options are waiting (up to
+// a chunk's worth, no timer: a lone request leaves at once), runs them as ONE lilliput_hip_batch_transform -- the ingest pipeline, the
+// fused planes -> thumbnail kernels, one encode launch, one packed D2H -- and wakes the callers. Results are the batched path's, i.e.
+// byte-identical to the reference path's for integer scales and within the +-1 LSB contract otherwise, exactly like the direct route;
+// an item the batch does not answer with LILLIPUT_OK is run again on the direct route, so error behaviour is the direct route's.
+//   LILLIPUT_HIP_COALESCE          = n: coalesce once n Transform calls are in flight (default 3; 0 = never)
+//   LILLIPUT_HIP_COALESCE_WORKERS  = dispatcher threads per device (default 4)
+//   LILLIPUT_HIP_COALESCE_MAX      = requests per dispatch (default 32)
+#pragma once
+#include <stddef.h>
+
+#include "../../include/lilliput_hip.h"
+
+// counts the Transform calls in flight (constructed at the top of lilliput_image_ops_transform)
+struct LpTransformInFlight {
+    LpTransformInFlight();
+    ~LpTransformInFlight();
+    int now;    // calls in flight including this one
+};
+// true when a call that sees `in_flight` concurrent calls should go through the dispatchers (and this thread is allowed to)
+bool lp_coalesce_wanted(int in_flight);
+// Hands one request over and waits for it. Returns true when the batched path served it (LILLIPUT_OK, *out_len set); false = take the
+// direct route (not served, failed, or no device).
+bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len);
+// Transform calls made from inside a batch (its workers for non-JPEG items, its retry of short streams) must never queue behind the
+// batch that issued them: a scope of this suppresses coalescing on the calling thread.
+struct LpCoalesceSuppress { LpCoalesceSuppress(); ~LpCoalesceSuppress(); int prev; };

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "lp_abi.h"
+#include "lp_coalesce.h"
 #include "lp_ops_logic.h"
 
 // ---------------------------------------------------------------- opencv.go:468-637 byte scanners
@@ -499,6 +500,29 @@ void lilliput_image_ops_close(lilliput_image_ops oo)
     delete o;
 }
 
+// What the batched path (lp_batch.cpp) serves exactly like the loop below would: one frame of a JPEG file, decoded once, Fit or Resize, JPEG out,
+// inside the bounds this ImageOps was built with (opencv.go:250-267 resizeMat answers ErrBufTooSmall beyond them -- left to the direct route).
+static bool coalescible(const ImageOps* o, const Decoder* d, const Header& hdr, const lilliput_image_options* opt)
+{
+    if (d->kind != Decoder::OPENCV || d->has_decoded || hdr.num_frames != 1 || !d->buf || !d->len) return false;
+    const char* desc = opencv_decoder_get_description(d->dec);
+    if (!desc || strcmp(desc, "JPEG") != 0) return false;
+    const std::string ext = lower(opt->file_type);
+    if (ext != ".jpeg" && ext != ".jpg" && ext != ".jpe") return false;
+    if (opt->resize_method != LILLIPUT_OPS_FIT && opt->resize_method != LILLIPUT_OPS_RESIZE) return false;
+    if (opt->encode_options_len && !opt->encode_options) return false;
+    for (size_t i = 0; i + 1 < opt->encode_options_len; i += 2)
+        if (opt->encode_options[i] == CV_IMWRITE_JPEG_QUALITY && opt->encode_options[i + 1] <= 0) return false; // the batch options spell "default" as 0
+    const size_t cn = (size_t)opencv_type_channels(hdr.pixel_type);
+    int in_w = hdr.width, in_h = hdr.height;
+    if (opt->normalize_orientation && lp_swaps_axes(hdr.orientation)) { in_w = hdr.height; in_h = hdr.width; }
+    int nw = opt->width, nh = opt->height;
+    if (opt->resize_method == LILLIPUT_OPS_FIT) lp_calculate_expected_size(in_w, in_h, opt->width, opt->height, &nw, &nh);
+    if (nw < 1) nw = 1;
+    if (nh < 1) nh = 1;
+    return (size_t)hdr.width * hdr.height * cn <= o->frames[0].buf_len && (size_t)nw * nh * cn <= o->frames[0].buf_len;
+}
+
 int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, const lilliput_image_options* opt, void* dst, size_t dst_cap, size_t* dst_len)
 {
     auto o = static_cast<ImageOps*>(oo);
@@ -508,12 +532,33 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     // The framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so decoded, composited
     // and resized frames stay on the device for the duration of the call.
     struct LazyScope { int prev = lp_lazy_host_scope(1); ~LazyScope() { lp_lazy_host_scope(prev); } } lazy_scope;
-    LpEngineLease lease; // the whole Transform on one engine, one stream: the ABI calls below nest inside it
-    struct CompositeScope { ImageOps* o; ~CompositeScope() { o->drop_composite(); } } composite_scope{o}; // ops.go:353-358
+    LpTransformInFlight in_flight;
     // initializeTransform (ops.go:483-546)
     Header hdr;
     int e = decoder_header(d, &hdr);
     if (e) return e;
+    // Several Transform calls in flight at once (a service's goroutines, README.md:82-85): the ones the batched path answers with the
+    // same bytes -- static JPEG source, JPEG output, Fit / Resize -- share its launches instead of each paying its own (lp_coalesce.h).
+    // Whatever the batch does not answer with LILLIPUT_OK runs below as if nothing had happened.
+    if (lp_coalesce_wanted(in_flight.now) && coalescible(o, d, hdr, opt)) {
+        lilliput_batch_options bo;
+        memset(&bo, 0, sizeof(bo));
+        bo.width = opt->width; bo.height = opt->height;
+        bo.resize_method = opt->resize_method;
+        bo.normalize_orientation = opt->normalize_orientation;
+        for (size_t i = 0; i + 1 < opt->encode_options_len; i += 2) { // as opencv_encoder_write reads them: the last one wins
+            if (opt->encode_options[i] == CV_IMWRITE_JPEG_QUALITY) bo.jpeg_quality = std::min(100, opt->encode_options[i + 1]);
+            else if (opt->encode_options[i] == CV_IMWRITE_JPEG_PROGRESSIVE) bo.jpeg_progressive = opt->encode_options[i + 1] != 0;
+        }
+        size_t n = 0;
+        if (lp_coalesce_transform(lp_current_device(), d->buf, d->len, dst, dst_cap, bo, &n)) {
+            d->has_decoded = true; // openCVDecoder.DecodeTo has run once (opencv.go:816-839): a second Transform on this decoder answers EOF
+            *dst_len = n;
+            return LILLIPUT_OK;
+        }
+    }
+    LpEngineLease lease; // the whole Transform on one engine, one stream: the ABI calls below nest inside it
+    struct CompositeScope { ImageOps* o; ~CompositeScope() { o->drop_composite(); } } composite_scope{o}; // ops.go:353-358
     // ICC override for HDR -> SDR (ops.go:489-498): ForceSdr + a source profile whose 'cicp' tag names PQ / HLG -> tag the output sRGB
     const uint8_t* icc_override = nullptr;
     size_t icc_override_len = 0;

@@ -1,0 +1,115 @@
+/* lp_service_sim.c -- a stand-in for the Go service that links this library: N OS threads ("goroutines on their Ms"), each with ONE
+ * ImageOps for its lifetime (/root/reference/README.md:82-85, ops.go:83-91), each doing per request what lilliput's callers do:
+ *     NewDecoder(buf) -> Header() -> ops.Transform(decoder, options, dst) -> decoder.Close()      (lilliput.go:129-164, ops.go:352-444)
+ * through Part C of include/lilliput_hip.h -- plain C against the public header, nothing internal. bench.py --workload abi drives it
+ * (the image has no Go toolchain; Python threads would put the GIL between the calls). Built as ../liblilliput_service_sim.so, which
+ * links liblilliput_hip.so like a cgo build would; it is measurement scaffolding, not part of the product library.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/lilliput_hip.h"
+
+typedef struct {
+    const void* const* srcs;
+    const size_t* lens;
+    int nsrc;
+    long jobs;
+    int width, height, quality, max_size, resize_method;
+    atomic_long next, ok, failed;
+    int first_error;
+    pthread_barrier_t gate;
+    uint8_t* keep; size_t keep_cap; long* keep_len;
+    float* lat_ms;              /* per job, optional */
+} sim_t;
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static int one_request(sim_t* s, lilliput_image_ops ops, const void* src, size_t len, uint8_t* dst, size_t cap, size_t* n)
+{
+    lilliput_decoder d = NULL;
+    int rc = lilliput_new_decoder(src, len, &d);
+    if (rc) return rc;
+    int w = 0, h = 0;
+    rc = lilliput_decoder_header(d, &w, &h, NULL, NULL, NULL, NULL);
+    if (!rc) {
+        const int enc[2] = {CV_IMWRITE_JPEG_QUALITY, s->quality};
+        lilliput_image_options o;
+        memset(&o, 0, sizeof(o));
+        o.file_type = ".jpeg";
+        o.width = s->width; o.height = s->height;
+        o.resize_method = s->resize_method;
+        o.encode_options = enc;
+        o.encode_options_len = 2;
+        o.encode_timeout_ns = 60ll * 1000000000ll;
+        rc = lilliput_image_ops_transform(ops, d, &o, dst, cap, n);
+    }
+    lilliput_decoder_close(d);
+    return rc;
+}
+
+static void* sim_worker(void* arg)
+{
+    sim_t* s = (sim_t*)arg;
+    lilliput_image_ops ops = lilliput_new_image_ops(s->max_size);
+    const size_t cap = 4u << 20;
+    uint8_t* dst = (uint8_t*)malloc(cap);
+    size_t n = 0;
+    if (ops) (void)one_request(s, ops, s->srcs[0], s->lens[0], dst, cap, &n); /* untimed: the thread's first call builds what a running service has */
+    pthread_barrier_wait(&s->gate);
+    for (;;) {
+        const long j = atomic_fetch_add(&s->next, 1);
+        if (j >= s->jobs) break;
+        const int k = (int)(j % s->nsrc);
+        const double t0 = now_s();
+        const int rc = ops ? one_request(s, ops, s->srcs[k], s->lens[k], dst, cap, &n) : LILLIPUT_ERR_DEVICE;
+        if (s->lat_ms) s->lat_ms[j] = (float)((now_s() - t0) * 1e3);
+        if (rc == 0) atomic_fetch_add(&s->ok, 1);
+        else { atomic_fetch_add(&s->failed, 1); s->first_error = rc; }
+        if (j < s->nsrc && s->keep) {
+            s->keep_len[k] = rc == 0 ? (long)n : -(long)rc;
+            if (rc == 0 && n <= s->keep_cap) memcpy(s->keep + (size_t)k * s->keep_cap, dst, n);
+        }
+    }
+    pthread_barrier_wait(&s->gate);
+    if (ops) lilliput_image_ops_close(ops);
+    free(dst);
+    return NULL;
+}
+
+/* `jobs` requests (request j carries source j % nsrc) served by `threads` workers; *seconds = wall time from the moment every worker
+ * stands ready to the moment the queue is empty. Returns the number of successful requests; *first_error = a LILLIPUT_* code if any
+ * failed. keep / keep_cap / keep_len: optional copies of the first response per distinct source (nsrc slots). lat_ms: optional,
+ * one float per job. resize_method: LILLIPUT_OPS_FIT / _RESIZE / _NO_RESIZE. */
+long lilliput_service_sim_run(const void* const* srcs, const size_t* lens, int nsrc, int threads, long jobs, int width, int height, int quality, int resize_method,
+                              int max_size, double* seconds, int* first_error, uint8_t* keep, size_t keep_cap, long* keep_len, float* lat_ms)
+{
+    if (threads < 1) threads = 1;
+    sim_t s;
+    memset(&s, 0, sizeof(s));
+    s.srcs = srcs; s.lens = lens; s.nsrc = nsrc; s.jobs = jobs;
+    s.width = width; s.height = height; s.quality = quality; s.max_size = max_size; s.resize_method = resize_method;
+    s.keep = keep; s.keep_cap = keep_cap; s.keep_len = keep_len; s.lat_ms = lat_ms;
+    atomic_init(&s.next, 0); atomic_init(&s.ok, 0); atomic_init(&s.failed, 0);
+    pthread_barrier_init(&s.gate, NULL, (unsigned)threads + 1);
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, 1u << 20);
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], &at, sim_worker, &s);
+    pthread_barrier_wait(&s.gate);
+    const double t0 = now_s();
+    pthread_barrier_wait(&s.gate);
+    *seconds = now_s() - t0;
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    pthread_attr_destroy(&at);
+    pthread_barrier_destroy(&s.gate);
+    if (first_error) *first_error = s.first_error;
+    return atomic_load(&s.ok);
+}

@@ -1,0 +1,209 @@
+/*
+ * oracle/cpu_path.c -- TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * The reference CPU path of ImageOps.Transform as a C worker loop, for bench.py's `cpu_baseline` leg: N pthreads, each with the buffers
+ * an ImageOps holds for its lifetime (/root/reference/ops.go:83-91: two framebuffers allocated once per ImageOps; README.md:82-85: one
+ * ImageOps per goroutine), pulling jobs from one atomic counter and running
+ *     decode (opencv.cpp:166-171) -> orientation (opencv.cpp:217-221) -> Fit crop + INTER_AREA (opencv.go:331-363, opencv.cpp:196-215)
+ *     -> JPEG encode (opencv.cpp:185-194)
+ * with no Python between the stages. Round 3 timed the same stages from a Python thread pool (fresh 50 MB numpy frames per call, glue
+ * under the GIL) and understated the CPU path about five-fold.
+ *
+ * The codecs come in as function pointers so that one loop serves both baselines bench.py can report:
+ *   kind "reference": the reference's own libjpeg-turbo 3.1.0 / libpng 1.6.47 / libwebp 1.5.0 through oracle/_ref/libref*.so,
+ *   kind "port"     : this directory's restatement (lo_jpeg_decode_pixels / lo_jpeg_encode).
+ * The resize is imgproc_oracle.c's restatement of cv::resize(INTER_AREA) either way (libopencv_imgproc.a is absent from the mount);
+ * it is single-threaded per image like everything else here -- images saturate the cores, which is the throughput-optimal way to
+ * run the CPU path.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* jpeg_oracle.c / imgproc_oracle.c (same library) */
+typedef struct lo_jpeg_info_s lo_jpeg_info;
+int lo_jpeg_header_brief(const uint8_t* d, size_t n, int* w, int* h, int* ncomp, int* orientation);
+int lo_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, int cn, uint8_t* dst, int dw, int dh, size_t dstep);
+void lo_orientation(const uint8_t* src, int w, int h, size_t sstep, int cn, int orientation, uint8_t* dst, int* dw, int* dh);
+long lo_jpeg_encode(const uint8_t* px, int W, int H, int ch, size_t stride, int quality, uint8_t* out, size_t cap, void* dbg);
+
+typedef int (*dec_jpeg_fn)(const uint8_t*, size_t, uint8_t*, size_t, int*, int*, int*);
+typedef long (*enc_jpeg_fn)(const uint8_t*, int, int, int, size_t, int, uint8_t*, size_t);
+typedef int (*dec_png_fn)(const uint8_t*, size_t, uint8_t*, size_t, int info[6]);
+typedef long (*dec_webp_fn)(const uint8_t*, size_t, int, uint8_t*, size_t, int meta[8]);
+typedef int (*info_webp_fn)(const uint8_t*, size_t, uint32_t out[8]);
+
+typedef struct {
+    dec_jpeg_fn dec_jpeg;       /* JPEG bytes -> BGR / grey rows */
+    enc_jpeg_fn enc_jpeg;       /* NULL: lo_jpeg_encode */
+    dec_png_fn dec_png;         /* may be NULL: PNG items fail */
+    dec_webp_fn dec_webp;       /* may be NULL */
+    info_webp_fn info_webp;
+    int width, height, quality;
+    int resize_method;          /* 0 none, 1 Fit, 2 Resize (ops.go:18-22) */
+} lo_path_cfg;
+
+typedef struct { uint8_t *frame, *oriented, *thumb; size_t frame_cap, oriented_cap, thumb_cap; } lo_path_scratch;
+
+static int need(uint8_t** p, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return 0;
+    free(*p);
+    *p = (uint8_t*)malloc(bytes + 64);
+    *cap = *p ? bytes : 0;
+    return *p ? 0 : -1;
+}
+
+/* ops.go:243-255 calculateExpectedSize */
+static void expected_size(int ow, int oh, int rw, int rh, int* nw, int* nh)
+{
+    const int m = ow < oh ? ow : oh;
+    if (rw == rh && rw > m) { *nw = m; *nh = m; return; }
+    if (rw > ow && rh > oh && rw != rh) { *nw = ow; *nh = oh; return; }
+    *nw = rw; *nh = rh;
+}
+
+/* opencv.go:331-363 Framebuffer.Fit: the centre crop that has the output's aspect ratio */
+static void fit_crop(int fw, int fh, int width, int height, int* left, int* top, int* wpc, int* hpc)
+{
+    const double aspect_in = (double)fw / (double)fh, aspect_out = (double)width / (double)height;
+    if (aspect_in > aspect_out) { *wpc = (int)(aspect_out * (double)fh + 0.5); *hpc = fh; }
+    else { *hpc = (int)((double)fw / aspect_out + 0.5); *wpc = fw; }
+    if (*wpc < 1) *wpc = 1;
+    if (*hpc < 1) *hpc = 1;
+    *left = (int)((double)(fw - *wpc) * 0.5);
+    *top = (int)((double)(fh - *hpc) * 0.5);
+    if (*left < 0) *left = 0;
+    if (*top < 0) *top = 0;
+}
+
+static uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+/* One ImageOps.Transform of a still source -> JPEG. Returns the output length, or a negative code. */
+long lo_path_transform(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t* d, size_t n, uint8_t* out, size_t cap)
+{
+    int w = 0, h = 0, cn = 0, orientation = 1;
+    const uint8_t* px = NULL;
+    size_t stride = 0;
+    if (n >= 32 && !memcmp(d, "LPPIXELS", 8)) { /* a frame some host codec decoded (include/lilliput_hip.h lilliput_hip_pixels_header) */
+        w = (int)le32(d + 8); h = (int)le32(d + 12); cn = (int)le32(d + 16); stride = le32(d + 20); orientation = (int)le32(d + 24);
+        if (!stride) stride = (size_t)w * cn;
+        if (w <= 0 || h <= 0 || (cn != 1 && cn != 3 && cn != 4) || 32 + stride * (size_t)(h - 1) + (size_t)w * cn > n) return -2;
+        px = d + 32;
+    } else if (n >= 8 && !memcmp(d, "\x89PNG\r\n\x1a\n", 8)) {
+        int info[6];
+        if (!cfg->dec_png || cfg->dec_png(d, n, NULL, 0, info)) return -2;
+        w = info[0]; h = info[1]; cn = info[2];
+        if (need(&s->frame, &s->frame_cap, (size_t)w * h * cn)) return -4;
+        if (cfg->dec_png(d, n, s->frame, s->frame_cap, info)) return -2;
+        px = s->frame; stride = (size_t)w * cn;
+    } else if (n >= 12 && !memcmp(d, "RIFF", 4) && !memcmp(d + 8, "WEBP", 4)) {
+        uint32_t inf[8];
+        int meta[8];
+        if (!cfg->dec_webp || !cfg->info_webp || cfg->info_webp(d, n, inf)) return -2;
+        if (need(&s->frame, &s->frame_cap, (size_t)inf[0] * inf[1] * 4 + 16)) return -4;
+        if (cfg->dec_webp(d, n, 1, s->frame, s->frame_cap, meta) < 0) return -2;
+        w = meta[0]; h = meta[1]; cn = meta[2];
+        px = s->frame; stride = (size_t)w * cn;
+    } else {
+        int nc = 0;
+        if (lo_jpeg_header_brief(d, n, &w, &h, &nc, &orientation)) return -2;
+        if (need(&s->frame, &s->frame_cap, (size_t)w * h * (nc == 1 ? 1 : 3))) return -4;
+        if (cfg->dec_jpeg(d, n, s->frame, s->frame_cap, &w, &h, &cn)) return -2;
+        px = s->frame; stride = (size_t)w * cn;
+    }
+    int fw = w, fh = h;
+    if (orientation > 1 && orientation <= 8) { /* ops.go:392: applied unconditionally */
+        if (need(&s->oriented, &s->oriented_cap, (size_t)w * h * cn)) return -4;
+        lo_orientation(px, w, h, stride, cn, orientation, s->oriented, &fw, &fh);
+        px = s->oriented; stride = (size_t)fw * cn;
+    }
+    int ow = fw, oh = fh;
+    if (cfg->resize_method != 0) {
+        /* inputCanvasSize (ops.go:474-479): header dimensions, swapped only when the caller asked for normalisation (not modelled: never set here) */
+        int hw = fw, hh = fh;
+        if (orientation >= 5 && orientation <= 8) { hw = fh; hh = fw; }
+        int left = 0, top = 0, wpc = fw, hpc = fh;
+        if (cfg->resize_method == 1) {
+            expected_size(hw, hh, cfg->width, cfg->height, &ow, &oh);
+            fit_crop(fw, fh, ow, oh, &left, &top, &wpc, &hpc);
+        } else { ow = cfg->width < 1 ? 1 : cfg->width; oh = cfg->height < 1 ? 1 : cfg->height; }
+        if (need(&s->thumb, &s->thumb_cap, (size_t)ow * oh * cn)) return -4;
+        lo_resize_area(px + (size_t)top * stride + (size_t)left * cn, wpc, hpc, stride, cn, s->thumb, ow, oh, (size_t)ow * cn);
+        px = s->thumb; stride = (size_t)ow * cn;
+    }
+    return cfg->enc_jpeg ? cfg->enc_jpeg(px, ow, oh, cn, stride, cfg->quality, out, cap) : lo_jpeg_encode(px, ow, oh, cn, stride, cfg->quality, out, cap, NULL);
+}
+
+void lo_path_scratch_free(lo_path_scratch* s) { free(s->frame); free(s->oriented); free(s->thumb); memset(s, 0, sizeof(*s)); }
+
+typedef struct {
+    const lo_path_cfg* cfg;
+    const uint8_t* const* srcs;
+    const size_t* lens;
+    int nsrc;
+    long jobs;
+    atomic_long next, ok, failed;
+    pthread_barrier_t start;
+    /* the output of the first job on every distinct source, for the caller to compare with the Python-level oracle */
+    uint8_t* keep; size_t keep_cap; long* keep_len;
+} run_t;
+
+static void* worker(void* arg)
+{
+    run_t* r = (run_t*)arg;
+    lo_path_scratch s;
+    memset(&s, 0, sizeof(s));
+    const size_t cap = 8u << 20;
+    uint8_t* out = (uint8_t*)malloc(cap);
+    /* one untimed transform: the worker's buffers exist and their pages are touched, as in a service that has been up for a second */
+    (void)lo_path_transform(r->cfg, &s, r->srcs[0], r->lens[0], out, cap);
+    pthread_barrier_wait(&r->start);
+    for (;;) {
+        const long j = atomic_fetch_add(&r->next, 1);
+        if (j >= r->jobs) break;
+        const int k = (int)(j % r->nsrc);
+        const long n = lo_path_transform(r->cfg, &s, r->srcs[k], r->lens[k], out, cap);
+        if (n > 0) atomic_fetch_add(&r->ok, 1); else atomic_fetch_add(&r->failed, 1);
+        if (j < r->nsrc && r->keep) {
+            r->keep_len[k] = n;
+            if (n > 0 && (size_t)n <= r->keep_cap) memcpy(r->keep + (size_t)k * r->keep_cap, out, (size_t)n);
+        }
+    }
+    pthread_barrier_wait(&r->start);
+    lo_path_scratch_free(&s);
+    free(out);
+    return NULL;
+}
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* `jobs` transforms (job j works on source j % nsrc) on `threads` workers. *seconds = wall time between the barrier that releases the
+ * workers and the one they reach when the queue is empty. keep (optional): nsrc slots of keep_cap bytes + keep_len[nsrc].
+ * Returns the number of successful transforms. */
+long lo_path_run(const lo_path_cfg* cfg, const uint8_t* const* srcs, const size_t* lens, int nsrc, long jobs, int threads, double* seconds,
+                 uint8_t* keep, size_t keep_cap, long* keep_len)
+{
+    if (threads < 1) threads = 1;
+    run_t r;
+    memset(&r, 0, sizeof(r));
+    r.cfg = cfg; r.srcs = srcs; r.lens = lens; r.nsrc = nsrc; r.jobs = jobs;
+    r.keep = keep; r.keep_cap = keep_cap; r.keep_len = keep_len;
+    atomic_init(&r.next, 0); atomic_init(&r.ok, 0); atomic_init(&r.failed, 0);
+    pthread_barrier_init(&r.start, NULL, (unsigned)threads + 1);
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &r);
+    pthread_barrier_wait(&r.start);
+    const double t0 = now_s();
+    pthread_barrier_wait(&r.start);
+    *seconds = now_s() - t0;
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    pthread_barrier_destroy(&r.start);
+    return atomic_load(&r.ok);
+}

@@ -909,6 +909,16 @@ int lo_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, 
 }
 
 /* Intermediate stages, for stage-by-stage parity of the HIP kernels. */
+/* width, height, component count and EXIF orientation of a JPEG (cpu_path.c: sizes the frame before the decode) */
+int lo_jpeg_header_brief(const uint8_t* d, size_t n, int* w, int* h, int* ncomp, int* orientation)
+{
+    lo_jpeg_info in;
+    const int rc = lo_jpeg_read_header(d, n, &in);
+    if (rc) return rc;
+    *w = in.width; *h = in.height; *ncomp = in.ncomp; *orientation = in.orientation;
+    return 0;
+}
+
 int lo_jpeg_decode_coefs(const uint8_t* d, size_t n, int comp, int16_t* out, size_t cap_elems, int* bw, int* bh)
 {
     lo_dec D;

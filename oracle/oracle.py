@@ -686,6 +686,42 @@ def transform_any_to_jpeg(data, width, height, quality=85, resize_method=FIT):
     return None if f is None else jpeg_encode(f if f.shape[2] > 1 else f[:, :, 0], quality)
 
 
+class _PathCfg(C.Structure):
+    _fields_ = [("dec_jpeg", C.c_void_p), ("enc_jpeg", C.c_void_p), ("dec_png", C.c_void_p), ("dec_webp", C.c_void_p), ("info_webp", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int)]
+
+
+def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True):
+    """The reference CPU path as a C worker loop (oracle/cpu_path.c): `jobs` transforms (job j = sources[j % len]) on `threads`
+    pthreads, each with its own preallocated frame buffers, no Python between decode, orientation, Fit / INTER_AREA and encode.
+    Returns {"seconds", "ok", "jobs", "kind", "outputs"}: outputs[k] = the bytes the first job on sources[k] produced (None if it
+    failed or was never reached), byte-identical to transform_any_to_jpeg / transform_jpeg_thumbnail of the same source."""
+    L = lib()
+    from_ref = use_ref and ref() is not None
+    cfg = _PathCfg()
+    cfg.dec_jpeg = C.cast(ref().ref_jpeg_decode_pixels if from_ref else L.lo_jpeg_decode_pixels, C.c_void_p)
+    cfg.enc_jpeg = C.cast(ref().ref_jpeg_encode, C.c_void_p) if from_ref else None
+    cfg.dec_png = C.cast(ref_png().ref_png_decode, C.c_void_p) if ref_png() is not None else None
+    if ref_webp() is not None:
+        cfg.dec_webp = C.cast(ref_webp().ref_webp_decode_frame, C.c_void_p)
+        cfg.info_webp = C.cast(ref_webp().ref_webp_info, C.c_void_p)
+    cfg.width, cfg.height, cfg.quality, cfg.resize_method = int(width), int(height), int(quality), int(resize_method)
+    bufs = [np.frombuffer(bytes(d), dtype=np.uint8) for d in sources]
+    n = len(bufs)
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    jobs = n if jobs is None else int(jobs)
+    keep_cap = max(1 << 16, int(width) * int(height) * 4 + 4096) if keep else 0
+    keep_buf = np.zeros(max(1, n * keep_cap), dtype=np.uint8)
+    keep_len = (C.c_long * n)(*([0] * n))
+    secs = C.c_double(0.0)
+    L.lo_path_run.restype = C.c_long
+    L.lo_path_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_size_t, C.c_void_p]
+    ok = L.lo_path_run(C.byref(cfg), ptrs, lens, n, jobs, int(threads), C.byref(secs), keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None)
+    outs = [keep_buf[k * keep_cap: k * keep_cap + keep_len[k]].tobytes() if keep and 0 < keep_len[k] <= keep_cap else None for k in range(n)]
+    return {"seconds": secs.value, "ok": int(ok), "jobs": jobs, "kind": "reference" if from_ref else "port", "outputs": outs}
+
+
 class _Info(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int),
                 ("cid", C.c_int * 4), ("hs", C.c_int * 4), ("vs", C.c_int * 4), ("tq", C.c_int * 4),
