@@ -139,6 +139,152 @@ def kernel_table(stage, images, c_in, c_out, size):
     }, plane_b
 
 
+def exclusive_leg(la, device, sources, args):
+    """Exclusive kernel durations: ONE engine, one stream, two launches of one resident chunk, HIP events on that stream -- no other
+    stream's kernels share the GPU with the launch being timed (what `rocprofv3 --kernel-trace --stats` reports for a single-stream run)."""
+    b1 = la.Batch(device)
+    round_images = args.chunk or b1.resident_round(max(len(x) for x in sources))
+    nx = min(2 * round_images, len(sources))   # two launches of the resident chunk size
+    if args.sub_bits:
+        b1.set_subsequence(args.sub_bits, args.ckpt_bits)
+    b1.upload(sources[:nx], dst_cap=256 << 10, streams=1)
+    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+    excl = b1.timings()
+    excl["images"] = nx
+    excl["launch_images"] = min(round_images, nx)
+    b1.close()
+    return excl
+
+
+def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, breakdown):
+    """Dominant kernel, EXCLUSIVE: algorithmic bytes per launch / average launch duration with one engine (HIP events on its stream).
+    This is a property of the kernel; the same figure follows from the rocprofv3 kernel trace of
+    `LILLIPUT_HIP_STREAMS=1 python bench.py --resident` committed under profiles/."""
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    src_tab, src_n = (kernel_table(excl, excl["images"], c_in, c_out, args.size)[0], excl["images"]) if excl else (kernels, per_rank_images)
+    dom = max(src_tab.items(), key=lambda kv: kv[1][0])
+    dom_ms, dom_bytes = dom[1]
+    if dom_ms <= 0:
+        return roof
+    launch_images = excl["launch_images"] if excl else min(args.chunk or (32 if not args.resident else 113), args.batch)  # without the exclusive leg: the chunk size of the timed mode
+    achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
+    # HBM bytes of the dominant kernel from the newest committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE;
+    # rocprofv3 counters cannot be collected from inside this process). The file is stamped with a hash of the kernel sources it was
+    # measured on; a stamp that no longer matches means the number is stale and it is withheld.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        pm = json.load(open(cand[-1]))
+        stamp = pm.get("kernel_source_sha16")
+        if stamp is not None and stamp != kernel_source_sha16():
+            traffic_src = "%s is stale (kernel sources changed since it was measured)" % os.path.basename(cand[-1])
+        else:
+            keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
+            traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
+            traffic_src = os.path.basename(cand[-1])
+    except Exception:
+        traffic = None
+    return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(dom_bytes * launch_images), "launch_images": launch_images,
+            "avg_launch_us": round(dom_ms * 1e3 / (src_n / launch_images), 1),
+            "traffic_over_algorithmic": round(traffic / (dom_bytes * launch_images), 3) if traffic else None,
+            "traffic_source": traffic_src,
+            "streams": 1 if excl else streams,
+            "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
+                    "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
+                    "(~47 vector instructions per Huffman symbol in this kernel), not by HBM (DESIGN.md 4.1)" % streams,
+            "per_kernel_exclusive_us_per_image": {k.split(" ")[0]: round(v[0] * 1e3 / src_n, 2) for k, v in src_tab.items()} if excl else None,
+            "per_kernel_in_timed_region": breakdown}
+
+
+def main_abi(args, ranks, la):
+    """The drop-in path under service concurrency: N OS threads, each with its own ImageOps, each NewDecoder -> Header -> Transform ->
+    Close per request through Part C of the C ABI (lilliput_amd/csrc/lp_service_sim.c; README.md:82-85, opencv.go:816-839) on the
+    headline sources held in ordinary (pageable) host memory, like a Go []byte. One "step" = `--batch` requests per GPU."""
+    import numpy as np
+
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    ndev = max(1, la.lib().lilliput_hip_device_count())
+    os.environ.setdefault("LILLIPUT_HIP_DEVICE", str(local_rank % ndev))
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
+    ranks.barrier()
+    distinct = [np.frombuffer(open(p, "rb").read(), dtype=np.uint8) for p in paths]
+    threads = [int(t) for t in str(args.threads).split(",") if t]
+    from oracle import oracle as O
+
+    O.lib()
+    use_ref = O.ref() is not None
+    by_threads, bad = {}, []
+    best_t, best_v, best_elapsed = None, -1.0, None
+    for t in threads:
+        jobs = args.batch
+        for _ in range(args.warmup):
+            la.service_sim(distinct, t, min(jobs, max(4 * t, 64)), args.out, args.out, 85, la.ImageOpsFit, keep=False)
+        el, ok, lat, outs, err = 0.0, 0, [], None, 0
+        for k in range(args.steps):
+            ranks.barrier()
+            r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1))
+            el += r["seconds"]
+            ok += r["ok"]
+            err = err or r["first_error"]
+            lat.append(r["latency_ms"])
+            outs = r["outputs"] if r["outputs"][0] is not None else outs
+        el = ranks.reduce(el, "max")
+        lat = np.concatenate(lat)
+        v = jobs * args.steps * world / el
+        # correctness gate: the first response per source of the last step, `--verify` of them, byte for byte against the reference CPU path
+        checked = 0
+        for j in range(min(args.verify, len(distinct))):
+            i = int.from_bytes(hashlib.sha256(b"abi:%d:%d:%d" % (t, rank, j)).digest()[:8], "little") % min(len(distinct), jobs)
+            exp = O.transform_jpeg_thumbnail(bytes(distinct[i]), args.out, args.out, 85, use_ref=use_ref)
+            checked += 1
+            if outs is None or outs[i] != exp:
+                bad.append((t, i))
+        by_threads[str(t)] = {"images_per_s": round(v, 1), "ok": ok, "requests": jobs * args.steps, "first_error": err, "latency_ms_p50": round(float(np.percentile(lat, 50)), 3),
+                              "latency_ms_p99": round(float(np.percentile(lat, 99)), 3), "verified": checked}
+        if v > best_v:
+            best_t, best_v, best_elapsed = t, v, el
+    import ctypes
+
+    pool = (ctypes.c_size_t * 4)()
+    la.lib().lilliput_hip_engine_pool_stats(pool)
+    gate = ranks.all_gather_ints([len(bad)])
+    if rank == 0:
+        c_in = sum(a.size for a in distinct) / len(distinct)
+        out = {"metric": "images/sec (%dx%d->%dx%d JPEG q85, ImageOps.Transform through the one-image C ABI under concurrent callers)" % (args.size, args.size, args.out, args.out),
+               "value": round(best_v, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1000.0 * best_elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "the drop-in path: %d requests per GPU and step on the BASELINE configs[1] sources (%d distinct %dx%d 4:2:0 q90 JPEGs in pageable host memory), each "
+                                      "NewDecoder -> Header -> ImageOps.Transform(Fit %dx%d, q85) -> Close on the calling thread's own ImageOps, `threads` OS threads at once "
+                                      "(lp_service_sim.c, plain C against include/lilliput_hip.h); value = the best of the thread counts" % (args.batch, len(distinct), args.size, args.size, args.out, args.out),
+                          "threads_of_value": best_t, "by_threads": by_threads,
+                          "coalescing": {"LILLIPUT_HIP_COALESCE": os.environ.get("LILLIPUT_HIP_COALESCE", "default (3 calls in flight)"),
+                                         "LILLIPUT_HIP_COALESCE_WORKERS": os.environ.get("LILLIPUT_HIP_COALESCE_WORKERS", "default (4)"),
+                                         "what": "calls in flight at once that the batched path serves with the same bytes share its launches (lp_coalesce.h)"},
+                          "host_write_back": "lazy inside ImageOps.Transform (the framebuffers are private to ImageOps, ops.go:67-81)",
+                          "engine_pool_after": {"checked_out": pool[0], "idle": pool[1], "created": pool[2], "destroyed_by_bounds": pool[3]},
+                          "mean_input_bytes": int(c_in),
+                          "verified_identical": all(g[0] == 0 for g in gate),
+                          "verified_against": "oracle.transform_jpeg_thumbnail, byte for byte, first response per picked source of the last step"}}
+        if not args.no_extra_legs:
+            excl = exclusive_leg(la, local_rank % ndev, distinct, args)
+            c_out = 30000.0
+            out["roofline"] = make_roofline(excl, None, 0, c_in, c_out, args, 1, None)
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline([bytes(d) for d in distinct[: min(32, len(distinct))]], args.out, args.out, 85, what="%dx%d q90 -> %dx%d q85" % (args.size, args.size, args.out, args.out))
+        print(json.dumps(out), flush=True)
+    ranks.close()
+    if any(g[0] for g in gate):
+        log("[bench] abi CORRECTNESS GATE FAILED on rank %d: %r" % (rank, bad))
+        sys.exit(3)
+
+
 def firehose_check(la, O, ops, data, out, side, quality):
     """One firehose output against the reference CPU path: the bytes, or -- where the resample is fractional (float taps: +-1 LSB per
     channel is north_star's contract) -- a pre-encode frame within +-1 LSB of the oracle's that `out` encodes byte-exactly."""
@@ -260,7 +406,8 @@ def main():
                          "service that reads its network bytes into pinned memory has -- the DMA engine reads them in place, no host copy (zero-copy); pageable = "
                          "the caller's ordinary buffers, memcpy'd through the engines' pinned slots (the round-2 pipeline); register = pageable buffers whose "
                          "pages are registered per call (opt-in: slower than the copy on this driver); staged = force the slot route whatever the memory")
-    ap.add_argument("--workload", choices=["jpeg4096", "firehose"], default="jpeg4096",
+    ap.add_argument("--threads", default="64", help="--workload abi: concurrent caller threads, or a comma list (1,8,64,256: one measurement each)")
+    ap.add_argument("--workload", choices=["jpeg4096", "firehose", "abi"], default="jpeg4096",
                     help="jpeg4096 = BASELINE configs[1], the headline metric (default); firehose = BASELINE configs[4] in miniature: a mixed-format stream (JPEG 70 / PNG 15 / "
                          "WebP 10 / handed-over decoded frames 5 %%, sides log-uniform 512-4096 px) -> 256 px JPEG q85 through lilliput_hip_node_transform")
     ap.add_argument("--verify", type=int, default=8, help="outputs of the last timed step compared byte for byte with the oracle's after the timed region (0 = none)")
@@ -282,6 +429,8 @@ def main():
 
     if args.workload == "firehose":
         return main_firehose(args, ranks, la)
+    if args.workload == "abi":
+        return main_abi(args, ranks, la)
 
     paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
     barrier()
@@ -378,19 +527,7 @@ def main():
             for _ in range(2):
                 b.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
             resident_ips = 2 * args.batch / (time.time() - t)
-        # exclusive kernel durations: ONE engine, so that no other stream's kernels share the GPU with the launch being timed
-        b1 = la.Batch(local_rank % ndev)
-        round_images = args.chunk or b1.resident_round(max(len(x) for x in sources))
-        nx = min(2 * round_images, args.batch)   # two launches of the resident chunk size
-        if args.sub_bits:
-            b1.set_subsequence(args.sub_bits, args.ckpt_bits)
-        b1.upload(sources[:nx], dst_cap=256 << 10, streams=1)
-        b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
-        b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
-        excl = b1.timings()
-        excl["images"] = nx
-        excl["launch_images"] = min(round_images, nx)
-        b1.close()
+        excl = exclusive_leg(la, local_rank % ndev, sources, args)
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -399,47 +536,7 @@ def main():
         kernels, plane_b = kernel_table(stage, per_rank_images, c_in, c_out, args.size)
         breakdown = {k: {"ms_per_image": round(v[0] / per_rank_images, 5), "algorithmic_GBps": round(v[1] * per_rank_images / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                      for k, v in kernels.items()}
-        # Dominant kernel, EXCLUSIVE: algorithmic bytes per launch / average launch duration with one engine (HIP events on its
-        # stream). This is a property of the kernel; the same figure follows from the rocprofv3 kernel trace of
-        # `LILLIPUT_HIP_STREAMS=1 python bench.py --resident` committed under profiles/.
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-        src_tab, src_n = (kernel_table(excl, excl["images"], c_in, c_out, args.size)[0], excl["images"]) if excl else (kernels, per_rank_images)
-        dom = max(src_tab.items(), key=lambda kv: kv[1][0])
-        dom_ms, dom_bytes = dom[1]
-        if dom_ms > 0:
-            launch_images = excl["launch_images"] if excl else min(args.chunk or (32 if not args.resident else 113), args.batch)  # without the exclusive leg: the chunk size of the timed mode
-            achieved = dom_bytes * src_n / (dom_ms * 1e-3) / 1e9
-            # HBM bytes of the dominant kernel from the newest committed PMC passes (FETCH_SIZE x 2, the gfx950 correction, + WRITE_SIZE;
-            # rocprofv3 counters cannot be collected from inside this process). The file is stamped with a hash of the kernel sources it was
-            # measured on; a stamp that no longer matches means the number is stale and it is withheld.
-            traffic, traffic_src = None, None
-            try:
-                import glob
-
-                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-                pm = json.load(open(cand[-1]))
-                stamp = pm.get("kernel_source_sha16")
-                if stamp is not None and stamp != kernel_source_sha16():
-                    traffic_src = "%s is stale (kernel sources changed since it was measured)" % os.path.basename(cand[-1])
-                else:
-                    keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
-                    traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
-                    traffic_src = os.path.basename(cand[-1])
-            except Exception:
-                traffic = None
-            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(dom_bytes * launch_images), "launch_images": launch_images,
-                    "avg_launch_us": round(dom_ms * 1e3 / (src_n / launch_images), 1),
-                    "traffic_over_algorithmic": round(traffic / (dom_bytes * launch_images), 3) if traffic else None,
-                    "traffic_source": traffic_src,
-                    "streams": 1 if excl else streams,
-                    "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
-                            "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
-                            "(a wave64 vector instruction holds its SIMD for four cycles; ~47 vector instructions per Huffman symbol in this kernel "
-                            "after round 3's rewrite of the decode step, ~60 before), not by HBM (DESIGN.md 4.1; profiles/r03_c_final.md)" % streams,
-                    "per_kernel_exclusive_us_per_image": {k.split(" ")[0]: round(v[0] * 1e3 / src_n, 2) for k, v in src_tab.items()} if excl else None,
-                    "per_kernel_in_timed_region": breakdown}
+        roof = make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, breakdown)
         e2e_bytes = c_in + 2 * plane_b + 3 * 256 * 256 + c_out
         out = {
             "metric": "images/sec (%dx%d->%dx%d JPEG q85)" % (args.size, args.size, args.out, args.out),

@@ -119,12 +119,17 @@ bool lp_bmp_read_data(const uint8_t* data, size_t len, const LpBmpInfo& bi, uint
     const bool color = cn > 1;
     if ((uint64_t)H * (uint64_t)W * (uint64_t)nch >= (1ull << 30)) return false; // "doesn't support large images >= 1Gb"
     if (bi.offset < 0) return false;
-    const int src_pitch = ((W * (bi.bpp != 15 ? bi.bpp : 16) + 7) / 8 + 3) & -4;
+    // cv::BmpDecoder computes the row pitch in 32-bit int; a header whose width makes that overflow (W = 2^26 at 32 bits per pixel passes
+    // the size test above with H = 1) ends in a failed allocation there and a refused decode here -- never in a wrapped pitch
+    const int64_t pitch64 = (((int64_t)W * (bi.bpp != 15 ? bi.bpp : 16) + 7) / 8 + 3) & ~(int64_t)3;
+    if (W <= 0 || H <= 0 || pitch64 <= 0 || pitch64 > 0x7fffffff - 64 || (int64_t)W * nch > 0x7fffffff) return false;
+    const int src_pitch = (int)pitch64;
     const int width3 = W * nch;
     long step = (long)step_in;
     uint8_t* d = out;
     if (bi.bottom_up) { d += (size_t)(H - 1) * step_in; step = -step; }
-    std::vector<uint8_t> srcv((size_t)src_pitch + 32);
+    std::vector<uint8_t> srcv;
+    try { srcv.resize((size_t)src_pitch + 32); } catch (const std::exception&) { return false; } // nothing unwinds through the C ABI
     uint8_t* src = srcv.data();
     uint8_t grey_pal[256];
     memset(grey_pal, 0, sizeof(grey_pal));
@@ -305,5 +310,6 @@ bool lp_bmp_read_data(const uint8_t* data, size_t len, const LpBmpInfo& bi, uint
         default: break;
         }
     } catch (const Short&) { return false; }
+    catch (const std::exception&) { return false; } // an allocation inside: the decode is refused, nothing unwinds through the C ABI
     return result;
 }

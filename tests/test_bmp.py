@@ -112,6 +112,25 @@ def _decode_abi(L, data):
     return out, desc
 
 
+def test_row_pitch_that_overflows_int_is_refused_not_thrown(hip_lib):
+    """A 200-byte file claiming 2^26 .. 2^30 pixels per row at 32 bits per pixel: cv::BmpDecoder's 32-bit row pitch goes negative (a
+    failed allocation there, the decode refused); here the pitch is computed in 64 bits and the decode refused -- no exception may
+    unwind through opencv_decoder_read_data (ADVICE r03: std::length_error reached terminate())."""
+    L = hip_lib
+    L.lilliput_hip_bmp_decode.restype = C.c_int
+    L.lilliput_hip_bmp_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    out = np.zeros(1 << 20, np.uint8)
+    for width in (1 << 26, (1 << 26) + 3, 1 << 27, (1 << 27) + 5, 1 << 29, (1 << 31) - 1):
+        for bpp in (24, 32):
+            head = b"BM" + struct.pack("<IHHI", 54 + 146, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, width, 1, 1, bpp, 0, 0, 0, 0, 0, 0)
+            data = head + bytes(146)
+            w, h, cn = C.c_int(), C.c_int(), C.c_int()
+            # cap = SIZE_MAX / 2: the entry point's own size test passes, the row reader must refuse before it writes anything
+            r = L.lilliput_hip_bmp_decode(data, len(data), C.byref(w), C.byref(h), C.byref(cn), out.ctypes.data_as(C.c_void_p), (1 << 62))
+            assert r in (1, 2), (width, bpp, r)
+    assert not out.any()
+
+
 def test_opencv_decoder_abi_serves_bmp_files(hip_lib):
     """opencv_decoder_create .. read_data on BMP buffers: "BMP" as the description (what cv::ImageDecoder::getDescription answers in the
     reference build), the decoder's own Mat type, the recorded pixels. No device involved: the rows are unpacked on the host."""
