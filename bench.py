@@ -285,6 +285,203 @@ def main_abi(args, ranks, la):
         sys.exit(3)
 
 
+def stage_profile_roofline(la, run_once, repeats=8):
+    """`roofline` of a workload served by the one-image entry points: the library's stage profile (lilliput_hip_stage_profile: two HIP events
+    around every probed launch on the engine's stream, measured live here, outside the timed region) over `repeats` single-threaded
+    transforms; the dominant launch by device time, its algorithmic bytes / its time against the HBM peak."""
+    import ctypes
+
+    L = la.lib()
+    L.lilliput_hip_stage_profile.argtypes = [ctypes.c_int]
+    L.lilliput_hip_stage_profile_read.restype = ctypes.c_size_t
+    L.lilliput_hip_stage_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    run_once()
+    L.lilliput_hip_stage_profile(1)
+    for _ in range(repeats):
+        run_once()
+    L.lilliput_hip_stage_profile(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    L.lilliput_hip_stage_profile_read(buf, len(buf))
+    rows = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms, by = line.split("\t")
+        rows[name] = {"calls": int(calls), "device_ms": float(ms), "algorithmic_bytes": float(by)}
+    if not rows:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    dom = max(rows, key=lambda k: rows[k]["device_ms"])
+    r = rows[dom]
+    achieved = r["algorithmic_bytes"] / max(1e-9, r["device_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "avg_launch_us": round(1e3 * r["device_ms"] / r["calls"], 2), "algorithmic_bytes_per_launch": int(r["algorithmic_bytes"] / r["calls"]),
+            "per_stage": {k: {"launches": v["calls"], "us_per_launch": round(1e3 * v["device_ms"] / v["calls"], 2),
+                              "algorithmic_GBps": round(v["algorithmic_bytes"] / max(1e-9, v["device_ms"] * 1e-3) / 1e9, 3)} for k, v in rows.items()},
+            "note": "launches of this size (a few hundred KB) are bound by launch latency, not by HBM; the workload itself is bound by the host codecs (inflate / LZW / VP8), see cpu_baseline and DESIGN.md 5"}
+
+
+def cpu_baseline_processes(fn, jobs_per_worker, what):
+    """A CPU baseline for a path that has no C worker loop (the animated sources): forked worker PROCESSES, one per logical CPU and one
+    per physical core, each running `fn()` jobs_per_worker times (no GIL between them; the codecs are the reference's C libraries)."""
+    import multiprocessing as mp
+
+    logical, physical = host_cores()
+    t0 = time.time()
+    units1 = fn()
+    one = units1 / max(1e-9, time.time() - t0)
+
+    def work(n, q):
+        u = 0
+        for _ in range(n):
+            u += fn()
+        q.put(u)
+
+    runs = {}
+    for th in sorted({physical, logical}):
+        q = mp.get_context("fork").Queue()
+        ps = [mp.get_context("fork").Process(target=work, args=(jobs_per_worker, q)) for _ in range(th)]
+        t0 = time.time()
+        for p_ in ps:
+            p_.start()
+        units = sum(q.get() for _ in ps)
+        for p_ in ps:
+            p_.join()
+        dt = time.time() - t0
+        runs[th] = {"units_per_s": round(units / dt, 2), "seconds": round(dt, 2)}
+    best = max(runs, key=lambda t: runs[t]["units_per_s"])
+    return {"value": runs[best]["units_per_s"], "unit": "frames/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
+            "one_core_units_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["units_per_s"] / max(1e-9, physical * one), 3),
+            "runs_by_processes": {str(k): v for k, v in runs.items()},
+            "harness": "forked worker processes (no C worker loop exists for the animated path; fork time is inside the measurement)",
+            "sample": "%d x %s per worker process on %d processes" % (jobs_per_worker, what, best)}
+
+
+def main_formats(args, ranks, la):
+    """BASELINE configs[2] (--workload png2webp: testdata/ferry_sunset.png -> 512 x 512 WebP; webp.cpp:707-751) and configs[3]
+    (--workload animated: party-discord.gif + big_buck_bunny_720_5s.webp -> 128 x 128 animated WebP; giflib.cpp:349-568, ops.go:552-591)
+    as driver-runnable lines: `--threads` concurrent callers, each with its own ImageOps, `--batch` requests per step through Part C."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    O.lib()
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    ndev = max(1, la.lib().lilliput_hip_device_count())
+    os.environ.setdefault("LILLIPUT_HIP_DEVICE", str(local_rank % ndev))
+    gold = os.path.join(ROOT, "tests", "golden")
+    if args.workload == "png2webp":
+        names = [os.path.join(gold, "inputs_png", "ferry_sunset.png")]
+        W = H = 512
+        q = 85
+        unit, what = "images/s", "testdata/ferry_sunset.png (800x297 RGB + ICC) -> 512x512 WebP q85, ImageOpsFit: 297x297 by the no-upscale rule (BASELINE configs[2])"
+    else:
+        names = [os.path.join(gold, "inputs_gif", "party-discord.gif"), os.path.join(gold, "inputs_webp", "big_buck_bunny_720_5s.webp")]
+        W = H = 128
+        q = 75
+        unit, what = "frames/s", "testdata/party-discord.gif (28x18, 16 frames) + big_buck_bunny_720_5s.webp (480x270, 50 frames) -> 128x128 animated WebP q75, per-frame dispose / blend + Fit (BASELINE configs[3])"
+    srcs = [open(n, "rb").read() for n in names]
+    frames_of = []
+    for d in srcs:
+        dec = la.Decoder(d)
+        frames_of.append(max(1, dec.AnimationInfo()[1]) if args.workload == "animated" else 1)
+        dec.Close()
+    opts = {la.WebpQuality: q}
+    threads = int(str(args.threads).split(",")[0])
+    jobs = args.batch
+    cap = 8 << 20
+
+    def sim(keep):
+        return la.service_sim(srcs, threads, jobs, W, H, resize_method=la.ImageOpsFit, keep=keep, file_type=".webp", encode_options=opts, dst_cap=cap, max_size=2048)
+
+    for _ in range(args.warmup):
+        sim(False)
+    el, ok, outs = 0.0, 0, None
+    for k in range(args.steps):
+        ranks.barrier()
+        r = sim(k == args.steps - 1)
+        el += r["seconds"]
+        ok += r["ok"]
+        outs = r["outputs"] if r["outputs"][0] is not None else outs
+    el = ranks.reduce(el, "max")
+    units_per_req = sum(frames_of[j % len(srcs)] for j in range(jobs)) / jobs
+    value = jobs * args.steps * world * units_per_req / el
+    # ---- correctness gate: (i) the concurrent run's bytes are the serial run's; (ii) the frames handed to the encoder are the reference
+    # CPU path's (exactly where the scale is an integer or a copy, +-1 LSB where INTER_AREA is fractional: north_star's contract)
+    ops = la.ImageOps(2048)
+    bad = []
+    for i, d in enumerate(srcs):
+        dec = la.Decoder(d)
+        serial = ops.Transform(dec, la.ImageOptions(".webp", W, H, la.ImageOpsFit, False, opts, EncodeTimeout=10**11), dst_cap=cap)
+        dec.Close()
+        if outs is None or outs[i] != serial:
+            bad.append(("bytes differ from the serial run", i))
+        dec = la.Decoder(d)
+        pre = la.parse_raw_frames(ops.Transform(dec, la.ImageOptions(".bgra-frames", W, H, la.ImageOpsFit, False, {}, EncodeTimeout=10**11), dst_cap=64 << 20))
+        dec.Close()
+        if d[:3] == b"GIF":
+            ref = [O.transform_static(f[0], 1, W, H, O.FIT, False) for f in O.ref_gif_frames(d)[2]]
+        elif d[:4] == b"RIFF":
+            ref = [O.transform_static(c, 1, W, H, O.FIT, False) for c in O.ref_webp_play(d)[0]] if O.ref_webp() is not None else None
+        else:
+            ref = [O.transform_static(O.ref_png_decode(d), 1, W, H, O.FIT, False)] if O.ref_png() is not None else None
+        if ref is not None:
+            if len(ref) != len(pre):
+                bad.append(("frame count", i, len(pre), len(ref)))
+            else:
+                for k, (f, _ms) in enumerate(pre):
+                    a, b2 = f.astype(int), ref[k].astype(int)
+                    if a.shape[2] == 4 and b2.shape[2] == 4:  # colour under fully transparent pixels is not content
+                        vis = (a[:, :, 3] > 0) | (b2[:, :, 3] > 0)
+                        a, b2 = a * vis[:, :, None], b2 * vis[:, :, None]
+                    if a.shape != b2.shape or np.abs(a - b2).max() > 1:
+                        bad.append(("frame", i, k))
+                        break
+
+    def once():
+        for d in srcs:
+            dec = la.Decoder(d)
+            ops.Transform(dec, la.ImageOptions(".webp", W, H, la.ImageOpsFit, False, opts, EncodeTimeout=10**11), dst_cap=cap)
+            dec.Close()
+
+    roof = stage_profile_roofline(la, once) if not args.no_extra_legs else {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    ops.Close()
+    gate = ranks.all_gather_ints([len(bad), ok])
+    if rank == 0:
+        out = {"metric": "%s (%s)" % (unit.replace("/s", "/sec"), "PNG -> 512x512 WebP" if args.workload == "png2webp" else "animated GIF / WebP -> 128x128 animated WebP"),
+               "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * el / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "reference fixtures (tests/golden)",
+               "config": {"workload": "%s; %d requests per GPU and step from %d concurrent callers (one ImageOps each, NewDecoder -> Transform -> Close through Part C, lp_service_sim.c)" % (what, jobs, threads),
+                          "threads": threads, "requests_per_s": round(jobs * args.steps * world / el, 2), "frames_per_request": round(units_per_req, 2), "ok_requests": ok,
+                          "output_bytes": [len(o) if o else None for o in (outs or [])],
+                          "verified_identical": all(g[0] == 0 for g in gate) and all(g[1] == jobs * args.steps for g in gate),
+                          "verified_against": "(i) the bytes of a serial Transform of the same source; (ii) every frame handed to the encoder against the reference CPU path (reference libpng / giflib + "
+                                              "restated compositing / libwebp playback -> INTER_AREA restatement): exact for copies and integer scales, +-1 LSB for fractional ones; the WebP "
+                                              "payload itself is written by the host's libwebp (DESIGN.md 4.5)"},
+               "roofline": roof}
+        if not args.no_cpu_baseline:
+            if args.workload == "png2webp":
+                logical, physical = host_cores()
+                r1 = O.cpu_path_run(srcs, W, H, threads=1, jobs=16, keep=False, webp_quality=q)
+                one = r1["ok"] / max(1e-9, r1["seconds"])
+                runs = {}
+                for th in sorted({physical, logical}):
+                    r = O.cpu_path_run(srcs, W, H, threads=th, jobs=int(max(8 * th, one * 0.7 * th * 4)), keep=False, webp_quality=q)
+                    runs[th] = {"images_per_s": round(r["ok"] / max(1e-9, r["seconds"]), 2), "jobs": r["jobs"], "seconds": round(r["seconds"], 2)}
+                best = max(runs, key=lambda t: runs[t]["images_per_s"])
+                out["cpu_baseline"] = {"value": runs[best]["images_per_s"], "unit": "images/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
+                                       "one_core_images_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["images_per_s"] / max(1e-9, physical * one), 3),
+                                       "runs_by_threads": {str(k): v for k, v in runs.items()}, "harness": "oracle/cpu_path.c (pthreads, preallocated buffers per worker)",
+                                       "sample": "%d transforms of ferry_sunset.png -> 297x297 WebP q85 (reference libpng 1.6.47 decode, INTER_AREA restatement, reference libwebp 1.5.0 encode) on %d threads" % (runs[best]["jobs"], best)}
+            else:
+                def one_pass():
+                    return sum(O.transform_animated_to_webp(d, W, H, q)[1] for d in srcs)
+
+                out["cpu_baseline"] = cpu_baseline_processes(one_pass, 4, "both sources -> 128x128 animated WebP (reference giflib / libwebp decode + playback, restated compositing and INTER_AREA, reference WebPAnimEncoder)")
+        print(json.dumps(out), flush=True)
+    ranks.close()
+    if any(g[0] for g in gate) or any(g[1] != jobs * args.steps for g in gate):
+        log("[bench] %s CORRECTNESS GATE FAILED on rank %d: %r (ok %d of %d)" % (args.workload, rank, bad, ok, jobs * args.steps))
+        sys.exit(3)
+
+
 def firehose_check(la, O, ops, data, out, side, quality):
     """One firehose output against the reference CPU path: the bytes, or -- where the resample is fractional (float taps: +-1 LSB per
     channel is north_star's contract) -- a pre-encode frame within +-1 LSB of the oracle's that `out` encodes byte-exactly."""
@@ -407,9 +604,11 @@ def main():
                          "the caller's ordinary buffers, memcpy'd through the engines' pinned slots (the round-2 pipeline); register = pageable buffers whose "
                          "pages are registered per call (opt-in: slower than the copy on this driver); staged = force the slot route whatever the memory")
     ap.add_argument("--threads", default="64", help="--workload abi: concurrent caller threads, or a comma list (1,8,64,256: one measurement each)")
-    ap.add_argument("--workload", choices=["jpeg4096", "firehose", "abi"], default="jpeg4096",
+    ap.add_argument("--workload", choices=["jpeg4096", "firehose", "abi", "png2webp", "animated"], default="jpeg4096",
                     help="jpeg4096 = BASELINE configs[1], the headline metric (default); firehose = BASELINE configs[4] in miniature: a mixed-format stream (JPEG 70 / PNG 15 / "
-                         "WebP 10 / handed-over decoded frames 5 %%, sides log-uniform 512-4096 px) -> 256 px JPEG q85 through lilliput_hip_node_transform")
+                         "WebP 10 / handed-over decoded frames 5 %%, sides log-uniform 512-4096 px) -> 256 px JPEG q85 through lilliput_hip_node_transform; "
+                         "abi = the drop-in path under service concurrency (--threads callers, each NewDecoder -> ImageOps.Transform -> Close through Part C on the headline sources); "
+                         "png2webp = BASELINE configs[2]; animated = BASELINE configs[3] (both: --threads callers, --batch requests per step)")
     ap.add_argument("--verify", type=int, default=8, help="outputs of the last timed step compared byte for byte with the oracle's after the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
@@ -431,6 +630,8 @@ def main():
         return main_firehose(args, ranks, la)
     if args.workload == "abi":
         return main_abi(args, ranks, la)
+    if args.workload in ("png2webp", "animated"):
+        return main_formats(args, ranks, la)
 
     paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
     barrier()

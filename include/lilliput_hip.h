@@ -416,6 +416,13 @@ int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
  * front of each buffer is checked when it is freed. out[0] = alignment in force (0: mode off), out[1] = guarded allocations so far,
  * out[2] = canary violations found, out[3] = peak of mapped device bytes. */
 void lilliput_hip_guard_stats(size_t out[4]);
+/* Stage profile of the one-image entry points (measurement access; bench.py's roofline of the PNG / WebP / animated workloads): while on,
+ * every probed launch (PNG un-filter + expansion, GIF frame, composite, orientation, crop + resize, WebP Y'CbCr import, JPEG decode,
+ * JPEG encode, PNG filter) is bracketed by two HIP events on the engine's stream and waited for. _profile(on) returns the previous
+ * setting and clears the table when switching on; _read copies "name<TAB>calls<TAB>device ms<TAB>algorithmic bytes" lines into out and
+ * returns the length of the whole text. */
+int lilliput_hip_stage_profile(int on);
+size_t lilliput_hip_stage_profile_read(char* out, size_t cap);
 
 /* Test access (no device work): number of inflated image-data bytes of a PNG, or -1 when libpng would reject the file. */
 int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8_t* v); /* test access: the planes the lossy WebP encoder is handed

@@ -517,25 +517,30 @@ class Node(Batch):
             self._n = None
 
 
-def service_sim(sources, threads, jobs, width=256, height=256, quality=85, resize_method=ImageOpsFit, max_size=8192, keep=True):
+def service_sim(sources, threads, jobs, width=256, height=256, quality=85, resize_method=ImageOpsFit, max_size=8192, keep=True, file_type=".jpeg", encode_options=None,
+                dst_cap=0):
     """N OS threads, each with one ImageOps, each doing NewDecoder -> Header -> Transform -> Close per request through Part C of the
     C ABI (csrc/lp_service_sim.c: the Go service of /root/reference/README.md:82-85 in plain C, no interpreter between the calls).
-    Returns {"seconds", "ok", "jobs", "first_error", "outputs" (first response per distinct source), "latency_ms" (numpy, per job)}."""
+    encode_options: {key: value} (default {JpegQuality: quality}). Returns {"seconds", "ok", "jobs", "first_error", "outputs" (first
+    response per distinct source), "latency_ms" (numpy, per job)}."""
     lib()  # the library itself first: the simulator links it by soname next to itself
     S = C.CDLL(os.path.join(_HERE, "liblilliput_service_sim.so"))
     bufs = [np.frombuffer(bytes(d), dtype=np.uint8) if not isinstance(d, np.ndarray) else d for d in sources]
     n = len(bufs)
     ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
     lens = (C.c_size_t * n)(*[b.size for b in bufs])
-    keep_cap = max(1 << 16, width * height * 4 + 4096) if keep else 0
+    keep_cap = max(1 << 16, width * height * 4 + 4096, dst_cap) if keep else 0
     keep_buf = np.zeros(max(1, n * keep_cap), dtype=np.uint8)
     keep_len = (C.c_long * n)(*([0] * n))
     lat = np.zeros(max(1, jobs), dtype=np.float32)
     secs, err = C.c_double(0.0), C.c_int(0)
-    S.lilliput_service_sim_run.restype = C.c_long
-    S.lilliput_service_sim_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
-                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    ok = S.lilliput_service_sim_run(ptrs, lens, n, int(threads), int(jobs), int(width), int(height), int(quality), int(resize_method), int(max_size), C.byref(secs), C.byref(err),
-                                    keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None, lat.ctypes.data)
+    eo = encode_options if encode_options is not None else {JpegQuality: quality}
+    flat = [int(x) for kv in eo.items() for x in kv]
+    enc = (C.c_int * max(1, len(flat)))(*flat)
+    S.lilliput_service_sim_run2.restype = C.c_long
+    S.lilliput_service_sim_run2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    ok = S.lilliput_service_sim_run2(ptrs, lens, n, int(threads), int(jobs), int(width), int(height), file_type.encode(), enc, len(flat), int(resize_method), int(max_size), int(dst_cap),
+                                     C.byref(secs), C.byref(err), keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None, lat.ctypes.data)
     outs = [keep_buf[k * keep_cap: k * keep_cap + keep_len[k]].tobytes() if keep and 0 < keep_len[k] <= keep_cap else None for k in range(n)]
     return {"seconds": secs.value, "ok": int(ok), "jobs": int(jobs), "first_error": err.value, "outputs": outs, "latency_ms": lat[:jobs]}

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -28,6 +29,7 @@ int env_int(const char* name, int dflt, int lo, int hi)
 }
 int threshold() { static const int v = env_int("LILLIPUT_HIP_COALESCE", 3, 0, 1 << 20); return v; }
 int n_workers() { static const int v = env_int("LILLIPUT_HIP_COALESCE_WORKERS", 4, 1, 16); return v; }
+int idle_ms() { static const int v = env_int("LILLIPUT_HIP_COALESCE_IDLE_MS", 1000, 1, 1 << 30); return v; }
 size_t max_take() { static const int v = env_int("LILLIPUT_HIP_COALESCE_MAX", 32, 1, 1024); return (size_t)v; }
 
 struct Req {
@@ -67,7 +69,17 @@ struct Dispatch {
             take.clear();
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !q.empty(); });
+                // an idle dispatcher gives its batch -- engines, streams, the arenas of its largest chunk -- back after a while: what the
+                // process holds follows the calls in flight, as with the engine pool of the direct route
+                while (!stop && q.empty()) {
+                    if (!batch) { cv.wait(lk); continue; }
+                    if (cv.wait_for(lk, std::chrono::milliseconds(idle_ms())) == std::cv_status::timeout && q.empty() && !stop) {
+                        lk.unlock();
+                        lilliput_hip_batch_destroy(batch);
+                        batch = nullptr;
+                        lk.lock();
+                    }
+                }
                 if (stop) break;
                 // the oldest request and every waiting one with the same options, in arrival order
                 const lilliput_batch_options key = q.front()->opt;

@@ -13,6 +13,7 @@
 //   LILLIPUT_HIP_COALESCE          = n: coalesce once n Transform calls are in flight (default 3; 0 = never)
 //   LILLIPUT_HIP_COALESCE_WORKERS  = dispatcher threads per device (default 4)
 //   LILLIPUT_HIP_COALESCE_MAX      = requests per dispatch (default 32)
+//   LILLIPUT_HIP_COALESCE_IDLE_MS  = an idle dispatcher destroys its batch (engines, arenas) after this long (default 1000)
 #pragma once
 #include <stddef.h>
 

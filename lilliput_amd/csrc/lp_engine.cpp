@@ -76,6 +76,79 @@ void lp_retired_collect()
     for (void* p : h) lp_pinned_free(p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage profile (lilliput_hip_stage_profile, include/lilliput_hip.h): device time and algorithmic bytes of the launches behind the
+// one-image entry points, by kernel name -- what bench.py's roofline of the PNG / WebP / animated workloads is computed from. Off by
+// default; when on, every probed launch is bracketed by two events and waited for (measurement legs only, never the timed region).
+namespace {
+struct StageRow { double ms = 0; double bytes = 0; uint64_t calls = 0; };
+struct StageTable {
+    std::mutex mu;
+    std::map<std::string, StageRow> rows;
+};
+StageTable& stage_table()
+{
+    static StageTable* t = new StageTable();
+    return *t;
+}
+std::atomic<int> g_stage_profile{0};
+struct LpStageProbe {
+    hipStream_t st;
+    const char* name;
+    double bytes;
+    hipEvent_t a = nullptr, b = nullptr;
+    LpStageProbe(hipStream_t stream, const char* n, double by) : st(stream), name(n), bytes(by)
+    {
+        if (!g_stage_profile.load(std::memory_order_relaxed)) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); a = nullptr; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~LpStageProbe()
+    {
+        if (!a) return;
+        float ms = 0;
+        if (b && hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+            StageTable& T = stage_table();
+            std::lock_guard<std::mutex> lk(T.mu);
+            StageRow& r = T.rows[name];
+            r.ms += ms; r.bytes += bytes; r.calls++;
+        } else
+            (void)hipGetLastError();
+        (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+}
+extern "C" int lilliput_hip_stage_profile(int on)
+{
+    const int prev = g_stage_profile.exchange(on ? 1 : 0);
+    if (on && !prev) {
+        StageTable& T = stage_table();
+        std::lock_guard<std::mutex> lk(T.mu);
+        T.rows.clear();
+    }
+    return prev;
+}
+extern "C" size_t lilliput_hip_stage_profile_read(char* out, size_t cap)
+{
+    std::string s;
+    {
+        StageTable& T = stage_table();
+        std::lock_guard<std::mutex> lk(T.mu);
+        char line[256];
+        for (const auto& kv : T.rows) {
+            snprintf(line, sizeof(line), "%s\t%llu\t%.6f\t%.0f\n", kv.first.c_str(), (unsigned long long)kv.second.calls, kv.second.ms, kv.second.bytes);
+            s += line;
+        }
+    }
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return s.size();
+}
+
 LpDevBuf::~LpDevBuf() { if (p) lp_dev_free(p); }
 bool LpDevBuf::ensure(size_t bytes)
 {
@@ -954,7 +1027,12 @@ int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
 {
     int rc = upload_jpegs(srcs, n, hdrs);
     if (rc) return rc;
-    rc = run_decode(0, n, frames, status, nullptr, false);
+    {
+        double db = 0;
+        for (int i = 0; i < n; i++) db += (double)srcs[i].len + 4.5 * hdrs[i].j.width * hdrs[i].j.height * (hdrs[i].j.ncomp == 1 ? 1.0 / 1.5 : 1.0);
+        LpStageProbe probe_(stream_, "JPEG decode (k_unstuff .. k_idct, k_ycc_to_frame)", db);
+        rc = run_decode(0, n, frames, status, nullptr, false);
+    }
     if (rc == LP_RETRY) rc = LP_OK;
     if (rc == LP_ERR_DEVICE) return rc; // anything else is the status of an image that failed
     // A baseline stream that came up short of blocks (truncated upload, damaged data) is not an error to libjpeg: it warns, feeds zero
@@ -983,10 +1061,11 @@ int LpEngine::orient(const LpOrientOp* ops, int n)
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
     if (!d_ops_.ensure(std::max(sizeof(LpOrientOp), sizeof(LpResizeOp)) * (size_t)n)) return LP_ERR_DEVICE;
     uint32_t mw = 0, mh = 0;
-    for (int i = 0; i < n; i++) { mw = std::max(mw, std::max(ops[i].src.w, ops[i].src.h)); mh = mw; }
+    double orient_bytes = 0;
+    for (int i = 0; i < n; i++) { mw = std::max(mw, std::max(ops[i].src.w, ops[i].src.h)); mh = mw; orient_bytes += 2.0 * ops[i].src.w * ops[i].src.h * ops[i].src.cn; }
     if (!check(hipMemcpyAsync(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D orient ops")) return LP_ERR_DEVICE;
     // the op array is pageable host memory: make sure the copy has been consumed before the caller frees it
-    lp_launch_orient(stream_, d_ops_.as<LpOrientOp>(), (uint32_t)n, mw, mh, nullptr, nullptr);
+    { LpStageProbe probe_(stream_, "k_orient", (double)(orient_bytes)); lp_launch_orient(stream_, d_ops_.as<LpOrientOp>(), (uint32_t)n, mw, mh, nullptr, nullptr); }
     if (!check(hipStreamSynchronize(stream_), "orient sync")) return LP_ERR_DEVICE;
     return check(hipGetLastError(), "orient kernel") ? LP_OK : LP_ERR_DEVICE;
 }
@@ -1125,7 +1204,12 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     if (!ranges.empty() && !check(hipMemcpyAsync(d_ranges_.p, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, stream_), "H2D ranges"))
         return LP_ERR_DEVICE;
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
-    lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, area3_mask, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
+    {
+        double rb = 0;
+        for (int i = 0; i < n; i++) rb += (double)reqs[i].crop_w * reqs[i].crop_h * reqs[i].src.cn + (double)reqs[i].dst_w * reqs[i].dst_h * reqs[i].src.cn;
+        LpStageProbe probe_(stream_, "k_resize_* (crop + INTER_AREA from a frame)", rb);
+        lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, area3_mask, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
+    }
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
     if (!check(hipStreamSynchronize(stream_), "resize sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "resize kernels")) return LP_ERR_DEVICE;
@@ -1363,7 +1447,7 @@ int LpEngine::composite(const LpCompositeOp& op)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    lp_launch_composite(stream_, op, nullptr, nullptr);
+    { LpStageProbe probe_(stream_, "k_composite", (double)((size_t)op.w * op.h * (op.src.cn + 2 * op.dst.cn))); lp_launch_composite(stream_, op, nullptr, nullptr); }
     if (!check(hipStreamSynchronize(stream_), "composite sync")) return LP_ERR_DEVICE;
     return check(hipGetLastError(), "composite kernel") ? LP_OK : LP_ERR_DEVICE;
 }
@@ -1395,7 +1479,7 @@ int LpEngine::webp_yuv420(const LpFrame& f, const LpWebpYuvTab& tab, uint8_t* y,
     if (!check(hipMemcpyAsync(base, &tab, sizeof(tab), hipMemcpyHostToDevice, stream_), "H2D webp tables")) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(base + tab_b, 0, 256, stream_), "memset webp flag")) return LP_ERR_DEVICE;
     uint8_t *dy = base + tab_b + 256, *du = dy + y_b, *dv = du + c_b;
-    lp_launch_webp_yuv420(stream_, f, reinterpret_cast<const LpWebpYuvTab*>(base), dy, du, dv, reinterpret_cast<uint32_t*>(base + tab_b));
+    { LpStageProbe probe_(stream_, "k_webp_yuv420", (double)((size_t)f.w * f.h * f.cn + yb + 2 * cb)); lp_launch_webp_yuv420(stream_, f, reinterpret_cast<const LpWebpYuvTab*>(base), dy, du, dv, reinterpret_cast<uint32_t*>(base + tab_b)); }
     if (!check(hipMemcpyAsync(y, dy, yb, hipMemcpyDeviceToHost, stream_), "D2H Y plane")) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(u, du, cb, hipMemcpyDeviceToHost, stream_), "D2H U plane")) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(v, dv, cb, hipMemcpyDeviceToHost, stream_), "D2H V plane")) return LP_ERR_DEVICE;
@@ -1419,7 +1503,7 @@ int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const ui
     op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
     op.error_off = (uint64_t)(uintptr_t)(base + pal_off + 1024);
     op.sync_off = (uint64_t)(uintptr_t)(base + pal_off + 1024 + 256);
-    lp_launch_png(stream_, op);
+    { LpStageProbe probe_(stream_, "k_png_unfilter + k_png_convert", (double)(3 * n + (size_t)op.dst.w * op.dst.h * op.dst.cn)); lp_launch_png(stream_, op); }
     uint32_t* flag = h_small_.ensure(4096) ? h_small_.as<uint32_t>() : nullptr;
     if (!flag) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(flag, base + pal_off + 1024, 4, hipMemcpyDeviceToHost, stream_), "D2H png flag")) return LP_ERR_DEVICE;
@@ -1441,7 +1525,7 @@ int LpEngine::png_filter(const LpFrame& src, uint32_t filters, uint8_t* out)
     op.src = src;
     op.out_off = (uint64_t)(uintptr_t)d_packed_.p;
     op.filters = filters;
-    lp_launch_png_filter(stream_, op);
+    { LpStageProbe probe_(stream_, "k_png_filter", (double)((size_t)src.w * src.h * src.cn + n)); lp_launch_png_filter(stream_, op); }
     if (!check(hipMemcpyAsync(out, d_packed_.p, n, hipMemcpyDeviceToHost, stream_), "D2H filtered rows")) return LP_ERR_DEVICE;
     if (!check(hipStreamSynchronize(stream_), "png filter sync")) return LP_ERR_DEVICE;
     return check(hipGetLastError(), "png filter kernel") ? LP_OK : LP_ERR_DEVICE;
@@ -1543,7 +1627,7 @@ int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indice
     if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D gif palette")) return LP_ERR_DEVICE;
     op.index_off = (uint64_t)(uintptr_t)base;
     op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
-    lp_launch_gif_frame(stream_, op);
+    { LpStageProbe probe_(stream_, "k_gif_frame", (double)(n_indices + 2.0 * op.canvas.w * op.canvas.h * 4)); lp_launch_gif_frame(stream_, op); }
     if (!check(hipStreamSynchronize(stream_), "gif frame sync")) return LP_ERR_DEVICE; // the host buffers are the caller's
     return check(hipGetLastError(), "gif frame kernel") ? LP_OK : LP_ERR_DEVICE;
 }
@@ -1688,8 +1772,13 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         return check(hipGetLastError(), "fdct kernel") ? LP_OK : LP_ERR_DEVICE;
     }
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
-    lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
-                     d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
+    {
+        double eb = 0;
+        for (int i = 0; i < n; i++) eb += (double)h_jobs_[(size_t)i].src.w * h_jobs_[(size_t)i].src.h * h_jobs_[(size_t)i].src.cn * 1.1;
+        LpStageProbe probe_(stream_, "k_enc_* (JPEG encode)", eb);
+        lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
+                         d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
+    }
     if (timing_) (void)hipEventRecord(ev_[6], stream_);
     {   // results: every stream into its slot of the pinned output buffer (a slot bounds the usual size; a stream that outgrows it
         // is fetched from the output arena by encoded_fetch_all), and the states -- one wait for both

@@ -87,7 +87,16 @@ int guarded_dev_malloc(void** out, size_t bytes, const char* tag)
         return 1;
     }
     uint8_t* p = lo + (mapped - body);
-    if (hipMemset(lo, kCanary, mapped - body) != hipSuccess) (void)hipGetLastError();
+    {   // the canary band: written by a synchronous copy and read back at once, so that a band that is wrong at the free is known to have been
+        // right here (the first run of this mode filled it with hipMemset and found whole first pages of fresh mappings "overwritten")
+        std::vector<uint8_t> band(mapped - body, kCanary), back(mapped - body, 0);
+        const hipError_t e1 = hipMemcpy(lo, band.data(), band.size(), hipMemcpyHostToDevice);
+        const hipError_t e2 = hipMemcpy(back.data(), lo, back.size(), hipMemcpyDeviceToHost);
+        if (e1 != hipSuccess || e2 != hipSuccess || memcmp(band.data(), back.data(), band.size()) != 0) {
+            (void)hipGetLastError();
+            fprintf(stderr, "[lilliput_hip guard] canary band of %s (%zu B) did not take: write %d, read %d\n", tag ? tag : "?", bytes, (int)e1, (int)e2);
+        }
+    }
     State& s = state();
     std::lock_guard<std::mutex> lk(s.mu);
     s.dev[(uintptr_t)p] = DevRec{base, reserved, mapped, body, bytes, h, tag, device};
@@ -120,11 +129,14 @@ bool guarded_dev_free(void* p)
     const size_t gap = r.mapped - r.body;
     std::vector<uint8_t> h(gap);
     if (hipMemcpy(h.data(), lo, gap, hipMemcpyDeviceToHost) == hipSuccess) {
-        size_t bad = 0, first = 0;
+        size_t bad = 0, first = 0, last = 0;
         for (size_t i = 0; i < gap; i++)
-            if (h[i] != kCanary) { if (!bad) first = i; bad++; }
+            if (h[i] != kCanary) { if (!bad) first = i; bad++; last = i; }
         if (bad) {
-            fprintf(stderr, "[lilliput_hip guard] CANARY of %s (%zu B at %p) overwritten: %zu bytes, the first %zu bytes BEFORE the buffer\n", r.tag ? r.tag : "?", r.bytes, p, bad, gap - first);
+            char hex[3 * 16 + 1] = {0};
+            for (size_t i = 0; i < 16 && first + i < gap; i++) snprintf(hex + 3 * i, 4, "%02x ", h[first + i]);
+            fprintf(stderr, "[lilliput_hip guard] CANARY of %s (%zu B at %p) overwritten: %zu bytes in [-%zu, -%zu) before the buffer (band %zu B, mapping starts at -%zu); first bytes: %s\n",
+                    r.tag ? r.tag : "?", r.bytes, p, bad, gap - first, gap - last - 1, gap, gap, hex);
             State& s = state();
             std::lock_guard<std::mutex> lk(s.mu);
             s.n_violations++;
@@ -133,7 +145,11 @@ bool guarded_dev_free(void* p)
         (void)hipGetLastError();
     (void)hipMemUnmap(lo, r.mapped);
     (void)hipMemRelease(r.handle);
-    (void)hipMemAddressFree(r.base, r.reserved);
+    // The address range is NOT given back: a later reservation must never land on an address some kernel may still hold (a stale pointer
+    // then faults instead of reading a stranger's buffer), and no mapping is ever made twice at one address. 47 bits of address space
+    // outlast any run of this mode. LILLIPUT_HIP_GUARD_REUSE_VA=1 frees the range as the first version did.
+    static const bool reuse_va = getenv("LILLIPUT_HIP_GUARD_REUSE_VA") && atoi(getenv("LILLIPUT_HIP_GUARD_REUSE_VA")) != 0;
+    if (reuse_va) (void)hipMemAddressFree(r.base, r.reserved);
     if (prev >= 0 && prev != r.device) (void)hipSetDevice(prev);
     return true;
 }

@@ -21,6 +21,9 @@ typedef struct {
     int nsrc;
     long jobs;
     int width, height, quality, max_size, resize_method;
+    const char* file_type;      /* ".jpeg", ".webp", ".png" ... (ImageOptions.FileType) */
+    const int* enc_opts;        /* EncodeOptions as key, value, key, value ...; NULL: {JpegQuality: quality} */
+    size_t enc_opts_len, dst_cap;
     atomic_long next, ok, failed;
     int first_error;
     pthread_barrier_t gate;
@@ -41,11 +44,11 @@ static int one_request(sim_t* s, lilliput_image_ops ops, const void* src, size_t
         const int enc[2] = {CV_IMWRITE_JPEG_QUALITY, s->quality};
         lilliput_image_options o;
         memset(&o, 0, sizeof(o));
-        o.file_type = ".jpeg";
+        o.file_type = s->file_type ? s->file_type : ".jpeg";
         o.width = s->width; o.height = s->height;
         o.resize_method = s->resize_method;
-        o.encode_options = enc;
-        o.encode_options_len = 2;
+        o.encode_options = s->enc_opts ? s->enc_opts : enc;
+        o.encode_options_len = s->enc_opts ? s->enc_opts_len : 2;
         o.encode_timeout_ns = 60ll * 1000000000ll;
         rc = lilliput_image_ops_transform(ops, d, &o, dst, cap, n);
     }
@@ -57,7 +60,7 @@ static void* sim_worker(void* arg)
 {
     sim_t* s = (sim_t*)arg;
     lilliput_image_ops ops = lilliput_new_image_ops(s->max_size);
-    const size_t cap = 4u << 20;
+    const size_t cap = s->dst_cap ? s->dst_cap : (size_t)4u << 20;
     uint8_t* dst = (uint8_t*)malloc(cap);
     size_t n = 0;
     if (ops) (void)one_request(s, ops, s->srcs[0], s->lens[0], dst, cap, &n); /* untimed: the thread's first call builds what a running service has */
@@ -86,14 +89,30 @@ static void* sim_worker(void* arg)
  * stands ready to the moment the queue is empty. Returns the number of successful requests; *first_error = a LILLIPUT_* code if any
  * failed. keep / keep_cap / keep_len: optional copies of the first response per distinct source (nsrc slots). lat_ms: optional,
  * one float per job. resize_method: LILLIPUT_OPS_FIT / _RESIZE / _NO_RESIZE. */
+long lilliput_service_sim_run2(const void* const* srcs, const size_t* lens, int nsrc, int threads, long jobs, int width, int height, const char* file_type, const int* enc_opts,
+                               size_t enc_opts_len, int resize_method, int max_size, size_t dst_cap, double* seconds, int* first_error, uint8_t* keep, size_t keep_cap,
+                               long* keep_len, float* lat_ms);
+
 long lilliput_service_sim_run(const void* const* srcs, const size_t* lens, int nsrc, int threads, long jobs, int width, int height, int quality, int resize_method,
                               int max_size, double* seconds, int* first_error, uint8_t* keep, size_t keep_cap, long* keep_len, float* lat_ms)
 {
+    const int enc[2] = {CV_IMWRITE_JPEG_QUALITY, quality};
+    return lilliput_service_sim_run2(srcs, lens, nsrc, threads, jobs, width, height, ".jpeg", enc, 2, resize_method, max_size, 0, seconds, first_error, keep, keep_cap, keep_len, lat_ms);
+}
+
+/* The general form: any output type ImageOps.Transform serves (file_type, EncodeOptions as a flat key / value list), dst_cap bytes of
+ * output buffer per worker (0: 4 MiB). */
+long lilliput_service_sim_run2(const void* const* srcs, const size_t* lens, int nsrc, int threads, long jobs, int width, int height, const char* file_type, const int* enc_opts,
+                               size_t enc_opts_len, int resize_method, int max_size, size_t dst_cap, double* seconds, int* first_error, uint8_t* keep, size_t keep_cap,
+                               long* keep_len, float* lat_ms)
+{
+    const int quality = 0;
     if (threads < 1) threads = 1;
     sim_t s;
     memset(&s, 0, sizeof(s));
     s.srcs = srcs; s.lens = lens; s.nsrc = nsrc; s.jobs = jobs;
     s.width = width; s.height = height; s.quality = quality; s.max_size = max_size; s.resize_method = resize_method;
+    s.file_type = file_type; s.enc_opts = enc_opts; s.enc_opts_len = enc_opts_len; s.dst_cap = dst_cap;
     s.keep = keep; s.keep_cap = keep_cap; s.keep_len = keep_len; s.lat_ms = lat_ms;
     atomic_init(&s.next, 0); atomic_init(&s.ok, 0); atomic_init(&s.failed, 0);
     pthread_barrier_init(&s.gate, NULL, (unsigned)threads + 1);

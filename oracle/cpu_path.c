@@ -37,6 +37,7 @@ typedef long (*enc_jpeg_fn)(const uint8_t*, int, int, int, size_t, int, uint8_t*
 typedef int (*dec_png_fn)(const uint8_t*, size_t, uint8_t*, size_t, int info[6]);
 typedef long (*dec_webp_fn)(const uint8_t*, size_t, int, uint8_t*, size_t, int meta[8]);
 typedef int (*info_webp_fn)(const uint8_t*, size_t, uint32_t out[8]);
+typedef size_t (*enc_webp_fn)(const uint8_t*, int, int, int, float, const uint8_t*, size_t, uint8_t*, size_t);
 
 typedef struct {
     dec_jpeg_fn dec_jpeg;       /* JPEG bytes -> BGR / grey rows */
@@ -46,6 +47,8 @@ typedef struct {
     info_webp_fn info_webp;
     int width, height, quality;
     int resize_method;          /* 0 none, 1 Fit, 2 Resize (ops.go:18-22) */
+    enc_webp_fn enc_webp;       /* non-NULL: WebP output at webp_quality (webp.cpp:707-751) instead of JPEG */
+    float webp_quality;
 } lo_path_cfg;
 
 typedef struct { uint8_t *frame, *oriented, *thumb; size_t frame_cap, oriented_cap, thumb_cap; } lo_path_scratch;
@@ -136,6 +139,11 @@ long lo_path_transform(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t
         if (need(&s->thumb, &s->thumb_cap, (size_t)ow * oh * cn)) return -4;
         lo_resize_area(px + (size_t)top * stride + (size_t)left * cn, wpc, hpc, stride, cn, s->thumb, ow, oh, (size_t)ow * cn);
         px = s->thumb; stride = (size_t)ow * cn;
+    }
+    if (cfg->enc_webp) { /* the writers take tightly packed BGR / BGRA rows: every buffer above is */
+        if (cn == 1 || stride != (size_t)ow * cn) return -5;
+        const size_t n2 = cfg->enc_webp(px, ow, oh, cn, cfg->webp_quality, NULL, 0, out, cap);
+        return n2 ? (long)n2 : -6;
     }
     return cfg->enc_jpeg ? cfg->enc_jpeg(px, ow, oh, cn, stride, cfg->quality, out, cap) : lo_jpeg_encode(px, ow, oh, cn, stride, cfg->quality, out, cap, NULL);
 }

@@ -686,12 +686,35 @@ def transform_any_to_jpeg(data, width, height, quality=85, resize_method=FIT):
     return None if f is None else jpeg_encode(f if f.shape[2] > 1 else f[:, :, 0], quality)
 
 
+def transform_animated_to_webp(data, width, height, quality=75):
+    """The reference CPU path for BASELINE configs[3]: an animated GIF (giflib 5.2.2 + the reference's compositing, restated) or an
+    animated WebP (libwebp 1.5.0's demuxer + animation decoder) -> every composited canvas through Fit(width, height) -> the reference's
+    animation writer (WebPAnimEncoder as webp.cpp:631-706 configures it). Returns (bytes, number of frames) or None."""
+    d = bytes(data)
+    if d[:3] == b"GIF":
+        g = ref_gif_frames(d)
+        if g is None:
+            return None
+        canv = [f[0] for f in g[2]]
+        delays = [max(int(f[1][4]) * 10, 0) if len(f[1]) > 4 else 100 for f in g[2]]
+    else:
+        pl = ref_webp_play(d)
+        if pl is None:
+            return None
+        canv = list(pl[0])
+        ts = [0] + list(pl[1])
+        delays = [ts[i + 1] - ts[i] for i in range(len(canv))]
+    frames = [transform_static(c, 1, width, height, FIT, False) for c in canv]
+    out = ref_webp_encode_anim(np.stack(frames), delays, quality)
+    return None if out is None else (out, len(frames))
+
+
 class _PathCfg(C.Structure):
     _fields_ = [("dec_jpeg", C.c_void_p), ("enc_jpeg", C.c_void_p), ("dec_png", C.c_void_p), ("dec_webp", C.c_void_p), ("info_webp", C.c_void_p),
-                ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int), ("enc_webp", C.c_void_p), ("webp_quality", C.c_float)]
 
 
-def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True):
+def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True, webp_quality=None):
     """The reference CPU path as a C worker loop (oracle/cpu_path.c): `jobs` transforms (job j = sources[j % len]) on `threads`
     pthreads, each with its own preallocated frame buffers, no Python between decode, orientation, Fit / INTER_AREA and encode.
     Returns {"seconds", "ok", "jobs", "kind", "outputs"}: outputs[k] = the bytes the first job on sources[k] produced (None if it
@@ -706,6 +729,12 @@ def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_r
         cfg.dec_webp = C.cast(ref_webp().ref_webp_decode_frame, C.c_void_p)
         cfg.info_webp = C.cast(ref_webp().ref_webp_info, C.c_void_p)
     cfg.width, cfg.height, cfg.quality, cfg.resize_method = int(width), int(height), int(quality), int(resize_method)
+    if webp_quality is not None:  # WebP output through the reference's own writer (webp.cpp:707-751)
+        if ref_webp() is None:
+            raise RuntimeError("oracle/_ref/librefwebp.so is not built")
+        ref_webp().ref_webp_encode_still.restype = C.c_size_t
+        cfg.enc_webp = C.cast(ref_webp().ref_webp_encode_still, C.c_void_p)
+        cfg.webp_quality = float(webp_quality)
     bufs = [np.frombuffer(bytes(d), dtype=np.uint8) for d in sources]
     n = len(bufs)
     ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
