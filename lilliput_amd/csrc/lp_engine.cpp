@@ -325,6 +325,8 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
     u.prog.assign((size_t)n, std::vector<LpUpload::ProgScanUp>());
     u.phuffs.clear();
     u.prog_on_device = lp_prog_entropy_on_device();
+    for (int i = 0; i < n; i++) // a QM-coded scan only has a host decoder (lp_arith_host.h): a set that holds one is decoded in hybrid mode as a whole
+        if (hdrs[i].arith) u.prog_on_device = false;
     u.pcoef_off.assign((size_t)n, 0);
     u.perr.assign((size_t)n, 0);
     u.pcoef_total = 0;

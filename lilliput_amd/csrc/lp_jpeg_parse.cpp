@@ -147,7 +147,10 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
     bool h_ok[2][4] = {{false, false, false, false}, {false, false, false, false}};
     int cid[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0}, td[4] = {0, 0, 0, 0}, ta[4] = {0, 0, 0, 0};
     bool have_sof = false, saw_jfif = false, saw_adobe = false, sof_unsupported = false, sof_bad_sampling = false, progressive = false;
-    struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; bool sequential; uint8_t bits[8][17], vals[8][256]; size_t ecs_off, ecs_len; };
+    struct RawScan { unsigned ns; int comp[4], td[4], ta[4]; unsigned Ss, Se, Ah, Al, dri; bool sequential; uint8_t bits[8][17], vals[8][256]; size_t ecs_off, ecs_len; LpArithScan ar; };
+    bool arith = false;     // SOF9 / SOF10: QM-coded scans (jdarith.c), always taken scan by scan
+    uint8_t dac_L[16], dac_U[16], dac_K[16]; // DAC conditioning as jpeg_create_decompress / start of every datastream leaves it: L = 0, U = 1, Kx = 5
+    for (int t = 0; t < 16; t++) { dac_L[t] = 0; dac_U[t] = 1; dac_K[t] = 5; }
     bool seq_scans = false; // a sequential file that goes scan by scan (see LpProgScan::sequential); decided at its first SOS
     std::vector<RawScan> raw_scans;
     unsigned sof_nc = 0;
@@ -225,8 +228,9 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
             j.width = be16(p + 3);
             if (j.height == 0 || j.width == 0 || nc == 0) return LP_PARSE_NOT_JPEG; // JERR_EMPTY_IMAGE
             if (pl != 6 + 3u * nc) return LP_PARSE_NOT_JPEG;             // JERR_BAD_LENGTH
-            progressive = m == 0xC2;
-            if (m != 0xC0 && m != 0xC1 && m != 0xC2) { sof_unsupported = true; } // lossless, arithmetic: judged at SOS
+            progressive = m == 0xC2 || m == 0xCA;
+            arith = m == 0xC9 || m == 0xCA;
+            if (m != 0xC0 && m != 0xC1 && m != 0xC2 && !arith) { sof_unsupported = true; } // lossless (SOF3, SOF11): judged at SOS
             if (prec != 8 || (nc != 1 && nc != 3 && nc != 4)) sof_unsupported = true; // 12-bit, two-component
             sof_nc = nc;
             for (unsigned c = 0; c < nc; c++) {
@@ -244,11 +248,13 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         } else if (m == 0xDD) { // get_dri
             if (L != 4) return LP_PARSE_NOT_JPEG;
             j.dri = be16(p);
-        } else if (m == 0xCC) { // get_dac: checked like libjpeg does, although no arithmetic scan is accepted further down
+        } else if (m == 0xCC) { // get_dac
             if (pl & 1) return LP_PARSE_NOT_JPEG;
             for (size_t k = 0; k < pl; k += 2) {
                 if (p[k] >= 32) return LP_PARSE_NOT_JPEG;                                   // JERR_DAC_INDEX
                 if (p[k] < 16 && (p[k + 1] & 15) > (p[k + 1] >> 4)) return LP_PARSE_NOT_JPEG; // JERR_DAC_VALUE
+                if (p[k] < 16) { dac_L[p[k]] = p[k + 1] & 15; dac_U[p[k]] = p[k + 1] >> 4; }
+                else dac_K[p[k] - 16] = p[k + 1];
             }
         } else if (m == 0xE0) {
             if (pl >= 14 && memcmp(p, "JFIF\0", 5) == 0) saw_jfif = true;
@@ -273,7 +279,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 for (unsigned q = 0; q < s; q++) if (cur[q] == c) return LP_PARSE_NOT_JPEG;
                 // jpeg_make_d_derived_tbl rejects an index above 3 -- of the tables a scan actually builds: both in a sequential
                 // scan, only the DC or the AC one in a progressive scan (checked below)
-                if (!progressive && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
+                if (!progressive && !arith && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
                 if (s < 4) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
             if (!progressive && raw_scans.empty()) {
@@ -283,7 +289,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 // sampling factors the baseline kernels do not take (anything but luma 1x1 / 2x1 / 1x2 / 2x2 over 1x1 chroma): same walk
                 if (j.ncomp == 3 && (j.hs[1] != 1 || j.vs[1] != 1 || j.hs[2] != 1 || j.vs[2] != 1 || j.hs[0] > 2 || j.vs[0] > 2)) seq_scans = true;
                 for (unsigned s = 0; s < ns; s++) seq_scans = seq_scans || cur[s] != (int)s || (p[2 + 2 * s] >> 4) > 1 || (p[2 + 2 * s] & 15) > 1;
-                seq_scans = seq_scans || force_scans;
+                seq_scans = seq_scans || force_scans || arith;
             }
             if (ns > 1) { // jdinput.c per_scan_setup: an interleaved MCU holds at most D_MAX_BLOCKS_IN_MCU = 10 blocks
                 unsigned blocks = 0;
@@ -312,7 +318,12 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 }
                 rs.dri = j.dri;
                 const bool dc_scan = rs.Ss == 0;
-                if (rs.sequential) { // both tables of every component, Annex-K ones for undefined numbers 0 / 1 (jinit_huff_decoder -> std_huff_tables)
+                if (arith) { // jdarith.c start_pass: any table number 0..15 is fine; the conditioning is what the DAC segments so far left
+                    for (unsigned s = 0; s < ns; s++) {
+                        rs.ar.dc_tbl[s] = (uint8_t)rs.td[s]; rs.ar.ac_tbl[s] = (uint8_t)rs.ta[s];
+                        rs.ar.dc_L[s] = dac_L[rs.td[s] & 15]; rs.ar.dc_U[s] = dac_U[rs.td[s] & 15]; rs.ar.ac_K[s] = dac_K[rs.ta[s] & 15];
+                    }
+                } else if (rs.sequential) { // both tables of every component, Annex-K ones for undefined numbers 0 / 1 (jinit_huff_decoder -> std_huff_tables)
                     for (unsigned s = 0; s < ns; s++)
                         for (int cls = 0; cls < 2; cls++) {
                             const int id = cls ? rs.ta[s] : rs.td[s], slot = cls ? 4 + (int)s : (int)s;
@@ -456,7 +467,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 hs.s.hs[s] = rs.ns == 1 ? 1 : j.hs[c];
                 hs.s.vs[s] = rs.ns == 1 ? 1 : j.vs[c];
             }
-            for (unsigned slot = 0; slot < 8; slot++) { // canonical tables + an 8-bit first-level lookup
+            for (unsigned slot = 0; slot < 8 && !arith; slot++) { // canonical tables + an 8-bit first-level lookup (Huffman scans)
                 const unsigned s = slot;
                 if ((slot & 3u) >= rs.ns) continue;
                 if (rs.sequential ? false : (slot >= 4 || (rs.Ss == 0 && rs.Ah != 0))) continue; // progressive: one table per component, none in a DC refinement
@@ -476,9 +487,12 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
             }
             hs.ecs_off = rs.ecs_off;
             hs.ecs_len = rs.ecs_len;
+            hs.arith = arith;
+            hs.ar = rs.ar;
             out->scans.push_back(hs);
         }
         if (out->scans.empty()) return LP_PARSE_NOT_JPEG;
+        out->arith = arith;
         out->ecs_off = out->scans.front().ecs_off;
         out->ecs_len = out->scans.back().ecs_off + out->scans.back().ecs_len - out->ecs_off;
         return LP_PARSE_OK;

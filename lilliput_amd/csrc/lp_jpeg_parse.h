@@ -5,11 +5,12 @@
 #include <vector>
 
 #include "lp_types.h"
+#include "lp_arith_host.h"
 
 enum {
     LP_PARSE_OK = 0,
     LP_PARSE_NOT_JPEG = 1,      // no SOI / broken marker structure      -> ErrInvalidImage
-    LP_PARSE_UNSUPPORTED = 2,   // arithmetic coding, lossless, 12-bit, sampling factors above 2
+    LP_PARSE_UNSUPPORTED = 2,   // lossless, 12-bit, fractional sampling ratios
     LP_PARSE_TRUNCATED = 3
 };
 
@@ -17,6 +18,8 @@ struct LpProgScanHost {         // one scan of a file that is decoded scan by sc
     LpProgScan s;               // img / stream / huff indices are filled in by the engine
     LpProgHuff tables;
     size_t ecs_off, ecs_len;    // this scan's entropy-coded bytes in the file
+    bool arith = false;         // an arithmetic-coded scan (SOF9 / SOF10): `tables` is unused, `ar` holds the conditioning (lp_arith_host.h)
+    LpArithScan ar = {};
 };
 
 struct LpJpegHeader {
@@ -25,6 +28,7 @@ struct LpJpegHeader {
     size_t ecs_off = 0;         // first entropy-coded byte in the file
     size_t ecs_len = 0;         // bytes up to (not including) the terminating marker / end of file (progressive: through the last scan)
     int saw_eoi = 0;
+    bool arith = false;         // an arithmetic-coded file (always decoded scan by scan, on host threads)
     bool scan_path = false;     // decoded scan by scan (progressive, multi-scan sequential, four components, unusual sampling):
                                 // `scans` lists the scans in file order, `huff` is unused
     std::vector<LpProgScanHost> scans;

@@ -86,6 +86,10 @@ void unstuff(const uint8_t* raw, size_t n, std::vector<uint8_t>& clean, std::vec
 void run_task(const LpProgHostTask& t, std::vector<uint8_t>& clean, std::vector<uint32_t>& rst, std::vector<uint32_t>& words)
 {
     const LpProgScanHost& sh = *t.scan;
+    if (sh.arith) { // a QM-coded scan reads its raw bytes itself (lp_arith_host.h); an impossible code leaves the rest of the scan alone, like libjpeg's warning
+        (void)lp_arith_scan(t.data + sh.ecs_off, sh.ecs_len, sh.s, sh.ar, t.coef);
+        return;
+    }
     unstuff(t.data + sh.ecs_off, sh.ecs_len, clean, rst);
     const LpProgScan& sc = sh.s;
     const uint32_t rst_cap = sc.dri ? (sc.mcux * sc.mcuy + sc.dri - 1) / sc.dri + 2 : 2;

@@ -180,7 +180,11 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
             in->height = rd16(p + 1);
             in->width = rd16(p + 3);
             if (in->height == 0 || in->width == 0 || nc == 0 || pl != 6 + 3 * nc) return LO_ERR_FORMAT;
-            if ((m != 0xC0 && m != 0xC1 && m != 0xC2) || p[0] != 8 || (nc != 1 && nc != 3 && nc != 4)) unsupported = 1;
+            /* SOF9 / SOF10 (arithmetic coding): libjpeg decodes them (jdarith.c) and so does the product (host threads, lp_arith_host.h). This
+               restatement accepts their HEADER -- the accept / reject verdict is compared with the product's -- and leaves the entropy
+               decode to the real library: the arithmetic-coded fixtures are checked against recorded answers of the reference's libjpeg.a
+               (tests/test_arith.py), lo_jpeg_decode_* answer LO_ERR_UNSUPPORTED for them. */
+            if ((m != 0xC0 && m != 0xC1 && m != 0xC2 && m != 0xC9 && m != 0xCA) || p[0] != 8 || (nc != 1 && nc != 3 && nc != 4)) unsupported = 1;
             in->ncomp = nc <= 4 ? nc : 4;
             for (int c = 0; c < nc; c++) {
                 int hs = p[7 + 3 * c] >> 4, vs = p[7 + 3 * c] & 15;
@@ -211,6 +215,31 @@ int lo_jpeg_read_header(const uint8_t* d, size_t n, lo_jpeg_info* in)
             if (in->height > 65500 || in->width > 65500 || bad_sampling) return LO_ERR_FORMAT;
             if (unsupported) return LO_ERR_UNSUPPORTED;
             if (in->sof == 2) { in->ecs_off = seg_end; break; } /* progressive: the scans are walked by decode_coefs_progressive */
+            if (in->sof == 9 || in->sof == 10) { /* arithmetic: component matching as below, no Huffman tables; jdarith.c start_pass checks a progressive scan's parameters */
+                for (int s = 0; s < ns; s++) {
+                    int cs = p[1 + 2 * s], c;
+                    for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs && cur[c] < 0) break;
+                    if (c == in->ncomp) return LO_ERR_FORMAT;
+                    cur[s] = c;
+                    for (int q = 0; q < s; q++) if (cur[q] == c) return LO_ERR_FORMAT;
+                }
+                if (ns > 1) {
+                    int blocks = 0;
+                    for (int s = 0; s < ns; s++) blocks += in->hs[cur[s]] * in->vs[cur[s]];
+                    if (blocks > 10) return LO_ERR_FORMAT;
+                }
+                if (in->sof == 10) {
+                    const int Ss = p[1 + 2 * ns], Se = p[2 + 2 * ns], Ah = p[3 + 2 * ns] >> 4, Al = p[3 + 2 * ns] & 15;
+                    int bad = 0;
+                    if (Ss == 0) { if (Se != 0) bad = 1; } else { if (Se < Ss || Se > 63) bad = 1; if (ns != 1) bad = 1; }
+                    if (Ah != 0 && Ah - 1 != Al) bad = 1;
+                    if (Al > 13) bad = 1;
+                    if (bad) return LO_ERR_FORMAT;
+                }
+                in->scan_path = 1;
+                in->ecs_off = seg_end;
+                break;
+            }
             for (int s = 0; s < ns; s++) {
                 int cs = p[1 + 2 * s], t = p[2 + 2 * s], c;
                 for (c = 0; c < in->ncomp; c++) if (in->cid[c] == cs && cur[c] < 0) break; /* libjpeg-turbo's slot rule */
@@ -676,6 +705,7 @@ static int decode_coefs(const uint8_t* d, size_t n, lo_dec* D)
     lo_jpeg_info* in = &D->in;
     int rc = lo_jpeg_read_header(d, n, in);
     if (rc) return rc;
+    if (in->sof == 9 || in->sof == 10) return LO_ERR_UNSUPPORTED; /* arithmetic coding: header only, see lo_jpeg_read_header */
     if (in->sof == 2 || in->scan_path) return decode_coefs_progressive(d, n, D);
     lo_htab dc[4], ac[4];
     for (int t = 0; t < 4; t++) {

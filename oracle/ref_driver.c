@@ -273,6 +273,16 @@ long ref_jpeg_encode_ex(const uint8_t* px, int W, int H, int ncomp, int mode, co
     }
     if (optimize & 32)
         for (int c = 0; c < ncomp; c++) { ci.comp_info[c].dc_tbl_no = c; ci.comp_info[c].ac_tbl_no = c; }
+    /* bit 7: arithmetic coding (SOF9, or SOF10 with a progressive script); bit 8: conditioning values other than the defaults, so that
+     * the file carries DAC segments (T.81 B.2.4.3); bit 9 (with bit 7): a table number of its own for every component */
+    if (optimize & 128) ci.arith_code = TRUE;
+    if (optimize & 256) {
+        ci.arith_dc_L[0] = 1; ci.arith_dc_U[0] = 4; ci.arith_ac_K[0] = 3;
+        ci.arith_dc_L[1] = 0; ci.arith_dc_U[1] = 2; ci.arith_ac_K[1] = 7;
+        ci.arith_dc_L[2] = 2; ci.arith_dc_U[2] = 2; ci.arith_ac_K[2] = 1;
+    }
+    if (optimize & 512)
+        for (int c = 0; c < ncomp; c++) { ci.comp_info[c].dc_tbl_no = c; ci.comp_info[c].ac_tbl_no = c; }
     jpeg_start_compress(&ci, TRUE);
     while (ci.next_scanline < ci.image_height) {
         JSAMPROW row = (JSAMPROW)(px + (size_t)ci.next_scanline * W * ncomp);

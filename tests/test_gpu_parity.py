@@ -112,7 +112,7 @@ def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
 
     data = fixture_bytes["large-sunrise.jpg"]
     sof = data.index(b"\xff\xc0")
-    for marker in (0xC9, 0xC3, 0xCA):  # arithmetic-coded, lossless, arithmetic progressive: outside the device path, said so loudly
+    for marker in (0xC3, 0xCB):  # lossless (Huffman, arithmetic): outside the device path, said so loudly (arithmetic-coded DCT files are served since round 4: tests/test_arith.py)
         with pytest.raises(lilliput_amd.LilliputError) as e:
             batch.decode_jpeg(data[: sof + 1] + bytes([marker]) + data[sof + 2 :])
         assert e.value.code == 4, marker
