@@ -78,6 +78,23 @@ def host_cores():
     return len(allowed), (len(phys) or len(allowed))
 
 
+def cgroup_cpus():
+    """CPUs' worth of time the container may use per second (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited. The gpurun boxes
+    show 256 hardware threads and grant 16 (cpu.max = "1600000 100000", scripts/host_scale.cpp): every host-side figure measured there
+    -- the CPU baseline, the ingest threads, the host codecs of the firehose -- lives inside that quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample, out_w=256, out_h=256, quality=85, budget_s=10.0, what="4096x4096 q90 -> 256x256 q85"):
     """The reference CPU path on this box's host cores, on a bounded sample of the timed workload: a C worker loop (oracle/cpu_path.c), one
     pthread per core, each with the preallocated frame buffers an ImageOps holds for its lifetime (ops.go:83-91), decode (the reference's
@@ -89,12 +106,17 @@ def cpu_baseline(sample, out_w=256, out_h=256, quality=85, budget_s=10.0, what="
 
     O.lib()
     logical, physical = host_cores()
+    quota = cgroup_cpus()
+    usable = min(float(physical), quota) if quota else float(physical)   # what can run at once: the cores, or the container's CPU quota
     r1 = O.cpu_path_run(sample, out_w, out_h, quality, threads=1, jobs=min(len(sample), 3), keep=False)
     one = r1["ok"] / max(r1["seconds"], 1e-9)
     runs = {}
     checked = None
-    for th in sorted({physical, logical}):
-        jobs = int(max(4 * th, one * 0.7 * th * budget_s / 2))  # about budget_s / 2 seconds per run if the cores scale
+    counts = {physical, logical}
+    if quota:
+        counts = {max(1, int(quota + 0.5)), physical}   # one thread per granted CPU (no throttling), and one per core (what an unaware service starts)
+    for th in sorted(counts):
+        jobs = int(max(2 * th, one * 0.7 * min(th, usable) * budget_s / 2))  # about budget_s / 2 seconds per run if the usable CPUs scale
         r = O.cpu_path_run(sample, out_w, out_h, quality, threads=th, jobs=jobs, keep=checked is None)
         runs[th] = {"images_per_s": round(r["ok"] / max(r["seconds"], 1e-9), 2), "jobs": jobs, "ok": r["ok"], "seconds": round(r["seconds"], 2)}
         if checked is None:
@@ -103,8 +125,9 @@ def cpu_baseline(sample, out_w=256, out_h=256, quality=85, budget_s=10.0, what="
     best = max(runs, key=lambda t: runs[t]["images_per_s"])
     value = runs[best]["images_per_s"]
     return {"value": value, "unit": "images/s", "cores": best, "kind": r1["kind"],
-            "physical_cores": physical, "logical_cpus": logical, "one_core_images_per_s": round(one, 2),
-            "scaling_efficiency": round(value / max(1e-9, physical * one), 3),
+            "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_quota": quota, "usable_cpus": usable, "one_core_images_per_s": round(one, 2),
+            "scaling_efficiency": round(value / max(1e-9, usable * one), 3),
+            "scaling_efficiency_is": "value / (usable_cpus x one_core): usable_cpus = min(physical cores, the container's cgroup CPU quota)",
             "runs_by_threads": {str(k): v for k, v in runs.items()},
             "harness": "oracle/cpu_path.c: pthreads, one preallocated frame-buffer set per worker, one atomic job counter, timed between barriers",
             "first_output_equals_python_oracle": checked,
@@ -324,6 +347,8 @@ def cpu_baseline_processes(fn, jobs_per_worker, what):
     import multiprocessing as mp
 
     logical, physical = host_cores()
+    quota = cgroup_cpus()
+    usable = min(float(physical), quota) if quota else float(physical)
     t0 = time.time()
     units1 = fn()
     one = units1 / max(1e-9, time.time() - t0)
@@ -335,7 +360,7 @@ def cpu_baseline_processes(fn, jobs_per_worker, what):
         q.put(u)
 
     runs = {}
-    for th in sorted({physical, logical}):
+    for th in sorted({max(1, int(quota + 0.5)), physical} if quota else {physical, logical}):
         q = mp.get_context("fork").Queue()
         ps = [mp.get_context("fork").Process(target=work, args=(jobs_per_worker, q)) for _ in range(th)]
         t0 = time.time()
@@ -348,7 +373,8 @@ def cpu_baseline_processes(fn, jobs_per_worker, what):
         runs[th] = {"units_per_s": round(units / dt, 2), "seconds": round(dt, 2)}
     best = max(runs, key=lambda t: runs[t]["units_per_s"])
     return {"value": runs[best]["units_per_s"], "unit": "frames/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
-            "one_core_units_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["units_per_s"] / max(1e-9, physical * one), 3),
+            "cgroup_cpu_quota": quota, "usable_cpus": usable,
+            "one_core_units_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["units_per_s"] / max(1e-9, usable * one), 3),
             "runs_by_processes": {str(k): v for k, v in runs.items()},
             "harness": "forked worker processes (no C worker loop exists for the animated path; fork time is inside the measurement)",
             "sample": "%d x %s per worker process on %d processes" % (jobs_per_worker, what, best)}
@@ -459,15 +485,18 @@ def main_formats(args, ranks, la):
         if not args.no_cpu_baseline:
             if args.workload == "png2webp":
                 logical, physical = host_cores()
+                quota = cgroup_cpus()
+                usable = min(float(physical), quota) if quota else float(physical)
                 r1 = O.cpu_path_run(srcs, W, H, threads=1, jobs=16, keep=False, webp_quality=q)
                 one = r1["ok"] / max(1e-9, r1["seconds"])
                 runs = {}
-                for th in sorted({physical, logical}):
-                    r = O.cpu_path_run(srcs, W, H, threads=th, jobs=int(max(8 * th, one * 0.7 * th * 4)), keep=False, webp_quality=q)
+                for th in sorted({max(1, int(quota + 0.5)), physical} if quota else {physical, logical}):
+                    r = O.cpu_path_run(srcs, W, H, threads=th, jobs=int(max(8 * th, one * 0.7 * min(th, usable) * 4)), keep=False, webp_quality=q)
                     runs[th] = {"images_per_s": round(r["ok"] / max(1e-9, r["seconds"]), 2), "jobs": r["jobs"], "seconds": round(r["seconds"], 2)}
                 best = max(runs, key=lambda t: runs[t]["images_per_s"])
                 out["cpu_baseline"] = {"value": runs[best]["images_per_s"], "unit": "images/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
-                                       "one_core_images_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["images_per_s"] / max(1e-9, physical * one), 3),
+                                       "cgroup_cpu_quota": quota, "usable_cpus": usable,
+                                       "one_core_images_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["images_per_s"] / max(1e-9, usable * one), 3),
                                        "runs_by_threads": {str(k): v for k, v in runs.items()}, "harness": "oracle/cpu_path.c (pthreads, preallocated buffers per worker)",
                                        "sample": "%d transforms of ferry_sunset.png -> 297x297 WebP q85 (reference libpng 1.6.47 decode, INTER_AREA restatement, reference libwebp 1.5.0 encode) on %d threads" % (runs[best]["jobs"], best)}
             else:

@@ -404,8 +404,12 @@ int lilliput_hip_device_count(void);
  *     value the host application exported itself is left alone; LILLIPUT_HIP_KEEP_RUNTIME_ENV=1 makes the library touch nothing.
  *   - one-image ABI (Parts A, A2-A4, C): every call checks an engine (one stream + grow-only device arenas) out of a process-wide
  *     pool and returns it synchronised, so consecutive calls on one handle may come from any OS thread (cgo) and the number of
- *     engines follows the number of calls in flight, not the number of threads. At most LILLIPUT_HIP_ENGINE_POOL (default 8) idle
- *     engines are kept; an engine whose arenas grew beyond LILLIPUT_HIP_ENGINE_TRIM_MB (default 1024) is destroyed on return.
+ *     engines follows the number of calls in flight, not the number of threads. At most LILLIPUT_HIP_ENGINE_POOL (default 64) idle
+ *     engines holding at most LILLIPUT_HIP_ENGINE_POOL_MB (default 4096) of device arenas between them are kept, least recently used
+ *     out first; an engine whose arenas grew beyond LILLIPUT_HIP_ENGINE_TRIM_MB (default 1024) is destroyed on return.
+ *   - concurrent ImageOps.Transform calls (Part C) on static JPEG sources with JPEG output share batch launches once
+ *     LILLIPUT_HIP_COALESCE (default 3) of them are in flight (lilliput_amd/csrc/lp_coalesce.h): LILLIPUT_HIP_COALESCE_WORKERS
+ *     dispatcher threads (default 4) per device, each with a batch object that it gives back after LILLIPUT_HIP_COALESCE_IDLE_MS idle.
  * lilliput_hip_engine_pool_stats: engines checked out now, idle in the pool, created so far, destroyed by the bounds.
  * lilliput_hip_mem_info: hipMemGetInfo of `device` (LILLIPUT_OK or LILLIPUT_ERR_DEVICE). */
 void lilliput_hip_engine_pool_stats(size_t out[4]);

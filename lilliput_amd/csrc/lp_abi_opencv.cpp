@@ -57,9 +57,19 @@ EnginePool& engine_pool()
     static EnginePool* p = new EnginePool(); // never destroyed: at process exit the HIP runtime may already be gone
     return *p;
 }
-size_t pool_keep() // idle engines kept per process (LILLIPUT_HIP_ENGINE_POOL)
+// Idle engines kept per process: at most LILLIPUT_HIP_ENGINE_POOL of them (default 64) holding at most LILLIPUT_HIP_ENGINE_POOL_MB of
+// device arenas between them (default 4096). Round 3 kept 8: a service with more callers than that in flight on sources the call
+// coalescer does not take (PNG, WebP, GIF) built and tore down an engine -- two streams, sixteen events, some forty arenas whose
+// hipFree synchronises the device -- for a third of its requests (bench.py --workload abi, 64 callers, direct route: 314 engines
+// created for 1 024 requests, 367 images/s against 2 366 with 8 callers; profiles/r04_a_service.md).
+size_t pool_keep()
 {
-    static const size_t v = getenv("LILLIPUT_HIP_ENGINE_POOL") ? (size_t)std::max(0, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL"))) : 8;
+    static const size_t v = getenv("LILLIPUT_HIP_ENGINE_POOL") ? (size_t)std::max(0, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL"))) : 64;
+    return v;
+}
+size_t pool_keep_bytes()
+{
+    static const size_t v = (getenv("LILLIPUT_HIP_ENGINE_POOL_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL_MB"))) : 4096) << 20;
     return v;
 }
 size_t pool_trim_bytes() // an engine whose arenas grew beyond this is not kept (LILLIPUT_HIP_ENGINE_TRIM_MB, default 1 GiB: a 8192 x 8192 decode is ~0.5 GiB)
@@ -118,18 +128,27 @@ LpEngineLease::~LpEngineLease()
     // what the call left in flight (lazy write-back) must be visible to whichever engine serves the handle's next call
     (void)eng_->sync();
     EnginePool& P = engine_pool();
-    bool keep = eng_->device_bytes() <= pool_trim_bytes();
+    const size_t mine = eng_->device_bytes();
+    bool keep = mine <= pool_trim_bytes() && pool_keep() > 0;
+    std::vector<LpEngine*> drop;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.live--;
-        if (keep && P.idle.size() >= pool_keep()) { // the least recently used one goes
-            if (!P.idle.empty()) { LpEngine* old = P.idle.front().second; P.idle.erase(P.idle.begin()); P.idle.emplace_back(dev_, eng_); eng_ = old; }
-            keep = false;
-        } else if (keep)
+        if (keep) {
             P.idle.emplace_back(dev_, eng_);
-        if (!keep) P.trimmed++;
+            // over either bound: the least recently used ones go (the one just returned is the most recently used and stays)
+            size_t total = 0;
+            for (auto& e : P.idle) total += e.second->device_bytes();
+            while (P.idle.size() > 1 && (P.idle.size() > pool_keep() || total > pool_keep_bytes())) {
+                total -= P.idle.front().second->device_bytes();
+                drop.push_back(P.idle.front().second);
+                P.idle.erase(P.idle.begin());
+            }
+        } else
+            drop.push_back(eng_);
+        P.trimmed += drop.size();
     }
-    if (!keep) delete eng_;
+    for (LpEngine* e : drop) delete e;
 }
 
 // engines checked out now, idle in the pool, created so far, destroyed by the pool's bounds

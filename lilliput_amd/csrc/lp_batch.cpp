@@ -661,10 +661,11 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
     io.encode_timeout_ns = 30ll * 1000000000ll;
     // The host side of these sources is serial per image (inflate, LZW), so the items are spread over a few workers, each with its
     // own ImageOps (ops.go: "one ImageOps per goroutine") and its own per-thread engine on the batch's device.
-    // workers: an eighth of the host threads, at most 32 (LILLIPUT_HIP_OTHER_WORKERS overrides) -- a mixed-format firehose is bound by the
-    // serial host codecs (inflate, LZW, VP8), each worker keeps one engine's worth of device arenas
+    // workers: the CPUs this device's share of the host really has (lp_usable_cpus_per_device: affinity, cgroup quota, ranks of the node), at
+    // most 32 (LILLIPUT_HIP_OTHER_WORKERS overrides) -- a mixed-format firehose is bound by the serial host codecs (inflate, LZW, VP8),
+    // each worker keeps one engine's worth of device arenas
     static const int other_workers = getenv("LILLIPUT_HIP_OTHER_WORKERS") ? std::max(1, atoi(getenv("LILLIPUT_HIP_OTHER_WORKERS")))
-                                                                           : std::max(1, std::min(32, (int)std::thread::hardware_concurrency() / 8));
+                                                                           : std::max(2, std::min(32, (int)lp_usable_cpus_per_device()));
     const size_t nw = std::min<size_t>(b->other.size(), (size_t)other_workers);
     while (b->other_ops.size() < nw) b->other_ops.push_back(lilliput_new_image_ops(8192));
     while (b->other_eng.size() < nw) {

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -275,3 +276,31 @@ extern "C" int lilliput_hip_host_unregister(void* p)
 }
 
 extern "C" int lilliput_hip_host_is_pinned(const void* p, size_t bytes) { return lp_host_is_pinned(p, bytes) ? 1 : 0; }
+
+unsigned lp_usable_cpus_per_device()
+{
+    static const unsigned v = [] {
+        double cpus = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (double)CPU_COUNT(&set);
+        else cpus = (double)sysconf(_SC_NPROCESSORS_ONLN);
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[64] = {0};
+            double per = 0;
+            if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) cpus = std::min(cpus, atof(q) / per);
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+            double q = -1, per = 0;
+            if (fscanf(g, "%lf", &q) != 1) q = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) != 1) per = 0; fclose(h); }
+            if (q > 0 && per > 0) cpus = std::min(cpus, q / per);
+        }
+        int share = 0;
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) share = atoi(e);
+        if (share <= 0) { if (hipGetDeviceCount(&share) != hipSuccess) { (void)hipGetLastError(); share = 1; } }
+        cpus /= (double)std::max(1, share);
+        return (unsigned)std::max(1.0, cpus + 0.5);
+    }();
+    return v;
+}

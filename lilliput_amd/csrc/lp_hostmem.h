@@ -52,3 +52,8 @@ private:
 // LILLIPUT_HIP_NUMA=0). lp_bind_thread_near(device) pins the calling thread to them; returns the node or -1.
 int lp_device_numa_node(int device);
 int lp_bind_thread_near(int device);
+
+// Host CPUs this process can really use at once: the hardware threads it may run on (affinity mask), cut down to the container's cgroup
+// CPU quota when there is one (cpu.max; the gpurun boxes show 256 threads and grant 16 -- scripts/host_scale.cpp), and shared between the
+// ranks of a node (LOCAL_WORLD_SIZE under torchrun, else the visible devices). Worker pools of host codecs are sized from it.
+unsigned lp_usable_cpus_per_device();

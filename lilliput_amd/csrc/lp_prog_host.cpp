@@ -8,6 +8,7 @@
 #include <atomic>
 #include <thread>
 
+#include "lp_hostmem.h"
 #include "lp_prog_core.h"
 #include "lp_huff_core.h" // LP_ZIGZAG_INIT
 
@@ -158,7 +159,7 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
         const char* e = getenv("LILLIPUT_HIP_PROG_THREADS");
         nthreads = e ? atoi(e) : 0;
         if (nthreads <= 0) { // a quarter of the cores (the batch front end runs up to four uploads side by side), at least min(16, cores)
-            const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned hc = std::max(1u, std::min(std::thread::hardware_concurrency(), 4u * lp_usable_cpus_per_device())); // (the formula below takes a quarter)
             nthreads = (int)std::min(64u, std::max(std::min(16u, hc), hc / 4));
         }
     }

@@ -226,7 +226,7 @@ def test_one_image_abi_engines_are_pooled_not_per_thread(hip_lib, fixture_bytes)
     assert all(o == want for o in outs)
     hip_lib.lilliput_hip_engine_pool_stats(stats)
     live, idle, created, trimmed = list(stats)
-    assert live == 0 and idle <= 8, list(stats)
+    assert live == 0 and idle <= 64, list(stats)
     assert created - created0 <= 128
     # a handle used from two different threads one call after the other (what a migrating goroutine does): the second call's engine
     # sees what the first one's left on the device
