@@ -419,14 +419,16 @@ def main_formats(args, ranks, la):
 
     for _ in range(args.warmup):
         sim(False)
-    el, ok, outs = 0.0, 0, None
+    el, ok, outs, lat = 0.0, 0, None, []
     for k in range(args.steps):
         ranks.barrier()
         r = sim(k == args.steps - 1)
         el += r["seconds"]
         ok += r["ok"]
+        lat.append(r["latency_ms"])
         outs = r["outputs"] if r["outputs"][0] is not None else outs
     el = ranks.reduce(el, "max")
+    lat = np.concatenate(lat)
     units_per_req = sum(frames_of[j % len(srcs)] for j in range(jobs)) / jobs
     value = jobs * args.steps * world * units_per_req / el
     # ---- correctness gate: (i) the concurrent run's bytes are the serial run's; (ii) the frames handed to the encoder are the reference
@@ -476,6 +478,7 @@ def main_formats(args, ranks, la):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "reference fixtures (tests/golden)",
                "config": {"workload": "%s; %d requests per GPU and step from %d concurrent callers (one ImageOps each, NewDecoder -> Transform -> Close through Part C, lp_service_sim.c)" % (what, jobs, threads),
                           "threads": threads, "requests_per_s": round(jobs * args.steps * world / el, 2), "frames_per_request": round(units_per_req, 2), "ok_requests": ok,
+                          "request_latency_ms_p50": round(float(np.percentile(lat, 50)), 3), "request_latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
                           "output_bytes": [len(o) if o else None for o in (outs or [])],
                           "verified_identical": all(g[0] == 0 for g in gate) and all(g[1] == jobs * args.steps for g in gate),
                           "verified_against": "(i) the bytes of a serial Transform of the same source; (ii) every frame handed to the encoder against the reference CPU path (reference libpng / giflib + "
@@ -511,18 +514,20 @@ def main_formats(args, ranks, la):
         sys.exit(3)
 
 
-def firehose_check(la, O, ops, data, out, side, quality):
+def firehose_check(la, O, ops, data, out, side, quality, height=None):
     """One firehose output against the reference CPU path: the bytes, or -- where the resample is fractional (float taps: +-1 LSB per
-    channel is north_star's contract) -- a pre-encode frame within +-1 LSB of the oracle's that `out` encodes byte-exactly."""
-    exp = O.transform_any_to_jpeg(data, side, side, quality)
+    channel is north_star's contract) -- a pre-encode frame within +-1 LSB of the oracle's that `out` encodes byte-exactly.
+    side x (height or side) = the box asked for."""
+    h = side if height is None else height
+    exp = O.transform_any_to_jpeg(data, side, h, quality)
     if exp is None:
         return None  # the reference library of this format is not built here
     if out == exp:
         return True
-    ref = O.transform_any_frame(data, side, side)
+    ref = O.transform_any_frame(data, side, h)
     d = la.Decoder(data)
     try:
-        frame = la.parse_raw_frames(ops.Transform(d, la.ImageOptions(".bgra-frames", side, side, la.ImageOpsFit, False, {}, EncodeTimeout=10**10), dst_cap=ref.size * 2 + 4096))[0][0]
+        frame = la.parse_raw_frames(ops.Transform(d, la.ImageOptions(".bgra-frames", side, h, la.ImageOpsFit, False, {}, EncodeTimeout=10**10), dst_cap=ref.size * 2 + 4096))[0][0]
     finally:
         d.Close()
     import numpy as np
@@ -544,7 +549,7 @@ def main_firehose(args, ranks, la):
     ndev = max(1, la.lib().lilliput_hip_device_count())
     per_kind = max(4, min(args.distinct, 256) // 8)
     t0 = time.time()
-    pools = synth.firehose_pool(per_kind, 512, 4096, seed=1)
+    pools = synth.firehose_pool(per_kind, 512, args.max_side, seed=1)
     items = synth.firehose_items(pools, args.batch, seed=2 + rank)
     log("[bench] firehose: %d distinct sources per format generated in %.1fs" % (per_kind, time.time() - t0))
     arena = None
@@ -555,14 +560,39 @@ def main_firehose(args, ranks, la):
         placed = {k: arena.put(d) for k, d in distinct.items()}
     sources = [placed[id(d)] if arena is not None else np.frombuffer(d, dtype=np.uint8) for _, d in items]
     node = la.Node([local_rank % ndev])
-    node.prepare(sources, dst_cap=512 << 10)
+    window = args.window if 0 < args.window < args.batch else args.batch
+    kinds = [k for k, _ in items]
+    # the outputs the gate will look at are fixed before the run, so that a streamed run keeps only those (bounded memory)
+    gate_picks = {}
+    for k, _ in synth.FIREHOSE_MIX:
+        idx = [i for i, kk in enumerate(kinds) if kk == k]
+        gate_picks[k] = sorted({idx[int.from_bytes(hashlib.sha256(b"%d:%d:%s:%d" % (args.steps - 1, rank, k.encode(), j)).digest()[:8], "little") % len(idx)] for j in range(args.verify)}) if idx else []
+    wanted = {i for v in gate_picks.values() for i in v}
+    kept, status = {}, [0] * len(items)
+    if window == args.batch:
+        node.prepare(sources, dst_cap=512 << 10)
 
     def step():
-        node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+        if window == args.batch:
+            node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            return
+        # streamed: one lilliput_hip_node_transform per window of the stream; the window's item array and destination buffers are all that is held
+        for w0 in range(0, len(sources), window):
+            node.prepare(sources[w0:w0 + window], dst_cap=512 << 10)
+            node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            for j, r in enumerate(node.results()):
+                status[w0 + j] = r.status
+                if w0 + j in wanted:
+                    kept[w0 + j] = r
 
     elapsed = ranks.timed(step, args.steps, args.warmup)
-    res = node.results()
-    kinds = [k for k, _ in items]
+    if window == args.batch:
+        res = node.results()
+    else:
+        class _R:  # the streamed run kept statuses for all and bytes for the gate's picks
+            def __init__(self, st, data=b""):
+                self.status, self.data = st, data
+        res = [kept[i] if i in kept else _R(status[i]) for i in range(len(items))]
     counts = {k: kinds.count(k) for k, _ in synth.FIREHOSE_MIX}
     ok = {k: sum(1 for kk, r in zip(kinds, res) if kk == k and r.status == 0) for k in counts}
     # ---- correctness gate: K outputs per format of the last step
@@ -572,9 +602,7 @@ def main_firehose(args, ranks, la):
     ops = la.ImageOps(8192)
     verified, bad = {k: 0 for k in counts}, []
     for k in counts:
-        idx = [i for i, kk in enumerate(kinds) if kk == k]
-        picks = sorted({idx[int.from_bytes(hashlib.sha256(b"%d:%d:%s:%d" % (args.steps - 1, rank, k.encode(), j)).digest()[:8], "little") % len(idx)] for j in range(args.verify)}) if idx else []
-        for i in picks:
+        for i in gate_picks[k]:
             v = firehose_check(la, O, ops, bytes(items[i][1]), res[i].data if res[i].status == 0 else b"", args.out, 85)
             if v is None:
                 continue
@@ -582,16 +610,24 @@ def main_firehose(args, ranks, la):
             if not v:
                 bad.append((k, i))
     ops.Close()
+    # a format that has items but no verified output (its reference library is not built here) fails the gate: "nothing compared" is not "identical"
+    unverified = [k for k in counts if counts[k] and args.verify > 0 and not verified[k]]
+    for k in unverified:
+        bad.append((k, "no output of this format could be verified"))
     gate = ranks.all_gather_ints([sum(verified.values()), len(bad), sum(ok.values())])
     if rank == 0:
         n = args.batch * world * args.steps
         mb_in = sum(len(d) for _, d in items) / 1e6
-        out = {"metric": "images/sec (mixed-format firehose, sides 512-4096 px -> 256x256 JPEG q85)", "value": round(n / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        out = {"metric": "images/sec (mixed-format firehose, sides 512-%d px -> 256x256 JPEG q85)" % args.max_side, "value": round(n / elapsed, 2), "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[4] in miniature: %d items per GPU and step, JPEG 70 / PNG 15 / WebP 10 / handed-over decoded frames (stand-in for AVIF) 5 %%, "
-                                      "sides log-uniform 512-4096 px (every second source 4:3), %d distinct sources per format -> 256x256 JPEG q85, ImageOpsFit; "
-                                      "lilliput_hip_node_transform, host bytes in -> host bytes out" % (args.batch, per_kind),
+               "config": {"workload": "BASELINE configs[4]%s: %d items per GPU and step, JPEG 70 / PNG 15 / WebP 10 / handed-over decoded frames 5 %% (they stand in for AVIF: the AV1 decode is a host "
+                                      "feeder by design, and the reference's libavif.a does not link in this mount -- libaom.a is among its missing blobs), "
+                                      "sides log-uniform 512-%d px (every second source 4:3), %d distinct sources per format -> 256x256 JPEG q85, ImageOpsFit; "
+                                      "lilliput_hip_node_transform, host bytes in -> host bytes out%s" % (
+                                          "" if args.batch >= 100000 and args.max_side >= 8192 else " in miniature", args.batch, args.max_side, per_kind,
+                                          "" if window == args.batch else ", streamed in windows of %d items (bounded memory: one window's item array and destination buffers)" % window),
+                          "items_per_s_per_format": {k: round(counts[k] * args.steps * world / elapsed, 1) for k in counts},
                           "items_per_format": counts, "ok_per_format": ok, "input_MB_per_step": round(mb_in, 1),
                           "verified_outputs_per_format": verified, "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
                           "verified_against": "oracle.transform_any_to_jpeg (reference libjpeg-turbo / libpng / libwebp decode -> INTER_AREA restatement -> libjpeg-turbo encode); bytes, or "
@@ -632,6 +668,8 @@ def main():
                          "service that reads its network bytes into pinned memory has -- the DMA engine reads them in place, no host copy (zero-copy); pageable = "
                          "the caller's ordinary buffers, memcpy'd through the engines' pinned slots (the round-2 pipeline); register = pageable buffers whose "
                          "pages are registered per call (opt-in: slower than the copy on this driver); staged = force the slot route whatever the memory")
+    ap.add_argument("--max-side", type=int, default=4096, help="--workload firehose: largest source side (BASELINE configs[4] says 8192)")
+    ap.add_argument("--window", type=int, default=0, help="--workload firehose: stream the step's items through lilliput_hip_node_transform in windows of this many (0 = one call)")
     ap.add_argument("--threads", default="64", help="--workload abi: concurrent caller threads, or a comma list (1,8,64,256: one measurement each)")
     ap.add_argument("--workload", choices=["jpeg4096", "firehose", "abi", "png2webp", "animated"], default="jpeg4096",
                     help="jpeg4096 = BASELINE configs[1], the headline metric (default); firehose = BASELINE configs[4] in miniature: a mixed-format stream (JPEG 70 / PNG 15 / "

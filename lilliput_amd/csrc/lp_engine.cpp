@@ -51,8 +51,14 @@ struct LpRuntimeEnv {
 namespace {
 struct Retired {
     std::mutex mu;
-    std::vector<void*> dev, host;
+    std::vector<std::pair<int, void*>> dev, host; // (owning device, block): the list is process-wide, engines of several devices feed it
 };
+int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d;
+}
 Retired& retired()
 {
     static Retired* r = new Retired(); // never destroyed: engines may be torn down from atexit handlers
@@ -63,7 +69,7 @@ size_t grown(size_t cap, size_t bytes) { return lp_guard_on() ? bytes : std::max
 }
 void lp_retired_collect()
 {
-    std::vector<void*> d, h;
+    std::vector<std::pair<int, void*>> d, h;
     {
         Retired& r = retired();
         std::lock_guard<std::mutex> lk(r.mu);
@@ -71,9 +77,19 @@ void lp_retired_collect()
         h.swap(r.host);
     }
     if (d.empty() && h.empty()) return;
-    (void)hipDeviceSynchronize(); // whatever was enqueued against the old blocks has run
-    for (void* p : d) lp_dev_free(p);
-    for (void* p : h) lp_pinned_free(p);
+    // every device that owns a block is synchronised before its blocks go: whatever was enqueued against them has run (the list is
+    // process-wide; round 3 synchronised only the caller's current device and relied on hipFree doing the rest)
+    const int prev = current_device();
+    std::vector<int> devs;
+    for (auto& e : d) if (std::find(devs.begin(), devs.end(), e.first) == devs.end()) devs.push_back(e.first);
+    for (auto& e : h) if (std::find(devs.begin(), devs.end(), e.first) == devs.end()) devs.push_back(e.first);
+    for (int dev : devs) {
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipDeviceSynchronize();
+        for (auto& e : d) if (e.first == dev) lp_dev_free(e.second);
+        for (auto& e : h) if (e.first == dev) lp_pinned_free(e.second);
+    }
+    (void)hipSetDevice(prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,7 +178,7 @@ bool LpDevBuf::ensure(size_t bytes)
     if (p) {
         Retired& r = retired();
         std::lock_guard<std::mutex> lk(r.mu);
-        r.dev.push_back(p);
+        r.dev.emplace_back(current_device(), p);
     }
     p = np;
     cap = want;
@@ -178,7 +194,7 @@ bool LpPinned::ensure(size_t bytes)
     if (p) { // kernels read and write these blocks through their device alias
         Retired& r = retired();
         std::lock_guard<std::mutex> lk(r.mu);
-        r.host.push_back(p);
+        r.host.emplace_back(current_device(), p);
     }
     p = np;
     if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) dev = p; // unified addressing: the same pointer
@@ -204,6 +220,13 @@ LpEngine::LpEngine(int device) : device_(device)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { err_ = "no HIP device visible"; return; }
     if (device_ < 0 || device_ >= n) { err_ = "HIP device index out of range"; return; }
     if (!check(hipSetDevice(device_), "hipSetDevice")) return;
+    {   // LILLIPUT_HIP_BLOCKING_SYNC=1: host threads that wait for the device sleep instead of spinning (hipDeviceScheduleBlockingSync). A spin
+        // costs nothing on a host with idle cores and a whole CPU per waiting caller inside a CPU quota (profiles/r04_a_service.md)
+        static const bool blocking = getenv("LILLIPUT_HIP_BLOCKING_SYNC") && atoi(getenv("LILLIPUT_HIP_BLOCKING_SYNC")) != 0;
+        static std::atomic<uint64_t> done_mask{0};
+        if (blocking && device_ < 64 && !(done_mask.fetch_or(1ull << device_) & (1ull << device_)))
+            if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+    }
     if (!check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
     if (!check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto& e : ev_)

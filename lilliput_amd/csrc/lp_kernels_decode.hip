@@ -546,11 +546,7 @@ struct DevSink {
         asm volatile("" :: "v"(where), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
 #endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
-#ifdef LP_SLOT_DWORD_ROWS
-            const uint32_t nat = (((uint32_t)where >> 8) << 2) | (where & 3u);
-#else
             const uint32_t nat = (((uint32_t)where >> 10) << 4) | (where & 15u);
-#endif
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
             // A settled decode hands out at most one slot per block. A pass over UNSETTLED exit states (the deferred chunk whose verify
             // rounds were not enough: it is decoded again afterwards) lets subsequences overlap, so more slots than blocks can be asked
@@ -603,17 +599,9 @@ struct DevSink {
             const uint32_t e = i + (lane >> 2);
             if (e < n) {
                 const uint32_t ent = qlist[e], c = lane & 3u;
-#ifdef LP_SLOT_DWORD_ROWS
-                // dword rows: coefficient dword d of lane L at wslots + d * 256 + L * 4; this lane moves dwords 4c .. 4c + 3 of the listed
-                // lane's block: two ds_read2st64_b32 (rows d, d + 1: 256 bytes = 64 dwords apart), two ds_write2st64_b32 of zeros
-                uint32_t* s = reinterpret_cast<uint32_t*>(wslots + (c << 10) + ((ent & 63u) << 2));
-                const uint4 r = make_uint4(s[0], s[64], s[128], s[192]);
-                s[0] = 0; s[64] = 0; s[128] = 0; s[192] = 0;
-#else
                 uint4* s = reinterpret_cast<uint4*>(wslots + (c << 10) + ((ent & 63u) << 4));
                 const uint4 r = *s;
                 *s = make_uint4(0, 0, 0, 0);
-#endif
                 // streaming store: the block is written once and read once by k_idct; a regular store write-allocates the line
                 // (PMC: 33 MB fetched per image by a kernel that reads 4 MB)
                 __builtin_nontemporal_store((u32x4){r.x, r.y, r.z, r.w}, reinterpret_cast<u32x4*>(coef8 + ((size_t)(ent >> 6) << 6) + (c << 4)));
@@ -653,11 +641,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
         // blocks are stored transposed (column-major) for k_idct's column pass
         if (threadIdx.x < 80) {
             const uint32_t nat = ((zz[threadIdx.x] & 7u) << 3) | (zz[threadIdx.x] >> 3);
-#ifdef LP_SLOT_DWORD_ROWS
-            s_zz[threadIdx.x] = (uint16_t)(((nat >> 2) << 8) | (nat & 3u)); // dword row nat / 4 (256 bytes per row: 64 lanes x 4 B), byte nat % 4 of the lane's dword
-#else
             s_zz[threadIdx.x] = (uint16_t)(((nat >> 4) << 10) | (nat & 15u)); // where DevSink::put stores it, relative to the lane's slot
-#endif
         }
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
         for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
@@ -681,11 +665,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     DevSink sink;
     sink.wslots = s_slots + (threadIdx.x >> 6) * 4096;
     sink.lane = threadIdx.x & 63;
-#ifdef LP_SLOT_DWORD_ROWS
-    sink.slot = sink.wslots + sink.lane * 4;
-#else
     sink.slot = sink.wslots + sink.lane * 16;
-#endif
     sink.qlist = s_qlist + (threadIdx.x >> 6) * 64;
     sink.qbc = 0xffffffffu;
     sink.coef8 = coef8_arena + img.coef_off;

@@ -834,8 +834,9 @@ __device__ __forceinline__ uint32_t png_byte(const uint32_t (&w)[4], int i) { re
 // run as ONE diagonal across the whole pass: band b + 1 starts as soon as band b's last row has produced its first chunks. That row's
 // output is read back from memory by lane 0 of the band below; the writer publishes its progress (count of finished chunks, tagged
 // with the band number) every PNG_PUB chunks behind an agent-scope release fence. The only waits in the kernel go from a band to the
-// band ABOVE it, and workgroups are dispatched in index order, so the band above is always running or done; a spin that does not end
-// (it cannot, short of a lost device) gives up after PNG_SPIN_MAX polls and flags the image as failed instead of hanging the queue.
+// band ABOVE it; with LP_PNG_WGS = 1 (lp_types.h) that band runs on a wave of the same workgroup, which is resident whenever the waiting
+// wave is; a spin that does not end (it cannot, short of a lost device) gives up after PNG_SPIN_MAX polls and flags the image as
+// failed instead of hanging the queue. A progress slot is reused LP_PNG_SLOTS bands later, more bands than can be in flight at once.
 // Round 2 ran the bands one after the other in a single wave: rows / 64 x (chunks + 63) steps for a pass, ~0.6 - 1 GB/s; one workgroup
 // of sixteen waves pipelined this way reaches 3.5 GB/s (one CU's issue rate), eight of them share the pass.
 #define PNG_WAVES 16

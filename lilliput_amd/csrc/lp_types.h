@@ -272,8 +272,15 @@ struct LpGifEncOp {
 
 // One PNG image on the device: `data_off` holds the inflated stream (per Adam7 pass, per row: filter byte + packed row);
 // k_png_unfilter reconstructs it in place, k_png_convert expands it to the 8-bit BGR(A) / grey frame OpenCV's PngDecoder yields.
-#define LP_PNG_WGS 8            // workgroups of 16 waves that share one Adam7 pass (one band of 64 rows per wave at a time)
-#define LP_PNG_SLOTS (2 * LP_PNG_WGS * 16)
+#ifndef LP_PNG_WGS
+#define LP_PNG_WGS 1            // workgroups of 16 waves that share one Adam7 pass (one band of 64 rows per wave at a time). ONE since round 4: a band
+                                // waits for the band above, and with several workgroups per pass that band may sit in a workgroup of a HIGHER
+                                // index (band 128 on workgroup 0 waits for band 127 on workgroup 7) which a busy device has not dispatched yet --
+                                // forward progress then hangs on co-residency. Inside one workgroup every wave the kernel waits for is resident
+                                // by construction. The pass is one dependency diagonal: about (chunks + 63) / 64 bands are in flight at a time
+                                // (17 for a 4096-pixel RGBA row), which sixteen waves cover; eight workgroups measured the same 3.5 GB/s (r03)
+#endif
+#define LP_PNG_SLOTS (2 * 16 * (LP_PNG_WGS > 2 ? LP_PNG_WGS : 2))  // progress words per pass: more than the bands that can be in flight at once (16 per workgroup)
 #define LP_PNG_SYNC_BYTES (7 * LP_PNG_SLOTS * 8)
 struct LpPngPass {
     uint64_t off;               // byte offset of the pass inside the inflated stream

@@ -72,10 +72,9 @@ def test_every_item_of_a_mixed_stream_matches_the_reference_path(hip_lib, oracle
         res = b.transform(datas[:24], 200, 120, quality=70, dst_cap=512 << 10)
         for i, (k, d) in enumerate(mix[:24]):
             assert res[i].status == 0, (i, k)
-            exp = oracle.transform_any_to_jpeg(d, 200, 120, 70)
-            if res[i].data != exp:
-                a, e = oracle.jpeg_decode(res[i].data), oracle.jpeg_decode(exp)
-                assert a.shape == e.shape and np.abs(a.astype(int) - e.astype(int)).max() <= 8, (i, k)  # +-1 LSB before a q70 encoder
+            # the reference path's bytes, or a pre-encode frame within +-1 LSB of the oracle's that the output encodes byte-exactly (the rule of
+            # the bench's gate; round 3 compared decoded thumbnails to within 8 here)
+            assert bench.firehose_check(la, oracle, ops, d, res[i].data, 200, 70, height=120), (i, k)
     finally:
         ops.Close()
         b.close()

@@ -134,6 +134,44 @@ def test_pixels_match_reference_live_and_thumbhash(hip_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_tall_and_long_chained_images_unfilter_like_libpng(hip_lib, oracle):
+    """Images whose un-filter is one long dependency chain (every row filtered Up, Average or Paeth: no None / Sub row cuts it) and
+    whose band count exceeds the progress slots of the kernel several times over (20 000 rows = 313 bands of 64): ADVICE r03 -- a
+    band's progress slot is reused LP_PNG_SLOTS bands later and the waits must stay inside one workgroup."""
+    import struct
+    import zlib
+
+    if oracle.ref_png() is None:
+        pytest.skip("oracle/_ref/librefpng.so not built")
+    rng = np.random.default_rng(9)
+    for (w, h, ct, filt) in ((3, 20000, 2, 2), (5, 17001, 6, 4), (260, 4100, 2, 3), (1030, 700, 6, 4)):
+        cn = 3 if ct == 2 else 4
+        px = rng.integers(0, 256, (h, w * cn), dtype=np.uint8)
+        raw = bytearray()
+        prev = np.zeros(w * cn, np.int32)
+        for y in range(h):
+            cur = px[y].astype(np.int32)
+            if filt == 2:
+                f = (cur - prev) & 255
+            else:
+                left = np.concatenate([np.zeros(cn, np.int32), cur[:-cn]])
+                ul = np.concatenate([np.zeros(cn, np.int32), prev[:-cn]])
+                if filt == 3:
+                    f = (cur - ((left + prev) >> 1)) & 255
+                else:
+                    p0 = left + prev - ul
+                    pa, pb, pc = np.abs(p0 - left), np.abs(p0 - prev), np.abs(p0 - ul)
+                    pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+                    f = (cur - pred) & 255
+            raw += bytes([filt]) + f.astype(np.uint8).tobytes()
+            prev = cur
+        data = png_cases.SIG + png_cases.chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ct, 0, 0, 0)) + png_cases.chunk(b"IDAT", zlib.compress(bytes(raw), 1)) + png_cases.chunk(b"IEND", b"")
+        ref, mine = oracle.ref_png_decode(data), _decode(hip_lib, data)
+        assert ref is not None and mine is not None, (w, h, ct, filt)
+        assert np.array_equal(ref, mine), (w, h, ct, filt)
+
+
+@pytest.mark.gpu
 def test_png_to_jpeg_transform_and_batch(hip_lib, oracle, fixture_bytes):
     import lilliput_amd as la
 
