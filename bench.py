@@ -130,7 +130,7 @@ def cpu_baseline(sample, out_w=256, out_h=256, quality=85, budget_s=10.0, what="
             "scaling_efficiency_is": "value / (usable_cpus x one_core): usable_cpus = min(physical cores, the container's cgroup CPU quota)",
             "runs_by_threads": {str(k): v for k, v in runs.items()},
             "harness": "oracle/cpu_path.c: pthreads, one preallocated frame-buffer set per worker, one atomic job counter, timed between barriers",
-            "first_output_equals_python_oracle": checked,
+            "first_output_equals_python_oracle": checked, "failed_transforms": runs[best]["jobs"] - runs[best]["ok"],
             "sample": "%d transforms of %s (%d distinct sources of the timed workload, cycled) on %d threads in %.1fs; one thread alone: %.2f images/s" % (
                 runs[best]["jobs"], what, len(sample), best, runs[best]["seconds"], one)}
 

@@ -108,7 +108,7 @@ long lo_path_transform(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t
     } else if (n >= 12 && !memcmp(d, "RIFF", 4) && !memcmp(d + 8, "WEBP", 4)) {
         uint32_t inf[8];
         int meta[8];
-        if (!cfg->dec_webp || !cfg->info_webp || cfg->info_webp(d, n, inf)) return -2;
+        if (!cfg->dec_webp || !cfg->info_webp || cfg->info_webp(d, n, inf) != 1) return -2; /* ref_webp_info: 1 = webp_decoder_create would succeed */
         if (need(&s->frame, &s->frame_cap, (size_t)inf[0] * inf[1] * 4 + 16)) return -4;
         if (cfg->dec_webp(d, n, 1, s->frame, s->frame_cap, meta) < 0) return -2;
         w = meta[0]; h = meta[1]; cn = meta[2];
