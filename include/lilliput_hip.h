@@ -328,6 +328,12 @@ void lilliput_hip_batch_destroy(lilliput_hip_batch b);
  * the device work: per engine a stager thread walks the headers of chunk k + 1, copies its entropy-coded bytes into pinned memory
  * and enqueues the H2D copy on a copy stream while chunk k is decoded. Returns the number of failed items. */
 int lilliput_hip_batch_transform(lilliput_hip_batch b, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt);
+/* ONE image, from any thread, through the process-wide dispatchers that turn concurrent calls into shared batch launches
+ * (lilliput_amd/csrc/lp_coalesce.h): what a Go build's ImageOps.Transform calls for a static source with JPEG output when the
+ * service runs one ImageOps per goroutine (README.md:82-85). Blocks until the item is done; returns its LILLIPUT_*
+ * status, *dst_len = bytes written. Same results as n such items in one lilliput_hip_batch_transform. Part C's
+ * lilliput_image_ops_transform takes this route by itself once LILLIPUT_HIP_COALESCE (3) calls are in flight. */
+int lilliput_hip_transform_one(int device, const void* src, size_t src_len, const lilliput_batch_options* opt, void* dst, size_t dst_cap, size_t* dst_len);
 /* Of the last transform: out[0] entropy-coded bytes that reached the device, out[1] host ms the ingest threads spent (header walk,
  * registration, staging copies, copy enqueue; summed over the threads), out[2] ms the compute threads waited for a chunk, out[3] wall
  * ms of the call. ingest_stats2 adds: out[4] bytes that were copied through the engines' pinned slots (a host memcpy each), out[5]

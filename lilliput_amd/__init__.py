@@ -29,4 +29,5 @@ from .binding import (  # noqa: F401
     lib_path,
     parse_raw_frames,
     service_sim,
+    transform_one,
 )

@@ -544,3 +544,17 @@ def service_sim(sources, threads, jobs, width=256, height=256, quality=85, resiz
                                      C.byref(secs), C.byref(err), keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None, lat.ctypes.data)
     outs = [keep_buf[k * keep_cap: k * keep_cap + keep_len[k]].tobytes() if keep and 0 < keep_len[k] <= keep_cap else None for k in range(n)]
     return {"seconds": secs.value, "ok": int(ok), "jobs": int(jobs), "first_error": err.value, "outputs": outs, "latency_ms": lat[:jobs]}
+
+
+def transform_one(data, width, height, method=ImageOpsFit, normalize=False, quality=85, device=0, dst_cap=1 << 20, progressive=False):
+    """lilliput_hip_transform_one: one image through the process-wide dispatchers (calls in flight at once share batch launches)."""
+    L = lib()
+    L.lilliput_hip_transform_one.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(_BatchOptions), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    dst = np.empty(dst_cap, dtype=np.uint8)
+    o = _BatchOptions(width, height, method, int(bool(normalize)), quality, 0, int(bool(progressive)))
+    n = C.c_size_t(0)
+    rc = L.lilliput_hip_transform_one(int(device), src.ctypes.data, src.size, C.byref(o), dst.ctypes.data, dst_cap, C.byref(n))
+    if rc:
+        raise LilliputError(rc, "transform_one")
+    return dst[: n.value].tobytes()

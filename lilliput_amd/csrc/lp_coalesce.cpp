@@ -178,15 +178,16 @@ bool lp_coalesce_wanted(int in_flight)
     return t > 0 && !t_suppress && in_flight >= t;
 }
 
-bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len)
+int lp_coalesce_transform_status(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len)
 {
+    *out_len = 0;
     Dispatch* D = dispatch_for(device);
-    if (!D) return false;
+    if (!D) return LILLIPUT_ERR_DEVICE;
     Req r;
     r.src = src; r.len = len; r.dst = dst; r.cap = cap; r.opt = opt;
     {
         std::lock_guard<std::mutex> lk(D->mu);
-        if (D->stop) return false;
+        if (D->stop) return LILLIPUT_ERR_DEVICE;
         D->q.push_back(&r);
     }
     D->cv.notify_one();
@@ -194,7 +195,24 @@ bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, s
         std::unique_lock<std::mutex> lk(r.mu);
         r.cv.wait(lk, [&] { return r.done; });
     }
-    if (r.status != LILLIPUT_OK) return false;
-    *out_len = r.out_len;
-    return true;
+    if (r.status == LILLIPUT_OK) *out_len = r.out_len;
+    return r.status;
+}
+
+bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len)
+{
+    return lp_coalesce_transform_status(device, src, len, dst, cap, opt, out_len) == LILLIPUT_OK;
+}
+
+// Part B: one image through the shared dispatchers, whatever the number of calls in flight -- the entry point a Go build's Transform
+// calls for a static source with JPEG output. The answer is the batched path's for that item.
+extern "C" int lilliput_hip_transform_one(int device, const void* src, size_t src_len, const lilliput_batch_options* opt, void* dst, size_t dst_cap, size_t* dst_len)
+{
+    size_t n = 0;
+    if (dst_len) *dst_len = 0;
+    if (!src || !src_len || !opt || !dst || !dst_cap) return LILLIPUT_ERR_INVALID_IMAGE;
+    if (t_suppress) return LILLIPUT_ERR_DEVICE; // called from inside a batch: it would wait for itself
+    const int rc = lp_coalesce_transform_status(device, src, src_len, dst, dst_cap, *opt, &n);
+    if (dst_len) *dst_len = n;
+    return rc;
 }

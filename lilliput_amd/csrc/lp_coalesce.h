@@ -30,6 +30,8 @@ bool lp_coalesce_wanted(int in_flight);
 // Hands one request over and waits for it. Returns true when the batched path served it (LILLIPUT_OK, *out_len set); false = take the
 // direct route (not served, failed, or no device).
 bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len);
+// The same with the batch item's own status (LILLIPUT_*) as the answer: what lilliput_hip_transform_one returns.
+int lp_coalesce_transform_status(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len);
 // Transform calls made from inside a batch (its workers for non-JPEG items, its retry of short streams) must never queue behind the
 // batch that issued them: a scope of this suppresses coalescing on the calling thread.
 struct LpCoalesceSuppress { LpCoalesceSuppress(); ~LpCoalesceSuppress(); int prev; };

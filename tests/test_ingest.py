@@ -287,3 +287,45 @@ def test_webp_canvas_size_is_untrusted(hip_lib, small_set):
         assert rss1 - rss0 < (512 << 10), (rss0, rss1)  # KiB: 17 x 1 GB canvases would show
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+def test_transform_one_from_many_threads_shares_launches_and_keeps_the_bytes(hip_lib, oracle, fixture_bytes):
+    """lilliput_hip_transform_one (Part B; lp_coalesce.h): 48 threads, each one image at a time through the process-wide dispatchers --
+    what a Go service with one ImageOps per goroutine does (README.md:82-85). Every answer is the reference CPU path's bytes (integer
+    scale) or passes the frame-level rule; errors come back per item."""
+    import lilliput_amd as la
+
+    names = ["large-sunrise.jpg", "coast.jpg", "field.jpg", "sunrise.jpg", "firefox-gray.jpg"]
+    want = {n: oracle.transform_jpeg_thumbnail(fixture_bytes[n], 50, 50, 85) for n in names}
+    outs, errs = {}, []
+
+    def work(i):
+        try:
+            for k in range(3):
+                n = names[(i + k) % len(names)]
+                outs[(i, k)] = (n, la.transform_one(fixture_bytes[n], 50, 50, quality=85))
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(48)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]
+    assert len(outs) == 48 * 3
+    ops = la.ImageOps(2048)
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    seen = {}
+    for (i, k), (n, out) in outs.items():
+        if out != want[n] and (n, out) not in seen:
+            seen[(n, out)] = bench.firehose_check(la, oracle, ops, fixture_bytes[n], out, 50, 85)
+            assert seen[(n, out)], n
+    ops.Close()
+    with pytest.raises(la.LilliputError):
+        la.transform_one(b"\xff\xd8\xff\xe0 not a jpeg", 50, 50)
