@@ -78,6 +78,15 @@ def host_cores():
     return len(allowed), (len(phys) or len(allowed))
 
 
+def cgroup_cpu_stat():
+    """(CPU seconds this container has used, periods in which it was throttled) from cgroup v2 cpu.stat, or (None, None)."""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat") if len(line.split()) == 2)
+        return int(kv["usage_usec"]) * 1e-6, int(kv.get("nr_throttled", 0))
+    except Exception:
+        return None, None
+
+
 def cgroup_cpus():
     """CPUs' worth of time the container may use per second (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited. The gpurun boxes
     show 256 hardware threads and grant 16 (cpu.max = "1600000 100000", scripts/host_scale.cpp): every host-side figure measured there
@@ -248,6 +257,7 @@ def main_abi(args, ranks, la):
         for _ in range(args.warmup):
             la.service_sim(distinct, t, min(jobs, max(4 * t, 64)), args.out, args.out, 85, la.ImageOpsFit, keep=False)
         el, ok, lat, outs, err = 0.0, 0, [], None, 0
+        cpu0, thr0 = cgroup_cpu_stat()
         for k in range(args.steps):
             ranks.barrier()
             r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1))
@@ -256,6 +266,7 @@ def main_abi(args, ranks, la):
             err = err or r["first_error"]
             lat.append(r["latency_ms"])
             outs = r["outputs"] if r["outputs"][0] is not None else outs
+        cpu1, thr1 = cgroup_cpu_stat()
         el = ranks.reduce(el, "max")
         lat = np.concatenate(lat)
         v = jobs * args.steps * world / el
@@ -268,7 +279,9 @@ def main_abi(args, ranks, la):
             if outs is None or outs[i] != exp:
                 bad.append((t, i))
         by_threads[str(t)] = {"images_per_s": round(v, 1), "ok": ok, "requests": jobs * args.steps, "first_error": err, "latency_ms_p50": round(float(np.percentile(lat, 50)), 3),
-                              "latency_ms_p99": round(float(np.percentile(lat, 99)), 3), "verified": checked}
+                              "latency_ms_p99": round(float(np.percentile(lat, 99)), 3), "verified": checked,
+                              "host_cpu_ms_per_request": None if cpu0 is None else round(1e3 * (cpu1 - cpu0) / max(1, jobs * args.steps), 3),
+                              "host_cpus_busy": None if cpu0 is None else round((cpu1 - cpu0) / max(1e-9, el), 2), "throttled_periods": None if thr0 is None else thr1 - thr0}
         if v > best_v:
             best_t, best_v, best_elapsed = t, v, el
     import ctypes
@@ -420,6 +433,7 @@ def main_formats(args, ranks, la):
     for _ in range(args.warmup):
         sim(False)
     el, ok, outs, lat = 0.0, 0, None, []
+    cpu0, thr0 = cgroup_cpu_stat()
     for k in range(args.steps):
         ranks.barrier()
         r = sim(k == args.steps - 1)
@@ -427,6 +441,7 @@ def main_formats(args, ranks, la):
         ok += r["ok"]
         lat.append(r["latency_ms"])
         outs = r["outputs"] if r["outputs"][0] is not None else outs
+    cpu1, thr1 = cgroup_cpu_stat()
     el = ranks.reduce(el, "max")
     lat = np.concatenate(lat)
     units_per_req = sum(frames_of[j % len(srcs)] for j in range(jobs)) / jobs
@@ -479,6 +494,9 @@ def main_formats(args, ranks, la):
                "config": {"workload": "%s; %d requests per GPU and step from %d concurrent callers (one ImageOps each, NewDecoder -> Transform -> Close through Part C, lp_service_sim.c)" % (what, jobs, threads),
                           "threads": threads, "requests_per_s": round(jobs * args.steps * world / el, 2), "frames_per_request": round(units_per_req, 2), "ok_requests": ok,
                           "request_latency_ms_p50": round(float(np.percentile(lat, 50)), 3), "request_latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
+                          "host_cpu_ms_per_request": None if cpu0 is None else round(1e3 * (cpu1 - cpu0) / max(1, jobs * args.steps), 3),
+                          "host_cpus_busy": None if cpu0 is None else round((cpu1 - cpu0) / max(1e-9, el), 2), "cgroup_cpu_quota": cgroup_cpus(),
+                          "throttled_periods": None if thr0 is None else thr1 - thr0,
                           "output_bytes": [len(o) if o else None for o in (outs or [])],
                           "verified_identical": all(g[0] == 0 for g in gate) and all(g[1] == jobs * args.steps for g in gate),
                           "verified_against": "(i) the bytes of a serial Transform of the same source; (ii) every frame handed to the encoder against the reference CPU path (reference libpng / giflib + "

@@ -513,8 +513,17 @@ __global__ __launch_bounds__(256) void k_sub_scan(const LpJpeg* __restrict__ img
 // A finished block is only queued; flush() runs at wave-uniform points so that its loads/stores execute with many lanes
 // active instead of once per lane divergently. Blocks are stored in decode order: block n at coef8[n * 64], and TRANSPOSED
 // (element v * 8 + u holds the coefficient of row u, column v: the write kernel feeds put() a transposed zigzag table).
+// Bytes between the 16-byte chunks of a lane's slot. 1024 (= 64 lanes x 16 B) puts chunk c of every lane 256 dwords after chunk c - 1:
+// the four lanes that move one block in a flush (one chunk each) then hit the same banks, a 4-way conflict on every read and clear --
+// more than half of the kernel's LDS bank-conflict cycles (timing builds without the coefficient stores / without the flush:
+// 170 -> 132 / 78 M conflict cycles, profiles/r04_d_write_lds.md). One 16-byte pad per chunk row (LP_SLOT_STRIDE 1040) moves the four
+// lanes four banks apart.
+#ifndef LP_SLOT_STRIDE
+#define LP_SLOT_STRIDE 1040
+#endif
+#define LP_SLOT_WAVE_BYTES (4 * LP_SLOT_STRIDE)
 struct DevSink {
-    int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * 1024
+    int8_t* slot;           // LDS: this lane's bytes of chunk 0; chunk c at slot + c * LP_SLOT_STRIDE
     int8_t* wslots;         // LDS: the wave's slots (lane 0's chunk 0)
     uint32_t* qlist;        // LDS: the wave's list of finished blocks, (block << 6) | lane -- 64 entries
     uint32_t lane;
@@ -539,14 +548,14 @@ struct DevSink {
     }
     uint32_t blk0, last;    // first block of this lane, last block flushed (0xffffffff = none yet)
     __device__ __forceinline__ void put_dc(int32_t v, bool on) { dcv = on ? v : dcv; }
-    // where = the coefficient's byte offset inside the lane's slot: ((nat >> 4) << 10) | (nat & 15), precomputed per zigzag index (s_zz)
+    // where = the coefficient's byte offset inside the lane's slot: (nat >> 4) * LP_SLOT_STRIDE + (nat & 15), precomputed per zigzag index (s_zz)
     __device__ __forceinline__ void put(uint16_t where, int32_t v)
     {
 #ifdef LP_EXP_NOPUT
         asm volatile("" :: "v"(where), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
 #endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
-            const uint32_t nat = (((uint32_t)where >> 10) << 4) | (where & 15u);
+            const uint32_t nat = (((uint32_t)where / LP_SLOT_STRIDE) << 4) | (((uint32_t)where % LP_SLOT_STRIDE) & 15u);
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
             // A settled decode hands out at most one slot per block. A pass over UNSETTLED exit states (the deferred chunk whose verify
             // rounds were not enough: it is decoded again afterwards) lets subsequences overlap, so more slots than blocks can be asked
@@ -599,7 +608,7 @@ struct DevSink {
             const uint32_t e = i + (lane >> 2);
             if (e < n) {
                 const uint32_t ent = qlist[e], c = lane & 3u;
-                uint4* s = reinterpret_cast<uint4*>(wslots + (c << 10) + ((ent & 63u) << 4));
+                uint4* s = reinterpret_cast<uint4*>(wslots + c * LP_SLOT_STRIDE + ((ent & 63u) << 4));
                 const uint4 r = *s;
                 *s = make_uint4(0, 0, 0, 0);
                 // streaming store: the block is written once and read once by k_idct; a regular store write-allocates the line
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
     const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
-    __shared__ __attribute__((aligned(16))) int8_t s_slots[HUFF_T * 64];
+    __shared__ __attribute__((aligned(16))) int8_t s_slots[(HUFF_T / 64) * LP_SLOT_WAVE_BYTES];
     __shared__ uint16_t s_zz[80];
     __shared__ uint32_t s_qlist[HUFF_T];
     const LpJpeg& img = imgs[blockIdx.y];
@@ -641,10 +650,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
         // blocks are stored transposed (column-major) for k_idct's column pass
         if (threadIdx.x < 80) {
             const uint32_t nat = ((zz[threadIdx.x] & 7u) << 3) | (zz[threadIdx.x] >> 3);
-            s_zz[threadIdx.x] = (uint16_t)(((nat >> 4) << 10) | (nat & 15u)); // where DevSink::put stores it, relative to the lane's slot
+            s_zz[threadIdx.x] = (uint16_t)((nat >> 4) * LP_SLOT_STRIDE + (nat & 15u)); // where DevSink::put stores it, relative to the lane's slot
         }
         uint4* z4 = reinterpret_cast<uint4*>(s_slots);
-        for (uint32_t i = threadIdx.x; i < HUFF_T * 64 / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < (HUFF_T / 64) * LP_SLOT_WAVE_BYTES / 16; i += HUFF_T) z4[i] = make_uint4(0, 0, 0, 0);
     }
     stage_huff(s_hs4, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     uint32_t end_p = exits[g].p;
     if (idle) { entry.p = end_p = ic.total_bits; prefix.nblk = ic.total_blocks; }
     DevSink sink;
-    sink.wslots = s_slots + (threadIdx.x >> 6) * 4096;
+    sink.wslots = s_slots + (threadIdx.x >> 6) * LP_SLOT_WAVE_BYTES;
     sink.lane = threadIdx.x & 63;
     sink.slot = sink.wslots + sink.lane * 16;
     sink.qlist = s_qlist + (threadIdx.x >> 6) * 64;
