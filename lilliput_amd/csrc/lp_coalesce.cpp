@@ -130,8 +130,10 @@ struct Dispatch {
 // start -- 16 x 4.2 MB, 3 - 5 ms on the critical path of every dispatch. Instead every CALLER copies its own source into a pinned slot
 // before it queues the request (64 callers copy in parallel, off the dispatchers' path) and the batch reads it in place like any
 // pinned source (lp_hostmem.h). Slots are power-of-two sized arenas from lilliput_hip_host_alloc, kept on free lists per size class
-// and device, at most LILLIPUT_HIP_COALESCE_PINNED_MB (default 2048) in all; when the bound is reached, or for sources above 64 MiB,
-// the request goes in as it is.
+// and device, at most LILLIPUT_HIP_COALESCE_PINNED_MB in all; when the bound is reached, or for sources above 64 MiB, the request goes
+// in as it is. OFF by default (0): on the measurement boxes the container is granted 16 CPUs, and 64 / 256 callers copying 4.2 MB each
+// with plain memcpy cost more CPU time than the dispatchers' streaming-store stagers do for the same bytes -- 5.1 k / 6.1 k images/s
+// with the slots against 5.4 k / 9.3 k without (profiles/r04_a_service.md). For hosts with CPUs to spare.
 struct StagePool {
     std::mutex mu;
     std::map<std::pair<int, size_t>, std::vector<void*>> free_slots; // (device, class bytes) -> idle slots
@@ -142,7 +144,7 @@ StagePool& stage_pool()
     static StagePool* p = new StagePool(); // never destroyed (slots are given back to the runtime at exit by the registry's hook)
     return *p;
 }
-size_t stage_cap_bytes() { static const size_t v = (size_t)env_int("LILLIPUT_HIP_COALESCE_PINNED_MB", 2048, 0, 1 << 20) << 20; return v; }
+size_t stage_cap_bytes() { static const size_t v = (size_t)env_int("LILLIPUT_HIP_COALESCE_PINNED_MB", 0, 0, 1 << 20) << 20; return v; }
 size_t stage_class(size_t n) { size_t c = (size_t)256 << 10; while (c < n) c <<= 1; return c; }
 void* stage_acquire(int device, size_t len, size_t* cls)
 {

@@ -14,7 +14,8 @@
 //   LILLIPUT_HIP_COALESCE_WORKERS  = dispatcher threads per device (default 4)
 //   LILLIPUT_HIP_COALESCE_MAX      = requests per dispatch (default 32)
 //   LILLIPUT_HIP_COALESCE_IDLE_MS  = an idle dispatcher destroys its batch (engines, arenas) after this long (default 1000)
-//   LILLIPUT_HIP_COALESCE_PINNED_MB = pinned staging slots the callers copy their sources into before queueing (default 2048; 0 = none)
+//   LILLIPUT_HIP_COALESCE_PINNED_MB = pinned staging slots the callers copy their sources into before queueing (default 0 = none: measured a loss
+//                                    inside a 16-CPU container; for hosts with CPUs to spare)
 #pragma once
 #include <stddef.h>
 
