@@ -232,7 +232,17 @@ bool lp_mat_to_device(LpMat* m, LpEngine* eng)
         if (!m->dev) return false;
     }
     m->dev_step = rowb;
-    if (hipMemcpy2DAsync((uint8_t*)m->dev->p + m->dev_off, rowb, m->data, m->step, rowb, (size_t)m->rows, hipMemcpyHostToDevice, eng->stream()) != hipSuccess)
+    // rows that follow each other without a gap on both sides travel as ONE copy: the runtime executes a 2-D copy between pageable host
+    // memory and the device row by row (HIP API trace, profiles/r04_a_service.md: 300 transfers of 5 us for a 297-row frame, 16 ms per
+    // call with eight callers queueing behind each other)
+    if (m->step == rowb && need <= ((size_t)4 << 20)) { // small frames: through the engine's pinned buffers
+        if (!eng->upload_any((uint8_t*)m->dev->p + m->dev_off, m->data, need) || eng->sync()) return false;
+        m->dev_valid = true;
+        return true;
+    }
+    const hipError_t ce = m->step == rowb ? hipMemcpyAsync((uint8_t*)m->dev->p + m->dev_off, m->data, need, hipMemcpyHostToDevice, eng->stream())
+                                          : hipMemcpy2DAsync((uint8_t*)m->dev->p + m->dev_off, rowb, m->data, m->step, rowb, (size_t)m->rows, hipMemcpyHostToDevice, eng->stream());
+    if (ce != hipSuccess)
         return false;
     if (eng->sync()) return false;
     m->dev_valid = true;
@@ -260,8 +270,18 @@ static bool mat_copy_to_host(LpMat* m, LpEngine* eng)
 {
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     if (!m->dev || !rowb || !m->rows) return false;
-    if (hipMemcpy2DAsync(m->data, m->step, (uint8_t*)m->dev->p + m->dev_off, m->dev_step, rowb, (size_t)m->rows, hipMemcpyDeviceToHost, eng->stream()) !=
-        hipSuccess)
+    const bool flat = m->step == rowb && m->dev_step == rowb; // contiguous on both sides: one copy (see lp_mat_to_device)
+    const size_t all = rowb * (size_t)m->rows;
+    if (flat && all <= ((size_t)4 << 20)) { // small frames: through the engine's pinned buffer, not the runtime's pageable path
+        const uint8_t* got = eng->download_begin((uint8_t*)m->dev->p + m->dev_off, all);
+        if (!got || eng->sync() != LP_OK) return false;
+        memcpy(m->data, got, all);
+        m->host_stale = false;
+        return true;
+    }
+    const hipError_t ce = flat ? hipMemcpyAsync(m->data, (uint8_t*)m->dev->p + m->dev_off, all, hipMemcpyDeviceToHost, eng->stream())
+                               : hipMemcpy2DAsync(m->data, m->step, (uint8_t*)m->dev->p + m->dev_off, m->dev_step, rowb, (size_t)m->rows, hipMemcpyDeviceToHost, eng->stream());
+    if (ce != hipSuccess)
         return false;
     m->host_stale = false;
     return eng->sync() == LP_OK;

@@ -210,7 +210,7 @@ LpEngine::LpEngine(int device) : device_(device)
 #define LP_TAG(b) b.tag = #b
     LP_TAG(d_imgs_); LP_TAG(d_states_); LP_TAG(d_clean_); LP_TAG(d_rst_); LP_TAG(d_chunk_); LP_TAG(d_ckpt_); LP_TAG(d_exit_); LP_TAG(d_spec_exit_); LP_TAG(d_entry_);
     LP_TAG(d_tot_); LP_TAG(d_spec_tot_); LP_TAG(d_prefix_); LP_TAG(d_changed_); LP_TAG(d_coef_); LP_TAG(d_wide_); LP_TAG(d_wide_id_); LP_TAG(d_dc_); LP_TAG(d_dcpart_);
-    LP_TAG(d_planes_); LP_TAG(d_frames_desc_); LP_TAG(h_small_); LP_TAG(h_out_); LP_TAG(h_dstate_); LP_TAG(h_desc_); LP_TAG(d_pscans_); LP_TAG(d_pstreams_);
+    LP_TAG(d_planes_); LP_TAG(d_frames_desc_); LP_TAG(h_small_); LP_TAG(h_out_); LP_TAG(h_dstate_); LP_TAG(h_desc_); LP_TAG(h_xfer_in_); LP_TAG(h_xfer_out_); LP_TAG(d_pscans_); LP_TAG(d_pstreams_);
     LP_TAG(d_pstates_); LP_TAG(d_pcoef_); LP_TAG(heap_); LP_TAG(d_ops_); LP_TAG(d_taps_); LP_TAG(d_ranges_); LP_TAG(d_fops_); LP_TAG(d_aops_); LP_TAG(d_ataps_);
     LP_TAG(d_aranges_); LP_TAG(d_tone_); LP_TAG(d_jobs_); LP_TAG(d_estates_); LP_TAG(d_ecoef_); LP_TAG(d_blkbits_); LP_TAG(d_bits_); LP_TAG(d_hdrs_); LP_TAG(d_out_);
     LP_TAG(d_packed_); LP_TAG(d_pkoff_);
@@ -274,6 +274,25 @@ bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
     desc_used_ += need;
     lp_launch_copy_small(stream_, dst, static_cast<uint8_t*>(h_desc_.dev) + (stage - h_desc_.as<uint8_t>()), bytes);
     return true;
+}
+
+bool LpEngine::h2d_any(void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return true;
+    if (bytes <= (2u << 20)) return h2d_small(dst, src, bytes);
+    // the pinned buffer is reused by the next large transfer of this engine: wait for whatever still reads it
+    if (!check(hipStreamSynchronize(stream_), "transfer buffer sync")) return false;
+    if (!h_xfer_in_.ensure(bytes + 64)) { err_ = "pinned allocation failed"; return false; }
+    memcpy(h_xfer_in_.p, src, bytes);
+    return check(hipMemcpyAsync(dst, h_xfer_in_.p, bytes, hipMemcpyHostToDevice, stream_), "H2D (pinned transfer buffer)");
+}
+
+const uint8_t* LpEngine::d2h_begin(const void* dev, size_t bytes, size_t slot_off)
+{
+    if (!h_xfer_out_.ensure(slot_off + bytes + 64)) { err_ = "pinned allocation failed"; return nullptr; }
+    uint8_t* h = h_xfer_out_.as<uint8_t>() + slot_off;
+    if (!check(hipMemcpyAsync(h, dev, bytes, hipMemcpyDeviceToHost, stream_), "D2H (pinned transfer buffer)")) return nullptr;
+    return h;
 }
 
 // Small device -> pinned host download by a kernel (the counterpart of h2d_small); `host` lies inside the pinned buffer `pin`.
@@ -1084,11 +1103,11 @@ int LpEngine::orient(const LpOrientOp* ops, int n)
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    if (!d_ops_.ensure(std::max(sizeof(LpOrientOp), sizeof(LpResizeOp)) * (size_t)n)) return LP_ERR_DEVICE;
+    if (!d_ops_.ensure(std::max(sizeof(LpOrientOp), sizeof(LpResizeOp)) * (size_t)n + 64)) return LP_ERR_DEVICE;
     uint32_t mw = 0, mh = 0;
     double orient_bytes = 0;
     for (int i = 0; i < n; i++) { mw = std::max(mw, std::max(ops[i].src.w, ops[i].src.h)); mh = mw; orient_bytes += 2.0 * ops[i].src.w * ops[i].src.h * ops[i].src.cn; }
-    if (!check(hipMemcpyAsync(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D orient ops")) return LP_ERR_DEVICE;
+    if (!h2d_any(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n)) return LP_ERR_DEVICE;
     // the op array is pageable host memory: make sure the copy has been consumed before the caller frees it
     { LpStageProbe probe_(stream_, "k_orient", (double)(orient_bytes)); lp_launch_orient(stream_, d_ops_.as<LpOrientOp>(), (uint32_t)n, mw, mh, nullptr, nullptr); }
     if (!check(hipStreamSynchronize(stream_), "orient sync")) return LP_ERR_DEVICE;
@@ -1221,13 +1240,11 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
         mdw = std::max(mdw, r.dst_w);
         mdh = std::max(mdh, r.dst_h);
     }
-    if (!d_ops_.ensure(sizeof(LpResizeOp) * (size_t)n) || !d_taps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_ranges_.ensure(4 * ranges.size() + 64))
+    if (!d_ops_.ensure(sizeof(LpResizeOp) * (size_t)n + 64) || !d_taps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_ranges_.ensure(4 * ranges.size() + 64))
         return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n, hipMemcpyHostToDevice, stream_), "H2D resize ops")) return LP_ERR_DEVICE;
-    if (!taps.empty() && !check(hipMemcpyAsync(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size(), hipMemcpyHostToDevice, stream_), "H2D taps"))
-        return LP_ERR_DEVICE;
-    if (!ranges.empty() && !check(hipMemcpyAsync(d_ranges_.p, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, stream_), "H2D ranges"))
-        return LP_ERR_DEVICE;
+    if (!h2d_any(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n)) return LP_ERR_DEVICE;
+    if (!taps.empty() && !h2d_any(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size())) return LP_ERR_DEVICE;
+    if (!ranges.empty() && !h2d_any(d_ranges_.p, ranges.data(), 4 * ranges.size())) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventRecord(ev_[5], stream_);
     {
         double rb = 0;
@@ -1484,10 +1501,12 @@ int LpEngine::gather_samples(const LpFrame& f, const uint32_t* idx, uint32_t w, 
     const size_t ib = ((size_t)(w + h) * 4 + 255) & ~(size_t)255, ob = (size_t)w * h * f.cn;
     if (!d_ops_.ensure(ib + ob + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     uint8_t* base = d_ops_.as<uint8_t>();
-    if (!check(hipMemcpyAsync(base, idx, (size_t)(w + h) * 4, hipMemcpyHostToDevice, stream_), "H2D sample coordinates")) return LP_ERR_DEVICE;
+    if (!h2d_any(base, idx, (size_t)(w + h) * 4)) return LP_ERR_DEVICE;
     lp_launch_gather_samples(stream_, f, reinterpret_cast<const uint32_t*>(base), w, h, base + ib);
-    if (!check(hipMemcpyAsync(out, base + ib, ob, hipMemcpyDeviceToHost, stream_), "D2H samples")) return LP_ERR_DEVICE;
+    const uint8_t* got = d2h_begin(base + ib, ob);
+    if (!got) return LP_ERR_DEVICE;
     if (!check(hipStreamSynchronize(stream_), "gather sync")) return LP_ERR_DEVICE;
+    memcpy(out, got, ob);
     return check(hipGetLastError(), "gather kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
@@ -1501,15 +1520,18 @@ int LpEngine::webp_yuv420(const LpFrame& f, const LpWebpYuvTab& tab, uint8_t* y,
     uint8_t* base = d_ops_.as<uint8_t>();
     uint32_t* flag = h_small_.ensure(4096) ? h_small_.as<uint32_t>() : nullptr;
     if (!flag) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(base, &tab, sizeof(tab), hipMemcpyHostToDevice, stream_), "H2D webp tables")) return LP_ERR_DEVICE;
+    if (!h2d_any(base, &tab, sizeof(tab))) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(base + tab_b, 0, 256, stream_), "memset webp flag")) return LP_ERR_DEVICE;
     uint8_t *dy = base + tab_b + 256, *du = dy + y_b, *dv = du + c_b;
     { LpStageProbe probe_(stream_, "k_webp_yuv420", (double)((size_t)f.w * f.h * f.cn + yb + 2 * cb)); lp_launch_webp_yuv420(stream_, f, reinterpret_cast<const LpWebpYuvTab*>(base), dy, du, dv, reinterpret_cast<uint32_t*>(base + tab_b)); }
-    if (!check(hipMemcpyAsync(y, dy, yb, hipMemcpyDeviceToHost, stream_), "D2H Y plane")) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(u, du, cb, hipMemcpyDeviceToHost, stream_), "D2H U plane")) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(v, dv, cb, hipMemcpyDeviceToHost, stream_), "D2H V plane")) return LP_ERR_DEVICE;
+    // the three planes lie behind each other in the arena (256-byte aligned): one transfer into the pinned buffer, three memcpys out of it
+    const uint8_t* got = d2h_begin(dy, y_b + 2 * c_b);
+    if (!got) return LP_ERR_DEVICE;
     if (!check(hipMemcpyAsync(flag, base + tab_b, 4, hipMemcpyDeviceToHost, stream_), "D2H webp flag")) return LP_ERR_DEVICE;
     if (!check(hipStreamSynchronize(stream_), "webp yuv sync")) return LP_ERR_DEVICE;
+    memcpy(y, got, yb);
+    memcpy(u, got + y_b, cb);
+    memcpy(v, got + y_b + c_b, cb);
     *translucent = *flag != 0;
     return check(hipGetLastError(), "webp yuv kernel") ? LP_OK : LP_ERR_DEVICE;
 }
@@ -1521,8 +1543,8 @@ int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const ui
     const size_t pal_off = (n + 255) & ~(size_t)255;
     if (!d_planes_.ensure(pal_off + 1024 + 256 + LP_PNG_SYNC_BYTES)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     uint8_t* base = d_planes_.as<uint8_t>();
-    if (n && !check(hipMemcpyAsync(base, filtered, n, hipMemcpyHostToDevice, stream_), "H2D png data")) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D png palette")) return LP_ERR_DEVICE;
+    if (n && !h2d_any(base, filtered, n)) return LP_ERR_DEVICE;
+    if (!h2d_any(base + pal_off, palette_bgra, 1024)) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(base + pal_off + 1024, 0, 256 + LP_PNG_SYNC_BYTES, stream_), "memset png flag")) return LP_ERR_DEVICE; // the error flag and the un-filter kernel's progress words
     op.data_off = (uint64_t)(uintptr_t)base;
     op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
@@ -1551,8 +1573,10 @@ int LpEngine::png_filter(const LpFrame& src, uint32_t filters, uint8_t* out)
     op.out_off = (uint64_t)(uintptr_t)d_packed_.p;
     op.filters = filters;
     { LpStageProbe probe_(stream_, "k_png_filter", (double)((size_t)src.w * src.h * src.cn + n)); lp_launch_png_filter(stream_, op); }
-    if (!check(hipMemcpyAsync(out, d_packed_.p, n, hipMemcpyDeviceToHost, stream_), "D2H filtered rows")) return LP_ERR_DEVICE;
+    const uint8_t* got = d2h_begin(d_packed_.p, n);
+    if (!got) return LP_ERR_DEVICE;
     if (!check(hipStreamSynchronize(stream_), "png filter sync")) return LP_ERR_DEVICE;
+    memcpy(out, got, n);
     return check(hipGetLastError(), "png filter kernel") ? LP_OK : LP_ERR_DEVICE;
 }
 
@@ -1648,8 +1672,8 @@ int LpEngine::gif_frame(LpGifFrameOp op, const uint8_t* indices, size_t n_indice
     const size_t pal_off = (n_indices + 255) & ~(size_t)255;
     if (!d_ops_.ensure(pal_off + 1024)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     uint8_t* base = d_ops_.as<uint8_t>();
-    if (n_indices && !check(hipMemcpyAsync(base, indices, n_indices, hipMemcpyHostToDevice, stream_), "H2D gif indices")) return LP_ERR_DEVICE;
-    if (!check(hipMemcpyAsync(base + pal_off, palette_bgra, 1024, hipMemcpyHostToDevice, stream_), "H2D gif palette")) return LP_ERR_DEVICE;
+    if (n_indices && !h2d_any(base, indices, n_indices)) return LP_ERR_DEVICE;
+    if (!h2d_any(base + pal_off, palette_bgra, 1024)) return LP_ERR_DEVICE;
     op.index_off = (uint64_t)(uintptr_t)base;
     op.palette_off = (uint64_t)(uintptr_t)(base + pal_off);
     { LpStageProbe probe_(stream_, "k_gif_frame", (double)(n_indices + 2.0 * op.canvas.w * op.canvas.h * 4)); lp_launch_gif_frame(stream_, op); }

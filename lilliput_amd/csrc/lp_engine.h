@@ -221,6 +221,9 @@ public:
     // lossy WebP front end: the frame as Y (w x h), U, V ((w + 1) / 2 x (h + 1) / 2) planes into host memory; *translucent = some alpha below 255
     int webp_yuv420(const LpFrame& f, const LpWebpYuvTab& tab, uint8_t* y, uint8_t* u, uint8_t* v, bool* translucent);
     int sync();
+    // transfers between this engine's stream and host memory that may be pageable, through its pinned buffers (see h2d_any / d2h_begin)
+    bool upload_any(void* dst, const void* src, size_t bytes) { return h2d_any(dst, src, bytes); }
+    const uint8_t* download_begin(const void* dev, size_t bytes) { return d2h_begin(dev, bytes); }
     size_t device_bytes() const;                 // HBM held by this engine's grow-only arenas (the pool of the one-image ABI trims by it)
     const LpTimings& timings() const { return tm_; }
     void enable_timing(bool on) { timing_ = on; }
@@ -229,6 +232,12 @@ public:
 private:
     bool check(hipError_t e, const char* what);
     bool h2d_small(void* dst, const void* src, size_t bytes);
+    // Host -> device from memory that may be pageable, without the runtime's own pageable path (a staged, host-blocking copy behind a
+    // process-wide lock: 0.6 ms per call with eight callers, HIP API trace of round 4): small blocks through the descriptor ring
+    // (h2d_small), large ones through this engine's pinned transfer buffer. dst needs room for bytes rounded up to 16.
+    bool h2d_any(void* dst, const void* src, size_t bytes);
+    // Device -> pinned transfer buffer (asynchronous); the bytes are at the returned host pointer once the stream has been waited for.
+    const uint8_t* d2h_begin(const void* dev, size_t bytes, size_t slot_off = 0);
     void d2h_small(const LpPinned& pin, void* host, const void* dev, size_t bytes);
     int run_decode(int first, int n, LpFrame* frames, int* status, const uint8_t* want_frame, bool defer);
 
@@ -252,7 +261,7 @@ private:
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
     LpDevBuf d_imgs_, d_states_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
     LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_dcpart_, d_planes_, d_frames_desc_;
-    LpPinned h_small_, h_out_, h_dstate_, h_desc_;
+    LpPinned h_small_, h_out_, h_dstate_, h_desc_, h_xfer_in_, h_xfer_out_;
     size_t desc_used_ = 0;
     std::vector<uint32_t> h_pk_;                                    // slot offsets of the encoded streams in h_out_ (n + 1 entries)
     std::vector<std::pair<size_t, std::vector<uint8_t>>> h_big_;    // streams that outgrew their slot
