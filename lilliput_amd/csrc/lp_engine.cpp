@@ -248,6 +248,14 @@ LpEngine::~LpEngine()
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
 
+void LpEngine::mark(int i)
+{
+    if (!timing_) return;
+    static const bool drain = getenv("LILLIPUT_HIP_TIMING_SYNC") != nullptr && atoi(getenv("LILLIPUT_HIP_TIMING_SYNC")) != 0;
+    if (drain) (void)hipStreamSynchronize(stream_);
+    (void)hipEventRecord(ev_[i], stream_);
+}
+
 bool LpEngine::check(hipError_t e, const char* what)
 {
     if (e == hipSuccess) return true;
@@ -836,11 +844,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         (void)hipStreamSynchronize(stream_);
         fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
     };
-    if (timing_) (void)hipEventRecord(ev_[0], stream_);
+    mark(0);
     lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>());
     stage("unstuff");
-    if (timing_) (void)hipEventRecord(ev_[1], stream_);
+    mark(1);
     LpHuffArgs ha;
     ha.imgs = di; ha.states = ds; ha.huffs = u_->d_huffs.as<LpHuffSet>();
     ha.nimg = (uint32_t)n; ha.max_sub = max_sub_; ha.tot_sub = tot_sub_;
@@ -853,17 +861,17 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     ha.sched = sched_;
     lp_launch_huff_spec(stream_, ha);
     stage("huff_spec");
-    if (timing_) (void)hipEventRecord(ev_[8], stream_);
+    mark(8);
     // Verify rounds back to back, no host round trip in between: round r counts the exit states it moved into changed[r] and a
     // round that follows an idle one returns at once. The last counter is looked at when the decode is collected (finish_decode);
     // streams that need more than LP_VERIFY_ROUNDS rounds (tiny subsequences, hostile data) continue there under host control.
     if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (LP_VERIFY_ROUNDS + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
     for (uint32_t r = 0; r < LP_VERIFY_ROUNDS; r++) lp_launch_huff_verify(stream_, ha, r);
-    if (timing_) (void)hipEventRecord(ev_[9], stream_);
+    mark(9);
     stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
     stage("sub_scan");
-    if (timing_) (void)hipEventRecord(ev_[10], stream_);
+    mark(10);
     lp_launch_huff_write(stream_, ha);
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
@@ -901,11 +909,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
 #endif
         stage("prog_scans");
     }
-    if (timing_) (void)hipEventRecord(ev_[2], stream_);
+    mark(2);
     lp_launch_idct(stream_, di, ds, (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(), d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(),
                    (any_baseline ? 1u : 0u) | (pcoef_elems ? 2u : 0u), d_pcoef_.as<int16_t>());
     stage("idct");
-    if (timing_) (void)hipEventRecord(ev_[3], stream_);
+    mark(3);
     // frames
     for (int i = 0; i < n; i++) {
         const LpJpeg& j = h_imgs_[(size_t)i];
@@ -922,7 +930,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         if (!h2d_small(d_frames_desc_.p, frames, sizeof(LpFrame) * (size_t)n)) return LP_ERR_DEVICE;
         lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, any_generic, any_420, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
     }
-    if (timing_) (void)hipEventRecord(ev_[4], stream_);
+    mark(4);
     pend_ = Pending{true, first, n, nstreams, pcoef_elems, any_baseline, any_frame, any_generic, any_420, frames, ha};
     d2h_small(h_dstate_, h_dstate_.as<uint8_t>() + 64, ds, sizeof(LpJpegState) * (size_t)n);
     d2h_small(h_dstate_, h_dstate_.p, d_changed_.p, 4 * (LP_VERIFY_ROUNDS + 1));
@@ -1245,14 +1253,14 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     if (!h2d_any(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n)) return LP_ERR_DEVICE;
     if (!taps.empty() && !h2d_any(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size())) return LP_ERR_DEVICE;
     if (!ranges.empty() && !h2d_any(d_ranges_.p, ranges.data(), 4 * ranges.size())) return LP_ERR_DEVICE;
-    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    mark(5);
     {
         double rb = 0;
         for (int i = 0; i < n; i++) rb += (double)reqs[i].crop_w * reqs[i].crop_h * reqs[i].src.cn + (double)reqs[i].dst_w * reqs[i].dst_h * reqs[i].src.cn;
         LpStageProbe probe_(stream_, "k_resize_* (crop + INTER_AREA from a frame)", rb);
         lp_launch_resize(stream_, d_ops_.as<LpResizeOp>(), (uint32_t)n, modes & 15u, area3_mask, mdw, mdh, d_taps_.as<LpTap>(), d_ranges_.as<uint32_t>(), nullptr, nullptr);
     }
-    if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    mark(6);
     if (!check(hipStreamSynchronize(stream_), "resize sync")) return LP_ERR_DEVICE;
     if (!check(hipGetLastError(), "resize kernels")) return LP_ERR_DEVICE;
     if (timing_) (void)hipEventElapsedTime(&tm_.resize_ms, ev_[5], ev_[6]);
@@ -1298,9 +1306,9 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
         }
     }
     if (!h2d_small(d_fops_.p, ops.data(), sizeof(LpFusedOp) * (size_t)n)) return LP_ERR_DEVICE;
-    if (timing_) (void)hipEventRecord(ev_[11], stream_);
+    mark(11);
     lp_launch_resample_fused(stream_, d_imgs_.as<LpJpeg>(), d_fops_.as<LpFusedOp>(), (uint32_t)n, max_px, general, fast_mask, fast_grid, d_planes_.as<uint8_t>());
-    if (timing_) (void)hipEventRecord(ev_[7], stream_);
+    mark(7);
     // not waited for: the encode (or whatever reads the thumbnails next) is enqueued behind it; resample_ms() reads the events
     if (!check(hipGetLastError(), "fused resample kernel")) return LP_ERR_DEVICE;
     tm_.resize_ms = 0;
@@ -1390,10 +1398,10 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
     if (!h2d_small(d_aops_.p, ops.data(), sizeof(LpArea420Op) * (size_t)n) || !h2d_small(d_ataps_.p, taps.data(), sizeof(LpTap) * taps.size()) ||
         !h2d_small(d_aranges_.p, ranges.data(), 4 * ranges.size()))
         return LP_ERR_DEVICE;
-    if (timing_ && !(after_fused && fused_timed_)) (void)hipEventRecord(ev_[11], stream_); // behind a fused_resample: its start event stands
+    if (!(after_fused && fused_timed_)) mark(11); // behind a fused_resample: its start event stands
     lp_launch_area_420(stream_, d_imgs_.as<LpJpeg>(), d_aops_.as<LpArea420Op>(), (uint32_t)n, mask, mdw, mdh, d_ataps_.as<LpTap>(), d_aranges_.as<uint32_t>(),
                        d_planes_.as<uint8_t>());
-    if (timing_) (void)hipEventRecord(ev_[7], stream_);
+    mark(7);
     if (!check(hipGetLastError(), "area resample kernel")) return LP_ERR_DEVICE;
     tm_.resize_ms = 0;
     fused_timed_ = timing_;
@@ -1820,7 +1828,7 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         if (!check(hipStreamSynchronize(stream_), "fdct sync")) return LP_ERR_DEVICE;
         return check(hipGetLastError(), "fdct kernel") ? LP_OK : LP_ERR_DEVICE;
     }
-    if (timing_) (void)hipEventRecord(ev_[5], stream_);
+    mark(5);
     {
         double eb = 0;
         for (int i = 0; i < n; i++) eb += (double)h_jobs_[(size_t)i].src.w * h_jobs_[(size_t)i].src.h * h_jobs_[(size_t)i].src.cn * 1.1;
@@ -1828,7 +1836,7 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         lp_launch_encode(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, max_blocks, nullptr, d_ecoef_.as<int16_t>(),
                          d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
     }
-    if (timing_) (void)hipEventRecord(ev_[6], stream_);
+    mark(6);
     {   // results: every stream into its slot of the pinned output buffer (a slot bounds the usual size; a stream that outgrows it
         // is fetched from the output arena by encoded_fetch_all), and the states -- one wait for both
         std::vector<uint32_t>& pk = h_pk_;

@@ -227,6 +227,10 @@ public:
     size_t device_bytes() const;                 // HBM held by this engine's grow-only arenas (the pool of the one-image ABI trims by it)
     const LpTimings& timings() const { return tm_; }
     void enable_timing(bool on) { timing_ = on; }
+    // Stage timestamps (the durations bench.py's exclusive leg reads). LILLIPUT_HIP_TIMING_SYNC=1 drains the stream before every
+    // timestamp, so that a bracket holds exactly the kernels launched inside it and nothing of its neighbours' tails (A/B against the
+    // rocprofv3 kernel trace: profiles/r04_f_event_brackets.md).
+    void mark(int i);
     void set_timings(const LpTimings& t) { tm_ = t; }
 
 private:

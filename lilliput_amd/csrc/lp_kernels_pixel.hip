@@ -321,8 +321,13 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
 // h2v2_fancy_upsample (jdsample.c), then the horizontal half, YCbCr->BGR (jdcolor.c) and the integer box sums.
 // RWC = chroma columns per box (box width / 2). Requirements (checked by the host, LpFusedOp::fast): YCbCr 4:2:0,
 // box width in {8,16,32}, even box height, every box starts at a multiple of its width in x and at an even y.
+#ifdef LP_RESAMPLE_WPE // A/B: ask the register allocator for this many waves per SIMD
+#define LP_RESAMPLE_ATTR __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE_WPE)))
+#else
+#define LP_RESAMPLE_ATTR
+#endif
 template <int RWC>
-__global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+__global__ __launch_bounds__(256) LP_RESAMPLE_ATTR void k_resample_420(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
                                                       const uint8_t* __restrict__ plane_arena)
 {
     const LpFusedOp& op = ops[blockIdx.y];
@@ -378,9 +383,13 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
     uint32_t sb = 0, sg = 0, sr = 0;
     const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
     const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
+#if defined(LP_RESAMPLE_R03) || defined(LP_RESAMPLE_NOSDWA)
     auto sat_pk = [](uint32_t x) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x)); return d; }; // two signed halves -> two bytes clamped to 0..255
-    for (int32_t q = 0; q < nrows; q++) {
-        load_row(cy0 + q + 1, P[2]);
+#endif
+    // one step = two luma rows; A / B / C = the chroma rows above, at and below them. The three row buffers change roles from step to
+    // step (unrolled by three below) instead of being copied.
+    auto step = [&](const int32_t q, const uint32_t (&A)[RWC + 2], const uint32_t (&B)[RWC + 2], uint32_t (&C)[RWC + 2]) __attribute__((always_inline)) {
+        load_row(cy0 + q + 1, C);
         // luma rows 2q and 2q+1 of the box
         uint32_t ly[2][RWC / 2];
 #pragma unroll
@@ -401,21 +410,90 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
             // vertical pass: 3 * this row + the nearer neighbour row (above for the upper output row, below for the lower one)
             u16x2 V[RWC + 2];
 #pragma unroll
-            for (int i = 0; i < RWC + 2; i++) V[i] = pk(P[1][i]) * (u16x2){3, 3} + pk(P[rr ? 2 : 0][i]);
+            for (int i = 0; i < RWC + 2; i++) V[i] = pk(B[i]) * (u16x2){3, 3} + pk(rr ? C[i] : A[i]);
+#ifndef LP_RESAMPLE_R03
+            // jdcolor.c ycc_rgb_convert with the luma kept out of the 32-bit arithmetic: (Y << 16 + t) >> 16 == Y + (t >> 16) for any t, so a
+            // channel is Y + the upper half of its fixed-point chroma term (the -128 offsets folded into the constants). Each term is one
+            // v_dot2_u32_u16 over the {Cb, Cr} pair: FIX(1.772) = 2 * 58065 and FIX(1.402) = 3 * 30627, so with {2 Cb, 3 Cr} the 17-bit
+            // constants fit 16-bit operands; green: floor((KG - x) / 65536) == -floor((x + 65535 - KG) / 65536). Four pixels (two chroma
+            // columns = the four bytes of one luma word) per group: the 16-bit sums Y + term are formed by SDWA adds that read the luma
+            // byte and the term's upper half in place and write one half of a pair register, two pairs are clamped into the four bytes
+            // of one word (v_sat_pk_u8_i16, the second one into the upper half) and summed by one v_sad_u8.
+            static_assert(FIX16(1.77200) == 2 * 58065 && FIX16(1.40200) == 3 * 30627, "split of the colour constants");
+#pragma unroll
+            for (int i = 0; i < RWC; i += 2) {
+                uint32_t Tr[4], Tg[4], Tb[4];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    // horizontal pass: even output column leans on the left neighbour (+8), odd on the right one (+7)
+                    const u16x2 c3 = V[i + k + 1] * (u16x2){3, 3};
+                    const u16x2 H[2] = {(u16x2)((c3 + V[i + k] + (u16x2){8, 8}) >> (u16x2){4, 4}), (u16x2)((c3 + V[i + k + 2] + (u16x2){7, 7}) >> (u16x2){4, 4})};
+#pragma unroll
+                    for (int hx = 0; hx < 2; hx++) {
+                        const u16x2 hs = H[hx] * (u16x2){2, 3};
+                        Tr[2 * k + hx] = __builtin_amdgcn_udot2(hs, (u16x2){0, 30627}, (uint32_t)KR, false);
+                        Tb[2 * k + hx] = __builtin_amdgcn_udot2(hs, (u16x2){58065, 0}, (uint32_t)KB, false);
+                        Tg[2 * k + hx] = __builtin_amdgcn_udot2(H[hx], (u16x2){(unsigned short)FIX16(0.34414), (unsigned short)FIX16(0.71414)}, 65535u - (uint32_t)KG, false);
+                    }
+                }
+                const uint32_t y4 = ly[rr][i >> 1];
+#ifndef LP_RESAMPLE_NOSDWA
+                // One block so that every SDWA write of half a register is at least three instructions away from its reader (gfx940
+                // family: a destination-select write needs one wait state before a VALU read, and the compiler does not look inside).
+                uint32_t r0, r1, g0, g1, b0, b1;
+                asm("v_add_u16_sdwa %[r0], %[tr0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+                    "v_sub_u16_sdwa %[g0], %[y], %[tg0] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_1\n\t"
+                    "v_add_u16_sdwa %[b0], %[tb0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
+                    "v_add_u16_sdwa %[r1], %[tr2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+                    "v_sub_u16_sdwa %[g1], %[y], %[tg2] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_1\n\t"
+                    "v_add_u16_sdwa %[b1], %[tb2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
+                    "v_add_u16_sdwa %[r0], %[tr1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
+                    "v_sub_u16_sdwa %[g0], %[y], %[tg1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:WORD_1\n\t"
+                    "v_add_u16_sdwa %[b0], %[tb1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
+                    "v_add_u16_sdwa %[r1], %[tr3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
+                    "v_sub_u16_sdwa %[g1], %[y], %[tg3] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:WORD_1\n\t"
+                    "v_add_u16_sdwa %[b1], %[tb3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
+                    "v_sat_pk_u8_i16 %[r0], %[r0]\n\t"
+                    "v_sat_pk_u8_i16 %[g0], %[g0]\n\t"
+                    "v_sat_pk_u8_i16 %[b0], %[b0]\n\t"
+                    "v_sat_pk_u8_i16_sdwa %[r0], %[r1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                    "v_sat_pk_u8_i16_sdwa %[g0], %[g1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                    "v_sat_pk_u8_i16_sdwa %[b0], %[b1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+                    "v_sad_u8 %[sr], %[r0], 0, %[sr]\n\t"
+                    "v_sad_u8 %[sg], %[g0], 0, %[sg]\n\t"
+                    "v_sad_u8 %[sb], %[b0], 0, %[sb]"
+                    : [r0] "=&v"(r0), [r1] "=&v"(r1), [g0] "=&v"(g0), [g1] "=&v"(g1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+                      [sr] "+v"(sr), [sg] "+v"(sg), [sb] "+v"(sb)
+                    : [y] "v"(y4), [tr0] "v"(Tr[0]), [tr1] "v"(Tr[1]), [tr2] "v"(Tr[2]), [tr3] "v"(Tr[3]),
+                      [tg0] "v"(Tg[0]), [tg1] "v"(Tg[1]), [tg2] "v"(Tg[2]), [tg3] "v"(Tg[3]),
+                      [tb0] "v"(Tb[0]), [tb1] "v"(Tb[1]), [tb2] "v"(Tb[2]), [tb3] "v"(Tb[3]));
+#else
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const u16x2 yp = pk(__builtin_amdgcn_perm(0u, y4, 0x0c000c00u | ((uint32_t)(2 * k + 1) << 16) | (uint32_t)(2 * k)));
+                    const u16x2 pr = yp + pk(__builtin_amdgcn_perm(Tr[2 * k + 1], Tr[2 * k], 0x07060302u));
+                    const u16x2 pg = yp - pk(__builtin_amdgcn_perm(Tg[2 * k + 1], Tg[2 * k], 0x07060302u));
+                    const u16x2 pb = yp + pk(__builtin_amdgcn_perm(Tb[2 * k + 1], Tb[2 * k], 0x07060302u));
+                    sr = __builtin_amdgcn_sad_u8(sat_pk(__builtin_bit_cast(uint32_t, pr)), 0u, sr);
+                    sg = __builtin_amdgcn_sad_u8(sat_pk(__builtin_bit_cast(uint32_t, pg)), 0u, sg);
+                    sb = __builtin_amdgcn_sad_u8(sat_pk(__builtin_bit_cast(uint32_t, pb)), 0u, sb);
+                }
+#endif
+            }
+#else
 #pragma unroll
             for (int i = 0; i < RWC; i++) {
                 // horizontal pass: even output column leans on the left neighbour (+8), odd on the right one (+7)
                 const u16x2 c3 = V[i + 1] * (u16x2){3, 3};
-                const uint32_t H[2] = {__builtin_bit_cast(uint32_t, (u16x2)((c3 + V[i] + (u16x2){8, 8}) >> (u16x2){4, 4})),
-                                       __builtin_bit_cast(uint32_t, (u16x2)((c3 + V[i + 2] + (u16x2){7, 7}) >> (u16x2){4, 4}))};
+                const u16x2 H[2] = {(u16x2)((c3 + V[i] + (u16x2){8, 8}) >> (u16x2){4, 4}), (u16x2)((c3 + V[i + 2] + (u16x2){7, 7}) >> (u16x2){4, 4})};
                 uint32_t Tr[2], Tg[2], Tb[2];
 #pragma unroll
                 for (int hx = 0; hx < 2; hx++) {
-                    const int32_t cb = (int32_t)(H[hx] & 0xffffu), cr = (int32_t)(H[hx] >> 16);
+                    const uint32_t h = __builtin_bit_cast(uint32_t, H[hx]);
+                    const int32_t cb = (int32_t)(h & 0xffffu), cr = (int32_t)(h >> 16);
                     const int px = 2 * i + hx;
                     // the luma sample in bits 16..23: channel = (luma << 16 + fixed-point chroma term) >> 16, read off as the upper half
                     const uint32_t yk = __builtin_amdgcn_perm(0u, ly[rr][px >> 2], 0x0c000c0cu | ((uint32_t)(px & 3) << 16));
-                    // jdcolor.c ycc_rgb_convert with the -128 offsets folded into the rounding constants
                     Tr[hx] = (uint32_t)(FIX16(1.40200) * cr + (int32_t)(yk + (uint32_t)KR));
                     Tb[hx] = (uint32_t)(FIX16(1.77200) * cb + (int32_t)(yk + (uint32_t)KB));
                     Tg[hx] = (uint32_t)(-FIX16(0.34414) * cb - FIX16(0.71414) * cr + (int32_t)(yk + (uint32_t)KG));
@@ -425,10 +503,24 @@ __global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__
                 sg = __builtin_amdgcn_sad_u8(sat_pk(__builtin_amdgcn_perm(Tg[1], Tg[0], 0x07060302u)), 0u, sg);
                 sb = __builtin_amdgcn_sad_u8(sat_pk(__builtin_amdgcn_perm(Tb[1], Tb[0], 0x07060302u)), 0u, sb);
             }
+#endif
         }
+        asm volatile("" ::: "memory"); // keep the steps apart (no load of the next step is moved up): three steps' rows and luma words at once do not fit the register budget
+    };
+#ifdef LP_RESAMPLE_ROT3
+    int32_t q = 0;
+    for (; q + 3 <= nrows; q += 3) { step(q, P[0], P[1], P[2]); step(q + 1, P[1], P[2], P[0]); step(q + 2, P[2], P[0], P[1]); }
+    if (q < nrows) {
+        step(q, P[0], P[1], P[2]);
+        if (q + 1 < nrows) step(q + 1, P[1], P[2], P[0]);
+    }
+#else
+    for (int32_t q = 0; q < nrows; q++) {
+        step(q, P[0], P[1], P[2]);
 #pragma unroll
         for (int i = 0; i < RWC + 2; i++) { P[0][i] = P[1][i]; P[1][i] = P[2][i]; }
     }
+#endif
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
     const int32_t sums[3] = {(int32_t)sb, (int32_t)sg, (int32_t)sr};
 #pragma unroll

@@ -551,6 +551,33 @@ def _with_exif_orientation(jpeg, o):
     return jpeg[:2] + b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload + jpeg[2:]
 
 
+def test_fused_resample_saturated_colours(batch, oracle):
+    """k_resample_420's clamp: sources whose decoded Y'CbCr lands far outside the RGB cube in every direction (saturated primaries
+    and their complements in hard-edged patches, black / white, full-range noise on top; q40 rings on top of that), so that the
+    per-pixel clamp of jdcolor.c fires on a large share of the pixels of every box and in all three channels. Boxes of 8, 16 and 32
+    pixels (the three instances of the kernel), orientations 1 and 6. Byte-exact against decode -> crop -> box mean -> encode on the CPU."""
+    from PIL import Image
+
+    rng = np.random.default_rng(77)
+    pal = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255], [0, 0, 0], [255, 255, 255],
+                    [255, 128, 0], [0, 128, 255], [128, 0, 255], [16, 240, 16]], np.int32)
+    for q, cell, amp in ((40, 5, 60), (92, 3, 25), (75, 11, 120)):
+        idx = rng.integers(0, len(pal), (256 // cell + 1, 256 // cell + 1))
+        img = pal[np.kron(idx, np.ones((cell, cell), np.int64))[:256, :256]] + rng.integers(-amp, amp + 1, (256, 256, 3))
+        b = io.BytesIO()
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(b, "JPEG", quality=q, subsampling=2)
+        # how much the clamp matters on this source: share of decoded pixels with a channel at 0 or 255
+        dec = oracle.jpeg_decode(b.getvalue())
+        assert ((dec == 0) | (dec == 255)).any(axis=2).mean() > 0.2
+        for o in (1, 6):
+            d = _with_exif_orientation(b.getvalue(), o)
+            for t in (32, 16, 8):
+                r = batch.transform([d], t, t, normalize=False, quality=90)[0]
+                assert r.status == 0
+                frame = oracle.transform_static(oracle.jpeg_decode(d), o, t, t, oracle.FIT, False)
+                assert r.data == oracle.jpeg_encode(frame, 90), (q, cell, o, t)
+
+
 def test_fused_resample_all_orientations_integer_scales(batch, oracle):
     """The fused planes->thumbnail kernel (orientation + crop folded into addressing) against decode -> ExifTransform ->
     crop -> resizeAreaFast_ done step by step on the CPU. Bit-exact: integer sums, exact float scale."""
