@@ -890,6 +890,75 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
     }
 }
 
+// ---- the path almost every tile takes (no escape in the tile, 8-bit quantisation table): the same arithmetic with fewer instructions.
+// k_idct runs at the vector ALU's issue rate (profiles/r04_g: 612 G wave-instructions/s of 614), so its time is its instruction count.
+// * the 1-D transform takes tmp0 / tmp1 = (d0 +- d4) << 13 ready-made, with the pass's rounding constant already inside (every output is
+//   t1x +- odd part, and each t1x holds exactly one of the two): no add per output;
+// * column pass: a coefficient byte is sign-extended and multiplied by its quantiser in one SDWA multiply; d0 and d4 are multiplied by
+//   q << 13 directly (24-bit operands; the 32-bit result wraps exactly like the shift it replaces);
+// * row pass: (o + C) >> 18 is the upper half of the sum shifted right by two more bits -- the upper halves of two sums are taken by one
+//   v_perm, shifted as a pair, and clamped to bytes two at a time by v_sat_pk_u8_i16 (the second pair straight into the upper half of the
+//   output word) instead of a shift, a median and a merge per pixel.
+__device__ __forceinline__ void idct_1d_pre(int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7, int32_t tmp0, int32_t tmp1, int32_t o[8])
+{
+    const int32_t za = __mul24(d2 + d6, 4433);
+    const int32_t tmp2 = za - __mul24(d6, 15137), tmp3 = za + __mul24(d2, 6270);
+    const int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
+    int32_t z1 = d7 + d1, z2 = d5 + d3, z3 = d7 + d3, z4 = d5 + d1;
+    const int32_t z5 = __mul24(z3 + z4, 9633);
+    int32_t a0 = __mul24(d7, 2446), a1 = __mul24(d5, 16819), a2 = __mul24(d3, 25172), a3 = __mul24(d1, 12299);
+    z1 = __mul24(z1, -7373); z2 = __mul24(z2, -20995); z3 = __mul24(z3, -16069) + z5; z4 = __mul24(z4, -3196) + z5;
+    a0 += z1 + z3; a1 += z2 + z4; a2 += z2 + z3; a3 += z1 + z4;
+    o[0] = t10 + a3; o[7] = t10 - a3; o[1] = t11 + a2; o[6] = t11 - a2;
+    o[2] = t12 + a1; o[5] = t12 - a1; o[3] = t13 + a0; o[4] = t13 - a0;
+}
+template <int B> // sign-extended byte B of w times q
+__device__ __forceinline__ int32_t idct_deq(uint32_t w, int32_t q)
+{
+    int32_t d;
+    if (B == 0) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
+    else if (B == 1) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
+    else if (B == 2) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
+    else asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
+    return d;
+}
+// qv = the lane's quantiser column; q0s / q4s = qv[0] << 13, qv[4] << 13; is_dc: this lane holds column 0 of a real block, whose first
+// element is the 16-bit DC
+__device__ __forceinline__ void idct_cols_fast(uint2 raw, int32_t dc, bool is_dc, const int32_t qv[8], int32_t q0s, int32_t q4s, int32_t* s_w, uint32_t j, uint32_t r)
+{
+    int32_t o[8];
+    const int32_t c0 = is_dc ? dc : (int32_t)(int8_t)(raw.x & 0xffu);
+    const int32_t tmp0e = __mul24(c0, q0s) + (1 << 10), d4s = idct_deq<0>(raw.y, q4s); // PASS1 rounding: 1 << (CONST_BITS - PASS1_BITS - 1)
+    idct_1d_pre(idct_deq<1>(raw.x, qv[1]), idct_deq<2>(raw.x, qv[2]), idct_deq<3>(raw.x, qv[3]), idct_deq<1>(raw.y, qv[5]), idct_deq<2>(raw.y, qv[6]),
+                idct_deq<3>(raw.y, qv[7]), tmp0e + d4s, tmp0e - d4s, o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_w[j * IDCT_WSTRIDE + k * 8 + r] = o[k] >> 11;
+}
+__device__ __forceinline__ uint32_t idct_pack4(int32_t o0, int32_t o1, int32_t o2, int32_t o3)
+{
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o1, (uint32_t)o0, 0x07060302u)) >> (s16x2){2, 2};
+    const s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o3, (uint32_t)o2, 0x07060302u)) >> (s16x2){2, 2};
+    uint32_t d;
+    // the trailing s_nop: on the gfx940 family a destination-select write needs one wait state before the register is read again, and the
+    // compiler does not look inside an asm block
+    asm("v_sat_pk_u8_i16 %0, %1\n\tv_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\ts_nop 0"
+        : "=&v"(d) : "v"(__builtin_bit_cast(uint32_t, p01)), "v"(__builtin_bit_cast(uint32_t, p23)));
+    return d;
+}
+__device__ __forceinline__ void idct_rows_fast(const int32_t* s_w, uint32_t j, uint32_t r, bool blk_ok, uint8_t* dst)
+{
+    int32_t o[8];
+    const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
+    const int4 a = wp[0], b = wp[1];
+    const uint32_t C = (1u << 17) + (128u << 18); // DESCALE rounding, then + 128
+    idct_1d_pre(a.y, a.z, a.w, b.y, b.z, b.w, (int32_t)(((uint32_t)(a.x + b.x) << 13) + C), (int32_t)(((uint32_t)(a.x - b.x) << 13) + C), o);
+    uint2 out;
+    out.x = idct_pack4(o[0], o[1], o[2], o[3]);
+    out.y = idct_pack4(o[4], o[5], o[6], o[7]);
+    if (blk_ok) *reinterpret_cast<uint2*>(dst) = out;
+}
+
 __constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
 
 // Orders this wave's LDS writes before its following LDS reads of other lanes' data (and the other way round) for the compiler; the
@@ -915,8 +984,13 @@ __device__ __forceinline__ void idct_wave_sync()
 #endif
 // PROG = false: the baseline images of the range (int8 blocks in decode order + wide slots + the DC array);
 // PROG = true: the progressive ones (int16 blocks, raster order per component, see LpProgScan). Each skips the other kind.
+#ifdef LP_IDCT_WPE // A/B: register budget for this many waves per SIMD
+#define LP_IDCT_ATTR __attribute__((amdgpu_waves_per_eu(LP_IDCT_WPE)))
+#else
+#define LP_IDCT_ATTR
+#endif
 template <bool PROG>
-__global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
+__global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restrict__ imgs, const LpJpegState* __restrict__ states,
                                               const int8_t* __restrict__ coef8_arena, const int16_t* __restrict__ wide_arena,
                                               const uint32_t* __restrict__ wide_id_arena, const int16_t* __restrict__ dc_arena,
                                               const int16_t* __restrict__ pcoef_arena, uint8_t* __restrict__ plane_arena)
@@ -946,6 +1020,11 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         qv[0] = (int32_t)(q.x & 0xffffu); qv[1] = (int32_t)(q.x >> 16); qv[2] = (int32_t)(q.y & 0xffffu); qv[3] = (int32_t)(q.y >> 16);
         qv[4] = (int32_t)(q.z & 0xffffu); qv[5] = (int32_t)(q.z >> 16); qv[6] = (int32_t)(q.w & 0xffffu); qv[7] = (int32_t)(q.w >> 16);
     }
+    const bool q_small_wave = __all(q_small);
+    const int32_t q0s = qv[0] << 13, q4s = qv[4] << 13;
+    // this lane's pixel row of the component (the descriptor is read here, once: behind the wave fences of the loop the compiler would
+    // load it -- and redo the 64-bit address arithmetic -- for every tile)
+    uint8_t* const dst_row = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c];
     // Baseline blocks: the coefficient column (8 bytes) and the DC of the tiles IDCT_AHEAD steps ahead are requested before the
     // current tile is transformed -- one 8-byte load per lane and tile in flight kept the kernel at a third of the HBM rate
     // (bytes in flight per CU, not VALU, bound it: 73 % of the wave cycles in s_waitcnt, profiles/r02_a_sq_counters.md).
@@ -959,15 +1038,20 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
     auto block_of = [&](uint32_t bx) { return (row_blk + (bx >> hsh)) * d_bpm + row_in + (bx & hsh); };
     // unconditional loads from a clamped block index (a load under a lane mask would be merged with a constant afterwards, and
     // that merge waits for the load): a tile past the end of the row re-reads the row's last block and is masked where it is used
-    auto fetch = [&](uint32_t t, uint2& raw, int32_t& dcv) {
+    // the decode index of this lane's block advances by a constant from tile to tile (32 blocks = a whole number of MCUs further along
+    // the row) and grows with bx, so "the block at min(bx, bw - 1)" is min(index, index of the row's last block): one add and one min per
+    // tile instead of the shift / multiply / add chain of block_of
+    const uint32_t blk_step = (32u >> hsh) * d_bpm, blk_last = block_of(bw - 1u);
+    uint32_t blk_next = block_of(blockIdx.x * IDCT_TPW * 32 + wv * 8 + j); // tile 0; bx may lie past the row: the min below covers it
+    auto fetch = [&](uint2& raw, int32_t& dcv) { // the next tile not yet requested
         if (PROG) { raw = make_uint2(0, 0); dcv = 0; return; }
-        const uint32_t base = (blockIdx.x * IDCT_TPW + t) * 32, bx = base + wv * 8 + j;
-        const uint32_t blk = block_of(bx < bw ? bx : bw - 1u);
+        const uint32_t blk = blk_next < blk_last ? blk_next : blk_last;
+        blk_next += blk_step;
         raw = *reinterpret_cast<const uint2*>(coef8 + (size_t)blk * 64 + r * 8);
         dcv = dc16[blk];
     };
 #pragma unroll
-    for (uint32_t a = 0; a < IDCT_AHEAD; a++) fetch(a, pre_raw[a], pre_dc[a]);
+    for (uint32_t a = 0; a < IDCT_AHEAD; a++) fetch(pre_raw[a], pre_dc[a]);
     // unrolled by IDCT_AHEAD: tile t lives in register slot t % IDCT_AHEAD, which is refilled with tile t + IDCT_AHEAD as soon as it
     // has been read (moving a pending load's register to another slot would wait for it)
     for (uint32_t t0 = 0; t0 < IDCT_TPW; t0 += IDCT_AHEAD) {
@@ -985,7 +1069,22 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         raw.x = blk_ok ? raw.x : 0u;
         raw.y = blk_ok ? raw.y : 0u;
         const int32_t dc_now = pre_dc[a];
-        fetch(t + IDCT_AHEAD, pre_raw[a], pre_dc[a]);
+        fetch(pre_raw[a], pre_dc[a]);
+        uint8_t* const dst = dst_row + bx * 8;
+#ifndef LP_IDCT_R03 // A/B: round 3's tile code for every tile
+        if (!PROG) {
+            // a byte equals 0x80 (the escape) <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
+            const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
+            const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
+            if (q_small_wave && __all((zx | zy) == 0)) { // see the note on 24-bit multiplies below
+                idct_cols_fast(raw, dc_now, r == 0 && blk_ok, qv, q0s, q4s, s_w[wv], j, r);
+                idct_wave_sync();
+                idct_rows_fast(s_w[wv], j, r, blk_ok, dst);
+                idct_wave_sync();
+                continue;
+            }
+        }
+#endif
         if (PROG) {
             // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
             // its 128 bytes between them)
@@ -1024,7 +1123,6 @@ __global__ __launch_bounds__(256) void k_idct(const LpJpeg* __restrict__ imgs, c
         // multiplied terms stay below 2^15 in the column pass and 2^23 in the row pass. Anything else takes the 32-bit path.
         const bool fast = !any_esc && q_small;
         const bool wave_fast = __all(fast);
-        uint8_t* dst = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c] + bx * 8;
         // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between the
         // passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every load wait
         if (wave_fast) idct_cols<true>(cv, qv, s_w[wv], j, r); else idct_cols<false>(cv, qv, s_w[wv], j, r);

@@ -321,14 +321,8 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
 // h2v2_fancy_upsample (jdsample.c), then the horizontal half, YCbCr->BGR (jdcolor.c) and the integer box sums.
 // RWC = chroma columns per box (box width / 2). Requirements (checked by the host, LpFusedOp::fast): YCbCr 4:2:0,
 // box width in {8,16,32}, even box height, every box starts at a multiple of its width in x and at an even y.
-#ifdef LP_RESAMPLE_WPE // A/B: ask the register allocator for this many waves per SIMD
-#define LP_RESAMPLE_ATTR __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE_WPE)))
-#else
-#define LP_RESAMPLE_ATTR
-#endif
 template <int RWC>
-__global__ __launch_bounds__(256) LP_RESAMPLE_ATTR void k_resample_420(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
-                                                      const uint8_t* __restrict__ plane_arena)
+__device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
 {
     const LpFusedOp& op = ops[blockIdx.y];
     if (op.fast != (uint32_t)RWC) return;
@@ -530,6 +524,30 @@ __global__ __launch_bounds__(256) LP_RESAMPLE_ATTR void k_resample_420(const LpJ
         else r = sat_round_u8(__fmul_rn((float)sums[c], op.inv_area));
         D[c] = (uint8_t)r;
     }
+}
+
+// The kernels proper. The register budget is part of the measurement (profiles/r04_g_resample.md): the 8- and 16-pixel-box instances
+// are asked to fit seven waves per SIMD (58 / 72 VGPRs, nothing spilled; left alone the allocator takes 74 / 81 and the 16-pixel
+// instance runs 10 % slower at five waves); the 32-pixel-box instance would spill at that budget and is left alone (105 VGPRs).
+#ifndef LP_RESAMPLE_WPE
+#define LP_RESAMPLE_WPE 7
+#endif
+template <int RWC>
+__global__ __launch_bounds__(256) void k_resample_420(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
+{
+    resample_420_body<RWC>(imgs, ops, plane_arena);
+}
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE_WPE))) void k_resample_420<4>(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+                                                                                                             const uint8_t* __restrict__ plane_arena)
+{
+    resample_420_body<4>(imgs, ops, plane_arena);
+}
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE_WPE))) void k_resample_420<8>(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops,
+                                                                                                             const uint8_t* __restrict__ plane_arena)
+{
+    resample_420_body<8>(imgs, ops, plane_arena);
 }
 
 // K_resample fast path for YCbCr 4:4:4 (HR = 1) and 4:2:2 (HR = 2, h2v1_fancy_upsample): same thread-per-thumbnail-pixel walk as
