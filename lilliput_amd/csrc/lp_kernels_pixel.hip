@@ -380,8 +380,8 @@ __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ img
 #if defined(LP_RESAMPLE_R03) || defined(LP_RESAMPLE_NOSDWA)
     auto sat_pk = [](uint32_t x) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x)); return d; }; // two signed halves -> two bytes clamped to 0..255
 #endif
-    // one step = two luma rows; A / B / C = the chroma rows above, at and below them. The three row buffers change roles from step to
-    // step (unrolled by three below) instead of being copied.
+    // one step = two luma rows; A / B / C = the chroma rows above, at and below them. (Unrolling three steps so that the row buffers change
+    // roles instead of being copied saves 20 of 457 instructions per step and measured the same: profiles/r04_g_resample_idct.md.)
     auto step = [&](const int32_t q, const uint32_t (&A)[RWC + 2], const uint32_t (&B)[RWC + 2], uint32_t (&C)[RWC + 2]) __attribute__((always_inline)) {
         load_row(cy0 + q + 1, C);
         // luma rows 2q and 2q+1 of the box
@@ -499,22 +499,12 @@ __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ img
             }
 #endif
         }
-        asm volatile("" ::: "memory"); // keep the steps apart (no load of the next step is moved up): three steps' rows and luma words at once do not fit the register budget
     };
-#ifdef LP_RESAMPLE_ROT3
-    int32_t q = 0;
-    for (; q + 3 <= nrows; q += 3) { step(q, P[0], P[1], P[2]); step(q + 1, P[1], P[2], P[0]); step(q + 2, P[2], P[0], P[1]); }
-    if (q < nrows) {
-        step(q, P[0], P[1], P[2]);
-        if (q + 1 < nrows) step(q + 1, P[1], P[2], P[0]);
-    }
-#else
     for (int32_t q = 0; q < nrows; q++) {
         step(q, P[0], P[1], P[2]);
 #pragma unroll
         for (int i = 0; i < RWC + 2; i++) { P[0][i] = P[1][i]; P[1][i] = P[2][i]; }
     }
-#endif
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
     const int32_t sums[3] = {(int32_t)sb, (int32_t)sg, (int32_t)sr};
 #pragma unroll
