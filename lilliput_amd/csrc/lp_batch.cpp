@@ -1001,29 +1001,11 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         const size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : pipe_chunk;
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
-        // Ramp: the call's first chunks are short, so that the first kernels start after a quarter of a chunk's transfer instead of a whole
-        // one, and so are its last ones, so that what is left to compute when the last transfer ends is a quarter chunk (a call is one
-        // pipeline fill and one drain: 2.4 + ~2 ms of an 83 ms call of 1024 headline images with full chunks at both ends).
-        // LILLIPUT_HIP_PIPE_RAMP=0 turns it off (A/B); an explicit opt->chunk is taken as it is.
-        static const bool ramp_on = !getenv("LILLIPUT_HIP_PIPE_RAMP") || atoi(getenv("LILLIPUT_HIP_PIPE_RAMP")) != 0;
-        const size_t lanes = np * devs.size();
-        const bool ramp = ramp_on && opt->chunk <= 0 && chunk >= 8 && n >= 12 * chunk;
-        auto limit_at = [&](size_t i) { // items the chunk that starts at item i may hold
-            if (!ramp) return chunk;
-            const size_t q = chunk / 4, h = chunk / 2, head = lanes * (q + h);
-            if (i < lanes * q) return q;
-            if (i < head) return h;
-            const size_t left = n - i; // tail: ... full, then `lanes` halves, then `lanes` quarters
-            if (left <= lanes * q) return q;
-            if (left <= head) return std::min(h, left - lanes * q);
-            return std::min(chunk, left - head);
-        };
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
             LpPipeJob job;
             job.i0 = i;
             size_t bytes = 0, cnt = 0;
-            const size_t lim = limit_at(i);
-            while (i < n && cnt < lim && (cnt == 0 || bytes + items[i].src_len <= (1ull << 30))) { bytes += items[i].src_len; cnt++; i++; }
+            while (i < n && cnt < chunk && (cnt == 0 || bytes + items[i].src_len <= (1ull << 30))) { bytes += items[i].src_len; cnt++; i++; }
             job.i1 = i;
             sh.jobs.push_back(std::move(job));
         }
