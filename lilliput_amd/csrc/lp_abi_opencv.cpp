@@ -746,7 +746,7 @@ static bool png_read_data(LpDecoder* d, LpMat* m)
 {
     const LpPngInfo& pi = d->png;
     if (m->rows != (int)pi.height || m->cols != (int)pi.width || cv_channels(m->type) != d->png_channels || cv_depth_bytes(m->type) != 1) return false;
-    std::vector<uint8_t> filtered;
+    LpBytes filtered;
     if (!lp_png_read_idat(d->data, d->len, pi, filtered)) { lp_set_error("PNG image data is damaged"); return false; }
     LpEngineLease lease;
     LpEngine* eng = lease.get();
@@ -817,7 +817,7 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
 extern "C" long lilliput_hip_png_inflate_check(const void* data, size_t len)
 {
     LpPngInfo pi;
-    std::vector<uint8_t> filtered;
+    LpBytes filtered;
     if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
     return (long)filtered.size();
 }
@@ -827,7 +827,7 @@ extern "C" long lilliput_hip_png_inflate_check(const void* data, size_t len)
 extern "C" long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap)
 {
     LpPngInfo pi;
-    std::vector<uint8_t> filtered;
+    LpBytes filtered;
     if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
     if (filtered.size() > cap) return -2;
     memcpy(out, filtered.data(), filtered.size());

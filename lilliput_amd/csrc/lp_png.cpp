@@ -291,7 +291,7 @@ static bool png_tail_ok(const uint8_t* s, size_t n, size_t i, const LpPngInfo& i
 // filter bytes 0..4, a well-formed tail -- and `filtered` holds it; 0 = anything else: the caller takes libpng's walk, whose accept /
 // reject rules (warnings against errors, where damage is tolerated) are then authoritative.
 // png_read_filter_row's check of every row's filter byte
-static bool png_filter_bytes_ok(const LpPngInfo& info, const std::vector<uint8_t>& filtered)
+static bool png_filter_bytes_ok(const LpPngInfo& info, const LpBytes& filtered)
 {
     const int bits = info.depth * lp_png_channels_in_file(info.color_type);
     size_t o = 0;
@@ -310,15 +310,18 @@ static std::atomic<int> g_own_inflater{getenv("LILLIPUT_HIP_PNG_ZLIB") ? 0 : 1};
 int lp_png_set_inflater(int own) { return g_own_inflater.exchange(own ? 1 : 0); }
 
 // ... and the same sweep through the library's own inflater (lp_inflate.cpp), which only ever says
-// "ordinary, here it is" or "ask zlib". LILLIPUT_HIP_PNG_ZLIB=1 skips it (A/B, tests).
-static int png_idat_own(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
+// "ordinary, here it is" or "ask zlib". LILLIPUT_HIP_PNG_ZLIB=1 skips it (A/B, tests). Returns 1 = done, 0 = the inflater declined
+// (zlib's one-sweep may still take the stream), -1 = declined for a reason the zlib sweep would find too (a chunk that does not fit the
+// file, an IDAT CRC, a filter byte above 4, a broken tail): the caller goes straight to the row-wise walk instead of inflating a
+// damaged file three times.
+static int png_idat_own(const uint8_t* s, size_t n, const LpPngInfo& info, LpBytes& filtered)
 {
     static thread_local std::vector<uint8_t> z; // the IDAT payloads, joined
     size_t total = 0, i = info.idat_off;
     for (;;) { // first walk: sizes
-        if (n - i < 12) return 0;
+        if (n - i < 12) return -1;
         const uint32_t len = be32(s + i);
-        if (len > 0x7fffffffu || n - i - 8 < (size_t)len + 4) return 0;
+        if (len > 0x7fffffffu || n - i - 8 < (size_t)len + 4) return -1;
         if (!is_type(s + i + 4, "IDAT")) break;
         total += len;
         i += 12 + (size_t)len;
@@ -331,18 +334,18 @@ static int png_idat_own(const uint8_t* s, size_t n, const LpPngInfo& info, std::
         const uint8_t* type = s + i + 4;
         if (!is_type(type, "IDAT")) break;
         const uint8_t* d = s + i + 8;
-        if (be32(d + len) != lp_crc32((uint32_t)crc32(0, type, 4), d, len)) return 0;
+        if (be32(d + len) != lp_crc32((uint32_t)crc32(0, type, 4), d, len)) return -1;
         memcpy(z.data() + o, d, len);
         o += len;
         i += 12 + (size_t)len;
     }
     memset(z.data() + total, 0, LP_INFLATE_PAD);
     if (lp_inflate_exact(z.data(), total, filtered.data(), filtered.size()) != 1) return 0;
-    if (!png_filter_bytes_ok(info, filtered)) return 0;
-    return png_tail_ok(s, n, i, info) ? 1 : 0;
+    if (!png_filter_bytes_ok(info, filtered)) return -1;
+    return png_tail_ok(s, n, i, info) ? 1 : -1;
 }
 
-static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
+static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, LpBytes& filtered)
 {
     const size_t need = filtered.size();
     z_stream zs;
@@ -377,14 +380,15 @@ static int png_idat_fast(const uint8_t* s, size_t n, const LpPngInfo& info, std:
     return png_tail_ok(s, n, i, info) ? 1 : 0;
 }
 
-bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered)
+bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, LpBytes& filtered)
 {
     {
         const size_t need0 = lp_png_filtered_size(info);
-        filtered.resize(need0); // no zero-fill: inflate writes every byte of an ordinary stream
+        filtered.resize(need0); // LpBytes: nothing is cleared -- inflate writes every byte of an ordinary stream
         static const bool no_fast = getenv("LILLIPUT_HIP_PNG_ROWWISE") != nullptr; // A/B: libpng's row-by-row pattern for every file
-        if (!no_fast && g_own_inflater.load(std::memory_order_relaxed) && need0 && png_idat_own(s, n, info, filtered) == 1) return true;
-        if (!no_fast && need0 && png_idat_fast(s, n, info, filtered) == 1) return true;
+        int own = 0;
+        if (!no_fast && g_own_inflater.load(std::memory_order_relaxed) && need0 && (own = png_idat_own(s, n, info, filtered)) == 1) return true;
+        if (!no_fast && need0 && own == 0 && png_idat_fast(s, n, info, filtered) == 1) return true;
     }
     IdatFeed in{s, n, info.idat_off};
     if (!in.open_chunk(true)) return false;

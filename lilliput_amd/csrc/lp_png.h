@@ -7,6 +7,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 struct LpPngInfo {
@@ -29,10 +33,21 @@ struct LpPngInfo {
 // png_read_info: false = libpng would have raised an error before reaching the image data.
 bool lp_png_read_info(const uint8_t* s, size_t n, LpPngInfo& out);
 
+// A byte buffer whose resize() does not clear what it adds (std::vector<uint8_t>::resize value-initialises: a memset of the whole image
+// in front of an inflate that writes every byte of it).
+template <class T>
+struct LpDefaultInit : std::allocator<T> {
+    template <class U> struct rebind { typedef LpDefaultInit<U> other; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint8_t, LpDefaultInit<uint8_t>> LpBytes;
+
 // Image data: concatenates the IDAT run that starts at info.idat_off, inflates exactly the bytes the image needs into `filtered`
 // (per Adam7 pass / per row: one filter-type byte + the packed row), then walks the chunks up to IEND like png_read_end.
 // false = libpng would have failed (CRC error in an IDAT / critical chunk, broken or short zlib stream, truncated file, missing IEND).
-bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, std::vector<uint8_t>& filtered);
+bool lp_png_read_idat(const uint8_t* s, size_t n, const LpPngInfo& info, LpBytes& filtered);
 
 // Bytes of filtered data the image needs, and the geometry of Adam7 pass p (0..6): pass_w/pass_h may be 0.
 size_t lp_png_filtered_size(const LpPngInfo& info);
