@@ -255,7 +255,7 @@ def main_abi(args, ranks, la):
     for t in threads:
         jobs = args.batch
         for _ in range(args.warmup):
-            la.service_sim(distinct, t, min(jobs, max(4 * t, 64)), args.out, args.out, 85, la.ImageOpsFit, keep=False)
+            la.service_sim(distinct, t, min(jobs, max(8 * t, 512)), args.out, args.out, 85, la.ImageOpsFit, keep=False)
         el, ok, lat, outs, err = 0.0, 0, [], None, 0
         cpu0, thr0 = cgroup_cpu_stat()
         for k in range(args.steps):
