@@ -45,7 +45,9 @@ def make_sources(batch, distinct, size, rank, world):
             t = time.time()
             import multiprocessing as mp
 
-            workers = max(1, min(len(missing), (os.cpu_count() or 2) - 1, 96))  # ~0.7 GB of numpy temporaries per worker
+            quota = cgroup_cpus()  # a container that shows 256 CPUs and grants 16: more processes than ~2 per granted CPU only add memory
+            cpus = (os.cpu_count() or 2) - 1 if quota is None else max(1, int(2 * quota))
+            workers = max(1, min(len(missing), cpus, 96))  # ~0.7 GB of numpy temporaries per worker
             with mp.get_context("fork").Pool(workers) as pool:
                 for i, data in zip(missing, pool.imap(synth._job, [(i, size, 90) for i in missing], chunksize=1)):
                     with open(paths[i] + ".tmp", "wb") as f:
