@@ -28,6 +28,7 @@ struct LpArea420Op {
     LpFrame dst;
 };
 
+#define LP_AREA_SLACK 128 // bytes the plane arena keeps free before its first and after its last plane (the widest window, 67 columns, overhangs a row by < 80 bytes)
 struct LpAreaPlanes {
     const uint8_t* py; const uint8_t* pb; const uint8_t* pr;
     uint32_t sy, sc;                    // plane strides (luma, chroma)
@@ -66,7 +67,30 @@ struct LpaPlane {
     __amdgpu_buffer_rsrc_t rs;
     __device__ __forceinline__ uint32_t word(uint32_t row_off, uint32_t lane_off) const
     {
-        return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, (int)row_off, 0);
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off + LP_AREA_SLACK, (int)row_off, 0);
+    }
+    // N consecutive dwords from (row offset, lane offset) in as few instructions as the widths allow (dwordx4 / x2 / x1): a window's 6 luma
+    // dwords are two loads instead of six, a chroma row's 4 dwords one instead of four -- 6 vector-memory instructions per source row
+    // instead of 22. The offsets are NOT clamped into the row: a window that hangs over a row's end reads on into the next row (or, past
+    // the last plane, into the arena's slack: LP_AREA_SLACK bytes before the first and after the last plane), and one that starts
+    // left of column 0 reads the bytes before the row; those bytes only ever meet weight 0 (see LpaWindow).
+    template <int N>
+    __device__ __forceinline__ void words(uint32_t row_off, int32_t lane_off, uint32_t* out) const
+    {
+        typedef unsigned int v4_ __attribute__((ext_vector_type(4)));
+        typedef unsigned int v2_ __attribute__((ext_vector_type(2)));
+        int i = 0;
+#pragma unroll
+        for (; i + 4 <= N; i += 4) {
+            const v4_ t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + LP_AREA_SLACK + 4 * i, (int)row_off, 0);
+            out[i] = t.x; out[i + 1] = t.y; out[i + 2] = t.z; out[i + 3] = t.w;
+        }
+        if (i + 2 <= N) {
+            const v2_ t = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off + LP_AREA_SLACK + 4 * i, (int)row_off, 0);
+            out[i] = t.x; out[i + 1] = t.y;
+            i += 2;
+        }
+        if (i < N) out[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + LP_AREA_SLACK + 4 * i, (int)row_off, 0);
     }
 #else
     const uint8_t* p;
@@ -82,7 +106,9 @@ LPA_HD LpaPlane lpa_plane(const uint8_t* p)
 {
     LpaPlane q;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    // the resource starts LP_AREA_SLACK bytes BEFORE the plane and every lane offset carries the same bias (it rides in the instruction's
+    // immediate offset): buffer offsets are unsigned, and a window that starts left of column 0 has a negative one
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p) - LP_AREA_SLACK;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(a >> 32));
     q.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
 #else
@@ -147,6 +173,7 @@ struct LpaWindow {
     static constexpr int NWC = (NC + 3) / 4;
     uint32_t oy[NWY + 1], oc[NWC + 1];              // dword offsets inside a plane row (unsigned: scalar row + zero-extended lane offset is one addressing mode)
     uint32_t shy, shc;                              // byte phase of the window in its first dword, luma / chroma
+    int32_t oyb, ocb;                               // the first dword's offset as it is (device: wide loads, not clamped; may be negative)
     int32_t il, ir;                                 // window index that stands for chroma column -1 / column dw
     bool edge;
 
@@ -154,6 +181,7 @@ struct LpaWindow {
     {
         const int32_t xo = xe & ~3, c_lo = SS ? (xe >> 1) - 1 : xe, co = c_lo & ~3;
         shy = (uint32_t)(xe & 3) * 8; shc = (uint32_t)(c_lo & 3) * 8;
+        oyb = xo; ocb = co;
         // clamped into the row: a clamped dword only feeds columns outside the image
 #pragma unroll
         for (int i = 0; i <= NWY; i++) oy[i] = (uint32_t)lpa_clamp(xo + 4 * i, 0, (int32_t)P.sy - 4);
@@ -191,6 +219,11 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
     const int32_t ny = SS == 2 ? lpa_clamp((sy & 1) ? cy + 1 : cy - 1, 0, P.dh - 1) : cy;
     const uint32_t ry = (uint32_t)sy * P.sy, rc0 = (uint32_t)cy * P.sc, rc1 = (uint32_t)ny * P.sc;
     uint32_t wy[NWY + 1], wb0[NWC + 1], wb1[NWC + 1], wr0[NWC + 1], wr1[NWC + 1];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LP_AREA_NARROW_LOADS)
+    PY.template words<NWY + 1>(ry, W.oyb, wy);
+    PB.template words<NWC + 1>(rc0, W.ocb, wb0); PR.template words<NWC + 1>(rc0, W.ocb, wr0);
+    if (SS == 2) { PB.template words<NWC + 1>(rc1, W.ocb, wb1); PR.template words<NWC + 1>(rc1, W.ocb, wr1); }
+#else
 #pragma unroll
     for (int i = 0; i <= NWY; i++) wy[i] = PY.word(ry, W.oy[i]);
 #pragma unroll
@@ -198,6 +231,7 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
         wb0[i] = PB.word(rc0, W.oc[i]); wr0[i] = PR.word(rc0, W.oc[i]);
         if (SS == 2) { wb1[i] = PB.word(rc1, W.oc[i]); wr1[i] = PR.word(rc1, W.oc[i]); }
     }
+#endif
 #pragma unroll
     for (int i = 0; i < NWY; i++) wy[i] = lpa_alignbit(wy[i + 1], wy[i], W.shy);
 #pragma unroll

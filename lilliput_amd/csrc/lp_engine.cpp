@@ -729,7 +729,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
     sched_ = lp_make_sched(S_, C_cfg_ ? C_cfg_ : 256); // checkpoint schedule of the speculative pass (see LpCkSched)
     K_ = sched_.K;
-    size_t clean_words = 0, coef_elems = 0, plane_bytes = 0, pcoef_elems = 0;
+    size_t clean_words = 0, coef_elems = 0, plane_bytes = LP_AREA_SLACK, pcoef_elems = 0; // the planes start behind a slack the area kernels' unclamped window loads may touch (lp_area_core.h)
     uint32_t max_pchunks = 0;
     h_pstreams_.clear();
     std::vector<std::pair<uint32_t, LpProgScan>> leveled; // (dependency level, scan)
@@ -828,7 +828,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
              d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
-             d_planes_.ensure(plane_bytes + 64) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
+             d_planes_.ensure(plane_bytes + LP_AREA_SLACK) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     if (!h2d_small(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n)) return LP_ERR_DEVICE;
