@@ -258,26 +258,94 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
 #pragma unroll
         for (int i = 1; i < NC; i++) V[i] = i == W.ir ? V[i - 1] : V[i];
     }
+    // the {Cb, Cr} pair of window column c (16-bit halves): the horizontal half of the upsampler
+    auto chroma = [&](int c) -> uint32_t {
+        if (!SS) return V[c];
+        // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right, even ones with the one to the
+        // left -- the horizontal half of h2v2_fancy_upsample on the vertical sums, (3 * near + far + 7 or 8) >> 4, or
+        // h2v1_fancy_upsample on the samples, (3 * near + far + 2 or 1) >> 2 (a replicated neighbour gives the edge rule: near itself)
+        const int ic = c / 2 + 1;
+        const uint32_t bias = SS == 2 ? ((c & 1) ? 0x00070007u : 0x00080008u) : ((c & 1) ? 0x00020002u : 0x00010001u);
+        const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + bias; // both halves at once: neither carries into the other (<= 4088)
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned short u16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, (u16x2_)(__builtin_bit_cast(u16x2_, h) >> (u16x2_){SS == 2 ? 4 : 2, SS == 2 ? 4 : 2})); // one packed shift
+#else
+        return (h >> (SS == 2 ? 4 : 2)) & (SS == 2 ? 0x0fff0fffu : 0x3fff3fffu);
+#endif
+    };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LP_AREA_PLAIN_COLUMNS)
+    // Device: two columns at a time. Every colour term is one v_dot2_u32_u16 over the {Cb, Cr} pair (FIX(1.772) = 2 * 58065 and
+    // FIX(1.402) = 3 * 30627: with {2 Cb, 3 Cr} the constants fit 16-bit operands; green as -floor((x + 65535 - KG) / 65536)), the luma is
+    // added to the terms' upper halves by SDWA adds that read the byte in place and write one half of a pair register ({B, G} of a column;
+    // the R of the two columns), v_sat_pk_u8_i16 clamps a pair to two bytes, v_cvt_f32_ubyte0 / 1 turns them into the floats the taps
+    // multiply: 7.5 instructions per column where a shift, an add, a median and a conversion per channel took 9 (same integers, same
+    // floats). One asm block per pair keeps every half-register write three instructions away from its reader (gfx940 family: one wait
+    // state, and the compiler does not look inside).
+    typedef unsigned short lpa_u16x2 __attribute__((ext_vector_type(2)));
+    auto terms = [&](int c, uint32_t& tb, uint32_t& tg, uint32_t& tr) {
+        const lpa_u16x2 h = __builtin_bit_cast(lpa_u16x2, chroma(c));
+        const lpa_u16x2 hs = h * (lpa_u16x2){2, 3};
+        static_assert(LPA_FIX16(1.77200) == 2 * 58065 && LPA_FIX16(1.40200) == 3 * 30627, "split of the colour constants");
+        tr = __builtin_amdgcn_udot2(hs, (lpa_u16x2){0, 30627}, (uint32_t)KR, false);
+        tb = __builtin_amdgcn_udot2(hs, (lpa_u16x2){58065, 0}, (uint32_t)KB, false);
+        tg = __builtin_amdgcn_udot2(h, (lpa_u16x2){(unsigned short)LPA_FIX16(0.34414), (unsigned short)LPA_FIX16(0.71414)}, 65535u - (uint32_t)KG, false);
+    };
+#define LPA_PAIR_ASM(B0, B1)                                                                                                              \
+    asm("v_add_u16_sdwa %[x0], %[tb0], %[y0] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_" #B0 "\n\t"                 \
+        "v_add_u16_sdwa %[x1], %[tb1], %[y1] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_" #B1 "\n\t"                 \
+        "v_add_u16_sdwa %[xr], %[tr0], %[y0] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_" #B0 "\n\t"                 \
+        "v_sub_u16_sdwa %[x0], %[y0], %[tg0] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B0 " src1_sel:WORD_1\n\t"            \
+        "v_sub_u16_sdwa %[x1], %[y1], %[tg1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B1 " src1_sel:WORD_1\n\t"            \
+        "v_add_u16_sdwa %[xr], %[tr1], %[y1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_" #B1 "\n\t"            \
+        "v_sat_pk_u8_i16 %[x0], %[x0]\n\t"                                                                                                \
+        "v_sat_pk_u8_i16 %[x1], %[x1]\n\t"                                                                                                \
+        "v_sat_pk_u8_i16 %[xr], %[xr]\n\t"                                                                                                \
+        "v_cvt_f32_ubyte0 %[b0], %[x0]\n\t"                                                                                               \
+        "v_cvt_f32_ubyte1 %[g0], %[x0]\n\t"                                                                                               \
+        "v_cvt_f32_ubyte0 %[b1], %[x1]\n\t"                                                                                               \
+        "v_cvt_f32_ubyte1 %[g1], %[x1]\n\t"                                                                                               \
+        "v_cvt_f32_ubyte0 %[r0], %[xr]\n\t"                                                                                               \
+        "v_cvt_f32_ubyte1 %[r1], %[xr]"                                                                                                   \
+        : [x0] "=&v"(x0), [x1] "=&v"(x1), [xr] "=&v"(xr), [b0] "=&v"(fb0), [g0] "=&v"(fg0), [r0] "=&v"(fr0), [b1] "=&v"(fb1), [g1] "=&v"(fg1),    \
+          [r1] "=&v"(fr1)                                                                                                                 \
+        : [y0] "v"(y0), [y1] "v"(y1), [tb0] "v"(tb0), [tg0] "v"(tg0), [tr0] "v"(tr0), [tb1] "v"(tb1), [tg1] "v"(tg1), [tr1] "v"(tr1))
 #pragma unroll
-    for (int t = 0; t < NX; t++) {
-        const int c = REV ? NX - 1 - t : t;
-        int32_t cb, cr;
-        if (SS) {
-            // column xe + c: chroma window index c / 2 + 1; odd columns blend with the column to the right, even ones with the one to the
-            // left -- the horizontal half of h2v2_fancy_upsample on the vertical sums, (3 * near + far + 7 or 8) >> 4, or
-            // h2v1_fancy_upsample on the samples, (3 * near + far + 2 or 1) >> 2 (a replicated neighbour gives the edge rule: near itself)
-            const int ic = c / 2 + 1;
-            const uint32_t bias = SS == 2 ? ((c & 1) ? 0x00070007u : 0x00080008u) : ((c & 1) ? 0x00020002u : 0x00010001u);
-            const uint32_t h = 3u * V[ic] + V[(c & 1) ? ic + 1 : ic - 1] + bias;
-            cb = (int32_t)((h >> (SS == 2 ? 4 : 2)) & 0xfffu); cr = (int32_t)(h >> (SS == 2 ? 20 : 18));
-        } else {
-            cb = (int32_t)(V[c] & 0xffffu); cr = (int32_t)(V[c] >> 16);
+    for (int t = 0; t + 1 < NX; t += 2) {
+        const int c0 = REV ? NX - 1 - t : t, c1 = REV ? NX - 2 - t : t + 1;
+        uint32_t tb0, tg0, tr0, tb1, tg1, tr1, x0, x1, xr;
+        float fb0, fg0, fr0, fb1, fg1, fr1;
+        terms(c0, tb0, tg0, tr0);
+        terms(c1, tb1, tg1, tr1);
+        const uint32_t y0 = wy[c0 >> 2], y1 = wy[c1 >> 2];
+        switch ((c0 & 3) * 4 + (c1 & 3)) { // compile-time: the loop is unrolled
+        case 0 * 4 + 1: LPA_PAIR_ASM(0, 1); break;
+        case 2 * 4 + 3: LPA_PAIR_ASM(2, 3); break;
+        case 2 * 4 + 1: LPA_PAIR_ASM(2, 1); break;
+        case 0 * 4 + 3: LPA_PAIR_ASM(0, 3); break;
+        case 1 * 4 + 0: LPA_PAIR_ASM(1, 0); break;
+        case 3 * 4 + 2: LPA_PAIR_ASM(3, 2); break;
+        case 1 * 4 + 2: LPA_PAIR_ASM(1, 2); break;
+        default: LPA_PAIR_ASM(3, 0); break;
         }
+        f(c0, fb0, fg0, fr0);
+        f(c1, fb1, fg1, fr1);
+    }
+#undef LPA_PAIR_ASM
+    constexpr int T0 = (NX / 2) * 2; // the window is MAXT + 1 columns wide: one is left over
+#else
+    constexpr int T0 = 0;
+#endif
+#pragma unroll
+    for (int t = T0; t < NX; t++) {
+        const int c = REV ? NX - 1 - t : t;
+        const uint32_t h = chroma(c);
+        const int32_t cb = (int32_t)(h & 0xffffu), cr = (int32_t)(h >> 16);
         const int32_t yy = (int32_t)((wy[c >> 2] >> (8 * (c & 3))) & 255u);
         const int32_t r = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.40200), cr, KR) >> 16), 0, 255);
         const int32_t b = lpa_clamp(yy + (lpa_mad24(LPA_FIX16(1.77200), cb, KB) >> 16), 0, 255);
         const int32_t g = lpa_clamp(yy + (lpa_mad24(-LPA_FIX16(0.34414), cb, lpa_mad24(-LPA_FIX16(0.71414), cr, KG)) >> 16), 0, 255);
-        f(c, b, g, r);
+        f(c, (float)b, (float)g, (float)r);
     }
 }
 
@@ -308,10 +376,10 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
         // blue and green travel as a pair (one v_pk_mul_f32 + one v_pk_add_f32 for the two: each half is the same IEEE multiply and add)
         lpa_f2 bg = {0.f, 0.f};
         float rs = 0.f;
-        lpa_row<MAXT, SS, FLIPX>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
-            const lpa_f2 pbg = {(float)b, (float)g}, ww = {w[c], w[c]};
+        lpa_row<MAXT, SS, FLIPX>(P, PY, PB, PR, W, sy, [&](int c, float b, float g, float r) {
+            const lpa_f2 pbg = {b, g}, ww = {w[c], w[c]};
             bg = bg + pbg * ww;
-            rs = lpa_add(rs, lpa_mul((float)r, w[c]));
+            rs = lpa_add(rs, lpa_mul(r, w[c]));
         });
         const lpa_f2 bb = {beta, beta};
         sbg = sbg + bb * bg;
@@ -349,10 +417,10 @@ LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&b
         const float alpha = xt[k].alpha;
         const int32_t sy = rbase + rstep * (int32_t)xt[k].si;
         const lpa_f2 aa = {alpha, alpha};
-        lpa_row<MAXT, SS, false>(P, PY, PB, PR, W, sy, [&](int c, int32_t b, int32_t g, int32_t r) {
-            const lpa_f2 pbg = {(float)b, (float)g};
+        lpa_row<MAXT, SS, false>(P, PY, PB, PR, W, sy, [&](int c, float b, float g, float r) {
+            const lpa_f2 pbg = {b, g};
             bg[c] = bg[c] + pbg * aa;
-            rs[c] = lpa_add(rs[c], lpa_mul((float)r, alpha));
+            rs[c] = lpa_add(rs[c], lpa_mul(r, alpha));
         });
     }
     lpa_f2 sbg = {0.f, 0.f};
