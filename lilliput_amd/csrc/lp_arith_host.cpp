@@ -125,8 +125,28 @@ int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const Lp
                         }
                     }
                     if (d.marker == 0xD0 + (int)next_rst) d.marker = 0; // the expected one: decoding goes on behind it
-                    // (anything else stays unread: the interval decodes from zero bytes, as after jpeg_resync_to_restart's "leave it" verdict;
-                    // its other verdicts -- skip a marker, re-use one -- are not restated, like for the Huffman scans)
+                    else { // jdmarker.c jpeg_resync_to_restart(desired = next_rst)
+                        for (;;) {
+                            const int m = d.marker;
+                            int action;
+                            if (m < 0xC0) action = 2;                         // not a marker code at all: look further
+                            else if (m < 0xD0 || m > 0xD7) action = 3;        // some other marker: leave it, the interval decodes from zero bytes
+                            else if (m == 0xD0 + (int)((next_rst + 1u) & 7u) || m == 0xD0 + (int)((next_rst + 2u) & 7u)) action = 3; // one of the next two: this interval is missing
+                            else if (m == 0xD0 + (int)((next_rst - 1u) & 7u) || m == 0xD0 + (int)((next_rst - 2u) & 7u)) action = 2; // one of the last two: skip it
+                            else action = 1;                                  // the expected one (not here) or too far away: drop it, go on
+                            if (action == 1) { d.marker = 0; break; }
+                            if (action == 3) break;
+                            d.marker = 0; // next_marker(): on to the next marker in the data (a fake EOI at its end)
+                            for (;;) {
+                                int b = d.byte();
+                                if (b < 0) { d.marker = 0xD9; break; }
+                                if (b != 0xFF) continue;
+                                do b = d.byte(); while (b == 0xFF);
+                                if (b < 0) { d.marker = 0xD9; break; }
+                                if (b != 0) { d.marker = b; break; }
+                            }
+                        }
+                    }
                     next_rst = (next_rst + 1u) & 7u;
                     reset();
                     rst_left = sc.dri;

@@ -74,8 +74,9 @@ def test_header_verdicts_agree_on_arithmetic_files(hip_lib, oracle):
 
 def test_damaged_arithmetic_streams_decode_like_the_reference_library(hip_lib, oracle):
     """Bit flips, byte substitutions and truncation inside the entropy-coded data: wherever both decoders take the file, the
-    coefficients are the library's -- except where a damaged restart marker sends libjpeg through jpeg_resync_to_restart, whose
-    heuristics are not restated (as for the Huffman scans)."""
+    coefficients are the library's. A damaged restart marker sends both through jpeg_resync_to_restart's rules (restated in
+    lp_arith_host.cpp); what is left over are bytes that turned into a marker code below 0xC0: the product's header walk ends the scan
+    there, libjpeg's resync skips it and reads on (fewer than 1 % of the cases, all in files with restart markers)."""
     if oracle.ref() is None:
         pytest.skip("oracle/_ref/libref.so not built")
     rnd = random.Random(5)
@@ -112,9 +113,9 @@ def test_damaged_arithmetic_streams_decode_like_the_reference_library(hip_lib, o
         else:
             diff += 1
             odd.append((it, n, "differs"))
-    assert same >= 300, (same, diff, odd[:8])
+    assert same >= 380, (same, diff, odd[:8])
     assert all("dri" in n for _, n, _ in odd), odd[:8]  # every divergence sits in a file with restart markers
-    assert len(odd) <= 0.06 * (same + len(odd)), (same, odd[:8])
+    assert len(odd) <= 0.02 * (same + len(odd)), (same, odd[:8])
 
 
 @pytest.mark.gpu
