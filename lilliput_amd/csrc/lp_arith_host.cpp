@@ -278,6 +278,9 @@ int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const Lp
                 }
             }
         }
+    // jdmarker.c read_markers after the scan: a pending marker code libjpeg does not know (only a scan with a restart interval is handed
+    // data that can contain one, lp_jpeg_parse.cpp) is JERR_UNKNOWN_MARKER -- the image fails, it is not merely warned about
+    if (d.marker > 0 && d.marker < 0xC0) bad = 2;
     delete dp;
     return bad;
 }

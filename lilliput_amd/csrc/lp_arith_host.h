@@ -21,5 +21,6 @@ struct LpArithScan {
 
 // Decodes one scan from its raw entropy-coded bytes (stuffed zeros and restart markers still in: the QM decoder's byte-in does the
 // unstuffing, T.81 D.2.6) into the image's coefficient arena (blocks in raster order per component, 64 zigzag-ordered values each).
-// Returns 0, or 1 when the decoder met an impossible code (jdarith.c JWRN_ARITH_BAD_CODE: the rest of the scan is left alone).
+// Returns 0, 1 when the decoder met an impossible code (jdarith.c JWRN_ARITH_BAD_CODE: the rest of the scan is left alone: a warning),
+// or 2 when the scan ended with a marker code pending that libjpeg does not know (read_markers: JERR_UNKNOWN_MARKER: the image fails).
 int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const LpArithScan& ar, int16_t* coef);

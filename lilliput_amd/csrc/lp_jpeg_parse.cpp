@@ -355,6 +355,11 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                     if (d[q] != 0xFF) continue;
                     const unsigned c = d[q + 1];
                     if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
+                    // QM-coded scans with a restart interval (decoded on the host, lp_arith_host.cpp): a byte pair that only looks like a
+                    // marker (code below 0xC0: nothing libjpeg knows) does not end the data -- the decoder runs dry there, and
+                    // jpeg_resync_to_restart skips the pair at the next interval boundary and reads on. (A scan that ENDS with such a
+                    // pair pending is refused by lp_arith_scan, as read_markers refuses it: JERR_UNKNOWN_MARKER.)
+                    if (arith && rs.dri && c < 0xC0) continue;
                     break;
                 }
                 if (q + 1 >= n) q = n;                                    // ran off the end: the scan takes what is there

@@ -88,7 +88,7 @@ void run_task(const LpProgHostTask& t, std::vector<uint8_t>& clean, std::vector<
 {
     const LpProgScanHost& sh = *t.scan;
     if (sh.arith) { // a QM-coded scan reads its raw bytes itself (lp_arith_host.h); an impossible code leaves the rest of the scan alone, like libjpeg's warning
-        (void)lp_arith_scan(t.data + sh.ecs_off, sh.ecs_len, sh.s, sh.ar, t.coef);
+        if (lp_arith_scan(t.data + sh.ecs_off, sh.ecs_len, sh.s, sh.ar, t.coef) == 2) __atomic_or_fetch(t.error, 4u, __ATOMIC_RELAXED); // the scan ended on an unknown marker
         return;
     }
     unstuff(t.data + sh.ecs_off, sh.ecs_len, clean, rst);
