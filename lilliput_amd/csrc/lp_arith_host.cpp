@@ -2,6 +2,8 @@
 // the reference's own libjpeg.a through oracle/_ref, tests/test_arith.py) after T.81 Annex D (the QM decoder) and F.1.4 / G.1.3.
 #include "lp_arith_host.h"
 
+#include "lp_jbits.h"
+
 #include <string.h>
 
 namespace {
@@ -31,18 +33,17 @@ const Qe kQe[114] = {
     {0x5597, 110, 109, 0}, {0x504F, 111, 107, 0}, {0x5A10, 110, 111, 1}, {0x5522, 112, 109, 0}, {0x59EB, 112, 111, 1}, {0x5A1D, 113, 113, 0}};
 
 struct Dec {
-    const uint8_t* p;
-    const uint8_t* end;
-    int marker;         // jdarith.c cinfo->unread_marker: once a marker has been met the decoder is fed zero bytes
+    LpJSrc src;         // the raw bytes and jdarith.c's cinfo->unread_marker: once a marker has been met the decoder is fed zero bytes
     int64_t c, a;
     int ct;             // -16 at the start of an interval; -1 = the decoder has given up (JWRN_ARITH_BAD_CODE)
     uint8_t dc_stats[16][64], ac_stats[16][256], fixed_bin[4];
     int32_t last_dc[4];
     int dc_ctx[4];
 
-    int byte()          // jdatasrc.c at the end of a memory source: a fake EOI
+    int byte()          // jdarith.c get_byte over cv::JpegDecoder's source manager: an empty buffer is JERR_CANT_SUSPEND (the image fails)
     {
-        return p < end ? *p++ : -1;
+        if (src.p == src.end) { src.suspended = true; return -1; }
+        return *src.p++;
     }
     // T.81 D.2: one binary decision with statistics bin *st (bit 7: sense of the MPS, bits 0..6: index into Table D.3)
     int decode(uint8_t* st)
@@ -50,15 +51,15 @@ struct Dec {
         while (a < 0x8000) { // renormalisation and byte-in, D.2.6
             if (--ct < 0) {
                 int data;
-                if (marker) data = 0;
+                if (src.marker || src.suspended) data = 0;
                 else {
                     data = byte();
-                    if (data < 0) { marker = 0xD9; data = 0; }
+                    if (data < 0) data = 0;
                     else if (data == 0xFF) {
                         do data = byte(); while (data == 0xFF); // fill bytes
-                        if (data < 0) { marker = 0xD9; data = 0; }
+                        if (data < 0) data = 0;
                         else if (data == 0) data = 0xFF;        // a stuffed zero
-                        else { marker = data; data = 0; }       // a marker inside the segment is legal: zeros from here on
+                        else { src.marker = data; data = 0; }   // a marker inside the segment is legal: zeros from here on
                     }
                 }
                 c = (c << 8) | data;
@@ -88,11 +89,11 @@ struct Dec {
 
 } // namespace
 
-int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const LpArithScan& ar, int16_t* coef)
+int lp_arith_scan(const uint8_t* ecs, const uint8_t* file_end, const LpProgScan& sc, const LpArithScan& ar, int16_t* coef, bool whole_file)
 {
     Dec* dp = new Dec();
     Dec& d = *dp;
-    d.p = ecs; d.end = ecs + len; d.marker = 0;
+    d.src.init(ecs, file_end);
     const uint32_t Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al;
     const bool seq = sc.sequential != 0;
     const bool dc_part = seq || (Ss == 0 && Ah == 0), ac_part = seq || Ss != 0;
@@ -113,46 +114,15 @@ int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const Lp
         for (uint32_t mx = 0; mx < sc.mcux; mx++) {
             if (sc.dri) { // decode_mcu_*: "Process restart marker if needed"
                 if (rst_left == 0) {
-                    // jdmarker.c read_restart_marker: the marker the decoder ran into, or the next one in the data
-                    if (!d.marker) {
-                        for (;;) {
-                            int b = d.byte();
-                            if (b < 0) { d.marker = 0xD9; break; }
-                            if (b != 0xFF) continue;
-                            do b = d.byte(); while (b == 0xFF);
-                            if (b < 0) { d.marker = 0xD9; break; }
-                            if (b != 0) { d.marker = b; break; }
-                        }
-                    }
-                    if (d.marker == 0xD0 + (int)next_rst) d.marker = 0; // the expected one: decoding goes on behind it
-                    else { // jdmarker.c jpeg_resync_to_restart(desired = next_rst)
-                        for (;;) {
-                            const int m = d.marker;
-                            int action;
-                            if (m < 0xC0) action = 2;                         // not a marker code at all: look further
-                            else if (m < 0xD0 || m > 0xD7) action = 3;        // some other marker: leave it, the interval decodes from zero bytes
-                            else if (m == 0xD0 + (int)((next_rst + 1u) & 7u) || m == 0xD0 + (int)((next_rst + 2u) & 7u)) action = 3; // one of the next two: this interval is missing
-                            else if (m == 0xD0 + (int)((next_rst - 1u) & 7u) || m == 0xD0 + (int)((next_rst - 2u) & 7u)) action = 2; // one of the last two: skip it
-                            else action = 1;                                  // the expected one (not here) or too far away: drop it, go on
-                            if (action == 1) { d.marker = 0; break; }
-                            if (action == 3) break;
-                            d.marker = 0; // next_marker(): on to the next marker in the data (a fake EOI at its end)
-                            for (;;) {
-                                int b = d.byte();
-                                if (b < 0) { d.marker = 0xD9; break; }
-                                if (b != 0xFF) continue;
-                                do b = d.byte(); while (b == 0xFF);
-                                if (b < 0) { d.marker = 0xD9; break; }
-                                if (b != 0) { d.marker = b; break; }
-                            }
-                        }
-                    }
+                    // jdmarker.c read_restart_marker / jpeg_resync_to_restart (lp_jbits.h); out of bytes: JERR_CANT_SUSPEND
+                    if (!d.src.restart_marker(next_rst)) { delete dp; return LP_SCAN_OUT_OF_DATA; }
                     next_rst = (next_rst + 1u) & 7u;
                     reset();
                     rst_left = sc.dri;
                 }
                 rst_left--;
             }
+            if (d.src.suspended) { delete dp; return LP_SCAN_OUT_OF_DATA; } // the decoder asked for a byte the buffer does not hold
             if (d.ct == -1) continue; // "if error do nothing"
             if (seq || Ss == 0) {
                 for (uint32_t s = 0; s < sc.ns && d.ct != -1; s++)
@@ -257,7 +227,7 @@ int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const Lp
                 }
             } else { // decode_mcu_AC_refine
                 int kex = (int)Se;
-                for (; kex > 0; kex--) if (blk[kex]) break; // end of block of the previous stage
+                for (; kex >= (int)Ss; kex--) if (blk[kex]) break; // end of block of the previous stage (inside the band: what lies below it belongs to other scans, and cannot change the k > kex test)
                 for (uint32_t k = Ss; k <= Se; k++) {
                     uint8_t* st = d.ac_stats[at] + 3 * (k - 1);
                     if ((int)k > kex && d.decode(st)) break; // EOB
@@ -278,9 +248,12 @@ int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const Lp
                 }
             }
         }
-    // jdmarker.c read_markers after the scan: a pending marker code libjpeg does not know (only a scan with a restart interval is handed
-    // data that can contain one, lp_jpeg_parse.cpp) is JERR_UNKNOWN_MARKER -- the image fails, it is not merely warned about
-    if (d.marker > 0 && d.marker < 0xC0) bad = 2;
+    if (d.src.suspended) { delete dp; return LP_SCAN_OUT_OF_DATA; }
+    // what jdmarker.c read_markers meets behind the scan (a file of several scans is read to its end before any pixel is returned)
+    if (whole_file) {
+        const int after = d.src.after_scan(sc.dri != 0);
+        if (after) bad = after;
+    }
     delete dp;
     return bad;
 }

@@ -21,6 +21,10 @@ struct LpArithScan {
 
 // Decodes one scan from its raw entropy-coded bytes (stuffed zeros and restart markers still in: the QM decoder's byte-in does the
 // unstuffing, T.81 D.2.6) into the image's coefficient arena (blocks in raster order per component, 64 zigzag-ordered values each).
-// Returns 0, 1 when the decoder met an impossible code (jdarith.c JWRN_ARITH_BAD_CODE: the rest of the scan is left alone: a warning),
-// or 2 when the scan ended with a marker code pending that libjpeg does not know (read_markers: JERR_UNKNOWN_MARKER: the image fails).
-int lp_arith_scan(const uint8_t* ecs, size_t len, const LpProgScan& sc, const LpArithScan& ar, int16_t* coef);
+// The decoder reads up to the end of the FILE the way libjpeg does (the marker that ends the scan stops it; lp_jbits.h). whole_file:
+// libjpeg reads this file to its end before it returns pixels (several scans), so what follows the scan matters.
+// Returns LP_SCAN_OK, LP_SCAN_WARNED when the decoder met an impossible code (jdarith.c JWRN_ARITH_BAD_CODE: the rest of the scan is left
+// alone), LP_SCAN_BAD_MARKER when the scan ended with a marker code pending that libjpeg does not know (read_markers:
+// JERR_UNKNOWN_MARKER) or LP_SCAN_OUT_OF_DATA when the decoder needed a byte past the end of the file (JERR_CANT_SUSPEND under
+// cv::JpegDecoder's source manager): the image fails in both.
+int lp_arith_scan(const uint8_t* ecs, const uint8_t* file_end, const LpProgScan& sc, const LpArithScan& ar, int16_t* coef, bool whole_file);

@@ -128,7 +128,14 @@ static bool huff_table_valid(const uint8_t bits[17], const uint8_t* vals, bool i
     return true;
 }
 
-int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out) { return lp_jpeg_parse_opts(d, n, out, false); }
+int lp_jpeg_parse(const uint8_t* d, size_t n, LpJpegHeader* out)
+{
+    const int rc = lp_jpeg_parse_opts(d, n, out, false);
+    // entropy-coded data that runs to the end of the buffer with no marker behind it: whether cv::JpegDecoder still returns the image
+    // depends on where libjpeg's read-ahead falls (lp_jbits.h) -- the serial route, which models it, decides
+    if (rc == LP_PARSE_OK && !out->scan_path && out->open_end) return lp_jpeg_parse_opts(d, n, out, true);
+    return rc;
+}
 
 int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force_scans)
 {
@@ -158,6 +165,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
     int adobe_tf = 0;
     size_t i = 2;
     size_t ecs = 0;
+    bool ran_off_end = false;
     // The walk accepts and rejects what jdmarker.c read_markers does (the reference decodes through it): garbage between
     // segments is skipped, an unknown marker code, a repeated SOI/SOF, or a table segment whose length does not add up is
     // an error; running off the end is "no image".
@@ -167,12 +175,12 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         for (;;) {
             while (i < n && d[i] != 0xFF) i++;
             while (i < n && d[i] == 0xFF) i++;
-            if (i >= n) { if (!raw_scans.empty()) { m = 0xD9; break; } return LP_PARSE_TRUNCATED; }
+            if (i >= n) { if (!raw_scans.empty()) { m = 0xD9; ran_off_end = true; break; } return LP_PARSE_TRUNCATED; }
             m = d[i++];
             if (m != 0) break; // FF 00: stuffed data, keep looking
         }
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (m == 0xD9 && !raw_scans.empty()) { out->saw_eoi = 1; break; } // end of a progressive file
+        if (m == 0xD9 && !raw_scans.empty()) { out->saw_eoi = ran_off_end ? 0 : 1; break; } // end of a progressive file (or of the buffer: no EOI)
         if (m == 0xD8 || m == 0xD9) return LP_PARSE_NOT_JPEG; // JERR_SOI_DUPLICATE / EOI before any scan
         const bool is_sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
         const bool known = (m >= 0xC0 && m <= 0xCF && m != 0xC8) || m == 0xDA || m == 0xDB || m == 0xDC || m == 0xDD || (m >= 0xE0 && m <= 0xEF) || m == 0xFE;
@@ -282,6 +290,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 if (!progressive && !arith && ((t >> 4) > 3 || (t & 15) > 3)) return LP_PARSE_NOT_JPEG; // JERR_NO_HUFF_TABLE
                 if (s < 4) { scan_comp[s] = c; td[c] = t >> 4; ta[c] = t & 15; }
             }
+            if (raw_scans.empty() && !ecs) out->one_pass = !progressive && ns == (unsigned)j.ncomp; // jdinput.c initial_setup: has_multiple_scans
             if (!progressive && raw_scans.empty()) {
                 // A sequential file the baseline kernels do not take as it is -- fewer components in the first scan than in the frame
                 // (more scans follow), components in another order, table numbers 2 / 3 -- is decoded scan by scan like a progressive one.
@@ -355,11 +364,11 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                     if (d[q] != 0xFF) continue;
                     const unsigned c = d[q + 1];
                     if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
-                    // QM-coded scans with a restart interval (decoded on the host, lp_arith_host.cpp): a byte pair that only looks like a
-                    // marker (code below 0xC0: nothing libjpeg knows) does not end the data -- the decoder runs dry there, and
-                    // jpeg_resync_to_restart skips the pair at the next interval boundary and reads on. (A scan that ENDS with such a
-                    // pair pending is refused by lp_arith_scan, as read_markers refuses it: JERR_UNKNOWN_MARKER.)
-                    if (arith && rs.dri && c < 0xC0) continue;
+                    // Scans with a restart interval: a byte pair that only looks like a marker (code below 0xC0: nothing libjpeg knows) does
+                    // not end the data -- the decoder runs dry there, and jpeg_resync_to_restart skips the pair at the next interval
+                    // boundary and reads on (lp_jbits.h). (A scan that ENDS with such a pair pending is refused by the scan decoders when
+                    // libjpeg reads the file to its end, as read_markers refuses it: JERR_UNKNOWN_MARKER.)
+                    if (rs.dri && c < 0xC0) continue;
                     break;
                 }
                 if (q + 1 >= n) q = n;                                    // ran off the end: the scan takes what is there
@@ -498,6 +507,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         }
         if (out->scans.empty()) return LP_PARSE_NOT_JPEG;
         out->arith = arith;
+        out->decode_fails = !out->one_pass && !out->saw_eoi; // jpeg_start_decompress reads a multi-scan file to EOI; without one it suspends
         out->ecs_off = out->scans.front().ecs_off;
         out->ecs_len = out->scans.back().ecs_off + out->scans.back().ecs_len - out->ecs_off;
         return LP_PARSE_OK;
@@ -514,12 +524,15 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         end = n - 2;
         out->saw_eoi = 1;
     } else {
+        out->open_end = true;
         for (size_t q = ecs; q + 1 < n; q++) {
             if (d[q] != 0xFF) continue;
             unsigned c = d[q + 1];
             if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
+            if (j.dri && c < 0xC0) continue; // not a marker libjpeg knows: with a restart interval the decoder reads past it (lp_jbits.h)
             end = q;
             out->saw_eoi = c == 0xD9;
+            out->open_end = false;
             break;
         }
     }

@@ -29,6 +29,12 @@ struct LpJpegHeader {
     size_t ecs_len = 0;         // bytes up to (not including) the terminating marker / end of file (progressive: through the last scan)
     int saw_eoi = 0;
     bool arith = false;         // an arithmetic-coded file (always decoded scan by scan, on host threads)
+    bool one_pass = true;       // libjpeg returns pixels while it reads the one scan (a sequential file whose first scan holds every
+                                // component: jdinput.c has_multiple_scans false); otherwise the whole file is read first, to EOI
+    bool decode_fails = false;  // the header walk already knows that the reference's read_data fails: a file of several scans without
+                                // its EOI (jpeg_start_decompress suspends at the end of the buffer, cv::JpegDecoder gives up)
+    bool open_end = false;      // the entropy-coded data of a one-scan file runs to the end of the buffer, no marker behind it: whether
+                                // the reference decodes it depends on where libjpeg's read-ahead falls (lp_jbits.h): the serial route
     bool scan_path = false;     // decoded scan by scan (progressive, multi-scan sequential, four components, unusual sampling):
                                 // `scans` lists the scans in file order, `huff` is unused
     std::vector<LpProgScanHost> scans;

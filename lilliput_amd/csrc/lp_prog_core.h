@@ -44,8 +44,26 @@ struct LpProgBits {
     uint32_t cw, w0, w1;
     bool insufficient;  // jdhuff.c insufficient_data: a read went past `total` (JWRN_HIT_MARKER); until the next restart marker
                         // the remaining MCUs are left as they are
+    uint32_t all_bits, n_rst, rst_k; // the whole stream, its restart boundaries, the next one to cross
 
-    LP_PHD LpProgBits(P& m_, uint32_t total_) : m(m_), p(0), total(total_), cw(0xfffffff0u), w0(0), w1(0), insufficient(false) {}
+    LP_PHD LpProgBits(P& m_, uint32_t total_bits, uint32_t n_rst_)
+        : m(m_), p(0), total(n_rst_ ? m_.rst_bit(0) : total_bits), cw(0xfffffff0u), w0(0), w1(0), insufficient(false), all_bits(total_bits), n_rst(n_rst_), rst_k(0) {}
+    // process_restart over an unstuffed stream (k_unstuff_*: the markers are cut out, their positions listed; the numbers of the RSTn
+    // are not kept -- the device-lane build trusts them, the host reader lp_jbits.h does what libjpeg does with a wrong one)
+    LP_PHD bool restart()
+    {
+        if (rst_k < n_rst) { // the marker is there: decoding resumes behind it ("reset out-of-data flag, unless ... up against end of data")
+            seek(m.rst_bit(rst_k), rst_k + 1u < n_rst ? m.rst_bit(rst_k + 1u) : all_bits);
+            insufficient = false;
+        } else
+            seek(all_bits, all_bits);
+        rst_k++;
+        return true;
+    }
+    LP_PHD void mcu_begin(uint32_t, bool) {}
+    LP_PHD bool mcu_redo() { return false; }
+    LP_PHD bool failed() const { return false; }
+    LP_PHD uint32_t get_each(uint32_t n) { return get(n); } // n single-bit reads (libjpeg reads correction bits one by one; here the same bits)
     LP_PHD void seek(uint32_t pos, uint32_t new_total) // start of a restart interval: the cached words were cut at the old end
     {
         p = pos;
@@ -119,13 +137,13 @@ LP_PHD uint32_t lp_ctz64(uint64_t v)
 
 // One correction bit for every coefficient of `bits` (ascending = scan order): a set bit moves a coefficient whose p1 bit is
 // still clear away from zero by p1.
-template <class P>
-LP_PHD void lp_prog_correct(P& m, LpProgBits<P>& b, uint64_t bits, int32_t p1, int32_t m1)
+template <class P, class B>
+LP_PHD void lp_prog_correct(P& m, B& b, uint64_t bits, int32_t p1, int32_t m1)
 {
     while (bits) { // the correction bits of up to 32 coefficients come out of the stream in one read
         uint32_t n = lp_popc64(bits);
         if (n > 32u) n = 32u;
-        uint32_t v = b.get(n) << (32u - n); // first coefficient's bit on top
+        uint32_t v = b.get_each(n) << (32u - n); // first coefficient's bit on top
         for (; n; n--, v <<= 1) {
             const uint32_t e = lp_ctz64(bits);
             bits &= bits - 1ull;
@@ -137,23 +155,20 @@ LP_PHD void lp_prog_correct(P& m, LpProgBits<P>& b, uint64_t bits, int32_t p1, i
     }
 }
 
-template <class P>
-LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32_t n_rst)
+// Reader B: LpProgBits (an unstuffed stream with listed restart boundaries) or LpJBits (lp_jbits.h: the raw bytes, read the way libjpeg
+// reads them under cv::JpegDecoder's source manager). Returns false when the reader ran out of bytes (LpJBits only): the image fails.
+template <class P, class B>
+LP_PHD bool lp_prog_scan_with(P& m, B& b, const LpProgScan& sc)
 {
-    LpProgBits<P> b(m, n_rst ? m.rst_bit(0) : total_bits);
     const uint32_t Ss = sc.Ss, Se = sc.Se, Ah = sc.Ah, Al = sc.Al;
     const int32_t p1 = 1 << Al, m1 = -(1 << Al);
     int32_t pred[4] = {0, 0, 0, 0};
-    uint32_t eobrun = 0, rst_left = sc.dri, rst_k = 0;
+    uint32_t eobrun = 0, rst_left = sc.dri, bpm = 0;
+    for (uint32_t s = 0; s < sc.ns; s++) bpm += (uint32_t)sc.hs[s] * sc.vs[s];
     for (uint32_t my = 0; my < sc.mcuy; my++)
         for (uint32_t mx = 0; mx < sc.mcux; mx++) {
             if (sc.dri && rst_left == 0) { // process_restart: the rest of the interval's bits are dropped, predictors and the EOB run start over
-                if (rst_k < n_rst) { // the marker is there: decoding resumes behind it ("reset out-of-data flag, unless ... up against end of data")
-                    b.seek(m.rst_bit(rst_k), rst_k + 1u < n_rst ? m.rst_bit(rst_k + 1u) : total_bits);
-                    b.insufficient = false;
-                } else
-                    b.seek(total_bits, total_bits);
-                rst_k++;
+                if (!b.restart()) return false;
                 pred[0] = pred[1] = pred[2] = pred[3] = 0;
                 eobrun = 0;
                 rst_left = sc.dri;
@@ -165,6 +180,9 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
                 continue;
             }
             if (sc.sequential) { // jdhuff.c decode_mcu: every block of the MCU whole, its DC difference then its AC run/size pairs
+                const int32_t pred0[4] = {pred[0], pred[1], pred[2], pred[3]};
+                b.mcu_begin(bpm, sc.dri == 0);
+            mcu_again:
                 for (uint32_t s = 0; s < sc.ns; s++)
                     for (uint32_t v = 0; v < sc.vs[s]; v++)
                         for (uint32_t h = 0; h < sc.hs[s]; h++) {
@@ -183,6 +201,11 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
                                     break;
                             }
                         }
+                if (b.mcu_redo()) { // decode_mcu_fast met a marker and gave the MCU up: decode_mcu_slow takes it from the same state
+                    pred[0] = pred0[0]; pred[1] = pred0[1]; pred[2] = pred0[2]; pred[3] = pred0[3];
+                    goto mcu_again;
+                }
+                if (b.failed()) return false;
                 if (sc.dri) rst_left--;
                 continue;
             }
@@ -254,6 +277,15 @@ LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32
                     m.close(blk);
                 }
             }
+            if (b.failed()) return false;
             if (sc.dri) rst_left--;
         }
+    return true;
+}
+
+template <class P>
+LP_PHD void lp_prog_scan(P& m, const LpProgScan& sc, uint32_t total_bits, uint32_t n_rst)
+{
+    LpProgBits<P> b(m, total_bits, n_rst);
+    (void)lp_prog_scan_with(m, b, sc);
 }

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "lp_hostmem.h"
+#include "lp_jbits.h"
 #include "lp_prog_core.h"
 #include "lp_huff_core.h" // LP_ZIGZAG_INIT
 
@@ -36,19 +37,9 @@ static inline uint64_t lp_host_nonzero_mask(const int16_t* c)
 }
 
 namespace {
-struct HostProgMem {
-    const uint32_t* words;
-    size_t nwords;
-    const uint32_t* rst;
-    const LpProgHuff* ht;
+struct HostProgMem { // the coefficient side of lp_prog_core.h's memory policy (the bits come from LpJBits)
     int16_t* coef;
     int16_t* cur;
-    uint32_t word(uint32_t w) const { return w < nwords ? words[w] : 0u; }
-    uint32_t rst_bit(uint32_t k) const { return rst[k]; }
-    uint32_t lut8(uint32_t s, uint32_t i) const { return ht->lut8[s][i]; }
-    int32_t maxcode(uint32_t s, uint32_t l) const { return ht->maxcode[s][l]; }
-    int32_t valoff(uint32_t s, uint32_t l) const { return ht->valoff[s][l]; }
-    uint32_t val(uint32_t s, uint32_t i) const { return ht->vals[s][i]; }
     void st(uint32_t blk, uint32_t e, int32_t v) { coef[(size_t)blk * 64 + e] = (int16_t)v; }
     int32_t ld(uint32_t blk, uint32_t e) const { return coef[(size_t)blk * 64 + e]; }
     uint64_t open(uint32_t blk)
@@ -61,46 +52,22 @@ struct HostProgMem {
     void close(uint32_t) {}
 };
 
-// What k_unstuff_* produce on the device: stuffed zero bytes and restart markers removed, the bit position of every restart
-// boundary recorded, the stream packed into big-endian words. (Fill bytes before a marker -- FF FF Dn -- are dropped as well.)
-void unstuff(const uint8_t* raw, size_t n, std::vector<uint8_t>& clean, std::vector<uint32_t>& rst)
-{
-    clean.clear();
-    rst.clear();
-    clean.reserve(n + 8);
-    size_t q = 0;
-    while (q < n) {
-        const uint8_t* ff = static_cast<const uint8_t*>(memchr(raw + q, 0xFF, n - q));
-        const size_t run = ff ? (size_t)(ff - (raw + q)) : n - q;
-        clean.insert(clean.end(), raw + q, raw + q + run);
-        q += run;
-        if (q >= n) break;
-        // raw[q] == 0xFF
-        const uint8_t next = q + 1 < n ? raw[q + 1] : 0xD9;
-        if (next == 0x00) { clean.push_back(0xFF); q += 2; }
-        else if (next == 0xFF) q += 1;                                  // fill byte
-        else if (next >= 0xD0 && next <= 0xD7) { rst.push_back((uint32_t)clean.size() * 8u); q += 2; }
-        else q += 2;                                                    // cannot happen: the parser ends the scan at the first other marker
-    }
-}
-
-void run_task(const LpProgHostTask& t, std::vector<uint8_t>& clean, std::vector<uint32_t>& rst, std::vector<uint32_t>& words)
+// One scan, the way libjpeg reads it under cv::JpegDecoder (lp_jbits.h): from the raw bytes -- stuffed zeros, fill bytes, restart
+// markers with whatever numbers they carry and byte pairs that only look like markers are the reader's business -- to the marker
+// that ends the scan or the end of the file, whichever the decoder meets.
+void run_task(const LpProgHostTask& t)
 {
     const LpProgScanHost& sh = *t.scan;
-    if (sh.arith) { // a QM-coded scan reads its raw bytes itself (lp_arith_host.h); an impossible code leaves the rest of the scan alone, like libjpeg's warning
-        if (lp_arith_scan(t.data + sh.ecs_off, sh.ecs_len, sh.s, sh.ar, t.coef) == 2) __atomic_or_fetch(t.error, 4u, __ATOMIC_RELAXED); // the scan ended on an unknown marker
-        return;
+    int rc;
+    if (sh.arith) rc = lp_arith_scan(t.data + sh.ecs_off, t.data + t.len, sh.s, sh.ar, t.coef, t.whole_file); // a QM-coded scan (lp_arith_host.h)
+    else {
+        LpJBits b(t.data + sh.ecs_off, t.data + t.len, &sh.tables);
+        HostProgMem m{t.coef, t.coef};
+        rc = lp_prog_scan_with(m, b, sh.s) ? LP_SCAN_OK : LP_SCAN_OUT_OF_DATA;
+        if (rc == LP_SCAN_OK && t.whole_file) rc = b.src.after_scan(sh.s.dri != 0);
     }
-    unstuff(t.data + sh.ecs_off, sh.ecs_len, clean, rst);
-    const LpProgScan& sc = sh.s;
-    const uint32_t rst_cap = sc.dri ? (sc.mcux * sc.mcuy + sc.dri - 1) / sc.dri + 2 : 2;
-    uint32_t n_rst = (uint32_t)rst.size();
-    if (n_rst > rst_cap) { __atomic_or_fetch(t.error, 4u, __ATOMIC_RELAXED); n_rst = rst_cap; }
-    words.assign((clean.size() + 3) / 4 + 4, 0u);
-    for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
-    rst.push_back(0);
-    HostProgMem m{words.data(), words.size(), rst.data(), &sh.tables, t.coef, t.coef};
-    lp_prog_scan(m, sc, (uint32_t)clean.size() * 8u, n_rst);
+    if (rc == LP_SCAN_OUT_OF_DATA) __atomic_or_fetch(t.error, 8u, __ATOMIC_RELAXED);
+    else if (rc == LP_SCAN_BAD_MARKER) __atomic_or_fetch(t.error, 16u, __ATOMIC_RELAXED);
 }
 
 std::atomic<int> g_mode{-1};
@@ -173,12 +140,10 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
         while (hi < tasks.size() && tasks[hi].level == tasks[lo].level) hi++;
         std::atomic<size_t> next{lo};
         auto worker = [&]() {
-            std::vector<uint8_t> clean;
-            std::vector<uint32_t> rst, words;
             for (;;) {
                 const size_t k = next.fetch_add(1, std::memory_order_relaxed);
                 if (k >= hi) break;
-                run_task(tasks[k], clean, rst, words);
+                run_task(tasks[k]);
             }
         };
         // a level with little data is decoded faster than threads start: one thread per ~8 KiB of entropy-coded data (≈0.4 ms of work)
@@ -199,10 +164,15 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
 // Test access (no device work): the coefficients of component `comp` as the hybrid mode's host threads decode them,
 // [block row][block column][64 natural-order values] over the MCU-padded grid. Returns 0, or -1 (not a progressive JPEG the
 // parser accepts) / -3 (dst too small).
+// nthreads < 0: the serial route of ANY sequential file (lp_jpeg_parse_opts force_scans: what a baseline stream the device decoder
+// flagged as irregular is decoded by), on -nthreads threads. Returns -2 when the reference's decoder fails on the file (out of data,
+// unknown marker behind a scan of a multi-scan file), with the coefficients as far as they were decoded.
 extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads)
 {
     LpJpegHeader h;
-    if (lp_jpeg_parse(static_cast<const uint8_t*>(data), len, &h) != LP_PARSE_OK || !h.scan_path || comp < 0 || comp >= h.j.ncomp) return -1;
+    const bool force = nthreads < 0;
+    if (force) nthreads = -nthreads;
+    if (lp_jpeg_parse_opts(static_cast<const uint8_t*>(data), len, &h, force) != LP_PARSE_OK || !h.scan_path || comp < 0 || comp >= h.j.ncomp) return -1;
     size_t total = 0, base = 0;
     for (int c = 0; c < h.j.ncomp; c++) {
         if (c == comp) base = total;
@@ -213,9 +183,9 @@ extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len,
     std::vector<int16_t> coef(total, 0);
     std::vector<uint32_t> lev;
     lp_prog_levels(h.scans, lev);
-    uint32_t err = 0;
+    uint32_t err = h.decode_fails ? 8u : 0u;
     std::vector<LpProgHostTask> tasks;
-    for (size_t q = 0; q < h.scans.size(); q++) tasks.push_back(LpProgHostTask{static_cast<const uint8_t*>(data), &h.scans[q], coef.data(), lev[q], &err});
+    for (size_t q = 0; q < h.scans.size(); q++) tasks.push_back(LpProgHostTask{static_cast<const uint8_t*>(data), len, &h.scans[q], coef.data(), lev[q], &err, !h.one_pass});
     lp_prog_host_run(tasks, nthreads);
     static const uint8_t zz[80] = LP_ZIGZAG_INIT;
     for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | zz[q & 63]] = coef[base + q]; // stored in zigzag order

@@ -19,10 +19,14 @@
 
 struct LpProgHostTask {
     const uint8_t* data;            // the file
+    size_t len;                     // ... all of it: the reader stops where libjpeg's would (lp_jbits.h), not at a precomputed end
     const LpProgScanHost* scan;
     int16_t* coef;                  // the image's first block (zeroed before the first scan)
     uint32_t level;                 // dependency level: a task runs after every task of a lower level
-    uint32_t* error;                // |= 4 when the scan holds more restart markers than its MCU count allows (as the device path reports it)
+    uint32_t* error;                // |= 8: the decoder needed bytes the file does not hold (cv::JpegDecoder's source manager suspends: the
+                                    // reference fails the image); |= 16: a marker code libjpeg does not know is pending behind the scan
+                                    // of a file that is read to its end before pixels are returned (JERR_UNKNOWN_MARKER)
+    bool whole_file;                // several scans: libjpeg reads on to EOI before it returns (jdapimin.c jpeg_start_decompress)
 };
 
 // Runs the tasks level by level on up to `nthreads` threads (0 = LILLIPUT_HIP_PROG_THREADS, default max(min(16, cores), cores / 4) capped at 64).

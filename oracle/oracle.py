@@ -432,6 +432,43 @@ def ref_jpeg_decode(data):
     return _decode_pixels(ref().ref_jpeg_decode_pixels, data)
 
 
+_refjcv = None
+
+
+def ref_cvjpeg():
+    """The reference's own cv::JpegDecoder (object code out of its libopencv_imgcodecs.a) over its own libjpeg.a, or None when
+    oracle/_ref/librefjpegcv.so has not been built (oracle/ref_jpegcv_driver.cpp)."""
+    global _refjcv
+    if _refjcv is None:
+        _refjcv = _load(os.path.join("_ref", "librefjpegcv.so"))
+    return _refjcv
+
+
+_cvjpeg_buf = None
+
+
+def ref_cv_jpeg_decode(data):
+    """What opencv_decoder_read_header + opencv_decoder_read_data return for a JPEG buffer in the reference (opencv.cpp:126-171):
+    the pixels (HxWxC, BGR or gray), or None when cv::JpegDecoder refuses the header or fails the data -- a stream that runs out of
+    bytes is a FAILURE here (OpenCV's source manager suspends; jpeg_mem_src, behind ref_jpeg_decode, would paint the rest grey)."""
+    global _cvjpeg_buf
+    L = ref_cvjpeg()
+    arr, p = _buf(data)
+    w, h, t = C.c_int(), C.c_int(), C.c_int()
+    if _cvjpeg_buf is None:
+        _cvjpeg_buf = np.empty(1 << 20, dtype=np.uint8)
+    while True:
+        rc = L.ref_cvjpeg_decode(p, C.c_size_t(len(arr)), C.byref(w), C.byref(h), C.byref(t), _cvjpeg_buf.ctypes.data_as(_u8p), C.c_size_t(_cvjpeg_buf.size))
+        if rc == -1:
+            _cvjpeg_buf = np.empty(w.value * h.value * 4, dtype=np.uint8)
+            continue
+        break
+    if rc != 0:
+        return None
+    cn = (t.value >> 3) + 1
+    return _cvjpeg_buf[: w.value * h.value * cn].reshape(h.value, w.value, cn).copy()
+
+
 def _coefs(fn, data, comp):
     arr, p = _buf(data)
     bw, bh = C.c_int(), C.c_int()

@@ -21,16 +21,19 @@ def _files():
     return {n: open(os.path.join(DIR, n), "rb").read() for n in sorted(os.listdir(DIR))}
 
 
-def _host_coefs(L, data, comp):
-    """The coefficients the product's host threads decode (test access, no device): [block row][block column][64] or None."""
+def _host_coefs(L, data, comp, with_rc=False):
+    """The coefficients the product's host threads decode (test access, no device): [block row][block column][64] or None.
+    with_rc: (rc, coefficients) -- rc -2 = the scan decoders report that the reference's decoder fails on this file (out of data, an
+    unknown marker behind a scan)."""
     a = np.frombuffer(bytes(data), np.uint8)
     out = np.zeros(1 << 22, np.int16)
     bw, bh = C.c_int(), C.c_int()
     rc = L.lilliput_hip_progressive_coefs_host(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_int(comp), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size),
                                                C.byref(bw), C.byref(bh), C.c_int(2))
     if rc not in (0, -2):
-        return None
-    return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64).copy()
+        return (rc, None) if with_rc else None
+    co = out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64).copy()
+    return (rc, co) if with_rc else co
 
 
 def test_fixture_set_is_what_the_generator_wrote():
@@ -73,16 +76,18 @@ def test_header_verdicts_agree_on_arithmetic_files(hip_lib, oracle):
 
 
 def test_damaged_arithmetic_streams_decode_like_the_reference_library(hip_lib, oracle):
-    """Bit flips, byte substitutions and truncation inside the entropy-coded data: wherever both decoders take the file, the
-    coefficients are the library's. A damaged restart marker sends both through jpeg_resync_to_restart's rules (restated in
-    lp_arith_host.cpp); a byte pair that only looks like a marker (code below 0xC0) inside a scan with a restart interval is read
-    past by both (lp_jpeg_parse.cpp), and a scan that ends on one is refused by both."""
-    if oracle.ref() is None:
-        pytest.skip("oracle/_ref/libref.so not built")
+    """Bit flips, byte substitutions and truncation inside the entropy-coded data. The verdict is the reference's own decoder's
+    (cv::JpegDecoder over its libjpeg.a, oracle/_ref/librefjpegcv.so): a stream that runs out of bytes FAILS there (jdarith.c get_byte
+    cannot suspend under OpenCV's source manager), a damaged one decodes with a warning. Wherever it returns an image the coefficients
+    are the library's. A damaged restart marker sends both through jpeg_resync_to_restart's rules (lp_jbits.h); a byte pair that only
+    looks like a marker (code below 0xC0) inside a scan with a restart interval is read past by both (lp_jpeg_parse.cpp), and a
+    multi-scan file whose scan ends on one is refused by both."""
+    if oracle.ref() is None or oracle.ref_cvjpeg() is None:
+        pytest.skip("oracle/_ref not built")
     rnd = random.Random(5)
     files = {n: d for n, d in _files().items() if "big" not in n}
     names = sorted(files)
-    same = diff = 0
+    same = failed = 0
     odd = []
     for it in range(400):
         n = rnd.choice(names)
@@ -92,29 +97,34 @@ def test_damaged_arithmetic_streams_decode_like_the_reference_library(hip_lib, o
         if lo >= len(d) - 2:
             continue
         q = rnd.randrange(lo, len(d) - 2)
-        mode = rnd.randrange(3)
+        mode = rnd.randrange(4)
         if mode == 0:
             d[q] ^= 1 << rnd.randrange(8)
         elif mode == 1:
             d = d[:q]
+        elif mode == 2:
+            d = d[:q] + b"\xff\xd9"  # cut short and closed: zero bytes from the marker on, a warning, an image
         else:
             d[q] = rnd.randrange(256)
         d = bytes(d)
+        cv = oracle.ref_cv_jpeg_decode(d)
+        rc, mine = _host_coefs(hip_lib, d, 0, with_rc=True)
+        if (cv is None) != (rc != 0):
+            odd.append((it, n, mode, "verdict", cv is None, rc))
+            continue
+        if cv is None:
+            failed += 1
+            continue
         try:
             ref = oracle.ref_jpeg_decode_coefs(d, 0)
         except Exception:
-            continue
-        mine = _host_coefs(hip_lib, d, 0)
-        if mine is None:  # a byte that became a marker code the product's scan walk stops at: libjpeg's resync skips it (not restated)
-            odd.append((it, n, "refused"))
-            continue
+            continue  # (the coefficient interface reads on to EOI and may stumble there; the verdict above stands)
         if np.array_equal(mine.ravel(), ref.ravel()):
             same += 1
         else:
-            diff += 1
-            odd.append((it, n, "differs"))
-    assert same >= 390, (same, diff, odd[:8])
-    assert diff == 0 and not odd, (same, diff, odd[:8])
+            odd.append((it, n, mode, "differs"))
+    assert not odd, (same, failed, odd[:8])
+    assert same >= 250 and failed >= 60, (same, failed)
 
 
 @pytest.mark.gpu
