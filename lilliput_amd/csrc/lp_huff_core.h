@@ -64,6 +64,7 @@ struct LpImgCtx {
     uint32_t n_rst;         // restart boundaries found by the unstuff kernels
     uint32_t total_bits;    // length of the clean stream
     uint32_t total_blocks;
+    uint32_t rst_blocks;    // blocks per restart interval (dri x bpm), 0 = no restart interval
     uint32_t tb, nx;        // derived from blkpack / bpm by lp_ctx_tables(): 5-bit field i (at bit 5 i) belongs to block i of the MCU.
                             // tb: bits 0..1 = the block's DC table slot (0 / 1), bits 2..3 = its AC table slot (2 / 3);
                             // nx: 5 x the index of the block that follows it (0 after the last block of the MCU)
@@ -155,8 +156,11 @@ struct LpLane {
                         // the lane has not seen a block start yet
     uint32_t next_rst;  // bit position of the next restart boundary (stream end when none left)
     uint32_t rst_k;     // index of that boundary
+    uint32_t irregular; // the lane ran over a restart boundary in the middle of a block. In the counting passes that is a lane on a wrong
+                        // state (nobody reads the flag there); in the WRITE pass, whose lanes start from verified states, it is a stream
+                        // whose interval holds more data than its MCUs need -- libjpeg drops such data at the marker (lp_write_pass)
 
-    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), np(0), z(0), bc(0), next_rst(0), rst_k(0) {}
+    LP_HD LpLane(M& m_, const LpImgCtx& ic_) : m(m_), ic(ic_), np(0), z(0), bc(0), next_rst(0), rst_k(0), irregular(0) {}
 
     // The bias of three words changes nothing for the funnel shift (it looks at np mod 32) and makes "the ring slot of word
     // ceil(p / 32)" a bit field of np itself: the policy stores word w at slot (3 - w) mod kRing, and (np >> 5) mod kRing is that slot.
@@ -216,6 +220,7 @@ struct LpLane {
         while (rem < 0) {
             if (rst_k < ic.n_rst) {
                 rst_k++;
+                irregular = 1u;
                 next_rst = rst_k < ic.n_rst ? m.rst_bit(rst_k) : ic.total_bits;
             } else
                 next_rst = 0x7fffffffu;
@@ -568,9 +573,12 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
 #ifndef LP_FLUSH_EVERY
 #define LP_FLUSH_EVERY 4   // 2 / 3 / 4 / 6 measured (8-word ring, top-up every 2 steps): 4 is the best trade of flush instructions against lanes waiting for the flush
 #endif
+// *irregular is set when the restart intervals of the stream do not hold exactly their MCUs (an interval that is short of blocks or
+// holds more data than its blocks need, a boundary inside a block): what libjpeg makes of such a stream -- zero bits to the end of
+// the interval, surplus data dropped at the marker -- is the serial decoder's business (lp_jbits.h); the caller sends the image there.
 template <class M, class Sink, class ZZ>
 LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_t end_p, const LpSubSum& prefix, const ZZ* zigzag,
-                             Sink& sink)
+                             Sink& sink, bool* irregular)
 {
     LpLane<M> L(m, ic);
     L.start(entry.p, entry.bz);
@@ -594,11 +602,17 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         if (m.any2((int32_t)L.np <= nlim, (int32_t)L.bc >= left_bc)) {
             LP_KEEP_UNIFORM_BRANCH();
             if (act) {
-                if (L.z == 0) (void)L.restart_check(pk); // DC predictors restart in k_dc_scan, by MCU index
+                if (L.z == 0) { // DC predictors restart in k_dc_scan, by MCU index
+                    const uint32_t k0 = L.rst_k;
+                    // crossing into interval rst_k: exactly rst_k x (blocks per interval) blocks must lie behind the lane
+                    if (L.restart_check(pk) && L.rst_k != k0 && prefix.nblk + (uint32_t)((int32_t)L.bc >> 5) != L.rst_k * ic.rst_blocks) L.irregular = 1u;
+                }
                 pk = L.peek();
                 // a lane stops at the first block start at or after the end of its subsequence (or when the stream is truncated)
                 const uint32_t p = L.pos();
                 const bool stop = L.z == 0 ? (p >= end_p || (int32_t)L.bc >= left_bc) : p >= ic.total_bits;
+                // the stream ends inside a block this lane is writing: libjpeg finishes the block (and its MCU) on zero bits -- the serial decoder's case
+                if (stop && L.z != 0 && L.seen_block_start()) L.irregular = 1u;
                 done = stop;
                 go = !stop;
                 // past the end of the subsequence inside a block: the lane finishes the block. Instead of coming through here at every
@@ -634,6 +648,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     }
     sink.flush();
     sink.finish();
+    *irregular = L.irregular != 0u;
     return written;
 }
 

@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__
         st.clean_bytes = ta;
         st.n_rst = tb < img.rst_cap ? tb : img.rst_cap;
         if (tb > img.rst_cap) st.error |= 4u;
+        // A baseline image (not a scan's pseudo stream) must hold exactly the restart markers its MCU count asks for; anything else --
+        // one missing, one too many, any at all without a DRI -- is decoded by the serial route, which does what libjpeg does with it
+        // (jdmarker.c jpeg_resync_to_restart, lp_jbits.h)
+        if (img.total_blocks && !img.scan_path && tb != (img.dri ? (img.mcus_x * img.mcus_y + img.dri - 1u) / img.dri - 1u : 0u)) st.error |= 8u;
         uint64_t bits = (uint64_t)ta * 8;
         st.nsub = (uint32_t)((bits + img.sub_bits - 1) / img.sub_bits);
     }
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void k_unstuff_scan(const LpJpeg* __restrict__
 // leave as coalesced dword stores; only the <= 3 bytes of a word shared with the neighbouring chunk use byte stores.
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena,
                                                                const uint2* __restrict__ chunk_cnt, uint32_t* __restrict__ clean_arena,
-                                                               uint32_t* __restrict__ rst_bits)
+                                                               uint32_t* __restrict__ rst_bits, LpJpegState* __restrict__ states)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16 + UNSTUFF_T]; // + one byte per lane where dropped bytes go
@@ -164,6 +168,8 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
             const uint32_t bit = 0x80u << (8u * (j & 3u));
             if (R[j >> 2] & bit) {
                 if (rpos < img.rst_cap) rst_bits[img.rst_off + rpos] = c * 8;
+                // the k-th marker must be RST(k mod 8): libjpeg treats any other number as a lost or repeated interval (lp_jbits.h)
+                if (((u.w[j >> 2] >> (8u * (j & 3u))) & 7u) != (rpos & 7u) && img.total_blocks && !img.scan_path) atomicOr(&states[blockIdx.y].error, 8u);
                 rpos++;
             }
             c += (K[j >> 2] & bit) ? 1u : 0u;
@@ -323,6 +329,7 @@ __device__ __forceinline__ LpImgCtx make_ctx(const LpJpeg& img, const LpJpegStat
     ic.n_rst = st.n_rst;
     ic.total_bits = st.clean_bytes * 8;
     ic.total_blocks = img.total_blocks;
+    ic.rst_blocks = img.dri * img.bpm;
     lp_ctx_tables(ic);
     return ic;
 }
@@ -688,7 +695,9 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.dq0 = sink.dq1 = sink.dq2 = sink.dq3 = 0;
     sink.blk0 = prefix.nblk;
     sink.last = 0xffffffffu;
-    lp_write_pass(m, ic, entry, end_p, prefix, s_zz, sink);
+    bool irregular = false;
+    lp_write_pass(m, ic, entry, end_p, prefix, s_zz, sink, &irregular);
+    if (irregular && !idle) atomicOr(&st.error, 8u); // the restart intervals do not hold exactly their MCUs: the serial decoder's case (lp_jbits.h)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1222,7 +1231,7 @@ void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint3
     dim3 g(max_chunks, nimg);
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean);
-    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst);
+    hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst, d_states);
 }
 
 void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a)

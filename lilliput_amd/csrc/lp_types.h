@@ -142,7 +142,10 @@ struct LpJpegState {
     uint32_t clean_bytes;       // unstuffed length
     uint32_t n_rst;             // restart markers found
     uint32_t nsub;              // ceil(clean_bytes*8 / S)
-    uint32_t error;             // bit 0: unexpected marker in ECS, bit 1: block count mismatch
+    uint32_t error;             // bit 0: a marker other than RSTn inside the entropy-coded data, bit 1: the stream came up short of blocks,
+                                // bit 2: more restart markers than the list holds, bit 3: the restart markers are not RST0..7 in turn, one per
+                                // interval, or an interval does not hold exactly its MCUs. Any of them sends a baseline image through the
+                                // serial decoder, which does with such a stream what libjpeg does (lp_jbits.h)
     uint32_t end_marker_pos;    // raw position of the first non-RST marker (or raw_len)
     uint32_t blocks_decoded;
     uint32_t n_wide;            // blocks that needed a 16-bit (wide) slot

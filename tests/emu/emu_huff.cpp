@@ -74,6 +74,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     LpJpegHeader h;
     int rc = lp_jpeg_parse(data, len, &h);
     if (rc) return -rc;
+    if (h.scan_path) return -17; // not a file the subsequence-parallel kernels take (or one the parser sends through the serial route: open end)
     const LpJpeg& img = h.j;
     if (comp >= img.ncomp) return -10;
     // unstuff (mirrors k_unstuff_*): keep data bytes, one FF per FF..FF00 run, drop RSTn and record boundaries
@@ -81,16 +82,23 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     size_t rl = h.ecs_len;
     std::vector<uint8_t> clean;
     std::vector<uint32_t> rst;
+    bool rst_numbers_ok = true;
     for (size_t q = 0; q < rl; q++) {
         uint8_t c = raw[q], prev = q ? raw[q - 1] : 0, next = q + 1 < rl ? raw[q + 1] : 0xD9;
         if (c == 0xFF) { if (next == 0) clean.push_back(0xFF); continue; }
         if (prev == 0xFF) {
             if (c == 0) continue;
-            if (c >= 0xD0 && c <= 0xD7) { rst.push_back((uint32_t)clean.size() * 8); continue; }
-            return -11; // unexpected marker
+            if (c >= 0xD0 && c <= 0xD7) { // k_unstuff_scatter: the k-th marker must be RST(k mod 8)
+                if ((c & 7u) != (rst.size() & 7u)) rst_numbers_ok = false;
+                rst.push_back((uint32_t)clean.size() * 8);
+                continue;
+            }
+            return -11; // unexpected marker (state error bit 0)
         }
         clean.push_back(c);
     }
+    // k_unstuff_scan: exactly the restart markers the MCU count asks for (state error bit 3)
+    if (!rst_numbers_ok || rst.size() != (size_t)(img.dri ? (img.mcus_x * img.mcus_y + img.dri - 1u) / img.dri - 1u : 0u)) return -16;
     uint32_t total_bits = (uint32_t)clean.size() * 8;
     std::vector<uint32_t> words((clean.size() + 3) / 4 + 64, 0);
     for (size_t q = 0; q < clean.size(); q++) words[q >> 2] |= (uint32_t)clean[q] << (24 - 8 * (q & 3));
@@ -98,7 +106,7 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     rst.push_back(0);
     bool violation = false;
     LpImgCtx ic;
-    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks; lp_ctx_tables(ic);
+    ic.blkpack = (uint32_t)img.blkpack; ic.bpm = img.bpm; ic.n_rst = n_rst; ic.total_bits = total_bits; ic.total_blocks = img.total_blocks; ic.rst_blocks = img.dri * img.bpm; lp_ctx_tables(ic);
     // the engine's schedule (lp_engine.cpp run_decode)
     const LpCkSched cs = lp_make_sched(S, C ? C : 256); // the engine's schedule (lp_engine.cpp run_decode)
     const uint32_t K = cs.K;
@@ -151,12 +159,16 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
     HostSink sink;
     sink.coef = all.data();
     uint32_t written = 0;
+    bool irregular = false;
     for (uint32_t i = 0; i < nsub; i++) {
         LpSubState e = i ? ex[i - 1] : LpSubState{0, 0};
         HostMemWrite m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
         sink.blk0 = prefix[i].nblk;
-        written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink);
+        bool irr = false;
+        written += lp_write_pass(m, ic, e, ex[i].p, prefix[i], zz, sink, &irr);
+        irregular = irregular || irr;
     }
+    if (irregular) return -16; // k_huff_write: the restart intervals do not hold exactly their MCUs (state error bit 3)
     if (written != img.total_blocks) return -14;
     {   // DC differences -> absolute values (k_dc_scan on the device; same lane logic, one range)
         std::vector<int16_t> dcs(img.total_blocks);

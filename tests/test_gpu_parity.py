@@ -122,13 +122,14 @@ def test_unsupported_and_corrupt_streams_fail_loudly(batch, fixture_bytes):
 
 
 def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes):
-    """A baseline stream that ends before its last block (truncated upload) or loses blocks to damage is not an error to libjpeg: it
-    warns, feeds zero bits to the MCU at hand and leaves the following MCUs untouched (flat grey). The device decoder notices the
-    missing blocks and the image is decoded once more by the serial scan decoder, which implements libjpeg's rule: coefficients and
-    pixels must equal the oracle's (jdhuff.c's "if (!entropy->insufficient_data)" restated; itself held to the reference's own
-    libjpeg-turbo on truncated files by tests/test_oracle_golden.py) and, when oracle/_ref is there, the real library's.
-    Round 1 answered ErrDecodingFailed here. What the reference's patched OpenCV source manager does at the end of a truncated
-    memory buffer cannot be checked (its archives are unlinkable): this pins the codec's behaviour, not OpenCV's."""
+    """A baseline stream that ends AT A MARKER before its last block (a short upload closed with EOI, a marker dropped into the data)
+    or loses blocks to damage is not an error to libjpeg: it warns, feeds zero bits to the MCU at hand and leaves the following MCUs
+    untouched (flat grey). The device decoder notices the missing blocks and the image is decoded once more by the serial scan
+    decoder, which implements libjpeg's rule: coefficients and pixels must equal the oracle's (jdhuff.c's
+    "if (!entropy->insufficient_data)" restated; itself held to the reference's own libjpeg-turbo by tests/test_oracle_golden.py) and,
+    when oracle/_ref is there, the real library's. A stream whose bytes simply STOP is another matter: OpenCV's source manager suspends
+    libjpeg there and the reference fails the image (ErrDecodingFailed) -- round 5 read that out of the reference's own
+    cv::JpegDecoder object code and pinned it (tests/test_damaged.py); rounds 2-4 painted such files grey like jpeg_mem_src would."""
     import lilliput_amd as la
 
     have_ref = oracle.ref() is not None
@@ -136,7 +137,10 @@ def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes
     for name in ("sunrise.jpg", "ferry_sunset.jpg", "firefox-gray.jpg", "coast.jpg", "large-sunrise.jpg"):
         data = fixture_bytes[name]
         for frac in (0.3, 0.5, 0.8, 0.95):
-            cut = data[: int(len(data) * frac)]
+            with pytest.raises(la.LilliputError) as e:
+                batch.decode_jpeg(data[: int(len(data) * frac)])
+            assert e.value.code == 2, (name, frac)
+            cut = data[: int(len(data) * frac)] + b"\xff\xd9"
             px, _ = batch.decode_jpeg(cut)
             assert np.array_equal(px, oracle.jpeg_decode(cut)), (name, frac)
             if have_ref:
@@ -144,7 +148,7 @@ def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes
             n += 1
     assert n == 20
     # through the whole transform, one image at a time and as a batch item next to an intact one
-    cut = fixture_bytes["coast.jpg"][: len(fixture_bytes["coast.jpg"]) * 2 // 3]
+    cut = fixture_bytes["coast.jpg"][: len(fixture_bytes["coast.jpg"]) * 2 // 3] + b"\xff\xd9"
     want = oracle.jpeg_encode(oracle.transform_static(oracle.jpeg_decode(cut), 1, 64, 48, oracle.FIT, False), 85)
     d = la.Decoder(cut)
     ops = la.ImageOps(2048)
@@ -152,10 +156,12 @@ def test_short_baseline_streams_decode_like_libjpeg(batch, oracle, fixture_bytes
     ops.Close()
     d.Close()
     assert got == want
-    b = la.Batch(0)
-    res = b.transform([fixture_bytes["coast.jpg"], cut, fixture_bytes["field.jpg"]], 64, 48, quality=85)
-    b.close()
+    b2 = la.Batch(0)
+    res = b2.transform([fixture_bytes["coast.jpg"], cut, fixture_bytes["field.jpg"]], 64, 48, quality=85)
     assert [r.status for r in res] == [0, 0, 0] and res[1].data == want
+    res = b2.transform([fixture_bytes["coast.jpg"], cut[:-2], fixture_bytes["field.jpg"]], 64, 48, quality=85)
+    assert [r.status for r in res] == [0, 2, 0]
+    b2.close()
 
 
 def test_corrupt_streams_never_hang_and_are_deterministic(batch):
@@ -194,7 +200,8 @@ def test_corrupt_streams_never_hang_and_are_deterministic(batch):
     for a, b2 in zip(r1, r2):
         assert a.status in (0, 1, 2, 4)
         assert a.status == b2.status and a.data == b2.data
-    # libjpeg never fails on damaged entropy data (it warns and carries on); since the short-stream fallback neither does this path
+    # libjpeg does not fail on damaged entropy data that ends at a marker (it warns and carries on; every file here ends with EOI):
+    # neither does this path. (Verdicts and bytes against the reference's own decoder: tests/test_damaged.py.)
     assert all(a.status == 0 for a in r1), [a.status for a in r1]
     # and the engine is still healthy afterwards
     ok = batch.transform([bases[0]], 64, 64, quality=80)[0]
@@ -475,18 +482,20 @@ def test_batch_transform_mixed_inputs(batch, oracle, fixture_bytes):
     huge = bytearray(fixture_bytes["sunrise.jpg"])  # a frame header claiming 65 000 x 65 000 pixels: refused by itself, the rest untouched
     sof = huge.index(b"\xff\xc0")
     huge[sof + 5 : sof + 9] = bytes([0xFD, 0xE8, 0xFD, 0xE8])
-    sources = [fixture_bytes[n] for n in names] + [bytes(huge), b"not a jpeg", fixture_bytes["large-sunrise.jpg"][:100000]]
+    sources = [fixture_bytes[n] for n in names] + [bytes(huge), b"not a jpeg", fixture_bytes["large-sunrise.jpg"][:100000], fixture_bytes["large-sunrise.jpg"][:100000] + b"\xff\xd9"]
     import lilliput_amd as la
 
     res = batch.transform(sources, 64, 64, quality=85)
-    assert res[-3].status == 3  # ErrBufTooSmall, what lilliput answers for a frame beyond NewImageOps(maxSize)
+    assert res[-4].status == 3  # ErrBufTooSmall, what lilliput answers for a frame beyond NewImageOps(maxSize)
     ops = la.ImageOps(2048)
     for n, r in zip(names, res):
         assert r.status == 0, n
         _check_thumbnail(la, ops, oracle, fixture_bytes[n], r.data, 64, 64, 85, n)
     ops.Close()
-    assert res[-2].status == 1
-    # the truncated file decodes like libjpeg decodes it (the part that arrived, grey below): test_short_baseline_streams_decode_like_libjpeg
+    assert res[-3].status == 1
+    # a file whose bytes simply stop fails in the reference (cv::JpegDecoder's source manager suspends libjpeg: ErrDecodingFailed); cut
+    # short and closed with EOI it decodes like libjpeg decodes it (the part that arrived, grey below): tests/test_damaged.py
+    assert res[-2].status == 2
     assert res[-1].status == 0
     cut = oracle.jpeg_decode(sources[-1])
     assert res[-1].data == oracle.jpeg_encode(oracle.transform_static(cut, oracle.jpeg_info(sources[-1])["orientation"], 64, 64, oracle.FIT, False), 85)
