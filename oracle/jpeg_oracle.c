@@ -798,10 +798,15 @@ void lo_idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int str
     }
 }
 
+static int planes_from_coefs(lo_dec* D);
 static int decode_planes(const uint8_t* d, size_t n, lo_dec* D)
 {
     int rc = decode_coefs(d, n, D);
     if (rc) return rc;
+    return planes_from_coefs(D);
+}
+static int planes_from_coefs(lo_dec* D)
+{
     lo_jpeg_info* in = &D->in;
     for (int c = 0; c < in->ncomp; c++) {
         int pw = D->bw[c] * 8, ph = D->bh[c] * 8;
@@ -895,12 +900,45 @@ void lo_ycc_to_bgr(int y, int cb, int cr, uint8_t* bgr)
 
 /* Public: decode to pixels the way opencv_decoder_read_data does: 3 comps -> BGR interleaved,
  * 1 comp -> 8-bit gray. */
+static int pixels_from_planes(lo_dec* Dp, uint8_t* out, size_t cap, int* w, int* h, int* ch);
 int lo_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* w, int* h, int* ch)
 {
     lo_dec D;
     memset(&D, 0, sizeof(D));
     int rc = decode_planes(d, n, &D);
     if (rc) { dec_free(&D); return rc; }
+    return pixels_from_planes(&D, out, cap, w, h, ch);
+}
+
+/* The back half alone -- dequantisation + jidctint.c in its C (32-bit) arithmetic, upsampling, colour -- on coefficients the caller
+ * brings (coefs[c] = [bh][bw][64] natural order as lo_jpeg_decode_coefs / jpeg_read_coefficients hand them out; baseline and
+ * sequential files: the quantisation tables of the header). For streams whose entropy decode is somebody else's business (damaged
+ * data: the real library's coefficients, tests/test_damaged.py) and for telling an IDCT difference from an entropy-decode one:
+ * libjpeg-turbo's SIMD IDCT works in 16-bit lanes and wraps on dequantised values a real image cannot have. */
+int lo_jpeg_pixels_from_coefs(const uint8_t* d, size_t n, const int16_t* const* coefs, uint8_t* out, size_t cap, int* w, int* h, int* ch)
+{
+    lo_dec D;
+    memset(&D, 0, sizeof(D));
+    int rc = lo_jpeg_read_header(d, n, &D.in);
+    if (rc) return rc;
+    for (int c = 0; c < D.in.ncomp; c++) {
+        D.bw[c] = D.in.mcus_x * D.in.hs[c];
+        D.bh[c] = D.in.mcus_y * D.in.vs[c];
+        const size_t ne = (size_t)D.bw[c] * D.bh[c] * 64;
+        D.coef[c] = (int16_t*)malloc(ne * sizeof(int16_t));
+        if (!D.coef[c]) { dec_free(&D); return LO_ERR_BUF; }
+        memcpy(D.coef[c], coefs[c], ne * sizeof(int16_t));
+    }
+    rc = planes_from_coefs(&D);
+    if (rc) { dec_free(&D); return rc; }
+    return pixels_from_planes(&D, out, cap, w, h, ch);
+}
+
+static int pixels_from_planes(lo_dec* Dp, uint8_t* out, size_t cap, int* w, int* h, int* ch)
+{
+    lo_dec D = *Dp;
+    int rc = 0;
+    (void)rc;
     int W = D.in.width, H = D.in.height, C = D.in.ncomp == 1 ? 1 : 3;
     *w = W; *h = H; *ch = C;
     if ((size_t)W * H * C > cap) { dec_free(&D); return LO_ERR_BUF; }

@@ -484,6 +484,21 @@ def _coefs(fn, data, comp):
         return out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64).copy()
 
 
+def jpeg_pixels_from_coefs(data, coefs):
+    """Restatement, back half only: dequantisation + islow IDCT in its C (32-bit) arithmetic, upsampling, colour conversion on the
+    coefficients in `coefs` (one [bh][bw][64] int16 array per component, e.g. the real library's) with the tables of `data`'s header."""
+    arr, p = _buf(data)
+    cs = [np.ascontiguousarray(c, dtype=np.int16) for c in coefs]
+    ptrs = (_i16p * len(cs))(*[c.ctypes.data_as(_i16p) for c in cs])
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    info = jpeg_info(data)
+    out = np.empty(info["width"] * info["height"] * 3, dtype=np.uint8)
+    rc = lib().lo_jpeg_pixels_from_coefs(p, C.c_size_t(len(arr)), ptrs, out.ctypes.data_as(_u8p), C.c_size_t(out.size), C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError("pixels from coefficients failed rc=%d" % rc)
+    return out[: w.value * h.value * ch.value].reshape(h.value, w.value, ch.value).copy()
+
+
 def jpeg_decode_coefs(data, comp):
     return _coefs(lib().lo_jpeg_decode_coefs, data, comp)
 

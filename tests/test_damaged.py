@@ -160,6 +160,22 @@ def test_device_lane_logic_hands_over_every_stream_it_would_decode_differently(e
 
 
 # ------------------------------------------------------------------------------------------------ GPU half
+def _reference_pixels(oracle, data):
+    """(pixels of the reference's decoder or None, second acceptable answer or None). The second answer exists where damaged bits
+    produce dequantised coefficients a real image cannot have: libjpeg-turbo's SIMD IDCT (x86-64: 16-bit lanes, wrapping adds,
+    saturating packs) and its C IDCT (32-bit) then differ; the product computes such blocks in the C path's arithmetic.
+    The entropy decode is held to the library either way: the second answer is the restatement's BACK HALF run on the library's own
+    coefficients."""
+    cv = oracle.ref_cv_jpeg_decode(data)
+    if cv is None:
+        return None, None
+    try:
+        alt = oracle.jpeg_pixels_from_coefs(data, [oracle.ref_jpeg_decode_coefs(data, c) for c in range(3 if cv.shape[2] == 3 else 1)])
+    except ValueError:
+        return cv, None
+    return cv, (None if np.array_equal(alt, cv) else alt)
+
+
 @pytest.mark.gpu
 def test_damaged_streams_decode_like_the_reference_decoder_on_the_device(batch, oracle):
     """>= 600 damaged / cut / padded baseline streams through lilliput_hip_decode_jpeg (what opencv_decoder_read_data does): the
@@ -168,9 +184,9 @@ def test_damaged_streams_decode_like_the_reference_decoder_on_the_device(batch, 
 
     _need_refs(oracle)
     cases = jpeg_damage.cases(5)
-    bad, ok, failed = [], 0, 0
+    bad, ok, failed, c_arith = [], 0, 0, 0
     for tag, data in cases:
-        cv = oracle.ref_cv_jpeg_decode(data)
+        cv, alt = _reference_pixels(oracle, data)
         try:
             px, _ = batch.decode_jpeg(data)
         except lilliput_amd.LilliputError as e:
@@ -181,12 +197,14 @@ def test_damaged_streams_decode_like_the_reference_decoder_on_the_device(batch, 
             continue
         if cv is None:
             bad.append((tag, "decodes, the reference fails"))
-        elif not np.array_equal(px, cv):
-            bad.append((tag, "pixels differ", int((px != cv).any(axis=2).sum())))
-        else:
+        elif np.array_equal(px, cv):
             ok += 1
+        elif alt is not None and np.array_equal(px, alt):
+            c_arith += 1
+        else:
+            bad.append((tag, "pixels differ", int((px != cv).any(axis=2).sum())))
     assert not bad, bad[:8]
-    assert len(cases) >= 600 and ok >= 400 and failed >= 100, (ok, failed)
+    assert len(cases) >= 600 and ok >= 400 and failed >= 100 and c_arith <= ok // 20, (ok, failed, c_arith)
     # the engine is healthy afterwards
     base = jpeg_damage.bases()[0][1]
     assert np.array_equal(batch.decode_jpeg(base)[0], oracle.ref_cv_jpeg_decode(base))
@@ -199,7 +217,7 @@ def test_damaged_progressive_streams_decode_like_the_reference_decoder_on_the_de
     _need_refs(oracle)
     bad, ok, failed = [], 0, 0
     for tag, data in jpeg_damage.cases(6, per_base=40, progressive=True):
-        cv = oracle.ref_cv_jpeg_decode(data)
+        cv, alt = _reference_pixels(oracle, data)
         try:
             px, _ = batch.decode_jpeg(data)
         except lilliput_amd.LilliputError as e:
@@ -208,7 +226,7 @@ def test_damaged_progressive_streams_decode_like_the_reference_decoder_on_the_de
             else:
                 failed += 1
             continue
-        if cv is None or not np.array_equal(px, cv):
+        if cv is None or not (np.array_equal(px, cv) or (alt is not None and np.array_equal(px, alt))):
             bad.append((tag, "decodes" if cv is None else "pixels differ"))
         else:
             ok += 1
@@ -225,8 +243,8 @@ def test_damaged_streams_as_items_of_a_batch(batch, oracle):
     items = [d for _, d in cases]
     want = []
     for _, d in cases:
-        cv = oracle.ref_cv_jpeg_decode(d)
-        want.append(None if cv is None else oracle.jpeg_encode(oracle.transform_static(cv, 1, 64, 64, oracle.FIT, False), 80))
+        cv, alt = _reference_pixels(oracle, d)
+        want.append(None if cv is None else [oracle.jpeg_encode(oracle.transform_static(x, 1, 64, 64, oracle.FIT, False), 80) for x in (cv, alt) if x is not None])
     for _ in range(2):
         res = batch.transform(items, 64, 64, quality=80)
         bad = []
@@ -234,7 +252,7 @@ def test_damaged_streams_as_items_of_a_batch(batch, oracle):
             if w is None:
                 if r.status not in (1, 2):
                     bad.append((tag, "status", r.status, "the reference fails"))
-            elif r.status != 0 or r.data != w:
+            elif r.status != 0 or r.data not in w:
                 bad.append((tag, "status", r.status, "bytes differ" if r.status == 0 else ""))
         assert not bad, bad[:8]
     assert sum(w is not None for w in want) >= 250 and sum(w is None for w in want) >= 80

@@ -259,7 +259,7 @@ def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
     import lilliput_amd
 
     rng = np.random.default_rng(0)
-    n_img = n_err = 0
+    n_img = n_err = n_same = 0
     for i, desc, data in _cases(8, 10, lo=40, hi=200):
         sos = data.index(b"\xff\xda")
         for k in range(12):
@@ -286,9 +286,14 @@ def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
                 n_err += 1
                 continue
             n_img += 1
-            if max(int(np.abs(oracle.jpeg_decode_coefs(d, c)).max()) for c in range(1 if desc[2] else 3)) < 1024:
-                assert np.array_equal(outs[0], exp), (i, k, desc)
-    assert n_img > 50 and n_err > 3, (n_img, n_err)
+            if np.array_equal(outs[0], exp):
+                n_same += 1
+                continue
+            # differing pixels are allowed in ONE case: damaged bits produced dequantised coefficients beyond the 16-bit lanes of
+            # libjpeg-turbo's SIMD IDCT (quality-1 tables multiply by 255), which wraps there; the product computes such blocks with
+            # the C path's 32-bit arithmetic, and so does the restatement
+            assert np.array_equal(outs[0], oracle.jpeg_decode(d)), (i, k, desc)
+    assert n_img > 50 and n_err > 3 and n_same >= n_img * 9 // 10, (n_img, n_err, n_same)
 
 
 @pytest.mark.gpu
