@@ -3,7 +3,12 @@
 (ImageOps.Transform hot path: decode -> orientation/crop -> resize -> encode) on N x MI355X.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...            ONE process drives N GPUs through lilliput_hip_node_transform (one chunk queue in host memory,
+                                          device-affine shares + work stealing): what a cgo service links; no PyTorch, no torchrun
+  python bench.py --gpus N --ranks ...    one process per GPU, spawned here, meeting through files (lilliput_amd.dist backend "file"): no PyTorch
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+                                          one rank per GPU under torchrun (how the driver launches N > 1): barrier / reductions over RCCL
+  (--alias-devices 0,0: list the device of every slot yourself -- the same GPU twice exercises the N = 2 plumbing on a one-GPU box)
 
 One "step" = one pass of the hot path over one batch: 1024 distinct synthetic 4096x4096 4:2:0 q90 JPEGs per GPU handed over as
 host buffers, thumbnails returned in host buffers -- header walk, staging, H2D, every device stage and the D2H of the results are
@@ -669,6 +674,171 @@ def main_firehose(args, ranks, la):
         sys.exit(3)
 
 
+def node_devices(la, args, alias):
+    """The HIP device of every slot of the node; fails loudly when the box has fewer GPUs than --gpus asks for."""
+    visible = la.lib().lilliput_hip_device_count()
+    if visible <= 0:
+        log("[bench] no HIP device visible")
+        sys.exit(2)
+    if alias:
+        if any(d < 0 or d >= visible for d in alias):
+            log("[bench] --alias-devices %r: this box has %d GPU(s)" % (alias, visible))
+            sys.exit(2)
+        return alias
+    if args.gpus > visible:
+        log("[bench] --gpus %d, but only %d GPU(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?). To exercise the N-GPU plumbing on fewer "
+            "GPUs name the device of every slot: --alias-devices 0,0" % (args.gpus, visible))
+        sys.exit(2)
+    return list(range(args.gpus))
+
+
+def spawn_ranks(args, alias):
+    """--gpus N --ranks: one process per GPU without torchrun or PyTorch. The children are this script again with RANK / LOCAL_RANK /
+    WORLD_SIZE set and lilliput_amd.dist's "file" backend (barrier, max-reduce and gathers through a rendezvous directory); rank 0
+    prints the JSON line, which is passed through."""
+    import subprocess
+    import tempfile
+
+    import lilliput_amd as la
+
+    devices = node_devices(la, args, alias)
+    rdv = tempfile.mkdtemp(prefix="lilliput_rdv_")
+    os.rmdir(rdv)  # the ranks create it; the last one out removes it
+    argv = [a for a in sys.argv[1:] if a != "--ranks"]
+    procs = []
+    for r in range(len(devices)):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(devices[r]), WORLD_SIZE=str(len(devices)), LILLIPUT_BENCH_BACKEND="file", LILLIPUT_BENCH_RDV=rdv)
+        env.pop("MASTER_ADDR", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def main_node(args, alias):
+    """--gpus N in ONE process: the headline workload through lilliput_hip_node_create(devices) + lilliput_hip_node_transform -- the
+    multi-GPU entry point of the C ABI, what a cgo service links (cgo cannot be one process per GPU). A step = N x --batch images: the
+    k-th contiguous share of the item array sits in a pinned arena next to device k (lilliput_hip_host_alloc(.., k)) and is device k's
+    share of the chunk queue (it claims there first and steals elsewhere once it is dry, lp_batch.cpp LpPipeShared). No PyTorch, no
+    RCCL: the queue is a host atomic; no pixel or bitstream byte crosses between GPUs."""
+    import numpy as np
+
+    import lilliput_amd as la
+
+    devices = node_devices(la, args, alias)
+    n_dev = len(devices)
+    if args.ingest in ("staged", "register"):
+        os.environ["LILLIPUT_HIP_INGEST"] = args.ingest
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, 0, 1)
+    distinct = [open(p, "rb").read() for p in paths]
+    if args.orientation != 1:
+        tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([args.orientation, 0, 0, 0]) + b"\x00\x00\x00\x00"
+        app1 = b"\xff\xe1" + (len(tiff) + 8).to_bytes(2, "big") + b"Exif\x00\x00" + tiff
+        distinct = [d[:2] + app1 + d[2:] for d in distinct]
+    arenas, per_dev = [], []
+    for k, dev in enumerate(devices):
+        if args.ingest == "pinned":
+            a = la.HostArena(sum(len(d) + 64 for d in distinct) + 4096, dev)  # on device k's NUMA node, filled BEFORE the timed region
+            arenas.append(a)
+            per_dev.append([a.put(d) for d in distinct])
+        else:
+            per_dev.append(per_dev[0] if per_dev else [np.frombuffer(d, dtype=np.uint8) for d in distinct])
+    # share k of the item array = device k's images (its own rotation of the set: per-GPU work is fixed, weak scaling)
+    sources = [per_dev[k][(i + k * 7) % len(distinct)] for k in range(n_dev) for i in range(args.batch)]
+    n_items = len(sources)
+    c_in = sum(a.size for a in sources) / n_items
+    streams = int(os.environ.get("LILLIPUT_HIP_STREAMS", "4"))
+    node = la.Node(devices)
+    node.prepare(sources, dst_cap=256 << 10)
+
+    def step():
+        node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+
+    for _ in range(args.warmup):
+        step()
+    per_device = [{"images": 0, "staged_bytes": 0} for _ in devices]
+    stolen = chunks = 0
+    t0 = time.time()  # (one process: the calls are synchronous, host bytes in -> host bytes out; nothing is in flight when a call returns)
+    for _ in range(args.steps):
+        step()
+    elapsed = time.time() - t0
+    for _ in range(1):  # the shares of the LAST step (the library reports per call)
+        for k, st in enumerate(node.device_stats()):
+            per_device[k] = st
+        q = node.queue_stats()
+        chunks, stolen = q["chunks"], q["stolen"]
+    res = node.results()
+    ok = sum(1 for r in res if r.status == 0)
+    c_out = sum(len(r.data) for r in res) / max(1, len(res))
+    digest = hashlib.sha256(res[0].data).hexdigest()[:16] if res and res[0].status == 0 else None
+    verified, mismatched = 0, []
+    if args.verify > 0:
+        from oracle import oracle as O
+
+        O.lib()
+        use_ref = O.ref() is not None
+        for k in range(n_dev):  # `--verify` outputs of every device's share of the last step, byte for byte against the reference CPU path
+            seen = set()
+            for j in range(args.verify * 4):
+                if len(seen) >= min(args.verify, args.batch):
+                    break
+                i = k * args.batch + int.from_bytes(hashlib.sha256(b"%d:%d:%d" % (args.steps - 1, k, j)).digest()[:8], "little") % args.batch
+                if i in seen:
+                    continue
+                seen.add(i)
+                exp = O.transform_jpeg_thumbnail(bytes(sources[i]), args.out, args.out, 85, use_ref=use_ref)
+                verified += 1
+                if res[i].status != 0 or res[i].data != exp:
+                    mismatched.append(i)
+    excl = None
+    if not args.no_extra_legs:
+        excl = exclusive_leg(la, devices[0], sources[: args.batch], args)
+    value = n_items * args.steps / elapsed
+    roof = make_roofline(excl, None, 0, c_in, c_out, args, streams, None) if excl else {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    plane_b = 1.5 * args.size * args.size
+    e2e_bytes = c_in + 2 * plane_b + 3 * 256 * 256 + c_out
+    out = {
+        "metric": "images/sec (%dx%d->%dx%d JPEG q85)" % (args.size, args.size, args.out, args.out),
+        "value": round(value, 2), "unit": "images/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU (%d per step) -> %dx%d JPEG q85, ImageOpsFit (%s); sources in %s" % (
+                       args.batch, args.size, args.size, n_items, args.out, args.out,
+                       "BASELINE configs[1]" if (args.size, args.out, args.orientation) == (4096, 256, 1) else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d" % (args.size, args.out, args.orientation),
+                       "one lilliput_hip_host_alloc pinned arena per device, on that device's NUMA node (zero-copy ingest)" if args.ingest == "pinned" else "host memory, ingest mode %s" % args.ingest),
+                   "timed_region": "host bytes in -> host bytes out: header walk + staging + H2D + decode/resample/encode + D2H (lilliput_hip_node_transform, one call per step for all devices)",
+                   "parallelism": "ONE process, %d device slots %r, one chunk queue in host memory: device k claims from the k-th share of the chunk list first and steals from the fullest "
+                                  "share once its own is dry; no PyTorch, no RCCL (nothing to exchange: no pixel or bitstream byte crosses between GPUs)" % (n_dev, devices),
+                   "devices": devices, "aliased_devices": len(set(devices)) < n_dev,
+                   "per_device_last_step": [{"slot": k, "device": devices[k], "images": per_device[k]["images"], "staged_MB": round(per_device[k]["staged_bytes"] / 1e6, 1),
+                                             "h2d_GBps": round(per_device[k]["staged_bytes"] / max(1e-9, elapsed / args.steps) / 1e9, 2)} for k in range(n_dev)],
+                   "chunks_last_step": chunks, "chunks_stolen_last_step": stolen,
+                   "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out), "engines_per_gpu": streams,
+                   "ok_images": ok, "first_output_sha256_16": digest, "verified_outputs": verified, "verified_identical": not mismatched and ok == n_items,
+                   "verified_against": "oracle.transform_jpeg_thumbnail (reference libjpeg-turbo decode -> INTER_AREA restatement -> reference libjpeg-turbo encode), byte for byte, "
+                                       "outputs of every device's share of the last timed step picked by sha256(step:slot:j)",
+                   "end_to_end_algorithmic_bytes_per_image": int(e2e_bytes),
+                   "end_to_end_hbm_roofline_frac": round(e2e_bytes * value / n_dev / (HBM_PEAK_GBS * 1e9), 5)},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q90 -> %dx%d q85" % (args.size, args.size, args.out, args.out))
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    print(json.dumps(out), flush=True)
+    node.close()
+    for a in arenas:
+        a.close()
+    if args.verify > 0 and (mismatched or ok != n_items):
+        log("[bench] CORRECTNESS GATE FAILED (node mode): mismatched outputs %r, ok images %d of %d" % (mismatched, ok, n_items))
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -697,9 +867,22 @@ def main():
                          "abi = the drop-in path under service concurrency (--threads callers, each NewDecoder -> ImageOps.Transform -> Close through Part C on the headline sources); "
                          "png2webp = BASELINE configs[2]; animated = BASELINE configs[3] (both: --threads callers, --batch requests per step)")
     ap.add_argument("--verify", type=int, default=8, help="outputs of the last timed step compared byte for byte with the oracle's after the timed region (0 = none)")
+    ap.add_argument("--ranks", action="store_true", help="--gpus N without torchrun: spawn one process per GPU (file rendezvous, no PyTorch) instead of driving the N GPUs from this one process")
+    ap.add_argument("--alias-devices", default="", help="comma list: the HIP device of every one of the --gpus slots (default 0..N-1); naming one GPU twice runs the multi-GPU plumbing on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
     args = ap.parse_args()
+
+    alias = [int(x) for x in args.alias_devices.split(",") if x.strip() != ""]
+    if alias and len(alias) != args.gpus:
+        log("[bench] --alias-devices names %d devices for --gpus %d" % (len(alias), args.gpus))
+        sys.exit(2)
+    if os.environ.get("WORLD_SIZE") is None and (args.gpus > 1 or alias):
+        # not under torchrun: this process owns the node
+        if args.workload != "jpeg4096":
+            log("[bench] --gpus N without torchrun drives the headline workload (jpeg4096); the other workloads run one rank per GPU under torchrun")
+            sys.exit(2)
+        return spawn_ranks(args, alias) if args.ranks else main_node(args, alias)
 
     from lilliput_amd.dist import Ranks
 
@@ -742,6 +925,11 @@ def main():
     c_in = sum(a.size for a in sources) / args.batch
     ndev = max(1, la.lib().lilliput_hip_device_count())
     streams = int(os.environ.get("LILLIPUT_HIP_STREAMS", "4"))
+    if alias:                       # (spawned ranks of --ranks --alias-devices: this rank's slot names its device)
+        local_rank = alias[rank % len(alias)]
+    elif world > ndev and ranks.backend == "nccl":
+        log("[bench] %d ranks but %d visible GPUs" % (world, ndev))
+        sys.exit(2)
 
     b = la.Batch(local_rank % ndev)
     if args.sub_bits:
@@ -848,7 +1036,9 @@ def main():
                        "timed_region": "compressed bytes resident in HBM -> thumbnails in host memory (device pipeline only)" if args.resident else
                                        "host bytes in -> host bytes out: header walk + staging + H2D + decode/resample/encode + D2H (lilliput_hip_batch_transform)",
                        "distinct_sources": len(distinct), "mean_input_bytes": int(c_in), "mean_output_bytes": int(c_out),
-                       "parallelism": "independent images sharded per rank, no data-path collective", "engines_per_gpu": streams,
+                       "parallelism": "one process per GPU, independent images sharded per rank, no data-path collective; barrier / max-reduce / gathers over %s" % (
+                           {"nccl": "RCCL (torch.distributed)", "gloo": "gloo (torch.distributed)", "file": "a rendezvous directory (no PyTorch in the process)", "none": "nothing (one rank)"}[ranks.backend]),
+                       "engines_per_gpu": streams,
                        "ok_images": ok, "first_output_sha256_16": digest,
                        "verified_outputs": sum(g[0] for g in gate), "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
                        "verified_against": "oracle.transform_jpeg_thumbnail (reference libjpeg-turbo decode -> INTER_AREA restatement -> reference libjpeg-turbo encode), byte for byte, "

@@ -386,6 +386,10 @@ void lilliput_hip_node_destroy(lilliput_hip_node n);
 int lilliput_hip_node_device_count(lilliput_hip_node n);
 int lilliput_hip_node_transform(lilliput_hip_node n, lilliput_batch_item* items, size_t n_items, const lilliput_batch_options* opt); /* like lilliput_hip_batch_transform */
 void lilliput_hip_node_device_stats(lilliput_hip_node n, int k, double out[2]); /* device k in the last transform: images served, bytes staged */
+void lilliput_hip_node_queue_stats(lilliput_hip_node n, double out[2]); /* the last transform: chunks in the queue, chunks a device took from another device's share.
+ * The chunk list is dealt out in contiguous shares, device k (the k-th entry of `devices`) first claims from the k-th share -- keep the k-th part of a
+ * batch's sources in lilliput_hip_host_alloc(.., device k) memory and every DMA read stays on the near NUMA node -- and steals from the fullest share
+ * once its own is dry (static block assignment, then work stealing for the tail / for heterogeneous sizes). */
 
 /* Per-stage device milliseconds of the last run (HIP events on the engine's stream): unstuff, huffman (total), idct,
  * colour, resize, encode, then the huffman breakdown: speculate, verify, scan, write; plus the verify rounds. */

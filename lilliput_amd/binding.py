@@ -117,6 +117,8 @@ def lib():
     L.lilliput_hip_node_transform.argtypes = [C.c_void_p, C.POINTER(_Item), C.c_size_t, C.POINTER(_BatchOptions)]
     L.lilliput_hip_node_device_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.lilliput_hip_node_device_stats.restype = None
+    L.lilliput_hip_node_queue_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.lilliput_hip_node_queue_stats.restype = None
     L.lilliput_hip_decode_jpeg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
     L.lilliput_hip_decode_jpeg_coefs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lilliput_hip_decode_jpeg_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -510,6 +512,11 @@ class Node(Batch):
             lib().lilliput_hip_node_device_stats(self._n, k, v)
             out.append({"images": int(v[0]), "staged_bytes": int(v[1])})
         return out
+
+    def queue_stats(self):
+        v = (C.c_double * 2)()
+        lib().lilliput_hip_node_queue_stats(self._n, v)
+        return {"chunks": int(v[0]), "stolen": int(v[1])}
 
     def close(self):
         if self._n:

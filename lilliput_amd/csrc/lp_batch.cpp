@@ -150,6 +150,7 @@ struct LpBatch {
     int n_extra_copy = 0;
     int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
     size_t last_images = 0;                    // images this device's engines served in the last transform
+    size_t last_chunks = 0, last_stolen = 0;   // (devs[0] of a call) chunks of the last transform, and how many a device took from another device's share
     ~LpBatch() { for (auto o : other_ops) if (o) lilliput_image_ops_close(o); if (shared_copy) { (void)hipStreamSynchronize(shared_copy); (void)hipStreamDestroy(shared_copy); } for (auto q : extra_copy) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); } }
     LpEngine& eng0() { return *parts[0].eng; }
     bool ensure_parts(size_t n)
@@ -835,10 +836,44 @@ struct LpPipeJob {
 };
 // The chunks of a batch form one queue; every part's stager claims the next chunk when one of its slots is free, so the parts
 // finish within a chunk of each other whatever the mix of image sizes (and whichever copy stream the link served first).
+// The chunk queue of one call. With several devices (lilliput_hip_node_*) the chunks are dealt out as SURVEY.md 8(e) asks: device k
+// owns the k-th contiguous share of the chunk list (static block assignment: a caller that keeps the k-th share of its sources in
+// pinned memory next to device k gets its DMA reads from the near NUMA node) and claims from it first; a device that has run its
+// share dry steals from the share with the most chunks left, so heterogeneous streams and unequal devices still finish together.
+// The cursors are plain host atomics: one process drives every device of the node, no message crosses between them.
 struct LpPipeShared {
     std::vector<LpPipeJob> jobs;
-    std::atomic<size_t> next{0};
+    struct Share { std::atomic<size_t> next{0}; size_t end = 0; };
+    std::unique_ptr<Share[]> share;     // [n_share]: share k = jobs [share[k].next, share[k].end)
+    size_t n_share = 1;
+    std::atomic<size_t> stolen{0};
     double t0 = 0;
+    void deal(size_t devices)
+    {
+        n_share = std::max<size_t>(1, devices);
+        share.reset(new Share[n_share]);
+        for (size_t k = 0; k < n_share; k++) {
+            share[k].next.store(jobs.size() * k / n_share);
+            share[k].end = jobs.size() * (k + 1) / n_share;
+        }
+    }
+    // the next chunk for an engine of device `home` (its index in the node), or jobs.size() when the call has none left
+    size_t claim(size_t home)
+    {
+        Share& own = share[home % n_share];
+        size_t j = own.next.fetch_add(1);
+        if (j < own.end) return j;
+        for (;;) { // steal from the fullest share
+            size_t best = n_share, left = 0;
+            for (size_t k = 0; k < n_share; k++) {
+                const size_t nx = share[k].next.load();
+                if (nx < share[k].end && share[k].end - nx > left) { left = share[k].end - nx; best = k; }
+            }
+            if (best == n_share) return jobs.size();
+            j = share[best].next.fetch_add(1);
+            if (j < share[best].end) { stolen.fetch_add(1); return j; }
+        }
+    }
 };
 struct LpPipe {
     std::vector<size_t> mine;           // claimed jobs, in order (job k of this part uses upload slot k % LP_UPLOAD_SLOTS)
@@ -867,7 +902,7 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
             pp.cv.wait(lk, [&] { return pp.abort || k < pp.done + LP_UPLOAD_SLOTS; }); // slot k % SLOTS: its previous chunk has been decoded
             if (pp.abort) break;
         }
-        const size_t ji = sh.next.fetch_add(1);
+        const size_t ji = sh.claim((size_t)b->node_index);
         if (ji >= sh.jobs.size()) break;
         const double t0 = now();
         LpPipeJob& job = sh.jobs[ji];
@@ -1016,6 +1051,7 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
                 part.rounds = 0; part.rc = 0; part.stage_ms = part.stall_ms = part.register_ms = 0; part.staged_bytes = part.copied_bytes = part.direct_bytes = 0;
                 part.failed_chunks = 0; part.err.clear();
             }
+        sh.deal(devs.size());
         const LpSink sink{b, items};
         sh.t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         std::vector<std::thread> th;
@@ -1042,6 +1078,8 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
             b->other.clear();
         }
         for (LpBatch* d : devs) d->last_images = 0;
+        b->last_chunks = sh.jobs.size();
+        b->last_stolen = sh.stolen.load();
         for (size_t j = 0; j < sh.jobs.size(); j++) {
             if (sh.jobs[j].part >= 0) devs[(size_t)(sh.jobs[j].part / 16)]->last_images += sh.jobs[j].items.size();
             if (trace)
@@ -1112,6 +1150,16 @@ extern "C" int lilliput_hip_node_transform(lilliput_hip_node nn, lilliput_batch_
     std::vector<LpBatch*> devs;
     for (auto& d : node->devs) devs.push_back(d.get());
     return transform_on(devs, items, n, opt);
+}
+
+// chunks of the last node transform and how many of them a device claimed out of another device's share (work stealing)
+extern "C" void lilliput_hip_node_queue_stats(lilliput_hip_node nn, double out[2])
+{
+    auto node = static_cast<LpNode*>(nn);
+    out[0] = out[1] = 0;
+    if (!node || node->devs.empty()) return;
+    out[0] = (double)node->devs[0]->last_chunks;
+    out[1] = (double)node->devs[0]->last_stolen;
 }
 
 // images served and bytes staged by device k in the last node transform

@@ -1,11 +1,84 @@
-"""Multi-GPU plumbing of the batched path: one process per GPU, images sharded by rank, no data-path collective.
+"""Multi-GPU plumbing of the batched path when it runs as ONE PROCESS PER GPU: images sharded by rank, no data-path collective.
 
-The images of a batch are independent, so N ranks simply take N disjoint shards; torch.distributed is
-used only for the barrier around the timed region and for the max-over-ranks of the elapsed time (backend "nccl" = RCCL
-on the GPUs, "gloo" in the CPU tests). bench.py and tests/test_multi_rank.py both go through this module.
+The images of a batch are independent, so N ranks simply take N disjoint shards; what the ranks need from each
+other is a barrier around the timed region, the max-over-ranks of the elapsed time and a few gathered counters. Three ways to get it:
+  * backend "nccl" (the default under torchrun, which is how the driver launches N > 1): torch.distributed over RCCL;
+  * backend "gloo": torch.distributed on the CPU (the CPU tests);
+  * backend "file": NO PyTorch at all -- the ranks of one node meet in a directory (one small file per rank and phase). What
+    `bench.py --gpus N --ranks` uses for the processes it spawns itself, and what "nccl" falls back to when torch or RCCL cannot be
+    brought up (say so: Ranks.backend).
+(One process driving every GPU of the node -- lilliput_hip_node_*, what a cgo service links and what `bench.py --gpus N` runs by
+default -- needs none of this: its chunk queue is a host atomic, lp_batch.cpp.)
+bench.py and tests/test_multi_rank.py both go through this module.
 """
 import os
+import struct
 import time
+
+
+class _FileGroup:
+    """Barrier / all-gather of a few numbers among the ranks of ONE node through a shared directory: rank r publishes
+    <dir>/<phase>.<r> (written under another name, then renamed: a reader never sees half a file) and polls for the others'."""
+
+    def __init__(self, rank, world, path, timeout_s=600.0):
+        self.rank, self.world, self.path, self.timeout_s, self.phase = rank, world, path, timeout_s, 0
+        os.makedirs(path, exist_ok=True)
+
+    def all_gather(self, payload):
+        ph, self.phase = self.phase, self.phase + 1
+        mine = os.path.join(self.path, "%d.%d" % (ph, self.rank))
+        with open(mine + ".tmp", "wb") as f:
+            f.write(payload)
+        os.replace(mine + ".tmp", mine)
+        out, t_end, nap = [], time.time() + self.timeout_s, 0.0002
+        for r in range(self.world):
+            p = os.path.join(self.path, "%d.%d" % (ph, r))
+            while True:
+                try:
+                    with open(p, "rb") as f:
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    if time.time() > t_end:
+                        raise TimeoutError("rank %d never reached phase %d of %s" % (r, ph, self.path))
+                    time.sleep(nap)
+                    nap = min(nap * 1.5, 0.005)
+        if ph >= 2:  # everybody has read phase ph - 2 (they published ph - 1 after reading it): this rank's old file can go
+            try:
+                os.remove(os.path.join(self.path, "%d.%d" % (ph - 2, self.rank)))
+            except OSError:
+                pass
+        return out
+
+    def close(self):
+        # leaving: a rank may only remove what nobody will read again. Everybody says "bye" and, having read everybody's, "done";
+        # rank 0 waits for the "done"s and clears the directory.
+        self.all_gather(b"bye")
+        if self.rank != 0:
+            with open(os.path.join(self.path, "done.%d.tmp" % self.rank), "wb") as f:
+                f.write(b"1")
+            os.replace(os.path.join(self.path, "done.%d.tmp" % self.rank), os.path.join(self.path, "done.%d" % self.rank))
+            return
+        t_end = time.time() + self.timeout_s
+        while any(not os.path.exists(os.path.join(self.path, "done.%d" % r)) for r in range(1, self.world)) and time.time() < t_end:
+            time.sleep(0.001)
+        for name in os.listdir(self.path):
+            try:
+                os.remove(os.path.join(self.path, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.path)
+        except OSError:
+            pass
+
+
+def _rendezvous_dir():
+    d = os.environ.get("LILLIPUT_BENCH_RDV")
+    if d:
+        return d
+    # under torchrun every worker has the same parent (the elastic agent): its pid + the master port name this run
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_rdv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
 
 
 class Ranks:
@@ -15,21 +88,34 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = None
+        self.files = None
+        self.backend = "none"
         # under torchrun (RANK set) the process group is brought up even for ONE rank, so that the RCCL path of the multi-GPU runs
         # (backend "nccl": barrier, all-reduce of the elapsed time, all-gather of the counters) is the path a 1-GPU run takes too
         if self.world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_ADDR")):
-            import torch
-            import torch.distributed as dist
-
             backend = backend or "nccl"
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device("cuda", self.local_rank)
-                dist.init_process_group(backend, device_id=self.device)
-            else:
-                self.device = torch.device("cpu")
-                dist.init_process_group(backend)
-            self.dist = dist
+            if backend != "file":
+                try:
+                    import torch
+                    import torch.distributed as dist
+
+                    if backend == "nccl":
+                        torch.cuda.set_device(self.local_rank)
+                        self.device = torch.device("cuda", self.local_rank)
+                        dist.init_process_group(backend, device_id=self.device)
+                    else:
+                        self.device = torch.device("cpu")
+                        dist.init_process_group(backend)
+                    self.dist = dist
+                    self.backend = backend
+                except Exception as e:  # no torch, no RCCL, a rendezvous that does not come up: the ranks still only need a barrier
+                    import sys
+
+                    print("[lilliput_amd.dist] rank %d: backend %s unavailable (%r): meeting the other ranks through files instead" % (self.rank, backend, e), file=sys.stderr, flush=True)
+                    self.dist, self.device, backend = None, None, "file"
+            if backend == "file":
+                self.files = _FileGroup(self.rank, self.world, _rendezvous_dir())
+                self.backend = "file"
 
     def shard(self, n_items):
         """Indices of the global item list this rank owns: contiguous, sizes differing by at most one."""
@@ -38,6 +124,8 @@ class Ranks:
         return range(lo, lo + base + (1 if self.rank < extra else 0))
 
     def barrier(self):
+        if self.files is not None:
+            self.files.all_gather(b"b")  # (the product's calls are synchronous: when transform returns the device is idle)
         if self.dist is not None:
             self.dist.barrier()
             if self.device.type == "cuda":
@@ -47,6 +135,9 @@ class Ranks:
 
     def reduce(self, value, op="max"):
         """max / sum of a python float over the ranks (every rank gets the result)."""
+        if self.files is not None:
+            vals = [struct.unpack("<d", b)[0] for b in self.files.all_gather(struct.pack("<d", float(value)))]
+            return max(vals) if op == "max" else sum(vals)
         if self.dist is None:
             return float(value)
         import torch
@@ -69,6 +160,9 @@ class Ranks:
 
     def all_gather_ints(self, values):
         """values: list of python ints of this rank -> list (one entry per rank) of lists."""
+        if self.files is not None:
+            vals = list(values)
+            return [list(struct.unpack("<%dq" % len(vals), b)) for b in self.files.all_gather(struct.pack("<%dq" % len(vals), *[int(v) for v in vals]))]
         if self.dist is None:
             return [list(values)]
         import torch
@@ -79,6 +173,9 @@ class Ranks:
         return [[int(v) for v in t.tolist()] for t in out]
 
     def close(self):
+        if self.files is not None:
+            self.files.close()
+            self.files = None
         if self.dist is not None:
             self.dist.destroy_process_group()
 

@@ -1,4 +1,5 @@
-"""Worker of tests/test_multi_rank.py: run under torch.distributed.run with the gloo backend (CPU)."""
+"""Worker of tests/test_multi_rank.py: run under torch.distributed.run with the gloo backend (CPU), or as plain processes that meet
+through files (LILLIPUT_BENCH_BACKEND=file: no PyTorch in the process)."""
 import hashlib
 import json
 import os
@@ -13,7 +14,9 @@ from lilliput_amd.dist import Ranks, WorkQueue  # noqa: E402
 
 def main():
     out_dir, n_items = sys.argv[1], int(sys.argv[2])
-    r = Ranks(backend="gloo")
+    r = Ranks(backend=os.environ.get("LILLIPUT_BENCH_BACKEND", "gloo"))
+    if r.backend == "file":
+        assert "torch" not in sys.modules
     mine = list(r.shard(n_items))
     # the "work": a digest per owned item (stands for one image through the device path)
     digests = {i: hashlib.sha256(b"item-%d" % i).hexdigest()[:8] for i in mine}

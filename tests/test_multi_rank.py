@@ -34,6 +34,29 @@ def test_two_ranks_shard_time_and_reduce(tmp_path):
     assert res[0]["queue_s"] < 16 / 2 * 0.08                    # faster than the static split (8 chunks x 0.08 s on the slow rank)
 
 
+def test_two_ranks_meet_through_files_without_pytorch(tmp_path):
+    """The same contract with NO torch.distributed and no torchrun: two plain processes (what `bench.py --gpus N --ranks` spawns) whose
+    barrier, max-reduce and all-gather go through a rendezvous directory (lilliput_amd.dist backend "file")."""
+    n_items = 11
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LILLIPUT_BENCH_BACKEND="file", LILLIPUT_BENCH_RDV=os.path.join(str(tmp_path), "rdv"))
+        env.pop("MASTER_ADDR", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(tmp_path), str(n_items)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err.decode()[-2000:]
+    res = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in (0, 1)]
+    assert sorted(res[0]["items"] + res[1]["items"]) == list(range(n_items))
+    assert res[0]["total"] == res[1]["total"] == n_items
+    assert all(r["steps_run"] == 4 for r in res)
+    assert res[0]["elapsed"] == res[1]["elapsed"] and res[0]["elapsed"] >= 3 * 0.1 - 0.01
+    d0, d1 = res[0]["queue_done"], res[1]["queue_done"]
+    assert sorted(d0 + d1) == list(range(16)) and len(d0) > 8 > len(d1)
+    assert res[0]["queue_epochs"] == res[1]["queue_epochs"]
+    assert not os.path.exists(os.path.join(str(tmp_path), "rdv"))  # the last rank out removed the directory
+
+
 def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     from lilliput_amd.dist import Ranks
@@ -102,3 +125,40 @@ def test_node_entry_point_shares_one_queue_between_device_slots():
     assert every.device_count() >= 1
     assert [(g.status, g.data) for g in every.transform(sources[:7], 96, 96, quality=85)] == [(r.status, r.data) for r in ref[:7]]
     every.close()
+
+
+def _run_bench(tmp_path, *argv, expect_rc=0):
+    """bench.py in a process where `import torch` fails: the node mode and the --ranks mode must not need PyTorch."""
+    poison = os.path.join(str(tmp_path), "poison")
+    os.makedirs(poison, exist_ok=True)
+    with open(os.path.join(poison, "torch.py"), "w") as f:
+        f.write("raise ImportError('bench.py must not import torch on this path')\n")
+    env = dict(os.environ, PYTHONPATH=poison + os.pathsep + os.environ.get("PYTHONPATH", ""), TMPDIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == expect_rc, (p.returncode, p.stderr.decode()[-3000:])
+    return p.stdout.decode(), p.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_drives_n_device_slots_in_one_process_without_pytorch(tmp_path):
+    """`bench.py --gpus 2` not under torchrun = ONE process, lilliput_hip_node_transform over two device slots (here the same GPU
+    twice: --alias-devices 0,0): n_gpus 2, both slots served images, every checked output byte-identical to the reference CPU path."""
+    small = ["--batch", "24", "--distinct", "24", "--size", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--verify", "4"]
+    out, _ = _run_bench(tmp_path, "--gpus", "2", "--alias-devices", "0,0", *small)
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["verified_identical"] and line["config"]["ok_images"] == 48
+    per = line["config"]["per_device_last_step"]
+    assert len(per) == 2 and all(d["images"] > 0 for d in per) and sum(d["images"] for d in per) == 48
+    assert line["config"]["aliased_devices"] is True and line["value"] > 0
+    # on a box with fewer GPUs than asked for: a clear error, not a silent one-GPU run
+    import lilliput_amd as la
+
+    if la.lib().lilliput_hip_device_count() < 2:
+        _, err = _run_bench(tmp_path, "--gpus", "2", *small, expect_rc=2)
+        assert "only 1 GPU" in err and "--alias-devices" in err
+    # one process per GPU, spawned by bench.py itself, meeting through files: still no PyTorch
+    out, _ = _run_bench(tmp_path, "--gpus", "2", "--alias-devices", "0,0", "--ranks", *small)
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["verified_identical"] and "rendezvous directory" in line["config"]["parallelism"]
