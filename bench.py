@@ -262,12 +262,12 @@ def main_abi(args, ranks, la):
     for t in threads:
         jobs = args.batch
         for _ in range(args.warmup):
-            la.service_sim(distinct, t, min(jobs, max(8 * t, 512)), args.out, args.out, 85, la.ImageOpsFit, keep=False)
+            la.service_sim(distinct, t, min(jobs, max(8 * t, 512)), args.out, args.out, 85, la.ImageOpsFit, keep=False, part=args.part)
         el, ok, lat, outs, err = 0.0, 0, [], None, 0
         cpu0, thr0 = cgroup_cpu_stat()
         for k in range(args.steps):
             ranks.barrier()
-            r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1))
+            r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1), part=args.part)
             el += r["seconds"]
             ok += r["ok"]
             err = err or r["first_error"]
@@ -295,15 +295,20 @@ def main_abi(args, ranks, la):
 
     pool = (ctypes.c_size_t * 4)()
     la.lib().lilliput_hip_engine_pool_stats(pool)
+    dstat = (ctypes.c_uint64 * 4)()
+    la.lib().lilliput_hip_deferred_stats(dstat)
     gate = ranks.all_gather_ints([len(bad)])
     if rank == 0:
         c_in = sum(a.size for a in distinct) / len(distinct)
-        out = {"metric": "images/sec (%dx%d->%dx%d JPEG q85, ImageOps.Transform through the one-image C ABI under concurrent callers)" % (args.size, args.size, args.out, args.out),
+        out = {"metric": "images/sec (%dx%d->%dx%d JPEG q85, ImageOps.Transform through the one-image C ABI under concurrent callers, Part %s)" % (args.size, args.size, args.out, args.out, args.part),
                "value": round(best_v, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1000.0 * best_elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": "the drop-in path: %d requests per GPU and step on the BASELINE configs[1] sources (%d distinct %dx%d 4:2:0 q90 JPEGs in pageable host memory), each "
                                       "NewDecoder -> Header -> ImageOps.Transform(Fit %dx%d, q85) -> Close on the calling thread's own ImageOps, `threads` OS threads at once "
                                       "(lp_service_sim.c, plain C against include/lilliput_hip.h); value = the best of the thread counts" % (args.batch, len(distinct), args.size, args.size, args.out, args.out),
+                          "part": "A: the opencv_* calls of unchanged ops.go / opencv.go, in their order (lp_service_sim.c one_request_part_a)" if args.part == "A" else "C: lilliput_image_ops_transform (the Go API mirrored in C)",
+                          "deferred_part_a": {"LILLIPUT_HIP_DEFER": os.environ.get("LILLIPUT_HIP_DEFER", "default (on)"), "chains_recorded": int(dstat[0]), "served_by_the_batched_path": int(dstat[1]),
+                                              "run_the_eager_way": int(dstat[2]), "sources_copied_at_decoder_release": int(dstat[3])},
                           "threads_of_value": best_t, "by_threads": by_threads,
                           "coalescing": {"LILLIPUT_HIP_COALESCE": os.environ.get("LILLIPUT_HIP_COALESCE", "default (3 calls in flight)"),
                                          "LILLIPUT_HIP_COALESCE_WORKERS": os.environ.get("LILLIPUT_HIP_COALESCE_WORKERS", "default (4)"),
@@ -860,6 +865,8 @@ def main():
                          "pages are registered per call (opt-in: slower than the copy on this driver); staged = force the slot route whatever the memory")
     ap.add_argument("--max-side", type=int, default=4096, help="--workload firehose: largest source side (BASELINE configs[4] says 8192)")
     ap.add_argument("--window", type=int, default=0, help="--workload firehose: stream the step's items through lilliput_hip_node_transform in windows of this many (0 = one call)")
+    ap.add_argument("--part", choices=["A", "C"], default="C", help="--workload abi: C = every request through Part C (lilliput_image_ops_transform, the Go API mirrored in C); "
+                    "A = through Part A, the opencv_* call sequence that UNCHANGED ops.go / opencv.go issue (the literal drop-in)")
     ap.add_argument("--threads", default="64", help="--workload abi: concurrent caller threads, or a comma list (1,8,64,256: one measurement each)")
     ap.add_argument("--workload", choices=["jpeg4096", "firehose", "abi", "png2webp", "animated"], default="jpeg4096",
                     help="jpeg4096 = BASELINE configs[1], the headline metric (default); firehose = BASELINE configs[4] in miniature: a mixed-format stream (JPEG 70 / PNG 15 / "

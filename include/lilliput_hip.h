@@ -460,6 +460,22 @@ int lilliput_hip_area420_host(const uint8_t* py, const uint8_t* pb, const uint8_
 void lilliput_hip_set_lazy_host(int on);
 int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current */
 
+/* Deferred Part A (on by default; LILLIPUT_HIP_DEFER=0 or lilliput_hip_set_deferred(0): off). What unchanged ops.go does per image --
+ * opencv_decoder_read_data, opencv_mat_orientation_transform, opencv_mat_crop, opencv_mat_resize, opencv_encoder_write (ops.go:352-444
+ * through opencv.go:816-839, 271-279, 326-374, 872-900) -- is RECORDED for a baseline JPEG source instead of executed call by call:
+ * every dimension is known from the header, and nothing needs bytes before opencv_encoder_write(".jpeg"), which hands {source,
+ * orientation, crop, size, quality} to the batched path as one item, sharing launches with the calls other goroutines have in
+ * flight. Anything else that touches such a Mat (opencv_mat_get_data, a PNG / WebP / GIF / ThumbHash encoder, a composite) runs the
+ * recorded calls first, the eager way. Results are the batched path's: byte-identical to the eager route for integer scales, within
+ * the +-1 LSB contract otherwise. What the caller must not do while it is on: read Framebuffer.buf behind the library's back (ops.go
+ * never does; the same contract as lazy write-back), or modify the encoded source bytes between DecodeTo and the decoder's Close
+ * (opencv_decoder_release copies the bytes if a recorded chain still needs them). Sources that can FAIL to decode (a stream that
+ * runs out of bytes: scan-path files) are decoded in opencv_decoder_read_data as before, so that ErrDecodingFailed surfaces there.
+ * lilliput_hip_deferred_stats: chains recorded, chains served by the batched path, chains run the eager way after all, sources copied
+ * at decoder release -- process-wide counters since start. */
+void lilliput_hip_set_deferred(int on);
+void lilliput_hip_deferred_stats(uint64_t out[4]);
+
 /* Progressive (SOF2) JPEG sources: the scans' entropy decode runs on host threads feeding the device IDCT with coefficients (a scan
  * is serial by construction; see lilliput_amd/csrc/lp_prog_host.h; thread count: LILLIPUT_HIP_PROG_THREADS). A second home -- one device
  * lane per scan (k_prog_scan), 25x slower at 4096 x 4096 -- is a BUILD option since round 3 (make DEFS=-DLP_PROG_DEVICE_LANES);

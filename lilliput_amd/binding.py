@@ -525,7 +525,7 @@ class Node(Batch):
 
 
 def service_sim(sources, threads, jobs, width=256, height=256, quality=85, resize_method=ImageOpsFit, max_size=8192, keep=True, file_type=".jpeg", encode_options=None,
-                dst_cap=0):
+                dst_cap=0, part="C"):
     """N OS threads, each with one ImageOps, each doing NewDecoder -> Header -> Transform -> Close per request through Part C of the
     C ABI (csrc/lp_service_sim.c: the Go service of /root/reference/README.md:82-85 in plain C, no interpreter between the calls).
     encode_options: {key: value} (default {JpegQuality: quality}). Returns {"seconds", "ok", "jobs", "first_error", "outputs" (first
@@ -544,10 +544,11 @@ def service_sim(sources, threads, jobs, width=256, height=256, quality=85, resiz
     eo = encode_options if encode_options is not None else {JpegQuality: quality}
     flat = [int(x) for kv in eo.items() for x in kv]
     enc = (C.c_int * max(1, len(flat)))(*flat)
-    S.lilliput_service_sim_run2.restype = C.c_long
-    S.lilliput_service_sim_run2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t,
+    S.lilliput_service_sim_run3.restype = C.c_long
+    S.lilliput_service_sim_run3.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t,
                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    ok = S.lilliput_service_sim_run2(ptrs, lens, n, int(threads), int(jobs), int(width), int(height), file_type.encode(), enc, len(flat), int(resize_method), int(max_size), int(dst_cap),
+    # part "A": every request as the opencv_* call sequence of unchanged ops.go / opencv.go (lp_service_sim.c one_request_part_a)
+    ok = S.lilliput_service_sim_run3(1 if str(part).upper() == "A" else 0, ptrs, lens, n, int(threads), int(jobs), int(width), int(height), file_type.encode(), enc, len(flat), int(resize_method), int(max_size), int(dst_cap),
                                      C.byref(secs), C.byref(err), keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None, lat.ctypes.data)
     outs = [keep_buf[k * keep_cap: k * keep_cap + keep_len[k]].tobytes() if keep and 0 < keep_len[k] <= keep_cap else None for k in range(n)]
     return {"seconds": secs.value, "ok": int(ok), "jobs": int(jobs), "first_error": err.value, "outputs": outs, "latency_ms": lat[:jobs]}

@@ -16,6 +16,29 @@ struct LpDevBlock {
 };
 std::shared_ptr<LpDevBlock> lp_dev_alloc(size_t bytes);
 
+// Deferred Part A (lp_abi_opencv.cpp "deferred chains"): the encoded bytes a chain starts from. Shared by every Mat derived from one
+// opencv_decoder_read_data; when the decoder is released before the chain has run, the bytes are copied into `keep` (the caller may
+// free or reuse its buffer after Close, opencv.go:663-667).
+struct LpLazySrc {
+    const uint8_t* p = nullptr;     // nullptr: the decoder went away after the chain had been served (see opencv_decoder_release)
+    size_t len = 0;
+    std::vector<uint8_t> keep;
+    bool served = false;            // opencv_encoder_write has produced a result from a chain over these bytes
+};
+// A Mat whose pixels have not been computed yet: decode [-> orientation] [-> crop] [-> resize] of a baseline JPEG, recorded call by call
+// as unchanged ops.go issues them (ops.go:352-444 through opencv.go:250-374, 816-900). opencv_encoder_write(".jpeg") hands the whole
+// chain to the batched path (lp_coalesce.h) -- one launch sequence shared with whatever other calls are in flight, no 48 MB frame ever
+// written back; anything else that needs the pixels (a host read, another encoder, a composite) runs the chain the eager way first.
+struct LpLazy {
+    std::shared_ptr<LpLazySrc> src;
+    int hdr_w = 0, hdr_h = 0, hdr_orientation = 1;  // of the source
+    int orientation = 1;                            // what opencv_mat_orientation_transform was asked to apply (1 = nothing yet)
+    bool has_crop = false;
+    int cx = 0, cy = 0, cw = 0, ch = 0;             // opencv_mat_crop, on the oriented frame
+    bool has_resize = false;
+    int rw = 0, rh = 0;                             // opencv_mat_resize target
+};
+
 // What an `opencv_mat` handle points at (the reference's is a cv::Mat*, opencv.cpp:22-49).
 struct LpMat {
     uint8_t* data = nullptr;        // first pixel of this (view of a) matrix -- host memory, usually Go-owned
@@ -30,6 +53,7 @@ struct LpMat {
     bool dev_valid = false;
     bool dev_shared = false;        // a crop view sharing its parent's block
     bool host_stale = false;        // lazy write-back: the device holds newer pixels than `data`
+    std::shared_ptr<LpLazy> lazy;   // non-null: neither `data` nor `dev` hold this Mat's pixels yet (see LpLazy); rows / cols / type are the result's
 };
 
 struct LpDecoder {
@@ -43,6 +67,7 @@ struct LpDecoder {
     LpJpegHeader hdr;
     LpPngInfo png;
     int png_channels = 0;           // channels of the Mat cv::PngDecoder::readHeader announces
+    std::vector<std::weak_ptr<LpLazySrc>> lazies;   // deferred chains that still read this decoder's bytes
 };
 
 struct LpEncoder {
@@ -71,6 +96,10 @@ private:
 int lp_thread_device(int device); // device for this thread's one-image ABI calls (-1 = default); returns the previous setting
 int lp_current_device();          // the device this thread's one-image calls run on
 void lp_set_error(const std::string& s);
+// Deferred Part A is for the library's callers, not for the library itself: a scope of this on the calling thread makes the opencv_*
+// entry points eager (Part C and the batch workers bring their own strategy).
+struct LpEagerScope { LpEagerScope(); ~LpEagerScope(); int prev; };
+bool lp_mat_materialize(LpMat* m); // run a deferred chain the eager way (no-op for an ordinary Mat); false = it failed, the Mat is left without pixels
 bool lp_mat_to_device(LpMat* m, LpEngine* eng);
 bool lp_mat_to_host(LpMat* m, LpEngine* eng);
 bool lp_mat_host_current(LpMat* m);

@@ -244,6 +244,7 @@ bool giflib_decoder_decode_frame(giflib_decoder d, opencv_mat mat) // giflib.cpp
     m->dev = lp_dev_alloc(canvas_bytes);
     if (!m->dev) return false;
     m->dev_off = 0; m->dev_step = (size_t)bw * 4; m->dev_shared = false; m->host_stale = false;
+    m->lazy.reset();
     if (hipMemcpyAsync(m->dev->p, d->canvas->p, canvas_bytes, hipMemcpyDeviceToDevice, eng->stream()) != hipSuccess) return false;
     m->dev_valid = true;
     if (!lp_mat_to_host(m, eng)) return false;

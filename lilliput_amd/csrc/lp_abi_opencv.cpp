@@ -8,7 +8,9 @@
 // resized pixels on the host (ops.go:331-446 only passes Mats back into this ABI), so the JPEG->JPEG path
 // loses two device->host copies per image.
 #include "lp_abi.h"
+#include "lp_coalesce.h"
 #include "lp_inflate.h"
+#include "lp_ops_logic.h"
 
 #include <ctype.h>
 #include <stdio.h>
@@ -18,6 +20,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 
 extern "C" {
@@ -221,6 +225,7 @@ static inline size_t cv_elem_size(int type) { return (size_t)cv_channels(type) *
 
 bool lp_mat_to_device(LpMat* m, LpEngine* eng)
 {
+    if (m->lazy && !lp_mat_materialize(m)) return false; // a deferred chain: its pixels are needed now
     if (m->dev && m->dev_valid) return true;
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     const size_t need = rowb * (size_t)m->rows;
@@ -297,6 +302,7 @@ bool lp_mat_to_host(LpMat* m, LpEngine* eng)
 // Make the host pixels current before something reads or partially overwrites them.
 bool lp_mat_host_current(LpMat* m)
 {
+    if (m->lazy && !lp_mat_materialize(m)) return false; // a deferred chain: somebody is about to look at the pixels
     if (!m->host_stale) return true;
     if (!m->dev || !m->dev_valid) { m->host_stale = false; return true; }
     LpEngineLease lease;
@@ -345,6 +351,150 @@ bool lp_mat_reshape(LpMat* m, int rows, int cols, int type)
     m->datalimit = m->data + need;
     m->rows = rows; m->cols = cols; m->type = type; m->step = (size_t)cols * cv_elem_size(type);
     return true;
+}
+
+// ---- deferred chains (LpLazy, lp_abi.h): unchanged ops.go through Part A
+// ops.go's Transform is a dozen opencv_* calls per image (opencv.go:816-839 DecodeTo, :271-279 OrientationTransform, :326-374 Fit, :872-900
+// Encode). Executed one by one each pays its own launches and synchronisations, the decode of ONE image cannot fill the device, and the
+// decoded frame (48 MB for 4096 x 4096) crosses PCIe for nothing: 452 images/s for one caller, 2.3 k at eight, collapsing beyond
+// (profiles/r04_a_service.md). Instead the Mats the library produces stay UNCOMPUTED: read_data of a baseline JPEG records the
+// source, orientation_transform / crop / resize append to the record (every dimension is known from the header), and
+// opencv_encoder_write(".jpeg") -- the first point where bytes must exist -- hands {source, orientation, crop, size, quality} to the
+// batched path through the call coalescer (lp_coalesce.h), where it shares launches with whatever other goroutines' calls are in
+// flight. Whatever else touches such a Mat (opencv_mat_get_data, a PNG / WebP / GIF / ThumbHash encoder, a composite, a second
+// resize) runs the chain the old way first (lp_mat_materialize). The contract this relies on is the one lazy host write-back already
+// states: the caller must not read Framebuffer.buf behind the library's back, and must leave the encoded source
+// bytes alone until the decoder is closed (Close copies them if a chain still needs them). LILLIPUT_HIP_DEFER=0 or
+// lilliput_hip_set_deferred(0): every call eager again.
+// Which sources: baseline JPEGs the device decoder takes whole (not scan-path: those are decoded on host threads and may FAIL in
+// read_data -- a stream that runs out of bytes -- which must surface there, as ErrDecodingFailed; a closed baseline stream cannot fail).
+static int g_defer = -1;
+static thread_local int t_eager = 0;
+LpEagerScope::LpEagerScope() { prev = t_eager; t_eager = 1; }
+LpEagerScope::~LpEagerScope() { t_eager = prev; }
+static bool defer_on()
+{
+    if (t_eager) return false;
+    int g = __atomic_load_n(&g_defer, __ATOMIC_RELAXED);
+    if (g < 0) {
+        const char* e = getenv("LILLIPUT_HIP_DEFER");
+        g = !(e && atoi(e) == 0 && e[0] != '\0');
+        __atomic_store_n(&g_defer, g, __ATOMIC_RELAXED);
+    }
+    return g != 0;
+}
+extern "C" void lilliput_hip_set_deferred(int on) { __atomic_store_n(&g_defer, on ? 1 : 0, __ATOMIC_RELAXED); }
+static std::atomic<uint64_t> g_defer_stats[4]; // chains recorded, served by the batched path, materialised, sources copied at decoder release
+extern "C" void lilliput_hip_deferred_stats(uint64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = g_defer_stats[i].load(); }
+
+// device-only forms of the two pixel operations (no host buffer involved): cv::ExifTransform and cv::resize(INTER_AREA)
+static bool dev_orient(LpMat* m, int o, LpEngine* eng)
+{
+    const bool swap = o >= 5;
+    LpOrientOp op;
+    op.src = lp_mat_frame(m);
+    op.orientation = (uint32_t)o;
+    op.pad = 0;
+    auto src_blk = m->dev; // keep the source alive until the kernel has run
+    const int nr = swap ? m->cols : m->rows, nc = swap ? m->rows : m->cols;
+    LpMat tmp;
+    tmp.rows = nr; tmp.cols = nc; tmp.type = m->type;
+    if (!mat_new_dev(&tmp)) return false;
+    op.dst = lp_mat_frame(&tmp);
+    if (eng->orient(&op, 1)) return false;
+    m->rows = nr; m->cols = nc;
+    m->dev = tmp.dev; m->dev_off = 0; m->dev_step = tmp.dev_step; m->dev_shared = false; m->dev_valid = true;
+    return true;
+}
+static bool dev_resize(LpMat* s, LpMat* d, int width, int height, LpEngine* eng) // d: rows / cols / type set, gets a fresh device block
+{
+    if (!mat_new_dev(d)) return false;
+    LpResizeReq rq;
+    rq.src = lp_mat_frame(s);
+    rq.crop_x = rq.crop_y = 0; rq.crop_w = (uint32_t)s->cols; rq.crop_h = (uint32_t)s->rows;
+    rq.dst_w = (uint32_t)width; rq.dst_h = (uint32_t)height;
+    LpFrame df = lp_mat_frame(d);
+    int st = 0;
+    if (eng->resize(&rq, 1, &df, &st) || st) { fprintf(stderr, "lilliput_hip: resize failed: %s\n", eng->last_error().c_str()); return false; }
+    d->dev_valid = true;
+    return true;
+}
+
+bool lp_mat_materialize(LpMat* m)
+{
+    if (!m->lazy) return true;
+    const std::shared_ptr<LpLazy> z = std::move(m->lazy);
+    m->lazy.reset();
+    g_defer_stats[2]++;
+    LpEagerScope eager;
+    if (!z->src->p) {
+        lp_set_error("deferred chain: its decoder was closed after the chain had been encoded once; keep the decoder open until the framebuffer's last use (or LILLIPUT_HIP_DEFER=0)");
+        fprintf(stderr, "lilliput_hip: a framebuffer was asked for pixels after its decoder had been closed and its recorded chain already encoded once; "
+                        "keep the decoder open until the framebuffer's last use, or set LILLIPUT_HIP_DEFER=0\n");
+        return false;
+    }
+    std::unique_ptr<LpJpegHeader> hdr(new LpJpegHeader());
+    if (lp_jpeg_parse(z->src->p, z->src->len, hdr.get()) != LP_PARSE_OK) { lp_set_error("deferred decode: the source no longer parses (was the buffer modified before the decoder was closed?)"); return false; }
+    const LpJpeg& j = hdr->j;
+    LpEngineLease lease;
+    LpEngine* eng = lease.get();
+    if (!eng) return false;
+    LpMat cur; // device-only intermediate
+    cur.rows = (int)j.height; cur.cols = (int)j.width; cur.type = j.ncomp == 1 ? CV_8UC1 : CV_8UC3;
+    if (!mat_new_dev(&cur)) return false;
+    {
+        LpFrame f = lp_mat_frame(&cur);
+        LpJpegSrc src{z->src->p, z->src->len};
+        int st = 0;
+        const int rc = eng->decode_jpegs(&src, 1, hdr.get(), &f, &st);
+        if (rc || st) { lp_set_error(eng->last_error()); return false; }
+        cur.dev_valid = true;
+    }
+    if (z->orientation > 1 && !dev_orient(&cur, z->orientation, eng)) return false;
+    if (z->has_crop) { // a view, like cv::Mat(Rect)
+        const size_t es = cv_elem_size(cur.type);
+        cur.dev_off += (size_t)z->cy * cur.dev_step + (size_t)z->cx * es;
+        cur.rows = z->ch; cur.cols = z->cw;
+        cur.dev_shared = true;
+    }
+    if (z->has_resize) {
+        LpMat out;
+        out.rows = z->rh; out.cols = z->rw; out.type = cur.type;
+        if (!dev_resize(&cur, &out, z->rw, z->rh, eng)) return false;
+        cur = out;
+    }
+    if (eng->sync()) return false;
+    m->dev = cur.dev; m->dev_off = cur.dev_off; m->dev_step = cur.dev_step; m->dev_shared = cur.dev_shared; m->dev_valid = true;
+    m->host_stale = true; // the caller's buffer is brought up to date when somebody asks for it (lp_mat_host_current)
+    return true;
+}
+
+// The batched path's options for a recorded chain, or false when the chain is not what ops.go's Fit / ResizeTo produce for some request
+// (a crop of the caller's own, an orientation other than the header's): such a chain is materialised instead.
+static bool lazy_plan_options(const LpLazy& z, int quality, bool progressive, lilliput_batch_options* o)
+{
+    if (z.orientation != z.hdr_orientation && !(z.orientation == 1 && (z.hdr_orientation < 1 || z.hdr_orientation > 8))) return false; // ops.go:392 applies the header's
+    const int ori = z.hdr_orientation >= 1 && z.hdr_orientation <= 8 ? z.hdr_orientation : 1;
+    const bool swap = lp_swaps_axes(ori);
+    const int ow = swap ? z.hdr_h : z.hdr_w, oh = swap ? z.hdr_w : z.hdr_h; // the oriented frame
+    memset(o, 0, sizeof(*o));
+    o->jpeg_quality = quality;
+    o->jpeg_progressive = progressive ? 1 : 0;
+    if (!z.has_resize) { // the oriented frame (or nothing at all) encoded as it is: ImageOpsNoResize
+        if (z.has_crop) return false;
+        o->width = ow; o->height = oh; o->resize_method = LILLIPUT_OPS_NO_RESIZE;
+        return true;
+    }
+    for (int method = 1; method <= 2; method++)
+        for (int norm = 1; norm >= 0; norm--) {
+            const LpOpsPlan p = lp_plan_static_transform(z.hdr_w, z.hdr_h, ori, z.rw, z.rh, method, norm != 0, ow, oh);
+            const bool crop_same = z.has_crop ? (p.crop_x == z.cx && p.crop_y == z.cy && p.crop_w == z.cw && p.crop_h == z.ch) : (p.crop_x == 0 && p.crop_y == 0 && p.crop_w == ow && p.crop_h == oh);
+            if (p.resize && crop_same && p.out_w == z.rw && p.out_h == z.rh) {
+                o->width = z.rw; o->height = z.rh; o->resize_method = method == 1 ? LILLIPUT_OPS_FIT : LILLIPUT_OPS_RESIZE; o->normalize_orientation = norm;
+                return true;
+            }
+        }
+    return false;
 }
 
 // ---- PNG output: cv::PngEncoder::write (OpenCV 4.11 grfmt_png.cpp; source not in the reference tree) over libpng 1.6.47.
@@ -500,11 +650,20 @@ opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int he
         fprintf(stderr, "lilliput_hip: opencv_mat_crop rectangle outside the matrix\n");
         return NULL;
     }
+    if (s->lazy && s->lazy->has_resize && !lp_mat_materialize(const_cast<LpMat*>(s))) return NULL; // a view of a resized frame: computed first
     auto m = new LpMat();
     m->rows = height; m->cols = width; m->type = s->type; m->step = s->step;
     m->data = s->data + (size_t)y * s->step + (size_t)x * cv_elem_size(s->type);
     m->datastart = s->datastart;
     m->datalimit = s->datalimit;
+    if (s->lazy) { // a view of pixels that do not exist yet: the chain with the rectangle appended (rectangles compose)
+        m->lazy = std::make_shared<LpLazy>(*s->lazy);
+        m->lazy->cx = (s->lazy->has_crop ? s->lazy->cx : 0) + x;
+        m->lazy->cy = (s->lazy->has_crop ? s->lazy->cy : 0) + y;
+        m->lazy->cw = width; m->lazy->ch = height;
+        m->lazy->has_crop = true;
+        return m;
+    }
     if (s->dev && s->dev_valid) { // a view of the parent's device mirror, like cv::Mat(Rect) is a view of its data
         m->dev = s->dev;
         m->dev_off = s->dev_off + (size_t)y * s->dev_step + (size_t)x * cv_elem_size(s->type);
@@ -525,17 +684,18 @@ void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int heig
     if (!eng || !s || !d || width <= 0 || height <= 0 || s->rows <= 0 || s->cols <= 0) { fprintf(stderr, "lilliput_hip: opencv_mat_resize failed (no device / empty matrix)\n"); return; }
     if (interpolation != CV_INTER_AREA) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports CV_INTER_AREA only\n"); return; }
     if (cv_depth_bytes(s->type) != 1) { fprintf(stderr, "lilliput_hip: opencv_mat_resize supports 8-bit matrices only\n"); return; }
+    if (s->lazy && !s->lazy->has_resize && s != d && defer_on()) { // the source is a recorded chain: so is the result
+        lp_mat_reshape(d, height, width, s->type);
+        d->lazy = std::make_shared<LpLazy>(*s->lazy);
+        d->lazy->has_resize = true;
+        d->lazy->rw = width; d->lazy->rh = height;
+        d->dev.reset(); d->dev_valid = false; d->dev_shared = false; d->host_stale = false;
+        return;
+    }
     if (!lp_mat_to_device(s, eng)) return;
     lp_mat_reshape(d, height, width, s->type);
-    if (!mat_new_dev(d)) return;
-    LpResizeReq rq;
-    rq.src = lp_mat_frame(s);
-    rq.crop_x = rq.crop_y = 0; rq.crop_w = (uint32_t)s->cols; rq.crop_h = (uint32_t)s->rows;
-    rq.dst_w = (uint32_t)width; rq.dst_h = (uint32_t)height;
-    LpFrame df = lp_mat_frame(d);
-    int st = 0;
-    if (eng->resize(&rq, 1, &df, &st) || st) { fprintf(stderr, "lilliput_hip: resize failed: %s\n", eng->last_error().c_str()); return; }
-    d->dev_valid = true;
+    d->lazy.reset();
+    if (!dev_resize(s, d, width, height, eng)) return;
     lp_mat_to_host(d, eng);
 }
 
@@ -544,26 +704,22 @@ void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat
     auto m = static_cast<LpMat*>(mat);
     int o = (int)orientation;
     if (!m || o <= 1 || o > 8 || m->rows <= 0 || m->cols <= 0) return; // cv::ExifTransform: TL and unknown values are no-ops
+    const bool swap = o >= 5;
+    const int nr = swap ? m->cols : m->rows, nc = swap ? m->rows : m->cols;
+    // the pixels stay in the caller's buffer (tightly packed), unlike cv::transpose which reallocates (SURVEY.md 3.4 #8)
+    const size_t need = (size_t)nr * nc * cv_elem_size(m->type);
+    if (m->lazy && m->lazy->orientation == 1 && !m->lazy->has_crop && !m->lazy->has_resize && defer_on()) { // recorded, not executed
+        if ((size_t)(m->datalimit - m->data) < need) { fprintf(stderr, "lilliput_hip: orientation transform: buffer too small\n"); return; }
+        m->lazy->orientation = o;
+        m->rows = nr; m->cols = nc; m->step = (size_t)nc * cv_elem_size(m->type);
+        return;
+    }
     LpEngineLease lease;
     LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(m, eng)) { fprintf(stderr, "lilliput_hip: orientation transform failed (no device)\n"); return; }
-    const bool swap = o >= 5;
-    LpOrientOp op;
-    op.src = lp_mat_frame(m);
-    op.orientation = (uint32_t)o;
-    op.pad = 0;
-    auto src_blk = m->dev; // keep the source alive until the kernel has run
-    int nr = swap ? m->cols : m->rows, nc = swap ? m->rows : m->cols;
-    LpMat tmp;
-    tmp.rows = nr; tmp.cols = nc; tmp.type = m->type;
-    if (!mat_new_dev(&tmp)) return;
-    op.dst = lp_mat_frame(&tmp);
-    if (eng->orient(&op, 1)) return;
-    // the pixels stay in the caller's buffer (tightly packed), unlike cv::transpose which reallocates (SURVEY.md 3.4 #8)
-    const size_t need = (size_t)nr * nc * cv_elem_size(m->type);
     if ((size_t)(m->datalimit - m->data) < need) { fprintf(stderr, "lilliput_hip: orientation transform: buffer too small\n"); return; }
-    m->rows = nr; m->cols = nc; m->step = (size_t)nc * cv_elem_size(m->type);
-    m->dev = tmp.dev; m->dev_off = 0; m->dev_step = tmp.dev_step; m->dev_shared = false; m->dev_valid = true;
+    if (!dev_orient(m, o, eng)) return;
+    m->step = (size_t)nc * cv_elem_size(m->type);
     lp_mat_to_host(m, eng);
 }
 
@@ -576,6 +732,7 @@ extern "C" int lilliput_hip_mat_set_pixels(opencv_mat mat, const void* pixels, s
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     if (stride < rowb || (size_t)(m->datalimit - m->data) < m->step * (size_t)(m->rows - 1) + rowb) return -1;
     for (int y = 0; y < m->rows; y++) memcpy(m->data + (size_t)y * m->step, (const uint8_t*)pixels + (size_t)y * stride, rowb);
+    m->lazy.reset();
     m->dev_valid = false;
     m->host_stale = false;
     return 0;
@@ -587,6 +744,7 @@ void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
     if (!m) return;
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
     for (int y = 0; y < m->rows; y++) memset(m->data + (size_t)y * m->step, 0, rowb);
+    m->lazy.reset();
     m->dev_valid = false;
     m->host_stale = false;
 }
@@ -600,6 +758,7 @@ void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alph
     for (int y = 0; y < m->rows; y++)
         for (int x = 0; x < m->cols; x++)
             for (int c = 0; c < cn && c < 4; c++) m->data[(size_t)y * m->step + (size_t)x * cn + c] = v[c];
+    m->lazy.reset();
     m->dev_valid = false;
     m->host_stale = false;
 }
@@ -689,7 +848,27 @@ const char* opencv_decoder_get_description(const opencv_decoder d)
     auto p = static_cast<const LpDecoder*>(d);
     return p->is_png ? "PNG" : p->is_bmp ? "BMP" : "JPEG";
 }
-void opencv_decoder_release(opencv_decoder d) { delete static_cast<LpDecoder*>(d); }
+void opencv_decoder_release(opencv_decoder dd)
+{
+    auto d = static_cast<LpDecoder*>(dd);
+    if (!d) return;
+    // Deferred chains still read this decoder's bytes, and after Close the caller may free or reuse its buffer (opencv.go:663-667).
+    // A chain that has NOT produced anything yet gets its own copy of the bytes. A chain that has been served -- ops.go's Transform:
+    // the framebuffers of the ImageOps still carry the record when the caller closes the decoder, and nothing will ever look at them
+    // again before the next DecodeTo replaces it -- just loses its source: copying 4 MB per request for nobody would cost more host
+    // time than the whole transform. Should somebody ask such a Mat for pixels after all, lp_mat_materialize fails loudly.
+    for (auto& w : d->lazies)
+        if (auto src = w.lock()) {
+            if (src->p != d->data || !src->keep.empty()) continue;
+            if (src->served) src->p = nullptr;
+            else {
+                src->keep.assign(d->data, d->data + d->len);
+                src->p = src->keep.data();
+                g_defer_stats[3]++;
+            }
+        }
+    delete d;
+}
 
 bool opencv_decoder_read_header(opencv_decoder dd)
 {
@@ -786,6 +965,7 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     if (!d || !m) return false;
     if (!d->parsed && !opencv_decoder_read_header(dd)) return false;
     if (d->parse_rc != LP_PARSE_OK) return false;
+    m->lazy.reset(); // whatever the Mat was, it is this frame now
     if (d->is_png) return png_read_data(d, m);
     if (d->is_bmp) { // cv::BmpDecoder::readData: rows unpacked on the host, straight into the Mat (lp_bmp.h)
         const LpBmpInfo& bi = d->bmp;
@@ -800,6 +980,19 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     const LpJpeg& j = d->hdr.j;
     const int cn = j.ncomp == 1 ? 1 : 3;
     if (m->rows != (int)j.height || m->cols != (int)j.width || cv_channels(m->type) != cn || cv_depth_bytes(m->type) != 1) return false;
+    m->lazy.reset();
+    if (!d->hdr.scan_path && defer_on() && lilliput_hip_device_count() > 0) { // a closed baseline stream: cannot fail to decode, so nothing is lost by not doing it yet
+        auto z = std::make_shared<LpLazy>();
+        z->src = std::make_shared<LpLazySrc>();
+        z->src->p = d->data; z->src->len = d->len;
+        z->hdr_w = (int)j.width; z->hdr_h = (int)j.height; z->hdr_orientation = (int)j.orientation;
+        d->lazies.erase(std::remove_if(d->lazies.begin(), d->lazies.end(), [](const std::weak_ptr<LpLazySrc>& w) { return w.expired(); }), d->lazies.end());
+        d->lazies.push_back(z->src);
+        m->lazy = z;
+        m->dev.reset(); m->dev_valid = false; m->dev_shared = false; m->host_stale = false;
+        g_defer_stats[0]++;
+        return true;
+    }
     LpEngineLease lease;
     LpEngine* eng = lease.get();
     if (!eng) return false;
@@ -891,11 +1084,29 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
         if (opt[i] == CV_IMWRITE_JPEG_QUALITY) quality = opt[i + 1] < 0 ? 0 : opt[i + 1] > 100 ? 100 : opt[i + 1];
         else if (opt[i] == CV_IMWRITE_JPEG_PROGRESSIVE) progressive = opt[i + 1] != 0; // cv::JpegEncoder: jpeg_simple_progression
     }
+    LpMat* d = e->dst;
+    const size_t cap = (size_t)(d->datalimit - d->datastart);
+    if (s->lazy && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
+        lilliput_batch_options bo;
+        if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {
+            size_t n = 0;
+            const std::shared_ptr<LpLazySrc> src = s->lazy->src;
+            const int st = lp_coalesce_transform_status(lp_current_device(), src->p, src->len, d->datastart, cap, bo, &n);
+            if (st == LILLIPUT_OK && n > 0 && n <= cap) {
+                src->served = true;
+                d->data = d->datastart;
+                d->rows = (int)n; d->cols = 1; d->type = CV_8U; d->step = 1;
+                d->dev_valid = false;
+                g_defer_stats[1]++;
+                return true;
+            }
+            // anything else (a result larger than the caller's buffer: the pointer must change; a dispatcher that is shutting down;
+            // a device error): the eager route below reproduces the direct behaviour
+        }
+    }
     LpEngineLease lease;
     LpEngine* eng = lease.get();
     if (!eng || !lp_mat_to_device(s, eng)) return false;
-    LpMat* d = e->dst;
-    const size_t cap = (size_t)(d->datalimit - d->datastart);
     LpEncodeReq rq;
     rq.src = lp_mat_frame(s);
     rq.quality = quality;

@@ -126,6 +126,7 @@ bool webp_decoder_decode(webp_decoder d, opencv_mat mat) // webp.cpp:302-362
     uint8_t* res = cn == 4 ? WebPDecodeBGRAInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step)
                            : WebPDecodeBGRInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step);
     if (!res) return false;
+    m->lazy.reset();
     m->dev_valid = false;   // the host copy is the frame now; it reaches the device with the next opencv_* call
     m->host_stale = false;
     return true;

@@ -532,6 +532,7 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
     // The framebuffers are private to ImageOps (ops.go:67-81): nothing reads their pixels on the host, so decoded, composited
     // and resized frames stay on the device for the duration of the call.
     struct LazyScope { int prev = lp_lazy_host_scope(1); ~LazyScope() { lp_lazy_host_scope(prev); } } lazy_scope;
+    LpEagerScope eager; // Part C brings its own strategy (the whole call is handed to the batched path below when others are in flight): the opencv_* calls it makes are executed, not recorded
     LpTransformInFlight in_flight;
     // initializeTransform (ops.go:483-546)
     Header hdr;

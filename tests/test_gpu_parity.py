@@ -621,3 +621,103 @@ def test_fused_resample_all_orientations_integer_scales(batch, oracle):
                 frame = oracle.transform_static(oracle.jpeg_decode(d), o, tw, th, oracle.FIT, norm)
                 assert (r.width, r.height) == (frame.shape[1], frame.shape[0]), (o, norm, tw, th)
                 assert r.data == oracle.jpeg_encode(frame, 85), (info["width"], info["height"], o, norm, tw, th)
+
+
+# ------------------------------------------------------------------------------------------ Part A as unchanged ops.go calls it
+def _part_a_run(la, sources, threads, jobs, w, h, method, deferred, quality=85, dst_cap=0):
+    la.lib().lilliput_hip_set_deferred(1 if deferred else 0)
+    try:
+        return la.service_sim(sources, threads, jobs, w, h, quality, method, max_size=4096, keep=True, part="A", dst_cap=dst_cap)
+    finally:
+        la.lib().lilliput_hip_set_deferred(1)
+
+
+@pytest.mark.gpu
+def test_part_a_call_sequence_of_ops_go_deferred_and_eager(hip_lib, oracle, fixture_bytes):
+    """The opencv_* calls that unchanged ops.go / opencv.go issue per request (lp_service_sim.c one_request_part_a: decoder_create,
+    read_header, encoder_create, get_jpeg_icc, resizeMat, read_data, orientation_transform, crop, resizeMat, resize, encoder_write,
+    get_data / get_height, releases), from several threads at once. With the calls DEFERRED (the default: recorded, then served as
+    one item of the batched path at encoder_write) and with every call executed eagerly: the reference CPU path's bytes both ways,
+    for Fit and Resize, all eight orientations (sunrise.jpg is EXIF 6), grey, and sources the deferral leaves alone (progressive)."""
+    import ctypes as C
+
+    import lilliput_amd as la
+
+    names = [n for n in sorted(fixture_bytes) if n.endswith(".jpg")]
+    sources = [fixture_bytes[n] for n in names]
+    st0 = (C.c_uint64 * 4)()
+    hip_lib.lilliput_hip_deferred_stats(st0)
+    ops = la.ImageOps(4096)
+    b = la.Batch(0)
+    for method, w, h in ((la.ImageOpsFit, 64, 48), (la.ImageOpsResize, 50, 70), (la.ImageOpsFit, 5000, 5000)):
+        # The two routes' own answers -- each held to the reference CPU path by the tests above (byte for byte at integer scales, a
+        # pre-encode frame within +-1 LSB that the output encodes exactly at fractional ones): deferred Part A must give what the
+        # batched path gives, eager Part A what the direct route gives; and the reference's bytes outright wherever the resample is exact.
+        via_batch = [r.data for r in b.transform(sources, w, h, method=method, quality=85)]
+        direct = []
+        for d_ in sources:
+            dec = la.Decoder(d_)
+            direct.append(ops.Transform(dec, la.ImageOptions(".jpeg", w, h, method, False, {la.JpegQuality: 85})))
+            dec.Close()
+        exact = [oracle.transform_any_to_jpeg(d_, w, h, 85, method) for d_ in sources] if (w, h) == (5000, 5000) else None
+        for deferred in (True, False):
+            r = _part_a_run(la, sources, 6, 3 * len(sources), w, h, method, deferred)
+            assert r["ok"] == r["jobs"], (method, w, h, deferred, r["first_error"])
+            for k, (n, got) in enumerate(zip(names, r["outputs"])):
+                assert got == (via_batch if deferred else direct)[k], (n, method, w, h, "deferred" if deferred else "eager")
+                if exact is not None:
+                    assert got == exact[k], (n, "no resample: the reference's bytes")
+    ops.Close()
+    b.close()
+    st1 = (C.c_uint64 * 4)()
+    hip_lib.lilliput_hip_deferred_stats(st1)
+    assert st1[0] > st0[0] and st1[1] > st0[1]      # chains were recorded, and served by the batched path
+    # a destination too small for the result: the encoder "reallocates", the Go side sees the pointer change -> ErrBufTooSmall, both ways
+    for deferred in (True, False):
+        r = _part_a_run(la, sources[:2], 2, 4, 256, 256, la.ImageOpsFit, deferred, dst_cap=300)
+        assert r["ok"] == 0 and r["first_error"] == 3, (deferred, r["first_error"])
+
+
+@pytest.mark.gpu
+def test_deferred_mats_materialise_for_anyone_who_looks(hip_lib, oracle, fixture_bytes):
+    """A recorded chain is run the eager way as soon as something other than the JPEG encoder needs the pixels: opencv_mat_get_data on
+    the decoded / oriented / resized framebuffer returns the reference's pixels; a decoder closed before the chain ran leaves the chain
+    with its own copy of the bytes (the caller may reuse its buffer after Close)."""
+    import ctypes as C
+
+    L = hip_lib
+    L.opencv_mat_create_from_data.restype = C.c_void_p
+    L.opencv_decoder_create.restype = C.c_void_p
+    L.opencv_mat_get_data.restype = C.c_void_p
+    L.opencv_mat_crop.restype = C.c_void_p
+    for f in ("opencv_mat_release", "opencv_decoder_release", "opencv_mat_orientation_transform", "opencv_mat_resize"):
+        getattr(L, f).restype = None
+    data = fixture_bytes["sunrise.jpg"]  # 100 x 75, EXIF orientation 6
+    px = oracle.jpeg_decode(data)
+    src = np.frombuffer(bytearray(data), dtype=np.uint8).copy()
+    buf = L.opencv_mat_create_from_data(C.c_int(src.size), C.c_int(1), C.c_int(0), C.c_void_p(src.ctypes.data), C.c_size_t(src.size))
+    d = L.opencv_decoder_create(C.c_void_p(buf))
+    assert L.opencv_decoder_read_header(C.c_void_p(d))
+    fb = np.zeros(1 << 20, dtype=np.uint8)
+    fb2 = np.zeros(1 << 20, dtype=np.uint8)
+    m = L.opencv_mat_create_from_data(C.c_int(100), C.c_int(75), C.c_int(16), C.c_void_p(fb.ctypes.data), C.c_size_t(fb.size))
+    assert L.opencv_decoder_read_data(C.c_void_p(d), C.c_void_p(m))
+    assert not fb[:100].any()                                   # nothing decoded yet: the call was recorded
+    L.opencv_mat_orientation_transform(C.c_int(6), C.c_void_p(m))
+    assert (L.opencv_mat_get_width(C.c_void_p(m)), L.opencv_mat_get_height(C.c_void_p(m))) == (75, 100)
+    view = L.opencv_mat_crop(C.c_void_p(m), C.c_int(5), C.c_int(10), C.c_int(60), C.c_int(80))
+    m2 = L.opencv_mat_create_from_data(C.c_int(30), C.c_int(40), C.c_int(16), C.c_void_p(fb2.ctypes.data), C.c_size_t(fb2.size))
+    L.opencv_mat_resize(C.c_void_p(view), C.c_void_p(m2), C.c_int(30), C.c_int(40), C.c_int(3))
+    # the decoder goes away and the caller scribbles over its buffer BEFORE anyone asked for pixels
+    L.opencv_decoder_release(C.c_void_p(d))
+    L.opencv_mat_release(C.c_void_p(buf))
+    src[:] = 0
+    oriented = oracle.orientation_transform(px, 6)
+    want, _ = oracle.resize_area(np.ascontiguousarray(oriented[10:90, 5:65]), 30, 40)
+    assert L.opencv_mat_get_data(C.c_void_p(m2)) == fb2.ctypes.data
+    got = fb2[: 40 * 30 * 3].reshape(40, 30, 3)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1   # a fractional scale: the +-1 LSB contract of the resize (integer scales are exact)
+    assert L.opencv_mat_get_data(C.c_void_p(m)) == fb.ctypes.data
+    assert np.array_equal(fb[: 100 * 75 * 3].reshape(100, 75, 3), oriented)   # the oriented frame itself: exact
+    for x in (view, m2, m):
+        L.opencv_mat_release(C.c_void_p(x))
