@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "lp_abi.h"
+#include "lp_abi_guard.h"
 
 namespace {
 
@@ -141,16 +142,17 @@ extern "C" {
 bool cicp_is_hdr_transfer(uint8_t transfer) { return transfer == 16 || transfer == 18; } // color_info.cpp:38-41: PQ, HLG
 
 bool icc_header_is_sane(const uint8_t* icc, size_t icc_len) // color_info.cpp:70-79
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!icc || icc_len < 128) return false;
     return (size_t)be32(icc) == icc_len;
 }
+LP_ABI_CATCH("icc_header_is_sane", return false)
 
 // color_info.cpp:17-36: the ICC profile's 'cicp' tag names PQ or HLG. The acceptance rules are those of lcms on this route:
 // 'acsp' magic, at most 100 tags, a tag is ignored when it does not fit inside the profile, the element is type 'cicp' and
 // exactly 12 bytes (Type_VideoSignal_Read).
 bool is_hdr_transfer_function(const uint8_t* icc, size_t len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!icc || len == 0 || len > 1024 * 1024 || len < 132) return false;
     if (memcmp(icc + 36, "acsp", 4) != 0) return false;
     size_t limit = be32(icc);
@@ -168,9 +170,10 @@ bool is_hdr_transfer_function(const uint8_t* icc, size_t len)
     }
     return false;
 }
+LP_ABI_CATCH("is_hdr_transfer_function", return false)
 
 const uint8_t* cicp_get_icc_profile(uint8_t primaries, size_t* profile_size) // color_info.cpp:43-68
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     int idx;
     switch (primaries) {
     case 11: case 12: idx = 1; break; // SMPTE RP 431-2, EG 432-1: P3 primaries, D65
@@ -183,37 +186,41 @@ const uint8_t* cicp_get_icc_profile(uint8_t primaries, size_t* profile_size) // 
     if (profile_size) *profile_size = p.size();
     return p.data();
 }
+LP_ABI_CATCH("cicp_get_icc_profile", return nullptr)
 
 const uint8_t* lilliput_hip_srgb_icc_profile(size_t* profile_size) // lilliput.go:18-22 SRGBICCProfile
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     const std::vector<uint8_t>& p = profile(0);
     if (profile_size) *profile_size = p.size();
     return p.data();
 }
+LP_ABI_CATCH("lilliput_hip_srgb_icc_profile", return nullptr)
 
 // color_info.cpp:112-204. src: width * height * 3 samples of src_depth bits; dst: width * height * 3 bytes. Host pointers.
 void tonemap_rgb_to_sdr(const uint16_t* src, uint8_t* dst, int width, int height, int src_depth, uint8_t transfer, uint8_t primaries)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!src || !dst || width <= 0 || height <= 0 || src_depth < 1 || src_depth > 16) return;
     LpEngineLease lease;
     LpEngine* eng = lease.get();
     if (!eng) { fprintf(stderr, "lilliput_hip: tone map failed (no device)\n"); return; }
     if (eng->tonemap_host(src, dst, width, height, src_depth, transfer, primaries)) fprintf(stderr, "lilliput_hip: tone map failed: %s\n", eng->last_error().c_str());
 }
+LP_ABI_CATCH("tonemap_rgb_to_sdr", return)
 
 // color_info.cpp:206-236. Host pointer, tightly packed; alpha untouched.
 void tonemap_rgb_8u_inplace(uint8_t* pixels, int width, int height, int channels, uint8_t transfer, uint8_t primaries)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!pixels || width <= 0 || height <= 0 || (channels != 3 && channels != 4)) return;
     LpEngineLease lease;
     LpEngine* eng = lease.get();
     if (!eng) { fprintf(stderr, "lilliput_hip: tone map failed (no device)\n"); return; }
     if (eng->tonemap_host8(pixels, width, height, channels, transfer, primaries)) fprintf(stderr, "lilliput_hip: tone map failed: %s\n", eng->last_error().c_str());
 }
+LP_ABI_CATCH("tonemap_rgb_8u_inplace", return)
 
 // Framebuffer.TonemapToSDR (opencv.go:794-812) for a Mat whose pixels live on the device: no host round trip.
 int lilliput_hip_mat_tonemap(opencv_mat mat, uint8_t transfer, uint8_t primaries)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!m || m->rows <= 0 || m->cols <= 0) return 0;
     const int type_cn = ((m->type >> 3) & 511) + 1, depth = m->type & 7;
@@ -225,5 +232,6 @@ int lilliput_hip_mat_tonemap(opencv_mat mat, uint8_t transfer, uint8_t primaries
     m->dev_valid = true;
     return lp_mat_to_host(m, eng) ? 0 : -1;
 }
+LP_ABI_CATCH("lilliput_hip_mat_tonemap", return 0)
 
 } // extern "C"

@@ -13,6 +13,7 @@
 #include "lp_abi.h"
 #include "lp_abi_gif.h"
 #include "lp_gif.h"
+#include "lp_abi_guard.h"
 
 struct giflib_decoder_struct {
     LpMat* src = nullptr; // the 1 x N CV_8U Mat over the caller's GIF bytes
@@ -103,7 +104,8 @@ void clip_prev(giflib_decoder d, int bw, int bh, int* x, int* y, int* w, int* h)
 extern "C" {
 
 giflib_decoder giflib_decoder_create(const opencv_mat buf) // giflib.cpp:103-158
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     if (!buf) return nullptr;
     auto m = static_cast<LpMat*>(const_cast<void*>((const void*)buf));
     auto d = new giflib_decoder_struct();
@@ -112,6 +114,7 @@ giflib_decoder giflib_decoder_create(const opencv_mat buf) // giflib.cpp:103-158
     if (!m->data || !d->gif.open(m->data, len) || d->gif.swidth <= 0 || d->gif.sheight <= 0) { delete d; return nullptr; }
     return d;
 }
+LP_ABI_CATCH("giflib_decoder_create", return nullptr)
 
 int giflib_decoder_get_width(const giflib_decoder d) { return d->gif.swidth; }
 int giflib_decoder_get_height(const giflib_decoder d) { return d->gif.sheight; }
@@ -121,26 +124,28 @@ int giflib_decoder_get_frame_height(const giflib_decoder d) { return d->gif.heig
 int giflib_decoder_get_prev_frame_delay(const giflib_decoder d) { return d->prev_delay; }
 
 int giflib_decoder_get_prev_frame_disposal(const giflib_decoder d) // giflib.cpp:190-202
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     switch (d->prev_disposal) {
     case DISPOSE_BACKGROUND: return GIF_DISPOSE_BACKGROUND;
     case DISPOSE_PREVIOUS: return GIF_DISPOSE_PREVIOUS;
     default: return GIF_DISPOSE_NONE; // "do not dispose" and "unspecified"
     }
 }
+LP_ABI_CATCH("giflib_decoder_get_prev_frame_disposal", return 0)
 
 void giflib_decoder_release(giflib_decoder d) { delete d; }
 
 giflib_decoder_frame_state giflib_decoder_decode_frame_header(giflib_decoder d) // giflib.cpp:329-342
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     giflib_decoder_frame_state seek = seek_next_frame(d);
     if (seek == giflib_decoder_eof || seek == giflib_decoder_error) return seek;
     if (d->gif.get_image_header() == LP_GIF_ERROR) return giflib_decoder_error;
     return giflib_decoder_have_next_frame;
 }
+LP_ABI_CATCH("giflib_decoder_decode_frame_header", return giflib_decoder_error)
 
 giflib_decoder_frame_state giflib_decoder_skip_frame(giflib_decoder d) // giflib.cpp:563-583
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     giflib_decoder_frame_state seek = giflib_decoder_decode_frame_header(d);
     if (seek != giflib_decoder_have_next_frame) return seek;
     const uint8_t* block;
@@ -150,6 +155,7 @@ giflib_decoder_frame_state giflib_decoder_skip_frame(giflib_decoder d) // giflib
     }
     return giflib_decoder_have_next_frame;
 }
+LP_ABI_CATCH("giflib_decoder_skip_frame", return giflib_decoder_error)
 
 // Host half of giflib_decoder_decode_frame (giflib.cpp:632-690): the frame's colour indices, de-interlaced.
 static bool read_frame_indices(giflib_decoder d)
@@ -191,7 +197,7 @@ static void after_frame(giflib_decoder d, const LpGifGcb& gcb) // giflib.cpp:713
 }
 
 bool giflib_decoder_decode_frame(giflib_decoder d, opencv_mat mat) // giflib.cpp:632-724 + render_frame :349-561
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!d || !m) return false;
     if (!read_frame_indices(d)) return false;
@@ -259,9 +265,10 @@ bool giflib_decoder_decode_frame(giflib_decoder d, opencv_mat mat) // giflib.cpp
     after_frame(d, gcb);
     return true;
 }
+LP_ABI_CATCH("giflib_decoder_decode_frame", return false)
 
 struct GifAnimationInfo giflib_decoder_get_animation_info(const giflib_decoder d) // giflib.cpp:1308-1431
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     GifAnimationInfo info = {1, 0, 255, 255, 255, 0, 0};
     LpGifReader g; // a second walk over the same bytes, independent of the decode position
     if (!d || !d->src || !g.open(d->src->data, (size_t)d->src->rows * (size_t)d->src->cols)) return info;
@@ -313,11 +320,12 @@ struct GifAnimationInfo giflib_decoder_get_animation_info(const giflib_decoder d
     }
     return info;
 }
+LP_ABI_CATCH("giflib_decoder_get_animation_info", return GifAnimationInfo{})
 
 // Test access (no device work): the host half of decode_frame -- colour indices, frame rectangle, GCB and palette of the frame
 // whose header was just read. meta = {left, top, width, height, interlace, disposal, delay, transparent, color_count, local_map}.
 int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, int meta[10], uint8_t palette_rgb[768])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!d) return -1;
     if (!read_frame_indices(d)) return -1;
     LpGifReader& g = d->gif;
@@ -334,5 +342,6 @@ int lilliput_hip_gif_read_frame(giflib_decoder d, uint8_t* indices, size_t cap, 
     after_frame(d, gcb);
     return (int)n;
 }
+LP_ABI_CATCH("lilliput_hip_gif_read_frame", return -1)
 
 } // extern "C"

@@ -16,6 +16,7 @@
 #include "lp_abi.h"
 #include "lp_abi_gif.h"
 #include "lp_launch.h"
+#include "lp_abi_guard.h"
 
 namespace {
 const int kLzMaxCode = 4095, kFlush = 4096, kFirstCode = 4097;
@@ -174,7 +175,7 @@ static void frame_gcb_of(const std::vector<LpGifExtBlock>& ext, LpGifGcb* gcb, b
 extern "C" {
 
 giflib_encoder giflib_encoder_create(void* buf, size_t buf_len) // giflib.cpp:773-797
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!buf) return nullptr;
     auto e = new giflib_encoder_struct();
     e->dst = (uint8_t*)buf;
@@ -182,9 +183,10 @@ giflib_encoder giflib_encoder_create(void* buf, size_t buf_len) // giflib.cpp:77
     memset(e->buf, 0, sizeof(e->buf));
     return e;
 }
+LP_ABI_CATCH("giflib_encoder_create", return nullptr)
 
 bool giflib_encoder_init(giflib_encoder e, const giflib_decoder d, int width, int height) // giflib.cpp:800-851 + EGifPutScreenDesc
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!e || !d) return false;
     const LpGifReader& g = lp_gif_reader(d);
     e->swidth = width;
@@ -203,9 +205,10 @@ bool giflib_encoder_init(giflib_encoder e, const giflib_decoder d, int width, in
     for (int i = 0; i < g.global_map.count; i++) e->write(g.global_map.rgb[i], 3);
     return !e->write_failed;
 }
+LP_ABI_CATCH("giflib_encoder_init", return false)
 
 bool giflib_encoder_encode_frame(giflib_encoder e, const giflib_decoder d, const opencv_mat frame) // giflib.cpp:1135-1214
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!e || !d || !frame) return false;
     const LpGifReader& g = lp_gif_reader(d);
     auto m = static_cast<LpMat*>(const_cast<void*>((const void*)frame));
@@ -301,9 +304,10 @@ bool giflib_encoder_encode_frame(giflib_encoder e, const giflib_decoder d, const
     e->have_written_first_frame = true;
     return !e->write_failed;
 }
+LP_ABI_CATCH("giflib_encoder_encode_frame", return false)
 
 bool giflib_encoder_flush(giflib_encoder e, const giflib_decoder d) // giflib.cpp:1216-1250 + EGifCloseFile
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!e || !d) return false;
     e->ext = lp_gif_reader(d).ext_blocks; // whatever followed the last frame
     if (!e->write_extensions()) return false;
@@ -311,6 +315,7 @@ bool giflib_encoder_flush(giflib_encoder e, const giflib_decoder d) // giflib.cp
     e->write(&term, 1);
     return !e->write_failed;
 }
+LP_ABI_CATCH("giflib_encoder_flush", return false)
 
 void giflib_encoder_release(giflib_encoder e) { delete e; }
 int giflib_encoder_get_output_length(giflib_encoder e) { return (int)e->off; }

@@ -14,6 +14,7 @@
 
 #include "../../include/lilliput_hip.h"
 #include "lp_png.h"
+#include "lp_abi_guard.h"
 
 namespace {
 // ------------------------------------------------------------------------------------------------ JPEG
@@ -176,15 +177,16 @@ static inline bool is_type(const uint8_t* t, const char* name) { return memcmp(t
 extern "C" {
 
 int opencv_decoder_get_jpeg_icc(void* src, size_t src_len, void* dest, size_t dest_len) // opencv.cpp:252-296
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!src || !dest) return 0;
     std::vector<App2> app2;
     if (!jpeg_header_ok(static_cast<const uint8_t*>(src), src_len, app2)) return 0;
     return jpeg_icc_assemble(app2, static_cast<uint8_t*>(dest), dest_len);
 }
+LP_ABI_CATCH("opencv_decoder_get_jpeg_icc", return 0)
 
 int opencv_decoder_get_png_icc(void* src, size_t src_len, void* dest, size_t dest_len) // opencv.cpp:314-344
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!src || !dest) return 0;
     LpPngInfo info;
     if (!lp_png_read_info(static_cast<const uint8_t*>(src), src_len, info)) return 0;
@@ -192,9 +194,10 @@ int opencv_decoder_get_png_icc(void* src, size_t src_len, void* dest, size_t des
     memcpy(dest, info.icc.data(), info.icc.size());
     return (int)info.icc.size();
 }
+LP_ABI_CATCH("opencv_decoder_get_png_icc", return 0)
 
 int opencv_decoder_get_png_cicp(void* src, size_t src_len, uint8_t* primaries, uint8_t* transfer, uint8_t* matrix, uint8_t* full_range) // opencv.cpp:357-395
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!src) return 0;
     LpPngInfo info;
     if (!lp_png_read_info(static_cast<const uint8_t*>(src), src_len, info) || !info.have_cicp) return 0;
@@ -204,11 +207,12 @@ int opencv_decoder_get_png_cicp(void* src, size_t src_len, uint8_t* primaries, u
     *full_range = info.cicp[3];
     return 1;
 }
+LP_ABI_CATCH("opencv_decoder_get_png_cicp", return 0)
 
 // Splice a 16-byte cICP chunk in right after IHDR of a finished PNG, in place; returns the new length, or the old one
 // when the buffer is not a PNG or has no room (opencv.cpp:413-463).
 size_t opencv_png_insert_cicp(void* png, size_t png_len, size_t png_cap, uint8_t primaries, uint8_t transfer, uint8_t matrix, uint8_t full_range)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     uint8_t* b = static_cast<uint8_t*>(png);
     const size_t add = 16;
     if (!b || png_len < 8 + 12 || png_len + add > png_cap) return png_len;
@@ -222,5 +226,6 @@ size_t opencv_png_insert_cicp(void* png, size_t png_len, size_t png_cap, uint8_t
     memcpy(b + at, c, add);
     return png_len + add;
 }
+LP_ABI_CATCH("opencv_png_insert_cicp", return 0)
 
 } // extern "C"

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include "lp_abi_guard.h"
 
 extern "C" {
 const int CV_INTER_AREA = 3;   // cv::INTER_AREA
@@ -33,12 +34,22 @@ const int CV_INTER_CUBIC = 2;  // cv::INTER_CUBIC
 static thread_local std::string g_last_error;
 void lp_set_error(const std::string& s) { g_last_error = s; }
 extern "C" const char* lilliput_hip_last_error(void) { return g_last_error.c_str(); }
-extern "C" int lilliput_hip_device_count(void)
+// lp_abi_guard.h's test hook: the next n calls of lp_abi_test_fault() throw (what an allocation that fails looks like to the guard)
+static std::atomic<int> g_test_faults{0};
+extern "C" void lilliput_hip_test_fault(int n) { g_test_faults.store(n); }
+void lp_abi_test_fault()
 {
+    int v = g_test_faults.load(std::memory_order_relaxed);
+    while (v > 0 && !g_test_faults.compare_exchange_weak(v, v - 1)) {}
+    if (v > 0) throw std::bad_alloc();
+}
+extern "C" int lilliput_hip_device_count(void)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+LP_ABI_CATCH("lilliput_hip_device_count", return 0)
 
 static thread_local int t_device = -1; // lp_thread_device: which GPU this thread's one-image calls run on (-1: LILLIPUT_HIP_DEVICE, else 0)
 int lp_thread_device(int device) { int prev = t_device; t_device = device; return prev; }
@@ -157,14 +168,15 @@ LpEngineLease::~LpEngineLease()
 
 // engines checked out now, idle in the pool, created so far, destroyed by the pool's bounds
 extern "C" void lilliput_hip_engine_pool_stats(size_t out[4])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     EnginePool& P = engine_pool();
     std::lock_guard<std::mutex> lk(P.mu);
     out[0] = P.live; out[1] = P.idle.size(); out[2] = P.created; out[3] = P.trimmed;
 }
+LP_ABI_CATCH("lilliput_hip_engine_pool_stats", return)
 
 extern "C" int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return LILLIPUT_ERR_DEVICE; }
@@ -176,6 +188,7 @@ extern "C" int lilliput_hip_mem_info(int device, size_t* free_bytes, size_t* tot
     if (total_bytes) *total_bytes = t;
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_hip_mem_info", return LILLIPUT_ERR_DEVICE)
 
 // ---- device block pool (size-bucketed free lists; hipMalloc is too slow to call per Mat)
 namespace {
@@ -311,10 +324,11 @@ bool lp_mat_host_current(LpMat* m)
 }
 
 extern "C" int lilliput_hip_mat_sync_host(opencv_mat mat)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     return m && lp_mat_host_current(m) ? 0 : -1;
 }
+LP_ABI_CATCH("lilliput_hip_mat_sync_host", return -1)
 
 LpFrame lp_mat_frame(const LpMat* m)
 {
@@ -586,7 +600,8 @@ int opencv_type_channels(int type) { return cv_channels(type); }              //
 int opencv_type_convert_depth(int t, int depth) { return (depth & 7) + ((cv_channels(t) - 1) << 3); } // opencv.cpp:93-96
 
 opencv_mat opencv_mat_create(int width, int height, int type) // opencv.cpp:22-25
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto m = new LpMat();
     m->rows = height; m->cols = width; m->type = type;
     m->step = (size_t)width * cv_elem_size(type);
@@ -595,9 +610,10 @@ opencv_mat opencv_mat_create(int width, int height, int type) // opencv.cpp:22-2
     m->datalimit = m->data + m->own.size();
     return m;
 }
+LP_ABI_CATCH("opencv_mat_create", return nullptr)
 
 opencv_mat opencv_mat_create_from_data(int width, int height, int type, void* data, size_t data_len) // opencv.cpp:27-36
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     size_t total = (size_t)width * height * cv_elem_size(type);
     if (total > data_len) return NULL;
     auto m = new LpMat();
@@ -607,18 +623,20 @@ opencv_mat opencv_mat_create_from_data(int width, int height, int type, void* da
     m->datalimit = (uint8_t*)data + data_len;
     return m;
 }
+LP_ABI_CATCH("opencv_mat_create_from_data", return nullptr)
 
 opencv_mat opencv_mat_create_empty_from_data(int length, void* data) // opencv.cpp:38-49
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = new LpMat();
     m->rows = 0; m->cols = 1; m->type = CV_8U; m->step = 1;
     m->data = m->datastart = (uint8_t*)data;
     m->datalimit = m->data + length;
     return m;
 }
+LP_ABI_CATCH("opencv_mat_create_empty_from_data", return nullptr)
 
 bool opencv_mat_set_row_stride(opencv_mat mat, size_t stride) // opencv.cpp:51-75
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (m->step == stride) return true;
     size_t ws = (size_t)m->cols * cv_elem_size(m->type);
@@ -630,20 +648,22 @@ bool opencv_mat_set_row_stride(opencv_mat mat, size_t stride) // opencv.cpp:51-7
     m->dev_valid = false;
     return true;
 }
+LP_ABI_CATCH("opencv_mat_set_row_stride", return false)
 
 void opencv_mat_release(opencv_mat mat) { delete static_cast<LpMat*>(mat); } // opencv.cpp:77-81
 
 int opencv_mat_get_width(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->cols; }   // opencv.cpp:223-227
 int opencv_mat_get_height(const opencv_mat mat) { return static_cast<const LpMat*>(mat)->rows; }  // opencv.cpp:229-233
 void* opencv_mat_get_data(const opencv_mat mat) // opencv.cpp:235-239
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(const_cast<void*>((const void*)mat));
     lp_mat_host_current(m); // a caller that asks for the pointer is about to look at the pixels
     return m->data;
 }
+LP_ABI_CATCH("opencv_mat_get_data", return nullptr)
 
 opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int height) // opencv.cpp:210-215
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto s = static_cast<const LpMat*>(src);
     if (x < 0 || y < 0 || width < 0 || height < 0 || x + width > s->cols || y + height > s->rows) {
         // cv::Mat(Rect) asserts here and the reference would abort; refuse instead
@@ -674,9 +694,10 @@ opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int he
     }
     return m;
 }
+LP_ABI_CATCH("opencv_mat_crop", return nullptr)
 
 void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int height, int interpolation) // opencv.cpp:196-208
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     auto d = static_cast<LpMat*>(dst);
     LpEngineLease lease;
@@ -698,9 +719,10 @@ void opencv_mat_resize(const opencv_mat src, opencv_mat dst, int width, int heig
     if (!dev_resize(s, d, width, height, eng)) return;
     lp_mat_to_host(d, eng);
 }
+LP_ABI_CATCH("opencv_mat_resize", return)
 
 void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat mat) // opencv.cpp:217-221
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     int o = (int)orientation;
     if (!m || o <= 1 || o > 8 || m->rows <= 0 || m->cols <= 0) return; // cv::ExifTransform: TL and unknown values are no-ops
@@ -722,11 +744,12 @@ void opencv_mat_orientation_transform(CVImageOrientation orientation, opencv_mat
     m->step = (size_t)nc * cv_elem_size(m->type);
     lp_mat_to_host(m, eng);
 }
+LP_ABI_CATCH("opencv_mat_orientation_transform", return)
 
 // The host side of the pixel hand-over (lilliput_hip_pixels_header): rows from a frame decoded elsewhere become the Mat's content;
 // they reach the device with the next opencv_* call, like a WebP frame decoded by libwebp.
 extern "C" int lilliput_hip_mat_set_pixels(opencv_mat mat, const void* pixels, size_t stride)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!m || !pixels || !m->data || m->rows <= 0 || m->cols <= 0) return -1;
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
@@ -737,9 +760,10 @@ extern "C" int lilliput_hip_mat_set_pixels(opencv_mat mat, const void* pixels, s
     m->host_stale = false;
     return 0;
 }
+LP_ABI_CATCH("lilliput_hip_mat_set_pixels", return -1)
 
 void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!m) return;
     const size_t rowb = (size_t)m->cols * cv_elem_size(m->type);
@@ -748,9 +772,10 @@ void opencv_mat_reset(opencv_mat mat) // opencv.cpp:471-477
     m->dev_valid = false;
     m->host_stale = false;
 }
+LP_ABI_CATCH("opencv_mat_reset", return)
 
 void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alpha) // opencv.cpp:488-496
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!m) return;
     const int cn = cv_channels(m->type);
@@ -762,6 +787,7 @@ void opencv_mat_set_color(opencv_mat mat, int red, int green, int blue, int alph
     m->dev_valid = false;
     m->host_stale = false;
 }
+LP_ABI_CATCH("opencv_mat_set_color", return)
 
 static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int width, int height, int kind)
 {
@@ -804,27 +830,31 @@ static int composite_common(LpMat* s, LpMat* d, int xOffset, int yOffset, int wi
 }
 
 int opencv_mat_clear_to_transparent(opencv_mat mat, int xOffset, int yOffset, int width, int height) // opencv.cpp:508-543
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!m) return OPENCV_ERROR_NULL_MATRIX;
     if (xOffset < 0 || yOffset < 0 || xOffset + width > m->cols || yOffset + height > m->rows) return OPENCV_ERROR_OUT_OF_BOUNDS;
     if (width <= 0 || height <= 0) return OPENCV_ERROR_INVALID_DIMENSIONS;
     return composite_common(nullptr, m, xOffset, yOffset, width, height, 2);
 }
+LP_ABI_CATCH("opencv_mat_clear_to_transparent", return OPENCV_ERROR_UNKNOWN)
 
 int opencv_copy_to_region_with_alpha(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height) // opencv.cpp:556-667
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return composite_common(static_cast<LpMat*>(src), static_cast<LpMat*>(dst), xOffset, yOffset, width, height, 0);
 }
+LP_ABI_CATCH("opencv_copy_to_region_with_alpha", return OPENCV_ERROR_UNKNOWN)
 
 int opencv_copy_to_region(opencv_mat src, opencv_mat dst, int xOffset, int yOffset, int width, int height) // opencv.cpp:680-752
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return composite_common(static_cast<LpMat*>(src), static_cast<LpMat*>(dst), xOffset, yOffset, width, height, 1);
 }
+LP_ABI_CATCH("opencv_copy_to_region", return OPENCV_ERROR_UNKNOWN)
 
 // ---- decoder (opencv.cpp:99-171)
 opencv_decoder opencv_decoder_create(const opencv_mat buf)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto m = static_cast<const LpMat*>(buf);
     if (!m || !m->data) return NULL;
     const size_t len = (size_t)m->cols * (size_t)m->rows * cv_elem_size(m->type);
@@ -841,15 +871,17 @@ opencv_decoder opencv_decoder_create(const opencv_mat buf)
     d->is_bmp = bmp;
     return d;
 }
+LP_ABI_CATCH("opencv_decoder_create", return nullptr)
 
 const char* opencv_decoder_get_description(const opencv_decoder d)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!d) return nullptr;
     auto p = static_cast<const LpDecoder*>(d);
     return p->is_png ? "PNG" : p->is_bmp ? "BMP" : "JPEG";
 }
+LP_ABI_CATCH("opencv_decoder_get_description", return nullptr)
 void opencv_decoder_release(opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<LpDecoder*>(dd);
     if (!d) return;
     // Deferred chains still read this decoder's bytes, and after Close the caller may free or reuse its buffer (opencv.go:663-667).
@@ -869,9 +901,11 @@ void opencv_decoder_release(opencv_decoder dd)
         }
     delete d;
 }
+LP_ABI_CATCH("opencv_decoder_release", return)
 
 bool opencv_decoder_read_header(opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto d = static_cast<LpDecoder*>(dd);
     if (!d) return false;
     if (d->parsed) return d->parse_rc == LP_PARSE_OK;
@@ -895,29 +929,34 @@ bool opencv_decoder_read_header(opencv_decoder dd)
     }
     return d->parse_rc == LP_PARSE_OK;
 }
+LP_ABI_CATCH("opencv_decoder_read_header", return false)
 
 int opencv_decoder_get_width(const opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
     return d->is_png ? (int)d->png.width : d->is_bmp ? d->bmp.width : (int)d->hdr.j.width;
 }
+LP_ABI_CATCH("opencv_decoder_get_width", return 0)
 int opencv_decoder_get_height(const opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
     return d->is_png ? (int)d->png.height : d->is_bmp ? d->bmp.height : (int)d->hdr.j.height;
 }
+LP_ABI_CATCH("opencv_decoder_get_height", return 0)
 int opencv_decoder_get_pixel_type(const opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
     if (d->is_png) return (d->png.depth == 16 ? 2 /* CV_16U */ : 0) + ((d->png_channels - 1) << 3); // the Go side demotes 16-bit types (opencv.go:255-257)
     if (d->is_bmp) return (d->bmp.channels - 1) << 3; // CV_8UC1 / C3 / C4
     return d->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3;
 }
+LP_ABI_CATCH("opencv_decoder_get_pixel_type", return 0)
 int opencv_decoder_get_orientation(const opencv_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
     return d->is_png || d->is_bmp ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
 }
+LP_ABI_CATCH("opencv_decoder_get_orientation", return 0)
 
 // cv::PngDecoder::readData into an 8-bit Mat of the announced channel count: chunk walk + inflate on the
 // host (serial, like libpng + zlib-ng in the reference), filter reversal and pixel expansion on the device.
@@ -959,7 +998,7 @@ static bool png_read_data(LpDecoder* d, LpMat* m)
 }
 
 bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<LpDecoder*>(dd);
     auto m = static_cast<LpMat*>(dst);
     if (!d || !m) return false;
@@ -1005,20 +1044,22 @@ bool opencv_decoder_read_data(opencv_decoder dd, opencv_mat dst)
     m->dev_valid = true;
     return lp_mat_to_host(m, eng);
 }
+LP_ABI_CATCH("opencv_decoder_read_data", return false)
 
 // Test access (no device work): would the PNG's image data be accepted? Returns the number of inflated bytes, or -1.
 extern "C" long lilliput_hip_png_inflate_check(const void* data, size_t len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     LpPngInfo pi;
     LpBytes filtered;
     if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
     return (long)filtered.size();
 }
+LP_ABI_CATCH("lilliput_hip_png_inflate_check", return -1)
 
 // Test access: the filtered rows the image data inflates to (what the un-filter kernel is given). Returns their size, -1 when the file
 // is rejected, -2 when `cap` is too small.
 extern "C" long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     LpPngInfo pi;
     LpBytes filtered;
     if (!lp_png_read_info((const uint8_t*)data, len, pi) || !lp_png_read_idat((const uint8_t*)data, len, pi, filtered)) return -1;
@@ -1026,11 +1067,12 @@ extern "C" long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uin
     memcpy(out, filtered.data(), filtered.size());
     return (long)filtered.size();
 }
+LP_ABI_CATCH("lilliput_hip_png_inflate_bytes", return -1)
 // Test access: which inflater lp_png_read_idat tries first: 1 the library's own (default), 0 zlib only. Returns the previous setting.
 extern "C" int lilliput_hip_png_set_inflater(int own) { return lp_png_set_inflater(own); }
 // Test access: lp_inflate_exact on a caller's buffer (copied behind the padding the bit reader wants)
 extern "C" int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t* out, size_t out_len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     std::vector<uint8_t> z(in_len + LP_INFLATE_PAD, 0);
     memcpy(z.data(), in, in_len);
     std::vector<uint8_t> o(out_len + 1, 0xa5); // one guard byte: the decoder must not write past out_len
@@ -1039,26 +1081,29 @@ extern "C" int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t
     if (r == 1 && out_len) memcpy(out, o.data(), out_len);
     return r;
 }
+LP_ABI_CATCH("lilliput_hip_inflate_exact", return 0)
 
 // Test access: the checksum routines of lp_inflate.cpp (which = 0 Adler-32, 1 CRC-32), same conventions as zlib's
 extern "C" uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return which ? lp_crc32(seed, (const uint8_t*)p, n) : lp_adler32(seed, (const uint8_t*)p, n);
 }
+LP_ABI_CATCH("lilliput_hip_checksum", return 0)
 
 // Test access (no device work): cv::BmpDecoder's answer for a file -- 0 decoded (w, h, channels, pixels), 1 header refused, 2 data refused, -1 cap
 extern "C" int lilliput_hip_bmp_decode(const void* data, size_t len, int* w, int* h, int* channels, uint8_t* out, size_t cap)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     LpBmpInfo bi;
     if (!lp_bmp_read_info((const uint8_t*)data, len, bi)) return 1;
     *w = bi.width; *h = bi.height; *channels = bi.channels;
     if ((size_t)bi.width * bi.height * bi.channels > cap) return -1;
     return lp_bmp_read_data((const uint8_t*)data, len, bi, out, (size_t)bi.width * bi.channels) ? 0 : 2;
 }
+LP_ABI_CATCH("lilliput_hip_bmp_decode", return -1)
 
 // ---- encoder (opencv.cpp:173-194)
 opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!ext || !dst) return NULL;
     std::string e(ext);
     for (auto& c : e) c = (char)tolower(c);
@@ -1069,11 +1114,13 @@ opencv_encoder opencv_encoder_create(const char* ext, opencv_mat dst)
     enc->png = png;
     return enc;
 }
+LP_ABI_CATCH("opencv_encoder_create", return nullptr)
 
 void opencv_encoder_release(opencv_encoder e) { delete static_cast<LpEncoder*>(e); }
 
 bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* opt, size_t opt_len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto e = static_cast<LpEncoder*>(ee);
     auto s = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     if (!e || !s || s->rows <= 0 || s->cols <= 0) return false;
@@ -1137,6 +1184,7 @@ bool opencv_encoder_write(opencv_encoder ee, const opencv_mat src, const int* op
     d->dev_valid = false;
     return true;
 }
+LP_ABI_CATCH("opencv_encoder_write", return false)
 
 } // extern "C"
 

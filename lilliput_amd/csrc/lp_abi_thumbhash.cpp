@@ -12,6 +12,7 @@
 
 #include "lp_abi.h"
 #include "lp_launch.h"
+#include "lp_abi_guard.h"
 
 struct thumbhash_encoder_struct {
     uint8_t* dst;
@@ -134,15 +135,17 @@ bool opponent_planes(const uint8_t* px, size_t n, int cn, float* L, float* P, fl
 extern "C" {
 
 thumbhash_encoder thumbhash_encoder_create(void* buf, size_t buf_len) // thumbhash.cpp:17-25
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto e = new thumbhash_encoder_struct();
     e->dst = (uint8_t*)buf;
     e->dst_len = buf_len;
     return e;
 }
+LP_ABI_CATCH("thumbhash_encoder_create", return nullptr)
 
 int thumbhash_encoder_encode(thumbhash_encoder e, const opencv_mat opaque_frame) // thumbhash.cpp:86-277
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(const_cast<void*>((const void*)opaque_frame));
     if (!e || !m || m->rows <= 0 || m->cols <= 0) return -1;
     const int cn = m->type == CV_8UC4 ? 4 : m->type == CV_8UC3 ? 3 : m->type == CV_8U ? 1 : 0;
@@ -207,6 +210,7 @@ int thumbhash_encoder_encode(thumbhash_encoder e, const opencv_mat opaque_frame)
     memcpy(e->dst, hash.data(), hash.size());
     return (int)hash.size();
 }
+LP_ABI_CATCH("thumbhash_encoder_encode", return -1)
 
 void thumbhash_encoder_release(thumbhash_encoder e) { delete e; }
 

@@ -15,6 +15,7 @@
 #include "lp_abi.h"
 #include "lp_webp.h"
 #include "lp_webp_sys.h"
+#include "lp_abi_guard.h"
 
 struct webp_decoder_struct {        // webp.cpp:10-29
     LpWebpFile file;
@@ -50,7 +51,8 @@ static inline int cvc(int type) { return (type >> 3) + 1; }
 extern "C" {
 
 webp_decoder webp_decoder_create(const opencv_mat buf) // webp.cpp:61-134
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto m = static_cast<const LpMat*>(buf);
     if (!m || !m->data) return nullptr;
     const size_t len = (size_t)m->rows * (size_t)m->cols * (size_t)cvc(m->type);
@@ -76,6 +78,7 @@ webp_decoder webp_decoder_create(const opencv_mat buf) // webp.cpp:61-134
     // webp_decoder_decode writes the frame straight into the caller's Mat, whose size the caller has checked (opencv.go:250-267).
     return d;
 }
+LP_ABI_CATCH("webp_decoder_create", return nullptr)
 
 int webp_decoder_get_width(const webp_decoder d) { return d->width; }
 int webp_decoder_get_height(const webp_decoder d) { return d->height; }
@@ -92,19 +95,20 @@ uint32_t webp_decoder_get_bg_color(const webp_decoder d) { return d->bgcolor; }
 uint32_t webp_decoder_get_loop_count(const webp_decoder d) { return d->loop_count; }
 
 size_t webp_decoder_get_icc(const webp_decoder d, void* dst, size_t dst_len) // webp.cpp:262-273
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (d->file.icc && d->file.icc_size > 0 && d->file.icc_size <= dst_len) {
         memcpy(dst, d->file.icc, d->file.icc_size);
         return d->file.icc_size;
     }
     return 0;
 }
+LP_ABI_CATCH("webp_decoder_get_icc", return 0)
 
 int webp_decoder_has_more_frames(webp_decoder d) { return d->current_frame_index < d->total_frame_count; }
 void webp_decoder_advance_frame(webp_decoder d) { d->current_frame_index++; }
 
 bool webp_decoder_decode(webp_decoder d, opencv_mat mat) // webp.cpp:302-362
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(mat);
     if (!d || !m) return false;
     if (d->current_frame_index < 1 || d->current_frame_index > d->total_frame_count) return false; // WebPMuxGetFrame: WEBP_MUX_NOT_FOUND
@@ -131,12 +135,13 @@ bool webp_decoder_decode(webp_decoder d, opencv_mat mat) // webp.cpp:302-362
     m->host_stale = false;
     return true;
 }
+LP_ABI_CATCH("webp_decoder_decode", return false)
 
 void webp_decoder_release(webp_decoder d) { delete d; }
 
 // ------------------------------------------------------------------------------------------------ encoder
 webp_encoder webp_encoder_create(void* buf, size_t buf_len, const void* icc, size_t icc_len, uint32_t bgcolor, int loop_count) // webp.cpp:395-426
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     webp_encoder e = new (std::nothrow) webp_encoder_struct();
     if (!e) return nullptr;
     e->dst = (uint8_t*)buf;
@@ -146,6 +151,7 @@ webp_encoder webp_encoder_create(void* buf, size_t buf_len, const void* icc, siz
     if (icc && icc_len) e->icc.assign((const uint8_t*)icc, (const uint8_t*)icc + icc_len);
     return e;
 }
+LP_ABI_CATCH("webp_encoder_create", return nullptr)
 
 static bool config_from_options(WebPConfig* c, const int* opt, size_t opt_len) // webp.cpp:450-498
 {
@@ -281,7 +287,7 @@ static bool anim_add(webp_encoder e, const WebPConfig& cfg, const uint8_t* px, i
 }
 
 size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, size_t opt_len, int delay, int blend, int dispose, int x_offset, int y_offset) // webp.cpp:436-755
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     (void)blend; (void)dispose; (void)x_offset; (void)y_offset; // stored by the reference for the first frame and never used
     if (!e) return 0;
     WebPConfig config;
@@ -344,11 +350,12 @@ size_t webp_encoder_write(webp_encoder e, const opencv_mat src, const int* opt, 
         return 0;
     }
 }
+LP_ABI_CATCH("webp_encoder_write", return 0)
 
 // Test access: the Y, U, V planes the lossy encoder is handed for this frame (k_webp_yuv420). 0 = ok, 1 = the frame has translucent pixels
 // (the product then lets libwebp import it), -1 = error.
 int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8_t* v)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto m = static_cast<LpMat*>(const_cast<void*>((const void*)src));
     if (!m || m->rows <= 0 || m->cols <= 0 || (cvc(m->type) != 3 && cvc(m->type) != 4)) return -1;
     LpEngineLease lease;
@@ -358,6 +365,7 @@ int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8
     if (eng->webp_yuv420(lp_mat_frame(m), webp_yuv_tables(), y, u, v, &translucent)) return -1;
     return translucent ? 1 : 0;
 }
+LP_ABI_CATCH("lilliput_hip_webp_yuv420", return -1)
 
 size_t webp_encoder_flush(webp_encoder e) { return webp_encoder_write(e, nullptr, nullptr, 0, 0, 0, 0, 0, 0); } // webp.cpp:780-783
 void webp_encoder_release(webp_encoder e) { delete e; }

@@ -23,6 +23,7 @@
 #include "lp_abi.h"
 #include "lp_coalesce.h"
 #include "lp_ops_logic.h"
+#include "lp_abi_guard.h"
 
 // One engine (= one compute stream + one copy stream + its arenas) per worker; a batch is split into contiguous parts, one per
 // worker, and the workers run concurrently on host threads so that one part's HBM-bound stages (IDCT, resample, unstuff) overlap
@@ -234,51 +235,57 @@ static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinn
 extern "C" {
 
 lilliput_hip_batch lilliput_hip_batch_create(int device)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = new LpBatch();
     b->device = device;
     if (!b->ensure_parts(1)) { delete b; return nullptr; }
     return b;
 }
+LP_ABI_CATCH("lilliput_hip_batch_create", return nullptr)
 
 void lilliput_hip_batch_destroy(lilliput_hip_batch b) { delete static_cast<LpBatch*>(b); }
 
 void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     b->S = S; b->C = C;
     for (auto& p : b->parts) p.eng->set_subsequence(S, C);
 }
+LP_ABI_CATCH("lilliput_hip_batch_set_subsequence", return)
 
 int lilliput_hip_batch_resident_round(lilliput_hip_batch bb, size_t max_src_len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     static const int round_env = getenv("LILLIPUT_HIP_RESIDENT_CHUNK") ? atoi(getenv("LILLIPUT_HIP_RESIDENT_CHUNK")) : 0;
     if (round_env > 0) return round_env;
     if (!b || b->parts.empty() || !b->parts[0].eng) return 112;
     return (int)b->parts[0].eng->resident_round(max_src_len);
 }
+LP_ABI_CATCH("lilliput_hip_batch_resident_round", return 0)
 
 void lilliput_hip_batch_timings(lilliput_hip_batch bb, float out_ms[10], int* verify_rounds)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     const LpTimings& t = static_cast<LpBatch*>(bb)->tm;
     out_ms[6] = t.huff_spec_ms; out_ms[7] = t.huff_verify_ms; out_ms[8] = t.huff_scan_ms; out_ms[9] = t.huff_write_ms;
     out_ms[0] = t.unstuff_ms; out_ms[1] = t.huff_ms; out_ms[2] = t.idct_ms; out_ms[3] = t.color_ms; out_ms[4] = t.resize_ms; out_ms[5] = t.encode_ms;
     if (verify_rounds) *verify_rounds = (int)t.verify_rounds;
 }
+LP_ABI_CATCH("lilliput_hip_batch_timings", return)
 
 void lilliput_hip_batch_ingest_stats(lilliput_hip_batch bb, double out[4])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     out[0] = (double)b->last_staged_bytes; out[1] = b->last_stage_ms; out[2] = b->last_stall_ms; out[3] = b->last_wall_ms;
 }
+LP_ABI_CATCH("lilliput_hip_batch_ingest_stats", return)
 
 void lilliput_hip_batch_ingest_stats2(lilliput_hip_batch bb, double out[8])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     out[0] = (double)b->last_staged_bytes; out[1] = b->last_stage_ms; out[2] = b->last_stall_ms; out[3] = b->last_wall_ms;
     out[4] = (double)b->last_copied_bytes; out[5] = (double)b->last_direct_bytes; out[6] = b->last_register_ms; out[7] = (double)b->last_numa_node;
 }
+LP_ABI_CATCH("lilliput_hip_batch_ingest_stats2", return)
 
 } // extern "C"
 
@@ -290,7 +297,7 @@ static int batch_streams(int requested)
 }
 
 extern "C" int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n, int streams)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     if (!b) return LILLIPUT_ERR_DEVICE;
     b->n_items = n;
@@ -331,6 +338,7 @@ extern "C" int lilliput_hip_batch_upload2(lilliput_hip_batch bb, const lilliput_
     }
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_hip_batch_upload2", return LILLIPUT_ERR_DEVICE)
 
 extern "C" int lilliput_hip_batch_upload(lilliput_hip_batch bb, const lilliput_batch_item* items, size_t n) { return lilliput_hip_batch_upload2(bb, items, n, 0); }
 
@@ -770,7 +778,7 @@ static int end_run(LpBatch* b, size_t n, bool trace, std::chrono::steady_clock::
 }
 
 extern "C" int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batch_options* opt)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     if (!b || !opt) return LILLIPUT_ERR_DEVICE;
     const size_t n = b->n_items;
@@ -793,9 +801,10 @@ extern "C" int lilliput_hip_batch_run(lilliput_hip_batch bb, const lilliput_batc
     lp_retired_collect();
     return end_run(b, n, trace, t_run0);
 }
+LP_ABI_CATCH("lilliput_hip_batch_run", return LILLIPUT_ERR_DEVICE)
 
 extern "C" int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     if (!b || n != b->n_items) return -1;
     int failed = 0;
@@ -815,6 +824,7 @@ extern "C" int lilliput_hip_batch_download(lilliput_hip_batch bb, lilliput_batch
     }
     return failed;
 }
+LP_ABI_CATCH("lilliput_hip_batch_download", return LILLIPUT_ERR_DEVICE)
 
 // ------------------------------------------------------------------------------------------------
 // Host bytes in -> host bytes out, pipelined: what n calls of ImageOps.Transform do in the reference (each starts from the caller's
@@ -1104,12 +1114,13 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
 }
 
 extern "C" int lilliput_hip_batch_transform(lilliput_hip_batch bb, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     if (!b || !opt || (!items && n)) return (int)n;
     b->node_index = 0;
     return transform_on(std::vector<LpBatch*>{b}, items, n, opt);
 }
+LP_ABI_CATCH("lilliput_hip_batch_transform", return (int)n)
 
 // ------------------------------------------------------------------------------------------------
 // One process, every GPU of the node: what a Go service links (cgo cannot run one process per GPU under torchrun). The devices
@@ -1121,7 +1132,7 @@ struct LpNode {
 };
 
 extern "C" lilliput_hip_node lilliput_hip_node_create(const int* devices, int n_devices)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) { lp_set_error("no HIP device visible"); fprintf(stderr, "lilliput_hip: no HIP device visible\n"); return nullptr; }
     std::vector<int> ids;
@@ -1138,39 +1149,43 @@ extern "C" lilliput_hip_node lilliput_hip_node_create(const int* devices, int n_
     }
     return node;
 }
+LP_ABI_CATCH("lilliput_hip_node_create", return nullptr)
 
 extern "C" void lilliput_hip_node_destroy(lilliput_hip_node n) { delete static_cast<LpNode*>(n); }
 
 extern "C" int lilliput_hip_node_device_count(lilliput_hip_node n) { return n ? (int)static_cast<LpNode*>(n)->devs.size() : 0; }
 
 extern "C" int lilliput_hip_node_transform(lilliput_hip_node nn, lilliput_batch_item* items, size_t n, const lilliput_batch_options* opt)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto node = static_cast<LpNode*>(nn);
     if (!node || node->devs.empty() || !opt || (!items && n)) return (int)n;
     std::vector<LpBatch*> devs;
     for (auto& d : node->devs) devs.push_back(d.get());
     return transform_on(devs, items, n, opt);
 }
+LP_ABI_CATCH("lilliput_hip_node_transform", return (int)n)
 
 // chunks of the last node transform and how many of them a device claimed out of another device's share (work stealing)
 extern "C" void lilliput_hip_node_queue_stats(lilliput_hip_node nn, double out[2])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto node = static_cast<LpNode*>(nn);
     out[0] = out[1] = 0;
     if (!node || node->devs.empty()) return;
     out[0] = (double)node->devs[0]->last_chunks;
     out[1] = (double)node->devs[0]->last_stolen;
 }
+LP_ABI_CATCH("lilliput_hip_node_queue_stats", return)
 
 // images served and bytes staged by device k in the last node transform
 extern "C" void lilliput_hip_node_device_stats(lilliput_hip_node nn, int k, double out[2])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto node = static_cast<LpNode*>(nn);
     out[0] = out[1] = 0;
     if (!node || k < 0 || (size_t)k >= node->devs.size()) return;
     out[0] = (double)node->devs[(size_t)k]->last_images;
     out[1] = (double)node->devs[(size_t)k]->last_staged_bytes;
 }
+LP_ABI_CATCH("lilliput_hip_node_device_stats", return)
 
 extern "C" {
 
@@ -1192,7 +1207,7 @@ static int decode_one(LpBatch* b, const void* src, size_t len, LpJpegHeader* h, 
 }
 
 int lilliput_hip_decode_jpeg(lilliput_hip_batch bb, const void* src, size_t len, void* dst, size_t cap, int* w, int* h, int* channels, int* orientation)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     LpJpegHeader hd;
     LpFrame f;
@@ -1204,9 +1219,10 @@ int lilliput_hip_decode_jpeg(lilliput_hip_batch bb, const void* src, size_t len,
     if (hipMemcpyAsync(dst, (const void*)(uintptr_t)f.off, nb, hipMemcpyDeviceToHost, b->eng0().stream()) != hipSuccess) return LILLIPUT_ERR_DEVICE;
     return b->eng0().sync() ? LILLIPUT_ERR_DEVICE : LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_hip_decode_jpeg", return LILLIPUT_ERR_DEVICE)
 
 int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch bb, const void* src, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     LpJpegHeader hd;
     LpFrame f;
@@ -1216,9 +1232,10 @@ int lilliput_hip_decode_jpeg_coefs(lilliput_hip_batch bb, const void* src, size_
     *bw = (int)hd.j.bw[comp]; *bh = (int)hd.j.bh[comp];
     return map_status(b->eng0().copy_coefs(0, comp, dst, cap_elems));
 }
+LP_ABI_CATCH("lilliput_hip_decode_jpeg_coefs", return LILLIPUT_ERR_DEVICE)
 
 int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch bb, const void* src, size_t len, int comp, uint8_t* dst, size_t cap, int* pw, int* ph)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto b = static_cast<LpBatch*>(bb);
     LpJpegHeader hd;
     LpFrame f;
@@ -1228,5 +1245,6 @@ int lilliput_hip_decode_jpeg_plane(lilliput_hip_batch bb, const void* src, size_
     *pw = (int)hd.j.bw[comp] * 8; *ph = (int)hd.j.bh[comp] * 8;
     return map_status(b->eng0().copy_plane(0, comp, dst, cap));
 }
+LP_ABI_CATCH("lilliput_hip_decode_jpeg_plane", return LILLIPUT_ERR_DEVICE)
 
 } // extern "C"

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include "lp_abi_guard.h"
 
 namespace {
 
@@ -266,7 +267,7 @@ bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, s
 // Part B: one image through the shared dispatchers, whatever the number of calls in flight -- the entry point a Go build's Transform
 // calls for a static source with JPEG output. The answer is the batched path's for that item.
 extern "C" int lilliput_hip_transform_one(int device, const void* src, size_t src_len, const lilliput_batch_options* opt, void* dst, size_t dst_cap, size_t* dst_len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     size_t n = 0;
     if (dst_len) *dst_len = 0;
     if (!src || !src_len || !opt || !dst || !dst_cap) return LILLIPUT_ERR_INVALID_IMAGE;
@@ -275,3 +276,4 @@ extern "C" int lilliput_hip_transform_one(int device, const void* src, size_t sr
     if (dst_len) *dst_len = n;
     return rc;
 }
+LP_ABI_CATCH("lilliput_hip_transform_one", return LILLIPUT_ERR_DEVICE)

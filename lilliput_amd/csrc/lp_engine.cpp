@@ -18,6 +18,7 @@
 #include "lp_launch.h"
 #include "lp_jpeg_progenc.h"
 #include "lp_prog_host.h"
+#include "lp_abi_guard.h"
 
 void lp_encode_upload_tables(const uint16_t code[4][256], const uint8_t len[4][256]);
 
@@ -136,7 +137,7 @@ struct LpStageProbe {
 };
 }
 extern "C" int lilliput_hip_stage_profile(int on)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     const int prev = g_stage_profile.exchange(on ? 1 : 0);
     if (on && !prev) {
         StageTable& T = stage_table();
@@ -145,8 +146,9 @@ extern "C" int lilliput_hip_stage_profile(int on)
     }
     return prev;
 }
+LP_ABI_CATCH("lilliput_hip_stage_profile", return 0)
 extern "C" size_t lilliput_hip_stage_profile_read(char* out, size_t cap)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     std::string s;
     {
         StageTable& T = stage_table();
@@ -164,6 +166,7 @@ extern "C" size_t lilliput_hip_stage_profile_read(char* out, size_t cap)
     }
     return s.size();
 }
+LP_ABI_CATCH("lilliput_hip_stage_profile_read", return 0)
 
 LpDevBuf::~LpDevBuf() { if (p) lp_dev_free(p); }
 bool LpDevBuf::ensure(size_t bytes)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/lilliput_hip.h"
+#include "lp_abi_guard.h"
 
 namespace {
 
@@ -244,8 +245,9 @@ void lp_pinned_free(void* p)
 // out[0] = guard alignment (0: the mode is off), out[1] = allocations so far, out[2] = canary violations seen at frees,
 // out[3] = peak of mapped device bytes
 extern "C" void lilliput_hip_guard_stats(size_t out[4])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     State& s = state();
     std::lock_guard<std::mutex> lk(s.mu);
     out[0] = guard_align(); out[1] = s.n_alloc; out[2] = s.n_violations; out[3] = s.peak_bytes;
 }
+LP_ABI_CATCH("lilliput_hip_guard_stats", return)

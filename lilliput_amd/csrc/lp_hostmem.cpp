@@ -16,6 +16,7 @@
 
 #include "../../include/lilliput_hip.h"
 #include "lp_guard.h"
+#include "lp_abi_guard.h"
 
 namespace {
 
@@ -89,11 +90,12 @@ LpIngestMode lp_ingest_mode()
     return (LpIngestMode)m;
 }
 extern "C" int lilliput_hip_set_ingest_mode(const char* mode)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     const int prev = (int)lp_ingest_mode();
     __atomic_store_n(&g_ingest_mode, (int)parse_ingest(mode), __ATOMIC_RELAXED);
     return prev;
 }
+LP_ABI_CATCH("lilliput_hip_set_ingest_mode", return 0)
 
 bool lp_host_is_pinned(const void* p, size_t n, ptrdiff_t* dev_delta, uintptr_t* base)
 {
@@ -218,7 +220,7 @@ int lp_bind_thread_near(int device)
 
 // ---- Part B: pinned arenas and long-lived registrations
 extern "C" void* lilliput_hip_host_alloc(size_t bytes, int device)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!bytes) return nullptr;
     int prev = -1;
     (void)hipGetDevice(&prev);
@@ -234,9 +236,10 @@ extern "C" void* lilliput_hip_host_alloc(size_t bytes, int device)
     t.by_start[(uintptr_t)p] = Entry{(uintptr_t)p + bytes, kArena, 1, dd};
     return p;
 }
+LP_ABI_CATCH("lilliput_hip_host_alloc", return nullptr)
 
 extern "C" void lilliput_hip_host_free(void* p)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!p) return;
     {
         Table& t = table();
@@ -247,9 +250,10 @@ extern "C" void lilliput_hip_host_free(void* p)
     }
     lp_pinned_free(p);
 }
+LP_ABI_CATCH("lilliput_hip_host_free", return)
 
 extern "C" int lilliput_hip_host_register(void* p, size_t bytes)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!p || !bytes) return LILLIPUT_ERR_INVALID_IMAGE;
     const uintptr_t ps = page_size(), a = (uintptr_t)p & ~(ps - 1), b = ((uintptr_t)p + bytes + ps - 1) & ~(ps - 1);
     Table& t = table();
@@ -261,9 +265,10 @@ extern "C" int lilliput_hip_host_register(void* p, size_t bytes)
     t.by_start[a] = Entry{b, kExplicit, 1, device_delta((void*)a)};
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_hip_host_register", return LILLIPUT_ERR_DEVICE)
 
 extern "C" int lilliput_hip_host_unregister(void* p)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!p) return LILLIPUT_ERR_INVALID_IMAGE;
     const uintptr_t ps = page_size(), a = (uintptr_t)p & ~(ps - 1);
     Table& t = table();
@@ -274,6 +279,7 @@ extern "C" int lilliput_hip_host_unregister(void* p)
     t.by_start.erase(it);
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_hip_host_unregister", return LILLIPUT_ERR_DEVICE)
 
 extern "C" int lilliput_hip_host_is_pinned(const void* p, size_t bytes) { return lp_host_is_pinned(p, bytes) ? 1 : 0; }
 

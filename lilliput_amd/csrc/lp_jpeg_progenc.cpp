@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "lp_engine.h"
+#include "lp_abi_guard.h"
 
 namespace {
 struct Scan { int ncomp; int comp[3]; int Ss, Se, Ah, Al; };
@@ -311,10 +312,11 @@ bool lp_jpeg_encode_progressive(int W, int H, int ncomp, int quality, const int1
 // Test access (no device work): progressive JPEG bytes from quantised coefficients in the encoder's own layout (MCU order, zigzag
 // order per block). Returns the length, 0 on failure, or the negated length needed when cap is too small.
 extern "C" long lilliput_hip_progressive_encode_coefs(int width, int height, int ncomp, int quality, const int16_t* coef, uint8_t* out, size_t cap)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     std::vector<uint8_t> v;
     if (!lp_jpeg_encode_progressive(width, height, ncomp, quality, coef, v)) return 0;
     if (v.size() > cap) return -(long)v.size();
     memcpy(out, v.data(), v.size());
     return (long)v.size();
 }
+LP_ABI_CATCH("lilliput_hip_progressive_encode_coefs", return -1)

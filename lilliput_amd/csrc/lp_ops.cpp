@@ -14,6 +14,7 @@
 #include "lp_abi.h"
 #include "lp_coalesce.h"
 #include "lp_ops_logic.h"
+#include "lp_abi_guard.h"
 
 // ---------------------------------------------------------------- opencv.go:468-637 byte scanners
 static const uint8_t kPngMagic[8] = {0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a};
@@ -371,7 +372,8 @@ int lilliput_detect_content_length(const void* buf, size_t len) { return lp_dete
 int lilliput_detect_apng(const void* buf, size_t len) { return lp_detect_apng((const uint8_t*)buf, len) ? 1 : 0; }
 
 int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // lilliput.go:129-164 + opencv.go:442-463 + giflib.go:56-75
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     *out = nullptr;
     if (!buf || len == 0) return LILLIPUT_ERR_INVALID_IMAGE;
     const uint8_t* b = (const uint8_t*)buf;
@@ -409,9 +411,10 @@ int lilliput_new_decoder(const void* buf, size_t len, lilliput_decoder* out) // 
     *out = d;
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_new_decoder", return LILLIPUT_ERR_DEVICE)
 
 void lilliput_decoder_close(lilliput_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<Decoder*>(dd);
     if (!d) return;
     if (d->gif) giflib_decoder_release(d->gif);
@@ -420,9 +423,10 @@ void lilliput_decoder_close(lilliput_decoder dd)
     opencv_mat_release(d->mat);
     delete d;
 }
+LP_ABI_CATCH("lilliput_decoder_close", return)
 
 int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* pixel_type, int* orientation, int* num_frames, int* content_length)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     Header h;
     int e = decoder_header(static_cast<Decoder*>(dd), &h);
     if (e) return e;
@@ -434,16 +438,18 @@ int lilliput_decoder_header(lilliput_decoder dd, int* width, int* height, int* p
     if (content_length) *content_length = h.content_length;
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_decoder_header", return LILLIPUT_ERR_DEVICE)
 
 const char* lilliput_decoder_description(lilliput_decoder dd)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<Decoder*>(dd);
     if (d->kind == Decoder::PIXELS) return "PIXELS";
     return d->kind == Decoder::GIF ? "GIF" : d->kind == Decoder::WEBP ? "WEBP" : opencv_decoder_get_description(d->dec); // giflib.go:107-109, webp.go:67-69
 }
+LP_ABI_CATCH("lilliput_decoder_description", return nullptr)
 
 int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDecoder.ICC, opencv.go:697-712; gifDecoder.ICC is empty (giflib.go:122-124)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<Decoder*>(dd);
     if (!d || !dst || d->kind == Decoder::GIF || d->kind == Decoder::PIXELS) return 0;
     if (d->kind == Decoder::WEBP) return (int)webp_decoder_get_icc(d->webp, dst, cap); // webp.go:99-103
@@ -452,10 +458,11 @@ int lilliput_decoder_icc(lilliput_decoder dd, void* dst, size_t cap) // openCVDe
     if (desc && strcmp(desc, "PNG") == 0) return opencv_decoder_get_png_icc((void*)d->buf, d->len, dst, cap);
     return 0;
 }
+LP_ABI_CATCH("lilliput_decoder_icc", return 0)
 
 // gifDecoder.LoopCount / FrameCount / Duration / BackgroundColor (giflib.go:126-178): {loop_count, frame_count, duration_ms, background ARGB}
 int lilliput_decoder_animation_info(lilliput_decoder dd, int out[4])
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<Decoder*>(dd);
     if (d && d->kind == Decoder::WEBP) { // webp.go:71-73, 105-111: Duration, BackgroundColor, LoopCount
         out[0] = (int)webp_decoder_get_loop_count(d->webp);
@@ -473,25 +480,28 @@ int lilliput_decoder_animation_info(lilliput_decoder dd, int out[4])
     out[3] = (int)(((uint32_t)(uint8_t)d->anim.bg_red << 16) | ((uint32_t)(uint8_t)d->anim.bg_green << 8) | (uint32_t)(uint8_t)d->anim.bg_blue | ((uint32_t)(uint8_t)d->anim.bg_alpha << 24));
     return LILLIPUT_OK;
 }
+LP_ABI_CATCH("lilliput_decoder_animation_info", return LILLIPUT_ERR_DEVICE)
 
 lilliput_image_ops lilliput_new_image_ops(int max_size) // ops.go:83-91
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto o = new ImageOps();
     o->frames[0].init(max_size, max_size);
     o->frames[1].init(max_size, max_size);
     if (!o->frames[0].buf || !o->frames[1].buf) { o->frames[0].destroy(); o->frames[1].destroy(); delete o; return nullptr; }
     return o;
 }
+LP_ABI_CATCH("lilliput_new_image_ops", return nullptr)
 
 void lilliput_image_ops_clear(lilliput_image_ops oo) // ops.go:111-117
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto o = static_cast<ImageOps*>(oo);
     o->frames[0].clear();
     o->frames[1].clear();
     if (o->have_composite) o->composite.clear();
 }
+LP_ABI_CATCH("lilliput_image_ops_clear", return)
 void lilliput_image_ops_close(lilliput_image_ops oo)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto o = static_cast<ImageOps*>(oo);
     if (!o) return;
     o->frames[0].destroy();
@@ -499,6 +509,7 @@ void lilliput_image_ops_close(lilliput_image_ops oo)
     o->drop_composite();
     delete o;
 }
+LP_ABI_CATCH("lilliput_image_ops_close", return)
 
 // What the batched path (lp_batch.cpp) serves exactly like the loop below would: one frame of a JPEG file, decoded once, Fit or Resize, JPEG out,
 // inside the bounds this ImageOps was built with (opencv.go:250-267 resizeMat answers ErrBufTooSmall beyond them -- left to the direct route).
@@ -524,7 +535,8 @@ static bool coalescible(const ImageOps* o, const Decoder* d, const Header& hdr, 
 }
 
 int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, const lilliput_image_options* opt, void* dst, size_t dst_cap, size_t* dst_len)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    lp_abi_test_fault();
     auto o = static_cast<ImageOps*>(oo);
     auto d = static_cast<Decoder*>(dd);
     *dst_len = 0;
@@ -770,5 +782,6 @@ int lilliput_image_ops_transform(lilliput_image_ops oo, lilliput_decoder dd, con
         if (swapped) o->swap();
     }
 }
+LP_ABI_CATCH("lilliput_image_ops_transform", return LILLIPUT_ERR_DEVICE)
 
 } // extern "C"

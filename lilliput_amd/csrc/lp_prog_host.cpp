@@ -15,6 +15,7 @@
 
 #if defined(__SSE2__)
 #include <emmintrin.h>
+#include "lp_abi_guard.h"
 #endif
 
 // bit k set <=> element k of the block is non-zero
@@ -93,13 +94,14 @@ bool lp_prog_entropy_on_device()
 }
 extern "C" void lilliput_hip_set_progressive_entropy(int on_device) { g_mode.store(on_device ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int lilliput_hip_progressive_device_lanes_built(void)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
 #ifdef LP_PROG_DEVICE_LANES
     return 1;
 #else
     return 0;
 #endif
 }
+LP_ABI_CATCH("lilliput_hip_progressive_device_lanes_built", return 0)
 
 void lp_prog_levels(const std::vector<LpProgScanHost>& scans, std::vector<uint32_t>& level)
 {
@@ -168,7 +170,7 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
 // flagged as irregular is decoded by), on -nthreads threads. Returns -2 when the reference's decoder fails on the file (out of data,
 // unknown marker behind a scan of a multi-scan file), with the coefficients as far as they were decoded.
 extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads)
-{
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     LpJpegHeader h;
     const bool force = nthreads < 0;
     if (force) nthreads = -nthreads;
@@ -193,3 +195,4 @@ extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len,
     *bh = (int)h.j.bh[comp];
     return err ? -2 : 0;
 }
+LP_ABI_CATCH("lilliput_hip_progressive_coefs_host", return -1)

@@ -244,3 +244,74 @@ def test_lane_logic_random_sweep(emu, oracle):
                     if not ok:
                         bad.append((seed, i, desc, S, comp))
     assert not bad, bad[:8]
+
+
+def test_nothing_unwinds_through_the_c_abi(hip_lib, fixture_bytes):
+    """An exception inside an exported function -- std::bad_alloc from a buffer a header sized, std::length_error -- must come out as the
+    entry point's failure value with the reason in lilliput_hip_last_error(), never as an unwind into the caller (a Go process would
+    abort). lilliput_hip_test_fault(n) makes the next n guarded allocation sites throw std::bad_alloc (csrc/lp_abi_guard.h); every
+    exported function with a body is a function-try-block (the check at the end reads that off the sources)."""
+    import re
+
+    L = hip_lib
+    L.lilliput_hip_last_error.restype = C.c_char_p
+    L.opencv_mat_create.restype = C.c_void_p
+    L.opencv_mat_create_from_data.restype = C.c_void_p
+    L.opencv_decoder_create.restype = C.c_void_p
+    L.giflib_decoder_create.restype = C.c_void_p
+    L.webp_decoder_create.restype = C.c_void_p
+    L.thumbhash_encoder_create.restype = C.c_void_p
+    for f in ("opencv_mat_release", "opencv_decoder_release", "lilliput_decoder_close"):
+        getattr(L, f).restype = None
+    data = np.frombuffer(fixture_bytes["coast.jpg"], dtype=np.uint8).copy()
+    buf = L.opencv_mat_create_from_data(C.c_int(data.size), C.c_int(1), C.c_int(0), C.c_void_p(data.ctypes.data), C.c_size_t(data.size))
+    assert buf
+
+    def faulted(call, failure):
+        L.lilliput_hip_test_fault(1)
+        got = call()
+        L.lilliput_hip_test_fault(0)
+        assert got == failure or (failure is None and not got), (got, failure)
+        assert b"out of memory" in L.lilliput_hip_last_error(), L.lilliput_hip_last_error()
+
+    faulted(lambda: L.opencv_mat_create(C.c_int(8), C.c_int(8), C.c_int(16)), None)
+    faulted(lambda: L.opencv_decoder_create(C.c_void_p(buf)), None)
+    d = L.opencv_decoder_create(C.c_void_p(buf))
+    assert d
+    L.opencv_decoder_read_header.restype = C.c_bool
+    faulted(lambda: L.opencv_decoder_read_header(C.c_void_p(d)), False)
+    assert L.opencv_decoder_read_header(C.c_void_p(d))          # and the decoder is still usable afterwards
+    L.opencv_decoder_release(C.c_void_p(d))
+    faulted(lambda: L.giflib_decoder_create(C.c_void_p(buf)), None)
+    faulted(lambda: L.webp_decoder_create(C.c_void_p(buf)), None)
+    out = np.zeros(64, dtype=np.uint8)
+    faulted(lambda: L.thumbhash_encoder_create(C.c_void_p(out.ctypes.data), C.c_size_t(out.size)), None)
+    dec = C.c_void_p()
+    faulted(lambda: L.lilliput_new_decoder(C.c_void_p(data.ctypes.data), C.c_size_t(data.size), C.byref(dec)), 5)  # LILLIPUT_ERR_DEVICE + the text
+    assert L.lilliput_new_decoder(C.c_void_p(data.ctypes.data), C.c_size_t(data.size), C.byref(dec)) == 0
+    L.lilliput_decoder_close(dec)
+    L.opencv_mat_release(C.c_void_p(buf))
+    # hostile headers: dimensions that would size gigabytes -- refused by value, no exception reaches the caller either way
+    png = bytearray(open(os.path.join(ROOT, "tests/golden/inputs_png", sorted(os.listdir(os.path.join(ROOT, "tests/golden/inputs_png")))[0]), "rb").read())
+    png[16:24] = (0x7FFFFFFF).to_bytes(4, "big") * 2
+    a = np.frombuffer(bytes(png), dtype=np.uint8).copy()
+    if L.lilliput_new_decoder(C.c_void_p(a.ctypes.data), C.c_size_t(a.size), C.byref(dec)) == 0:  # (the size check is DecodeTo's, opencv.go:824-827)
+        w, h = C.c_int(), C.c_int()
+        L.lilliput_decoder_header(dec, C.byref(w), C.byref(h), None, None, None, None)
+        L.lilliput_decoder_close(dec)
+    # every exported function that has a body of its own is guarded
+    src_dir = os.path.join(ROOT, "lilliput_amd", "csrc")
+    import subprocess
+
+    exported = {l.split()[2] for l in subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "lilliput_amd", "liblilliput_hip.so")], capture_output=True, text=True).stdout.splitlines()
+                if " T " in l and not l.split()[2].startswith("_Z")}
+    unguarded = []
+    for f in sorted(os.listdir(src_dir)):
+        if not f.endswith(".cpp"):
+            continue
+        lines = open(os.path.join(src_dir, f)).read().split("\n")
+        for i, l in enumerate(lines[:-1]):
+            m = re.match(r'^(?:extern "C" )?[A-Za-z_][\w \*:<>]*?[ \*](\w+)\(.*\)\s*(//.*|/\*.*\*/)?\s*$', l)
+            if m and m.group(1) in exported and lines[i + 1].startswith("{"):
+                unguarded.append((f, m.group(1)))
+    assert not unguarded, unguarded
