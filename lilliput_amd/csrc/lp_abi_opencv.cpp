@@ -151,13 +151,19 @@ LpEngineLease::~LpEngineLease()
         P.live--;
         if (keep) {
             P.idle.emplace_back(dev_, eng_);
-            // over either bound: the least recently used ones go (the one just returned is the most recently used and stays)
-            size_t total = 0;
-            for (auto& e : P.idle) total += e.second->device_bytes();
-            while (P.idle.size() > 1 && (P.idle.size() > pool_keep() || total > pool_keep_bytes())) {
-                total -= P.idle.front().second->device_bytes();
-                drop.push_back(P.idle.front().second);
-                P.idle.erase(P.idle.begin());
+            // over either bound ON THIS DEVICE (the bounds are per GPU: with several ranks or processes per node every device has its own
+            // HBM to answer for): its least recently used ones go (the one just returned is the most recently used and stays)
+            size_t total = 0, count = 0;
+            for (auto& e : P.idle)
+                if (e.first == dev_) { total += e.second->device_bytes(); count++; }
+            while (count > 1 && (count > pool_keep() || total > pool_keep_bytes())) {
+                auto it = P.idle.begin();
+                while (it != P.idle.end() && it->first != dev_) ++it;
+                if (it == P.idle.end() || it->second == eng_) break;
+                total -= it->second->device_bytes();
+                count--;
+                drop.push_back(it->second);
+                P.idle.erase(it);
             }
         } else
             drop.push_back(eng_);

@@ -207,7 +207,9 @@ Dispatch* dispatch_for(int device)
             Registry& R2 = registry();
             std::map<int, std::unique_ptr<Dispatch>> all;
             { std::lock_guard<std::mutex> lk2(R2.mu); R2.closed = true; all.swap(R2.by_device); }
-            for (auto& kv : all) kv.second->shutdown();
+            // the dispatchers are stopped and then LEAKED, like the registry itself: a thread that is still inside a Transform at process
+            // exit may hold a Dispatch* from dispatch_for() and is about to lock its mutex or queue a request into it
+            for (auto& kv : all) { kv.second->shutdown(); (void)kv.second.release(); }
             stage_pool_free_all();
         });
     }

@@ -290,7 +290,10 @@ bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
 bool LpEngine::h2d_any(void* dst, const void* src, size_t bytes)
 {
     if (!bytes) return true;
-    if (bytes <= (2u << 20)) return h2d_small(dst, src, bytes);
+    // k_copy_small moves 16-byte groups: it needs a 16-byte aligned destination and writes the size rounded UP to 16 (the surplus bytes
+    // are whatever the pinned ring held). Fine for the descriptor arenas it was written for; a destination that is a view with an odd
+    // offset, or one sized to the byte, takes the copy engine instead.
+    if (bytes <= (2u << 20) && ((uintptr_t)dst & 15u) == 0 && (bytes & 15u) == 0) return h2d_small(dst, src, bytes);
     // the pinned buffer is reused by the next large transfer of this engine: wait for whatever still reads it
     if (!check(hipStreamSynchronize(stream_), "transfer buffer sync")) return false;
     if (!h_xfer_in_.ensure(bytes + 64)) { err_ = "pinned allocation failed"; return false; }
