@@ -142,6 +142,10 @@ def cpu_baseline(sample, out_w=256, out_h=256, quality=85, budget_s=10.0, what="
     value = runs[best]["images_per_s"]
     return {"value": value, "unit": "images/s", "cores": best, "kind": r1["kind"],
             "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_quota": quota, "usable_cpus": usable, "one_core_images_per_s": round(one, 2),
+            "host_extrapolation": {"images_per_s": round(one * physical, 1),
+                                   "is": "one_core_images_per_s x physical_cores: what the reference CPU path would do with the WHOLE host (perfect scaling assumed) -- `value` was "
+                                         "measured inside the container's CPU quota (%s CPUs of %d cores); compare GPU figures with THIS number when judging against a full host" % (
+                                             "all" if not quota else "%.0f" % quota, physical)},
             "scaling_efficiency": round(value / max(1e-9, usable * one), 3),
             "scaling_efficiency_is": "value / (usable_cpus x one_core): usable_cpus = min(physical cores, the container's cgroup CPU quota)",
             "runs_by_threads": {str(k): v for k, v in runs.items()},
@@ -233,6 +237,11 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
             "traffic_over_algorithmic": round(traffic / (dom_bytes * launch_images), 3) if traffic else None,
             "traffic_source": traffic_src,
             "streams": 1 if excl else streams,
+            "duration_source": "hip_events" if excl else "hip_events_pipelined",
+            "duration_source_is": ("HIP events on the engine's stream around two exclusive launches of one resident chunk, measured live in this run (rocprofv3 --kernel-trace --stats of the "
+                                   "same launches: profiles/r05_kernel_stats.md)") if excl else
+                                  ("HIP events around the stages of the TIMED region, where %d engines share the GPU: a launch lasts 2-3x its exclusive duration, so achieved / frac are "
+                                   "lower bounds (run without --no-extra-legs for the exclusive figure)" % streams),
             "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
                     "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
                     "(~47 vector instructions per Huffman symbol in this kernel), not by HBM (DESIGN.md 4.1)" % streams,
