@@ -830,28 +830,30 @@ __global__ __launch_bounds__(64) void k_dc_apply(const LpJpeg* __restrict__ imgs
 // blocks of one component; lane = (block j, row/column r). Coefficient rows arrive as one coalesced
 // 1 KiB wave load, are transposed through LDS for the column pass, and leave as 8-byte pixel rows
 // (64 contiguous bytes per row across the 8 blocks).
-// MUL24: multiply with v_mul_i32_i24 (full rate; the 32-bit v_mul_lo_u32 is a quarter-rate instruction and was the single
-// largest cost of this kernel). Exact as long as every multiplied value fits 24 signed bits -- see the guard in k_idct.
-template <bool MUL24>
-__device__ __forceinline__ int32_t idct_mul(int32_t a, int32_t c)
+// What "jpeg_idct_islow" means here is what the reference's libjpeg-turbo computes on x86-64: its SIMD routine (jidctint-sse2 / -avx2),
+// which has the C code's butterflies and constants but works in 16-bit lanes -- dequantisation wraps (pmullw), so do in0 +- in4 and the
+// odd part's z3 = in7 + in3, z4 = in5 + in1 (paddw / psubw), the rotations are 32-bit sums of two 16 x 16 products (pmaddwd), the first
+// pass's outputs are SATURATED to 16 bits (packssdw) -- except in a block without AC coefficients, whose first pass is in0 << 2 in 16
+// bits (psllw: wraps) -- and the second pass ends saturated to 8 bits. For the coefficients of real images none of that triggers and
+// the result is the C code's; damaged streams and hostile tables do trigger it, and the reference's pixels are then the SIMD routine's
+// (oracle/jpeg_oracle.c lo_idct_islow_simd, pinned against the reference's own decoder on 1 300 damaged files, 360 of which differ
+// between the two arithmetics). Two implementations below: the exact lane arithmetic for any input (idct_*_exact: every progressive /
+// scan-path image, every tile with an escaped coefficient or a large quantiser), and the fast path for the rest, which is the same
+// arithmetic wherever a handful of cheap conditions hold and falls back to the exact one where they do not.
+__device__ __forceinline__ int32_t sx16(int32_t v) { return (int32_t)(int16_t)v; } // v_bfe_i32
+// one 1-D pass on eight 16-bit values (held in int32): every product has a 16-bit and a 15-bit factor (24-bit multiplies are exact),
+// every sum is a 32-bit wrapping add
+__device__ __forceinline__ void idct_1d_simd(const int32_t d[8], int32_t o[8])
 {
-    return MUL24 ? __mul24(a, c) : a * c;
-}
-template <bool MUL24>
-__device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
-{
-    int32_t z1 = idct_mul<MUL24>(d[2] + d[6], 4433);
-    int32_t tmp2 = z1 - idct_mul<MUL24>(d[6], 15137), tmp3 = z1 + idct_mul<MUL24>(d[2], 6270);
-    int32_t tmp0 = (int32_t)((uint32_t)(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)(d[0] - d[4]) << 13);
-    int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
-    tmp0 = d[7]; tmp1 = d[5]; tmp2 = d[3]; tmp3 = d[1];
-    z1 = tmp0 + tmp3;
-    int32_t z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3, z5 = idct_mul<MUL24>(z3 + z4, 9633);
-    tmp0 = idct_mul<MUL24>(tmp0, 2446); tmp1 = idct_mul<MUL24>(tmp1, 16819); tmp2 = idct_mul<MUL24>(tmp2, 25172); tmp3 = idct_mul<MUL24>(tmp3, 12299);
-    z1 = idct_mul<MUL24>(z1, -7373); z2 = idct_mul<MUL24>(z2, -20995); z3 = idct_mul<MUL24>(z3, -16069) + z5; z4 = idct_mul<MUL24>(z4, -3196) + z5;
-    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    o[0] = t10 + tmp3; o[7] = t10 - tmp3; o[1] = t11 + tmp2; o[6] = t11 - tmp2;
-    o[2] = t12 + tmp1; o[5] = t12 - tmp1; o[3] = t13 + tmp0; o[4] = t13 - tmp0;
+    const int32_t tmp3 = __mul24(d[2], 10703) + __mul24(d[6], 4433), tmp2 = __mul24(d[2], 4433) + __mul24(d[6], -10704);
+    const int32_t tmp0 = (int32_t)((uint32_t)sx16(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)sx16(d[0] - d[4]) << 13);
+    const int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
+    const int32_t z3 = sx16(d[7] + d[3]), z4 = sx16(d[5] + d[1]);
+    const int32_t z3n = __mul24(z3, -6436) + __mul24(z4, 9633), z4n = __mul24(z3, 9633) + __mul24(z4, 6437);
+    const int32_t o0 = __mul24(d[7], -4927) + __mul24(d[1], -7373) + z3n, o3 = __mul24(d[7], -7373) + __mul24(d[1], 4926) + z4n;
+    const int32_t o1 = __mul24(d[5], -4176) + __mul24(d[3], -20995) + z4n, o2 = __mul24(d[5], -20995) + __mul24(d[3], 4177) + z3n;
+    o[0] = t10 + o3; o[7] = t10 - o3; o[1] = t11 + o2; o[6] = t11 - o2;
+    o[2] = t12 + o1; o[5] = t12 - o1; o[3] = t13 + o0; o[4] = t13 - o0;
 }
 
 #define IDCT_WSTRIDE 72 // int32 per block in LDS (64 + 8 pad): conflict-free column writes
@@ -864,39 +866,40 @@ __device__ __forceinline__ void idct_1d(const int32_t d[8], int32_t o[8])
 // column v) loads its whole column as 8 contiguous bytes and the column pass needs no LDS transpose; only the row pass
 // reads the workspace back through LDS.
 // The two passes of one 8-block tile for lane (block j, column/row r): column pass from registers into the wave's LDS
-// workspace, row pass back out of it, clamp, 8-byte pixel-row store. (The workgroup barrier between them sits in the
-// caller, outside of any wave-divergent branch.)
-template <bool MUL24>
-__device__ __forceinline__ void idct_cols(const int32_t cv[8], const int32_t qv[8], int32_t* s_w, uint32_t j, uint32_t r)
+// workspace, row pass back out of it, 8-byte pixel-row store.
+// cv: the lane's coefficient column (16-bit values), qv: its quantiser column (the SIMD routine multiplies by the table entry as a
+// 16-bit SIGNED value); no_ac: rows 1-7 of the lane's block are empty (the routine then skips the first pass: every column is its
+// first-row element << 2, in 16 bits)
+__device__ __forceinline__ void idct_cols_exact(const int32_t cv[8], const int32_t qv[8], bool no_ac, int32_t* s_w, uint32_t j, uint32_t r)
 {
     int32_t d[8], o[8];
-    d[0] = cv[0] * qv[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) d[k] = idct_mul<MUL24>(cv[k], qv[k]);
-    idct_1d<MUL24>(d, o);
+    for (int k = 0; k < 8; k++) d[k] = sx16(cv[k] * sx16(qv[k])); // pmullw: 16 x 16 -> low 16 bits (a 16-bit table entry times a 16-bit coefficient needs the full multiply)
+    idct_1d_simd(d, o);
+    const int32_t dc_only = sx16((int32_t)((uint32_t)d[0] << 2));
 #pragma unroll
-    for (int k = 0; k < 8; k++) s_w[j * IDCT_WSTRIDE + k * 8 + r] = (o[k] + (1 << 10)) >> 11;
+    for (int k = 0; k < 8; k++) {
+        const int32_t v = (o[k] + (1 << 10)) >> 11;
+        s_w[j * IDCT_WSTRIDE + k * 8 + r] = no_ac ? dc_only : (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+    }
 }
-template <bool MUL24>
-__device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32_t r, bool blk_ok, uint8_t* dst)
+__device__ __forceinline__ uint2 idct_rows_exact(const int32_t* s_w, uint32_t j, uint32_t r)
 {
     int32_t d[8], o[8];
     const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
-    int4 a = wp[0], b = wp[1];
+    const int4 a = wp[0], b = wp[1];
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-    idct_1d<MUL24>(d, o);
+    idct_1d_simd(d, o);
     uint32_t px[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int32_t s = (o[k] + ((1 << 17) + (128 << 18))) >> 18; // DESCALE, then + 128 (folded into the rounding constant)
-        px[k] = (uint32_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+        const int32_t v = (o[k] + (1 << 17)) >> 18; // packssdw, packsswb, + 128: saturated to [-128, 127]
+        px[k] = (uint32_t)((v < -128 ? -128 : v > 127 ? 127 : v) + 128);
     }
-    if (blk_ok) {
-        uint2 out;
-        out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-        out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-        *reinterpret_cast<uint2*>(dst) = out;
-    }
+    uint2 out;
+    out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+    return out;
 }
 
 // ---- the path almost every tile takes (no escape in the tile, 8-bit quantisation table): the same arithmetic with fewer instructions.
@@ -908,12 +911,15 @@ __device__ __forceinline__ void idct_rows(const int32_t* s_w, uint32_t j, uint32
 // * row pass: (o + C) >> 18 is the upper half of the sum shifted right by two more bits -- the upper halves of two sums are taken by one
 //   v_perm, shifted as a pair, and clamped to bytes two at a time by v_sat_pk_u8_i16 (the second pair straight into the upper half of the
 //   output word) instead of a shift, a median and a merge per pixel.
-__device__ __forceinline__ void idct_1d_pre(int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7, int32_t tmp0, int32_t tmp1, int32_t o[8])
+// zsum (optional): z3 | z4 biased by 32768 each -- bits 16.. of the OR are clear iff both odd-part sums fit 16 signed bits
+template <bool CHECK = false>
+__device__ __forceinline__ void idct_1d_pre(int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7, int32_t tmp0, int32_t tmp1, int32_t o[8], uint32_t* zsum = nullptr)
 {
     const int32_t za = __mul24(d2 + d6, 4433);
     const int32_t tmp2 = za - __mul24(d6, 15137), tmp3 = za + __mul24(d2, 6270);
     const int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
     int32_t z1 = d7 + d1, z2 = d5 + d3, z3 = d7 + d3, z4 = d5 + d1;
+    if (CHECK) *zsum = (uint32_t)(z3 + 32768) | (uint32_t)(z4 + 32768);
     const int32_t z5 = __mul24(z3 + z4, 9633);
     int32_t a0 = __mul24(d7, 2446), a1 = __mul24(d5, 16819), a2 = __mul24(d3, 25172), a3 = __mul24(d1, 12299);
     z1 = __mul24(z1, -7373); z2 = __mul24(z2, -20995); z3 = __mul24(z3, -16069) + z5; z4 = __mul24(z4, -3196) + z5;
@@ -932,16 +938,27 @@ __device__ __forceinline__ int32_t idct_deq(uint32_t w, int32_t q)
     return d;
 }
 // qv = the lane's quantiser column; q0s / q4s = qv[0] << 13, qv[4] << 13; is_dc: this lane holds column 0 of a real block, whose first
-// element is the 16-bit DC
-__device__ __forceinline__ void idct_cols_fast(uint2 raw, int32_t dc, bool is_dc, const int32_t qv[8], int32_t q0s, int32_t q4s, int32_t* s_w, uint32_t j, uint32_t r)
+// element is the 16-bit DC.
+// Where this equals the reference's 16-bit lane arithmetic (idct_cols_exact): the caller has made sure that every AC quantiser is at most
+// 129 and every AC coefficient at most 127, so an AC term is at most 16 383 and no sum of two of them leaves 16 bits; the first-row
+// element of every column (the DC in column 0) is checked here -- beyond 8 191 (no real image: a dequantised coefficient is bounded by
+// 8 x 128 x sqrt 2) the tile is done again the exact way, which covers the DC's range and the in0 << 2 wrap of the shortcut the SIMD
+// routine takes for a block whose rows 1-7 are empty; the outputs are saturated to 16 bits like packssdw does.
+// Returns non-zero when the lane's tile needs the exact path.
+__device__ __forceinline__ uint32_t idct_cols_fast(uint2 raw, int32_t dc, bool is_dc, const int32_t qv[8], int32_t q0s, int32_t q4s, int32_t* s_w, uint32_t j, uint32_t r)
 {
     int32_t o[8];
     const int32_t c0 = is_dc ? dc : (int32_t)(int8_t)(raw.x & 0xffu);
+    const uint32_t far = (uint32_t)(__mul24(c0, qv[0]) + 8192) >> 14; // the dequantised first-row element outside [-8192, 8191]
     const int32_t tmp0e = __mul24(c0, q0s) + (1 << 10), d4s = idct_deq<0>(raw.y, q4s); // PASS1 rounding: 1 << (CONST_BITS - PASS1_BITS - 1)
     idct_1d_pre(idct_deq<1>(raw.x, qv[1]), idct_deq<2>(raw.x, qv[2]), idct_deq<3>(raw.x, qv[3]), idct_deq<1>(raw.y, qv[5]), idct_deq<2>(raw.y, qv[6]),
                 idct_deq<3>(raw.y, qv[7]), tmp0e + d4s, tmp0e - d4s, o);
 #pragma unroll
-    for (int k = 0; k < 8; k++) s_w[j * IDCT_WSTRIDE + k * 8 + r] = o[k] >> 11;
+    for (int k = 0; k < 8; k++) {
+        const int32_t v = o[k] >> 11;
+        s_w[j * IDCT_WSTRIDE + k * 8 + r] = v < -32768 ? -32768 : v > 32767 ? 32767 : v; // packssdw (one v_med3_i32)
+    }
+    return far;
 }
 __device__ __forceinline__ uint32_t idct_pack4(int32_t o0, int32_t o1, int32_t o2, int32_t o3)
 {
@@ -955,17 +972,22 @@ __device__ __forceinline__ uint32_t idct_pack4(int32_t o0, int32_t o1, int32_t o
         : "=&v"(d) : "v"(__builtin_bit_cast(uint32_t, p01)), "v"(__builtin_bit_cast(uint32_t, p23)));
     return d;
 }
-__device__ __forceinline__ void idct_rows_fast(const int32_t* s_w, uint32_t j, uint32_t r, bool blk_ok, uint8_t* dst)
+// The row pass works on the first pass's 16-bit values: equal to the reference's lane arithmetic as long as in0 +- in4, in7 + in3 and
+// in5 + in1 fit 16 bits (real images stay near 4 096 here); *bad gets bits 16.. set when one does not.
+__device__ __forceinline__ uint2 idct_rows_fast(const int32_t* s_w, uint32_t j, uint32_t r, uint32_t* bad)
 {
     int32_t o[8];
     const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
     const int4 a = wp[0], b = wp[1];
     const uint32_t C = (1u << 17) + (128u << 18); // DESCALE rounding, then + 128
-    idct_1d_pre(a.y, a.z, a.w, b.y, b.z, b.w, (int32_t)(((uint32_t)(a.x + b.x) << 13) + C), (int32_t)(((uint32_t)(a.x - b.x) << 13) + C), o);
+    const int32_t s04 = a.x + b.x, d04 = a.x - b.x;
+    uint32_t zsum;
+    idct_1d_pre<true>(a.y, a.z, a.w, b.y, b.z, b.w, (int32_t)(((uint32_t)s04 << 13) + C), (int32_t)(((uint32_t)d04 << 13) + C), o, &zsum);
+    *bad = zsum | (uint32_t)(s04 + 32768) | (uint32_t)(d04 + 32768);
     uint2 out;
     out.x = idct_pack4(o[0], o[1], o[2], o[3]);
     out.y = idct_pack4(o[4], o[5], o[6], o[7]);
-    if (blk_ok) *reinterpret_cast<uint2*>(dst) = out;
+    return out;
 }
 
 __constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
@@ -1025,9 +1047,15 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
     int32_t qv[8]; // this lane's column of the quantisation table, unpacked once for all tiles
     {
         const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
-        q_small = ((q.x | q.y | q.z | q.w) & 0xff00ff00u) == 0; // the wave vote below covers all eight columns
         qv[0] = (int32_t)(q.x & 0xffffu); qv[1] = (int32_t)(q.x >> 16); qv[2] = (int32_t)(q.y & 0xffffu); qv[3] = (int32_t)(q.y >> 16);
         qv[4] = (int32_t)(q.z & 0xffffu); qv[5] = (int32_t)(q.z >> 16); qv[6] = (int32_t)(q.w & 0xffffu); qv[7] = (int32_t)(q.w >> 16);
+        // the fast path's static condition (idct_cols_fast): the DC quantiser fits a byte, every AC quantiser is at most 129 -- an AC term
+        // (coefficient at most 127 without an escape) then stays below 16 384 and no sum of two leaves 16 bits. Tables beyond that
+        // (quality below ~20) take the exact lane arithmetic for every tile. The wave vote below covers all eight columns.
+        uint32_t ac_max = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) ac_max = ac_max > (uint32_t)qv[k] ? ac_max : (uint32_t)qv[k];
+        q_small = ac_max <= 129u && (uint32_t)qv[0] <= (r == 0 ? 255u : 129u);
     }
     const bool q_small_wave = __all(q_small);
     const int32_t q0s = qv[0] << 13, q4s = qv[4] << 13;
@@ -1073,27 +1101,30 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
         const uint32_t bx = base + wv * 8 + j;
         const bool blk_ok = bx < bw;
         int32_t cv[8];
-        bool any_esc = false;
         uint2 raw = pre_raw[a];
         raw.x = blk_ok ? raw.x : 0u;
         raw.y = blk_ok ? raw.y : 0u;
         const int32_t dc_now = pre_dc[a];
         fetch(pre_raw[a], pre_dc[a]);
         uint8_t* const dst = dst_row + bx * 8;
-#ifndef LP_IDCT_R03 // A/B: round 3's tile code for every tile
-        if (!PROG) {
+        if (!PROG && q_small_wave) {
             // a byte equals 0x80 (the escape) <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
             const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
             const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
-            if (q_small_wave && __all((zx | zy) == 0)) { // see the note on 24-bit multiplies below
-                idct_cols_fast(raw, dc_now, r == 0 && blk_ok, qv, q0s, q4s, s_w[wv], j, r);
+            if (__all((zx | zy) == 0)) {
+                // the path almost every tile takes; the reference's 16-bit lane arithmetic as long as the conditions of idct_cols_fast /
+                // idct_rows_fast hold -- a tile where one does not (no real image) is done again below, the exact way
+                const uint32_t far = idct_cols_fast(raw, dc_now, r == 0 && blk_ok, qv, q0s, q4s, s_w[wv], j, r);
                 idct_wave_sync();
-                idct_rows_fast(s_w[wv], j, r, blk_ok, dst);
+                uint32_t bad;
+                const uint2 px = idct_rows_fast(s_w[wv], j, r, &bad);
                 idct_wave_sync();
-                continue;
+                if (__all((far | (bad >> 16)) == 0)) {
+                    if (blk_ok) *reinterpret_cast<uint2*>(dst) = px;
+                    continue;
+                }
             }
         }
-#endif
         if (PROG) {
             // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
             // its 128 bytes between them)
@@ -1101,43 +1132,39 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
             const int16_t* src = pcoef_arena + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
 #pragma unroll
             for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) any_esc = any_esc || ((i || r) && (cv[i] > 127 || cv[i] < -127)); // same bound as the int8 path, DC aside
         } else {
             const uint32_t blk = block_of(bx);
             // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
-            {
 #pragma unroll
-                for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-                {   // a byte equals 0x80 <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
-                    const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
-                    const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
-                    any_esc = (zx | zy) != 0;
-                }
-                if (any_esc) {
-                    // a block no lane wrote (the stream ended early: the image is reported as failed) holds stale bytes, and a stale
-                    // escape comes with a stale slot number: keep the read inside the image's own slots
-                    uint32_t wid = wide_id_arena[img.coef_off / 64 + blk];
-                    wid = wid < img.total_blocks ? wid : 0u;
-                    const int16_t* w = wide_arena + img.coef_off + (size_t)wid * 64 + r * 8;
+            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+            const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
+            const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
+            if ((zx | zy) != 0) {
+                // a block no lane wrote (the stream ended early: the image is reported as failed) holds stale bytes, and a stale
+                // escape comes with a stale slot number: keep the read inside the image's own slots
+                uint32_t wid = wide_id_arena[img.coef_off / 64 + blk];
+                wid = wid < img.total_blocks ? wid : 0u;
+                const int16_t* w = wide_arena + img.coef_off + (size_t)wid * 64 + r * 8;
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (cv[i] == -128) cv[i] = w[i];
-                }
-                if (r == 0 && blk_ok) cv[0] = dc_now; // the DC lives in its own 16-bit array
+                for (int i = 0; i < 8; i++)
+                    if (cv[i] == -128) cv[i] = w[i];
             }
+            if (r == 0 && blk_ok) cv[0] = dc_now; // the DC lives in its own 16-bit array
         }
-        // 24-bit multiplies are exact when every multiplied term fits 24 signed bits. The DC (and the workspace column it feeds) is
-        // only shifted, never multiplied; an AC coefficient without an escape is at most 127, so with 8-bit quantisation tables the
-        // multiplied terms stay below 2^15 in the column pass and 2^23 in the row pass. Anything else takes the 32-bit path.
-        const bool fast = !any_esc && q_small;
-        const bool wave_fast = __all(fast);
-        // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between the
-        // passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every load wait
-        if (wave_fast) idct_cols<true>(cv, qv, s_w[wv], j, r); else idct_cols<false>(cv, qv, s_w[wv], j, r);
-        idct_wave_sync();
-        if (wave_fast) idct_rows<true>(s_w[wv], j, r, blk_ok, dst); else idct_rows<false>(s_w[wv], j, r, blk_ok, dst);
-        idct_wave_sync();
+        {   // the exact lane arithmetic (idct_cols_exact). The SIMD routine's shortcut tests ROWS 1-7 of the block: the eight lanes vote
+            bool lane_ac = false;
+#pragma unroll
+            for (int i = 1; i < 8; i++) lane_ac = lane_ac || cv[i] != 0;
+            const uint64_t ac_mask = __builtin_amdgcn_ballot_w64(lane_ac);
+            const bool no_ac = ((ac_mask >> (j * 8u)) & 0xffull) == 0;
+            // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between
+            // the passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every wait
+            idct_cols_exact(cv, qv, no_ac, s_w[wv], j, r);
+            idct_wave_sync();
+            const uint2 px = idct_rows_exact(s_w[wv], j, r);
+            idct_wave_sync();
+            if (blk_ok) *reinterpret_cast<uint2*>(dst) = px;
+        }
       }
       if (out) break;
     }

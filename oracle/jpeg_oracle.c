@@ -798,6 +798,58 @@ void lo_idct_islow(const int16_t* coef, const uint16_t* q, uint8_t* out, int str
     }
 }
 
+/* jpeg_idct_islow as libjpeg-turbo's x86-64 SIMD routines compute it (simd/x86_64/jidctint-sse2.asm / -avx2.asm of 3.1.0; source not in
+ * the reference tree -- restated from the algorithm's published structure and PINNED against the reference's own libjpeg.a through
+ * cv::JpegDecoder on coefficients a real image cannot have, tests/test_damaged.py). Same butterflies and constants as the C code, but in
+ * 16-bit lanes: dequantisation is pmullw (the product wraps), in0 +- in4 and the two odd-part sums z3 = in7 + in3, z4 = in5 + in1 are
+ * paddw / psubw (wrap), every rotation is a pmaddwd of two 16-bit values with two combined constants into 32 bits (wraps at 32), the
+ * first pass's outputs are packssdw (SATURATED to 16 bits) -- except in a block whose AC coefficients are all zero, where the first pass
+ * is psllw(in0, 2) (wraps) -- and the second pass ends in packssdw + packsswb (saturate to 8 bits) + 128. For coefficients of real images
+ * none of this triggers and the result equals lo_idct_islow's. This is what the restatement's decode uses (lo_set_idct_simd(0) switches to
+ * the C arithmetic, for the test that tells the two apart). */
+static inline int16_t wr16(int32_t v) { return (int16_t)(uint16_t)(uint32_t)v; }
+static inline int32_t wr32(int64_t v) { return (int32_t)(uint32_t)(uint64_t)v; }
+static inline int32_t madd(int16_t a, int32_t ca, int16_t b, int32_t cb) { return wr32((int64_t)a * ca + (int64_t)b * cb); }
+static inline int16_t sat16(int32_t v) { return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
+static void idct1d_simd(const int16_t* d, int32_t* o)
+{
+    const int32_t tmp3 = madd(d[2], 10703, d[6], 4433), tmp2 = madd(d[2], 4433, d[6], -10704);
+    const int32_t tmp0 = wr32((int64_t)wr16(d[0] + d[4]) * 8192), tmp1 = wr32((int64_t)wr16(d[0] - d[4]) * 8192);
+    const int32_t t10 = wr32((int64_t)tmp0 + tmp3), t13 = wr32((int64_t)tmp0 - tmp3), t11 = wr32((int64_t)tmp1 + tmp2), t12 = wr32((int64_t)tmp1 - tmp2);
+    const int16_t z3 = wr16(d[7] + d[3]), z4 = wr16(d[5] + d[1]);
+    const int32_t z3n = madd(z3, -6436, z4, 9633), z4n = madd(z3, 9633, z4, 6437);
+    const int32_t o0 = wr32((int64_t)madd(d[7], -4927, d[1], -7373) + z3n), o3 = wr32((int64_t)madd(d[7], -7373, d[1], 4926) + z4n);
+    const int32_t o1 = wr32((int64_t)madd(d[5], -4176, d[3], -20995) + z4n), o2 = wr32((int64_t)madd(d[5], -20995, d[3], 4177) + z3n);
+    o[0] = wr32((int64_t)t10 + o3); o[7] = wr32((int64_t)t10 - o3); o[1] = wr32((int64_t)t11 + o2); o[6] = wr32((int64_t)t11 - o2);
+    o[2] = wr32((int64_t)t12 + o1); o[5] = wr32((int64_t)t12 - o1); o[3] = wr32((int64_t)t13 + o0); o[4] = wr32((int64_t)t13 - o0);
+}
+void lo_idct_islow_simd(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride)
+{
+    int16_t ws[64], in[8];
+    int32_t o[8];
+    int ac = 0;
+    for (int k = 8; k < 64; k++) ac |= coef[k];
+    for (int c = 0; c < 8; c++) {
+        for (int r = 0; r < 8; r++) in[r] = wr16((int32_t)coef[r * 8 + c] * (int32_t)(int16_t)q[r * 8 + c]);
+        if (!ac) { /* every AC coefficient of the block is zero: in0 << PASS1_BITS in 16 bits */
+            for (int r = 0; r < 8; r++) ws[r * 8 + c] = wr16((int32_t)in[0] * 4);
+            continue;
+        }
+        idct1d_simd(in, o);
+        for (int r = 0; r < 8; r++) ws[r * 8 + c] = sat16(wr32((int64_t)o[r] + 1024) >> 11);
+    }
+    for (int r = 0; r < 8; r++) {
+        idct1d_simd(ws + r * 8, o);
+        for (int c = 0; c < 8; c++) {
+            int v = sat16(wr32((int64_t)o[c] + (1 << 17)) >> 18);
+            v = v > 127 ? 127 : v < -128 ? -128 : v;
+            out[r * stride + c] = (uint8_t)(v + 128);
+        }
+    }
+}
+static int lo_idct_simd = 1; /* the restatement follows the reference (libjpeg-turbo's SIMD routine on x86-64); 0: the C code's 32-bit arithmetic */
+void lo_set_idct_simd(int on) { lo_idct_simd = on; }
+
 static int planes_from_coefs(lo_dec* D);
 static int decode_planes(const uint8_t* d, size_t n, lo_dec* D)
 {
@@ -814,7 +866,7 @@ static int planes_from_coefs(lo_dec* D)
         if (!D->plane[c]) return LO_ERR_BUF;
         for (int by = 0; by < D->bh[c]; by++)
             for (int bx = 0; bx < D->bw[c]; bx++)
-                lo_idct_islow(D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64, D->have_latched_qt ? D->latched_qt[c] : in->qt[in->tq[c]],
+                (lo_idct_simd ? lo_idct_islow_simd : lo_idct_islow)(D->coef[c] + ((size_t)by * D->bw[c] + bx) * 64, D->have_latched_qt ? D->latched_qt[c] : in->qt[in->tq[c]],
                               D->plane[c] + (size_t)by * 8 * pw + bx * 8, pw);
     }
     return LO_OK;

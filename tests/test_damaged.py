@@ -159,21 +159,104 @@ def test_device_lane_logic_hands_over_every_stream_it_would_decode_differently(e
     assert accepted >= 150 and rejected >= 300, (accepted, rejected)
 
 
+def test_simd_idct_restatement_equals_the_reference_decoder_on_hostile_coefficients(oracle):
+    """oracle/jpeg_oracle.c lo_idct_islow_simd -- libjpeg-turbo's x86-64 SIMD jpeg_idct_islow restated (16-bit lanes: wrapping
+    dequantisation and sums, saturating packs, the in0 << 2 shortcut of a block without AC coefficients) -- against the reference's
+    own decoder: damaged files at quality 1-5 (quantisers up to 255) produce dequantised values far outside 16 bits. The restatement's
+    back half on the library's own coefficients must give the library's pixels on every file, where the C arithmetic does not."""
+    import io
+
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    _need_refs(oracle)
+    rng = np.random.default_rng(3)
+    rgb = synth.synth_rgb(7, 256)[:96, :128]
+    files = [d for _, d in jpeg_damage.cases(5, per_base=20)]
+    for q in (1, 2, 3, 5):
+        for sub in (0, 2):
+            b = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(rgb)).save(b, "JPEG", quality=q, subsampling=sub)
+            files += [jpeg_damage.damage(b.getvalue(), rng, (0, 2, 9)[it % 3]) for it in range(30)]
+    n = c_differs = 0
+    L = oracle.lib()
+    for d in files:
+        cv = oracle.ref_cv_jpeg_decode(d)
+        if cv is None:
+            continue
+        try:
+            co = [oracle.ref_jpeg_decode_coefs(d, c) for c in range(3 if cv.shape[2] == 3 else 1)]
+        except ValueError:
+            continue
+        n += 1
+        L.lo_set_idct_simd(0)
+        try:
+            c_differs += not np.array_equal(oracle.jpeg_pixels_from_coefs(d, co), cv)
+        finally:
+            L.lo_set_idct_simd(1)
+        assert np.array_equal(oracle.jpeg_pixels_from_coefs(d, co), cv)
+    assert n >= 300 and c_differs >= 40, (n, c_differs)
+
+
 # ------------------------------------------------------------------------------------------------ GPU half
+def _hostile(seed=3):
+    """Damaged quality-1..5 files: quantisers up to 255, dequantised coefficients far outside 16 bits."""
+    import io
+
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rng = np.random.default_rng(seed)
+    rgb = synth.synth_rgb(7, 256)[:96, :128]
+    out = []
+    for q in (1, 2, 3, 5):
+        for sub in (0, 2):
+            b = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(rgb)).save(b, "JPEG", quality=q, subsampling=sub)
+            out += [("q%d/%d/%d" % (q, sub, it), jpeg_damage.damage(b.getvalue(), rng, (0, 2, 9)[it % 3])) for it in range(30)]
+            b = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(rgb)).save(b, "JPEG", quality=q, subsampling=sub, progressive=True)
+            out += [("q%dp/%d/%d" % (q, sub, it), jpeg_damage.damage(b.getvalue(), rng, (0, 9)[it % 2])) for it in range(10)]
+    return out
+
+
+@pytest.mark.gpu
+def test_hostile_coefficients_decode_like_the_reference_decoder_on_the_device(batch, oracle):
+    """k_idct computes libjpeg-turbo's SIMD lane arithmetic: on damaged quality-1..5 files (a third of which the C arithmetic gets
+    differently) the product's pixels are the reference decoder's, baseline (fast path with its fall-back) and progressive (exact path)."""
+    import lilliput_amd
+
+    _need_refs(oracle)
+    bad, ok, failed = [], 0, 0
+    for tag, data in _hostile():
+        cv = oracle.ref_cv_jpeg_decode(data)
+        try:
+            px, _ = batch.decode_jpeg(data)
+        except lilliput_amd.LilliputError as e:
+            if cv is not None or e.code not in (1, 2):
+                bad.append((tag, "fails with", e.code, cv is None))
+            else:
+                failed += 1
+            continue
+        if cv is None:
+            bad.append((tag, "decodes, the reference fails"))
+        elif np.array_equal(px, cv):
+            ok += 1
+        else:
+            bad.append((tag, "pixels differ", int((px != cv).any(axis=2).sum())))
+    assert not bad, (len(bad), bad[:8])
+    assert ok >= 250, (ok, failed)
+
+
+
 def _reference_pixels(oracle, data):
-    """(pixels of the reference's decoder or None, second acceptable answer or None). The second answer exists where damaged bits
-    produce dequantised coefficients a real image cannot have: libjpeg-turbo's SIMD IDCT (x86-64: 16-bit lanes, wrapping adds,
-    saturating packs) and its C IDCT (32-bit) then differ; the product computes such blocks in the C path's arithmetic.
-    The entropy decode is held to the library either way: the second answer is the restatement's BACK HALF run on the library's own
-    coefficients."""
-    cv = oracle.ref_cv_jpeg_decode(data)
-    if cv is None:
-        return None, None
-    try:
-        alt = oracle.jpeg_pixels_from_coefs(data, [oracle.ref_jpeg_decode_coefs(data, c) for c in range(3 if cv.shape[2] == 3 else 1)])
-    except ValueError:
-        return cv, None
-    return cv, (None if np.array_equal(alt, cv) else alt)
+    """(pixels of the reference's decoder or None, None). Until round 5's end a second answer was accepted where damaged bits produce
+    dequantised coefficients a real image cannot have -- libjpeg-turbo's SIMD IDCT (x86-64: 16-bit lanes, wrapping adds, saturating
+    packs) and its C IDCT then differ; k_idct now computes the SIMD routine's lane arithmetic (lp_kernels_decode.hip idct_*_exact, the
+    fast path's conditions), so the reference's pixels are the only answer."""
+    return oracle.ref_cv_jpeg_decode(data), None
 
 
 @pytest.mark.gpu

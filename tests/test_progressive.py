@@ -286,14 +286,11 @@ def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
                 n_err += 1
                 continue
             n_img += 1
-            if np.array_equal(outs[0], exp):
-                n_same += 1
-                continue
-            # differing pixels are allowed in ONE case: damaged bits produced dequantised coefficients beyond the 16-bit lanes of
-            # libjpeg-turbo's SIMD IDCT (quality-1 tables multiply by 255), which wraps there; the product computes such blocks with
-            # the C path's 32-bit arithmetic, and so does the restatement
-            assert np.array_equal(outs[0], oracle.jpeg_decode(d)), (i, k, desc)
-    assert n_img > 50 and n_err > 3 and n_same >= n_img * 9 // 10, (n_img, n_err, n_same)
+            # (damaged bits at quality 1 produce dequantised coefficients beyond 16 bits: the reference's SIMD IDCT wraps and saturates there,
+            # and so does k_idct since round 5 -- no allowance)
+            assert np.array_equal(outs[0], exp), (i, k, desc)
+            n_same += 1
+    assert n_img > 50 and n_err > 3, (n_img, n_err, n_same)
 
 
 @pytest.mark.gpu
