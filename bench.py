@@ -553,17 +553,20 @@ def main_formats(args, ranks, la):
         sys.exit(3)
 
 
-def firehose_check(la, O, ops, data, out, side, quality, height=None):
+def firehose_check(la, O, ops, data, out, side, quality, height=None, ref_data=None):
     """One firehose output against the reference CPU path: the bytes, or -- where the resample is fractional (float taps: +-1 LSB per
     channel is north_star's contract) -- a pre-encode frame within +-1 LSB of the oracle's that `out` encodes byte-exactly.
     side x (height or side) = the box asked for."""
     h = side if height is None else height
-    exp = O.transform_any_to_jpeg(data, side, h, quality)
+    # ref_data: the bytes the REFERENCE path starts from when they are not what the library was handed -- an AVIF file (decoded by the
+    # reference's own libavif + dav1d, oracle/_ref/librefavif.so) whose frame the bench's host feeder handed over as `data`
+    rd = data if ref_data is None else ref_data
+    exp = O.transform_any_to_jpeg(rd, side, h, quality)
     if exp is None:
         return None  # the reference library of this format is not built here
     if out == exp:
         return True
-    ref = O.transform_any_frame(data, side, h)
+    ref = O.transform_any_frame(rd, side, h)
     d = la.Decoder(data)
     try:
         frame = la.parse_raw_frames(ops.Transform(d, la.ImageOptions(".bgra-frames", side, h, la.ImageOpsFit, False, {}, EncodeTimeout=10**10), dst_cap=ref.size * 2 + 4096))[0][0]
@@ -588,8 +591,10 @@ def main_firehose(args, ranks, la):
     ndev = max(1, la.lib().lilliput_hip_device_count())
     per_kind = max(4, min(args.distinct, 256) // 8)
     t0 = time.time()
-    pools = synth.firehose_pool(per_kind, 512, args.max_side, seed=1)
-    items = synth.firehose_items(pools, args.batch, seed=2 + rank)
+    real_avif = synth.avif_supported()
+    mix = synth.FIREHOSE_MIX_AVIF if real_avif else synth.FIREHOSE_MIX
+    pools = synth.firehose_pool(per_kind, 512, args.max_side, seed=1, mix=mix)
+    items = synth.firehose_items(pools, args.batch, seed=2 + rank, mix=mix)
     log("[bench] firehose: %d distinct sources per format generated in %.1fs" % (per_kind, time.time() - t0))
     arena = None
     placed = {}
@@ -599,40 +604,70 @@ def main_firehose(args, ranks, la):
         placed = {k: arena.put(d) for k, d in distinct.items()}
     sources = [placed[id(d)] if arena is not None else np.frombuffer(d, dtype=np.uint8) for _, d in items]
     node = la.Node([local_rank % ndev])
+    node_avif = la.Node([local_rank % ndev]) if real_avif else None
     window = args.window if 0 < args.window < args.batch else args.batch
     kinds = [k for k, _ in items]
+    # AVIF items: the AV1 decode is the HOST FEEDER's (a service has libavif in front of the library, lilliput.go:136-164 -> avif.cpp; here
+    # Pillow's bundled libavif on a feeder thread), inside the timed region; its frames enter through the hand-over item while the
+    # library works on the rest of the window
+    feeder, feeder_wait_s, frame_bytes = None, [0.0], {}
+    if real_avif:
+        for k, d in items:
+            if k == "avif" and id(d) not in frame_bytes:
+                frame_bytes[id(d)] = synth.avif_frame_bytes(d)
+        win = args.window if 0 < args.window < args.batch else args.batch
+        cap = max([sum((frame_bytes[id(items[i][1])] + 63) // 64 * 64 for i in range(w0, min(len(items), w0 + win)) if items[i][0] == "avif") for w0 in range(0, len(items), win)] + [64])
+        quota = cgroup_cpus()
+        feed_workers = max(2, int((quota if quota else host_cores()[1]) // 2))   # half of the CPUs the container grants: the library's own host codecs need the rest
+        feeder = synth.AvifFeeder(feed_workers, cap)
     # the outputs the gate will look at are fixed before the run, so that a streamed run keeps only those (bounded memory)
     gate_picks = {}
-    for k, _ in synth.FIREHOSE_MIX:
+    for k, _ in mix:
         idx = [i for i, kk in enumerate(kinds) if kk == k]
         gate_picks[k] = sorted({idx[int.from_bytes(hashlib.sha256(b"%d:%d:%s:%d" % (args.steps - 1, rank, k.encode(), j)).digest()[:8], "little") % len(idx)] for j in range(args.verify)}) if idx else []
     wanted = {i for v in gate_picks.values() for i in v}
     kept, status = {}, [0] * len(items)
-    if window == args.batch:
+    one_call = window == args.batch and not real_avif
+    if one_call:
         node.prepare(sources, dst_cap=512 << 10)
 
     def step():
-        if window == args.batch:
+        if one_call:
             node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
             return
-        # streamed: one lilliput_hip_node_transform per window of the stream; the window's item array and destination buffers are all that is held
+        # streamed: one lilliput_hip_node_transform per window of the stream (plus one for the window's AVIF frames once the feeder has
+        # decoded them); the window's item array, destination buffers and decoded AVIF frames are all that is held
         for w0 in range(0, len(sources), window):
-            node.prepare(sources[w0:w0 + window], dst_cap=512 << 10)
+            w1 = min(len(sources), w0 + window)
+            av = [i for i in range(w0, w1) if kinds[i] == "avif"]
+            rest = [i for i in range(w0, w1) if kinds[i] != "avif"]
+            fut = feeder.submit([items[i][1] for i in av], [frame_bytes[id(items[i][1])] for i in av]) if av else None
+            node.prepare([sources[i] for i in rest], dst_cap=512 << 10)
             node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
-            for j, r in enumerate(node.results()):
-                status[w0 + j] = r.status
-                if w0 + j in wanted:
-                    kept[w0 + j] = r
+            for i, r in zip(rest, node.results()):
+                status[i] = r.status
+                if i in wanted:
+                    kept[i] = r
+            if fut is not None:
+                t_w = time.time()
+                frames = feeder.collect(fut)
+                feeder_wait_s[0] += time.time() - t_w
+                node_avif.prepare(frames, dst_cap=512 << 10)
+                node_avif.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+                for i, r in zip(av, node_avif.results()):
+                    status[i] = r.status
+                    if i in wanted:
+                        kept[i] = r
 
     elapsed = ranks.timed(step, args.steps, args.warmup)
-    if window == args.batch:
+    if one_call:
         res = node.results()
     else:
         class _R:  # the streamed run kept statuses for all and bytes for the gate's picks
             def __init__(self, st, data=b""):
                 self.status, self.data = st, data
         res = [kept[i] if i in kept else _R(status[i]) for i in range(len(items))]
-    counts = {k: kinds.count(k) for k, _ in synth.FIREHOSE_MIX}
+    counts = {k: kinds.count(k) for k, _ in mix}
     ok = {k: sum(1 for kk, r in zip(kinds, res) if kk == k and r.status == 0) for k in counts}
     # ---- correctness gate: K outputs per format of the last step
     from oracle import oracle as O
@@ -642,7 +677,10 @@ def main_firehose(args, ranks, la):
     verified, bad = {k: 0 for k in counts}, []
     for k in counts:
         for i in gate_picks[k]:
-            v = firehose_check(la, O, ops, bytes(items[i][1]), res[i].data if res[i].status == 0 else b"", args.out, 85)
+            if k == "avif":  # the library saw the feeder's frame; the reference path starts from the file (its own libavif + dav1d)
+                v = firehose_check(la, O, ops, synth.avif_to_handover(items[i][1]).tobytes(), res[i].data if res[i].status == 0 else b"", args.out, 85, ref_data=bytes(items[i][1]))
+            else:
+                v = firehose_check(la, O, ops, bytes(items[i][1]), res[i].data if res[i].status == 0 else b"", args.out, 85)
             if v is None:
                 continue
             verified[k] += 1
@@ -660,12 +698,17 @@ def main_firehose(args, ranks, la):
         out = {"metric": "images/sec (mixed-format firehose, sides 512-%d px -> 256x256 JPEG q85)" % args.max_side, "value": round(n / elapsed, 2), "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[4]%s: %d items per GPU and step, JPEG 70 / PNG 15 / WebP 10 / handed-over decoded frames 5 %% (they stand in for AVIF: the AV1 decode is a host "
-                                      "feeder by design, and the reference's libavif.a does not link in this mount -- libaom.a is among its missing blobs), "
+               "config": {"workload": "BASELINE configs[4]%s: %d items per GPU and step, JPEG 70 / PNG 15 / WebP 10 / %s, "
                                       "sides log-uniform 512-%d px (every second source 4:3), %d distinct sources per format -> 256x256 JPEG q85, ImageOpsFit; "
                                       "lilliput_hip_node_transform, host bytes in -> host bytes out%s" % (
-                                          "" if args.batch >= 100000 and args.max_side >= 8192 else " in miniature", args.batch, args.max_side, per_kind,
+                                          "" if args.batch >= 100000 and args.max_side >= 8192 else " in miniature", args.batch,
+                                          "REAL AVIF files 5 % (AV1 is a host codec: decoded inside the timed region by the bench's host feeder -- worker processes with Pillow's bundled libavif, "
+                                          "running while the library works on the rest of the window -- and handed over as decoded frames, the route a service with libavif in front takes: "
+                                          "lilliput.go:136-164, INTEGRATION.md 2f; the gate's answer comes from the reference's own libavif + dav1d)" if real_avif else
+                                          "handed-over decoded frames 5 % (they stand in for AVIF: this Pillow cannot write AVIF)",
+                                          args.max_side, per_kind,
                                           "" if window == args.batch else ", streamed in windows of %d items (bounded memory: one window's item array and destination buffers)" % window),
+                          "avif_feeder": {"worker_processes": feed_workers, "waited_for_the_feeder_s_per_step": round(feeder_wait_s[0] / max(1, args.steps + args.warmup), 3)} if real_avif else None,
                           "items_per_s_per_format": {k: round(counts[k] * args.steps * world / elapsed, 1) for k in counts},
                           "items_per_format": counts, "ok_per_format": ok, "input_MB_per_step": round(mb_in, 1),
                           "verified_outputs_per_format": verified, "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
@@ -674,12 +717,44 @@ def main_firehose(args, ranks, la):
                           "ingest_source_memory": args.ingest},
                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                             "note": "the mixed stream is bound by the host codecs (inflate, VP8) and the per-item launches of the non-JPEG items, not by a kernel: see DESIGN.md 5"}}
+        if not args.no_extra_legs:
+            # the dominant device stage of THIS mix, from the library's stage profile (HIP events around every probed launch of the one-image
+            # route, live, outside the timed region) over a sample of the step's items (AVIF items as the feeder's frames)
+            sample = [(synth.avif_to_handover(d).tobytes() if k == "avif" else bytes(d)) for k, d in items[: min(len(items), 48)]]
+            pops = la.ImageOps(8192)
+
+            def run_once():
+                for d in sample:
+                    dec = la.Decoder(d)
+                    try:
+                        pops.Transform(dec, la.ImageOptions(".jpeg", args.out, args.out, la.ImageOpsFit, False, {la.JpegQuality: 85}, EncodeTimeout=10**10), dst_cap=512 << 10)
+                    finally:
+                        dec.Close()
+
+            try:
+                roof = stage_profile_roofline(la, run_once, repeats=2)
+                roof["note"] = ("the dominant device stage of this mix by the library's stage profile over %d of the step's items through the one-image route (a launch serves ONE image of "
+                                "0.3 - 50 MP here, so achieved / frac are those of small launches); the stream as a whole is bound by the host codecs (inflate, VP8, AV1) -- cpu_baseline, DESIGN.md 5" % len(sample))
+                out["roofline"] = roof
+            finally:
+                pops.Close()
         if not args.no_cpu_baseline:
             ncpu = host_cores()[0]
             sample = [bytes(d) for _, d in items[: min(len(items), max(64, ncpu))]]
-            out["cpu_baseline"] = cpu_baseline(sample, args.out, args.out, 85, what="the same mix (reference libjpeg-turbo / libpng / libwebp decode, INTER_AREA restatement, libjpeg-turbo encode)")
+            out["cpu_baseline"] = cpu_baseline(sample, args.out, args.out, 85, what="the same mix (reference libjpeg-turbo / libpng / libwebp / libavif + dav1d decode, INTER_AREA restatement, libjpeg-turbo encode)")
         print(json.dumps(out), flush=True)
     node.close()
+    if node_avif is not None:
+        node_avif.close()
+        node_avif._items = node_avif._keep = None   # the item array holds views of the feeder's shared memory
+    if feeder is not None:
+        import gc
+
+        gc.collect()
+        try:
+            feeder.close()
+        except BufferError:  # a view of the block is still alive somewhere: the block goes with the process
+            pass
     if arena is not None:
         arena.close()
     ranks.close()

@@ -38,6 +38,7 @@ typedef int (*dec_png_fn)(const uint8_t*, size_t, uint8_t*, size_t, int info[6])
 typedef long (*dec_webp_fn)(const uint8_t*, size_t, int, uint8_t*, size_t, int meta[8]);
 typedef int (*info_webp_fn)(const uint8_t*, size_t, uint32_t out[8]);
 typedef size_t (*enc_webp_fn)(const uint8_t*, int, int, int, float, const uint8_t*, size_t, uint8_t*, size_t);
+typedef int (*dec_avif_fn)(const uint8_t*, size_t, uint8_t*, size_t, int info[4]);
 
 typedef struct {
     dec_jpeg_fn dec_jpeg;       /* JPEG bytes -> BGR / grey rows */
@@ -49,6 +50,7 @@ typedef struct {
     int resize_method;          /* 0 none, 1 Fit, 2 Resize (ops.go:18-22) */
     enc_webp_fn enc_webp;       /* non-NULL: WebP output at webp_quality (webp.cpp:707-751) instead of JPEG */
     float webp_quality;
+    dec_avif_fn dec_avif;       /* may be NULL: AVIF items fail (ref_avif_driver.c: the reference's libavif + dav1d, avif.cpp:164-321) */
 } lo_path_cfg;
 
 typedef struct { uint8_t *frame, *oriented, *thumb; size_t frame_cap, oriented_cap, thumb_cap; } lo_path_scratch;
@@ -112,6 +114,13 @@ long lo_path_transform(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t
         if (need(&s->frame, &s->frame_cap, (size_t)inf[0] * inf[1] * 4 + 16)) return -4;
         if (cfg->dec_webp(d, n, 1, s->frame, s->frame_cap, meta) < 0) return -2;
         w = meta[0]; h = meta[1]; cn = meta[2];
+        px = s->frame; stride = (size_t)w * cn;
+    } else if (n >= 12 && !memcmp(d + 4, "ftyp", 4) && (!memcmp(d + 8, "avif", 4) || !memcmp(d + 8, "avis", 4))) { /* lilliput.go:136-164: the AVIF signature */
+        int info[4];
+        if (!cfg->dec_avif || cfg->dec_avif(d, n, NULL, 0, info) != -3) return -2;
+        if (need(&s->frame, &s->frame_cap, (size_t)info[0] * info[1] * info[2])) return -4;
+        if (cfg->dec_avif(d, n, s->frame, s->frame_cap, info)) return -2;
+        w = info[0]; h = info[1]; cn = info[2]; orientation = info[3];
         px = s->frame; stride = (size_t)w * cn;
     } else {
         int nc = 0;

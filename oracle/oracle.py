@@ -432,6 +432,35 @@ def ref_jpeg_decode(data):
     return _decode_pixels(ref().ref_jpeg_decode_pixels, data)
 
 
+_refavif = None
+
+
+def ref_avif():
+    """The reference's own libavif + dav1d + libyuv (decode only; oracle/ref_avif_driver.c), or None when not built."""
+    global _refavif
+    if _refavif is None:
+        _refavif = _load(os.path.join("_ref", "librefavif.so"))
+    return _refavif
+
+
+def ref_avif_decode(data):
+    """AVIF bytes -> (HxWx3 BGR or HxWx4 BGRA uint8, EXIF-style orientation of the irot / imir boxes) the way avif.cpp:164-321 decodes a
+    still, or None when libavif refuses the file."""
+    L = ref_avif()
+    arr, p = _buf(data)
+    info = (C.c_int * 4)()
+    if L.ref_avif_decode(p, C.c_size_t(len(arr)), None, C.c_size_t(0), info) != -3:
+        return None
+    out = np.empty(info[0] * info[1] * info[2], dtype=np.uint8)
+    if L.ref_avif_decode(p, C.c_size_t(len(arr)), out.ctypes.data_as(_u8p), C.c_size_t(out.size), info) != 0:
+        return None
+    return out.reshape(info[1], info[0], info[2]), int(info[3])
+
+
+def is_avif(d):
+    return len(d) >= 12 and d[4:8] == b"ftyp" and d[8:12] in (b"avif", b"avis")
+
+
 _refjcv = None
 
 
@@ -729,6 +758,9 @@ def transform_any_frame(data, width, height, resize_method=FIT):
     if d[:4] == b"RIFF" and d[8:12] == b"WEBP":
         fr = ref_webp_frames(d) if ref_webp() is not None else None
         return None if not fr or fr[0] is None else transform_static(fr[0][0], 1, width, height, resize_method, False)
+    if is_avif(d):  # avifDecoder.DecodeTo leaves BGR(A) in the framebuffer (avif.cpp:277-321); the orientation is the irot / imir boxes'
+        r = ref_avif_decode(d) if ref_avif() is not None else None
+        return None if r is None else transform_static(r[0], r[1], width, height, resize_method, False)
     return transform_static(jpeg_decode(d), jpeg_info(d)["orientation"], width, height, resize_method, False)
 
 
@@ -763,7 +795,8 @@ def transform_animated_to_webp(data, width, height, quality=75):
 
 class _PathCfg(C.Structure):
     _fields_ = [("dec_jpeg", C.c_void_p), ("enc_jpeg", C.c_void_p), ("dec_png", C.c_void_p), ("dec_webp", C.c_void_p), ("info_webp", C.c_void_p),
-                ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int), ("enc_webp", C.c_void_p), ("webp_quality", C.c_float)]
+                ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int), ("enc_webp", C.c_void_p), ("webp_quality", C.c_float),
+                ("dec_avif", C.c_void_p)]
 
 
 def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True, webp_quality=None):
@@ -780,6 +813,8 @@ def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_r
     if ref_webp() is not None:
         cfg.dec_webp = C.cast(ref_webp().ref_webp_decode_frame, C.c_void_p)
         cfg.info_webp = C.cast(ref_webp().ref_webp_info, C.c_void_p)
+    if ref_avif() is not None:
+        cfg.dec_avif = C.cast(ref_avif().ref_avif_decode, C.c_void_p)
     cfg.width, cfg.height, cfg.quality, cfg.resize_method = int(width), int(height), int(quality), int(resize_method)
     if webp_quality is not None:  # WebP output through the reference's own writer (webp.cpp:707-751)
         if ref_webp() is None:

@@ -79,3 +79,53 @@ def test_every_item_of_a_mixed_stream_matches_the_reference_path(hip_lib, oracle
         ops.Close()
         b.close()
         n.close()
+
+
+def test_avif_feeder_frames_are_the_reference_decoders(oracle):
+    """(no GPU) Real AVIF files in the mix: the bench's host feeder (Pillow's bundled libavif -> hand-over item) must hand the library
+    the pixels the reference's own libavif + dav1d decode (oracle/_ref/librefavif.so, avif.cpp:164-321), or the gate would compare two
+    different images."""
+    import struct
+
+    from lilliput_amd import synth
+
+    if not synth.avif_supported() or oracle.ref_avif() is None:
+        pytest.skip("Pillow without AVIF, or oracle/_ref/librefavif.so not built")
+    for seed, side in ((4001, 512), (4002, 776), (4003, 1032)):
+        d = synth.firehose_source("avif", seed, side)
+        assert oracle.is_avif(d)
+        px, orientation = oracle.ref_avif_decode(d)
+        h = synth.avif_to_handover(d)
+        w_, h_, cn, stride, ori, _ = struct.unpack("<6I", h[8:32].tobytes())
+        assert (h_, w_, cn) == px.shape and ori == orientation == 1 and stride == 0
+        assert np.array_equal(h[32:].reshape(px.shape), px), (seed, side)
+        assert oracle.transform_any_to_jpeg(d, 128, 128, 85) == oracle.transform_any_to_jpeg(h.tobytes(), 128, 128, 85)
+    out = oracle.cpu_path_run([synth.firehose_source("avif", 4004, 640)], 96, 96, 85, threads=1, jobs=1)
+    assert out["ok"] == 1 and out["outputs"][0] == oracle.transform_any_to_jpeg(synth.firehose_source("avif", 4004, 640), 96, 96, 85)
+
+
+@pytest.mark.gpu
+def test_avif_items_through_the_feeder_match_the_reference_path(hip_lib, oracle):
+    """AVIF file -> host feeder -> hand-over item -> device (orientation, Fit, encode): the reference CPU path's answer, which starts from
+    the file (reference libavif + dav1d decode -> INTER_AREA restatement -> libjpeg-turbo encode)."""
+    import lilliput_amd as la
+    from lilliput_amd import synth
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    if not synth.avif_supported() or oracle.ref_avif() is None:
+        pytest.skip("Pillow without AVIF, or oracle/_ref/librefavif.so not built")
+    files = [synth.firehose_source("avif", 4100 + i, side) for i, side in enumerate((512, 640, 904, 1400))]
+    frames = [synth.avif_to_handover(d) for d in files]
+    ops = la.ImageOps(8192)
+    b = la.Batch(0)
+    try:
+        for w, h in ((256, 256), (200, 120)):
+            res = b.transform(frames, w, h, quality=85, dst_cap=512 << 10)
+            for d, f, r in zip(files, frames, res):
+                assert r.status == 0
+                assert bench.firehose_check(la, oracle, ops, f.tobytes(), r.data, w, 85, height=h, ref_data=d)
+    finally:
+        ops.Close()
+        b.close()
