@@ -873,6 +873,8 @@ struct LpPipeShared {
         Share& own = share[home % n_share];
         size_t j = own.next.fetch_add(1);
         if (j < own.end) return j;
+        static const bool no_steal = getenv("LILLIPUT_HIP_NODE_STEAL") && atoi(getenv("LILLIPUT_HIP_NODE_STEAL")) == 0; // tests / A-B: static shares only
+        if (no_steal) return jobs.size();
         for (;;) { // steal from the fullest share
             size_t best = n_share, left = 0;
             for (size_t k = 0; k < n_share; k++) {
