@@ -674,7 +674,9 @@ static void run_other(LpBatch* b, const lilliput_batch_options* opt, lilliput_ba
     // most 32 (LILLIPUT_HIP_OTHER_WORKERS overrides) -- a mixed-format firehose is bound by the serial host codecs (inflate, LZW, VP8),
     // each worker keeps one engine's worth of device arenas
     static const int other_workers = getenv("LILLIPUT_HIP_OTHER_WORKERS") ? std::max(1, atoi(getenv("LILLIPUT_HIP_OTHER_WORKERS")))
-                                                                           : std::max(2, std::min(32, (int)lp_usable_cpus_per_device()));
+                                                                           : std::max(2, std::min(32, (int)(lp_usable_cpus_per_device() * (lp_cpu_quota_limited() ? 1.5 : 1.0))));
+    // (inside a CPU quota the waits of these workers sleep -- LpEngine's blocking-sync default -- so one and a half workers per granted CPU keep
+    // the CPUs busy while half a worker's worth of them waits for the device: +10 % on the mixed stream, profiles/r04_j_firehose_host.md)
     const size_t nw = std::min<size_t>(b->other.size(), (size_t)other_workers);
     while (b->other_ops.size() < nw) b->other_ops.push_back(lilliput_new_image_ops(8192));
     while (b->other_eng.size() < nw) {

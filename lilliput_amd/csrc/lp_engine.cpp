@@ -1,5 +1,6 @@
 // lp_engine.cpp -- see lp_engine.h.
 #include "lp_engine.h"
+#include "lp_hostmem.h"
 
 #include <emmintrin.h>
 #include <float.h>
@@ -225,7 +226,8 @@ LpEngine::LpEngine(int device) : device_(device)
     if (!check(hipSetDevice(device_), "hipSetDevice")) return;
     {   // LILLIPUT_HIP_BLOCKING_SYNC=1: host threads that wait for the device sleep instead of spinning (hipDeviceScheduleBlockingSync). A spin
         // costs nothing on a host with idle cores and a whole CPU per waiting caller inside a CPU quota (profiles/r04_a_service.md)
-        static const bool blocking = getenv("LILLIPUT_HIP_BLOCKING_SYNC") && atoi(getenv("LILLIPUT_HIP_BLOCKING_SYNC")) != 0;
+        // Default: on inside a CPU quota that is clearly smaller than the CPUs the container shows (lp_cpu_quota_limited), off otherwise.
+        static const bool blocking = getenv("LILLIPUT_HIP_BLOCKING_SYNC") ? atoi(getenv("LILLIPUT_HIP_BLOCKING_SYNC")) != 0 : lp_cpu_quota_limited();
         static std::atomic<uint64_t> done_mask{0};
         if (blocking && device_ < 64 && !(done_mask.fetch_or(1ull << device_) & (1ull << device_)))
             if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();

@@ -283,6 +283,32 @@ LP_ABI_CATCH("lilliput_hip_host_unregister", return LILLIPUT_ERR_DEVICE)
 
 extern "C" int lilliput_hip_host_is_pinned(const void* p, size_t bytes) { return lp_host_is_pinned(p, bytes) ? 1 : 0; }
 
+// true when the container grants fewer CPUs than it shows (a cgroup CPU quota below the affinity mask: the gpurun boxes show 256 hardware
+// threads and grant 16): spinning waits then burn granted CPU time that the host codecs need (profiles/r04_j_firehose_host.md)
+bool lp_cpu_quota_limited()
+{
+    static const bool v = [] {
+        double shown = 1, quota = -1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) shown = (double)CPU_COUNT(&set);
+        else shown = (double)sysconf(_SC_NPROCESSORS_ONLN);
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            double per = 0;
+            if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+            fclose(f);
+        } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            double q = -1, per = 0;
+            if (fscanf(g, "%lf", &q) != 1) q = -1;
+            fclose(g);
+            if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) != 1) per = 0; fclose(h); }
+            if (q > 0 && per > 0) quota = q / per;
+        }
+        return quota > 0 && quota < shown * 0.75;
+    }();
+    return v;
+}
+
 unsigned lp_usable_cpus_per_device()
 {
     static const unsigned v = [] {

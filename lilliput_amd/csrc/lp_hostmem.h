@@ -57,3 +57,4 @@ int lp_bind_thread_near(int device);
 // CPU quota when there is one (cpu.max; the gpurun boxes show 256 threads and grant 16 -- scripts/host_scale.cpp), and shared between the
 // ranks of a node (LOCAL_WORLD_SIZE under torchrun, else the visible devices). Worker pools of host codecs are sized from it.
 unsigned lp_usable_cpus_per_device();
+bool lp_cpu_quota_limited(); // the container grants clearly fewer CPUs than it shows (cgroup quota below the affinity mask)
