@@ -826,143 +826,72 @@ __global__ __launch_bounds__(64) void k_dc_apply(const LpJpeg* __restrict__ imgs
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dequantise + jpeg_idct_islow (jidctint.c). One wave = 8 horizontally adjacent
-// blocks of one component; lane = (block j, row/column r). Coefficient rows arrive as one coalesced
-// 1 KiB wave load, are transposed through LDS for the column pass, and leave as 8-byte pixel rows
-// (64 contiguous bytes per row across the 8 blocks).
+// Dequantise + jpeg_idct_islow. One wave = 8 horizontally adjacent blocks of one component; lane = (block j,
+// row/column r). Coefficient columns arrive as 8-byte loads (the WRITE pass stores blocks transposed), the first pass's outputs cross to
+// the row pass through a per-wave LDS workspace of 16-bit values, and leave as 8-byte pixel rows (64 contiguous bytes per row across
+// the 8 blocks).
+//
 // What "jpeg_idct_islow" means here is what the reference's libjpeg-turbo computes on x86-64: its SIMD routine (jidctint-sse2 / -avx2),
 // which has the C code's butterflies and constants but works in 16-bit lanes -- dequantisation wraps (pmullw), so do in0 +- in4 and the
-// odd part's z3 = in7 + in3, z4 = in5 + in1 (paddw / psubw), the rotations are 32-bit sums of two 16 x 16 products (pmaddwd), the first
-// pass's outputs are SATURATED to 16 bits (packssdw) -- except in a block without AC coefficients, whose first pass is in0 << 2 in 16
-// bits (psllw: wraps) -- and the second pass ends saturated to 8 bits. For the coefficients of real images none of that triggers and
-// the result is the C code's; damaged streams and hostile tables do trigger it, and the reference's pixels are then the SIMD routine's
-// (oracle/jpeg_oracle.c lo_idct_islow_simd, pinned against the reference's own decoder on 1 300 damaged files, 360 of which differ
-// between the two arithmetics). Two implementations below: the exact lane arithmetic for any input (idct_*_exact: every progressive /
-// scan-path image, every tile with an escaped coefficient or a large quantiser), and the fast path for the rest, which is the same
-// arithmetic wherever a handful of cheap conditions hold and falls back to the exact one where they do not.
-__device__ __forceinline__ int32_t sx16(int32_t v) { return (int32_t)(int16_t)v; } // v_bfe_i32
-// one 1-D pass on eight 16-bit values (held in int32): every product has a 16-bit and a 15-bit factor (24-bit multiplies are exact),
-// every sum is a 32-bit wrapping add
-__device__ __forceinline__ void idct_1d_simd(const int32_t d[8], int32_t o[8])
+// odd part's z3 = in7 + in3, z4 = in5 + in1 (paddw / psubw), every rotation is a 32-bit sum of two 16 x 16 products with two combined
+// constants (pmaddwd), the first pass's outputs are SATURATED to 16 bits (packssdw) -- except in a block whose rows 1-7 are empty, where
+// the first pass is in0 << 2 in 16 bits (psllw: wraps) -- and the second pass ends saturated to 8 bits. For the coefficients of real
+// images none of that triggers and the result is the C code's; damaged streams and hostile tables do trigger it, and the reference's
+// pixels are then the SIMD routine's (oracle/jpeg_oracle.c lo_idct_islow_simd, pinned against the reference's own decoder on 1 300
+// damaged files, 360 of which differ between the two arithmetics).
+// gfx950 has the same lane operations: v_pk_mul_lo_u16 = pmullw, v_pk_add_u16 / v_pk_sub_u16 = paddw / psubw, v_dot2_i32_i16 = pmaddwd
+// (+ the add that follows it), v_cvt_pk_i16_i32 = packssdw. So the transform is written in them (round 5; rounds 1-4 computed the C
+// code's 32-bit arithmetic, ~150 vector instructions per tile and lane; this is ~110 and exact for EVERY input, no checks, one path).
+// A lane holds its eight values as four 16-bit pairs, paired the way the rotations need them:
+//     p04 = (d0, d4)   p26 = (d2, d6)   p71 = (d7, d1)   p35 = (d3, d5)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+#define IDCT_K2(lo, hi) ((s16x2){(short)(lo), (short)(hi)})
+__device__ __forceinline__ int32_t idct_dot2(s16x2 a, s16x2 b, int32_t c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
+__device__ __forceinline__ s16x2 idct_pair(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+
+// One 1-D pass; rnd = the pass's rounding constant (every output holds tmp0 or tmp1 exactly once, so it rides in on them).
+__device__ __forceinline__ void idct_1d_pk(s16x2 p04, s16x2 p26, s16x2 p71, s16x2 p35, int32_t rnd, int32_t o[8])
 {
-    const int32_t tmp3 = __mul24(d[2], 10703) + __mul24(d[6], 4433), tmp2 = __mul24(d[2], 4433) + __mul24(d[6], -10704);
-    const int32_t tmp0 = (int32_t)((uint32_t)sx16(d[0] + d[4]) << 13), tmp1 = (int32_t)((uint32_t)sx16(d[0] - d[4]) << 13);
+    const int32_t tmp3 = idct_dot2(p26, IDCT_K2(10703, 4433), 0), tmp2 = idct_dot2(p26, IDCT_K2(4433, -10704), 0);
+    const s16x2 p40 = __builtin_shufflevector(p04, p04, 1, 0);
+    const s16x2 s = p04 + p40, d = p04 - p40;                      // (d0 + d4, ..), (d0 - d4, ..) in 16 bits
+    const int32_t tmp0 = idct_dot2(s, IDCT_K2(8192, 0), rnd), tmp1 = idct_dot2(d, IDCT_K2(8192, 0), rnd);   // sign-extended << 13
     const int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
-    const int32_t z3 = sx16(d[7] + d[3]), z4 = sx16(d[5] + d[1]);
-    const int32_t z3n = __mul24(z3, -6436) + __mul24(z4, 9633), z4n = __mul24(z3, 9633) + __mul24(z4, 6437);
-    const int32_t o0 = __mul24(d[7], -4927) + __mul24(d[1], -7373) + z3n, o3 = __mul24(d[7], -7373) + __mul24(d[1], 4926) + z4n;
-    const int32_t o1 = __mul24(d[5], -4176) + __mul24(d[3], -20995) + z4n, o2 = __mul24(d[5], -20995) + __mul24(d[3], 4177) + z3n;
+    const s16x2 z = p71 + p35;                                     // (z3, z4) = (d7 + d3, d1 + d5) in 16 bits
+    const int32_t z3n = idct_dot2(z, IDCT_K2(-6436, 9633), 0), z4n = idct_dot2(z, IDCT_K2(9633, 6437), 0);
+    const int32_t o0 = idct_dot2(p71, IDCT_K2(-4927, -7373), z3n), o3 = idct_dot2(p71, IDCT_K2(-7373, 4926), z4n);
+    const int32_t o1 = idct_dot2(p35, IDCT_K2(-20995, -4176), z4n), o2 = idct_dot2(p35, IDCT_K2(4177, -20995), z3n);
     o[0] = t10 + o3; o[7] = t10 - o3; o[1] = t11 + o2; o[6] = t11 - o2;
     o[2] = t12 + o1; o[5] = t12 - o1; o[3] = t13 + o0; o[4] = t13 - o0;
 }
 
-#define IDCT_WSTRIDE 72 // int32 per block in LDS (64 + 8 pad): conflict-free column writes
+// The per-wave workspace: 8 blocks x 8 rows x 8 halfwords, a block every IDCT_WPITCH halfwords (144 bytes: the eight blocks of a tile
+// start four banks apart, so the halfword stores of the column pass -- lane (j, c) writes row k, slot of column c -- spread over all 32
+// banks). A row's eight values sit in the order (c0, c4, c2, c6, c7, c1, c3, c5): the row pass reads them as ONE 16-byte load that is
+// already the four pairs idct_1d_pk takes.
+#define IDCT_WPITCH 72
+__device__ __forceinline__ uint32_t idct_slot(uint32_t c) { return (0x43716250u >> (4u * c)) & 7u; } // column -> halfword slot in its row
 
-// Grid: x = group of IDCT_TPW * 32 blocks along a block row, y = block row over the image's components stacked (all Y rows,
-// then Cb, then Cr), z = image -- no integer division anywhere. A wave walks IDCT_TPW tiles of 8 blocks (its setup -- the
-// descriptor loads, the quantisation column -- is paid once, and the next tile's coefficients are in flight while the
-// current one is transformed; one-tile waves were bound by wave launch rate, not by HBM or VALU).
-// Blocks are stored TRANSPOSED by the WRITE pass (element v * 8 + u = coefficient row u, column v), so lane (block j,
-// column v) loads its whole column as 8 contiguous bytes and the column pass needs no LDS transpose; only the row pass
-// reads the workspace back through LDS.
-// The two passes of one 8-block tile for lane (block j, column/row r): column pass from registers into the wave's LDS
-// workspace, row pass back out of it, 8-byte pixel-row store.
-// cv: the lane's coefficient column (16-bit values), qv: its quantiser column (the SIMD routine multiplies by the table entry as a
-// 16-bit SIGNED value); no_ac: rows 1-7 of the lane's block are empty (the routine then skips the first pass: every column is its
-// first-row element << 2, in 16 bits)
-__device__ __forceinline__ void idct_cols_exact(const int32_t cv[8], const int32_t qv[8], bool no_ac, int32_t* s_w, uint32_t j, uint32_t r)
-{
-    int32_t d[8], o[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = sx16(cv[k] * sx16(qv[k])); // pmullw: 16 x 16 -> low 16 bits (a 16-bit table entry times a 16-bit coefficient needs the full multiply)
-    idct_1d_simd(d, o);
-    const int32_t dc_only = sx16((int32_t)((uint32_t)d[0] << 2));
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int32_t v = (o[k] + (1 << 10)) >> 11;
-        s_w[j * IDCT_WSTRIDE + k * 8 + r] = no_ac ? dc_only : (v < -32768 ? -32768 : v > 32767 ? 32767 : v);
-    }
-}
-__device__ __forceinline__ uint2 idct_rows_exact(const int32_t* s_w, uint32_t j, uint32_t r)
-{
-    int32_t d[8], o[8];
-    const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
-    const int4 a = wp[0], b = wp[1];
-    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-    idct_1d_simd(d, o);
-    uint32_t px[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int32_t v = (o[k] + (1 << 17)) >> 18; // packssdw, packsswb, + 128: saturated to [-128, 127]
-        px[k] = (uint32_t)((v < -128 ? -128 : v > 127 ? 127 : v) + 128);
-    }
-    uint2 out;
-    out.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-    out.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-    return out;
-}
-
-// ---- the path almost every tile takes (no escape in the tile, 8-bit quantisation table): the same arithmetic with fewer instructions.
-// k_idct runs at the vector ALU's issue rate (profiles/r04_g: 612 G wave-instructions/s of 614), so its time is its instruction count.
-// * the 1-D transform takes tmp0 / tmp1 = (d0 +- d4) << 13 ready-made, with the pass's rounding constant already inside (every output is
-//   t1x +- odd part, and each t1x holds exactly one of the two): no add per output;
-// * column pass: a coefficient byte is sign-extended and multiplied by its quantiser in one SDWA multiply; d0 and d4 are multiplied by
-//   q << 13 directly (24-bit operands; the 32-bit result wraps exactly like the shift it replaces);
-// * row pass: (o + C) >> 18 is the upper half of the sum shifted right by two more bits -- the upper halves of two sums are taken by one
-//   v_perm, shifted as a pair, and clamped to bytes two at a time by v_sat_pk_u8_i16 (the second pair straight into the upper half of the
-//   output word) instead of a shift, a median and a merge per pixel.
-// zsum (optional): z3 | z4 biased by 32768 each -- bits 16.. of the OR are clear iff both odd-part sums fit 16 signed bits
-template <bool CHECK = false>
-__device__ __forceinline__ void idct_1d_pre(int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7, int32_t tmp0, int32_t tmp1, int32_t o[8], uint32_t* zsum = nullptr)
-{
-    const int32_t za = __mul24(d2 + d6, 4433);
-    const int32_t tmp2 = za - __mul24(d6, 15137), tmp3 = za + __mul24(d2, 6270);
-    const int32_t t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
-    int32_t z1 = d7 + d1, z2 = d5 + d3, z3 = d7 + d3, z4 = d5 + d1;
-    if (CHECK) *zsum = (uint32_t)(z3 + 32768) | (uint32_t)(z4 + 32768);
-    const int32_t z5 = __mul24(z3 + z4, 9633);
-    int32_t a0 = __mul24(d7, 2446), a1 = __mul24(d5, 16819), a2 = __mul24(d3, 25172), a3 = __mul24(d1, 12299);
-    z1 = __mul24(z1, -7373); z2 = __mul24(z2, -20995); z3 = __mul24(z3, -16069) + z5; z4 = __mul24(z4, -3196) + z5;
-    a0 += z1 + z3; a1 += z2 + z4; a2 += z2 + z3; a3 += z1 + z4;
-    o[0] = t10 + a3; o[7] = t10 - a3; o[1] = t11 + a2; o[6] = t11 - a2;
-    o[2] = t12 + a1; o[5] = t12 - a1; o[3] = t13 + a0; o[4] = t13 - a0;
-}
-template <int B> // sign-extended byte B of w times q
-__device__ __forceinline__ int32_t idct_deq(uint32_t w, int32_t q)
-{
-    int32_t d;
-    if (B == 0) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
-    else if (B == 1) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
-    else if (B == 2) asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
-    else asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(w), "v"(q));
-    return d;
-}
-// qv = the lane's quantiser column; q0s / q4s = qv[0] << 13, qv[4] << 13; is_dc: this lane holds column 0 of a real block, whose first
-// element is the 16-bit DC.
-// Where this equals the reference's 16-bit lane arithmetic (idct_cols_exact): the caller has made sure that every AC quantiser is at most
-// 129 and every AC coefficient at most 127, so an AC term is at most 16 383 and no sum of two of them leaves 16 bits; the first-row
-// element of every column (the DC in column 0) is checked here -- beyond 8 191 (no real image: a dequantised coefficient is bounded by
-// 8 x 128 x sqrt 2) the tile is done again the exact way, which covers the DC's range and the in0 << 2 wrap of the shortcut the SIMD
-// routine takes for a block whose rows 1-7 are empty; the outputs are saturated to 16 bits like packssdw does.
-// Returns non-zero when the lane's tile needs the exact path.
-__device__ __forceinline__ uint32_t idct_cols_fast(uint2 raw, int32_t dc, bool is_dc, const int32_t qv[8], int32_t q0s, int32_t q4s, int32_t* s_w, uint32_t j, uint32_t r)
+// Column pass for lane (block j, column c): the four dequantised pairs in, the first pass's outputs (saturated to 16 bits; for a block
+// whose rows 1-7 are empty the routine's shortcut value instead) out to the workspace.
+__device__ __forceinline__ void idct_cols_pk(s16x2 p04, s16x2 p26, s16x2 p71, s16x2 p35, bool rows17_empty, short* s_w, uint32_t j, uint32_t slot)
 {
     int32_t o[8];
-    const int32_t c0 = is_dc ? dc : (int32_t)(int8_t)(raw.x & 0xffu);
-    const uint32_t far = (uint32_t)(__mul24(c0, qv[0]) + 8192) >> 14; // the dequantised first-row element outside [-8192, 8191]
-    const int32_t tmp0e = __mul24(c0, q0s) + (1 << 10), d4s = idct_deq<0>(raw.y, q4s); // PASS1 rounding: 1 << (CONST_BITS - PASS1_BITS - 1)
-    idct_1d_pre(idct_deq<1>(raw.x, qv[1]), idct_deq<2>(raw.x, qv[2]), idct_deq<3>(raw.x, qv[3]), idct_deq<1>(raw.y, qv[5]), idct_deq<2>(raw.y, qv[6]),
-                idct_deq<3>(raw.y, qv[7]), tmp0e + d4s, tmp0e - d4s, o);
+    idct_1d_pk(p04, p26, p71, p35, 1 << 10, o);
+    const short dc_only = (short)(p04 << (s16x2){2, 2}).x;          // psllw(in0, PASS1_BITS): wraps
+    short* w = s_w + j * IDCT_WPITCH + slot;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int32_t v = o[k] >> 11;
-        s_w[j * IDCT_WSTRIDE + k * 8 + r] = v < -32768 ? -32768 : v > 32767 ? 32767 : v; // packssdw (one v_med3_i32)
+    for (int k = 0; k < 8; k += 2) {
+        const s16x2 v = __builtin_amdgcn_cvt_pk_i16(o[k] >> 11, o[k + 1] >> 11);   // packssdw
+        w[k * 8] = rows17_empty ? dc_only : v.x;
+        w[(k + 1) * 8] = rows17_empty ? dc_only : v.y;
     }
-    return far;
 }
+// (o + C) >> 18 clamped to a byte for four outputs: the upper halves of two sums are taken by one v_perm, shifted as a pair, and clamped
+// two at a time by v_sat_pk_u8_i16 (the second pair straight into the upper half of the output word). C carries the DESCALE rounding and
+// the + 128 (packssdw + packsswb + 128 = clamp to [-128, 127], + 128 = clamp of the sum with 128 added to [0, 255]).
 __device__ __forceinline__ uint32_t idct_pack4(int32_t o0, int32_t o1, int32_t o2, int32_t o3)
 {
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
     const s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o1, (uint32_t)o0, 0x07060302u)) >> (s16x2){2, 2};
     const s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o3, (uint32_t)o2, 0x07060302u)) >> (s16x2){2, 2};
     uint32_t d;
@@ -972,23 +901,32 @@ __device__ __forceinline__ uint32_t idct_pack4(int32_t o0, int32_t o1, int32_t o
         : "=&v"(d) : "v"(__builtin_bit_cast(uint32_t, p01)), "v"(__builtin_bit_cast(uint32_t, p23)));
     return d;
 }
-// The row pass works on the first pass's 16-bit values: equal to the reference's lane arithmetic as long as in0 +- in4, in7 + in3 and
-// in5 + in1 fit 16 bits (real images stay near 4 096 here); *bad gets bits 16.. set when one does not.
-__device__ __forceinline__ uint2 idct_rows_fast(const int32_t* s_w, uint32_t j, uint32_t r, uint32_t* bad)
+// Row pass for lane (block j, row r): the row's four pairs in one load, eight pixels out.
+__device__ __forceinline__ uint2 idct_rows_pk(const short* s_w, uint32_t j, uint32_t r)
 {
     int32_t o[8];
-    const int4* wp = reinterpret_cast<const int4*>(&s_w[j * IDCT_WSTRIDE + r * 8]);
-    const int4 a = wp[0], b = wp[1];
-    const uint32_t C = (1u << 17) + (128u << 18); // DESCALE rounding, then + 128
-    const int32_t s04 = a.x + b.x, d04 = a.x - b.x;
-    uint32_t zsum;
-    idct_1d_pre<true>(a.y, a.z, a.w, b.y, b.z, b.w, (int32_t)(((uint32_t)s04 << 13) + C), (int32_t)(((uint32_t)d04 << 13) + C), o, &zsum);
-    *bad = zsum | (uint32_t)(s04 + 32768) | (uint32_t)(d04 + 32768);
+    const uint4 v = *reinterpret_cast<const uint4*>(s_w + j * IDCT_WPITCH + r * 8);
+    idct_1d_pk(idct_pair(v.x), idct_pair(v.y), idct_pair(v.z), idct_pair(v.w), (int32_t)((1u << 17) + (128u << 18)), o);
     uint2 out;
     out.x = idct_pack4(o[0], o[1], o[2], o[3]);
     out.y = idct_pack4(o[4], o[5], o[6], o[7]);
     return out;
 }
+// Dequantisation of a column held as eight signed bytes (raw.x = rows 0-3, raw.y = rows 4-7) straight into the four pairs: one SDWA
+// multiply per value (sign-extended byte x 16-bit quantiser -> low 16 bits, written into its half of the pair).
+#define IDCT_DEQ_PAIR(NAME, LO_SEL, HI_SEL)                                                                                                   \
+    __device__ __forceinline__ s16x2 NAME(uint32_t wlo, uint32_t whi, uint32_t q)                                                             \
+    {                                                                                                                                          \
+        uint32_t d;                                                                                                                            \
+        asm("v_mul_lo_u16_sdwa %0, sext(%1), %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:" LO_SEL " src1_sel:WORD_0\n\ts_nop 0\n\t"         \
+            "v_mul_lo_u16_sdwa %0, sext(%2), %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:" HI_SEL " src1_sel:WORD_1\n\ts_nop 0"      \
+            : "=&v"(d) : "v"(wlo), "v"(whi), "v"(q));                                                                                          \
+        return __builtin_bit_cast(s16x2, d);                                                                                                   \
+    }
+IDCT_DEQ_PAIR(idct_deq04, "BYTE_0", "BYTE_0")   // (row 0 of raw.x, row 4 = byte 0 of raw.y)
+IDCT_DEQ_PAIR(idct_deq26, "BYTE_2", "BYTE_2")   // (row 2, row 6)
+IDCT_DEQ_PAIR(idct_deq71, "BYTE_3", "BYTE_1")   // (row 7 = byte 3 of raw.y, row 1 = byte 1 of raw.x): called with (raw.y, raw.x)
+IDCT_DEQ_PAIR(idct_deq35, "BYTE_3", "BYTE_1")   // (row 3 = byte 3 of raw.x, row 5 = byte 1 of raw.y): called with (raw.x, raw.y)
 
 __constant__ uint8_t c_nat2zigzag[64] = LP_NAT2ZIGZAG_INIT;
 
@@ -1008,11 +946,15 @@ __device__ __forceinline__ void idct_wave_sync()
 #ifndef IDCT_TPW
 #define IDCT_TPW 16     // tiles of 32 blocks a workgroup walks along a block row (16 = a whole 4096-pixel luma row). The kernel is bound by
                         // how long its waves live against the rate they are dispatched at: 4 / 8 / 16 tiles -> 22.8 / 18.2 / 13.6 us per
-                        // 4096 x 4096 image (scripts/r03_run18.sh); taking several block rows per workgroup on top of that gains nothing
+                        // 4096 x 4096 image (scripts/archive/r03_run18.sh); taking several block rows per workgroup on top of that gains nothing
 #endif
 #ifndef IDCT_AHEAD
 #define IDCT_AHEAD 4      // divides IDCT_TPW
 #endif
+// Grid: x = group of IDCT_TPW * 32 blocks along a block row, y = block row over the image's components stacked (all Y rows,
+// then Cb, then Cr), z = image -- no integer division anywhere. A wave walks IDCT_TPW tiles of 8 blocks (its setup -- the
+// descriptor loads, the quantisation column -- is paid once, and the next tile's coefficients are in flight while the
+// current one is transformed; one-tile waves were bound by wave launch rate, not by HBM or VALU).
 // PROG = false: the baseline images of the range (int8 blocks in decode order + wide slots + the DC array);
 // PROG = true: the progressive ones (int16 blocks, raster order per component, see LpProgScan). Each skips the other kind.
 #ifdef LP_IDCT_WPE // A/B: register budget for this many waves per SIMD
@@ -1026,7 +968,7 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
                                               const uint32_t* __restrict__ wide_id_arena, const int16_t* __restrict__ dc_arena,
                                               const int16_t* __restrict__ pcoef_arena, uint8_t* __restrict__ plane_arena)
 {
-    __shared__ __attribute__((aligned(16))) int32_t s_w[4][8 * IDCT_WSTRIDE];
+    __shared__ __attribute__((aligned(16))) short s_w[4][8 * IDCT_WPITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_qt[64]; // transposed like the blocks: [column][row]
     __shared__ uint8_t s_n2z[64];
     const LpJpeg& img = imgs[blockIdx.z];
@@ -1040,25 +982,19 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
     if (PROG && threadIdx.x < 64) s_n2z[threadIdx.x] = c_nat2zigzag[threadIdx.x];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t j = lane >> 3, r = lane & 7;
+    const uint32_t slot = idct_slot(r);
     // decode order: MCU (my, mx), then the component's blocks inside the MCU in scan order; sampling factors are 1 or 2
     const uint32_t hsh = img.hs[c] - 1u, vsh = img.vs[c] - 1u;
     __syncthreads();
-    bool q_small;
-    int32_t qv[8]; // this lane's column of the quantisation table, unpacked once for all tiles
+    // this lane's column of the quantisation table as the four pairs of idct_1d_pk, unpacked once for all tiles
+    uint32_t q04, q26, q71, q35;
     {
-        const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]);
-        qv[0] = (int32_t)(q.x & 0xffffu); qv[1] = (int32_t)(q.x >> 16); qv[2] = (int32_t)(q.y & 0xffffu); qv[3] = (int32_t)(q.y >> 16);
-        qv[4] = (int32_t)(q.z & 0xffffu); qv[5] = (int32_t)(q.z >> 16); qv[6] = (int32_t)(q.w & 0xffffu); qv[7] = (int32_t)(q.w >> 16);
-        // the fast path's static condition (idct_cols_fast): the DC quantiser fits a byte, every AC quantiser is at most 129 -- an AC term
-        // (coefficient at most 127 without an escape) then stays below 16 384 and no sum of two leaves 16 bits. Tables beyond that
-        // (quality below ~20) take the exact lane arithmetic for every tile. The wave vote below covers all eight columns.
-        uint32_t ac_max = 0;
-#pragma unroll
-        for (int k = 1; k < 8; k++) ac_max = ac_max > (uint32_t)qv[k] ? ac_max : (uint32_t)qv[k];
-        q_small = ac_max <= 129u && (uint32_t)qv[0] <= (r == 0 ? 255u : 129u);
+        const uint4 q = *reinterpret_cast<const uint4*>(&s_qt[r * 8]); // (q0, q1) (q2, q3) (q4, q5) (q6, q7)
+        q04 = (q.x & 0xffffu) | (q.z << 16);
+        q26 = (q.y & 0xffffu) | (q.w << 16);
+        q71 = (q.w >> 16) | (q.x & 0xffff0000u);
+        q35 = (q.y >> 16) | (q.z & 0xffff0000u);
     }
-    const bool q_small_wave = __all(q_small);
-    const int32_t q0s = qv[0] << 13, q4s = qv[4] << 13;
     // this lane's pixel row of the component (the descriptor is read here, once: behind the wave fences of the loop the compiler would
     // load it -- and redo the 64-bit address arithmetic -- for every tile)
     uint8_t* const dst_row = plane_arena + img.plane_off[c] + (size_t)(by * 8 + r) * img.plane_stride[c];
@@ -1100,71 +1036,75 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
         if (t >= IDCT_TPW || base >= bw) { out = true; break; } // workgroup-uniform
         const uint32_t bx = base + wv * 8 + j;
         const bool blk_ok = bx < bw;
-        int32_t cv[8];
         uint2 raw = pre_raw[a];
         raw.x = blk_ok ? raw.x : 0u;
         raw.y = blk_ok ? raw.y : 0u;
         const int32_t dc_now = pre_dc[a];
         fetch(pre_raw[a], pre_dc[a]);
         uint8_t* const dst = dst_row + bx * 8;
-        if (!PROG && q_small_wave) {
-            // a byte equals 0x80 (the escape) <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
+        s16x2 p04, p26, p71, p35;
+        bool lane_rows17; // this lane's column has something in rows 1-7
+        bool packed_bytes = false;
+        if (!PROG) {
+            // a byte equals 0x80 (the escape to the block's wide slot) <=> the byte of (x ^ 0x80808080) is zero; exact zero-byte test
             const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
             const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
-            if (__all((zx | zy) == 0)) {
-                // the path almost every tile takes; the reference's 16-bit lane arithmetic as long as the conditions of idct_cols_fast /
-                // idct_rows_fast hold -- a tile where one does not (no real image) is done again below, the exact way
-                const uint32_t far = idct_cols_fast(raw, dc_now, r == 0 && blk_ok, qv, q0s, q4s, s_w[wv], j, r);
-                idct_wave_sync();
-                uint32_t bad;
-                const uint2 px = idct_rows_fast(s_w[wv], j, r, &bad);
-                idct_wave_sync();
-                if (__all((far | (bad >> 16)) == 0)) {
-                    if (blk_ok) *reinterpret_cast<uint2*>(dst) = px;
-                    continue;
-                }
-            }
+            packed_bytes = __all((zx | zy) == 0); // the path almost every tile takes: the column is its eight bytes
         }
-        if (PROG) {
-            // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
-            // its 128 bytes between them)
-            const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u) + (c > 2 ? img.bw[2] * img.bh[2] : 0u);
-            const int16_t* src = pcoef_arena + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
-#pragma unroll
-            for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;
+        if (packed_bytes) {
+            p04 = idct_deq04(raw.x, raw.y, q04);
+            p26 = idct_deq26(raw.x, raw.y, q26);
+            p71 = idct_deq71(raw.y, raw.x, q71);
+            p35 = idct_deq35(raw.x, raw.y, q35);
+            if (r == 0 && blk_ok) p04.x = (short)((uint32_t)dc_now * (q04 & 0xffffu)); // the DC lives in its own 16-bit array (pmullw: low 16 bits)
+            lane_rows17 = ((raw.x >> 8) | raw.y) != 0u;
         } else {
-            const uint32_t blk = block_of(bx);
-            // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
+            int32_t cv[8];
+            if (PROG) {
+                // column r of the block: rows 0..7, gathered out of the zigzag order the scans store (the eight lanes of a block read
+                // its 128 bytes between them)
+                const uint32_t cbase = (c > 0 ? img.bw[0] * img.bh[0] : 0u) + (c > 1 ? img.bw[1] * img.bh[1] : 0u) + (c > 2 ? img.bw[2] * img.bh[2] : 0u);
+                const int16_t* src = pcoef_arena + img.coef_off + ((size_t)cbase + (size_t)by * bw + bx) * 64;
 #pragma unroll
-            for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
-            const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
-            const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
-            if ((zx | zy) != 0) {
-                // a block no lane wrote (the stream ended early: the image is reported as failed) holds stale bytes, and a stale
-                // escape comes with a stale slot number: keep the read inside the image's own slots
-                uint32_t wid = wide_id_arena[img.coef_off / 64 + blk];
-                wid = wid < img.total_blocks ? wid : 0u;
-                const int16_t* w = wide_arena + img.coef_off + (size_t)wid * 64 + r * 8;
+                for (int i = 0; i < 8; i++) cv[i] = blk_ok ? (int32_t)src[s_n2z[i * 8 + r]] : 0;
+            } else {
+                const uint32_t blk = block_of(bx);
+                // column r of the block: 8 x int8 (see DevSink); -128 escapes to the block's wide slot
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (cv[i] == -128) cv[i] = w[i];
+                for (int i = 0; i < 8; i++) cv[i] = (int32_t)(int8_t)(((i < 4 ? raw.x : raw.y) >> (8 * (i & 3))) & 0xffu);
+                const uint32_t ex = raw.x ^ 0x80808080u, ey = raw.y ^ 0x80808080u;
+                const uint32_t zx = ~(((ex & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ex | 0x7f7f7f7fu), zy = ~(((ey & 0x7f7f7f7fu) + 0x7f7f7f7fu) | ey | 0x7f7f7f7fu);
+                if ((zx | zy) != 0) {
+                    // a block no lane wrote (the stream ended early: the image is reported as failed) holds stale bytes, and a stale
+                    // escape comes with a stale slot number: keep the read inside the image's own slots
+                    uint32_t wid = wide_id_arena[img.coef_off / 64 + blk];
+                    wid = wid < img.total_blocks ? wid : 0u;
+                    const int16_t* w = wide_arena + img.coef_off + (size_t)wid * 64 + r * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (cv[i] == -128) cv[i] = w[i];
+                }
+                if (r == 0 && blk_ok) cv[0] = dc_now; // the DC lives in its own 16-bit array
             }
-            if (r == 0 && blk_ok) cv[0] = dc_now; // the DC lives in its own 16-bit array
-        }
-        {   // the exact lane arithmetic (idct_cols_exact). The SIMD routine's shortcut tests ROWS 1-7 of the block: the eight lanes vote
-            bool lane_ac = false;
+            auto pk = [](int32_t lo, int32_t hi) { return idct_pair(((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16)); };
+            p04 = pk(cv[0], cv[4]) * idct_pair(q04);   // v_pk_mul_lo_u16 = pmullw
+            p26 = pk(cv[2], cv[6]) * idct_pair(q26);
+            p71 = pk(cv[7], cv[1]) * idct_pair(q71);
+            p35 = pk(cv[3], cv[5]) * idct_pair(q35);
+            lane_rows17 = false;
 #pragma unroll
-            for (int i = 1; i < 8; i++) lane_ac = lane_ac || cv[i] != 0;
-            const uint64_t ac_mask = __builtin_amdgcn_ballot_w64(lane_ac);
-            const bool no_ac = ((ac_mask >> (j * 8u)) & 0xffull) == 0;
-            // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between
-            // the passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every wait
-            idct_cols_exact(cv, qv, no_ac, s_w[wv], j, r);
-            idct_wave_sync();
-            const uint2 px = idct_rows_exact(s_w[wv], j, r);
-            idct_wave_sync();
-            if (blk_ok) *reinterpret_cast<uint2*>(dst) = px;
+            for (int i = 1; i < 8; i++) lane_rows17 = lane_rows17 || cv[i] != 0;
         }
+        // the routine's shortcut tests rows 1-7 of the whole block: the eight lanes of a block vote
+        const uint64_t ac_mask = __builtin_amdgcn_ballot_w64(lane_rows17);
+        const bool rows17_empty = ((ac_mask >> (j * 8u)) & 0xffull) == 0;
+        // the transpose workspace is per wave (s_w[wv]) and a wave's LDS operations execute in order: no workgroup barrier between the
+        // passes -- the first version had three per tile, which kept the four waves of a workgroup in lock step through every load wait
+        idct_cols_pk(p04, p26, p71, p35, rows17_empty, s_w[wv], j, slot);
+        idct_wave_sync();
+        const uint2 px = idct_rows_pk(s_w[wv], j, r);
+        idct_wave_sync();
+        if (blk_ok) *reinterpret_cast<uint2*>(dst) = px;
       }
       if (out) break;
     }
