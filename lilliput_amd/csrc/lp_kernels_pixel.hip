@@ -917,157 +917,146 @@ __global__ __launch_bounds__(256) void k_gif_frame(LpGifFrameOp op)
 
 // ------------------------------------------------------------------------------------------------
 // PNG (n2): reverse the per-row filters of the inflated stream in place (pngrutil.c png_read_filter_row: None, Sub, Up,
-// Average, Paeth on bytes `bpp` apart). A reconstructed byte needs its left neighbour, the byte above and the one above-left,
-// so rows are not independent, but row r may run one pixel behind row r-1: a wave takes 64 consecutive rows, lane = row,
-// and walks them as a skewed diagonal -- lane r works on pixel t - r at step t, gets "above" from lane r-1 by a shuffle of
-// that lane's previous result and remembers last step's "above" as "above-left". Bands of 64 rows follow one another in
-// the same wave (lane 0 reads the row above from memory, written by lane 63 of the previous band). One workgroup per pass.
-struct __attribute__((packed, aligned(1))) PngChunk { uint32_t w[4]; }; // 16 bytes at any address (rows start on odd offsets)
+// Average, Paeth on bytes `bpp` apart). A reconstructed byte needs its left neighbour (a: the byte bpp before it), the byte above (b)
+// and the one above-left (c). Two things follow: the bpp byte positions of a pixel ("channels") never meet -- channel k of a pass is a
+// filtering problem of its own, on the bytes k, k + bpp, k + 2 bpp ... of every row -- and inside a channel the finest schedule is ONE
+// DIAGONAL over all rows: row r may run exactly one byte behind row r-1. Round 5 runs that schedule:
+//   * one wave per (channel, band of 64 rows), lane = row; at step s lane r reconstructs byte s - r of its row and channel. "Above"
+//     is what lane r-1 produced in the step before -- one DPP wave shift, no LDS, no memory -- and "above-left" is the "above" of the
+//     step before. Every step is the same short instruction sequence for every lane (the load of the byte PNG_AHEAD steps ahead into a
+//     register ring, ~20 VALU operations of filter arithmetic, one store), so nothing waits on memory inside the dependency chain.
+//     The channels of a band run on bpp different CUs at once (they share cache lines but no byte).
+//   * a pass of more than 64 rows is a pipeline of bands: band t + 1 starts when the last row of band t has its first bytes. That row
+//     travels through a MAILBOX, one 32-bit word per byte: {tag = t + 1 : 24, the byte : 8}, written and read with relaxed agent-scope
+//     atomics. Data and flag are the same word, so no fence, no L2 write-back and no ordering between two stores is involved. The
+//     band below fetches the words sixteen at a time (lanes 0-15, PNG_AHEAD steps before they are due), checks the tags when lane 0
+//     reaches the block and re-reads what is not there yet. One mailbox per pass and channel serves every band boundary: band t + 1
+//     reads word p (at its step p) before its own last row overwrites it with tag t + 2 (at step p + 63).
+//   * forward progress: a band waits for the band above only, and bands are numbered by a ticket in the order their workgroups START
+//     (not by blockIdx): the workgroup that holds ticket t - 1 is running when ticket t is drawn, whatever else occupies the device.
+//     A wait that does not end (it cannot, short of a lost device) gives up after PNG_SPIN_MAX polls and fails the image.
+// The filter arithmetic per byte: three v_sad_u16, the Paeth choice as ONE v_min3 over keys (distance << 10 | priority << 8 | value),
+// the None / Sub / Up / Average predictor from per-row weights. BASELINE configs[2]'s 800 x 297 RGB image is 15 waves and 800 + 297 + 4
+// band hand-overs steps. Round 4's kernel walked the diagonal in 16-byte chunks (16 bytes of serial arithmetic per step, all channels
+// in one lane, bands handing rows over through memory behind agent-scope fences): ~880 us for that image.
+#define PNG_AHEAD 32            // steps between the load of a byte and its use (the register ring)
+#define PNG_MB 16               // bytes of the row above a band that the band below fetches at a time
+#define PNG_SPIN_MAX (1u << 22)
+// every pointer of the band loop is a GLOBAL pointer (address space 1), not a generic one: the accesses are then counted by vmcnt alone
+// and the compiler can wait for a load of the ring without draining the queue (flat accesses force vmcnt(0) lgkmcnt(0))
+#define PNG_G __attribute__((address_space(1)))
 
-__device__ __forceinline__ uint32_t png_byte(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 255u; }
-
-// The filters work on bytes BPP apart, so a row can be cut into 16-byte chunks regardless of the pixel size: a lane keeps its
-// previous output chunk (left neighbours) and the previous chunk of the row above (above-left), and one step of the diagonal
-// is one chunk: lane r works on chunk t - r, the chunk above arrives from lane r-1 with four shuffles. Loads run one chunk
-// ahead of the arithmetic.
-// Bands of 64 rows are spread over the 16 waves of LP_PNG_WGS workgroups (band b on wave b mod (16 x LP_PNG_WGS) of the pass) and
-// run as ONE diagonal across the whole pass: band b + 1 starts as soon as band b's last row has produced its first chunks. That row's
-// output is read back from memory by lane 0 of the band below; the writer publishes its progress (count of finished chunks, tagged
-// with the band number) every PNG_PUB chunks behind an agent-scope release fence. The only waits in the kernel go from a band to the
-// band ABOVE it; with LP_PNG_WGS = 1 (lp_types.h) that band runs on a wave of the same workgroup, which is resident whenever the waiting
-// wave is; a spin that does not end (it cannot, short of a lost device) gives up after PNG_SPIN_MAX polls and flags the image as
-// failed instead of hanging the queue. A progress slot is reused LP_PNG_SLOTS bands later, more bands than can be in flight at once.
-// Round 2 ran the bands one after the other in a single wave: rows / 64 x (chunks + 63) steps for a pass, ~0.6 - 1 GB/s; one workgroup
-// of sixteen waves pipelined this way reaches 3.5 GB/s (one CU's issue rate), eight of them share the pass.
-#define PNG_WAVES 16
-#define PNG_PUB 4       // the last row of a band publishes every fourth chunk (one fence per four steps)
-#define PNG_SPIN_MAX (1u << 24)
 template <int BPP>
-__device__ void png_unfilter_pass(uint8_t* base, const LpPngPass& ps, uint32_t* error, unsigned long long* prog, uint32_t wgi)
+__device__ void png_unfilter_band(PNG_G uint8_t* base, const LpPngPass& ps, PNG_G uint32_t* error, PNG_G uint32_t* mail, PNG_G uint8_t* dump_base, uint32_t bi, uint32_t ch)
 {
-    const uint32_t lane = threadIdx.x & 63u, wv = wgi * PNG_WAVES + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x;
     const size_t stride = (size_t)ps.row_bytes + 1;
-    const uint32_t nchunk = (ps.row_bytes + 15) / 16;
-    const uint32_t nbands = (ps.ph + 63u) / 64u;
-    for (uint32_t bi = wv; bi < nbands; bi += PNG_WAVES * LP_PNG_WGS) {
-        const uint32_t band = bi * 64u;
-        const uint32_t row = band + lane;
-        const bool live = row < ps.ph;
-        uint8_t* cur = base + ps.off + (size_t)(live ? row : 0) * stride;
-        const uint32_t ft = live ? cur[0] : 0;
-        if (live && ft > 4) atomicOr(error, 1u); // "bad adaptive filter value" (the host has already refused such a file)
-        cur += 1;
-        const uint8_t* up_row = (lane == 0 && row && ft > 1u) ? cur - stride : nullptr; // lane 0's "above" is the last row of the band above (not needed by None / Sub)
-        const uint32_t slot = bi % LP_PNG_SLOTS, pslot = (bi + LP_PNG_SLOTS - 1u) % LP_PNG_SLOTS;
-        const unsigned long long tag = (unsigned long long)(bi + 1u) << 32;
-        uint32_t out[4] = {0, 0, 0, 0}, upp[4] = {0, 0, 0, 0}, nxt[4] = {0, 0, 0, 0}, upn[4] = {0, 0, 0, 0};
-        const uint32_t rows_here = ps.ph - band < 64 ? ps.ph - band : 64;
-        const bool hands_off = bi + 1u < nbands;             // a band below reads this band's last row
-        if (lane == 0) __hip_atomic_store(&prog[slot], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this band: nothing final yet
-        // wave-uniform wait until the band above has `want` chunks of its last row final in memory
-        auto wait_above = [&](uint32_t want) -> uint32_t {
-            uint32_t have = 0;
-            for (uint32_t spin = 0;; spin++) {
-                const unsigned long long v = __hip_atomic_load(&prog[pslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                have = (uint32_t)v;
-                if ((uint32_t)(v >> 32) == bi && have >= want) break; // the band above carries tag (bi - 1) + 1
-                if (spin > PNG_SPIN_MAX) { if (lane == 0) atomicOr(error, 2u); have = 0xffffffffu; break; } // never seen; see the header comment
-                __builtin_amdgcn_s_sleep(4);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            return have;
-        };
-        // A band whose first row is filtered None or Sub does not look at the row above at all: it starts at once, and the diagonal of
-        // dependencies is cut there (adaptive encoders choose those filters for a good share of the rows)
-        const bool chained = bi && (uint32_t)__builtin_amdgcn_readfirstlane((int)ft) > 1u;
-        uint32_t seen = 0; // chunks of the row above known to be final
-        if (chained) seen = wait_above(1u);
-        if (live && lane == 0) { // prime the pipeline of the first row of the band
-            const PngChunk c0 = *reinterpret_cast<const PngChunk*>(cur);
+    const int nunit = (int)(ps.row_bytes / BPP);
+    const uint32_t band = bi * 64u;
+    const uint32_t rows_here = ps.ph - band < 64u ? ps.ph - band : 64u;
+    const bool live = lane < rows_here;
+    PNG_G uint8_t* cur = base + ps.off + (size_t)(band + (live ? lane : 0u)) * stride;
+    const uint32_t ft = live ? cur[0] : 0u;
+    if (live && ft > 4 && ch == 0) __hip_atomic_fetch_or(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // "bad adaptive filter value" (the host has already refused such a file)
+    cur += 1 + ch;
+    PNG_G uint8_t* dump = dump_base + lane;
+    const bool fed = bi > 0;                                     // wave-uniform: lane 0's "above" comes out of the mailbox
+    const bool feeds = band + 64u < ps.ph && lane == 63u;        // this lane's results go into it
+    const uint32_t tag_out = (bi + 1u) << 8;
+    const bool paeth = ft >= 4;
+    const uint32_t wa = (0xAu >> ft) & 1u, wb = (0xCu >> ft) & 1u, sh = ft == 3 ? 1u : 0u; // None 0, Sub a, Up b, Average (a + b) >> 1
+    uint32_t xa = 0, xc = 0, res = 0;
+    auto unit_at = [&](int p) { return p < 0 ? 0 : p >= nunit ? nunit - 1 : p; };
+    // the row above the band, PNG_MB bytes at a time: lanes 0 .. PNG_MB-1 hold the words of a block, lane 0 takes its byte out of them
+    // step by step (v_readlane)
+    uint32_t mcur = 0, mnext[PNG_AHEAD / PNG_MB];
+    auto mail_load = [&](int first, uint32_t& m) {
+        const int u = unit_at(first + (int)lane);
+        if (fed && lane < PNG_MB) m = __hip_atomic_load(&mail[(size_t)u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
 #pragma unroll
-            for (int k = 0; k < 4; k++) nxt[k] = c0.w[k];
-            if (up_row) {
-                const PngChunk u0 = *reinterpret_cast<const PngChunk*>(up_row);
+    for (int j = 0; j < PNG_AHEAD / PNG_MB; j++) { mnext[j] = 0; mail_load(j * PNG_MB, mnext[j]); }
+    uint32_t xr[PNG_AHEAD];
 #pragma unroll
-                for (int k = 0; k < 4; k++) upn[k] = u0.w[k];
-            }
-        }
-        for (uint32_t t = 0; t < nchunk + rows_here - 1; t++) {
-            const int j = (int)t - (int)lane;
-            const bool on = live && j >= 0 && j < (int)nchunk;
-            // lane 0 fetches chunk t + 1 of the row above in this step
-            if (chained && t + 1u < nchunk && seen < t + 2u) seen = wait_above(t + 2u);
-            uint32_t f[4], up[4];
+    for (int k = 0; k < PNG_AHEAD; k++) xr[k] = cur[(size_t)unit_at(k - (int)lane) * BPP];
+    const int nsteps = nunit + (int)rows_here - 1;
+    for (int s0 = 0; s0 < nsteps; s0 += PNG_AHEAD) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t from_above = (uint32_t)__shfl_up((int)out[k], 1, 64); // lane r-1 finished chunk j in the previous step
-                up[k] = lane ? from_above : upn[k];
-                f[k] = nxt[k];
-            }
-            // fetch the chunk of the next step (a lane's first chunk is fetched in the step before it starts)
-            const int jn = j + 1;
-            if (live && jn >= 0 && jn < (int)nchunk) {
-                const PngChunk c = *reinterpret_cast<const PngChunk*>(cur + (size_t)jn * 16);
-#pragma unroll
-                for (int k = 0; k < 4; k++) nxt[k] = c.w[k];
-                if (up_row) {
-                    const PngChunk u = *reinterpret_cast<const PngChunk*>(up_row + (size_t)jn * 16);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) upn[k] = u.w[k];
+        for (int k = 0; k < PNG_AHEAD; k++) {
+            const int p = s0 + k - (int)lane;
+            const bool on = live && p >= 0 && p < nunit;
+            if (k % PNG_MB == 0 && fed) { // lane 0 enters a new block of the row above
+                const int u = s0 + k + (int)lane;
+                mcur = mnext[k / PNG_MB];
+                // The re-read of a word that is not there yet is inline assembly with its own wait: the compiler sees no memory access
+                // in this loop, so its count of the accesses in flight around the loop stays exact (a load inside a loop makes it drain
+                // the queue at the next use of any loaded register)
+                bool gave_up = false;
+                for (uint32_t spin = 0;; spin++) {
+                    const bool late = (mcur >> 8) != bi && lane < PNG_MB && u < nunit; // the band above carries tag (bi - 1) + 1
+                    if (!__builtin_amdgcn_ballot_w64(late)) break;
+                    if (spin > PNG_SPIN_MAX) { gave_up = true; break; } // never seen; see the header comment
+                    __builtin_amdgcn_s_sleep(4);
+                    if (late) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(mcur) : "v"(&mail[(size_t)u]) : "memory");
                 }
+                if (gave_up && lane == 0) __hip_atomic_fetch_or(error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mail_load(s0 + k + PNG_AHEAD, mnext[k / PNG_MB]); // the block PNG_AHEAD steps from here
             }
-            if (on) {
-                uint32_t o[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t a = i >= BPP ? png_byte(o, i - BPP) : png_byte(out, 16 - BPP + i);
-                    const uint32_t b = row ? png_byte(up, i) : 0u;
-                    const uint32_t c = i >= BPP ? png_byte(up, i - BPP) : png_byte(upp, 16 - BPP + i);
-                    const int pa = abs((int)b - (int)c), pb = abs((int)a - (int)c), pc = abs((int)a + (int)b - 2 * (int)c);
-                    const uint32_t paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    const uint32_t pred = ft == 0 ? 0u : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) >> 1 : paeth;
-                    o[i >> 2] |= ((png_byte(f, i) + pred) & 255u) << ((i & 3) * 8);
-                }
-                const uint32_t left = ps.row_bytes - (uint32_t)j * 16;
-                if (left >= 16) {
-                    PngChunk c;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) c.w[k] = o[k];
-                    *reinterpret_cast<PngChunk*>(cur + (size_t)j * 16) = c;
-                } else {
-                    for (uint32_t i = 0; i < left; i++) cur[(size_t)j * 16 + i] = (uint8_t)(o[i >> 2] >> ((i & 3) * 8));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) { out[k] = o[k]; upp[k] = up[k]; }
-            }
-            // the band's last row tells the band below how far it is: every PNG_PUB chunks and at the end of the row
-            if (hands_off) {
-                const int jl = (int)t - (int)(rows_here - 1u); // chunk the last row finished in this step (wave-uniform)
-                if (jl >= 0 && jl < (int)nchunk && (((uint32_t)jl % PNG_PUB) == PNG_PUB - 1u || jl == (int)nchunk - 1)) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // its stores first
-                    if (lane == rows_here - 1u) __hip_atomic_store(&prog[slot], tag | (uint32_t)(jl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            // what the row above produced one step ago: the lane above, or (lane 0 of a band below another) the mailbox
+            const uint32_t top = fed ? (uint32_t)__builtin_amdgcn_readlane((int)mcur, k % PNG_MB) & 255u : 0u;
+            const uint32_t xb = (uint32_t)__builtin_amdgcn_update_dpp((int)top, (int)res, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const uint32_t x = xr[k];
+            xr[k] = cur[(size_t)unit_at(p + PNG_AHEAD) * BPP]; // the byte PNG_AHEAD steps from here
+            // The arithmetic runs on every lane in every step. A lane that has not reached its row yet must keep a = c = result = 0: its
+            // result is masked (and with it everything derived from it); a lane past its row computes what nobody reads. The store of a
+            // lane outside its row goes to a dump slot instead of sitting in a branch: the compiler then counts it among the accesses
+            // in flight
+            const uint32_t pa = __builtin_amdgcn_sad_u16(xb, xc, 0u), pb = __builtin_amdgcn_sad_u16(xa, xc, 0u), pc = __builtin_amdgcn_sad_u16(xa + xb, xc << 1, 0u);
+            // a unless b or c is strictly nearer, b unless c is strictly nearer: the smallest of (distance, priority) keys
+            const uint32_t ka = (pa << 10) | xa, kb = (pb << 10) | 256u | xb, kc = (pc << 10) | 512u | xc;
+            const uint32_t best = min(ka, min(kb, kc));
+            const uint32_t lin = (__umul24(xa, wa) + __umul24(xb, wb)) >> sh;
+            const uint32_t r = (x + (paeth ? best : lin)) & (p >= 0 ? 255u : 0u); // the key's upper bits fall to the mask
+            *(on ? cur + (size_t)p * BPP : dump) = (uint8_t)r;
+            xa = r;
+            xc = xb;
+            res = r;
+            if (feeds && on) __hip_atomic_store(&mail[(size_t)p], tag_out | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_unfilter(LpPngOp op)
+__global__ __launch_bounds__(64) void k_png_unfilter(LpPngOp op)
 {
-    const uint32_t pass = blockIdx.x / LP_PNG_WGS, wgi = blockIdx.x % LP_PNG_WGS;
+    // workgroup -> pass (a pass owns bands x channels workgroups), channel, then a ticket -> band
+    uint32_t wg = blockIdx.x, pass = 0;
+    size_t mail_words = 0;
+    for (; pass < op.npass; pass++) {
+        const LpPngPass& q = op.pass[pass];
+        const uint32_t nb = lp_png_bands(q) * op.bpp;
+        if (wg < nb) break;
+        wg -= nb;
+        mail_words += lp_png_bands(q) ? q.row_bytes : 0u;
+    }
+    if (pass >= op.npass) return;
     const LpPngPass& ps = op.pass[pass];
-    if (!ps.pw || !ps.ph) return;
-    if (wgi * PNG_WAVES * 64u >= ps.ph) return; // no band for this workgroup
-    uint8_t* base = reinterpret_cast<uint8_t*>(op.data_off);
-    uint32_t* err = reinterpret_cast<uint32_t*>(op.error_off);
-    unsigned long long* prog = reinterpret_cast<unsigned long long*>(op.sync_off) + (size_t)pass * LP_PNG_SLOTS;
+    const uint32_t ch = wg % op.bpp; // neighbouring workgroups take different channels of the same bands
+    PNG_G uint32_t* tickets = (PNG_G uint32_t*)(uintptr_t)op.sync_off;
+    uint32_t bi = 0;
+    if (threadIdx.x == 0) bi = __hip_atomic_fetch_add(&tickets[pass * 8u + ch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi);
+    PNG_G uint8_t* base = (PNG_G uint8_t*)(uintptr_t)op.data_off;
+    PNG_G uint32_t* err = (PNG_G uint32_t*)(uintptr_t)op.error_off;
+    PNG_G uint8_t* dump = (PNG_G uint8_t*)(uintptr_t)(op.sync_off + LP_PNG_TICKET_BYTES);
+    // the mailbox of (pass, channel): one word per byte of that channel in a row
+    PNG_G uint32_t* mail = (PNG_G uint32_t*)(uintptr_t)(op.sync_off + LP_PNG_TICKET_BYTES + LP_PNG_DUMP_BYTES) + mail_words + (size_t)ch * (ps.row_bytes / op.bpp);
     switch (op.bpp) {
-    case 1: png_unfilter_pass<1>(base, ps, err, prog, wgi); break;
-    case 2: png_unfilter_pass<2>(base, ps, err, prog, wgi); break;
-    case 3: png_unfilter_pass<3>(base, ps, err, prog, wgi); break;
-    case 4: png_unfilter_pass<4>(base, ps, err, prog, wgi); break;
-    case 6: png_unfilter_pass<6>(base, ps, err, prog, wgi); break;
-    default: png_unfilter_pass<8>(base, ps, err, prog, wgi); break;
+    case 1: png_unfilter_band<1>(base, ps, err, mail, dump, bi, ch); break;
+    case 2: png_unfilter_band<2>(base, ps, err, mail, dump, bi, ch); break;
+    case 3: png_unfilter_band<3>(base, ps, err, mail, dump, bi, ch); break;
+    case 4: png_unfilter_band<4>(base, ps, err, mail, dump, bi, ch); break;
+    case 6: png_unfilter_band<6>(base, ps, err, mail, dump, bi, ch); break;
+    default: png_unfilter_band<8>(base, ps, err, mail, dump, bi, ch); break;
     }
 }
 
@@ -1127,7 +1116,9 @@ __global__ __launch_bounds__(256) void k_png_convert(LpPngOp op)
 void lp_launch_png(hipStream_t s, const LpPngOp& op)
 {
     if (!op.npass) return;
-    hipLaunchKernelGGL(k_png_unfilter, dim3(op.npass * LP_PNG_WGS), dim3(PNG_WAVES * 64), 0, s, op);
+    uint32_t bands = 0;
+    for (uint32_t p = 0; p < op.npass; p++) bands += lp_png_bands(op.pass[p]) * op.bpp;
+    if (bands) hipLaunchKernelGGL(k_png_unfilter, dim3(bands), dim3(64), 0, s, op);
     uint32_t mw = 0, mh = 0;
     for (uint32_t p = 0; p < op.npass; p++) { mw = op.pass[p].pw > mw ? op.pass[p].pw : mw; mh = op.pass[p].ph > mh ? op.pass[p].ph : mh; }
     if (!mw || !mh) return;

@@ -275,16 +275,6 @@ struct LpGifEncOp {
 
 // One PNG image on the device: `data_off` holds the inflated stream (per Adam7 pass, per row: filter byte + packed row);
 // k_png_unfilter reconstructs it in place, k_png_convert expands it to the 8-bit BGR(A) / grey frame OpenCV's PngDecoder yields.
-#ifndef LP_PNG_WGS
-#define LP_PNG_WGS 1            // workgroups of 16 waves that share one Adam7 pass (one band of 64 rows per wave at a time). ONE since round 4: a band
-                                // waits for the band above, and with several workgroups per pass that band may sit in a workgroup of a HIGHER
-                                // index (band 128 on workgroup 0 waits for band 127 on workgroup 7) which a busy device has not dispatched yet --
-                                // forward progress then hangs on co-residency. Inside one workgroup every wave the kernel waits for is resident
-                                // by construction. The pass is one dependency diagonal: about (chunks + 63) / 64 bands are in flight at a time
-                                // (17 for a 4096-pixel RGBA row), which sixteen waves cover; eight workgroups measured the same 3.5 GB/s (r03)
-#endif
-#define LP_PNG_SLOTS (2 * 16 * (LP_PNG_WGS > 2 ? LP_PNG_WGS : 2))  // progress words per pass: more than the bands that can be in flight at once (16 per workgroup)
-#define LP_PNG_SYNC_BYTES (7 * LP_PNG_SLOTS * 8)
 struct LpPngPass {
     uint64_t off;               // byte offset of the pass inside the inflated stream
     uint32_t pw, ph;            // pixels per row / rows of this pass (0 = empty pass, no data)
@@ -297,7 +287,7 @@ struct LpPngOp {
     uint64_t data_off;          // device address of the inflated stream
     uint64_t palette_off;       // device address of 256 x {B, G, R, A} (palette images)
     uint64_t error_off;         // device address of a uint32 flag: set when a row carries a filter type above 4
-    uint64_t sync_off;          // device address of the un-filter kernel's progress words (LP_PNG_SYNC_BYTES, zeroed before the launch)
+    uint64_t sync_off;          // device address of the un-filter kernel's tickets and mailboxes (lp_png_sync_bytes(op), zeroed before the launch)
     LpPngPass pass[7];
     uint32_t npass;
     uint32_t depth, color_type; // as in IHDR
@@ -305,6 +295,22 @@ struct LpPngOp {
     uint32_t has_key;           // RGB / grey colour key from tRNS (only RGB makes a difference: alpha 0 where the pixel equals it)
     uint32_t key[3];            // 16-bit R, G, B
 };
+// k_png_unfilter's scratch (lp_kernels_pixel.hip): a ticket counter per (pass, channel), the dump slots, then per pass one 32-bit
+// mailbox word per byte of a row -- the channel through which the last row of a band of 64 rows reaches the band below.
+#define LP_PNG_TICKET_BYTES 256     // 7 passes x 8 channels x uint32
+#define LP_PNG_DUMP_BYTES 256       // where lanes outside their row send their stores (never read)
+#if defined(__HIP__)
+#define LP_TYPES_HD __host__ __device__
+#else
+#define LP_TYPES_HD
+#endif
+static inline LP_TYPES_HD uint32_t lp_png_bands(const LpPngPass& q) { return (q.pw && q.ph) ? (q.ph + 63u) / 64u : 0u; }
+static inline size_t lp_png_sync_bytes(const LpPngOp& op)
+{
+    size_t words = 0;
+    for (uint32_t p = 0; p < op.npass; p++) words += lp_png_bands(op.pass[p]) ? op.pass[p].row_bytes : 0u;
+    return LP_PNG_TICKET_BYTES + LP_PNG_DUMP_BYTES + words * 4;
+}
 
 // PNG output (cv::PngEncoder::write over libpng, opencv.cpp:185-194 with FileType ".png"): every row of the frame becomes a filter
 // byte + the filtered row, RGB(A) byte order. libpng picks a row's filter by trying the enabled ones (NONE, SUB, UP, AVG, PAETH in this

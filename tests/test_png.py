@@ -136,8 +136,9 @@ def test_pixels_match_reference_live_and_thumbhash(hip_lib, oracle):
 @pytest.mark.gpu
 def test_tall_and_long_chained_images_unfilter_like_libpng(hip_lib, oracle):
     """Images whose un-filter is one long dependency chain (every row filtered Up, Average or Paeth: no None / Sub row cuts it) and
-    whose band count exceeds the progress slots of the kernel several times over (20 000 rows = 313 bands of 64): ADVICE r03 -- a
-    band's progress slot is reused LP_PNG_SLOTS bands later and the waits must stay inside one workgroup."""
+    that are hundreds of bands of 64 rows tall (20 000 rows = 313 bands, a workgroup per band and channel): ADVICE r03 -- a band waits
+    for the band above only, bands are numbered by tickets in the order their workgroups start (lp_kernels_pixel.hip k_png_unfilter), and
+    one mailbox per pass and channel is reused by every band boundary."""
     import struct
     import zlib
 
