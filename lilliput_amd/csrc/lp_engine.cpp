@@ -1557,10 +1557,10 @@ int LpEngine::png_decode(LpPngOp op, const uint8_t* filtered, size_t n, const ui
 {
     if (!ok_) return LP_ERR_DEVICE;
     if (!check(hipSetDevice(device_), "hipSetDevice")) return LP_ERR_DEVICE;
-    const size_t pal_off = (n + 255) & ~(size_t)255;
+    const size_t pal_off = (n + LP_PNG_MARGIN + 255) & ~(size_t)255;
     const size_t sync_b = lp_png_sync_bytes(op);
-    if (!d_planes_.ensure(pal_off + 1024 + 256 + sync_b)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
-    uint8_t* base = d_planes_.as<uint8_t>();
+    if (!d_planes_.ensure(LP_PNG_MARGIN + pal_off + 1024 + 256 + sync_b)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
+    uint8_t* base = d_planes_.as<uint8_t>() + LP_PNG_MARGIN; // the stream, with LP_PNG_MARGIN readable bytes before it and (up to the palette) behind it
     if (n && !h2d_any(base, filtered, n)) return LP_ERR_DEVICE;
     if (!h2d_any(base + pal_off, palette_bgra, 1024)) return LP_ERR_DEVICE;
     if (!check(hipMemsetAsync(base + pal_off + 1024, 0, 256 + sync_b, stream_), "memset png flag")) return LP_ERR_DEVICE; // the error flag, the un-filter kernel's tickets and its mailboxes (no stale tag may match)

@@ -8,6 +8,7 @@
 // Byte/integer work, HBM-bound: no MFMA. Float taps use explicit non-fused mul/add to follow OpenCV's
 // accumulation order.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <stdint.h>
 
@@ -939,12 +940,14 @@ __global__ __launch_bounds__(256) void k_gif_frame(LpGifFrameOp op)
 // the None / Sub / Up / Average predictor from per-row weights. BASELINE configs[2]'s 800 x 297 RGB image is 15 waves and 800 + 297 + 4
 // band hand-overs steps. Round 4's kernel walked the diagonal in 16-byte chunks (16 bytes of serial arithmetic per step, all channels
 // in one lane, bands handing rows over through memory behind agent-scope fences): ~880 us for that image.
-#define PNG_AHEAD 32            // steps between the load of a byte and its use (the register ring)
-#define PNG_MB 16               // bytes of the row above a band that the band below fetches at a time
+#define PNG_IT 16               // steps of one loop iteration: the unit in which a lane's input and the row above a band are fetched
 #define PNG_SPIN_MAX (1u << 22)
 // every pointer of the band loop is a GLOBAL pointer (address space 1), not a generic one: the accesses are then counted by vmcnt alone
 // and the compiler can wait for a load of the ring without draining the queue (flat accesses force vmcnt(0) lgkmcnt(0))
 #define PNG_G __attribute__((address_space(1)))
+
+typedef uint32_t png_u32x4 __attribute__((ext_vector_type(4)));
+typedef png_u32x4 png_u32x4_any __attribute__((aligned(1))); // 16 bytes at any address (rows start on odd offsets)
 
 template <int BPP>
 __device__ void png_unfilter_band(PNG_G uint8_t* base, const LpPngPass& ps, PNG_G uint32_t* error, PNG_G uint32_t* mail, PNG_G uint8_t* dump_base, uint32_t bi, uint32_t ch)
@@ -966,51 +969,72 @@ __device__ void png_unfilter_band(PNG_G uint8_t* base, const LpPngPass& ps, PNG_
     const bool paeth = ft >= 4;
     const uint32_t wa = (0xAu >> ft) & 1u, wb = (0xCu >> ft) & 1u, sh = ft == 3 ? 1u : 0u; // None 0, Sub a, Up b, Average (a + b) >> 1
     uint32_t xa = 0, xc = 0, res = 0;
-    auto unit_at = [&](int p) { return p < 0 ? 0 : p >= nunit ? nunit - 1 : p; };
-    // the row above the band, PNG_MB bytes at a time: lanes 0 .. PNG_MB-1 hold the words of a block, lane 0 takes its byte out of them
-    // step by step (v_readlane)
-    uint32_t mcur = 0, mnext[PNG_AHEAD / PNG_MB];
-    auto mail_load = [&](int first, uint32_t& m) {
-        const int u = unit_at(first + (int)lane);
-        if (fed && lane < PNG_MB) m = __hip_atomic_load(&mail[(size_t)u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A lane's input arrives PNG_IT steps at a time: the PNG_IT * BPP bytes behind (row, byte s0 - lane) -- this channel's byte of the
+    // next PNG_IT steps at every BPP-th position -- as BPP 16-byte loads, asked for one iteration before they are used. (64 lanes on 64
+    // rows are 64 cache lines an access whatever its width: a byte a step costs the memory pipeline as much as 16 bytes every 16 steps.)
+    // Lanes that are before or behind their row read what lies there -- other rows, or the margins LpEngine::png_decode keeps around
+    // the stream (LP_PNG_MARGIN) -- and never use it.
+    //
+    // These loads and the one of the mailbox block are inline assembly with a hand-placed wait. The compiler's own bookkeeping counts
+    // loads across the loop's back edge but not stores, so for a register loaded one iteration ago it waits until all but the last
+    // few accesses have completed -- that is: for the byte stores of the last steps, ~1 us every iteration (SQ_WAIT_ANY was 53 % of the
+    // waves' cycles). What is certain here: after these loads every step issues its store (PNG_IT of them, the dump-slot trick below
+    // makes them unconditional), accesses complete in order, so "at most PNG_IT outstanding" means the loads have landed.
+    png_u32x4 xn[BPP];
+    uint32_t xw[4 * BPP];
+    uint32_t mcur = 0, mnext = 0;
+    auto load_window = [&](int s0) {
+        const PNG_G uint8_t* w = cur + (ptrdiff_t)(s0 - (int)lane) * BPP;
+#pragma unroll
+        for (int i = 0; i < BPP; i++) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(xn[i]) : "v"(w), "n"(16 * i) : "memory");
+        // the row above the band, PNG_IT bytes at a time: lanes 0 .. PNG_IT-1 hold the words of a block, lane 0 takes its byte out of
+        // them step by step (v_readlane)
+        const int u = s0 + (int)lane;
+        if (fed && lane < PNG_IT && u < nunit) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(mnext) : "v"(&mail[(size_t)u]) : "memory");
     };
+    auto loads_landed = [&](auto outstanding) { // outstanding: an integral constant
 #pragma unroll
-    for (int j = 0; j < PNG_AHEAD / PNG_MB; j++) { mnext[j] = 0; mail_load(j * PNG_MB, mnext[j]); }
-    uint32_t xr[PNG_AHEAD];
+        for (int i = 0; i < BPP; i++) asm volatile("" : "+v"(xn[i]));
+        if (BPP == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xn[0]), "+v"(mnext) : "n"(decltype(outstanding)::value) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(xn[0]), "+v"(xn[BPP - 1]), "+v"(mnext) : "n"(decltype(outstanding)::value) : "memory");
 #pragma unroll
-    for (int k = 0; k < PNG_AHEAD; k++) xr[k] = cur[(size_t)unit_at(k - (int)lane) * BPP];
+        for (int i = 0; i < BPP; i++) asm volatile("" : "+v"(xn[i]));
+    };
+    load_window(0);
+    loads_landed(std::integral_constant<int, 0>());
     const int nsteps = nunit + (int)rows_here - 1;
-    for (int s0 = 0; s0 < nsteps; s0 += PNG_AHEAD) {
+    for (int s0 = 0; s0 < nsteps; s0 += PNG_IT) {
+        if (s0) loads_landed(std::integral_constant<int, PNG_IT>());
 #pragma unroll
-        for (int k = 0; k < PNG_AHEAD; k++) {
+        for (int i = 0; i < BPP; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) xw[4 * i + j] = xn[i][j];
+        }
+        mcur = mnext;
+        load_window(s0 + PNG_IT);
+        if (fed) { // lane 0 enters a new block of the row above: every word of it must carry the tag of the band above, (bi - 1) + 1
+            const int u = s0 + (int)lane;
+            bool gave_up = false;
+            for (uint32_t spin = 0;; spin++) {
+                const bool late = (mcur >> 8) != bi && lane < PNG_IT && u < nunit;
+                if (!__builtin_amdgcn_ballot_w64(late)) break;
+                if (spin > PNG_SPIN_MAX) { gave_up = true; break; } // never seen; see the header comment
+                __builtin_amdgcn_s_sleep(4);
+                if (late) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(mcur) : "v"(&mail[(size_t)u]) : "memory");
+            }
+            if (gave_up && lane == 0) __hip_atomic_fetch_or(error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < PNG_IT; k++) {
             const int p = s0 + k - (int)lane;
             const bool on = live && p >= 0 && p < nunit;
-            if (k % PNG_MB == 0 && fed) { // lane 0 enters a new block of the row above
-                const int u = s0 + k + (int)lane;
-                mcur = mnext[k / PNG_MB];
-                // The re-read of a word that is not there yet is inline assembly with its own wait: the compiler sees no memory access
-                // in this loop, so its count of the accesses in flight around the loop stays exact (a load inside a loop makes it drain
-                // the queue at the next use of any loaded register)
-                bool gave_up = false;
-                for (uint32_t spin = 0;; spin++) {
-                    const bool late = (mcur >> 8) != bi && lane < PNG_MB && u < nunit; // the band above carries tag (bi - 1) + 1
-                    if (!__builtin_amdgcn_ballot_w64(late)) break;
-                    if (spin > PNG_SPIN_MAX) { gave_up = true; break; } // never seen; see the header comment
-                    __builtin_amdgcn_s_sleep(4);
-                    if (late) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(mcur) : "v"(&mail[(size_t)u]) : "memory");
-                }
-                if (gave_up && lane == 0) __hip_atomic_fetch_or(error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mail_load(s0 + k + PNG_AHEAD, mnext[k / PNG_MB]); // the block PNG_AHEAD steps from here
-            }
             // what the row above produced one step ago: the lane above, or (lane 0 of a band below another) the mailbox
-            const uint32_t top = fed ? (uint32_t)__builtin_amdgcn_readlane((int)mcur, k % PNG_MB) & 255u : 0u;
+            const uint32_t top = fed ? (uint32_t)__builtin_amdgcn_readlane((int)mcur, k) & 255u : 0u;
             const uint32_t xb = (uint32_t)__builtin_amdgcn_update_dpp((int)top, (int)res, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const uint32_t x = xr[k];
-            xr[k] = cur[(size_t)unit_at(p + PNG_AHEAD) * BPP]; // the byte PNG_AHEAD steps from here
+            const uint32_t x = (xw[(k * BPP) >> 2] >> (((k * BPP) & 3) * 8)) & 255u;
             // The arithmetic runs on every lane in every step. A lane that has not reached its row yet must keep a = c = result = 0: its
             // result is masked (and with it everything derived from it); a lane past its row computes what nobody reads. The store of a
-            // lane outside its row goes to a dump slot instead of sitting in a branch: the compiler then counts it among the accesses
-            // in flight
+            // lane outside its row goes to a dump slot instead of sitting in a branch
             const uint32_t pa = __builtin_amdgcn_sad_u16(xb, xc, 0u), pb = __builtin_amdgcn_sad_u16(xa, xc, 0u), pc = __builtin_amdgcn_sad_u16(xa + xb, xc << 1, 0u);
             // a unless b or c is strictly nearer, b unless c is strictly nearer: the smallest of (distance, priority) keys
             const uint32_t ka = (pa << 10) | xa, kb = (pb << 10) | 256u | xb, kc = (pc << 10) | 512u | xc;

@@ -299,6 +299,8 @@ struct LpPngOp {
 // mailbox word per byte of a row -- the channel through which the last row of a band of 64 rows reaches the band below.
 #define LP_PNG_TICKET_BYTES 256     // 7 passes x 8 channels x uint32
 #define LP_PNG_DUMP_BYTES 256       // where lanes outside their row send their stores (never read)
+#define LP_PNG_MARGIN 1024          // bytes the device keeps readable before and behind the inflated stream: lanes of the un-filter kernel that are
+                                    // not inside their row yet (or any more) fetch up to 63 + 32 filter units beside it, and use none of it
 #if defined(__HIP__)
 #define LP_TYPES_HD __host__ __device__
 #else

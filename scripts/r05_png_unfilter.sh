@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05: k_png_unfilter (unit-granular diagonal, mailbox hand-over) -- PNG parity tests + configs[2] at 16 callers + kernel trace
+# r05: k_png_unfilter (byte-granular diagonal per channel, mailbox hand-over between bands) -- PNG parity tests, configs[2] at 16 callers, kernel trace
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/png_ab; rm -rf $O; mkdir -p $O
