@@ -36,12 +36,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_sources(batch, distinct, size, rank, world):
+def make_sources(batch, distinct, size, rank, world, quality=90, sampling="420"):
     """`distinct` different synthetic JPEGs (seeds 0..distinct-1) tiled to `batch` items. Rank 0 of the node
     generates them once into a cache directory; the other ranks read them."""
     from lilliput_amd import synth
 
-    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_bench_%d_q90" % size)
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_bench_%d_q%d%s" % (size, quality, "" if sampling == "420" else "_" + sampling))
     os.makedirs(cache, exist_ok=True)
     paths = [os.path.join(cache, "synth_%04d.jpg" % i) for i in range(distinct)]
     if rank == 0:
@@ -54,7 +54,7 @@ def make_sources(batch, distinct, size, rank, world):
             cpus = (os.cpu_count() or 2) - 1 if quota is None else max(1, int(2 * quota))
             workers = max(1, min(len(missing), cpus, 96))  # ~0.7 GB of numpy temporaries per worker
             with mp.get_context("fork").Pool(workers) as pool:
-                for i, data in zip(missing, pool.imap(synth._job, [(i, size, 90) for i in missing], chunksize=1)):
+                for i, data in zip(missing, pool.imap(synth._job, [(i, size, quality, 0, None, None, {"420": 2, "422": 1, "444": 0}[sampling]) for i in missing], chunksize=1)):
                     with open(paths[i] + ".tmp", "wb") as f:
                         f.write(data)
                     os.replace(paths[i] + ".tmp", paths[i])
@@ -258,7 +258,7 @@ def main_abi(args, ranks, la):
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     ndev = max(1, la.lib().lilliput_hip_device_count())
     os.environ.setdefault("LILLIPUT_HIP_DEVICE", str(local_rank % ndev))
-    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world, args.source_quality, args.source_sampling)
     ranks.barrier()
     distinct = [np.frombuffer(open(p, "rb").read(), dtype=np.uint8) for p in paths]
     threads = [int(t) for t in str(args.threads or "64").split(",") if t]
@@ -312,9 +312,9 @@ def main_abi(args, ranks, la):
         out = {"metric": "images/sec (%dx%d->%dx%d JPEG q85, ImageOps.Transform through the one-image C ABI under concurrent callers, Part %s)" % (args.size, args.size, args.out, args.out, args.part),
                "value": round(best_v, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1000.0 * best_elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "the drop-in path: %d requests per GPU and step on the BASELINE configs[1] sources (%d distinct %dx%d 4:2:0 q90 JPEGs in pageable host memory), each "
+               "config": {"workload": "the drop-in path: %d requests per GPU and step on the BASELINE configs[1] sources (%d distinct %dx%d 4:2:0 q%d JPEGs in pageable host memory), each "
                                       "NewDecoder -> Header -> ImageOps.Transform(Fit %dx%d, q85) -> Close on the calling thread's own ImageOps, `threads` OS threads at once "
-                                      "(lp_service_sim.c, plain C against include/lilliput_hip.h); value = the best of the thread counts" % (args.batch, len(distinct), args.size, args.size, args.out, args.out),
+                                      "(lp_service_sim.c, plain C against include/lilliput_hip.h); value = the best of the thread counts" % (args.batch, len(distinct), args.size, args.size, args.source_quality, args.out, args.out),
                           "part": "A: the opencv_* calls of unchanged ops.go / opencv.go, in their order (lp_service_sim.c one_request_part_a)" if args.part == "A" else "C: lilliput_image_ops_transform (the Go API mirrored in C)",
                           "deferred_part_a": {"LILLIPUT_HIP_DEFER": os.environ.get("LILLIPUT_HIP_DEFER", "default (on)"), "chains_recorded": int(dstat[0]), "served_by_the_batched_path": int(dstat[1]),
                                               "run_the_eager_way": int(dstat[2]), "sources_copied_at_decoder_release": int(dstat[3])},
@@ -334,7 +334,7 @@ def main_abi(args, ranks, la):
         else:
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline([bytes(d) for d in distinct[: min(32, len(distinct))]], args.out, args.out, 85, what="%dx%d q90 -> %dx%d q85" % (args.size, args.size, args.out, args.out))
+            out["cpu_baseline"] = cpu_baseline([bytes(d) for d in distinct[: min(32, len(distinct))]], args.out, args.out, 85, what="%dx%d q%d -> %dx%d q85" % (args.size, args.size, args.source_quality, args.out, args.out))
         print(json.dumps(out), flush=True)
     ranks.close()
     if any(g[0] for g in gate):
@@ -829,7 +829,7 @@ def main_node(args, alias):
     n_dev = len(devices)
     if args.ingest in ("staged", "register"):
         os.environ["LILLIPUT_HIP_INGEST"] = args.ingest
-    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, 0, 1)
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, 0, 1, args.source_quality, args.source_sampling)
     distinct = [open(p, "rb").read() for p in paths]
     if args.orientation != 1:
         tiff = b"II*\x00\x08\x00\x00\x00" + b"\x01\x00" + b"\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([args.orientation, 0, 0, 0]) + b"\x00\x00\x00\x00"
@@ -901,9 +901,9 @@ def main_node(args, alias):
         "metric": "images/sec (%dx%d->%dx%d JPEG q85)" % (args.size, args.size, args.out, args.out),
         "value": round(value, 2), "unit": "images/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU (%d per step) -> %dx%d JPEG q85, ImageOpsFit (%s); sources in %s" % (
-                       args.batch, args.size, args.size, n_items, args.out, args.out,
-                       "BASELINE configs[1]" if (args.size, args.out, args.orientation) == (4096, 256, 1) else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d" % (args.size, args.out, args.orientation),
+        "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU (%d per step) -> %dx%d JPEG q85, ImageOpsFit (%s); sources in %s" % (
+                       args.batch, args.size, args.size, args.source_quality, n_items, args.out, args.out,
+                       "BASELINE configs[1]" if (args.size, args.out, args.orientation, args.source_quality, args.source_sampling) == (4096, 256, 1, 90, "420") else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d --source-quality %d --source-sampling %s" % (args.size, args.out, args.orientation, args.source_quality, args.source_sampling),
                        "one lilliput_hip_host_alloc pinned arena per device, on that device's NUMA node (zero-copy ingest)" if args.ingest == "pinned" else "host memory, ingest mode %s" % args.ingest),
                    "timed_region": "host bytes in -> host bytes out: header walk + staging + H2D + decode/resample/encode + D2H (lilliput_hip_node_transform, one call per step for all devices)",
                    "parallelism": "ONE process, %d device slots %r, one chunk queue in host memory: device k claims from the k-th share of the chunk list first and steals from the fullest "
@@ -922,7 +922,7 @@ def main_node(args, alias):
     }
     if not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q90 -> %dx%d q85" % (args.size, args.size, args.out, args.out))
+            out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q%d -> %dx%d q85" % (args.size, args.size, args.source_quality, args.out, args.out))
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
@@ -942,6 +942,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct synthetic source images (seed = index), tiled to the batch when fewer")
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--source-sampling", choices=["420", "422", "444"], default="420", help="chroma sampling of the synthetic sources (420 = the BASELINE workload; 422 / 444 run k_resample_hv1)")
+    ap.add_argument("--source-quality", type=int, default=90, help="JPEG quality of the synthetic sources (90 = the BASELINE workload, ~2 bits/pixel; 75 gives ~1 bit/pixel, the density of a camera photograph: the link then carries half the bytes per image and the device kernels, not PCIe, set the rate)")
     ap.add_argument("--orientation", type=int, default=1, choices=range(1, 9), help="EXIF orientation written into the sources (1 = the BASELINE workload; others measure the orientation folded into the resample kernels)")
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device per engine (0 = automatic)")
     ap.add_argument("--sub-bits", type=int, default=0, help="Huffman subsequence size in bits (0 = automatic)")
@@ -1001,7 +1003,7 @@ def main():
     if args.workload in ("png2webp", "animated"):
         return main_formats(args, ranks, la)
 
-    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world)
+    paths = make_sources(args.batch, min(args.distinct, args.batch), args.size, local_rank, world, args.source_quality, args.source_sampling)
     barrier()
     distinct = [open(p, "rb").read() for p in paths]
     if args.orientation != 1:  # an APP1 / EXIF segment with that orientation right after SOI (ops.go:392 applies it unconditionally)
@@ -1125,9 +1127,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q90 baseline JPEGs per GPU -> %dx%d JPEG q85, ImageOpsFit (%s)%s; sources in %s" % (
-                           args.batch, args.size, args.size, args.out, args.out,
-                           "BASELINE configs[1]" if (args.size, args.out, args.orientation) == (4096, 256, 1) else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d" % (args.size, args.out, args.orientation),
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU -> %dx%d JPEG q85, ImageOpsFit (%s)%s; sources in %s" % (
+                           args.batch, args.size, args.size, args.source_quality, args.out, args.out,
+                           "BASELINE configs[1]" if (args.size, args.out, args.orientation, args.source_quality, args.source_sampling) == (4096, 256, 1, 90, "420") else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d --source-quality %d --source-sampling %s" % (args.size, args.out, args.orientation, args.source_quality, args.source_sampling),
                            "" if args.orientation == 1 else ", EXIF orientation %d" % args.orientation,
                            "HBM (resident form)" if args.resident else {"pinned": "a lilliput_hip_host_alloc pinned arena (zero-copy ingest)", "pageable": "pageable host memory (staged ingest)",
                                                                           "register": "pageable host memory, pages registered per call", "staged": "host memory, staged ingest forced"}[args.ingest]),
@@ -1168,7 +1170,7 @@ def main():
                 out["config"]["resident_images_per_s"] = round(resident_ips, 2)
         if not args.no_cpu_baseline:  # rank 0 only, after the timed region (every rank has passed the closing barrier)
             try:
-                out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q90 -> %dx%d q85" % (args.size, args.size, args.out, args.out))
+                out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q%d -> %dx%d q85" % (args.size, args.size, args.source_quality, args.out, args.out))
             except Exception as e:  # the checker is optional for the measurement itself
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
