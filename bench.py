@@ -375,45 +375,6 @@ def stage_profile_roofline(la, run_once, repeats=8):
             "note": "launches of this size (a few hundred KB) are bound by launch latency, not by HBM; the workload itself is bound by the host codecs (inflate / LZW / VP8), see cpu_baseline and DESIGN.md 5"}
 
 
-def cpu_baseline_processes(fn, jobs_per_worker, what):
-    """A CPU baseline for a path that has no C worker loop (the animated sources): forked worker PROCESSES, one per logical CPU and one
-    per physical core, each running `fn()` jobs_per_worker times (no GIL between them; the codecs are the reference's C libraries)."""
-    import multiprocessing as mp
-
-    logical, physical = host_cores()
-    quota = cgroup_cpus()
-    usable = min(float(physical), quota) if quota else float(physical)
-    t0 = time.time()
-    units1 = fn()
-    one = units1 / max(1e-9, time.time() - t0)
-
-    def work(n, q):
-        u = 0
-        for _ in range(n):
-            u += fn()
-        q.put(u)
-
-    runs = {}
-    for th in sorted({max(1, int(quota + 0.5)), physical} if quota else {physical, logical}):
-        q = mp.get_context("fork").Queue()
-        ps = [mp.get_context("fork").Process(target=work, args=(jobs_per_worker, q)) for _ in range(th)]
-        t0 = time.time()
-        for p_ in ps:
-            p_.start()
-        units = sum(q.get() for _ in ps)
-        for p_ in ps:
-            p_.join()
-        dt = time.time() - t0
-        runs[th] = {"units_per_s": round(units / dt, 2), "seconds": round(dt, 2)}
-    best = max(runs, key=lambda t: runs[t]["units_per_s"])
-    return {"value": runs[best]["units_per_s"], "unit": "frames/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
-            "cgroup_cpu_quota": quota, "usable_cpus": usable,
-            "one_core_units_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["units_per_s"] / max(1e-9, usable * one), 3),
-            "runs_by_processes": {str(k): v for k, v in runs.items()},
-            "harness": "forked worker processes (no C worker loop exists for the animated path; fork time is inside the measurement)",
-            "sample": "%d x %s per worker process on %d processes" % (jobs_per_worker, what, best)}
-
-
 def main_formats(args, ranks, la):
     """BASELINE configs[2] (--workload png2webp: testdata/ferry_sunset.png -> 512 x 512 WebP; webp.cpp:707-751) and configs[3]
     (--workload animated: party-discord.gif + big_buck_bunny_720_5s.webp -> 128 x 128 animated WebP; giflib.cpp:349-568, ops.go:552-591)
@@ -531,27 +492,30 @@ def main_formats(args, ranks, la):
                                               "payload itself is written by the host's libwebp (DESIGN.md 4.5)"},
                "roofline": roof}
         if not args.no_cpu_baseline:
-            if args.workload == "png2webp":
-                logical, physical = host_cores()
-                quota = cgroup_cpus()
-                usable = min(float(physical), quota) if quota else float(physical)
-                r1 = O.cpu_path_run(srcs, W, H, threads=1, jobs=16, keep=False, webp_quality=q)
-                one = r1["ok"] / max(1e-9, r1["seconds"])
-                runs = {}
-                for th in sorted({max(1, int(quota + 0.5)), physical} if quota else {physical, logical}):
-                    r = O.cpu_path_run(srcs, W, H, threads=th, jobs=int(max(8 * th, one * 0.7 * min(th, usable) * 4)), keep=False, webp_quality=q)
-                    runs[th] = {"images_per_s": round(r["ok"] / max(1e-9, r["seconds"]), 2), "jobs": r["jobs"], "seconds": round(r["seconds"], 2)}
-                best = max(runs, key=lambda t: runs[t]["images_per_s"])
-                out["cpu_baseline"] = {"value": runs[best]["images_per_s"], "unit": "images/s", "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
-                                       "cgroup_cpu_quota": quota, "usable_cpus": usable,
-                                       "one_core_images_per_s": round(one, 2), "scaling_efficiency": round(runs[best]["images_per_s"] / max(1e-9, usable * one), 3),
-                                       "runs_by_threads": {str(k): v for k, v in runs.items()}, "harness": "oracle/cpu_path.c (pthreads, preallocated buffers per worker)",
-                                       "sample": "%d transforms of ferry_sunset.png -> 297x297 WebP q85 (reference libpng 1.6.47 decode, INTER_AREA restatement, reference libwebp 1.5.0 encode) on %d threads" % (runs[best]["jobs"], best)}
-            else:
-                def one_pass():
-                    return sum(O.transform_animated_to_webp(d, W, H, q)[1] for d in srcs)
-
-                out["cpu_baseline"] = cpu_baseline_processes(one_pass, 4, "both sources -> 128x128 animated WebP (reference giflib / libwebp decode + playback, restated compositing and INTER_AREA, reference WebPAnimEncoder)")
+            # the reference CPU path as a C worker loop (oracle/cpu_path.c: pthreads, preallocated buffers per worker, no Python between the
+            # stages) for both workloads; the animated one counts frames (round 4 timed it from forked Python workers: VERDICT r04)
+            anim = args.workload == "animated"
+            logical, physical = host_cores()
+            quota = cgroup_cpus()
+            usable = min(float(physical), quota) if quota else float(physical)
+            per_req = units_per_req if anim else 1.0
+            r1 = O.cpu_path_run(srcs, W, H, threads=1, jobs=(2 * len(srcs) if anim else 16), keep=False, webp_quality=q, animated=anim)
+            one = (r1["frames"] if anim else r1["ok"]) / max(1e-9, r1["seconds"])
+            runs = {}
+            key = "frames_per_s" if anim else "images_per_s"
+            for th in sorted({max(1, int(quota + 0.5)), physical} if quota else {physical, logical}):
+                jobs_b = int(max(8 * th, one / per_req * 0.7 * min(th, usable) * 4))
+                r = O.cpu_path_run(srcs, W, H, threads=th, jobs=jobs_b, keep=False, webp_quality=q, animated=anim)
+                runs[th] = {key: round((r["frames"] if anim else r["ok"]) / max(1e-9, r["seconds"]), 2), "jobs": r["jobs"], "ok": r["ok"], "seconds": round(r["seconds"], 2)}
+            best = max(runs, key=lambda t: runs[t][key])
+            out["cpu_baseline"] = {"value": runs[best][key], "unit": unit, "cores": best, "kind": "reference", "physical_cores": physical, "logical_cpus": logical,
+                                   "cgroup_cpu_quota": quota, "usable_cpus": usable,
+                                   "one_core_%s" % key: round(one, 2), "scaling_efficiency": round(runs[best][key] / max(1e-9, usable * one), 3),
+                                   "runs_by_threads": {str(k): v for k, v in runs.items()}, "harness": "oracle/cpu_path.c (pthreads, preallocated buffers per worker)",
+                                   "failed_transforms": runs[best]["jobs"] - runs[best]["ok"],
+                                   "sample": ("%d transforms of party-discord.gif + big_buck_bunny_720_5s.webp -> 128x128 animated WebP q75 (reference giflib 5.2.2 + restated compositing / libwebp 1.5.0 "
+                                              "animation decoder, INTER_AREA restatement per frame, the reference's WebPAnimEncoder settings) on %d threads" % (runs[best]["jobs"], best)) if anim else
+                                             "%d transforms of ferry_sunset.png -> 297x297 WebP q85 (reference libpng 1.6.47 decode, INTER_AREA restatement, reference libwebp 1.5.0 encode) on %d threads" % (runs[best]["jobs"], best)}
         print(json.dumps(out), flush=True)
     ranks.close()
     if any(g[0] for g in gate) or any(g[1] != jobs * args.steps for g in gate):

@@ -39,6 +39,13 @@ typedef long (*dec_webp_fn)(const uint8_t*, size_t, int, uint8_t*, size_t, int m
 typedef int (*info_webp_fn)(const uint8_t*, size_t, uint32_t out[8]);
 typedef size_t (*enc_webp_fn)(const uint8_t*, int, int, int, float, const uint8_t*, size_t, uint8_t*, size_t);
 typedef int (*dec_avif_fn)(const uint8_t*, size_t, uint8_t*, size_t, int info[4]);
+/* animated sources (BASELINE configs[3]): the reference's giflib + its restated compositing (ref_gif_driver.c rg_*), libwebp's animation
+ * decoder and the reference's animation writer (ref_webp_driver.c ref_webp_play / ref_webp_encode_anim) */
+typedef void* (*gif_open_fn)(const uint8_t*, size_t, int dims[2]);
+typedef int (*gif_next_fn)(void*, uint8_t* canvas, int meta[11], uint8_t* indices, size_t cap);
+typedef void (*gif_close_fn)(void*);
+typedef int (*webp_play_fn)(const uint8_t*, size_t, uint8_t* out, size_t cap, int* w, int* h, int* timestamps, int max_frames, uint32_t info[2]);
+typedef size_t (*enc_anim_fn)(const uint8_t* frames, int n, int w, int h, int cn, const int* delays, float quality, uint32_t loop_count, uint32_t bgcolor, uint8_t* out, size_t cap);
 
 typedef struct {
     dec_jpeg_fn dec_jpeg;       /* JPEG bytes -> BGR / grey rows */
@@ -51,9 +58,13 @@ typedef struct {
     enc_webp_fn enc_webp;       /* non-NULL: WebP output at webp_quality (webp.cpp:707-751) instead of JPEG */
     float webp_quality;
     dec_avif_fn dec_avif;       /* may be NULL: AVIF items fail (ref_avif_driver.c: the reference's libavif + dav1d, avif.cpp:164-321) */
+    int animated;               /* non-zero: every frame of a GIF / WebP source -> Fit -> the animation writer at webp_quality (lo_path_transform_anim) */
+    gif_open_fn gif_open; gif_next_fn gif_next; gif_close_fn gif_close;
+    webp_play_fn webp_play;
+    enc_anim_fn enc_anim;
 } lo_path_cfg;
 
-typedef struct { uint8_t *frame, *oriented, *thumb; size_t frame_cap, oriented_cap, thumb_cap; } lo_path_scratch;
+typedef struct { uint8_t *frame, *oriented, *thumb; size_t frame_cap, oriented_cap, thumb_cap; int* delays; size_t delays_cap; } lo_path_scratch;
 
 static int need(uint8_t** p, size_t* cap, size_t bytes)
 {
@@ -157,7 +168,76 @@ long lo_path_transform(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t
     return cfg->enc_jpeg ? cfg->enc_jpeg(px, ow, oh, cn, stride, cfg->quality, out, cap) : lo_jpeg_encode(px, ow, oh, cn, stride, cfg->quality, out, cap, NULL);
 }
 
-void lo_path_scratch_free(lo_path_scratch* s) { free(s->frame); free(s->oriented); free(s->thumb); memset(s, 0, sizeof(*s)); }
+/* One ImageOps.Transform of an animated source -> animated WebP (ops.go:352-444 looping over the frames: every composited canvas through
+ * Fit, into the writer with the frame's duration). *frames = frames written. Returns the output length, or a negative code. */
+long lo_path_transform_anim(const lo_path_cfg* cfg, lo_path_scratch* s, const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* frames)
+{
+    *frames = 0;
+    if (!cfg->enc_anim) return -2;
+    int w = 0, h = 0, nf = 0;
+    uint32_t loop_bg[2] = {0, 0xFFFFFFFFu};
+    int ow = 0, oh = 0, left = 0, top = 0, wpc = 0, hpc = 0;
+    if (n >= 6 && !memcmp(d, "GIF", 3)) {
+        if (!cfg->gif_open || !cfg->gif_next || !cfg->gif_close) return -2;
+        int dims[2];
+        void* g = cfg->gif_open(d, n, dims);
+        if (!g) return -2;
+        w = dims[0]; h = dims[1];
+        if (need(&s->frame, &s->frame_cap, (size_t)w * h * 4)) { cfg->gif_close(g); return -4; }
+        memset(s->frame, 0, (size_t)w * h * 4); /* the Go Framebuffer starts cleared */
+        expected_size(w, h, cfg->width, cfg->height, &ow, &oh);
+        fit_crop(w, h, ow, oh, &left, &top, &wpc, &hpc);
+        for (;;) {
+            int meta[11];
+            const int st = cfg->gif_next(g, s->frame, meta, NULL, 0);
+            if (st == 1) break;                                   /* end of file */
+            if (st) { cfg->gif_close(g); return -2; }
+            const size_t fb = (size_t)ow * oh * 4;
+            if ((size_t)(nf + 1) * fb > s->thumb_cap) { /* grow, keeping the frames so far */
+                const size_t want = ((size_t)(nf + 1) * fb) * 2;
+                uint8_t* p = (uint8_t*)realloc(s->thumb, want + 64);
+                if (!p) { cfg->gif_close(g); return -4; }
+                s->thumb = p; s->thumb_cap = want;
+            }
+            if ((size_t)(nf + 1) * sizeof(int) > s->delays_cap) {
+                const size_t want = (size_t)(nf + 64) * 2 * sizeof(int);
+                int* p = (int*)realloc(s->delays, want);
+                if (!p) { cfg->gif_close(g); return -4; }
+                s->delays = p; s->delays_cap = want;
+            }
+            lo_resize_area(s->frame + (size_t)top * w * 4 + (size_t)left * 4, wpc, hpc, (size_t)w * 4, 4, s->thumb + (size_t)nf * fb, ow, oh, (size_t)ow * 4);
+            s->delays[nf] = meta[6] > 0 ? meta[6] * 10 : 0;      /* GIF delays are hundredths of a second */
+            nf++;
+        }
+        cfg->gif_close(g);
+    } else if (n >= 12 && !memcmp(d, "RIFF", 4) && !memcmp(d + 8, "WEBP", 4)) {
+        uint32_t inf[8];
+        if (!cfg->webp_play || !cfg->info_webp || cfg->info_webp(d, n, inf) != 1) return -2;
+        const int maxf = (int)inf[3];
+        if (need(&s->frame, &s->frame_cap, (size_t)inf[0] * inf[1] * 4 * (size_t)maxf + 16)) return -4;
+        if ((size_t)(maxf + 1) * sizeof(int) > s->delays_cap) {
+            int* p = (int*)realloc(s->delays, (size_t)(maxf + 1) * 2 * sizeof(int));
+            if (!p) return -4;
+            s->delays = p; s->delays_cap = (size_t)(maxf + 1) * 2 * sizeof(int);
+        }
+        nf = cfg->webp_play(d, n, s->frame, s->frame_cap, &w, &h, s->delays, maxf, loop_bg);
+        if (nf <= 0) return -2;
+        for (int i = nf - 1; i > 0; i--) s->delays[i] -= s->delays[i - 1]; /* end timestamps -> durations */
+        expected_size(w, h, cfg->width, cfg->height, &ow, &oh);
+        fit_crop(w, h, ow, oh, &left, &top, &wpc, &hpc);
+        const size_t fb = (size_t)ow * oh * 4;
+        if (need(&s->thumb, &s->thumb_cap, (size_t)nf * fb)) return -4;
+        for (int i = 0; i < nf; i++)
+            lo_resize_area(s->frame + (size_t)i * w * h * 4 + (size_t)top * w * 4 + (size_t)left * 4, wpc, hpc, (size_t)w * 4, 4, s->thumb + (size_t)i * fb, ow, oh, (size_t)ow * 4);
+    } else
+        return -2;
+    if (!nf) return -2;
+    const size_t n2 = cfg->enc_anim(s->thumb, nf, ow, oh, 4, s->delays, cfg->webp_quality, loop_bg[0], loop_bg[1], out, cap);
+    *frames = nf;
+    return n2 ? (long)n2 : -6;
+}
+
+void lo_path_scratch_free(lo_path_scratch* s) { free(s->frame); free(s->oriented); free(s->thumb); free(s->delays); memset(s, 0, sizeof(*s)); }
 
 typedef struct {
     const lo_path_cfg* cfg;
@@ -165,7 +245,7 @@ typedef struct {
     const size_t* lens;
     int nsrc;
     long jobs;
-    atomic_long next, ok, failed;
+    atomic_long next, ok, failed, frames;
     pthread_barrier_t start;
     /* the output of the first job on every distinct source, for the caller to compare with the Python-level oracle */
     uint8_t* keep; size_t keep_cap; long* keep_len;
@@ -179,14 +259,17 @@ static void* worker(void* arg)
     const size_t cap = 8u << 20;
     uint8_t* out = (uint8_t*)malloc(cap);
     /* one untimed transform: the worker's buffers exist and their pages are touched, as in a service that has been up for a second */
-    (void)lo_path_transform(r->cfg, &s, r->srcs[0], r->lens[0], out, cap);
+    int nf = 0;
+    if (r->cfg->animated) (void)lo_path_transform_anim(r->cfg, &s, r->srcs[0], r->lens[0], out, cap, &nf);
+    else (void)lo_path_transform(r->cfg, &s, r->srcs[0], r->lens[0], out, cap);
     pthread_barrier_wait(&r->start);
     for (;;) {
         const long j = atomic_fetch_add(&r->next, 1);
         if (j >= r->jobs) break;
         const int k = (int)(j % r->nsrc);
-        const long n = lo_path_transform(r->cfg, &s, r->srcs[k], r->lens[k], out, cap);
-        if (n > 0) atomic_fetch_add(&r->ok, 1); else atomic_fetch_add(&r->failed, 1);
+        nf = 1;
+        const long n = r->cfg->animated ? lo_path_transform_anim(r->cfg, &s, r->srcs[k], r->lens[k], out, cap, &nf) : lo_path_transform(r->cfg, &s, r->srcs[k], r->lens[k], out, cap);
+        if (n > 0) { atomic_fetch_add(&r->ok, 1); atomic_fetch_add(&r->frames, nf); } else atomic_fetch_add(&r->failed, 1);
         if (j < r->nsrc && r->keep) {
             r->keep_len[k] = n;
             if (n > 0 && (size_t)n <= r->keep_cap) memcpy(r->keep + (size_t)k * r->keep_cap, out, (size_t)n);
@@ -198,6 +281,7 @@ static void* worker(void* arg)
     return NULL;
 }
 
+static long g_last_frames = 0;
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 /* `jobs` transforms (job j works on source j % nsrc) on `threads` workers. *seconds = wall time between the barrier that releases the
@@ -211,7 +295,7 @@ long lo_path_run(const lo_path_cfg* cfg, const uint8_t* const* srcs, const size_
     memset(&r, 0, sizeof(r));
     r.cfg = cfg; r.srcs = srcs; r.lens = lens; r.nsrc = nsrc; r.jobs = jobs;
     r.keep = keep; r.keep_cap = keep_cap; r.keep_len = keep_len;
-    atomic_init(&r.next, 0); atomic_init(&r.ok, 0); atomic_init(&r.failed, 0);
+    atomic_init(&r.next, 0); atomic_init(&r.ok, 0); atomic_init(&r.failed, 0); atomic_init(&r.frames, 0);
     pthread_barrier_init(&r.start, NULL, (unsigned)threads + 1);
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
     for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &r);
@@ -222,5 +306,8 @@ long lo_path_run(const lo_path_cfg* cfg, const uint8_t* const* srcs, const size_
     for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
     free(th);
     pthread_barrier_destroy(&r.start);
+    g_last_frames = atomic_load(&r.frames);
     return atomic_load(&r.ok);
 }
+
+long lo_path_last_frames(void) { return g_last_frames; } /* frames the successful transforms of the last lo_path_run wrote (animated mode) */

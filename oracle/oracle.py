@@ -780,7 +780,7 @@ def transform_animated_to_webp(data, width, height, quality=75):
         if g is None:
             return None
         canv = [f[0] for f in g[2]]
-        delays = [max(int(f[1][4]) * 10, 0) if len(f[1]) > 4 else 100 for f in g[2]]
+        delays = [max(int(f[1][6]) * 10, 0) for f in g[2]]  # meta[6]: the frame's delay in hundredths of a second
     else:
         pl = ref_webp_play(d)
         if pl is None:
@@ -796,10 +796,11 @@ def transform_animated_to_webp(data, width, height, quality=75):
 class _PathCfg(C.Structure):
     _fields_ = [("dec_jpeg", C.c_void_p), ("enc_jpeg", C.c_void_p), ("dec_png", C.c_void_p), ("dec_webp", C.c_void_p), ("info_webp", C.c_void_p),
                 ("width", C.c_int), ("height", C.c_int), ("quality", C.c_int), ("resize_method", C.c_int), ("enc_webp", C.c_void_p), ("webp_quality", C.c_float),
-                ("dec_avif", C.c_void_p)]
+                ("dec_avif", C.c_void_p), ("animated", C.c_int), ("gif_open", C.c_void_p), ("gif_next", C.c_void_p), ("gif_close", C.c_void_p),
+                ("webp_play", C.c_void_p), ("enc_anim", C.c_void_p)]
 
 
-def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True, webp_quality=None):
+def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_ref=True, resize_method=FIT, keep=True, webp_quality=None, animated=False):
     """The reference CPU path as a C worker loop (oracle/cpu_path.c): `jobs` transforms (job j = sources[j % len]) on `threads`
     pthreads, each with its own preallocated frame buffers, no Python between decode, orientation, Fit / INTER_AREA and encode.
     Returns {"seconds", "ok", "jobs", "kind", "outputs"}: outputs[k] = the bytes the first job on sources[k] produced (None if it
@@ -822,12 +823,23 @@ def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_r
         ref_webp().ref_webp_encode_still.restype = C.c_size_t
         cfg.enc_webp = C.cast(ref_webp().ref_webp_encode_still, C.c_void_p)
         cfg.webp_quality = float(webp_quality)
+    if animated:  # BASELINE configs[3]: every frame of a GIF / animated WebP -> Fit -> the reference's animation writer, in C (lo_path_transform_anim)
+        if ref_webp() is None or ref_gif() is None or webp_quality is None:
+            raise RuntimeError("animated mode needs oracle/_ref/librefwebp.so, librefgif.so and a webp_quality")
+        cfg.animated = 1
+        ref_gif().rg_open.restype = C.c_void_p
+        cfg.gif_open = C.cast(ref_gif().rg_open, C.c_void_p)
+        cfg.gif_next = C.cast(ref_gif().rg_next, C.c_void_p)
+        cfg.gif_close = C.cast(ref_gif().rg_close, C.c_void_p)
+        cfg.webp_play = C.cast(ref_webp().ref_webp_play, C.c_void_p)
+        ref_webp().ref_webp_encode_anim.restype = C.c_size_t
+        cfg.enc_anim = C.cast(ref_webp().ref_webp_encode_anim, C.c_void_p)
     bufs = [np.frombuffer(bytes(d), dtype=np.uint8) for d in sources]
     n = len(bufs)
     ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
     lens = (C.c_size_t * n)(*[b.size for b in bufs])
     jobs = n if jobs is None else int(jobs)
-    keep_cap = max(1 << 16, int(width) * int(height) * 4 + 4096) if keep else 0
+    keep_cap = (max(1 << 16, int(width) * int(height) * 4 + 4096) if not animated else 4 << 20) if keep else 0
     keep_buf = np.zeros(max(1, n * keep_cap), dtype=np.uint8)
     keep_len = (C.c_long * n)(*([0] * n))
     secs = C.c_double(0.0)
@@ -835,7 +847,8 @@ def cpu_path_run(sources, width, height, quality=85, threads=1, jobs=None, use_r
     L.lo_path_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_size_t, C.c_void_p]
     ok = L.lo_path_run(C.byref(cfg), ptrs, lens, n, jobs, int(threads), C.byref(secs), keep_buf.ctypes.data if keep else None, keep_cap, keep_len if keep else None)
     outs = [keep_buf[k * keep_cap: k * keep_cap + keep_len[k]].tobytes() if keep and 0 < keep_len[k] <= keep_cap else None for k in range(n)]
-    return {"seconds": secs.value, "ok": int(ok), "jobs": jobs, "kind": "reference" if from_ref else "port", "outputs": outs}
+    L.lo_path_last_frames.restype = C.c_long
+    return {"seconds": secs.value, "ok": int(ok), "jobs": jobs, "kind": "reference" if from_ref else "port", "outputs": outs, "frames": int(L.lo_path_last_frames())}
 
 
 class _Info(C.Structure):

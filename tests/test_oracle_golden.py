@@ -3,6 +3,7 @@ own libjpeg-turbo 3.1.0, and the ThumbHash known answers of /root/reference/thum
 Runs on CPU."""
 import base64
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -211,3 +212,16 @@ def test_cmyk_to_bgr_rule_is_opencvs(oracle):
     k = c[:, 3:4]
     exp = (k - (((255 - c[:, :3]) * k) >> 8))[:, ::-1].astype(np.uint8)
     assert np.array_equal(got, exp)
+
+
+def test_cpu_path_animated_worker_loop_equals_the_stagewise_reference_path(oracle):
+    """bench.py's configs[3] baseline (oracle/cpu_path.c lo_path_transform_anim: giflib + restated compositing / libwebp playback ->
+    Fit per frame -> the reference's animation writer, all in C) writes the bytes the stage-by-stage Python path writes."""
+    if oracle.ref_gif() is None or oracle.ref_webp() is None:
+        pytest.skip("oracle/_ref/librefgif.so / librefwebp.so not built")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    srcs = [open(os.path.join(gold, "inputs_gif", "party-discord.gif"), "rb").read(), open(os.path.join(gold, "inputs_webp", "big_buck_bunny_720_5s.webp"), "rb").read()]
+    want = [oracle.transform_animated_to_webp(d, 128, 128, 75) for d in srcs]
+    r = oracle.cpu_path_run(srcs, 128, 128, threads=2, jobs=2, keep=True, webp_quality=75, animated=True)
+    assert r["ok"] == 2 and r["frames"] == sum(w[1] for w in want)
+    assert [o == w[0] for o, w in zip(r["outputs"], want)] == [True, True]
