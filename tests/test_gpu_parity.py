@@ -721,3 +721,145 @@ def test_deferred_mats_materialise_for_anyone_who_looks(hip_lib, oracle, fixture
     assert np.array_equal(fb[: 100 * 75 * 3].reshape(100, 75, 3), oriented)   # the oriented frame itself: exact
     for x in (view, m2, m):
         L.opencv_mat_release(C.c_void_p(x))
+
+
+@pytest.mark.gpu
+def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
+    """Differential test of the deferred Part A machinery (lp_abi_opencv.cpp "deferred chains"): random sequences of the calls a cgo caller
+    may issue after opencv_decoder_read_data -- orientation, crop, resize, in any order and number, ending in the JPEG encoder, the PNG
+    encoder or a look at the pixels -- run once with the calls recorded and once with every call executed when it is made. Sizes,
+    verdicts and (integer scales and plain copies) bytes must be the same; a fractional resize may differ by the +-1 LSB of its two
+    kernels before the encoder, so those outputs are compared as decoded pictures."""
+    import ctypes as C
+    import io
+
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    L = hip_lib
+    for f in ("opencv_mat_create_from_data", "opencv_decoder_create", "opencv_mat_get_data", "opencv_mat_crop", "opencv_encoder_create"):
+        getattr(L, f).restype = C.c_void_p
+    for f in ("opencv_mat_release", "opencv_decoder_release", "opencv_encoder_release", "opencv_mat_orientation_transform", "opencv_mat_resize"):
+        getattr(L, f).restype = None
+    L.opencv_encoder_write.restype = C.c_bool
+    L.opencv_decoder_read_data.restype = C.c_bool
+    L.opencv_decoder_read_header.restype = C.c_bool
+    rng = np.random.default_rng(505)
+    rgb = synth.synth_rgb(77, 512)
+
+    def make_source(k):
+        w, h = int(rng.integers(17, 200)), int(rng.integers(17, 200))
+        if k % 3 == 0:
+            w, h = 16 * int(rng.integers(2, 12)), 16 * int(rng.integers(2, 12))   # sizes that allow integer scales
+        x0, y0 = int(rng.integers(0, 512 - w)), int(rng.integers(0, 512 - h))
+        b = io.BytesIO()
+        img = Image.fromarray(np.ascontiguousarray(rgb[y0:y0 + h, x0:x0 + w]))
+        if k % 7 == 3:
+            img = img.convert("L")
+        img.save(b, "JPEG", quality=int(rng.integers(60, 96)), subsampling=int(rng.choice([0, 1, 2])) if img.mode != "L" else -1)
+        return b.getvalue(), w, h, (1 if img.mode == "L" else 3)
+
+    def run(data, w, h, cn, steps, ending, deferred):
+        L.lilliput_hip_set_deferred(1 if deferred else 0)
+        keep = []
+        try:
+            src = np.frombuffer(bytearray(data), dtype=np.uint8).copy()
+            buf = L.opencv_mat_create_from_data(C.c_int(src.size), C.c_int(1), C.c_int(0), C.c_void_p(src.ctypes.data), C.c_size_t(src.size))
+            d = L.opencv_decoder_create(C.c_void_p(buf))
+            assert d and L.opencv_decoder_read_header(C.c_void_p(d))
+            typ = 0 if cn == 1 else 16
+            fb = np.zeros(1 << 18, dtype=np.uint8)
+            cur = L.opencv_mat_create_from_data(C.c_int(w), C.c_int(h), C.c_int(typ), C.c_void_p(fb.ctypes.data), C.c_size_t(fb.size))
+            keep += [src, fb]
+            mats = [cur]
+            cur_buf = fb
+            if not L.opencv_decoder_read_data(C.c_void_p(d), C.c_void_p(cur)):
+                return ("decode failed",)
+            for st in steps:
+                cw, ch = L.opencv_mat_get_width(C.c_void_p(cur)), L.opencv_mat_get_height(C.c_void_p(cur))
+                if st[0] == "orient":
+                    L.opencv_mat_orientation_transform(C.c_int(st[1]), C.c_void_p(cur))
+                elif st[0] == "crop":
+                    fx, fy, fw, fh = st[1:]
+                    x, y = int(fx * (cw - 1)), int(fy * (ch - 1))
+                    ww, hh = max(1, int(fw * (cw - x))), max(1, int(fh * (ch - y)))
+                    cur = L.opencv_mat_crop(C.c_void_p(cur), C.c_int(x), C.c_int(y), C.c_int(ww), C.c_int(hh))
+                    mats.append(cur)
+                else:
+                    kind, a, b_ = st[1:]
+                    if kind == "int":   # an integer scale where the size allows one
+                        nw, nh = (cw // a if cw % a == 0 else cw), (ch // a if ch % a == 0 else ch)
+                    else:
+                        nw, nh = max(1, int(cw * a)), max(1, int(ch * b_))
+                    nb = np.zeros(1 << 18, dtype=np.uint8)
+                    keep.append(nb)
+                    dst = L.opencv_mat_create_from_data(C.c_int(nw), C.c_int(nh), C.c_int(typ), C.c_void_p(nb.ctypes.data), C.c_size_t(nb.size))
+                    L.opencv_mat_resize(C.c_void_p(cur), C.c_void_p(dst), C.c_int(nw), C.c_int(nh), C.c_int(3))
+                    mats.append(dst)
+                    cur, cur_buf = dst, nb
+            cw, ch = L.opencv_mat_get_width(C.c_void_p(cur)), L.opencv_mat_get_height(C.c_void_p(cur))
+            if ending == "pixels":
+                p = L.opencv_mat_get_data(C.c_void_p(cur))
+                step = cw * cn
+                out = ("pixels", cw, ch, bytes((C.c_uint8 * (ch * step)).from_address(p)) if p else None)
+            else:
+                ob = np.zeros(1 << 20, dtype=np.uint8)
+                om = L.opencv_mat_create_from_data(C.c_int(ob.size), C.c_int(1), C.c_int(0), C.c_void_p(ob.ctypes.data), C.c_size_t(ob.size))
+                e = L.opencv_encoder_create(b".jpeg" if ending == "jpeg" else b".png", C.c_void_p(om))
+                opts = (C.c_int * 2)(1, 85) if ending == "jpeg" else (C.c_int * 2)(16, 3)
+                ok = L.opencv_encoder_write(C.c_void_p(e), C.c_void_p(cur), opts, C.c_size_t(2))
+                n = L.opencv_mat_get_height(C.c_void_p(om)) if ok else 0
+                out = (ending, cw, ch, bytes(ob[:n]) if ok else None)
+                L.opencv_encoder_release(C.c_void_p(e))
+                L.opencv_mat_release(C.c_void_p(om))
+            L.opencv_decoder_release(C.c_void_p(d))
+            for m_ in reversed(mats):
+                L.opencv_mat_release(C.c_void_p(m_))
+            L.opencv_mat_release(C.c_void_p(buf))
+            return out
+        finally:
+            L.lilliput_hip_set_deferred(1)
+
+    bad, answered = [], 0
+    st0 = (C.c_uint64 * 4)()
+    L.lilliput_hip_deferred_stats(st0)
+    for k in range(400):
+        data, w, h, cn = make_source(k)
+        steps, exact = [], True
+        for _ in range(int(rng.integers(0, 5))):
+            t = int(rng.integers(0, 4))
+            if t == 0:
+                steps.append(("orient", int(rng.integers(1, 9))))
+            elif t == 1:
+                steps.append(("crop", float(rng.random() * 0.5), float(rng.random() * 0.5), float(0.3 + 0.7 * rng.random()), float(0.3 + 0.7 * rng.random())))
+            elif t == 2:
+                steps.append(("resize", "int", int(rng.choice([1, 2, 4, 8])), 0))
+            else:
+                steps.append(("resize", "frac", float(0.2 + 0.7 * rng.random()), float(0.2 + 0.7 * rng.random())))
+                exact = False
+        ending = ("jpeg", "jpeg", "pixels", "png")[k % 4]
+        if ending == "pixels" and any(st[0] == "crop" for st in steps) and not (steps and steps[-1][0] == "resize"):
+            ending = "jpeg"  # a crop is a view with its parent's row pitch: Go only ever hands it to the resize or an encoder
+        a = run(data, w, h, cn, steps, ending, True)
+        b = run(data, w, h, cn, steps, ending, False)
+        if a[:3] != b[:3] or (a[3] is None) != (b[3] is None):
+            bad.append((k, steps, ending, a[:3], b[:3], a[3] is None, b[3] is None))
+            continue
+        answered += a[3] is not None
+        if a[3] is None or a[3] == b[3]:
+            continue
+        if exact:
+            bad.append((k, steps, ending, "bytes differ without a fractional resize"))
+            continue
+        if ending == "pixels":
+            pa, pb = np.frombuffer(a[3], np.uint8).astype(int), np.frombuffer(b[3], np.uint8).astype(int)
+        else:
+            pa, pb = (np.asarray(Image.open(io.BytesIO(x)).convert("RGB")).astype(int) for x in (a[3], b[3]))
+        lim = 1 if ending != "jpeg" else 12
+        if pa.shape != pb.shape or np.abs(pa - pb).max() > lim or np.abs(pa - pb).mean() > 0.5:
+            bad.append((k, steps, ending, "pictures differ", int(np.abs(pa - pb).max()) if pa.shape == pb.shape else -1))
+    assert not bad, bad[:5]
+    st1 = (C.c_uint64 * 4)()
+    L.lilliput_hip_deferred_stats(st1)
+    assert answered > 380 and st1[0] - st0[0] >= 400 and st1[1] - st0[1] > 40 and st1[2] - st0[2] > 100, (answered, list(st0), list(st1))  # chains recorded, served by the batched path, run the eager way after all
