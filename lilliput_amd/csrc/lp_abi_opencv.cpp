@@ -671,7 +671,7 @@ LP_ABI_CATCH("opencv_mat_get_data", return nullptr)
 opencv_mat opencv_mat_crop(const opencv_mat src, int x, int y, int width, int height) // opencv.cpp:210-215
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto s = static_cast<const LpMat*>(src);
-    if (x < 0 || y < 0 || width < 0 || height < 0 || x + width > s->cols || y + height > s->rows) {
+    if (x < 0 || y < 0 || width < 0 || height < 0 || (int64_t)x + width > s->cols || (int64_t)y + height > s->rows) {
         // cv::Mat(Rect) asserts here and the reference would abort; refuse instead
         fprintf(stderr, "lilliput_hip: opencv_mat_crop rectangle outside the matrix\n");
         return NULL;
