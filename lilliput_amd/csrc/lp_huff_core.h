@@ -31,6 +31,9 @@
 #pragma once
 #include "lp_types.h"
 
+#ifndef LP_MULTI
+#define LP_MULTI 1   // SPEC / VERIFY decode several short symbols per step (LpHuffSet::lutm); 0 = one symbol per step (round 4's passes, A/B builds)
+#endif
 #if defined(__HIPCC__)
 #define LP_HD __host__ __device__ __forceinline__
 #else
@@ -128,6 +131,7 @@ LP_HD uint32_t lp_bfe(uint32_t v, uint32_t off, uint32_t width)
 //   bool any2(bool a, bool b)               any(a || b), as two votes or-ed in scalar registers (a vote on a compare costs nothing; a vote on
 //                                           a combination of compares is materialised in a VGPR first: two more vector instructions)
 //   uint32_t lut(uint32_t tbl, uint32_t i), lut2(uint32_t i)   first-level entry of table tbl, entry i of the second-level pool
+//   uint32_t lutc(uint32_t tbl, uint32_t i)  lut[tbl][i] | lutm[tbl][i] << 16 (the counting passes' combined entry)
 //   int32_t maxcode(tbl, l), valoff(tbl, l); uint32_t val(tbl, i)   canonical tables (third level, corrupt streams / huge tables)
 //   uint32_t rst_bit(uint32_t k)            bit position of the k-th restart boundary
 //   void settle(uint32_t& v)                v came from rst_bit() inside a rare branch: finish the load there (device), no-op on the host
@@ -279,11 +283,21 @@ struct LpLane {
         Sym r;
         // DC table at a block start, the block's AC table inside: two bits of the block's field in ic.tb
         const uint32_t tbl = lp_bfe(ic.tb, bc + 2u * lp_min1(z), 2);
-        uint32_t e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
+        uint32_t e;
+        if (NEED_VAL || !LP_MULTI)
+            e = m.lut(tbl, pk >> (32 - LP_LUT_BITS));
+        else {
+            // The counting passes take every symbol whose code lies inside the lookup window in ONE step (LpHuffSet::lutm: bits consumed,
+            // zigzag advance, ends-the-block of the whole group in the upper half of the entry) -- unless the group would run past
+            // coefficient 63 from this lane's z: then the one-symbol entry in the lower half, i.e. the step of the WRITE pass. The
+            // bits above an entry's 16 stay in e: every field below is read with a bit-field extract.
+            const uint32_t ec = m.lutc(tbl, pk >> (32 - LP_LUT_BITS));
+            e = z + lp_bfe(ec, 25, 6) < 64u ? ec >> 16 : ec;
+        }
         if (LP_E_BITS(e) == 0) e = long_code(tbl, e, pk >> 16);
         const uint32_t n = LP_E_BITS(e);          // code + extra bits
         const uint32_t s = LP_E_SIZE(e);
-        const uint32_t runx = LP_E_RUNX(e);       // run, + 64 when the symbol ends the block. DC symbols are categories 0..15 (validated by the parser): run == 0
+        const uint32_t runx = lp_bfe(e, 9, 7);    // LP_E_RUNX: run, + 64 when the symbol ends the block. DC symbols are categories 0..15 (validated by the parser): run == 0
         r.val = 0;
         if (NEED_VAL) {
             const uint32_t x = lp_bfe_w(pk, 32u - n, s);  // the s extra bits that follow the code (0 when s == 0)

@@ -82,6 +82,38 @@ void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const u
     memcpy(hs->vals[slot], vals, (size_t)(k > 256 ? 256 : k));
 }
 
+// The counting passes' multi-symbol entries (LpHuffSet::lutm, lp_types.h). From the window's bit i on, symbols are taken while the
+// whole CODE of the next one lies inside the LP_LUT_BITS window (its extra bits may reach beyond: the counting passes skip them
+// unread) and the group stays a run the lane logic can apply in one step: one block (an EOB closes the group; so does a group whose
+// advance would reach 64 with certainty), at most 31 bits (LP_E_BITS is five bits wide; the bit reader's ring geometry assumes as much).
+void lp_build_huff_multi(LpHuffSet* hs, const int ac_of_dc[2])
+{
+    for (int slot = 0; slot < 4; slot++) {
+        const int ac = slot >= 2 ? slot : ac_of_dc[slot];
+        for (uint32_t i = 0; i < LP_LUT_SIZE; i++) {
+            const uint16_t e1 = hs->lut[slot][i];
+            hs->lutm[slot][i] = e1;
+            if (LP_E_BITS(e1) == 0 || ac < 2 || ac > 3) continue; // the prefix of a long code / no code; a DC slot without one AC slot behind it
+            if (e1 & 0x8000u) continue;                             // the first symbol ends the block
+            uint32_t nbits = LP_E_BITS(e1), adv = (LP_E_RUNX(e1) & 15u) + 1u, nsym = 1;
+            bool eob = false;
+            while (nbits < LP_LUT_BITS) {
+                const uint32_t known = LP_LUT_BITS - nbits;     // window bits left for the next code
+                const uint16_t e = hs->lut[ac][(i << nbits) & (LP_LUT_SIZE - 1u)];
+                const uint32_t n = LP_E_BITS(e), sz = LP_E_SIZE(e);
+                if (n == 0 || n - sz > known) break;            // a long code, or a code that reaches past the window: not decided by these bits
+                if (nbits + n > 31u) break;
+                if (e & 0x8000u) { eob = true; nbits += n; nsym++; break; }
+                const uint32_t a = (LP_E_RUNX(e) & 15u) + 1u;   // ZRL: run 15, size 0 -> 16 coefficients
+                if (adv + a > 63u) break;                       // (a group of 64 or more can never be applied: z + advance <= 64 with z >= 0 ... keep the field six bits)
+                adv += a; nbits += n; nsym++;
+            }
+            if (nsym < 2) continue;
+            hs->lutm[slot][i] = (uint16_t)(nbits | ((eob ? adv : adv - 1u) << 9) | (eob ? 0x8000u : 0u));
+        }
+    }
+}
+
 // T.81 Annex K.3 typical Huffman tables (jstdhuff.c): what the encoder writes, and what libjpeg-turbo falls back to for a
 // table id 0/1 that no DHT defined (jdhuff.c jinit_huff_decoder -> std_huff_tables, "Motion JPEG frames typically do not
 // include the Huffman tables"). Order: DC luma, AC luma, DC chroma, AC chroma.
@@ -516,6 +548,15 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         static const uint8_t no_bits[17] = {0}, no_vals[1] = {0};
         for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, t, h_ok[0][t] ? hbits[0][t] : no_bits, h_ok[0][t] ? hvals[0][t] : no_vals);
         for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, 2 + t, h_ok[1][t] ? hbits[1][t] : no_bits, h_ok[1][t] ? hvals[1][t] : no_vals);
+        int ac_of_dc[2] = {-1, -1}; // the AC slot behind each DC slot, when the scan's components agree on one
+        bool clash[2] = {false, false};
+        for (int c = 0; c < j.ncomp && c < LP_MAX_COMP; c++) {
+            const int d = j.dc_tbl[c] & 1;
+            if (ac_of_dc[d] >= 0 && ac_of_dc[d] != j.ac_tbl[c]) clash[d] = true;
+            ac_of_dc[d] = j.ac_tbl[c];
+        }
+        for (int d = 0; d < 2; d++) if (clash[d]) ac_of_dc[d] = -1;
+        lp_build_huff_multi(&out->huff, ac_of_dc);
     }
     // End of the scan: the common case is a file that ends in EOI; otherwise walk the ECS once.
     out->ecs_off = ecs;

@@ -49,6 +49,9 @@ int lp_jpeg_parse_opts(const uint8_t* data, size_t len, LpJpegHeader* out, bool 
 
 // Build one table slot of an LpHuffSet from DHT counts/values.
 void lp_build_huff_slot(LpHuffSet* hs, int slot, const uint8_t bits[17], const uint8_t* vals);
+// After the four slots: the multi-symbol entries of the counting passes (LpHuffSet::lutm). ac_of_dc[d] = the AC slot (2 / 3) every
+// block with DC slot d decodes its coefficients with, or -1 (no such block, or two different ones: DC entries then stay one symbol).
+void lp_build_huff_multi(LpHuffSet* hs, const int ac_of_dc[2]);
 
 // T.81 Annex K.3 tables (DC luma, AC luma, DC chroma, AC chroma): encoder output and the decoder's fallback for undefined ids 0/1.
 extern const uint8_t lp_std_huff_bits[4][17];

@@ -221,16 +221,18 @@ struct DevMem {
                             // the slot a decode step asks for is a bit field of the lane's negated position (LpLane::np, fetch_np)
     uint32_t fbits;         // next stream word to load, as a BIT position (a multiple of 128): the top-up test compares it with the
                             // lane's bit position directly
-    const LpHuffSet* hs;    // LDS: the lookup part (lut, lut2) only
+    const uint16_t* l1;     // LDS: LpHuffSet::lut (the WRITE pass; the counting passes of an LP_MULTI == 0 build)
+    const uint16_t* l2;     // LDS: LpHuffSet::lut2
+    const uint32_t* lc;     // LDS: lut | lutm << 16, the counting passes' combined first level (stage_huff_count)
     const LpHuffSet* hsg;   // HBM: the whole set; the canonical tables are read on damaged streams only
     const uint32_t* rst;
     uint4 pend[Q];          // see reseek / topup
-    static __device__ __forceinline__ DevMem make(const uint32_t* stream, uint32_t cap_words, uint32_t* ring_, const LpHuffSet* hs_, const LpHuffSet* hsg_,
-                                                  const uint32_t* rst_)
+    static __device__ __forceinline__ DevMem make(const uint32_t* stream, uint32_t cap_words, uint32_t* ring_, const uint16_t* l1_, const uint16_t* l2_,
+                                                  const uint32_t* lc_, const LpHuffSet* hsg_, const uint32_t* rst_)
     {
         DevMem m;
         m.words = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(stream), 0, (int)(cap_words * 4u), 0x00020000);
-        m.ring = ring_; m.fbits = 0; m.hs = hs_; m.hsg = hsg_; m.rst = rst_;
+        m.ring = ring_; m.fbits = 0; m.l1 = l1_; m.l2 = l2_; m.lc = lc_; m.hsg = hsg_; m.rst = rst_;
         return m;
     }
     __device__ __forceinline__ uint32_t fetch1(uint32_t w) const { return ring[((3u - w) & (R - 1u)) << 6]; }
@@ -293,8 +295,9 @@ struct DevMem {
     // instructions per vote, three votes per decode step)
     __device__ __forceinline__ bool any(bool p) const { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
     __device__ __forceinline__ bool any2(bool a, bool b) const { return (__builtin_amdgcn_ballot_w64(a) | __builtin_amdgcn_ballot_w64(b)) != 0ull; }
-    __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[0][(t << LP_LUT_BITS) | i]; }
-    __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
+    __device__ __forceinline__ uint32_t lut(uint32_t t, uint32_t i) const { return l1[(t << LP_LUT_BITS) | i]; }
+    __device__ __forceinline__ uint32_t lutc(uint32_t t, uint32_t i) const { return lc[(t << LP_LUT_BITS) | i]; }
+    __device__ __forceinline__ uint32_t lut2(uint32_t i) const { return l2[i]; }
     __device__ __forceinline__ int32_t maxcode(uint32_t t, uint32_t l) const { return hsg->maxcode[t][l]; }
     __device__ __forceinline__ int32_t valoff(uint32_t t, uint32_t l) const { return hsg->valoff[t][l]; }
     __device__ __forceinline__ uint32_t val(uint32_t t, uint32_t i) const { return hsg->vals[t][i & 255]; }
@@ -320,6 +323,30 @@ __device__ __forceinline__ void stage_huff(uint4* d, const LpHuffSet* src)
     for (uint32_t i = threadIdx.x; i < LP_HUFF_LDS_BYTES / 16; i += blockDim.x) d[i] = s[i];
     __syncthreads();
 }
+// The counting passes' tables: the second level as it is, the first level as one 32-bit entry per index -- the one-symbol entry in the
+// lower half, the multi-symbol entry (LpHuffSet::lutm) in the upper: one LDS read serves both (LpLane::step).
+#if LP_MULTI
+#define LP_COUNT_LDS_BYTES (LP_LUT2_POOL * 2 + 4 * LP_LUT_SIZE * 4)
+__device__ __forceinline__ void stage_huff_count(uint4* d, const LpHuffSet* src)
+{
+    const uint4* s2 = reinterpret_cast<const uint4*>(src->lut2);
+    for (uint32_t i = threadIdx.x; i < LP_LUT2_POOL * 2 / 16; i += blockDim.x) d[i] = s2[i];
+    const uint4* lo = reinterpret_cast<const uint4*>(src->lut);
+    const uint4* hi = reinterpret_cast<const uint4*>(src->lutm);
+    uint4* c = d + LP_LUT2_POOL * 2 / 16;
+    for (uint32_t i = threadIdx.x; i < 4 * LP_LUT_SIZE / 8; i += blockDim.x) { // eight entries of each half -> eight combined entries
+        const uint4 a = lo[i], b = hi[i];
+        c[2 * i] = make_uint4((a.x & 0xffffu) | (b.x << 16), (a.x >> 16) | (b.x & 0xffff0000u), (a.y & 0xffffu) | (b.y << 16), (a.y >> 16) | (b.y & 0xffff0000u));
+        c[2 * i + 1] = make_uint4((a.z & 0xffffu) | (b.z << 16), (a.z >> 16) | (b.z & 0xffff0000u), (a.w & 0xffffu) | (b.w << 16), (a.w >> 16) | (b.w & 0xffff0000u));
+    }
+    __syncthreads();
+}
+#define LP_COUNT_TABLES(s4) nullptr, reinterpret_cast<const uint16_t*>(s4), reinterpret_cast<const uint32_t*>(s4 + LP_LUT2_POOL * 2 / 16)
+#else
+#define LP_COUNT_LDS_BYTES LP_HUFF_LDS_BYTES
+__device__ __forceinline__ void stage_huff_count(uint4* d, const LpHuffSet* src) { stage_huff(d, src); }
+#define LP_COUNT_TABLES(s4) reinterpret_cast<const LpHuffSet*>(s4)->lut[0], reinterpret_cast<const LpHuffSet*>(s4)->lut2, nullptr
+#endif
 
 __device__ __forceinline__ LpImgCtx make_ctx(const LpJpeg& img, const LpJpegState& st)
 {
@@ -366,19 +393,18 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_spec(const LpJpeg* __restrict__
                                                       LpSubState* __restrict__ entry_used, LpCkSched cs, uint32_t tot_sub)
 {
     typedef CountMem MEM;
-    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
-    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
+    __shared__ uint4 s_hs4[LP_COUNT_LDS_BYTES / 16];
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     const LpJpeg& img = imgs[blockIdx.y];
     const LpJpegState& st = states[blockIdx.y];
     const uint32_t nsub = st.nsub < img.sub_cap ? st.nsub : img.sub_cap;
     if (blockIdx.x * HUFF_T >= nsub) return;
-    stage_huff(s_hs4, huffs + img.huff_idx);
+    stage_huff_count(s_hs4, huffs + img.huff_idx);
     const uint32_t sub = blockIdx.x * HUFF_T + threadIdx.x;
     const bool valid = sub < nsub;
     const uint32_t g = img.sub_off + (valid ? sub : 0);
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), LP_COUNT_TABLES(s_hs4), huffs + img.huff_idx,
                       rst_bits + img.rst_off);
     LpSubState entry;
     const uint32_t S = img.sub_bits;
@@ -429,8 +455,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
                                                         uint32_t* changed, uint32_t round, uint32_t K, uint32_t tot_sub)
 {
     typedef CountMem MEM;
-    __shared__ uint4 s_hs4[LP_HUFF_LDS_BYTES / 16];
-    const LpHuffSet* s_hs = reinterpret_cast<const LpHuffSet*>(s_hs4);
+    __shared__ uint4 s_hs4[LP_COUNT_LDS_BYTES / 16];
     __shared__ uint32_t s_ring[HUFF_T * MEM::kRows];
     __shared__ uint16_t s_ckpos[HUFF_T * LP_MAX_CKPT];
     // changed[r] counts the exit states round r moved. The rounds of a decode are enqueued back to back without a host round
@@ -453,10 +478,10 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_verify(const LpJpeg* __restrict
         need = !lp_state_eq(entry, entry_used[g]);
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;
-    stage_huff(s_hs4, huffs + img.huff_idx);
+    stage_huff_count(s_hs4, huffs + img.huff_idx);
     if (!need) return;
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), LP_COUNT_TABLES(s_hs4), huffs + img.huff_idx,
                       rst_bits + img.rst_off);
     const uint32_t S = img.sub_bits;
     uint16_t* cp = s_ckpos + (threadIdx.x >> 6) * (64 * LP_MAX_CKPT) + (threadIdx.x & 63);
@@ -670,7 +695,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     const bool idle = sub >= nsub;
     const uint32_t g = img.sub_off + (idle ? nsub - 1u : sub);
     const LpImgCtx ic = make_ctx(img, st);
-    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs, huffs + img.huff_idx,
+    MEM m = MEM::make(clean_arena + img.clean_off, img.clean_cap_words, s_ring + (threadIdx.x >> 6) * (64 * MEM::kRows) + (threadIdx.x & 63), s_hs->lut[0], s_hs->lut2, nullptr, huffs + img.huff_idx,
                       rst_bits + img.rst_off);
     LpSubState entry;
     entry.p = 0; entry.bz = 0;

@@ -46,11 +46,20 @@ static inline uint16_t lp_lut_entry(int t, int len, unsigned v)
     const bool ends_block = t >= 2 && (v & 15u) == 0 && (v >> 4) != 15; // AC symbol of size 0 that is not ZRL: EOB (jdhuff.c decode_mcu)
     return (uint16_t)(((unsigned)len + (v & 15u)) | ((v & 15u) << 5) | (((v >> 4) & 15u) << 9) | (ends_block ? 0x8000u : 0u));
 }
+// lutm[t][i] : the counting passes' MULTI-SYMBOL entry for the same index (round 5; SPEC / VERIFY only need where the next code starts,
+//              how far the zigzag index moves and whether the block ended -- not the values): every symbol whose CODE lies inside the
+//              LP_LUT_BITS window, first to last, as one entry of the same layout -- field 0 = the bits all of them consume, run field =
+//              (zigzag advance of all of them) - 1, or the advance of the symbols before the EOB that ends the run, + 64 (ends_block).
+//              A lane uses it when z + (run field & 63) < 64 -- then no symbol of the group is read at or beyond coefficient 64, where
+//              jdhuff.c's decode_mcu has left the block -- and the one-symbol entry otherwise. Equal to lut[t][i] where only one
+//              symbol fits (and for every prefix of a long code). DC slots: the DC symbol and the AC symbols behind it, when every block
+//              that uses DC slot d uses one and the same AC slot (lp_build_huff_multi).
 struct LpHuffSet {
     uint16_t lut[4][LP_LUT_SIZE];
     uint16_t lut2[LP_LUT2_POOL];
     uint32_t lut2_used;         // slices handed out so far (host-side bookkeeping while the four slots are built)
     uint32_t pad[3];
+    uint16_t lutm[4][LP_LUT_SIZE];
     int32_t maxcode[4][18];     // maxcode[l] = largest code of length l, -1 if none; [17] = sentinel
     int32_t valoff[4][17];      // valptr[l] - mincode[l]
     uint8_t vals[4][256];

@@ -36,8 +36,10 @@ struct HostMemT {
     void topup(uint32_t p) { const uint32_t w = p >> 5; for (int i = 0; i < Q; i++) if (fill + 4u <= w + R) fill += 4; }
     bool any(bool p) const { return p; }
     bool any2(bool a, bool b) const { return a || b; }
-    uint32_t lut(uint32_t t, uint32_t i) const { return hs->lut[t][i]; }
+    uint32_t lut(uint32_t t, uint32_t i) const { if (step_count) ++*step_count; return hs->lut[t][i]; }
     uint32_t lut2(uint32_t i) const { return hs->lut2[i]; }
+    uint32_t lutc(uint32_t t, uint32_t i) const { if (step_count) ++*step_count; return hs->lut[t][i] | ((uint32_t)hs->lutm[t][i] << 16); }
+    unsigned long long* step_count = nullptr;
     int32_t maxcode(uint32_t t, uint32_t l) const { return hs->maxcode[t][l]; }
     int32_t valoff(uint32_t t, uint32_t l) const { return hs->valoff[t][l]; }
     uint32_t val(uint32_t t, uint32_t i) const { return hs->vals[t][i & 255]; }
@@ -67,6 +69,10 @@ struct HostCk {
     uint32_t pos(uint32_t k) const { return rec[k].p; }
     LpCkptPk load(uint32_t k) const { return rec[k]; }
 };
+
+// statistics of the last emu_decode_coefs call: table lookups (= decode steps) of the SPEC pass over all subsequences
+static unsigned long long g_spec_steps = 0;
+extern "C" unsigned long long emu_last_spec_steps() { return g_spec_steps; }
 
 extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uint32_t C, int comp, int16_t* out, size_t cap_elems,
                                 int* bw, int* bh, int* rounds, int* nsub_out, int* spec_hits)
@@ -120,6 +126,8 @@ extern "C" int emu_decode_coefs(const uint8_t* data, size_t len, uint32_t S, uin
         HostMem m{words.data(), &h.huff, rst.data(), 0, 0, &violation};
         HostCk hc{&ck[(size_t)i * K]};
         uint32_t sub_end = i * S + S < total_bits ? i * S + S : total_bits;
+        if (i == 0) g_spec_steps = 0;
+        m.step_count = &g_spec_steps;
         lp_spec_pass(m, ic, sub_end, e, cs, hc, &spec_ex[i], &spec_tot[i]);
         ex[i] = spec_ex[i];
         tot[i] = spec_tot[i];
