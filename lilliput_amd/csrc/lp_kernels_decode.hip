@@ -1332,10 +1332,17 @@ void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)
 
 // How many workgroups of the WRITE kernel the device holds at once (LDS-limited occupancy x CUs): a resident batch sizes its chunks
 // so that a launch is one full round of them (a second, mostly empty round costs as much as the first).
+// LILLIPUT_HIP_WRITE_LDS_PAD: bytes of (unused) dynamic LDS added to every WRITE workgroup -- an occupancy knob for measurements (4 KB
+// more leaves three workgroups per CU, 16 KB more two); the resident chunk size follows through lp_huff_write_slots().
+static size_t write_lds_pad()
+{
+    static const size_t pad = getenv("LILLIPUT_HIP_WRITE_LDS_PAD") ? (size_t)atol(getenv("LILLIPUT_HIP_WRITE_LDS_PAD")) : 0;
+    return pad;
+}
 uint32_t lp_huff_write_slots()
 {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_huff_write<WriteMem>, HUFF_T, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_huff_write<WriteMem>, HUFF_T, write_lds_pad()) != hipSuccess || per_cu <= 0) per_cu = 4;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     return (uint32_t)per_cu * (uint32_t)cus;
 }
@@ -1344,7 +1351,7 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a)
 {
     if (!a.nimg || !a.max_sub) return;
     dim3 g((a.max_sub + HUFF_T - 1) / HUFF_T, a.nimg);
-    hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), 0, s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
+    hipLaunchKernelGGL(k_huff_write<WriteMem>, g, dim3(HUFF_T), write_lds_pad(), s, a.imgs, a.states, a.huffs, a.clean, a.rst, (const LpSubState*)a.cur_exit,
                        (const LpSubSum*)a.prefix, a.coef8, a.wide, a.wide_id, a.dc16);
 }
 

@@ -334,3 +334,17 @@ extern "C" long emu_unstuff_classify_check(long iters, uint32_t seed)
     }
     return bad;
 }
+
+// The lookup tables the parser builds for a file: lut (one symbol per entry) and lutm (the counting passes' multi-symbol entries) --
+// tests/test_host_logic.py checks lutm against an independent walk of lut.
+extern "C" int emu_huff_tables(const uint8_t* data, size_t len, uint16_t* lut, uint16_t* lutm, int* lut_bits)
+{
+    LpJpegHeader h;
+    int rc = lp_jpeg_parse(data, len, &h);
+    if (rc) return -rc;
+    if (h.scan_path) return -17;
+    memcpy(lut, h.huff.lut, sizeof(h.huff.lut));
+    memcpy(lutm, h.huff.lutm, sizeof(h.huff.lutm));
+    *lut_bits = LP_LUT_BITS;
+    return (int)h.j.ncomp;
+}

@@ -144,6 +144,89 @@ def test_lane_logic_other_samplings_and_tables(emu, oracle):
                 assert np.array_equal(got, oracle.jpeg_decode_coefs(data, comp)), (w, h, kw, comp)
 
 
+def test_multi_symbol_entries_of_the_counting_passes(emu, oracle, fixture_bytes):
+    """LpHuffSet::lutm (lp_build_huff_multi): every entry re-derived here from the one-symbol table by walking the window bit by bit --
+    bits consumed, zigzag advance, EOB flag of the group -- for Annex-K and optimised tables, every sampling; a multi-symbol step must
+    be exactly the one-symbol steps it stands for (jdhuff.c decode_mcu's loop, symbol by symbol), for every z the lane logic applies
+    it at. And the SPEC pass really takes fewer steps with it."""
+    import io
+
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    files = [fixture_bytes["sunrise.jpg"], fixture_bytes["large-sunrise.jpg"], fixture_bytes["firefox-gray.jpg"]]
+    rgb = synth.synth_rgb(3, 128)
+    for kw in ({"subsampling": 0}, {"subsampling": 2, "optimize": True}, {"subsampling": 1, "optimize": True, "quality": 35}):
+        b = io.BytesIO()
+        Image.fromarray(rgb).save(b, "JPEG", **({"quality": 90} | kw))
+        files.append(b.getvalue())
+    groups = 0
+    for data in files:
+        a = np.frombuffer(data, np.uint8)
+        lut = np.zeros((4, 1024), np.uint16)
+        lutm = np.zeros((4, 1024), np.uint16)
+        bits = C.c_int()
+        ncomp = emu.emu_huff_tables(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), lut.ctypes.data_as(C.c_void_p), lutm.ctypes.data_as(C.c_void_p), C.byref(bits))
+        assert ncomp > 0 and bits.value == 10
+        W = bits.value
+        for slot in range(4):
+            for i in range(1 << W):
+                e1, em = int(lut[slot, i]), int(lutm[slot, i])
+                if em == e1:
+                    continue
+                groups += 1
+                assert e1 & 31 and not e1 & 0x8000            # a short first code that does not end the block
+                # walk: symbols whose whole code lies inside the window, through the AC table behind this slot (a DC slot: the builder
+                # knows which AC slot follows; one of the two must reproduce the entry)
+                ok_any = False
+                for t in ([slot] if slot >= 2 else [2, 3]):
+                    syms = [(e1 & 31, (e1 >> 9) & 15, False)]   # (bits, run, EOB) of every symbol of the group
+                    n2, adv2 = e1 & 31, ((e1 >> 9) & 15) + 1
+                    while n2 < W:
+                        e = int(lut[t, (i << n2) & ((1 << W) - 1)])
+                        nb, sz = e & 31, (e >> 5) & 15
+                        if nb == 0 or nb - sz > W - n2 or n2 + nb > 31:
+                            break
+                        if e & 0x8000:
+                            syms.append((nb, 0, True))
+                            n2 += nb
+                            break
+                        a2 = ((e >> 9) & 15) + 1
+                        if adv2 + a2 > 63:
+                            break
+                        syms.append((nb, a2 - 1, False))
+                        adv2, n2 = adv2 + a2, n2 + nb
+                    eob2 = syms[-1][2]
+                    want = n2 | ((adv2 if eob2 else adv2 - 1) << 9) | (0x8000 if eob2 else 0)
+                    if len(syms) < 2 or want != em:
+                        continue
+                    ok_any = True
+                    # the lane logic (LpLane::step): from every z it can stand at, the group step == its symbols one at a time
+                    for z in ([0] if slot < 2 else range(1, 64)):
+                        runx = em >> 9
+                        if not z + (runx & 63) < 64:
+                            continue                            # the lane takes the one-symbol entry instead
+                        zg = z + runx + 1
+                        g = (em & 31, 0 if zg > 63 else zg, zg > 63)
+                        zs, ns, done = z, 0, False
+                        for (nb, run, eob) in syms:
+                            assert not done, (slot, i, z)      # no symbol of a group is read after the block has ended
+                            k = zs + run + (64 if eob else 0)
+                            ns, done = ns + nb, k + 1 > 63
+                            zs = 0 if done else k + 1
+                        assert g == (ns, zs, done), (slot, i, z, g, (ns, zs, done))
+                assert ok_any, (slot, i, hex(e1), hex(em))
+    assert groups > 1000
+    # fewer SPEC steps, same coefficients (the emulation counts first-level lookups of the speculative pass)
+    emu.emu_last_spec_steps.restype = C.c_ulonglong
+    data = fixture_bytes["large-sunrise.jpg"]
+    got, _, nsub = _emu_coefs(emu, data, 4096, 256, 0)
+    assert np.array_equal(got, oracle.jpeg_decode_coefs(data, 0))
+    steps = emu.emu_last_spec_steps()
+    assert steps / nsub < 700, steps / nsub                           # 1 054 steps per subsequence one symbol at a time, 519 with the groups
+
+
 def _strip_segments(jpeg, marker):
     """Drop every segment with this marker code between SOI and SOS."""
     out, i = bytearray(jpeg[:2]), 2
