@@ -546,8 +546,6 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
     }
     {   // slots are built in order 0..3 (the second-level pool is handed out in that order); an absent table id is an empty table
         static const uint8_t no_bits[17] = {0}, no_vals[1] = {0};
-        for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, t, h_ok[0][t] ? hbits[0][t] : no_bits, h_ok[0][t] ? hvals[0][t] : no_vals);
-        for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, 2 + t, h_ok[1][t] ? hbits[1][t] : no_bits, h_ok[1][t] ? hvals[1][t] : no_vals);
         int ac_of_dc[2] = {-1, -1}; // the AC slot behind each DC slot, when the scan's components agree on one
         bool clash[2] = {false, false};
         for (int c = 0; c < j.ncomp && c < LP_MAX_COMP; c++) {
@@ -556,7 +554,33 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
             ac_of_dc[d] = j.ac_tbl[c];
         }
         for (int d = 0; d < 2; d++) if (clash[d]) ac_of_dc[d] = -1;
-        lp_build_huff_multi(&out->huff, ac_of_dc);
+        // Most files of a stream carry the same tables (the Annex-K set of every encoder that does not optimise): the set built last on
+        // this thread is kept with the DHT contents it was built from and copied when they come again (24 -> 9 us per header walk).
+        struct Memo { bool valid = false; bool ok[2][2]; uint8_t bits[2][2][17]; uint8_t vals[2][2][256]; int ac_of_dc[2]; LpHuffSet set; };
+        static thread_local Memo* memo = new Memo(); // leaked at thread exit on purpose: 24 KB, and no destructor order to think about
+        bool same = memo->valid && memo->ac_of_dc[0] == ac_of_dc[0] && memo->ac_of_dc[1] == ac_of_dc[1];
+        for (int cls = 0; cls < 2 && same; cls++)
+            for (int t = 0; t < 2 && same; t++)
+                same = memo->ok[cls][t] == h_ok[cls][t] &&
+                       (!h_ok[cls][t] || (memcmp(memo->bits[cls][t], hbits[cls][t], 17) == 0 && memcmp(memo->vals[cls][t], hvals[cls][t], 256) == 0));
+        if (same) {
+            memcpy(&out->huff, &memo->set, sizeof(LpHuffSet));
+        } else {
+            memset(&out->huff, 0, sizeof(LpHuffSet)); // (every byte defined: sets are compared with memcmp when a batch deduplicates them)
+            for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, t, h_ok[0][t] ? hbits[0][t] : no_bits, h_ok[0][t] ? hvals[0][t] : no_vals);
+            for (int t = 0; t < 2; t++) lp_build_huff_slot(&out->huff, 2 + t, h_ok[1][t] ? hbits[1][t] : no_bits, h_ok[1][t] ? hvals[1][t] : no_vals);
+            lp_build_huff_multi(&out->huff, ac_of_dc);
+            memo->valid = false;
+            for (int cls = 0; cls < 2; cls++)
+                for (int t = 0; t < 2; t++) {
+                    memo->ok[cls][t] = h_ok[cls][t];
+                    memcpy(memo->bits[cls][t], hbits[cls][t], 17);
+                    memcpy(memo->vals[cls][t], hvals[cls][t], 256);
+                }
+            memo->ac_of_dc[0] = ac_of_dc[0]; memo->ac_of_dc[1] = ac_of_dc[1];
+            memcpy(&memo->set, &out->huff, sizeof(LpHuffSet));
+            memo->valid = true;
+        }
     }
     // End of the scan: the common case is a file that ends in EOI; otherwise walk the ECS once.
     out->ecs_off = ecs;
