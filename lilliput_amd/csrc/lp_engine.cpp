@@ -1296,7 +1296,15 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
         const bool ycc = j.ncomp == 3 && j.colorspace == 2;
         const uint32_t rwbit = op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
         bool fast = false;
-        if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>
+        // 2- and 4-pixel boxes of a 4:2:0 source (a 512 x 512 or 1024 x 1024 file and a 256 x 256 thumbnail): k_resample_420_small walks tiles of
+        // eight luma columns = four or two boxes, so the boxes must tile that grid exactly
+        const uint32_t nb = op.rw == 2 ? 4u : op.rw == 4 ? 2u : 0u;
+        const bool small_ok = nb && (op.x0 % 8) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3 && (U % nb) == 0;
+        if (ycc && small_ok && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) {   // k_resample_420_small<8 / rw>
+            op.fast = op.rw / 2;
+            fast_mask |= op.rw == 2 ? 0x1000u : 0x2000u;
+            fast = true;
+        } else if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>
             op.fast = op.rw / 2;
             fast_mask |= rwbit;
             fast = true;

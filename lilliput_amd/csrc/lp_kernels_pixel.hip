@@ -322,18 +322,35 @@ __global__ __launch_bounds__(256) void k_resample_fused(const LpJpeg* __restrict
 // h2v2_fancy_upsample (jdsample.c), then the horizontal half, YCbCr->BGR (jdcolor.c) and the integer box sums.
 // RWC = chroma columns per box (box width / 2). Requirements (checked by the host, LpFusedOp::fast): YCbCr 4:2:0,
 // box width in {8,16,32}, even box height, every box starts at a multiple of its width in x and at an even y.
-template <int RWC>
+// NB > 1 (round 5): SMALL boxes -- a thread still walks a tile of 2 RWC = 8 luma columns with the arithmetic above, but the tile is NB
+// boxes side by side (box width 8 / NB: 4 or 2 pixels, LpFusedOp::fast = RWC / NB = 2 or 1) and the clamped pixels are summed per box:
+// one v_sad_u8 per box of four pixels, two v_dot4_u32_u8 with byte masks where a word of four pixels holds two boxes. The host sends
+// an op here when its boxes tile the 8-column grid exactly (x0 a multiple of 8, U a multiple of NB). Before this, 2 x 2 and 4 x 4 boxes
+// -- a 512 x 512 or 1024 x 1024 source and a 256 x 256 thumbnail -- went through k_resample_fused's wave per destination pixel: 30 us
+// per image where the 16 x 16 boxes of a 4096 x 4096 source take 7.4.
+template <int RWC, int NB = 1>
 __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
 {
+    static_assert(NB == 1 || (RWC == 4 && (NB == 2 || NB == 4)), "small boxes: a tile of four chroma columns holds two or four boxes");
     const LpFusedOp& op = ops[blockIdx.y];
-    if (op.fast != (uint32_t)RWC) return;
+    if (op.fast != (uint32_t)(RWC / NB)) return;
     const LpJpeg& img = imgs[op.img];
     const bool swapped = op.dxy != 0;                     // orientations 5..8: destination x runs along source y
-    const uint32_t U = swapped ? op.dst.h : op.dst.w;     // boxes along source x
+    const uint32_t UB = swapped ? op.dst.h : op.dst.w;    // boxes along source x
+    const uint32_t U = UB / NB;                           // ... tiles along source x (NB > 1: the host checked that NB divides UB)
     const uint32_t V = swapped ? op.dst.w : op.dst.h;
-    const uint32_t ublocks = (U + 255u) / 256u;
-    const uint32_t v = blockIdx.x / ublocks, u = (blockIdx.x - v * ublocks) * 256u + threadIdx.x;
-    if (v >= V || u >= U) return;
+    uint32_t v, ut;
+    if (NB == 1) {
+        const uint32_t ublocks = (U + 255u) / 256u;
+        v = blockIdx.x / ublocks; ut = (blockIdx.x - v * ublocks) * 256u + threadIdx.x;
+    } else { // a row of a small thumbnail is a fraction of a workgroup (64 tiles for 256 two-pixel boxes): rows share workgroups
+        const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+        v = gid / U; ut = gid - v * U;
+    }
+    if (v >= V || ut >= U) return;
+    // the tile's boxes in SOURCE order: box j is destination index u0 + j when the destination runs along +x, u0 + NB - 1 - j when mirrored
+    const int32_t stepx = swapped ? op.dyx : op.dxx;
+    const uint32_t u0 = ut * NB, u = (NB > 1 && stepx < 0) ? u0 + (NB - 1) : u0; // u: the box at the tile's lowest x
     const int32_t dx = (int32_t)(swapped ? v : u), dy = (int32_t)(swapped ? u : v);
     const int32_t fx0 = op.x0 + dx * op.dxx + dy * op.dyx, fy0 = op.y0 + dx * op.dxy + dy * op.dyy;
     const uint32_t sy_ = img.plane_stride[0], sc_ = img.plane_stride[1];
@@ -375,10 +392,14 @@ __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ img
     };
     load_row(cy0 - 1, P[0]);
     load_row(cy0, P[1]);
-    uint32_t sb = 0, sg = 0, sr = 0;
+    uint32_t sbx[NB], sgx[NB], srx[NB];                  // per box of the tile (NB == 1: the one box)
+#pragma unroll
+    for (int j = 0; j < NB; j++) sbx[j] = sgx[j] = srx[j] = 0;
     const int32_t KR = 32768 - 128 * FIX16(1.40200), KB = 32768 - 128 * FIX16(1.77200);
     const int32_t KG = 32768 + 128 * FIX16(0.34414) + 128 * FIX16(0.71414);
 #if defined(LP_RESAMPLE_R03) || defined(LP_RESAMPLE_NOSDWA)
+    static_assert(NB == 1, "the timing builds of round 4 know the one-box kernels only");
+    uint32_t &sr = srx[0], &sg = sgx[0], &sb = sbx[0];
     auto sat_pk = [](uint32_t x) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(x)); return d; }; // two signed halves -> two bytes clamped to 0..255
 #endif
     // one step = two luma rows; A / B / C = the chroma rows above, at and below them. (Unrolling three steps so that the row buffers change
@@ -436,32 +457,61 @@ __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ img
                 // One block so that every SDWA write of half a register is at least three instructions away from its reader (gfx940
                 // family: a destination-select write needs one wait state before a VALU read, and the compiler does not look inside).
                 uint32_t r0, r1, g0, g1, b0, b1;
-                asm("v_add_u16_sdwa %[r0], %[tr0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
-                    "v_sub_u16_sdwa %[g0], %[y], %[tg0] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_1\n\t"
-                    "v_add_u16_sdwa %[b0], %[tb0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t"
-                    "v_add_u16_sdwa %[r1], %[tr2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
-                    "v_sub_u16_sdwa %[g1], %[y], %[tg2] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_1\n\t"
-                    "v_add_u16_sdwa %[b1], %[tb2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t"
-                    "v_add_u16_sdwa %[r0], %[tr1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
-                    "v_sub_u16_sdwa %[g0], %[y], %[tg1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:WORD_1\n\t"
-                    "v_add_u16_sdwa %[b0], %[tb1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t"
-                    "v_add_u16_sdwa %[r1], %[tr3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
-                    "v_sub_u16_sdwa %[g1], %[y], %[tg3] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:WORD_1\n\t"
-                    "v_add_u16_sdwa %[b1], %[tb3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t"
-                    "v_sat_pk_u8_i16 %[r0], %[r0]\n\t"
-                    "v_sat_pk_u8_i16 %[g0], %[g0]\n\t"
-                    "v_sat_pk_u8_i16 %[b0], %[b0]\n\t"
-                    "v_sat_pk_u8_i16_sdwa %[r0], %[r1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-                    "v_sat_pk_u8_i16_sdwa %[g0], %[g1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+#define LP_RS_PIXELS \
+                    "v_add_u16_sdwa %[r0], %[tr0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t" \
+                    "v_sub_u16_sdwa %[g0], %[y], %[tg0] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_1\n\t" \
+                    "v_add_u16_sdwa %[b0], %[tb0], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0\n\t" \
+                    "v_add_u16_sdwa %[r1], %[tr2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t" \
+                    "v_sub_u16_sdwa %[g1], %[y], %[tg2] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_1\n\t" \
+                    "v_add_u16_sdwa %[b1], %[tb2], %[y] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2\n\t" \
+                    "v_add_u16_sdwa %[r0], %[tr1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t" \
+                    "v_sub_u16_sdwa %[g0], %[y], %[tg1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:WORD_1\n\t" \
+                    "v_add_u16_sdwa %[b0], %[tb1], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1\n\t" \
+                    "v_add_u16_sdwa %[r1], %[tr3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t" \
+                    "v_sub_u16_sdwa %[g1], %[y], %[tg3] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:WORD_1\n\t" \
+                    "v_add_u16_sdwa %[b1], %[tb3], %[y] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3\n\t" \
+                    "v_sat_pk_u8_i16 %[r0], %[r0]\n\t" \
+                    "v_sat_pk_u8_i16 %[g0], %[g0]\n\t" \
+                    "v_sat_pk_u8_i16 %[b0], %[b0]\n\t" \
+                    "v_sat_pk_u8_i16_sdwa %[r0], %[r1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t" \
+                    "v_sat_pk_u8_i16_sdwa %[g0], %[g1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t" \
                     "v_sat_pk_u8_i16_sdwa %[b0], %[b1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
-                    "v_sad_u8 %[sr], %[r0], 0, %[sr]\n\t"
-                    "v_sad_u8 %[sg], %[g0], 0, %[sg]\n\t"
-                    "v_sad_u8 %[sb], %[b0], 0, %[sb]"
-                    : [r0] "=&v"(r0), [r1] "=&v"(r1), [g0] "=&v"(g0), [g1] "=&v"(g1), [b0] "=&v"(b0), [b1] "=&v"(b1),
-                      [sr] "+v"(sr), [sg] "+v"(sg), [sb] "+v"(sb)
-                    : [y] "v"(y4), [tr0] "v"(Tr[0]), [tr1] "v"(Tr[1]), [tr2] "v"(Tr[2]), [tr3] "v"(Tr[3]),
+                if constexpr (NB == 1) {        // the four pixels of the word belong to the thread's one box
+                    asm(LP_RS_PIXELS
+                        "v_sad_u8 %[sr], %[r0], 0, %[sr]\n\t"
+                        "v_sad_u8 %[sg], %[g0], 0, %[sg]\n\t"
+                        "v_sad_u8 %[sb], %[b0], 0, %[sb]"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [g0] "=&v"(g0), [g1] "=&v"(g1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+                          [sr] "+v"(srx[0]), [sg] "+v"(sgx[0]), [sb] "+v"(sbx[0])
+                        : [y] "v"(y4), [tr0] "v"(Tr[0]), [tr1] "v"(Tr[1]), [tr2] "v"(Tr[2]), [tr3] "v"(Tr[3]),
                       [tg0] "v"(Tg[0]), [tg1] "v"(Tg[1]), [tg2] "v"(Tg[2]), [tg3] "v"(Tg[3]),
                       [tb0] "v"(Tb[0]), [tb1] "v"(Tb[1]), [tb2] "v"(Tb[2]), [tb3] "v"(Tb[3]));
+                } else if constexpr (NB == 2) { // ... to box i / 2 of the tile
+                    asm(LP_RS_PIXELS
+                        "v_sad_u8 %[sr], %[r0], 0, %[sr]\n\t"
+                        "v_sad_u8 %[sg], %[g0], 0, %[sg]\n\t"
+                        "v_sad_u8 %[sb], %[b0], 0, %[sb]"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [g0] "=&v"(g0), [g1] "=&v"(g1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+                          [sr] "+v"(srx[(i >> 1) % NB]), [sg] "+v"(sgx[(i >> 1) % NB]), [sb] "+v"(sbx[(i >> 1) % NB])
+                        : [y] "v"(y4), [tr0] "v"(Tr[0]), [tr1] "v"(Tr[1]), [tr2] "v"(Tr[2]), [tr3] "v"(Tr[3]),
+                      [tg0] "v"(Tg[0]), [tg1] "v"(Tg[1]), [tg2] "v"(Tg[2]), [tg3] "v"(Tg[3]),
+                      [tb0] "v"(Tb[0]), [tb1] "v"(Tb[1]), [tb2] "v"(Tb[2]), [tb3] "v"(Tb[3]));
+                } else {                        // two boxes of two pixels: the lower and the upper two bytes of the word
+                    asm(LP_RS_PIXELS
+                        "v_dot4_u32_u8 %[srl], %[r0], %[mlo], %[srl]\n\t"
+                        "v_dot4_u32_u8 %[sgl], %[g0], %[mlo], %[sgl]\n\t"
+                        "v_dot4_u32_u8 %[sbl], %[b0], %[mlo], %[sbl]\n\t"
+                        "v_dot4_u32_u8 %[srh], %[r0], %[mhi], %[srh]\n\t"
+                        "v_dot4_u32_u8 %[sgh], %[g0], %[mhi], %[sgh]\n\t"
+                        "v_dot4_u32_u8 %[sbh], %[b0], %[mhi], %[sbh]"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [g0] "=&v"(g0), [g1] "=&v"(g1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+                          [srl] "+v"(srx[i % NB]), [sgl] "+v"(sgx[i % NB]), [sbl] "+v"(sbx[i % NB]),
+                          [srh] "+v"(srx[(i + 1) % NB]), [sgh] "+v"(sgx[(i + 1) % NB]), [sbh] "+v"(sbx[(i + 1) % NB])
+                        : [y] "v"(y4), [tr0] "v"(Tr[0]), [tr1] "v"(Tr[1]), [tr2] "v"(Tr[2]), [tr3] "v"(Tr[3]),
+                      [tg0] "v"(Tg[0]), [tg1] "v"(Tg[1]), [tg2] "v"(Tg[2]), [tg3] "v"(Tg[3]),
+                      [tb0] "v"(Tb[0]), [tb1] "v"(Tb[1]), [tb2] "v"(Tb[2]), [tb3] "v"(Tb[3]), [mlo] "s"(0x00000101u), [mhi] "s"(0x01010000u));
+                }
+#undef LP_RS_PIXELS
 #else
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -506,14 +556,19 @@ __device__ __forceinline__ void resample_420_body(const LpJpeg* __restrict__ img
 #pragma unroll
         for (int i = 0; i < RWC + 2; i++) { P[0][i] = P[1][i]; P[1][i] = P[2][i]; }
     }
-    uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    const int32_t sums[3] = {(int32_t)sb, (int32_t)sg, (int32_t)sr};
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        uint32_t r;
-        if (op.round_2x2) r = (uint32_t)(sums[c] + 2) >> 2;
-        else r = sat_round_u8(__fmul_rn((float)sums[c], op.inv_area));
-        D[c] = (uint8_t)r;
+    for (int j = 0; j < NB; j++) { // box j of the tile in source order
+        const uint32_t uj = NB == 1 ? u : stepx < 0 ? u0 + (uint32_t)(NB - 1 - j) : u0 + (uint32_t)j;
+        const int32_t bdx = (int32_t)(swapped ? v : uj), bdy = (int32_t)(swapped ? uj : v);
+        uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)bdy * op.dst.stride + (size_t)bdx * 3;
+        const int32_t sums[3] = {(int32_t)sbx[j], (int32_t)sgx[j], (int32_t)srx[j]};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            uint32_t r;
+            if (op.round_2x2) r = (uint32_t)(sums[c] + 2) >> 2;
+            else r = sat_round_u8(__fmul_rn((float)sums[c], op.inv_area));
+            D[c] = (uint8_t)r;
+        }
     }
 }
 
@@ -539,6 +594,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE
                                                                                                              const uint8_t* __restrict__ plane_arena)
 {
     resample_420_body<8>(imgs, ops, plane_arena);
+}
+
+// Small boxes (2 x 2 and 4 x 4 pixels: NB = 4 / 2 boxes per 8-column tile), see resample_420_body
+template <int NB>
+__global__ __launch_bounds__(256) void k_resample_420_small(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
+{
+    resample_420_body<4, NB>(imgs, ops, plane_arena);
 }
 
 // K_resample fast path for YCbCr 4:4:4 (HR = 1) and 4:2:2 (HR = 2, h2v1_fancy_upsample): same thread-per-thumbnail-pixel walk as
@@ -1420,6 +1482,8 @@ void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFused
     if (fast_mask & 1u) hipLaunchKernelGGL(k_resample_420<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 2u) hipLaunchKernelGGL(k_resample_420<8>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 4u) hipLaunchKernelGGL(k_resample_420<16>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x1000u) hipLaunchKernelGGL(k_resample_420_small<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes); // 2-pixel boxes
+    if (fast_mask & 0x2000u) hipLaunchKernelGGL(k_resample_420_small<2>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes); // 4-pixel boxes
     if (fast_mask & 0x10u) hipLaunchKernelGGL((k_resample_hv1<8, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 0x20u) hipLaunchKernelGGL((k_resample_hv1<16, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 0x40u) hipLaunchKernelGGL((k_resample_hv1<32, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);

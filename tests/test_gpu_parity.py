@@ -623,6 +623,38 @@ def test_fused_resample_all_orientations_integer_scales(batch, oracle):
                 assert r.data == oracle.jpeg_encode(frame, 85), (info["width"], info["height"], o, norm, tw, th)
 
 
+@pytest.mark.gpu
+def test_small_box_resample_all_orientations(batch, oracle):
+    """2 x 2 and 4 x 4 boxes (a source two or four times the thumbnail: k_resample_420_small, four or two boxes per 8-column tile of a
+    4:2:0 source) against decode -> ExifTransform -> crop -> resizeAreaFast_ on the CPU, every orientation, with and without
+    normalisation. Bit-exact, encoder included. Crops that start off the 8-column grid, box counts that do not fill whole tiles and
+    the other samplings take the general kernel: same answer."""
+    from PIL import Image
+
+    from lilliput_amd import synth
+
+    rgb = synth.synth_rgb(12, 512)
+    cases = []
+    for (w, h, tw, th, ss) in ((256, 256, 128, 128, 2), (256, 256, 64, 64, 2), (512, 512, 256, 256, 2), (512, 384, 128, 96, 2), (288, 256, 128, 128, 2),
+                               (272, 256, 128, 128, 2), (264, 256, 128, 128, 2), (252, 252, 126, 126, 2), (256, 248, 62, 62, 2), (250, 244, 125, 122, 2),
+                               (320, 256, 64, 64, 2), (512, 128, 128, 32, 2), (128, 512, 32, 128, 2), (16, 16, 8, 8, 2), (8, 8, 2, 2, 2),
+                               (256, 256, 128, 128, 0), (256, 256, 64, 64, 1)):
+        im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
+        b = io.BytesIO()
+        im.save(b, "JPEG", quality=92, subsampling=ss)
+        cases.append((b.getvalue(), tw, th))
+    for data, tw, th in cases:
+        for o in range(1, 9):
+            d = _with_exif_orientation(data, o)
+            for norm in (False, True):
+                r = batch.transform([d], tw, th, normalize=norm, quality=85)[0]
+                assert r.status == 0
+                info = oracle.jpeg_info(d)
+                frame = oracle.transform_static(oracle.jpeg_decode(d), o, tw, th, oracle.FIT, norm)
+                assert (r.width, r.height) == (frame.shape[1], frame.shape[0]), (o, norm, tw, th)
+                assert r.data == oracle.jpeg_encode(frame, 85), (info["width"], info["height"], o, norm, tw, th)
+
+
 # ------------------------------------------------------------------------------------------ Part A as unchanged ops.go calls it
 def _part_a_run(la, sources, threads, jobs, w, h, method, deferred, quality=85, dst_cap=0):
     la.lib().lilliput_hip_set_deferred(1 if deferred else 0)
