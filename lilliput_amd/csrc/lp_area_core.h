@@ -25,6 +25,11 @@ struct LpArea420Op {
     uint32_t xrange_off, yrange_off;    // into the range arena: [dw + 1] / [dh + 1] tap ranges
     uint32_t maxt;                      // 6 / 10 / 18 / 34 / 66: which instantiation takes it
     uint32_t transposed;                // orientations 5-8 (k_area_420t): x0 / xstep place the Y taps along source x, y0 / ystep the X taps along source y; maxt counts y taps
+    // Integer scales (round 5): cv::resize's resizeAreaFast_ -- the integer sum of the box, then saturate_cast<uchar>(sum * (1 / area)), or
+    // (sum + 2) >> 2 for 2 x 2 boxes (ResizeAreaFastVec_SIMD_8u) -- through the same walk: every tap carries weight 1 (the float sums of at
+    // most 66 x 66 bytes are exact integers) and the result is finished by `post`. Fractional scales: post = 1 (x * 1.f == x), half_up = 0.
+    float post;                         // the sum is multiplied by this before it is rounded (half to even) and clamped
+    uint32_t half_up;                   // 1: (sum + 2) >> 2 instead
     LpFrame dst;
 };
 
@@ -141,6 +146,13 @@ LPA_HD uint32_t lpa_round_u8(float v) // saturate_cast<uchar>(float): cvRound (h
     const int32_t i = (int32_t)__builtin_lrintf(v);
 #endif
     return (uint32_t)(i < 0 ? 0 : i > 255 ? 255 : i);
+}
+
+// the sum of a destination pixel -> its byte: fractional scales round the sum itself (post == 1); integer scales see LpArea420Op::post
+LPA_HD uint8_t lpa_finish(float sum, float post, uint32_t half_up)
+{
+    if (half_up) return (uint8_t)(((uint32_t)(int32_t)sum + 2u) >> 2); // four bytes: at most 1020, an exact float
+    return (uint8_t)lpa_round_u8(lpa_mul(sum, post));
 }
 
 LPA_HD int32_t lpa_mad24(int32_t a, int32_t b, int32_t c) // a * b + c, both factors within 24 bits
@@ -356,7 +368,7 @@ LPA_HD void lpa_row(const LpAreaPlanes& P, const LpaPlane& PY, const LpaPlane& P
 // resize.cpp ResizeArea_Invoker: per source row buf = sum over the x taps of value * alpha; sum += beta * buf.
 template <int MAXT, int SS, bool FLIPX>
 LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al)[MAXT], const LpTap* __restrict__ yt, uint32_t y0, uint32_t y1,
-                             int32_t ybase, int32_t ystep, uint8_t* __restrict__ out)
+                             int32_t ybase, int32_t ystep, uint8_t* __restrict__ out, float post = 1.f, uint32_t half_up = 0)
 {
 #pragma clang fp contract(off) // every product is rounded before it is added, as in resize.cpp's scalar loops
     constexpr int NX = LpaWindow<MAXT, SS>::NX;
@@ -385,7 +397,7 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
         sbg = sbg + bb * bg;
         sum_r = lpa_add(sum_r, lpa_mul(beta, rs));
     }
-    out[0] = (uint8_t)lpa_round_u8(sbg.x); out[1] = (uint8_t)lpa_round_u8(sbg.y); out[2] = (uint8_t)lpa_round_u8(sum_r);
+    out[0] = lpa_finish(sbg.x, post, half_up); out[1] = lpa_finish(sbg.y, post, half_up); out[2] = lpa_finish(sum_r, post, half_up);
 }
 
 // ---- orientations 5-8: destination x runs along source y --------------------------------------------------------------------------
@@ -398,7 +410,7 @@ LPA_HD void lp_area420_pixel(const LpAreaPlanes& P, int32_t xa, const float (&al
 //   xt, x0..x1, rbase, rstep  the destination column's taps (wave-uniform): source row = rbase + rstep * xt[k].si
 template <int MAXT, int SS, bool FLIPC>
 LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&be)[MAXT], const LpTap* __restrict__ xt, uint32_t x0, uint32_t x1,
-                              int32_t rbase, int32_t rstep, uint8_t* __restrict__ out)
+                              int32_t rbase, int32_t rstep, uint8_t* __restrict__ out, float post = 1.f, uint32_t half_up = 0)
 {
 #pragma clang fp contract(off)
     constexpr int NX = LpaWindow<MAXT, SS>::NX;
@@ -432,5 +444,5 @@ LPA_HD void lp_area420t_pixel(const LpAreaPlanes& P, int32_t xa, const float (&b
         sbg = sbg + ww * bg[c];
         sum_r = lpa_add(sum_r, lpa_mul(w[c], rs[c]));
     }
-    out[0] = (uint8_t)lpa_round_u8(sbg.x); out[1] = (uint8_t)lpa_round_u8(sbg.y); out[2] = (uint8_t)lpa_round_u8(sum_r);
+    out[0] = lpa_finish(sbg.x, post, half_up); out[1] = lpa_finish(sbg.y, post, half_up); out[2] = lpa_finish(sum_r, post, half_up);
 }

@@ -485,6 +485,24 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
             uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);
             if (!p) return fail("frame heap exhausted");
             op.dst.off = (uint64_t)(uintptr_t)p;
+            // A box none of the thread-per-box kernels takes (3, 5, 6, 12 ... pixels wide, a crop off their grid, 2- and 4-pixel boxes of
+            // 4:2:2 / 4:4:4 sources) would cost a whole wave per destination pixel in the general kernel (33 - 58 us per image against
+            // 7.4 for the 16 x 16 boxes of the headline); the area walk does it as unit taps instead (LpArea420Op::post: same integers)
+            const bool swapped_src = j.orientation >= 5;
+            if (area_on && !lp_fused_op_is_fast(op, j) && lp_area_sampling(j) >= 0 &&
+                lp_area420_bucket_int(swapped_src ? iy : ix, swapped_src) != 0) {
+                LpAreaReq rq;
+                memset(&rq, 0, sizeof(rq));
+                rq.img = (uint32_t)k;
+                lp_area420_place((int)j.orientation, (int)j.width, (int)j.height, plan.crop_x, plan.crop_y, &rq);
+                rq.crop_w = (uint32_t)plan.crop_w; rq.crop_h = (uint32_t)plan.crop_h;
+                rq.int_x = (uint32_t)ix; rq.int_y = (uint32_t)iy;
+                rq.dst = op.dst;
+                areqs.push_back(rq);
+                aidx.push_back(k);
+                want[(size_t)k] = 0;
+                continue;
+            }
             fops.push_back(op);
             fidx.push_back(k);
             want[(size_t)k] = 0;

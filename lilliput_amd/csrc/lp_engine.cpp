@@ -1276,6 +1276,38 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     return LP_OK;
 }
 
+// Which thread-per-box kernel takes a fused op, if any (LpFusedOp::fast and the launch-mask bit of lp_launch_resample_fused).
+bool lp_fused_op_is_fast(const LpFusedOp& op, const LpJpeg& j, uint32_t* fast_out, uint32_t* mask_bit)
+{
+    // the 4:2:0 thread-per-pixel kernel needs aligned, even boxes (see k_resample_420)
+    const bool swapped = op.dxy != 0;
+    const uint32_t U = swapped ? op.dst.h : op.dst.w;
+    const int32_t stepx = swapped ? op.dyx : op.dxx;  // source-x step between neighbouring boxes: +-rw
+    const bool rw_ok = op.rw == 8 || op.rw == 16 || op.rw == 32;
+    const bool steps = stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw;
+    const bool aligned = rw_ok && (op.x0 % (int32_t)op.rw) == 0 && steps && op.dst.cn == 3;
+    const bool ycc = j.ncomp == 3 && j.colorspace == 2;
+    const uint32_t rwbit = op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
+    // 2- and 4-pixel boxes of a 4:2:0 source (a 512 x 512 or 1024 x 1024 file and a 256 x 256 thumbnail): k_resample_420_small walks tiles of
+    // eight luma columns = four or two boxes, so the boxes must tile that grid exactly
+    const uint32_t nb = op.rw == 2 ? 4u : op.rw == 4 ? 2u : 0u;
+    const bool small_ok = nb && (op.x0 % 8) == 0 && steps && op.dst.cn == 3 && (U % nb) == 0;
+    uint32_t fast = 0, bit = 0;
+    if (ycc && small_ok && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) {   // k_resample_420_small<8 / rw>
+        fast = op.rw / 2;
+        bit = op.rw == 2 ? 0x1000u : 0x2000u;
+    } else if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>
+        fast = op.rw / 2;
+        bit = rwbit;
+    } else if (ycc && aligned && j.vs[0] == 1 && (j.hs[0] == 1 || j.hs[0] == 2)) {         // k_resample_hv1<rw, hs>: 4:4:4 / 4:2:2
+        fast = 0x100u * (1u + j.hs[0]) + op.rw;
+        bit = rwbit << (j.hs[0] == 1 ? 4 : 8);
+    }
+    if (fast_out) *fast_out = fast;
+    if (mask_bit) *mask_bit = bit;
+    return fast != 0;
+}
+
 int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
 {
     if (!ok_) return LP_ERR_DEVICE;
@@ -1286,38 +1318,15 @@ int LpEngine::fused_resample(const LpFusedOp* ops_in, int n)
     uint32_t max_px = 0, fast_mask = 0, fast_grid = 0;
     bool general = false;
     for (auto& op : ops) {
-        // the 4:2:0 thread-per-pixel kernel needs aligned, even boxes (see k_resample_420)
         const LpJpeg& j = h_imgs_[op.img];
         const bool swapped = op.dxy != 0;
         const uint32_t U = swapped ? op.dst.h : op.dst.w, V = swapped ? op.dst.w : op.dst.h;
-        const int32_t stepx = swapped ? op.dyx : op.dxx;  // source-x step between neighbouring boxes: +-rw
-        const bool rw_ok = op.rw == 8 || op.rw == 16 || op.rw == 32;
-        const bool aligned = rw_ok && (op.x0 % (int32_t)op.rw) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3;
-        const bool ycc = j.ncomp == 3 && j.colorspace == 2;
-        const uint32_t rwbit = op.rw == 8 ? 1u : op.rw == 16 ? 2u : 4u;
-        bool fast = false;
-        // 2- and 4-pixel boxes of a 4:2:0 source (a 512 x 512 or 1024 x 1024 file and a 256 x 256 thumbnail): k_resample_420_small walks tiles of
-        // eight luma columns = four or two boxes, so the boxes must tile that grid exactly
-        const uint32_t nb = op.rw == 2 ? 4u : op.rw == 4 ? 2u : 0u;
-        const bool small_ok = nb && (op.x0 % 8) == 0 && (stepx == (int32_t)op.rw || stepx == -(int32_t)op.rw) && op.dst.cn == 3 && (U % nb) == 0;
-        if (ycc && small_ok && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) {   // k_resample_420_small<8 / rw>
-            op.fast = op.rw / 2;
-            fast_mask |= op.rw == 2 ? 0x1000u : 0x2000u;
-            fast = true;
-        } else if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>
-            op.fast = op.rw / 2;
-            fast_mask |= rwbit;
-            fast = true;
-        } else if (ycc && aligned && j.vs[0] == 1 && (j.hs[0] == 1 || j.hs[0] == 2)) {         // k_resample_hv1<rw, hs>: 4:4:4 / 4:2:2
-            op.fast = 0x100u * (1u + j.hs[0]) + op.rw;
-            fast_mask |= rwbit << (j.hs[0] == 1 ? 4 : 8);
-            fast = true;
-        } else {
-            op.fast = 0;
-        }
-        if (fast) {
+        uint32_t bit = 0;
+        if (lp_fused_op_is_fast(op, j, &op.fast, &bit)) {
+            fast_mask |= bit;
             fast_grid = std::max(fast_grid, V * ((U + 255u) / 256u));
         } else {
+            op.fast = 0;
             general = true;
             max_px = std::max(max_px, op.dst.w * op.dst.h);
         }
@@ -1364,6 +1373,24 @@ uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed)
     return transposed && b > 34 ? 0 : b;
 }
 
+uint32_t lp_area420_bucket_int(int scale, bool transposed)
+{
+    if (scale < 2 || scale > 66) return 0;
+    const uint32_t b = scale <= 6 ? 6u : scale <= 10 ? 10u : scale <= 18 ? 18u : scale <= 34 ? 34u : 66u;
+    return transposed && b > 34 ? 0 : b;
+}
+
+// resizeAreaFast_'s boxes as a tap table: destination dx takes the `scale` source columns from dx * scale, weight 1 each
+static void area_tab_int(int dsize, int scale, std::vector<LpTap>& taps, std::vector<uint32_t>& ranges)
+{
+    const uint32_t base = (uint32_t)taps.size();
+    for (int dx = 0; dx < dsize; dx++) {
+        ranges.push_back((uint32_t)taps.size() - base);
+        for (int k = 0; k < scale; k++) taps.push_back(LpTap{(uint32_t)(dx * scale + k), 1.f});
+    }
+    ranges.push_back((uint32_t)taps.size() - base);
+}
+
 int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
 {
     if (!ok_) return LP_ERR_DEVICE;
@@ -1390,13 +1417,18 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
         op.transposed = r.transposed ? 1u : 0u;
         op.dst = r.dst; op.dst.cn = 3;
         if (!op.dst.stride) op.dst.stride = r.dst.w * 3;
-        const auto kx = std::make_pair((int)r.crop_w, (int)r.dst.w), ky = std::make_pair((int)r.crop_h, (int)r.dst.h);
+        // integer scales: unit taps (keyed by a negative source size: -scale) and the finish of resizeAreaFast_
+        const bool integer = r.int_x && r.int_y;
+        op.post = integer ? 1.f / (float)(r.int_x * r.int_y) : 1.f;
+        op.half_up = integer && r.int_x == 2 && r.int_y == 2 ? 1u : 0u;
+        const auto kx = std::make_pair(integer ? -(int)r.int_x : (int)r.crop_w, (int)r.dst.w), ky = std::make_pair(integer ? -(int)r.int_y : (int)r.crop_h, (int)r.dst.h);
         for (int ax = 0; ax < 2; ax++) {
             const auto key = ax ? ky : kx;
             auto it = cache.find(key);
             if (it == cache.end()) {
                 const uint32_t to = (uint32_t)taps.size(), ro = (uint32_t)ranges.size();
-                lp_area_tab(key.first, key.second, taps, ranges);
+                if (integer) area_tab_int(key.second, -key.first, taps, ranges);
+                else lp_area_tab(key.first, key.second, taps, ranges);
                 it = cache.emplace(key, std::make_pair(to, ro)).first;
             }
             if (ax) { op.ytab_off = it->second.first; op.yrange_off = it->second.second; }

@@ -77,6 +77,8 @@ struct LpAreaReq {
     int32_t x0, y0, xstep, ystep;
     uint32_t crop_w, crop_h;
     uint32_t transposed;
+    uint32_t int_x, int_y;       // 0: fractional scale (cv::resize's resizeArea_); otherwise the integer scale factors of crop -> dst along the oriented
+                                 // frame's x and y (resizeAreaFast_: unit taps, sum * 1 / (int_x * int_y), or (sum + 2) >> 2 for 2 x 2)
     LpFrame dst;
 };
 
@@ -313,6 +315,11 @@ int lp_area_tab(int ssize, int dsize, std::vector<LpTap>& taps, std::vector<uint
 // (the axis meant is the one that runs along source x: the crop's x axis, or its y axis for the transposing orientations, whose
 // kernel stops at 34 taps)
 uint32_t lp_area420_bucket(int ssize, int dsize, bool transposed = false);
+// ... of an integer scale: the taps of a destination pixel are the `scale` columns of its box
+uint32_t lp_area420_bucket_int(int scale, bool transposed = false);
+// Would fused_resample hand this op to one of the thread-per-box kernels (k_resample_420 / _small / _hv1)? Otherwise its wave-per-pixel
+// kernel takes it, which the batch path avoids where the area walk can do the box instead.
+bool lp_fused_op_is_fast(const LpFusedOp& op, const LpJpeg& j, uint32_t* fast = nullptr, uint32_t* mask_bit = nullptr);
 // which chroma layout of k_area_420 an image has: 2 = YCbCr 4:2:0, 1 = 4:2:2, 0 = 4:4:4, -1 = none of them (frame route)
 int lp_area_sampling(const LpJpeg& j);
 // fills x0 / xstep / y0 / ystep / transposed of a request from the EXIF orientation (cv::ExifTransform's inverse), the decoded size and

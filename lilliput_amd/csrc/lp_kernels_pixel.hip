@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void k_area_420(const LpJpeg* __restrict__ img
     const int32_t si0 = (int32_t)xt[0].si;
     const int32_t xa = FLIPX ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    lp_area420_pixel<MAXT, SS, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D);
+    lp_area420_pixel<MAXT, SS, FLIPX>(P, xa, al, taps + op.ytab_off, y0, y1, op.y0, op.ystep, D, op.post, op.half_up);
 }
 
 // The same for the orientations that swap the axes (5-8): the lanes of a wave are 64 neighbouring destination ROWS of one destination
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void k_area_420t(const LpJpeg* __restrict__ im
     const int32_t si0 = (int32_t)yt[0].si;
     const int32_t xa = FLIPC ? op.x0 - si0 - (MAXT - 1) : op.x0 + si0;
     uint8_t* D = reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off) + (size_t)dy * op.dst.stride + (size_t)dx * 3;
-    lp_area420t_pixel<MAXT, SS, FLIPC>(P, xa, be, taps + op.xtab_off, x0, x1, op.y0, op.ystep, D);
+    lp_area420t_pixel<MAXT, SS, FLIPC>(P, xa, be, taps + op.xtab_off, x0, x1, op.y0, op.ystep, D, op.post, op.half_up);
 }
 
 // INTER_AREA with an up-scaling axis: bilinear, area-style coefficients, 11-bit fixed point

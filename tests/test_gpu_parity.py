@@ -627,8 +627,9 @@ def test_fused_resample_all_orientations_integer_scales(batch, oracle):
 def test_small_box_resample_all_orientations(batch, oracle):
     """2 x 2 and 4 x 4 boxes (a source two or four times the thumbnail: k_resample_420_small, four or two boxes per 8-column tile of a
     4:2:0 source) against decode -> ExifTransform -> crop -> resizeAreaFast_ on the CPU, every orientation, with and without
-    normalisation. Bit-exact, encoder included. Crops that start off the 8-column grid, box counts that do not fill whole tiles and
-    the other samplings take the general kernel: same answer."""
+    normalisation. Bit-exact, encoder included. Crops that start off the 8-column grid, box counts that do not fill whole tiles, the
+    other samplings and the box sizes between the kernels' (3, 5, 6, 12 ...) take the area walk with unit taps (LpArea420Op::post) --
+    the integer sums of resizeAreaFast_ as exact floats: same answer."""
     from PIL import Image
 
     from lilliput_amd import synth
@@ -638,7 +639,11 @@ def test_small_box_resample_all_orientations(batch, oracle):
     for (w, h, tw, th, ss) in ((256, 256, 128, 128, 2), (256, 256, 64, 64, 2), (512, 512, 256, 256, 2), (512, 384, 128, 96, 2), (288, 256, 128, 128, 2),
                                (272, 256, 128, 128, 2), (264, 256, 128, 128, 2), (252, 252, 126, 126, 2), (256, 248, 62, 62, 2), (250, 244, 125, 122, 2),
                                (320, 256, 64, 64, 2), (512, 128, 128, 32, 2), (128, 512, 32, 128, 2), (16, 16, 8, 8, 2), (8, 8, 2, 2, 2),
-                               (256, 256, 128, 128, 0), (256, 256, 64, 64, 1)):
+                               (256, 256, 128, 128, 0), (256, 256, 64, 64, 1),
+                               # boxes no thread-per-box kernel takes: the area walk with unit taps (3, 5, 6, 12, 20 pixels; 2 x 2 off the grid or 4:4:4 / 4:2:2)
+                               (384, 384, 128, 128, 2), (320, 320, 64, 64, 2), (384, 192, 64, 32, 2), (288, 288, 24, 24, 2), (300, 200, 100, 100, 2),
+                               (384, 384, 128, 128, 0), (320, 320, 64, 64, 1), (288, 288, 24, 24, 0), (300, 200, 100, 100, 1), (400, 400, 20, 20, 2),
+                               (330, 330, 110, 110, 2), (510, 510, 15, 15, 2), (512, 512, 8, 8, 2), (501, 334, 167, 167, 2)):
         im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
         b = io.BytesIO()
         im.save(b, "JPEG", quality=92, subsampling=ss)
