@@ -1066,13 +1066,20 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         // chunk: LILLIPUT_HIP_PIPE_CHUNK images (default 32) -- small enough that the first chunk's copy is short, large enough to fill the device
         static const size_t pipe_chunk = getenv("LILLIPUT_HIP_PIPE_CHUNK") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PIPE_CHUNK"))) : 32;
         const size_t chunk = opt->chunk > 0 ? (size_t)opt->chunk : pipe_chunk;
+        // Small sources (round 5): a chunk of 32 files of 100 KB is 3 MB -- twenty launches and their waits for 0.2 ms of kernels
+        // (512 x 512 sources ran at 66 k images/s end to end against 184 k resident). Beyond its first `chunk` items a chunk goes on while it
+        // holds less than LILLIPUT_HIP_PIPE_CHUNK_MB (default 128: what 32 of the 4 MB headline sources weigh) and fewer than its share of a
+        // queue that gives every engine four chunks; an explicit chunk size (option or environment) is taken as it is.
+        static const size_t pipe_chunk_bytes = (getenv("LILLIPUT_HIP_PIPE_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PIPE_CHUNK_MB"))) : 128) << 20;
+        const bool grow = opt->chunk <= 0 && !getenv("LILLIPUT_HIP_PIPE_CHUNK");
+        const size_t chunk_max = grow ? std::max(chunk, std::min<size_t>(1024, n / std::max<size_t>(1, 4 * np * devs.size()))) : chunk;
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
             LpPipeJob job;
             job.i0 = i;
             size_t bytes = 0, cnt = 0;
-            while (i < n && cnt < chunk && (cnt == 0 || bytes + items[i].src_len <= (1ull << 30))) { bytes += items[i].src_len; cnt++; i++; }
+            while (i < n && (cnt < chunk ? (cnt == 0 || bytes + items[i].src_len <= (1ull << 30)) : (cnt < chunk_max && bytes + items[i].src_len <= pipe_chunk_bytes))) { bytes += items[i].src_len; cnt++; i++; }
             job.i1 = i;
             sh.jobs.push_back(std::move(job));
         }
