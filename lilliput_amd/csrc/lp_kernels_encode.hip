@@ -40,6 +40,32 @@ __device__ __forceinline__ void load_bgr(const LpFrame& f, const uint8_t* __rest
     b = p[0];
     if (f.cn == 1) { g = b; r = b; } else { g = p[1]; r = p[2]; }
 }
+// N consecutive pixels of row y from column x (N = 8 or 16) as packed 0x00RRGGBB words. Inside the frame, with three channels and a
+// dword-aligned run (a frame whose width is a multiple of four, the usual thumbnail), the run is 3 N / 4 dword loads; otherwise the
+// per-pixel route with its edge replication (the FDCT kernel issued 9 byte loads per pixel: 0.58 of the encoder's 1.0 us per image).
+template <int N>
+__device__ __forceinline__ void load_bgr_run(const LpFrame& f, const uint8_t* __restrict__ base, int32_t x, int32_t y, uint32_t (&px)[N])
+{
+    const uint8_t* p = base + f.off + (size_t)(y > (int32_t)f.h - 1 ? (int32_t)f.h - 1 : y) * f.stride + (size_t)x * 3;
+    if (f.cn == 3 && x + N <= (int32_t)f.w && y < (int32_t)f.h && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        uint32_t w[3 * N / 4];
+#pragma unroll
+        for (int i = 0; i < 3 * N / 4; i++) w[i] = reinterpret_cast<const uint32_t*>(p)[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) { // pixel i = bytes 3 i .. 3 i + 2 of the run
+            const int b0 = 3 * i, q = b0 >> 2, sh = (b0 & 3) * 8;
+            px[i] = (sh == 0 ? w[q] : sh == 8 ? w[q] >> 8 : __builtin_amdgcn_alignbit(w[(q + 1) % (3 * N / 4)], w[q], sh)) & 0xffffffu;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t b, g, r;
+            load_bgr(f, base, x + i, y, b, g, r);
+            px[i] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+        }
+    }
+}
+
 __device__ __forceinline__ int32_t to_y(int32_t b, int32_t g, int32_t r) { return (FIX16(0.29900) * r + FIX16(0.58700) * g + FIX16(0.11400) * b + 32768) >> 16; }
 __device__ __forceinline__ int32_t to_cb(int32_t b, int32_t g, int32_t r) { return (-FIX16(0.16874) * r - FIX16(0.33126) * g + FIX16(0.50000) * b + (128 << 16) + 32767) >> 16; }
 __device__ __forceinline__ int32_t to_cr(int32_t b, int32_t g, int32_t r) { return (FIX16(0.50000) * r - FIX16(0.41869) * g - FIX16(0.08131) * b + (128 << 16) + 32767) >> 16; }
@@ -89,21 +115,26 @@ __global__ __launch_bounds__(256) void k_enc_fdct(const LpEncJob* __restrict__ j
     } else if (k < 4) {
         const uint32_t bx = mx * 2 + (k & 1), by = my * 2 + (k >> 1);
         dummy = bx >= job.wib || by >= job.hib;
+        uint32_t px[8];
+        load_bgr_run<8>(job.src, frames, (int32_t)bx * 8, (int32_t)by * 8 + (int32_t)r, px);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { int32_t b, g, rr; load_bgr(job.src, frames, (int32_t)bx * 8 + i, (int32_t)by * 8 + (int32_t)r, b, g, rr); v[i] = to_y(b, g, rr) - 128; }
+        for (int i = 0; i < 8; i++) v[i] = to_y((int32_t)(px[i] & 255u), (int32_t)((px[i] >> 8) & 255u), (int32_t)(px[i] >> 16)) - 128;
     } else {
         qsel = 1;
         const int32_t dh = (H + 1) / 2;
         int32_t cy = (int32_t)my * 8 + (int32_t)r;
         if (cy > dh - 1) cy = dh - 1; // downsampled rows below the image replicate the last downsampled row
+        uint32_t p0[16], p1[16]; // the two source rows of downsampled row cy, 16 pixels each
+        load_bgr_run<16>(job.src, frames, (int32_t)mx * 16, 2 * cy, p0);
+        load_bgr_run<16>(job.src, frames, (int32_t)mx * 16, 2 * cy + 1, p1);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int32_t cx = (int32_t)mx * 8 + i;
             int32_t s = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                int32_t b, g, rr;
-                load_bgr(job.src, frames, 2 * cx + (j & 1), 2 * cy + (j >> 1), b, g, rr);
+                const uint32_t q = (j >> 1) ? p1[2 * i + (j & 1)] : p0[2 * i + (j & 1)];
+                const int32_t b = (int32_t)(q & 255u), g = (int32_t)((q >> 8) & 255u), rr = (int32_t)(q >> 16);
                 s += k == 4 ? to_cb(b, g, rr) : to_cr(b, g, rr);
             }
             v[i] = ((s + ((cx & 1) ? 2 : 1)) >> 2) - 128;
