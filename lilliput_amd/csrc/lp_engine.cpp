@@ -1293,7 +1293,10 @@ bool lp_fused_op_is_fast(const LpFusedOp& op, const LpJpeg& j, uint32_t* fast_ou
     const uint32_t nb = op.rw == 2 ? 4u : op.rw == 4 ? 2u : 0u;
     const bool small_ok = nb && (op.x0 % 8) == 0 && steps && op.dst.cn == 3 && (U % nb) == 0;
     uint32_t fast = 0, bit = 0;
-    if (ycc && small_ok && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) {   // k_resample_420_small<8 / rw>
+    if (j.ncomp == 1 && op.dst.cn == 1) {                                                      // k_resample_gray
+        fast = 0x1000u;
+        bit = 0x4000u;
+    } else if (ycc && small_ok && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) {   // k_resample_420_small<8 / rw>
         fast = op.rw / 2;
         bit = op.rw == 2 ? 0x1000u : 0x2000u;
     } else if (ycc && aligned && j.hs[0] == 2 && j.vs[0] == 2 && !(op.rh & 1) && !(op.y0 & 1)) { // k_resample_420<rw / 2>

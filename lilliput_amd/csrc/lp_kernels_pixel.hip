@@ -596,6 +596,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LP_RESAMPLE
     resample_420_body<8>(imgs, ops, plane_arena);
 }
 
+// Grey sources at integer scales: a thread per destination pixel sums its box of luma bytes (LpFusedOp::fast = LP_FAST_GRAY). The wave
+// per destination pixel of k_resample_fused is for what nothing else takes.
+#define LP_FAST_GRAY 0x1000u
+__global__ __launch_bounds__(256) void k_resample_gray(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
+{
+    const LpFusedOp& op = ops[blockIdx.y];
+    if (op.fast != LP_FAST_GRAY) return;
+    const LpJpeg& img = imgs[op.img];
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= op.dst.w * op.dst.h) return;
+    const int32_t dy = (int32_t)(gid / op.dst.w), dx = (int32_t)(gid - (uint32_t)dy * op.dst.w);
+    const int32_t fx0 = op.x0 + dx * op.dxx + dy * op.dyx, fy0 = op.y0 + dx * op.dxy + dy * op.dyy;
+    const uint32_t sy_ = img.plane_stride[0];
+    const uint8_t* p = plane_arena + img.plane_off[0] + (size_t)fy0 * sy_ + fx0;
+    int32_t sum = 0;
+    for (uint32_t ry = 0; ry < op.rh; ry++, p += sy_)
+        for (uint32_t rx = 0; rx < op.rw; rx++) sum += p[rx];
+    uint32_t r;
+    if (op.round_2x2) r = (uint32_t)(sum + 2) >> 2;
+    else r = sat_round_u8(__fmul_rn((float)sum, op.inv_area));
+    reinterpret_cast<uint8_t*>((uintptr_t)op.dst.off)[(size_t)dy * op.dst.stride + (size_t)dx] = (uint8_t)r;
+}
+
 // Small boxes (2 x 2 and 4 x 4 pixels: NB = 4 / 2 boxes per 8-column tile), see resample_420_body
 template <int NB>
 __global__ __launch_bounds__(256) void k_resample_420_small(const LpJpeg* __restrict__ imgs, const LpFusedOp* __restrict__ ops, const uint8_t* __restrict__ plane_arena)
@@ -1482,6 +1505,7 @@ void lp_launch_resample_fused(hipStream_t s, const LpJpeg* d_imgs, const LpFused
     if (fast_mask & 1u) hipLaunchKernelGGL(k_resample_420<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 2u) hipLaunchKernelGGL(k_resample_420<8>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 4u) hipLaunchKernelGGL(k_resample_420<16>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
+    if (fast_mask & 0x4000u) hipLaunchKernelGGL(k_resample_gray, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);
     if (fast_mask & 0x1000u) hipLaunchKernelGGL(k_resample_420_small<4>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes); // 2-pixel boxes
     if (fast_mask & 0x2000u) hipLaunchKernelGGL(k_resample_420_small<2>, dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes); // 4-pixel boxes
     if (fast_mask & 0x10u) hipLaunchKernelGGL((k_resample_hv1<8, 1>), dim3(fast_grid, nops), dim3(256), 0, s, d_imgs, d_ops, d_planes);

@@ -643,10 +643,15 @@ def test_small_box_resample_all_orientations(batch, oracle):
                                # boxes no thread-per-box kernel takes: the area walk with unit taps (3, 5, 6, 12, 20 pixels; 2 x 2 off the grid or 4:4:4 / 4:2:2)
                                (384, 384, 128, 128, 2), (320, 320, 64, 64, 2), (384, 192, 64, 32, 2), (288, 288, 24, 24, 2), (300, 200, 100, 100, 2),
                                (384, 384, 128, 128, 0), (320, 320, 64, 64, 1), (288, 288, 24, 24, 0), (300, 200, 100, 100, 1), (400, 400, 20, 20, 2),
-                               (330, 330, 110, 110, 2), (510, 510, 15, 15, 2), (512, 512, 8, 8, 2), (501, 334, 167, 167, 2)):
+                               (330, 330, 110, 110, 2), (510, 510, 15, 15, 2), (512, 512, 8, 8, 2), (501, 334, 167, 167, 2),
+                               # grey sources: k_resample_gray (a thread per destination pixel)
+                               (256, 256, 128, 128, "gray"), (384, 384, 128, 128, "gray"), (512, 320, 32, 20, "gray"), (300, 200, 100, 100, "gray"), (130, 70, 13, 7, "gray")):
         im = Image.fromarray(np.ascontiguousarray(rgb[:h, :w]))
         b = io.BytesIO()
-        im.save(b, "JPEG", quality=92, subsampling=ss)
+        if ss == "gray":
+            im.convert("L").save(b, "JPEG", quality=92)
+        else:
+            im.save(b, "JPEG", quality=92, subsampling=ss)
         cases.append((b.getvalue(), tw, th))
     for data, tw, th in cases:
         for o in range(1, 9):
