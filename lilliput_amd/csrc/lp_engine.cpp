@@ -733,6 +733,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // 4096 x 4096 sources (p99 ~800 symbols) spans several subsequences. Measured, 4 / 8 images per call: 5.3 / 6.4 ms with the
         // floor at 1 024, 2.5 / 4.3 ms at 4 096 (profiles/r03_c_final.md).
         const uint32_t floor_S = defer ? std::max(min_S, 4096u) : min_S;
+        // Small files (round 5): pick_S sizes by the largest file alone and hands 1 024 or 256 bits to sources of a few KB -- whose
+        // entropy streams then need a verify round per subsequence the self-synchronisation distance spans (22 rounds for 128 x 128
+        // sources, against the four that are queued). The floor holds for them too: a chunk of many small files gets its lanes from
+        // the number of files, not from cutting each of them finer.
+        S_ = std::max(S_, floor_S);
         while (S_ > floor_S && bits / S_ < want_lanes) S_ >>= 1;
     }
     if (S_ % 32 || S_ < 64 || S_ > 32768) { err_ = "bad subsequence size"; return LP_ERR_DEVICE; }
