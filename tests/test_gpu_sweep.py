@@ -76,6 +76,45 @@ def test_random_jpegs_transform_matches_oracle(batch, oracle):
 
 
 @pytest.mark.gpu
+def test_random_integer_scales_every_kernel_bit_exact(batch, oracle):
+    """Integer scales at random: box sizes 2 .. 34, crops that start anywhere (Fit centres them: even, odd, on and off the kernels'
+    grids), every sampling and grey, every orientation, with and without normalisation -- whichever kernel takes the op (k_resample_420 /
+    _small / _hv1 / _gray, the area walk with unit taps, the general kernel), the bytes are decode -> ExifTransform -> crop ->
+    resizeAreaFast_ -> the reference encoder's."""
+    import test_gpu_parity as P
+
+    rng = np.random.default_rng(20260923)
+    bad = []
+    n = 0
+    for it in range(140):
+        s = int(rng.choice([2, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 16, 20, 24, 32, 34]))
+        tw, th = int(rng.integers(1, 40 if s > 8 else 90)), int(rng.integers(1, 40 if s > 8 else 90))
+        if rng.random() < 0.3:
+            tw = th = int(rng.choice([8, 16, 32, 64]))
+        extra = int(rng.integers(0, 24))
+        wide = rng.random() < 0.5
+        ow, oh = (tw * s + (extra if wide else 0), th * s + (0 if wide else extra))  # the ORIENTED frame: Fit crops `extra` off the longer side
+        # Fit keeps the crop an exact multiple only when the aspect ratios work out; check with the oracle's own plan below
+        o = int(rng.integers(1, 9))
+        w, h = (oh, ow) if o >= 5 else (ow, oh)
+        gray = rng.random() < 0.12
+        img = _image(rng, h, w, gray)
+        kw = {"quality": int(rng.choice([60, 85, 92, 100]))}
+        if not gray:
+            kw["subsampling"] = int(rng.choice([0, 1, 2, 2]))
+        buf = io.BytesIO()
+        PIL.fromarray(img).save(buf, "JPEG", **kw)
+        d = P._with_exif_orientation(buf.getvalue(), o)
+        for norm in (False, True):
+            r = batch.transform([d], tw, th, normalize=norm, quality=85)[0]
+            frame = oracle.transform_static(oracle.jpeg_decode(d), o, tw, th, oracle.FIT, norm)
+            n += 1
+            if r.status != 0 or (r.width, r.height) != (frame.shape[1], frame.shape[0]) or r.data != oracle.jpeg_encode(frame, 85):
+                bad.append((it, s, (w, h), (tw, th), o, norm, gray, kw, r.status))
+    assert not bad, (len(bad), n, bad[:10])
+
+
+@pytest.mark.gpu
 def test_narrow_images_use_plain_chroma_replication(batch, oracle):
     """jdsample.c picks the fancy h2v1 / h2v2 upsamplers only when the chroma plane is more than two samples wide: images up to
     four pixels wide get plain replication (the oracle is checked against the real libjpeg on the same files in
