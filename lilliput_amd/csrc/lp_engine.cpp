@@ -748,7 +748,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     h_pstreams_.clear();
     std::vector<std::pair<uint32_t, LpProgScan>> leveled; // (dependency level, scan)
     tot_sub_ = tot_chunks_ = tot_rst_ = 0;
-    max_chunks_ = max_sub_ = max_bw_ = max_rows_ = max_w_ = max_h_ = 0;
+    max_chunks_ = max_sub_ = max_bw_ = max_rows_ = max_w_ = max_h_ = max_mcus_ = 0;
     bool any_frame = false, any_generic = false, any_420 = false, any_baseline = false;
     for (size_t i = 0; i < h_imgs_.size(); i++) {
         LpJpeg& j = h_imgs_[i];
@@ -812,6 +812,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         max_rows_ = std::max(max_rows_, rows);
         max_chunks_ = std::max(max_chunks_, j.nchunks);
         max_sub_ = std::max(max_sub_, j.sub_cap);
+        max_mcus_ = std::max(max_mcus_, j.mcus_x * j.mcus_y);
         if (!want_frame || want_frame[i]) {
             any_frame = true;
             const bool f420 = j.ncomp == 3 && !j.generic_sampling && j.colorspace == 2 && j.hs[0] == 2 && j.vs[0] == 2 && j.width > 4;
@@ -841,7 +842,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_ckpt_.ensure((size_t)tot_sub_ * K_ * sizeof(LpCkptPk) + 64) && d_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_spec_exit_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) && d_entry_.ensure((size_t)tot_sub_ * sizeof(LpSubState) + 64) &&
              d_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_spec_tot_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) &&
-             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * 16 * 16 + 64) &&
+             d_prefix_.ensure((size_t)tot_sub_ * sizeof(LpSubSum) + 64) && d_changed_.ensure(64) && h_dstate_.ensure(64 + sizeof(LpJpegState) * (size_t)n + 64) && d_coef_.ensure(coef_elems + 64) && d_wide_.ensure(coef_elems * 2 + 64) && d_wide_id_.ensure(coef_elems / 16 + 64) && d_dc_.ensure(coef_elems / 32 + 64) && d_dcpart_.ensure((size_t)n * lp_dc_scan_max_ranges() * 16 + 64) &&
              d_planes_.ensure(plane_bytes + LP_AREA_SLACK) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
@@ -888,7 +889,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     mark(10);
     lp_launch_huff_write(stream_, ha);
     stage("huff_write");
-    lp_launch_dc_scan(stream_, di, (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
+    lp_launch_dc_scan(stream_, di, (uint32_t)n, max_mcus_, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
     if (pcoef_elems && !u_->prog_on_device) { // hybrid mode: the coefficients were decoded at upload time
         for (int i = 0; i < n; i++) {
@@ -982,7 +983,7 @@ int LpEngine::finish_decode(int* status)
         lp_launch_reset_tail_state(stream_, d_states_.as<LpJpegState>(), (uint32_t)n);
         lp_launch_sub_scan(stream_, ha);
         lp_launch_huff_write(stream_, ha);
-        lp_launch_dc_scan(stream_, d_imgs_.as<LpJpeg>(), (uint32_t)n, d_dc_.as<int16_t>(), d_dcpart_.p);
+        lp_launch_dc_scan(stream_, d_imgs_.as<LpJpeg>(), (uint32_t)n, max_mcus_, d_dc_.as<int16_t>(), d_dcpart_.p);
         lp_launch_idct(stream_, d_imgs_.as<LpJpeg>(), d_states_.as<LpJpegState>(), (uint32_t)n, max_bw_, max_rows_, d_coef_.as<int8_t>(), d_wide_.as<int16_t>(),
                        d_wide_id_.as<uint32_t>(), d_dc_.as<int16_t>(), d_planes_.as<uint8_t>(), (pend_.any_baseline ? 1u : 0u) | (pend_.pcoef_elems ? 2u : 0u), d_pcoef_.as<int16_t>());
         if (pend_.any_frame)

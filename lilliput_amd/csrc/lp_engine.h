@@ -263,7 +263,7 @@ private:
     std::vector<LpJpegState> h_states_;
     uint32_t S_ = 0, K_ = 0;
     LpCkSched sched_ = {};
-    uint32_t max_chunks_ = 0, max_sub_ = 0, max_bw_ = 0, max_rows_ = 0, max_w_ = 0, max_h_ = 0;
+    uint32_t max_chunks_ = 0, max_sub_ = 0, max_bw_ = 0, max_rows_ = 0, max_w_ = 0, max_h_ = 0, max_mcus_ = 0;
     uint32_t tot_sub_ = 0, tot_chunks_ = 0, tot_rst_ = 0;
     LpDevBuf d_imgs_, d_states_, d_clean_, d_rst_, d_chunk_, d_ckpt_, d_exit_, d_spec_exit_, d_entry_, d_tot_, d_spec_tot_, d_prefix_, d_changed_;
     LpDevBuf d_coef_, d_wide_, d_wide_id_, d_dc_, d_dcpart_, d_planes_, d_frames_desc_;

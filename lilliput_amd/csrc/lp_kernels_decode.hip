@@ -803,13 +803,17 @@ __device__ __forceinline__ DcSeg dc_walk_range(int16_t* dc, uint32_t m0, uint32_
 // slots, and while the other parts of a batch keep the CUs full of Huffman workgroups it waited for milliseconds. Here every
 // range of an image is an independent 64-thread workgroup: k_dc_sum stores each range's (sums, had-a-reset), k_dc_apply
 // combines the ranges before its own (at most DCSCAN_RANGES - 1 records) and rewrites its range.
-#define DCSCAN_RANGES 16
+// Round 5: the launch picks the number of ranges (gridDim.x, at most DCSCAN_RANGES) from the largest image so that a range is about four
+// 64-MCU steps -- with 16 ranges whatever the size a 4096 x 4096 image was 64 serial steps per wave, 107 us per launch and kernel (1.9 us per
+// image for the two: as much as the unstuff kernels' count pass).
+#define DCSCAN_RANGES 64
 struct DcPartial { int32_t v[LP_MAX_COMP]; int32_t f; };
 
 __device__ __forceinline__ void dc_range(const LpJpeg& img, uint32_t w, uint32_t& m0, uint32_t& m1, uint32_t& comps)
 {
     const uint32_t nmcu = img.mcus_x * img.mcus_y;
-    const uint32_t per = ((nmcu + DCSCAN_RANGES - 1) / DCSCAN_RANGES + 63) / 64 * 64; // whole 64-MCU steps per range
+    const uint32_t nr = gridDim.x;
+    const uint32_t per = ((nmcu + nr - 1) / nr + 63) / 64 * 64; // whole 64-MCU steps per range
     m0 = w * per < nmcu ? w * per : nmcu;
     m1 = m0 + per < nmcu ? m0 + per : nmcu;
     comps = 0;
@@ -1317,11 +1321,14 @@ void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round)
                        round, a.sched.K, a.tot_sub);
 }
 
-void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */)
+uint32_t lp_dc_scan_max_ranges() { return DCSCAN_RANGES; }
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_mcus, int16_t* d_dc, void* d_partials /* nimg * lp_dc_scan_max_ranges() * 16 bytes */)
 {
     if (!nimg) return;
-    hipLaunchKernelGGL(k_dc_sum, dim3(DCSCAN_RANGES, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<DcPartial*>(d_partials));
-    hipLaunchKernelGGL(k_dc_apply, dim3(DCSCAN_RANGES, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<const DcPartial*>(d_partials));
+    uint32_t nr = (max_mcus + 255u) / 256u; // ~four steps of 64 MCUs per range
+    nr = nr < 1u ? 1u : nr > DCSCAN_RANGES ? DCSCAN_RANGES : nr;
+    hipLaunchKernelGGL(k_dc_sum, dim3(nr, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<DcPartial*>(d_partials));
+    hipLaunchKernelGGL(k_dc_apply, dim3(nr, nimg), dim3(64), 0, s, d_imgs, d_dc, reinterpret_cast<const DcPartial*>(d_partials));
 }
 
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a)

@@ -40,7 +40,8 @@ void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
 // zero-copy ingest: pieces in pinned, device-mapped host memory -> the raw arena (see k_gather_raw). The two arrays live in mapped pinned memory.
 struct LpGatherPiece { const uint8_t* src; uint64_t dst_off; uint32_t len; uint32_t pad; };
 void lp_launch_gather_raw(hipStream_t s, const LpGatherPiece* d_pcs, const uint32_t* d_tile_first, uint32_t npieces, uint8_t* d_arena, uint32_t workgroups);
-void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, int16_t* d_dc, void* d_partials /* nimg * 16 * 16 bytes */);
+uint32_t lp_dc_scan_max_ranges();
+void lp_launch_dc_scan(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_mcus, int16_t* d_dc, void* d_partials /* nimg * lp_dc_scan_max_ranges() * 16 bytes */);
 void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_states, uint32_t nimg, uint32_t max_bw, uint32_t max_rows, const int8_t* d_coef8,
                     const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes, uint32_t which /* 1 baseline, 2 progressive */,
                     const int16_t* d_pcoef);
