@@ -860,7 +860,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         fprintf(stderr, "[lilliput_hip] stage %s done (%s)\n", name, hipGetErrorString(hipGetLastError()));
     };
     mark(0);
-    lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, tot_chunks_, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
+    lp_launch_unstuff(stream_, di, (uint32_t)n, max_chunks_, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(), ds, d_clean_.as<uint32_t>(),
                       d_rst_.as<uint32_t>());
     stage("unstuff");
     mark(1);
@@ -907,7 +907,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             !check(hipMemsetAsync(d_pstates_.p, 0, sizeof(LpJpegState) * nstreams, stream_), "memset scan states") ||
             !check(hipMemsetAsync(d_pcoef_.p, 0, pcoef_elems * 2, stream_), "memset coefficients"))
             return LP_ERR_DEVICE;
-        lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, tot_chunks_, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
+        lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
                           d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
         stage("prog_unstuff");
 #ifdef LP_PROG_DEVICE_LANES

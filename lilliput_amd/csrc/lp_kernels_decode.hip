@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <string.h>
 
 #include "lp_huff_core.h"
 #include "lp_prog_core.h"
@@ -203,142 +202,6 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
                 const uint32_t q = q0 + k;
                 if (q >= lo && q < hi) ob[3u - k] = s_out[q];
             }
-        }
-    }
-}
-
-// One pass (round 5): count, scan and scatter in one kernel. A workgroup takes the image's next 4 KiB chunk by ticket (LpJpegState::pad,
-// zeroed with the states: tickets are handed out in start order, so the holder of every lower ticket is running or done), classifies
-// and counts its bytes, publishes the counts as an AGGREGATE in the chunk's status word, looks back over the chunks before it -- wave 0,
-// 64 status words per step, until one of them holds an INCLUSIVE prefix -- publishes its own inclusive prefix and scatters. A status
-// word carries its data (kept bytes in bits 0..31, restart markers in 32..57, state in 62..63: 0 empty, 1 aggregate, 2 inclusive), so a
-// relaxed 64-bit atomic at agent scope is all the ordering there is. Nobody waits for anything but a running workgroup's publish,
-// which waits for nobody; a wait is bounded all the same (the image then goes the serial route: error bit 3). The last chunk's
-// workgroup knows the totals and does what k_unstuff_scan did for the image. 8.4 MB instead of 13 MB per 4.2 MB stream.
-#define LP_UNSTUFF_SPIN_LIMIT (1u << 20)
-__device__ __forceinline__ unsigned long long unstuff_pack(uint32_t state, uint32_t a, uint32_t b) { return ((unsigned long long)state << 62) | ((unsigned long long)(b & 0x3ffffffu) << 32) | a; }
-__global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_fused(const LpJpeg* __restrict__ imgs, const uint8_t* __restrict__ raw_arena, unsigned long long* status,
-                                                             uint32_t* __restrict__ clean_arena, uint32_t* __restrict__ rst_bits, LpJpegState* states)
-{
-    __shared__ uint32_t s_tmp[4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16 + UNSTUFF_T]; // + one byte per lane where dropped bytes go
-    __shared__ uint32_t s_chunk;
-    __shared__ uint2 s_base;
-    const LpJpeg& img = imgs[blockIdx.y];
-    LpJpegState& st = states[blockIdx.y];
-    if (threadIdx.x == 0) s_chunk = blockIdx.x < img.nchunks ? atomicAdd(&st.pad, 1u) : 0xffffffffu; // exactly nchunks workgroups take a ticket
-    __syncthreads();
-    const uint32_t chunk = s_chunk;
-    if (chunk >= img.nchunks) return;
-    const uint8_t* raw = raw_arena + img.raw_off;
-    const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
-    uint32_t pos0 = chunk * UNSTUFF_CHUNK + threadIdx.x * 16;
-    UnstuffBytes u;
-    unstuff_load(raw, raw_end, pos0, u);
-    uint32_t K[4], R[4], err = 0;
-    if (chunk == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
-    else if ((chunk + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
-    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
-    if (err) atomicOr(&st.error, err);
-    const uint32_t rany = R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3; // disjoint bit positions: one popcount for the four words
-    uint32_t ea, eb, ta, tb;
-    block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
-    unsigned long long* sp = status + img.chunk_off;
-    if (threadIdx.x < 64) { // wave 0: publish, look back, publish
-        const uint32_t lane = threadIdx.x;
-        uint32_t pa = 0, pb = 0;
-        if (chunk != 0) {
-            if (lane == 0) __hip_atomic_store(sp + chunk, unstuff_pack(1u, ta, tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int32_t idx = (int32_t)chunk - 1;
-            bool ok = true;
-            for (;;) {
-                const int32_t my = idx - (int32_t)lane;
-                unsigned long long v = unstuff_pack(2u, 0u, 0u); // before chunk 0: an inclusive prefix of nothing
-                if (my >= 0) {
-                    uint32_t spins = 0;
-                    do v = __hip_atomic_load(sp + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while ((v >> 62) == 0 && ++spins < LP_UNSTUFF_SPIN_LIMIT);
-                }
-                if (__ballot((v >> 62) == 0) != 0ull) { ok = false; break; } // a wait ran out: give up on the image, not on the device
-                const unsigned long long incl = __ballot((v >> 62) == 2);
-                const uint32_t first = incl ? (uint32_t)__ffsll((long long)incl) - 1u : 64u; // the nearest chunk that knows its inclusive prefix
-                uint32_t ca = lane <= first ? (uint32_t)v : 0u, cb = lane <= first ? (uint32_t)(v >> 32) & 0x3ffffffu : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { ca += __shfl_xor(ca, d, 64); cb += __shfl_xor(cb, d, 64); }
-                pa += ca; pb += cb;
-                if (first < 64u) break;
-                idx -= 64;
-            }
-            if (!ok) { pa = pb = 0; if (lane == 0) atomicOr(&st.error, 8u); }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(sp + chunk, unstuff_pack(2u, pa + ta, pb + tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base = make_uint2(pa, pb);
-        }
-    }
-    const bool last = chunk + 1u == img.nchunks;
-    __syncthreads();
-    const uint2 base = s_base;
-    const uint32_t a0 = base.x & ~3u;           // clean position of the first (maybe shared) word
-    uint32_t cpos = base.x + ea;
-    if (rany) { // restart markers: a handful per image
-        uint32_t rpos = base.y + eb, c = cpos;
-        for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t bit = 0x80u << (8u * (j & 3u));
-            if (R[j >> 2] & bit) {
-                if (rpos < img.rst_cap) rst_bits[img.rst_off + rpos] = c * 8;
-                // the k-th marker must be RST(k mod 8): libjpeg treats any other number as a lost or repeated interval (lp_jbits.h)
-                if (((u.w[j >> 2] >> (8u * (j & 3u))) & 7u) != (rpos & 7u) && img.total_blocks && !img.scan_path) atomicOr(&st.error, 8u);
-                rpos++;
-            }
-            c += (K[j >> 2] & bit) ? 1u : 0u;
-        }
-    }
-    // Compaction, branch-free (see k_unstuff_scatter)
-    uint32_t l = cpos - a0;
-    const uint32_t dump = UNSTUFF_CHUNK + 16 + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t kept = (K[j >> 2] >> (8 * (j & 3) + 7)) & 1u;
-        s_out[kept ? l : dump] = (uint8_t)(u.w[j >> 2] >> (8 * (j & 3)));
-        l += kept;
-    }
-    const uint32_t lo = base.x - a0, hi_data = lo + ta;
-    if (last && threadIdx.x < 4) s_out[hi_data + threadIdx.x] = 0; // the stream's last word is filled up with zero bytes (nobody else owns them)
-    __syncthreads();
-    const uint32_t hi = last ? (hi_data + 3u) & ~3u : hi_data;  // owned clean positions relative to a0: [lo, hi)
-    const uint32_t cap = img.clean_cap_words;
-    uint32_t* out = clean_arena + img.clean_off + (a0 >> 2);
-    const uint32_t nwords = (hi + 3) >> 2;
-    for (uint32_t w = threadIdx.x; w < nwords; w += UNSTUFF_T) {
-        if ((a0 >> 2) + w >= cap) break;
-        const uint32_t q0 = w * 4;
-        if (q0 >= lo && q0 + 4 <= hi) {
-            out[w] = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(&s_out[q0])); // the clean stream is big-endian words: bit 31 = first bit
-        } else { // word shared with a neighbouring chunk: touch only the owned bytes
-            uint8_t* ob = reinterpret_cast<uint8_t*>(out + w);
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t q = q0 + k;
-                if (q >= lo && q < hi) ob[3u - k] = s_out[q];
-            }
-        }
-    }
-    if (last) { // what k_unstuff_scan did once per image: totals -> state, the zeroed tail
-        const uint32_t tot_a = base.x + ta, tot_b = base.y + tb;
-        if (threadIdx.x == 0) {
-            st.clean_bytes = tot_a;
-            st.n_rst = tot_b < img.rst_cap ? tot_b : img.rst_cap;
-            uint32_t e = 0;
-            if (tot_b > img.rst_cap) e |= 4u;
-            // A baseline image (not a scan's pseudo stream) must hold exactly the restart markers its MCU count asks for (k_unstuff_scan)
-            if (img.total_blocks && !img.scan_path && tot_b != (img.dri ? (img.mcus_x * img.mcus_y + img.dri - 1u) / img.dri - 1u : 0u)) e |= 8u;
-            if (e) atomicOr(&st.error, e);
-            const uint64_t bits = (uint64_t)tot_a * 8;
-            st.nsub = (uint32_t)((bits + img.sub_bits - 1) / img.sub_bits);
-        }
-        if (threadIdx.x < 16) { // zero the tail words so that reads past the end of the stream are deterministic
-            const uint32_t w = ((tot_a + 3u) >> 2) + threadIdx.x;
-            if (w < cap) clean_arena[img.clean_off + w] = 0;
         }
     }
 }
@@ -1357,18 +1220,11 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (plain C++ signatures; see lp_launch.h)
-void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, uint32_t tot_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
+void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
                        LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst)
 {
     if (!nimg || !max_chunks) return;
     dim3 g(max_chunks, nimg);
-    // LILLIPUT_HIP_UNSTUFF=3pass: round 1's count / scan / scatter launches (A/B measurements; same bytes)
-    static const bool three = getenv("LILLIPUT_HIP_UNSTUFF") && !strcmp(getenv("LILLIPUT_HIP_UNSTUFF"), "3pass");
-    if (!three) {
-        (void)hipMemsetAsync(d_chunk_cnt, 0, (size_t)tot_chunks * 8, s); // the status words (LpJpegState::pad, the ticket, is zeroed with the states)
-        hipLaunchKernelGGL(k_unstuff_fused, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, reinterpret_cast<unsigned long long*>(d_chunk_cnt), d_clean, d_rst, d_states);
-        return;
-    }
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean);
     hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst, d_states);

@@ -5,7 +5,7 @@
 #include "lp_types.h"
 
 // decode
-void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, uint32_t tot_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
+void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_chunks, const uint8_t* d_raw, uint2* d_chunk_cnt,
                        LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst);
 // Everything the Huffman kernels share (device pointers; arrays indexed by LpJpeg::sub_off + subsequence).
 struct LpHuffArgs {
