@@ -586,14 +586,6 @@ struct DevSink {
 #ifdef LP_EXP_NOPUT
         asm volatile("" :: "v"(where), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
 #endif
-#ifndef LP_WRITE_NO_UNIFORM_GUARDS
-        // Rare per lane AND per wave (a few blocks in a thousand at q90): the wave votes first and skips the predicated region with a scalar
-        // branch -- the exec-mask save / branch / restore pair around a region no lane enters was six of a step's 75 instructions.
-        if (__builtin_amdgcn_ballot_w64(v < -127 || v > 127) != 0ull) {
-            LP_KEEP_UNIFORM_BRANCH();
-#else
-        {
-#endif
         if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
             const uint32_t nat = (((uint32_t)where / LP_SLOT_STRIDE) << 4) | (((uint32_t)where % LP_SLOT_STRIDE) & 15u);
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
@@ -604,21 +596,13 @@ struct DevSink {
             if (wslot < wide_cap) wide[(size_t)wslot * 64 + nat] = (int16_t)v;
             v = -128;
         }
-        }
         slot[where] = (int8_t)v;
     }
     // the queue entry is the lane's block counter word as it is (no arithmetic in the decode step); flush() turns it into the block index
     __device__ __forceinline__ void end_block(uint32_t bc, bool on)
     {
         qbc = on ? bc : qbc;
-#ifndef LP_WRITE_NO_UNIFORM_GUARDS
-        if (__builtin_amdgcn_ballot_w64(wslot != 0xffffffffu) != 0ull) { // some lane of the wave holds a wide slot: rare (see put)
-            LP_KEEP_UNIFORM_BRANCH();
-            if (on && wslot != 0xffffffffu) { wide_id[blk0 + (bc >> 5) - 1u] = wslot; wslot = 0xffffffffu; }
-        }
-#else
         if (on && wslot != 0xffffffffu) { wide_id[blk0 + (bc >> 5) - 1u] = wslot; wslot = 0xffffffffu; } // rare
-#endif
     }
     __device__ __forceinline__ bool stalled() const { return qbc != 0xffffffffu; }
     // Wave-cooperative: the lanes with a finished block put (block, lane) on a per-wave list; then four lanes move one block each --
