@@ -160,6 +160,10 @@ struct LpJBits {
     }
     uint32_t get_each(uint32_t n) // n x (CHECK_BIT_BUFFER(1) + GET_BITS(1)): how jdphuff.c reads correction bits; first bit on top
     {
+        if (bits >= (int)n) { // the register holds them all: the n single reads are one shift (no refill falls between them either way)
+            bits -= (int)n;
+            return (uint32_t)(buf >> bits) & (n >= 32u ? 0xffffffffu : (1u << n) - 1u);
+        }
         uint32_t v = 0;
         for (; n; n--) {
             if (bits < 1 && !fill(1)) return 0u;

@@ -137,9 +137,18 @@ LP_PHD uint32_t lp_ctz64(uint64_t v)
 
 // One correction bit for every coefficient of `bits` (ascending = scan order): a set bit moves a coefficient whose p1 bit is
 // still clear away from zero by p1.
+// A memory policy may bring its own versions of the two bit-mask walks of a refinement scan (P::kBulkCorrect: the host policy of
+// lp_prog_host.cpp does them with PDEP where the CPU has it) -- same reads from the bit reader, same stores.
+template <class P, class = void> struct LpProgHasBulk { static constexpr bool value = false; };
+template <class P> struct LpProgHasBulk<P, decltype((void)P::kBulkCorrect)> { static constexpr bool value = true; };
+
 template <class P, class B>
 LP_PHD void lp_prog_correct(P& m, B& b, uint64_t bits, int32_t p1, int32_t m1)
 {
+    if constexpr (LpProgHasBulk<P>::value) {
+        m.correct_bulk(b, bits, p1, m1);
+        return;
+    }
     while (bits) { // the correction bits of up to 32 coefficients come out of the stream in one read
         uint32_t n = lp_popc64(bits);
         if (n > 32u) n = 32u;
@@ -258,7 +267,8 @@ LP_PHD bool lp_prog_scan_with(P& m, B& b, const LpProgScan& sc)
                             // ones on the way: the (r + 1)-th zero at or after k
                             const uint64_t from_k = ~0ull << k;
                             uint64_t zeros = ~nz & from_k & band;
-                            for (; r && zeros; r--) zeros &= zeros - 1ull;
+                            if constexpr (LpProgHasBulk<P>::value) zeros = m.drop_lowest(zeros, r);
+                            else for (; r && zeros; r--) zeros &= zeros - 1ull;
                             const uint32_t stop = zeros ? lp_ctz64(zeros) : Se + 1u;
                             lp_prog_correct(m, b, nz & from_k & (stop >= 64u ? ~0ull : (1ull << stop) - 1ull), p1, m1);
                             k = stop;
