@@ -1069,10 +1069,13 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         // Small sources (round 5): a chunk of 32 files of 100 KB is 3 MB -- twenty launches and their waits for 0.2 ms of kernels
         // (512 x 512 sources ran at 66 k images/s end to end against 184 k resident). Beyond its first `chunk` items a chunk goes on while it
         // holds less than LILLIPUT_HIP_PIPE_CHUNK_MB (default 128: what 32 of the 4 MB headline sources weigh) and fewer than its share of a
-        // queue that gives every engine four chunks; an explicit chunk size (option or environment) is taken as it is.
+        // queue of ONE chunk per engine -- a chunk of small files is ~2.5 ms of launch and walk latencies around 0.4 ms of kernels, so the
+        // fewer chunks the better (2 048 sources of 256 x 256: 127 k images/s with four chunks per engine, 182 k with one); files big enough
+        // for the copy to matter run into the byte bound long before. An explicit chunk size (option or environment) is taken as it is.
         static const size_t pipe_chunk_bytes = (getenv("LILLIPUT_HIP_PIPE_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PIPE_CHUNK_MB"))) : 128) << 20;
         const bool grow = opt->chunk <= 0 && !getenv("LILLIPUT_HIP_PIPE_CHUNK");
-        const size_t chunk_max = grow ? std::max(chunk, std::min<size_t>(1024, n / std::max<size_t>(1, 4 * np * devs.size()))) : chunk;
+        const size_t engines = std::max<size_t>(1, np * devs.size());
+        const size_t chunk_max = grow ? std::max(chunk, std::min<size_t>(1024, (n + engines - 1) / engines)) : chunk;
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
