@@ -83,12 +83,9 @@ struct Dispatch {
                 }
                 if (stop) break;
                 // the oldest request and every waiting one with the same options, in arrival order
-                // (small sources, round 5: past max_take() requests a dispatch goes on while it holds less than 32 MB of sources -- a dispatch
-                // of 32 files of 100 KB is mostly launch latency -- up to eight times as many)
                 const lilliput_batch_options key = q.front()->opt;
-                size_t bytes = 0;
-                for (auto it = q.begin(); it != q.end() && (take.size() < max_take() || (take.size() < 8 * max_take() && bytes + (*it)->len <= (32u << 20)));) {
-                    if (same_options((*it)->opt, key)) { bytes += (*it)->len; take.push_back(*it); it = q.erase(it); }
+                for (auto it = q.begin(); it != q.end() && take.size() < max_take();) {
+                    if (same_options((*it)->opt, key)) { take.push_back(*it); it = q.erase(it); }
                     else ++it;
                 }
             }
