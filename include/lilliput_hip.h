@@ -445,6 +445,11 @@ int lilliput_hip_bmp_decode(const void* data, size_t len, int* w, int* h, int* c
 long lilliput_hip_png_inflate_check(const void* data, size_t len);
 long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap); /* test access: the filtered rows; -1 rejected, -2 cap too small */
 int lilliput_hip_png_set_inflater(int own);   /* test access / A-B: 1 = the library's one-shot inflater first (default), 0 = zlib only; returns the previous setting */
+/* Test access (no device work): the kernel the batch path hands a JPEG source of this shape to between its decoded planes and the output size:
+ * 0 a materialised frame, 1 k_resample_420 (8 / 16 / 32-pixel boxes), 2 k_resample_420_small (2 / 4), 3 k_resample_hv1 (4:4:4 / 4:2:2), 4 k_resample_gray,
+ * 5 the area walk with float taps (fractional scales), 6 the area walk with unit taps (other integer scales), 7 a wave per destination pixel. hs / vs = the luma
+ * sampling factors (2,2 = 4:2:0; 2,1 = 4:2:2; 1,1 = 4:4:4 or grey). */
+int lilliput_hip_resample_route(int width, int height, int orientation, int ncomp, int hs, int vs, int out_w, int out_h, int resize_method, int normalize_orientation);
 uint32_t lilliput_hip_checksum(int which, uint32_t seed, const void* p, size_t n); /* test access: 0 = Adler-32, 1 = CRC-32 of the PNG path (zlib's conventions) */
 int lilliput_hip_inflate_exact(const void* in, size_t in_len, uint8_t* out, size_t out_len); /* test access: 1 = ordinary zlib stream of exactly out_len bytes, decoded; 0 = ask zlib */
 /* Test access, no device work: the per-pixel walk of the fused fractional INTER_AREA kernel (lp_area_core.h), run on the host over

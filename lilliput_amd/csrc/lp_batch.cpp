@@ -355,6 +355,76 @@ struct LpSink {
     }
 };
 
+// The integer-scale op of one image: where the box of destination (0, 0) lies in the un-oriented decoded image and how it moves with
+// the destination coordinates (cv::ExifTransform inverse folded into the addressing). Everything but the image index and dst.off.
+static void fused_op_of(const LpJpeg& j, const LpOpsPlan& plan, int ix, int iy, LpFusedOp* out)
+{
+    const bool swap = j.orientation >= 5;
+    const int OW = swap ? (int)j.height : (int)j.width, OH = swap ? (int)j.width : (int)j.height;
+    // oriented-frame rectangle of destination (dx, dy) -> rectangle of the un-oriented decoded image
+    auto map = [&](int dx, int dy, int* fx, int* fy) {
+        const int ox0 = plan.crop_x + dx * ix, oy0 = plan.crop_y + dy * iy;
+        switch (j.orientation) {
+        case 2: *fx = OW - ox0 - ix; *fy = oy0; break;
+        case 3: *fx = OW - ox0 - ix; *fy = OH - oy0 - iy; break;
+        case 4: *fx = ox0; *fy = OH - oy0 - iy; break;
+        case 5: *fx = oy0; *fy = ox0; break;
+        case 6: *fx = oy0; *fy = OW - ox0 - ix; break;
+        case 7: *fx = OH - oy0 - iy; *fy = OW - ox0 - ix; break;
+        case 8: *fx = OH - oy0 - iy; *fy = ox0; break;
+        default: *fx = ox0; *fy = oy0; break;
+        }
+    };
+    LpFusedOp& op = *out;
+    memset(&op, 0, sizeof(op));
+    op.rw = (uint32_t)(swap ? iy : ix);
+    op.rh = (uint32_t)(swap ? ix : iy);
+    int ax, ay, bx, by;
+    map(0, 0, &op.x0, &op.y0);
+    map(1, 0, &ax, &ay);
+    map(0, 1, &bx, &by);
+    op.dxx = ax - op.x0; op.dxy = ay - op.y0; op.dyx = bx - op.x0; op.dyy = by - op.y0;
+    op.inv_area = 1.f / (float)(ix * iy);
+    op.round_2x2 = (ix == 2 && iy == 2) ? 1 : 0;
+    op.dst.w = (uint32_t)plan.out_w; op.dst.h = (uint32_t)plan.out_h; op.dst.cn = j.ncomp == 1 ? 1 : 3;
+    op.dst.stride = op.dst.w * op.dst.cn;
+}
+
+// Test access (no device work): which kernel the batch path hands an image of this shape to on its way from decoded planes to the
+// output size. 0 = through a materialised frame (no resize, CMYK, unusual sampling, grey at a fractional scale ...), 1 = k_resample_420
+// (8 / 16 / 32-pixel boxes), 2 = k_resample_420_small (2 / 4), 3 = k_resample_hv1 (4:4:4 / 4:2:2), 4 = k_resample_gray, 5 = the area walk
+// with cv::resize's float taps (fractional scales), 6 = the area walk with unit taps (the other integer scales), 7 = k_resample_fused's
+// wave per destination pixel (what is left). tests/test_host_logic.py holds the shapes a service sees to routes 1 - 6: round 5 found
+// every integer scale but 8 / 16 / 32 on route 7 at 30 - 58 us per image.
+extern "C" int lilliput_hip_resample_route(int width, int height, int orientation, int ncomp, int hs, int vs, int out_w, int out_h, int resize_method,
+                                           int normalize_orientation)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    LpJpeg j;
+    memset(&j, 0, sizeof(j));
+    j.width = (uint32_t)width; j.height = (uint32_t)height; j.orientation = (uint8_t)orientation; j.ncomp = (uint8_t)ncomp;
+    j.colorspace = ncomp == 1 ? 1 : 2;
+    j.hs[0] = (uint8_t)hs; j.vs[0] = (uint8_t)vs; j.hmax = (uint8_t)hs; j.vmax = (uint8_t)vs;
+    for (int c = 1; c < ncomp && c < LP_GEOM_COMP; c++) { j.hs[c] = 1; j.vs[c] = 1; }
+    const bool swap = j.orientation >= 5;
+    const int OW = swap ? height : width, OH = swap ? width : height;
+    const LpOpsPlan plan = lp_plan_static_transform(width, height, orientation, out_w, out_h, resize_method, normalize_orientation != 0, OW, OH);
+    if (!plan.resize || j.ncomp == 4) return 0;
+    int ix = 1, iy = 1;
+    const int mode = lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
+    if (mode == 2) {
+        if (lp_area_sampling(j) < 0) return 0;
+        return (swap ? lp_area420_bucket(plan.crop_h, plan.out_h, true) : lp_area420_bucket(plan.crop_w, plan.out_w)) ? 5 : 0;
+    }
+    if (mode != 1) return 0;
+    LpFusedOp op;
+    fused_op_of(j, plan, ix, iy, &op);
+    uint32_t fast = 0;
+    if (lp_fused_op_is_fast(op, j, &fast)) return fast == 0x1000u ? 4 : fast >= 0x100u ? 3 : (op.rw == 2 || op.rw == 4) ? 2 : 1;
+    if (lp_area_sampling(j) >= 0 && lp_area420_bucket_int(swap ? iy : ix, swap) != 0) return 6;
+    return 7;
+}
+LP_ABI_CATCH("lilliput_hip_resample_route", return -1)
+
 static size_t auto_chunk(const lilliput_batch_options* opt, const LpJpegHeader* hdrs, size_t n, size_t cap)
 {
     // chunk size: bound the working set (coefficients + planes + BGR frame ~ 7.5 B/pixel + oriented copy)
@@ -454,32 +524,9 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
                 continue;
             }
             lp_resize_mode(plan.crop_w, plan.crop_h, plan.out_w, plan.out_h, &ix, &iy);
-            // oriented-frame rectangle of destination (dx, dy) -> rectangle of the un-oriented decoded image (cv::ExifTransform inverse)
-            auto map = [&](int dx, int dy, int* fx, int* fy) {
-                const int ox0 = plan.crop_x + dx * ix, oy0 = plan.crop_y + dy * iy;
-                switch (j.orientation) {
-                case 2: *fx = OW - ox0 - ix; *fy = oy0; break;
-                case 3: *fx = OW - ox0 - ix; *fy = OH - oy0 - iy; break;
-                case 4: *fx = ox0; *fy = OH - oy0 - iy; break;
-                case 5: *fx = oy0; *fy = ox0; break;
-                case 6: *fx = oy0; *fy = OW - ox0 - ix; break;
-                case 7: *fx = OH - oy0 - iy; *fy = OW - ox0 - ix; break;
-                case 8: *fx = OH - oy0 - iy; *fy = ox0; break;
-                default: *fx = ox0; *fy = oy0; break;
-                }
-            };
             LpFusedOp op;
-            memset(&op, 0, sizeof(op));
+            fused_op_of(j, plan, ix, iy, &op);
             op.img = (uint32_t)k;
-            op.rw = (uint32_t)(swap ? iy : ix);
-            op.rh = (uint32_t)(swap ? ix : iy);
-            int ax, ay, bx, by;
-            map(0, 0, &op.x0, &op.y0);
-            map(1, 0, &ax, &ay);
-            map(0, 1, &bx, &by);
-            op.dxx = ax - op.x0; op.dxy = ay - op.y0; op.dyx = bx - op.x0; op.dyy = by - op.y0;
-            op.inv_area = 1.f / (float)(ix * iy);
-            op.round_2x2 = (ix == 2 && iy == 2) ? 1 : 0;
             op.dst.w = (uint32_t)plan.out_w; op.dst.h = (uint32_t)plan.out_h; op.dst.cn = j.ncomp == 1 ? 1 : 3;
             op.dst.stride = op.dst.w * op.dst.cn;
             uint8_t* p = eng.heap_alloc((size_t)op.dst.stride * op.dst.h);

@@ -1297,7 +1297,8 @@ bool lp_fused_op_is_fast(const LpFusedOp& op, const LpJpeg& j, uint32_t* fast_ou
     // 2- and 4-pixel boxes of a 4:2:0 source (a 512 x 512 or 1024 x 1024 file and a 256 x 256 thumbnail): k_resample_420_small walks tiles of
     // eight luma columns = four or two boxes, so the boxes must tile that grid exactly
     const uint32_t nb = op.rw == 2 ? 4u : op.rw == 4 ? 2u : 0u;
-    const bool small_ok = nb && (op.x0 % 8) == 0 && steps && op.dst.cn == 3 && (U % nb) == 0;
+    // (mirrored orientations: op.x0 is the box of destination 0, the one at the HIGHEST x; the tile's origin is NB - 1 boxes below it)
+    const bool small_ok = nb && steps && op.dst.cn == 3 && (U % nb) == 0 && ((stepx > 0 ? op.x0 : op.x0 + (int32_t)op.rw) % 8) == 0;
     uint32_t fast = 0, bit = 0;
     if (j.ncomp == 1 && op.dst.cn == 1) {                                                      // k_resample_gray
         fast = 0x1000u;

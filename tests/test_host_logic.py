@@ -227,6 +227,45 @@ def test_multi_symbol_entries_of_the_counting_passes(emu, oracle, fixture_bytes)
     assert steps / nsub < 700, steps / nsub                           # 1 054 steps per subsequence one symbol at a time, 519 with the groups
 
 
+def test_shapes_a_service_sees_reach_a_thread_per_box_kernel_or_the_area_walk(hip_lib):
+    """Regression guard for round 5's finding: every integer scale but 8 / 16 / 32 used to take k_resample_fused's wave per destination
+    pixel (30 - 58 us per image; 512 x 512 sources ran at 23 k images/s, now 154 k). lilliput_hip_resample_route answers, without a device,
+    which kernel the batch path picks for a shape: YCbCr and grey sources of the sizes a service sees, Fit to a square thumbnail, every
+    orientation -- never route 7, and the expected kernel for the common cases."""
+    L = hip_lib
+    FIT = 1  # ops.go:18-22 ImageOpsFit
+    route = lambda w, h, o, nc, hs, vs, tw, th: L.lilliput_hip_resample_route(w, h, o, nc, hs, vs, tw, th, FIT, 0)
+    assert route(4096, 4096, 1, 3, 2, 2, 256, 256) == 1      # the headline: 16 x 16 boxes
+    assert route(2048, 2048, 6, 3, 2, 2, 256, 256) == 1      # 8 x 8, rotated
+    assert route(512, 512, 1, 3, 2, 2, 256, 256) == 2        # 2 x 2
+    assert route(1024, 1024, 3, 3, 2, 2, 256, 256) == 2      # 4 x 4, mirrored both ways
+    assert route(4096, 4096, 1, 3, 1, 1, 256, 256) == 3      # 4:4:4
+    assert route(4096, 4096, 1, 3, 2, 1, 256, 256) == 3      # 4:2:2
+    assert route(1024, 1024, 1, 1, 1, 1, 256, 256) == 4      # grey
+    assert route(4000, 3000, 1, 3, 2, 2, 256, 256) == 5      # a photograph: fractional scale
+    assert route(4032, 3024, 6, 3, 2, 2, 256, 256) == 5
+    assert route(768, 768, 1, 3, 2, 2, 256, 256) == 6        # 3 x 3
+    assert route(3072, 3072, 8, 3, 2, 2, 256, 256) == 6      # 12 x 12, transposed
+    assert route(512, 512, 1, 3, 1, 1, 256, 256) == 6        # 2 x 2 of a 4:4:4 source
+    assert route(200, 200, 1, 3, 2, 2, 256, 256) == 0        # no upscale: no resize
+    seen = {}
+    for nc, hs, vs in ((3, 2, 2), (3, 2, 1), (3, 1, 1), (1, 1, 1)):
+        for side in (128, 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096):
+            for extra in (0, 2, 8, 10, 128, 250):                 # the crop Fit takes starts at extra / 2
+                for t in (64, 128, 256):
+                    if side < t:
+                        continue
+                    for o in range(1, 9):
+                        for wide in (True, False):
+                            w, h = (side + extra, side) if wide else (side, side + extra)
+                            r = route(w, h, o, nc, hs, vs, t, t)
+                            assert r >= 0
+                            seen[r] = seen.get(r, 0) + 1
+                            if side % t == 0 and side // t <= 34 and side > t:
+                                assert r != 7, (w, h, o, nc, hs, vs, t)
+    assert all(seen.get(k, 0) for k in (1, 2, 3, 4, 6)), seen
+
+
 def _strip_segments(jpeg, marker):
     """Drop every segment with this marker code between SOI and SOS."""
     out, i = bytearray(jpeg[:2]), 2
