@@ -266,6 +266,39 @@ def test_shapes_a_service_sees_reach_a_thread_per_box_kernel_or_the_area_walk(hi
     assert all(seen.get(k, 0) for k in (1, 2, 3, 4, 6)), seen
 
 
+def test_multi_symbol_entries_when_components_share_a_dc_table_but_not_an_ac_table(emu, oracle, fixture_bytes):
+    """A scan whose components use ONE DC table with DIFFERENT AC tables (legal, unusual): the DC slot's multi-symbol entries must stay one
+    symbol (there is no single AC table behind the slot), and the lane logic still reproduces libjpeg's coefficients for the file --
+    here a fixture whose SOS selectors were rewritten (Cb: DC table 0 with AC table 1), i.e. a stream decoded with tables it was not
+    written for: both decoders read the same garbage the same way, or the device logic hands the stream over (negative code)."""
+    data = bytearray(fixture_bytes["sunrise.jpg"])
+    sos = data.find(b"\xff\xda")
+    assert sos > 0 and data[sos + 4] == 3                      # three components in the scan
+    assert data[sos + 5 + 2 * 1 + 1] == 0x11                   # Cb: Td 1, Ta 1
+    data[sos + 5 + 2 * 1 + 1] = 0x01                           # -> Td 0, Ta 1
+    data = bytes(data)
+    a = np.frombuffer(data, np.uint8)
+    lut = np.zeros((4, 1024), np.uint16)
+    lutm = np.zeros((4, 1024), np.uint16)
+    bits = C.c_int()
+    assert emu.emu_huff_tables(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), lut.ctypes.data_as(C.c_void_p), lutm.ctypes.data_as(C.c_void_p), C.byref(bits)) == 3
+    assert np.array_equal(lut[0], lutm[0])                     # DC slot 0 feeds AC slots 2 and 3: no group may continue into either
+    assert not np.array_equal(lut[2], lutm[2])                 # the AC slots keep their groups
+    cap = 1 << 22
+    out = np.empty(cap, np.int16)
+    for comp in range(3):
+        bw, bh, r, ns, hits = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rc = emu.emu_decode_coefs(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size), C.c_uint32(1024), C.c_uint32(64), C.c_int(comp), out.ctypes.data_as(C.c_void_p),
+                                  C.c_size_t(cap), C.byref(bw), C.byref(bh), C.byref(r), C.byref(ns), C.byref(hits))
+        if rc < 0:
+            continue                                           # handed to the serial route: its business (tests/test_damaged.py)
+        try:
+            ref = oracle.ref_jpeg_decode_coefs(data, comp) if oracle.ref() is not None else oracle.jpeg_decode_coefs(data, comp)
+        except Exception:
+            continue
+        assert np.array_equal(out[: bw.value * bh.value * 64].reshape(bh.value, bw.value, 64), ref), comp
+
+
 def _strip_segments(jpeg, marker):
     """Drop every segment with this marker code between SOI and SOS."""
     out, i = bytearray(jpeg[:2]), 2
