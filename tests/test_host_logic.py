@@ -268,9 +268,10 @@ def test_shapes_a_service_sees_reach_a_thread_per_box_kernel_or_the_area_walk(hi
 
 def test_multi_symbol_entries_when_components_share_a_dc_table_but_not_an_ac_table(emu, oracle, fixture_bytes):
     """A scan whose components use ONE DC table with DIFFERENT AC tables (legal, unusual): the DC slot's multi-symbol entries must stay one
-    symbol (there is no single AC table behind the slot), and the lane logic still reproduces libjpeg's coefficients for the file --
-    here a fixture whose SOS selectors were rewritten (Cb: DC table 0 with AC table 1), i.e. a stream decoded with tables it was not
-    written for: both decoders read the same garbage the same way, or the device logic hands the stream over (negative code)."""
+    symbol (there is no single AC table behind the slot) while the AC slots keep their groups. The fixture is a file whose SOS selectors
+    were rewritten (Cb: DC table 0 with AC table 1), i.e. a stream read with tables it was not written for: the lane logic either
+    reproduces libjpeg's coefficients for it or hands the stream over (a negative code; this fixture: the block count does not come out,
+    -16) -- never a different answer."""
     data = bytearray(fixture_bytes["sunrise.jpg"])
     sos = data.find(b"\xff\xda")
     assert sos > 0 and data[sos + 4] == 3                      # three components in the scan
