@@ -481,13 +481,18 @@ int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current
 void lilliput_hip_set_deferred(int on);
 void lilliput_hip_deferred_stats(uint64_t out[4]);
 
-/* Progressive (SOF2) JPEG sources: the scans' entropy decode runs on host threads feeding the device IDCT with coefficients (a scan
- * is serial by construction; see lilliput_amd/csrc/lp_prog_host.h; thread count: LILLIPUT_HIP_PROG_THREADS). A second home -- one device
- * lane per scan (k_prog_scan), 25x slower at 4096 x 4096 -- is a BUILD option since round 3 (make DEFS=-DLP_PROG_DEVICE_LANES);
- * lilliput_hip_progressive_device_lanes_built() says whether this library carries it, and only then do
- * lilliput_hip_set_progressive_entropy(1) / LILLIPUT_HIP_PROG_ENTROPY=device select it. Same results either way. */
-void lilliput_hip_set_progressive_entropy(int on_device);
+/* Progressive (SOF2) JPEG sources (libjpeg-turbo jdphuff.c behind opencv_decoder_read_data, opencv.cpp:166-171): where the scans' entropy
+ * decode runs. mode -1 = auto (default): on the device -- one wave per scan, lilliput_amd/csrc/lp_kernels_prog.hip -- for the progressive
+ * images of an upload set that holds at least LILLIPUT_HIP_PROG_DEVICE_MIN (default 48) of them, on host threads (lp_prog_host.h; thread
+ * count LILLIPUT_HIP_PROG_THREADS) otherwise; 0 = host threads always; 1 = device always; 2 = the generic one-lane-per-scan device kernel
+ * (k_prog_scan, the wave decoder's tested reference). LILLIPUT_HIP_PROG_ENTROPY=auto|host|device|lanes sets the process default.
+ * Same results in every mode: an image whose data the device decoders find irregular is decoded again by the host threads.
+ * lilliput_hip_progressive_device_lanes_built(): 1 (the device decoders were a build option in rounds 3-5). */
+void lilliput_hip_set_progressive_entropy(int mode);
 int lilliput_hip_progressive_device_lanes_built(void);
+/* Process-wide counters since start: out[0] scan-path images whose scans were decoded on the device, out[1] those of them the device decoders
+ * gave up on (irregular data: decoded again by the host threads), out[2] scans launched on the device. */
+void lilliput_hip_progressive_stats(uint64_t out[3]);
 /* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
  * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
  * -3 = dst too small. nthreads 0 = default. */

@@ -886,6 +886,14 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return p->is_png ? "PNG" : p->is_bmp ? "BMP" : "JPEG";
 }
 LP_ABI_CATCH("opencv_decoder_get_description", return nullptr)
+// LILLIPUT_HIP_DEFER_KEEP_SERVED=1: a chain that has been encoded once keeps a copy of its source at Close as well, so that a caller
+// who closes the decoder and THEN encodes the same framebuffer a second time (or reads it) still gets pixels, as with the reference's
+// framebuffer of real pixels. Off by default: ops.go never does that, and the copy is 4 MB of host traffic per request for nobody.
+static bool keep_served_sources()
+{
+    static const bool on = [] { const char* e = getenv("LILLIPUT_HIP_DEFER_KEEP_SERVED"); return e && atoi(e) != 0; }();
+    return on;
+}
 void opencv_decoder_release(opencv_decoder dd)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<LpDecoder*>(dd);
@@ -898,7 +906,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     for (auto& w : d->lazies)
         if (auto src = w.lock()) {
             if (src->p != d->data || !src->keep.empty()) continue;
-            if (src->served) src->p = nullptr;
+            if (src->served && !keep_served_sources()) src->p = nullptr;
             else {
                 src->keep.assign(d->data, d->data + d->len);
                 src->p = src->keep.data();
@@ -1144,7 +1152,9 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
         if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {
             size_t n = 0;
             const std::shared_ptr<LpLazySrc> src = s->lazy->src;
-            const int st = lp_coalesce_transform_status(lp_current_device(), src->p, src->len, d->datastart, cap, bo, &n);
+            // a chain whose decoder was closed after it had been served once has lost its bytes (opencv_decoder_release): no batched
+            // route for it -- the eager route below reports the broken contract (lp_mat_materialize) instead of reading a null source
+            const int st = src->p ? lp_coalesce_transform_status(lp_current_device(), src->p, src->len, d->datastart, cap, bo, &n) : LILLIPUT_ERR_INVALID_IMAGE;
             if (st == LILLIPUT_OK && n > 0 && n <= cap) {
                 src->served = true;
                 d->data = d->datastart;

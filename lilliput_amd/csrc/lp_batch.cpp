@@ -683,7 +683,7 @@ static int run_chunk(LpBatch* b, LpBatchPart& part, int first, int cnt, const Lp
         for (int k = 0; k < cnt; k++) {
             const size_t item = (size_t)item_of[k];
             if (st[(size_t)k]) b->status[item] = map_status(st[(size_t)k]);
-            if (st[(size_t)k] == LP_ERR_DECODE_FAILED && sink.items && !hdrs[k].scan_path) { // see LpEngine::decode_jpegs
+            if (st[(size_t)k] == LP_ERR_DECODE_FAILED && sink.items && (!hdrs[k].scan_path || eng.scan_gave_up(k))) { // see LpEngine::decode_jpegs
                 std::lock_guard<std::mutex> lk(b->retry_mu);
                 b->retry.push_back((int)item);
             }

@@ -237,6 +237,7 @@ bool lp_coalesce_wanted(int in_flight)
 int lp_coalesce_transform_status(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len)
 {
     *out_len = 0;
+    if (!src || !len) return LILLIPUT_ERR_INVALID_IMAGE; // nothing to stage (a deferred chain whose source was dropped never gets here)
     Dispatch* D = dispatch_for(device);
     if (!D) return LILLIPUT_ERR_DEVICE;
     Req r;

@@ -382,9 +382,28 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
     u.huffs.clear();
     u.prog.assign((size_t)n, std::vector<LpUpload::ProgScanUp>());
     u.phuffs.clear();
-    u.prog_on_device = lp_prog_entropy_on_device();
-    for (int i = 0; i < n; i++) // a QM-coded scan only has a host decoder (lp_arith_host.h): a set that holds one is decoded in hybrid mode as a whole
-        if (hdrs[i].arith) u.prog_on_device = false;
+    // Where each scan-path image's entropy decode runs (lp_prog_host.h): 0 host threads, 1 device (a wave per progressive scan, lanes for
+    // sequential ones), 2 device lanes throughout (the generic kernel: the tested reference of the wave decoder).
+    u.prog_mode = u.force_host_scans ? 0 : lp_prog_entropy_mode();
+    u.prog_dev.assign((size_t)n, 0);
+    u.any_prog_dev = false;
+    {
+        size_t cand = 0;
+        for (int i = 0; i < n; i++) {
+            if (!hdrs[i].scan_path || hdrs[i].arith) continue; // a QM-coded scan only has a host decoder (lp_arith_host.h)
+            bool seq = false;
+            for (const LpProgScanHost& sh : hdrs[i].scans) seq = seq || sh.s.sequential;
+            if (u.prog_mode < 0 && seq) continue;               // auto: the wave decoder's files only
+            u.prog_dev[(size_t)i] = 1;
+            cand++;
+        }
+        // auto: a scan is a serial chain and one wave walks it ~3x slower than a host core, so the device only wins with enough
+        // chains side by side (measured break-even: profiles/r06_progressive.md); below it the host threads keep the set
+        if (u.prog_mode < 0 && cand < lp_prog_device_min_images()) cand = 0;
+        if (u.prog_mode == 0 || !cand) u.prog_dev.assign((size_t)n, 0);
+        u.any_prog_dev = u.prog_mode != 0 && cand != 0;
+        if (u.prog_mode < 0) u.prog_mode = 1;
+    }
     u.pcoef_off.assign((size_t)n, 0);
     u.perr.assign((size_t)n, 0);
     u.pcoef_total = 0;
@@ -404,7 +423,7 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
         j.raw_off = raw_bytes;
         j.raw_skip = 0;
         j.scan_path = hdrs[i].scan_path ? 1 : 0;
-        if (hdrs[i].scan_path && !u.prog_on_device) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
+        if (hdrs[i].scan_path && !u.prog_dev[(size_t)i]) { // hybrid mode: host threads decode the scans into a pinned coefficient buffer
             j.raw_len = 0;
             u.pcoef_off[(size_t)i] = u.pcoef_total;
             for (int c = 0; c < j.ncomp; c++) u.pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
@@ -790,6 +809,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
                 ps.rst_off = tot_rst_;
                 ps.rst_cap = sa.dri ? (sa.mcux * sa.mcuy + sa.dri - 1) / sa.dri + 2 : 2;
                 tot_rst_ += ps.rst_cap;
+                // the unstuff kernels check a stream's restart markers (one per interval, RST0..7 in turn) when it looks like an image of its
+                // own: anything else is the host route's (jdmarker.c jpeg_resync_to_restart, lp_jbits.h)
+                ps.dri = sa.dri; ps.mcus_x = sa.mcux; ps.mcus_y = sa.mcuy; ps.total_blocks = 1;
                 max_pchunks = std::max(max_pchunks, ps.nchunks);
                 LpProgScan sc = sa;
                 sc.img = (uint32_t)i;
@@ -891,10 +913,11 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     stage("huff_write");
     lp_launch_dc_scan(stream_, di, (uint32_t)n, max_mcus_, d_dc_.as<int16_t>(), d_dcpart_.p);
     stage("dc_scan");
-    if (pcoef_elems && !u_->prog_on_device) { // hybrid mode: the coefficients were decoded at upload time
+    if (nstreams && !check(hipMemsetAsync(d_pcoef_.p, 0, pcoef_elems * 2, stream_), "memset coefficients")) return LP_ERR_DEVICE;
+    if (pcoef_elems) { // hybrid mode: the coefficients were decoded at upload time
         for (int i = 0; i < n; i++) {
             const LpJpeg& j = h_imgs_[(size_t)i];
-            if (!j.scan_path) continue;
+            if (!j.scan_path || u_->prog_dev[(size_t)first + i]) continue;
             size_t ne = 0;
             for (int c = 0; c < j.ncomp; c++) ne += (size_t)j.bw[c] * j.bh[c] * 64;
             if (!check(hipMemcpyAsync(d_pcoef_.as<int16_t>() + j.coef_off, u_->pcoef.as<int16_t>() + u_->pcoef_off[(size_t)first + i], ne * 2, hipMemcpyHostToDevice, stream_), "H2D coefficients"))
@@ -904,24 +927,27 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     if (nstreams) { // progressive images: unstuff every scan, then the scans level by level into the zeroed int16 arena
         if (!check(hipMemcpyAsync(d_pstreams_.p, h_pstreams_.data(), sizeof(LpJpeg) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scan streams") ||
             !check(hipMemcpyAsync(d_pscans_.p, h_pscans_.data(), sizeof(LpProgScan) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scans") ||
-            !check(hipMemsetAsync(d_pstates_.p, 0, sizeof(LpJpegState) * nstreams, stream_), "memset scan states") ||
-            !check(hipMemsetAsync(d_pcoef_.p, 0, pcoef_elems * 2, stream_), "memset coefficients"))
+            !check(hipMemsetAsync(d_pstates_.p, 0, sizeof(LpJpegState) * nstreams, stream_), "memset scan states"))
             return LP_ERR_DEVICE;
         lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
                           d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
         stage("prog_unstuff");
-#ifdef LP_PROG_DEVICE_LANES
         for (size_t l = 0; l + 1 < h_plevel_first_.size(); l++) {
             const uint32_t f = h_plevel_first_[l], cnt = h_plevel_first_[l + 1] - f;
+            bool any_seq = false, any_prog = false;
+            for (uint32_t q = f; q < f + cnt; q++) (h_pscans_[q].sequential ? any_seq : any_prog) = true;
+            const bool waves = u_->prog_mode == 1;
+            // one WAVE per progressive scan (lp_kernels_prog.hip); sequential scans, and everything in lanes mode, one LANE per scan:
             // few lanes: one per wave (a lane alone on its SIMD runs fastest); many: pack them so that the grid stays a few waves per SIMD
-            const uint32_t lpw = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (cnt + 4095u) / 4096u));
-            lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),
-                                 u_->d_phuffs.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+            if (waves && any_prog)
+                lp_launch_prog_wave(stream_, d_pscans_.as<LpProgScan>(), f, cnt, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(), u_->d_phuffs.as<LpProgHuff>(),
+                                    d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+            if (!waves || any_seq) {
+                const uint32_t lpw = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (cnt + 4095u) / 4096u));
+                lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, waves, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),
+                                     u_->d_phuffs.as<LpProgHuff>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+            }
         }
-#else
-        err_ = "this build carries no device-lane scan decoder"; // unreachable: lp_prog_entropy_on_device() is false without the build flag
-        return LP_ERR_DEVICE;
-#endif
         stage("prog_scans");
     }
     mark(2);
@@ -999,10 +1025,17 @@ int LpEngine::finish_decode(int* status)
     if (nstreams) { // a scan that failed to unstuff fails its image
         h_pstates_.resize(nstreams);
         if (!check(hipMemcpy(h_pstates_.data(), d_pstates_.p, sizeof(LpJpegState) * nstreams, hipMemcpyDeviceToHost), "D2H scan states")) return LP_ERR_DEVICE;
-        for (const LpProgScan& sc : h_pscans_) h_states_[sc.img].error |= h_pstates_[sc.stream].error;
+        // a scan the device gave up on (a marker inside it, restart markers out of turn, a code that matches nothing, data that runs out ...):
+        // the image is the host route's, which does with such a stream what libjpeg does (LpEngine::scan_gave_up)
+        for (const LpProgScan& sc : h_pscans_)
+            if (h_pstates_[sc.stream].error) h_states_[sc.img].error |= 64u;
+        uint64_t dev = 0, gave_up = 0;
+        for (int i = 0; i < n; i++)
+            if (h_imgs_[(size_t)i].scan_path && u_->prog_dev[(size_t)first + i]) { dev++; gave_up += (h_states_[(size_t)i].error & 64u) ? 1u : 0u; }
+        lp_prog_count(dev, gave_up, h_pscans_.size());
     }
     for (int i = 0; i < n; i++)
-        if (h_imgs_[(size_t)i].scan_path && !u_->prog_on_device) h_states_[(size_t)i].error |= u_->perr[(size_t)first + i];
+        if (h_imgs_[(size_t)i].scan_path && !u_->prog_dev[(size_t)first + i]) h_states_[(size_t)i].error |= u_->perr[(size_t)first + i];
     int rc = LP_OK;
     for (int i = 0; i < n; i++) {
         status[i] = h_states_[(size_t)i].error ? LP_ERR_DECODE_FAILED : LP_OK;
@@ -1112,6 +1145,18 @@ int LpEngine::decode_jpegs(const LpJpegSrc* srcs, int n, const LpJpegHeader* hdr
         int st = 0;
         if (upload_jpegs(&srcs[i], 1, &again)) continue;
         const int r2 = run_decode(0, 1, &frames[i], &st, nullptr, false);
+        if (r2 != LP_ERR_DEVICE) status[i] = st;
+    }
+    // a progressive image the device's scan decoders gave up on: once more with its scans on host threads
+    std::vector<int> gave_up;
+    for (int i = 0; i < n; i++)
+        if (status[i] == LP_ERR_DECODE_FAILED && hdrs[i].scan_path && scan_gave_up(i)) gave_up.push_back(i);
+    for (int i : gave_up) {
+        int st = 0;
+        for (int s = 0; s < LP_UPLOAD_SLOTS; s++) up_[s].force_host_scans = true;
+        const int ru = upload_jpegs(&srcs[i], 1, &hdrs[i]);
+        const int r2 = ru ? LP_ERR_DEVICE : run_decode(0, 1, &frames[i], &st, nullptr, false);
+        for (int s = 0; s < LP_UPLOAD_SLOTS; s++) up_[s].force_host_scans = false;
         if (r2 != LP_ERR_DEVICE) status[i] = st;
     }
     rc = LP_OK;

@@ -116,7 +116,10 @@ struct LpUpload {
     LpPinScope pins;                                // the page ranges registered for this set (released when the slot is reused)
     bool staged_whole = false;                      // the pinned buffer holds the whole set (upload_copy / upload_commit); else windowed
     // progressive images (SOF2) and the other scan-by-scan cases
-    bool prog_on_device = false;                    // where this set's scans are entropy-decoded (lp_prog_host.h)
+    int prog_mode = 0;                              // how the set's device-side scans are decoded: 1 a wave per progressive scan, 2 lanes (lp_prog_host.h)
+    std::vector<uint8_t> prog_dev;                  // per image: 1 = its scans are entropy-decoded on the device, 0 = on host threads
+    bool any_prog_dev = false;
+    bool force_host_scans = false;                  // the next layout keeps every scan on host threads (an image the device gave up on)
     LpPinned pcoef;                                 // host mode: the decoded int16 coefficients of every scan-path image of the set
     std::vector<size_t> pcoef_off;                  // element offset per image
     std::vector<uint32_t> perr;                     // per image
@@ -188,6 +191,10 @@ public:
     const LpJpeg& uploaded(size_t i) const { return u_->src[i]; }
     // stage-level read-back for parity tests (valid after a decode of the current range)
     int copy_coefs(int i, int comp, int16_t* dst, size_t cap_elems);
+    // image i of the last collected decode: a scan-path image whose scans ran on the device and met something only the host route decodes
+    // the way libjpeg does (lp_kernels_prog.hip "irregular", a marker inside a scan, restart markers out of turn): decode it again with
+    // LpUpload::force_host_scans (decode_jpegs does; the batch path sends it through its one-image retry)
+    bool scan_gave_up(int i) const { return (size_t)i < h_states_.size() && (h_states_[(size_t)i].error & 64u) != 0; }
     int copy_plane(int i, int comp, uint8_t* dst, size_t cap);
     const LpJpeg& decoded(int i) const { return h_imgs_[(size_t)i]; }
 

@@ -1139,9 +1139,11 @@ __global__ __launch_bounds__(256) LP_IDCT_ATTR void k_idct(const LpJpeg* __restr
     }
 }
 
-#ifdef LP_PROG_DEVICE_LANES // the device-lane home of the progressive scans is a build option (make DEFS=-DLP_PROG_DEVICE_LANES): see lp_prog_host.h
 // ------------------------------------------------------------------------------------------------
-// Progressive scans (lp_prog_core.h): lane = one scan of one image, decoded serially from its first bit to its last. The lanes
+// Scans decoded by ONE LANE each (lp_prog_core.h), serially from the first bit to the last: the generic restatement of jdphuff.c / jdhuff.c.
+// Since round 6 the progressive scans proper have a wave each (lp_kernels_prog.hip: ~15x faster per scan); this kernel keeps the
+// sequential scan-path files (several scans, four components, table numbers 2 / 3: LpProgScan::sequential) and is the
+// LILLIPUT_HIP_PROG_ENTROPY=lanes reference the wave decoder is tested against. The lanes
 // of a launch share nothing (different streams, tables and blocks), so a workgroup carries only `lpw` of them: with few scans
 // in flight every lane gets a wave -- and its SIMD's issue slots -- to itself.
 struct DevProgMem {
@@ -1193,7 +1195,7 @@ struct DevProgMem {
     }
 };
 
-__global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, uint32_t lpw,
+__global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, uint32_t lpw, uint32_t only_sequential,
                                                   const LpJpeg* __restrict__ streams, const LpJpegState* __restrict__ stream_states,
                                                   const LpProgHuff* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                   const uint32_t* __restrict__ rst_arena, int16_t* __restrict__ pcoef)
@@ -1203,6 +1205,7 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
     const uint32_t i = blockIdx.x * lpw + threadIdx.x;
     if (i >= n) return;
     const LpProgScan sc = scans[first + i];
+    if (only_sequential && !sc.sequential) return; // k_prog_wave's
     const LpJpeg& stream = streams[sc.stream];
     const LpJpegState& st = stream_states[sc.stream];
     DevProgMem m;
@@ -1215,8 +1218,6 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
     m.dirty = 0;
     lp_prog_scan(m, sc, st.clean_bytes * 8u, st.n_rst);
 }
-
-#endif // LP_PROG_DEVICE_LANES
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (plain C++ signatures; see lp_launch.h)
@@ -1371,14 +1372,12 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
     if (which & 2u) hipLaunchKernelGGL(k_idct<true>, g, dim3(256), 0, s, d_imgs, d_states, d_coef8, d_wide, d_wide_id, d_dc, d_pcoef, d_planes);
 }
 
-#ifdef LP_PROG_DEVICE_LANES
-void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, const LpJpeg* d_streams,
+void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, bool only_sequential, const LpJpeg* d_streams,
                           const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
 {
     if (!n) return;
     if (lpw < 1) lpw = 1;
     if (lpw > 64) lpw = 64;
-    hipLaunchKernelGGL(k_prog_scan, dim3((n + lpw - 1) / lpw), dim3(64), 0, s, d_scans, first, n, lpw, d_streams, d_stream_states, d_huffs, d_clean, d_rst,
-                       d_pcoef);
+    hipLaunchKernelGGL(k_prog_scan, dim3((n + lpw - 1) / lpw), dim3(64), 0, s, d_scans, first, n, lpw, only_sequential ? 1u : 0u, d_streams, d_stream_states, d_huffs, d_clean,
+                       d_rst, d_pcoef);
 }
-#endif

@@ -46,8 +46,12 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
                     const int16_t* d_wide, const uint32_t* d_wide_id, const int16_t* d_dc, uint8_t* d_planes, uint32_t which /* 1 baseline, 2 progressive */,
                     const int16_t* d_pcoef);
 // progressive scans [first, first + n) of d_scans (one dependency level): lane = scan, `lpw` lanes per 64-thread workgroup
-void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, const LpJpeg* d_streams,
+// only_sequential: skip the progressive scans (lp_launch_prog_wave takes them)
+void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, bool only_sequential, const LpJpeg* d_streams,
                           const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
+// the same level, one WAVE per scan (lp_kernels_prog.hip): the progressive scans; sequential ones (LpProgScan::sequential) are left to the lanes above
+void lp_launch_prog_wave(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, const LpJpeg* d_streams, LpJpegState* d_stream_states,
+                         const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
 // pixels
 void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, bool any_generic, bool any_420,
                             const uint8_t* d_planes, const LpFrame* d_dsts, uint8_t* d_frames);

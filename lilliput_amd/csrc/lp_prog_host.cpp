@@ -133,37 +133,33 @@ void run_task(const LpProgHostTask& t)
     else if (rc == LP_SCAN_BAD_MARKER) __atomic_or_fetch(t.error, 16u, __ATOMIC_RELAXED);
 }
 
-std::atomic<int> g_mode{-1};
+std::atomic<int> g_mode{-2}; // -2: not read from the environment yet
 } // namespace
 
-// Where the scans of a progressive file are entropy-decoded. Host threads always exist (the default: a scan is serial by construction and
-// a host core walks it ~30x faster than one GPU lane; 48 images/s against 1.9 at 4096 x 4096). The device-lane decoder (k_prog_scan)
-// only pays with thousands of images in flight and is a BUILD option since round 3 (make DEFS=-DLP_PROG_DEVICE_LANES); without it the
-// switch below is inert.
-bool lp_prog_entropy_on_device()
+// Where the scans of a progressive file are entropy-decoded (lp_prog_host.h): -1 auto (default), 0 host threads, 1 device, 2 device lanes.
+int lp_prog_entropy_mode()
 {
-#ifdef LP_PROG_DEVICE_LANES
     int m = g_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
+    if (m == -2) {
         const char* e = getenv("LILLIPUT_HIP_PROG_ENTROPY");
-        m = e && !strcmp(e, "device") ? 1 : 0;
+        m = !e ? -1 : !strcmp(e, "host") ? 0 : !strcmp(e, "device") ? 1 : !strcmp(e, "lanes") ? 2 : -1;
         g_mode.store(m, std::memory_order_relaxed);
     }
-    return m != 0;
-#else
-    return false;
-#endif
+    return m;
 }
-extern "C" void lilliput_hip_set_progressive_entropy(int on_device) { g_mode.store(on_device ? 1 : 0, std::memory_order_relaxed); }
-extern "C" int lilliput_hip_progressive_device_lanes_built(void)
-try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
-#ifdef LP_PROG_DEVICE_LANES
-    return 1;
-#else
-    return 0;
-#endif
+uint32_t lp_prog_device_min_images()
+{
+    static const uint32_t v = [] { const char* e = getenv("LILLIPUT_HIP_PROG_DEVICE_MIN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 48u; }();
+    return v;
 }
-LP_ABI_CATCH("lilliput_hip_progressive_device_lanes_built", return 0)
+extern "C" void lilliput_hip_set_progressive_entropy(int mode) { g_mode.store(mode < -1 || mode > 2 ? -1 : mode, std::memory_order_relaxed); }
+static std::atomic<uint64_t> g_prog_stats[3];
+void lp_prog_count(uint64_t device_images, uint64_t gave_up, uint64_t device_scans)
+{
+    g_prog_stats[0] += device_images; g_prog_stats[1] += gave_up; g_prog_stats[2] += device_scans;
+}
+extern "C" void lilliput_hip_progressive_stats(uint64_t out[3]) { for (int i = 0; i < 3; i++) out[i] = g_prog_stats[i].load(); }
+extern "C" int lilliput_hip_progressive_device_lanes_built(void) { return 1; } // (a build option in rounds 3-5; both device decoders are in every library now)
 
 void lp_prog_levels(const std::vector<LpProgScanHost>& scans, std::vector<uint32_t>& level)
 {

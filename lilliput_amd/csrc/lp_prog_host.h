@@ -1,14 +1,15 @@
-// lp_prog_host.h -- hybrid mode for progressive (SOF2) sources: the scans' entropy decode on host threads.
+// lp_prog_host.h -- progressive (SOF2) and other scan-by-scan sources: the scans' entropy decode on host threads, and the switch between
+// this home and the device's (lp_kernels_prog.hip: a wave per scan).
 //
 // A progressive scan is serial by construction (a refinement scan parses differently depending on which coefficients of the
-// block at hand are already non-zero, so nothing downstream of an unknown block index can be decoded), and one GPU lane runs
-// such a chain ~30x slower than a CPU core (measured: 8.3 s per 4096 x 4096 image with one lane per scan against ~0.2 s here).
-// So by default the scans are decoded by host threads -- the same lane logic, lp_prog_core.h -- straight into a pinned int16
+// block at hand are already non-zero, so nothing downstream of an unknown block index can be decoded). Host threads decode the scans --
+// lp_prog_core.h over the raw bytes (lp_jbits.h: libjpeg's reader restated, damaged data included) -- straight into a pinned int16
 // coefficient buffer, like the PNG path's inflate and the GIF path's LZW ("host inflate"); dequantisation,
 // IDCT, upsampling, colour, resample and encode stay on the device. This is part of the designed path, not a fallback: it feeds
-// k_idct<true> and fails like everything else when there is no device. LILLIPUT_HIP_PROG_ENTROPY=device (or
-// lilliput_hip_set_progressive_entropy(1)) keeps the scans on the device instead (k_prog_scan); both modes are tested against
-// the oracle and against each other.
+// k_idct<true> and fails like everything else when there is no device. It is the home of small sets (lower latency: a host core walks one
+// chain ~3x faster than a wave), of QM-coded files, of sequential multi-scan files in auto mode, and of every image the device decoders
+// give up on; large sets of progressive files go to the device (see lp_prog_entropy_mode below). All homes are tested against the oracle
+// and against each other.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -35,5 +36,19 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads);
 // Dependency level of every scan of one image: scans that touch the same coefficients of the same component keep file order.
 void lp_prog_levels(const std::vector<LpProgScanHost>& scans, std::vector<uint32_t>& level);
 
-// 1 = scans decoded on the device, 0 = on host threads (default)
-bool lp_prog_entropy_on_device();
+// Where the scans of a scan-path image are entropy-decoded. LILLIPUT_HIP_PROG_ENTROPY = auto | host | device | lanes, or
+// lilliput_hip_set_progressive_entropy(-1 | 0 | 1 | 2):
+//   0 host   host threads (this file), whatever the set holds.
+//   1 device every Huffman-coded scan-path image of an upload set on the device: a WAVE per progressive scan (lp_kernels_prog.hip), a lane per
+//            sequential scan (k_prog_scan). QM-coded files stay on host threads (a set may mix both).
+//   2 lanes  as 1 with the generic one-lane-per-scan kernel for every scan: the wave decoder's tested reference (30-50x slower).
+//  -1 auto   (default) device for the progressive images of a set that holds at least lp_prog_device_min_images() of them
+//            (LILLIPUT_HIP_PROG_DEVICE_MIN, default 48), host threads otherwise: a scan is a serial chain, a wave walks it ~3x slower than
+//            a host core, and a set only offers (images x independent scans) chains -- few images are faster on the host's cores, many
+//            on the device's thousands of wave slots.
+// An image the device decoders give up on (damaged data; LpEngine::scan_gave_up) is decoded again by the host threads in every mode.
+int lp_prog_entropy_mode();
+uint32_t lp_prog_device_min_images();
+// process-wide counters (lilliput_hip_progressive_stats): scan-path images whose scans ran on the device, those of them the device decoders
+// gave up on (decoded again by the host threads), scans launched on the device
+void lp_prog_count(uint64_t device_images, uint64_t gave_up, uint64_t device_scans);

@@ -161,6 +161,10 @@ struct LpJpegState {
     uint32_t pad;
 };
 
+// LpJpegState::error of a progressive scan's pseudo stream: the wave decoder (lp_kernels_prog.hip) met something a well-formed stream does
+// not hold; the image is decoded by the host route, which does what libjpeg does with it
+#define LP_PROG_IRREGULAR 32u
+
 // Decoder state at a symbol boundary.
 struct LpSubState {
     uint32_t p;                 // bit position in the clean stream

@@ -766,6 +766,52 @@ def test_deferred_mats_materialise_for_anyone_who_looks(hip_lib, oracle, fixture
 
 
 @pytest.mark.gpu
+def test_served_chain_after_decoder_close_fails_without_a_crash(hip_lib, oracle, fixture_bytes):
+    """encode, decoder.Close, encode the SAME framebuffer again: the served chain has lost its source bytes (opencv_decoder_release does not
+    copy 4 MB per request for ops.go's benefit), so the second encode must answer false -- not hand a null source to the call coalescer's
+    staging copy (round-5 advisor finding; LILLIPUT_HIP_DEFER_KEEP_SERVED=1 keeps the bytes instead)."""
+    import ctypes as C
+
+    L = hip_lib
+    for f in ("opencv_mat_create_from_data", "opencv_mat_create_empty_from_data", "opencv_decoder_create", "opencv_encoder_create", "opencv_mat_get_data"):
+        getattr(L, f).restype = C.c_void_p
+    for f in ("opencv_mat_release", "opencv_decoder_release", "opencv_encoder_release"):
+        getattr(L, f).restype = None
+    for f in ("opencv_encoder_write", "opencv_decoder_read_data", "opencv_decoder_read_header"):
+        getattr(L, f).restype = C.c_bool
+    data = fixture_bytes["ferry_sunset.jpg"]
+    src = np.frombuffer(bytearray(data), dtype=np.uint8).copy()
+    buf = L.opencv_mat_create_from_data(C.c_int(src.size), C.c_int(1), C.c_int(0), C.c_void_p(src.ctypes.data), C.c_size_t(src.size))
+    d = L.opencv_decoder_create(C.c_void_p(buf))
+    assert L.opencv_decoder_read_header(C.c_void_p(d))
+    w, h = L.opencv_decoder_get_width(C.c_void_p(d)), L.opencv_decoder_get_height(C.c_void_p(d))
+    fb = np.zeros(w * h * 4, dtype=np.uint8)
+    m = L.opencv_mat_create_from_data(C.c_int(w), C.c_int(h), C.c_int(16), C.c_void_p(fb.ctypes.data), C.c_size_t(fb.size))
+    assert L.opencv_decoder_read_data(C.c_void_p(d), C.c_void_p(m))
+    out = np.zeros(1 << 20, dtype=np.uint8)
+    opts = (C.c_int * 2)(1, 85)
+
+    def encode():
+        dm = L.opencv_mat_create_empty_from_data(C.c_int(out.size), C.c_void_p(out.ctypes.data))
+        e = L.opencv_encoder_create(b".jpeg", C.c_void_p(dm))
+        ok = L.opencv_encoder_write(C.c_void_p(e), C.c_void_p(m), opts, C.c_size_t(2))
+        n = L.opencv_mat_get_height(C.c_void_p(dm)) if ok else 0
+        L.opencv_encoder_release(C.c_void_p(e))
+        L.opencv_mat_release(C.c_void_p(dm))
+        return ok, n
+
+    ok, n = encode()
+    assert ok and bytes(out[:n]) == oracle.jpeg_encode(oracle.jpeg_decode(data), 85)
+    L.opencv_decoder_release(C.c_void_p(d))
+    src[:] = 0
+    ok2, _ = encode()          # the chain was served and its decoder is gone: a loud false, never a crash
+    assert not ok2
+    L.opencv_mat_get_data(C.c_void_p(m))   # whatever the accessor answers, it must not crash either
+    L.opencv_mat_release(C.c_void_p(m))
+    L.opencv_mat_release(C.c_void_p(buf))
+
+
+@pytest.mark.gpu
 def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
     """Differential test of the deferred Part A machinery (lp_abi_opencv.cpp "deferred chains"): random sequences of the calls a cgo caller
     may issue after opencv_decoder_read_data -- orientation, crop, resize, in any order and number, ending in the JPEG encoder, the PNG
