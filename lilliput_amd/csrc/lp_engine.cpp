@@ -215,7 +215,7 @@ LpEngine::LpEngine(int device) : device_(device)
     LP_TAG(d_imgs_); LP_TAG(d_states_); LP_TAG(d_clean_); LP_TAG(d_rst_); LP_TAG(d_chunk_); LP_TAG(d_ckpt_); LP_TAG(d_exit_); LP_TAG(d_spec_exit_); LP_TAG(d_entry_);
     LP_TAG(d_tot_); LP_TAG(d_spec_tot_); LP_TAG(d_prefix_); LP_TAG(d_changed_); LP_TAG(d_coef_); LP_TAG(d_wide_); LP_TAG(d_wide_id_); LP_TAG(d_dc_); LP_TAG(d_dcpart_);
     LP_TAG(d_planes_); LP_TAG(d_frames_desc_); LP_TAG(h_small_); LP_TAG(h_out_); LP_TAG(h_dstate_); LP_TAG(h_desc_); LP_TAG(h_xfer_in_); LP_TAG(h_xfer_out_); LP_TAG(d_pscans_); LP_TAG(d_pstreams_);
-    LP_TAG(d_pstates_); LP_TAG(d_pcoef_); LP_TAG(heap_); LP_TAG(d_ops_); LP_TAG(d_taps_); LP_TAG(d_ranges_); LP_TAG(d_fops_); LP_TAG(d_aops_); LP_TAG(d_ataps_);
+    LP_TAG(d_pstates_); LP_TAG(d_pcoef_); LP_TAG(d_pdeps_); LP_TAG(d_pprog_); LP_TAG(heap_); LP_TAG(d_ops_); LP_TAG(d_taps_); LP_TAG(d_ranges_); LP_TAG(d_fops_); LP_TAG(d_aops_); LP_TAG(d_ataps_);
     LP_TAG(d_aranges_); LP_TAG(d_tone_); LP_TAG(d_jobs_); LP_TAG(d_estates_); LP_TAG(d_ecoef_); LP_TAG(d_blkbits_); LP_TAG(d_bits_); LP_TAG(d_hdrs_); LP_TAG(d_out_);
     LP_TAG(d_packed_); LP_TAG(d_pkoff_);
 #undef LP_TAG
@@ -322,7 +322,7 @@ size_t LpEngine::device_bytes() const
     size_t n = 0;
     for (const LpUpload& u : up_) n += u.d_raw.cap + u.d_huffs.cap + u.d_phuffs.cap;
     for (const LpDevBuf* b : {&d_imgs_, &d_states_, &d_clean_, &d_rst_, &d_chunk_, &d_ckpt_, &d_exit_, &d_spec_exit_, &d_entry_, &d_tot_, &d_spec_tot_, &d_prefix_, &d_changed_,
-                              &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &heap_,
+                              &d_coef_, &d_wide_, &d_wide_id_, &d_dc_, &d_dcpart_, &d_planes_, &d_frames_desc_, &d_pscans_, &d_pstreams_, &d_pstates_, &d_pcoef_, &d_pdeps_, &d_pprog_, &heap_,
                               &d_ops_, &d_taps_, &d_ranges_, &d_fops_, &d_aops_, &d_ataps_, &d_aranges_, &d_tone_, &d_jobs_, &d_estates_, &d_ecoef_, &d_blkbits_, &d_bits_, &d_hdrs_, &d_out_, &d_packed_, &d_pkoff_})
         n += b->cap;
     return n;
@@ -852,10 +852,57 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         h_pscans_.push_back(leveled[q].second);
     }
     h_plevel_first_.push_back((uint32_t)leveled.size());
+    // Pipelined launch (lp_kernels_prog.hip): every level of the range in one grid, each scan staying one MCU row behind the scans whose
+    // coefficients it refines -- an image then costs its longest scan instead of the sum of its levels' longest. Needs the wave decoder for
+    // every scan (no sequential ones) and at most LP_PROG_MAX_DEPS direct dependencies per scan (libjpeg's scripts have one or two).
+    h_pdeps_.clear();
+    {
+        static const bool pipeline_on = !(getenv("LILLIPUT_HIP_PROG_PIPELINE") && atoi(getenv("LILLIPUT_HIP_PROG_PIPELINE")) == 0);
+        bool can = pipeline_on && u_->prog_mode == 1 && h_plevel_first_.size() > 2 && !leveled.empty();
+        for (const auto& lv : leveled) can = can && !lv.second.sequential;
+        if (can) {
+            auto conflicts = [](const LpProgScan& a, const LpProgScan& b, int* va, int* vb) {
+                if (!(a.Ss <= b.Se && b.Ss <= a.Se)) return false;
+                for (uint32_t x = 0; x < a.ns; x++)
+                    for (uint32_t y = 0; y < b.ns; y++)
+                        if (a.comp[x] == b.comp[y]) { *va = a.vs[x]; *vb = b.vs[y]; return true; }
+                return false;
+            };
+            h_pdeps_.assign(leveled.size(), LpProgDep());
+            std::vector<std::vector<uint32_t>> of_img(h_imgs_.size());
+            for (uint32_t q = 0; q < leveled.size() && can; q++) {
+                const LpProgScan& a = leveled[q].second;
+                std::vector<uint32_t> dep; // earlier scans of the image this one conflicts with (all of a lower level)
+                int va, vb;
+                for (uint32_t b : of_img[a.img])
+                    if (leveled[b].first < leveled[q].first && conflicts(a, leveled[b].second, &va, &vb)) dep.push_back(b);
+                std::vector<uint32_t> direct; // minus those another dependency already stays behind
+                for (uint32_t c : dep) {
+                    bool implied = false;
+                    for (uint32_t b : dep)
+                        implied = implied || (b != c && leveled[c].first < leveled[b].first && conflicts(leveled[b].second, leveled[c].second, &va, &vb));
+                    if (!implied) direct.push_back(c);
+                }
+                if (direct.size() > LP_PROG_MAX_DEPS) { can = false; break; }
+                LpProgDep& d = h_pdeps_[q];
+                memset(&d, 0, sizeof(d));
+                d.ndep = (uint32_t)direct.size();
+                for (size_t k = 0; k < direct.size(); k++) {
+                    conflicts(a, leveled[direct[k]].second, &va, &vb);
+                    d.scan[k] = direct[k];
+                    d.vs_self[k] = (uint8_t)va;
+                    d.vs_dep[k] = (uint8_t)vb;
+                }
+                of_img[a.img].push_back(q);
+            }
+        }
+        if (!can) h_pdeps_.clear();
+    }
     const size_t nstreams = h_pstreams_.size();
     if (pcoef_elems && !d_pcoef_.ensure(pcoef_elems * 2 + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
     if (nstreams && !(d_pstreams_.ensure(sizeof(LpJpeg) * nstreams) && d_pstates_.ensure(sizeof(LpJpegState) * nstreams) &&
-                      d_pscans_.ensure(sizeof(LpProgScan) * nstreams) && d_pcoef_.ensure(pcoef_elems * 2 + 64))) {
+                      d_pscans_.ensure(sizeof(LpProgScan) * nstreams) && d_pcoef_.ensure(pcoef_elems * 2 + 64) &&
+                      d_pdeps_.ensure(sizeof(LpProgDep) * nstreams + 64) && d_pprog_.ensure(4 * (nstreams + 1) + 64))) {
         err_ = "device allocation failed";
         return LP_ERR_DEVICE;
     }
@@ -932,6 +979,13 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         lp_launch_unstuff(stream_, d_pstreams_.as<LpJpeg>(), (uint32_t)nstreams, max_pchunks, u_->d_raw.as<uint8_t>(), d_chunk_.as<uint2>(),
                           d_pstates_.as<LpJpegState>(), d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>());
         stage("prog_unstuff");
+        if (!h_pdeps_.empty()) { // every level in one grid
+            if (!check(hipMemcpyAsync(d_pdeps_.p, h_pdeps_.data(), sizeof(LpProgDep) * nstreams, hipMemcpyHostToDevice, stream_), "H2D scan dependencies") ||
+                !check(hipMemsetAsync(d_pprog_.p, 0, 4 * (nstreams + 1), stream_), "memset scan progress"))
+                return LP_ERR_DEVICE;
+            lp_launch_prog_wave(stream_, d_pscans_.as<LpProgScan>(), 0, (uint32_t)nstreams, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(), u_->d_phuffs.as<LpProgHuff>(),
+                                d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>(), d_pdeps_.as<LpProgDep>(), d_pprog_.as<uint32_t>());
+        } else
         for (size_t l = 0; l + 1 < h_plevel_first_.size(); l++) {
             const uint32_t f = h_plevel_first_[l], cnt = h_plevel_first_[l + 1] - f;
             bool any_seq = false, any_prog = false;
@@ -941,7 +995,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             // few lanes: one per wave (a lane alone on its SIMD runs fastest); many: pack them so that the grid stays a few waves per SIMD
             if (waves && any_prog)
                 lp_launch_prog_wave(stream_, d_pscans_.as<LpProgScan>(), f, cnt, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(), u_->d_phuffs.as<LpProgHuff>(),
-                                    d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>());
+                                    d_clean_.as<uint32_t>(), d_rst_.as<uint32_t>(), d_pcoef_.as<int16_t>(), nullptr, nullptr);
             if (!waves || any_seq) {
                 const uint32_t lpw = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (cnt + 4095u) / 4096u));
                 lp_launch_prog_scans(stream_, d_pscans_.as<LpProgScan>(), f, cnt, lpw, waves, d_pstreams_.as<LpJpeg>(), d_pstates_.as<LpJpegState>(),

@@ -289,7 +289,8 @@ private:
     std::vector<uint32_t> h_plevel_first_;          // level l = h_pscans_[h_plevel_first_[l] .. h_plevel_first_[l + 1])
     std::vector<LpJpeg> h_pstreams_;                // one pseudo stream per scan (what the unstuff kernels need)
     std::vector<LpJpegState> h_pstates_;
-    LpDevBuf d_pscans_, d_pstreams_, d_pstates_, d_pcoef_;
+    LpDevBuf d_pscans_, d_pstreams_, d_pstates_, d_pcoef_, d_pdeps_, d_pprog_;
+    std::vector<LpProgDep> h_pdeps_;                // non-empty: the range's scans run as ONE pipelined launch (lp_kernels_prog.hip)
 
     // frame heap
     LpDevBuf heap_;

@@ -393,7 +393,11 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 rs.ecs_off = seg_end;
                 size_t q = seg_end;
                 for (; q + 1 < n; q++) {
-                    if (d[q] != 0xFF) continue;
+                    // (memchr: the entropy-coded bytes are nine tenths of a progressive file, and a byte loop over them was 0.3 ms per
+                    // 1024 x 1024 file -- 20 ms of a 64-image chunk's ingest)
+                    const void* ff = memchr(d + q, 0xFF, n - 1 - q);
+                    if (!ff) { q = n; break; }
+                    q = (size_t)((const uint8_t*)ff - d);
                     const unsigned c = d[q + 1];
                     if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
                     // Scans with a restart interval: a byte pair that only looks like a marker (code below 0xC0: nothing libjpeg knows) does
@@ -591,7 +595,9 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
     } else {
         out->open_end = true;
         for (size_t q = ecs; q + 1 < n; q++) {
-            if (d[q] != 0xFF) continue;
+            const void* ff = memchr(d + q, 0xFF, n - 1 - q);
+            if (!ff) break;
+            q = (size_t)((const uint8_t*)ff - d);
             unsigned c = d[q + 1];
             if (c == 0 || c == 0xFF || (c >= 0xD0 && c <= 0xD7)) continue;
             if (j.dri && c < 0xC0) continue; // not a marker libjpeg knows: with a restart interval the decoder reads past it (lp_jbits.h)

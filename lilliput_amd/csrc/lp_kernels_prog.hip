@@ -222,9 +222,41 @@ struct PwScan { // what every scan type needs, wave-uniform
     uint32_t n_rst, total_bits;
     uint32_t lane;
     uint32_t* err;
+    // pipelined launches (every dependency level of the decode range in one grid): this scan's progress word, its dependencies
+    uint32_t* progress; // 0 = level-by-level launches: nothing to wait for, nothing to publish
+    const LpProgDep* dep;
+    uint32_t self;
     __device__ __forceinline__ void irregular() const
     {
         if (lane == 0u) atomicOr(err, LP_PROG_IRREGULAR);
+    }
+    // MCU rows [0, rows) of this scan are final: visible to the device before the counter moves
+    __device__ __forceinline__ void publish(uint32_t rows) const
+    {
+        if (!progress) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0u) __hip_atomic_store(progress + self, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // before MCU row `my` of this scan is read or written: every scan it refines has finished the block rows it covers. A producer
+    // always holds a lower ticket (it is running or done), so the wait ends; the clock is there for the day something else breaks:
+    // ~2 s without progress flags the image (host route) and goes on.
+    __device__ __forceinline__ bool wait_for(uint32_t my) const
+    {
+        if (!progress) return true;
+        bool ok = true;
+        const uint32_t nd = dep->ndep;
+        for (uint32_t d = 0; d < nd; d++) {
+            const uint32_t need = ((my + 1u) * dep->vs_self[d] - 1u) / dep->vs_dep[d] + 1u; // (a producer that has finished publishes ~0)
+            const uint32_t* p = progress + dep->scan[d];
+            if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) continue;
+            const uint64_t t0 = wall_clock64();
+            while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > 200000000ull) { ok = false; break; } // 100 MHz
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return ok;
     }
 };
 
@@ -272,6 +304,8 @@ __device__ __forceinline__ void pw_ac_first(const PwScan& s, PwBits& b, const ui
     uint32_t E = refill(0);
     for (uint32_t my = 0; my < sc.mcuy; my++) {
         int16_t* row = s.coef + ((size_t)sc.cblk[0] + (size_t)my * sc.bw[0]) * 64u;
+        bad = !s.wait_for(my) || bad;
+        if (my) s.publish(my);
         for (uint32_t mx = 0; mx < sc.mcux; mx++) {
             uint32_t np;
             if (iv.crossing(s, b.pb + o, &np, &bad)) {
@@ -328,11 +362,16 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
     const size_t row_pitch = (size_t)sc.bw[0] * 64u;
     uint32_t pf_mx = 0, pf_n = 0;
     const int16_t* pf_row = s.coef + (size_t)sc.cblk[0] * 64u;
+    uint32_t pf_my = 0, pf_waited = 0, cur_my = 0;
     auto fetch_ptr = [&]() __attribute__((always_inline)) -> const int16_t* {
+        if (s.progress && pf_my >= pf_waited) { // the cursor enters a row: what it is about to read must be final
+            bad = !s.wait_for(pf_my) || bad;
+            pf_waited = pf_my + 1u;
+        }
         const int16_t* ptr = pf_row + (size_t)pf_mx * 64u + lane;
         if (pf_n + 1u < nblk) {
             pf_n++;
-            if (++pf_mx == mcux) { pf_mx = 0; pf_row += row_pitch; }
+            if (++pf_mx == mcux) { pf_mx = 0; pf_row += row_pitch; pf_my++; }
         }
         return ptr;
     };
@@ -341,7 +380,8 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
     int16_t* cur_row = s.coef + (size_t)sc.cblk[0] * 64u;
     auto block = [&](int32_t c) __attribute__((always_inline)) { // one block: c = its coefficients (lane = zigzag index)
         int16_t* dst = cur_row + (size_t)cur_mx * 64u + lane;
-        if (++cur_mx == mcux) { cur_mx = 0; cur_row += row_pitch; }
+        if (cur_mx == 0u && cur_my) s.publish(cur_my); // the row above is complete (its last store was issued one block ago)
+        if (++cur_mx == mcux) { cur_mx = 0; cur_row += row_pitch; cur_my++; }
         uint32_t np;
         if (iv.crossing(s, b.pb + o, &np, &bad)) {
             eobrun = 0;
@@ -458,7 +498,9 @@ __device__ __forceinline__ void pw_dc_first(const PwScan& s, PwBits& b, const ui
         if (lane < pn) s.coef[(size_t)pa * 64u] = (int16_t)pv;
         pn = 0;
     };
-    for (uint32_t my = 0; my < sc.mcuy; my++)
+    for (uint32_t my = 0; my < sc.mcuy; my++) {
+        bad = !s.wait_for(my) || bad;
+        if (s.progress && my) { flush(); s.publish(my); }
         for (uint32_t mx = 0; mx < sc.mcux; mx++) {
             uint32_t np;
             if (iv.crossing(s, b.pb + o, &np, &bad)) {
@@ -484,6 +526,7 @@ __device__ __forceinline__ void pw_dc_first(const PwScan& s, PwBits& b, const ui
                     }
             }
         }
+    }
     flush();
     if (bad || b.pb + o > iv.end) s.irregular();
 }
@@ -507,7 +550,14 @@ __device__ __forceinline__ void pw_dc_refine(const PwScan& s, const PwBits& b)
         bad = bad || beg + m_in * bpm > end;
     }
     if (ballot(bad)) { s.irregular(); return; }
+    uint32_t waited = 0, published = 0; // MCU rows
+    bool stuck = false;
     for (uint32_t m0 = 0; m0 < nmcu; m0 += 64u) {
+        if (s.progress) { // the 64 MCUs of this step reach into row (m0 + 63) / mcux; rows below m0 / mcux are complete
+            const uint32_t last = (m0 + 63u < nmcu ? m0 + 63u : nmcu - 1u) / sc.mcux, done = m0 / sc.mcux;
+            for (; waited <= last; waited++) stuck = !s.wait_for(waited) || stuck;
+            if (done > published) { s.publish(done); published = done; }
+        }
         const uint32_t m = m0 + lane;
         const bool live = m < nmcu;
         const uint32_t mm = live ? m : 0u;
@@ -523,6 +573,7 @@ __device__ __forceinline__ void pw_dc_refine(const PwScan& s, const PwBits& b)
                     bp++;
                 }
     }
+    if (stuck) s.irregular();
 }
 
 } // namespace
@@ -532,18 +583,27 @@ __device__ __forceinline__ void pw_dc_refine(const PwScan& s, const PwBits& b)
 __global__ __launch_bounds__(64) void k_prog_wave(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, const LpJpeg* __restrict__ streams,
                                                   LpJpegState* __restrict__ stream_states, const LpProgHuff* __restrict__ huffs,
                                                   const uint32_t* __restrict__ clean_arena, const uint32_t* __restrict__ rst_arena, int16_t* __restrict__ pcoef,
-                                                  uint32_t skip_types)
+                                                  uint32_t skip_types, const LpProgDep* __restrict__ deps, uint32_t* __restrict__ progress)
 {
     __shared__ uint16_t s_lut[1u << PW_AC_BITS];
     __shared__ PwCanon s_can[4];
-    const uint32_t i = blockIdx.x;
+    // Pipelined (progress != 0: every level of the range in this grid, scans sorted by level): a wave takes the next scan in line when it
+    // STARTS, so that whatever scan it may have to wait for is held by a wave that is already running (workgroup ids promise no order).
+    uint32_t i = blockIdx.x;
+    if (progress) {
+        if (threadIdx.x == 0) i = atomicAdd(progress + n, 1u); // the ticket counter sits behind the n progress words
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    }
     if (i >= n) return;
     const LpProgScan* sc = scans + first + i;
-    if (sc->sequential) return;
-    if ((skip_types >> ((sc->Ss ? 2u : 0u) + (sc->Ah ? 1u : 0u))) & 1u) return; // development: LILLIPUT_HIP_PW_SKIP bit 0 DC first, 1 DC refine, 2 AC first, 3 AC refine
     const LpJpeg& stream = streams[sc->stream];
     LpJpegState& st = stream_states[sc->stream];
-    if (st.error) return; // the unstuff kernels already sent the image to the host route
+    const bool skip = sc->sequential || ((skip_types >> ((sc->Ss ? 2u : 0u) + (sc->Ah ? 1u : 0u))) & 1u) || // development: LILLIPUT_HIP_PW_SKIP bit 0 DC first, 1 DC refine, 2 AC first, 3 AC refine
+                      st.error; // (the unstuff kernels already sent the image to the host route)
+    if (skip) {
+        if (progress && threadIdx.x == 0) __hip_atomic_store(progress + i, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // nobody waits for this one
+        return;
+    }
     PwScan s;
     s.sc = sc;
     s.ht = huffs + sc->huff;
@@ -553,6 +613,9 @@ __global__ __launch_bounds__(64) void k_prog_wave(const LpProgScan* __restrict__
     s.total_bits = st.clean_bytes * 8u;
     s.lane = threadIdx.x;
     s.err = &st.error;
+    s.progress = progress;
+    s.dep = deps + i;
+    s.self = i;
     PwBits b;
     b.words = clean_arena + stream.clean_off;
     b.cap = stream.clean_cap_words;
@@ -571,12 +634,13 @@ __global__ __launch_bounds__(64) void k_prog_wave(const LpProgScan* __restrict__
         if (sc->Ah == 0u) pw_ac_first(s, b, s_lut, s_can);
         else pw_ac_refine(s, b, s_lut, s_can);
     }
+    s.publish(0xffffffffu);
 }
 
 void lp_launch_prog_wave(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, const LpJpeg* d_streams, LpJpegState* d_stream_states,
-                         const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
+                         const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef, const LpProgDep* d_deps, uint32_t* d_progress)
 {
     if (!n) return;
     static const uint32_t skip = getenv("LILLIPUT_HIP_PW_SKIP") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_PW_SKIP")) : 0u;
-    hipLaunchKernelGGL(k_prog_wave, dim3(n), dim3(64), 0, s, d_scans, first, n, d_streams, d_stream_states, d_huffs, d_clean, d_rst, d_pcoef, skip);
+    hipLaunchKernelGGL(k_prog_wave, dim3(n), dim3(64), 0, s, d_scans, first, n, d_streams, d_stream_states, d_huffs, d_clean, d_rst, d_pcoef, skip, d_deps, d_progress);
 }

@@ -50,8 +50,10 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
 void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, bool only_sequential, const LpJpeg* d_streams,
                           const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
 // the same level, one WAVE per scan (lp_kernels_prog.hip): the progressive scans; sequential ones (LpProgScan::sequential) are left to the lanes above
+// d_progress != 0: PIPELINED -- scans [first, first + n) span every dependency level of the range, sorted by level; d_deps[i] names the scans
+// scan first + i stays behind (indices relative to first), d_progress = n progress words + the ticket counter, all zero
 void lp_launch_prog_wave(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, const LpJpeg* d_streams, LpJpegState* d_stream_states,
-                         const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
+                         const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef, const LpProgDep* d_deps, uint32_t* d_progress);
 // pixels
 void lp_launch_ycc_to_frame(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint32_t max_w, uint32_t max_h, bool any_generic, bool any_420,
                             const uint8_t* d_planes, const LpFrame* d_dsts, uint8_t* d_frames);

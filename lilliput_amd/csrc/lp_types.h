@@ -146,6 +146,18 @@ struct LpProgScan {
     uint64_t coef_off;          // element offset of the image in the int16 coefficient arena
 };
 
+// Which earlier scans of its image a scan must stay behind when all dependency levels of a decode range run in ONE launch
+// (lp_kernels_prog.hip "pipelined"): the scans that wrote the coefficients it refines. Progress is published per MCU row of the
+// producer's own grid; vs_self / vs_dep = block rows of the shared component per MCU row of the two scans (1 in a single-component scan).
+#define LP_PROG_MAX_DEPS 3
+struct LpProgDep {
+    uint32_t ndep;
+    uint32_t scan[LP_PROG_MAX_DEPS];    // indices into the launch's scan array (always lower than the scan's own)
+    uint8_t vs_self[LP_PROG_MAX_DEPS];
+    uint8_t vs_dep[LP_PROG_MAX_DEPS];
+    uint8_t pad[2];
+};
+
 // Per-image results produced on the device.
 struct LpJpegState {
     uint32_t clean_bytes;       // unstuffed length
