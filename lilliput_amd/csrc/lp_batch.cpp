@@ -24,6 +24,8 @@
 #include "lp_coalesce.h"
 #include "lp_ops_logic.h"
 #include "lp_abi_guard.h"
+#include "lp_jpeg_parse.h"
+#include "lp_prog_host.h"
 
 // One engine (= one compute stream + one copy stream + its arenas) per worker; a batch is split into contiguous parts, one per
 // worker, and the workers run concurrently on host threads so that one part's HBM-bound stages (IDCT, resample, unstuff) overlap
@@ -1125,11 +1127,19 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         const size_t chunk_max = grow ? std::max(chunk, std::min<size_t>(1024, (n + engines - 1) / engines)) : chunk;
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
+        const bool prog_on_device_possible = lp_prog_entropy_mode() != 0;
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
             LpPipeJob job;
             job.i0 = i;
             size_t bytes = 0, cnt = 0;
-            while (i < n && (cnt < chunk ? (cnt == 0 || bytes + items[i].src_len <= (1ull << 30)) : (cnt < chunk_max && bytes + items[i].src_len <= pipe_chunk_bytes))) { bytes += items[i].src_len; cnt++; i++; }
+            // (a progressive file counts a sixteenth of its bytes: the device walks its scans one wave each, in a time that does not depend
+            // on how many files the chunk holds -- the more of them are in flight, the better; lp_kernels_prog.hip)
+            auto weight = [&](size_t k) { return prog_on_device_possible && lp_jpeg_sniff_progressive((const uint8_t*)items[k].src, items[k].src_len) ? items[k].src_len / 16 + 1 : items[k].src_len; };
+            while (i < n) {
+                const size_t w = weight(i);
+                if (!(cnt < chunk ? (cnt == 0 || bytes + w <= (1ull << 30)) : (cnt < chunk_max && bytes + w <= pipe_chunk_bytes))) break;
+                bytes += w; cnt++; i++;
+            }
             job.i1 = i;
             sh.jobs.push_back(std::move(job));
         }

@@ -897,6 +897,30 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
             }
         }
         if (!can) h_pdeps_.clear();
+        else {
+            // Launch order = ticket order: a wave takes the next scan in line and a chip holds ~1 000 of these waves at full speed (one per
+            // SIMD: k_prog_wave's LDS footprint keeps it at that -- chains that share a SIMD share its one scalar issue slot per four
+            // cycles), so the scans on an image's CRITICAL PATH go first: by the length of the longest dependency chain that starts at the
+            // scan (entropy-coded bytes as the measure), longest first. A scan's chain is longer than that of any scan that waits for it, so
+            // producers still come before their consumers.
+            const size_t ns = leveled.size();
+            std::vector<uint64_t> cp(ns, 0), below(ns, 0);
+            for (size_t q = ns; q-- > 0;) {
+                cp[q] = (uint64_t)h_pstreams_[leveled[q].second.stream].raw_len + 1u + below[q];
+                for (uint32_t k = 0; k < h_pdeps_[q].ndep; k++) below[h_pdeps_[q].scan[k]] = std::max(below[h_pdeps_[q].scan[k]], cp[q]);
+            }
+            std::vector<uint32_t> order(ns), pos(ns);
+            for (size_t q = 0; q < ns; q++) order[q] = (uint32_t)q;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cp[x] > cp[y]; }); // (ties keep level order)
+            for (size_t q = 0; q < ns; q++) pos[order[q]] = (uint32_t)q;
+            std::vector<LpProgDep> nd(ns);
+            for (size_t q = 0; q < ns; q++) {
+                h_pscans_[q] = leveled[order[q]].second;
+                nd[q] = h_pdeps_[order[q]];
+                for (uint32_t k = 0; k < nd[q].ndep; k++) nd[q].scan[k] = pos[nd[q].scan[k]];
+            }
+            h_pdeps_.swap(nd);
+        }
     }
     const size_t nstreams = h_pstreams_.size();
     if (pcoef_elems && !d_pcoef_.ensure(pcoef_elems * 2 + 64)) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }

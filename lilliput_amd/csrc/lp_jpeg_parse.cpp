@@ -610,3 +610,22 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
     out->ecs_len = end - ecs;
     return LP_PARSE_OK;
 }
+
+// A look at the frame header only (segment lengths, no entropy-coded byte is touched): is this a progressive (SOF2) Huffman-coded JPEG?
+// The batch front end sizes its chunks with it before the real header walk: the device decodes such files one wave per scan, at a
+// latency that does not depend on how many of them a chunk holds.
+bool lp_jpeg_sniff_progressive(const uint8_t* d, size_t n)
+{
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
+    size_t i = 2;
+    while (i + 4 <= n) {
+        if (d[i] != 0xFF) return false;
+        const unsigned m = d[i + 1];
+        if (m == 0xFF) { i++; continue; }
+        if (m == 0xC2) return true;
+        if (m == 0xDA || m == 0xD9 || (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
+        i += 2 + (((size_t)d[i + 2] << 8) | d[i + 3]);
+    }
+    return false;
+}

@@ -58,3 +58,6 @@ extern const uint8_t lp_std_huff_bits[4][17];
 extern const uint8_t lp_std_huff_dc_vals[12];
 extern const uint8_t lp_std_huff_ac_luma[162];
 extern const uint8_t lp_std_huff_ac_chroma[162];
+
+// frame-header sniff (no entropy-coded byte read): a progressive (SOF2) Huffman-coded file?
+bool lp_jpeg_sniff_progressive(const uint8_t* data, size_t len);

@@ -37,6 +37,7 @@ namespace {
 
 typedef unsigned long long u64;
 
+#define PW_RARE(x) __builtin_expect(!!(x), 0) // keeps the rare paths out of the straight-line code: a taken branch costs a lone wave ~25 cycles
 #define PW_AC_BITS 12u // first-level width of an AC scan's table (8 KB of LDS); longer codes: canonical search, per lane, rare
 #define PW_DC_BITS 10u // DC scans: up to four tables (one per scan component) share the same 8 KB
 
@@ -125,7 +126,7 @@ struct PwBits {
         const uint32_t wi = (bp >> 5) - wb;
         uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi & 63u) << 2), (int)cur);
         const bool far = active && wi >= 64u;
-        if (ballot(far)) { // (the load carries its own wait: a compiler-visible one puts a vmcnt(0) at the join, on every block's path)
+        if (PW_RARE(ballot(far))) { // (the load carries its own wait: a compiler-visible one puts a vmcnt(0) at the join, on every block's path)
             if (far) asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(addr(bp >> 5)) : "memory");
         }
         return (w >> (31u - (bp & 31u))) & 1u;
@@ -163,7 +164,7 @@ __device__ __forceinline__ void pw_build_lut(uint16_t* lut, PwCanon* can, uint32
 __device__ __forceinline__ uint32_t pw_lookup(const uint16_t* lut, const PwCanon* can, uint32_t bits, uint32_t peek)
 {
     uint32_t e = lut[peek >> (32u - bits)];
-    if (ballot(e == 0u)) {
+    if (PW_RARE(ballot(e == 0u))) {
         if (e == 0u) {
             e = 17u << 8;
             for (uint32_t l = bits + 1u; l <= 16u; l++) {
@@ -316,10 +317,10 @@ __device__ __forceinline__ void pw_ac_first(const PwScan& s, PwBits& b, const ui
             if (((b.pb + o) >> 5) - b.wb >= 32u && ((b.pb + o) >> 5) - b.wb < 61u) b.shift(false);
             uint32_t c = 0, k = Ss, special = 0;
             while (k <= Se) {
-                if (o >= 64u) E = refill(b.pb + o);
+                if (PW_RARE(o >= 64u)) E = refill(b.pb + o);
                 const uint32_t e = rl(E, o);
                 o += PW_ADV(e);
-                if (PW_SPECIAL(e)) {
+                if (PW_RARE(PW_SPECIAL(e))) {
                     if (e & PW_F_ZRL) { k += 16u; continue; }
                     special = e;
                     break;
@@ -364,14 +365,14 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
     const int16_t* pf_row = s.coef + (size_t)sc.cblk[0] * 64u;
     uint32_t pf_my = 0, pf_waited = 0, cur_my = 0;
     auto fetch_ptr = [&]() __attribute__((always_inline)) -> const int16_t* {
-        if (s.progress && pf_my >= pf_waited) { // the cursor enters a row: what it is about to read must be final
+        if (PW_RARE(s.progress && pf_my >= pf_waited)) { // the cursor enters a row: what it is about to read must be final
             bad = !s.wait_for(pf_my) || bad;
             pf_waited = pf_my + 1u;
         }
         const int16_t* ptr = pf_row + (size_t)pf_mx * 64u + lane;
         if (pf_n + 1u < nblk) {
             pf_n++;
-            if (++pf_mx == mcux) { pf_mx = 0; pf_row += row_pitch; pf_my++; }
+            if (PW_RARE(++pf_mx == mcux)) { pf_mx = 0; pf_row += row_pitch; pf_my++; }
         }
         return ptr;
     };
@@ -380,16 +381,16 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
     int16_t* cur_row = s.coef + (size_t)sc.cblk[0] * 64u;
     auto block = [&](int32_t c) __attribute__((always_inline)) { // one block: c = its coefficients (lane = zigzag index)
         int16_t* dst = cur_row + (size_t)cur_mx * 64u + lane;
-        if (cur_mx == 0u && cur_my) s.publish(cur_my); // the row above is complete (its last store was issued one block ago)
-        if (++cur_mx == mcux) { cur_mx = 0; cur_row += row_pitch; cur_my++; }
+        if (PW_RARE(cur_mx == 0u && cur_my)) s.publish(cur_my); // the row above is complete (its last store was issued one block ago)
+        if (PW_RARE(++cur_mx == mcux)) { cur_mx = 0; cur_row += row_pitch; cur_my++; }
         uint32_t np;
-        if (iv.crossing(s, b.pb + o, &np, &bad)) {
+        if (PW_RARE(iv.crossing(s, b.pb + o, &np, &bad))) {
             eobrun = 0;
             E = refill(np);
         }
         // the stream registers move on between blocks only: a block's correction bits are fetched from `cur` at its end
         since_shift++;
-        if (((b.pb + o) >> 5) - b.wb >= 32u && ((b.pb + o) >> 5) - b.wb < 61u) {
+        if (PW_RARE(((b.pb + o) >> 5) - b.wb >= 32u && ((b.pb + o) >> 5) - b.wb < 61u)) {
             b.shift(since_shift >= 5u);
             since_shift = 0;
         }
@@ -405,9 +406,9 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
         if (eobrun == 0u) {
             uint32_t special = 0, k_special = 0;
             do {
-                if (o >= 64u) { const uint32_t mc = o - g; E = refill(b.pb + o); g = 0u - mc; }
+                if (PW_RARE(o >= 64u)) { const uint32_t mc = o - g; E = refill(b.pb + o); g = 0u - mc; }
                 const uint32_t e = rl(E, o);
-                if (PW_SPECIAL(e)) { // (no second exit from the loop: two exits cost five scalar instructions per symbol in flag handling)
+                if (PW_RARE(PW_SPECIAL(e))) { // (no second exit from the loop: two exits cost five scalar instructions per symbol in flag handling)
                     special = e;
                     k_special = k;
                     k = 200u;
@@ -513,7 +514,7 @@ __device__ __forceinline__ void pw_dc_first(const PwScan& s, PwBits& b, const ui
                 if (q >= ns) break;
                 for (uint32_t v = 0; v < sc.vs[q]; v++)
                     for (uint32_t h = 0; h < sc.hs[q]; h++) {
-                        if (o >= 64u) refill(b.pb + o);
+                        if (PW_RARE(o >= 64u)) refill(b.pb + o);
                         const uint32_t Ec = q == 0u ? E0 : q == 1u ? E1 : q == 2u ? E2 : E3; // (read after the refill)
                         const uint32_t e = rl(Ec, o);
                         bad = bad || PW_SPECIAL(e);
@@ -642,5 +643,10 @@ void lp_launch_prog_wave(hipStream_t s, const LpProgScan* d_scans, uint32_t firs
 {
     if (!n) return;
     static const uint32_t skip = getenv("LILLIPUT_HIP_PW_SKIP") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_PW_SKIP")) : 0u;
-    hipLaunchKernelGGL(k_prog_wave, dim3(n), dim3(64), 0, s, d_scans, first, n, d_streams, d_stream_states, d_huffs, d_clean, d_rst, d_pcoef, skip, d_deps, d_progress);
+    // LILLIPUT_HIP_PW_LDS_KB: unused dynamic LDS per workgroup = fewer waves per CU. Measured (profiles/r06_progressive.md): keeping the
+    // waves at one per SIMD (30 KB) is SLOWER than letting the whole grid in (61 against 50 ms for 256 files of 1024 x 1024) -- the short
+    // scans then queue behind the long ones they feed; 0 / 6 / 10 / 16 KB are within the noise of each other. What does matter is the
+    // ticket order (critical path first, LpEngine::run_decode).
+    static const uint32_t pad_kb = getenv("LILLIPUT_HIP_PW_LDS_KB") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_PW_LDS_KB")) : 0u;
+    hipLaunchKernelGGL(k_prog_wave, dim3(n), dim3(64), pad_kb << 10, s, d_scans, first, n, d_streams, d_stream_states, d_huffs, d_clean, d_rst, d_pcoef, skip, d_deps, d_progress);
 }
