@@ -906,7 +906,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=1024, help="distinct synthetic source images (seed = index), tiled to the batch when fewer")
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--source-sampling", choices=["420", "422", "444", "420p"], default="420", help="chroma sampling of the synthetic sources (420 = the BASELINE workload; 422 / 444 run k_resample_hv1; 420p = PROGRESSIVE 4:2:0 files, whose scans are entropy-decoded on host threads -- DESIGN.md 4.4)")
+    ap.add_argument("--source-sampling", choices=["420", "422", "444", "420p"], default="420", help="chroma sampling of the synthetic sources (420 = the BASELINE workload; 422 / 444 run k_resample_hv1; 420p = PROGRESSIVE 4:2:0 files: one wave per scan on the device for large sets, host threads for small ones -- DESIGN.md 4.4; LILLIPUT_HIP_PROG_ENTROPY=host|device forces either)")
     ap.add_argument("--source-quality", type=int, default=90, help="JPEG quality of the synthetic sources (90 = the BASELINE workload, ~2 bits/pixel; 75 gives ~1 bit/pixel, the density of a camera photograph: the link then carries half the bytes per image and the device kernels, not PCIe, set the rate)")
     ap.add_argument("--orientation", type=int, default=1, choices=range(1, 9), help="EXIF orientation written into the sources (1 = the BASELINE workload; others measure the orientation folded into the resample kernels)")
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device per engine (0 = automatic)")

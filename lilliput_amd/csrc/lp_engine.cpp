@@ -391,6 +391,7 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
         size_t cand = 0;
         for (int i = 0; i < n; i++) {
             if (!hdrs[i].scan_path || hdrs[i].arith) continue; // a QM-coded scan only has a host decoder (lp_arith_host.h)
+            if (hdrs[i].decode_fails) continue;                 // a multi-scan file without its EOI: the host route reports what the reference does
             bool seq = false;
             for (const LpProgScanHost& sh : hdrs[i].scans) seq = seq || sh.s.sequential;
             if (u.prog_mode < 0 && seq) continue;               // auto: the wave decoder's files only
@@ -568,7 +569,9 @@ int LpEngine::upload_layout(int slot, const LpJpegSrc* srcs, int n, const LpJpeg
     for (size_t q = 0; q < u.pieces.size(); q++) {
         LpUpload::Piece& pc = u.pieces[q];
         const LpUpload::Piece* pv = q ? &u.pieces[q - 1] : nullptr;
-        const bool follows = !by_kernel && pv && pc.direct && pv->direct && pc.scan < 0 && pv->scan < 0 && pc.pin_base && pc.pin_base == pv->pin_base &&
+        // (the scans of a progressive file lie a table segment apart: one transfer per file -- or per run of files -- instead of ten; a
+        // 256-image set of 1024 x 1024 progressive files was 2 560 transfers, 51 ms of the stager's time)
+        const bool follows = !by_kernel && pv && pc.direct && pv->direct && pc.pin_base && pc.pin_base == pv->pin_base &&
                              pc.src >= pv->src + pv->len && (size_t)(pc.src - (pv->src + pv->len)) <= max_gap;
         pc.arena_off = follows ? pv->arena_off + (size_t)(pc.src - pv->src) : align_up(off, 16);
         off = pc.arena_off + pc.len + 32;
@@ -796,9 +799,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
                 const LpProgScan& sa = ups[a].s;
                 LpJpeg ps;
                 memset(&ps, 0, sizeof(ps));
-                ps.raw_off = ups[a].raw_off;
+                ps.raw_off = ups[a].raw_off & ~(uint64_t)15; // (a scan fetched in one transfer with its neighbours starts wherever the file puts it)
+                ps.raw_skip = (uint32_t)(ups[a].raw_off & 15);
                 ps.raw_len = ups[a].raw_len;
-                ps.nchunks = (ps.raw_len + 4095) / 4096;
+                ps.nchunks = (ps.raw_skip + ps.raw_len + 4095) / 4096;
                 ps.chunk_off = tot_chunks_;
                 tot_chunks_ += ps.nchunks;
                 ps.clean_off = clean_words;

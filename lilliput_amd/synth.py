@@ -46,7 +46,7 @@ def synth_jpeg(seed, size=4096, quality=90, restart_rows=0, width=None, height=N
     if restart_rows:
         kw["restart_marker_rows"] = restart_rows
     if progressive:
-        kw["progressive"] = True   # libjpeg's default script: ten scans (the entropy decode of such a file runs on host threads)
+        kw["progressive"] = True   # libjpeg default script: ten scans
     Image.fromarray(rgb).save(b, "JPEG", quality=quality, subsampling=subsampling, optimize=False, **kw)  # Pillow: 2 = 4:2:0, 1 = 4:2:2, 0 = 4:4:4
     return b.getvalue()
 
