@@ -498,6 +498,31 @@ def ref_cv_jpeg_decode(data):
     return _cvjpeg_buf[: w.value * h.value * cn].reshape(h.value, w.value, cn).copy()
 
 
+def ref_cv_jpeg_encode(px, params=(1, 85), cap=None):
+    """cv::JpegEncoder::write(img, params) of the reference -- the class behind opencv_encoder_create(".jpeg") / opencv_encoder_write
+    (opencv.cpp:173-194), object code out of its libopencv_imgcodecs.a over its libjpeg.a -- into a destination Mat of `cap` bytes built
+    like opencv_mat_create_empty_from_data. px: HxW (gray), HxWx3 (BGR) or HxWx4 (BGRA) uint8; params: the flat int pairs opencv.go
+    passes. Returns the bytes; None when write answers false or throws; ("moved", n) when the n encoded bytes did not fit `cap` and the
+    Mat took a block of its own (the Go layer's ErrBufTooSmall)."""
+    L = ref_cvjpeg()
+    L.ref_cvjpeg_encode.restype = C.c_long
+    px = np.ascontiguousarray(px, dtype=np.uint8)
+    if px.ndim == 2:
+        px = px[:, :, None]
+    h, w, ch = px.shape
+    cap = cap if cap is not None else w * h * ch * 2 + 8192
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    par = (C.c_int * max(len(params), 1))(*params)
+    moved = C.c_long(0)
+    n = L.ref_cvjpeg_encode(px.ctypes.data_as(_u8p), C.c_int(w), C.c_int(h), C.c_int((ch - 1) << 3), C.c_size_t(w * ch), par, C.c_int(len(params)),
+                            out.ctypes.data_as(_u8p), C.c_size_t(cap), C.byref(moved))
+    if n == -2:
+        return ("moved", moved.value)
+    if n < 0:
+        return None
+    return out[:n].tobytes()
+
+
 def _coefs(fn, data, comp):
     arr, p = _buf(data)
     bw, bh = C.c_int(), C.c_int()
@@ -582,7 +607,8 @@ def _encode(fn, px, quality, extra=()):
 
 
 def jpeg_encode(px, quality=85):
-    """Restatement of cv::JpegEncoder::write({IMWRITE_JPEG_QUALITY: quality}) -> bytes."""
+    """Restatement of cv::JpegEncoder::write({IMWRITE_JPEG_QUALITY: quality}) -> bytes; pinned against the reference's own class
+    (ref_cv_jpeg_encode, tests/test_encoder_ref.py)."""
     return _encode(lib().lo_jpeg_encode, px, quality, (C.c_void_p(0),))
 
 

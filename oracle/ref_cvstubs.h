@@ -38,8 +38,25 @@ Mat::~Mat() {}
 void Mat::release() { data = 0; datastart = dataend = datalimit = 0; rows = cols = 0; }
 bool Mat::empty() const { return data == 0 || rows * cols == 0; }
 size_t Mat::total() const { return (size_t)rows * cols; }
-void Mat::reserve(size_t) { abort(); } // the encoder's
-void Mat::resize(size_t) { abort(); }
+void Mat::reserve(size_t) { abort(); }
+// cv::Mat::resize(nelems) as the patched encoder's destination manager uses it on its 1-column CV_8U destination (a Mat over the caller's
+// buffer whose datalimit tells the capacity, /root/reference/opencv.cpp:38-49): rows grow in place while the bytes fit; beyond the
+// capacity a new block is taken and the data pointer CHANGES -- which is how opencv.go:890-895 notices ErrBufTooSmall. (The block is
+// leaked: test infrastructure, once per overflowing call.)
+void Mat::resize(size_t nelems)
+{
+    const size_t row = step[0] ? (size_t)step[0] : (size_t)CV_ELEM_SIZE(flags & TYPE_MASK) * cols;
+    if ((size_t)(datalimit - datastart) < nelems * row) {
+        const size_t ncap = nelems * row * 2 + 64;
+        uchar* nb = (uchar*)malloc(ncap);
+        memcpy(nb, data, (size_t)rows * row);
+        data = nb;
+        datastart = nb;
+        datalimit = nb + ncap;
+    }
+    rows = (int)nelems;
+    dataend = data + nelems * row;
+}
 void Mat::updateContinuityFlag() { flags |= CONTINUOUS_FLAG; }
 Mat& Mat::operator=(const Mat& m)
 {

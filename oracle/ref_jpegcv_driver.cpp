@@ -45,6 +45,12 @@ bool _ZN2cv11JpegDecoder10readHeaderEv(void* self);
 bool _ZN2cv11JpegDecoder8readDataERNS_3MatE(void* self, cv::Mat* img);
 bool _ZN2cv12ImageDecoder4Impl9setSourceERKNS_3MatE(void* self, const cv::Mat* buf);
 static int field(const void* self, int i) { int v; memcpy(&v, (const char*)self + 8 + 4 * i, 4); return v; }
+// the encoder class of the same object file (what cv::ImageEncoder(".jpeg", dst) holds behind opencv_encoder_create / opencv_encoder_write,
+// /root/reference/opencv.cpp:173-194): constructor, the patched base class's setDestination(Mat&), write(img, params)
+void _ZN2cv11JpegEncoderC1Ev(void* self);
+void _ZN2cv11JpegEncoderD1Ev(void* self);
+bool _ZN2cv11JpegEncoder5writeERKNS_3MatERKSt6vectorIiSaIiEE(void* self, const cv::Mat* img, const std::vector<int>* params);
+bool _ZN2cv12ImageEncoder4Impl14setDestinationERNS_3MatE(void* self, cv::Mat* dst);
 
 // 0: decoded, out = h x w x channels (CV_8UC1 / CV_8UC3) the way opencv_decoder_read_data fills a Mat of the decoder's own type;
 // 1: readHeader refused the file; 2: readData failed (what the Go layer reports as ErrDecodingFailed, opencv.go:828-831); -1: cap too small
@@ -70,6 +76,31 @@ int ref_cvjpeg_decode(const uint8_t* data, size_t len, int* w, int* h, int* type
         }
     } catch (...) { rc = rc ? rc : 2; }
     try { _ZN2cv11JpegDecoderD1Ev(obj); } catch (...) {}
+    return rc;
+}
+
+// cv::JpegEncoder::write the way opencv_encoder_write drives it: img = h x w of `type` (CV_8UC1 / CV_8UC3 / CV_8UC4 ...) with row step
+// `step`, params = the int pairs of opencv.go:877-884 as they are (any key, any value). The destination is a 0 x 1 CV_8U Mat over `out`
+// with datalimit = out + cap, like opencv_mat_create_empty_from_data. Returns the encoded length; -1: write answered false or threw;
+// -2: the result did not fit and the Mat moved to a block of its own (*moved_len = its length: what the Go layer calls ErrBufTooSmall).
+long ref_cvjpeg_encode(const uint8_t* px, int w, int h, int type, size_t step, const int* params, int nparams, uint8_t* out, size_t cap, long* moved_len)
+{
+    alignas(64) static thread_local unsigned char obj[16384];
+    memset(obj, 0, sizeof(obj));
+    _ZN2cv11JpegEncoderC1Ev(obj);
+    long rc = -1;
+    try {
+        cv::Mat dst(0, 1, CV_8U, out);
+        dst.dataend = dst.data;
+        dst.datalimit = dst.data + cap;
+        cv::Mat img(h, w, type, const_cast<uint8_t*>(px), step);
+        const std::vector<int> p(params, params + nparams);
+        if (_ZN2cv12ImageEncoder4Impl14setDestinationERNS_3MatE(obj, &dst) && _ZN2cv11JpegEncoder5writeERKNS_3MatERKSt6vectorIiSaIiEE(obj, &img, &p)) {
+            if (dst.data == out) rc = dst.rows;
+            else { rc = -2; if (moved_len) *moved_len = dst.rows; }
+        }
+    } catch (...) { rc = -1; }
+    try { _ZN2cv11JpegEncoderD1Ev(obj); } catch (...) {}
     return rc;
 }
 }
