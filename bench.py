@@ -54,7 +54,8 @@ def make_sources(batch, distinct, size, rank, world, quality=90, sampling="420")
             cpus = (os.cpu_count() or 2) - 1 if quota is None else max(1, int(2 * quota))
             workers = max(1, min(len(missing), cpus, 96))  # ~0.7 GB of numpy temporaries per worker
             with mp.get_context("fork").Pool(workers) as pool:
-                for i, data in zip(missing, pool.imap(synth._job, [(i, size, quality, 0, None, None, {"420": 2, "422": 1, "444": 0, "420p": 2}[sampling], sampling.endswith("p")) for i in missing], chunksize=1)):
+                base, _, rrows = sampling.partition("r")   # "420r1" = 4:2:0 with a restart marker every MCU row (--restart-rows 1: SURVEY 8(d)'s DRI set)
+                for i, data in zip(missing, pool.imap(synth._job, [(i, size, quality, int(rrows or 0), None, None, {"420": 2, "422": 1, "444": 0, "420p": 2}[base], base.endswith("p")) for i in missing], chunksize=1)):
                     with open(paths[i] + ".tmp", "wb") as f:
                         f.write(data)
                     os.replace(paths[i] + ".tmp", paths[i])
@@ -629,7 +630,12 @@ def main_firehose(args, ranks, la):
                     if i in wanted:
                         kept[i] = r
 
+    import resource
+
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     elapsed = ranks.timed(step, args.steps, args.warmup)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s_timed = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)   # this process, every thread: warm-up steps included
     if one_call:
         res = node.results()
     else:
@@ -684,9 +690,34 @@ def main_firehose(args, ranks, la):
                           "verified_outputs_per_format": verified, "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
                           "verified_against": "oracle.transform_any_to_jpeg (reference libjpeg-turbo / libpng / libwebp decode -> INTER_AREA restatement -> libjpeg-turbo encode); bytes, or "
                                               "a pre-encode frame within +-1 LSB that the output encodes byte-exactly (fractional scales)",
-                          "ingest_source_memory": args.ingest},
-               "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                            "note": "the mixed stream is bound by the host codecs (inflate, VP8) and the per-item launches of the non-JPEG items, not by a kernel: see DESIGN.md 5"}}
+                          "ingest_source_memory": args.ingest}}
+        # What bounds this stream is the HOST: inflate, VP8 / VP8L and (in the feeder) AV1 are serial host codecs, the header walks and the
+        # per-item launches of the non-JPEG routes run on host threads. So the line's roofline is the host's: CPU-seconds per item (process
+        # CPU time of the library's threads, measured per format on up to 64 items of the step, alone, outside the timed region) against the
+        # CPUs the container grants; frac = this run's rate / (usable CPUs / CPU-seconds per item of the mix).
+        usable = cgroup_cpus() or float(host_cores()[0])
+        per_fmt_cpu = {}
+        for k in counts:
+            idx = [i for i, kk in enumerate(kinds) if kk == k][:64]
+            if not idx or k == "avif":
+                continue
+            sub = [sources[i] for i in idx]
+            node.prepare(sub, dst_cap=512 << 10)
+            node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            r0, t0w = resource.getrusage(resource.RUSAGE_SELF), time.time()
+            node.transform_prepared(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+            r1 = resource.getrusage(resource.RUSAGE_SELF)
+            per_fmt_cpu[k] = {"cpu_seconds_per_item": round(((r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime)) / len(idx), 6), "items": len(idx),
+                              "wall_ms_per_item": round(1000.0 * (time.time() - t0w) / len(idx), 4)}
+        cpu_per_item = cpu_s_timed / max(1, args.batch * (args.steps + args.warmup))
+        host_bound = usable / cpu_per_item if cpu_per_item > 0 else None
+        out["roofline"] = {"bound": "host", "unit": "items/s", "achieved": round(n / elapsed / world, 2), "peak": round(host_bound, 1) if host_bound else None,
+                           "frac": round(n / elapsed / world / host_bound, 4) if host_bound else None, "traffic": None,
+                           "usable_cpus": usable, "cpu_seconds_per_item_in_timed_region": round(cpu_per_item, 6),
+                           "cpu_seconds_per_item_by_format": per_fmt_cpu,
+                           "is": "peak = usable CPUs / process CPU-seconds per item of the timed region (library threads; the AVIF feeder's worker processes are not in it: "
+                                 "config.avif_feeder); frac = achieved / peak: how much of the host the stream keeps busy -- the rest is waiting (launch round trips of the one-image "
+                                 "routes, the device, the feeder)"}
         if not args.no_extra_legs:
             # the dominant device stage of THIS mix, from the library's stage profile (HIP events around every probed launch of the one-image
             # route, live, outside the timed region) over a sample of the step's items (AVIF items as the feeder's frames)
@@ -705,7 +736,7 @@ def main_firehose(args, ranks, la):
                 roof = stage_profile_roofline(la, run_once, repeats=2)
                 roof["note"] = ("the dominant device stage of this mix by the library's stage profile over %d of the step's items through the one-image route (a launch serves ONE image of "
                                 "0.3 - 50 MP here, so achieved / frac are those of small launches); the stream as a whole is bound by the host codecs (inflate, VP8, AV1) -- cpu_baseline, DESIGN.md 5" % len(sample))
-                out["roofline"] = roof
+                out["roofline"]["device_stage_profile"] = roof
             finally:
                 pops.Close()
         if not args.no_cpu_baseline:
@@ -907,6 +938,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=1024, help="distinct synthetic source images (seed = index), tiled to the batch when fewer")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--source-sampling", choices=["420", "422", "444", "420p"], default="420", help="chroma sampling of the synthetic sources (420 = the BASELINE workload; 422 / 444 run k_resample_hv1; 420p = PROGRESSIVE 4:2:0 files: one wave per scan on the device for large sets, host threads for small ones -- DESIGN.md 4.4; LILLIPUT_HIP_PROG_ENTROPY=host|device forces either)")
+    ap.add_argument("--restart-rows", type=int, default=0, help="restart interval of the synthetic sources in MCU rows (0 = none, the BASELINE workload; 1 = a marker every MCU row: "
+                    "SURVEY.md 8(d)'s second set -- the subsequence-parallel decoder takes restart markers as forced synchronisation points)")
     ap.add_argument("--source-quality", type=int, default=90, help="JPEG quality of the synthetic sources (90 = the BASELINE workload, ~2 bits/pixel; 75 gives ~1 bit/pixel, the density of a camera photograph: the link then carries half the bytes per image and the device kernels, not PCIe, set the rate)")
     ap.add_argument("--orientation", type=int, default=1, choices=range(1, 9), help="EXIF orientation written into the sources (1 = the BASELINE workload; others measure the orientation folded into the resample kernels)")
     ap.add_argument("--chunk", type=int, default=0, help="images in flight on the device per engine (0 = automatic)")
@@ -936,6 +969,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the resident-throughput and exclusive-kernel legs that follow the timed region")
     args = ap.parse_args()
+    if args.restart_rows > 0:
+        args.source_sampling += "r%d" % args.restart_rows   # travels with the sampling: source cache name, workload description
 
     alias = [int(x) for x in args.alias_devices.split(",") if x.strip() != ""]
     if alias and len(alias) != args.gpus:

@@ -483,7 +483,7 @@ void lilliput_hip_deferred_stats(uint64_t out[4]);
 
 /* Progressive (SOF2) JPEG sources (libjpeg-turbo jdphuff.c behind opencv_decoder_read_data, opencv.cpp:166-171): where the scans' entropy
  * decode runs. mode -1 = auto (default): on the device -- one wave per scan, lilliput_amd/csrc/lp_kernels_prog.hip -- for the progressive
- * images of an upload set that holds at least LILLIPUT_HIP_PROG_DEVICE_MIN (default 48) of them, on host threads (lp_prog_host.h; thread
+ * images of an upload set that holds at least LILLIPUT_HIP_PROG_DEVICE_MIN (default: five per usable host CPU) of them, on host threads (lp_prog_host.h; thread
  * count LILLIPUT_HIP_PROG_THREADS) otherwise; 0 = host threads always; 1 = device always; 2 = the generic one-lane-per-scan device kernel
  * (k_prog_scan, the wave decoder's tested reference). LILLIPUT_HIP_PROG_ENTROPY=auto|host|device|lanes sets the process default.
  * Same results in every mode: an image whose data the device decoders find irregular is decoded again by the host threads.

@@ -1128,6 +1128,12 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
         const bool prog_on_device_possible = lp_prog_entropy_mode() != 0;
+        if (prog_on_device_possible) { // how many progressive files the call holds: the engines' host / device choice (lp_prog_host.h)
+            uint32_t nprog = 0;
+            for (size_t i = 0; i < n; i++) nprog += lp_jpeg_sniff_progressive((const uint8_t*)items[i].src, items[i].src_len) ? 1u : 0u;
+            for (LpBatch* d : devs)
+                for (auto& part : d->parts) part.eng->set_progressive_in_call(nprog / (uint32_t)devs.size());
+        }
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
             LpPipeJob job;
             job.i0 = i;

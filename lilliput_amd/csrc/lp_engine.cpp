@@ -400,7 +400,7 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
         }
         // auto: a scan is a serial chain and one wave walks it ~3x slower than a host core, so the device only wins with enough
         // chains side by side (measured break-even: profiles/r06_progressive.md); below it the host threads keep the set
-        if (u.prog_mode < 0 && cand < lp_prog_device_min_images()) cand = 0;
+        if (u.prog_mode < 0 && std::max<size_t>(cand, u.prog_in_call) < lp_prog_device_min_images()) cand = 0;
         if (u.prog_mode == 0 || !cand) u.prog_dev.assign((size_t)n, 0);
         u.any_prog_dev = u.prog_mode != 0 && cand != 0;
         if (u.prog_mode < 0) u.prog_mode = 1;

@@ -119,6 +119,7 @@ struct LpUpload {
     int prog_mode = 0;                              // how the set's device-side scans are decoded: 1 a wave per progressive scan, 2 lanes (lp_prog_host.h)
     std::vector<uint8_t> prog_dev;                  // per image: 1 = its scans are entropy-decoded on the device, 0 = on host threads
     bool any_prog_dev = false;
+    uint32_t prog_in_call = 0;                      // see LpEngine::set_progressive_in_call
     bool force_host_scans = false;                  // the next layout keeps every scan on host threads (an image the device gave up on)
     LpPinned pcoef;                                 // host mode: the decoded int16 coefficients of every scan-path image of the set
     std::vector<size_t> pcoef_off;                  // element offset per image
@@ -145,6 +146,10 @@ public:
 
     // Subsequence size in bits (multiple of 32, 64..32768) and checkpoint spacing in bits (sets the schedule); 0 = automatic.
     void set_subsequence(uint32_t S, uint32_t C) { S_cfg_ = S; C_cfg_ = C; }
+    // Progressive sources of the CALL this engine's next upload sets belong to (the batch front end counts them over all its chunks): the
+    // automatic host / device choice of a set looks at the larger of this and the set's own count -- the device wins by the number of scan
+    // chains in flight, and the chunks of one call are in flight together.
+    void set_progressive_in_call(uint32_t n) { for (LpUpload& u : up_) u.prog_in_call = n; }
 
     // Heap for intermediate frames: bump-allocated, reset per batch.
     void heap_reset() { heap_used_ = 0; }

@@ -13,7 +13,7 @@
 // A guarded buffer is allocated at exactly the size asked for (no geometric growth), so the arenas re-allocate more often: a
 // debugging mode, several times slower on mixed batches. LILLIPUT_HIP_GUARD_LOG=1 prints one line per allocation (tag, size, address
 // range) -- the "Memory access fault ... on address X" line of the runtime then names the buffer whose end X is.
-// scripts/r04_guard.sh runs the GPU test suite, smoke() and every bench workload under it (profiles/r04_guard.md).
+// scripts/archive/r04_guard.sh runs the GPU test suite, smoke() and every bench workload under it (profiles/r04_guard.md).
 #pragma once
 #include <stddef.h>
 

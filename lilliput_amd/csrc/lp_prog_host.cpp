@@ -149,7 +149,14 @@ int lp_prog_entropy_mode()
 }
 uint32_t lp_prog_device_min_images()
 {
-    static const uint32_t v = [] { const char* e = getenv("LILLIPUT_HIP_PROG_DEVICE_MIN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 48u; }();
+    // Measured on the 16-CPU box (profiles/r06_progressive.md): the device's time for a set is its longest scan chain whatever the count
+    // (29 / 115 ms at 1024 / 2048 pixels a side), the host threads' time grows with the count; they cross between 64 and 96 files at
+    // every size -- about five files per host thread.
+    static const uint32_t v = [] {
+        const char* e = getenv("LILLIPUT_HIP_PROG_DEVICE_MIN");
+        if (e && atoi(e) > 0) return (uint32_t)atoi(e);
+        return std::max(16u, std::min(512u, 5u * lp_usable_cpus_per_device()));
+    }();
     return v;
 }
 extern "C" void lilliput_hip_set_progressive_entropy(int mode) { g_mode.store(mode < -1 || mode > 2 ? -1 : mode, std::memory_order_relaxed); }

@@ -43,7 +43,7 @@ void lp_prog_levels(const std::vector<LpProgScanHost>& scans, std::vector<uint32
 //            sequential scan (k_prog_scan). QM-coded files stay on host threads (a set may mix both).
 //   2 lanes  as 1 with the generic one-lane-per-scan kernel for every scan: the wave decoder's tested reference (30-50x slower).
 //  -1 auto   (default) device for the progressive images of a set that holds at least lp_prog_device_min_images() of them
-//            (LILLIPUT_HIP_PROG_DEVICE_MIN, default 48), host threads otherwise: a scan is a serial chain, a wave walks it ~3x slower than
+//            (LILLIPUT_HIP_PROG_DEVICE_MIN, default five per usable host CPU: 80 on the 16-CPU box), host threads otherwise: a scan is a serial chain, a wave walks it ~3x slower than
 //            a host core, and a set only offers (images x independent scans) chains -- few images are faster on the host's cores, many
 //            on the device's thousands of wave slots.
 // An image the device decoders give up on (damaged data; LpEngine::scan_gave_up) is decoded again by the host threads in every mode.

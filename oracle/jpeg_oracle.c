@@ -10,7 +10,8 @@
  * reference tree), so this file restates the published algorithm (ITU T.81 +
  * the libjpeg "islow" DCT, "fancy" triangle upsampling, 16-bit fixed point colour
  * conversion) and is pinned against
- *   (a) the reference's own prebuilt libjpeg.a via oracle/_ref (tests/test_oracle_ref.py),
+ *   (a) the reference's own prebuilt libjpeg.a via oracle/_ref (tests/test_oracle_golden.py, tests/test_damaged.py; the encoder also
+ *       against the reference's cv::JpegEncoder class, tests/test_encoder_ref.py),
  *   (b) the ThumbHash known answers of /root/reference/thumbhash_test.go:63-81
  *       (tests/test_oracle_golden.py).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.

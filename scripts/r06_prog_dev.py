@@ -56,8 +56,8 @@ if what == "check":
 
 for side in sides:
     files = [synth.synth_jpeg(i, side, 90, progressive=True) for i in range(8)]
-    for n in (16, 64, 256):
-        if side >= 4096 and n > 64:
+    for n in ([int(x) for x in os.environ["BATCHES"].split(",")] if os.environ.get("BATCHES") else (16, 64, 256)):
+        if side >= 4096 and n > 64 and not os.environ.get("BATCHES"):
             continue
         srcs = [files[i % 8] for i in range(n)]
         row = []
