@@ -419,7 +419,9 @@ __device__ __forceinline__ void pw_ac_refine(const PwScan& s, PwBits& b, const u
                 const uint32_t t = zc + PW_R(e);
                 const u64 hit = ballot(zrank == t);
                 const uint32_t stop = hit ? (uint32_t)__builtin_ctzll(hit) : 64u;
-                const uint32_t ms = rl(mrank, stop); // non-zero lanes below stop
+                // non-zero lanes below stop: on the scalar side (s_bfm + s_and + s_bcnt1) -- a v_readlane of the lanes' ranks would be one more
+                // SALU -> VALU -> SALU round trip on the chain, and those, not the instruction count, are what a symbol waits for
+                const uint32_t ms = (uint32_t)__popcll(Mb & ((1ull << (stop & 63u)) - 1ull));
                 g += PW_ADV(e);
                 const uint32_t base = b.pb + g;
                 D = lane >= k ? base : D;

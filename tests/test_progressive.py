@@ -329,3 +329,17 @@ def test_progressive_modes_agree_on_damaged_files(batch, hip_lib):
             hip_lib.lilliput_hip_set_progressive_entropy(-1)
     assert outs[0] == outs[1] and outs[0] == outs[2]
     assert sum(isinstance(x, bytes) for x in outs[0]) > 5
+
+
+def test_wave_decoder_listing_keeps_its_hand_managed_registers():
+    """lp_kernels_prog.hip keeps its in-flight loads in physical registers the compiler does not know about (PW_RING_*): the gfx950
+    listing must name them in the hand-written instructions only, every take behind its s_waitcnt, and use no scratch
+    (scripts/r06_check_prog_isa.py; hipcc cross-compiles without a GPU)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r06_check_prog_isa.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
