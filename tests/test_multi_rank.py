@@ -168,3 +168,44 @@ def test_bench_gpus_n_drives_n_device_slots_in_one_process_without_pytorch(tmp_p
     out, _ = _run_bench(tmp_path, "--gpus", "2", "--alias-devices", "0,0", "--ranks", *small)
     line = json.loads(out.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["verified_identical"] and "rendezvous directory" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_eight_device_slots_share_the_queue_fairly(tmp_path):
+    """The shape of the 8-GPU run the driver will make, on one GPU listed eight times: lilliput_hip_node_transform over eight engine
+    sets and ONE chunk queue, 8 x 1024 tiny items. With the static shares pinned (LILLIPUT_HIP_NODE_STEAL=0 in a child process) every slot
+    serves exactly its eighth; with stealing every image is still served exactly once, the bytes equal a single batch's, and no slot starves.
+    Then `bench.py --gpus 8 --alias-devices 0,0,0,0,0,0,0,0` end to end (no PyTorch in the process)."""
+    sys.path.insert(0, ROOT)
+    import lilliput_amd as la
+    from lilliput_amd import synth
+
+    tiny = [synth.synth_jpeg(s, 64, 85) for s in range(16)]
+    sources = [tiny[i % 16] for i in range(8 * 1024)]
+    b = la.Batch(0)
+    ref = b.transform(tiny, 32, 32, quality=85)
+    b.close()
+    node = la.Node([0] * 8)
+    assert node.device_count() == 8
+    got = node.transform(sources, 32, 32, quality=85, chunk=64)
+    assert all(g.status == 0 for g in got)
+    assert all(got[i].data == ref[i % 16].data for i in range(len(got)))
+    stats = node.device_stats()
+    assert len(stats) == 8 and sum(s["images"] for s in stats) == len(sources), stats
+    assert min(s["images"] for s in stats) > 0, stats   # nobody starved (128 chunks, 16 per slot before stealing)
+    q = node.queue_stats()
+    assert q["chunks"] == 128, q
+    node.close()
+    code = ("import sys; sys.path.insert(0, %r); import lilliput_amd as la; from lilliput_amd import synth\n"
+            "t = [synth.synth_jpeg(s, 64, 85) for s in range(16)]; n = la.Node([0] * 8)\n"
+            "r = n.transform([t[i %% 16] for i in range(8192)], 32, 32, quality=85, chunk=64)\n"
+            "assert all(x.status == 0 for x in r); print([s['images'] for s in n.device_stats()], n.queue_stats()['stolen'])\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LILLIPUT_HIP_NODE_STEAL="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout.decode().strip().splitlines()[-1] == "[1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024] 0", p.stdout.decode()
+    small = ["--batch", "16", "--distinct", "16", "--size", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--verify", "4", "--chunk", "4"]
+    out, _ = _run_bench(tmp_path, "--gpus", "8", "--alias-devices", "0,0,0,0,0,0,0,0", *small)
+    line = json.loads(out.strip().splitlines()[-1])
+    per = line["config"]["per_device_last_step"]
+    assert line["n_gpus"] == 8 and line["config"]["verified_identical"] and line["config"]["ok_images"] == 8 * 16 and len(per) == 8
+    assert sum(d["images"] for d in per) == 128 and line["scaling"] == "weak"
