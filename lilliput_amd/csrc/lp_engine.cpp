@@ -738,6 +738,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     size_t max_ecs = 0;
     for (auto& j : h_imgs_) max_ecs = std::max<size_t>(max_ecs, j.raw_len);
     S_ = S_cfg_ ? S_cfg_ : pick_S(max_ecs);
+    vr_ = LP_VERIFY_ROUNDS;
     if (!S_cfg_) {
         // Small launches (the one-image ABI) are bound by the length of a lane's serial walk, not by throughput: cut the
         // subsequences shorter until the launch has enough lanes to occupy a good part of the device.
@@ -754,7 +755,18 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // subsequence that does not settle within them with a second pass: below 4 096 bits the self-synchronisation distance of
         // 4096 x 4096 sources (p99 ~800 symbols) spans several subsequences. Measured, 4 / 8 images per call: 5.3 / 6.4 ms with the
         // floor at 1 024, 2.5 / 4.3 ms at 4 096 (profiles/r03_c_final.md).
-        const uint32_t floor_S = defer ? std::max(min_S, 4096u) : min_S;
+        // ... for the large sources that was measured on. A SMALL deferred launch (one 512 x 512 file through the batched entry point: 228
+        // lanes of 4 096 bits = ONE workgroup, k_huff_spec 122 us + k_huff_verify 170 + k_huff_write 337 of a 0.9 ms call, profiles/
+        // r06_one_image.md) is bound by the length of the lanes' walks like the one-image ABI is: below LILLIPUT_HIP_DEFER_SMALL_KBIT
+        // (default 8 192 = 1 MB of entropy-coded data in the launch) the floor is the one-image ABI's.
+        static const uint64_t defer_small_bits = (uint64_t)(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT") ? atoi(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT")) : 8192) << 10;
+        // ... and a small launch may go below the one-image floor when MORE verify rounds are queued behind it (vr_: an idle round costs
+        // ~4 us, a host-driven second pass ~0.8 ms): LILLIPUT_HIP_SMALL_S / LILLIPUT_HIP_SMALL_ROUNDS, measured in profiles/r06_one_image.md
+        static const uint32_t small_S = getenv("LILLIPUT_HIP_SMALL_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_SMALL_S")) : 2048u;
+        static const uint32_t small_rounds = getenv("LILLIPUT_HIP_SMALL_ROUNDS") ? (uint32_t)std::min(LP_VERIFY_MAX, std::max(1, atoi(getenv("LILLIPUT_HIP_SMALL_ROUNDS")))) : (uint32_t)LP_VERIFY_ROUNDS;
+        const bool small_launch = bits <= defer_small_bits;
+        vr_ = small_launch ? small_rounds : (uint32_t)LP_VERIFY_ROUNDS;
+        const uint32_t floor_S = small_launch ? std::min(min_S, small_S) : defer ? std::max(min_S, 4096u) : min_S;
         // Small files (round 5): pick_S sizes by the largest file alone and hands 1 024 or 256 bits to sources of a few KB -- whose
         // entropy streams then need a verify round per subsequence the self-synchronisation distance spans (22 rounds for 128 x 128
         // sources, against the four that are queued). The floor holds for them too: a chunk of many small files gets its lanes from
@@ -977,8 +989,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     // Verify rounds back to back, no host round trip in between: round r counts the exit states it moved into changed[r] and a
     // round that follows an idle one returns at once. The last counter is looked at when the decode is collected (finish_decode);
     // streams that need more than LP_VERIFY_ROUNDS rounds (tiny subsequences, hostile data) continue there under host control.
-    if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (LP_VERIFY_ROUNDS + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
-    for (uint32_t r = 0; r < LP_VERIFY_ROUNDS; r++) lp_launch_huff_verify(stream_, ha, r);
+    if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (vr_ + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
+    for (uint32_t r = 0; r < vr_; r++) lp_launch_huff_verify(stream_, ha, r);
     mark(9);
     stage("huff_verify");
     lp_launch_sub_scan(stream_, ha);
@@ -1054,9 +1066,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         lp_launch_ycc_to_frame(stream_, di, (uint32_t)n, max_w_, max_h_, any_generic, any_420, d_planes_.as<uint8_t>(), d_frames_desc_.as<LpFrame>(), nullptr);
     }
     mark(4);
-    pend_ = Pending{true, first, n, nstreams, pcoef_elems, any_baseline, any_frame, any_generic, any_420, frames, ha};
+    pend_ = Pending{true, first, n, nstreams, pcoef_elems, any_baseline, any_frame, any_generic, any_420, frames, ha, vr_};
     d2h_small(h_dstate_, h_dstate_.as<uint8_t>() + 64, ds, sizeof(LpJpegState) * (size_t)n);
-    d2h_small(h_dstate_, h_dstate_.p, d_changed_.p, 4 * (LP_VERIFY_ROUNDS + 1));
+    d2h_small(h_dstate_, h_dstate_.p, d_changed_.p, 4 * (vr_ + 1));
     return defer ? LP_OK : finish_decode(status);
 }
 
@@ -1073,14 +1085,15 @@ int LpEngine::finish_decode(int* status)
     if (!check(hipGetLastError(), "decode kernels")) return LP_ERR_DEVICE;
     const uint32_t* h_changed = h_dstate_.as<uint32_t>();
     uint32_t rounds = 1;
-    for (uint32_t r = 0; r + 1 < LP_VERIFY_ROUNDS; r++) rounds += h_changed[r] ? 1u : 0u;
+    const uint32_t vr = pend_.vr; // verify rounds that were queued behind the speculative pass
+    for (uint32_t r = 0; r + 1 < vr; r++) rounds += h_changed[r] ? 1u : 0u;
     bool redone = false;
-    if (h_changed[LP_VERIFY_ROUNDS - 1] != 0) {
+    if (h_changed[vr - 1] != 0) {
         const LpHuffArgs& ha = pend_.ha;
-        for (;;) { // round index LP_VERIFY_ROUNDS: its gate reads the previous counter, which is non-zero here
-            if (!check(hipMemsetAsync(d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
-            lp_launch_huff_verify(stream_, ha, LP_VERIFY_ROUNDS);
-            if (!check(hipMemcpyAsync(h_small_.p, d_changed_.as<uint32_t>() + LP_VERIFY_ROUNDS, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
+        for (;;) { // round index vr: its gate reads the previous counter, which is non-zero here
+            if (!check(hipMemsetAsync(d_changed_.as<uint32_t>() + vr, 0, 4, stream_), "memset changed")) return LP_ERR_DEVICE;
+            lp_launch_huff_verify(stream_, ha, vr);
+            if (!check(hipMemcpyAsync(h_small_.p, d_changed_.as<uint32_t>() + vr, 4, hipMemcpyDeviceToHost, stream_), "D2H changed")) return LP_ERR_DEVICE;
             if (!check(hipStreamSynchronize(stream_), "verify sync")) return LP_ERR_DEVICE;
             rounds++;
             if (*h_small_.as<uint32_t>() == 0) break;

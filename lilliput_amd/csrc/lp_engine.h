@@ -285,7 +285,8 @@ private:
     std::vector<std::pair<size_t, std::vector<uint8_t>>> h_big_;    // streams that outgrew their slot
     std::vector<LpFusedOp> h_fops_;
     bool fused_timed_ = false;
-    struct Pending { bool active; int first, n; size_t nstreams, pcoef_elems; bool any_baseline, any_frame, any_generic, any_420; LpFrame* frames; LpHuffArgs ha; };
+    struct Pending { bool active; int first, n; size_t nstreams, pcoef_elems; bool any_baseline, any_frame, any_generic, any_420; LpFrame* frames; LpHuffArgs ha; uint32_t vr; };
+    uint32_t vr_ = LP_VERIFY_ROUNDS;                // verify rounds queued behind the speculative pass of the current launch
     Pending pend_ = {};
     std::vector<size_t> h_out_off_;
 

@@ -32,6 +32,7 @@ struct LpHuffArgs {
 void lp_launch_huff_spec(hipStream_t s, const LpHuffArgs& a);
 uint32_t lp_huff_write_slots(); // WRITE workgroups resident on the current device at once
 void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round); // counts into a.changed[round]; idle when changed[round - 1] == 0
+#define LP_VERIFY_MAX 12        // ... at most (small launches with short subsequences may queue more: LpEngine::vr_; the counter array holds 16)
 #define LP_VERIFY_ROUNDS 4      // rounds enqueued without looking (photographic streams settle in two); more only after a host check
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_reset_tail_state(hipStream_t s, LpJpegState* d_states, uint32_t n);
