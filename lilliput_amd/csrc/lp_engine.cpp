@@ -758,8 +758,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // ... for the large sources that was measured on. A SMALL deferred launch (one 512 x 512 file through the batched entry point: 228
         // lanes of 4 096 bits = ONE workgroup, k_huff_spec 122 us + k_huff_verify 170 + k_huff_write 337 of a 0.9 ms call, profiles/
         // r06_one_image.md) is bound by the length of the lanes' walks like the one-image ABI is: below LILLIPUT_HIP_DEFER_SMALL_KBIT
-        // (default 8 192 = 1 MB of entropy-coded data in the launch) the floor is the one-image ABI's.
-        static const uint64_t defer_small_bits = (uint64_t)(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT") ? atoi(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT")) : 8192) << 10;
+        // (default 40 960 = 5 MB of entropy-coded data in the launch: one 4096 x 4096 q90 file) the floor is the one-image ABI's.
+        static const uint64_t defer_small_bits = (uint64_t)(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT") ? atoi(getenv("LILLIPUT_HIP_DEFER_SMALL_KBIT")) : 40960) << 10;
         // ... and a small launch may go below the one-image floor when MORE verify rounds are queued behind it (vr_: an idle round costs
         // ~4 us, a host-driven second pass ~0.8 ms): LILLIPUT_HIP_SMALL_S / LILLIPUT_HIP_SMALL_ROUNDS, measured in profiles/r06_one_image.md
         static const uint32_t small_S = getenv("LILLIPUT_HIP_SMALL_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_SMALL_S")) : 2048u;
