@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -31,7 +32,7 @@ int env_int(const char* name, int dflt, int lo, int hi)
 int threshold() { static const int v = env_int("LILLIPUT_HIP_COALESCE", 3, 0, 1 << 20); return v; }
 int n_workers() { static const int v = env_int("LILLIPUT_HIP_COALESCE_WORKERS", 4, 1, 16); return v; }
 int idle_ms() { static const int v = env_int("LILLIPUT_HIP_COALESCE_IDLE_MS", 1000, 1, 1 << 30); return v; }
-size_t max_take() { static const int v = env_int("LILLIPUT_HIP_COALESCE_MAX", 32, 1, 1024); return (size_t)v; }
+size_t max_take() { static const int v = env_int("LILLIPUT_HIP_COALESCE_MAX", 16, 1, 1024); return (size_t)v; }
 
 struct Req {
     const void* src; size_t len; void* dst; size_t cap;
@@ -83,8 +84,12 @@ struct Dispatch {
                 }
                 if (stop) break;
                 // the oldest request and every waiting one with the same options, in arrival order
+                // how many: at most LILLIPUT_HIP_COALESCE_MAX (16 since round 6: 64 callers are served faster by four dispatchers with 16 requests
+                // each than by two with 32 -- 8.7-9.7 k against 5.8-7.8 k images/s, p99 10-14 ms against 20-70; a limit that grows with the
+                // queue was measured and bought nothing at 256 callers: profiles/r06_part_a.md)
+                const size_t limit = max_take();
                 const lilliput_batch_options key = q.front()->opt;
-                for (auto it = q.begin(); it != q.end() && take.size() < max_take();) {
+                for (auto it = q.begin(); it != q.end() && take.size() < limit;) {
                     if (same_options((*it)->opt, key)) { take.push_back(*it); it = q.erase(it); }
                     else ++it;
                 }
