@@ -560,6 +560,12 @@ def main_firehose(args, ranks, la):
 
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     ndev = max(1, la.lib().lilliput_hip_device_count())
+    # node mode (`--gpus N` not under torchrun): ONE process drives the N devices through lilliput_hip_node_transform and one chunk queue;
+    # --batch stays "items per GPU and step", the step's stream holds N times that
+    node_devs = getattr(args, "node_devices", None)
+    ngpu = len(node_devs) if node_devs else 1
+    per_gpu_batch = args.batch
+    args.batch = args.batch * ngpu
     per_kind = max(4, min(args.distinct, 256) // 8)
     t0 = time.time()
     real_avif = synth.avif_supported()
@@ -574,8 +580,8 @@ def main_firehose(args, ranks, la):
         arena = la.HostArena(sum(len(d) + 64 for d in distinct.values()) + 4096, local_rank % ndev)
         placed = {k: arena.put(d) for k, d in distinct.items()}
     sources = [placed[id(d)] if arena is not None else np.frombuffer(d, dtype=np.uint8) for _, d in items]
-    node = la.Node([local_rank % ndev])
-    node_avif = la.Node([local_rank % ndev]) if real_avif else None
+    node = la.Node(node_devs if node_devs else [local_rank % ndev])
+    node_avif = la.Node(node_devs if node_devs else [local_rank % ndev]) if real_avif else None
     window = args.window if 0 < args.window < args.batch else args.batch
     kinds = [k for k, _ in items]
     # AVIF items: the AV1 decode is the HOST FEEDER's (a service has libavif in front of the library, lilliput.go:136-164 -> avif.cpp; here
@@ -671,13 +677,13 @@ def main_firehose(args, ranks, la):
     if rank == 0:
         n = args.batch * world * args.steps
         mb_in = sum(len(d) for _, d in items) / 1e6
-        out = {"metric": "images/sec (mixed-format firehose, sides 512-%d px -> 256x256 JPEG q85)" % args.max_side, "value": round(n / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        out = {"metric": "images/sec (mixed-format firehose, sides 512-%d px -> 256x256 JPEG q85)" % args.max_side, "value": round(n / elapsed, 2), "unit": "images/s", "n_gpus": world * ngpu,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "BASELINE configs[4]%s: %d items per GPU and step, JPEG 70 / PNG 15 / WebP 10 / %s, "
                                       "sides log-uniform 512-%d px (every second source 4:3), %d distinct sources per format -> 256x256 JPEG q85, ImageOpsFit; "
                                       "lilliput_hip_node_transform, host bytes in -> host bytes out%s" % (
-                                          "" if args.batch >= 100000 and args.max_side >= 8192 else " in miniature", args.batch,
+                                          "" if args.batch >= 100000 and args.max_side >= 8192 else " in miniature", per_gpu_batch,
                                           "REAL AVIF files 5 % (AV1 is a host codec: decoded inside the timed region by the bench's host feeder -- worker processes with Pillow's bundled libavif, "
                                           "running while the library works on the rest of the window -- and handed over as decoded frames, the route a service with libavif in front takes: "
                                           "lilliput.go:136-164, INTEGRATION.md 2f; the gate's answer comes from the reference's own libavif + dav1d)" if real_avif else
@@ -690,7 +696,9 @@ def main_firehose(args, ranks, la):
                           "verified_outputs_per_format": verified, "verified_identical": all(g[1] == 0 for g in gate) and all(g[2] == args.batch for g in gate),
                           "verified_against": "oracle.transform_any_to_jpeg (reference libjpeg-turbo / libpng / libwebp decode -> INTER_AREA restatement -> libjpeg-turbo encode); bytes, or "
                                               "a pre-encode frame within +-1 LSB that the output encodes byte-exactly (fractional scales)",
-                          "ingest_source_memory": args.ingest}}
+                          "ingest_source_memory": args.ingest,
+                          "node_mode": {"devices": node_devs, "aliased": len(set(node_devs)) < len(node_devs), "per_device_last_step": node.device_stats(), "queue": node.queue_stats(),
+                                        "is": "one process, lilliput_hip_node_transform over these device slots and ONE chunk queue in host memory (no PyTorch, no collective)"} if node_devs else None}}
         # What bounds this stream is the HOST: inflate, VP8 / VP8L and (in the feeder) AV1 are serial host codecs, the header walks and the
         # per-item launches of the non-JPEG routes run on host threads. So the line's roofline is the host's: CPU-seconds per item (process
         # CPU time of the library's threads, measured per format on up to 64 items of the step, alone, outside the timed region) against the
@@ -978,10 +986,19 @@ def main():
         sys.exit(2)
     if os.environ.get("WORLD_SIZE") is None and (args.gpus > 1 or alias):
         # not under torchrun: this process owns the node
-        if args.workload != "jpeg4096":
-            log("[bench] --gpus N without torchrun drives the headline workload (jpeg4096); the other workloads run one rank per GPU under torchrun")
+        if args.workload == "firehose":   # BASELINE configs[4] sharded over the node's GPUs: one process, one queue (main_firehose's node mode)
+            import lilliput_amd as la_
+
+            have = la_.lib().lilliput_hip_device_count()
+            args.node_devices = alias if alias else list(range(args.gpus))
+            if max(args.node_devices) >= have:
+                log("[bench] --gpus %d: only %d GPU(s) visible; name devices with --alias-devices to run the multi-GPU plumbing on fewer" % (args.gpus, have))
+                sys.exit(2)
+        elif args.workload != "jpeg4096":
+            log("[bench] --gpus N without torchrun drives the headline workload (jpeg4096) or the firehose; the other workloads run one rank per GPU under torchrun")
             sys.exit(2)
-        return spawn_ranks(args, alias) if args.ranks else main_node(args, alias)
+        if args.workload == "jpeg4096":
+            return spawn_ranks(args, alias) if args.ranks else main_node(args, alias)
 
     from lilliput_amd.dist import Ranks
 

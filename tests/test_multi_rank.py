@@ -209,3 +209,15 @@ def test_eight_device_slots_share_the_queue_fairly(tmp_path):
     per = line["config"]["per_device_last_step"]
     assert line["n_gpus"] == 8 and line["config"]["verified_identical"] and line["config"]["ok_images"] == 8 * 16 and len(per) == 8
     assert sum(d["images"] for d in per) == 128 and line["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_firehose_shards_over_device_slots_in_one_process(tmp_path):
+    """BASELINE configs[4] in node mode: `bench.py --workload firehose --gpus 2` not under torchrun = one process, one queue, two device
+    slots (the same GPU twice here); every format gated against the reference CPU path, both slots served items, no PyTorch."""
+    out, _ = _run_bench(tmp_path, "--workload", "firehose", "--gpus", "2", "--alias-devices", "0,0", "--batch", "48", "--distinct", "64", "--max-side", "1024",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--verify", "2")
+    line = json.loads(out.strip().splitlines()[-1])
+    nm = line["config"]["node_mode"]
+    assert line["n_gpus"] == 2 and line["config"]["verified_identical"] and nm["devices"] == [0, 0] and nm["aliased"] is True
+    assert sum(d["images"] for d in nm["per_device_last_step"]) > 0 and line["roofline"]["bound"] == "host"
