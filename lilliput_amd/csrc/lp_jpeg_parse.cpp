@@ -9,6 +9,8 @@
 
 #include <string.h>
 
+#include <memory>
+
 static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
@@ -561,7 +563,8 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
         // Most files of a stream carry the same tables (the Annex-K set of every encoder that does not optimise): the set built last on
         // this thread is kept with the DHT contents it was built from and copied when they come again (24 -> 9 us per header walk).
         struct Memo { bool valid = false; bool ok[2][2]; uint8_t bits[2][2][17]; uint8_t vals[2][2][256]; int ac_of_dc[2]; LpHuffSet set; };
-        static thread_local Memo* memo = new Memo(); // leaked at thread exit on purpose: 24 KB, and no destructor order to think about
+        static thread_local std::unique_ptr<Memo> memo_owner(new Memo()); // freed at thread exit (short-lived cgo threads would otherwise leave 24 KB each behind)
+        Memo* const memo = memo_owner.get();
         bool same = memo->valid && memo->ac_of_dc[0] == ac_of_dc[0] && memo->ac_of_dc[1] == ac_of_dc[1];
         for (int cls = 0; cls < 2 && same; cls++)
             for (int t = 0; t < 2 && same; t++)
@@ -578,6 +581,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
             for (int cls = 0; cls < 2; cls++)
                 for (int t = 0; t < 2; t++) {
                     memo->ok[cls][t] = h_ok[cls][t];
+                    if (!h_ok[cls][t]) continue; // (an absent table's bits / vals were never written: nothing to copy, nothing compared above)
                     memcpy(memo->bits[cls][t], hbits[cls][t], 17);
                     memcpy(memo->vals[cls][t], hvals[cls][t], 256);
                 }

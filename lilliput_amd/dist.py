@@ -77,8 +77,15 @@ def _rendezvous_dir():
     d = os.environ.get("LILLIPUT_BENCH_RDV")
     if d:
         return d
-    # under torchrun every worker has the same parent (the elastic agent): its pid + the master port name this run
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_rdv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    # under torchrun every worker has the same parent (the elastic agent): its pid, its START TIME (a recycled pid is not the same run:
+    # phase files a crashed earlier run left behind must not be read as this run's) and the master port name this run
+    ppid, born = os.getppid(), "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]   # field 22: starttime in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "lilliput_rdv_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), ppid, born))
 
 
 class Ranks:
@@ -94,6 +101,26 @@ class Ranks:
         # (backend "nccl": barrier, all-reduce of the elapsed time, all-gather of the counters) is the path a 1-GPU run takes too
         if self.world > 1 or (os.environ.get("RANK") is not None and os.environ.get("MASTER_ADDR")):
             backend = backend or "nccl"
+            if backend != "file" and self.world > 1:
+                # The choice between torch.distributed and the file rendezvous is made by ALL ranks together, before anybody enters
+                # init_process_group: a rank that cannot import torch (or sees no GPU for "nccl") would otherwise meet through files while
+                # the others wait for it in the process group until its timeout. Every rank says whether it can; one "no" sends all to files.
+                can = True
+                try:
+                    import torch
+
+                    can = backend != "nccl" or torch.cuda.is_available()
+                except Exception:
+                    can = False
+                pre = _FileGroup(self.rank, self.world, _rendezvous_dir() + "_pre")
+                votes = pre.all_gather(b"1" if can else b"0")
+                pre.close()
+                if any(v != b"1" for v in votes):
+                    import sys
+
+                    print("[lilliput_amd.dist] rank %d: backend %s is not available on every rank (%s): all ranks meet through files" % (
+                        self.rank, backend, "".join(v.decode() for v in votes)), file=sys.stderr, flush=True)
+                    backend = "file"
             if backend != "file":
                 try:
                     import torch

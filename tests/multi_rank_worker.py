@@ -15,8 +15,8 @@ from lilliput_amd.dist import Ranks, WorkQueue  # noqa: E402
 def main():
     out_dir, n_items = sys.argv[1], int(sys.argv[2])
     r = Ranks(backend=os.environ.get("LILLIPUT_BENCH_BACKEND", "gloo"))
-    if r.backend == "file":
-        assert "torch" not in sys.modules
+    if os.environ.get("LILLIPUT_BENCH_BACKEND") == "file":
+        assert r.backend == "file" and "torch" not in sys.modules
     mine = list(r.shard(n_items))
     # the "work": a digest per owned item (stands for one image through the device path)
     digests = {i: hashlib.sha256(b"item-%d" % i).hexdigest()[:8] for i in mine}
@@ -44,7 +44,7 @@ def main():
     epochs = epochs[0]
     queue_s = time.time() - t0
     with open(os.path.join(out_dir, "rank%d.json" % r.rank), "w") as f:
-        json.dump({"rank": r.rank, "world": r.world, "items": mine, "digests": digests, "elapsed": elapsed, "steps_run": len(calls), "total": total, "queue_done": done, "queue_epochs": epochs, "queue_s": queue_s}, f)
+        json.dump({"rank": r.rank, "world": r.world, "items": mine, "digests": digests, "elapsed": elapsed, "steps_run": len(calls), "total": total, "queue_done": done, "queue_epochs": epochs, "queue_s": queue_s, "backend": r.backend}, f)
     r.close()
 
 

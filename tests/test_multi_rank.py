@@ -57,6 +57,29 @@ def test_two_ranks_meet_through_files_without_pytorch(tmp_path):
     assert not os.path.exists(os.path.join(str(tmp_path), "rdv"))  # the last rank out removed the directory
 
 
+def test_ranks_agree_on_the_file_rendezvous_when_one_of_them_has_no_pytorch(tmp_path):
+    """Two ranks asked for a torch.distributed backend, one of them in an environment where `import torch` fails: the choice is made by
+    all ranks together BEFORE anybody enters init_process_group (round-5 advisor finding: it used to be made per rank, and the rank with
+    torch waited in the process group for the one that had gone to files until the 600 s timeout). Both end on the file backend."""
+    poison = os.path.join(str(tmp_path), "poison")
+    os.makedirs(poison, exist_ok=True)
+    with open(os.path.join(poison, "torch.py"), "w") as f:
+        f.write("raise ImportError('no torch here')\n")
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LILLIPUT_BENCH_BACKEND="gloo", LILLIPUT_BENCH_RDV=os.path.join(str(tmp_path), "rdv"),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        if r == 1:
+            env["PYTHONPATH"] = poison + os.pathsep + env.get("PYTHONPATH", "")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(tmp_path), "7"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()[-2000:]
+    res = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in (0, 1)]
+    assert [x["backend"] for x in res] == ["file", "file"]
+    assert sorted(res[0]["items"] + res[1]["items"]) == list(range(7)) and res[0]["elapsed"] == res[1]["elapsed"]
+
+
 def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     from lilliput_amd.dist import Ranks
