@@ -289,9 +289,12 @@ bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
     return true;
 }
 
-bool LpEngine::h2d_any(void* dst, const void* src, size_t bytes)
+bool LpEngine::h2d_any(void* dst, const void* src, size_t bytes, bool dst_has_slack)
 {
     if (!bytes) return true;
+    // dst_has_slack: the destination is a descriptor arena allocated with room behind the payload (ensure(... + 64)): the 16-byte
+    // groups of k_copy_small may spill up to 15 surplus bytes there, so an odd size need not take the synchronising route below
+    if (dst_has_slack && bytes <= (2u << 20) && ((uintptr_t)dst & 15u) == 0) return h2d_small(dst, src, bytes);
     // k_copy_small moves 16-byte groups: it needs a 16-byte aligned destination and writes the size rounded UP to 16 (the surplus bytes
     // are whatever the pinned ring held). Fine for the descriptor arenas it was written for; a destination that is a view with an odd
     // offset, or one sized to the byte, takes the copy engine instead.
@@ -1270,7 +1273,7 @@ int LpEngine::orient(const LpOrientOp* ops, int n)
     uint32_t mw = 0, mh = 0;
     double orient_bytes = 0;
     for (int i = 0; i < n; i++) { mw = std::max(mw, std::max(ops[i].src.w, ops[i].src.h)); mh = mw; orient_bytes += 2.0 * ops[i].src.w * ops[i].src.h * ops[i].src.cn; }
-    if (!h2d_any(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n)) return LP_ERR_DEVICE;
+    if (!h2d_any(d_ops_.p, ops, sizeof(LpOrientOp) * (size_t)n, true)) return LP_ERR_DEVICE;
     // the op array is pageable host memory: make sure the copy has been consumed before the caller frees it
     { LpStageProbe probe_(stream_, "k_orient", (double)(orient_bytes)); lp_launch_orient(stream_, d_ops_.as<LpOrientOp>(), (uint32_t)n, mw, mh, nullptr, nullptr); }
     if (!check(hipStreamSynchronize(stream_), "orient sync")) return LP_ERR_DEVICE;
@@ -1405,9 +1408,9 @@ int LpEngine::resize(const LpResizeReq* reqs, int n, LpFrame* dsts, int* status)
     }
     if (!d_ops_.ensure(sizeof(LpResizeOp) * (size_t)n + 64) || !d_taps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_ranges_.ensure(4 * ranges.size() + 64))
         return LP_ERR_DEVICE;
-    if (!h2d_any(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n)) return LP_ERR_DEVICE;
-    if (!taps.empty() && !h2d_any(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size())) return LP_ERR_DEVICE;
-    if (!ranges.empty() && !h2d_any(d_ranges_.p, ranges.data(), 4 * ranges.size())) return LP_ERR_DEVICE;
+    if (!h2d_any(d_ops_.p, ops.data(), sizeof(LpResizeOp) * (size_t)n, true)) return LP_ERR_DEVICE;
+    if (!taps.empty() && !h2d_any(d_taps_.p, taps.data(), sizeof(LpTap) * taps.size(), true)) return LP_ERR_DEVICE;
+    if (!ranges.empty() && !h2d_any(d_ranges_.p, ranges.data(), 4 * ranges.size(), true)) return LP_ERR_DEVICE;
     mark(5);
     {
         double rb = 0;

@@ -253,7 +253,7 @@ private:
     // Host -> device from memory that may be pageable, without the runtime's own pageable path (a staged, host-blocking copy behind a
     // process-wide lock: 0.6 ms per call with eight callers, HIP API trace of round 4): small blocks through the descriptor ring
     // (h2d_small), large ones through this engine's pinned transfer buffer. dst needs room for bytes rounded up to 16.
-    bool h2d_any(void* dst, const void* src, size_t bytes);
+    bool h2d_any(void* dst, const void* src, size_t bytes, bool dst_has_slack = false);
     // Device -> pinned transfer buffer (asynchronous); the bytes are at the returned host pointer once the stream has been waited for.
     const uint8_t* d2h_begin(const void* dev, size_t bytes, size_t slot_off = 0);
     void d2h_small(const LpPinned& pin, void* host, const void* dev, size_t bytes);
