@@ -926,6 +926,12 @@ struct LpPipeShared {
     std::unique_ptr<Share[]> share;     // [n_share]: share k = jobs [share[k].next, share[k].end)
     size_t n_share = 1;
     std::atomic<size_t> stolen{0};
+    // Fair first round: a stager claims its SECOND chunk only after every pipe of the call has claimed its first. Stagers run ahead of
+    // their compute threads, and the pipes' threads start tens of microseconds apart -- with as many chunks as engines (a call of
+    // latency-bound chunks: 128 progressive files of 4096 x 4096 as four chunks of 0.48 s each) one engine now and then took two chunks
+    // and another none: 0.98 s instead of 0.49 (profiles/r06_progressive.md).
+    std::atomic<size_t> first_claims{0};
+    size_t n_pipes = 0;
     double t0 = 0;
     void deal(size_t devices)
     {
@@ -983,7 +989,10 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
             pp.cv.wait(lk, [&] { return pp.abort || k < pp.done + LP_UPLOAD_SLOTS; }); // slot k % SLOTS: its previous chunk has been decoded
             if (pp.abort) break;
         }
+        if (k == 1) // (bounded: a pipe whose thread never starts must not hold the others)
+            for (int spin = 0; sh.first_claims.load() < sh.n_pipes && spin < 20000; spin++) std::this_thread::sleep_for(std::chrono::microseconds(5));
         const size_t ji = sh.claim((size_t)b->node_index);
+        if (k == 0) sh.first_claims.fetch_add(1);
         if (ji >= sh.jobs.size()) break;
         const double t0 = now();
         LpPipeJob& job = sh.jobs[ji];
@@ -1160,6 +1169,7 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         const LpSink sink{b, items};
         sh.t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         std::vector<std::thread> th;
+        sh.n_pipes = std::min(np * devs.size(), sh.jobs.size());
         // engines are started device by device in turn (engine 0 of every device, then engine 1 ...) so that a short queue spreads over the devices
         for (size_t p = 0; p < np; p++)
             for (LpBatch* d : devs) {
