@@ -240,7 +240,7 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
             "streams": 1 if excl else streams,
             "duration_source": "hip_events" if excl else "hip_events_pipelined",
             "duration_source_is": ("HIP events on the engine's stream around two exclusive launches of one resident chunk, measured live in this run (rocprofv3 --kernel-trace --stats of the "
-                                   "same launches: profiles/r05_kernel_stats.md)") if excl else
+                                   "same launches: profiles/r06_kernel_stats.md)") if excl else
                                   ("HIP events around the stages of the TIMED region, where %d engines share the GPU: a launch lasts 2-3x its exclusive duration, so achieved / frac are "
                                    "lower bounds (run without --no-extra-legs for the exclusive figure)" % streams),
             "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
