@@ -220,9 +220,9 @@ static size_t prog_pinned_max()
 
 // Header walk of one JPEG item + the batch's size bounds. Returns LILLIPUT_OK when the item goes to the device. *pinned accumulates the
 // host coefficient bytes of the set the item joins.
-static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinned)
+static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinned, int parsed_rc = -1000)
 {
-    const int rc = (src && len) ? lp_jpeg_parse((const uint8_t*)src, len, h) : LP_PARSE_NOT_JPEG;
+    const int rc = parsed_rc != -1000 ? parsed_rc : (src && len) ? lp_jpeg_parse((const uint8_t*)src, len, h) : LP_PARSE_NOT_JPEG; // (parsed_rc: the walk was done already, see pipe_stager)
     if (rc != LP_PARSE_OK) return map_parse(rc);
     if ((uint64_t)h->j.width * h->j.height > batch_max_pixels()) return LILLIPUT_ERR_BUF_TOO_SMALL;
     if (h->scan_path) {
@@ -1001,10 +1001,35 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
         const int slot = (int)(k % LP_UPLOAD_SLOTS);
         try {
             size_t pinned = 0;
+            // The header walks of a chunk whose files are expensive to walk (a progressive file's scans are found by reading through its
+            // entropy-coded bytes: ~0.1 ms per 1024 x 1024 file, 7 ms of a 64-file chunk's ingest) are spread over a few helpers; the walk of
+            // a baseline file ends at its first scan and is not worth a thread.
+            const size_t cnt = job.i1 - job.i0;
+            std::vector<LpJpegHeader> walked;
+            std::vector<int> walked_rc;
+            if (cnt >= 16 && lp_jpeg_sniff_progressive((const uint8_t*)items[job.i0].src, items[job.i0].src_len)) {
+                walked.resize(cnt);
+                walked_rc.assign(cnt, -1000);
+                static const size_t team = getenv("LILLIPUT_HIP_PARSE_THREADS") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_PARSE_THREADS"))) : 4;
+                const size_t nt = std::min(team, cnt / 8);
+                auto walk = [&](size_t t) {
+                    for (size_t q = cnt * t / nt; q < cnt * (t + 1) / nt; q++) {
+                        const lilliput_batch_item& it = items[job.i0 + q];
+                        if (is_other_format((const uint8_t*)it.src, it.src_len)) continue;
+                        walked_rc[q] = (it.src && it.src_len) ? lp_jpeg_parse((const uint8_t*)it.src, it.src_len, &walked[q]) : LP_PARSE_NOT_JPEG;
+                    }
+                };
+                std::vector<std::thread> helpers;
+                for (size_t t = 1; t < nt; t++) helpers.emplace_back(walk, t);
+                walk(0);
+                for (auto& h : helpers) h.join();
+            }
             for (size_t i = job.i0; i < job.i1; i++) {
                 if (is_other_format((const uint8_t*)items[i].src, items[i].src_len)) continue; // run_other's
-                job.hdrs.emplace_back();
-                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), &pinned);
+                const bool pre = !walked_rc.empty() && walked_rc[i - job.i0] != -1000;
+                if (pre) job.hdrs.emplace_back(std::move(walked[i - job.i0]));
+                else job.hdrs.emplace_back();
+                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), &pinned, pre ? walked_rc[i - job.i0] : -1000);
                 res->status[i] = st;
                 if (st != LILLIPUT_OK) { job.hdrs.pop_back(); continue; }
                 job.items.push_back((int)i);

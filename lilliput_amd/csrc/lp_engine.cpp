@@ -442,9 +442,15 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
                 LpUpload::ProgScanUp up;
                 up.s = sh.s;
                 up.level = lev[u.prog[(size_t)i].size()];
+                // (eight bytes a step: byte by byte this hash was 4.7 ms of a 64-file chunk's layout -- 640 tables of 7 KB)
                 uint64_t hash = 1469598103934665603ull;
-                const uint8_t* tb = reinterpret_cast<const uint8_t*>(&sh.tables);
-                for (size_t q = 0; q < sizeof(LpProgHuff); q++) hash = (hash ^ tb[q]) * 1099511628211ull;
+                static_assert(sizeof(LpProgHuff) % 8 == 0, "hashed in 64-bit words");
+                for (size_t q = 0; q < sizeof(LpProgHuff); q += 8) {
+                    uint64_t w;
+                    memcpy(&w, reinterpret_cast<const uint8_t*>(&sh.tables) + q, 8);
+                    hash = (hash ^ w) * 1099511628211ull;
+                    hash ^= hash >> 29;
+                }
                 uint32_t found = 0xffffffffu;
                 for (uint32_t cand : phuff_by_hash[hash])
                     if (memcmp(&u.phuffs[cand], &sh.tables, sizeof(LpProgHuff)) == 0) { found = cand; break; }
