@@ -164,7 +164,11 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def kernel_table(stage, images, c_in, c_out, size):
+PROG_STAGE = "k_prog_wave (all scans of a progressive file, one wave per scan, one pipelined launch) + k_dc_sum + k_dc_apply"
+SEQ_STAGE = "k_huff_write + k_dc_sum + k_dc_apply (entropy decode -> int8 coefficient blocks + DC)"
+
+
+def kernel_table(stage, images, c_in, c_out, size, progressive=False):
     """Per-kernel device ms per image and algorithmic GB/s from the summed HIP-event timings of `images` images:
     coefficient blocks are 64 x int8 + one int16 DC per block (1.5 x W x H bytes + 2 B per block), planes 1.5 x W x H."""
     px = size * size
@@ -173,7 +177,7 @@ def kernel_table(stage, images, c_in, c_out, size):
     return {
         "k_huff_spec (speculative entropy pass)": (stage.get("huff_spec_ms", 0.0), c_in),
         "k_huff_verify (verify rounds)": (stage.get("huff_verify_ms", 0.0), c_in),
-        "k_huff_write + k_dc_sum + k_dc_apply (entropy decode -> int8 coefficient blocks + DC)": (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
+        (PROG_STAGE if progressive else SEQ_STAGE): (stage.get("huff_write_ms", 0.0), c_in + coef_b + 3 * dc_b),
         "k_unstuff_* (FF00/RST removal)": (stage.get("unstuff_ms", 0.0), 3 * c_in),
         "k_idct": (stage.get("idct_ms", 0.0), coef_b + dc_b + plane_b),
         "k_ycc_to_frame": (stage.get("color_ms", 0.0), 0.0),
@@ -206,7 +210,7 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
     This is a property of the kernel; the same figure follows from the rocprofv3 kernel trace of
     `LILLIPUT_HIP_STREAMS=1 python bench.py --resident` committed under profiles/."""
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-    src_tab, src_n = (kernel_table(excl, excl["images"], c_in, c_out, args.size)[0], excl["images"]) if excl else (kernels, per_rank_images)
+    src_tab, src_n = (kernel_table(excl, excl["images"], c_in, c_out, args.size, args.source_sampling.endswith("p"))[0], excl["images"]) if excl else (kernels, per_rank_images)
     dom = max(src_tab.items(), key=lambda kv: kv[1][0])
     dom_ms, dom_bytes = dom[1]
     if dom_ms <= 0:
@@ -227,8 +231,11 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
             traffic_src = "%s is stale (kernel sources changed since it was measured)" % os.path.basename(cand[-1])
         else:
             keys = ["k_huff_write", "k_dc_sum", "k_dc_apply"] if dom[0].startswith("k_huff_write") else [dom[0].split(" ")[0]]
-            traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
-            traffic_src = os.path.basename(cand[-1])
+            if dom[0] == PROG_STAGE:
+                traffic_src = "no PMC pass of k_prog_wave kept (its coefficient planes are read and written once per refining scan: profiles/r06_progressive.md)"
+            else:
+                traffic = round(sum(pm[k]["hbm_bytes_per_image"] for k in keys) * launch_images)
+                traffic_src = os.path.basename(cand[-1])
     except Exception:
         traffic = None
     return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -243,7 +250,10 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
                                    "same launches: profiles/r06_kernel_stats.md)") if excl else
                                   ("HIP events around the stages of the TIMED region, where %d engines share the GPU: a launch lasts 2-3x its exclusive duration, so achieved / frac are "
                                    "lower bounds (run without --no-extra-legs for the exclusive figure)" % streams),
-            "note": "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
+            "note": ("progressive sources: the launch lasts as long as its longest dependency chain of scans (first scan -> refinements of the same band, "
+                     "each one wave, ~30 instructions per symbol issued by a lone wave: profiles/r06_progressive.md 3), whatever the number of files in "
+                     "it -- a latency bound; the HBM fraction is reported for the contract's sake") if dom[0] == PROG_STAGE else
+                    "exclusive launch durations (one engine / one stream, HIP events on that stream); with the default %d concurrent engines a "
                     "launch shares the GPU and lasts 2-3x longer while the batch finishes sooner. The entropy decoder is bound by instruction issue "
                     "(~47 vector instructions per Huffman symbol in this kernel), not by HBM (DESIGN.md 4.1)" % streams,
             "per_kernel_exclusive_us_per_image": {k.split(" ")[0]: round(v[0] * 1e3 / src_n, 2) for k, v in src_tab.items()} if excl else None,
@@ -1125,7 +1135,7 @@ def main():
         images = args.batch * world * args.steps
         value = images / elapsed
         per_rank_images = args.batch * args.steps
-        kernels, plane_b = kernel_table(stage, per_rank_images, c_in, c_out, args.size)
+        kernels, plane_b = kernel_table(stage, per_rank_images, c_in, c_out, args.size, args.source_sampling.endswith("p"))
         breakdown = {k: {"ms_per_image": round(v[0] / per_rank_images, 5), "algorithmic_GBps": round(v[1] * per_rank_images / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
                      for k, v in kernels.items()}
         roof = make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, breakdown)
@@ -1143,8 +1153,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU -> %dx%d JPEG q85, ImageOpsFit (%s)%s; sources in %s" % (
-                           args.batch, args.size, args.size, args.source_quality, args.out, args.out,
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d %s JPEGs per GPU -> %dx%d JPEG q85, ImageOpsFit (%s)%s; sources in %s" % (
+                           args.batch, args.size, args.size, args.source_quality, "progressive (SOF2, libjpeg's ten-scan script)" if args.source_sampling.endswith("p") else "baseline", args.out, args.out,
                            "BASELINE configs[1]" if (args.size, args.out, args.orientation, args.source_quality, args.source_sampling) == (4096, 256, 1, 90, "420") else "a variant of BASELINE configs[1]: --size %d --out %d --orientation %d --source-quality %d --source-sampling %s" % (args.size, args.out, args.orientation, args.source_quality, args.source_sampling),
                            "" if args.orientation == 1 else ", EXIF orientation %d" % args.orientation,
                            "HBM (resident form)" if args.resident else {"pinned": "a lilliput_hip_host_alloc pinned arena (zero-copy ingest)", "pageable": "pageable host memory (staged ingest)",

@@ -442,6 +442,7 @@ size_t lilliput_hip_stage_profile_read(char* out, size_t cap);
 int lilliput_hip_webp_yuv420(const opencv_mat src, uint8_t* y, uint8_t* u, uint8_t* v); /* test access: the planes the lossy WebP encoder is handed
                                                                                          * (w x h, then two of (w+1)/2 x (h+1)/2); 1 = translucent frame, -1 = error */
 int lilliput_hip_bmp_decode(const void* data, size_t len, int* w, int* h, int* channels, uint8_t* out, size_t cap); /* test access: 0 decoded, 1 header refused, 2 data refused, -1 cap */
+int lilliput_hip_pxm_decode(const void* data, size_t len, int* w, int* h, int* type, uint8_t* out, size_t cap);     /* the same for PBM / PGM / PPM (cv::PxMDecoder, opencv.cpp:99-171): *type = the decoder's Mat type, out = 8-bit pixels */
 long lilliput_hip_png_inflate_check(const void* data, size_t len);
 long lilliput_hip_png_inflate_bytes(const void* data, size_t len, uint8_t* out, size_t cap); /* test access: the filtered rows; -1 rejected, -2 cap too small */
 int lilliput_hip_png_set_inflater(int own);   /* test access / A-B: 1 = the library's one-shot inflater first (default), 0 = zlib only; returns the previous setting */

@@ -8,6 +8,7 @@
 #include "lp_engine.h"
 #include "lp_png.h"
 #include "lp_bmp.h"
+#include "lp_pxm.h"
 
 struct LpDevBlock {
     void* p = nullptr;
@@ -61,7 +62,9 @@ struct LpDecoder {
     size_t len = 0;
     bool is_png = false;            // which of cv::findDecoder's signatures matched
     bool is_bmp = false;
+    bool is_pxm = false;            // "P1" .. "P6": cv::PxMDecoder (lp_pxm.h)
     LpBmpInfo bmp;
+    LpPxmInfo pxm;
     bool parsed = false;
     int parse_rc = 0;
     LpJpegHeader hdr;

@@ -869,12 +869,14 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     const bool jpeg = len >= 3 && m->data[0] == 0xFF && m->data[1] == 0xD8 && m->data[2] == 0xFF;
     const bool png = len >= 8 && memcmp(m->data, png_sig, 8) == 0;
     const bool bmp = len >= 2 && m->data[0] == 'B' && m->data[1] == 'M'; // cv::BmpDecoder's signature: the two letters, nothing more
-    if (!jpeg && !png && !bmp) return NULL;
+    const bool pxm = lp_pxm_signature(m->data, len); // cv::PxMDecoder's: 'P', '1'..'6', a white-space character
+    if (!jpeg && !png && !bmp && !pxm) return NULL;
     auto d = new LpDecoder();
     d->data = m->data;
     d->len = len;
     d->is_png = png;
     d->is_bmp = bmp;
+    d->is_pxm = pxm;
     return d;
 }
 LP_ABI_CATCH("opencv_decoder_create", return nullptr)
@@ -883,7 +885,7 @@ const char* opencv_decoder_get_description(const opencv_decoder d)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (!d) return nullptr;
     auto p = static_cast<const LpDecoder*>(d);
-    return p->is_png ? "PNG" : p->is_bmp ? "BMP" : "JPEG";
+    return p->is_png ? "PNG" : p->is_bmp ? "BMP" : p->is_pxm ? "PXM" : "JPEG";
 }
 LP_ABI_CATCH("opencv_decoder_get_description", return nullptr)
 // LILLIPUT_HIP_DEFER_KEEP_SERVED=1: a chain that has been encoded once keeps a copy of its source at Close as well, so that a caller
@@ -923,6 +925,11 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<LpDecoder*>(dd);
     if (!d) return false;
     if (d->parsed) return d->parse_rc == LP_PARSE_OK;
+    if (d->is_pxm) { // cv::PxMDecoder::readHeader
+        d->parsed = true;
+        d->parse_rc = lp_pxm_read_info(d->data, d->len, d->pxm) ? LP_PARSE_OK : LP_PARSE_NOT_JPEG;
+        return d->parse_rc == LP_PARSE_OK;
+    }
     if (d->is_bmp) { // cv::BmpDecoder::readHeader
         d->parsed = true;
         d->parse_rc = lp_bmp_read_info(d->data, d->len, d->bmp) ? LP_PARSE_OK : LP_PARSE_NOT_JPEG;
@@ -948,13 +955,13 @@ LP_ABI_CATCH("opencv_decoder_read_header", return false)
 int opencv_decoder_get_width(const opencv_decoder dd)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png ? (int)d->png.width : d->is_bmp ? d->bmp.width : (int)d->hdr.j.width;
+    return d->is_png ? (int)d->png.width : d->is_bmp ? d->bmp.width : d->is_pxm ? d->pxm.width : (int)d->hdr.j.width;
 }
 LP_ABI_CATCH("opencv_decoder_get_width", return 0)
 int opencv_decoder_get_height(const opencv_decoder dd)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png ? (int)d->png.height : d->is_bmp ? d->bmp.height : (int)d->hdr.j.height;
+    return d->is_png ? (int)d->png.height : d->is_bmp ? d->bmp.height : d->is_pxm ? d->pxm.height : (int)d->hdr.j.height;
 }
 LP_ABI_CATCH("opencv_decoder_get_height", return 0)
 int opencv_decoder_get_pixel_type(const opencv_decoder dd)
@@ -962,13 +969,14 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
     if (d->is_png) return (d->png.depth == 16 ? 2 /* CV_16U */ : 0) + ((d->png_channels - 1) << 3); // the Go side demotes 16-bit types (opencv.go:255-257)
     if (d->is_bmp) return (d->bmp.channels - 1) << 3; // CV_8UC1 / C3 / C4
+    if (d->is_pxm) return ((d->pxm.channels - 1) << 3) | (d->pxm.maxval > 255 ? 2 : 0); // CV_8UC1 / CV_8UC3, CV_16UC1 / CV_16UC3 for samples above 255 (the Go layer demotes the depth)
     return d->hdr.j.ncomp == 1 ? CV_8UC1 : CV_8UC3;
 }
 LP_ABI_CATCH("opencv_decoder_get_pixel_type", return 0)
 int opencv_decoder_get_orientation(const opencv_decoder dd)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     auto d = static_cast<const LpDecoder*>(dd);
-    return d->is_png || d->is_bmp ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
+    return d->is_png || d->is_bmp || d->is_pxm ? 1 : (int)d->hdr.j.orientation; // a PNG's eXIf chunk is only looked at while the pixels are read, after lilliput has asked
 }
 LP_ABI_CATCH("opencv_decoder_get_orientation", return 0)
 
@@ -1020,6 +1028,16 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     if (d->parse_rc != LP_PARSE_OK) return false;
     m->lazy.reset(); // whatever the Mat was, it is this frame now
     if (d->is_png) return png_read_data(d, m);
+    if (d->is_pxm) { // cv::PxMDecoder::readData into the 8-bit Mat the Go layer hands over (lp_pxm.h)
+        const LpPxmInfo& pi = d->pxm;
+        if (m->rows != pi.height || m->cols != pi.width || cv_channels(m->type) != pi.channels || cv_depth_bytes(m->type) != 1 || !m->data) return false;
+        if (m->step < (size_t)pi.width * pi.channels) return false;
+        const bool ok = lp_pxm_read_data(d->data, d->len, pi, m->data, m->step);
+        m->dev_valid = false;
+        m->host_stale = false;
+        if (!ok) lp_set_error("PBM / PGM / PPM image data is damaged");
+        return ok;
+    }
     if (d->is_bmp) { // cv::BmpDecoder::readData: rows unpacked on the host, straight into the Mat (lp_bmp.h)
         const LpBmpInfo& bi = d->bmp;
         if (m->rows != bi.height || m->cols != bi.width || cv_channels(m->type) != bi.channels || cv_depth_bytes(m->type) != 1 || !m->data) return false;
@@ -1103,6 +1121,18 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return which ? lp_crc32(seed, (const uint8_t*)p, n) : lp_adler32(seed, (const uint8_t*)p, n);
 }
 LP_ABI_CATCH("lilliput_hip_checksum", return 0)
+
+// Test access (no device work): cv::PxMDecoder's answer for a file -- 0 decoded (w, h, the decoder's type, 8-bit pixels of its channels), 1 header
+// refused (or not its signature), 2 data refused (what was written before stays), -1 cap
+extern "C" int lilliput_hip_pxm_decode(const void* data, size_t len, int* w, int* h, int* type, uint8_t* out, size_t cap)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    LpPxmInfo pi;
+    if (!lp_pxm_read_info((const uint8_t*)data, len, pi)) return 1;
+    *w = pi.width; *h = pi.height; *type = ((pi.channels - 1) << 3) | (pi.maxval > 255 ? 2 : 0);
+    if ((size_t)pi.width * pi.height * pi.channels > cap) return -1;
+    return lp_pxm_read_data((const uint8_t*)data, len, pi, out, (size_t)pi.width * pi.channels) ? 0 : 2;
+}
+LP_ABI_CATCH("lilliput_hip_pxm_decode", return -1)
 
 // Test access (no device work): cv::BmpDecoder's answer for a file -- 0 decoded (w, h, channels, pixels), 1 header refused, 2 data refused, -1 cap
 extern "C" int lilliput_hip_bmp_decode(const void* data, size_t len, int* w, int* h, int* channels, uint8_t* out, size_t cap)

@@ -25,6 +25,7 @@
 #include "lp_ops_logic.h"
 #include "lp_abi_guard.h"
 #include "lp_jpeg_parse.h"
+#include "lp_pxm.h"
 #include "lp_prog_host.h"
 
 // One engine (= one compute stream + one copy stream + its arenas) per worker; a batch is split into contiguous parts, one per
@@ -205,6 +206,7 @@ static bool is_other_format(const uint8_t* sp, size_t len)
     return sp && ((len >= 6 && (memcmp(sp, "GIF87a", 6) == 0 || memcmp(sp, "GIF89a", 6) == 0)) || // lilliput.go:100-102 isGIF
                   (len >= 8 && memcmp(sp, png_sig, 8) == 0) ||
                   (len >= 2 && sp[0] == 'B' && sp[1] == 'M') || // what cv::findDecoder takes for a BMP: the OpenCV decoder's path (lp_bmp.h)
+                  lp_pxm_signature(sp, len) ||                   // ... and for PBM / PGM / PPM (lp_pxm.h)
                   (len >= 12 && memcmp(sp, "RIFF", 4) == 0 && memcmp(sp + 8, "WEBP", 4) == 0) || // isWebp, lilliput.go:104-115
                   (len >= sizeof(lilliput_hip_pixels_header) && memcmp(sp, LILLIPUT_HIP_PIXELS_MAGIC, 8) == 0)); // frames a host decoder handed over
 }

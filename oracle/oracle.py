@@ -94,6 +94,29 @@ def ref_bmp_decode(data):
     return None, r
 
 
+def ref_pxm():
+    """oracle/_ref/librefpxm.so: the reference's own cv::PxMDecoder (None when not built)."""
+    return _load("_ref/librefpxm.so")
+
+
+def ref_pxm_decode(data):
+    """cv::PxMDecoder on a "P1".."P6" file, the way opencv_decoder_read_header / _read_data drive it into the 8-bit Mat the Go layer
+    hands them (opencv.go:250-267): (pixels [h, w, channels], None, type) when it decodes, (None, 1, None) when readHeader refuses the
+    file, (pixels written before the failure, 2, type) when readData fails, (None, -1, type) beyond this wrapper's buffer."""
+    L = ref_pxm()
+    data = bytes(data)
+    w, h, t = C.c_int(), C.c_int(), C.c_int()
+    cap = 1 << 26
+    out = np.zeros(cap, dtype=np.uint8)
+    L.ref_pxm_decode.restype = C.c_int
+    L.ref_pxm_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    r = L.ref_pxm_decode(data, len(data), C.byref(w), C.byref(h), C.byref(t), out.ctypes.data, cap)
+    if r in (0, 2):
+        cn = (t.value >> 3) + 1
+        return out[: w.value * h.value * cn].reshape(h.value, w.value, cn).copy(), (None if r == 0 else 2), t.value
+    return None, r, (t.value if r == -1 else None)
+
+
 def ref_meta():
     """The reference's libjpeg-turbo / libpng metadata readers (ICC, cICP), or None when not built."""
     global _refmeta
@@ -781,6 +804,9 @@ def transform_any_frame(data, width, height, resize_method=FIT):
     if d[:2] == b"BM":
         px = ref_bmp_decode(d)[0] if ref_bmp() is not None else None
         return None if px is None else transform_static(px, 1, width, height, resize_method, False)
+    if len(d) >= 3 and d[:1] == b"P" and d[1:2] in b"123456" and d[2:3] in b" \t\n\v\f\r":  # cv::PxMDecoder::checkSignature
+        r = ref_pxm_decode(d) if ref_pxm() is not None else None
+        return None if r is None or r[1] is not None else transform_static(r[0], 1, width, height, resize_method, False)
     if d[:4] == b"RIFF" and d[8:12] == b"WEBP":
         fr = ref_webp_frames(d) if ref_webp() is not None else None
         return None if not fr or fr[0] is None else transform_static(fr[0][0], 1, width, height, resize_method, False)
