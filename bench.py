@@ -1050,7 +1050,8 @@ def main():
     sources = [arrays[(i + rank * 7) % len(arrays)] for i in range(args.batch)]
     c_in = sum(a.size for a in sources) / args.batch
     ndev = max(1, la.lib().lilliput_hip_device_count())
-    streams = int(os.environ.get("LILLIPUT_HIP_STREAMS", "4"))
+    # engines per GPU: the pipelined transform takes four, the resident form eight for a large set (lp_batch.cpp batch_streams)
+    streams = int(os.environ.get("LILLIPUT_HIP_STREAMS", "8" if args.resident and args.batch >= 512 else "4"))
     if alias:                       # (spawned ranks of --ranks --alias-devices: this rank's slot names its device)
         local_rank = alias[rank % len(alias)]
     elif world > ndev and ranks.backend == "nccl":
@@ -1194,6 +1195,7 @@ def main():
                                        "numa_node_of_ingest_threads": ingest["numa_node"]}
             if resident_ips:
                 out["config"]["resident_images_per_s"] = round(resident_ips, 2)
+                out["config"]["resident_engines_per_gpu"] = int(os.environ.get("LILLIPUT_HIP_STREAMS", "8" if args.batch >= 512 else "4"))
         if not args.no_cpu_baseline:  # rank 0 only, after the timed region (every rank has passed the closing barrier)
             try:
                 out["cpu_baseline"] = cpu_baseline(distinct[: min(32, len(distinct))], args.out, args.out, 85, what="%dx%d q%d -> %dx%d q85" % (args.size, args.size, args.source_quality, args.out, args.out))

@@ -293,10 +293,15 @@ LP_ABI_CATCH("lilliput_hip_batch_ingest_stats2", return)
 
 } // extern "C"
 
-static int batch_streams(int requested)
+// Engines a call is split over. resident_items > 0: the resident form (upload / run / download) with that many items -- a large set takes
+// eight engines, one launch each: 1 024 sources of 4096 x 4096 run at 21.1 k images/s as 8 x 128 against 19.5 k as 4 x (113 + 113 + 30)
+// (profiles/r06_resident.md: a launch pays for its slowest verify lane and its ramps once, whatever it holds, and the other engines'
+// kernels fill what a launch beyond one round of WRITE workgroups leaves idle). The pipelined transform keeps four: it is bound by the
+// link, and more engines cost it staging slots (12.1 k -> 10.7 k with eight).
+static int batch_streams(int requested, size_t resident_items = 0)
 {
     int n = requested;
-    if (n <= 0) { const char* e = getenv("LILLIPUT_HIP_STREAMS"); n = e ? atoi(e) : 4; }
+    if (n <= 0) { const char* e = getenv("LILLIPUT_HIP_STREAMS"); n = e ? atoi(e) : (resident_items >= 512 ? 8 : 4); }
     return std::max(1, std::min(8, n));
 }
 
@@ -323,7 +328,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     }
     for (auto& o : b->other) o.data = o.copy.data();
     // contiguous parts, one per worker; small batches stay on one stream
-    size_t np = (size_t)batch_streams(streams);
+    size_t np = (size_t)batch_streams(streams, valid.size());
     if (valid.size() < 2 * np) np = 1;
     if (!b->ensure_parts(np)) return LILLIPUT_ERR_DEVICE;
     for (auto& p : b->parts) { p.hdrs.clear(); p.items.clear(); }
@@ -713,7 +718,13 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
     size_t max_raw = 0;
     for (const LpJpegHeader& h : part.hdrs) max_raw = std::max(max_raw, (size_t)h.ecs_len);
     static const size_t round_env = getenv("LILLIPUT_HIP_RESIDENT_CHUNK") ? (size_t)atoi(getenv("LILLIPUT_HIP_RESIDENT_CHUNK")) : 0;
-    const size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, round_env ? round_env : eng.resident_round(max_raw));
+    size_t chunk = auto_chunk(opt, part.hdrs.data(), nv, round_env ? round_env : eng.resident_round(max_raw));
+    if (opt->chunk <= 0 && !round_env) {
+        // equal launches instead of full ones and a remainder; a part up to a quarter beyond the bound is one launch (round 6: the fixed
+        // cost of a launch -- the verify tail, the ramps -- outweighs a partly filled second round of WRITE workgroups)
+        if (nv <= chunk + chunk / 4) chunk = nv;
+        else { const size_t launches = (nv + chunk - 1) / chunk; chunk = (nv + launches - 1) / launches; }
+    }
     const LpSink sink{b, nullptr};
     eng.enable_timing(true);
     int rc = LILLIPUT_OK;
