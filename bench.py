@@ -191,13 +191,16 @@ def exclusive_leg(la, device, sources, args):
     """Exclusive kernel durations: ONE engine, one stream, two launches of one resident chunk, HIP events on that stream -- no other
     stream's kernels share the GPU with the launch being timed (what `rocprofv3 --kernel-trace --stats` reports for a single-stream run)."""
     b1 = la.Batch(device)
+    # one full round of WRITE workgroups (113 images of 4096 x 4096): the launch that shows the kernels by themselves. The resident form's
+    # engines launch 128 since round 6 -- alone on the GPU such a launch pays a nearly empty second round (WRITE 3 448 us against 2 263), which
+    # the other seven engines' kernels fill (profiles/r06_resident.md)
     round_images = args.chunk or b1.resident_round(max(len(x) for x in sources))
     nx = min(2 * round_images, len(sources))   # two launches of the resident chunk size
     if args.sub_bits:
         b1.set_subsequence(args.sub_bits, args.ckpt_bits)
     b1.upload(sources[:nx], dst_cap=256 << 10, streams=1)
-    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
-    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, args.chunk)
+    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, round_images)
+    b1.run(args.out, args.out, la.ImageOpsFit, False, 85, round_images)
     excl = b1.timings()
     excl["images"] = nx
     excl["launch_images"] = min(round_images, nx)

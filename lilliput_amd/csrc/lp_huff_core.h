@@ -41,6 +41,20 @@
 #endif
 // Inside a branch on a wave-uniform condition: keeps it a scalar branch. Without it the compiler folds the uniform test into the
 // per-lane condition that follows and evaluates both in every iteration (the ring top-up test ran every step instead of every second).
+// A/B switches of the decode steps (profiles/r06_write_stream.md)
+#ifndef LP_X_LAYOUT
+#define LP_X_LAYOUT 1   // rare paths out of line: the common step falls through instead of taking its branches (nothing for full launches,
+                        // 3-4 % of a one-image call, whose lone waves pay for every taken branch)
+#endif
+#ifndef LP_X_FLUSH2
+#define LP_X_FLUSH2 0   // the WRITE loop flushes every second step: a lane finishes at most one block between two flushes (a block is at least a DC
+                        // symbol and an end-of-block), so no lane ever waits for a flush -- no stalled() test in the step, no idle steps
+#endif
+#if LP_X_LAYOUT
+#define LP_RARE(x) __builtin_expect(!!(x), 0)
+#else
+#define LP_RARE(x) (x)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LP_KEEP_UNIFORM_BRANCH() asm volatile("")
 #else
@@ -257,7 +271,7 @@ struct LpLane {
     {
         const uint32_t sub = LP_E_SLICE(e1);
         uint32_t e = sub != 0xffu ? m.lut2((sub << LP_LUT2_BITS) | (top & ((1u << LP_LUT2_BITS) - 1u))) : 0u;
-        if (LP_E_BITS(e) == 0) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
+        if (LP_RARE(LP_E_BITS(e) == 0)) { // canonical search (T.81 F.2.2.3, jdhuff.c jpeg_huff_decode): corrupt prefix, or a table whose long codes overflow the pool
             uint32_t len = 17, sym = 0; // no code matches: jpeg_huff_decode reads on to the sentinel length 17, warns and fakes a zero
             for (uint32_t l = LP_LUT_BITS + 1; l <= 16; l++) {
                 const int32_t code = (int32_t)(top >> (16 - l));
@@ -299,7 +313,11 @@ struct LpLane {
         const uint32_t s = LP_E_SIZE(e);
         const uint32_t runx = lp_bfe(e, 9, 7);    // LP_E_RUNX: run, + 64 when the symbol ends the block. DC symbols are categories 0..15 (validated by the parser): run == 0
         r.val = 0;
+#ifdef LP_EXP_NOVAL
+        if (false) { // timing experiment: what does the value reconstruction cost?
+#else
         if (NEED_VAL) {
+#endif
             const uint32_t x = lp_bfe_w(pk, 32u - n, s);  // the s extra bits that follow the code (0 when s == 0)
             // HUFF_EXTEND: a first extra bit of 0 means negative: val = x - (2^s - 1). nm = 1 - 2^s; the first bit is set iff 2x + nm > 0
             const uint32_t nm = (0xffffffffu << s) + 1u;
@@ -440,7 +458,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     auto pre = [&] {
         pk = L.peek();
         near = m.any((int32_t)L.np <= nlim); // the subsequence ends here, or a restart boundary / the stream end is near
-        if (near) {
+        if (LP_RARE(near)) {
             LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.z == 0 && L.restart_check(pk)) nreset++; // also catches the padded end of the stream
             pk = L.peek();
@@ -448,7 +466,7 @@ LP_HD void lp_spec_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState e
     };
     // second half: a lane that has reached the end of its subsequence sets its results aside; then the decode, for every lane
     auto post = [&] {
-        if (near) {
+        if (LP_RARE(near)) {
             LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.pos() >= sub_end) {
                 ex = lp_lane_exit(L, nreset);
@@ -519,13 +537,13 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
     auto one_step = [&] { // same shape as a SPEC step, plus the look at the lane's next checkpoint
         uint32_t pk = L.peek();
         const bool near = m.any((int32_t)L.np <= nlim);
-        if (near) {
+        if (LP_RARE(near)) {
             LP_KEEP_UNIFORM_BRANCH();
             if (!done && L.z == 0 && L.restart_check(pk)) nreset++;
             pk = L.peek();
         }
         bool now_done = false;
-        if (m.any(ncp >= (int32_t)L.np)) { // some lane stands at or behind its next checkpoint (a finished lane's is out of reach)
+        if (LP_RARE(m.any(ncp >= (int32_t)L.np))) { // some lane stands at or behind its next checkpoint (a finished lane's is out of reach)
             LP_KEEP_UNIFORM_BRANCH();
             if (!done) {
                 while (ncp > (int32_t)L.np) { // checkpoints are strictly ordered until the lane that recorded them finished
@@ -547,7 +565,7 @@ LP_HD void lp_verify_pass(M& m, const LpImgCtx& ic, uint32_t sub_end, LpSubState
                 }
             }
         }
-        if (near || m.any(now_done)) {
+        if (LP_RARE(near || m.any(now_done))) {
             LP_KEEP_UNIFORM_BRANCH();
             if (!done && !now_done && L.pos() >= sub_end) {
                 ex = lp_lane_exit(L, nreset);
@@ -609,11 +627,11 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     bool live = true;
     auto one_step = [&] {
         uint32_t pk = L.peek();
-        const bool act = !done && !sink.stalled();
+        const bool act = LP_X_FLUSH2 ? !done : !done && !sink.stalled();
         bool go = act;
         // slow path: the lane is at / past the end of its subsequence or of the stream, near a restart boundary, or out of blocks
         // (a stalled lane may cast a vote too: it costs a pass through here and changes nothing)
-        if (m.any2((int32_t)L.np <= nlim, (int32_t)L.bc >= left_bc)) {
+        if (LP_RARE(m.any2((int32_t)L.np <= nlim, (int32_t)L.bc >= left_bc))) {
             LP_KEEP_UNIFORM_BRANCH();
             if (act) {
                 if (L.z == 0) { // DC predictors restart in k_dc_scan, by MCU index
@@ -651,6 +669,14 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
     };
     // groups of four steps: a ring top-up before the second and the fourth, a flush before the fourth (the order the one-step loop
     // with its tests of the iteration count had); whether anyone is still working is looked at once per group
+#if LP_X_FLUSH2
+    while (live) {
+        one_step();
+        one_step();
+        m.topup(L.pos());
+        sink.flush();
+    }
+#else
     while (live) {
         one_step();
         m.topup(L.pos());
@@ -660,6 +686,7 @@ LP_HD uint32_t lp_write_pass(M& m, const LpImgCtx& ic, LpSubState entry, uint32_
         sink.flush();
         one_step();
     }
+#endif
     sink.flush();
     sink.finish();
     *irregular = L.irregular != 0u;

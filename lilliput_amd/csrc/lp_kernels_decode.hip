@@ -15,7 +15,10 @@
 #include "lp_types.h"
 
 #define UNSTUFF_T 256
-#define UNSTUFF_CHUNK 4096 // bytes per workgroup, 16 per thread
+#define UNSTUFF_CHUNK 4096 // bytes per chunk (the unit of the count / scan / scatter bookkeeping), 16 per thread
+#ifndef LP_UNSTUFF_CPW
+#define LP_UNSTUFF_CPW 1   // chunks a workgroup of the count / scatter kernels walks (A/B: profiles/r06_write_stream.md)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // block-wide helpers (256 threads = 4 waves of 64)
@@ -80,20 +83,21 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __res
 {
     __shared__ uint32_t s_tmp[4];
     const LpJpeg& img = imgs[blockIdx.y];
-    if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
     const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
-    uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
-    UnstuffBytes u;
-    unstuff_load(raw, raw_end, pos0, u);
-    uint32_t K[4], R[4], err = 0;
-    if (blockIdx.x == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
-    else if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
-    else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
-    uint32_t ea, eb, ta, tb;
-    block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
-    if (threadIdx.x == 0) chunk_cnt[img.chunk_off + blockIdx.x] = make_uint2(ta, tb);
-    if (err) atomicOr(&states[blockIdx.y].error, err);
+    for (uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW; chunk < (blockIdx.x + 1u) * LP_UNSTUFF_CPW && chunk < img.nchunks; chunk++) { // workgroup-uniform
+        uint32_t pos0 = chunk * UNSTUFF_CHUNK + threadIdx.x * 16;
+        UnstuffBytes u;
+        unstuff_load(raw, raw_end, pos0, u);
+        uint32_t K[4], R[4], err = 0;
+        if (chunk == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
+        else if ((chunk + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
+        else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
+        uint32_t ea, eb, ta, tb;
+        block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
+        if (threadIdx.x == 0) chunk_cnt[img.chunk_off + chunk] = make_uint2(ta, tb);
+        if (err) atomicOr(&states[blockIdx.y].error, err);
+    }
 }
 
 // One workgroup per image: exclusive scan of the chunk counts (in place), totals -> state.
@@ -146,20 +150,21 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
     __shared__ uint32_t s_tmp[4];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[UNSTUFF_CHUNK + 16 + UNSTUFF_T]; // + one byte per lane where dropped bytes go
     const LpJpeg& img = imgs[blockIdx.y];
-    if (blockIdx.x >= img.nchunks) return;
     const uint8_t* raw = raw_arena + img.raw_off;
     const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
-    uint32_t pos0 = blockIdx.x * UNSTUFF_CHUNK + threadIdx.x * 16;
+    for (uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW; chunk < (blockIdx.x + 1u) * LP_UNSTUFF_CPW && chunk < img.nchunks; chunk++) { // workgroup-uniform
+    if (chunk != blockIdx.x * LP_UNSTUFF_CPW) __syncthreads(); // s_out changes hands
+    uint32_t pos0 = chunk * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
     unstuff_load(raw, raw_end, pos0, u);
     uint32_t K[4], R[4], err = 0;
-    if (blockIdx.x == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
-    else if ((blockIdx.x + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
+    if (chunk == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
+    else if ((chunk + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     const uint32_t rany = R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3; // disjoint bit positions: one popcount for the four words
     uint32_t ea, eb, ta, tb;
     block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
-    const uint2 base = chunk_cnt[img.chunk_off + blockIdx.x];
+    const uint2 base = chunk_cnt[img.chunk_off + chunk];
     const uint32_t a0 = base.x & ~3u;           // clean position of the first (maybe shared) word
     uint32_t cpos = base.x + ea;
     if (rany) { // restart markers: a handful per image
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
                 if (q >= lo && q < hi) ob[3u - k] = s_out[q];
             }
         }
+    }
     }
 }
 
@@ -569,6 +575,7 @@ struct DevSink {
     int16_t* dc16;          // this image's DC values, one per block (the DC rarely fits a byte): the WRITE pass stores the decoded
                             // DIFFERENCE, k_dc_scan turns the array into absolute values before k_idct reads it
     int32_t dcv;            // DC difference of the current block
+    int32_t qdc;            // LP_X_FLUSH2: ... of the queued block (the next block's DC may be decoded before the flush)
     uint32_t dq0, dq1, dq2, dq3; // this lane's 8 most recent DC differences, newest in the top half of dq3 (a lane's blocks are consecutive, so
                             // eight of them are one aligned 16-byte store; one 2-byte store per block cost a 32-byte write transaction
                             // each -- profiles/r01_e). A 128-bit shift register in VGPRs: it was 4 KB of LDS per workgroup.
@@ -586,7 +593,7 @@ struct DevSink {
 #ifdef LP_EXP_NOPUT
         asm volatile("" :: "v"(where), "v"(v)); return; // timing experiment: what do the coefficient stores cost?
 #endif
-        if (v < -127 || v > 127) { // rare: strong edges at fine quantisation
+        if (LP_RARE(v < -127 || v > 127)) { // rare: strong edges at fine quantisation
             const uint32_t nat = (((uint32_t)where / LP_SLOT_STRIDE) << 4) | (((uint32_t)where % LP_SLOT_STRIDE) & 15u);
             if (wslot == 0xffffffffu) wslot = atomicAdd(n_wide, 1u);
             // A settled decode hands out at most one slot per block. A pass over UNSETTLED exit states (the deferred chunk whose verify
@@ -602,7 +609,8 @@ struct DevSink {
     __device__ __forceinline__ void end_block(uint32_t bc, bool on)
     {
         qbc = on ? bc : qbc;
-        if (on && wslot != 0xffffffffu) { wide_id[blk0 + (bc >> 5) - 1u] = wslot; wslot = 0xffffffffu; } // rare
+        if (LP_X_FLUSH2) qdc = on ? dcv : qdc;
+        if (LP_RARE(on && wslot != 0xffffffffu)) { wide_id[blk0 + (bc >> 5) - 1u] = wslot; wslot = 0xffffffffu; } // rare
     }
     __device__ __forceinline__ bool stalled() const { return qbc != 0xffffffffu; }
     // Wave-cooperative: the lanes with a finished block put (block, lane) on a per-wave list; then four lanes move one block each --
@@ -624,7 +632,7 @@ struct DevSink {
             qlist[pos] = (qblk << 6) | lane;
             const uint32_t k = qblk & 7u;
             dq0 = (dq0 >> 16) | (dq1 << 16); dq1 = (dq1 >> 16) | (dq2 << 16); // four v_alignbit
-            dq2 = (dq2 >> 16) | (dq3 << 16); dq3 = (dq3 >> 16) | ((uint32_t)dcv << 16);
+            dq2 = (dq2 >> 16) | (dq3 << 16); dq3 = (dq3 >> 16) | ((uint32_t)(LP_X_FLUSH2 ? qdc : dcv) << 16);
             if (k == 7u) { // after the eighth block of an aligned group, element j holds block g0 + j
                 const uint32_t g0 = qblk - 7u;
                 if (g0 >= blk0) *reinterpret_cast<uint4*>(dc16 + g0) = make_uint4(dq0, dq1, dq2, dq3); // the whole group is this lane's
@@ -717,6 +725,7 @@ __global__ __launch_bounds__(HUFF_T) void k_huff_write(const LpJpeg* __restrict_
     sink.wide_cap = img.total_blocks;
     sink.dc16 = dc_arena + img.coef_off / 64;
     sink.dcv = 0;
+    sink.qdc = 0;
     sink.dq0 = sink.dq1 = sink.dq2 = sink.dq3 = 0;
     sink.blk0 = prefix.nblk;
     sink.last = 0xffffffffu;
@@ -1225,7 +1234,7 @@ void lp_launch_unstuff(hipStream_t s, const LpJpeg* d_imgs, uint32_t nimg, uint3
                        LpJpegState* d_states, uint32_t* d_clean, uint32_t* d_rst)
 {
     if (!nimg || !max_chunks) return;
-    dim3 g(max_chunks, nimg);
+    dim3 g((max_chunks + LP_UNSTUFF_CPW - 1) / LP_UNSTUFF_CPW, nimg);
     hipLaunchKernelGGL(k_unstuff_count, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, d_chunk_cnt, d_states);
     hipLaunchKernelGGL(k_unstuff_scan, dim3(nimg), dim3(256), 0, s, d_imgs, d_chunk_cnt, d_states, d_clean);
     hipLaunchKernelGGL(k_unstuff_scatter, g, dim3(UNSTUFF_T), 0, s, d_imgs, d_raw, (const uint2*)d_chunk_cnt, d_clean, d_rst, d_states);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-6 profile run on one MI355X: exclusive kernel statistics of the headline workload (rocprofv3 --kernel-trace --stats, one stream,
-# launches of 113 images), the SQ / TCC counter passes each in their own run (scripts/pmc_sq.sh), the summaries, then the default bench line.
+# launches of 113 images = one full round of WRITE workgroups), the SQ / TCC counter passes each in their own run (scripts/pmc_sq.sh), the summaries, then the default bench line.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; tag=${1:-r06_sq}
 bash $R/scripts/pmc_sq.sh $tag --batch 226 > $R/gpurun_out/${tag}_run.log 2>&1
 cd $R
