@@ -1,0 +1,11 @@
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=gpurun_out/r06_ingest_chunk; mkdir -p $O
+for rep in 1 2; do for q in 75 90; do for ch in 0 24 48 64 96 128; do
+    timeout 300 python bench.py --distinct 128 --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs --source-quality $q --chunk $ch > $O/c_${q}_${ch}_$rep.json 2> $O/c_${q}_${ch}_$rep.err
+    python - <<PY
+import json
+def v(p):
+    try: return json.loads(open(p).read().strip().splitlines()[-1])["value"]
+    except Exception as e: return -1
+print("q$q chunk %3s rep $rep: e2e %.1f" % ("$ch", v("$O/c_${q}_${ch}_$rep.json")))
+PY
+done; done; done
