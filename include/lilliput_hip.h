@@ -76,6 +76,9 @@ int opencv_type_convert_depth(int type, int depth);
 opencv_decoder opencv_decoder_create(const opencv_mat buf);
 const char* opencv_decoder_get_description(const opencv_decoder d);
 void opencv_decoder_release(opencv_decoder d);
+/* opencv.hpp:68: declared there, never defined or called by the reference. Here: the decoder chosen at create() now reads `buf`
+ * (cv::ImageDecoder::setSource: no signature check, header state forgotten); false for a NULL argument. */
+bool opencv_decoder_set_source(opencv_decoder d, const opencv_mat buf);
 bool opencv_decoder_read_header(opencv_decoder d);
 int opencv_decoder_get_width(const opencv_decoder d);
 int opencv_decoder_get_height(const opencv_decoder d);

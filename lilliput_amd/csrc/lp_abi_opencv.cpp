@@ -896,15 +896,9 @@ static bool keep_served_sources()
     static const bool on = [] { const char* e = getenv("LILLIPUT_HIP_DEFER_KEEP_SERVED"); return e && atoi(e) != 0; }();
     return on;
 }
-void opencv_decoder_release(opencv_decoder dd)
-try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
-    auto d = static_cast<LpDecoder*>(dd);
-    if (!d) return;
-    // Deferred chains still read this decoder's bytes, and after Close the caller may free or reuse its buffer (opencv.go:663-667).
-    // A chain that has NOT produced anything yet gets its own copy of the bytes. A chain that has been served -- ops.go's Transform:
-    // the framebuffers of the ImageOps still carry the record when the caller closes the decoder, and nothing will ever look at them
-    // again before the next DecodeTo replaces it -- just loses its source: copying 4 MB per request for nobody would cost more host
-    // time than the whole transform. Should somebody ask such a Mat for pixels after all, lp_mat_materialize fails loudly.
+// Deferred chains that still read `d`'s bytes when the decoder lets go of them (release, set_source): see opencv_decoder_release
+static void lp_decoder_detach_chains(LpDecoder* d)
+{
     for (auto& w : d->lazies)
         if (auto src = w.lock()) {
             if (src->p != d->data || !src->keep.empty()) continue;
@@ -915,6 +909,40 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
                 g_defer_stats[3]++;
             }
         }
+    d->lazies.clear();
+}
+// opencv.hpp:68 declares this entry and the reference never defines or calls it; it is here so that the header's every prototype
+// links. Meaning taken from cv::ImageDecoder::setSource(const Mat&): the decoder chosen at create() now reads `buf` -- no signature
+// check (OpenCV has none either: a buffer of another format fails at read_header), header state forgotten.
+bool opencv_decoder_set_source(opencv_decoder dd, const opencv_mat buf)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    auto d = static_cast<LpDecoder*>(dd);
+    auto m = static_cast<const LpMat*>(buf);
+    if (!d || !m || !m->data) return false;
+    lp_decoder_detach_chains(d);
+    d->data = m->data;
+    d->len = (size_t)m->cols * (size_t)m->rows * cv_elem_size(m->type);
+    d->parsed = false;
+    d->parse_rc = 0;
+    d->hdr = LpJpegHeader();
+    d->png = LpPngInfo();
+    d->bmp = LpBmpInfo();
+    d->pxm = LpPxmInfo();
+    d->png_channels = 0;
+    return true;
+}
+LP_ABI_CATCH("opencv_decoder_set_source", return false)
+
+void opencv_decoder_release(opencv_decoder dd)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    auto d = static_cast<LpDecoder*>(dd);
+    if (!d) return;
+    // Deferred chains still read this decoder's bytes, and after Close the caller may free or reuse its buffer (opencv.go:663-667).
+    // A chain that has NOT produced anything yet gets its own copy of the bytes. A chain that has been served -- ops.go's Transform:
+    // the framebuffers of the ImageOps still carry the record when the caller closes the decoder, and nothing will ever look at them
+    // again before the next DecodeTo replaces it -- just loses its source: copying 4 MB per request for nobody would cost more host
+    // time than the whole transform. Should somebody ask such a Mat for pixels after all, lp_mat_materialize fails loudly.
+    lp_decoder_detach_chains(d);
     delete d;
 }
 LP_ABI_CATCH("opencv_decoder_release", return)

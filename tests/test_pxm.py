@@ -147,6 +147,30 @@ def test_decoder_entry_points_on_pxm_files(hip_lib, oracle):
     L.opencv_mat_release(src)
 
 
+def test_set_source_points_the_decoder_at_another_buffer(hip_lib):
+    """opencv_decoder_set_source (opencv.hpp:68: declared, never defined by the reference): cv::ImageDecoder::setSource's meaning -- the
+    decoder chosen at create() reads the new buffer, no signature check, the header is read again. Host-decoded formats only: no device."""
+    L = _abi(hip_lib)
+    L.opencv_decoder_set_source.restype = C.c_bool
+    L.opencv_decoder_set_source.argtypes = [C.c_void_p, C.c_void_p]
+    a, b = pxm_cases.make_pxm(5, 31, 17, 255, seed=1), pxm_cases.make_pxm(6, 12, 9, 255, seed=2)
+    ba, bb = np.frombuffer(a, np.uint8).copy(), np.frombuffer(b, np.uint8).copy()
+    ma = L.opencv_mat_create_from_data(len(a), 1, 0, ba.ctypes.data_as(C.c_void_p), len(a))
+    mb = L.opencv_mat_create_from_data(len(b), 1, 0, bb.ctypes.data_as(C.c_void_p), len(b))
+    d = L.opencv_decoder_create(ma)
+    assert d and L.opencv_decoder_read_header(d) and (L.opencv_decoder_get_width(d), L.opencv_decoder_get_height(d)) == (31, 17)
+    assert L.opencv_decoder_set_source(d, mb)
+    assert L.opencv_decoder_read_header(d) and (L.opencv_decoder_get_width(d), L.opencv_decoder_get_height(d)) == (12, 9)
+    assert L.opencv_decoder_get_pixel_type(d) == 16
+    assert not L.opencv_decoder_set_source(d, None) and not L.opencv_decoder_set_source(None, mb)
+    jpeg = np.frombuffer(b"\xff\xd8\xff\xe0 not a pxm file", np.uint8).copy()
+    mj = L.opencv_mat_create_from_data(jpeg.size, 1, 0, jpeg.ctypes.data_as(C.c_void_p), jpeg.size)
+    assert L.opencv_decoder_set_source(d, mj) and not L.opencv_decoder_read_header(d)  # another format: fails at the header, like OpenCV
+    L.opencv_decoder_release(d)
+    for m in (ma, mb, mj):
+        L.opencv_mat_release(m)
+
+
 @pytest.mark.gpu
 def test_pxm_sources_through_transform(hip_lib, oracle):
     """PPM / PGM / PBM -> ImageOps.Transform -> JPEG on the device path, one image at a time and as items of a batch, against the
