@@ -17,7 +17,9 @@
 #define UNSTUFF_T 256
 #define UNSTUFF_CHUNK 4096 // bytes per chunk (the unit of the count / scan / scatter bookkeeping), 16 per thread
 #ifndef LP_UNSTUFF_CPW
-#define LP_UNSTUFF_CPW 1   // chunks a workgroup of the count / scatter kernels walks (A/B: profiles/r06_write_stream.md)
+#define LP_UNSTUFF_CPW 2   // chunks a workgroup of the count / scatter kernels walks: all of them are requested before the first is looked at, and
+                           // the barriers in between wait for LDS only (lds_barrier) -- 3.85 -> 3.25 us per 4096 x 4096 image with 2 / 3 / 4, 3.7 with 8;
+                           // walking them one after the other behind __syncthreads() gained nothing (profiles/r06_write_stream.md section 3)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -33,8 +35,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
+// A workgroup barrier for data exchanged through LDS only: __syncthreads() also waits for the wave's outstanding global loads (vmcnt(0) on
+// gfx9), which is exactly what the unstuff kernels' prefetch of the next chunks must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exclusive scan of a pair of small counts (a <= 16, b <= 8 per thread: the block totals fit 16 bits each), packed into one word so
 // that the wave scan's cross-lane steps are paid once
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t& ea, uint32_t& eb, uint32_t& ta, uint32_t& tb,
                                                  uint32_t* s_tmp /* >= 4 words */)
 {
@@ -42,7 +49,7 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_
     const uint32_t v = a | (b << 16);
     const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) s_tmp[wv] = inc;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     uint32_t o = 0, t = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -53,7 +60,7 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_
     const uint32_t e = o + inc - v;
     ea = e & 0xffffu; eb = e >> 16;
     ta = t & 0xffffu; tb = t >> 16;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -63,6 +70,27 @@ struct UnstuffBytes {
     uint32_t w[4];      // 16 raw bytes
     uint32_t prev, next; // neighbours
 };
+
+// The same in two halves, for kernels that request several chunks before they look at the first (LP_UNSTUFF_CPW > 1): the loads ...
+struct UnstuffRaw { uint4 v; uint32_t ep, en; };
+__device__ __forceinline__ void unstuff_request(const uint8_t* raw, uint32_t raw_len, uint32_t pos0, UnstuffRaw& r)
+{
+    r.v = *reinterpret_cast<const uint4*>(raw + pos0);
+    const uint32_t lane = threadIdx.x & 63u;
+    r.ep = 0u; r.en = 0xD9u;
+    if (lane == 0u && pos0) r.ep = raw[pos0 - 1u];
+    if (lane == 63u && pos0 + 16u < raw_len) r.en = raw[pos0 + 16u];
+}
+// ... and the neighbours' edge bytes by lane shuffle, once the data is needed
+__device__ __forceinline__ void unstuff_finish(const UnstuffRaw& r, UnstuffBytes& u)
+{
+    u.w[0] = r.v.x; u.w[1] = r.v.y; u.w[2] = r.v.z; u.w[3] = r.v.w;
+    const uint32_t lane = threadIdx.x & 63u;
+    u.prev = __shfl_up(r.v.w >> 24, 1, 64);
+    u.next = __shfl_down(r.v.x & 0xFFu, 1, 64);
+    if (lane == 0u) u.prev = r.ep;
+    if (lane == 63u) u.next = r.en;
+}
 
 __device__ __forceinline__ void unstuff_load(const uint8_t* raw, uint32_t raw_len, uint32_t pos0, UnstuffBytes& u)
 {
@@ -85,16 +113,25 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(const LpJpeg* __res
     const LpJpeg& img = imgs[blockIdx.y];
     const uint8_t* raw = raw_arena + img.raw_off;
     const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
-    for (uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW; chunk < (blockIdx.x + 1u) * LP_UNSTUFF_CPW && chunk < img.nchunks; chunk++) { // workgroup-uniform
+    UnstuffRaw rq[LP_UNSTUFF_CPW];
+#pragma unroll
+    for (uint32_t c = 0; c < LP_UNSTUFF_CPW; c++) { // every chunk of the workgroup is requested before the first is looked at
+        const uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW + c;
+        if (chunk < img.nchunks) unstuff_request(raw, raw_end, chunk * UNSTUFF_CHUNK + threadIdx.x * 16, rq[c]);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < LP_UNSTUFF_CPW; c++) {
+        const uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW + c;
+        if (chunk >= img.nchunks) break; // workgroup-uniform
         uint32_t pos0 = chunk * UNSTUFF_CHUNK + threadIdx.x * 16;
         UnstuffBytes u;
-        unstuff_load(raw, raw_end, pos0, u);
+        unstuff_finish(rq[c], u);
         uint32_t K[4], R[4], err = 0;
         if (chunk == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
         else if ((chunk + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
         else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
         uint32_t ea, eb, ta, tb;
-        block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
+        block_excl_scan2<(LP_UNSTUFF_CPW > 1)>(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3), ea, eb, ta, tb, s_tmp);
         if (threadIdx.x == 0) chunk_cnt[img.chunk_off + chunk] = make_uint2(ta, tb);
         if (err) atomicOr(&states[blockIdx.y].error, err);
     }
@@ -152,19 +189,29 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
     const LpJpeg& img = imgs[blockIdx.y];
     const uint8_t* raw = raw_arena + img.raw_off;
     const uint32_t raw_end = img.raw_skip + img.raw_len; // positions count from raw_off; the first raw_skip bytes are not the segment's
-    for (uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW; chunk < (blockIdx.x + 1u) * LP_UNSTUFF_CPW && chunk < img.nchunks; chunk++) { // workgroup-uniform
-    if (chunk != blockIdx.x * LP_UNSTUFF_CPW) __syncthreads(); // s_out changes hands
+    UnstuffRaw rq[LP_UNSTUFF_CPW];
+    uint2 bases[LP_UNSTUFF_CPW];
+#pragma unroll
+    for (uint32_t c = 0; c < LP_UNSTUFF_CPW; c++) { // every chunk of the workgroup is requested before the first is looked at
+        const uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW + c;
+        if (chunk < img.nchunks) { unstuff_request(raw, raw_end, chunk * UNSTUFF_CHUNK + threadIdx.x * 16, rq[c]); bases[c] = chunk_cnt[img.chunk_off + chunk]; }
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < LP_UNSTUFF_CPW; c++) {
+    const uint32_t chunk = blockIdx.x * LP_UNSTUFF_CPW + c;
+    if (chunk >= img.nchunks) break; // workgroup-uniform
+    if (c) { if (LP_UNSTUFF_CPW > 1) lds_barrier(); else __syncthreads(); } // s_out changes hands
     uint32_t pos0 = chunk * UNSTUFF_CHUNK + threadIdx.x * 16;
     UnstuffBytes u;
-    unstuff_load(raw, raw_end, pos0, u);
+    unstuff_finish(rq[c], u);
     uint32_t K[4], R[4], err = 0;
     if (chunk == 0 && img.raw_skip) lp_unstuff_classify_masks<true, true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err, threadIdx.x == 0 ? img.raw_skip : 0u); // workgroup-uniform
     else if ((chunk + 1u) * UNSTUFF_CHUNK < raw_end) lp_unstuff_classify_masks<false>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     else lp_unstuff_classify_masks<true>(u.w, u.prev, u.next, pos0, raw_end, K, R, err);
     const uint32_t rany = R[0] | R[1] >> 1 | R[2] >> 2 | R[3] >> 3; // disjoint bit positions: one popcount for the four words
     uint32_t ea, eb, ta, tb;
-    block_excl_scan2(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
-    const uint2 base = chunk_cnt[img.chunk_off + chunk];
+    block_excl_scan2<(LP_UNSTUFF_CPW > 1)>(__popc(K[0]) + __popc(K[1]) + __popc(K[2]) + __popc(K[3]), __popc(rany), ea, eb, ta, tb, s_tmp);
+    const uint2 base = bases[c];
     const uint32_t a0 = base.x & ~3u;           // clean position of the first (maybe shared) word
     uint32_t cpos = base.x + ea;
     if (rany) { // restart markers: a handful per image
@@ -190,7 +237,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_scatter(const LpJpeg* __r
         s_out[kept ? l : dump] = (uint8_t)(u.w[j >> 2] >> (8 * (j & 3)));
         l += kept;
     }
-    __syncthreads();
+    if (LP_UNSTUFF_CPW > 1) lds_barrier(); else __syncthreads();
     const uint32_t lo = base.x - a0, hi = lo + ta;  // owned clean positions relative to a0: [lo, hi)
     const uint32_t cap = img.clean_cap_words;
     uint32_t* out = clean_arena + img.clean_off + (a0 >> 2);
