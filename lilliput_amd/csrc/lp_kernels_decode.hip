@@ -817,16 +817,27 @@ template <bool WRITE>
 __device__ __forceinline__ DcSeg dc_walk_range(int16_t* dc, uint32_t m0, uint32_t m1, uint32_t bpm, uint32_t dri, uint32_t comps, DcSeg carry)
 {
     const uint32_t lane = threadIdx.x & 63;
+    // the next step's DC differences are requested before this step's scan (a range is a handful of steps, each a load latency and a
+    // dozen cross-lane hops: the kernel is all latency)
+    int32_t nx[LP_MAX_BPM];
+    auto request = [&](uint32_t mb) {
+        const uint32_t m = mb + lane;
+#pragma unroll
+        for (uint32_t b = 0; b < LP_MAX_BPM; b++) nx[b] = (m < m1 && b < bpm) ? (int32_t)dc[(size_t)m * bpm + b] : 0;
+    };
+    if (m0 < m1) request(m0);
     for (uint32_t mb = m0; mb < m1; mb += 64) {
         const uint32_t m = mb + lane;
         const bool ok = m < m1;
         int32_t df[LP_MAX_BPM];
+#pragma unroll
+        for (uint32_t b = 0; b < LP_MAX_BPM; b++) df[b] = nx[b];
+        if (mb + 64 < m1) request(mb + 64);
         DcSeg mine;
         mine.v[0] = mine.v[1] = mine.v[2] = 0;
         mine.f = ok && dri && m % dri == 0;
 #pragma unroll
         for (uint32_t b = 0; b < LP_MAX_BPM; b++) {
-            df[b] = (ok && b < bpm) ? (int32_t)dc[(size_t)m * bpm + b] : 0;
             const uint32_t c = (comps >> (2 * b)) & 3u; // uniform
             mine.v[0] += c == 0 ? df[b] : 0; mine.v[1] += c == 1 ? df[b] : 0; mine.v[2] += c == 2 ? df[b] : 0;
         }
