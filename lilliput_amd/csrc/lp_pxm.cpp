@@ -80,6 +80,7 @@ bool lp_pxm_read_info(const uint8_t* d, size_t n, LpPxmInfo& info)
 bool lp_pxm_read_data(const uint8_t* d, size_t n, const LpPxmInfo& info, uint8_t* out, size_t step)
 {
     const bool wide = info.maxval > 255;                          // the decoder's 16-bit types: the 8-bit Mat gets the upper byte
+    if ((long long)info.width * info.channels > INT_MAX / 2) return false; // (no caller has a Mat with such rows; keeps the int arithmetic below honest)
     const int w = info.width, nch = info.channels, width3 = w * nch;
     Stream s{d, n, (size_t)info.offset};
     uint8_t lut[256];
