@@ -333,3 +333,29 @@ def test_transform_one_from_many_threads_shares_launches_and_keeps_the_bytes(hip
     ops.Close()
     with pytest.raises(la.LilliputError):
         la.transform_one(b"\xff\xd8\xff\xe0 not a jpeg", 50, 50)
+
+
+def test_resident_form_upload_run_download(hip_lib, small_set):
+    """The resident form (lilliput_hip_batch_upload / _run / _download: compressed bytes in HBM, what bench.py --resident times): a set of
+    600 items takes eight engines since round 6 (lp_batch.cpp batch_streams) and every part is cut into equal launches; one engine with an
+    explicit launch size, and the default, must both hand back the reference's bytes for every item (a truncated file, which the reference's decoder refuses, among them)."""
+    import lilliput_amd as la
+
+    datas, exp = small_set
+    n = 600
+    srcs = [datas[i % len(datas)] for i in range(n)]
+    want = [exp[i % len(datas)] for i in range(n)]
+    srcs[17] = datas[3][: len(datas[3]) // 2]          # runs out of bytes: the reference's decoder fails
+    want[17] = None
+    b = la.Batch(0)
+    for streams, chunk in ((0, 0), (1, 37), (3, 0)):
+        b.upload(srcs, dst_cap=64 << 10, streams=streams)
+        b.run(64, 64, la.ImageOpsFit, False, 85, chunk)
+        res = b.download()
+        assert len(res) == n
+        for i, (r, w) in enumerate(zip(res, want)):
+            if w is None:
+                assert r.status != 0, i
+            else:
+                assert r.status == 0 and r.data == w, (streams, chunk, i)
+    b.close()
