@@ -16,7 +16,7 @@ for i, l in enumerate(body):
             best = span
 loop = body[best[0]:best[1] + 1]
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_fma_f32",
-        "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32"}
+        "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_lshrrev_b32", "v_ashrrev_i32"}
 cnt = collections.Counter()
 for l in loop:
     t = l.strip().split()
