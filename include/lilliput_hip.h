@@ -484,6 +484,11 @@ int lilliput_hip_mat_sync_host(opencv_mat mat);   /* 0 = host pixels are current
  * at decoder release -- process-wide counters since start. */
 void lilliput_hip_set_deferred(int on);
 void lilliput_hip_deferred_stats(uint64_t out[4]);
+/* A recorded chain that reaches opencv_encoder_write while no other is being served (one goroutine, a quiet moment) runs on the caller's
+ * own thread through the one-image route -- the Mat then holds real pixels on the device, like the reference's framebuffer -- instead of
+ * travelling to a dispatcher thread as a batch of one (round 6; on by default, LILLIPUT_HIP_DEFER_INLINE=0 or ...(0): always the batched
+ * path). Returns the previous setting. */
+int lilliput_hip_set_deferred_inline(int on);
 
 /* Progressive (SOF2) JPEG sources (libjpeg-turbo jdphuff.c behind opencv_decoder_read_data, opencv.cpp:166-171): where the scans' entropy
  * decode runs. mode -1 = auto (default): on the device -- one wave per scan, lilliput_amd/csrc/lp_kernels_prog.hip -- for the progressive

@@ -404,6 +404,19 @@ static bool defer_on()
     return g != 0;
 }
 extern "C" void lilliput_hip_set_deferred(int on) { __atomic_store_n(&g_defer, on ? 1 : 0, __ATOMIC_RELAXED); }
+// A recorded chain that finds no other being served runs on the caller's thread (opencv_encoder_write); 0 = always the batched path
+static int g_defer_inline = -1;
+static bool defer_inline_on()
+{
+    int g = __atomic_load_n(&g_defer_inline, __ATOMIC_RELAXED);
+    if (g < 0) {
+        const char* e = getenv("LILLIPUT_HIP_DEFER_INLINE");
+        g = !(e && atoi(e) == 0 && e[0] != '\0');
+        __atomic_store_n(&g_defer_inline, g, __ATOMIC_RELAXED);
+    }
+    return g != 0;
+}
+extern "C" int lilliput_hip_set_deferred_inline(int on) { const int prev = defer_inline_on() ? 1 : 0; __atomic_store_n(&g_defer_inline, on ? 1 : 0, __ATOMIC_RELAXED); return prev; }
 static std::atomic<uint64_t> g_defer_stats[4]; // chains recorded, served by the batched path, materialised, sources copied at decoder release
 extern "C" void lilliput_hip_deferred_stats(uint64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = g_defer_stats[i].load(); }
 
@@ -1205,7 +1218,14 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     }
     LpMat* d = e->dst;
     const size_t cap = (size_t)(d->datalimit - d->datastart);
-    if (s->lazy && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
+    // A recorded chain that arrives while no other is being served (one goroutine, or a quiet moment) runs on the caller's own thread
+    // through the one-image route below -- no hand-over to a dispatcher thread and back, no stager / compute thread pair for a batch of
+    // one (round 6: 0.92 -> 0.7x ms for a 512 x 512 source, profiles/r06_one_image.md). LILLIPUT_HIP_DEFER_INLINE=0: always the batched path.
+    static std::atomic<int> parta_active{0};
+    const bool inline_lone = defer_inline_on();
+    struct ActiveScope { std::atomic<int>& a; int before; explicit ActiveScope(std::atomic<int>& x) : a(x), before(x.fetch_add(1, std::memory_order_relaxed)) {} ~ActiveScope() { a.fetch_sub(1, std::memory_order_relaxed); } } active(parta_active);
+    const bool lone = inline_lone && active.before == 0;
+    if (s->lazy && !lone && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
         lilliput_batch_options bo;
         if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {
             size_t n = 0;

@@ -800,15 +800,38 @@ def test_served_chain_after_decoder_close_fails_without_a_crash(hip_lib, oracle,
         L.opencv_mat_release(C.c_void_p(dm))
         return ok, n
 
-    ok, n = encode()
-    assert ok and bytes(out[:n]) == oracle.jpeg_encode(oracle.jpeg_decode(data), 85)
-    L.opencv_decoder_release(C.c_void_p(d))
-    src[:] = 0
-    ok2, _ = encode()          # the chain was served and its decoder is gone: a loud false, never a crash
-    assert not ok2
-    L.opencv_mat_get_data(C.c_void_p(m))   # whatever the accessor answers, it must not crash either
-    L.opencv_mat_release(C.c_void_p(m))
-    L.opencv_mat_release(C.c_void_p(buf))
+    want = oracle.jpeg_encode(oracle.jpeg_decode(data), 85)
+    L.lilliput_hip_set_deferred_inline.restype = C.c_int
+    prev = L.lilliput_hip_set_deferred_inline(C.c_int(0))   # this chain through the batched path, whatever else is in flight
+    try:
+        ok, n = encode()
+        assert ok and bytes(out[:n]) == want
+        L.opencv_decoder_release(C.c_void_p(d))
+        src[:] = 0
+        ok2, _ = encode()          # the chain was served and its decoder is gone: a loud false, never a crash
+        assert not ok2
+        L.opencv_mat_get_data(C.c_void_p(m))   # whatever the accessor answers, it must not crash either
+        L.opencv_mat_release(C.c_void_p(m))
+        L.opencv_mat_release(C.c_void_p(buf))
+        # the default since round 6: a lone chain runs on the caller's thread and leaves real pixels in the Mat -- encoding it again after the
+        # decoder is gone (and the source bytes with it) works, as it does with the reference's framebuffer
+        L.lilliput_hip_set_deferred_inline(C.c_int(1))
+        src[:] = np.frombuffer(bytearray(data), dtype=np.uint8)
+        buf = L.opencv_mat_create_from_data(C.c_int(src.size), C.c_int(1), C.c_int(0), C.c_void_p(src.ctypes.data), C.c_size_t(src.size))
+        d = L.opencv_decoder_create(C.c_void_p(buf))
+        assert L.opencv_decoder_read_header(C.c_void_p(d))
+        m = L.opencv_mat_create_from_data(C.c_int(w), C.c_int(h), C.c_int(16), C.c_void_p(fb.ctypes.data), C.c_size_t(fb.size))
+        assert L.opencv_decoder_read_data(C.c_void_p(d), C.c_void_p(m))
+        ok, n = encode()
+        assert ok and bytes(out[:n]) == want
+        L.opencv_decoder_release(C.c_void_p(d))
+        src[:] = 0
+        ok2, n2 = encode()
+        assert ok2 and bytes(out[:n2]) == want
+        L.opencv_mat_release(C.c_void_p(m))
+        L.opencv_mat_release(C.c_void_p(buf))
+    finally:
+        L.lilliput_hip_set_deferred_inline(C.c_int(prev))
 
 
 @pytest.mark.gpu
@@ -848,8 +871,9 @@ def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
         img.save(b, "JPEG", quality=int(rng.integers(60, 96)), subsampling=int(rng.choice([0, 1, 2])) if img.mode != "L" else -1)
         return b.getvalue(), w, h, (1 if img.mode == "L" else 3)
 
-    def run(data, w, h, cn, steps, ending, deferred):
+    def run(data, w, h, cn, steps, ending, deferred, inline=1):
         L.lilliput_hip_set_deferred(1 if deferred else 0)
+        L.lilliput_hip_set_deferred_inline(C.c_int(inline))  # a lone recorded chain on the caller's thread (round 6) or through the batched path
         keep = []
         try:
             src = np.frombuffer(bytearray(data), dtype=np.uint8).copy()
@@ -908,6 +932,7 @@ def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
             return out
         finally:
             L.lilliput_hip_set_deferred(1)
+            L.lilliput_hip_set_deferred_inline(C.c_int(1))
 
     bad, answered = [], 0
     st0 = (C.c_uint64 * 4)()
@@ -929,7 +954,7 @@ def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
         ending = ("jpeg", "jpeg", "pixels", "png")[k % 4]
         if ending == "pixels" and any(st[0] == "crop" for st in steps) and not (steps and steps[-1][0] == "resize"):
             ending = "jpeg"  # a crop is a view with its parent's row pitch: Go only ever hands it to the resize or an encoder
-        a = run(data, w, h, cn, steps, ending, True)
+        a = run(data, w, h, cn, steps, ending, True, inline=k % 2)   # this test is one caller: every chain is "lone"; both ways of serving it are held to the eager run
         b = run(data, w, h, cn, steps, ending, False)
         if a[:3] != b[:3] or (a[3] is None) != (b[3] is None):
             bad.append((k, steps, ending, a[:3], b[:3], a[3] is None, b[3] is None))
@@ -950,4 +975,4 @@ def test_part_a_random_call_sequences_deferred_against_eager(hip_lib, oracle):
     assert not bad, bad[:5]
     st1 = (C.c_uint64 * 4)()
     L.lilliput_hip_deferred_stats(st1)
-    assert answered > 380 and st1[0] - st0[0] >= 400 and st1[1] - st0[1] > 40 and st1[2] - st0[2] > 100, (answered, list(st0), list(st1))  # chains recorded, served by the batched path, run the eager way after all
+    assert answered > 380 and st1[0] - st0[0] >= 400 and st1[1] - st0[1] > 20 and st1[2] - st0[2] > 100, (answered, list(st0), list(st1))  # chains recorded, served by the batched path, run the eager way after all
