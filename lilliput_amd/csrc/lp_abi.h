@@ -1,5 +1,6 @@
 // lp_abi.h -- internal types behind the opaque handles of include/lilliput_hip.h.
 #pragma once
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
@@ -25,7 +26,15 @@ struct LpLazySrc {
     size_t len = 0;
     std::vector<uint8_t> keep;
     bool served = false;            // opencv_encoder_write has produced a result from a chain over these bytes
+    // A request "in flight" of deferred Part A: from the read_data that recorded the chain to the first time it is served (or run the eager
+    // way, or dropped). The count of those is how opencv_encoder_write tells one or a few goroutines -- each served on its own thread -- from a
+    // loaded service, whose requests share batch launches (lp_abi_opencv.cpp, profiles/r06_part_a.md section 4).
+    std::atomic<bool> in_flight{false};
+    void enter();
+    void leave();
+    ~LpLazySrc() { leave(); }
 };
+int lp_part_a_in_flight();
 // A Mat whose pixels have not been computed yet: decode [-> orientation] [-> crop] [-> resize] of a baseline JPEG, recorded call by call
 // as unchanged ops.go issues them (ops.go:352-444 through opencv.go:250-374, 816-900). opencv_encoder_write(".jpeg") hands the whole
 // chain to the batched path (lp_coalesce.h) -- one launch sequence shared with whatever other calls are in flight, no 48 MB frame ever

@@ -73,7 +73,8 @@ EnginePool& engine_pool()
     return *p;
 }
 // Idle engines kept per process: at most LILLIPUT_HIP_ENGINE_POOL of them (default 64) holding at most LILLIPUT_HIP_ENGINE_POOL_MB of
-// device arenas between them (default 4096). Round 3 kept 8: a service with more callers than that in flight on sources the call
+// device arenas between them (default 16 384 of the 288 GB; 4 096 until round 6, when a few engines that had served a 4096 x 4096 decode each
+// on their caller's thread pushed the pool over it and every trim's hipFree stalled the dispatchers' launches). Round 3 kept 8: a service with more callers than that in flight on sources the call
 // coalescer does not take (PNG, WebP, GIF) built and tore down an engine -- two streams, sixteen events, some forty arenas whose
 // hipFree synchronises the device -- for a third of its requests (bench.py --workload abi, 64 callers, direct route: 314 engines
 // created for 1 024 requests, 367 images/s against 2 366 with 8 callers; profiles/r04_a_service.md).
@@ -84,7 +85,7 @@ size_t pool_keep()
 }
 size_t pool_keep_bytes()
 {
-    static const size_t v = (getenv("LILLIPUT_HIP_ENGINE_POOL_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL_MB"))) : 4096) << 20;
+    static const size_t v = (getenv("LILLIPUT_HIP_ENGINE_POOL_MB") ? (size_t)std::max(1, atoi(getenv("LILLIPUT_HIP_ENGINE_POOL_MB"))) : 16384) << 20;
     return v;
 }
 size_t pool_trim_bytes() // an engine whose arenas grew beyond this is not kept (LILLIPUT_HIP_ENGINE_TRIM_MB, default 1 GiB: a 8192 x 8192 decode is ~0.5 GiB)
@@ -417,6 +418,10 @@ static bool defer_inline_on()
     return g != 0;
 }
 extern "C" int lilliput_hip_set_deferred_inline(int on) { const int prev = defer_inline_on() ? 1 : 0; __atomic_store_n(&g_defer_inline, on ? 1 : 0, __ATOMIC_RELAXED); return prev; }
+static std::atomic<int> g_part_a_in_flight{0};
+void LpLazySrc::enter() { if (!in_flight.exchange(true)) g_part_a_in_flight.fetch_add(1, std::memory_order_relaxed); }
+void LpLazySrc::leave() { if (in_flight.exchange(false)) g_part_a_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+int lp_part_a_in_flight() { return g_part_a_in_flight.load(std::memory_order_relaxed); }
 static std::atomic<uint64_t> g_defer_stats[4]; // chains recorded, served by the batched path, materialised, sources copied at decoder release
 extern "C" void lilliput_hip_deferred_stats(uint64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = g_defer_stats[i].load(); }
 
@@ -459,6 +464,7 @@ bool lp_mat_materialize(LpMat* m)
     const std::shared_ptr<LpLazy> z = std::move(m->lazy);
     m->lazy.reset();
     g_defer_stats[2]++;
+    struct Leave { LpLazySrc* s; ~Leave() { s->leave(); } } leave_when_done{z->src.get()};
     LpEagerScope eager;
     if (!z->src->p) {
         lp_set_error("deferred chain: its decoder was closed after the chain had been encoded once; keep the decoder open until the framebuffer's last use (or LILLIPUT_HIP_DEFER=0)");
@@ -1097,6 +1103,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
         auto z = std::make_shared<LpLazy>();
         z->src = std::make_shared<LpLazySrc>();
         z->src->p = d->data; z->src->len = d->len;
+        z->src->enter();
         z->hdr_w = (int)j.width; z->hdr_h = (int)j.height; z->hdr_orientation = (int)j.orientation;
         d->lazies.erase(std::remove_if(d->lazies.begin(), d->lazies.end(), [](const std::weak_ptr<LpLazySrc>& w) { return w.expired(); }), d->lazies.end());
         d->lazies.push_back(z->src);
@@ -1221,10 +1228,13 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     // A recorded chain that arrives while no other is being served (one goroutine, or a quiet moment) runs on the caller's own thread
     // through the one-image route below -- no hand-over to a dispatcher thread and back, no stager / compute thread pair for a batch of
     // one (round 6: 0.92 -> 0.7x ms for a 512 x 512 source, profiles/r06_one_image.md). LILLIPUT_HIP_DEFER_INLINE=0: always the batched path.
-    static std::atomic<int> parta_active{0};
-    const bool inline_lone = defer_inline_on();
-    struct ActiveScope { std::atomic<int>& a; int before; explicit ActiveScope(std::atomic<int>& x) : a(x), before(x.fetch_add(1, std::memory_order_relaxed)) {} ~ActiveScope() { a.fetch_sub(1, std::memory_order_relaxed); } } active(parta_active);
-    const bool lone = inline_lone && active.before == 0;
+    // ... "few" = at most LILLIPUT_HIP_DEFER_INLINE_MAX (default 8) requests of deferred Part A in flight, from the read_data that recorded a
+    // chain to the first time it is served: 8 callers all on their own threads 3.0 k images/s, all through the dispatchers 2.5 k; 16 callers 4.0 / 4.3 k;
+    // 64 callers 8 / 10 k -- and a mix of the two routes is slower than either.
+    static const int inline_max = getenv("LILLIPUT_HIP_DEFER_INLINE_MAX") ? std::max(1, atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_MAX"))) : 8;
+    const bool lone = s->lazy && defer_inline_on() && lp_part_a_in_flight() <= inline_max && lp_coalesce_busy() == 0;
+    struct ServedScope { LpLazySrc* p; ~ServedScope() { if (p) p->leave(); } } served_scope{s->lazy ? s->lazy->src.get() : nullptr};
+    std::shared_ptr<LpLazySrc> keep_src = s->lazy ? s->lazy->src : nullptr; // (the scope's pointer stays valid)
     if (s->lazy && !lone && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
         lilliput_batch_options bo;
         if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {

@@ -20,6 +20,7 @@
 namespace {
 
 std::atomic<int> g_in_flight{0};
+std::atomic<int> g_busy{0}; // requests queued for, or being served by, the dispatchers (lp_coalesce_busy)
 thread_local int t_suppress = 0;
 
 int env_int(const char* name, int dflt, int lo, int hi)
@@ -233,6 +234,8 @@ LpTransformInFlight::~LpTransformInFlight() { g_in_flight.fetch_sub(1, std::memo
 LpCoalesceSuppress::LpCoalesceSuppress() { prev = t_suppress; t_suppress = 1; }
 LpCoalesceSuppress::~LpCoalesceSuppress() { t_suppress = prev; }
 
+int lp_coalesce_busy() { return g_busy.load(std::memory_order_relaxed); }
+
 bool lp_coalesce_wanted(int in_flight)
 {
     const int t = threshold();
@@ -247,6 +250,7 @@ int lp_coalesce_transform_status(int device, const void* src, size_t len, void* 
     if (!D) return LILLIPUT_ERR_DEVICE;
     Req r;
     r.src = src; r.len = len; r.dst = dst; r.cap = cap; r.opt = opt;
+    struct Busy { Busy() { g_busy.fetch_add(1, std::memory_order_relaxed); } ~Busy() { g_busy.fetch_sub(1, std::memory_order_relaxed); } } busy;
     // the caller's own copy into pinned memory (see StagePool); a source that is pinned already travels as it is
     size_t cls = 0;
     void* slot = lilliput_hip_host_is_pinned(src, len) ? nullptr : stage_acquire(device, len, &cls);

@@ -29,6 +29,10 @@ struct LpTransformInFlight {
 };
 // true when a call that sees `in_flight` concurrent calls should go through the dispatchers (and this thread is allowed to)
 bool lp_coalesce_wanted(int in_flight);
+// requests queued for, or being served by, the dispatchers right now (all devices). Deferred Part A serves a recorded chain on its caller's
+// thread only while this is 0: once one request has gone to the dispatchers the ones arriving behind it follow, so the two routes do not mix
+// under load (profiles/r06_part_a.md section 4).
+int lp_coalesce_busy();
 // Hands one request over and waits for it. Returns true when the batched path served it (LILLIPUT_OK, *out_len set); false = take the
 // direct route (not served, failed, or no device).
 bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len);

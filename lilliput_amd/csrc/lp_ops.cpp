@@ -553,7 +553,9 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     // Several Transform calls in flight at once (a service's goroutines, README.md:82-85): the ones the batched path answers with the
     // same bytes -- static JPEG source, JPEG output, Fit / Resize -- share its launches instead of each paying its own (lp_coalesce.h).
     // Whatever the batch does not answer with LILLIPUT_OK runs below as if nothing had happened.
-    if (lp_coalesce_wanted(in_flight.now) && coalescible(o, d, hdr, opt)) {
+    // (Deferred Part A counts its own requests in flight, lp_abi_opencv.cpp; here it is the Transform calls of any kind, LILLIPUT_HIP_COALESCE.)
+    const bool can_share = coalescible(o, d, hdr, opt);
+    if (can_share && lp_coalesce_wanted(in_flight.now)) {
         lilliput_batch_options bo;
         memset(&bo, 0, sizeof(bo));
         bo.width = opt->width; bo.height = opt->height;
