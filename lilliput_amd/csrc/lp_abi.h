@@ -35,6 +35,7 @@ struct LpLazySrc {
     ~LpLazySrc() { leave(); }
 };
 int lp_part_a_in_flight();
+extern "C" void lp_batch_set_stage_timing(void* batch, bool on); // lp_batch.cpp: the resident run of this batch records no stage events
 // A Mat whose pixels have not been computed yet: decode [-> orientation] [-> crop] [-> resize] of a baseline JPEG, recorded call by call
 // as unchanged ops.go issues them (ops.go:352-444 through opencv.go:250-374, 816-900). opencv_encoder_write(".jpeg") hands the whole
 // chain to the batched path (lp_coalesce.h) -- one launch sequence shared with whatever other calls are in flight, no 48 MB frame ever

@@ -422,6 +422,40 @@ static std::atomic<int> g_part_a_in_flight{0};
 void LpLazySrc::enter() { if (!in_flight.exchange(true)) g_part_a_in_flight.fetch_add(1, std::memory_order_relaxed); }
 void LpLazySrc::leave() { if (in_flight.exchange(false)) g_part_a_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 int lp_part_a_in_flight() { return g_part_a_in_flight.load(std::memory_order_relaxed); }
+// A chain served on its caller's thread runs as a resident batch of one (upload / run / download on this thread: the fused planes -> thumbnail
+// kernels, one deferred status fetch, no frame in between) on a batch object from a small pool -- at most LILLIPUT_HIP_DEFER_INLINE_MAX are in
+// use at once, so that many idle ones are kept (engine, streams and one image's arenas each); never destroyed, like the engine pool.
+namespace {
+struct LoneBatchPool {
+    std::mutex mu;
+    std::vector<std::pair<int, lilliput_hip_batch>> idle;
+};
+LoneBatchPool& lone_pool() { static LoneBatchPool* p = new LoneBatchPool(); return *p; }
+struct LoneBatchLease {
+    int dev;
+    lilliput_hip_batch b = nullptr;
+    explicit LoneBatchLease(int device) : dev(device)
+    {
+        LoneBatchPool& P = lone_pool();
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            for (size_t i = P.idle.size(); i-- > 0;)
+                if (P.idle[i].first == dev) { b = P.idle[i].second; P.idle.erase(P.idle.begin() + (long)i); break; }
+        }
+        if (!b) { b = lilliput_hip_batch_create(dev); lp_batch_set_stage_timing(b, false); }
+    }
+    ~LoneBatchLease()
+    {
+        if (!b) return;
+        LoneBatchPool& P = lone_pool();
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            if (P.idle.size() < 16) { P.idle.emplace_back(dev, b); b = nullptr; }
+        }
+        if (b) lilliput_hip_batch_destroy(b);
+    }
+};
+}
 static std::atomic<uint64_t> g_defer_stats[4]; // chains recorded, served by the batched path, materialised, sources copied at decoder release
 extern "C" void lilliput_hip_deferred_stats(uint64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = g_defer_stats[i].load(); }
 
@@ -1233,6 +1267,8 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     // 64 callers 8 / 10 k -- and a mix of the two routes is slower than either.
     static const int inline_max = getenv("LILLIPUT_HIP_DEFER_INLINE_MAX") ? std::max(1, atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_MAX"))) : 8;
     const bool lone = s->lazy && defer_inline_on() && lp_part_a_in_flight() <= inline_max && lp_coalesce_busy() == 0;
+    // LILLIPUT_HIP_DEFER_INLINE_FUSED=0: such a chain is materialised call by call instead (decode to a frame, resize, encode: the round-6 route before the batch of one)
+    static const bool lone_fused = !(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED") && atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED")) == 0);
     struct ServedScope { LpLazySrc* p; ~ServedScope() { if (p) p->leave(); } } served_scope{s->lazy ? s->lazy->src.get() : nullptr};
     std::shared_ptr<LpLazySrc> keep_src = s->lazy ? s->lazy->src : nullptr; // (the scope's pointer stays valid)
     if (s->lazy && !lone && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
@@ -1253,6 +1289,26 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
             }
             // anything else (a result larger than the caller's buffer: the pointer must change; a dispatcher that is shutting down;
             // a device error): the eager route below reproduces the direct behaviour
+        }
+    }
+    if (s->lazy && lone && lone_fused && quality > 0 && d->datastart && cap && s->lazy->src->p) { // ... on this thread, as a resident batch of one
+        lilliput_batch_options bo;
+        if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {
+            const std::shared_ptr<LpLazySrc> src = s->lazy->src;
+            LoneBatchLease lb(lp_current_device());
+            lilliput_batch_item it;
+            memset(&it, 0, sizeof(it));
+            it.src = src->p; it.src_len = src->len; it.dst = d->datastart; it.dst_cap = cap; it.status = LILLIPUT_ERR_DEVICE;
+            if (lb.b && lilliput_hip_batch_upload2(lb.b, &it, 1, 1) == LILLIPUT_OK && lilliput_hip_batch_run(lb.b, &bo) == LILLIPUT_OK &&
+                lilliput_hip_batch_download(lb.b, &it, 1) == 0 && it.status == LILLIPUT_OK && it.dst_len > 0 && it.dst_len <= cap) {
+                src->served = true;
+                d->data = d->datastart;
+                d->rows = (int)it.dst_len; d->cols = 1; d->type = CV_8U; d->step = 1;
+                d->dev_valid = false;
+                g_defer_stats[1]++;
+                return true;
+            }
+            // anything else: the eager route below, whose behaviour is the direct one's (errors, a result beyond the caller's buffer)
         }
     }
     LpEngineLease lease;

@@ -152,6 +152,7 @@ struct LpBatch {
     hipStream_t shared_copy = nullptr;         // the pipelined transform's H2D copies: one queue, so chunks arrive in the order they were claimed
     hipStream_t extra_copy[3] = {nullptr, nullptr, nullptr}; // more queues for the many per-source copies of zero-copy ingest (see LpEngine::upload_commit)
     int n_extra_copy = 0;
+    bool stage_timing = true;                  // the resident run records the engines' stage events (lilliput_hip_batch_timings); off for the batch of one a lone Part A chain runs as
     int node_index = 0;                        // position among the devices of a lilliput_hip_node (trace output)
     size_t last_images = 0;                    // images this device's engines served in the last transform
     size_t last_chunks = 0, last_stolen = 0;   // (devs[0] of a call) chunks of the last transform, and how many a device took from another device's share
@@ -248,6 +249,8 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
 LP_ABI_CATCH("lilliput_hip_batch_create", return nullptr)
 
 void lilliput_hip_batch_destroy(lilliput_hip_batch b) { delete static_cast<LpBatch*>(b); }
+
+void lp_batch_set_stage_timing(lilliput_hip_batch bb, bool on) { if (bb) static_cast<LpBatch*>(bb)->stage_timing = on; }
 
 void lilliput_hip_batch_set_subsequence(lilliput_hip_batch bb, unsigned S, unsigned C)
 try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
@@ -726,7 +729,7 @@ static int run_part(LpBatch* b, LpBatchPart& part, const lilliput_batch_options*
         else { const size_t launches = (nv + chunk - 1) / chunk; chunk = (nv + launches - 1) / launches; }
     }
     const LpSink sink{b, nullptr};
-    eng.enable_timing(true);
+    eng.enable_timing(b->stage_timing);
     int rc = LILLIPUT_OK;
     for (size_t first = 0; first < nv && rc == LILLIPUT_OK; first += chunk)
         rc = run_chunk(b, part, (int)first, (int)std::min(chunk, nv - first), part.hdrs.data() + first, part.items.data() + first, opt, sink);

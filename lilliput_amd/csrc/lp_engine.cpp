@@ -289,6 +289,46 @@ bool LpEngine::h2d_small(void* dst, const void* src, size_t bytes)
     return true;
 }
 
+bool LpEngine::small_flush(SmallBatch& sb)
+{
+    if (sb.n) lp_launch_small_ops(stream_, sb.ops, sb.n);
+    sb.n = 0;
+    return true;
+}
+bool LpEngine::small_copy(SmallBatch& sb, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return true;
+    const size_t kRing = 8u << 20, need = align_up(bytes, 256);
+    if (need > kRing / 2) return check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_), "H2D descriptors"); // in stream order before the flush: fine
+    if (!h_desc_.p && !h_desc_.ensure(kRing)) { err_ = "pinned allocation failed"; return false; }
+    if (desc_used_ + need > kRing) { // the ring wraps: what is pending still reads its old places
+        small_flush(sb);
+        if (!check(hipStreamSynchronize(stream_), "descriptor ring sync")) return false;
+        desc_used_ = 0;
+    }
+    uint8_t* stage = h_desc_.as<uint8_t>() + desc_used_;
+    memcpy(stage, src, bytes);
+    desc_used_ += need;
+    if (sb.n == LP_SMALL_SEGS) small_flush(sb);
+    sb.ops.s[sb.n++] = LpSmallSeg{dst, static_cast<uint8_t*>(h_desc_.dev) + (stage - h_desc_.as<uint8_t>()), (uint32_t)((bytes + 15) / 16), 0u};
+    return true;
+}
+bool LpEngine::small_zero(SmallBatch& sb, void* dst, size_t bytes)
+{
+    if (!bytes) return true;
+    if (bytes > (64u << 20) || ((uintptr_t)dst & 15u)) return check(hipMemsetAsync(dst, 0, bytes, stream_), "memset");
+    if (sb.n == LP_SMALL_SEGS) small_flush(sb);
+    sb.ops.s[sb.n++] = LpSmallSeg{dst, nullptr, (uint32_t)(bytes / 16), (uint32_t)(bytes & 15u)};
+    return true;
+}
+bool LpEngine::small_d2h(SmallBatch& sb, const LpPinned& pin, void* host, const void* dev, size_t bytes)
+{
+    if (!bytes) return true;
+    if (sb.n == LP_SMALL_SEGS) small_flush(sb);
+    sb.ops.s[sb.n++] = LpSmallSeg{static_cast<uint8_t*>(pin.dev) + (static_cast<uint8_t*>(host) - pin.as<uint8_t>()), dev, (uint32_t)((bytes + 15) / 16), 0u};
+    return true;
+}
+
 bool LpEngine::h2d_any(void* dst, const void* src, size_t bytes, bool dst_has_slack)
 {
     if (!bytes) return true;
@@ -964,10 +1004,14 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
              d_planes_.ensure(plane_bytes + LP_AREA_SLACK) && d_frames_desc_.ensure(sizeof(LpFrame) * (size_t)n) &&
              h_small_.ensure(std::max<size_t>(4096, sizeof(LpJpegState) * (size_t)n));
     if (!a) { err_ = "device allocation failed"; return LP_ERR_DEVICE; }
-    if (!h2d_small(d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n)) return LP_ERR_DEVICE;
     const LpJpeg* di = d_imgs_.as<LpJpeg>();
     LpJpegState* ds = d_states_.as<LpJpegState>();
-    if (!check(hipMemsetAsync(ds, 0, sizeof(LpJpegState) * (size_t)n, stream_), "memset states")) return LP_ERR_DEVICE;
+    {   // image descriptors up, states and the verify rounds' counters cleared: one launch
+        SmallBatch sb;
+        if (!small_copy(sb, d_imgs_.p, h_imgs_.data(), sizeof(LpJpeg) * (size_t)n) || !small_zero(sb, ds, sizeof(LpJpegState) * (size_t)n) ||
+            !small_zero(sb, d_changed_.p, 4 * (vr_ + 1)) || !small_flush(sb))
+            return LP_ERR_DEVICE;
+    }
     // LILLIPUT_HIP_DEBUG_SYNC=1: synchronise after every stage and name it on stderr (a faulting kernel aborts the process at
     // the next synchronisation, so the last line printed is the stage before the culprit)
     static const bool dbg = getenv("LILLIPUT_HIP_DEBUG_SYNC") != nullptr;
@@ -998,7 +1042,7 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     // Verify rounds back to back, no host round trip in between: round r counts the exit states it moved into changed[r] and a
     // round that follows an idle one returns at once. The last counter is looked at when the decode is collected (finish_decode);
     // streams that need more than LP_VERIFY_ROUNDS rounds (tiny subsequences, hostile data) continue there under host control.
-    if (!check(hipMemsetAsync(d_changed_.p, 0, 4 * (vr_ + 1), stream_), "memset changed")) return LP_ERR_DEVICE;
+    // (the counters were cleared with the descriptor upload above)
     for (uint32_t r = 0; r < vr_; r++) lp_launch_huff_verify(stream_, ha, r);
     mark(9);
     stage("huff_verify");
@@ -1076,8 +1120,12 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
     }
     mark(4);
     pend_ = Pending{true, first, n, nstreams, pcoef_elems, any_baseline, any_frame, any_generic, any_420, frames, ha, vr_};
-    d2h_small(h_dstate_, h_dstate_.as<uint8_t>() + 64, ds, sizeof(LpJpegState) * (size_t)n);
-    d2h_small(h_dstate_, h_dstate_.p, d_changed_.p, 4 * (vr_ + 1));
+    {
+        SmallBatch sb;
+        small_d2h(sb, h_dstate_, h_dstate_.as<uint8_t>() + 64, ds, sizeof(LpJpegState) * (size_t)n);
+        small_d2h(sb, h_dstate_, h_dstate_.p, d_changed_.p, 4 * (vr_ + 1));
+        small_flush(sb);
+    }
     return defer ? LP_OK : finish_decode(status);
 }
 
@@ -1603,9 +1651,12 @@ int LpEngine::area_resample(const LpAreaReq* reqs, int n, bool after_fused)
     }
     if (!d_aops_.ensure(sizeof(LpArea420Op) * (size_t)n) || !d_ataps_.ensure(sizeof(LpTap) * taps.size() + 64) || !d_aranges_.ensure(4 * ranges.size() + 64))
         return LP_ERR_DEVICE;
-    if (!h2d_small(d_aops_.p, ops.data(), sizeof(LpArea420Op) * (size_t)n) || !h2d_small(d_ataps_.p, taps.data(), sizeof(LpTap) * taps.size()) ||
-        !h2d_small(d_aranges_.p, ranges.data(), 4 * ranges.size()))
-        return LP_ERR_DEVICE;
+    {
+        SmallBatch sb;
+        if (!small_copy(sb, d_aops_.p, ops.data(), sizeof(LpArea420Op) * (size_t)n) || !small_copy(sb, d_ataps_.p, taps.data(), sizeof(LpTap) * taps.size()) ||
+            !small_copy(sb, d_aranges_.p, ranges.data(), 4 * ranges.size()) || !small_flush(sb))
+            return LP_ERR_DEVICE;
+    }
     if (!(after_fused && fused_timed_)) mark(11); // behind a fused_resample: its start event stands
     lp_launch_area_420(stream_, d_imgs_.as<LpJpeg>(), d_aops_.as<LpArea420Op>(), (uint32_t)n, mask, mdw, mdh, d_ataps_.as<LpTap>(), d_aranges_.as<uint32_t>(),
                        d_planes_.as<uint8_t>());
@@ -2028,10 +2079,28 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
         !d_blkbits_.ensure((size_t)tot_blocks * 4 + 64) || !d_bits_.ensure(bits_words * 4 + 64) || !d_hdrs_.ensure(hdrs.size() + 64) ||
         !d_out_.ensure(out_bytes + 64) || !h_small_.ensure(std::max<size_t>(4096, sizeof(LpEncState) * (size_t)n + 64)))
         return LP_ERR_DEVICE;
-    if (!h2d_small(d_jobs_.p, h_jobs_.data(), sizeof(LpEncJob) * (size_t)n)) return LP_ERR_DEVICE;
-    if (!hdrs.empty() && !h2d_small(d_hdrs_.p, hdrs.data(), hdrs.size())) return LP_ERR_DEVICE;
-    if (!check(hipMemsetAsync(d_bits_.p, 0, bits_words * 4 + 64, stream_), "memset bits")) return LP_ERR_DEVICE;
-    if (!check(hipMemsetAsync(d_estates_.p, 0, sizeof(LpEncState) * (size_t)n, stream_), "memset enc states")) return LP_ERR_DEVICE;
+    // where every stream goes in the pinned output buffer (a slot bounds the usual size; a stream that outgrows it is fetched from the
+    // output arena by encoded_fetch_all): host values only, so the offsets travel with the other descriptors
+    std::vector<uint32_t>& pk = h_pk_;
+    pk.assign((size_t)n + 1, 0);
+    size_t pk_total = 0;
+    h_out_off_.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        const LpEncJob& j = h_jobs_[(size_t)i];
+        const size_t slot = align_up(std::min<size_t>(j.out_cap, std::max<size_t>(16384, (size_t)j.src.w * j.src.h * j.ncomp / 2 + 4096)), 16) + 16;
+        h_out_off_[(size_t)i] = pk_total;
+        pk[(size_t)i] = (uint32_t)pk_total;
+        pk_total += j.total_blocks ? slot : 0;
+    }
+    pk[(size_t)n] = (uint32_t)pk_total;
+    if (!enc_fdct_only_ && (pk_total > 0xffffff00ull || !h_out_.ensure(pk_total + 64) || !d_pkoff_.ensure(((size_t)n + 1) * 4 + 64))) return LP_ERR_DEVICE;
+    {   // jobs, headers and pack offsets up, bit buffers and states cleared: one launch
+        SmallBatch sb;
+        if (!small_copy(sb, d_jobs_.p, h_jobs_.data(), sizeof(LpEncJob) * (size_t)n) || (!hdrs.empty() && !small_copy(sb, d_hdrs_.p, hdrs.data(), hdrs.size())) ||
+            (!enc_fdct_only_ && !small_copy(sb, d_pkoff_.p, pk.data(), ((size_t)n + 1) * 4)) || !small_zero(sb, d_bits_.p, bits_words * 4 + 64) ||
+            !small_zero(sb, d_estates_.p, sizeof(LpEncState) * (size_t)n) || !small_flush(sb))
+            return LP_ERR_DEVICE;
+    }
     if (enc_fdct_only_) { // progressive output: the entropy coding happens on the host
         lp_launch_enc_fdct(stream_, d_jobs_.as<LpEncJob>(), (uint32_t)n, max_blocks, d_ecoef_.as<int16_t>());
         if (!check(hipStreamSynchronize(stream_), "fdct sync")) return LP_ERR_DEVICE;
@@ -2046,22 +2115,7 @@ int LpEngine::encode_jpegs(const LpEncodeReq* reqs, int n, int* status, uint32_t
                          d_blkbits_.as<uint32_t>(), d_bits_.as<uint32_t>(), d_hdrs_.as<uint8_t>(), d_out_.as<uint8_t>());
     }
     mark(6);
-    {   // results: every stream into its slot of the pinned output buffer (a slot bounds the usual size; a stream that outgrows it
-        // is fetched from the output arena by encoded_fetch_all), and the states -- one wait for both
-        std::vector<uint32_t>& pk = h_pk_;
-        pk.assign((size_t)n + 1, 0);
-        size_t total = 0;
-        h_out_off_.assign((size_t)n, 0);
-        for (int i = 0; i < n; i++) {
-            const LpEncJob& j = h_jobs_[(size_t)i];
-            const size_t slot = align_up(std::min<size_t>(j.out_cap, std::max<size_t>(16384, (size_t)j.src.w * j.src.h * j.ncomp / 2 + 4096)), 16) + 16;
-            h_out_off_[(size_t)i] = total;
-            pk[(size_t)i] = (uint32_t)total;
-            total += j.total_blocks ? slot : 0;
-        }
-        pk[(size_t)n] = (uint32_t)total;
-        if (total > 0xffffff00ull || !h_out_.ensure(total + 64) || !d_pkoff_.ensure(((size_t)n + 1) * 4 + 64)) return LP_ERR_DEVICE;
-        if (!h2d_small(d_pkoff_.p, pk.data(), ((size_t)n + 1) * 4)) return LP_ERR_DEVICE;
+    {   // results: every stream into its slot of the pinned output buffer, and the states -- one wait for both
         lp_launch_enc_pack(stream_, d_jobs_.as<LpEncJob>(), d_estates_.as<LpEncState>(), (uint32_t)n, d_pkoff_.as<uint32_t>(), d_out_.as<uint8_t>(),
                            static_cast<uint8_t*>(h_out_.dev));
     }

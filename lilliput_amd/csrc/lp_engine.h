@@ -250,6 +250,14 @@ public:
 private:
     bool check(hipError_t e, const char* what);
     bool h2d_small(void* dst, const void* src, size_t bytes);
+    // Several small uploads, downloads and zero fills as ONE launch on the compute stream: add() them, then flush() before the first kernel
+    // that reads any of them (a full batch flushes itself). Copies keep h2d_small's contract (16-byte aligned destination, size rounded up
+    // to 16 inside padded arenas); zero fills are exact.
+    struct SmallBatch { LpSmallOps ops; uint32_t n = 0; };
+    bool small_copy(SmallBatch& sb, void* dst, const void* src, size_t bytes);
+    bool small_zero(SmallBatch& sb, void* dst, size_t bytes);
+    bool small_d2h(SmallBatch& sb, const LpPinned& pin, void* host, const void* dev, size_t bytes);
+    bool small_flush(SmallBatch& sb);
     // Host -> device from memory that may be pageable, without the runtime's own pageable path (a staged, host-blocking copy behind a
     // process-wide lock: 0.6 ms per call with eight callers, HIP API trace of round 4): small blocks through the descriptor ring
     // (h2d_small), large ones through this engine's pinned transfer buffer. dst needs room for bytes rounded up to 16.

@@ -1327,6 +1327,28 @@ __global__ void k_copy_small(uint4* __restrict__ dst, const uint4* __restrict__ 
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// Several of those in ONE launch (a one-image call is a chain of ~35 launches of ~5 us each, a third of them descriptor copies and small
+// fills: profiles/r06_one_image.md): blockIdx.y = segment; a segment without a source is a zero fill of exactly its bytes.
+__global__ void k_small_ops(LpSmallOps ops)
+{
+    const LpSmallSeg sg = ops.s[blockIdx.y];
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(sg.dst);
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sg.src);
+    if (src) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < sg.n16; i += gridDim.x * blockDim.x) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0 && threadIdx.x < sg.tail) reinterpret_cast<uint8_t*>(dst + sg.n16)[threadIdx.x] = 0;
+    }
+}
+void lp_launch_small_ops(hipStream_t s, const LpSmallOps& ops, uint32_t n)
+{
+    if (!n) return;
+    uint32_t max16 = 1;
+    for (uint32_t i = 0; i < n; i++) max16 = ops.s[i].n16 > max16 ? ops.s[i].n16 : max16;
+    const uint32_t blocks = max16 < 256u * 64u ? (max16 + 255u) / 256u : 64u;
+    hipLaunchKernelGGL(k_small_ops, dim3(blocks, n), dim3(256), 0, s, ops);
+}
 void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size_t bytes)
 {
     const uint32_t n16 = (uint32_t)((bytes + 15) / 16);

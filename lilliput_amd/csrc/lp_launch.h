@@ -37,6 +37,11 @@ void lp_launch_huff_verify(hipStream_t s, const LpHuffArgs& a, uint32_t round); 
 void lp_launch_sub_scan(hipStream_t s, const LpHuffArgs& a);
 void lp_launch_reset_tail_state(hipStream_t s, LpJpegState* d_states, uint32_t n);
 void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size_t bytes); // bytes rounded up to 16: both buffers padded accordingly
+// up to LP_SMALL_SEGS such copies and small zero fills as one launch (LpEngine::SmallBatch)
+#define LP_SMALL_SEGS 6
+struct LpSmallSeg { void* dst; const void* src; uint32_t n16; uint32_t tail; }; // src == nullptr: zero n16 * 16 + tail bytes; else copy n16 groups (tail unused)
+struct LpSmallOps { LpSmallSeg s[LP_SMALL_SEGS]; };
+void lp_launch_small_ops(hipStream_t s, const LpSmallOps& ops, uint32_t n);
 void lp_launch_huff_write(hipStream_t s, const LpHuffArgs& a);
 // zero-copy ingest: pieces in pinned, device-mapped host memory -> the raw arena (see k_gather_raw). The two arrays live in mapped pinned memory.
 struct LpGatherPiece { const uint8_t* src; uint64_t dst_off; uint32_t len; uint32_t pad; };
