@@ -35,6 +35,11 @@ struct LpLazySrc {
     ~LpLazySrc() { leave(); }
 };
 int lp_part_a_in_flight();
+// One item through a resident batch of one on the calling thread (a pooled batch object: upload / run / download); the item's LILLIPUT_* status.
+// What a lone deferred Part A chain and a Part C call without company run as (lp_abi_opencv.cpp).
+bool lp_lone_batch_enabled();
+int lp_lone_inline_max();     // LILLIPUT_HIP_DEFER_INLINE_MAX (8): that many requests in flight are served on their callers' threads while the dispatchers are idle
+int lp_lone_batch_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& bo, size_t* out_len);
 extern "C" void lp_batch_set_stage_timing(void* batch, bool on); // lp_batch.cpp: the resident run of this batch records no stage events
 // A Mat whose pixels have not been computed yet: decode [-> orientation] [-> crop] [-> resize] of a baseline JPEG, recorded call by call
 // as unchanged ops.go issues them (ops.go:352-444 through opencv.go:250-374, 816-900). opencv_encoder_write(".jpeg") hands the whole

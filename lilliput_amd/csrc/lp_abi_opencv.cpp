@@ -456,6 +456,35 @@ struct LoneBatchLease {
     }
 };
 }
+int lp_lone_inline_max()
+{
+    static const int v = getenv("LILLIPUT_HIP_DEFER_INLINE_MAX") ? std::max(1, atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_MAX"))) : 8;
+    return v;
+}
+bool lp_lone_batch_enabled()
+{
+    // LILLIPUT_HIP_DEFER_INLINE_FUSED=0: a chain served on its caller's thread is materialised call by call instead (decode to a frame, resize,
+    // encode: the round-6 route before the batch of one); Part C's direct route likewise runs its own calls
+    static const bool on = !(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED") && atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED")) == 0);
+    return on;
+}
+int lp_lone_batch_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& bo, size_t* out_len)
+{
+    *out_len = 0;
+    if (!src || !len || !dst || !cap) return LILLIPUT_ERR_INVALID_IMAGE;
+    LoneBatchLease lb(device);
+    if (!lb.b) return LILLIPUT_ERR_DEVICE;
+    lilliput_batch_item it;
+    memset(&it, 0, sizeof(it));
+    it.src = src; it.src_len = len; it.dst = dst; it.dst_cap = cap; it.status = LILLIPUT_ERR_DEVICE;
+    int rc = lilliput_hip_batch_upload2(lb.b, &it, 1, 1);
+    if (rc != LILLIPUT_OK) return rc;
+    if (lilliput_hip_batch_run(lb.b, &bo) != LILLIPUT_OK) return LILLIPUT_ERR_DEVICE;
+    (void)lilliput_hip_batch_download(lb.b, &it, 1);
+    if (it.status == LILLIPUT_OK && (it.dst_len == 0 || it.dst_len > cap)) return LILLIPUT_ERR_DEVICE;
+    if (it.status == LILLIPUT_OK) *out_len = it.dst_len;
+    return it.status;
+}
 static std::atomic<uint64_t> g_defer_stats[4]; // chains recorded, served by the batched path, materialised, sources copied at decoder release
 extern "C" void lilliput_hip_deferred_stats(uint64_t out[4]) { for (int i = 0; i < 4; i++) out[i] = g_defer_stats[i].load(); }
 
@@ -1265,10 +1294,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     // ... "few" = at most LILLIPUT_HIP_DEFER_INLINE_MAX (default 8) requests of deferred Part A in flight, from the read_data that recorded a
     // chain to the first time it is served: 8 callers all on their own threads 3.0 k images/s, all through the dispatchers 2.5 k; 16 callers 4.0 / 4.3 k;
     // 64 callers 8 / 10 k -- and a mix of the two routes is slower than either.
-    static const int inline_max = getenv("LILLIPUT_HIP_DEFER_INLINE_MAX") ? std::max(1, atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_MAX"))) : 8;
-    const bool lone = s->lazy && defer_inline_on() && lp_part_a_in_flight() <= inline_max && lp_coalesce_busy() == 0;
-    // LILLIPUT_HIP_DEFER_INLINE_FUSED=0: such a chain is materialised call by call instead (decode to a frame, resize, encode: the round-6 route before the batch of one)
-    static const bool lone_fused = !(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED") && atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED")) == 0);
+    const bool lone = s->lazy && defer_inline_on() && lp_part_a_in_flight() <= lp_lone_inline_max() && lp_coalesce_busy() == 0;
     struct ServedScope { LpLazySrc* p; ~ServedScope() { if (p) p->leave(); } } served_scope{s->lazy ? s->lazy->src.get() : nullptr};
     std::shared_ptr<LpLazySrc> keep_src = s->lazy ? s->lazy->src : nullptr; // (the scope's pointer stays valid)
     if (s->lazy && !lone && quality > 0 && d->datastart && cap) { // a recorded chain: decode -> orientation -> crop -> resize -> encode as ONE item of the batched path
@@ -1291,19 +1317,15 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
             // a device error): the eager route below reproduces the direct behaviour
         }
     }
-    if (s->lazy && lone && lone_fused && quality > 0 && d->datastart && cap && s->lazy->src->p) { // ... on this thread, as a resident batch of one
+    if (s->lazy && lone && lp_lone_batch_enabled() && quality > 0 && d->datastart && cap && s->lazy->src->p) { // ... on this thread, as a resident batch of one
         lilliput_batch_options bo;
         if (lazy_plan_options(*s->lazy, quality, progressive, &bo)) {
             const std::shared_ptr<LpLazySrc> src = s->lazy->src;
-            LoneBatchLease lb(lp_current_device());
-            lilliput_batch_item it;
-            memset(&it, 0, sizeof(it));
-            it.src = src->p; it.src_len = src->len; it.dst = d->datastart; it.dst_cap = cap; it.status = LILLIPUT_ERR_DEVICE;
-            if (lb.b && lilliput_hip_batch_upload2(lb.b, &it, 1, 1) == LILLIPUT_OK && lilliput_hip_batch_run(lb.b, &bo) == LILLIPUT_OK &&
-                lilliput_hip_batch_download(lb.b, &it, 1) == 0 && it.status == LILLIPUT_OK && it.dst_len > 0 && it.dst_len <= cap) {
+            size_t n = 0;
+            if (lp_lone_batch_transform(lp_current_device(), src->p, src->len, d->datastart, cap, bo, &n) == LILLIPUT_OK) {
                 src->served = true;
                 d->data = d->datastart;
-                d->rows = (int)it.dst_len; d->cols = 1; d->type = CV_8U; d->step = 1;
+                d->rows = (int)n; d->cols = 1; d->type = CV_8U; d->step = 1;
                 d->dev_valid = false;
                 g_defer_stats[1]++;
                 return true;

@@ -235,6 +235,7 @@ LpCoalesceSuppress::LpCoalesceSuppress() { prev = t_suppress; t_suppress = 1; }
 LpCoalesceSuppress::~LpCoalesceSuppress() { t_suppress = prev; }
 
 int lp_coalesce_busy() { return g_busy.load(std::memory_order_relaxed); }
+bool lp_coalesce_suppressed() { return t_suppress != 0; }
 
 bool lp_coalesce_wanted(int in_flight)
 {

@@ -33,6 +33,7 @@ bool lp_coalesce_wanted(int in_flight);
 // thread only while this is 0: once one request has gone to the dispatchers the ones arriving behind it follow, so the two routes do not mix
 // under load (profiles/r06_part_a.md section 4).
 int lp_coalesce_busy();
+bool lp_coalesce_suppressed(); // this thread is inside a batch (LpCoalesceSuppress): its Transform calls stay on the direct route
 // Hands one request over and waits for it. Returns true when the batched path served it (LILLIPUT_OK, *out_len set); false = take the
 // direct route (not served, failed, or no device).
 bool lp_coalesce_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& opt, size_t* out_len);
