@@ -303,7 +303,11 @@ struct DevMem {
     __device__ __forceinline__ uint4 load_quad(uint32_t bits) const
     {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifdef LP_EXP_HOT   // timing build (wrong pixels): every lane reads inside the first 256 KB of its image's stream -- what the walks would cost if no top-up ever missed the L2
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(words, (int)((bits >> 3) & 0x3fff0u), 0, 0);
+#else
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(words, (int)(bits >> 3), 0, 0);
+#endif
         return make_uint4(v.x, v.y, v.z, v.w);
     }
     __device__ __forceinline__ void store_quad(const uint4& v)
