@@ -1350,7 +1350,7 @@ void lp_launch_small_ops(hipStream_t s, const LpSmallOps& ops, uint32_t n)
     if (!n) return;
     uint32_t max16 = 1;
     for (uint32_t i = 0; i < n; i++) max16 = ops.s[i].n16 > max16 ? ops.s[i].n16 : max16;
-    const uint32_t blocks = max16 < 256u * 64u ? (max16 + 255u) / 256u : 64u;
+    const uint32_t blocks = max16 < 256u * 2048u ? (max16 + 255u) / 256u : 2048u; // (a batch's encode clears tens of MB of bit buffers in here: the whole device's worth of workgroups)
     hipLaunchKernelGGL(k_small_ops, dim3(blocks, n), dim3(256), 0, s, ops);
 }
 void lp_launch_copy_small(hipStream_t s, void* dst, const void* src_pinned, size_t bytes)
