@@ -363,9 +363,15 @@ struct DevMem {
 #ifndef LP_RING
 #define LP_RING 8   // measured against 16 (top-up of two quads every 8 steps): 8 KB less LDS per workgroup, 3-6 % more images/s
 #endif
+#ifndef LP_EXP_PREFETCH_COUNT
+#define LP_EXP_PREFETCH_COUNT 1   // quads in flight per lane ahead of the ring (1: the quad after next travels while the next one is consumed; 2: A/B build, profiles/r06_write_stream.md 6)
+#endif
+#ifndef LP_EXP_PREFETCH_WRITE
+#define LP_EXP_PREFETCH_WRITE 1
+#endif
 #if LP_RING == 8
-typedef DevMem<8, 2, 1> CountMem;   // SPEC / VERIFY: 8 words per lane, a top-up of one quad every 2 steps (2 + 3 + 3 <= 8)
-typedef DevMem<8, 2, 1> WriteMemSel;
+typedef DevMem<8, 2, LP_EXP_PREFETCH_COUNT> CountMem;   // SPEC / VERIFY: 8 words per lane, a top-up of one quad every 2 steps (2 + 3 + 3 <= 8)
+typedef DevMem<8, 2, LP_EXP_PREFETCH_WRITE> WriteMemSel;
 #else
 typedef DevMem<16, 8, 2> CountMem;  // SPEC / VERIFY
 typedef DevMem<16, 8, 2> WriteMemSel;
