@@ -220,10 +220,18 @@ static size_t prog_pinned_max()
     static const size_t v = getenv("LILLIPUT_HIP_PROG_PINNED_MAX") ? (size_t)strtoull(getenv("LILLIPUT_HIP_PROG_PINNED_MAX"), nullptr, 10) : (size_t)4 << 30;
     return v;
 }
+// ... and when the set's scans are decoded on the device (a call with many progressive files, lp_prog_host.h) nothing is pinned: the bound is the
+// device's coefficient arena, LILLIPUT_HIP_PROG_DEVICE_MAX bytes per set (default 16 GiB of the 288: 340 files of 4096 x 4096 -- the wave decoder's
+// launches last as long as their longest chain of scans whatever they hold, so the more files a set holds the better).
+static size_t prog_device_max()
+{
+    static const size_t v = getenv("LILLIPUT_HIP_PROG_DEVICE_MAX") ? (size_t)strtoull(getenv("LILLIPUT_HIP_PROG_DEVICE_MAX"), nullptr, 10) : (size_t)16 << 30;
+    return std::max(v, prog_pinned_max());
+}
 
 // Header walk of one JPEG item + the batch's size bounds. Returns LILLIPUT_OK when the item goes to the device. *pinned accumulates the
 // host coefficient bytes of the set the item joins.
-static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinned, int parsed_rc = -1000)
+static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t pinned[2], int parsed_rc = -1000, size_t scan_path_bound = 0)
 {
     const int rc = parsed_rc != -1000 ? parsed_rc : (src && len) ? lp_jpeg_parse((const uint8_t*)src, len, h) : LP_PARSE_NOT_JPEG; // (parsed_rc: the walk was done already, see pipe_stager)
     if (rc != LP_PARSE_OK) return map_parse(rc);
@@ -231,8 +239,11 @@ static int parse_item(const void* src, size_t len, LpJpegHeader* h, size_t* pinn
     if (h->scan_path) {
         size_t need = 0;
         for (int c = 0; c < h->j.ncomp; c++) need += (size_t)h->j.bw[c] * h->j.bh[c] * 128;
-        if (*pinned + need > prog_pinned_max()) return LILLIPUT_ERR_BUF_TOO_SMALL;
-        *pinned += need;
+        // (the larger bound of a set whose progressive files go to the device is for those files: QM-coded and sequential multi-scan ones stay with the host threads)
+        const bool wave_file = scan_path_bound && !h->arith && lp_jpeg_sniff_progressive((const uint8_t*)src, len);
+        size_t& held = pinned[wave_file ? 1 : 0];  // [0] what the host threads will decode into pinned memory, [1] the wave decoder's files
+        if (held + need > (wave_file ? scan_path_bound : prog_pinned_max())) return LILLIPUT_ERR_BUF_TOO_SMALL;
+        held += need;
     }
     return LILLIPUT_OK;
 }
@@ -317,7 +328,16 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     b->other.clear();
     std::vector<int> valid;
     std::vector<LpJpegHeader> hv;
-    size_t pinned = 0; // the whole upload shares the bound (its parts are cut afterwards)
+    size_t pinned[2] = {0, 0}; // the whole upload shares the bound (its parts are cut afterwards)
+    // ... the bound of what host threads decode into pinned memory at upload time. A set whose progressive files go to the device's wave decoder
+    // (lp_prog_host.h: forced, or enough of them in the upload) pins nothing and keeps only compressed bytes resident -- the run's launches bound
+    // their own arenas (auto_chunk) -- so it may hold any number of them.
+    uint32_t nprog = 0;
+    const int prog_mode = lp_prog_entropy_mode();
+    if (prog_mode != 0)
+        for (size_t i = 0; i < n; i++) nprog += lp_jpeg_sniff_progressive((const uint8_t*)items[i].src, items[i].src_len) ? 1u : 0u;
+    const bool prog_on_device = prog_mode > 0 || (prog_mode < 0 && nprog >= lp_prog_device_min_images());
+    const size_t scan_path_bound = prog_on_device ? (size_t)1 << 60 : 0;
     for (size_t i = 0; i < n; i++) {
         const uint8_t* sp = (const uint8_t*)items[i].src;
         if (is_other_format(sp, items[i].src_len)) {
@@ -326,7 +346,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
             continue;
         }
         LpJpegHeader h;
-        b->parse_status[i] = parse_item(items[i].src, items[i].src_len, &h, &pinned);
+        b->parse_status[i] = parse_item(items[i].src, items[i].src_len, &h, pinned, -1000, scan_path_bound);
         if (b->parse_status[i] == LILLIPUT_OK) { valid.push_back((int)i); hv.push_back(h); }
     }
     for (auto& o : b->other) o.data = o.copy.data();
@@ -345,6 +365,7 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
         if (p.items.empty()) continue;
         std::vector<LpJpegSrc> srcs;
         for (int it : p.items) srcs.push_back(LpJpegSrc{(const uint8_t*)items[it].src, items[it].src_len});
+        p.eng->set_progressive_in_call(nprog); // every part takes the route the whole upload was admitted for
         int rc = p.eng->upload_jpegs(srcs.data(), (int)srcs.size(), p.hdrs.data());
         if (rc) { lp_set_error(p.eng->last_error()); return map_status(rc); }
     }
@@ -938,6 +959,7 @@ struct LpPipeJob {
 // The cursors are plain host atomics: one process drives every device of the node, no message crosses between them.
 struct LpPipeShared {
     std::vector<LpPipeJob> jobs;
+    size_t scan_path_bound = 0;         // int16 coefficient bytes of scan-path files one chunk may hold (set before the chunks are cut; 0 until then)
     struct Share { std::atomic<size_t> next{0}; size_t end = 0; };
     std::unique_ptr<Share[]> share;     // [n_share]: share k = jobs [share[k].next, share[k].end)
     size_t n_share = 1;
@@ -1016,7 +1038,7 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
         job.part = (int)(&part - b->parts.data()) + 16 * b->node_index;
         const int slot = (int)(k % LP_UPLOAD_SLOTS);
         try {
-            size_t pinned = 0;
+            size_t pinned[2] = {0, 0};
             // The header walks of a chunk whose files are expensive to walk (a progressive file's scans are found by reading through its
             // entropy-coded bytes: ~0.1 ms per 1024 x 1024 file, 7 ms of a 64-file chunk's ingest) are spread over a few helpers; the walk of
             // a baseline file ends at its first scan and is not worth a thread.
@@ -1045,7 +1067,7 @@ static void pipe_stager(LpBatch* b, LpBatch* res, LpBatchPart& part, LpPipe& pp,
                 const bool pre = !walked_rc.empty() && walked_rc[i - job.i0] != -1000;
                 if (pre) job.hdrs.emplace_back(std::move(walked[i - job.i0]));
                 else job.hdrs.emplace_back();
-                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), &pinned, pre ? walked_rc[i - job.i0] : -1000);
+                const int st = parse_item(items[i].src, items[i].src_len, &job.hdrs.back(), pinned, pre ? walked_rc[i - job.i0] : -1000, sh.scan_path_bound);
                 res->status[i] = st;
                 if (st != LILLIPUT_OK) { job.hdrs.pop_back(); continue; }
                 job.items.push_back((int)i);
@@ -1177,12 +1199,14 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
         const size_t chunk_max = grow ? std::max(chunk, std::min<size_t>(1024, (n + engines - 1) / engines)) : chunk;
         std::vector<std::unique_ptr<LpPipe>> pipes;
         LpPipeShared sh;
+        sh.scan_path_bound = prog_pinned_max();
         const bool prog_on_device_possible = lp_prog_entropy_mode() != 0;
         if (prog_on_device_possible) { // how many progressive files the call holds: the engines' host / device choice (lp_prog_host.h)
             uint32_t nprog = 0;
             for (size_t i = 0; i < n; i++) nprog += lp_jpeg_sniff_progressive((const uint8_t*)items[i].src, items[i].src_len) ? 1u : 0u;
             for (LpBatch* d : devs)
                 for (auto& part : d->parts) part.eng->set_progressive_in_call(nprog / (uint32_t)devs.size());
+            if (lp_prog_entropy_mode() > 0 || nprog / (uint32_t)devs.size() >= lp_prog_device_min_images()) sh.scan_path_bound = prog_device_max(); // the engines will take the device route
         }
         for (size_t i = 0; i < n;) { // chunks of at most `chunk` items and 1 GiB of encoded bytes (the frame sizes are only known after the header walk)
             LpPipeJob job;
@@ -1190,11 +1214,15 @@ static int transform_on(const std::vector<LpBatch*>& devs, lilliput_batch_item* 
             size_t bytes = 0, cnt = 0;
             // (a progressive file counts a sixteenth of its bytes: the device walks its scans one wave each, in a time that does not depend
             // on how many files the chunk holds -- the more of them are in flight, the better; lp_kernels_prog.hip)
-            auto weight = [&](size_t k) { return prog_on_device_possible && lp_jpeg_sniff_progressive((const uint8_t*)items[k].src, items[k].src_len) ? items[k].src_len / 16 + 1 : items[k].src_len; };
+            // ... and a chunk never holds more progressive files than the set's coefficient bound lets through (parse_item): the files beyond it
+            // open the next chunk instead of answering ErrBufTooSmall (1 024 progressive files of 4096 x 4096 in one call: 340 served, round 6)
+            uint64_t coef = 0, need = 0;
+            auto weight = [&](size_t k) { return lp_jpeg_sniff_progressive((const uint8_t*)items[k].src, items[k].src_len, &need) && prog_on_device_possible ? items[k].src_len / 16 + 1 : items[k].src_len; };
             while (i < n) {
                 const size_t w = weight(i);
                 if (!(cnt < chunk ? (cnt == 0 || bytes + w <= (1ull << 30)) : (cnt < chunk_max && bytes + w <= pipe_chunk_bytes))) break;
-                bytes += w; cnt++; i++;
+                if (cnt && need && coef + need > sh.scan_path_bound) break;
+                bytes += w; cnt++; i++; coef += need;
             }
             job.i1 = i;
             sh.jobs.push_back(std::move(job));

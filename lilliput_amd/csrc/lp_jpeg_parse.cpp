@@ -618,15 +618,32 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
 // A look at the frame header only (segment lengths, no entropy-coded byte is touched): is this a progressive (SOF2) Huffman-coded JPEG?
 // The batch front end sizes its chunks with it before the real header walk: the device decodes such files one wave per scan, at a
 // latency that does not depend on how many of them a chunk holds.
-bool lp_jpeg_sniff_progressive(const uint8_t* d, size_t n)
+bool lp_jpeg_sniff_progressive(const uint8_t* d, size_t n, uint64_t* coef_bytes)
 {
+    if (coef_bytes) *coef_bytes = 0;
     if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
     size_t i = 2;
     while (i + 4 <= n) {
         if (d[i] != 0xFF) return false;
         const unsigned m = d[i + 1];
         if (m == 0xFF) { i++; continue; }
-        if (m == 0xC2) return true;
+        if (m == 0xC2) {
+            // the int16 coefficient bytes the frame header asks for (what lp_jpeg_parse's geometry gives: every component's MCU-padded blocks x 128)
+            if (coef_bytes && i + 10 <= n) {
+                const size_t h = ((size_t)d[i + 5] << 8) | d[i + 6], w = ((size_t)d[i + 7] << 8) | d[i + 8], nc = d[i + 9];
+                if (nc >= 1 && nc <= 4 && i + 10 + 3 * nc <= n) {
+                    size_t hmax = 1, vmax = 1, blocks_per_mcu = 0;
+                    for (size_t c = 0; c < nc; c++) {
+                        const size_t hs = d[i + 11 + 3 * c] >> 4, vs = d[i + 11 + 3 * c] & 15;
+                        hmax = hs > hmax ? hs : hmax; vmax = vs > vmax ? vs : vmax;
+                        blocks_per_mcu += hs * vs;
+                    }
+                    const size_t mx = (w + 8 * hmax - 1) / (8 * hmax), my = (h + 8 * vmax - 1) / (8 * vmax);
+                    *coef_bytes = (uint64_t)mx * my * blocks_per_mcu * 128;
+                }
+            }
+            return true;
+        }
         if (m == 0xDA || m == 0xD9 || (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false;
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
         i += 2 + (((size_t)d[i + 2] << 8) | d[i + 3]);

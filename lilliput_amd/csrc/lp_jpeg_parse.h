@@ -60,4 +60,4 @@ extern const uint8_t lp_std_huff_ac_luma[162];
 extern const uint8_t lp_std_huff_ac_chroma[162];
 
 // frame-header sniff (no entropy-coded byte read): a progressive (SOF2) Huffman-coded file?
-bool lp_jpeg_sniff_progressive(const uint8_t* data, size_t len);
+bool lp_jpeg_sniff_progressive(const uint8_t* data, size_t len, uint64_t* coef_bytes = nullptr); // coef_bytes: the int16 coefficient bytes its frame header asks for

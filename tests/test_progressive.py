@@ -241,6 +241,42 @@ def test_progressive_through_the_go_api_mirror(hip_lib, oracle, mode):
 
 
 @pytest.mark.gpu
+def test_a_call_with_more_progressive_files_than_one_set_may_hold_is_cut_into_chunks(oracle, tmp_path):
+    """lilliput_hip_batch_transform with more progressive files than LILLIPUT_HIP_PROG_PINNED_MAX / _DEVICE_MAX bytes of int16 coefficients let into one
+    upload set (defaults 4 / 16 GiB: 85 / 340 files of 4096 x 4096): the files beyond the bound open the next chunk -- until late round 6 they
+    answered ErrBufTooSmall (1 024 such files in one call: 340 served). A child process with bounds of three 256 x 192 files' worth, host and
+    device routes: every item served, every output the oracle's."""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(11)
+    files = []
+    for i in range(14):
+        buf = io.BytesIO()
+        PIL.fromarray(_photo(rng, 192, 256, False)).save(buf, "JPEG", quality=85, progressive=True, subsampling=2)
+        files.append(buf.getvalue())
+        open(os.path.join(tmp_path, "p%02d.jpg" % i), "wb").write(files[-1])
+    bound = 3 * (16 * 12 * 6 * 128) + 100   # 256 x 192 at 4:2:0 = 16 x 12 MCUs of six blocks, 128 bytes of int16 per block
+    child = (
+        "import glob, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import lilliput_amd as la\n"
+        "fs = [open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(%r, 'p*.jpg')))]\n"
+        "b = la.Batch(0)\n"
+        "r = b.transform(fs, 64, 64, quality=85)\n"
+        "assert all(x.status == 0 for x in r), [x.status for x in r]\n"
+        "[open(os.path.join(%r, 'o%%02d_%%s.jpg' %% (i, os.environ['LILLIPUT_HIP_PROG_ENTROPY'])), 'wb').write(x.data) for i, x in enumerate(r)]\n"
+        "b.close()\n") % (ROOT, str(tmp_path), str(tmp_path))
+    want = [oracle.transform_jpeg_thumbnail(f, 64, 64, 85) for f in files]
+    for mode in ("host", "device"):
+        env = dict(os.environ, LILLIPUT_HIP_PROG_PINNED_MAX=str(bound), LILLIPUT_HIP_PROG_DEVICE_MAX=str(bound), LILLIPUT_HIP_PROG_ENTROPY=mode)
+        p = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        for i, w in enumerate(want):
+            assert open(os.path.join(tmp_path, "o%02d_%s.jpg" % (i, mode)), "rb").read() == w, (mode, i)
+
+
+@pytest.mark.gpu
 def test_progressive_large_image(batch, oracle):
     """2048 x 1536, 4:2:0, ten scans: whole-image equality with the oracle plus the thumbnail (default mode; the device-lane mode
     is covered at smaller sizes above -- it needs seconds for an image this large)."""
