@@ -812,7 +812,9 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // ... and a small launch may go below the one-image floor when MORE verify rounds are queued behind it (vr_: an idle round costs
         // ~4 us, a host-driven second pass ~0.8 ms): LILLIPUT_HIP_SMALL_S / LILLIPUT_HIP_SMALL_ROUNDS, measured in profiles/r06_one_image.md
         static const uint32_t small_S = getenv("LILLIPUT_HIP_SMALL_S") ? (uint32_t)atoi(getenv("LILLIPUT_HIP_SMALL_S")) : 2048u;
-        static const uint32_t small_rounds = getenv("LILLIPUT_HIP_SMALL_ROUNDS") ? (uint32_t)std::min(LP_VERIFY_MAX, std::max(1, atoi(getenv("LILLIPUT_HIP_SMALL_ROUNDS")))) : (uint32_t)LP_VERIFY_ROUNDS;
+        static const uint32_t small_rounds = getenv("LILLIPUT_HIP_SMALL_ROUNDS") ? (uint32_t)std::min(LP_VERIFY_MAX, std::max(1, atoi(getenv("LILLIPUT_HIP_SMALL_ROUNDS")))) : 6u;
+        // (six since late round 6: with four, 40 % of 4096 x 4096 q90 sources -- 16 k lanes of 2 048 bits -- still moved an exit state in the fourth round and
+        // paid the host-driven pass and the second decode: a lone call 2.7 ms instead of 1.1; two idle rounds cost 9 us. profiles/r06_one_image.md)
         const bool small_launch = bits <= defer_small_bits;
         vr_ = small_launch ? small_rounds : (uint32_t)LP_VERIFY_ROUNDS;
         const uint32_t floor_S = small_launch ? std::min(min_S, small_S) : defer ? std::max(min_S, 4096u) : min_S;
