@@ -263,6 +263,15 @@ def make_roofline(excl, kernels, per_rank_images, c_in, c_out, args, streams, br
             "per_kernel_in_timed_region": breakdown}
 
 
+def redone_count(la):
+    """lilliput_hip_decode_redone_count: launches whose queued verify rounds did not settle (decoded a second time)."""
+    import ctypes
+
+    f = la.lib().lilliput_hip_decode_redone_count
+    f.restype = ctypes.c_uint64
+    return int(f())
+
+
 def main_abi(args, ranks, la):
     """The drop-in path under service concurrency: N OS threads, each with its own ImageOps, each NewDecoder -> Header -> Transform ->
     Close per request through Part C of the C ABI (lilliput_amd/csrc/lp_service_sim.c; README.md:82-85, opencv.go:816-839) on the
@@ -288,6 +297,7 @@ def main_abi(args, ranks, la):
             la.service_sim(distinct, t, min(jobs, max(8 * t, 512)), args.out, args.out, 85, la.ImageOpsFit, keep=False, part=args.part)
         el, ok, lat, outs, err = 0.0, 0, [], None, 0
         cpu0, thr0 = cgroup_cpu_stat()
+        redone0 = redone_count(la)
         for k in range(args.steps):
             ranks.barrier()
             r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1), part=args.part)
@@ -311,7 +321,8 @@ def main_abi(args, ranks, la):
         by_threads[str(t)] = {"images_per_s": round(v, 1), "ok": ok, "requests": jobs * args.steps, "first_error": err, "latency_ms_p50": round(float(np.percentile(lat, 50)), 3),
                               "latency_ms_p99": round(float(np.percentile(lat, 99)), 3), "verified": checked,
                               "host_cpu_ms_per_request": None if cpu0 is None else round(1e3 * (cpu1 - cpu0) / max(1, jobs * args.steps), 3),
-                              "host_cpus_busy": None if cpu0 is None else round((cpu1 - cpu0) / max(1e-9, el), 2), "throttled_periods": None if thr0 is None else thr1 - thr0}
+                              "host_cpus_busy": None if cpu0 is None else round((cpu1 - cpu0) / max(1e-9, el), 2), "throttled_periods": None if thr0 is None else thr1 - thr0,
+                              "decode_launches_redone": redone_count(la) - redone0}
         if v > best_v:
             best_t, best_v, best_elapsed = t, v, el
     import ctypes
@@ -1198,7 +1209,8 @@ def main():
                                            "outputs of the last timed step picked by sha256(step:rank:j)" + (" -- of BOTH legs: the resident one and the end-to-end one" if e2e is not None else ""),
                        "end_to_end_algorithmic_bytes_per_image": int(e2e_bytes),
                        "end_to_end_hbm_roofline_frac": round(e2e_bytes * value / world / (HBM_PEAK_GBS * 1e9), 5),
-                       "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps)},
+                       "verify_rounds": stage.get("verify_rounds", 0) / max(1, args.steps),
+                       "decode_launches_redone": redone_count(la)},
             "roofline": roof,
         }
         if args.resident:

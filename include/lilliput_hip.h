@@ -502,6 +502,11 @@ int lilliput_hip_progressive_device_lanes_built(void);
 /* Process-wide counters since start: out[0] scan-path images whose scans were decoded on the device, out[1] those of them the device decoders
  * gave up on (irregular data: decoded again by the host threads), out[2] scans launched on the device. */
 void lilliput_hip_progressive_stats(uint64_t out[3]);
+/* Launches of the baseline entropy decoder whose queued verify rounds (4 behind a large launch, 6 behind a small one: LILLIPUT_HIP_VERIFY_ROUNDS /
+ * LILLIPUT_HIP_SMALL_ROUNDS) did not settle every subsequence's exit state: they continued under host control and ran the stages behind the
+ * verification -- and, in the batched path, the chunk -- a second time. Process-wide, since load. A service whose sources make this number grow
+ * with its request count should raise the variables (an idle round costs ~5 us per launch). */
+uint64_t lilliput_hip_decode_redone_count(void);
 /* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
  * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
  * -3 = dst too small. nthreads 0 = default. */

@@ -816,7 +816,8 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
         // (six since late round 6: with four, 40 % of 4096 x 4096 q90 sources -- 16 k lanes of 2 048 bits -- still moved an exit state in the fourth round and
         // paid the host-driven pass and the second decode: a lone call 2.7 ms instead of 1.1; two idle rounds cost 9 us. profiles/r06_one_image.md)
         const bool small_launch = bits <= defer_small_bits;
-        vr_ = small_launch ? small_rounds : (uint32_t)LP_VERIFY_ROUNDS;
+        static const uint32_t big_rounds = getenv("LILLIPUT_HIP_VERIFY_ROUNDS") ? (uint32_t)std::min(LP_VERIFY_MAX, std::max(1, atoi(getenv("LILLIPUT_HIP_VERIFY_ROUNDS")))) : (uint32_t)LP_VERIFY_ROUNDS;
+        vr_ = small_launch ? small_rounds : big_rounds;
         const uint32_t floor_S = small_launch ? std::min(min_S, small_S) : defer ? std::max(min_S, 4096u) : min_S;
         // Small files (round 5): pick_S sizes by the largest file alone and hands 1 024 or 256 bits to sources of a few KB -- whose
         // entropy streams then need a verify round per subsequence the self-synchronisation distance spans (22 rounds for 128 x 128
@@ -1134,6 +1135,10 @@ int LpEngine::run_decode(int first, int n, LpFrame* frames, int* status, const u
 // Second half of a decode: wait for the stream, finish the verification under host control if the enqueued rounds did not settle
 // it (then everything behind the verify stage is enqueued again), and turn the per-image device states into statuses.
 // Returns LP_RETRY when a deferred decode had to redo its tail: what the caller enqueued behind it read unfinished planes.
+// launches whose queued verify rounds did not settle the exit states (host-driven rounds + the stages behind them once more + LP_RETRY): process-wide
+static std::atomic<uint64_t> g_decode_redone{0};
+extern "C" uint64_t lilliput_hip_decode_redone_count() { return g_decode_redone.load(std::memory_order_relaxed); }
+
 int LpEngine::finish_decode(int* status)
 {
     if (!pend_.active) return LP_ERR_DEVICE;
@@ -1205,6 +1210,7 @@ int LpEngine::finish_decode(int* status)
         (void)hipEventElapsedTime(&tm_.huff_scan_ms, ev_[9], ev_[10]);
         (void)hipEventElapsedTime(&tm_.huff_write_ms, ev_[10], ev_[2]);
     }
+    if (redone) g_decode_redone.fetch_add(1, std::memory_order_relaxed);
     return redone ? LP_RETRY : rc;
 }
 
