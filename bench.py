@@ -272,6 +272,14 @@ def redone_count(la):
     return int(f())
 
 
+def lone_count(la):
+    import ctypes
+
+    f = la.lib().lilliput_hip_lone_batch_count
+    f.restype = ctypes.c_uint64
+    return int(f())
+
+
 def main_abi(args, ranks, la):
     """The drop-in path under service concurrency: N OS threads, each with its own ImageOps, each NewDecoder -> Header -> Transform ->
     Close per request through Part C of the C ABI (lilliput_amd/csrc/lp_service_sim.c; README.md:82-85, opencv.go:816-839) on the
@@ -298,6 +306,7 @@ def main_abi(args, ranks, la):
         el, ok, lat, outs, err = 0.0, 0, [], None, 0
         cpu0, thr0 = cgroup_cpu_stat()
         redone0 = redone_count(la)
+        lone0 = lone_count(la)
         for k in range(args.steps):
             ranks.barrier()
             r = la.service_sim(distinct, t, jobs, args.out, args.out, 85, la.ImageOpsFit, keep=(k == args.steps - 1), part=args.part)
@@ -322,7 +331,7 @@ def main_abi(args, ranks, la):
                               "latency_ms_p99": round(float(np.percentile(lat, 99)), 3), "verified": checked,
                               "host_cpu_ms_per_request": None if cpu0 is None else round(1e3 * (cpu1 - cpu0) / max(1, jobs * args.steps), 3),
                               "host_cpus_busy": None if cpu0 is None else round((cpu1 - cpu0) / max(1e-9, el), 2), "throttled_periods": None if thr0 is None else thr1 - thr0,
-                              "decode_launches_redone": redone_count(la) - redone0}
+                              "decode_launches_redone": redone_count(la) - redone0, "served_on_the_callers_thread": lone_count(la) - lone0}
         if v > best_v:
             best_t, best_v, best_elapsed = t, v, el
     import ctypes

@@ -507,6 +507,9 @@ void lilliput_hip_progressive_stats(uint64_t out[3]);
  * verification -- and, in the batched path, the chunk -- a second time. Process-wide, since load. A service whose sources make this number grow
  * with its request count should raise the variables (an idle round costs ~5 us per launch). */
 uint64_t lilliput_hip_decode_redone_count(void);
+/* Requests served on their caller's own thread as a resident batch of one (deferred Part A chains and Part C calls without company:
+ * LILLIPUT_HIP_DEFER_INLINE, _INLINE_MAX), process-wide, since load -- the others went through the dispatchers' shared launches. */
+uint64_t lilliput_hip_lone_batch_count(void);
 /* Test access (no device work): component `comp` of a progressive JPEG as the host threads decode it, [block row][block column][64]
  * natural-order coefficients over the MCU-padded grid. 0 = ok, -1 = not an accepted progressive JPEG, -2 = restart-marker overflow,
  * -3 = dst too small. nthreads 0 = default. */

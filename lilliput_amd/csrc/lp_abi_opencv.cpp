@@ -468,8 +468,11 @@ bool lp_lone_batch_enabled()
     static const bool on = !(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED") && atoi(getenv("LILLIPUT_HIP_DEFER_INLINE_FUSED")) == 0);
     return on;
 }
+static std::atomic<uint64_t> g_lone_batches{0};
+extern "C" uint64_t lilliput_hip_lone_batch_count() { return g_lone_batches.load(std::memory_order_relaxed); }
 int lp_lone_batch_transform(int device, const void* src, size_t len, void* dst, size_t cap, const lilliput_batch_options& bo, size_t* out_len)
 {
+    g_lone_batches.fetch_add(1, std::memory_order_relaxed);
     *out_len = 0;
     if (!src || !len || !dst || !cap) return LILLIPUT_ERR_INVALID_IMAGE;
     LoneBatchLease lb(device);
