@@ -426,23 +426,39 @@ int lp_part_a_in_flight() { return g_part_a_in_flight.load(std::memory_order_rel
 // kernels, one deferred status fetch, no frame in between) on a batch object from a small pool -- at most LILLIPUT_HIP_DEFER_INLINE_MAX are in
 // use at once, so that many idle ones are kept (engine, streams and one image's arenas each); never destroyed, like the engine pool.
 namespace {
+struct LoneBatch { int dev; unsigned index; lilliput_hip_batch b; };
 struct LoneBatchPool {
     std::mutex mu;
-    std::vector<std::pair<int, lilliput_hip_batch>> idle;
+    std::vector<LoneBatch> idle;
+    unsigned made[64] = {0};    // per device: batches created so far (their index)
 };
 LoneBatchPool& lone_pool() { static LoneBatchPool* p = new LoneBatchPool(); return *p; }
+// The runtime maps a process's streams onto FOUR hardware queues per stream priority; two one-image chains on one queue run one after the other
+// (eight lone callers: 2.3 k images/s where 4.3 k are possible, profiles/r06_part_a.md section 6). The pool therefore builds its first four batches of a
+// device on streams of the default priority and the next four on the highest -- the second pool of queues -- and hands out the idle batch with the
+// lowest index, so that up to four callers never meet the other priority (two callers, one on each: 1.2 k against 1.7 k). LILLIPUT_HIP_LONE_PRIORITY=0: all default.
 struct LoneBatchLease {
     int dev;
+    unsigned index = 0;
     lilliput_hip_batch b = nullptr;
     explicit LoneBatchLease(int device) : dev(device)
     {
         LoneBatchPool& P = lone_pool();
         {
             std::lock_guard<std::mutex> lk(P.mu);
-            for (size_t i = P.idle.size(); i-- > 0;)
-                if (P.idle[i].first == dev) { b = P.idle[i].second; P.idle.erase(P.idle.begin() + (long)i); break; }
+            size_t best = P.idle.size();
+            for (size_t i = 0; i < P.idle.size(); i++)
+                if (P.idle[i].dev == dev && (best == P.idle.size() || P.idle[i].index < P.idle[best].index)) best = i;
+            if (best < P.idle.size()) { b = P.idle[best].b; index = P.idle[best].index; P.idle.erase(P.idle.begin() + (long)best); }
+            else index = P.made[dev & 63]++;
         }
-        if (!b) { b = lilliput_hip_batch_create(dev); lp_batch_set_stage_timing(b, false); }
+        if (!b) {
+            static const bool second_pool = !(getenv("LILLIPUT_HIP_LONE_PRIORITY") && atoi(getenv("LILLIPUT_HIP_LONE_PRIORITY")) == 0);
+            const int prev = lp_engine_stream_priority_hint(second_pool && (index & 4u) ? 1 : 0);
+            b = lilliput_hip_batch_create(dev);
+            lp_engine_stream_priority_hint(prev);
+            lp_batch_set_stage_timing(b, false);
+        }
     }
     ~LoneBatchLease()
     {
@@ -450,7 +466,7 @@ struct LoneBatchLease {
         LoneBatchPool& P = lone_pool();
         {
             std::lock_guard<std::mutex> lk(P.mu);
-            if (P.idle.size() < 16) { P.idle.emplace_back(dev, b); b = nullptr; }
+            if (P.idle.size() < 16) { P.idle.push_back(LoneBatch{dev, index, b}); b = nullptr; }
         }
         if (b) lilliput_hip_batch_destroy(b);
     }

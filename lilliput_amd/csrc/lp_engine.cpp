@@ -232,11 +232,26 @@ LpEngine::LpEngine(int device) : device_(device)
         if (blocking && device_ < 64 && !(done_mask.fetch_or(1ull << device_) & (1ull << device_)))
             if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     }
-    if (!check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
+    // lp_engine_stream_priority_hint (lp_engine.h): the engines of the batches that serve lone callers alternate between the default and the
+    // high stream priority -- the runtime keeps a pool of hardware queues per priority, so eight such engines do not pile up on the default four
+    // (profiles/r06_part_a.md section 6)
+    const int prio_hint = lp_engine_stream_priority_hint(-1);
+    int least = 0, greatest = 0;
+    if (prio_hint > 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+        if (!check(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "hipStreamCreate")) return;
+    } else if (!check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
     if (!check(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto& e : ev_)
         if (!check(hipEventCreate(&e), "hipEventCreate")) return;
     ok_ = true;
+}
+
+int lp_engine_stream_priority_hint(int set)
+{
+    thread_local int hint = 0;
+    const int prev = hint;
+    if (set >= 0) hint = set;
+    return prev;
 }
 
 LpEngine::~LpEngine()

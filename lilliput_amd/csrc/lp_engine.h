@@ -24,6 +24,9 @@
 #include "lp_types.h"
 #include "lp_area_core.h"
 
+// The stream priority the engines this thread constructs next ask for: 0 default, 1 the device's highest. set < 0: read only. Returns the value before.
+int lp_engine_stream_priority_hint(int set);
+
 // Frees the blocks that growing arenas have retired (see LpDevBuf::ensure in lp_engine.cpp); called at the end of a batch / node call.
 void lp_retired_collect();
 
