@@ -1307,12 +1307,13 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     }
     LpMat* d = e->dst;
     const size_t cap = (size_t)(d->datalimit - d->datastart);
-    // A recorded chain that arrives while no other is being served (one goroutine, or a quiet moment) runs on the caller's own thread
-    // through the one-image route below -- no hand-over to a dispatcher thread and back, no stager / compute thread pair for a batch of
-    // one (round 6: 0.92 -> 0.7x ms for a 512 x 512 source, profiles/r06_one_image.md). LILLIPUT_HIP_DEFER_INLINE=0: always the batched path.
-    // ... "few" = at most LILLIPUT_HIP_DEFER_INLINE_MAX (default 8) requests of deferred Part A in flight, from the read_data that recorded a
-    // chain to the first time it is served: 8 callers all on their own threads 3.0 k images/s, all through the dispatchers 2.5 k; 16 callers 4.0 / 4.3 k;
-    // 64 callers 8 / 10 k -- and a mix of the two routes is slower than either.
+    // A recorded chain that arrives while few others are in flight and the dispatchers are idle (a handful of goroutines, or a quiet moment) runs on
+    // the caller's own thread as a resident batch of one (lp_lone_batch_transform) -- no hand-over to a dispatcher thread and back, no stager /
+    // compute thread pair (profiles/r06_one_image.md). LILLIPUT_HIP_DEFER_INLINE=0: always through the dispatchers.
+    // "few" = at most LILLIPUT_HIP_DEFER_INLINE_MAX (default 8) requests of deferred Part A in flight, from the read_data that recorded a chain to the
+    // first time it is served; "idle" = nothing queued for or inside a dispatcher, so the first request that goes there pulls the ones behind it
+    // along: 8 callers all on their own threads 4.1 k images/s, all through the dispatchers 2.5 k; 64 callers 8 / 10 k -- and a mix of the two routes
+    // is slower than either (profiles/r06_part_a.md sections 4-6).
     const bool lone = s->lazy && defer_inline_on() && lp_part_a_in_flight() <= lp_lone_inline_max() && lp_coalesce_busy() == 0;
     struct ServedScope { LpLazySrc* p; ~ServedScope() { if (p) p->leave(); } } served_scope{s->lazy ? s->lazy->src.get() : nullptr};
     std::shared_ptr<LpLazySrc> keep_src = s->lazy ? s->lazy->src : nullptr; // (the scope's pointer stays valid)
