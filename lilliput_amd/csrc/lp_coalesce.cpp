@@ -34,6 +34,10 @@ int threshold() { static const int v = env_int("LILLIPUT_HIP_COALESCE", 3, 0, 1 
 int n_workers() { static const int v = env_int("LILLIPUT_HIP_COALESCE_WORKERS", 4, 1, 16); return v; }
 int idle_ms() { static const int v = env_int("LILLIPUT_HIP_COALESCE_IDLE_MS", 1000, 1, 1 << 30); return v; }
 size_t max_take() { static const int v = env_int("LILLIPUT_HIP_COALESCE_MAX", 16, 1, 1024); return (size_t)v; }
+// Dispatchers beyond the first n_workers() that join in only while at least extra_at() requests are WAITING (about 128 in flight with the defaults):
+// four dispatchers serve 12 ... 64 callers best, six to eight serve 256 best -- 9.9-10.1 k against 11.8-12.5 k images/s (profiles/r06_part_a.md section 7)
+int n_extra() { static const int v = env_int("LILLIPUT_HIP_COALESCE_EXTRA", 4, 0, 16); return v; }
+size_t extra_at() { static const int v = env_int("LILLIPUT_HIP_COALESCE_EXTRA_AT", 64, 1, 1 << 20); return (size_t)v; }
 
 struct Req {
     const void* src; size_t len; void* dst; size_t cap;
@@ -56,14 +60,16 @@ struct Dispatch {
     int device;
     std::mutex mu;
     std::condition_variable cv;
+    std::condition_variable cv_extra;   // the extra dispatchers wait here (see n_extra)
     std::deque<Req*> q;
     std::vector<std::thread> th;
     bool stop = false;
 
     explicit Dispatch(int dev) : device(dev) {}
 
-    void body()
+    void body(bool extra = false)
     {
+        std::condition_variable& cv = extra ? cv_extra : this->cv;
         LpCoalesceSuppress inner; // whatever this batch calls back into the one-image path stays on this thread
         lilliput_hip_batch batch = nullptr;
         std::vector<Req*> take;
@@ -74,9 +80,9 @@ struct Dispatch {
                 std::unique_lock<std::mutex> lk(mu);
                 // an idle dispatcher gives its batch -- engines, streams, the arenas of its largest chunk -- back after a while: what the
                 // process holds follows the calls in flight, as with the engine pool of the direct route
-                while (!stop && q.empty()) {
+                while (!stop && (extra ? q.size() < extra_at() : q.empty())) {
                     if (!batch) { cv.wait(lk); continue; }
-                    if (cv.wait_for(lk, std::chrono::milliseconds(idle_ms())) == std::cv_status::timeout && q.empty() && !stop) {
+                    if (cv.wait_for(lk, std::chrono::milliseconds(idle_ms())) == std::cv_status::timeout && (extra ? q.size() < extra_at() : q.empty()) && !stop) {
                         lk.unlock();
                         lilliput_hip_batch_destroy(batch);
                         batch = nullptr;
@@ -119,11 +125,13 @@ struct Dispatch {
     void start()
     {
         for (int i = 0; i < n_workers(); i++) th.emplace_back([this] { body(); });
+        for (int i = 0; i < n_extra(); i++) th.emplace_back([this] { body(true); });
     }
     void shutdown()
     {
         { std::lock_guard<std::mutex> lk(mu); if (stop) return; stop = true; }
         cv.notify_all();
+        cv_extra.notify_all();
         for (auto& t : th) t.join();
         th.clear();
         // requests that were still queued: back to their callers, who take the direct route
@@ -256,13 +264,14 @@ int lp_coalesce_transform_status(int device, const void* src, size_t len, void* 
     size_t cls = 0;
     void* slot = lilliput_hip_host_is_pinned(src, len) ? nullptr : stage_acquire(device, len, &cls);
     if (slot) { memcpy(slot, src, len); r.src = slot; }
-    bool queued = false;
+    bool queued = false, many = false;
     {
         std::lock_guard<std::mutex> lk(D->mu);
-        if (!D->stop) { D->q.push_back(&r); queued = true; }
+        if (!D->stop) { D->q.push_back(&r); queued = true; many = D->q.size() >= extra_at(); }
     }
     if (queued) {
         D->cv.notify_one();
+        if (many) D->cv_extra.notify_one();
         std::unique_lock<std::mutex> lk(r.mu);
         r.cv.wait(lk, [&] { return r.done; });
     }

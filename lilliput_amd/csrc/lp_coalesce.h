@@ -12,6 +12,7 @@
 // an item the batch does not answer with LILLIPUT_OK is run again on the direct route, so error behaviour is the direct route's.
 //   LILLIPUT_HIP_COALESCE          = n: coalesce once n Transform calls are in flight (default 3; 0 = never)
 //   LILLIPUT_HIP_COALESCE_WORKERS  = dispatcher threads per device (default 4)
+//   LILLIPUT_HIP_COALESCE_EXTRA    = dispatcher threads per device that take requests only while LILLIPUT_HIP_COALESCE_EXTRA_AT (64) are waiting (default 4)
 //   LILLIPUT_HIP_COALESCE_MAX      = requests per dispatch (default 32)
 //   LILLIPUT_HIP_COALESCE_IDLE_MS  = an idle dispatcher destroys its batch (engines, arenas) after this long (default 1000)
 //   LILLIPUT_HIP_COALESCE_PINNED_MB = pinned staging slots the callers copy their sources into before queueing (default 0 = none: measured a loss
