@@ -721,6 +721,36 @@ def test_part_a_call_sequence_of_ops_go_deferred_and_eager(hip_lib, oracle, fixt
 
 
 @pytest.mark.gpu
+def test_a_crowd_of_callers_goes_through_the_dispatchers_that_join_under_load(hip_lib, oracle, fixture_bytes):
+    """160 OS threads at once through Part A and Part C (lp_service_sim.c): with at least 64 requests waiting, the dispatchers that only join in
+    under load (lp_coalesce.cpp n_extra, round 6) take requests too; few callers are served on their own threads as resident batches of one
+    (lilliput_hip_lone_batch_count moves), a crowd is not. Every response is what the batched path gives for that source -- byte for byte --
+    whoever served it."""
+    import ctypes as C
+
+    import lilliput_amd as la
+
+    names = [n for n in sorted(fixture_bytes) if n.endswith(".jpg")][:6]
+    sources = [fixture_bytes[n] for n in names]
+    b = la.Batch(0)
+    want = [r.data for r in b.transform(sources, 96, 96, method=la.ImageOpsFit, quality=85)]
+    b.close()
+    lone = hip_lib.lilliput_hip_lone_batch_count
+    lone.restype = C.c_uint64
+    for part in ("A", "C"):
+        n0 = lone()
+        r = la.service_sim(sources, 2, 4 * len(sources), 96, 96, 85, la.ImageOpsFit, max_size=4096, keep=True, part=part)
+        assert r["ok"] == r["jobs"], (part, r["first_error"])
+        assert [bytes(o) for o in r["outputs"]] == want, part
+        n1 = lone()
+        assert n1 - n0 >= len(sources), (part, "two callers are served on their own threads")
+        r = la.service_sim(sources, 160, 160 * 12, 96, 96, 85, la.ImageOpsFit, max_size=4096, keep=True, part=part)
+        assert r["ok"] == r["jobs"], (part, r["first_error"])
+        assert [bytes(o) for o in r["outputs"]] == want, part
+        assert lone() - n1 < 160 * 12 // 2, (part, "a crowd shares the dispatchers' launches")
+
+
+@pytest.mark.gpu
 def test_deferred_mats_materialise_for_anyone_who_looks(hip_lib, oracle, fixture_bytes):
     """A recorded chain is run the eager way as soon as something other than the JPEG encoder needs the pixels: opencv_mat_get_data on
     the decoded / oriented / resized framebuffer returns the reference's pixels; a decoder closed before the chain ran leaves the chain
