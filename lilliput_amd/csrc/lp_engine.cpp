@@ -486,10 +486,11 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
             j.raw_len = 0;
             u.pcoef_off[(size_t)i] = u.pcoef_total;
             for (int c = 0; c < j.ncomp; c++) u.pcoef_total += (size_t)j.bw[c] * j.bh[c] * 64;
+            const size_t coef_elems = u.pcoef_total - u.pcoef_off[(size_t)i];
             lp_prog_levels(hdrs[i].scans, lev);
             if (hdrs[i].decode_fails) u.perr[(size_t)i] |= 8u; // a multi-scan file without its EOI: the reference's read_data fails (lp_jpeg_parse.h)
             for (size_t q = 0; q < hdrs[i].scans.size(); q++)
-                u.host_tasks.push_back(LpProgHostTask{srcs[i].data, srcs[i].len, &hdrs[i].scans[q], nullptr, lev[q], &u.perr[(size_t)i], !hdrs[i].one_pass});
+                u.host_tasks.push_back(LpProgHostTask{srcs[i].data, srcs[i].len, &hdrs[i].scans[q], nullptr, lev[q], &u.perr[(size_t)i], !hdrs[i].one_pass, coef_elems});
         } else if (hdrs[i].scan_path) { // every scan is a stream of its own
             j.raw_len = 0;
             lp_prog_levels(hdrs[i].scans, lev);

@@ -1231,6 +1231,10 @@ struct DevProgMem {
     int16_t* coef;  // the image's first block
     int16_t* stage; // this lane's 128 bytes of LDS: the block an AC refinement is working on
     uint64_t dirty; // elements changed since open(): only those go back -- other scans of the same level own the rest of the block
+    uint32_t* err;  // the error word of the scan's pseudo stream (LpJpegState::error)
+    // the scan stored outside its band (damaged data, lp_prog_core.h lp_prog_stray): what libjpeg makes of that depends on the order of the
+    // scans in the file -- the image goes to the host route, like everything else the device decoders call irregular
+    __device__ __forceinline__ void stray() { atomicOr(err, LP_PROG_IRREGULAR); }
     __device__ __forceinline__ uint32_t word(uint32_t w) const { return w < cap ? words[w] : 0u; }
     __device__ __forceinline__ uint32_t rst_bit(uint32_t k) const { return rst[k]; }
     __device__ __forceinline__ uint32_t lut8(uint32_t s, uint32_t i) const { return ht->lut8[s][i]; }
@@ -1273,7 +1277,7 @@ struct DevProgMem {
 };
 
 __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__ scans, uint32_t first, uint32_t n, uint32_t lpw, uint32_t only_sequential,
-                                                  const LpJpeg* __restrict__ streams, const LpJpegState* __restrict__ stream_states,
+                                                  const LpJpeg* __restrict__ streams, LpJpegState* stream_states,
                                                   const LpProgHuff* __restrict__ huffs, const uint32_t* __restrict__ clean_arena,
                                                   const uint32_t* __restrict__ rst_arena, int16_t* __restrict__ pcoef)
 {
@@ -1284,8 +1288,9 @@ __global__ __launch_bounds__(64) void k_prog_scan(const LpProgScan* __restrict__
     const LpProgScan sc = scans[first + i];
     if (only_sequential && !sc.sequential) return; // k_prog_wave's
     const LpJpeg& stream = streams[sc.stream];
-    const LpJpegState& st = stream_states[sc.stream];
+    LpJpegState& st = stream_states[sc.stream];
     DevProgMem m;
+    m.err = &st.error;
     m.words = clean_arena + stream.clean_off;
     m.cap = stream.clean_cap_words;
     m.rst = rst_arena + stream.rst_off;
@@ -1472,7 +1477,7 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
 }
 
 void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, bool only_sequential, const LpJpeg* d_streams,
-                          const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
+                          LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef)
 {
     if (!n) return;
     if (lpw < 1) lpw = 1;

@@ -54,7 +54,7 @@ void lp_launch_idct(hipStream_t s, const LpJpeg* d_imgs, const LpJpegState* d_st
 // progressive scans [first, first + n) of d_scans (one dependency level): lane = scan, `lpw` lanes per 64-thread workgroup
 // only_sequential: skip the progressive scans (lp_launch_prog_wave takes them)
 void lp_launch_prog_scans(hipStream_t s, const LpProgScan* d_scans, uint32_t first, uint32_t n, uint32_t lpw, bool only_sequential, const LpJpeg* d_streams,
-                          const LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
+                          LpJpegState* d_stream_states, const LpProgHuff* d_huffs, const uint32_t* d_clean, const uint32_t* d_rst, int16_t* d_pcoef);
 // the same level, one WAVE per scan (lp_kernels_prog.hip): the progressive scans; sequential ones (LpProgScan::sequential) are left to the lanes above
 // d_progress != 0: PIPELINED -- scans [first, first + n) span every dependency level of the range, sorted by level; d_deps[i] names the scans
 // scan first + i stays behind (indices relative to first), d_progress = n progress words + the ticket counter, all zero

@@ -142,6 +142,20 @@ LP_PHD uint32_t lp_ctz64(uint64_t v)
 template <class P, class = void> struct LpProgHasBulk { static constexpr bool value = false; };
 template <class P> struct LpProgHasBulk<P, decltype((void)P::kBulkCorrect)> { static constexpr bool value = true; };
 
+// A store OUTSIDE the scan's band Ss..Se (only a damaged stream does that: a run that carries an AC-first scan past Se, or a refinement
+// scan that runs out of still-zero coefficients and places its new one at Se + 1, jdphuff.c). libjpeg decodes the scans one after the
+// other, so a later scan that owns that coefficient overwrites -- or refines -- the stray value; the dependency levels of
+// lp_prog_levels let scans with disjoint bands run side by side and in any order, which is only the same thing while every scan stays
+// inside its band. A policy that has P::stray() is told (the host threads then decode the image again in file order, the device
+// decoders hand it to them); one without it (the CPU emulation of the tests: scans in file order anyway) is not.
+template <class P, class = void> struct LpProgHasStray { static constexpr bool value = false; };
+template <class P> struct LpProgHasStray<P, decltype((void)&P::stray)> { static constexpr bool value = true; };
+template <class P>
+LP_PHD void lp_prog_stray(P& m)
+{
+    if constexpr (LpProgHasStray<P>::value) m.stray();
+}
+
 template <class P, class B>
 LP_PHD void lp_prog_correct(P& m, B& b, uint64_t bits, int32_t p1, int32_t m1)
 {
@@ -241,6 +255,7 @@ LP_PHD bool lp_prog_scan_with(P& m, B& b, const LpProgScan& sc)
                                 k += r;
                                 const int32_t val = lp_prog_extend(b.get(t), t);
                                 // an index past 63 (corrupt stream) lands on jpeg_natural_order[64..79] = the last coefficient
+                                if (k > Se) lp_prog_stray(m);
                                 m.st(blk, k < 64u ? k : 63u, (int32_t)((uint32_t)val << Al));
                             } else if (r == 15u)
                                 k += 15u;
@@ -274,6 +289,7 @@ LP_PHD bool lp_prog_scan_with(P& m, B& b, const LpProgScan& sc)
                             k = stop;
                             if (t) { // index 64 (band ends at 63 and ran out of zeros) lands on the last coefficient, like jpeg_natural_order[64]
                                 const uint32_t e = k < 64u ? k : 63u;
+                                if (k > Se) lp_prog_stray(m);
                                 m.set(e, t);
                                 nz |= 1ull << e;
                             }

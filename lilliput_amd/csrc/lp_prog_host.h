@@ -28,7 +28,11 @@ struct LpProgHostTask {
                                     // reference fails the image); |= 16: a marker code libjpeg does not know is pending behind the scan
                                     // of a file that is read to its end before pixels are returned (JERR_UNKNOWN_MARKER)
     bool whole_file;                // several scans: libjpeg reads on to EOI before it returns (jdapimin.c jpeg_start_decompress)
+    size_t coef_elems;              // int16 elements of the image's coefficients behind `coef` (all components): zeroed again when the image is
+                                    // decoded a second time in file order (a scan stored outside its band, lp_prog_host_run)
 };
+// bit of *LpProgHostTask::error while lp_prog_host_run is at work (cleared before it returns): a scan of the image stored outside its band
+#define LP_PROG_HOST_STRAY 0x40000000u
 
 // Runs the tasks level by level on up to `nthreads` threads (0 = LILLIPUT_HIP_PROG_THREADS, default max(min(16, cores), cores / 4) capped at 64).
 void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads);

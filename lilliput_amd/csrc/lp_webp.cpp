@@ -105,22 +105,26 @@ bool lp_webp_parse(const uint8_t* data, size_t len, LpWebpFile* out)
             if (wpi.partial) return false;
             if (size < 16) return false;                        // ANMF_CHUNK_SIZE
             Wpi fr;
+            fr.partial = true;                                  // MuxImageParse: "waiting for ALPH and/or VP8/VP8L chunks" from the frame header on
             size_t q = 16;
-            bool have = false;
-            while (q != size) { // MuxImageParse: sub-chunks of the frame
+            while (q != size) { // MuxImageParse (libwebp 1.5.0 src/mux/muxread.c): the sub-chunks of the frame, every one of them
                 if (size - q < 8) return false;
                 const size_t ss = le32(payload + q + 4);
                 const size_t sp = ss + (ss & 1);
                 if (ss > kMaxChunkPayload || sp > size - q - 8) return false;
-                if (tag_is(payload + q, "ALPH") || tag_is(payload + q, "VP8 ") || tag_is(payload + q, "VP8L")) {
-                    if (have) break; // the mux stops at the first complete image; the rest of the payload is ignored
+                const uint8_t* st = payload + q;
+                if (tag_is(st, "ALPH") || tag_is(st, "VP8 ") || tag_is(st, "VP8L")) {
+                    // a second ALPH or a second image chunk fails (take_image_chunk); an ALPH behind the image leaves the frame partial again
                     bool fin;
-                    if (!take_image_chunk(fr, payload + q, payload + q + 8, ss, &fin)) return false;
-                    have = have || fin;
-                }
+                    if (!take_image_chunk(fr, st, st + 8, ss, &fin)) return false;
+                } else if (tag_is(st, "VP8X") || tag_is(st, "ICCP") || tag_is(st, "ANIM") || tag_is(st, "ANMF") || tag_is(st, "EXIF") || tag_is(st, "XMP ")) {
+                    return false;                               // a chunk the container knows, but not inside a frame ("default: goto Fail")
+                } else if (fr.partial) {
+                    return false;                               // an unknown chunk before the frame's image chunk ("between some image chunks")
+                }                                               // (an unknown chunk behind the image is kept aside by the mux: ignored here)
                 q += 8 + sp;
             }
-            if (!have || fr.partial) return false;
+            if (!fr.f.img || fr.partial) return false;
             fr.f.x_offset = 2 * (int)le24(payload);
             fr.f.y_offset = 2 * (int)le24(payload + 3);
             // (the frame's width / height fields are not read by the mux: the bitstream's own header counts)

@@ -11,6 +11,7 @@ import struct
 
 import numpy as np
 import pytest
+from conftest import fresh_seed
 
 import bmp_cases
 
@@ -68,7 +69,7 @@ def test_arbitrary_rle_streams_and_bit_field_masks_live(hip_lib, oracle):
     (end-of-bitmap before the last row, deltas, runs that leave their row, short data) and 32-bit bit fields with arbitrary masks."""
     if oracle.ref_bmp() is None:
         pytest.skip("oracle/_ref/librefbmp.so not built")
-    rnd = random.Random(123)
+    rnd = random.Random(fresh_seed(123))
     for t in range(4000):
         bpp = rnd.choice((4, 8))
         w, h = rnd.randrange(1, 40), rnd.randrange(1, 9)

@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import fresh_seed
 
 import gif_cases
 
@@ -118,7 +119,7 @@ def test_host_reader_matches_giflib_live(G, oracle):
         pytest.skip("oracle/_ref/librefgif.so not built (needs /root/reference)")
     cases = dict(gif_cases.fixtures())
     cases.update(gif_cases.hand_cases())
-    cases.update(gif_cases.fuzz_cases(77, 700))
+    cases.update(gif_cases.fuzz_cases(fresh_seed(77), 700))
     for name, data in cases.items():
         for skip in ((), (1,)):
             mine, ref = host_walk(G, data, skip), oracle.ref_gif_frames(data, skip=skip)

@@ -7,6 +7,7 @@ import json
 import os
 
 import pytest
+from conftest import fresh_seed
 
 import meta_cases
 
@@ -48,7 +49,7 @@ def test_readers_match_the_reference_libraries_live(readers, oracle):
     if oracle.ref_meta() is None:
         pytest.skip("oracle/_ref/librefmeta.so not built (needs /root/reference)")
     ref = {"jpeg_icc": oracle.ref_jpeg_icc, "png_icc": oracle.ref_png_icc, "png_cicp": lambda d: oracle.ref_png_cicp(d) or b""}
-    for kind, name, data in meta_cases.hand_cases() + meta_cases.fuzz_cases(303, 400):
+    for kind, name, data in meta_cases.hand_cases() + meta_cases.fuzz_cases(fresh_seed(303), 400):
         assert readers[kind](data) == ref[kind](data), (kind, name)
 
 

@@ -60,6 +60,17 @@ def test_recorded_answers_are_the_reference_decoders(oracle):
         assert _digest(*oracle.ref_pxm_decode(cases[k])) == GOLD[k], k
 
 
+def test_damaged_files_decode_like_the_reference_decoder_live(hip_lib, oracle):
+    """The same comparison live, on damaged files of a seed that LILLIPUT_FUZZ_SEED_OFFSET moves (conftest.fresh_seed)."""
+    if oracle.ref_pxm() is None:
+        pytest.skip("oracle/_ref/librefpxm.so not built")
+    from conftest import fresh_seed
+
+    cases = dict(pxm_cases.fuzz(fresh_seed(143), 600))
+    bad = [(k, _digest(*oracle.ref_pxm_decode(v)), _digest(*_mine(hip_lib, v))) for k, v in cases.items() if _digest(*_mine(hip_lib, v)) != _digest(*oracle.ref_pxm_decode(v))]
+    assert not bad, bad[:10]
+
+
 def test_sample_arithmetic_by_hand(hip_lib):
     """The few rules, on files small enough to check by eye: bitmaps 1 -> 0 and 0 -> 255; ASCII samples clamped to the announced range and
     scaled to 0..255; raw samples copied; 16-bit raw samples give their upper byte; RGB stored as BGR."""

@@ -10,6 +10,7 @@ import struct
 
 import numpy as np
 import pytest
+from conftest import fresh_seed
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "inputs_webp")
@@ -144,9 +145,61 @@ def test_decoder_matches_the_reference_library_live(W, oracle):
     if oracle.ref_webp() is None:
         pytest.skip("reference libwebp driver not built (oracle/_ref/librefwebp.so)")
     cases = dict(fixtures())
-    cases.update(mutations(7, 400))
+    cases.update(mutations(fresh_seed(7), 400))
     bad = [n for n, d in cases.items() if digest(product_decode(W, d)) != ref_digest(oracle, d)]
     assert not bad, bad[:10]
+
+
+def _frame_subchunk_cases():
+    """The first ANMF frame of party-discord.webp (ALPH + "VP8 ") with its sub-chunk area rebuilt: what libwebp 1.5.0's MuxImageParse makes
+    of every ordering (src/mux/muxread.c: a frame is "partial" from its header until its image chunk; an unknown chunk while partial, a
+    known non-image chunk anywhere, a second ALPH or image chunk and a frame that ends partial all fail WebPMuxCreate)."""
+    base = fixtures()["party-discord.webp"]
+
+    def chunks(pos, end):
+        out = []
+        while pos + 8 <= end:
+            sz = struct.unpack_from("<I", base, pos + 4)[0]
+            out.append((pos, bytes(base[pos : pos + 4]), sz))
+            pos += 8 + ((sz + 1) & ~1)
+        return out
+
+    p0, _, s0 = [c for c in chunks(12, len(base)) if c[1] == b"ANMF"][0]
+
+    def ck(tag, data):
+        return tag + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+
+    subs = [ck(t, base[p + 8 : p + 8 + s]) for p, t, s in chunks(p0 + 8 + 16, p0 + 8 + s0)]
+    A, I = [x for x in subs if x[:4] == b"ALPH"][0], [x for x in subs if x[:4] == b"VP8 "][0]
+    U = ck(b"JUNK", b"abcd")
+
+    def rebuild(sub_bytes):
+        payload = base[p0 + 8 : p0 + 8 + 16] + sub_bytes
+        body = base[12:p0] + b"ANMF" + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"") + base[p0 + 8 + ((s0 + 1) & ~1) :]
+        return b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WEBP" + body
+
+    # (sub-chunks, accepted by the reference's WebPMuxCreate)
+    table = {"orig": (A + I, True), "unknown_first": (U + A + I, False), "unknown_between": (A + U + I, False), "unknown_after": (A + I + U, True),
+             "no_alph": (I, True), "no_alph_unknown_first": (U + I, False), "second_image_after": (A + I + I, False), "alph_after": (A + I + A, False),
+             "alph_after_noalph": (I + A, False), "two_alph": (A + A + I, False), "iccp_first": (ck(b"ICCP", b"abcd") + A + I, False),
+             "iccp_after": (A + I + ck(b"ICCP", b"abcd"), False), "exif_after": (A + I + ck(b"EXIF", b"abcd"), False),
+             "xmp_after": (A + I + ck(b"XMP ", b"abcd"), False), "anim_after": (A + I + ck(b"ANIM", b"abcdef"), False),
+             "anmf_after": (A + I + ck(b"ANMF", b"0123456789abcdef"), False), "vp8x_after": (A + I + ck(b"VP8X", b"0123456789"), False),
+             "unknown_after_then_image": (A + I + U + I, False), "image_then_unknown_then_alph": (I + U + A, False),
+             "two_unknown_after": (A + I + U + U, True), "trailing_7_bytes": (A + I + b"JUNKxyz", False), "alph_only": (A, False), "empty": (b"", False)}
+    return {n: (rebuild(sb), ok) for n, (sb, ok) in table.items()}
+
+
+def test_frame_subchunk_orderings_accepted_and_refused_like_the_reference_mux(W, oracle):
+    """Found by the live differential test on fresh seeds in round 6 (a flipped byte in a frame's ALPH tag: the reference refuses the file,
+    the product served it): the sub-chunk rules of a frame, every ordering by hand. The verdicts in the table were read off the reference's
+    libwebpmux (and are compared with it live where oracle/_ref is built)."""
+    for name, (data, ok) in _frame_subchunk_cases().items():
+        mine = product_decode(W, data)
+        assert (mine is not None) == ok, name
+        if oracle.ref_webp() is not None:
+            assert (oracle.ref_webp_info(data) is not None) == ok, (name, "the table is the reference's")
+            assert digest(mine) == ref_digest(oracle, data), name
 
 
 def test_decoder_matches_recorded_reference_answers(W):
