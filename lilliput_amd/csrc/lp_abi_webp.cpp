@@ -126,6 +126,10 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     d->prev_frame_dispose = fr.dispose;
     d->prev_frame_blend = fr.blend;
     if (m->rows <= 0 || row_size <= 0 || m->step < (size_t)row_size) return false;
+    // The reference decodes into a buffer of canvas width x height x 4 bytes allocated with the decoder (webp.cpp:129-131, 339-350): a frame
+    // whose rows do not fit it -- a damaged VP8X canvas smaller than its frames -- fails in WebPDecodeBGR(A)Into's size check
+    // (MIN_BUFFER_SIZE: stride x (height - 1) + width x bytes per pixel), after the Mat was re-created and the frame's properties stored.
+    if ((uint64_t)row_size * (uint64_t)(m->rows - 1) + (uint64_t)row_size > (uint64_t)webp_decoder_get_width(d) * (uint64_t)webp_decoder_get_height(d) * 4u) return false;
     const size_t span = m->step * (size_t)(m->rows - 1) + (size_t)row_size; // rows m->step apart, straight into the Mat (the reference copies them there row by row)
     uint8_t* res = cn == 4 ? WebPDecodeBGRAInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step)
                            : WebPDecodeBGRInto(d->bitstream.data(), d->bitstream.size(), m->data, span, (int)m->step);

@@ -82,6 +82,8 @@ bool lp_webp_parse(const uint8_t* data, size_t len, LpWebpFile* out)
     if (riff < 8 || riff > kMaxChunkPayload) return false;
     if (riff > len - 8) return false;                           // truncated file
     if (riff < len - 8) len = riff + 8;                         // trailing bytes are not part of the container
+    // WebPMuxCreateInternal: "First chunk should be VP8, VP8L or VP8X" -- before anything else is looked at
+    if (!tag_is(data + 12, "VP8 ") && !tag_is(data + 12, "VP8L") && !tag_is(data + 12, "VP8X")) return false;
     size_t pos = 12;
     const uint8_t* vp8x = nullptr;
     int n_vp8x = 0, n_iccp = 0, n_anim = 0, n_anmf = 0, n_exif = 0, n_xmp = 0;

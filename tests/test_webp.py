@@ -194,12 +194,41 @@ def test_frame_subchunk_orderings_accepted_and_refused_like_the_reference_mux(W,
     """Found by the live differential test on fresh seeds in round 6 (a flipped byte in a frame's ALPH tag: the reference refuses the file,
     the product served it): the sub-chunk rules of a frame, every ordering by hand. The verdicts in the table were read off the reference's
     libwebpmux (and are compared with it live where oracle/_ref is built)."""
-    for name, (data, ok) in _frame_subchunk_cases().items():
+    cases = _frame_subchunk_cases()
+    # "First chunk should be VP8, VP8L or VP8X" (WebPMuxCreateInternal): anything else in front of an otherwise good file
+    for name, data in fixtures().items():
+        if len(data) < 200000:
+            for first in (b"JUNK", b"ALPH", b"ICCP", b"ANIM"):
+                body = first + struct.pack("<I", 6) + b"abcdef" + data[12:]
+                cases["%s behind a %s chunk" % (name, first.decode())] = (b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WEBP" + body, False)
+    for name, (data, ok) in cases.items():
         mine = product_decode(W, data)
         assert (mine is not None) == ok, name
         if oracle.ref_webp() is not None:
             assert (oracle.ref_webp_info(data) is not None) == ok, (name, "the table is the reference's")
             assert digest(mine) == ref_digest(oracle, data), name
+
+
+def test_frames_that_do_not_fit_the_canvas_sized_decode_buffer_fail_like_the_reference(W, oracle):
+    """The reference decodes every frame into ONE buffer of canvas width x height x 4 bytes (webp.cpp:129-131, 339-350): with a VP8X canvas
+    smaller than its frames (a flipped byte in the canvas width: fresh-seed finding of round 6) WebPDecodeBGRAInto refuses the frame --
+    webp_decoder_decode returns false for it, the container itself stays acceptable."""
+    for name, pos, val in (("party-discord.webp", 24, 0x12), ("animated-webp-supported.webp", 24, 0x27)):
+        d = bytearray(fixtures()[name])
+        d[pos] = val
+        info, frames, _ = product_decode(W, bytes(d))
+        assert info["num_frames"] == len(frames) and len(frames) > 1
+        cw, ch = info["width"], info["height"]
+        whole = product_decode(W, fixtures()[name])[1]
+        for k, (f, g) in enumerate(zip(frames, whole)):
+            h, w, cn = g[0].shape
+            fits = w * cn * h <= cw * ch * 4
+            assert (f is not None) == fits, (name, k)
+            if fits:
+                assert np.array_equal(f[0], g[0])
+        assert any(f is None for f in frames), name
+        if oracle.ref_webp() is not None:
+            assert digest((info, frames, b"")) == ref_digest(oracle, bytes(d)), name
 
 
 def test_decoder_matches_recorded_reference_answers(W):
