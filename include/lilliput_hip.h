@@ -518,6 +518,10 @@ uint64_t lilliput_hip_lone_batch_count(void);
  * dummy blocks included). Returns the byte count, 0 on failure, or minus the count needed when cap is too small. */
 long lilliput_hip_progressive_encode_coefs(int width, int height, int ncomp, int quality, const int16_t* coef, uint8_t* out, size_t cap);
 int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads);
+/* Test access: 1 when the reference's libjpeg applies its interblock smoothing to this progressive file (jdcoefct.c smoothing_ok: the scan
+ * script leaves one of the first nine AC coefficients of a component short of full precision) -- the one case where the product's pixels
+ * are knowingly NOT the reference's (the filter is not restated); 0 otherwise; -1: not a JPEG the parser takes. */
+int lilliput_hip_jpeg_reference_smooths(const void* data, size_t len);
 
 /* ------------------------------------------------------------------------------------------------
  * Part C -- host mirror of the Go API (ops.go / opencv.go / lilliput.go)

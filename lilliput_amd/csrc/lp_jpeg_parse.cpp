@@ -544,6 +544,24 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
             out->scans.push_back(hs);
         }
         if (out->scans.empty()) return LP_PARSE_NOT_JPEG;
+        if (progressive) {
+            // jdphuff.c / jdarith.c start_pass: coef_bits[component][k] = Al of the last scan that carried coefficient k (-1: none did);
+            // jdcoefct.c smoothing_ok (libjpeg-turbo 3.x: DC + the first nine AC coefficients): every component has its quantisation
+            // table latched, none of those ten quantisers is zero, its DC is at least partly known -- and some AC precision is missing
+            int cb[4][10];
+            for (auto& row : cb) for (int& v : row) v = -1;
+            for (const RawScan& rs : raw_scans)
+                for (unsigned s = 0; s < rs.ns; s++)
+                    for (int k = (int)rs.Ss; k <= (int)rs.Se && k < 10; k++) cb[rs.comp[s]][k] = (int)rs.Al;
+            static const int first10[10] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24}; // natural positions of zigzag 0..9
+            bool ok = true, useful = false;
+            for (int c = 0; c < j.ncomp && c < 4 && ok; c++) {
+                if (!latched[c] || cb[c][0] < 0) { ok = false; break; }
+                for (int q = 0; q < 10; q++) ok = ok && latched_qt[c][first10[q]] != 0;
+                for (int k = 1; k < 10; k++) useful = useful || cb[c][k] != 0;
+            }
+            out->ref_smooths = ok && useful;
+        }
         out->arith = arith;
         out->decode_fails = !out->one_pass && !out->saw_eoi; // jpeg_start_decompress reads a multi-scan file to EOI; without one it suspends
         out->ecs_off = out->scans.front().ecs_off;

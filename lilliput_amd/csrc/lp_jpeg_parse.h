@@ -35,6 +35,11 @@ struct LpJpegHeader {
                                 // its EOI (jpeg_start_decompress suspends at the end of the buffer, cv::JpegDecoder gives up)
     bool open_end = false;      // the entropy-coded data of a one-scan file runs to the end of the buffer, no marker behind it: whether
                                 // the reference decodes it depends on where libjpeg's read-ahead falls (lp_jbits.h): the serial route
+    bool ref_smooths = false;   // a progressive file whose scan script leaves one of the first nine AC coefficients of some component short
+                                // of full precision (never sent, or last sent with Al > 0): libjpeg then estimates those coefficients, where
+                                // they are zero, from the neighbouring blocks' DC values (jdcoefct.c smoothing_ok / decompress_smooth_data,
+                                // do_block_smoothing is on under cv::JpegDecoder). NOT restated here: such a file decodes to the plain
+                                // pixels of its coefficients (known differences); the flag lets tests and callers tell
     bool scan_path = false;     // decoded scan by scan (progressive, multi-scan sequential, four components, unusual sampling):
                                 // `scans` lists the scans in file order, `huff` is unused
     std::vector<LpProgScanHost> scans;

@@ -283,3 +283,13 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     return err ? -2 : 0;
 }
 LP_ABI_CATCH("lilliput_hip_progressive_coefs_host", return -1)
+
+// Test access: does libjpeg's interblock smoothing change the pixels the reference returns for this file (LpJpegHeader::ref_smooths)?
+// 1 / 0; -1: not a JPEG the parser takes. The product does not restate that filter.
+extern "C" int lilliput_hip_jpeg_reference_smooths(const void* data, size_t len)
+try {
+    LpJpegHeader h;
+    if (lp_jpeg_parse(static_cast<const uint8_t*>(data), len, &h) != LP_PARSE_OK) return -1;
+    return h.ref_smooths ? 1 : 0;
+}
+LP_ABI_CATCH("lilliput_hip_jpeg_reference_smooths", return -1)

@@ -455,6 +455,27 @@ def ref_jpeg_decode(data):
     return _decode_pixels(ref().ref_jpeg_decode_pixels, data)
 
 
+def ref_cv_jpeg_decode_unsmoothed_if(data, product_lib):
+    """The reference decoder's verdict and pixels (ref_cv_jpeg_decode) -- except for the ONE known pixel difference of the product: a
+    progressive file libjpeg smooths (lilliput_hip_jpeg_reference_smooths == 1: some low AC coefficient never reaches full precision)
+    is compared with the same library's pixels with do_block_smoothing off. Verdicts are never relaxed."""
+    cv = ref_cv_jpeg_decode(data)
+    if cv is not None and product_lib.lilliput_hip_jpeg_reference_smooths(bytes(data), len(data)) == 1:
+        return ref_jpeg_decode_unsmoothed(data)
+    return cv
+
+
+def ref_jpeg_decode_unsmoothed(data):
+    """The reference's libjpeg with do_block_smoothing = FALSE: the plain pixels of a progressive file's coefficients. What the product
+    returns for the files libjpeg would smooth (lilliput_hip_jpeg_reference_smooths; DESIGN.md 7: the filter is not restated)."""
+    L = ref()
+    L.ref_set_block_smoothing(0)
+    try:
+        return _decode_pixels(L.ref_jpeg_decode_pixels, data)
+    finally:
+        L.ref_set_block_smoothing(1)
+
+
 _refavif = None
 
 

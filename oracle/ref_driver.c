@@ -27,6 +27,12 @@ static void on_msg(j_common_ptr c) { (void)c; }
 static void (*ref_cmyk2bgr_hook)(const uint8_t* cmyk, uint8_t* bgr, int n) = 0;
 void ref_set_cmyk2bgr(void (*f)(const uint8_t*, uint8_t*, int)) { ref_cmyk2bgr_hook = f; }
 
+/* 1 (default, libjpeg's and cv::JpegDecoder's): progressive files whose scans leave low AC coefficients short of full precision get
+ * libjpeg's interblock smoothing (jdcoefct.c decompress_smooth_data); 0: cinfo.do_block_smoothing = FALSE -- the plain pixels of the
+ * coefficients, which is what the product returns for such files (it does not restate that filter: DESIGN.md 7). */
+static int ref_block_smoothing = 1;
+void ref_set_block_smoothing(int on) { ref_block_smoothing = on; }
+
 int ref_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap, int* w, int* h, int* ch)
 {
     struct jpeg_decompress_struct ci;
@@ -42,6 +48,7 @@ int ref_jpeg_decode_pixels(const uint8_t* d, size_t n, uint8_t* out, size_t cap,
     else if (ci.num_components == 3) { ci.out_color_space = JCS_EXT_BGR; ci.out_color_components = 3; }
     else if (ci.num_components == 4) { ci.out_color_space = JCS_CMYK; ci.out_color_components = 4; } /* cv::JpegDecoder::readData */
     else { jpeg_destroy_decompress(&ci); return -2; }
+    if (!ref_block_smoothing) ci.do_block_smoothing = FALSE;
     jpeg_start_decompress(&ci);
     *w = (int)ci.output_width; *h = (int)ci.output_height; *ch = ci.out_color_components == 4 ? 3 : ci.out_color_components;
     size_t stride = (size_t)*w * *ch;

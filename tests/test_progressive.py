@@ -162,6 +162,63 @@ def test_damaged_files_same_verdict_and_coefficients_as_the_oracle(hip_lib, orac
     assert n_ok > 300 and n_err > 20, (n_ok, n_err)
 
 
+def _sos_headers(data):
+    """(offset of the Ss byte) of every SOS header of a file"""
+    out, i = [], 2
+    while i + 4 <= len(data):
+        if data[i] != 0xFF or data[i + 1] in (0x00, 0xFF) or 0xD0 <= data[i + 1] <= 0xD7:
+            i += 1
+            continue
+        m, L = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == 0xD9:
+            break
+        if m == 0xDA:
+            out.append(i + 5 + 2 * data[i + 4])
+        i += 2 + L
+    return out
+
+
+def test_files_the_reference_smooths_are_told_apart(hip_lib, oracle):
+    """The one known pixel difference: libjpeg estimates low AC coefficients that never reached full precision from the
+    neighbouring blocks' DC values (jdcoefct.c smoothing_ok / decompress_smooth_data; on by default, also under cv::JpegDecoder); the
+    product does not restate that filter. lilliput_hip_jpeg_reference_smooths tells exactly those files: every bit of the Ss / Se / Ah-Al
+    bytes of every scan header of 12 files flipped -- wherever the reference's pixels change with do_block_smoothing off, the flag is up;
+    where it is down, the oracle's pixels are the reference decoder's; and always the oracle's pixels are libjpeg's unsmoothed ones."""
+    if oracle.ref() is None or oracle.ref_cvjpeg() is None:
+        pytest.skip("oracle/_ref not built")
+    f = hip_lib.lilliput_hip_jpeg_reference_smooths
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t]
+    n_smooth = n_plain = 0
+    for i, desc, data in _cases(29, 12, lo=24, hi=90):
+        assert f(data, len(data)) == 0, (i, desc)  # a complete scan script: nothing to estimate
+        q = _sos_headers(data)[0] + 3  # first entropy-coded byte of the first scan; its data ends at the next marker
+        while not (data[q] == 0xFF and data[q + 1] != 0 and not 0xD0 <= data[q + 1] <= 0xD7):
+            q += 1
+        cut = data[:q]
+        dc_only = cut + b"\xff\xd9"
+        assert f(dc_only, len(dc_only)) == 1, (i, desc, "only the DC scan: every AC coefficient is unknown")
+        for off in _sos_headers(data):
+            for byte in range(3):
+                for bit in range(8):
+                    d = bytearray(data)
+                    d[off + byte] ^= 1 << bit
+                    d = bytes(d)
+                    cv = oracle.ref_cv_jpeg_decode(d)
+                    if cv is None:
+                        continue
+                    flag = f(d, len(d))
+                    assert flag in (0, 1), (i, off, byte, bit)
+                    plain = oracle.ref_jpeg_decode_unsmoothed(d)
+                    assert np.array_equal(oracle.jpeg_decode(d), plain), (i, off, byte, bit, "the restatement is libjpeg without the filter")
+                    if not np.array_equal(cv, plain):
+                        assert flag == 1, (i, off, byte, bit, "the reference smooths this file and the flag is down")
+                        n_smooth += 1
+                    elif flag == 0:
+                        n_plain += 1
+    assert n_smooth > 20 and n_plain > 100, (n_smooth, n_plain)
+
+
 # ------------------------------------------------------------------------------------------ GPU
 _MODES = {"host-entropy": 0, "device-entropy": 1, "lanes-entropy": 2}
 
@@ -315,7 +372,7 @@ def test_progressive_damaged_files_match_the_oracle(batch, oracle, mode):
                     outs.append(e.code)
             assert type(outs[0]) is type(outs[1]) and np.array_equal(outs[0], outs[1]), (i, k)
             if oracle.ref_cvjpeg() is not None:  # the reference's own decoder (cv::JpegDecoder over its libjpeg.a): verdict and pixels
-                exp = oracle.ref_cv_jpeg_decode(d)
+                exp = oracle.ref_cv_jpeg_decode_unsmoothed_if(d, lilliput_amd.lib())  # (a flipped Ss / Se / Al can leave low AC coefficients unrefined: libjpeg then smooths)
             else:
                 try:
                     exp = oracle.jpeg_decode(d)
