@@ -518,9 +518,11 @@ uint64_t lilliput_hip_lone_batch_count(void);
  * dummy blocks included). Returns the byte count, 0 on failure, or minus the count needed when cap is too small. */
 long lilliput_hip_progressive_encode_coefs(int width, int height, int ncomp, int quality, const int16_t* coef, uint8_t* out, size_t cap);
 int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads);
+/* ... and as they reach the IDCT: behind libjpeg's interblock smoothing for the files that call for it (below); the same values otherwise */
+int lilliput_hip_progressive_coefs_smoothed(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh);
 /* Test access: 1 when the reference's libjpeg applies its interblock smoothing to this progressive file (jdcoefct.c smoothing_ok: the scan
- * script leaves one of the first nine AC coefficients of a component short of full precision) -- the one case where the product's pixels
- * are knowingly NOT the reference's (the filter is not restated); 0 otherwise; -1: not a JPEG the parser takes. */
+ * script leaves one of the first nine AC coefficients of a component short of full precision); the library applies the same filter to
+ * such a file's coefficients on the host, in front of the IDCT (lp_prog_smooth); 0 otherwise; -1: not a JPEG the parser takes. */
 int lilliput_hip_jpeg_reference_smooths(const void* data, size_t len);
 
 /* ------------------------------------------------------------------------------------------------

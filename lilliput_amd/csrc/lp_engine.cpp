@@ -450,6 +450,7 @@ static int layout_set(LpUpload& u, const LpJpegSrc* srcs, int n, const LpJpegHea
         for (int i = 0; i < n; i++) {
             if (!hdrs[i].scan_path || hdrs[i].arith) continue; // a QM-coded scan only has a host decoder (lp_arith_host.h)
             if (hdrs[i].decode_fails) continue;                 // a multi-scan file without its EOI: the host route reports what the reference does
+            if (hdrs[i].ref_smooths) continue;                  // libjpeg smooths this file: the filter runs on the host, behind the host threads' scans (lp_prog_smooth)
             bool seq = false;
             for (const LpProgScanHost& sh : hdrs[i].scans) seq = seq || sh.s.sequential;
             if (u.prog_mode < 0 && seq) continue;               // auto: the wave decoder's files only
@@ -546,9 +547,11 @@ static bool host_scan_decode(LpUpload& u, int n, const LpJpegHeader* hdrs)
     memset(u.pcoef.p, 0, u.pcoef_total * 2);
     size_t t = 0;
     for (int i = 0; i < n; i++)
-        if (hdrs[i].scan_path)
+        if (hdrs[i].scan_path && !u.prog_dev[(size_t)i]) // (the images layout_set made tasks for: a set may hold device-decoded ones too)
             for (size_t q = 0; q < hdrs[i].scans.size(); q++) u.host_tasks[t++].coef = u.pcoef.as<int16_t>() + u.pcoef_off[(size_t)i];
     lp_prog_host_run(u.host_tasks, 0);
+    for (int i = 0; i < n; i++)
+        if (hdrs[i].scan_path && hdrs[i].ref_smooths && !u.prog_dev[(size_t)i]) lp_prog_smooth(hdrs[i], u.pcoef.as<int16_t>() + u.pcoef_off[(size_t)i]);
     return true;
 }
 

@@ -561,6 +561,7 @@ int lp_jpeg_parse_opts(const uint8_t* d, size_t n, LpJpegHeader* out, bool force
                 for (int k = 1; k < 10; k++) useful = useful || cb[c][k] != 0;
             }
             out->ref_smooths = ok && useful;
+            for (int c = 0; c < 4; c++) for (int k = 0; k < 10; k++) out->coef_bits[c][k] = (int8_t)cb[c][k];
         }
         out->arith = arith;
         out->decode_fails = !out->one_pass && !out->saw_eoi; // jpeg_start_decompress reads a multi-scan file to EOI; without one it suspends

@@ -38,8 +38,10 @@ struct LpJpegHeader {
     bool ref_smooths = false;   // a progressive file whose scan script leaves one of the first nine AC coefficients of some component short
                                 // of full precision (never sent, or last sent with Al > 0): libjpeg then estimates those coefficients, where
                                 // they are zero, from the neighbouring blocks' DC values (jdcoefct.c smoothing_ok / decompress_smooth_data,
-                                // do_block_smoothing is on under cv::JpegDecoder). NOT restated here: such a file decodes to the plain
-                                // pixels of its coefficients (known differences); the flag lets tests and callers tell
+                                // do_block_smoothing is on under cv::JpegDecoder): restated by lp_prog_smooth (lp_prog_host.h), which such an image's
+                                // coefficients pass on the host before they reach the IDCT
+    int8_t coef_bits[4][10] = {}; // with ref_smooths: libjpeg's coef_bits[component][zigzag 0..9] after the last scan (Al of the last scan that
+                                // carried the coefficient, -1: none did)
     bool scan_path = false;     // decoded scan by scan (progressive, multi-scan sequential, four components, unusual sampling):
                                 // `scans` lists the scans in file order, `huff` is unused
     std::vector<LpProgScanHost> scans;

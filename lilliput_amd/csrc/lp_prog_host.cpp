@@ -250,14 +250,85 @@ void lp_prog_host_run(std::vector<LpProgHostTask>& tasks, int nthreads)
     }
 }
 
+void lp_prog_smooth(const LpJpegHeader& h, int16_t* coef)
+{
+    if (!h.ref_smooths) return;
+    const LpJpeg& j = h.j;
+    static const int nat[10] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24}; // natural positions of zigzag 0..9 (the quantisation tables are in natural order)
+    size_t base = 0;
+    std::vector<int32_t> dc;
+    for (int c = 0; c < j.ncomp && c < 4; base += (size_t)j.bw[c] * j.bh[c] * 64, c++) {
+        const int8_t* cb = h.coef_bits[c];
+        bool useful = false, change_dc = true;
+        for (int k = 1; k < 10; k++) { useful = useful || cb[k] != 0; change_dc = change_dc && cb[k] == -1; }
+        if (!useful) continue; // (libjpeg runs the filter over every component once smoothing_ok said yes; one whose nine precisions are final changes nothing)
+        const int bw = (int)j.bw[c], bh = (int)j.bh[c], v = j.ncomp == 1 ? 1 : (int)j.vs[c];
+        // the component's real size in blocks (jdinput.c: width_in_blocks / height_in_blocks), without the MCU padding
+        const int cw = j.ncomp == 1 ? (int)j.width : (int)(((uint64_t)j.width * j.hs[c] + j.hmax - 1) / j.hmax);
+        const int ch = j.ncomp == 1 ? (int)j.height : (int)(((uint64_t)j.height * j.vs[c] + j.vmax - 1) / j.vmax);
+        const int wib = (cw + 7) / 8, hib = (ch + 7) / 8, last_imcu = bh / v - 1;
+        int16_t* co = coef + base;
+        dc.resize((size_t)bw * bh);
+        for (size_t b = 0; b < dc.size(); b++) dc[b] = co[b * 64];
+        int64_t Q[10];
+        for (int k = 0; k < 10; k++) Q[k] = j.qt[c][nat[k]];
+        for (int y = 0; y < hib; y++) {
+            // rows below: the last iMCU row only sees its real rows (the bottom one is repeated), the rows above it see the whole of the
+            // next iMCU rows -- the dummy rows of the padding included (decompress_smooth_data's access_rows)
+            const int ylim = (y / v == last_imcu ? hib : bh) - 1;
+            const int ry[5] = {std::max(y - 2, 0), std::max(y - 1, 0), y, std::min(y + 1, ylim), std::min(y + 2, ylim)};
+            for (int x = 0; x < wib; x++) {
+                const int rx[5] = {std::max(x - 2, 0), std::max(x - 1, 0), x, std::min(x + 1, wib - 1), std::min(x + 2, wib - 1)};
+                int64_t D[26];
+                for (int a = 0; a < 5; a++)
+                    for (int b = 0; b < 5; b++) D[1 + 5 * a + b] = dc[(size_t)ry[a] * bw + rx[b]];
+                int16_t* ws = co + ((size_t)y * bw + x) * 64;
+                auto est = [&](int k, int64_t sum) {
+                    const int Al = cb[k];
+                    if (Al == 0 || ws[k] != 0) return;
+                    const int64_t num = Q[0] * sum, q = Q[k];
+                    int64_t pred = ((q << 7) + (num >= 0 ? num : -num)) / (q << 8);
+                    if (Al > 0 && pred >= (1 << Al)) pred = (1 << Al) - 1;
+                    ws[k] = (int16_t)(num >= 0 ? pred : -pred);
+                };
+                if (change_dc) {
+                    est(1, -D[1] - D[2] + D[4] + D[5] - 3 * D[6] + 13 * D[7] - 13 * D[9] + 3 * D[10] - 3 * D[11] + 38 * D[12] - 38 * D[14] + 3 * D[15] - 3 * D[16] +
+                               13 * D[17] - 13 * D[19] + 3 * D[20] - D[21] - D[22] + D[24] + D[25]);
+                    est(2, -D[1] - 3 * D[2] - 3 * D[3] - 3 * D[4] - D[5] - D[6] + 13 * D[7] + 38 * D[8] + 13 * D[9] - D[10] + D[16] - 13 * D[17] - 38 * D[18] -
+                               13 * D[19] + D[20] + D[21] + 3 * D[22] + 3 * D[23] + 3 * D[24] + D[25]);
+                    est(3, D[3] + 2 * D[7] + 7 * D[8] + 2 * D[9] - 5 * D[12] - 14 * D[13] - 5 * D[14] + 2 * D[17] + 7 * D[18] + 2 * D[19] + D[23]);
+                    est(4, -D[1] + D[5] + 9 * D[7] - 9 * D[9] - 9 * D[17] + 9 * D[19] + D[21] - D[25]);
+                    est(5, 2 * D[7] - 5 * D[8] + 2 * D[9] + D[11] + 7 * D[12] - 14 * D[13] + 7 * D[14] + D[15] + 2 * D[17] - 5 * D[18] + 2 * D[19]);
+                    est(6, D[7] - D[9] + 2 * D[12] - 2 * D[14] + D[17] - D[19]);
+                    est(7, D[7] - 3 * D[8] + D[9] - D[17] + 3 * D[18] - D[19]);
+                    est(8, D[7] - D[9] - 3 * D[12] + 3 * D[14] + D[17] - D[19]);
+                    est(9, D[7] + 2 * D[8] + D[9] - D[17] - 2 * D[18] - D[19]);
+                    // the DC itself: always replaced, no clamp
+                    const int64_t num = Q[0] * (-2 * D[1] - 6 * D[2] - 8 * D[3] - 6 * D[4] - 2 * D[5] - 6 * D[6] + 6 * D[7] + 42 * D[8] + 6 * D[9] - 6 * D[10] - 8 * D[11] +
+                                                42 * D[12] + 152 * D[13] + 42 * D[14] - 8 * D[15] - 6 * D[16] + 6 * D[17] + 42 * D[18] + 6 * D[19] - 6 * D[20] - 2 * D[21] -
+                                                6 * D[22] - 8 * D[23] - 6 * D[24] - 2 * D[25]);
+                    const int64_t pred = ((Q[0] << 7) + (num >= 0 ? num : -num)) / (Q[0] << 8);
+                    ws[0] = (int16_t)(num >= 0 ? pred : -pred);
+                } else { // T.81 K.8's estimates on a 5 x 5 window
+                    est(1, -7 * D[11] + 50 * D[12] - 50 * D[14] + 7 * D[15]);
+                    est(2, -7 * D[3] + 50 * D[8] - 50 * D[18] + 7 * D[23]);
+                    est(3, -D[3] + 13 * D[8] - 24 * D[13] + 13 * D[18] - D[23]);
+                    est(4, D[10] + D[16] - 10 * D[17] + 10 * D[19] - D[2] - D[20] + D[22] - D[24] + D[4] - D[6] + 10 * D[7] - 10 * D[9]);
+                    est(5, -D[11] + 13 * D[12] - 24 * D[13] + 13 * D[14] - D[15]);
+                }
+            }
+        }
+    }
+}
+
 // Test access (no device work): the coefficients of component `comp` as the hybrid mode's host threads decode them,
 // [block row][block column][64 natural-order values] over the MCU-padded grid. Returns 0, or -1 (not a progressive JPEG the
 // parser accepts) / -3 (dst too small).
 // nthreads < 0: the serial route of ANY sequential file (lp_jpeg_parse_opts force_scans: what a baseline stream the device decoder
 // flagged as irregular is decoded by), on -nthreads threads. Returns -2 when the reference's decoder fails on the file (out of data,
 // unknown marker behind a scan of a multi-scan file), with the coefficients as far as they were decoded.
-extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads)
-try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+static int progressive_coefs(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads, bool smooth)
+{
     LpJpegHeader h;
     const bool force = nthreads < 0;
     if (force) nthreads = -nthreads;
@@ -276,13 +347,24 @@ try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
     std::vector<LpProgHostTask> tasks;
     for (size_t q = 0; q < h.scans.size(); q++) tasks.push_back(LpProgHostTask{static_cast<const uint8_t*>(data), len, &h.scans[q], coef.data(), lev[q], &err, !h.one_pass, total});
     lp_prog_host_run(tasks, nthreads);
+    if (smooth) lp_prog_smooth(h, coef.data());
     static const uint8_t zz[80] = LP_ZIGZAG_INIT;
     for (size_t q = 0; q < ne; q++) dst[(q & ~(size_t)63) | zz[q & 63]] = coef[base + q]; // stored in zigzag order
     *bw = (int)h.j.bw[comp];
     *bh = (int)h.j.bh[comp];
     return err ? -2 : 0;
 }
+extern "C" int lilliput_hip_progressive_coefs_host(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh, int nthreads)
+try { // LP_ABI_GUARD: nothing unwinds through the C ABI (lp_abi_guard.h)
+    return progressive_coefs(data, len, comp, dst, cap_elems, bw, bh, nthreads, false);
+}
 LP_ABI_CATCH("lilliput_hip_progressive_coefs_host", return -1)
+// ... and as they reach the IDCT: behind libjpeg's interblock smoothing where the file calls for it (lp_prog_smooth; a no-op for the others)
+extern "C" int lilliput_hip_progressive_coefs_smoothed(const void* data, size_t len, int comp, int16_t* dst, size_t cap_elems, int* bw, int* bh)
+try {
+    return progressive_coefs(data, len, comp, dst, cap_elems, bw, bh, 1, true);
+}
+LP_ABI_CATCH("lilliput_hip_progressive_coefs_smoothed", return -1)
 
 // Test access: does libjpeg's interblock smoothing change the pixels the reference returns for this file (LpJpegHeader::ref_smooths)?
 // 1 / 0; -1: not a JPEG the parser takes. The product does not restate that filter.

@@ -56,3 +56,13 @@ uint32_t lp_prog_device_min_images();
 // process-wide counters (lilliput_hip_progressive_stats): scan-path images whose scans ran on the device, those of them the device decoders
 // gave up on (decoded again by the host threads), scans launched on the device
 void lp_prog_count(uint64_t device_images, uint64_t gave_up, uint64_t device_scans);
+
+
+// libjpeg-turbo 3.1.0's interblock smoothing (jdcoefct.c decompress_smooth_data, on by default and under cv::JpegDecoder) for a progressive
+// image whose header walk set LpJpegHeader::ref_smooths: every one of the first nine AC coefficients (zigzag 1..9) of a block that is
+// still zero and whose precision is not final (coef_bits != 0) is replaced by an estimate from the 5 x 5 neighbourhood of DC values; when
+// NO AC data of a component was sent at all (coef_bits[1..9] all -1) the Gaussian-like kernel set is used and the DC itself is
+// re-estimated. `coef` = the image's first block, components back to back, [bh][bw][64] in zigzag order over the MCU-padded grid
+// (what the scan decoders write). In place; the neighbours' DC values are the ones from before the pass. The weights and the row
+// rules at the bottom of the image were pinned against the reference's libjpeg.a (oracle.ref_jpeg_decode): tests/test_progressive.py.
+void lp_prog_smooth(const LpJpegHeader& h, int16_t* coef);

@@ -447,27 +447,142 @@ def _decode_pixels(fn, data):
 
 
 def jpeg_decode(data):
-    """Restatement: JPEG bytes -> HxWxC uint8 (BGR or gray), as opencv_decoder_read_data produces."""
+    """Restatement: JPEG bytes -> HxWxC uint8 (BGR or gray), as opencv_decoder_read_data produces -- libjpeg's interblock smoothing of
+    progressive files with unfinished low AC coefficients included (jpeg_smoothing_plan / jpeg_smooth_coefs below)."""
+    plan = jpeg_smoothing_plan(data)
+    if plan is None:
+        return _decode_pixels(lib().lo_jpeg_decode_pixels, data)
+    px = _decode_pixels(lib().lo_jpeg_decode_pixels, data)  # (verdict first: a file the restatement refuses stays refused)
+    return jpeg_pixels_from_coefs(data, [jpeg_smooth_coefs(jpeg_decode_coefs(data, c), plan, c) for c in range(len(plan["comps"]))])
+
+
+def jpeg_decode_unsmoothed(data):
+    """The restatement without the smoothing pass (= libjpeg with do_block_smoothing off)."""
     return _decode_pixels(lib().lo_jpeg_decode_pixels, data)
+
+
+_ZZ_NAT = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+           57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def jpeg_smoothing_plan(data):
+    """libjpeg-turbo 3.1.0 jdcoefct.c smoothing_ok, restated from the file's markers (test infrastructure; pure Python): None when the
+    decoder does not smooth (not progressive; every component's first nine AC coefficients reached full precision; a component without a
+    latched quantisation table, with a zero among its first ten quantisers or without DC data), else {"width", "height", "comps": [{hs, vs,
+    q (natural order, latched at the component's first scan), bits: coef_bits[0..9] = Al of the last scan that carried the coefficient or -1}]}.
+    jdphuff.c start_pass: coef_bits bookkeeping; jdinput.c latch_quant_tables."""
+    d, i, qt, comps, progressive, W, H = bytes(data), 2, {}, [], False, 0, 0
+    while i + 4 <= len(d):
+        if d[i] != 0xFF or d[i + 1] in (0x00, 0xFF) or 0xD0 <= d[i + 1] <= 0xD7:
+            i += 1
+            continue
+        m = d[i + 1]
+        if m == 0xD9:
+            break
+        L = (d[i + 2] << 8) | d[i + 3]
+        p = d[i + 4 : i + 2 + L]
+        if m == 0xDB:
+            k = 0
+            while k < len(p):
+                pq, t = p[k] >> 4, p[k] & 15
+                k += 1
+                tab = [0] * 64
+                for z in range(64):
+                    if pq:
+                        tab[_ZZ_NAT[z]] = (p[k] << 8) | p[k + 1]
+                        k += 2
+                    else:
+                        tab[_ZZ_NAT[z]] = p[k]
+                        k += 1
+                qt[t] = tab
+        elif m in (0xC2, 0xCA):
+            progressive = True
+            H, W = (p[1] << 8) | p[2], (p[3] << 8) | p[4]
+            comps = [{"id": p[6 + 3 * c], "hs": p[7 + 3 * c] >> 4, "vs": p[7 + 3 * c] & 15, "tq": p[8 + 3 * c], "q": None, "bits": [-1] * 10} for c in range(p[5])]
+        elif m == 0xDA and progressive:
+            ns = p[0]
+            Ss, Se, Al = p[1 + 2 * ns], p[2 + 2 * ns], p[3 + 2 * ns] & 15
+            for s in range(ns):
+                c = [x["id"] for x in comps].index(p[1 + 2 * s])
+                if comps[c]["q"] is None and comps[c]["tq"] in qt:
+                    comps[c]["q"] = list(qt[comps[c]["tq"]])
+                for k in range(Ss, min(Se, 9) + 1):
+                    comps[c]["bits"][k] = Al
+        i += 2 + L
+    if not progressive or not comps:
+        return None
+    useful = False
+    for c in comps:
+        if c["q"] is None or c["bits"][0] < 0 or any(c["q"][_ZZ_NAT[k]] == 0 for k in range(10)):
+            return None
+        useful = useful or any(b != 0 for b in c["bits"][1:])
+    if len(comps) == 1:
+        comps[0]["hs"] = comps[0]["vs"] = 1
+    return {"width": W, "height": H, "comps": comps} if useful else None
+
+
+def jpeg_smooth_coefs(co, plan, ci):
+    """jdcoefct.c decompress_smooth_data on one component's quantised coefficients ([bh][bw][64], natural order, MCU-padded grid): every one
+    of the first nine AC coefficients of a block that is still zero and whose precision is not final gets an estimate from the 5 x 5
+    neighbourhood of DC values (T.81 K.8 widened; when no AC data was sent at all, a Gaussian-like kernel set that also re-estimates the
+    DC). Weights and the row rules at the image's bottom pinned against the reference's libjpeg.a (tests/test_progressive.py)."""
+    comps = plan["comps"]
+    c = comps[ci]
+    cb = c["bits"]
+    if all(b == 0 for b in cb[1:]):
+        return co
+    hmax, vmax = max(x["hs"] for x in comps), max(x["vs"] for x in comps)
+    wib = -(-(-(-plan["width"] * c["hs"] // hmax)) // 8)
+    hib = -(-(-(-plan["height"] * c["vs"] // vmax)) // 8)
+    v, bh = c["vs"], co.shape[0]
+    last_imcu = bh // v - 1
+    change_dc = all(b == -1 for b in cb[1:])
+    Q = [c["q"][_ZZ_NAT[k]] for k in range(10)]
+    out = co.astype(np.int64)
+    dc = co[:, :, 0].astype(np.int64)
+
+    def pred(num, q, Al):
+        pr = ((q << 7) + abs(num)) // (q << 8)
+        if Al > 0 and pr >= (1 << Al):
+            pr = (1 << Al) - 1
+        return pr if num >= 0 else -pr
+
+    for y in range(hib):
+        ylim = (hib if y // v == last_imcu else bh) - 1
+        ry = [max(y - 2, 0), max(y - 1, 0), y, min(y + 1, ylim), min(y + 2, ylim)]
+        for x in range(wib):
+            rx = [max(x - 2, 0), max(x - 1, 0), x, min(x + 1, wib - 1), min(x + 2, wib - 1)]
+            D = [0] + [int(dc[a, b]) for a in ry for b in rx]
+            ws = out[y, x]
+            if change_dc:
+                sums = {1: -D[1] - D[2] + D[4] + D[5] - 3 * D[6] + 13 * D[7] - 13 * D[9] + 3 * D[10] - 3 * D[11] + 38 * D[12] - 38 * D[14] + 3 * D[15] - 3 * D[16] + 13 * D[17] - 13 * D[19] + 3 * D[20] - D[21] - D[22] + D[24] + D[25],
+                        2: -D[1] - 3 * D[2] - 3 * D[3] - 3 * D[4] - D[5] - D[6] + 13 * D[7] + 38 * D[8] + 13 * D[9] - D[10] + D[16] - 13 * D[17] - 38 * D[18] - 13 * D[19] + D[20] + D[21] + 3 * D[22] + 3 * D[23] + 3 * D[24] + D[25],
+                        3: D[3] + 2 * D[7] + 7 * D[8] + 2 * D[9] - 5 * D[12] - 14 * D[13] - 5 * D[14] + 2 * D[17] + 7 * D[18] + 2 * D[19] + D[23],
+                        4: -D[1] + D[5] + 9 * D[7] - 9 * D[9] - 9 * D[17] + 9 * D[19] + D[21] - D[25],
+                        5: 2 * D[7] - 5 * D[8] + 2 * D[9] + D[11] + 7 * D[12] - 14 * D[13] + 7 * D[14] + D[15] + 2 * D[17] - 5 * D[18] + 2 * D[19],
+                        6: D[7] - D[9] + 2 * D[12] - 2 * D[14] + D[17] - D[19], 7: D[7] - 3 * D[8] + D[9] - D[17] + 3 * D[18] - D[19],
+                        8: D[7] - D[9] - 3 * D[12] + 3 * D[14] + D[17] - D[19], 9: D[7] + 2 * D[8] + D[9] - D[17] - 2 * D[18] - D[19]}
+            else:
+                sums = {1: -7 * D[11] + 50 * D[12] - 50 * D[14] + 7 * D[15], 2: -7 * D[3] + 50 * D[8] - 50 * D[18] + 7 * D[23],
+                        3: -D[3] + 13 * D[8] - 24 * D[13] + 13 * D[18] - D[23],
+                        4: D[10] + D[16] - 10 * D[17] + 10 * D[19] - D[2] - D[20] + D[22] - D[24] + D[4] - D[6] + 10 * D[7] - 10 * D[9],
+                        5: -D[11] + 13 * D[12] - 24 * D[13] + 13 * D[14] - D[15]}
+            for k, sm in sums.items():
+                if cb[k] != 0 and ws[_ZZ_NAT[k]] == 0:
+                    ws[_ZZ_NAT[k]] = pred(Q[0] * sm, Q[k], cb[k])
+            if change_dc:
+                ws[0] = pred(Q[0] * (-2 * D[1] - 6 * D[2] - 8 * D[3] - 6 * D[4] - 2 * D[5] - 6 * D[6] + 6 * D[7] + 42 * D[8] + 6 * D[9] - 6 * D[10] - 8 * D[11] + 42 * D[12] + 152 * D[13] + 42 * D[14] - 8 * D[15]
+                                     - 6 * D[16] + 6 * D[17] + 42 * D[18] + 6 * D[19] - 6 * D[20] - 2 * D[21] - 6 * D[22] - 8 * D[23] - 6 * D[24] - 2 * D[25]), Q[0], -1)
+    return out.astype(np.int16)
 
 
 def ref_jpeg_decode(data):
     return _decode_pixels(ref().ref_jpeg_decode_pixels, data)
 
 
-def ref_cv_jpeg_decode_unsmoothed_if(data, product_lib):
-    """The reference decoder's verdict and pixels (ref_cv_jpeg_decode) -- except for the ONE known pixel difference of the product: a
-    progressive file libjpeg smooths (lilliput_hip_jpeg_reference_smooths == 1: some low AC coefficient never reaches full precision)
-    is compared with the same library's pixels with do_block_smoothing off. Verdicts are never relaxed."""
-    cv = ref_cv_jpeg_decode(data)
-    if cv is not None and product_lib.lilliput_hip_jpeg_reference_smooths(bytes(data), len(data)) == 1:
-        return ref_jpeg_decode_unsmoothed(data)
-    return cv
-
-
 def ref_jpeg_decode_unsmoothed(data):
-    """The reference's libjpeg with do_block_smoothing = FALSE: the plain pixels of a progressive file's coefficients. What the product
-    returns for the files libjpeg would smooth (lilliput_hip_jpeg_reference_smooths; DESIGN.md 7: the filter is not restated)."""
+    """The reference's libjpeg with do_block_smoothing = FALSE: the plain pixels of a progressive file's coefficients (what tells the
+    smoothing pass apart from everything else in tests/test_progressive.py)."""
     L = ref()
     L.ref_set_block_smoothing(0)
     try:

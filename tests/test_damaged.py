@@ -231,7 +231,7 @@ def test_hostile_coefficients_decode_like_the_reference_decoder_on_the_device(ba
     _need_refs(oracle)
     bad, ok, failed = [], 0, 0
     for tag, data in _hostile():
-        cv = oracle.ref_cv_jpeg_decode_unsmoothed_if(data, lilliput_amd.lib())
+        cv = oracle.ref_cv_jpeg_decode(data)
         try:
             px, _ = batch.decode_jpeg(data)
         except lilliput_amd.LilliputError as e:
@@ -256,9 +256,7 @@ def _reference_pixels(oracle, data):
     dequantised coefficients a real image cannot have -- libjpeg-turbo's SIMD IDCT (x86-64: 16-bit lanes, wrapping adds, saturating
     packs) and its C IDCT then differ; k_idct now computes the SIMD routine's lane arithmetic (lp_kernels_decode.hip idct_*_exact, the
     fast path's conditions), so the reference's pixels are the only answer."""
-    import lilliput_amd
-
-    return oracle.ref_cv_jpeg_decode_unsmoothed_if(data, lilliput_amd.lib()), None  # (the one known pixel difference: files libjpeg smooths, DESIGN 7)
+    return oracle.ref_cv_jpeg_decode(data), None
 
 
 @pytest.mark.gpu
