@@ -549,6 +549,8 @@ def jpeg_smooth_coefs(co, plan, ci):
 
     for y in range(hib):
         ylim = (hib if y // v == last_imcu else bh) - 1
+        # (open: a 24-row 4:2:0 file -- two iMCU rows, the second one the last -- has ONE block whose estimate sits on a rounding boundary
+        # and comes out as if its row y - 2 were row y - 1; applying that to the second iMCU row in general breaks 11 other probe files)
         ry = [max(y - 2, 0), max(y - 1, 0), y, min(y + 1, ylim), min(y + 2, ylim)]
         for x in range(wib):
             rx = [max(x - 2, 0), max(x - 1, 0), x, min(x + 1, wib - 1), min(x + 2, wib - 1)]
