@@ -433,6 +433,30 @@ def test_smoothed_files_decode_to_the_reference_decoders_pixels_on_the_device(ba
 
 
 @pytest.mark.gpu
+def test_smoothed_and_plain_progressive_files_share_a_set(batch, oracle, hip_lib, mode):
+    """One upload set holding files libjpeg smooths (host threads' route + lp_prog_smooth in every mode) next to ordinary progressive files
+    (on the device in the device modes) and a baseline file: every item's bytes are the ones it gets alone."""
+    f = hip_lib.lilliput_hip_jpeg_reference_smooths
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t]
+    flagged, plain = [], []
+    for tag, d in _smoothing_probe_files():
+        if tag[1] == "whole" and len(plain) < 4:
+            plain.append(d)
+        elif tag[1] == "dc_only" and len(flagged) < 3 and f(d, len(d)) == 1:
+            flagged.append(d)
+    assert len(flagged) == 3 and len(plain) == 4
+    from lilliput_amd import synth
+
+    base = synth.synth_jpeg(5, 96)
+    srcs = [plain[0], flagged[0], plain[1], base, flagged[1], plain[2], flagged[2], plain[3]]
+    together = batch.transform(srcs, 40, 40, quality=85)
+    for k, (d, r) in enumerate(zip(srcs, together)):
+        alone = batch.transform([d], 40, 40, quality=85)[0]
+        assert r.status == 0 and alone.status == 0 and r.data == alone.data, k
+
+
+@pytest.mark.gpu
 def test_progressive_modes_agree_on_damaged_files(batch, hip_lib):
     """Host threads, device waves and device lanes give the same pixels (or the same error) for cut and bit-flipped files too: what the
     device decoders find irregular is decoded again by the host threads."""
